@@ -1,0 +1,236 @@
+/*
+ * oracle/g1.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of BN254 G1 as the reference uses it through JoltGroup
+ * (/root/reference/crates/jolt-crypto/src/ec/group.rs:27-71, ec/bn254/mod.rs:17-24,176-212).
+ * The group law itself lives in the un-vendored arkworks fork (ark-ec 0.5.0 @ a16z/arkworks-algebra
+ * dev/twist-shout 76bb3a45, Cargo.lock:801); this file restates the public short-Weierstrass Jacobian
+ * formulas (a = 0, b = 3, generator (1,2)) with ark's layout: Projective {x,y,z} of Montgomery Fq limbs,
+ * identity <=> z == 0.
+ *
+ * PARITY UNPINNED by vectors: the reference's tests hold no golden G1 points (group_laws.rs
+ * checks msm == sum s_i P_i only).  Pinned here by: on-curve checks, group laws, msm_pippenger == naive
+ * sum (the reference's own property, crates/jolt-crypto/tests/group_laws.rs:69-78,135-146) and
+ * [k]G == known small multiples computed with Python big-int affine arithmetic (tests/test_oracle_g1.py).
+ */
+#include "fr.h"
+#include <stdlib.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+typedef struct { fq_t x, y, z; } g1_t;           /* Jacobian, 96 bytes == ark_bn254::G1Projective */
+typedef struct { fq_t x, y; } g1_affine_t;       /* affine, (0,0) encodes infinity (not on the curve) */
+
+static inline fq_t QADD(fq_t a, fq_t b) { fq_t o; fq_add(&o, &a, &b); return o; }
+static inline fq_t QSUB(fq_t a, fq_t b) { fq_t o; fq_sub(&o, &a, &b); return o; }
+static inline fq_t QMUL(fq_t a, fq_t b) { fq_t o; fq_mul(&o, &a, &b); return o; }
+static inline fq_t QSQR(fq_t a) { fq_t o; fq_sqr(&o, &a); return o; }
+static inline fq_t QDBL(fq_t a) { return QADD(a, a); }
+static inline fq_t QNEG(fq_t a) { fq_t o; fq_neg(&o, &a); return o; }
+
+static g1_t g1_identity(void) { g1_t p; p.x = FQ.r; p.y = FQ.r; memset(&p.z, 0, sizeof p.z); return p; }
+static int g1_is_identity(const g1_t *p) { return u256_is_zero(&p->z); }
+static int aff_is_inf(const g1_affine_t *p) { return u256_is_zero(&p->x) && u256_is_zero(&p->y); }
+
+/* dbl-2009-l (a = 0) */
+static g1_t g1_double(const g1_t *p) {
+    if (g1_is_identity(p)) return *p;
+    fq_t A = QSQR(p->x), B = QSQR(p->y), C = QSQR(B);
+    fq_t D = QDBL(QSUB(QSUB(QSQR(QADD(p->x, B)), A), C));
+    fq_t E = QADD(QDBL(A), A);
+    fq_t F = QSQR(E);
+    g1_t r;
+    r.x = QSUB(F, QDBL(D));
+    r.z = QDBL(QMUL(p->y, p->z));
+    fq_t C8 = QDBL(QDBL(QDBL(C)));
+    r.y = QSUB(QMUL(E, QSUB(D, r.x)), C8);
+    return r;
+}
+
+/* add-2007-bl with the special cases made explicit */
+static g1_t g1_add(const g1_t *p, const g1_t *q) {
+    if (g1_is_identity(p)) return *q;
+    if (g1_is_identity(q)) return *p;
+    fq_t Z1Z1 = QSQR(p->z), Z2Z2 = QSQR(q->z);
+    fq_t U1 = QMUL(p->x, Z2Z2), U2 = QMUL(q->x, Z1Z1);
+    fq_t S1 = QMUL(QMUL(p->y, q->z), Z2Z2), S2 = QMUL(QMUL(q->y, p->z), Z1Z1);
+    if (u256_eq(&U1, &U2)) {
+        if (u256_eq(&S1, &S2)) return g1_double(p);
+        return g1_identity();
+    }
+    fq_t H = QSUB(U2, U1);
+    fq_t I = QSQR(QDBL(H));
+    fq_t J = QMUL(H, I);
+    fq_t rr = QDBL(QSUB(S2, S1));
+    fq_t V = QMUL(U1, I);
+    g1_t r;
+    r.x = QSUB(QSUB(QSQR(rr), J), QDBL(V));
+    r.y = QSUB(QMUL(rr, QSUB(V, r.x)), QDBL(QMUL(S1, J)));
+    r.z = QMUL(QSUB(QSUB(QSQR(QADD(p->z, q->z)), Z1Z1), Z2Z2), H);
+    return r;
+}
+
+/* madd-2007-bl (q affine) */
+static g1_t g1_add_mixed(const g1_t *p, const g1_affine_t *q) {
+    if (aff_is_inf(q)) return *p;
+    if (g1_is_identity(p)) { g1_t r; r.x = q->x; r.y = q->y; r.z = FQ.r; return r; }
+    fq_t Z1Z1 = QSQR(p->z);
+    fq_t U2 = QMUL(q->x, Z1Z1);
+    fq_t S2 = QMUL(QMUL(q->y, p->z), Z1Z1);
+    if (u256_eq(&p->x, &U2)) {
+        if (u256_eq(&p->y, &S2)) return g1_double(p);
+        return g1_identity();
+    }
+    fq_t H = QSUB(U2, p->x);
+    fq_t HH = QSQR(H);
+    fq_t I = QDBL(QDBL(HH));
+    fq_t J = QMUL(H, I);
+    fq_t rr = QDBL(QSUB(S2, p->y));
+    fq_t V = QMUL(p->x, I);
+    g1_t r;
+    r.x = QSUB(QSUB(QSQR(rr), J), QDBL(V));
+    r.y = QSUB(QMUL(rr, QSUB(V, r.x)), QDBL(QMUL(p->y, J)));
+    r.z = QSUB(QSUB(QSQR(QADD(p->z, H)), Z1Z1), HH);
+    return r;
+}
+
+static g1_t g1_neg(const g1_t *p) { g1_t r = *p; r.y = QNEG(p->y); return r; }
+
+static g1_affine_t g1_to_affine(const g1_t *p) {
+    g1_affine_t a;
+    if (g1_is_identity(p)) { memset(&a, 0, sizeof a); return a; }
+    fq_t zinv;
+    fq_inv(&zinv, &p->z);
+    fq_t zinv2 = QSQR(zinv);
+    a.x = QMUL(p->x, zinv2);
+    a.y = QMUL(p->y, QMUL(zinv2, zinv));
+    return a;
+}
+
+/* equality as group elements (ark Projective PartialEq): cross-multiplied coordinates */
+static int g1_eq(const g1_t *p, const g1_t *q) {
+    int pi = g1_is_identity(p), qi = g1_is_identity(q);
+    if (pi || qi) return pi && qi;
+    fq_t Z1Z1 = QSQR(p->z), Z2Z2 = QSQR(q->z);
+    fq_t a = QMUL(p->x, Z2Z2), b = QMUL(q->x, Z1Z1);
+    if (!u256_eq(&a, &b)) return 0;
+    fq_t c = QMUL(p->y, QMUL(Z2Z2, q->z)), d = QMUL(q->y, QMUL(Z1Z1, p->z));
+    return u256_eq(&c, &d);
+}
+
+/* JoltGroup::scalar_mul (bn254/mod.rs:190-193): scalar is an Fr in Montgomery form; double-and-add over
+ * its canonical integer, MSB first */
+static g1_t g1_scalar_mul(const g1_t *p, const fr_t *scalar) {
+    u256 k;
+    mont_to_canonical(&k, scalar, &FR);
+    g1_t acc = g1_identity();
+    for (int i = 255; i >= 0; --i) {
+        acc = g1_double(&acc);
+        if ((k.l[i / 64] >> (i % 64)) & 1) acc = g1_add(&acc, p);
+    }
+    return acc;
+}
+
+EXPORT void orc_g1_generator(g1_t *out) {
+    fq_t one = FQ.r;
+    out->x = one;
+    out->y = QADD(one, one);
+    out->z = one;
+}
+EXPORT void orc_g1_identity(g1_t *out) { *out = g1_identity(); }
+EXPORT void orc_g1_add(const g1_t *p, const g1_t *q, g1_t *out) { *out = g1_add(p, q); }
+EXPORT void orc_g1_double(const g1_t *p, g1_t *out) { *out = g1_double(p); }
+EXPORT void orc_g1_neg(const g1_t *p, g1_t *out) { *out = g1_neg(p); }
+EXPORT void orc_g1_add_mixed(const g1_t *p, const g1_affine_t *q, g1_t *out) { *out = g1_add_mixed(p, q); }
+EXPORT void orc_g1_scalar_mul(const g1_t *p, const fr_t *s, g1_t *out) { *out = g1_scalar_mul(p, s); }
+EXPORT int orc_g1_eq(const g1_t *p, const g1_t *q) { return g1_eq(p, q); }
+EXPORT int orc_g1_is_identity(const g1_t *p) { return g1_is_identity(p); }
+EXPORT void orc_g1_to_affine_vec(const g1_t *p, g1_affine_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = g1_to_affine(&p[i]); }
+EXPORT int orc_g1_on_curve(const g1_t *p) {
+    if (g1_is_identity(p)) return 1;
+    g1_affine_t a = g1_to_affine(p);
+    fq_t three = {{3, 0, 0, 0}}, b;
+    mont_from_canonical(&b, &three, &FQ);
+    fq_t lhs = QSQR(a.y), rhs = QADD(QMUL(QSQR(a.x), a.x), b);
+    return u256_eq(&lhs, &rhs);
+}
+
+/* Compressed serialization as the reference appends points to transcripts and proofs
+ * (bn254/mod.rs:139-171 -> ark-serialize short-Weierstrass compressed): 32-byte LE x with flags in the top
+ * two bits of the last byte: 0x80 = y is the lexicographically larger root (y > -y), 0x40 = infinity. */
+EXPORT void orc_g1_serialize_compressed(const g1_t *p, uint8_t out[32]) {
+    memset(out, 0, 32);
+    if (g1_is_identity(p)) { out[31] |= 0x40; return; }
+    g1_affine_t a = g1_to_affine(p);
+    u256 xc, yc, nyc;
+    mont_to_canonical(&xc, &a.x, &FQ);
+    mont_to_canonical(&yc, &a.y, &FQ);
+    fq_t ny = QNEG(a.y);
+    mont_to_canonical(&nyc, &ny, &FQ);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)(xc.l[i] >> (8 * j));
+    int y_is_negative = !(u256_geq(&nyc, &yc)); /* y <= -y -> positive */
+    if (y_is_negative) out[31] |= 0x80;
+}
+
+/* JoltGroup::msm contract (group.rs:63-70) evaluated the slow, obviously-correct way */
+EXPORT void orc_g1_msm_naive(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out) {
+    g1_t acc = g1_identity();
+    for (size_t i = 0; i < n; ++i) {
+        g1_t t = g1_scalar_mul(&bases[i], &scalars[i]);
+        acc = g1_add(&acc, &t);
+    }
+    *out = acc;
+}
+
+/* Bucket-method MSM standing in for ark_ec::VariableBaseMSM::msm_bigint (bn254/mod.rs:195-212 converts every
+ * base to affine and every scalar to its canonical integer first, as done here).  Window size follows ark's
+ * rule c = 3 (n < 32) else floor(log2(n)*69/100) + 2.  Same group element as orc_g1_msm_naive. */
+EXPORT void orc_g1_msm_pippenger(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out) {
+    if (n == 0) { *out = g1_identity(); return; }
+    g1_affine_t *aff = (g1_affine_t *)malloc(n * sizeof(g1_affine_t));
+    u256 *ks = (u256 *)malloc(n * sizeof(u256));
+    for (size_t i = 0; i < n; ++i) { aff[i] = g1_to_affine(&bases[i]); mont_to_canonical(&ks[i], &scalars[i], &FR); }
+    unsigned log2n = 0;
+    while (((size_t)2 << log2n) <= n) log2n++;
+    unsigned c = n < 32 ? 3 : (log2n * 69 / 100) + 2;
+    size_t n_buckets = ((size_t)1 << c) - 1;
+    g1_t *buckets = (g1_t *)malloc(n_buckets * sizeof(g1_t));
+    unsigned num_bits = 254;
+    unsigned n_windows = (num_bits + c - 1) / c;
+    g1_t total = g1_identity();
+    for (int w = (int)n_windows - 1; w >= 0; --w) {
+        for (unsigned k = 0; k < c; ++k) total = g1_double(&total);
+        for (size_t b = 0; b < n_buckets; ++b) buckets[b] = g1_identity();
+        unsigned start = (unsigned)w * c;
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t digit = 0;
+            for (unsigned k = 0; k < c; ++k) {
+                unsigned bit = start + k;
+                if (bit < 256) digit |= ((ks[i].l[bit / 64] >> (bit % 64)) & 1) << k;
+            }
+            if (digit) buckets[digit - 1] = g1_add_mixed(&buckets[digit - 1], &aff[i]);
+        }
+        g1_t running = g1_identity(), wsum = g1_identity();
+        for (size_t b = n_buckets; b-- > 0;) {
+            running = g1_add(&running, &buckets[b]);
+            wsum = g1_add(&wsum, &running);
+        }
+        total = g1_add(&total, &wsum);
+    }
+    free(buckets);
+    free(aff);
+    free(ks);
+    *out = total;
+}
+
+/* HyperKZGScheme::setup_from_secret (crates/jolt-hyperkzg/src/scheme.rs:54-73): g1_powers[i] = beta^i * g1,
+ * built by repeated scalar_mul exactly as the reference does (max_degree + 1 entries). */
+EXPORT void orc_srs_setup_from_secret(const fr_t *beta, size_t count, g1_t *out) {
+    g1_t cur;
+    orc_g1_generator(&cur);
+    for (size_t i = 0; i < count; ++i) {
+        out[i] = cur;
+        cur = g1_scalar_mul(&cur, beta);
+    }
+}

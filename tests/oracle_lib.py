@@ -1,0 +1,590 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Field elements travel as numpy uint64 arrays of shape (..., 4): the 4 little-endian Montgomery limbs of
+jolt_field::Fr (reference crates/jolt-field/src/bn254/mod.rs:37-43).  G1 points are (..., 12) uint64
+(Jacobian x,y,z of Montgomery Fq limbs = ark_bn254::G1Projective layout).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(_HERE, "..", "oracle")
+_LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+MONT_R = 1 << 256
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fr_array(n):
+    return np.zeros((n, 4), dtype=np.uint64)
+
+
+# ---------------------------------------------------------------- Python <-> limb conversions (big-int side)
+def int_to_limbs(v, n=4):
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
+def limbs_to_int(l):
+    return sum(int(x) << (64 * i) for i, x in enumerate(l))
+
+
+def to_mont(values, mod=R_MOD):
+    """canonical python ints -> Montgomery limb array (computed with Python big ints, not the oracle)."""
+    out = np.zeros((len(values), 4), dtype=np.uint64)
+    for i, v in enumerate(values):
+        out[i] = int_to_limbs((v % mod) * MONT_R % mod)
+    return out
+
+
+def from_mont(arr, mod=R_MOD):
+    rinv = pow(MONT_R, -1, mod)
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1, 4)
+    return [limbs_to_int(row) * rinv % mod for row in arr]
+
+
+# ---------------------------------------------------------------- vector field ops
+def _binop(name, a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    o = np.zeros_like(a)
+    getattr(lib(), name)(_p(a), _p(b), _p(o), C.c_size_t(a.shape[0]))
+    return o
+
+
+def fr_add(a, b): return _binop("orc_fr_add_vec", a, b)
+def fr_sub(a, b): return _binop("orc_fr_sub_vec", a, b)
+def fr_mul(a, b): return _binop("orc_fr_mul_vec", a, b)
+def fq_add(a, b): return _binop("orc_fq_add_vec", a, b)
+def fq_sub(a, b): return _binop("orc_fq_sub_vec", a, b)
+def fq_mul(a, b): return _binop("orc_fq_mul_vec", a, b)
+
+
+def _unop(name, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    o = np.zeros_like(a)
+    getattr(lib(), name)(_p(a), _p(o), C.c_size_t(a.shape[0]))
+    return o
+
+
+def fr_neg(a): return _unop("orc_fr_neg_vec", a)
+def fr_inv(a): return _unop("orc_fr_inv_vec", a)
+def fq_inv(a): return _unop("orc_fq_inv_vec", a)
+def fr_to_canonical(a): return _unop("orc_fr_to_canonical_vec", a)
+def fr_from_canonical(a): return _unop("orc_fr_from_canonical_vec", a)
+def fq_to_canonical(a): return _unop("orc_fq_to_canonical_vec", a)
+def fq_from_canonical(a): return _unop("orc_fq_from_canonical_vec", a)
+
+
+def fr_from_u64(vals):
+    v = np.ascontiguousarray(vals, dtype=np.uint64)
+    o = fr_array(v.shape[0])
+    lib().orc_fr_from_u64_vec(_p(v), _p(o), C.c_size_t(v.shape[0]))
+    return o
+
+
+def fr_from_i64(vals):
+    v = np.ascontiguousarray(vals, dtype=np.int64)
+    o = fr_array(v.shape[0])
+    lib().orc_fr_from_i64_vec(_p(v), _p(o), C.c_size_t(v.shape[0]))
+    return o
+
+
+def fr_from_u128(v):
+    o = fr_array(1)
+    lib().orc_fr_from_u128(C.c_uint64(v & (2**64 - 1)), C.c_uint64(v >> 64), _p(o))
+    return o[0]
+
+
+def fr_from_i128(v):
+    m = abs(v)
+    o = fr_array(1)
+    lib().orc_fr_from_i128(C.c_uint64(m & (2**64 - 1)), C.c_uint64(m >> 64), C.c_int(1 if v < 0 else 0), _p(o))
+    return o[0]
+
+
+def fr_mul_u64(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    o = fr_array(1)
+    lib().orc_fr_mul_u64(_p(a), C.c_uint64(b), _p(o))
+    return o[0]
+
+
+def fr_mul_u128(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    o = fr_array(1)
+    lib().orc_fr_mul_u128(_p(a), C.c_uint64(b & (2**64 - 1)), C.c_uint64(b >> 64), _p(o))
+    return o[0]
+
+
+def fr_mul_pow_2(a, k):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    o = fr_array(1)
+    lib().orc_fr_mul_pow_2(_p(a), C.c_uint(k), _p(o))
+    return o[0]
+
+
+def _from_bytes(name, b):
+    buf = (C.c_uint8 * len(b)).from_buffer_copy(bytes(b)) if len(b) else (C.c_uint8 * 1)()
+    o = fr_array(1)
+    getattr(lib(), name)(buf, C.c_size_t(len(b)), _p(o))
+    return o[0]
+
+
+def fr_from_bytes_le_reduced(b): return _from_bytes("orc_fr_from_bytes_le_reduced", b)
+def fr_from_challenge_bytes(b): return _from_bytes("orc_fr_from_challenge_bytes", b)
+def fr_from_scalar_challenge_bytes(b): return _from_bytes("orc_fr_from_scalar_challenge_bytes", b)
+
+
+def fr_to_bytes_le(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = (C.c_uint8 * 32)()
+    lib().orc_fr_to_bytes_le(_p(a), out)
+    return bytes(out)
+
+
+def fr_from_montgomery_reduce(limbs):
+    l = np.ascontiguousarray(limbs, dtype=np.uint64)
+    o = fr_array(1)
+    lib().orc_fr_from_montgomery_reduce(_p(l), C.c_size_t(l.shape[0]), _p(o))
+    return o[0]
+
+
+def wide_accumulate(a, b, adds=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    adds = fr_array(0) if adds is None else np.ascontiguousarray(adds, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1)
+    lib().orc_wide_accumulate(_p(a), _p(b), C.c_size_t(a.shape[0]), _p(adds), C.c_size_t(adds.shape[0]), _p(o))
+    return o[0]
+
+
+# ---------------------------------------------------------------- poly
+def bind_high_to_low(table, r):
+    t = np.array(table, dtype=np.uint64, copy=True).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    lib().orc_bind_high_to_low(_p(t), C.c_size_t(t.shape[0]), _p(r))
+    return t[: t.shape[0] // 2].copy()
+
+
+def bind_low_to_high(table, r):
+    t = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    o = fr_array(t.shape[0] // 2)
+    lib().orc_bind_low_to_high(_p(t), C.c_size_t(t.shape[0]), _p(r), _p(o))
+    return o
+
+
+def bind_to_field_u64(table, r):
+    t = np.ascontiguousarray(table, dtype=np.uint64)
+    r = np.ascontiguousarray(r, dtype=np.uint64)
+    o = fr_array(t.shape[0] // 2)
+    lib().orc_bind_to_field_u64(_p(t), C.c_size_t(t.shape[0]), _p(r), _p(o))
+    return o
+
+
+def eq_evals(r, scale=None):
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    n = r.shape[0]
+    o = fr_array(1 << n)
+    s = None if scale is None else np.ascontiguousarray(scale, dtype=np.uint64)
+    lib().orc_eq_evals(_p(r), C.c_size_t(n), _p(s) if s is not None else None, _p(o))
+    return o
+
+
+def eq_evaluations(r):
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1 << r.shape[0])
+    lib().orc_eq_evaluations(_p(r), C.c_size_t(r.shape[0]), _p(o))
+    return o
+
+
+def eq_evals_aligned_block(r, start, block):
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(block)
+    lib().orc_eq_evals_aligned_block(_p(r), C.c_size_t(r.shape[0]), C.c_size_t(start), C.c_size_t(block), _p(o))
+    return o
+
+
+def eq_mle(x, y):
+    x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+    y = np.ascontiguousarray(y, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1)
+    lib().orc_eq_mle(_p(x), _p(y), C.c_size_t(x.shape[0]), _p(o))
+    return o[0]
+
+
+def poly_evaluate(evals, point):
+    e = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1)
+    lib().orc_poly_evaluate(_p(e), C.c_size_t(p.shape[0]), _p(p), _p(o))
+    return o[0]
+
+
+def lt_evals(r):
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1 << r.shape[0])
+    lib().orc_lt_evals(_p(r), C.c_size_t(r.shape[0]), _p(o))
+    return o
+
+
+def eq_plus_one_evals(r, scale=None):
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    n = r.shape[0]
+    e, e1 = fr_array(1 << n), fr_array(1 << n)
+    s = None if scale is None else np.ascontiguousarray(scale, dtype=np.uint64)
+    lib().orc_eq_plus_one_evals(_p(r), C.c_size_t(n), _p(s) if s is not None else None, _p(e), _p(e1))
+    return e, e1
+
+
+def univariate_from_evals(evals):
+    e = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(e.shape[0])
+    lib().orc_univariate_from_evals(_p(e), C.c_size_t(e.shape[0]), _p(o))
+    return o
+
+
+def univariate_evaluate(coeffs, x):
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    o = fr_array(1)
+    lib().orc_univariate_evaluate(_p(c), C.c_size_t(c.shape[0]), _p(x), _p(o))
+    return o[0]
+
+
+def split_eq_current_dims(n, bound):
+    a, b = C.c_size_t(), C.c_size_t()
+    lib().orc_split_eq_current_dims(C.c_size_t(n), C.c_size_t(bound), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def gruen_poly_deg_3(scalar, point_i, q0, qinf, claim):
+    args = [np.ascontiguousarray(x, dtype=np.uint64) for x in (scalar, point_i, q0, qinf, claim)]
+    o = fr_array(4)
+    rc = lib().orc_gruen_poly_deg_3(*[_p(a) for a in args], _p(o))
+    assert rc == 0
+    return o
+
+
+# ---------------------------------------------------------------- sumcheck members
+ORDER_LOW_TO_HIGH, ORDER_HIGH_TO_LOW = 0, 1
+
+
+class Member:
+    """Oracle twin of a jolt_sumcheck::ProveRounds member."""
+
+    def __init__(self, handle, degree, n_tables, gruen=False):
+        self.h, self.degree, self.n_tables, self.gruen = handle, degree, n_tables, gruen
+
+    @classmethod
+    def expr(cls, tables, terms, degree, order=ORDER_LOW_TO_HIGH, skip_one=False):
+        """terms = [(coeff_limbs, [table indices...]), ...]"""
+        L = lib()
+        L.orc_member_create_expr.restype = C.c_void_p
+        tabs = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+        ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+        offs, facs = [0], []
+        for _, f in terms:
+            facs.extend(f)
+            offs.append(len(facs))
+        offs = np.array(offs, dtype=np.uint32)
+        facs_a = np.array(facs if facs else [0], dtype=np.uint32)
+        coeffs = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c, _ in terms])).reshape(-1, 4)
+        h = L.orc_member_create_expr(ptrs, C.c_uint32(len(tabs)), C.c_size_t(tabs[0].shape[0]), C.c_uint32(len(terms)),
+                                     _p(offs), _p(facs_a), _p(coeffs), C.c_uint32(degree), C.c_int(order),
+                                     C.c_int(1 if skip_one else 0))
+        return cls(C.c_void_p(h), degree, len(tabs))
+
+    @classmethod
+    def gruen_product(cls, a, b, w, scale=None):
+        L = lib()
+        L.orc_member_create_gruen_product.restype = C.c_void_p
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
+        s = None if scale is None else np.ascontiguousarray(scale, dtype=np.uint64)
+        h = L.orc_member_create_gruen_product(_p(a), _p(b), C.c_size_t(a.shape[0]), _p(w), _p(s) if s is not None else None)
+        return cls(C.c_void_p(h), 3, 2, gruen=True)
+
+    def num_rounds(self):
+        lib().orc_member_num_rounds.restype = C.c_size_t
+        return lib().orc_member_num_rounds(self.h)
+
+    def prove_round(self, bind, previous_claim):
+        o = fr_array(self.degree + 1)
+        b = None if bind is None else np.ascontiguousarray(bind, dtype=np.uint64)
+        pc = np.ascontiguousarray(previous_claim, dtype=np.uint64)
+        rc = lib().orc_member_prove_round(self.h, _p(b) if b is not None else None, _p(pc), _p(o))
+        if rc != 0:
+            raise RuntimeError(f"oracle prove_round failed rc={rc}")
+        return o
+
+    def finish_rounds(self, bind):
+        b = np.ascontiguousarray(bind, dtype=np.uint64)
+        lib().orc_member_finish_rounds(self.h, _p(b))
+
+    def final_values(self):
+        o = fr_array(self.n_tables + (1 if self.gruen else 0))
+        rc = lib().orc_member_final_values(self.h, _p(o))
+        assert rc == 0
+        return o
+
+    def input_claim(self):
+        o = fr_array(1)
+        lib().orc_member_input_claim(self.h, _p(o))
+        return o[0]
+
+    def close(self):
+        if self.h:
+            lib().orc_member_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_batch(members, input_claims, coefficients, offsets, max_num_vars, max_degree, label=0, challenge_mode=0):
+    n = len(members)
+    hs = (C.c_void_p * n)(*[m.h for m in members])
+    ic = np.ascontiguousarray(np.stack(input_claims), dtype=np.uint64).reshape(-1, 4)
+    co = np.ascontiguousarray(np.stack(coefficients), dtype=np.uint64).reshape(-1, 4)
+    offs = (C.c_size_t * n)(*offsets)
+    polys = fr_array(max_num_vars * (max_degree + 1))
+    chal = fr_array(max_num_vars)
+    mclaims = fr_array(n)
+    final = fr_array(1)
+    rc = lib().orc_prove_batch(hs, C.c_size_t(n), _p(ic), _p(co), offs, C.c_size_t(max_num_vars), C.c_size_t(max_degree),
+                               C.c_uint64(label), C.c_int(challenge_mode), _p(polys), _p(chal), _p(mclaims), _p(final))
+    if rc != 0:
+        raise RuntimeError(f"oracle prove_batch failed rc={rc}")
+    return dict(polys=polys.reshape(max_num_vars, max_degree + 1, 4), challenges=chal, member_claims=mclaims, final_claim=final[0])
+
+
+def triple_product_round_evals(a, b, c):
+    a, b, c = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c)]
+    o = fr_array(3)
+    lib().orc_triple_product_round_evals(_p(a), _p(b), _p(c), C.c_size_t(a.shape[0]), _p(o))
+    return o
+
+
+class MockTranscript:
+    def __init__(self, label=0):
+        self.s = (C.c_uint64 * 4)()
+        lib().orc_mt_init(self.s, C.c_uint64(label))
+
+    def append_bytes(self, b):
+        buf = (C.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if len(b) else b"\0")
+        lib().orc_mt_append_bytes(self.s, buf, C.c_size_t(len(b)))
+
+    def append_fr(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        lib().orc_mt_append_fr(self.s, _p(a))
+
+    def challenge(self):
+        o = fr_array(1)
+        lib().orc_mt_challenge(self.s, _p(o))
+        return o[0]
+
+    def challenge_scalar(self):
+        o = fr_array(1)
+        lib().orc_mt_challenge_scalar(self.s, _p(o))
+        return o[0]
+
+
+# ---------------------------------------------------------------- G1 / MSM / HyperKZG
+def g1_array(n):
+    return np.zeros((n, 12), dtype=np.uint64)
+
+
+def g1_generator():
+    o = g1_array(1)
+    lib().orc_g1_generator(_p(o))
+    return o[0]
+
+
+def g1_identity():
+    o = g1_array(1)
+    lib().orc_g1_identity(_p(o))
+    return o[0]
+
+
+def _g1(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def g1_add(p, q):
+    o = g1_array(1)
+    lib().orc_g1_add(_p(_g1(p)), _p(_g1(q)), _p(o))
+    return o[0]
+
+
+def g1_double(p):
+    o = g1_array(1)
+    lib().orc_g1_double(_p(_g1(p)), _p(o))
+    return o[0]
+
+
+def g1_neg(p):
+    o = g1_array(1)
+    lib().orc_g1_neg(_p(_g1(p)), _p(o))
+    return o[0]
+
+
+def g1_scalar_mul(p, s):
+    o = g1_array(1)
+    lib().orc_g1_scalar_mul(_p(_g1(p)), _p(np.ascontiguousarray(s, dtype=np.uint64)), _p(o))
+    return o[0]
+
+
+def g1_eq(p, q):
+    return bool(lib().orc_g1_eq(_p(_g1(p)), _p(_g1(q))))
+
+
+def g1_is_identity(p):
+    return bool(lib().orc_g1_is_identity(_p(_g1(p))))
+
+
+def g1_on_curve(p):
+    return bool(lib().orc_g1_on_curve(_p(_g1(p))))
+
+
+def g1_to_affine(ps):
+    ps = _g1(ps).reshape(-1, 12)
+    o = np.zeros((ps.shape[0], 8), dtype=np.uint64)
+    lib().orc_g1_to_affine_vec(_p(ps), _p(o), C.c_size_t(ps.shape[0]))
+    return o
+
+
+def g1_serialize_compressed(p):
+    out = (C.c_uint8 * 32)()
+    lib().orc_g1_serialize_compressed(_p(_g1(p)), out)
+    return bytes(out)
+
+
+def g1_msm_naive(bases, scalars):
+    b = _g1(bases).reshape(-1, 12)
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    o = g1_array(1)
+    lib().orc_g1_msm_naive(_p(b), _p(s), C.c_size_t(b.shape[0]), _p(o))
+    return o[0]
+
+
+def g1_msm_pippenger(bases, scalars):
+    b = _g1(bases).reshape(-1, 12)
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    assert b.shape[0] == s.shape[0], "msm: bases/scalars length mismatch"
+    o = g1_array(1)
+    lib().orc_g1_msm_pippenger(_p(b), _p(s), C.c_size_t(b.shape[0]), _p(o))
+    return o[0]
+
+
+def srs_setup_from_secret(beta, count):
+    o = g1_array(count)
+    lib().orc_srs_setup_from_secret(_p(np.ascontiguousarray(beta, dtype=np.uint64)), C.c_size_t(count), _p(o))
+    return o
+
+
+def kzg_commit(coeffs, srs):
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    s = _g1(srs).reshape(-1, 12)
+    o = g1_array(1)
+    rc = lib().orc_kzg_commit(_p(c), C.c_size_t(c.shape[0]), _p(s), C.c_size_t(s.shape[0]), _p(o))
+    if rc != 0:
+        raise ValueError("SrsTooSmall")
+    return o[0]
+
+
+def kzg_witness_polynomial(f, u):
+    f = np.ascontiguousarray(f, dtype=np.uint64).reshape(-1, 4)
+    h = fr_array(max(f.shape[0] - 1, 0))
+    lib().orc_kzg_witness_polynomial(_p(f), C.c_size_t(f.shape[0]), _p(np.ascontiguousarray(u, dtype=np.uint64)), _p(h))
+    return h
+
+
+def kzg_eval_univariate(coeffs, u):
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1)
+    lib().orc_kzg_eval_univariate(_p(c), C.c_size_t(c.shape[0]), _p(np.ascontiguousarray(u, dtype=np.uint64)), _p(o))
+    return o[0]
+
+
+def hyperkzg_fold_polynomials(evals, point):
+    e = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+    ell = p.shape[0]
+    out = fr_array(2 * e.shape[0])
+    lib().orc_hyperkzg_fold_polynomials(_p(e), C.c_size_t(ell), _p(p), _p(out))
+    polys, off, ln = [], 0, e.shape[0]
+    for _ in range(ell):
+        polys.append(out[off:off + ln].copy())
+        off += ln
+        ln //= 2
+    return polys
+
+
+def hyperkzg_open(srs, evals, point, label=0):
+    s = _g1(srs).reshape(-1, 12)
+    e = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+    ell = p.shape[0]
+    com, w, v, ch = g1_array(max(ell - 1, 1)), g1_array(3), fr_array(3 * ell), fr_array(3)
+    rc = lib().orc_hyperkzg_open(_p(s), C.c_size_t(s.shape[0]), _p(e), C.c_size_t(ell), _p(p), C.c_uint64(label),
+                                 _p(com), _p(w), _p(v), _p(ch))
+    if rc != 0:
+        raise ValueError(f"hyperkzg open failed rc={rc}")
+    return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
+
+
+# ---------------------------------------------------------------- cpu baseline drivers (bench.py only)
+def baseline_threads():
+    return lib().orc_baseline_threads()
+
+
+def baseline_bind_low_to_high(table, r, out):
+    lib().orc_baseline_bind_low_to_high(_p(table), C.c_size_t(table.shape[0]), _p(np.ascontiguousarray(r, dtype=np.uint64)), _p(out))
+
+
+def baseline_round_evals(tables, terms, degree):
+    tabs = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+    ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+    offs, facs = [0], []
+    for _, f in terms:
+        facs.extend(f)
+        offs.append(len(facs))
+    offs = np.array(offs, dtype=np.uint32)
+    facs_a = np.array(facs if facs else [0], dtype=np.uint32)
+    coeffs = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c, _ in terms])).reshape(-1, 4)
+    o = fr_array(degree)
+    lib().orc_baseline_round_evals(ptrs, C.c_uint32(len(tabs)), C.c_size_t(tabs[0].shape[0]), C.c_uint32(len(terms)),
+                                   _p(offs), _p(facs_a), _p(coeffs), C.c_uint32(degree), _p(o))
+    return o

@@ -1,0 +1,171 @@
+"""Pin the oracle's BN254 G1 / MSM / HyperKZG restatement.  The reference holds no golden points
+(SURVEY.md 8c), so the pins are: an independent Python affine big-int model of y^2 = x^3 + 3, the group laws and
+msm == sum s_i P_i (/root/reference/crates/jolt-crypto/tests/group_laws.rs:69-78,135-146), the KZG division
+identity (/root/reference/crates/jolt-hyperkzg/src/kzg.rs:229-264) and commit(p) == p(beta) G."""
+import random
+
+import numpy as np
+
+import oracle_lib as O
+
+R, Q = O.R_MOD, O.Q_MOD
+
+
+# ---- independent affine model (None = infinity)
+def aff_add(P, S):
+    if P is None: return S
+    if S is None: return P
+    (x1, y1), (x2, y2) = P, S
+    if x1 == x2:
+        if (y1 + y2) % Q == 0: return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, Q) % Q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, Q) % Q
+    x3 = (lam * lam - x1 - x2) % Q
+    return (x3, (lam * (x1 - x3) - y1) % Q)
+
+
+def aff_mul(k, P):
+    acc = None
+    while k:
+        if k & 1: acc = aff_add(acc, P)
+        P = aff_add(P, P)
+        k >>= 1
+    return acc
+
+
+def to_model(p):
+    if O.g1_is_identity(p): return None
+    a = O.g1_to_affine(p)[0]
+    xs = O.from_mont(a[:4], Q)[0]
+    ys = O.from_mont(a[4:], Q)[0]
+    return (xs, ys)
+
+
+G = (1, 2)
+
+
+def test_generator_and_small_multiples_vs_affine_model():
+    g = O.g1_generator()
+    assert O.g1_on_curve(g) and to_model(g) == G
+    acc = O.g1_identity()
+    for k in range(1, 20):
+        acc = O.g1_add(acc, g)
+        assert O.g1_on_curve(acc)
+        assert to_model(acc) == aff_mul(k, G)
+    rng = random.Random(21)
+    for _ in range(5):
+        k = rng.randrange(R)
+        assert to_model(O.g1_scalar_mul(g, O.to_mont([k])[0])) == aff_mul(k, G)
+
+
+def test_group_laws_and_corner_cases():
+    g = O.g1_generator()
+    ident = O.g1_identity()
+    p = O.g1_scalar_mul(g, O.to_mont([12345])[0])
+    q = O.g1_scalar_mul(g, O.to_mont([67890])[0])
+    assert O.g1_eq(O.g1_add(p, q), O.g1_add(q, p))
+    assert O.g1_eq(O.g1_add(p, ident), p) and O.g1_eq(O.g1_add(ident, p), p)
+    assert O.g1_is_identity(O.g1_add(p, O.g1_neg(p)))          # P + (-P)
+    assert O.g1_eq(O.g1_add(p, p), O.g1_double(p))              # P + P through the add path
+    assert O.g1_is_identity(O.g1_double(ident))
+    # r*G = identity
+    assert O.g1_is_identity(O.g1_scalar_mul(g, O.to_mont([0])[0]))
+    # different projective representatives compare equal as points
+    p2 = O.g1_add(O.g1_add(p, q), O.g1_neg(q))
+    assert O.g1_eq(p, p2) and not np.array_equal(p, p2)
+
+
+def test_compressed_serialization_flags():
+    g = O.g1_generator()
+    b = O.g1_serialize_compressed(g)
+    assert b[:31] == (1).to_bytes(31, "little") and b[31] & 0xC0 == 0   # y = 2 <= q-2 -> positive
+    nb = O.g1_serialize_compressed(O.g1_neg(g))
+    assert nb[31] & 0x80 and nb[:31] == b[:31]
+    ib = O.g1_serialize_compressed(O.g1_identity())
+    assert ib[31] == 0x40 and ib[:31] == bytes(31)
+
+
+def test_msm_equals_sum_of_scalar_muls():
+    rng = random.Random(22)
+    g = O.g1_generator()
+    for n in (0, 1, 2, 33, 70):
+        ks = [rng.randrange(1, R) for _ in range(n)]
+        bases = np.stack([O.g1_scalar_mul(g, O.to_mont([k])[0]) for k in ks]) if n else O.g1_array(0)
+        svals = [rng.choice([0, 1, R - 1, rng.randrange(2**64), rng.randrange(R)]) for _ in range(n)]
+        scalars = O.to_mont(svals) if n else O.fr_array(0)
+        got = O.g1_msm_pippenger(bases, scalars)
+        assert O.g1_eq(got, O.g1_msm_naive(bases, scalars))
+        want = aff_mul(sum(k * s for k, s in zip(ks, svals)) % R, G)
+        assert to_model(got) == want
+    # repeated bases exercise the P+P / P+(-P) bucket corner cases
+    b = O.g1_scalar_mul(g, O.to_mont([5])[0])
+    bases = np.stack([b, b, O.g1_neg(b), b, O.g1_identity()])
+    scalars = O.to_mont([7, 7, 7, 3, 11])
+    assert to_model(O.g1_msm_pippenger(bases, scalars)) == aff_mul(5 * 10, G)
+
+
+def test_kzg_commit_and_division_identity():
+    rng = random.Random(23)
+    beta = rng.randrange(R)
+    n = 16
+    srs = O.srs_setup_from_secret(O.to_mont([beta])[0], n + 1)
+    assert to_model(srs[3]) == aff_mul(pow(beta, 3, R), G)
+    coeffs = [rng.randrange(R) for _ in range(n)]
+    cm = O.to_mont(coeffs)
+    com = O.kzg_commit(cm, srs)
+    pbeta = sum(c * pow(beta, i, R) for i, c in enumerate(coeffs)) % R
+    assert to_model(com) == aff_mul(pbeta, G)
+    # kzg.rs:229-264: f(x) = h(x) (x-u) + f(u)
+    u = rng.randrange(R)
+    h = O.from_mont(O.kzg_witness_polynomial(cm, O.to_mont([u])[0]))
+    fu = O.from_mont(O.kzg_eval_univariate(cm, O.to_mont([u])[0]))[0]
+    assert fu == sum(c * pow(u, i, R) for i, c in enumerate(coeffs)) % R
+    x = rng.randrange(R)
+    hx = sum(c * pow(x, i, R) for i, c in enumerate(h)) % R
+    fx = sum(c * pow(x, i, R) for i, c in enumerate(coeffs)) % R
+    assert fx == (hx * (x - u) + fu) % R
+    try:
+        O.kzg_commit(O.to_mont([1] * (n + 2)), srs)
+        assert False
+    except ValueError:
+        pass
+
+
+def test_hyperkzg_open_fold_consistency():
+    # scheme.rs:226-240: 2 r y_next = r (1-x)(y_pos+y_neg) + x (y_pos-y_neg) on every level, last y_next = eval
+    rng = random.Random(24)
+    ell = 4
+    n = 1 << ell
+    beta = rng.randrange(R)
+    srs = O.srs_setup_from_secret(O.to_mont([beta])[0], n + 1)
+    evals = [rng.randrange(R) for _ in range(n)]
+    point = [rng.randrange(R) for _ in range(ell)]
+    em, pm = O.to_mont(evals), O.to_mont(point)
+    polys = O.hyperkzg_fold_polynomials(em, pm)
+    assert [len(p) for p in polys] == [16, 8, 4, 2]
+    claimed = O.from_mont(O.poly_evaluate(em, pm))[0]
+    out = O.hyperkzg_open(srs, em, pm, label=5)
+    r = O.from_mont(out["challenges"][0])[0]
+    v = [O.from_mont(out["v"][t]) for t in range(3)]
+    y_sq = v[2] + [claimed]
+    for lvl in range(ell):
+        x = point[ell - 1 - lvl]
+        lhs = 2 * r * y_sq[lvl + 1] % R
+        rhs = (r * (1 - x) * (v[0][lvl] + v[1][lvl]) + x * (v[0][lvl] - v[1][lvl])) % R
+        assert lhs == rhs, lvl
+    # commitments are commitments of the folds; witnesses satisfy w_t * (beta - u_t) + B(u_t) G = B(beta) G
+    for i in range(1, ell):
+        pb = sum(c * pow(beta, k, R) for k, c in enumerate(O.from_mont(polys[i]))) % R
+        assert to_model(out["com"][i - 1]) == aff_mul(pb, G)
+    q = O.from_mont(out["challenges"][1])[0]
+    Bc = [0] * n
+    for j, p in enumerate(polys):
+        for k, c in enumerate(O.from_mont(p)):
+            Bc[k] = (Bc[k] + pow(q, j, R) * c) % R
+    Bbeta = sum(c * pow(beta, k, R) for k, c in enumerate(Bc)) % R
+    us = [r, (-r) % R, r * r % R]
+    for t in range(3):
+        Bu = sum(c * pow(us[t], k, R) for k, c in enumerate(Bc)) % R
+        wt = (Bbeta - Bu) * pow(beta - us[t], -1, R) % R
+        assert to_model(out["w"][t]) == aff_mul(wt, G)
