@@ -1,0 +1,266 @@
+/*
+ * include/jolt_hip.h -- C ABI of the MI355X-native Jolt prover hot path (libjolt_hip.so).
+ *
+ * This is the drop-in boundary: the entry points below are what a thin Rust FFI crate (`jolt-kernels-hip`,
+ * sketched in INTEGRATION.md) binds in order to implement the reference's own trait surface for this path --
+ * `ProveRounds`/`SumcheckKernel`/`PrepareKernel` (jolt-sumcheck, jolt-kernels), `JoltGroup::msm` (jolt-crypto) and
+ * `CommitmentScheme::{commit,open}` for HyperKZG (jolt-openings / jolt-hyperkzg).  Every function cites the
+ * reference interface it replaces (paths relative to the a16z/jolt checkout).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; every function returns an int32 status and never unwinds/aborts;
+ *  - jolt_fr_t  = 4 x u64 little-endian Montgomery limbs, canonical (< r)   == jolt_field::Fr::inner_limbs()
+ *                 (crates/jolt-field/src/bn254/mod.rs:33-43);
+ *  - jolt_g1_t  = Jacobian (x, y, z) of Montgomery Fq limbs, identity <=> z == 0 == ark_bn254::G1Projective, which
+ *                 jolt_crypto::Bn254G1 wraps #[repr(transparent)] (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24);
+ *  - handles are opaque and owned by the context that created them; a kernel/member owns its tables
+ *    (Box<dyn SumcheckKernel> semantics) and frees them on destroy;
+ *  - all work is enqueued on the context's HIP stream; functions that return field elements or points to host
+ *    memory synchronise that stream before returning (the per-round Fiat-Shamir sync point,
+ *    crates/jolt-sumcheck/src/prover.rs:326);
+ *  - there is NO CPU fallback: without a usable gfx950 device jolt_ctx_create fails with JOLT_ERR_NO_DEVICE.
+ */
+#ifndef JOLT_HIP_H
+#define JOLT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JOLT_HIP_ABI_VERSION 1
+
+typedef struct { uint64_t l[4]; } jolt_fr_t;
+typedef struct { uint64_t l[4]; } jolt_fq_t;
+typedef struct { jolt_fq_t x, y, z; } jolt_g1_t;
+
+typedef struct jolt_ctx jolt_ctx;       /* device + stream + scratch                                  */
+typedef struct jolt_table jolt_table;   /* device-resident dense table of Fr (Polynomial<Fr>)         */
+typedef struct jolt_member jolt_member; /* one sumcheck batch member (Box<dyn SumcheckKernel>)        */
+typedef struct jolt_srs jolt_srs;       /* device-resident affine SRS prefix (HyperKZGProverSetup.g1_powers) */
+
+/* Status codes.  Mapping to the reference's error types (crates/jolt-kernels/src/error.rs:11-90,
+ * crates/jolt-sumcheck/src/error.rs, crates/jolt-hyperkzg/src/error.rs) is given per value. */
+enum {
+    JOLT_OK = 0,
+    JOLT_ERR_INVALID_ARG = 1,     /* KernelError::InvariantViolation (caller bug)                       */
+    JOLT_ERR_NO_DEVICE = 2,       /* KernelError::Unsupported -> caller falls back to another backend   */
+    JOLT_ERR_OOM = 3,             /* KernelError::Unsupported                                           */
+    JOLT_ERR_HIP = 4,             /* KernelError::InvariantViolation, message via jolt_last_error       */
+    JOLT_ERR_SIZE_MISMATCH = 5,   /* KernelError::TableSizeMismatch / msm length-mismatch panic         */
+    JOLT_ERR_UNSUPPORTED = 6,     /* KernelError::Unsupported (descriptor beyond compiled limits)       */
+    JOLT_ERR_NOT_FULLY_BOUND = 7, /* SumcheckKernelError::NotFullyBound                                 */
+    JOLT_ERR_ROUND_CHECK = 8,     /* SumcheckError::RoundCheckFailed                                    */
+    JOLT_ERR_SRS_TOO_SMALL = 9,   /* HyperKZGError::SrsTooSmall                                         */
+    JOLT_ERR_EMPTY_POINT = 10,    /* HyperKZGError::EmptyPoint                                          */
+    JOLT_ERR_NOT_INVERTIBLE = 11  /* gruen_poly_deg_3 `expect` (split_eq.rs:403-405)                    */
+};
+
+/* BindingOrder (crates/jolt-poly/src/binding.rs) */
+enum { JOLT_ORDER_LOW_TO_HIGH = 0, JOLT_ORDER_HIGH_TO_LOW = 1 };
+
+const char *jolt_status_string(int32_t status);
+int32_t jolt_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Context.  One per GPU per process (one process per GPU; ranks shard the hypercube).
+ * `stream` = an existing hipStream_t to enqueue on (e.g. the caller's), or NULL to create a private one.
+ * ---------------------------------------------------------------------------------------------------------- */
+int32_t jolt_ctx_create(int32_t device_id, void *stream, jolt_ctx **out);
+int32_t jolt_ctx_destroy(jolt_ctx *ctx);
+int32_t jolt_ctx_synchronize(jolt_ctx *ctx);
+const char *jolt_last_error(const jolt_ctx *ctx);
+/* Device-event timing of everything enqueued between begin and end on the context's stream (milliseconds). */
+int32_t jolt_timer_begin(jolt_ctx *ctx);
+int32_t jolt_timer_end(jolt_ctx *ctx, float *elapsed_ms);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Tables: Polynomial<Fr> resident in HBM (crates/jolt-poly/src/dense.rs:36-39).
+ * Replaces the host Vec<Fr> that `witness.oracle_table(id)` / `dense_view` hand to kernels
+ * (crates/jolt-witness/src/backend/mod.rs:50-53, crates/jolt-kernels/src/reference/views.rs:20-33).
+ * ---------------------------------------------------------------------------------------------------------- */
+int32_t jolt_table_upload(jolt_ctx *ctx, const jolt_fr_t *host, size_t len, jolt_table **out);
+int32_t jolt_table_from_device(jolt_ctx *ctx, const void *device_ptr, size_t len, jolt_table **out); /* D2D copy */
+int32_t jolt_table_alloc(jolt_ctx *ctx, size_t len, jolt_table **out);                               /* zeroed   */
+int32_t jolt_table_clone(jolt_ctx *ctx, const jolt_table *src, jolt_table **out);
+/* Small-scalar promotion on device: Ring::from_u64 / from_i64 per entry (crates/jolt-field/src/bn254/mod.rs:265-292),
+ * the device twin of Polynomial<T>::bind_to_field's `From<T>` (dense.rs:129-142). */
+int32_t jolt_table_from_u64(jolt_ctx *ctx, const uint64_t *host, size_t len, jolt_table **out);
+int32_t jolt_table_from_i64(jolt_ctx *ctx, const int64_t *host, size_t len, jolt_table **out);
+int32_t jolt_table_download(jolt_ctx *ctx, const jolt_table *t, size_t offset, size_t len, jolt_fr_t *host);
+int32_t jolt_table_len(const jolt_table *t, size_t *len);
+int32_t jolt_table_device_ptr(const jolt_table *t, void **device_ptr); /* current evaluations, len*32 bytes */
+int32_t jolt_table_free(jolt_ctx *ctx, jolt_table *t);
+
+/* Polynomial::bind_with_order on k tables in ONE launch (dense.rs:178-263; optimized/support.rs:224-231 bind_all):
+ *   LowToHigh: t[y] <- t[2y] + r*(t[2y+1]-t[2y]);   HighToLow: t[i] <- t[i] + r*(t[i+half]-t[i]); len halves. */
+int32_t jolt_bind(jolt_ctx *ctx, jolt_table *const *tables, size_t k, const jolt_fr_t *r, int32_t order);
+
+/* EqPolynomial::evals(r, scaling_factor) (crates/jolt-poly/src/eq.rs:221-231): 2^n entries, big-endian index
+ * (r[0] pairs the MSB); scale may be NULL (= one). */
+int32_t jolt_eq_evals(jolt_ctx *ctx, const jolt_fr_t *r, size_t n, const jolt_fr_t *scale, jolt_table **out);
+/* EqPolynomial::evals_for_aligned_block (eq.rs:238-263): entries [start, start+block) only -- the per-GPU shard. */
+int32_t jolt_eq_evals_aligned_block(jolt_ctx *ctx, const jolt_fr_t *r, size_t n, size_t start, size_t block,
+                                    jolt_table **out);
+/* LtPolynomial::evaluations (crates/jolt-poly/src/lt.rs:115-117,144-156) */
+int32_t jolt_lt_evals(jolt_ctx *ctx, const jolt_fr_t *r, size_t n, jolt_table **out);
+/* EqPlusOnePolynomial::evals (crates/jolt-poly/src/eq_plus_one.rs:71-130): (eq, eq+1) tables */
+int32_t jolt_eq_plus_one_evals(jolt_ctx *ctx, const jolt_fr_t *r, size_t n, const jolt_fr_t *scale, jolt_table **eq_out,
+                               jolt_table **eq_plus_one_out);
+/* Polynomial::evaluate (dense.rs:340-366): sum_x t[x] * eq(x, point) */
+int32_t jolt_table_evaluate(jolt_ctx *ctx, const jolt_table *t, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
+/* Sum of all entries (input claims of linear members; DenseMember::with_sum, jolt-sumcheck/src/tests.rs:1129-1135) */
+int32_t jolt_table_sum(jolt_ctx *ctx, const jolt_table *t, jolt_fr_t *out);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sumcheck members: the device twin of NaiveSumcheckProver (crates/jolt-kernels/src/reference/naive.rs:53-377),
+ * serving every cycle-domain relation of SURVEY.md section 8 a13 from one descriptor, plus the split-eq product
+ * member (optimized/support.rs:391-411, ram_hamming_booleanity.rs:111-135).
+ *
+ * Summand = sum_k coeffs[k] * prod_{f in term k} table[factors[f]]   (jolt_claims::Expr, claims.rs:17-46 with
+ * Challenge leaves pre-folded into coeffs).  A term with no factors is a constant.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define JOLT_MAX_MEMBER_TABLES 40
+#define JOLT_MAX_MEMBER_TERMS 16
+#define JOLT_MAX_MEMBER_FACTORS 64
+#define JOLT_MAX_DEGREE 7
+
+typedef struct {
+    uint32_t n_tables;
+    uint32_t n_terms;
+    uint32_t degree;              /* relation.degree(): round polynomials have degree+1 evaluations            */
+    int32_t order;                /* JOLT_ORDER_*; every T-scale member of the reference binds LowToHigh        */
+    const uint32_t *term_offsets; /* n_terms+1 entries into `factors`                                          */
+    const uint32_t *factors;      /* table indices                                                             */
+    const jolt_fr_t *coeffs;      /* n_terms                                                                   */
+} jolt_member_desc;
+
+/* NaiveSumcheckProver::new (naive.rs:136-205).  Takes OWNERSHIP of the tables (they are freed with the member). */
+int32_t jolt_member_create_expr(jolt_ctx *ctx, jolt_table *const *tables, const jolt_member_desc *desc, jolt_member **out);
+
+/* The optimized tier's fused summands as a descriptor rewrite instead of a new kernel:
+ *   summand = sum_g prod_{f in group g} ( factor_consts[f] + sum_k lc_coeffs[k] * table[lc_tables[k]] )
+ * e.g. inc_claim_reduction's A = s1*eq(p1) + s2*eq(p2) linear-leaf fusion
+ * (crates/jolt-kernels/src/optimized/inc_claim_reduction.rs:68-89) is one factor with two entries.
+ * flags bit 0 = evaluate t in {0,2,..,degree} only and let the caller recover s(1) = claim - s(0)
+ * (optimized/support.rs:450-459 round_poly_from_skipped_evals); prove_round then returns `degree` values. */
+#define JOLT_MEMBER_FLAG_SKIP_ONE 1u
+typedef struct {
+    uint32_t n_tables, n_groups, n_factors, n_lc;
+    uint32_t degree;
+    int32_t order;
+    uint32_t flags;
+    const uint32_t *group_factor_offsets; /* n_groups+1  */
+    const uint32_t *factor_lc_offsets;    /* n_factors+1 */
+    const jolt_fr_t *factor_consts;       /* n_factors, or NULL = all zero */
+    const uint32_t *lc_tables;            /* n_lc */
+    const jolt_fr_t *lc_coeffs;           /* n_lc */
+} jolt_member_lc_desc;
+int32_t jolt_member_create_lc(jolt_ctx *ctx, jolt_table *const *tables, const jolt_member_lc_desc *desc, jolt_member **out);
+/* eq(w, j) * a(j) * b(j), eq served from split tables (GruenSplitEqPolynomial::new_with_scaling(w, LowToHigh, scale),
+ * crates/jolt-poly/src/split_eq.rs:187-236).  Takes ownership of a and b. */
+int32_t jolt_member_create_split_eq_product(jolt_ctx *ctx, jolt_table *a, jolt_table *b, const jolt_fr_t *w, size_t n,
+                                            const jolt_fr_t *scale, jolt_member **out);
+int32_t jolt_member_num_rounds(const jolt_member *m, size_t *rounds);
+int32_t jolt_member_degree(const jolt_member *m, uint32_t *degree);
+
+/* ProveRounds::prove_round (crates/jolt-sumcheck/src/prover.rs:57-66), device half: bind `bind` (NULL on the
+ * member's first active round -- the fused contract, prover.rs:45-51) and return the round sums.
+ *   expr member     : evals_out[t] = s(t), t = 0..degree           (n_evals must be degree+1)
+ *   split-eq member : evals_out = { q(0), q(inf) }, the eq-stripped endpoints that
+ *                     gruen_poly_deg_3 (split_eq.rs:383-417) completes on the host (n_evals must be 2);
+ *                     aux_out (3 entries, may be NULL) receives {current_scalar, w[current_index-1], 0}.
+ * The caller (Rust: UnivariatePoly::from_evals, univariate.rs:198-202) interpolates and checks s(0)+s(1). */
+int32_t jolt_member_prove_round(jolt_member *m, const jolt_fr_t *bind, jolt_fr_t *evals_out, size_t n_evals,
+                                jolt_fr_t *aux_out);
+/* All members of one batch round with as few launches/syncs as possible -- the BuildRoundScheduler hook
+ * (crates/jolt-kernels/src/backend.rs:68-70, RoundScheduler::batch_prove_round prover.rs:110-115).
+ * binds[i] may be NULL; evals_out is the concatenation of each member's evals (same layout as above). */
+int32_t jolt_round_group_prove(jolt_ctx *ctx, jolt_member *const *members, size_t n_members, const jolt_fr_t *const *binds,
+                               jolt_fr_t *evals_out, size_t evals_capacity);
+/* ProveRounds::finish_rounds (prover.rs:68-71) */
+int32_t jolt_member_finish(jolt_member *m, const jolt_fr_t *bind);
+/* SumcheckKernel::output_claims (naive.rs:331-347): every table's fully bound value, in table order; the split-eq
+ * member appends its bound eq scalar (k = n_tables (+1)).  JOLT_ERR_NOT_FULLY_BOUND before the last bind. */
+int32_t jolt_member_final_values(jolt_member *m, jolt_fr_t *out, size_t k);
+/* sum over the hypercube of the summand (the claim a stage would consume; test/bench convenience) */
+int32_t jolt_member_input_claim(jolt_member *m, jolt_fr_t *out);
+int32_t jolt_member_destroy(jolt_member *m);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * G1 MSM and HyperKZG prover pieces.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Upload bases once and keep them affine on the device -- replaces the per-call `into_affine` of every base in
+ * Bn254G1::msm (crates/jolt-crypto/src/ec/bn254/mod.rs:205).  An MSM over bases[..n] uses the prefix. */
+int32_t jolt_srs_upload_g1(jolt_ctx *ctx, const jolt_g1_t *bases, size_t n, jolt_srs **out);
+/* HyperKZGScheme::setup_from_secret (crates/jolt-hyperkzg/src/scheme.rs:54-73): g1_powers[i] = beta^i * g1,
+ * generated on the device (count = max_degree + 1). */
+int32_t jolt_srs_setup_from_secret(jolt_ctx *ctx, const jolt_fr_t *beta, size_t count, const jolt_g1_t *g1, jolt_srs **out);
+int32_t jolt_srs_len(const jolt_srs *srs, size_t *n);
+int32_t jolt_srs_download(jolt_ctx *ctx, const jolt_srs *srs, size_t offset, size_t n, jolt_g1_t *out); /* z = 1 */
+int32_t jolt_srs_free(jolt_ctx *ctx, jolt_srs *srs);
+
+/* JoltGroup::msm(bases, scalars) (crates/jolt-crypto/src/ec/group.rs:63-70, bn254/mod.rs:195-212) with the bases
+ * = srs[..n].  Length mismatch (n > srs length) is JOLT_ERR_SRS_TOO_SMALL (the Rust shim asserts equal lengths
+ * before calling, keeping the reference's panic).  Scalars from host memory or from a device table. */
+int32_t jolt_msm_g1(jolt_ctx *ctx, const jolt_srs *srs, const jolt_fr_t *scalars, size_t n, jolt_g1_t *out);
+int32_t jolt_msm_g1_table(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *scalars, size_t n, jolt_g1_t *out);
+
+/* fold_polynomials (crates/jolt-hyperkzg/src/scheme.rs:88-114): levels_out[0] = clone of evals, then ell-1
+ * LowToHigh folds with point[ell-1], ..., point[1]; ell output tables of length 2^ell, ..., 2. */
+int32_t jolt_hyperkzg_fold(jolt_ctx *ctx, const jolt_table *evals, const jolt_fr_t *point, size_t ell, jolt_table **levels_out);
+/* v[t][j] = P_j(u_t) (eval_univariate, crates/jolt-hyperkzg/src/kzg.rs:51-59,84-85): v_out is 3*ell, row-major */
+int32_t jolt_hyperkzg_eval3(jolt_ctx *ctx, jolt_table *const *levels, size_t ell, const jolt_fr_t u[3], jolt_fr_t *v_out);
+/* B = sum_j q^j * P_j (kzg.rs:95-105), length = len(levels[0]) */
+int32_t jolt_hyperkzg_rlc(jolt_ctx *ctx, jolt_table *const *levels, size_t ell, const jolt_fr_t *q, jolt_table **out);
+/* compute_witness_polynomial (kzg.rs:34-46): h = f / (x - u), len(f)-1 entries (parallel scan of the Horner
+ * recurrence, exact). */
+int32_t jolt_hyperkzg_witness_poly(jolt_ctx *ctx, const jolt_table *f, const jolt_fr_t *u, jolt_table **out);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Host-side mirror (C++ in this repo because the image has no Rust toolchain): the reference's callers of the path
+ * restated above the C ABI so that the parity tests read like the reference's own.  In a Rust deployment these stay
+ * in jolt-sumcheck / jolt-hyperkzg; they are exported here for tests and bench only.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Host field helpers used by round-message assembly (no GPU needed). */
+int32_t jolt_host_fr_mul(const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out);
+int32_t jolt_host_fr_add(const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out);
+int32_t jolt_host_fr_sub(const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out);
+int32_t jolt_host_fr_inv(const jolt_fr_t *a, jolt_fr_t *out);
+int32_t jolt_host_fr_from_u64(uint64_t v, jolt_fr_t *out);
+int32_t jolt_host_fr_mul_shifted(const jolt_fr_t *a, const jolt_fr_t *c, jolt_fr_t *out); /* c low limbs must be 0 */
+/* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
+int32_t jolt_host_univariate_from_evals(const jolt_fr_t *evals, size_t n, jolt_fr_t *coeffs_out);
+int32_t jolt_host_univariate_evaluate(const jolt_fr_t *coeffs, size_t n, const jolt_fr_t *x, jolt_fr_t *out);
+/* GruenSplitEqPolynomial::gruen_poly_deg_3 (split_eq.rs:383-417): 4 coefficients */
+int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t *current_scalar, const jolt_fr_t *point_i, const jolt_fr_t *q_constant,
+                                   const jolt_fr_t *q_quadratic, const jolt_fr_t *s0_plus_s1, jolt_fr_t *coeffs_out);
+/* G1 helpers on the host: group law, equality as points, compressed serialisation
+ * (crates/jolt-crypto/src/ec/bn254/mod.rs:139-171) */
+int32_t jolt_host_g1_add(const jolt_g1_t *p, const jolt_g1_t *q, jolt_g1_t *out);
+int32_t jolt_host_g1_eq(const jolt_g1_t *p, const jolt_g1_t *q, int32_t *equal);
+int32_t jolt_host_g1_serialize_compressed(const jolt_g1_t *p, uint8_t out[32]);
+
+/* jolt_sumcheck::prove_batch (crates/jolt-sumcheck/src/prover.rs:193-362) over device members with the
+ * deterministic test transcript of oracle/mock_transcript.h (spec in that header; re-implemented, not shared).
+ *   out_polys         max_num_vars x (max_degree+1) batched coefficients
+ *   out_challenges    max_num_vars
+ *   out_member_claims n_members,  out_final_claim 1
+ * challenge_mode 0 = Transcript::challenge (125-bit), 1 = challenge_scalar (full width). */
+int32_t jolt_host_prove_batch(jolt_ctx *ctx, jolt_member *const *members, size_t n_members, const jolt_fr_t *input_claims,
+                              const jolt_fr_t *coefficients, const size_t *offsets, size_t max_num_vars, size_t max_degree,
+                              uint64_t transcript_label, int32_t challenge_mode, int32_t use_round_group,
+                              jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
+                              jolt_fr_t *out_final_claim);
+/* HyperKZGScheme::commit / open (crates/jolt-hyperkzg/src/scheme.rs:122-158,302-325, kzg.rs:69-126) over the device
+ * kernels with the same test transcript.  com: ell-1 points, w: 3 points, v: 3*ell, challenges: {r, q, d_0}. */
+int32_t jolt_host_hyperkzg_commit(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, jolt_g1_t *out);
+int32_t jolt_host_hyperkzg_open(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
+                                uint64_t transcript_label, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JOLT_HIP_H */

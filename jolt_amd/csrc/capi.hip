@@ -1,0 +1,821 @@
+// jolt_amd/csrc/capi.hip -- implementation of include/jolt_hip.h: context, tables, bind/eq kernels launches and the
+// sumcheck members.  (MSM / HyperKZG device pieces live in msm.hip, the host-side mirror in host_mirror.hip.)
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "member.hpp"
+#include "poly_kernels.cuh"
+#include "sumcheck_kernels.cuh"
+
+using namespace jolt;
+
+// ------------------------------------------------------------------------------------------------------------------
+// status / context
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" const char* jolt_status_string(int32_t s) {
+    switch (s) {
+        case JOLT_OK: return "ok";
+        case JOLT_ERR_INVALID_ARG: return "invalid argument";
+        case JOLT_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case JOLT_ERR_OOM: return "out of device memory";
+        case JOLT_ERR_HIP: return "HIP runtime error";
+        case JOLT_ERR_SIZE_MISMATCH: return "size mismatch";
+        case JOLT_ERR_UNSUPPORTED: return "unsupported descriptor";
+        case JOLT_ERR_NOT_FULLY_BOUND: return "member not fully bound";
+        case JOLT_ERR_ROUND_CHECK: return "round check failed";
+        case JOLT_ERR_SRS_TOO_SMALL: return "SRS too small";
+        case JOLT_ERR_EMPTY_POINT: return "empty opening point";
+        case JOLT_ERR_NOT_INVERTIBLE: return "value not invertible";
+    }
+    return "unknown status";
+}
+extern "C" int32_t jolt_abi_version(void) { return JOLT_HIP_ABI_VERSION; }
+
+extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** out) {
+    if (!out) return JOLT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return JOLT_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return JOLT_ERR_NO_DEVICE;
+    // the code objects are gfx950-only: refuse anything else loudly instead of failing at the first launch
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return JOLT_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return JOLT_ERR_NO_DEVICE;
+    jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
+    if (!ctx) return JOLT_ERR_OOM;
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return JOLT_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { delete ctx; return JOLT_ERR_HIP; }
+    int32_t s = jolt_internal_ensure_scratch(ctx, 4096 * 8, 1024);
+    if (s != JOLT_OK) { delete ctx; return s; }
+    *out = ctx;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
+    if (!ctx) return JOLT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_results) (void)hipFree(ctx->d_results);
+    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_ctx_synchronize(jolt_ctx* ctx) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JOLT_OK;
+}
+extern "C" const char* jolt_last_error(const jolt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int32_t jolt_timer_begin(jolt_ctx* ctx) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_timer_end(jolt_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    JOLT_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end));
+    return JOLT_OK;
+}
+
+int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t results) {
+    if (partials > ctx->partials_cap) {
+        if (ctx->d_partials) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(ctx->d_partials)); }
+        ctx->d_partials = nullptr;
+        JOLT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_partials, partials * sizeof(Fr)));
+        ctx->partials_cap = partials;
+    }
+    if (results > ctx->results_cap) {
+        if (ctx->d_results) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(ctx->d_results)); }
+        if (ctx->h_results) JOLT_HIP_TRY(ctx, hipHostFree(ctx->h_results));
+        ctx->d_results = nullptr;
+        ctx->h_results = nullptr;
+        JOLT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_results, results * sizeof(Fr)));
+        JOLT_HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_results, results * sizeof(Fr), hipHostMallocDefault));
+        ctx->results_cap = results;
+    }
+    return JOLT_OK;
+}
+
+// grid for a grid-stride sweep over n work items: enough blocks to fill 256 CUs x 8, never more than needed
+static inline int sweep_grid(const jolt_ctx* ctx, size_t n) {
+    size_t need = (n + kBlock - 1) / kBlock;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    return (int)std::max<size_t>(1, std::min(need, cap));
+}
+
+// results[slot .. slot+ne) = sum over blocks of the partials just written
+static int32_t reduce_into_results(jolt_ctx* ctx, int nblocks, int ne, size_t slot) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->d_partials, nblocks, ne, ctx->d_results + slot);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    return JOLT_OK;
+}
+// copy results[0..count) to the host and wait (the protocol's per-round sync point)
+static int32_t fetch_results(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, count * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->h_results, count * sizeof(Fr));
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------------------------------
+int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out) {
+    jolt_table* t = new (std::nothrow) jolt_table();
+    if (!t) return JOLT_ERR_OOM;
+    t->ctx = ctx;
+    t->len = len;
+    size_t bytes = std::max<size_t>(len, 1) * sizeof(Fr);
+    hipError_t e = hipMalloc((void**)&t->buf[0], bytes);
+    if (e != hipSuccess) {
+        delete t;
+        ctx->last_error = std::string("hipMalloc table: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    t->cap[0] = std::max<size_t>(len, 1);
+    *out = t;
+    return JOLT_OK;
+}
+int32_t jolt_internal_table_ensure_alt(jolt_table* t, size_t need) {
+    int alt = 1 - t->cur;
+    if (t->cap[alt] >= need) return JOLT_OK;
+    jolt_ctx* ctx = t->ctx;
+    if (t->buf[alt]) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(t->buf[alt])); t->buf[alt] = nullptr; t->cap[alt] = 0; }
+    JOLT_HIP_TRY(ctx, hipMalloc((void**)&t->buf[alt], std::max<size_t>(need, 1) * sizeof(Fr)));
+    t->cap[alt] = std::max<size_t>(need, 1);
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_table_upload(jolt_ctx* ctx, const jolt_fr_t* host, size_t len, jolt_table** out) {
+    if (!ctx || !out || (!host && len)) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
+    if (len) {
+        hipError_t e = hipMemcpyAsync(t->buf[0], host, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host buffer may be pageable and short-lived
+        if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    }
+    *out = t;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_from_device(jolt_ctx* ctx, const void* dptr, size_t len, jolt_table** out) {
+    if (!ctx || !out || (!dptr && len)) return JOLT_ERR_INVALID_ARG;
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
+    if (len) JOLT_HIP_TRY(ctx, hipMemcpyAsync(t->buf[0], dptr, len * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    *out = t;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_alloc(jolt_ctx* ctx, size_t len, jolt_table** out) {
+    if (!ctx || !out) return JOLT_ERR_INVALID_ARG;
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
+    if (len) JOLT_HIP_TRY(ctx, hipMemsetAsync(t->buf[0], 0, len * sizeof(Fr), ctx->stream));
+    *out = t;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_clone(jolt_ctx* ctx, const jolt_table* src, jolt_table** out) {
+    if (!ctx || !src || !out) return JOLT_ERR_INVALID_ARG;
+    return jolt_table_from_device(ctx, src->data(), src->len, out);
+}
+template <typename T, typename K>
+static int32_t table_from_small(jolt_ctx* ctx, const T* host, size_t len, jolt_table** out, K kernel) {
+    if (!ctx || !out || (!host && len)) return JOLT_ERR_INVALID_ARG;
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
+    if (len) {
+        T* staging = nullptr;
+        hipError_t e = hipMalloc((void**)&staging, len * sizeof(T));
+        if (e == hipSuccess) e = hipMemcpyAsync(staging, host, len * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(kernel, dim3(sweep_grid(ctx, len)), dim3(kBlock), 0, ctx->stream, (const T*)staging, t->buf[0], len);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (staging) (void)hipFree(staging);
+        if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    }
+    *out = t;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_from_u64(jolt_ctx* ctx, const uint64_t* host, size_t len, jolt_table** out) {
+    return table_from_small(ctx, host, len, out, k_from_u64);
+}
+extern "C" int32_t jolt_table_from_i64(jolt_ctx* ctx, const int64_t* host, size_t len, jolt_table** out) {
+    return table_from_small(ctx, host, len, out, k_from_i64);
+}
+extern "C" int32_t jolt_table_download(jolt_ctx* ctx, const jolt_table* t, size_t offset, size_t len, jolt_fr_t* host) {
+    if (!ctx || !t || (!host && len)) return JOLT_ERR_INVALID_ARG;
+    if (offset + len > t->len) return JOLT_ERR_SIZE_MISMATCH;
+    if (len) {
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(host, t->data() + offset, len * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_len(const jolt_table* t, size_t* len) {
+    if (!t || !len) return JOLT_ERR_INVALID_ARG;
+    *len = t->len;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_device_ptr(const jolt_table* t, void** p) {
+    if (!t || !p) return JOLT_ERR_INVALID_ARG;
+    *p = t->data();
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_free(jolt_ctx* ctx, jolt_table* t) {
+    if (!t) return JOLT_OK;
+    jolt_ctx* c = ctx ? ctx : t->ctx;
+    if (c) (void)hipStreamSynchronize(c->stream);
+    if (t->buf[0]) (void)hipFree(t->buf[0]);
+    if (t->buf[1]) (void)hipFree(t->buf[1]);
+    delete t;
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bind
+// ------------------------------------------------------------------------------------------------------------------
+int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r, int32_t order) {
+    if (k == 0) return JOLT_OK;
+    size_t len = tables[0]->len;
+    for (size_t i = 0; i < k; ++i) {
+        if (!tables[i]) return JOLT_ERR_INVALID_ARG;
+        if (tables[i]->len != len) return JOLT_ERR_SIZE_MISMATCH;
+    }
+    if (len < 2) { ctx->last_error = "cannot bind a zero-variable polynomial"; return JOLT_ERR_INVALID_ARG; }  // dense.rs:190,225 assert
+    size_t half = len / 2;
+    const bool shifted = fr_low_limbs_zero(r);
+    for (size_t base = 0; base < k; base += kMaxBatchTables) {
+        size_t cnt = std::min<size_t>(kMaxBatchTables, k - base);
+        BindBatch b;
+        for (size_t i = 0; i < cnt; ++i) {
+            jolt_table* t = tables[base + i];
+            b.in[i] = t->data();
+            if (order == JOLT_ORDER_LOW_TO_HIGH) {
+                JOLT_TRY(jolt_internal_table_ensure_alt(t, half));
+                b.out[i] = t->buf[1 - t->cur];
+            } else {
+                b.out[i] = t->data();
+            }
+        }
+        dim3 grid(sweep_grid(ctx, half), (unsigned)cnt);
+        if (order == JOLT_ORDER_LOW_TO_HIGH) {
+            if (shifted) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
+            else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
+        } else {
+            if (shifted) hipLaunchKernelGGL(k_bind_high_to_low<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
+            else hipLaunchKernelGGL(k_bind_high_to_low<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
+        }
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        for (size_t i = 0; i < cnt; ++i) {
+            jolt_table* t = tables[base + i];
+            if (order == JOLT_ORDER_LOW_TO_HIGH) t->cur = 1 - t->cur;
+            t->len = half;
+        }
+    }
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const jolt_fr_t* r, int32_t order) {
+    if (!ctx || (!tables && k) || !r) return JOLT_ERR_INVALID_ARG;
+    if (order != JOLT_ORDER_LOW_TO_HIGH && order != JOLT_ORDER_HIGH_TO_LOW) return JOLT_ERR_INVALID_ARG;
+    Fr rr = fr_from_abi(r);
+    JOLT_REQUIRE(ctx, fr_is_canonical(rr), "bind challenge is not a canonical Fr");
+    return jolt_internal_bind(ctx, tables, k, rr, order);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// eq / LT / eq+1 tables
+// ------------------------------------------------------------------------------------------------------------------
+// Build eq(r[..n], .) * scale into a fresh table by tensor steps of <= 8 variables; optionally keep every
+// prefix level (used by eq+1 and by the split-eq member's cached tables when step = 1).
+static int32_t eq_build(jolt_ctx* ctx, const Fr* r, size_t n, const Fr& scale, size_t step_vars, std::vector<jolt_table*>* levels,
+                        jolt_table** out) {
+    jolt_table* cur = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, 1, &cur));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(cur->buf[0], &scale, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `scale` is a host temporary
+    if (levels) levels->push_back(cur);
+    size_t done = 0;
+    while (done < n) {
+        size_t c = std::min(step_vars, n - done);
+        EqChunk ch;
+        ch.c = (int)c;
+        for (size_t k = 0; k < 8; ++k) ch.r[k] = k < c ? r[done + k] : Fr::zero();
+        size_t out_len = (size_t)1 << (done + c);
+        jolt_table* nxt = nullptr;
+        int32_t s = jolt_internal_table_new(ctx, out_len, &nxt);
+        if (s != JOLT_OK) { if (!levels) jolt_table_free(ctx, cur); return s; }
+        hipLaunchKernelGGL(k_eq_expand, dim3(sweep_grid(ctx, out_len)), dim3(kBlock), 0, ctx->stream, (const Fr*)cur->data(), nxt->data(), out_len, ch);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        if (levels) levels->push_back(nxt);
+        else jolt_table_free(ctx, cur);
+        cur = nxt;
+        done += c;
+    }
+    *out = cur;
+    return JOLT_OK;
+}
+
+static int32_t read_point(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, std::vector<Fr>& out) {
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = fr_from_abi(&r[i]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(out[i]), "point coordinate is not a canonical Fr");
+    }
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_eq_evals(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, const jolt_fr_t* scale, jolt_table** out) {
+    if (!ctx || !out || (!r && n) || n > 40) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> pt;
+    JOLT_TRY(read_point(ctx, r, n, pt));
+    Fr s = scale ? fr_from_abi(scale) : Fr::one();
+    return eq_build(ctx, pt.data(), n, s, 8, nullptr, out);
+}
+
+extern "C" int32_t jolt_eq_evals_aligned_block(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, size_t start, size_t block, jolt_table** out) {
+    if (!ctx || !out || (!r && n) || n > 40) return JOLT_ERR_INVALID_ARG;
+    // eq.rs:243-245 asserts
+    JOLT_REQUIRE(ctx, block != 0 && (block & (block - 1)) == 0, "block_size must be a power of two");
+    JOLT_REQUIRE(ctx, start % block == 0, "start_index must be aligned to block_size");
+    size_t block_vars = 0;
+    while (((size_t)1 << block_vars) < block) block_vars++;
+    JOLT_REQUIRE(ctx, block_vars <= n, "block larger than the domain");
+    std::vector<Fr> pt;
+    JOLT_TRY(read_point(ctx, r, n, pt));
+    size_t prefix_len = n - block_vars;
+    size_t prefix_value = start >> block_vars;
+    Fr prefix_scale = Fr::one();
+    for (size_t pos = 0; pos < prefix_len; ++pos) {  // eq.rs:253-260
+        int bit = (int)((prefix_value >> (prefix_len - 1 - pos)) & 1);
+        prefix_scale = mul(prefix_scale, bit ? pt[pos] : sub(Fr::one(), pt[pos]));
+    }
+    return eq_build(ctx, pt.data() + prefix_len, block_vars, prefix_scale, 8, nullptr, out);
+}
+
+extern "C" int32_t jolt_lt_evals(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, jolt_table** out) {
+    if (!ctx || !out || (!r && n) || n > 40) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> pt;
+    JOLT_TRY(read_point(ctx, r, n, pt));
+    // LT over the first `done` variables and eq over the same prefix, extended <= 8 variables at a time
+    jolt_table *lt = nullptr, *eq = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, 1, &lt));
+    JOLT_TRY(jolt_internal_table_new(ctx, 1, &eq));
+    Fr zero = Fr::zero(), one = Fr::one();
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(lt->buf[0], &zero, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(eq->buf[0], &one, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t done = 0;
+    while (done < n) {
+        size_t c = std::min<size_t>(8, n - done);
+        EqChunk ch;
+        ch.c = (int)c;
+        for (size_t k = 0; k < 8; ++k) ch.r[k] = k < c ? pt[done + k] : Fr::zero();
+        size_t out_len = (size_t)1 << (done + c);
+        jolt_table *lt2 = nullptr, *eq2 = nullptr;
+        JOLT_TRY(jolt_internal_table_new(ctx, out_len, &lt2));
+        hipLaunchKernelGGL(k_lt_expand, dim3(sweep_grid(ctx, out_len)), dim3(kBlock), 0, ctx->stream, (const Fr*)lt->data(), (const Fr*)eq->data(), lt2->data(), out_len, ch);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        if (done + c < n) {
+            JOLT_TRY(jolt_internal_table_new(ctx, out_len, &eq2));
+            hipLaunchKernelGGL(k_eq_expand, dim3(sweep_grid(ctx, out_len)), dim3(kBlock), 0, ctx->stream, (const Fr*)eq->data(), eq2->data(), out_len, ch);
+            JOLT_HIP_TRY(ctx, hipGetLastError());
+        }
+        jolt_table_free(ctx, lt);
+        jolt_table_free(ctx, eq);
+        lt = lt2;
+        eq = eq2;
+        done += c;
+    }
+    if (eq) jolt_table_free(ctx, eq);
+    *out = lt;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_eq_plus_one_evals(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, const jolt_fr_t* scale, jolt_table** eq_out,
+                                          jolt_table** eqp1_out) {
+    if (!ctx || !eq_out || !eqp1_out || (!r && n) || n > 32) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> pt;
+    JOLT_TRY(read_point(ctx, r, n, pt));
+    Fr s = scale ? fr_from_abi(scale) : Fr::one();
+    std::vector<jolt_table*> levels;
+    jolt_table* full = nullptr;
+    JOLT_TRY(eq_build(ctx, pt.data(), n, s, 1, &levels, &full));
+    jolt_table* p1 = nullptr;
+    size_t len = (size_t)1 << n;
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &p1));
+    EqP1Args a;
+    a.n = (int)n;
+    for (size_t i = 0; i < 33; ++i) a.prefix[i] = i < levels.size() ? levels[i]->data() : nullptr;
+    for (size_t i = 0; i < 32; ++i) a.lower[i] = Fr::zero();
+    for (size_t i = 0; i < n; ++i) {  // eq_plus_one.rs:97-102
+        Fr lower = Fr::one();
+        for (size_t m = i + 1; m < n; ++m) lower = mul(lower, pt[m]);
+        a.lower[i] = mul(lower, sub(Fr::one(), pt[i]));
+    }
+    hipLaunchKernelGGL(k_eq_plus_one, dim3(sweep_grid(ctx, len)), dim3(kBlock), 0, ctx->stream, a, p1->data(), len);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    for (size_t i = 0; i + 1 < levels.size(); ++i) jolt_table_free(ctx, levels[i]);
+    *eq_out = full;
+    *eqp1_out = p1;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_table_sum(jolt_ctx* ctx, const jolt_table* t, jolt_fr_t* out) {
+    if (!ctx || !t || !out) return JOLT_ERR_INVALID_ARG;
+    int grid = sweep_grid(ctx, t->len);
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid, 1));
+    hipLaunchKernelGGL(k_sum_or_dot<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), (const Fr*)nullptr, t->len, ctx->d_partials);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
+    return fetch_results(ctx, 1, out);
+}
+
+extern "C" int32_t jolt_table_evaluate(jolt_ctx* ctx, const jolt_table* t, const jolt_fr_t* point, size_t n, jolt_fr_t* out) {
+    if (!ctx || !t || !out || (!point && n)) return JOLT_ERR_INVALID_ARG;
+    if (t->len != ((size_t)1 << n)) return JOLT_ERR_SIZE_MISMATCH;  // dense.rs:341-345 assert
+    jolt_table* eq = nullptr;
+    JOLT_TRY(jolt_eq_evals(ctx, point, n, nullptr, &eq));
+    int grid = sweep_grid(ctx, t->len);
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid, 1));
+    hipLaunchKernelGGL(k_sum_or_dot<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), (const Fr*)eq->data(), t->len, ctx->d_partials);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
+    int32_t s = fetch_results(ctx, 1, out);
+    jolt_table_free(ctx, eq);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// sumcheck members
+// ------------------------------------------------------------------------------------------------------------------
+static int32_t member_upload_desc(jolt_member* m) {
+    jolt_ctx* ctx = m->ctx;
+    JOLT_HIP_TRY(ctx, hipMalloc((void**)&m->d_desc, sizeof(MemberDesc)));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(m->d_desc, &m->desc, sizeof(MemberDesc), hipMemcpyHostToDevice, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JOLT_OK;
+}
+
+static int32_t member_common_init(jolt_ctx* ctx, jolt_table* const* tables, uint32_t n_tables, jolt_member* m) {
+    if (n_tables == 0 || n_tables > kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
+    size_t len = tables[0]->len;
+    for (uint32_t i = 0; i < n_tables; ++i) {
+        if (!tables[i]) return JOLT_ERR_INVALID_ARG;
+        if (tables[i]->len != len) return JOLT_ERR_SIZE_MISMATCH;  // KernelError::TableSizeMismatch, naive.rs:145-155
+    }
+    if (len == 0 || (len & (len - 1)) != 0) return JOLT_ERR_SIZE_MISMATCH;
+    m->ctx = ctx;
+    m->len = len;
+    m->rounds = 0;
+    while (((size_t)1 << m->rounds) < len) m->rounds++;
+    m->tables.assign(tables, tables + n_tables);
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_member_create_lc(jolt_ctx* ctx, jolt_table* const* tables, const jolt_member_lc_desc* d, jolt_member** out) {
+    if (!ctx || !tables || !d || !out) return JOLT_ERR_INVALID_ARG;
+    if (d->n_groups > kMaxGroups || d->n_factors > kMaxFactors || d->n_lc > kMaxLc || d->degree < 1 || d->degree > JOLT_MAX_DEGREE)
+        return JOLT_ERR_UNSUPPORTED;
+    if (d->order != JOLT_ORDER_LOW_TO_HIGH && d->order != JOLT_ORDER_HIGH_TO_LOW) return JOLT_ERR_INVALID_ARG;
+    jolt_member* m = new (std::nothrow) jolt_member();
+    if (!m) return JOLT_ERR_OOM;
+    int32_t s = member_common_init(ctx, tables, d->n_tables, m);
+    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    m->kind = jolt_member::kExpr;
+    m->degree = d->degree;
+    m->order = d->order;
+    m->skip_one = (d->flags & JOLT_MEMBER_FLAG_SKIP_ONE) != 0;
+    MemberDesc& md = m->desc;
+    std::memset(&md, 0, sizeof(md));
+    md.n_groups = d->n_groups;
+    md.n_factors = d->n_factors;
+    md.n_lc = d->n_lc;
+    bool ok = d->group_factor_offsets[0] == 0 && d->group_factor_offsets[d->n_groups] == d->n_factors && d->factor_lc_offsets[0] == 0 &&
+              d->factor_lc_offsets[d->n_factors] == d->n_lc;
+    for (uint32_t g = 0; ok && g <= d->n_groups; ++g) {
+        md.grp_fac_off[g] = d->group_factor_offsets[g];
+        if (g && md.grp_fac_off[g] < md.grp_fac_off[g - 1]) ok = false;
+        if (g && md.grp_fac_off[g] - md.grp_fac_off[g - 1] > d->degree) ok = false;  // a product of more factors than the degree bound
+    }
+    for (uint32_t f = 0; ok && f <= d->n_factors; ++f) {
+        md.fac_lc_off[f] = d->factor_lc_offsets[f];
+        if (f && md.fac_lc_off[f] < md.fac_lc_off[f - 1]) ok = false;
+    }
+    for (uint32_t f = 0; ok && f < d->n_factors; ++f) {
+        Fr c = d->factor_consts ? fr_from_abi(&d->factor_consts[f]) : Fr::zero();
+        if (!fr_is_canonical(c)) ok = false;
+        md.fac_const[f] = c;
+        md.fac_has_const[f] = c.is_zero() ? 0u : 1u;
+    }
+    for (uint32_t k = 0; ok && k < d->n_lc; ++k) {
+        if (d->lc_tables[k] >= d->n_tables) { ok = false; break; }
+        md.lc_tab[k] = d->lc_tables[k];
+        Fr c = fr_from_abi(&d->lc_coeffs[k]);
+        if (!fr_is_canonical(c)) ok = false;
+        md.lc_coeff[k] = c;
+        md.lc_one[k] = (c == Fr::one()) ? 1u : 0u;
+    }
+    if (!ok) { m->tables.clear(); delete m; ctx->last_error = "malformed member descriptor"; return JOLT_ERR_INVALID_ARG; }
+    s = member_upload_desc(m);
+    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    *out = m;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_member_create_expr(jolt_ctx* ctx, jolt_table* const* tables, const jolt_member_desc* d, jolt_member** out) {
+    if (!ctx || !tables || !d || !out) return JOLT_ERR_INVALID_ARG;
+    if (d->n_terms > kMaxGroups || d->n_terms > JOLT_MAX_MEMBER_TERMS) return JOLT_ERR_UNSUPPORTED;
+    // flat Expr -> LC form: term k is group k, every factor a one-entry LC; the term coefficient rides on the first
+    // factor (exact: coefficient * prod factors), a factor-less term is a constant factor.
+    std::vector<uint32_t> goff{0}, foff{0}, ltab;
+    std::vector<jolt_fr_t> fconst, lcoef;
+    jolt_fr_t one_abi, zero_abi;
+    Fr one = Fr::one(), zero = Fr::zero();
+    fr_to_abi(&one_abi, one);
+    fr_to_abi(&zero_abi, zero);
+    for (uint32_t k = 0; k < d->n_terms; ++k) {
+        uint32_t a = d->term_offsets[k], b = d->term_offsets[k + 1];
+        if (b < a || b > JOLT_MAX_MEMBER_FACTORS) return JOLT_ERR_UNSUPPORTED;
+        if (a == b) {
+            fconst.push_back(d->coeffs[k]);
+            foff.push_back((uint32_t)ltab.size());
+        } else {
+            for (uint32_t f = a; f < b; ++f) {
+                ltab.push_back(d->factors[f]);
+                lcoef.push_back(f == a ? d->coeffs[k] : one_abi);
+                fconst.push_back(zero_abi);
+                foff.push_back((uint32_t)ltab.size());
+            }
+        }
+        goff.push_back((uint32_t)fconst.size());
+    }
+    jolt_member_lc_desc lc;
+    lc.n_tables = d->n_tables;
+    lc.n_groups = d->n_terms;
+    lc.n_factors = (uint32_t)fconst.size();
+    lc.n_lc = (uint32_t)ltab.size();
+    lc.degree = d->degree;
+    lc.order = d->order;
+    lc.flags = 0;
+    lc.group_factor_offsets = goff.data();
+    lc.factor_lc_offsets = foff.data();
+    lc.factor_consts = fconst.data();
+    uint32_t dummy_tab = 0;
+    lc.lc_tables = ltab.empty() ? &dummy_tab : ltab.data();
+    lc.lc_coeffs = lcoef.empty() ? &one_abi : lcoef.data();
+    return jolt_member_create_lc(ctx, tables, &lc, out);
+}
+
+extern "C" int32_t jolt_member_create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n,
+                                                       const jolt_fr_t* scale, jolt_member** out) {
+    if (!ctx || !a || !b || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
+    jolt_member* m = new (std::nothrow) jolt_member();
+    if (!m) return JOLT_ERR_OOM;
+    jolt_table* tabs[2] = {a, b};
+    int32_t s = member_common_init(ctx, tabs, 2, m);
+    if (s == JOLT_OK && m->rounds != n) s = JOLT_ERR_SIZE_MISMATCH;
+    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    m->kind = jolt_member::kSplitEqProduct;
+    m->degree = 3;
+    m->order = JOLT_ORDER_LOW_TO_HIGH;
+    s = read_point(ctx, w, n, m->w);
+    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    m->current_scalar = scale ? fr_from_abi(scale) : Fr::one();
+    // GruenSplitEqPolynomial::new (split_eq.rs:214-236): head = w[..n-1], out_point = head[..split], in_point = rest;
+    // evals_cached -> one table per prefix length.
+    if (n > 0) {
+        size_t split = n / 2, head_len = n - 1;
+        m->out_len = std::min(split, head_len);
+        m->in_len = head_len - m->out_len;
+        jolt_table* last = nullptr;
+        s = eq_build(ctx, m->w.data(), m->out_len, Fr::one(), 1, &m->e_out_cache, &last);
+        if (s == JOLT_OK) s = eq_build(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), 1, &m->e_in_cache, &last);
+        if (s != JOLT_OK) { m->tables.clear(); jolt_member_destroy(m); return s; }
+        m->e_out_bits = m->out_len;
+        m->e_in_bits = m->in_len;
+    }
+    *out = m;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_member_num_rounds(const jolt_member* m, size_t* rounds) {
+    if (!m || !rounds) return JOLT_ERR_INVALID_ARG;
+    *rounds = m->rounds;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_member_degree(const jolt_member* m, uint32_t* degree) {
+    if (!m || !degree) return JOLT_ERR_INVALID_ARG;
+    *degree = m->degree;
+    return JOLT_OK;
+}
+
+// naive.rs:211-219 bind_tables (+ split_eq.rs:334-350 for the split-eq member)
+static int32_t member_bind(jolt_member* m, const Fr& c) {
+    if (m->bound >= m->rounds) { m->ctx->last_error = "member already fully bound"; return JOLT_ERR_INVALID_ARG; }
+    if (m->kind == jolt_member::kSplitEqProduct) {
+        size_t n = m->rounds;
+        size_t current_index = n - m->bound;
+        Fr p = m->w[current_index - 1];
+        Fr prod = mul(p, c);
+        Fr f = add(add(sub(sub(Fr::one(), p), c), prod), prod);
+        m->current_scalar = mul(m->current_scalar, f);
+        current_index -= 1;
+        if (n / 2 < current_index && m->e_in_bits > 0) m->e_in_bits -= 1;
+        else if (0 < current_index && m->e_out_bits > 0) m->e_out_bits -= 1;
+    }
+    JOLT_TRY(jolt_internal_bind(m->ctx, m->tables.data(), m->tables.size(), c, m->order));
+    m->len /= 2;
+    m->bound += 1;
+    return JOLT_OK;
+}
+
+template <int ORDER, bool SKIP1>
+static void launch_round_evals(int ne, int grid, hipStream_t s, const MemberDesc* d, const TablePtrs& tp, size_t half, Fr* partials) {
+    switch (ne) {
+        case 1: hipLaunchKernelGGL((k_round_evals<1, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 2: hipLaunchKernelGGL((k_round_evals<2, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 3: hipLaunchKernelGGL((k_round_evals<3, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 4: hipLaunchKernelGGL((k_round_evals<4, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 5: hipLaunchKernelGGL((k_round_evals<5, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 6: hipLaunchKernelGGL((k_round_evals<6, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 7: hipLaunchKernelGGL((k_round_evals<7, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+        case 8: hipLaunchKernelGGL((k_round_evals<8, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
+    }
+}
+
+size_t jolt_internal_member_n_evals(const jolt_member* m) {
+    if (m->kind == jolt_member::kSplitEqProduct) return 2;
+    return m->skip_one ? m->degree : m->degree + 1;
+}
+
+// enqueue bind + round sums of one member; the sums land in ctx->d_results[slot..]
+static int32_t member_enqueue_round(jolt_member* m, const Fr* bind, size_t slot) {
+    jolt_ctx* ctx = m->ctx;
+    if (bind) JOLT_TRY(member_bind(m, *bind));
+    if (m->len < 2) { ctx->last_error = "prove_round on a fully bound member"; return JOLT_ERR_INVALID_ARG; }
+    size_t half = m->len / 2;
+    int grid = sweep_grid(ctx, half);
+    size_t ne = jolt_internal_member_n_evals(m);
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 8, slot + 8));
+    if (m->kind == jolt_member::kExpr) {
+        TablePtrs tp;
+        for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
+        if (m->order == JOLT_ORDER_LOW_TO_HIGH) {
+            if (m->skip_one) launch_round_evals<0, true>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
+            else launch_round_evals<0, false>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
+        } else {
+            if (m->skip_one) launch_round_evals<1, true>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
+            else launch_round_evals<1, false>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
+        }
+    } else {
+        const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
+        const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
+        hipLaunchKernelGGL(k_split_eq_product, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)m->tables[0]->data(), (const Fr*)m->tables[1]->data(), e_out,
+                           e_in, (int)m->e_in_bits, half, ctx->d_partials);
+    }
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    return reduce_into_results(ctx, grid, (int)ne, slot);
+}
+
+static void member_aux(const jolt_member* m, jolt_fr_t* aux) {
+    if (!aux) return;
+    Fr z = Fr::zero();
+    if (m->kind == jolt_member::kSplitEqProduct && m->bound < m->rounds) {
+        fr_to_abi(&aux[0], m->current_scalar);
+        fr_to_abi(&aux[1], m->w[m->rounds - m->bound - 1]);
+    } else {
+        fr_to_abi(&aux[0], z);
+        fr_to_abi(&aux[1], z);
+    }
+    fr_to_abi(&aux[2], z);
+}
+
+extern "C" int32_t jolt_member_prove_round(jolt_member* m, const jolt_fr_t* bind, jolt_fr_t* evals_out, size_t n_evals, jolt_fr_t* aux_out) {
+    if (!m || !evals_out) return JOLT_ERR_INVALID_ARG;
+    jolt_ctx* ctx = m->ctx;
+    if (n_evals != jolt_internal_member_n_evals(m)) return JOLT_ERR_SIZE_MISMATCH;
+    Fr b;
+    if (bind) {
+        b = fr_from_abi(bind);
+        JOLT_REQUIRE(ctx, fr_is_canonical(b), "bind challenge is not a canonical Fr");
+    }
+    JOLT_TRY(member_enqueue_round(m, bind ? &b : nullptr, 0));
+    member_aux(m, aux_out);
+    return fetch_results(ctx, n_evals, evals_out);
+}
+
+extern "C" int32_t jolt_round_group_prove(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds, jolt_fr_t* evals_out,
+                                          size_t cap) {
+    if (!ctx || (!members && n) || !evals_out) return JOLT_ERR_INVALID_ARG;
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!members[i] || members[i]->ctx != ctx) return JOLT_ERR_INVALID_ARG;
+        total += jolt_internal_member_n_evals(members[i]);
+    }
+    if (total > cap) return JOLT_ERR_SIZE_MISMATCH;
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, total + 8));
+    size_t slot = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Fr b;
+        const Fr* bp = nullptr;
+        if (binds && binds[i]) {
+            b = fr_from_abi(binds[i]);
+            JOLT_REQUIRE(ctx, fr_is_canonical(b), "bind challenge is not a canonical Fr");
+            bp = &b;
+        }
+        JOLT_TRY(member_enqueue_round(members[i], bp, slot));
+        slot += jolt_internal_member_n_evals(members[i]);
+    }
+    return fetch_results(ctx, total, evals_out);  // ONE device->host copy and ONE sync for the whole batch round
+}
+
+extern "C" int32_t jolt_member_finish(jolt_member* m, const jolt_fr_t* bind) {
+    if (!m || !bind) return JOLT_ERR_INVALID_ARG;
+    Fr b = fr_from_abi(bind);
+    JOLT_REQUIRE(m->ctx, fr_is_canonical(b), "bind challenge is not a canonical Fr");
+    return member_bind(m, b);
+}
+
+extern "C" int32_t jolt_member_final_values(jolt_member* m, jolt_fr_t* out, size_t k) {
+    if (!m || !out) return JOLT_ERR_INVALID_ARG;
+    if (m->bound != m->rounds) return JOLT_ERR_NOT_FULLY_BOUND;
+    size_t need = m->tables.size() + (m->kind == jolt_member::kSplitEqProduct ? 1 : 0);
+    if (k != need) return JOLT_ERR_SIZE_MISMATCH;
+    jolt_ctx* ctx = m->ctx;
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, need));
+    for (size_t i = 0; i < m->tables.size(); ++i)
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_results + i, m->tables[i]->data(), sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    JOLT_TRY(fetch_results(ctx, m->tables.size(), out));
+    if (m->kind == jolt_member::kSplitEqProduct) fr_to_abi(&out[m->tables.size()], m->current_scalar);
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
+    if (!m || !out) return JOLT_ERR_INVALID_ARG;
+    jolt_ctx* ctx = m->ctx;
+    int grid = sweep_grid(ctx, m->len);
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid, 8));
+    if (m->kind == jolt_member::kExpr) {
+        TablePtrs tp;
+        for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
+        hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)m->d_desc, tp, m->len, ctx->d_partials);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
+        return fetch_results(ctx, 1, out);
+    }
+    // split-eq product: sum_x scale * eq(w[..remaining], x) a(x) b(x) with the dense eq table (claim helper only)
+    size_t rem = m->rounds - m->bound;
+    jolt_table* eq = nullptr;
+    JOLT_TRY(eq_build(ctx, m->w.data(), rem, m->current_scalar, 8, nullptr, &eq));
+    MemberDesc md;
+    std::memset(&md, 0, sizeof(md));
+    md.n_groups = 1; md.n_factors = 3; md.n_lc = 3;
+    md.grp_fac_off[0] = 0; md.grp_fac_off[1] = 3;
+    for (uint32_t f = 0; f <= 3; ++f) md.fac_lc_off[f] = f;
+    for (uint32_t k = 0; k < 3; ++k) { md.lc_tab[k] = k; md.lc_one[k] = 1; md.lc_coeff[k] = Fr::one(); }
+    MemberDesc* dd = nullptr;
+    JOLT_HIP_TRY(ctx, hipMalloc((void**)&dd, sizeof(MemberDesc)));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(dd, &md, sizeof(md), hipMemcpyHostToDevice, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    TablePtrs tp;
+    for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = nullptr;
+    tp.p[0] = eq->data(); tp.p[1] = m->tables[0]->data(); tp.p[2] = m->tables[1]->data();
+    hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)dd, tp, m->len, ctx->d_partials);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
+    int32_t s = fetch_results(ctx, 1, out);
+    (void)hipFree(dd);
+    jolt_table_free(ctx, eq);
+    return s;
+}
+
+extern "C" int32_t jolt_member_destroy(jolt_member* m) {
+    if (!m) return JOLT_OK;
+    jolt_ctx* ctx = m->ctx;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (jolt_table* t : m->tables) jolt_table_free(ctx, t);
+    for (jolt_table* t : m->e_out_cache) jolt_table_free(ctx, t);
+    for (jolt_table* t : m->e_in_cache) jolt_table_free(ctx, t);
+    if (m->d_desc) (void)hipFree(m->d_desc);
+    delete m;
+    return JOLT_OK;
+}

@@ -1,0 +1,82 @@
+// jolt_amd/csrc/ctx.hpp -- context, table and member objects behind the opaque C-ABI handles of include/jolt_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/jolt_hip.h"
+#include "field.cuh"
+
+using jolt::Fq;
+using jolt::Fr;
+
+static_assert(sizeof(Fr) == sizeof(jolt_fr_t), "Fr must be layout-compatible with jolt_fr_t");
+
+struct jolt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    std::string last_error;
+    // reduction scratch: per-block partial sums, final results (device) and their pinned host mirror
+    Fr* d_partials = nullptr;
+    size_t partials_cap = 0;  // in Fr
+    Fr* d_results = nullptr;
+    Fr* h_results = nullptr;  // pinned
+    size_t results_cap = 0;   // in Fr
+    void* d_desc_scratch = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+struct jolt_table {
+    jolt_ctx* ctx = nullptr;
+    Fr* buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    int cur = 0;
+    size_t len = 0;
+    Fr* data() const { return buf[cur]; }
+};
+
+#define JOLT_HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            if (ctx) (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            return e_ == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;                           \
+        }                                                                                             \
+    } while (0)
+
+#define JOLT_TRY(expr)                     \
+    do {                                   \
+        int32_t s_ = (expr);               \
+        if (s_ != JOLT_OK) return s_;      \
+    } while (0)
+
+#define JOLT_REQUIRE(ctx, cond, msg)                            \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            if (ctx) (ctx)->last_error = (msg);                 \
+            return JOLT_ERR_INVALID_ARG;                        \
+        }                                                       \
+    } while (0)
+
+static inline Fr fr_from_abi(const jolt_fr_t* p) {
+    Fr r;
+    std::memcpy(&r, p, sizeof(Fr));
+    return r;
+}
+static inline void fr_to_abi(jolt_fr_t* p, const Fr& v) { std::memcpy(p, &v, sizeof(Fr)); }
+static inline bool fr_low_limbs_zero(const Fr& v) { return (v.l[0] | v.l[1] | v.l[2] | v.l[3]) == 0; }
+static inline bool fr_is_canonical(const Fr& v) {
+    Fr d;
+    return jolt::sub_p(d, v) != 0;
+}
+
+// internal helpers implemented in capi.hip
+int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t results);
+int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out);
+int32_t jolt_internal_table_ensure_alt(jolt_table* t, size_t need);

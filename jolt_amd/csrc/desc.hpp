@@ -1,0 +1,32 @@
+// jolt_amd/csrc/desc.hpp -- plain descriptor structs shared by the kernels (device) and the member objects (host).
+#pragma once
+#include "field.cuh"
+
+namespace jolt {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBatchTables = 40;
+constexpr int kMaxGroups = 16;
+constexpr int kMaxFactors = 64;
+constexpr int kMaxLc = 96;
+
+// Device-resident descriptor (read through the scalar cache: every access is wave-uniform).
+struct MemberDesc {
+    uint32_t n_groups;
+    uint32_t n_factors;
+    uint32_t n_lc;
+    uint32_t grp_fac_off[kMaxGroups + 1];
+    uint32_t fac_lc_off[kMaxFactors + 1];
+    uint32_t fac_has_const[kMaxFactors];
+    uint32_t lc_tab[kMaxLc];
+    uint32_t lc_one[kMaxLc];  // coefficient == 1 -> skip the multiply
+    Fr fac_const[kMaxFactors];
+    Fr lc_coeff[kMaxLc];
+};
+// current evaluation buffers of the member's tables (they ping-pong on every LowToHigh bind), passed by value
+struct TablePtrs {
+    const Fr* p[kMaxBatchTables];
+};
+
+
+}  // namespace jolt

@@ -1,0 +1,230 @@
+// jolt_amd/csrc/field.cuh -- BN254 Fr / Fq arithmetic for gfx950 (and for the host-side mirror code).
+//
+// Representation: 8 x u32 little-endian limbs holding a*R mod p, R = 2^256, always canonical (< p).  The bytes are
+// identical to the reference's `Fr` (4 x u64 Montgomery limbs, crates/jolt-field/src/bn254/mod.rs:33-43), so tables
+// cross the C ABI without conversion.  The products are built from v_mad_u64_u32 (32x32+64 -> 64): CDNA4 has no
+// 64x64 multiplier, and no MFMA is used anywhere (integer prime-field work, not a dense contraction).
+//
+// Replaces: Fr add/sub/mul/neg (crates/jolt-field/src/bn254/mod.rs:76-83 -> ark-ff Fp), the Montgomery REDC
+// (crates/jolt-field/src/bn254/mont.rs:186-238) and Fq for G1 coordinates (crates/jolt-crypto/src/ec/bn254/mod.rs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bn254_constants.cuh"
+
+#define JOLT_HD __host__ __device__ __forceinline__
+
+namespace jolt {
+
+struct FrParams {
+    static constexpr uint32_t P[8] = FR32_P_LIMBS;
+    static constexpr uint32_t R[8] = FR32_R_LIMBS;    // Montgomery one
+    static constexpr uint32_t R2[8] = FR32_R2_LIMBS;  // R^2 mod p
+    static constexpr uint32_t INV = FR32_INV;         // -p^-1 mod 2^32
+};
+struct FqParams {
+    static constexpr uint32_t P[8] = FQ32_P_LIMBS;
+    static constexpr uint32_t R[8] = FQ32_R_LIMBS;
+    static constexpr uint32_t R2[8] = FQ32_R2_LIMBS;
+    static constexpr uint32_t INV = FQ32_INV;
+};
+
+template <class PR>
+struct alignas(16) Fp {
+    uint32_t l[8];
+
+    static JOLT_HD Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.l[i] = 0;
+        return r;
+    }
+    static JOLT_HD Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.l[i] = PR::R[i];
+        return r;
+    }
+    static JOLT_HD Fp r2() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.l[i] = PR::R2[i];
+        return r;
+    }
+    JOLT_HD bool is_zero() const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc |= l[i];
+        return acc == 0;
+    }
+    JOLT_HD bool operator==(const Fp& o) const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc |= l[i] ^ o.l[i];
+        return acc == 0;
+    }
+    JOLT_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+};
+
+// ---- 256-bit helpers ------------------------------------------------------------------------------------
+// Carries go through __builtin_addc/__builtin_subc so that hipcc emits v_add_co/v_addc_co chains.
+template <class PR>
+JOLT_HD uint32_t add256(Fp<PR>& r, const Fp<PR>& a, const Fp<PR>& b) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = __builtin_addc(a.l[i], b.l[i], c, &c);
+    return c;
+}
+// r = a - b, returns borrow-out (0/1)
+template <class PR>
+JOLT_HD uint32_t sub256(Fp<PR>& r, const Fp<PR>& a, const Fp<PR>& b) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = __builtin_subc(a.l[i], b.l[i], c, &c);
+    return c;
+}
+// r = a - P, returns borrow (1 iff a < P)
+template <class PR>
+JOLT_HD uint32_t sub_p(Fp<PR>& r, const Fp<PR>& a) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = __builtin_subc(a.l[i], (uint32_t)PR::P[i], c, &c);
+    return c;
+}
+// branch-free select (per limb v_cndmask)
+template <class PR>
+JOLT_HD Fp<PR> select(bool take_a, const Fp<PR>& a, const Fp<PR>& b) {
+    Fp<PR> r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = take_a ? a.l[i] : b.l[i];
+    return r;
+}
+// canonicalise a value known to be < 2P (carry = bit 256 of the value)
+template <class PR>
+JOLT_HD Fp<PR> reduce_once(const Fp<PR>& a, uint32_t carry = 0) {
+    Fp<PR> d;
+    uint32_t borrow = sub_p(d, a);
+    return select(carry == 0 && borrow != 0, a, d);
+}
+
+template <class PR>
+JOLT_HD Fp<PR> add(const Fp<PR>& a, const Fp<PR>& b) {
+    Fp<PR> s;
+    (void)add256(s, a, b);  // both moduli leave >= 2 spare bits in 256: the sum never carries out
+    return reduce_once(s);
+}
+template <class PR>
+JOLT_HD Fp<PR> sub(const Fp<PR>& a, const Fp<PR>& b) {
+    Fp<PR> d, e;
+    uint32_t borrow = sub256(d, a, b);
+    uint32_t mask = 0u - borrow;  // add P back when a < b
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e.l[i] = __builtin_addc(d.l[i], (uint32_t)PR::P[i] & mask, c, &c);
+    return e;
+}
+template <class PR>
+JOLT_HD Fp<PR> neg(const Fp<PR>& a) {
+    Fp<PR> z = Fp<PR>::zero();
+    return sub(z, a);
+}
+template <class PR>
+JOLT_HD Fp<PR> dbl(const Fp<PR>& a) { return add(a, a); }
+
+// ---- Montgomery multiplication ------------------------------------------------------------------------------
+// CIOS over 32-bit limbs, arranged so that each row is 8 independent v_mad_u64_u32 (a_j*b_i + t_j, which cannot
+// overflow 64 bits) followed by ONE v_addc carry chain that shifts the high halves up a limb; the reduction row
+// (m*P_j + u_j) has the same shape.  NROWS = 8 is a full multiplication; NROWS = 4 serves operands whose four low
+// limbs are zero (see mul_shifted).
+template <class PR, int NROWS>
+JOLT_HD Fp<PR> mont_rows(const Fp<PR>& a, const uint32_t* b) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        uint64_t p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = (uint64_t)a.l[j] * b[i] + t[j];
+        uint32_t c = 0, u[10];
+        u[0] = (uint32_t)p[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) u[j] = __builtin_addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c, &c);
+        u[8] = __builtin_addc(t[8], (uint32_t)(p[7] >> 32), c, &c);
+        u[9] = c;
+        uint32_t m = u[0] * PR::INV;
+        uint64_t q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = (uint64_t)m * (uint32_t)PR::P[j] + u[j];
+        c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t[j - 1] = __builtin_addc((uint32_t)q[j], (uint32_t)(q[j - 1] >> 32), c, &c);
+        t[7] = __builtin_addc(u[8], (uint32_t)(q[7] >> 32), c, &c);
+        t[8] = u[9] + c;
+    }
+    Fp<PR> r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = t[i];
+    return reduce_once(r, t[8]);
+}
+
+template <class PR>
+JOLT_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) { return mont_rows<PR, 8>(a, b.l); }
+template <class PR>
+JOLT_HD Fp<PR> sqr(const Fp<PR>& a) { return mul(a, a); }
+
+// a * c where c's Montgomery representation has its four low u32 limbs equal to zero -- the shape of every
+// sumcheck challenge (crates/jolt-field/src/bn254/mod.rs:172-184,254: limbs [0,0,low,high]).
+// With c = c' * 2^128:  a*c*2^-256 = a*c'*2^-128, so only an 8x4 product and FOUR reduction rows are needed:
+// half the multiplies of `mul`, same canonical result.  `chi` = the four high limbs of c.
+template <class PR>
+JOLT_HD Fp<PR> mul_shifted(const Fp<PR>& a, const uint32_t chi[4]) { return mont_rows<PR, 4>(a, chi); }
+
+// Montgomery form -> canonical integer (REDC of the bare limbs) and back
+template <class PR>
+JOLT_HD Fp<PR> from_mont(const Fp<PR>& a) {
+    Fp<PR> one_int = Fp<PR>::zero();
+    one_int.l[0] = 1;
+    return mul(a, one_int);
+}
+template <class PR>
+JOLT_HD Fp<PR> to_mont(const Fp<PR>& a) { return mul(a, Fp<PR>::r2()); }
+
+// a^e, e a canonical 256-bit integer (host-side use: inversions in round-message assembly)
+template <class PR>
+JOLT_HD Fp<PR> pow(const Fp<PR>& a, const uint32_t e[8]) {
+    Fp<PR> acc = Fp<PR>::one();
+    for (int i = 255; i >= 0; --i) {
+        acc = sqr(acc);
+        if ((e[i / 32] >> (i % 32)) & 1) acc = mul(acc, a);
+    }
+    return acc;
+}
+// Fermat inverse; zero maps to zero (the reference returns None: callers check is_zero first)
+template <class PR>
+JOLT_HD Fp<PR> inv(const Fp<PR>& a) {
+    uint32_t e[8];
+    // p - 2
+    int64_t c = -2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (int64_t)PR::P[i];
+        e[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return pow(a, e);
+}
+
+using Fr = Fp<FrParams>;
+using Fq = Fp<FqParams>;
+
+// small-integer -> Fr (Montgomery form): crates/jolt-field/src/bn254/mont.rs:307-315 (value == ark Fr::from(n))
+JOLT_HD Fr fr_from_u64(uint64_t n) {
+    Fr v = Fr::zero();
+    v.l[0] = (uint32_t)n;
+    v.l[1] = (uint32_t)(n >> 32);
+    return to_mont(v);
+}
+
+}  // namespace jolt

@@ -1,0 +1,420 @@
+// jolt_amd/csrc/host_mirror.hip -- implementation of host_mirror.hpp and of the jolt_host_* exports (sumcheck side).
+#include "host_mirror.hpp"
+
+#include "member.hpp"
+
+using namespace jolt;
+
+namespace jolt_host {
+
+// ---- field helpers -------------------------------------------------------------------------------------------
+Fr fr_mul_pow_2(Fr a, size_t k) {
+    for (size_t i = 0; i < k; ++i) a = add(a, a);
+    return a;
+}
+void fr_to_bytes_le(const Fr& a, uint8_t out[32]) {
+    Fr c = from_mont(a);
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(c.l[i] >> (8 * j));
+}
+// crates/jolt-field/src/bn254/mod.rs:171-184,254: masked 125-bit value placed raw in the two high u64 limbs
+Fr fr_from_challenge_bytes(const uint8_t* b, size_t n) {
+    uint8_t buf[16] = {0};
+    std::memcpy(buf, b, n < 16 ? n : 16);
+    Fr r = Fr::zero();
+    for (int i = 0; i < 4; ++i) {
+        uint32_t w = 0;
+        for (int j = 3; j >= 0; --j) w = (w << 8) | buf[4 * i + j];
+        r.l[4 + i] = w;
+    }
+    r.l[7] &= 0x1FFFFFFFu;  // top 3 bits of the high u64 limb cleared
+    return r;
+}
+// mod.rs:188-193: big-endian integer of the bytes, reduced mod r
+Fr fr_from_scalar_challenge_bytes(const uint8_t* b, size_t n) {
+    Fr acc = Fr::zero();
+    Fr base = fr_from_u64(256);
+    for (size_t i = 0; i < n; ++i) acc = add(mul(acc, base), fr_from_u64(b[i]));
+    return acc;
+}
+
+// ---- UnivariatePoly ------------------------------------------------------------------------------------------
+UnivariatePoly UnivariatePoly::from_evals(const Fr* evals, size_t n) {
+    // unique interpolant through (0,e0)..(n-1,e_{n-1}); the reference solves the Vandermonde system
+    // (univariate.rs:198-202), here Newton's forward differences followed by basis expansion.
+    std::vector<Fr> d(evals, evals + n);
+    for (size_t k = 1; k < n; ++k) {
+        Fr kinv = inv(fr_from_u64(k));
+        for (size_t i = n - 1; i >= k; --i) d[i] = mul(sub(d[i], d[i - 1]), kinv);
+    }
+    std::vector<Fr> c(n, Fr::zero()), basis(1, Fr::one());
+    for (size_t k = 0; k < n; ++k) {
+        for (size_t i = 0; i < basis.size(); ++i) c[i] = add(c[i], mul(d[k], basis[i]));
+        if (k + 1 < n) {
+            Fr kf = fr_from_u64(k);
+            std::vector<Fr> nb(basis.size() + 1, Fr::zero());
+            for (size_t i = 0; i < basis.size(); ++i) {
+                nb[i + 1] = add(nb[i + 1], basis[i]);
+                nb[i] = sub(nb[i], mul(basis[i], kf));
+            }
+            basis.swap(nb);
+        }
+    }
+    UnivariatePoly p;
+    p.coefficients = std::move(c);
+    return p;
+}
+Fr UnivariatePoly::evaluate(const Fr& x) const {
+    Fr acc = Fr::zero();
+    for (size_t i = coefficients.size(); i-- > 0;) acc = add(mul(acc, x), coefficients[i]);
+    return acc;
+}
+size_t UnivariatePoly::degree() const { return coefficients.empty() ? 0 : coefficients.size() - 1; }
+
+// split_eq.rs:383-417
+int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& q_constant, const Fr& q_quadratic, const Fr& s0_plus_s1,
+                         UnivariatePoly* out) {
+    Fr eq1 = mul(current_scalar, point_i);
+    Fr eq0 = sub(current_scalar, eq1);
+    Fr eqm = sub(eq1, eq0);
+    Fr eq2 = add(eq1, eqm);
+    Fr eq3 = add(eq2, eqm);
+    Fr cubic0 = mul(eq0, q_constant);
+    Fr cubic1 = sub(s0_plus_s1, cubic0);
+    if (eq1.is_zero()) return JOLT_ERR_NOT_INVERTIBLE;
+    Fr quad1 = mul(cubic1, inv(eq1));
+    Fr e2 = add(q_quadratic, q_quadratic);
+    Fr quad2 = add(sub(add(quad1, quad1), q_constant), e2);
+    Fr quad3 = add(add(sub(add(quad2, quad1), q_constant), e2), e2);
+    Fr evals[4] = {cubic0, cubic1, mul(eq2, quad2), mul(eq3, quad3)};
+    *out = UnivariatePoly::from_evals(evals, 4);  // interpolate_over_integers: same unique cubic
+    return JOLT_OK;
+}
+
+// ---- transcript ----------------------------------------------------------------------------------------------
+void Transcript::append_fr(const Fr& v) {
+    uint8_t b[32];
+    fr_to_bytes_le(v, b);
+    append_bytes(b, 32);
+}
+static inline uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+MockTranscript::MockTranscript(uint64_t label) {
+    s[0] = 0x6a09e667f3bcc908ull ^ label;
+    s[1] = 0xbb67ae8584caa73bull;
+    s[2] = 0x3c6ef372fe94f82bull;
+    s[3] = 0xa54ff53a5f1d36f1ull;
+}
+void MockTranscript::absorb_word(uint64_t w) {
+    s[0] = mix64(s[0] ^ w);
+    s[1] = mix64(s[1] + s[0]);
+    s[2] ^= (s[1] << 23) | (s[1] >> 41);
+    s[3] = mix64(s[3] ^ s[2] ^ w);
+}
+void MockTranscript::append_bytes(const uint8_t* b, size_t n) {
+    absorb_word((uint64_t)n);
+    for (size_t i = 0; i < n; i += 8) {
+        uint64_t w = 0;
+        for (size_t j = 0; j < 8 && i + j < n; ++j) w |= (uint64_t)b[i + j] << (8 * j);
+        absorb_word(w);
+    }
+}
+void MockTranscript::draw16(uint8_t out[16]) {
+    absorb_word(0xC4A11E46Eull);
+    uint64_t lo = mix64(s[0] ^ s[2]);
+    uint64_t hi = mix64(s[1] ^ s[3]);
+    absorb_word(lo ^ hi);
+    for (int i = 0; i < 8; ++i) { out[i] = (uint8_t)(lo >> (8 * i)); out[8 + i] = (uint8_t)(hi >> (8 * i)); }
+}
+Fr MockTranscript::challenge() {
+    uint8_t b[16];
+    draw16(b);
+    return fr_from_challenge_bytes(b, 16);
+}
+Fr MockTranscript::challenge_scalar() {
+    uint8_t b[16];
+    draw16(b);
+    return fr_from_scalar_challenge_bytes(b, 16);
+}
+
+// ---- DeviceMember --------------------------------------------------------------------------------------------
+size_t DeviceMember::num_rounds() const { return m->rounds; }
+size_t DeviceMember::n_evals() const { return jolt_internal_member_n_evals(m); }
+
+int32_t DeviceMember::assemble(const Fr* evals, const Fr& previous_claim, UnivariatePoly* out) const {
+    if (m->kind == jolt_member::kSplitEqProduct) {
+        // ram_hamming_booleanity.rs:128-135: message = gruen_poly_deg_3(q(0), q(inf), previous_claim)
+        size_t current_index = m->rounds - m->bound;
+        return gruen_poly_deg_3(m->current_scalar, m->w[current_index - 1], evals[0], evals[1], previous_claim, out);
+    }
+    std::vector<Fr> full;
+    if (m->skip_one) {
+        // support.rs:450-459 round_poly_from_skipped_evals
+        full.push_back(evals[0]);
+        full.push_back(sub(previous_claim, evals[0]));
+        for (uint32_t t = 1; t < m->degree; ++t) full.push_back(evals[t]);
+    } else {
+        full.assign(evals, evals + m->degree + 1);
+        // naive.rs:298-306 round check
+        if (add(full[0], full[1]) != previous_claim) return JOLT_ERR_ROUND_CHECK;
+    }
+    *out = UnivariatePoly::from_evals(full.data(), full.size());
+    return JOLT_OK;
+}
+
+int32_t DeviceMember::prove_round(const Fr* bind, size_t /*round*/, const Fr& previous_claim, UnivariatePoly* out) {
+    jolt_fr_t evals[JOLT_MAX_DEGREE + 1];
+    jolt_fr_t b;
+    if (bind) fr_to_abi(&b, *bind);
+    JOLT_TRY(jolt_member_prove_round(m, bind ? &b : nullptr, evals, n_evals(), nullptr));
+    Fr ev[JOLT_MAX_DEGREE + 1];
+    for (size_t i = 0; i < n_evals(); ++i) ev[i] = fr_from_abi(&evals[i]);
+    return assemble(ev, previous_claim, out);
+}
+int32_t DeviceMember::finish_rounds(const Fr& bind) {
+    jolt_fr_t b;
+    fr_to_abi(&b, bind);
+    return jolt_member_finish(m, &b);
+}
+
+// ---- schedulers ----------------------------------------------------------------------------------------------
+int32_t SequentialRounds::batch_prove_round(std::vector<MemberRound>& work) {
+    for (MemberRound& item : work) {
+        JOLT_TRY(item.member->prove_round(item.has_bind ? &item.bind : nullptr, item.local_round, item.claim, &item.message));
+        item.has_message = true;
+    }
+    return JOLT_OK;
+}
+int32_t SequentialRounds::batch_finish_rounds(std::vector<MemberFinish>& finishes) {
+    for (MemberFinish& f : finishes) JOLT_TRY(f.member->finish_rounds(f.bind));
+    return JOLT_OK;
+}
+
+int32_t DeviceGroupedRounds::batch_prove_round(std::vector<MemberRound>& work) {
+    std::vector<jolt_member*> ms;
+    std::vector<jolt_fr_t> bind_store(work.size());
+    std::vector<const jolt_fr_t*> binds;
+    size_t total = 0;
+    for (size_t i = 0; i < work.size(); ++i) {
+        DeviceMember* dm = dynamic_cast<DeviceMember*>(work[i].member);
+        if (!dm) return JOLT_ERR_UNSUPPORTED;  // mixed host/device batches go through SequentialRounds
+        ms.push_back(dm->m);
+        if (work[i].has_bind) { fr_to_abi(&bind_store[i], work[i].bind); binds.push_back(&bind_store[i]); }
+        else binds.push_back(nullptr);
+        total += dm->n_evals();
+    }
+    std::vector<jolt_fr_t> evals(total ? total : 1);
+    JOLT_TRY(jolt_round_group_prove(ctx, ms.data(), ms.size(), binds.data(), evals.data(), evals.size()));
+    size_t off = 0;
+    for (size_t i = 0; i < work.size(); ++i) {
+        DeviceMember* dm = static_cast<DeviceMember*>(work[i].member);
+        Fr ev[JOLT_MAX_DEGREE + 1];
+        for (size_t k = 0; k < dm->n_evals(); ++k) ev[k] = fr_from_abi(&evals[off + k]);
+        off += dm->n_evals();
+        JOLT_TRY(dm->assemble(ev, work[i].claim, &work[i].message));
+        work[i].has_message = true;
+    }
+    return JOLT_OK;
+}
+int32_t DeviceGroupedRounds::batch_finish_rounds(std::vector<MemberFinish>& finishes) {
+    for (MemberFinish& f : finishes) JOLT_TRY(f.member->finish_rounds(f.bind));
+    return JOLT_OK;
+}
+
+// ---- prove_batch ---------------------------------------------------------------------------------------------
+BatchPrelude BatchPrelude::make(std::vector<BatchMember> members, size_t max_num_vars, size_t max_degree) {
+    BatchPrelude p;
+    Fr sum = Fr::zero();
+    for (const BatchMember& m : members) sum = add(sum, mul(m.coefficient, fr_mul_pow_2(m.input_claim, max_num_vars - m.rounds)));  // batch.rs:57-64
+    p.members = std::move(members);
+    p.claimed_sum = sum;
+    p.max_num_vars = max_num_vars;
+    p.max_degree = max_degree;
+    return p;
+}
+
+int32_t prove_batch(const BatchPrelude& prelude, std::vector<ProveRounds*>& members, RoundScheduler& scheduler, Transcript& transcript,
+                    bool full_width_challenges, ProvedBatch* out, SumcheckError* err) {
+    auto fail = [&](int32_t s, size_t round) { if (err) { err->status = s; err->round = round; } return s; };
+    if (members.size() != prelude.members.size()) return fail(JOLT_ERR_SIZE_MISMATCH, 0);  // BatchMemberCountMismatch
+    for (size_t i = 0; i < members.size(); ++i) {
+        if (members[i]->num_rounds() != prelude.members[i].rounds) return fail(JOLT_ERR_SIZE_MISMATCH, 0);            // BatchMemberRoundsMismatch
+        if (prelude.members[i].offset + prelude.members[i].rounds > prelude.max_num_vars) return fail(JOLT_ERR_INVALID_ARG, 0);  // WindowOutOfRange
+    }
+    const size_t max_num_vars = prelude.max_num_vars;
+    if (max_num_vars > 0 && prelude.max_degree < 1) return fail(JOLT_ERR_INVALID_ARG, 0);  // ZeroBatchDegree
+    const Fr two_inv = inv(fr_from_u64(2));
+    std::vector<Fr> member_claims;
+    for (const BatchMember& m : prelude.members) member_claims.push_back(fr_mul_pow_2(m.input_claim, max_num_vars - m.rounds));  // prover.rs:244-248
+    Fr running_claim = prelude.claimed_sum;
+    std::vector<Fr> challenges;
+    std::vector<bool> has_pending(members.size(), false);
+    std::vector<Fr> pending(members.size(), Fr::zero());
+    out->round_polys.clear();
+
+    for (size_t round = 0; round < max_num_vars; ++round) {
+        std::vector<Fr> batched(prelude.max_degree + 1, Fr::zero());
+        std::vector<MemberRound> work;
+        for (size_t index = 0; index < members.size(); ++index) {
+            const BatchMember& described = prelude.members[index];
+            bool active = round >= described.offset && round < described.offset + described.rounds;
+            if (!active) {  // prover.rs:273-282
+                member_claims[index] = mul(member_claims[index], two_inv);
+                batched[0] = add(batched[0], mul(described.coefficient, member_claims[index]));
+                continue;
+            }
+            MemberRound mr;
+            mr.index = index;
+            mr.local_round = round - described.offset;
+            mr.has_bind = has_pending[index];
+            mr.bind = pending[index];
+            has_pending[index] = false;
+            mr.claim = member_claims[index];
+            mr.member = members[index];
+            mr.has_message = false;
+            work.push_back(std::move(mr));
+        }
+        int32_t s = scheduler.batch_prove_round(work);
+        if (s != JOLT_OK) return fail(s, round);
+        for (const MemberRound& item : work) {
+            if (!item.has_message) return fail(JOLT_ERR_INVALID_ARG, round);                                // MissingRoundMessage
+            if (item.message.degree() > prelude.max_degree) return fail(JOLT_ERR_UNSUPPORTED, round);       // DegreeBoundExceeded
+            const BatchMember& described = prelude.members[item.index];
+            for (size_t k = 0; k < item.message.coefficients.size(); ++k)
+                batched[k] = add(batched[k], mul(described.coefficient, item.message.coefficients[k]));
+        }
+        // trim_round_polynomial (prover.rs:168-177)
+        while (batched.size() > 2 && batched.back().is_zero()) batched.pop_back();
+        UnivariatePoly batched_poly;
+        batched_poly.coefficients = batched;
+        Fr round_sum = add(batched_poly.evaluate(Fr::zero()), batched_poly.evaluate(Fr::one()));
+        if (round_sum != running_claim) return fail(JOLT_ERR_ROUND_CHECK, round);  // prover.rs:316-324
+        // ClearSumcheckRecorder::absorb_round (recorder.rs:118-130): compressed poly (linear term omitted), then challenge
+        transcript.append_fr(batched_poly.coefficients[0]);
+        for (size_t k = 2; k < batched_poly.coefficients.size(); ++k) transcript.append_fr(batched_poly.coefficients[k]);
+        Fr challenge = full_width_challenges ? transcript.challenge_scalar() : transcript.challenge();
+        running_claim = batched_poly.evaluate(challenge);
+        challenges.push_back(challenge);
+        out->round_polys.push_back(batched_poly);
+        for (const MemberRound& item : work) {
+            member_claims[item.index] = item.message.evaluate(challenge);
+            pending[item.index] = challenge;
+            has_pending[item.index] = true;
+        }
+    }
+    std::vector<MemberFinish> finishes;  // prover.rs:343-355
+    for (size_t i = 0; i < members.size(); ++i)
+        if (has_pending[i]) finishes.push_back(MemberFinish{pending[i], members[i]});
+    int32_t s = scheduler.batch_finish_rounds(finishes);
+    if (s != JOLT_OK) return fail(s, max_num_vars);
+    out->challenges = std::move(challenges);
+    out->final_claim = running_claim;
+    out->member_claims = std::move(member_claims);
+    return JOLT_OK;
+}
+
+}  // namespace jolt_host
+
+// ------------------------------------------------------------------------------------------------------------------
+// C exports
+// ------------------------------------------------------------------------------------------------------------------
+using namespace jolt_host;
+
+extern "C" int32_t jolt_host_fr_mul(const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
+    if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
+    fr_to_abi(out, mul(fr_from_abi(a), fr_from_abi(b)));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_fr_add(const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
+    if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
+    fr_to_abi(out, add(fr_from_abi(a), fr_from_abi(b)));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_fr_sub(const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
+    if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
+    fr_to_abi(out, sub(fr_from_abi(a), fr_from_abi(b)));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_fr_inv(const jolt_fr_t* a, jolt_fr_t* out) {
+    if (!a || !out) return JOLT_ERR_INVALID_ARG;
+    Fr v = fr_from_abi(a);
+    if (v.is_zero()) return JOLT_ERR_NOT_INVERTIBLE;
+    fr_to_abi(out, inv(v));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_fr_from_u64(uint64_t v, jolt_fr_t* out) {
+    if (!out) return JOLT_ERR_INVALID_ARG;
+    fr_to_abi(out, fr_from_u64(v));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_fr_mul_shifted(const jolt_fr_t* a, const jolt_fr_t* c, jolt_fr_t* out) {
+    if (!a || !c || !out) return JOLT_ERR_INVALID_ARG;
+    Fr cc = fr_from_abi(c);
+    if (!fr_low_limbs_zero(cc)) return JOLT_ERR_INVALID_ARG;
+    uint32_t chi[4] = {cc.l[4], cc.l[5], cc.l[6], cc.l[7]};
+    fr_to_abi(out, mul_shifted(fr_from_abi(a), chi));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_univariate_from_evals(const jolt_fr_t* evals, size_t n, jolt_fr_t* coeffs_out) {
+    if (!evals || !coeffs_out || n == 0 || n > 16) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> e(n);
+    for (size_t i = 0; i < n; ++i) e[i] = fr_from_abi(&evals[i]);
+    UnivariatePoly p = UnivariatePoly::from_evals(e.data(), n);
+    for (size_t i = 0; i < n; ++i) fr_to_abi(&coeffs_out[i], p.coefficients[i]);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_univariate_evaluate(const jolt_fr_t* coeffs, size_t n, const jolt_fr_t* x, jolt_fr_t* out) {
+    if (!coeffs || !x || !out) return JOLT_ERR_INVALID_ARG;
+    UnivariatePoly p;
+    for (size_t i = 0; i < n; ++i) p.coefficients.push_back(fr_from_abi(&coeffs[i]));
+    fr_to_abi(out, p.evaluate(fr_from_abi(x)));
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t* current_scalar, const jolt_fr_t* point_i, const jolt_fr_t* q_constant,
+                                              const jolt_fr_t* q_quadratic, const jolt_fr_t* s0_plus_s1, jolt_fr_t* coeffs_out) {
+    if (!current_scalar || !point_i || !q_constant || !q_quadratic || !s0_plus_s1 || !coeffs_out) return JOLT_ERR_INVALID_ARG;
+    UnivariatePoly p;
+    JOLT_TRY(gruen_poly_deg_3(fr_from_abi(current_scalar), fr_from_abi(point_i), fr_from_abi(q_constant), fr_from_abi(q_quadratic),
+                              fr_from_abi(s0_plus_s1), &p));
+    for (size_t i = 0; i < 4; ++i) fr_to_abi(&coeffs_out[i], p.coefficients[i]);
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_host_prove_batch(jolt_ctx* ctx, jolt_member* const* members, size_t n_members, const jolt_fr_t* input_claims,
+                                         const jolt_fr_t* coefficients, const size_t* offsets, size_t max_num_vars, size_t max_degree,
+                                         uint64_t transcript_label, int32_t challenge_mode, int32_t use_round_group, jolt_fr_t* out_polys,
+                                         jolt_fr_t* out_challenges, jolt_fr_t* out_member_claims, jolt_fr_t* out_final_claim) {
+    if (!ctx || (!members && n_members) || !input_claims || !coefficients || !offsets || !out_polys || !out_challenges || !out_member_claims ||
+        !out_final_claim)
+        return JOLT_ERR_INVALID_ARG;
+    std::vector<std::unique_ptr<DeviceMember>> owned;
+    std::vector<ProveRounds*> ms;
+    std::vector<BatchMember> described;
+    for (size_t i = 0; i < n_members; ++i) {
+        if (!members[i]) return JOLT_ERR_INVALID_ARG;
+        owned.emplace_back(new DeviceMember(members[i]));
+        ms.push_back(owned.back().get());
+        described.push_back(BatchMember{fr_from_abi(&input_claims[i]), fr_from_abi(&coefficients[i]), members[i]->rounds, offsets[i]});
+    }
+    BatchPrelude prelude = BatchPrelude::make(std::move(described), max_num_vars, max_degree);
+    MockTranscript tr(transcript_label);
+    SequentialRounds seq;
+    DeviceGroupedRounds grouped(ctx);
+    RoundScheduler& sched = use_round_group ? static_cast<RoundScheduler&>(grouped) : static_cast<RoundScheduler&>(seq);
+    ProvedBatch proved;
+    SumcheckError err;
+    JOLT_TRY(prove_batch(prelude, ms, sched, tr, challenge_mode != 0, &proved, &err));
+    const size_t stride = max_degree + 1;
+    Fr zero = Fr::zero();
+    for (size_t r = 0; r < max_num_vars; ++r)
+        for (size_t k = 0; k < stride; ++k)
+            fr_to_abi(&out_polys[r * stride + k], k < proved.round_polys[r].coefficients.size() ? proved.round_polys[r].coefficients[k] : zero);
+    for (size_t r = 0; r < max_num_vars; ++r) fr_to_abi(&out_challenges[r], proved.challenges[r]);
+    for (size_t i = 0; i < n_members; ++i) fr_to_abi(&out_member_claims[i], proved.member_claims[i]);
+    fr_to_abi(out_final_claim, proved.final_claim);
+    return JOLT_OK;
+}

@@ -1,0 +1,28 @@
+// jolt_amd/csrc/member.hpp -- the object behind `jolt_member*`: one sumcheck batch member with device-resident tables
+// (the device twin of Box<dyn SumcheckKernel>, crates/jolt-kernels/src/kernel.rs:72-126).
+#pragma once
+#include "ctx.hpp"
+#include "desc.hpp"
+
+struct jolt_member {
+    enum Kind { kExpr = 0, kSplitEqProduct = 1 };
+    jolt_ctx* ctx = nullptr;
+    int kind = kExpr;
+    size_t rounds = 0, bound = 0;
+    size_t len = 0;  // current table length
+    uint32_t degree = 0;
+    int32_t order = JOLT_ORDER_LOW_TO_HIGH;
+    bool skip_one = false;
+    std::vector<jolt_table*> tables;  // owned
+    jolt::MemberDesc desc;            // host copy
+    jolt::MemberDesc* d_desc = nullptr;
+    // split-eq state (GruenSplitEqPolynomial, crates/jolt-poly/src/split_eq.rs:159-166)
+    std::vector<Fr> w;
+    Fr current_scalar;
+    size_t out_len = 0, in_len = 0;        // lengths of out_point / in_point
+    size_t e_out_bits = 0, e_in_bits = 0;  // prefix lengths of the CURRENT E_out / E_in tables
+    std::vector<jolt_table*> e_out_cache, e_in_cache;  // evals_cached: index j = eq over the first j coordinates
+};
+
+size_t jolt_internal_member_n_evals(const jolt_member* m);
+int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r, int32_t order);

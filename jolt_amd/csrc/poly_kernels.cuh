@@ -1,0 +1,219 @@
+// jolt_amd/csrc/poly_kernels.cuh -- dense-table kernels: bind, eq/LT/eq+1 expansion, small-scalar promotion, sums.
+//
+// Layout in HBM: a table is a contiguous array of 32-byte Fr (the reference's Vec<Fr>), index = big-endian boolean
+// point.  All of these kernels are HBM-bandwidth bound (1 Fr multiply per 96 B for bind) -- no MFMA, no GEMM shape.
+#pragma once
+#include "desc.hpp"
+
+namespace jolt {
+
+__device__ __forceinline__ Fr ld_fr(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// lo + r*(hi - lo); SHIFTED = r has its four low limbs zero (the 125-bit challenge shape) -> half the multiplies
+template <bool SHIFTED>
+__device__ __forceinline__ Fr bind_pair(const Fr& lo, const Fr& hi, const Fr& r) {
+    Fr d = sub(hi, lo);
+    Fr m;
+    if constexpr (SHIFTED) {
+        uint32_t chi[4] = {r.l[4], r.l[5], r.l[6], r.l[7]};
+        m = mul_shifted(d, chi);
+    } else {
+        m = mul(d, r);
+    }
+    return add(lo, m);
+}
+
+struct BindBatch {
+    const Fr* in[kMaxBatchTables];
+    Fr* out[kMaxBatchTables];
+};
+
+// Polynomial::bind_low_to_high (crates/jolt-poly/src/dense.rs:223-303) for blockIdx.y-many tables in one launch:
+// out[y] = in[2y] + r*(in[2y+1]-in[2y]).  Algorithmic traffic 96 B per output (64 read + 32 written).
+template <bool SHIFTED>
+__global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b, size_t half, Fr r) {
+    const Fr* __restrict__ in = b.in[blockIdx.y];
+    Fr* __restrict__ out = b.out[blockIdx.y];
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t y = (size_t)blockIdx.x * kBlock + threadIdx.x; y < half; y += stride) {
+        Fr lo = ld_fr(in + 2 * y), hi = ld_fr(in + 2 * y + 1);
+        st_fr(out + y, bind_pair<SHIFTED>(lo, hi, r));
+    }
+}
+
+// Polynomial::bind_high_to_low (dense.rs:188-220): in place, t[i] += r*(t[i+half]-t[i])
+template <bool SHIFTED>
+__global__ __launch_bounds__(kBlock) void k_bind_high_to_low(BindBatch b, size_t half, Fr r) {
+    const Fr* __restrict__ in = b.in[blockIdx.y];
+    Fr* out = b.out[blockIdx.y];
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < half; i += stride) {
+        Fr lo = ld_fr(in + i), hi = ld_fr(in + i + half);
+        st_fr(out + i, bind_pair<SHIFTED>(lo, hi, r));
+    }
+}
+
+// One tensor step of EqPolynomial::evals (crates/jolt-poly/src/eq.rs:221-231, big-endian): with the table `prev`
+// over the first a variables already scaled, out[x] = prev[x >> c] * L[x & (2^c-1)], L = eq over the next c <= 8
+// variables (built per block in LDS).  Field multiplication is exact, so this tensor order gives the same entries as
+// the reference's layer-by-layer doubling; every entry costs one multiply and the kernel is write-bound.
+struct EqChunk {
+    Fr r[8];
+    int c;
+};
+__global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr* __restrict__ prev, Fr* __restrict__ out, size_t out_len, EqChunk ch) {
+    __shared__ Fr L[256];
+    const int c = ch.c;
+    if ((int)threadIdx.x < (1 << c)) {
+        Fr acc = Fr::one();
+        for (int k = 0; k < c; ++k) {
+            int bit = (threadIdx.x >> (c - 1 - k)) & 1;
+            Fr f = bit ? ch.r[k] : sub(Fr::one(), ch.r[k]);
+            acc = mul(acc, f);
+        }
+        L[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * kBlock;
+    size_t mask = ((size_t)1 << c) - 1;
+    for (size_t x = (size_t)blockIdx.x * kBlock + threadIdx.x; x < out_len; x += stride) {
+        Fr p = ld_fr(prev + (x >> c));
+        st_fr(out + x, mul(p, L[x & mask]));
+    }
+}
+
+// LtPolynomial::evaluations (crates/jolt-poly/src/lt.rs:144-156) by the split identity the reference itself states
+// (lt.rs:19-21): with r = r_hi || r_lo,  LT(j_hi||j_lo, r) = LT(j_hi, r_hi) + eq(j_hi, r_hi) * LT(j_lo, r_lo).
+// out[x] = lt_hi[x>>c] + eq_hi[x>>c] * lt_lo[x & mask]; lt_lo (<= 256 entries) is built per block in LDS from
+// the closed form sum_i (1-x_i) r_i eq(x[..i], r[..i]) (lt.rs:126-137).
+__global__ __launch_bounds__(kBlock) void k_lt_expand(const Fr* __restrict__ lt_hi, const Fr* __restrict__ eq_hi, Fr* __restrict__ out,
+                                                     size_t out_len, EqChunk ch) {
+    __shared__ Fr L[256];
+    const int c = ch.c;
+    if ((int)threadIdx.x < (1 << c)) {
+        Fr lt = Fr::zero(), pre = Fr::one();
+        for (int k = 0; k < c; ++k) {
+            int bit = (threadIdx.x >> (c - 1 - k)) & 1;
+            Fr rk = ch.r[k];
+            if (!bit) lt = add(lt, mul(rk, pre));  // (1 - x_k) r_k eq_prefix with x_k = 0
+            Fr f = bit ? rk : sub(Fr::one(), rk);
+            pre = mul(pre, f);
+        }
+        L[threadIdx.x] = lt;
+    }
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * kBlock;
+    size_t mask = ((size_t)1 << c) - 1;
+    for (size_t x = (size_t)blockIdx.x * kBlock + threadIdx.x; x < out_len; x += stride) {
+        Fr h = ld_fr(lt_hi + (x >> c)), e = ld_fr(eq_hi + (x >> c));
+        st_fr(out + x, add(h, mul(e, L[x & mask])));
+    }
+}
+
+// EqPlusOnePolynomial::evals (crates/jolt-poly/src/eq_plus_one.rs:71-130): eq+1(r, j) is nonzero only through the
+// decomposition j = (prefix, 1, 0...0) with k trailing zeros:  eq+1[j] = eq(r[..i], prefix) * (1-r[i]) * prod_{m>i} r[m],
+// i = n-1-k.  `eq_prefix_tables` is not materialised: eq(r[..i], prefix) = eq_full[j - 2^k] / ... is avoided by using
+// the identity eq(r[..i],prefix) = sum over the cleared suffix, i.e. eq_full[j] / (r[i] * prod_{m>i}(1-r[m])) is NOT
+// used either (no division): instead the host passes suffix products and the kernel multiplies the prefix eq taken
+// from a strided read of the eq table over the first i variables (prefix_tables[i]).
+struct EqP1Args {
+    const Fr* prefix[33];  // prefix[i] = eq table over r[..i] (2^i entries), i = 0..n-1
+    Fr lower[32];          // lower[i] = (1 - r[i]) * prod_{m>i} r[m]
+    int n;
+};
+__global__ __launch_bounds__(kBlock) void k_eq_plus_one(EqP1Args a, Fr* __restrict__ out, size_t out_len) {
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < out_len; j += stride) {
+        if (j == 0) { st_fr(out, Fr::zero()); continue; }
+        int k = __builtin_ctzll((unsigned long long)j);  // trailing zeros
+        int i = a.n - 1 - k;
+        Fr e = ld_fr(a.prefix[i] + (j >> (k + 1)));
+        st_fr(out + j, mul(e, a.lower[i]));
+    }
+}
+
+// Ring::from_u64 / from_i64 per entry (crates/jolt-field/src/bn254/mod.rs:265-278): Montgomery form of the integer
+__global__ __launch_bounds__(kBlock) void k_from_u64(const uint64_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) st_fr(out + i, fr_from_u64(in[i]));
+}
+__global__ __launch_bounds__(kBlock) void k_from_i64(const int64_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        int64_t v = in[i];
+        uint64_t mag = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+        Fr m = fr_from_u64(mag);
+        st_fr(out + i, v < 0 ? neg(m) : m);
+    }
+}
+
+// ---- block-level reduction of NE field accumulators (wave64 shuffles, then LDS across the block's 4 waves) ----
+template <int NE>
+__device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict__ partials) {
+    __shared__ Fr sm[kBlock / 64][NE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int t = 0; t < NE; ++t) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.l[k] = __shfl_xor(acc[t].l[k], off, 64);
+            acc[t] = add(acc[t], o);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < NE; ++t) sm[wave][t] = acc[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < NE) {
+        Fr s = sm[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) s = add(s, sm[w][threadIdx.x]);
+        st_fr(partials + (size_t)blockIdx.x * NE + threadIdx.x, s);
+    }
+}
+
+// second stage: out[t] = sum_b partials[b*ne + t]   (one block)
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr* __restrict__ partials, int nblocks, int ne, Fr* __restrict__ out) {
+    __shared__ Fr sm[kBlock];
+    for (int t = 0; t < ne; ++t) {
+        Fr s = Fr::zero();
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) s = add(s, ld_fr(partials + (size_t)b * ne + t));
+        sm[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = kBlock / 2; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off) sm[threadIdx.x] = add(sm[threadIdx.x], sm[threadIdx.x + off]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) st_fr(out + t, sm[0]);
+        __syncthreads();
+    }
+}
+
+// sum of a table / dot product with a second table (Polynomial::evaluate = dot with the eq table, dense.rs:340-366)
+template <bool DOT>
+__global__ __launch_bounds__(kBlock) void k_sum_or_dot(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ partials) {
+    Fr acc[1] = {Fr::zero()};
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        Fr v = ld_fr(a + i);
+        if constexpr (DOT) v = mul(v, ld_fr(b + i));
+        acc[0] = add(acc[0], v);
+    }
+    block_reduce_store<1>(acc, partials);
+}
+
+}  // namespace jolt

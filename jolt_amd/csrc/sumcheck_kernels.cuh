@@ -1,0 +1,117 @@
+// jolt_amd/csrc/sumcheck_kernels.cuh -- round-polynomial accumulation kernels.
+//
+// One kernel family serves every dense sumcheck member.  The summand is held in "sum of products of linear
+// combinations" form
+//        summand(x) = sum_g  prod_{f in group g} ( const_f + sum_k coeff_k * table_k(x) )
+// which contains the reference tier's flat jolt_claims::Expr (every LC has one entry; crates/jolt-claims/src/claims.rs:
+// 17-46, evaluated as in crates/jolt-kernels/src/reference/naive.rs:241-310) and the optimized tier's fused forms
+// (linear-leaf fusion, crates/jolt-kernels/src/optimized/inc_claim_reduction.rs:68-89) as descriptor rewrites.
+// Because every LC is linear in the round variable, a factor's values at t = 0..NE-1 are lo + t*(hi - lo): the
+// multiplies per pair are (entries with coeff != 1)*2 for the LCs plus (factors-1)*NE for the products.
+//
+// Work is ALU-bound on v_mad_u64_u32 for all but the smallest summands; HBM traffic is 64 B per table per pair.
+#pragma once
+#include "desc.hpp"
+#include "poly_kernels.cuh"
+
+namespace jolt {
+
+// s(t) partial sums for t = 0..NE-1 (or, with SKIP1, for t in {0,2,3,..,NE}: slot k>=1 holds s(k+1) -- the
+// optimized tier's skipped-evals form, crates/jolt-kernels/src/optimized/support.rs:450-459).
+// ORDER 0: LowToHigh pairs (2y, 2y+1); ORDER 1: HighToLow pairs (y, y+half).
+template <int NE, int ORDER, bool SKIP1>
+__global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t half, Fr* __restrict__ partials) {
+    Fr acc[NE];
+#pragma unroll
+    for (int t = 0; t < NE; ++t) acc[t] = Fr::zero();
+    const uint32_t n_groups = d->n_groups;
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t y = (size_t)blockIdx.x * kBlock + threadIdx.x; y < half; y += stride) {
+        const size_t i_lo = ORDER == 0 ? 2 * y : y;
+        const size_t i_hi = ORDER == 0 ? 2 * y + 1 : y + half;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            Fr prod[NE];
+            const uint32_t f0 = d->grp_fac_off[g], f1 = d->grp_fac_off[g + 1];
+            for (uint32_t f = f0; f < f1; ++f) {
+                Fr lo, hi;
+                if (d->fac_has_const[f]) { lo = d->fac_const[f]; hi = lo; }
+                else { lo = Fr::zero(); hi = lo; }
+                const uint32_t k0 = d->fac_lc_off[f], k1 = d->fac_lc_off[f + 1];
+                for (uint32_t k = k0; k < k1; ++k) {
+                    const Fr* __restrict__ tp = tabs.p[d->lc_tab[k]];
+                    Fr a = ld_fr(tp + i_lo), b = ld_fr(tp + i_hi);
+                    if (!d->lc_one[k]) {
+                        Fr c = d->lc_coeff[k];
+                        a = mul(a, c);
+                        b = mul(b, c);
+                    }
+                    lo = add(lo, a);
+                    hi = add(hi, b);
+                }
+                Fr step = sub(hi, lo);
+                Fr v = lo;
+                if (f == f0) {
+                    prod[0] = v;
+                    if constexpr (SKIP1) v = add(v, step);
+#pragma unroll
+                    for (int t = 1; t < NE; ++t) { v = add(v, step); prod[t] = v; }
+                } else {
+                    prod[0] = mul(prod[0], v);
+                    if constexpr (SKIP1) v = add(v, step);
+#pragma unroll
+                    for (int t = 1; t < NE; ++t) { v = add(v, step); prod[t] = mul(prod[t], v); }
+                }
+            }
+            if (f1 == f0) {  // empty product: the constant one
+#pragma unroll
+                for (int t = 0; t < NE; ++t) prod[t] = Fr::one();
+            }
+#pragma unroll
+            for (int t = 0; t < NE; ++t) acc[t] = add(acc[t], prod[t]);
+        }
+    }
+    block_reduce_store<NE>(acc, partials);
+}
+
+// Split-eq product member (a6): q(0) = sum_rows E_out[x_out] E_in[x_in] a_lo b_lo,
+// q(inf) = sum_rows E_out E_in (a_hi-a_lo)(b_hi-b_lo), row = (x_out << in_bits) | x_in over LowToHigh pairs
+// (crates/jolt-kernels/src/optimized/support.rs:391-411 over crates/jolt-poly/src/split_eq.rs:449-512).
+// eq is never materialised at size N: E_out, E_in are ~sqrt(N) tables that stay cache-resident.
+__global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ e_out,
+                                                            const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials) {
+    Fr acc[2] = {Fr::zero(), Fr::zero()};
+    size_t stride = (size_t)gridDim.x * kBlock;
+    size_t mask = ((size_t)1 << in_bits) - 1;
+    for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
+        Fr e = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+        Fr a_lo = ld_fr(a + 2 * row), a_hi = ld_fr(a + 2 * row + 1);
+        Fr b_lo = ld_fr(b + 2 * row), b_hi = ld_fr(b + 2 * row + 1);
+        acc[0] = add(acc[0], mul(e, mul(a_lo, b_lo)));
+        acc[1] = add(acc[1], mul(e, mul(sub(a_hi, a_lo), sub(b_hi, b_lo))));
+    }
+    block_reduce_store<2>(acc, partials);
+}
+
+// summand summed over the whole hypercube (member input claim): same descriptor, no pairing
+__global__ __launch_bounds__(kBlock) void k_member_claim(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t len, Fr* __restrict__ partials) {
+    Fr acc[1] = {Fr::zero()};
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t x = (size_t)blockIdx.x * kBlock + threadIdx.x; x < len; x += stride) {
+        for (uint32_t g = 0; g < d->n_groups; ++g) {
+            Fr prod = Fr::one();
+            for (uint32_t f = d->grp_fac_off[g]; f < d->grp_fac_off[g + 1]; ++f) {
+                Fr v = d->fac_has_const[f] ? d->fac_const[f] : Fr::zero();
+                for (uint32_t k = d->fac_lc_off[f]; k < d->fac_lc_off[f + 1]; ++k) {
+                    Fr a = ld_fr(tabs.p[d->lc_tab[k]] + x);
+                    if (!d->lc_one[k]) a = mul(a, d->lc_coeff[k]);
+                    v = add(v, a);
+                }
+                prod = mul(prod, v);
+            }
+            acc[0] = add(acc[0], prod);
+        }
+    }
+    block_reduce_store<1>(acc, partials);
+}
+
+}  // namespace jolt

@@ -1,0 +1,391 @@
+"""ctypes binding of libjolt_hip.so (include/jolt_hip.h) -- the same C ABI a Rust FFI crate would bind.
+
+Field elements are numpy uint64 arrays of shape (..., 4) (Montgomery limbs of jolt_field::Fr); G1 points are
+(..., 12) uint64 (Jacobian, ark_bn254::G1Projective layout).  There is no CPU fallback: if the shared library is
+missing or no gfx950 device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjolt_hip.so")
+
+STATUS = {0: "ok", 1: "invalid argument", 2: "no device", 3: "oom", 4: "hip error", 5: "size mismatch", 6: "unsupported",
+          7: "not fully bound", 8: "round check failed", 9: "srs too small", 10: "empty point", 11: "not invertible"}
+ORDER_LOW_TO_HIGH, ORDER_HIGH_TO_LOW = 0, 1
+MEMBER_FLAG_SKIP_ONE = 1
+
+
+class JoltError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({STATUS.get(status, '?')}) {detail}")
+
+
+class MemberDesc(C.Structure):
+    _fields_ = [("n_tables", C.c_uint32), ("n_terms", C.c_uint32), ("degree", C.c_uint32), ("order", C.c_int32),
+                ("term_offsets", C.c_void_p), ("factors", C.c_void_p), ("coeffs", C.c_void_p)]
+
+
+class MemberLcDesc(C.Structure):
+    _fields_ = [("n_tables", C.c_uint32), ("n_groups", C.c_uint32), ("n_factors", C.c_uint32), ("n_lc", C.c_uint32),
+                ("degree", C.c_uint32), ("order", C.c_int32), ("flags", C.c_uint32),
+                ("group_factor_offsets", C.c_void_p), ("factor_lc_offsets", C.c_void_p), ("factor_consts", C.c_void_p),
+                ("lc_tables", C.c_void_p), ("lc_coeffs", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the native library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -m jolt_amd.build` (there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.jolt_status_string.restype = C.c_char_p
+        _lib.jolt_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def fr(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def fr_array(n):
+    return np.zeros((n, 4), dtype=np.uint64)
+
+
+def g1_array(n):
+    return np.zeros((n, 12), dtype=np.uint64)
+
+
+def _ck(status, where, ctx=None):
+    if status != 0:
+        detail = ""
+        if ctx is not None and ctx.h:
+            detail = lib().jolt_last_error(ctx.h).decode()
+        raise JoltError(status, where, detail)
+
+
+class Context:
+    def __init__(self, device_id=0, stream=None):
+        self.h = C.c_void_p()
+        st = lib().jolt_ctx_create(C.c_int32(device_id), C.c_void_p(stream) if stream else None, C.byref(self.h))
+        if st != 0:
+            self.h = C.c_void_p()
+            raise JoltError(st, "jolt_ctx_create")
+
+    def close(self):
+        if self.h:
+            lib().jolt_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def synchronize(self):
+        _ck(lib().jolt_ctx_synchronize(self.h), "jolt_ctx_synchronize", self)
+
+    def timer_begin(self):
+        _ck(lib().jolt_timer_begin(self.h), "jolt_timer_begin", self)
+
+    def timer_end(self):
+        ms = C.c_float()
+        _ck(lib().jolt_timer_end(self.h, C.byref(ms)), "jolt_timer_end", self)
+        return ms.value
+
+    # ---- tables
+    def upload(self, arr):
+        a = fr(arr).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_table_upload(self.h, _p(a), C.c_size_t(a.shape[0]), C.byref(h)), "jolt_table_upload", self)
+        return Table(self, h)
+
+    def from_device(self, ptr, length):
+        h = C.c_void_p()
+        _ck(lib().jolt_table_from_device(self.h, C.c_void_p(ptr), C.c_size_t(length), C.byref(h)), "jolt_table_from_device", self)
+        return Table(self, h)
+
+    def alloc(self, length):
+        h = C.c_void_p()
+        _ck(lib().jolt_table_alloc(self.h, C.c_size_t(length), C.byref(h)), "jolt_table_alloc", self)
+        return Table(self, h)
+
+    def from_u64(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.uint64)
+        h = C.c_void_p()
+        _ck(lib().jolt_table_from_u64(self.h, _p(v), C.c_size_t(v.shape[0]), C.byref(h)), "jolt_table_from_u64", self)
+        return Table(self, h)
+
+    def from_i64(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.int64)
+        h = C.c_void_p()
+        _ck(lib().jolt_table_from_i64(self.h, _p(v), C.c_size_t(v.shape[0]), C.byref(h)), "jolt_table_from_i64", self)
+        return Table(self, h)
+
+    def bind(self, tables, r, order=ORDER_LOW_TO_HIGH):
+        hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        _ck(lib().jolt_bind(self.h, hs, C.c_size_t(len(tables)), _p(fr(r)), C.c_int32(order)), "jolt_bind", self)
+
+    def eq_evals(self, r, scale=None):
+        r = fr(r).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_eq_evals(self.h, _p(r), C.c_size_t(r.shape[0]), _p(fr(scale)) if scale is not None else None, C.byref(h)),
+            "jolt_eq_evals", self)
+        return Table(self, h)
+
+    def eq_evals_aligned_block(self, r, start, block):
+        r = fr(r).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_eq_evals_aligned_block(self.h, _p(r), C.c_size_t(r.shape[0]), C.c_size_t(start), C.c_size_t(block), C.byref(h)),
+            "jolt_eq_evals_aligned_block", self)
+        return Table(self, h)
+
+    def lt_evals(self, r):
+        r = fr(r).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_lt_evals(self.h, _p(r), C.c_size_t(r.shape[0]), C.byref(h)), "jolt_lt_evals", self)
+        return Table(self, h)
+
+    def eq_plus_one_evals(self, r, scale=None):
+        r = fr(r).reshape(-1, 4)
+        h1, h2 = C.c_void_p(), C.c_void_p()
+        _ck(lib().jolt_eq_plus_one_evals(self.h, _p(r), C.c_size_t(r.shape[0]), _p(fr(scale)) if scale is not None else None,
+                                         C.byref(h1), C.byref(h2)), "jolt_eq_plus_one_evals", self)
+        return Table(self, h1), Table(self, h2)
+
+    def evaluate(self, table, point):
+        p = fr(point).reshape(-1, 4)
+        o = fr_array(1)
+        _ck(lib().jolt_table_evaluate(self.h, table.h, _p(p), C.c_size_t(p.shape[0]), _p(o)), "jolt_table_evaluate", self)
+        return o[0]
+
+    def table_sum(self, table):
+        o = fr_array(1)
+        _ck(lib().jolt_table_sum(self.h, table.h, _p(o)), "jolt_table_sum", self)
+        return o[0]
+
+    # ---- members
+    def member_expr(self, tables, terms, degree, order=ORDER_LOW_TO_HIGH):
+        """terms = [(coeff_limbs, [table indices]), ...]; takes ownership of the tables."""
+        offs, facs = [0], []
+        for _, f in terms:
+            facs.extend(f)
+            offs.append(len(facs))
+        offs = np.array(offs, dtype=np.uint32)
+        facs_a = np.array(facs if facs else [0], dtype=np.uint32)
+        coeffs = np.ascontiguousarray(np.stack([fr(c) for c, _ in terms])).reshape(-1, 4)
+        d = MemberDesc(len(tables), len(terms), degree, order, offs.ctypes.data, facs_a.ctypes.data, coeffs.ctypes.data)
+        hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        h = C.c_void_p()
+        _ck(lib().jolt_member_create_expr(self.h, hs, C.byref(d), C.byref(h)), "jolt_member_create_expr", self)
+        for t in tables:
+            t.h = None  # ownership moved into the member
+        return Member(self, h, degree, len(tables), False, False)
+
+    def member_lc(self, tables, groups, degree, order=ORDER_LOW_TO_HIGH, skip_one=False):
+        """groups = [[factor, ...], ...]; factor = (const_limbs_or_None, [(coeff_limbs, table_idx), ...])."""
+        goff, foff, consts, ltab, lcoef = [0], [0], [], [], []
+        zero = np.zeros(4, dtype=np.uint64)
+        for g in groups:
+            for const, entries in g:
+                consts.append(zero if const is None else fr(const))
+                for c, ti in entries:
+                    lcoef.append(fr(c))
+                    ltab.append(ti)
+                foff.append(len(ltab))
+            goff.append(len(consts))
+        goff = np.array(goff, dtype=np.uint32)
+        foff = np.array(foff, dtype=np.uint32)
+        consts_a = np.ascontiguousarray(np.stack(consts)) if consts else fr_array(1)
+        ltab_a = np.array(ltab if ltab else [0], dtype=np.uint32)
+        lcoef_a = np.ascontiguousarray(np.stack(lcoef)) if lcoef else fr_array(1)
+        d = MemberLcDesc(len(tables), len(groups), len(consts), len(ltab), degree, order, MEMBER_FLAG_SKIP_ONE if skip_one else 0,
+                         goff.ctypes.data, foff.ctypes.data, consts_a.ctypes.data, ltab_a.ctypes.data, lcoef_a.ctypes.data)
+        hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        h = C.c_void_p()
+        _ck(lib().jolt_member_create_lc(self.h, hs, C.byref(d), C.byref(h)), "jolt_member_create_lc", self)
+        for t in tables:
+            t.h = None
+        return Member(self, h, degree, len(tables), False, skip_one)
+
+    def member_split_eq_product(self, a, b, w, scale=None):
+        w = fr(w).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_member_create_split_eq_product(self.h, a.h, b.h, _p(w), C.c_size_t(w.shape[0]),
+                                                      _p(fr(scale)) if scale is not None else None, C.byref(h)),
+            "jolt_member_create_split_eq_product", self)
+        a.h = None
+        b.h = None
+        return Member(self, h, 3, 2, True, False)
+
+    def round_group_prove(self, members, binds):
+        hs = (C.c_void_p * len(members))(*[m.h for m in members])
+        bstore = [None if b is None else fr(b) for b in binds]
+        bp = (C.c_void_p * len(members))(*[None if b is None else b.ctypes.data for b in bstore])
+        total = sum(m.n_evals for m in members)
+        out = fr_array(total)
+        _ck(lib().jolt_round_group_prove(self.h, hs, C.c_size_t(len(members)), bp, _p(out), C.c_size_t(total)), "jolt_round_group_prove", self)
+        res, off = [], 0
+        for m in members:
+            res.append(out[off:off + m.n_evals].copy())
+            off += m.n_evals
+        return res
+
+    def prove_batch(self, members, input_claims, coefficients, offsets, max_num_vars, max_degree, label=0, challenge_mode=0,
+                    use_round_group=True):
+        n = len(members)
+        hs = (C.c_void_p * n)(*[m.h for m in members])
+        ic = np.ascontiguousarray(np.stack(input_claims), dtype=np.uint64).reshape(-1, 4)
+        co = np.ascontiguousarray(np.stack(coefficients), dtype=np.uint64).reshape(-1, 4)
+        offs = (C.c_size_t * n)(*offsets)
+        polys, chal = fr_array(max_num_vars * (max_degree + 1)), fr_array(max_num_vars)
+        mclaims, final = fr_array(n), fr_array(1)
+        _ck(lib().jolt_host_prove_batch(self.h, hs, C.c_size_t(n), _p(ic), _p(co), offs, C.c_size_t(max_num_vars), C.c_size_t(max_degree),
+                                        C.c_uint64(label), C.c_int32(challenge_mode), C.c_int32(1 if use_round_group else 0),
+                                        _p(polys), _p(chal), _p(mclaims), _p(final)), "jolt_host_prove_batch", self)
+        return dict(polys=polys.reshape(max_num_vars, max_degree + 1, 4), challenges=chal, member_claims=mclaims, final_claim=final[0])
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Table:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_table_len(self.h, C.byref(n)), "jolt_table_len", self.ctx)
+        return n.value
+
+    def download(self, offset=0, length=None):
+        n = len(self) - offset if length is None else length
+        out = fr_array(n)
+        _ck(lib().jolt_table_download(self.ctx.h, self.h, C.c_size_t(offset), C.c_size_t(n), _p(out)), "jolt_table_download", self.ctx)
+        return out
+
+    def clone(self):
+        h = C.c_void_p()
+        _ck(lib().jolt_table_clone(self.ctx.h, self.h, C.byref(h)), "jolt_table_clone", self.ctx)
+        return Table(self.ctx, h)
+
+    def device_ptr(self):
+        p = C.c_void_p()
+        _ck(lib().jolt_table_device_ptr(self.h, C.byref(p)), "jolt_table_device_ptr", self.ctx)
+        return p.value
+
+    def free(self):
+        if self.h and self.ctx.h:
+            lib().jolt_table_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Member:
+    """Handle of a device-resident sumcheck member (jolt_sumcheck::ProveRounds, device half)."""
+
+    def __init__(self, ctx, handle, degree, n_tables, split_eq, skip_one):
+        self.ctx, self.h, self.degree, self.n_tables, self.split_eq, self.skip_one = ctx, handle, degree, n_tables, split_eq, skip_one
+        self.n_evals = 2 if split_eq else (degree if skip_one else degree + 1)
+
+    def num_rounds(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_member_num_rounds(self.h, C.byref(n)), "jolt_member_num_rounds", self.ctx)
+        return n.value
+
+    def prove_round(self, bind=None, want_aux=False):
+        out, aux = fr_array(self.n_evals), fr_array(3)
+        _ck(lib().jolt_member_prove_round(self.h, _p(fr(bind)) if bind is not None else None, _p(out), C.c_size_t(self.n_evals), _p(aux)),
+            "jolt_member_prove_round", self.ctx)
+        return (out, aux) if want_aux else out
+
+    def finish(self, bind):
+        _ck(lib().jolt_member_finish(self.h, _p(fr(bind))), "jolt_member_finish", self.ctx)
+
+    def final_values(self):
+        k = self.n_tables + (1 if self.split_eq else 0)
+        out = fr_array(k)
+        _ck(lib().jolt_member_final_values(self.h, _p(out), C.c_size_t(k)), "jolt_member_final_values", self.ctx)
+        return out
+
+    def input_claim(self):
+        out = fr_array(1)
+        _ck(lib().jolt_member_input_claim(self.h, _p(out)), "jolt_member_input_claim", self.ctx)
+        return out[0]
+
+    def destroy(self):
+        if self.h and self.ctx.h:
+            lib().jolt_member_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# ---- host-side helpers (no GPU needed) ------------------------------------------------------------------------------
+def host_fr_binop(name, a, b):
+    o = fr_array(1)
+    _ck(getattr(lib(), name)(_p(fr(a)), _p(fr(b)), _p(o)), name)
+    return o[0]
+
+
+def host_fr_mul(a, b): return host_fr_binop("jolt_host_fr_mul", a, b)
+def host_fr_add(a, b): return host_fr_binop("jolt_host_fr_add", a, b)
+def host_fr_sub(a, b): return host_fr_binop("jolt_host_fr_sub", a, b)
+def host_fr_mul_shifted(a, c): return host_fr_binop("jolt_host_fr_mul_shifted", a, c)
+
+
+def host_fr_inv(a):
+    o = fr_array(1)
+    _ck(lib().jolt_host_fr_inv(_p(fr(a)), _p(o)), "jolt_host_fr_inv")
+    return o[0]
+
+
+def host_fr_from_u64(v):
+    o = fr_array(1)
+    _ck(lib().jolt_host_fr_from_u64(C.c_uint64(v), _p(o)), "jolt_host_fr_from_u64")
+    return o[0]
+
+
+def host_univariate_from_evals(evals):
+    e = fr(evals).reshape(-1, 4)
+    o = fr_array(e.shape[0])
+    _ck(lib().jolt_host_univariate_from_evals(_p(e), C.c_size_t(e.shape[0]), _p(o)), "jolt_host_univariate_from_evals")
+    return o
+
+
+def host_univariate_evaluate(coeffs, x):
+    c = fr(coeffs).reshape(-1, 4)
+    o = fr_array(1)
+    _ck(lib().jolt_host_univariate_evaluate(_p(c), C.c_size_t(c.shape[0]), _p(fr(x)), _p(o)), "jolt_host_univariate_evaluate")
+    return o[0]
+
+
+def host_gruen_poly_deg_3(scalar, point_i, q0, qinf, claim):
+    o = fr_array(4)
+    _ck(lib().jolt_host_gruen_poly_deg_3(_p(fr(scalar)), _p(fr(point_i)), _p(fr(q0)), _p(fr(qinf)), _p(fr(claim)), _p(o)),
+        "jolt_host_gruen_poly_deg_3")
+    return o

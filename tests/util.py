@@ -1,0 +1,27 @@
+"""Shared helpers for the parity tests (seeded inputs, shapes of real sumcheck challenges)."""
+import numpy as np
+
+P_TOP = 0x30644E72E131A029  # top u64 limb of r: any limb vector with a smaller top limb is a canonical element
+
+
+def rand_fr(n, seed):
+    """n uniformly random canonical Montgomery-form elements (every 256-bit value < r is a valid Montgomery form)."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] = a[:, 3] % np.uint64(P_TOP)
+    return a
+
+
+def rand_challenge(seed, shifted=True):
+    """A challenge with the reference's 125-bit shape (two low u64 Montgomery limbs zero,
+    crates/jolt-field/src/bn254/mod.rs:172-184) or a full-width element."""
+    c = rand_fr(1, seed)[0]
+    if shifted:
+        c[0] = 0
+        c[1] = 0
+        c[3] &= np.uint64((1 << 61) - 1)
+    return c
+
+
+def small_fr(vals, oracle):
+    return oracle.fr_from_u64(np.asarray(vals, dtype=np.uint64))
