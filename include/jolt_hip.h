@@ -147,6 +147,11 @@ int32_t jolt_member_create_expr(jolt_ctx *ctx, jolt_table *const *tables, const 
  * flags bit 0 = evaluate t in {0,2,..,degree} only and let the caller recover s(1) = claim - s(0)
  * (optimized/support.rs:450-459 round_poly_from_skipped_evals); prove_round then returns `degree` values. */
 #define JOLT_MEMBER_FLAG_SKIP_ONE 1u
+/* flags bit 1 = BORROW: the member only READS the given tables (they stay owned by the caller and must outlive it) and
+ * binds into scratch of its own (N/2 + N/4 entries per table).  One resident witness table can then serve every
+ * relation that mentions it and the PCS opening afterwards, instead of one `oracle_table` materialisation per kernel
+ * (crates/jolt-kernels/src/reference/views.rs:20-33).  Borrowing members can be rewound with jolt_member_reset. */
+#define JOLT_MEMBER_FLAG_BORROW_TABLES 2u
 typedef struct {
     uint32_t n_tables, n_groups, n_factors, n_lc;
     uint32_t degree;
@@ -163,6 +168,10 @@ int32_t jolt_member_create_lc(jolt_ctx *ctx, jolt_table *const *tables, const jo
  * crates/jolt-poly/src/split_eq.rs:187-236).  Takes ownership of a and b. */
 int32_t jolt_member_create_split_eq_product(jolt_ctx *ctx, jolt_table *a, jolt_table *b, const jolt_fr_t *w, size_t n,
                                             const jolt_fr_t *scale, jolt_member **out);
+int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx *ctx, jolt_table *a, jolt_table *b, const jolt_fr_t *w, size_t n,
+                                                     const jolt_fr_t *scale, jolt_member **out);
+/* Rewind a BORROW member to round 0 (no device work). */
+int32_t jolt_member_reset(jolt_member *m);
 int32_t jolt_member_num_rounds(const jolt_member *m, size_t *rounds);
 int32_t jolt_member_degree(const jolt_member *m, uint32_t *degree);
 

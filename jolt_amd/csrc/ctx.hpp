@@ -34,11 +34,13 @@ struct jolt_ctx {
 
 struct jolt_table {
     jolt_ctx* ctx = nullptr;
-    Fr* buf[2] = {nullptr, nullptr};
+    Fr* buf[2] = {nullptr, nullptr};  // owned; LowToHigh binds ping-pong between them
     size_t cap[2] = {0, 0};
-    int cur = 0;
+    int cur = 0;                      // -1: the evaluations are the borrowed `view` (never written)
     size_t len = 0;
-    Fr* data() const { return buf[cur]; }
+    const Fr* view = nullptr;         // borrowed source of a member that does not own its tables
+    size_t view_len = 0;
+    Fr* data() const { return cur < 0 ? const_cast<Fr*>(view) : buf[cur]; }
 };
 
 #define JOLT_HIP_TRY(ctx, expr)                                                                       \

@@ -1,0 +1,155 @@
+// jolt_amd/csrc/g1.cuh -- BN254 G1 group law for device and host (y^2 = x^3 + 3 over Fq, a = 0).
+//
+// Jacobian (X, Y, Z) with ark's conventions: identity <=> Z == 0; layout = ark_bn254::G1Projective, which the
+// reference wraps transparently (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24).  Affine points carry (0,0) for
+// infinity (not on the curve).  Bucket sums in the MSM hit P+P, P+(-P) and infinity (specs/clean-slate-prover.md:557-563),
+// so every formula handles its special cases explicitly; results are the same POINT as the reference's, the
+// projective representative is free (serialisation is compressed affine).
+#pragma once
+#include "field.cuh"
+
+namespace jolt {
+
+struct G1Affine {
+    Fq x, y;
+};
+struct G1Jac {
+    Fq x, y, z;
+};
+static_assert(sizeof(G1Jac) == 96 && sizeof(G1Affine) == 64, "G1 layouts");
+
+JOLT_HD bool g1_is_identity(const G1Jac& p) { return p.z.is_zero(); }
+JOLT_HD bool g1_aff_is_inf(const G1Affine& p) { return p.x.is_zero() && p.y.is_zero(); }
+JOLT_HD G1Jac g1_identity() {
+    G1Jac r;
+    r.x = Fq::one();
+    r.y = Fq::one();
+    r.z = Fq::zero();
+    return r;
+}
+JOLT_HD G1Jac g1_from_affine(const G1Affine& a) {
+    G1Jac r;
+    if (g1_aff_is_inf(a)) return g1_identity();
+    r.x = a.x;
+    r.y = a.y;
+    r.z = Fq::one();
+    return r;
+}
+JOLT_HD G1Affine g1_aff_neg(const G1Affine& a) {
+    G1Affine r;
+    r.x = a.x;
+    r.y = neg(a.y);
+    return r;
+}
+JOLT_HD G1Jac g1_neg(const G1Jac& p) {
+    G1Jac r = p;
+    r.y = neg(p.y);
+    return r;
+}
+
+// dbl-2009-l
+JOLT_HD G1Jac g1_double(const G1Jac& p) {
+    if (g1_is_identity(p)) return p;
+    Fq A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    Fq D = dbl(sub(sub(sqr(add(p.x, B)), A), C));
+    Fq E = add(dbl(A), A);
+    Fq F = sqr(E);
+    G1Jac r;
+    r.x = sub(F, dbl(D));
+    r.z = dbl(mul(p.y, p.z));
+    r.y = sub(mul(E, sub(D, r.x)), dbl(dbl(dbl(C))));
+    return r;
+}
+
+// madd-2007-bl: Jacobian + affine
+JOLT_HD G1Jac g1_add_mixed(const G1Jac& p, const G1Affine& q) {
+    if (g1_aff_is_inf(q)) return p;
+    if (g1_is_identity(p)) return g1_from_affine(q);
+    Fq Z1Z1 = sqr(p.z);
+    Fq U2 = mul(q.x, Z1Z1);
+    Fq S2 = mul(mul(q.y, p.z), Z1Z1);
+    if (p.x == U2) {
+        if (p.y == S2) return g1_double(p);
+        return g1_identity();
+    }
+    Fq H = sub(U2, p.x);
+    Fq HH = sqr(H);
+    Fq I = dbl(dbl(HH));
+    Fq J = mul(H, I);
+    Fq rr = dbl(sub(S2, p.y));
+    Fq V = mul(p.x, I);
+    G1Jac r;
+    r.x = sub(sub(sqr(rr), J), dbl(V));
+    r.y = sub(mul(rr, sub(V, r.x)), dbl(mul(p.y, J)));
+    r.z = sub(sub(sqr(add(p.z, H)), Z1Z1), HH);
+    return r;
+}
+
+// add-2007-bl: Jacobian + Jacobian
+JOLT_HD G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
+    if (g1_is_identity(p)) return q;
+    if (g1_is_identity(q)) return p;
+    Fq Z1Z1 = sqr(p.z), Z2Z2 = sqr(q.z);
+    Fq U1 = mul(p.x, Z2Z2), U2 = mul(q.x, Z1Z1);
+    Fq S1 = mul(mul(p.y, q.z), Z2Z2), S2 = mul(mul(q.y, p.z), Z1Z1);
+    if (U1 == U2) {
+        if (S1 == S2) return g1_double(p);
+        return g1_identity();
+    }
+    Fq H = sub(U2, U1);
+    Fq I = sqr(dbl(H));
+    Fq J = mul(H, I);
+    Fq rr = dbl(sub(S2, S1));
+    Fq V = mul(U1, I);
+    G1Jac r;
+    r.x = sub(sub(sqr(rr), J), dbl(V));
+    r.y = sub(mul(rr, sub(V, r.x)), dbl(mul(S1, J)));
+    r.z = mul(sub(sub(sqr(add(p.z, q.z)), Z1Z1), Z2Z2), H);
+    return r;
+}
+
+JOLT_HD G1Affine g1_to_affine(const G1Jac& p) {
+    G1Affine a;
+    if (g1_is_identity(p)) {
+        a.x = Fq::zero();
+        a.y = Fq::zero();
+        return a;
+    }
+    Fq zi = inv(p.z);
+    Fq zi2 = sqr(zi);
+    a.x = mul(p.x, zi2);
+    a.y = mul(p.y, mul(zi2, zi));
+    return a;
+}
+
+// equality as group elements
+JOLT_HD bool g1_eq(const G1Jac& p, const G1Jac& q) {
+    bool pi = g1_is_identity(p), qi = g1_is_identity(q);
+    if (pi || qi) return pi && qi;
+    Fq Z1Z1 = sqr(p.z), Z2Z2 = sqr(q.z);
+    if (mul(p.x, Z2Z2) != mul(q.x, Z1Z1)) return false;
+    return mul(p.y, mul(Z2Z2, q.z)) == mul(q.y, mul(Z1Z1, p.z));
+}
+
+// k * p for a small non-negative integer k (bucket weights in the window reduction)
+JOLT_HD G1Jac g1_mul_small(const G1Jac& p, uint32_t k) {
+    G1Jac acc = g1_identity();
+    for (int i = 31; i >= 0; --i) {
+        acc = g1_double(acc);
+        if ((k >> i) & 1) acc = g1_add(acc, p);
+    }
+    return acc;
+}
+
+// scalar * p, scalar given as a canonical 256-bit integer (8 x u32), MSB-first double-and-add
+// (JoltGroup::scalar_mul, crates/jolt-crypto/src/ec/bn254/mod.rs:190-193)
+JOLT_HD G1Jac g1_mul_canonical(const G1Jac& p, const uint32_t k[8]) {
+    G1Jac acc = g1_identity();
+    for (int i = 255; i >= 0; --i) {
+        acc = g1_double(acc);
+        if ((k[i / 32] >> (i % 32)) & 1) acc = g1_add(acc, p);
+    }
+    return acc;
+}
+
+}  // namespace jolt

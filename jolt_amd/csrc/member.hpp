@@ -13,12 +13,13 @@ struct jolt_member {
     uint32_t degree = 0;
     int32_t order = JOLT_ORDER_LOW_TO_HIGH;
     bool skip_one = false;
+    bool borrowed = false;  // tables are views of caller-owned tables (never written); scratch is owned
     std::vector<jolt_table*> tables;  // owned
     jolt::MemberDesc desc;            // host copy
     jolt::MemberDesc* d_desc = nullptr;
     // split-eq state (GruenSplitEqPolynomial, crates/jolt-poly/src/split_eq.rs:159-166)
     std::vector<Fr> w;
-    Fr current_scalar;
+    Fr current_scalar, initial_scalar;
     size_t out_len = 0, in_len = 0;        // lengths of out_point / in_point
     size_t e_out_bits = 0, e_in_bits = 0;  // prefix lengths of the CURRENT E_out / E_in tables
     std::vector<jolt_table*> e_out_cache, e_in_cache;  // evals_cached: index j = eq over the first j coordinates

@@ -16,6 +16,7 @@ STATUS = {0: "ok", 1: "invalid argument", 2: "no device", 3: "oom", 4: "hip erro
           7: "not fully bound", 8: "round check failed", 9: "srs too small", 10: "empty point", 11: "not invertible"}
 ORDER_LOW_TO_HIGH, ORDER_HIGH_TO_LOW = 0, 1
 MEMBER_FLAG_SKIP_ONE = 1
+MEMBER_FLAG_BORROW_TABLES = 2
 
 
 class JoltError(RuntimeError):
@@ -188,8 +189,9 @@ class Context:
             t.h = None  # ownership moved into the member
         return Member(self, h, degree, len(tables), False, False)
 
-    def member_lc(self, tables, groups, degree, order=ORDER_LOW_TO_HIGH, skip_one=False):
-        """groups = [[factor, ...], ...]; factor = (const_limbs_or_None, [(coeff_limbs, table_idx), ...])."""
+    def member_lc(self, tables, groups, degree, order=ORDER_LOW_TO_HIGH, skip_one=False, borrow=False):
+        """groups = [[factor, ...], ...]; factor = (const_limbs_or_None, [(coeff_limbs, table_idx), ...]).
+        borrow=True: the member only reads `tables` (caller keeps ownership, tables must outlive the member)."""
         goff, foff, consts, ltab, lcoef = [0], [0], [], [], []
         zero = np.zeros(4, dtype=np.uint64)
         for g in groups:
@@ -205,24 +207,33 @@ class Context:
         consts_a = np.ascontiguousarray(np.stack(consts)) if consts else fr_array(1)
         ltab_a = np.array(ltab if ltab else [0], dtype=np.uint32)
         lcoef_a = np.ascontiguousarray(np.stack(lcoef)) if lcoef else fr_array(1)
-        d = MemberLcDesc(len(tables), len(groups), len(consts), len(ltab), degree, order, MEMBER_FLAG_SKIP_ONE if skip_one else 0,
+        flags = (MEMBER_FLAG_SKIP_ONE if skip_one else 0) | (MEMBER_FLAG_BORROW_TABLES if borrow else 0)
+        d = MemberLcDesc(len(tables), len(groups), len(consts), len(ltab), degree, order, flags,
                          goff.ctypes.data, foff.ctypes.data, consts_a.ctypes.data, ltab_a.ctypes.data, lcoef_a.ctypes.data)
         hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
         h = C.c_void_p()
         _ck(lib().jolt_member_create_lc(self.h, hs, C.byref(d), C.byref(h)), "jolt_member_create_lc", self)
-        for t in tables:
-            t.h = None
-        return Member(self, h, degree, len(tables), False, skip_one)
+        m = Member(self, h, degree, len(tables), False, skip_one)
+        if borrow:
+            m._keepalive = list(tables)
+        else:
+            for t in tables:
+                t.h = None
+        return m
 
-    def member_split_eq_product(self, a, b, w, scale=None):
+    def member_split_eq_product(self, a, b, w, scale=None, borrow=False):
         w = fr(w).reshape(-1, 4)
         h = C.c_void_p()
-        _ck(lib().jolt_member_create_split_eq_product(self.h, a.h, b.h, _p(w), C.c_size_t(w.shape[0]),
-                                                      _p(fr(scale)) if scale is not None else None, C.byref(h)),
+        fn = lib().jolt_member_create_split_eq_product_borrowed if borrow else lib().jolt_member_create_split_eq_product
+        _ck(fn(self.h, a.h, b.h, _p(w), C.c_size_t(w.shape[0]), _p(fr(scale)) if scale is not None else None, C.byref(h)),
             "jolt_member_create_split_eq_product", self)
-        a.h = None
-        b.h = None
-        return Member(self, h, 3, 2, True, False)
+        m = Member(self, h, 3, 2, True, False)
+        if borrow:
+            m._keepalive = [a, b]
+        else:
+            a.h = None
+            b.h = None
+        return m
 
     def round_group_prove(self, members, binds):
         hs = (C.c_void_p * len(members))(*[m.h for m in members])
@@ -332,6 +343,9 @@ class Member:
         out = fr_array(1)
         _ck(lib().jolt_member_input_claim(self.h, _p(out)), "jolt_member_input_claim", self.ctx)
         return out[0]
+
+    def reset(self):
+        _ck(lib().jolt_member_reset(self.h), "jolt_member_reset", self.ctx)
 
     def destroy(self):
         if self.h and self.ctx.h:

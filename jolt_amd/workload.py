@@ -1,0 +1,247 @@
+"""Synthetic "sha3-shaped" prover workload for the sumcheck hot path.
+
+The reference sizes a sha3 trace as 4330 cycles per hash at 90 % fill of 2^scale
+(crates/jolt-prover/src/profile.rs:80-84,547-551) and then runs, per stage, one batched sumcheck over the cycle
+domain.  Without the Rust toolchain no real trace exists here, so the workload is the member catalogue of
+SURVEY.md section 8 a13 -- every T-sized, cycle-domain relation of stages 2..6b with the reference's summand shape,
+degree and table count -- over synthetic tables of the right kind (u64-valued witness columns promoted on the
+device, eq / eq+1 / LT tables expanded on the device from random points).  Each relation is written in the fused
+"product of linear combinations" form the optimized tier uses, as a descriptor for the generic device member.
+
+This module only DESCRIBES the workload (numpy + descriptors); bench.py and the tests instantiate it on the GPU
+through the C ABI, and (tests / cpu_baseline only) on the CPU oracle.
+"""
+import numpy as np
+
+P_TOP = 0x30644E72E131A029
+
+
+def rand_fr(n, rng):
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] = a[:, 3] % np.uint64(P_TOP)
+    return a
+
+
+class TableSpec:
+    """kind: 'u64' (witness column, values < 2^bits), 'eq', 'eq1' (eq+1), 'lt' -- derived tables carry their point."""
+
+    def __init__(self, name, kind, bits=64, point=None, data=None):
+        self.name, self.kind, self.bits, self.point, self.data = name, kind, bits, point, data
+
+
+class MemberSpec:
+    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, reference=""):
+        self.name, self.stage, self.degree, self.tables = name, stage, degree, tables
+        self.groups = groups        # LC form: [[(const|None, [(coeff, local_table_idx), ...]), ...], ...]
+        self.split_eq = split_eq    # (a_idx, b_idx, w) for the split-eq product member
+        self.reference = reference  # reference file of the relation
+
+
+def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
+    """Returns (tables: dict name -> TableSpec, members: [MemberSpec]) for a trace of T = 2^n_vars cycles."""
+    rng = np.random.default_rng(seed)
+    T = 1 << n_vars
+    tables = {}
+    one = None  # resolved by the instantiator (Montgomery one)
+
+    def wit(name, bits=64):
+        hi = 2**bits if bits < 64 else 2**64
+        tables[name] = TableSpec(name, "u64", bits, data=rng.integers(0, hi, size=T, dtype=np.uint64))
+        return name
+
+    def derived(name, kind):
+        tables[name] = TableSpec(name, kind, point=rand_fr(n_vars, rng))
+        return name
+
+    def scalar():
+        return rand_fr(1, rng)[0]
+
+    def powers(g, k):
+        return ("powers", g, k)  # resolved lazily: [1, g, g^2, ...] needs field multiplication
+
+    members = []
+
+    # ---- stage 2: instruction_claim_reduction  eq(tau,j) * (o1 + g o2 + ... + g^4 o5)          deg 2, 6 tables
+    t = [derived("s2.eq", "eq")] + [wit(f"s2.o{k}") for k in range(5)]
+    members.append(MemberSpec("instruction_claim_reduction", 2, 2, t,
+                              groups=[[(None, [("one", 0)]), (None, [(("gpow", 0, k), 1 + k) for k in range(5)])]],
+                              reference="crates/jolt-kernels/src/reference/instruction_claim_reduction.rs"))
+    # ---- stage 3: spartan_shift  eq+1(tau,j)*(upc + g pc + g^2 virt + g^3 first) + g^4 eq+1(r,j)*(1 - noop)   deg 2, 7 tables
+    t = [derived("s3.eq1a", "eq1"), wit("s3.upc"), wit("s3.pc"), wit("s3.virt", 1), wit("s3.first", 1), derived("s3.eq1b", "eq1"),
+         wit("s3.noop", 1)]
+    members.append(MemberSpec("spartan_shift", 3, 2, t,
+                              groups=[[(None, [("one", 0)]), (None, [(("gpow", 1, k), 1 + k) for k in range(4)])],
+                                      [(None, [(("gpow", 1, 4), 5)]), ("one", [("minus_one", 6)])]],
+                              reference="crates/jolt-kernels/src/reference/spartan_shift.rs"))
+    # ---- stage 3: instruction_input  eq*((f1 rs2 + f2 imm) + g (f3 rs1 + f4 upc))                deg 3, 9 tables
+    t = [derived("s3.eq_in", "eq"), wit("s3.f1", 1), wit("s3.rs2"), wit("s3.f2", 1), wit("s3.imm"), wit("s3.f3", 1), wit("s3.rs1"),
+         wit("s3.f4", 1), wit("s3.upc2")]
+    members.append(MemberSpec("instruction_input", 3, 3, t,
+                              groups=[[(None, [("one", 0)]), (None, [("one", 1)]), (None, [("one", 2)])],
+                                      [(None, [("one", 0)]), (None, [("one", 3)]), (None, [("one", 4)])],
+                                      [(None, [(("gpow", 2, 1), 0)]), (None, [("one", 5)]), (None, [("one", 6)])],
+                                      [(None, [(("gpow", 2, 1), 0)]), (None, [("one", 7)]), (None, [("one", 8)])]],
+                              reference="crates/jolt-kernels/src/reference/instruction_input.rs"))
+    # ---- stage 3: registers_claim_reduction  eq*(rd_w + g rs1 + g^2 rs2)                        deg 2, 4 tables
+    t = [derived("s3.eq_reg", "eq"), wit("s3.rd_w"), wit("s3.rs1v"), wit("s3.rs2v")]
+    members.append(MemberSpec("registers_claim_reduction", 3, 2, t,
+                              groups=[[(None, [("one", 0)]), (None, [(("gpow", 3, k), 1 + k) for k in range(3)])]],
+                              reference="crates/jolt-kernels/src/reference/registers_claim_reduction.rs"))
+    # ---- stage 4: ram_val_check  inc(j) * ra(j) * (LT(j,r) + g)                                  deg 3, 3 tables
+    t = [wit("s4.inc"), derived("s4.ra", "eq"), derived("s4.lt", "lt")]
+    members.append(MemberSpec("ram_val_check", 4, 3, t,
+                              groups=[[(None, [("one", 0)]), (None, [("one", 1)]), (("gpow", 4, 1), [("one", 2)])]],
+                              reference="crates/jolt-kernels/src/reference/ram_val_check.rs"))
+    # ---- stage 5: registers_val_evaluation  LT(j,r) * rd_inc(j) * rd_wa(r_addr,j)                deg 3, 3 tables
+    t = [derived("s5.lt", "lt"), wit("s5.rd_inc"), derived("s5.rd_wa", "eq")]
+    members.append(MemberSpec("registers_val_evaluation", 5, 3, t,
+                              groups=[[(None, [("one", 0)]), (None, [("one", 1)]), (None, [("one", 2)])]],
+                              reference="crates/jolt-kernels/src/reference/registers_val_evaluation.rs"))
+    # ---- stage 5: ram_ra_claim_reduction  (eq1 + g eq2 + g^2 eq3)(j) * ra(r_addr,j)              deg 2, 4 tables
+    t = [derived("s5.eq1", "eq"), derived("s5.eq2", "eq"), derived("s5.eq3", "eq"), derived("s5.ra", "eq")]
+    members.append(MemberSpec("ram_ra_claim_reduction", 5, 2, t,
+                              groups=[[(None, [(("gpow", 5, k), k) for k in range(3)]), (None, [("one", 3)])]],
+                              reference="crates/jolt-kernels/src/reference/ram_ra_claim_reduction.rs"))
+    # ---- stage 6b: inc_claim_reduction  (eq1 + g eq2) RamInc + g^2 (eq3 + g eq4) RdInc           deg 2, 6 tables
+    t = [derived("s6.eq1", "eq"), derived("s6.eq2", "eq"), wit("s6.ram_inc"), derived("s6.eq3", "eq"), derived("s6.eq4", "eq"),
+         wit("s6.rd_inc")]
+    members.append(MemberSpec("inc_claim_reduction", 6, 2, t,
+                              groups=[[(None, [("one", 0), (("gpow", 6, 1), 1)]), (None, [("one", 2)])],
+                                      [(None, [(("gpow", 6, 2), 3), (("gpow", 6, 3), 4)]), (None, [("one", 5)])]],
+                              reference="crates/jolt-kernels/src/optimized/inc_claim_reduction.rs:6-13,68-89"))
+    # ---- stage 6b: ram_hamming_booleanity  eq(r,j) * (H^2 - H) = eq * H * (H - 1)                deg 3, split-eq member
+    t = [wit("s6.H", 1), "s6.H_minus_1"]
+    tables["s6.H_minus_1"] = TableSpec("s6.H_minus_1", "i64", data=tables["s6.H"].data.astype(np.int64) - 1)
+    members.append(MemberSpec("ram_hamming_booleanity", 6, 3, t, split_eq=(0, 1, rand_fr(n_vars, rng)),
+                              reference="crates/jolt-kernels/src/optimized/ram_hamming_booleanity.rs:111-135"))
+    # ---- stage 6b: ram_ra_virtualization  eq(r,j) * prod_{i<d} ra_i                             deg 1+d, 1+d tables
+    t = [derived("s6.eq_rv", "eq")] + [derived(f"s6.ram_ra{i}", "eq") for i in range(d_ram)]
+    members.append(MemberSpec("ram_ra_virtualization", 6, 1 + d_ram, t,
+                              groups=[[(None, [("one", i)]) for i in range(1 + d_ram)]],
+                              reference="crates/jolt-kernels/src/reference/ram_ra_virtualization.rs"))
+    # ---- stage 6b: instruction_ra_virtualization  eq * sum_v g^v prod_{i<4} ra_{4v+i}            deg 5, 1+32 tables
+    t = [derived("s6.eq_iv", "eq")] + [derived(f"s6.ins_ra{i}", "eq") for i in range(n_instruction_ra)]
+    members.append(MemberSpec("instruction_ra_virtualization", 6, 5, t,
+                              groups=[[(None, [(("gpow", 7, v), 0)])] + [(None, [("one", 1 + 4 * v + i)]) for i in range(4)]
+                                      for v in range(n_instruction_ra // 4)],
+                              reference="crates/jolt-kernels/src/reference/instruction_ra_virtualization.rs"))
+    gammas = [scalar() for _ in range(8)]
+    return tables, members, gammas
+
+
+class Resolver:
+    """Turns symbolic coefficients ('one', 'minus_one', ('gpow', g, k)) into Montgomery limbs with a caller-supplied
+    field multiplication (device host-helper for the product, oracle for the CPU baseline)."""
+
+    def __init__(self, gammas, one, mul, neg):
+        self.one, self.mul, self.negf = one, mul, neg
+        self.gammas = gammas
+        self.cache = {}
+
+    def coeff(self, c):
+        if isinstance(c, np.ndarray):
+            return c
+        if c is None:
+            return None
+        if c == "one":
+            return self.one
+        if c == "minus_one":
+            return self.negf(self.one)
+        if isinstance(c, tuple) and c[0] == "gpow":
+            key = (c[1], c[2])
+            if key not in self.cache:
+                v = self.one
+                for _ in range(c[2]):
+                    v = self.mul(v, self.gammas[c[1]])
+                self.cache[key] = v
+            return self.cache[key]
+        raise ValueError(c)
+
+    def groups(self, groups):
+        return [[(self.coeff(const), [(self.coeff(c), ti) for c, ti in entries]) for const, entries in g] for g in groups]
+
+
+def expand_to_flat_terms(groups, mul, one):
+    """Distribute a resolved LC-form summand into the reference tier's flat Expr terms [(coeff, [table idx...])]
+    (constants multiply into the coefficient).  Used by the tests to compare the fused device member with the
+    oracle's naive member."""
+    terms = []
+    for g in groups:
+        partial = [(one, [])]
+        for const, entries in g:
+            nxt = []
+            for c0, f0 in partial:
+                if const is not None:
+                    nxt.append((mul(c0, const), list(f0)))
+                for c, ti in entries:
+                    nxt.append((mul(c0, c), f0 + [ti]))
+            partial = nxt
+        terms.extend(partial)
+    return terms
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU instantiation through the C ABI (product path; no oracle involved)
+# ---------------------------------------------------------------------------------------------------------------------
+class DeviceWorkload:
+    """Resident tables + BORROW members for every relation, grouped by stage; `prove()` runs one batched sumcheck per
+    stage through jolt_host_prove_batch (grouped scheduler: one device->host copy and one sync per batch round)."""
+
+    def __init__(self, ctx, n_vars, seed=2026, **kw):
+        from . import ffi
+        self.ctx, self.n_vars, self.ffi = ctx, n_vars, ffi
+        self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
+        one = ffi.host_fr_from_u64(1)
+        zero = np.zeros(4, dtype=np.uint64)
+        self.resolver = Resolver(gammas, one, ffi.host_fr_mul, lambda x: ffi.host_fr_sub(zero, x))
+        self.one = one
+        self.tables = {}
+        for name, spec in self.tables_spec.items():
+            self.tables[name] = self._make_table(spec)
+        self.members, self.stages = [], {}
+        for ms in self.members_spec:
+            tabs = [self.tables[t] for t in ms.tables]
+            if ms.split_eq is not None:
+                a, b, w = ms.split_eq
+                m = ctx.member_split_eq_product(tabs[a], tabs[b], w, borrow=True)
+            else:
+                m = ctx.member_lc(tabs, self.resolver.groups(ms.groups), ms.degree, borrow=True, skip_one=True)
+            self.members.append(m)
+            self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+        ctx.synchronize()
+        # input claims: in the real prover these are the previous stage's output claims; here computed once, untimed
+        self.claims = [m.input_claim() for m in self.members]
+        rng = np.random.default_rng(seed + 1)
+        self.batch_coeffs = [rand_fr(1, rng)[0] for _ in self.members]
+        self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
+
+    def _make_table(self, spec):
+        c = self.ctx
+        if spec.kind == "u64":
+            return c.from_u64(spec.data)
+        if spec.kind == "i64":
+            return c.from_i64(spec.data)
+        if spec.kind == "eq":
+            return c.eq_evals(spec.point)
+        if spec.kind == "lt":
+            return c.lt_evals(spec.point)
+        if spec.kind == "eq1":
+            eq, eq1 = c.eq_plus_one_evals(spec.point)
+            eq.free()
+            return eq1
+        raise ValueError(spec.kind)
+
+    def prove(self, label=0):
+        """One pass of the hot path: every stage's batched sumcheck, then rewind the members. Returns per-stage outputs."""
+        outs = {}
+        for stage, idxs in sorted(self.stages.items()):
+            ms = [self.members[i] for i in idxs]
+            deg = max(m.degree for m in ms)
+            outs[stage] = self.ctx.prove_batch(ms, [self.claims[i] for i in idxs], [self.batch_coeffs[i] for i in idxs], [0] * len(ms),
+                                               self.n_vars, deg, label=label + stage, use_round_group=True)
+        for m in self.members:
+            m.reset()
+        return outs
+
+    def bytes_resident(self):
+        return sum(len(t) for t in self.tables.values()) * 32

@@ -570,6 +570,10 @@ def baseline_threads():
     return lib().orc_baseline_threads()
 
 
+def baseline_set_threads(n):
+    lib().orc_baseline_set_threads(C.c_int(n))
+
+
 def baseline_bind_low_to_high(table, r, out):
     lib().orc_baseline_bind_low_to_high(_p(table), C.c_size_t(table.shape[0]), _p(np.ascontiguousarray(r, dtype=np.uint64)), _p(out))
 
@@ -588,3 +592,37 @@ def baseline_round_evals(tables, terms, degree):
     lib().orc_baseline_round_evals(ptrs, C.c_uint32(len(tabs)), C.c_size_t(tabs[0].shape[0]), C.c_uint32(len(terms)),
                                    _p(offs), _p(facs_a), _p(coeffs), C.c_uint32(degree), _p(o))
     return o
+
+
+def baseline_member_sumcheck(tables, groups, degree, challenges):
+    """groups in resolved LC form: [[(const|None, [(coeff, table_idx), ...]), ...], ...]"""
+    tabs = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+    ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+    goff, foff, consts, has_c, ltab, lcoef, lone = [0], [0], [], [], [], [], []
+    one = to_mont([1])[0]
+    zero = np.zeros(4, dtype=np.uint64)
+    for g in groups:
+        for const, entries in g:
+            consts.append(zero if const is None else np.asarray(const, dtype=np.uint64))
+            has_c.append(0 if const is None else 1)
+            for c, ti in entries:
+                c = np.asarray(c, dtype=np.uint64)
+                lcoef.append(c)
+                lone.append(1 if np.array_equal(c, one) else 0)
+                ltab.append(ti)
+            foff.append(len(ltab))
+        goff.append(len(consts))
+    goff, foff = np.array(goff, dtype=np.uint32), np.array(foff, dtype=np.uint32)
+    consts_a = np.ascontiguousarray(np.stack(consts))
+    has_a = np.array(has_c, dtype=np.uint32)
+    ltab_a, lone_a = np.array(ltab, dtype=np.uint32), np.array(lone, dtype=np.uint32)
+    lcoef_a = np.ascontiguousarray(np.stack(lcoef))
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)
+    out = fr_array(8)
+    n_rounds = 0
+    while (1 << n_rounds) < tabs[0].shape[0]:
+        n_rounds += 1
+    lib().orc_baseline_member_sumcheck(ptrs, C.c_uint32(len(tabs)), C.c_size_t(tabs[0].shape[0]), C.c_uint32(len(groups)), _p(goff),
+                                       _p(foff), _p(consts_a), _p(has_a), _p(ltab_a), _p(lcoef_a), _p(lone_a), C.c_uint32(degree),
+                                       _p(ch), C.c_size_t(n_rounds), _p(out))
+    return out[:degree]

@@ -184,3 +184,38 @@ def test_full_size_sumcheck_properties(ctx):
                     O.fr_mul(O.fr_mul(g.reshape(1, 4), vals[0].reshape(1, 4)), vals[2].reshape(1, 4)))[0]
     assert np.array_equal(out["final_claim"], want)
     assert np.array_equal(dev.final_values(), np.stack(vals))
+
+
+def test_borrowed_members_leave_tables_intact_and_can_be_reset(ctx):
+    """BORROW members bind into their own scratch: the shared resident tables stay bit-identical, two members can
+    share one table, and a reset member re-proves to the same transcript."""
+    n_vars = 8
+    eq, a, b = [rand_fr(1 << n_vars, 8000 + k) for k in range(3)]
+    g = rand_fr(1, 8100)[0]
+    shared = [ctx.upload(t) for t in (eq, a, b)]
+    groups1 = [[(None, [(one(), 0)]), (None, [(one(), 1), (g, 2)])]]
+    groups2 = [[(None, [(one(), 0)]), (None, [(one(), 1)]), (None, [(one(), 2)])]]
+    for order in (ffi.ORDER_LOW_TO_HIGH, ffi.ORDER_HIGH_TO_LOW):
+        m1 = ctx.member_lc(shared, groups1, 2, order=order, borrow=True)
+        m2 = ctx.member_lc(shared, groups2, 3, order=order, borrow=True)
+        w = rand_fr(n_vars, 8200)
+        m3 = ctx.member_split_eq_product(shared[1], shared[2], w, borrow=True)
+        o1 = lambda: O.Member.expr([eq, a, b], [(one(), [0, 1]), (g, [0, 2])], 2, order)
+        o2 = lambda: O.Member.expr([eq, a, b], [(one(), [0, 1, 2])], 3, order)
+        o3 = lambda: O.Member.gruen_product(a, b, w)
+        for rep in range(2):
+            orcs = [o1(), o2(), o3()]
+            claims = [o.input_claim() for o in orcs]
+            coeffs = list(rand_fr(3, 8300))
+            want = O.prove_batch(orcs, claims, coeffs, [0, 0, 0], n_vars, 3, label=7 + rep)
+            got = ctx.prove_batch([m1, m2, m3], claims, coeffs, [0, 0, 0], n_vars, 3, label=7 + rep)
+            assert np.array_equal(got["polys"], want["polys"]) and np.array_equal(got["final_claim"], want["final_claim"])
+            for t, h in zip(shared, (eq, a, b)):
+                assert np.array_equal(t.download(), h)
+            for m in (m1, m2, m3):
+                m.reset()
+        for m in (m1, m2, m3):
+            m.destroy()
+    owned = ctx.member_expr([ctx.upload(a)], [(one(), [0])], 1)
+    with pytest.raises(ffi.JoltError):
+        owned.reset()
