@@ -39,12 +39,22 @@ Fr fr_from_scalar_challenge_bytes(const uint8_t* b, size_t n) {
 }
 
 // ---- UnivariatePoly ------------------------------------------------------------------------------------------
+// 1/k for the small integers Newton interpolation divides by (computed once: a Fermat inversion costs ~400 host multiplies)
+static const Fr& small_inverse(size_t k) {
+    static std::vector<Fr> table = [] {
+        std::vector<Fr> t(33, Fr::zero());
+        for (size_t i = 1; i < t.size(); ++i) t[i] = inv(fr_from_u64(i));
+        return t;
+    }();
+    return table[k];
+}
+
 UnivariatePoly UnivariatePoly::from_evals(const Fr* evals, size_t n) {
     // unique interpolant through (0,e0)..(n-1,e_{n-1}); the reference solves the Vandermonde system
     // (univariate.rs:198-202), here Newton's forward differences followed by basis expansion.
     std::vector<Fr> d(evals, evals + n);
     for (size_t k = 1; k < n; ++k) {
-        Fr kinv = inv(fr_from_u64(k));
+        Fr kinv = k < 33 ? small_inverse(k) : inv(fr_from_u64(k));
         for (size_t i = n - 1; i >= k; --i) d[i] = mul(sub(d[i], d[i - 1]), kinv);
     }
     std::vector<Fr> c(n, Fr::zero()), basis(1, Fr::one());
@@ -247,7 +257,7 @@ int32_t prove_batch(const BatchPrelude& prelude, std::vector<ProveRounds*>& memb
     }
     const size_t max_num_vars = prelude.max_num_vars;
     if (max_num_vars > 0 && prelude.max_degree < 1) return fail(JOLT_ERR_INVALID_ARG, 0);  // ZeroBatchDegree
-    const Fr two_inv = inv(fr_from_u64(2));
+    const Fr two_inv = small_inverse(2);
     std::vector<Fr> member_claims;
     for (const BatchMember& m : prelude.members) member_claims.push_back(fr_mul_pow_2(m.input_claim, max_num_vars - m.rounds));  // prover.rs:244-248
     Fr running_claim = prelude.claimed_sum;

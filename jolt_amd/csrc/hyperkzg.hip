@@ -1,0 +1,306 @@
+// jolt_amd/csrc/hyperkzg.hip -- HyperKZG prover pieces on gfx950 and the host-side mirror of commit/open.
+//
+// Device kernels replace the rayon / sequential loops of crates/jolt-hyperkzg/src/{scheme.rs,kzg.rs}:
+//   fold_polynomials            scheme.rs:88-114   -> out-of-place LowToHigh bind (same kernel as the sumcheck bind)
+//   eval_univariate x 3 points  kzg.rs:51-59,84-85 -> blocked Horner with per-block weights, one pass for the 3 points
+//   B = sum_j q^j P_j           kzg.rs:95-105      -> one fused pass over all levels
+//   compute_witness_polynomial  kzg.rs:34-46       -> the sequential recurrence h[i-1] = f[i] + h[i]*u as a blocked suffix
+//                                                     scan (exact: the recurrence is linear, chunks compose by mu^C)
+// All are HBM-bound streaming passes (<= 2 multiplies per element); the MSMs they feed dominate (msm.hip).
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "g1.cuh"
+#include "host_mirror.hpp"
+#include "poly_kernels.cuh"
+
+using namespace jolt;
+
+struct jolt_srs;
+int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out);
+
+namespace {
+
+constexpr int kHornerChunk = 16;
+
+struct Fr3 {
+    Fr v[3];
+};
+
+// partials[block*3 + t] = sum over this block's coefficients c[i] * u_t^i
+static __global__ __launch_bounds__(kBlock) void k_horner3(const Fr* __restrict__ c, size_t n, Fr3 u, Fr3 u_chunk /* u^16 */, Fr3 u_block /* u^4096 */,
+                                                           Fr* __restrict__ partials) {
+    size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHornerChunk;
+    Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+    if (base < n) {
+        size_t end = base + kHornerChunk < n ? base + kHornerChunk : n;
+        for (size_t i = end; i-- > base;) {
+            Fr ci = ld_fr(c + i);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = add(mul(acc[t], u.v[t]), ci);
+        }
+        // weight = (u^16)^tid * (u^4096)^blockIdx
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            Fr w = Fr::one(), b = u_chunk.v[t];
+            for (unsigned e = threadIdx.x; e; e >>= 1) {
+                if (e & 1) w = mul(w, b);
+                b = sqr(b);
+            }
+            b = u_block.v[t];
+            for (unsigned e = blockIdx.x; e; e >>= 1) {
+                if (e & 1) w = mul(w, b);
+                b = sqr(b);
+            }
+            acc[t] = mul(acc[t], w);
+        }
+    }
+    block_reduce_store<3>(acc, partials);
+}
+
+struct RlcArgs {
+    const Fr* level[40];
+    size_t len[40];
+    int ell;
+};
+// out[i] = sum_j q^j P_j[i] over the levels that still cover index i (qpow resident in device memory)
+static __global__ __launch_bounds__(kBlock) void k_rlc(RlcArgs a, const Fr* __restrict__ qpow, Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = ld_fr(a.level[0] + i);  // q^0 = 1
+    for (int j = 1; j < a.ell; ++j) {
+        if (i >= a.len[j]) break;  // lengths halve: no later level covers i either
+        acc = add(acc, mul(ld_fr(a.level[j] + i), ld_fr(qpow + j)));
+    }
+    st_fr(out + i, acc);
+}
+
+constexpr int kScanChunk = 64;
+// heads[c] = Horner of chunk c with zero carry-in: sum_{k in chunk} a[k] mu^(k - chunk_start)
+static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __restrict__ a, size_t m, Fr mu, Fr* __restrict__ heads, size_t nchunks) {
+    size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nchunks) return;
+    size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
+    Fr acc = Fr::zero();
+    for (size_t k = hi; k-- > lo;) acc = add(mul(acc, mu), ld_fr(a + k));
+    st_fr(heads + c, acc);
+}
+// s[k] = a[k] + mu*s[k+1] inside chunk c, starting from the true carry-in S[c+1]; writes s[k] to out[k - shift] (k >= shift)
+static __global__ __launch_bounds__(kBlock) void k_suffix_apply(const Fr* __restrict__ a, size_t m, Fr mu, const Fr* __restrict__ S, size_t nchunks,
+                                                                Fr* __restrict__ out, size_t shift) {
+    size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nchunks) return;
+    size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
+    Fr acc = (S != nullptr && c + 1 < nchunks) ? ld_fr(S + c + 1) : Fr::zero();
+    for (size_t k = hi; k-- > lo;) {
+        acc = add(mul(acc, mu), ld_fr(a + k));
+        if (k >= shift) st_fr(out + (k - shift), acc);
+    }
+}
+
+// s = suffix Horner of a (length m) with multiplier mu, written to out[k - shift]
+int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift) {
+    size_t nchunks = (m + kScanChunk - 1) / kScanChunk;
+    unsigned grid = (unsigned)((nchunks + kBlock - 1) / kBlock);
+    if (nchunks <= 1) {
+        hipLaunchKernelGGL(k_suffix_apply, dim3(1), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)nullptr, (size_t)1, out, shift);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        return JOLT_OK;
+    }
+    Fr *heads = nullptr, *S = nullptr;
+    JOLT_HIP_TRY(ctx, hipMalloc((void**)&heads, nchunks * sizeof(Fr)));
+    hipError_t e = hipMalloc((void**)&S, nchunks * sizeof(Fr));
+    if (e != hipSuccess) { (void)hipFree(heads); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_OOM; }
+    hipLaunchKernelGGL(k_suffix_heads, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, heads, nchunks);
+    Fr mu_c = mu;
+    for (int i = 0; i < 6; ++i) mu_c = sqr(mu_c);  // mu^64
+    int32_t s = suffix_horner(ctx, heads, nchunks, mu_c, S, 0);
+    if (s == JOLT_OK) {
+        hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift);
+        if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(heads);
+    (void)hipFree(S);
+    return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// device entry points
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t jolt_hyperkzg_fold(jolt_ctx* ctx, const jolt_table* evals, const jolt_fr_t* point, size_t ell, jolt_table** levels_out) {
+    if (!ctx || !evals || !point || !levels_out) return JOLT_ERR_INVALID_ARG;
+    if (ell == 0) return JOLT_ERR_EMPTY_POINT;
+    if (evals->len != ((size_t)1 << ell)) return JOLT_ERR_SIZE_MISMATCH;  // scheme.rs:133 assert
+    JOLT_TRY(jolt_table_clone(ctx, evals, &levels_out[0]));
+    for (size_t i = 1; i < ell; ++i) {  // fold i uses point[ell - i] (scheme.rs:97-98)
+        Fr x = fr_from_abi(&point[ell - i]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(x), "point coordinate is not a canonical Fr");
+        const jolt_table* prev = levels_out[i - 1];
+        size_t half = prev->len / 2;
+        jolt_table* nxt = nullptr;
+        JOLT_TRY(jolt_internal_table_new(ctx, half, &nxt));
+        BindBatch b;
+        b.in[0] = prev->data();
+        b.out[0] = nxt->data();
+        dim3 grid((unsigned)((half + kBlock - 1) / kBlock), 1);
+        if (fr_low_limbs_zero(x)) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, x);
+        else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, x);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        levels_out[i] = nxt;
+    }
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_hyperkzg_eval3(jolt_ctx* ctx, jolt_table* const* levels, size_t ell, const jolt_fr_t u[3], jolt_fr_t* v_out) {
+    if (!ctx || !levels || !u || !v_out || ell == 0 || ell > 40) return JOLT_ERR_INVALID_ARG;
+    Fr3 uu, u16, u4096;
+    for (int t = 0; t < 3; ++t) {
+        uu.v[t] = fr_from_abi(&u[t]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(uu.v[t]), "evaluation point is not a canonical Fr");
+        Fr p = uu.v[t];
+        for (int i = 0; i < 4; ++i) p = sqr(p);
+        u16.v[t] = p;
+        for (int i = 0; i < 8; ++i) p = sqr(p);
+        u4096.v[t] = p;
+    }
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
+    for (size_t j = 0; j < ell; ++j) {
+        const jolt_table* t = levels[j];
+        if (!t) return JOLT_ERR_INVALID_ARG;
+        size_t per_block = (size_t)kBlock * kHornerChunk;
+        int grid = (int)std::max<size_t>(1, (t->len + per_block - 1) / per_block);
+        JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 3, 3 * ell + 8));
+        hipLaunchKernelGGL(k_horner3, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, u16, u4096, ctx->d_partials);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * j);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, 3 * ell * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t j = 0; j < ell; ++j)
+        for (int t = 0; t < 3; ++t) fr_to_abi(&v_out[(size_t)t * ell + j], ctx->h_results[3 * j + t]);  // v[t][j], row-major
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_hyperkzg_rlc(jolt_ctx* ctx, jolt_table* const* levels, size_t ell, const jolt_fr_t* q, jolt_table** out) {
+    if (!ctx || !levels || !q || !out || ell == 0 || ell > 40) return JOLT_ERR_INVALID_ARG;
+    Fr qq = fr_from_abi(q);
+    JOLT_REQUIRE(ctx, fr_is_canonical(qq), "q is not a canonical Fr");
+    RlcArgs a;
+    a.ell = (int)ell;
+    std::vector<Fr> qpow(ell);
+    Fr cur = Fr::one();
+    for (size_t j = 0; j < 40; ++j) { a.level[j] = nullptr; a.len[j] = 0; }
+    for (size_t j = 0; j < ell; ++j) {  // challenge_powers (kzg.rs:213-221)
+        if (!levels[j]) return JOLT_ERR_INVALID_ARG;
+        if (j && levels[j]->len > levels[j - 1]->len) return JOLT_ERR_SIZE_MISMATCH;
+        a.level[j] = levels[j]->data();
+        a.len[j] = levels[j]->len;
+        qpow[j] = cur;
+        cur = mul(cur, qq);
+    }
+    size_t n = levels[0]->len;
+    jolt_table *res = nullptr, *dq = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, n, &res));
+    int32_t s = jolt_table_upload(ctx, reinterpret_cast<const jolt_fr_t*>(qpow.data()), ell, &dq);
+    if (s != JOLT_OK) { jolt_table_free(ctx, res); return s; }
+    hipLaunchKernelGGL(k_rlc, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, a, (const Fr*)dq->data(), res->data(), n);
+    hipError_t e = hipGetLastError();
+    jolt_table_free(ctx, dq);  // synchronises the stream
+    if (e != hipSuccess) { jolt_table_free(ctx, res); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    *out = res;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_hyperkzg_witness_poly(jolt_ctx* ctx, const jolt_table* f, const jolt_fr_t* u, jolt_table** out) {
+    if (!ctx || !f || !u || !out) return JOLT_ERR_INVALID_ARG;
+    Fr uu = fr_from_abi(u);
+    JOLT_REQUIRE(ctx, fr_is_canonical(uu), "u is not a canonical Fr");
+    size_t d = f->len;
+    jolt_table* h = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, d > 1 ? d - 1 : 0, &h));
+    if (d > 1) {
+        // h[k] = s[k+1] with s[k] = f[k] + u*s[k+1]  (kzg.rs:39-44)
+        int32_t s = suffix_horner(ctx, f->data(), d, uu, h->data(), 1);
+        if (s != JOLT_OK) { jolt_table_free(ctx, h); return s; }
+    }
+    *out = h;
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host mirror: HyperKZGScheme::{commit, open}
+// ------------------------------------------------------------------------------------------------------------------
+using namespace jolt_host;
+
+static void append_g1(Transcript& tr, const G1Jac& p) {
+    uint8_t b[32];
+    jolt_g1_t abi;
+    std::memcpy(&abi, &p, sizeof(abi));
+    jolt_host_g1_serialize_compressed(&abi, b);
+    tr.append_bytes(b, 32);
+}
+
+// CommitmentScheme::commit -> kzg_commit (scheme.rs:302-312, kzg.rs:15-27)
+extern "C" int32_t jolt_host_hyperkzg_commit(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, jolt_g1_t* out) {
+    if (!ctx || !srs || !evals || !out) return JOLT_ERR_INVALID_ARG;
+    G1Jac r;
+    JOLT_TRY(jolt_internal_msm(ctx, srs, evals->data(), evals->len, &r));  // SrsTooSmall when len > srs length
+    std::memcpy(out, &r, sizeof(r));
+    return JOLT_OK;
+}
+
+// HyperKZGScheme::open (scheme.rs:122-158) + kzg_open_batch (kzg.rs:69-126)
+extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                           uint64_t transcript_label, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    if (!ctx || !srs || !evals || !point || !w || !v || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
+    if (ell == 0) return JOLT_ERR_EMPTY_POINT;
+    if (ell > 40) return JOLT_ERR_UNSUPPORTED;
+    MockTranscript tr(transcript_label);
+    std::vector<jolt_table*> polys(ell, nullptr);
+    auto cleanup = [&](jolt_table* extra1 = nullptr, jolt_table* extra2 = nullptr) {
+        for (jolt_table* t : polys) if (t) jolt_table_free(ctx, t);
+        if (extra1) jolt_table_free(ctx, extra1);
+        if (extra2) jolt_table_free(ctx, extra2);
+    };
+    int32_t s = jolt_hyperkzg_fold(ctx, evals, point, ell, polys.data());  // phase 1
+    if (s != JOLT_OK) { cleanup(); return s; }
+    std::vector<G1Jac> coms(ell > 1 ? ell - 1 : 0);
+    for (size_t i = 1; i < ell; ++i) {  // scheme.rs:141-145
+        s = jolt_internal_msm(ctx, srs, polys[i]->data(), polys[i]->len, &coms[i - 1]);
+        if (s != JOLT_OK) { cleanup(); return s; }
+    }
+    for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
+    Fr r = tr.challenge();
+    Fr u[3] = {r, neg(r), mul(r, r)};
+    jolt_fr_t u_abi[3];
+    for (int t = 0; t < 3; ++t) fr_to_abi(&u_abi[t], u[t]);
+    s = jolt_hyperkzg_eval3(ctx, polys.data(), ell, u_abi, v);  // kzg.rs:84-85
+    if (s != JOLT_OK) { cleanup(); return s; }
+    for (int t = 0; t < 3; ++t)
+        for (size_t j = 0; j < ell; ++j) tr.append_fr(fr_from_abi(&v[(size_t)t * ell + j]));  // kzg.rs:88-92
+    Fr q = tr.challenge();
+    jolt_fr_t q_abi;
+    fr_to_abi(&q_abi, q);
+    jolt_table* b_poly = nullptr;
+    s = jolt_hyperkzg_rlc(ctx, polys.data(), ell, &q_abi, &b_poly);  // kzg.rs:95-105
+    if (s != JOLT_OK) { cleanup(); return s; }
+    G1Jac ws[3];
+    for (int t = 0; t < 3; ++t) {  // kzg.rs:108-116
+        jolt_table* h = nullptr;
+        s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[t], &h);
+        if (s == JOLT_OK) s = jolt_internal_msm(ctx, srs, h->data(), h->len, &ws[t]);
+        if (h) jolt_table_free(ctx, h);
+        if (s != JOLT_OK) { cleanup(b_poly); return s; }
+    }
+    for (int t = 0; t < 3; ++t) append_g1(tr, ws[t]);  // kzg.rs:118-124
+    Fr d0 = tr.challenge();
+    for (size_t i = 0; i + 1 < ell; ++i) std::memcpy(&com[i], &coms[i], sizeof(G1Jac));
+    for (int t = 0; t < 3; ++t) std::memcpy(&w[t], &ws[t], sizeof(G1Jac));
+    if (challenges_out) { fr_to_abi(&challenges_out[0], r); fr_to_abi(&challenges_out[1], q); fr_to_abi(&challenges_out[2], d0); }
+    cleanup(b_poly);
+    return JOLT_OK;
+}

@@ -43,7 +43,7 @@ struct BindBatch {
 // Polynomial::bind_low_to_high (crates/jolt-poly/src/dense.rs:223-303) for blockIdx.y-many tables in one launch:
 // out[y] = in[2y] + r*(in[2y+1]-in[2y]).  Algorithmic traffic 96 B per output (64 read + 32 written).
 template <bool SHIFTED>
-__global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b, size_t half, Fr r) {
+static __global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b, size_t half, Fr r) {
     const Fr* __restrict__ in = b.in[blockIdx.y];
     Fr* __restrict__ out = b.out[blockIdx.y];
     size_t stride = (size_t)gridDim.x * kBlock;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b, size_t
 
 // Polynomial::bind_high_to_low (dense.rs:188-220): in place, t[i] += r*(t[i+half]-t[i])
 template <bool SHIFTED>
-__global__ __launch_bounds__(kBlock) void k_bind_high_to_low(BindBatch b, size_t half, Fr r) {
+static __global__ __launch_bounds__(kBlock) void k_bind_high_to_low(BindBatch b, size_t half, Fr r) {
     const Fr* __restrict__ in = b.in[blockIdx.y];
     Fr* out = b.out[blockIdx.y];
     size_t stride = (size_t)gridDim.x * kBlock;
@@ -73,7 +73,7 @@ struct EqChunk {
     Fr r[8];
     int c;
 };
-__global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr* __restrict__ prev, Fr* __restrict__ out, size_t out_len, EqChunk ch) {
+static __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr* __restrict__ prev, Fr* __restrict__ out, size_t out_len, EqChunk ch) {
     __shared__ Fr L[256];
     const int c = ch.c;
     if ((int)threadIdx.x < (1 << c)) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr* __restrict__ pre
 // (lt.rs:19-21): with r = r_hi || r_lo,  LT(j_hi||j_lo, r) = LT(j_hi, r_hi) + eq(j_hi, r_hi) * LT(j_lo, r_lo).
 // out[x] = lt_hi[x>>c] + eq_hi[x>>c] * lt_lo[x & mask]; lt_lo (<= 256 entries) is built per block in LDS from
 // the closed form sum_i (1-x_i) r_i eq(x[..i], r[..i]) (lt.rs:126-137).
-__global__ __launch_bounds__(kBlock) void k_lt_expand(const Fr* __restrict__ lt_hi, const Fr* __restrict__ eq_hi, Fr* __restrict__ out,
+static __global__ __launch_bounds__(kBlock) void k_lt_expand(const Fr* __restrict__ lt_hi, const Fr* __restrict__ eq_hi, Fr* __restrict__ out,
                                                      size_t out_len, EqChunk ch) {
     __shared__ Fr L[256];
     const int c = ch.c;
@@ -133,7 +133,7 @@ struct EqP1Args {
     Fr lower[32];          // lower[i] = (1 - r[i]) * prod_{m>i} r[m]
     int n;
 };
-__global__ __launch_bounds__(kBlock) void k_eq_plus_one(EqP1Args a, Fr* __restrict__ out, size_t out_len) {
+static __global__ __launch_bounds__(kBlock) void k_eq_plus_one(EqP1Args a, Fr* __restrict__ out, size_t out_len) {
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < out_len; j += stride) {
         if (j == 0) { st_fr(out, Fr::zero()); continue; }
@@ -145,11 +145,11 @@ __global__ __launch_bounds__(kBlock) void k_eq_plus_one(EqP1Args a, Fr* __restri
 }
 
 // Ring::from_u64 / from_i64 per entry (crates/jolt-field/src/bn254/mod.rs:265-278): Montgomery form of the integer
-__global__ __launch_bounds__(kBlock) void k_from_u64(const uint64_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
+static __global__ __launch_bounds__(kBlock) void k_from_u64(const uint64_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) st_fr(out + i, fr_from_u64(in[i]));
 }
-__global__ __launch_bounds__(kBlock) void k_from_i64(const int64_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
+static __global__ __launch_bounds__(kBlock) void k_from_i64(const int64_t* __restrict__ in, Fr* __restrict__ out, size_t n) {
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         int64_t v = in[i];
@@ -187,7 +187,7 @@ __device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict
 }
 
 // second stage: out[t] = sum_b partials[b*ne + t]   (one block)
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr* __restrict__ partials, int nblocks, int ne, Fr* __restrict__ out) {
+static __global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr* __restrict__ partials, int nblocks, int ne, Fr* __restrict__ out) {
     __shared__ Fr sm[kBlock];
     for (int t = 0; t < ne; ++t) {
         Fr s = Fr::zero();
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr* __restrict
 
 // sum of a table / dot product with a second table (Polynomial::evaluate = dot with the eq table, dense.rs:340-366)
 template <bool DOT>
-__global__ __launch_bounds__(kBlock) void k_sum_or_dot(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ partials) {
+static __global__ __launch_bounds__(kBlock) void k_sum_or_dot(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ partials) {
     Fr acc[1] = {Fr::zero()};
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {

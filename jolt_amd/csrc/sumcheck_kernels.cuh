@@ -20,7 +20,7 @@ namespace jolt {
 // optimized tier's skipped-evals form, crates/jolt-kernels/src/optimized/support.rs:450-459).
 // ORDER 0: LowToHigh pairs (2y, 2y+1); ORDER 1: HighToLow pairs (y, y+half).
 template <int NE, int ORDER, bool SKIP1>
-__global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t half, Fr* __restrict__ partials) {
+static __global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t half, Fr* __restrict__ partials) {
     Fr acc[NE];
 #pragma unroll
     for (int t = 0; t < NE; ++t) acc[t] = Fr::zero();
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc* __rest
 // q(inf) = sum_rows E_out E_in (a_hi-a_lo)(b_hi-b_lo), row = (x_out << in_bits) | x_in over LowToHigh pairs
 // (crates/jolt-kernels/src/optimized/support.rs:391-411 over crates/jolt-poly/src/split_eq.rs:449-512).
 // eq is never materialised at size N: E_out, E_in are ~sqrt(N) tables that stay cache-resident.
-__global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ e_out,
+static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ e_out,
                                                             const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials) {
     Fr acc[2] = {Fr::zero(), Fr::zero()};
     size_t stride = (size_t)gridDim.x * kBlock;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restric
 }
 
 // summand summed over the whole hypercube (member input claim): same descriptor, no pairing
-__global__ __launch_bounds__(kBlock) void k_member_claim(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t len, Fr* __restrict__ partials) {
+static __global__ __launch_bounds__(kBlock) void k_member_claim(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t len, Fr* __restrict__ partials) {
     Fr acc[1] = {Fr::zero()};
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t x = (size_t)blockIdx.x * kBlock + threadIdx.x; x < len; x += stride) {

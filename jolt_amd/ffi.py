@@ -403,3 +403,133 @@ def host_gruen_poly_deg_3(scalar, point_i, q0, qinf, claim):
     _ck(lib().jolt_host_gruen_poly_deg_3(_p(fr(scalar)), _p(fr(point_i)), _p(fr(q0)), _p(fr(qinf)), _p(fr(claim)), _p(o)),
         "jolt_host_gruen_poly_deg_3")
     return o
+
+
+# ---- G1 / MSM / HyperKZG ---------------------------------------------------------------------------------------------
+class Srs:
+    """Device-resident affine bases (HyperKZGProverSetup.g1_powers)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_srs_len(self.h, C.byref(n)), "jolt_srs_len", self.ctx)
+        return n.value
+
+    def download(self, offset=0, n=None):
+        n = len(self) - offset if n is None else n
+        out = g1_array(n)
+        _ck(lib().jolt_srs_download(self.ctx.h, self.h, C.c_size_t(offset), C.c_size_t(n), _p(out)), "jolt_srs_download", self.ctx)
+        return out
+
+    def free(self):
+        if self.h and self.ctx.h:
+            lib().jolt_srs_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _srs_upload(self, bases):
+    b = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
+    h = C.c_void_p()
+    _ck(lib().jolt_srs_upload_g1(self.h, _p(b), C.c_size_t(b.shape[0]), C.byref(h)), "jolt_srs_upload_g1", self)
+    return Srs(self, h)
+
+
+def _srs_setup_from_secret(self, beta, count, g1):
+    h = C.c_void_p()
+    _ck(lib().jolt_srs_setup_from_secret(self.h, _p(fr(beta)), C.c_size_t(count), _p(np.ascontiguousarray(g1, dtype=np.uint64)), C.byref(h)),
+        "jolt_srs_setup_from_secret", self)
+    return Srs(self, h)
+
+
+def _msm(self, srs, scalars, n=None):
+    """JoltGroup::msm(bases = srs[..n], scalars); scalars = numpy (n,4) host array or a device Table."""
+    out = g1_array(1)
+    if isinstance(scalars, Table):
+        n = len(scalars) if n is None else n
+        _ck(lib().jolt_msm_g1_table(self.h, srs.h, scalars.h, C.c_size_t(n), _p(out)), "jolt_msm_g1_table", self)
+    else:
+        s = fr(scalars).reshape(-1, 4)
+        n = s.shape[0] if n is None else n
+        _ck(lib().jolt_msm_g1(self.h, srs.h, _p(s), C.c_size_t(n), _p(out)), "jolt_msm_g1", self)
+    return out[0]
+
+
+def _hyperkzg_fold(self, evals, point):
+    p = fr(point).reshape(-1, 4)
+    ell = p.shape[0]
+    hs = (C.c_void_p * max(ell, 1))()
+    _ck(lib().jolt_hyperkzg_fold(self.h, evals.h, _p(p), C.c_size_t(ell), hs), "jolt_hyperkzg_fold", self)
+    return [Table(self, C.c_void_p(hs[i])) for i in range(ell)]
+
+
+def _hyperkzg_eval3(self, levels, u):
+    hs = (C.c_void_p * len(levels))(*[t.h for t in levels])
+    uu = fr(u).reshape(3, 4)
+    out = fr_array(3 * len(levels))
+    _ck(lib().jolt_hyperkzg_eval3(self.h, hs, C.c_size_t(len(levels)), _p(uu), _p(out)), "jolt_hyperkzg_eval3", self)
+    return out.reshape(3, len(levels), 4)
+
+
+def _hyperkzg_rlc(self, levels, q):
+    hs = (C.c_void_p * len(levels))(*[t.h for t in levels])
+    h = C.c_void_p()
+    _ck(lib().jolt_hyperkzg_rlc(self.h, hs, C.c_size_t(len(levels)), _p(fr(q)), C.byref(h)), "jolt_hyperkzg_rlc", self)
+    return Table(self, h)
+
+
+def _hyperkzg_witness_poly(self, f, u):
+    h = C.c_void_p()
+    _ck(lib().jolt_hyperkzg_witness_poly(self.h, f.h, _p(fr(u)), C.byref(h)), "jolt_hyperkzg_witness_poly", self)
+    return Table(self, h)
+
+
+def _hyperkzg_commit(self, srs, evals):
+    out = g1_array(1)
+    _ck(lib().jolt_host_hyperkzg_commit(self.h, srs.h, evals.h, _p(out)), "jolt_host_hyperkzg_commit", self)
+    return out[0]
+
+
+def _hyperkzg_open(self, srs, evals, point, label=0):
+    p = fr(point).reshape(-1, 4)
+    ell = p.shape[0]
+    com, w, v, ch = g1_array(max(ell - 1, 1)), g1_array(3), fr_array(3 * max(ell, 1)), fr_array(3)
+    _ck(lib().jolt_host_hyperkzg_open(self.h, srs.h, evals.h, _p(p), C.c_size_t(ell), C.c_uint64(label), _p(com), _p(w), _p(v), _p(ch)),
+        "jolt_host_hyperkzg_open", self)
+    return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
+
+
+Context.srs_upload = _srs_upload
+Context.srs_setup_from_secret = _srs_setup_from_secret
+Context.msm = _msm
+Context.hyperkzg_fold = _hyperkzg_fold
+Context.hyperkzg_eval3 = _hyperkzg_eval3
+Context.hyperkzg_rlc = _hyperkzg_rlc
+Context.hyperkzg_witness_poly = _hyperkzg_witness_poly
+Context.hyperkzg_commit = _hyperkzg_commit
+Context.hyperkzg_open = _hyperkzg_open
+
+
+def host_g1_add(p, q):
+    o = g1_array(1)
+    _ck(lib().jolt_host_g1_add(_p(np.ascontiguousarray(p, dtype=np.uint64)), _p(np.ascontiguousarray(q, dtype=np.uint64)), _p(o)), "jolt_host_g1_add")
+    return o[0]
+
+
+def host_g1_eq(p, q):
+    e = C.c_int32()
+    _ck(lib().jolt_host_g1_eq(_p(np.ascontiguousarray(p, dtype=np.uint64)), _p(np.ascontiguousarray(q, dtype=np.uint64)), C.byref(e)), "jolt_host_g1_eq")
+    return bool(e.value)
+
+
+def host_g1_serialize_compressed(p):
+    out = (C.c_uint8 * 32)()
+    _ck(lib().jolt_host_g1_serialize_compressed(_p(np.ascontiguousarray(p, dtype=np.uint64)), out), "jolt_host_g1_serialize_compressed")
+    return bytes(out)

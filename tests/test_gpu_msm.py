@@ -1,0 +1,161 @@
+"""GPU parity: G1 MSM and the HyperKZG prover pieces through the C ABI vs the CPU oracle.
+Points are compared as group elements (the reference's PartialEq on Projective and its compressed-affine wire form):
+the Jacobian representative is free.  Mirrors crates/jolt-crypto/tests/group_laws.rs:69-78,135-146 and
+crates/jolt-hyperkzg/tests/commit_open_verify.rs."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from jolt_amd import ffi
+from util import rand_challenge, rand_fr
+
+pytestmark = pytest.mark.gpu
+R = O.R_MOD
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ffi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def srs_small(ctx):
+    beta = rand_fr(1, 77)[0]
+    host = O.srs_setup_from_secret(beta, 300)
+    return beta, host, ctx.srs_upload(host)
+
+
+def same_point(a, b):
+    return O.g1_eq(a, b) and O.g1_serialize_compressed(a) == O.g1_serialize_compressed(b)
+
+
+def test_srs_roundtrip_and_device_setup(ctx, srs_small):
+    beta, host, dev = srs_small
+    back = dev.download()
+    assert all(same_point(back[i], host[i]) for i in range(len(host)))
+    # device-side setup_from_secret == the reference's repeated scalar_mul (scheme.rs:54-73)
+    dev2 = ctx.srs_setup_from_secret(beta, 300, O.g1_generator())
+    back2 = dev2.download()
+    assert all(same_point(back2[i], host[i]) for i in range(300))
+    # identity among the bases survives the affine round trip
+    mixed = np.stack([host[0], O.g1_identity(), host[1]])
+    d3 = ctx.srs_upload(mixed).download()
+    assert O.g1_is_identity(d3[1]) and same_point(d3[2], host[1])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 257, 300])
+def test_msm_matches_oracle(ctx, srs_small, n):
+    _, host, dev = srs_small
+    scalars = rand_fr(n, 100 + n) if n else O.fr_array(0)
+    got = ctx.msm(dev, scalars)
+    want = O.g1_msm_pippenger(host[:n], scalars) if n else O.g1_identity()
+    assert same_point(got, want)
+    assert O.g1_on_curve(got)
+
+
+def test_msm_corner_scalars_and_repeated_bases(ctx):
+    rng = random.Random(5)
+    g = O.g1_generator()
+    b = O.g1_scalar_mul(g, O.to_mont([5])[0])
+    # repeated / negated / identity bases hit P+P, P+(-P) and infinity inside buckets
+    bases = np.stack([b, b, O.g1_neg(b), b, O.g1_identity(), b, O.g1_neg(b)] * 9)
+    vals = [7, 7, 7, 3, 11, 0, 1, R - 1, R - 2, 2**64 - 1, 2**128 + 5, 1 << 253] * 6
+    vals = vals[: len(bases)]
+    scalars = O.to_mont(vals)
+    dev = ctx.srs_upload(bases)
+    got = ctx.msm(dev, scalars)
+    assert same_point(got, O.g1_msm_naive(bases, scalars))
+    # all-equal digits: every point lands in the same bucket of each window (heavy-bucket path)
+    n = 2000
+    srs = ctx.srs_setup_from_secret(rand_fr(1, 9)[0], n, g)
+    host = srs.download()
+    ones = O.to_mont([1] * n)
+    assert same_point(ctx.msm(srs, ones), O.g1_msm_pippenger(host, ones))
+    same = np.repeat(rand_fr(1, 10), n, axis=0)
+    assert same_point(ctx.msm(srs, same), O.g1_msm_pippenger(host, same))
+    with pytest.raises(ffi.JoltError) as e:  # more scalars than bases: SrsTooSmall / the reference's length-mismatch panic
+        ctx.msm(srs, rand_fr(n + 1, 3))
+    assert e.value.status == 9
+
+
+def test_msm_small_scalars_and_device_table(ctx, srs_small):
+    _, host, dev = srs_small
+    small = O.fr_from_u64(np.arange(300, dtype=np.uint64) * 977 % 65536)  # witness-like <= 16-bit scalars
+    tab = ctx.upload(small)
+    assert same_point(ctx.msm(dev, tab), O.g1_msm_pippenger(host, small))
+    assert same_point(ctx.msm(dev, tab, n=100), O.g1_msm_pippenger(host[:100], small[:100]))
+
+
+def test_hyperkzg_pieces_match_oracle(ctx):
+    ell = 7
+    n = 1 << ell
+    evals, point = rand_fr(n, 200), np.stack([rand_challenge(210 + k) for k in range(ell)])
+    tab = ctx.upload(evals)
+    levels = ctx.hyperkzg_fold(tab, point)
+    want_levels = O.hyperkzg_fold_polynomials(evals, point)
+    assert [len(t) for t in levels] == [len(w) for w in want_levels]
+    for t, w in zip(levels, want_levels):
+        assert np.array_equal(t.download(), w)
+    u = rand_fr(3, 220)
+    v = ctx.hyperkzg_eval3(levels, u)
+    for t in range(3):
+        for j in range(ell):
+            assert np.array_equal(v[t, j], O.kzg_eval_univariate(want_levels[j], u[t]))
+    q = rand_fr(1, 230)[0]
+    b = ctx.hyperkzg_rlc(levels, q).download()
+    want_b = np.zeros((n, 4), dtype=np.uint64)
+    qj = O.to_mont([1])
+    for w in want_levels:
+        want_b[: len(w)] = O.fr_add(want_b[: len(w)], O.fr_mul(w, np.repeat(qj, len(w), axis=0)))
+        qj = O.fr_mul(qj, q.reshape(1, 4))
+    assert np.array_equal(b, want_b)
+    for m in (1, 2, 3, 64, 65, 128, 5000):  # chunk-boundary lengths of the suffix scan
+        f = rand_fr(m, 240 + m)
+        h = ctx.hyperkzg_witness_poly(ctx.upload(f), u[0])
+        assert len(h) == max(m - 1, 0)
+        if m > 1:
+            assert np.array_equal(h.download(), O.kzg_witness_polynomial(f, u[0]))
+    with pytest.raises(ffi.JoltError) as e:
+        ctx.hyperkzg_fold(tab, point[:0])
+    assert e.value.status == 10  # HyperKZGError::EmptyPoint
+
+
+@pytest.mark.parametrize("ell", [1, 2, 5, 8])
+def test_hyperkzg_commit_open_bit_exact_with_oracle(ctx, ell):
+    n = 1 << ell
+    beta = rand_fr(1, 300 + ell)[0]
+    host_srs = O.srs_setup_from_secret(beta, n + 1)
+    srs = ctx.srs_upload(host_srs)
+    evals, point = rand_fr(n, 310 + ell), np.stack([rand_challenge(320 + k) for k in range(ell)])
+    tab = ctx.upload(evals)
+    assert same_point(ctx.hyperkzg_commit(srs, tab), O.kzg_commit(evals, host_srs))
+    got = ctx.hyperkzg_open(srs, tab, point, label=9)
+    want = O.hyperkzg_open(host_srs, evals, point, label=9)
+    assert np.array_equal(got["challenges"], want["challenges"])  # transcripts agree byte for byte (compressed points + v)
+    assert np.array_equal(got["v"], want["v"])
+    for i in range(ell - 1):
+        assert same_point(got["com"][i], want["com"][i])
+    for t in range(3):
+        assert same_point(got["w"][t], want["w"][t])
+    small = ctx.srs_upload(host_srs[: n // 2 if n > 1 else 0])
+    with pytest.raises(ffi.JoltError) as e:
+        ctx.hyperkzg_commit(small, tab)
+    assert e.value.status == 9
+
+
+def test_full_size_msm_is_the_kzg_commitment(ctx):
+    """N = 2^20 terms (BASELINE configs[2] scale): commit(p) with bases beta^i*G must equal p(beta)*G
+    (size-independent identity; p(beta) from the oracle's Horner evaluation, one scalar multiplication)."""
+    n = 1 << 20
+    beta = rand_fr(1, 400)[0]
+    g = O.g1_generator()
+    srs = ctx.srs_setup_from_secret(beta, n, g)
+    for kind in ("full", "u64"):
+        scalars = rand_fr(n, 401) if kind == "full" else O.fr_from_u64(np.random.default_rng(402).integers(0, 2**64, size=n, dtype=np.uint64))
+        got = ctx.msm(srs, ctx.upload(scalars))
+        pbeta = O.kzg_eval_univariate(scalars, beta)
+        assert same_point(got, O.g1_scalar_mul(g, pbeta)), kind
