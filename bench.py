@@ -110,16 +110,16 @@ def cpu_baseline(log_t):
     # containers often expose more logical CPUs than they may use: calibrate the thread count on a tiny instance
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best_n, best_t = 1, None
-    for n in sorted({1, max(1, hw // 2), hw}):
+    for n in sorted({1, min(hw, 8), min(hw, 16), min(hw, 32), min(hw, 64), max(1, hw // 2), hw}):
         O.baseline_set_threads(n)
-        t = run(min(log_t, 11))
+        t = run(min(log_t, 14))
         if best_t is None or t < best_t:
             best_n, best_t = n, t
     O.baseline_set_threads(best_n)
     dt = run(log_t)
     return {"value": round((1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
             "sample": f"same 11-relation member mix at T=2^{log_t}, all rounds (bind + round sums), C port with OpenMP on {best_n} of "
-                      f"{hw} host threads (fastest of 1/{max(1, hw // 2)}/{hw}); {dt:.2f}s"}
+                      f"{hw} host threads (fastest of 1/8/16/32/64/{max(1, hw // 2)}/{hw} threads at T=2^14); {dt:.2f}s"}
 
 
 def main():

@@ -191,6 +191,8 @@ int32_t jolt_round_group_prove(jolt_ctx *ctx, jolt_member *const *members, size_
                                jolt_fr_t *evals_out, size_t evals_capacity);
 /* ProveRounds::finish_rounds (prover.rs:68-71) */
 int32_t jolt_member_finish(jolt_member *m, const jolt_fr_t *bind);
+/* RoundScheduler::batch_finish_rounds (prover.rs:116-119): the final binds of all members in as few launches as possible */
+int32_t jolt_round_group_finish(jolt_ctx *ctx, jolt_member *const *members, size_t n_members, const jolt_fr_t *const *binds);
 /* SumcheckKernel::output_claims (naive.rs:331-347): every table's fully bound value, in table order; the split-eq
  * member appends its bound eq scalar (k = n_tables (+1)).  JOLT_ERR_NOT_FULLY_BOUND before the last bind. */
 int32_t jolt_member_final_values(jolt_member *m, jolt_fr_t *out, size_t k);

@@ -252,22 +252,25 @@ extern "C" int32_t jolt_table_free(jolt_ctx* ctx, jolt_table* t) {
 // ------------------------------------------------------------------------------------------------------------------
 // bind
 // ------------------------------------------------------------------------------------------------------------------
+// Bind k tables (possibly of different lengths: members of different round counts share a batch round) with one
+// challenge: ceil(k/40) launches, blockIdx.y = table.
 int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r, int32_t order) {
     if (k == 0) return JOLT_OK;
-    size_t len = tables[0]->len;
     for (size_t i = 0; i < k; ++i) {
         if (!tables[i]) return JOLT_ERR_INVALID_ARG;
-        if (tables[i]->len != len) return JOLT_ERR_SIZE_MISMATCH;
+        if (tables[i]->len < 2) { ctx->last_error = "cannot bind a zero-variable polynomial"; return JOLT_ERR_INVALID_ARG; }  // dense.rs:190,225 assert
     }
-    if (len < 2) { ctx->last_error = "cannot bind a zero-variable polynomial"; return JOLT_ERR_INVALID_ARG; }  // dense.rs:190,225 assert
-    size_t half = len / 2;
     const bool shifted = fr_low_limbs_zero(r);
     for (size_t base = 0; base < k; base += kMaxBatchTables) {
         size_t cnt = std::min<size_t>(kMaxBatchTables, k - base);
         BindBatch b;
+        size_t max_half = 0;
         for (size_t i = 0; i < cnt; ++i) {
             jolt_table* t = tables[base + i];
+            size_t half = t->len / 2;
             b.in[i] = t->data();
+            b.half[i] = half;
+            max_half = std::max(max_half, half);
             if (order == JOLT_ORDER_LOW_TO_HIGH || t->cur < 0) {  // out of place (a borrowed view is never written)
                 JOLT_TRY(jolt_internal_table_ensure_alt(t, half));
                 b.out[i] = t->buf[t->cur < 0 ? 0 : 1 - t->cur];
@@ -276,20 +279,20 @@ int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, c
             }
         }
         // one output per thread: measured fastest (5.8 TB/s at 2^24, microbench) -- no grid-stride cap for bind
-        dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((half + kBlock - 1) / kBlock, 1u << 20)), (unsigned)cnt);
+        dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((max_half + kBlock - 1) / kBlock, 1u << 20)), (unsigned)cnt);
         if (order == JOLT_ORDER_LOW_TO_HIGH) {
-            if (shifted) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
-            else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
+            if (shifted) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, r);
+            else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, r);
         } else {
-            if (shifted) hipLaunchKernelGGL(k_bind_high_to_low<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
-            else hipLaunchKernelGGL(k_bind_high_to_low<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, r);
+            if (shifted) hipLaunchKernelGGL(k_bind_high_to_low<true>, grid, dim3(kBlock), 0, ctx->stream, b, r);
+            else hipLaunchKernelGGL(k_bind_high_to_low<false>, grid, dim3(kBlock), 0, ctx->stream, b, r);
         }
         JOLT_HIP_TRY(ctx, hipGetLastError());
         for (size_t i = 0; i < cnt; ++i) {
             jolt_table* t = tables[base + i];
             if (t->cur < 0) t->cur = 0;
             else if (order == JOLT_ORDER_LOW_TO_HIGH) t->cur = 1 - t->cur;
-            t->len = half;
+            t->len = t->len / 2;
         }
     }
     return JOLT_OK;
@@ -300,6 +303,10 @@ extern "C" int32_t jolt_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k,
     if (order != JOLT_ORDER_LOW_TO_HIGH && order != JOLT_ORDER_HIGH_TO_LOW) return JOLT_ERR_INVALID_ARG;
     Fr rr = fr_from_abi(r);
     JOLT_REQUIRE(ctx, fr_is_canonical(rr), "bind challenge is not a canonical Fr");
+    for (size_t i = 0; i < k; ++i) {
+        if (!tables[i]) return JOLT_ERR_INVALID_ARG;
+        if (tables[i]->len != tables[0]->len) return JOLT_ERR_SIZE_MISMATCH;
+    }
     return jolt_internal_bind(ctx, tables, k, rr, order);
 }
 
@@ -669,8 +676,9 @@ extern "C" int32_t jolt_member_degree(const jolt_member* m, uint32_t* degree) {
     return JOLT_OK;
 }
 
-// naive.rs:211-219 bind_tables (+ split_eq.rs:334-350 for the split-eq member)
-static int32_t member_bind(jolt_member* m, const Fr& c) {
+// naive.rs:211-219 bind_tables (+ split_eq.rs:334-350 for the split-eq member): host-side state only; the table
+// binds themselves are enqueued by the caller (grouped over members)
+static int32_t member_note_bind(jolt_member* m, const Fr& c) {
     if (m->bound >= m->rounds) { m->ctx->last_error = "member already fully bound"; return JOLT_ERR_INVALID_ARG; }
     if (m->kind == jolt_member::kSplitEqProduct) {
         size_t n = m->rounds;
@@ -683,24 +691,13 @@ static int32_t member_bind(jolt_member* m, const Fr& c) {
         if (n / 2 < current_index && m->e_in_bits > 0) m->e_in_bits -= 1;
         else if (0 < current_index && m->e_out_bits > 0) m->e_out_bits -= 1;
     }
-    JOLT_TRY(jolt_internal_bind(m->ctx, m->tables.data(), m->tables.size(), c, m->order));
     m->len /= 2;
     m->bound += 1;
     return JOLT_OK;
 }
-
-template <int ORDER, bool SKIP1>
-static void launch_round_evals(int ne, int grid, hipStream_t s, const MemberDesc* d, const TablePtrs& tp, size_t half, Fr* partials) {
-    switch (ne) {
-        case 1: hipLaunchKernelGGL((k_round_evals<1, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 2: hipLaunchKernelGGL((k_round_evals<2, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 3: hipLaunchKernelGGL((k_round_evals<3, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 4: hipLaunchKernelGGL((k_round_evals<4, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 5: hipLaunchKernelGGL((k_round_evals<5, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 6: hipLaunchKernelGGL((k_round_evals<6, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 7: hipLaunchKernelGGL((k_round_evals<7, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-        case 8: hipLaunchKernelGGL((k_round_evals<8, ORDER, SKIP1>), dim3(grid), dim3(kBlock), 0, s, d, tp, half, partials); break;
-    }
+static int32_t member_bind(jolt_member* m, const Fr& c) {
+    JOLT_TRY(member_note_bind(m, c));
+    return jolt_internal_bind(m->ctx, m->tables.data(), m->tables.size(), c, m->order);
 }
 
 size_t jolt_internal_member_n_evals(const jolt_member* m) {
@@ -708,33 +705,126 @@ size_t jolt_internal_member_n_evals(const jolt_member* m) {
     return m->skip_one ? m->degree : m->degree + 1;
 }
 
-// enqueue bind + round sums of one member; the sums land in ctx->d_results[slot..]
-static int32_t member_enqueue_round(jolt_member* m, const Fr* bind, size_t slot) {
-    jolt_ctx* ctx = m->ctx;
-    if (bind) JOLT_TRY(member_bind(m, *bind));
-    if (m->len < 2) { ctx->last_error = "prove_round on a fully bound member"; return JOLT_ERR_INVALID_ARG; }
-    size_t half = m->len / 2;
-    int grid = sweep_grid(ctx, half);
-    size_t ne = jolt_internal_member_n_evals(m);
-    JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 8, slot + 8));
-    if (m->kind == jolt_member::kExpr) {
-        TablePtrs tp;
-        for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
-        if (m->order == JOLT_ORDER_LOW_TO_HIGH) {
-            if (m->skip_one) launch_round_evals<0, true>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
-            else launch_round_evals<0, false>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
-        } else {
-            if (m->skip_one) launch_round_evals<1, true>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
-            else launch_round_evals<1, false>((int)ne, grid, ctx->stream, m->d_desc, tp, half, ctx->d_partials);
+template <int ORDER, bool SKIP1>
+static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGroupArgs& a, Fr* partials) {
+    switch (ne) {
+        case 1: hipLaunchKernelGGL((k_round_evals_group<1, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 2: hipLaunchKernelGGL((k_round_evals_group<2, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 3: hipLaunchKernelGGL((k_round_evals_group<3, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 4: hipLaunchKernelGGL((k_round_evals_group<4, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 5: hipLaunchKernelGGL((k_round_evals_group<5, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 6: hipLaunchKernelGGL((k_round_evals_group<6, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 7: hipLaunchKernelGGL((k_round_evals_group<7, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 8: hipLaunchKernelGGL((k_round_evals_group<8, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+    }
+}
+
+// Enqueue one batch round for n members: (1) every pending bind, grouped by challenge so that all tables of all
+// members go down in ceil(tables/40) launches; (2) the round sums, one launch per (NE, order, skip) class with
+// blockIdx.y = member; (3) ONE second-stage reduction launch for all members.  Results land in d_results at
+// consecutive slots in member order.
+static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
+    // ---- (1) binds
+    struct BindGroup { Fr r; int32_t order; std::vector<jolt_table*> tabs; };
+    std::vector<BindGroup> bgs;
+    for (size_t i = 0; i < n; ++i) {
+        if (!binds || !binds[i]) continue;
+        jolt_member* m = members[i];
+        JOLT_TRY(member_note_bind(m, *binds[i]));
+        BindGroup* g = nullptr;
+        for (BindGroup& c : bgs) if (c.order == m->order && c.r == *binds[i]) { g = &c; break; }
+        if (!g) { bgs.push_back(BindGroup{*binds[i], m->order, {}}); g = &bgs.back(); }
+        g->tabs.insert(g->tabs.end(), m->tables.begin(), m->tables.end());
+    }
+    for (BindGroup& g : bgs) JOLT_TRY(jolt_internal_bind(ctx, g.tabs.data(), g.tabs.size(), g.r, g.order));
+    // ---- (2) round sums
+    struct Item { size_t idx; int grid; size_t ne; uint32_t part_off; size_t slot; };
+    std::vector<Item> items(n);
+    size_t part_total = 0, slot = 0;
+    for (size_t i = 0; i < n; ++i) {
+        jolt_member* m = members[i];
+        if (m->len < 2) { ctx->last_error = "prove_round on a fully bound member"; return JOLT_ERR_INVALID_ARG; }
+        items[i].idx = i;
+        items[i].ne = jolt_internal_member_n_evals(m);
+        items[i].slot = slot;
+        slot += items[i].ne;
+    }
+    // classes of expr members sharing (ne, order, skip)
+    std::vector<bool> done(n, false);
+    struct Launch { RoundGroupArgs args; int ne, order, skip, count; unsigned grid; };
+    std::vector<Launch> launches;
+    for (size_t i = 0; i < n; ++i) {
+        jolt_member* m = members[i];
+        if (done[i] || m->kind != jolt_member::kExpr) continue;
+        Launch L;
+        L.ne = (int)items[i].ne; L.order = m->order; L.skip = m->skip_one ? 1 : 0; L.count = 0; L.grid = 1;
+        uint32_t tab_cursor = 0;
+        std::vector<size_t> in_class;
+        for (size_t j = i; j < n; ++j) {
+            jolt_member* mj = members[j];
+            if (done[j] || mj->kind != jolt_member::kExpr) continue;
+            if ((int)items[j].ne != L.ne || mj->order != L.order || (mj->skip_one ? 1 : 0) != L.skip) continue;
+            if (L.count == kMaxGroupMembers || tab_cursor + mj->tables.size() > (size_t)kMaxGroupTables) break;
+            L.args.desc[L.count] = mj->d_desc;
+            L.args.half[L.count] = mj->len / 2;
+            L.args.tab_off[L.count] = tab_cursor;
+            for (jolt_table* t : mj->tables) L.args.tabs[tab_cursor++] = t->data();
+            L.grid = std::max<unsigned>(L.grid, (unsigned)sweep_grid(ctx, mj->len / 2));
+            in_class.push_back(j);
+            done[j] = true;
+            L.count++;
         }
-    } else {
+        for (int c = 0; c < L.count; ++c) {
+            size_t j = in_class[c];
+            items[j].grid = (int)L.grid;
+            items[j].part_off = (uint32_t)part_total;
+            L.args.part_off[c] = (uint32_t)part_total;
+            part_total += (size_t)L.grid * items[j].ne;
+        }
+        launches.push_back(L);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (members[i]->kind != jolt_member::kSplitEqProduct) continue;
+        items[i].grid = sweep_grid(ctx, members[i]->len / 2);
+        items[i].part_off = (uint32_t)part_total;
+        part_total += (size_t)items[i].grid * 2;
+    }
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, part_total + 8, slot + 8));
+    for (Launch& L : launches) {
+        dim3 grid(L.grid, (unsigned)L.count);
+        if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
+            if (L.skip) launch_round_group<0, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
+            else launch_round_group<0, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
+        } else {
+            if (L.skip) launch_round_group<1, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
+            else launch_round_group<1, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
+        }
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    for (size_t i = 0; i < n; ++i) {
+        jolt_member* m = members[i];
+        if (m->kind != jolt_member::kSplitEqProduct) continue;
         const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
-        hipLaunchKernelGGL(k_split_eq_product, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)m->tables[0]->data(), (const Fr*)m->tables[1]->data(), e_out,
-                           e_in, (int)m->e_in_bits, half, ctx->d_partials);
+        hipLaunchKernelGGL(k_split_eq_product, dim3(items[i].grid), dim3(kBlock), 0, ctx->stream, (const Fr*)m->tables[0]->data(),
+                           (const Fr*)m->tables[1]->data(), e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + items[i].part_off);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
     }
-    JOLT_HIP_TRY(ctx, hipGetLastError());
-    return reduce_into_results(ctx, grid, (int)ne, slot);
+    // ---- (3) second-stage reduction, 24 members per launch
+    for (size_t base = 0; base < n; base += 24) {
+        ReduceGroupArgs ra;
+        size_t cnt = std::min<size_t>(24, n - base);
+        for (size_t k = 0; k < cnt; ++k) {
+            const Item& it = items[base + k];
+            ra.part_off[k] = it.part_off;
+            ra.nblocks[k] = (uint32_t)it.grid;
+            ra.ne[k] = (uint32_t)it.ne;
+            ra.slot[k] = (uint32_t)it.slot;
+        }
+        hipLaunchKernelGGL(k_reduce_partials_group, dim3((unsigned)cnt), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, ra, ctx->d_results);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    return JOLT_OK;
 }
 
 static void member_aux(const jolt_member* m, jolt_fr_t* aux) {
@@ -755,11 +845,13 @@ extern "C" int32_t jolt_member_prove_round(jolt_member* m, const jolt_fr_t* bind
     jolt_ctx* ctx = m->ctx;
     if (n_evals != jolt_internal_member_n_evals(m)) return JOLT_ERR_SIZE_MISMATCH;
     Fr b;
+    const Fr* bp = nullptr;
     if (bind) {
         b = fr_from_abi(bind);
         JOLT_REQUIRE(ctx, fr_is_canonical(b), "bind challenge is not a canonical Fr");
+        bp = &b;
     }
-    JOLT_TRY(member_enqueue_round(m, bind ? &b : nullptr, 0));
+    JOLT_TRY(group_enqueue(ctx, &m, 1, &bp));
     member_aux(m, aux_out);
     return fetch_results(ctx, n_evals, evals_out);
 }
@@ -773,20 +865,38 @@ extern "C" int32_t jolt_round_group_prove(jolt_ctx* ctx, jolt_member* const* mem
         total += jolt_internal_member_n_evals(members[i]);
     }
     if (total > cap) return JOLT_ERR_SIZE_MISMATCH;
-    JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, total + 8));
-    size_t slot = 0;
+    std::vector<Fr> bstore(n);
+    std::vector<const Fr*> bptr(n, nullptr);
     for (size_t i = 0; i < n; ++i) {
-        Fr b;
-        const Fr* bp = nullptr;
         if (binds && binds[i]) {
-            b = fr_from_abi(binds[i]);
-            JOLT_REQUIRE(ctx, fr_is_canonical(b), "bind challenge is not a canonical Fr");
-            bp = &b;
+            bstore[i] = fr_from_abi(binds[i]);
+            JOLT_REQUIRE(ctx, fr_is_canonical(bstore[i]), "bind challenge is not a canonical Fr");
+            bptr[i] = &bstore[i];
         }
-        JOLT_TRY(member_enqueue_round(members[i], bp, slot));
-        slot += jolt_internal_member_n_evals(members[i]);
     }
+    JOLT_TRY(group_enqueue(ctx, members, n, bptr.data()));
     return fetch_results(ctx, total, evals_out);  // ONE device->host copy and ONE sync for the whole batch round
+}
+
+// finish_rounds for a whole batch: every table of every member in ceil(tables/40) launches
+extern "C" int32_t jolt_round_group_finish(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds) {
+    if (!ctx || (!members && n) || !binds) return JOLT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n; ++i) {
+        if (!members[i] || !binds[i]) return JOLT_ERR_INVALID_ARG;
+        Fr b = fr_from_abi(binds[i]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(b), "bind challenge is not a canonical Fr");
+        // group consecutive members sharing challenge and order
+        size_t j = i;
+        std::vector<jolt_table*> tabs;
+        while (j < n && members[j] && binds[j] && fr_from_abi(binds[j]) == b && members[j]->order == members[i]->order) {
+            JOLT_TRY(member_note_bind(members[j], b));
+            tabs.insert(tabs.end(), members[j]->tables.begin(), members[j]->tables.end());
+            ++j;
+        }
+        JOLT_TRY(jolt_internal_bind(ctx, tabs.data(), tabs.size(), b, members[i]->order));
+        i = j - 1;
+    }
+    return JOLT_OK;
 }
 
 extern "C" int32_t jolt_member_finish(jolt_member* m, const jolt_fr_t* bind) {

@@ -231,8 +231,17 @@ int32_t DeviceGroupedRounds::batch_prove_round(std::vector<MemberRound>& work) {
     return JOLT_OK;
 }
 int32_t DeviceGroupedRounds::batch_finish_rounds(std::vector<MemberFinish>& finishes) {
-    for (MemberFinish& f : finishes) JOLT_TRY(f.member->finish_rounds(f.bind));
-    return JOLT_OK;
+    std::vector<jolt_member*> ms;
+    std::vector<jolt_fr_t> store(finishes.size());
+    std::vector<const jolt_fr_t*> binds;
+    for (size_t i = 0; i < finishes.size(); ++i) {
+        DeviceMember* dm = dynamic_cast<DeviceMember*>(finishes[i].member);
+        if (!dm) return JOLT_ERR_UNSUPPORTED;
+        ms.push_back(dm->m);
+        fr_to_abi(&store[i], finishes[i].bind);
+        binds.push_back(&store[i]);
+    }
+    return jolt_round_group_finish(ctx, ms.data(), ms.size(), binds.data());
 }
 
 // ---- prove_batch ---------------------------------------------------------------------------------------------

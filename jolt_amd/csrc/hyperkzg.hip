@@ -145,9 +145,10 @@ extern "C" int32_t jolt_hyperkzg_fold(jolt_ctx* ctx, const jolt_table* evals, co
         BindBatch b;
         b.in[0] = prev->data();
         b.out[0] = nxt->data();
+        b.half[0] = half;
         dim3 grid((unsigned)((half + kBlock - 1) / kBlock), 1);
-        if (fr_low_limbs_zero(x)) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, half, x);
-        else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, half, x);
+        if (fr_low_limbs_zero(x)) hipLaunchKernelGGL(k_bind_low_to_high<true>, grid, dim3(kBlock), 0, ctx->stream, b, x);
+        else hipLaunchKernelGGL(k_bind_low_to_high<false>, grid, dim3(kBlock), 0, ctx->stream, b, x);
         JOLT_HIP_TRY(ctx, hipGetLastError());
         levels_out[i] = nxt;
     }

@@ -38,14 +38,16 @@ __device__ __forceinline__ Fr bind_pair(const Fr& lo, const Fr& hi, const Fr& r)
 struct BindBatch {
     const Fr* in[kMaxBatchTables];
     Fr* out[kMaxBatchTables];
+    size_t half[kMaxBatchTables];  // output length per table (tables of different members may differ in a batch round)
 };
 
 // Polynomial::bind_low_to_high (crates/jolt-poly/src/dense.rs:223-303) for blockIdx.y-many tables in one launch:
 // out[y] = in[2y] + r*(in[2y+1]-in[2y]).  Algorithmic traffic 96 B per output (64 read + 32 written).
 template <bool SHIFTED>
-static __global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b, size_t half, Fr r) {
+static __global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b, Fr r) {
     const Fr* __restrict__ in = b.in[blockIdx.y];
     Fr* __restrict__ out = b.out[blockIdx.y];
+    const size_t half = b.half[blockIdx.y];
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t y = (size_t)blockIdx.x * kBlock + threadIdx.x; y < half; y += stride) {
         Fr lo = ld_fr(in + 2 * y), hi = ld_fr(in + 2 * y + 1);
@@ -55,9 +57,10 @@ static __global__ __launch_bounds__(kBlock) void k_bind_low_to_high(BindBatch b,
 
 // Polynomial::bind_high_to_low (dense.rs:188-220): in place, t[i] += r*(t[i+half]-t[i])
 template <bool SHIFTED>
-static __global__ __launch_bounds__(kBlock) void k_bind_high_to_low(BindBatch b, size_t half, Fr r) {
+static __global__ __launch_bounds__(kBlock) void k_bind_high_to_low(BindBatch b, Fr r) {
     const Fr* __restrict__ in = b.in[blockIdx.y];
     Fr* out = b.out[blockIdx.y];
+    const size_t half = b.half[blockIdx.y];
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < half; i += stride) {
         Fr lo = ld_fr(in + i), hi = ld_fr(in + i + half);
@@ -199,6 +202,40 @@ static __global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr* __r
             __syncthreads();
         }
         if (threadIdx.x == 0) st_fr(out + t, sm[0]);
+        __syncthreads();
+    }
+}
+
+// second stage for a whole batch round: blockIdx.x = member
+struct ReduceGroupArgs {
+    uint32_t part_off[24];
+    uint32_t nblocks[24];
+    uint32_t ne[24];
+    uint32_t slot[24];
+};
+static __global__ __launch_bounds__(kBlock) void k_reduce_partials_group(const Fr* __restrict__ partials, ReduceGroupArgs a, Fr* __restrict__ results) {
+    __shared__ Fr sm[kBlock / 64];
+    const int m = blockIdx.x;
+    const Fr* __restrict__ p = partials + a.part_off[m];
+    const int nblocks = (int)a.nblocks[m], ne = (int)a.ne[m];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = 0; t < ne; ++t) {
+        Fr s = Fr::zero();
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) s = add(s, ld_fr(p + (size_t)b * ne + t));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.l[k] = __shfl_xor(s.l[k], off, 64);
+            s = add(s, o);
+        }
+        if (lane == 0) sm[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Fr tot = sm[0];
+            for (int w = 1; w < kBlock / 64; ++w) tot = add(tot, sm[w]);
+            st_fr(results + a.slot[m] + t, tot);
+        }
         __syncthreads();
     }
 }

@@ -20,7 +20,8 @@ namespace jolt {
 // optimized tier's skipped-evals form, crates/jolt-kernels/src/optimized/support.rs:450-459).
 // ORDER 0: LowToHigh pairs (2y, 2y+1); ORDER 1: HighToLow pairs (y, y+half).
 template <int NE, int ORDER, bool SKIP1>
-static __global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t half, Fr* __restrict__ partials) {
+__device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ d, const Fr* const* __restrict__ tabs, size_t half,
+                                                 Fr* __restrict__ partials) {
     Fr acc[NE];
 #pragma unroll
     for (int t = 0; t < NE; ++t) acc[t] = Fr::zero();
@@ -38,7 +39,7 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc*
                 else { lo = Fr::zero(); hi = lo; }
                 const uint32_t k0 = d->fac_lc_off[f], k1 = d->fac_lc_off[f + 1];
                 for (uint32_t k = k0; k < k1; ++k) {
-                    const Fr* __restrict__ tp = tabs.p[d->lc_tab[k]];
+                    const Fr* __restrict__ tp = tabs[d->lc_tab[k]];
                     Fr a = ld_fr(tp + i_lo), b = ld_fr(tp + i_hi);
                     if (!d->lc_one[k]) {
                         Fr c = d->lc_coeff[k];
@@ -71,6 +72,23 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals(const MemberDesc*
         }
     }
     block_reduce_store<NE>(acc, partials);
+}
+
+// All members of one batch round that share (NE, ORDER, SKIP1) in ONE launch: blockIdx.y selects the member.
+// (Launch count per batch round drops from 3 per member to ~5 per stage; SURVEY.md section 7 "member group".)
+constexpr int kMaxGroupMembers = 16;
+constexpr int kMaxGroupTables = 96;
+struct RoundGroupArgs {
+    const Fr* tabs[kMaxGroupTables];  // flat: member m uses tabs[tab_off[m] ...]
+    const MemberDesc* desc[kMaxGroupMembers];
+    size_t half[kMaxGroupMembers];
+    uint32_t tab_off[kMaxGroupMembers];
+    uint32_t part_off[kMaxGroupMembers];  // offset (in Fr) of the member's partial sums
+};
+template <int NE, int ORDER, bool SKIP1>
+static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupArgs a, Fr* __restrict__ partials) {
+    const int m = blockIdx.y;
+    round_evals_body<NE, ORDER, SKIP1>(a.desc[m], a.tabs + a.tab_off[m], a.half[m], partials + a.part_off[m]);
 }
 
 // Split-eq product member (a6): q(0) = sum_rows E_out[x_out] E_in[x_in] a_lo b_lo,
