@@ -53,7 +53,17 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     }
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { delete ctx; return JOLT_ERR_HIP; }
     int32_t s = jolt_internal_ensure_scratch(ctx, 4096 * 8, 1024);
-    if (s != JOLT_OK) { delete ctx; return s; }
+    if (s == JOLT_OK) {
+        ctx->round_cap = 1024;
+        if (hipHostMalloc((void**)&ctx->h_round, ctx->round_cap * sizeof(Fr), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipMalloc((void**)&ctx->d_counters, 64 * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(ctx->d_counters, 0, 64 * sizeof(uint32_t)) != hipSuccess)
+            s = JOLT_ERR_HIP;
+        else
+            *ctx->h_flag = 0;
+    }
+    if (s != JOLT_OK) { jolt_ctx_destroy(ctx); return s; }
     *out = ctx;
     return JOLT_OK;
 }
@@ -65,6 +75,9 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+    if (ctx->h_round) (void)hipHostFree(ctx->h_round);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -706,16 +719,16 @@ size_t jolt_internal_member_n_evals(const jolt_member* m) {
 }
 
 template <int ORDER, bool SKIP1>
-static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGroupArgs& a, Fr* partials) {
+static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGroupArgs& a, Fr* partials, const RoundDone& rd) {
     switch (ne) {
-        case 1: hipLaunchKernelGGL((k_round_evals_group<1, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 2: hipLaunchKernelGGL((k_round_evals_group<2, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 3: hipLaunchKernelGGL((k_round_evals_group<3, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 4: hipLaunchKernelGGL((k_round_evals_group<4, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 5: hipLaunchKernelGGL((k_round_evals_group<5, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 6: hipLaunchKernelGGL((k_round_evals_group<6, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 7: hipLaunchKernelGGL((k_round_evals_group<7, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
-        case 8: hipLaunchKernelGGL((k_round_evals_group<8, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials); break;
+        case 1: hipLaunchKernelGGL((k_round_evals_group<1, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 2: hipLaunchKernelGGL((k_round_evals_group<2, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 3: hipLaunchKernelGGL((k_round_evals_group<3, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 4: hipLaunchKernelGGL((k_round_evals_group<4, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 5: hipLaunchKernelGGL((k_round_evals_group<5, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 6: hipLaunchKernelGGL((k_round_evals_group<6, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 7: hipLaunchKernelGGL((k_round_evals_group<7, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 8: hipLaunchKernelGGL((k_round_evals_group<8, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
     }
 }
 
@@ -779,6 +792,8 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             items[j].grid = (int)L.grid;
             items[j].part_off = (uint32_t)part_total;
             L.args.part_off[c] = (uint32_t)part_total;
+            L.args.ticket[c] = (uint32_t)(j % kGroupTicket);
+            L.args.slot[c] = (uint32_t)items[j].slot;
             part_total += (size_t)L.grid * items[j].ne;
         }
         launches.push_back(L);
@@ -790,14 +805,21 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         part_total += (size_t)items[i].grid * 2;
     }
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, part_total + 8, slot + 8));
+    if (n > (size_t)kGroupTicket || slot > ctx->round_cap) { ctx->last_error = "batch round too large (members/evals)"; return JOLT_ERR_UNSUPPORTED; }
+    RoundDone rd;
+    rd.counters = ctx->d_counters;
+    rd.results = ctx->h_round;
+    rd.flag = ctx->h_flag;
+    rd.seq = ++ctx->seq;
+    rd.group_total = (uint32_t)n;
     for (Launch& L : launches) {
         dim3 grid(L.grid, (unsigned)L.count);
         if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
-            if (L.skip) launch_round_group<0, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
-            else launch_round_group<0, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
+            if (L.skip) launch_round_group<0, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
+            else launch_round_group<0, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
         } else {
-            if (L.skip) launch_round_group<1, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
-            else launch_round_group<1, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials);
+            if (L.skip) launch_round_group<1, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
+            else launch_round_group<1, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
         }
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
@@ -807,23 +829,33 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
         hipLaunchKernelGGL(k_split_eq_product, dim3(items[i].grid), dim3(kBlock), 0, ctx->stream, (const Fr*)m->tables[0]->data(),
-                           (const Fr*)m->tables[1]->data(), e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + items[i].part_off);
+                           (const Fr*)m->tables[1]->data(), e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + items[i].part_off,
+                           (uint32_t)(i % kGroupTicket), (uint32_t)items[i].slot, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
-    // ---- (3) second-stage reduction, 24 members per launch
-    for (size_t base = 0; base < n; base += 24) {
-        ReduceGroupArgs ra;
-        size_t cnt = std::min<size_t>(24, n - base);
-        for (size_t k = 0; k < cnt; ++k) {
-            const Item& it = items[base + k];
-            ra.part_off[k] = it.part_off;
-            ra.nblocks[k] = (uint32_t)it.grid;
-            ra.ne[k] = (uint32_t)it.ne;
-            ra.slot[k] = (uint32_t)it.slot;
+    return JOLT_OK;
+}
+
+// Wait for the batch round enqueued last (spin on the host-mapped flag; fall back to a stream sync on timeout) and copy
+// its `count` round sums out of the pinned buffer.
+static int32_t round_wait(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
+    const uint64_t want = ctx->seq;
+    volatile uint64_t* flag = ctx->h_flag;
+    uint64_t spins = 0;
+    while (*flag != want) {
+        if (++spins > (1ull << 22)) {  // ~ tens of ms: something is off, ask the runtime
+            spins = 0;
+            hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (*flag == want) break;
+                ctx->last_error = "batch round finished without publishing its completion flag";
+                return JOLT_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) { ctx->last_error = std::string("batch round: ") + hipGetErrorString(q); return JOLT_ERR_HIP; }
         }
-        hipLaunchKernelGGL(k_reduce_partials_group, dim3((unsigned)cnt), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, ra, ctx->d_results);
-        JOLT_HIP_TRY(ctx, hipGetLastError());
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    std::memcpy(out, ctx->h_round, count * sizeof(Fr));
     return JOLT_OK;
 }
 
@@ -853,7 +885,7 @@ extern "C" int32_t jolt_member_prove_round(jolt_member* m, const jolt_fr_t* bind
     }
     JOLT_TRY(group_enqueue(ctx, &m, 1, &bp));
     member_aux(m, aux_out);
-    return fetch_results(ctx, n_evals, evals_out);
+    return round_wait(ctx, n_evals, evals_out);
 }
 
 extern "C" int32_t jolt_round_group_prove(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds, jolt_fr_t* evals_out,
@@ -875,7 +907,7 @@ extern "C" int32_t jolt_round_group_prove(jolt_ctx* ctx, jolt_member* const* mem
         }
     }
     JOLT_TRY(group_enqueue(ctx, members, n, bptr.data()));
-    return fetch_results(ctx, total, evals_out);  // ONE device->host copy and ONE sync for the whole batch round
+    return round_wait(ctx, total, evals_out);  // no copy, no stream sync: the last workgroup published the sums
 }
 
 // finish_rounds for a whole batch: every table of every member in ceil(tables/40) launches

@@ -29,6 +29,13 @@ struct jolt_ctx {
     Fr* h_results = nullptr;  // pinned
     size_t results_cap = 0;   // in Fr
     void* d_desc_scratch = nullptr;
+    // batch-round completion without a copy + stream sync: the last workgroup of a round writes the round sums straight
+    // into host-mapped pinned memory and then publishes a sequence number the host spins on
+    Fr* h_round = nullptr;          // pinned, device-mapped (fine-grained)
+    uint64_t* h_flag = nullptr;     // pinned, device-mapped
+    uint32_t* d_counters = nullptr; // [0..31] per-member tickets, [32] group ticket
+    uint64_t seq = 0;
+    size_t round_cap = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 };
 

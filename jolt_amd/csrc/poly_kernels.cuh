@@ -189,6 +189,64 @@ __device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict
     }
 }
 
+// ---- in-kernel completion of a batch round ------------------------------------------------------------------------
+// Called by every workgroup after block_reduce_store.  The LAST workgroup of a member (agent-scope release/acquire
+// around a ticket counter, MI355X guide G16) sums that member's per-block partials and writes the round sums directly
+// into host-mapped pinned memory; the last MEMBER of the round then publishes `seq` to the host flag.  This replaces
+// a second-stage kernel + device->host copy + stream synchronise per round with zero extra launches.
+constexpr int kGroupTicket = 32;
+struct RoundDone {
+    uint32_t* counters;   // device memory, zero between rounds
+    Fr* results;          // host-mapped pinned memory
+    uint64_t* flag;       // host-mapped pinned memory
+    uint64_t seq;
+    uint32_t group_total; // members in this batch round
+};
+__device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, int ne, uint32_t member_ticket, uint32_t slot, const RoundDone& rd) {
+    __shared__ uint32_t s_last;
+    __shared__ Fr s_red[kBlock / 64];
+    __syncthreads();  // this block's partials are written (block_reduce_store ends with the stores of threads < NE)
+    if (threadIdx.x == 0) {
+        __threadfence();  // release: partials visible at agent scope before the ticket
+        uint32_t t = atomicAdd(&rd.counters[member_ticket], 1u);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // acquire: drop stale L1 lines before reading the other blocks' partials
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblocks = (int)gridDim.x;
+    for (int t = 0; t < ne; ++t) {
+        Fr s = Fr::zero();
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) s = add(s, ld_fr(partials + (size_t)b * ne + t));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.l[k] = __shfl_xor(s.l[k], off, 64);
+            s = add(s, o);
+        }
+        if (lane == 0) s_red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Fr tot = s_red[0];
+            for (int w = 1; w < kBlock / 64; ++w) tot = add(tot, s_red[w]);
+            st_fr(rd.results + slot + t, tot);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rd.counters[member_ticket] = 0;  // ready for the next round
+        __threadfence_system();          // round sums reach host memory before the group ticket / flag
+        uint32_t g = atomicAdd(&rd.counters[kGroupTicket], 1u);
+        if (g == rd.group_total - 1) {
+            rd.counters[kGroupTicket] = 0;
+            __threadfence_system();
+            __hip_atomic_store(rd.flag, rd.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // second stage: out[t] = sum_b partials[b*ne + t]   (one block)
 static __global__ __launch_bounds__(kBlock) void k_reduce_partials(const Fr* __restrict__ partials, int nblocks, int ne, Fr* __restrict__ out) {
     __shared__ Fr sm[kBlock];

@@ -84,11 +84,14 @@ struct RoundGroupArgs {
     size_t half[kMaxGroupMembers];
     uint32_t tab_off[kMaxGroupMembers];
     uint32_t part_off[kMaxGroupMembers];  // offset (in Fr) of the member's partial sums
+    uint32_t ticket[kMaxGroupMembers];    // per-member ticket counter index
+    uint32_t slot[kMaxGroupMembers];      // result slot of the member's first sum
 };
 template <int NE, int ORDER, bool SKIP1>
-static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupArgs a, Fr* __restrict__ partials) {
+static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupArgs a, Fr* __restrict__ partials, RoundDone rd) {
     const int m = blockIdx.y;
     round_evals_body<NE, ORDER, SKIP1>(a.desc[m], a.tabs + a.tab_off[m], a.half[m], partials + a.part_off[m]);
+    finish_member(partials + a.part_off[m], NE, a.ticket[m], a.slot[m], rd);
 }
 
 // Split-eq product member (a6): q(0) = sum_rows E_out[x_out] E_in[x_in] a_lo b_lo,
@@ -96,7 +99,8 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupA
 // (crates/jolt-kernels/src/optimized/support.rs:391-411 over crates/jolt-poly/src/split_eq.rs:449-512).
 // eq is never materialised at size N: E_out, E_in are ~sqrt(N) tables that stay cache-resident.
 static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ e_out,
-                                                            const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials) {
+                                                            const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials,
+                                                            uint32_t ticket, uint32_t slot, RoundDone rd) {
     Fr acc[2] = {Fr::zero(), Fr::zero()};
     size_t stride = (size_t)gridDim.x * kBlock;
     size_t mask = ((size_t)1 << in_bits) - 1;
@@ -108,6 +112,7 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __
         acc[1] = add(acc[1], mul(e, mul(sub(a_hi, a_lo), sub(b_hi, b_lo))));
     }
     block_reduce_store<2>(acc, partials);
+    finish_member(partials, 2, ticket, slot, rd);
 }
 
 // summand summed over the whole hypercube (member input claim): same descriptor, no pairing
