@@ -762,8 +762,50 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         items[i].slot = slot;
         slot += items[i].ne;
     }
-    // classes of expr members sharing (ne, order, skip)
+    // tail rounds: every expr member with few pairs left goes into ONE launch (work item = pair x group x point)
+    constexpr size_t kTailPairs = 4096;
     std::vector<bool> done(n, false);
+    struct TailLaunch { TailArgs args; int count; unsigned gx, gz; };
+    std::vector<TailLaunch> tails;
+    {
+        TailLaunch T;
+        T.count = 0; T.gx = 1; T.gz = 1;
+        uint32_t tab_cursor = 0;
+        auto flush = [&]() { if (T.count) tails.push_back(T); T.count = 0; T.gx = 1; T.gz = 1; tab_cursor = 0; };
+        for (size_t i = 0; i < n; ++i) {
+            jolt_member* m = members[i];
+            if (m->kind != jolt_member::kExpr || m->len / 2 > kTailPairs) continue;
+            if (T.count == kMaxGroupMembers || tab_cursor + m->tables.size() > (size_t)kMaxGroupTables) flush();
+            int c = T.count++;
+            T.args.g.desc[c] = m->d_desc;
+            T.args.g.half[c] = m->len / 2;
+            T.args.g.tab_off[c] = tab_cursor;
+            for (jolt_table* t : m->tables) T.args.g.tabs[tab_cursor++] = t->data();
+            T.args.ne[c] = (uint32_t)items[i].ne;
+            T.args.order[c] = (uint32_t)m->order;
+            T.args.skip[c] = m->skip_one ? 1u : 0u;
+            T.args.g.ticket[c] = (uint32_t)(i % kGroupTicket);
+            T.args.g.slot[c] = (uint32_t)items[i].slot;
+            size_t work = (m->len / 2) * std::max<uint32_t>(1, m->desc.n_groups);
+            T.gx = std::max<unsigned>(T.gx, (unsigned)std::min<size_t>((work + kBlock - 1) / kBlock, 256));
+            T.gz = std::max<unsigned>(T.gz, (unsigned)items[i].ne);
+            items[i].grid = -1 - c;  // resolved after gx is final
+            done[i] = true;
+            // remember which tail launch this member belongs to through part_off (filled below)
+            items[i].part_off = (uint32_t)tails.size();
+        }
+        flush();
+        for (size_t i = 0; i < n; ++i) {
+            if (!done[i]) continue;
+            TailLaunch& L = tails[items[i].part_off];
+            int c = -1 - items[i].grid;
+            items[i].grid = (int)L.gx;
+            items[i].part_off = (uint32_t)part_total;
+            L.args.g.part_off[c] = (uint32_t)part_total;
+            part_total += (size_t)L.gx * items[i].ne;
+        }
+    }
+    // classes of the remaining expr members sharing (ne, order, skip)
     struct Launch { RoundGroupArgs args; int ne, order, skip, count; unsigned grid; };
     std::vector<Launch> launches;
     for (size_t i = 0; i < n; ++i) {
@@ -812,6 +854,10 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     rd.flag = ctx->h_flag;
     rd.seq = ++ctx->seq;
     rd.group_total = (uint32_t)n;
+    for (TailLaunch& T : tails) {
+        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, ctx->stream, T.args, ctx->d_partials, rd);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
     for (Launch& L : launches) {
         dim3 grid(L.grid, (unsigned)L.count);
         if (L.order == JOLT_ORDER_LOW_TO_HIGH) {

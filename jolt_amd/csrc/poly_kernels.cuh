@@ -202,23 +202,27 @@ struct RoundDone {
     uint64_t seq;
     uint32_t group_total; // members in this batch round
 };
-__device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, int ne, uint32_t member_ticket, uint32_t slot, const RoundDone& rd) {
+// LAYOUT_T_MAJOR = false: partials[b*ne + t] from gridDim.x blocks; true: partials[t*nblocks + b] with `expected` tickets.
+template <bool LAYOUT_T_MAJOR = false>
+__device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, int ne, uint32_t member_ticket, uint32_t slot, const RoundDone& rd,
+                                              int nblocks_arg = 0, uint32_t expected = 0) {
     __shared__ uint32_t s_last;
     __shared__ Fr s_red[kBlock / 64];
     __syncthreads();  // this block's partials are written (block_reduce_store ends with the stores of threads < NE)
     if (threadIdx.x == 0) {
         __threadfence();  // release: partials visible at agent scope before the ticket
         uint32_t t = atomicAdd(&rd.counters[member_ticket], 1u);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        s_last = (t == (LAYOUT_T_MAJOR ? expected : gridDim.x) - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();  // acquire: drop stale L1 lines before reading the other blocks' partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nblocks = (int)gridDim.x;
+    const int nblocks = LAYOUT_T_MAJOR ? nblocks_arg : (int)gridDim.x;
     for (int t = 0; t < ne; ++t) {
         Fr s = Fr::zero();
-        for (int b = threadIdx.x; b < nblocks; b += kBlock) s = add(s, ld_fr(partials + (size_t)b * ne + t));
+        for (int b = threadIdx.x; b < nblocks; b += kBlock)
+            s = add(s, ld_fr(partials + (LAYOUT_T_MAJOR ? (size_t)t * nblocks + b : (size_t)b * ne + t)));
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             Fr o;

@@ -94,6 +94,59 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupA
     finish_member(partials + a.part_off[m], NE, a.ticket[m], a.slot[m], rd);
 }
 
+// Tail rounds (few pairs left): the per-pair work of a big summand is a serial chain of ~100+ multiplies, which made a
+// round cost ~50-230 us however small the tables were.  Here every (pair, group, evaluation point) is its own work
+// item and ALL expr members of the round share one launch (blockIdx.y = member, blockIdx.z = evaluation point), so
+// the floor is one short chain (~ #factors multiplies) instead of the sum over classes.
+struct TailArgs {
+    RoundGroupArgs g;
+    uint32_t ne[kMaxGroupMembers];
+    uint32_t order[kMaxGroupMembers];
+    uint32_t skip[kMaxGroupMembers];
+};
+static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, Fr* __restrict__ partials, RoundDone rd) {
+    const int m = blockIdx.y;
+    const uint32_t t = blockIdx.z, ne = a.ne[m];
+    if (t >= ne) return;
+    const MemberDesc* __restrict__ d = a.g.desc[m];
+    const Fr* const* __restrict__ tabs = a.g.tabs + a.g.tab_off[m];
+    const size_t half = a.g.half[m];
+    const uint32_t ng = d->n_groups;
+    const bool l2h = a.order[m] == 0;
+    const uint32_t point = (a.skip[m] && t >= 1) ? t + 1 : t;
+    Fr acc[1] = {Fr::zero()};
+    const size_t items = half * ng;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += stride) {
+        const size_t y = i / ng;
+        const uint32_t g = (uint32_t)(i - y * ng);
+        const size_t i_lo = l2h ? 2 * y : y, i_hi = l2h ? 2 * y + 1 : y + half;
+        Fr prod = Fr::one();
+        const uint32_t f0 = d->grp_fac_off[g], f1 = d->grp_fac_off[g + 1];
+        for (uint32_t f = f0; f < f1; ++f) {
+            Fr lo = d->fac_has_const[f] ? d->fac_const[f] : Fr::zero(), hi = lo;
+            for (uint32_t k = d->fac_lc_off[f]; k < d->fac_lc_off[f + 1]; ++k) {
+                const Fr* __restrict__ tp = tabs[d->lc_tab[k]];
+                Fr x = ld_fr(tp + i_lo), z = ld_fr(tp + i_hi);
+                if (!d->lc_one[k]) {
+                    Fr c = d->lc_coeff[k];
+                    x = mul(x, c);
+                    z = mul(z, c);
+                }
+                lo = add(lo, x);
+                hi = add(hi, z);
+            }
+            Fr step = sub(hi, lo), v = lo;
+            for (uint32_t q = 0; q < point; ++q) v = add(v, step);
+            prod = f == f0 ? v : mul(prod, v);
+        }
+        acc[0] = add(acc[0], prod);
+    }
+    Fr* mine = partials + a.g.part_off[m];
+    block_reduce_store<1>(acc, mine + (size_t)t * gridDim.x);
+    finish_member<true>(mine, (int)ne, a.g.ticket[m], a.g.slot[m], rd, (int)gridDim.x, gridDim.x * ne);
+}
+
 // Split-eq product member (a6): q(0) = sum_rows E_out[x_out] E_in[x_in] a_lo b_lo,
 // q(inf) = sum_rows E_out E_in (a_hi-a_lo)(b_hi-b_lo), row = (x_out << in_bits) | x_in over LowToHigh pairs
 // (crates/jolt-kernels/src/optimized/support.rs:391-411 over crates/jolt-poly/src/split_eq.rs:449-512).
