@@ -824,7 +824,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             L.args.half[L.count] = mj->len / 2;
             L.args.tab_off[L.count] = tab_cursor;
             for (jolt_table* t : mj->tables) L.args.tabs[tab_cursor++] = t->data();
-            L.grid = std::max<unsigned>(L.grid, (unsigned)sweep_grid(ctx, mj->len / 2));
+            L.grid = std::max<unsigned>(L.grid, (unsigned)sweep_grid(ctx, (mj->len / 2) * std::max<uint32_t>(1, mj->desc.n_groups)));
             in_class.push_back(j);
             done[j] = true;
             L.count++;

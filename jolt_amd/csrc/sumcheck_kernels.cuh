@@ -25,51 +25,55 @@ __device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ 
     Fr acc[NE];
 #pragma unroll
     for (int t = 0; t < NE; ++t) acc[t] = Fr::zero();
+    // Work item = (group g, pair y), g slowest: a wave shares g (descriptor reads stay scalar) and walks consecutive pairs
+    // (same coalescing as a per-pair sweep), while a summand with many groups exposes groups x pairs parallelism --
+    // per-pair work of a big summand is a serial chain of >100 multiplies, which left mid-size rounds latency bound.
     const uint32_t n_groups = d->n_groups;
+    const size_t items = half * n_groups;
     size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t y = (size_t)blockIdx.x * kBlock + threadIdx.x; y < half; y += stride) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += stride) {
+        const uint32_t g = (uint32_t)(i / half);
+        const size_t y = i - (size_t)g * half;
         const size_t i_lo = ORDER == 0 ? 2 * y : y;
         const size_t i_hi = ORDER == 0 ? 2 * y + 1 : y + half;
-        for (uint32_t g = 0; g < n_groups; ++g) {
-            Fr prod[NE];
-            const uint32_t f0 = d->grp_fac_off[g], f1 = d->grp_fac_off[g + 1];
-            for (uint32_t f = f0; f < f1; ++f) {
-                Fr lo, hi;
-                if (d->fac_has_const[f]) { lo = d->fac_const[f]; hi = lo; }
-                else { lo = Fr::zero(); hi = lo; }
-                const uint32_t k0 = d->fac_lc_off[f], k1 = d->fac_lc_off[f + 1];
-                for (uint32_t k = k0; k < k1; ++k) {
-                    const Fr* __restrict__ tp = tabs[d->lc_tab[k]];
-                    Fr a = ld_fr(tp + i_lo), b = ld_fr(tp + i_hi);
-                    if (!d->lc_one[k]) {
-                        Fr c = d->lc_coeff[k];
-                        a = mul(a, c);
-                        b = mul(b, c);
-                    }
-                    lo = add(lo, a);
-                    hi = add(hi, b);
+        Fr prod[NE];
+        const uint32_t f0 = d->grp_fac_off[g], f1 = d->grp_fac_off[g + 1];
+        for (uint32_t f = f0; f < f1; ++f) {
+            Fr lo, hi;
+            if (d->fac_has_const[f]) { lo = d->fac_const[f]; hi = lo; }
+            else { lo = Fr::zero(); hi = lo; }
+            const uint32_t k0 = d->fac_lc_off[f], k1 = d->fac_lc_off[f + 1];
+            for (uint32_t k = k0; k < k1; ++k) {
+                const Fr* __restrict__ tp = tabs[d->lc_tab[k]];
+                Fr a = ld_fr(tp + i_lo), b = ld_fr(tp + i_hi);
+                if (!d->lc_one[k]) {
+                    Fr c = d->lc_coeff[k];
+                    a = mul(a, c);
+                    b = mul(b, c);
                 }
-                Fr step = sub(hi, lo);
-                Fr v = lo;
-                if (f == f0) {
-                    prod[0] = v;
-                    if constexpr (SKIP1) v = add(v, step);
-#pragma unroll
-                    for (int t = 1; t < NE; ++t) { v = add(v, step); prod[t] = v; }
-                } else {
-                    prod[0] = mul(prod[0], v);
-                    if constexpr (SKIP1) v = add(v, step);
-#pragma unroll
-                    for (int t = 1; t < NE; ++t) { v = add(v, step); prod[t] = mul(prod[t], v); }
-                }
+                lo = add(lo, a);
+                hi = add(hi, b);
             }
-            if (f1 == f0) {  // empty product: the constant one
+            Fr step = sub(hi, lo);
+            Fr v = lo;
+            if (f == f0) {
+                prod[0] = v;
+                if constexpr (SKIP1) v = add(v, step);
 #pragma unroll
-                for (int t = 0; t < NE; ++t) prod[t] = Fr::one();
+                for (int t = 1; t < NE; ++t) { v = add(v, step); prod[t] = v; }
+            } else {
+                prod[0] = mul(prod[0], v);
+                if constexpr (SKIP1) v = add(v, step);
+#pragma unroll
+                for (int t = 1; t < NE; ++t) { v = add(v, step); prod[t] = mul(prod[t], v); }
             }
-#pragma unroll
-            for (int t = 0; t < NE; ++t) acc[t] = add(acc[t], prod[t]);
         }
+        if (f1 == f0) {  // empty product: the constant one
+#pragma unroll
+            for (int t = 0; t < NE; ++t) prod[t] = Fr::one();
+        }
+#pragma unroll
+        for (int t = 0; t < NE; ++t) acc[t] = add(acc[t], prod[t]);
     }
     block_reduce_store<NE>(acc, partials);
 }
@@ -118,8 +122,8 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, 
     const size_t items = half * ng;
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += stride) {
-        const size_t y = i / ng;
-        const uint32_t g = (uint32_t)(i - y * ng);
+        const uint32_t g = (uint32_t)(i / half);  // g slowest: lanes of a wave mostly share the group
+        const size_t y = i - (size_t)g * half;
         const size_t i_lo = l2h ? 2 * y : y, i_hi = l2h ? 2 * y + 1 : y + half;
         Fr prod = Fr::one();
         const uint32_t f0 = d->grp_fac_off[g], f1 = d->grp_fac_off[g + 1];
