@@ -93,6 +93,9 @@ int32_t jolt_table_download(jolt_ctx *ctx, const jolt_table *t, size_t offset, s
 int32_t jolt_table_len(const jolt_table *t, size_t *len);
 int32_t jolt_table_device_ptr(const jolt_table *t, void **device_ptr); /* current evaluations, len*32 bytes */
 int32_t jolt_table_free(jolt_ctx *ctx, jolt_table *t);
+/* A read-only view of entries [offset, offset+len) of `parent` (which must outlive it); overwrite a range from the host. */
+int32_t jolt_table_slice(jolt_ctx *ctx, const jolt_table *parent, size_t offset, size_t len, jolt_table **out);
+int32_t jolt_table_write(jolt_ctx *ctx, jolt_table *t, size_t offset, const jolt_fr_t *host, size_t len);
 
 /* Polynomial::bind_with_order on k tables in ONE launch (dense.rs:178-263; optimized/support.rs:224-231 bind_all):
  *   LowToHigh: t[y] <- t[2y] + r*(t[2y+1]-t[2y]);   HighToLow: t[i] <- t[i] + r*(t[i+half]-t[i]); len halves. */
@@ -170,6 +173,11 @@ int32_t jolt_member_create_split_eq_product(jolt_ctx *ctx, jolt_table *a, jolt_t
                                             const jolt_fr_t *scale, jolt_member **out);
 int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx *ctx, jolt_table *a, jolt_table *b, const jolt_fr_t *w, size_t n,
                                                      const jolt_fr_t *scale, jolt_member **out);
+/* Sharded variant (one process per GPU): this rank holds rows of the block selected by the top log2 G
+ * variables; `w` are the n local coordinates (the low ones), `scale` the global initial scalar and `shard_scale` =
+ * eq(w_hi, rank) multiplies the E_out tables so that the ranks' partial sums simply add. Borrows a and b. */
+int32_t jolt_member_create_split_eq_product_sharded(jolt_ctx *ctx, jolt_table *a, jolt_table *b, const jolt_fr_t *w, size_t n,
+                                                    const jolt_fr_t *scale, const jolt_fr_t *shard_scale, jolt_member **out);
 /* Rewind a BORROW member to round 0 (no device work). */
 int32_t jolt_member_reset(jolt_member *m);
 int32_t jolt_member_num_rounds(const jolt_member *m, size_t *rounds);
@@ -265,6 +273,27 @@ int32_t jolt_host_prove_batch(jolt_ctx *ctx, jolt_member *const *members, size_t
                               uint64_t transcript_label, int32_t challenge_mode, int32_t use_round_group,
                               jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
                               jolt_fr_t *out_final_claim);
+/* Resumable form of the same round loop for the hypercube-sharded prover: local round sums come
+ * from the device members (local_fn == NULL) or from a callback, are all-gathered over the ranks through `gather` and added
+ * mod r; the loop can be paused after the shard-local rounds and resumed on members built from the gathered tables.
+ * kinds: 0 = expr (degree+1 sums), 1 = expr with skipped s(1) (degree sums), 2 = split-eq product (2 sums). */
+typedef struct jolt_batch jolt_batch;
+typedef int32_t (*jolt_local_round_fn)(void *user, const size_t *active, size_t n_active, const jolt_fr_t *const *binds,
+                                       jolt_fr_t *evals_out, size_t evals_count);
+typedef int32_t (*jolt_gather_fn)(void *user, const jolt_fr_t *local, size_t count, jolt_fr_t *gathered /* world*count */);
+int32_t jolt_host_batch_begin(jolt_ctx *ctx, size_t n_members, const jolt_fr_t *input_claims, const jolt_fr_t *coefficients,
+                              const size_t *rounds, const size_t *offsets, const int32_t *kinds, const uint32_t *degrees,
+                              const jolt_fr_t *const *split_eq_points, const jolt_fr_t *split_eq_scales, size_t max_num_vars,
+                              size_t max_degree, uint64_t transcript_label, int32_t challenge_mode, jolt_batch **out);
+int32_t jolt_host_batch_run(jolt_batch *b, jolt_member *const *members, size_t n_rounds, int32_t world, jolt_gather_fn gather,
+                            jolt_local_round_fn local_fn, void *user);
+int32_t jolt_host_batch_flush_binds(jolt_batch *b, jolt_member *const *members, jolt_fr_t *binds_out, int32_t *has_bind_out);
+int32_t jolt_host_batch_split_eq_scalar(const jolt_batch *b, size_t member, jolt_fr_t *out);
+int32_t jolt_host_batch_end(jolt_batch *b, jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
+                            jolt_fr_t *out_final_claim);
+/* The fully bound values of several members with one copy and one synchronisation (concatenated in member order). */
+int32_t jolt_round_group_final_values(jolt_ctx *ctx, jolt_member *const *members, size_t n_members, jolt_fr_t *out, size_t capacity);
+
 /* HyperKZGScheme::commit / open (crates/jolt-hyperkzg/src/scheme.rs:122-158,302-325, kzg.rs:69-126) over the device
  * kernels with the same test transcript.  com: ell-1 points, w: 3 points, v: 3*ell, challenges: {r, q, d_0}. */
 int32_t jolt_host_hyperkzg_commit(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, jolt_g1_t *out);

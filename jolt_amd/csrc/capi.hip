@@ -262,6 +262,29 @@ extern "C" int32_t jolt_table_free(jolt_ctx* ctx, jolt_table* t) {
     return JOLT_OK;
 }
 
+extern "C" int32_t jolt_table_slice(jolt_ctx* ctx, const jolt_table* parent, size_t offset, size_t len, jolt_table** out) {
+    if (!ctx || !parent || !out) return JOLT_ERR_INVALID_ARG;
+    if (offset + len > parent->len) return JOLT_ERR_SIZE_MISMATCH;
+    jolt_table* v = new (std::nothrow) jolt_table();
+    if (!v) return JOLT_ERR_OOM;
+    v->ctx = ctx;
+    v->cur = -1;
+    v->view = parent->data() + offset;
+    v->view_len = len;
+    v->len = len;
+    *out = v;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_table_write(jolt_ctx* ctx, jolt_table* t, size_t offset, const jolt_fr_t* host, size_t len) {
+    if (!ctx || !t || (!host && len)) return JOLT_ERR_INVALID_ARG;
+    if (offset + len > t->len) return JOLT_ERR_SIZE_MISMATCH;
+    if (len) {
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(t->data() + offset, host, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return JOLT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // bind
 // ------------------------------------------------------------------------------------------------------------------
@@ -625,7 +648,7 @@ extern "C" int32_t jolt_member_create_expr(jolt_ctx* ctx, jolt_table* const* tab
 }
 
 static int32_t create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale,
-                                       bool borrow, jolt_member** out) {
+                                       bool borrow, jolt_member** out, const jolt_fr_t* shard_scale = nullptr) {
     if (!ctx || !a || !b || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
     jolt_member* m = new (std::nothrow) jolt_member();
     if (!m) return JOLT_ERR_OOM;
@@ -647,7 +670,8 @@ static int32_t create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table*
         m->out_len = std::min(split, head_len);
         m->in_len = head_len - m->out_len;
         jolt_table* last = nullptr;
-        s = eq_build(ctx, m->w.data(), m->out_len, Fr::one(), 1, &m->e_out_cache, &last);
+        Fr e_out_scale = shard_scale ? fr_from_abi(shard_scale) : Fr::one();
+        s = eq_build(ctx, m->w.data(), m->out_len, e_out_scale, 1, &m->e_out_cache, &last);
         if (s == JOLT_OK) s = eq_build(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), 1, &m->e_in_cache, &last);
         if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
         m->e_out_bits = m->out_len;
@@ -663,6 +687,12 @@ extern "C" int32_t jolt_member_create_split_eq_product(jolt_ctx* ctx, jolt_table
 extern "C" int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n,
                                                                 const jolt_fr_t* scale, jolt_member** out) {
     return create_split_eq_product(ctx, a, b, w, n, scale, true, out);
+}
+
+extern "C" int32_t jolt_member_create_split_eq_product_sharded(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n,
+                                                               const jolt_fr_t* scale, const jolt_fr_t* shard_scale, jolt_member** out) {
+    if (n == 0) return JOLT_ERR_INVALID_ARG;  // a shard has at least one local variable
+    return create_split_eq_product(ctx, a, b, w, n, scale, true, out, shard_scale);
 }
 
 // rewind a member that borrows its tables to round 0 (no device work): re-prove with fresh challenges
@@ -996,6 +1026,23 @@ extern "C" int32_t jolt_member_final_values(jolt_member* m, jolt_fr_t* out, size
     JOLT_TRY(fetch_results(ctx, m->tables.size(), out));
     if (m->kind == jolt_member::kSplitEqProduct) fr_to_abi(&out[m->tables.size()], m->current_scalar);
     return JOLT_OK;
+}
+
+extern "C" int32_t jolt_round_group_final_values(jolt_ctx* ctx, jolt_member* const* members, size_t n, jolt_fr_t* out, size_t cap) {
+    if (!ctx || (!members && n) || !out) return JOLT_ERR_INVALID_ARG;
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!members[i]) return JOLT_ERR_INVALID_ARG;
+        if (members[i]->bound != members[i]->rounds) return JOLT_ERR_NOT_FULLY_BOUND;
+        total += members[i]->tables.size();
+    }
+    if (total > cap) return JOLT_ERR_SIZE_MISMATCH;
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, total + 8));
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i)
+        for (jolt_table* t : members[i]->tables)
+            JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_results + k++, t->data(), sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    return fetch_results(ctx, total, out);
 }
 
 extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {

@@ -227,6 +227,54 @@ EXPORT int orc_member_prove_round(orc_member *m, const fr_t *bind, const fr_t *p
     return m->kind == ORC_KIND_EXPR ? expr_round(m, previous_claim, coeffs_out) : gruen_round(m, previous_claim, coeffs_out);
 }
 
+/* Raw round sums without the round check or interpolation -- what ONE SHARD of a hypercube-sharded member contributes
+ * (its sums do not add up to the global claim by themselves).  EXPR: out[t] = s(t), t = 0..degree (naive.rs:262-296);
+ * GRUEN: out = {q(0), q(inf)} (support.rs:391-411) times `shard_scale` (= eq(w_hi, rank); NULL = one). */
+EXPORT int orc_member_round_sums(orc_member *m, const fr_t *bind, const fr_t *shard_scale, fr_t *out) {
+    if (bind) member_bind(m, bind);
+    if (m->len < 2) return ORC_ERR_ARG;
+    size_t half = m->len / 2;
+    if (m->kind == ORC_KIND_EXPR) {
+        for (uint32_t t = 0; t <= m->degree; ++t) {
+            fr_t point = fr_from_u64(t), sum = fr_zero();
+            for (size_t y = 0; y < half; ++y)
+                for (uint32_t k = 0; k < m->n_terms; ++k) {
+                    fr_t value = m->coeffs[k];
+                    for (uint32_t f = m->term_offsets[k]; f < m->term_offsets[k + 1]; ++f) {
+                        fr_t lo, hi;
+                        eval_pair(m, m->factors[f], y, &lo, &hi);
+                        value = FMUL(value, FADD(lo, FMUL(point, FSUB(hi, lo))));
+                    }
+                    sum = FADD(sum, value);
+                }
+            out[t] = sum;
+        }
+        return ORC_OK;
+    }
+    size_t n = m->rounds, out_bits, in_bits;
+    orc_split_eq_current_dims(n, m->rounds_bound, &out_bits, &in_bits);
+    size_t split = n / 2, head_len = n ? n - 1 : 0;
+    size_t out_len = split < head_len ? split : head_len;
+    size_t e_out_n = (size_t)1 << out_bits, e_in_n = (size_t)1 << in_bits;
+    fr_t *e_out = (fr_t *)malloc(e_out_n * sizeof(fr_t)), *e_in = (fr_t *)malloc(e_in_n * sizeof(fr_t));
+    orc_eq_evals(m->w, out_bits, shard_scale, e_out);
+    orc_eq_evals(m->w + out_len, in_bits, NULL, e_in);
+    fr_t zero = fr_zero(), infinity = fr_zero();
+    for (size_t x_out = 0; x_out < e_out_n; ++x_out)
+        for (size_t x_in = 0; x_in < e_in_n; ++x_in) {
+            size_t row = (x_out << in_bits) | x_in;
+            fr_t e = FMUL(e_out[x_out], e_in[x_in]);
+            fr_t al = m->tables[0][2 * row], ah = m->tables[0][2 * row + 1], bl = m->tables[1][2 * row], bh = m->tables[1][2 * row + 1];
+            zero = FADD(zero, FMUL(e, FMUL(al, bl)));
+            infinity = FADD(infinity, FMUL(e, FMUL(FSUB(ah, al), FSUB(bh, bl))));
+        }
+    free(e_out);
+    free(e_in);
+    out[0] = zero;
+    out[1] = infinity;
+    return ORC_OK;
+}
+
 /* ProveRounds::finish_rounds (prover.rs:68-71) */
 EXPORT int orc_member_finish_rounds(orc_member *m, const fr_t *bind) {
     member_bind(m, bind);

@@ -346,6 +346,14 @@ class Member:
             raise RuntimeError(f"oracle prove_round failed rc={rc}")
         return o
 
+    def round_sums(self, bind, shard_scale=None):
+        o = fr_array(2 if self.gruen else self.degree + 1)
+        b = None if bind is None else np.ascontiguousarray(bind, dtype=np.uint64)
+        sc = None if shard_scale is None else np.ascontiguousarray(shard_scale, dtype=np.uint64)
+        rc = lib().orc_member_round_sums(self.h, _p(b) if b is not None else None, _p(sc) if sc is not None else None, _p(o))
+        assert rc == 0
+        return o
+
     def finish_rounds(self, bind):
         b = np.ascontiguousarray(bind, dtype=np.uint64)
         lib().orc_member_finish_rounds(self.h, _p(b))

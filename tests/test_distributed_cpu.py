@@ -1,0 +1,102 @@
+"""N > 1 path on CPU ranks (gloo, world_size 2): the hypercube-sharded batched sumcheck -- partial round sums per
+shard, all-gather + modular sum, shard-local rounds then the gathered tail rounds -- must reproduce the transcript of
+the single-process prover over the global tables bit for bit.  The local compute is the CPU oracle here (there is no GPU
+in this container); the sharding / collective / round-loop logic under test is the product code of
+jolt_amd/distributed.py and jolt_amd/csrc/batch.hip."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from jolt_amd import distributed as D
+    from util import rand_fr
+
+    log_g = world.bit_length() - 1
+    n_total, n_local = 5, 5 - log_g
+    N, NL = 1 << n_total, 1 << n_local
+    one = O.to_mont([1])[0]
+    # global inputs (same seed on every rank)
+    eq_pt = rand_fr(n_total, 1)
+    eq = O.eq_evals(eq_pt)
+    a, b, c = rand_fr(N, 2), rand_fr(N, 3), rand_fr(N, 4)
+    g = rand_fr(1, 5)[0]
+    w = rand_fr(n_total, 6)
+    flat = [(one, [0, 1]), (g, [0, 2])]           # eq * (a + g b), degree 2
+    cubic = [(one, [0, 1, 2])]                    # a * b * c, degree 3
+    coeffs = list(rand_fr(3, 7))
+
+    lo, hi = rank * NL, (rank + 1) * NL
+
+    class OracleShard:
+        def __init__(self, members, scales):
+            self.members, self.scales = members, scales
+
+        def round(self, idx, binds):
+            out = []
+            for i, bnd in zip(idx, binds):
+                m = self.members[i]
+                s = m.round_sums(bnd, self.scales[i])
+                out.append(s if m.gruen else np.concatenate([s[:1], s[2:]]))  # skipped s(1) form
+            return np.concatenate(out, axis=0)
+
+        def flush(self, binds):
+            for m, bnd in zip(self.members, binds):
+                if bnd is not None:
+                    m.finish_rounds(bnd)
+
+        def finals(self):
+            return np.concatenate([m.final_values()[: m.n_tables] for m in self.members], axis=0)
+
+        def make_tail(self, gathered, scalars):
+            # gathered: (world, n_tables_total, 4) -> G-entry tables, rank = top variable(s)
+            tabs = [np.ascontiguousarray(gathered[:, k, :]) for k in range(gathered.shape[1])]
+            m0 = O.Member.expr(tabs[0:3], flat, 2)
+            m1 = O.Member.expr(tabs[3:6], cubic, 3)
+            m2 = O.Member.gruen_product(tabs[6], tabs[7], w[:log_g], scalars[2])
+            return OracleShard([m0, m1, m2], [None, None, None])
+
+        def close(self):
+            pass
+
+    shard_scale = one.reshape(1, 4)
+    for k in range(log_g):
+        bit = (rank >> (log_g - 1 - k)) & 1
+        f = w[k].reshape(1, 4) if bit else O.fr_sub(one.reshape(1, 4), w[k].reshape(1, 4))
+        shard_scale = O.fr_mul(shard_scale, f)
+    local = OracleShard([O.Member.expr([eq[lo:hi], a[lo:hi], b[lo:hi]], flat, 2), O.Member.expr([a[lo:hi], b[lo:hi], c[lo:hi]], cubic, 3),
+                         O.Member.gruen_product(a[lo:hi], c[lo:hi], w[log_g:])], [None, None, shard_scale[0]])
+    # global reference run (every rank computes it; cheap at 2^5)
+    gm = [O.Member.expr([eq, a, b], flat, 2), O.Member.expr([a, b, c], cubic, 3), O.Member.gruen_product(a, c, w)]
+    claims = [m.input_claim() for m in gm]
+    want = O.prove_batch(gm, claims, coeffs, [0, 0, 0], n_total, 3, label=11)
+    infos = [D.MemberInfo(D.KIND_EXPR_SKIP, 2, n_total, 3), D.MemberInfo(D.KIND_EXPR_SKIP, 3, n_total, 3),
+             D.MemberInfo(D.KIND_SPLIT_EQ, 3, n_total, 2, w=w)]
+    coll = D.Collective(dist, world, None)
+    got = D.prove_batch_sharded(None, infos, claims, coeffs, n_total, n_local, 3, world, coll, local, label=11)
+    ok = (np.array_equal(got["polys"], want["polys"]) and np.array_equal(got["challenges"], want["challenges"])
+          and np.array_equal(got["final_claim"], want["final_claim"]) and np.array_equal(got["member_claims"], want["member_claims"]))
+    open(os.path.join(tmpdir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_prove_batch_matches_single_process(world):
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 1000 + world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, port, tmp), nprocs=world, join=True)
+        for r in range(world):
+            assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"
