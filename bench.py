@@ -128,20 +128,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    sharded = world > 1 or os.environ.get("JOLT_FORCE_SHARDED") == "1"  # the env var exercises the RCCL path with one rank
+    if sharded:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from jolt_amd import ffi
     from jolt_amd.workload import DeviceWorkload
 
-    ctx = ffi.Context(local_rank if world > 1 else 0)
+    ctx = ffi.Context(local_rank if sharded else 0)
     if args.roofline_only:
         print(json.dumps(bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)))
         return
 
-    if world > 1:
+    if sharded:
         from jolt_amd.distributed import ShardedWorkload
         wl = ShardedWorkload(ctx, args.scale, rank, world, dist)
     else:
