@@ -595,6 +595,14 @@ extern "C" int32_t jolt_member_create_lc(jolt_ctx* ctx, jolt_table* const* table
         if (!fr_is_canonical(c)) ok = false;
         md.lc_coeff[k] = c;
         md.lc_one[k] = (c == Fr::one()) ? 1u : 0u;
+        md.lc_owner[k] = 1u;
+        for (uint32_t j = 0; j < k; ++j) if (d->lc_tables[j] == d->lc_tables[k]) { md.lc_owner[k] = 0u; break; }
+    }
+    // every table must be mentioned by the summand: a fused round binds a table through its owner entry
+    for (uint32_t t = 0; ok && t < d->n_tables; ++t) {
+        bool used = false;
+        for (uint32_t k = 0; k < d->n_lc; ++k) used = used || d->lc_tables[k] == t;
+        m->all_tables_used = m->all_tables_used && used;
     }
     if (!ok) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); ctx->last_error = "malformed member descriptor"; return JOLT_ERR_INVALID_ARG; }
     s = member_upload_desc(m);
@@ -748,127 +756,159 @@ size_t jolt_internal_member_n_evals(const jolt_member* m) {
     return m->skip_one ? m->degree : m->degree + 1;
 }
 
-template <int ORDER, bool SKIP1>
-static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGroupArgs& a, Fr* partials, const RoundDone& rd) {
+template <int ORDER, bool SKIP1, bool FUSED>
+static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGroupArgs& a, const Fr& r, int shifted, Fr* partials, const RoundDone& rd) {
     switch (ne) {
-        case 1: hipLaunchKernelGGL((k_round_evals_group<1, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 2: hipLaunchKernelGGL((k_round_evals_group<2, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 3: hipLaunchKernelGGL((k_round_evals_group<3, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 4: hipLaunchKernelGGL((k_round_evals_group<4, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 5: hipLaunchKernelGGL((k_round_evals_group<5, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 6: hipLaunchKernelGGL((k_round_evals_group<6, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 7: hipLaunchKernelGGL((k_round_evals_group<7, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
-        case 8: hipLaunchKernelGGL((k_round_evals_group<8, ORDER, SKIP1>), grid, dim3(kBlock), 0, s, a, partials, rd); break;
+        case 1: hipLaunchKernelGGL((k_round_evals_group<1, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 2: hipLaunchKernelGGL((k_round_evals_group<2, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 3: hipLaunchKernelGGL((k_round_evals_group<3, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 4: hipLaunchKernelGGL((k_round_evals_group<4, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 5: hipLaunchKernelGGL((k_round_evals_group<5, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 6: hipLaunchKernelGGL((k_round_evals_group<6, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 7: hipLaunchKernelGGL((k_round_evals_group<7, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
+        case 8: hipLaunchKernelGGL((k_round_evals_group<8, ORDER, SKIP1, FUSED>), grid, dim3(kBlock), 0, s, a, r, shifted, partials, rd); break;
     }
 }
 
-// Enqueue one batch round for n members: (1) every pending bind, grouped by challenge so that all tables of all
-// members go down in ceil(tables/40) launches; (2) the round sums, one launch per (NE, order, skip) class with
-// blockIdx.y = member; (3) ONE second-stage reduction launch for all members.  Results land in d_results at
-// consecutive slots in member order.
+// Enqueue one batch round for n members.  Pending binds of LowToHigh members are FUSED into the round kernels (one pass
+// over memory per round: read the unbound table, write the bound one, accumulate the round sums); the remaining binds
+// (HighToLow members, tables a summand does not mention) are grouped by challenge into ceil(tables/40) launches.
+// Round sums: one launch per (NE, order, skip, fused, challenge) class with blockIdx.y = member; rounds with few pairs
+// left go into the tail kernel (all members, pair x group x point work items).  The last workgroup of every member
+// publishes its sums into host-mapped memory (finish_member).
 static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
-    // ---- (1) binds
+    constexpr size_t kTailPairs = 4096;
+    if (n > (size_t)kGroupTicket) { ctx->last_error = "batch round has too many members"; return JOLT_ERR_UNSUPPORTED; }
+    struct Item {
+        size_t ne, slot;
+        bool fused = false, tail = false, done = false;
+        Fr r;                      // challenge of the fused bind
+        std::vector<const Fr*> in; // table pointers the round kernel reads
+        std::vector<Fr*> out;      // fused: where the bound tables go
+        int grid = 1;
+        uint32_t part_off = 0;
+    };
+    std::vector<Item> items(n);
+    // ---- (1) binds: fused where possible, grouped launches otherwise
     struct BindGroup { Fr r; int32_t order; std::vector<jolt_table*> tabs; };
     std::vector<BindGroup> bgs;
     for (size_t i = 0; i < n; ++i) {
-        if (!binds || !binds[i]) continue;
         jolt_member* m = members[i];
-        JOLT_TRY(member_note_bind(m, *binds[i]));
-        BindGroup* g = nullptr;
-        for (BindGroup& c : bgs) if (c.order == m->order && c.r == *binds[i]) { g = &c; break; }
-        if (!g) { bgs.push_back(BindGroup{*binds[i], m->order, {}}); g = &bgs.back(); }
-        g->tabs.insert(g->tabs.end(), m->tables.begin(), m->tables.end());
+        Item& it = items[i];
+        if (binds && binds[i]) {
+            const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && m->len >= 4 && (m->kind == jolt_member::kSplitEqProduct || m->all_tables_used);
+            JOLT_TRY(member_note_bind(m, *binds[i]));  // m->len is now the bound length
+            if (can_fuse) {
+                it.fused = true;
+                it.r = *binds[i];
+                for (jolt_table* t : m->tables) {
+                    size_t half = t->len / 2;
+                    JOLT_TRY(jolt_internal_table_ensure_alt(t, half));
+                    it.in.push_back(t->data());
+                    Fr* o = t->buf[t->cur < 0 ? 0 : 1 - t->cur];
+                    it.out.push_back(o);
+                    t->cur = t->cur < 0 ? 0 : 1 - t->cur;  // the round kernel fills it
+                    t->len = half;
+                }
+            } else {
+                BindGroup* g = nullptr;
+                for (BindGroup& c : bgs) if (c.order == m->order && c.r == *binds[i]) { g = &c; break; }
+                if (!g) { bgs.push_back(BindGroup{*binds[i], m->order, {}}); g = &bgs.back(); }
+                g->tabs.insert(g->tabs.end(), m->tables.begin(), m->tables.end());
+            }
+        }
     }
     for (BindGroup& g : bgs) JOLT_TRY(jolt_internal_bind(ctx, g.tabs.data(), g.tabs.size(), g.r, g.order));
-    // ---- (2) round sums
-    struct Item { size_t idx; int grid; size_t ne; uint32_t part_off; size_t slot; };
-    std::vector<Item> items(n);
-    size_t part_total = 0, slot = 0;
+    size_t slot = 0, part_total = 0;
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
+        Item& it = items[i];
         if (m->len < 2) { ctx->last_error = "prove_round on a fully bound member"; return JOLT_ERR_INVALID_ARG; }
-        items[i].idx = i;
-        items[i].ne = jolt_internal_member_n_evals(m);
-        items[i].slot = slot;
-        slot += items[i].ne;
+        if (!it.fused) for (jolt_table* t : m->tables) { it.in.push_back(t->data()); it.out.push_back(nullptr); }
+        it.ne = jolt_internal_member_n_evals(m);
+        it.slot = slot;
+        slot += it.ne;
+        it.tail = m->kind == jolt_member::kExpr && m->len / 2 <= kTailPairs;
     }
-    // tail rounds: every expr member with few pairs left goes into ONE launch (work item = pair x group x point)
-    constexpr size_t kTailPairs = 4096;
-    std::vector<bool> done(n, false);
-    struct TailLaunch { TailArgs args; int count; unsigned gx, gz; };
+    if (slot > ctx->round_cap) { ctx->last_error = "batch round returns too many sums"; return JOLT_ERR_UNSUPPORTED; }
+    auto same_challenge = [&](const Item& a, const Item& b) { return a.fused == b.fused && (!a.fused || a.r == b.r); };
+    // ---- (2a) tail launches
+    struct TailLaunch { TailArgs args; int count; unsigned gx, gz; Fr r; int shifted; std::vector<size_t> who; };
     std::vector<TailLaunch> tails;
-    {
+    for (size_t i = 0; i < n; ++i) {
+        if (!items[i].tail || items[i].done) continue;
         TailLaunch T;
         T.count = 0; T.gx = 1; T.gz = 1;
-        uint32_t tab_cursor = 0;
-        auto flush = [&]() { if (T.count) tails.push_back(T); T.count = 0; T.gx = 1; T.gz = 1; tab_cursor = 0; };
-        for (size_t i = 0; i < n; ++i) {
-            jolt_member* m = members[i];
-            if (m->kind != jolt_member::kExpr || m->len / 2 > kTailPairs) continue;
-            if (T.count == kMaxGroupMembers || tab_cursor + m->tables.size() > (size_t)kMaxGroupTables) flush();
+        T.r = items[i].fused ? items[i].r : Fr::zero();
+        T.shifted = fr_low_limbs_zero(T.r) ? 1 : 0;
+        uint32_t cursor = 0;
+        for (size_t j = i; j < n; ++j) {
+            jolt_member* m = members[j];
+            Item& it = items[j];
+            if (!it.tail || it.done || !same_challenge(items[i], it)) continue;
+            if (T.count == kMaxGroupMembers || cursor + m->tables.size() > (size_t)kMaxGroupTables) break;
             int c = T.count++;
             T.args.g.desc[c] = m->d_desc;
             T.args.g.half[c] = m->len / 2;
-            T.args.g.tab_off[c] = tab_cursor;
-            for (jolt_table* t : m->tables) T.args.g.tabs[tab_cursor++] = t->data();
-            T.args.ne[c] = (uint32_t)items[i].ne;
+            T.args.g.tab_off[c] = cursor;
+            for (size_t k = 0; k < m->tables.size(); ++k) { T.args.g.tabs[cursor] = it.in[k]; T.args.g.outs[cursor] = it.out[k]; cursor++; }
+            T.args.ne[c] = (uint32_t)it.ne;
             T.args.order[c] = (uint32_t)m->order;
             T.args.skip[c] = m->skip_one ? 1u : 0u;
-            T.args.g.ticket[c] = (uint32_t)(i % kGroupTicket);
-            T.args.g.slot[c] = (uint32_t)items[i].slot;
+            T.args.fused[c] = it.fused ? 1u : 0u;
+            T.args.g.ticket[c] = (uint32_t)j;
+            T.args.g.slot[c] = (uint32_t)it.slot;
             size_t work = (m->len / 2) * std::max<uint32_t>(1, m->desc.n_groups);
             T.gx = std::max<unsigned>(T.gx, (unsigned)std::min<size_t>((work + kBlock - 1) / kBlock, 256));
-            T.gz = std::max<unsigned>(T.gz, (unsigned)items[i].ne);
-            items[i].grid = -1 - c;  // resolved after gx is final
-            done[i] = true;
-            // remember which tail launch this member belongs to through part_off (filled below)
-            items[i].part_off = (uint32_t)tails.size();
+            T.gz = std::max<unsigned>(T.gz, (unsigned)it.ne);
+            T.who.push_back(j);
+            it.done = true;
         }
-        flush();
-        for (size_t i = 0; i < n; ++i) {
-            if (!done[i]) continue;
-            TailLaunch& L = tails[items[i].part_off];
-            int c = -1 - items[i].grid;
-            items[i].grid = (int)L.gx;
-            items[i].part_off = (uint32_t)part_total;
-            L.args.g.part_off[c] = (uint32_t)part_total;
-            part_total += (size_t)L.gx * items[i].ne;
+        for (int c = 0; c < T.count; ++c) {
+            Item& it = items[T.who[c]];
+            it.grid = (int)T.gx;
+            it.part_off = (uint32_t)part_total;
+            T.args.g.part_off[c] = (uint32_t)part_total;
+            part_total += (size_t)T.gx * it.ne;
         }
+        tails.push_back(std::move(T));
     }
-    // classes of the remaining expr members sharing (ne, order, skip)
-    struct Launch { RoundGroupArgs args; int ne, order, skip, count; unsigned grid; };
+    // ---- (2b) class launches of the remaining expr members
+    struct Launch { RoundGroupArgs args; int ne, order, skip, fused, count, shifted; unsigned grid; Fr r; std::vector<size_t> who; };
     std::vector<Launch> launches;
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
-        if (done[i] || m->kind != jolt_member::kExpr) continue;
+        if (items[i].done || m->kind != jolt_member::kExpr) continue;
         Launch L;
-        L.ne = (int)items[i].ne; L.order = m->order; L.skip = m->skip_one ? 1 : 0; L.count = 0; L.grid = 1;
-        uint32_t tab_cursor = 0;
-        std::vector<size_t> in_class;
+        L.ne = (int)items[i].ne; L.order = m->order; L.skip = m->skip_one ? 1 : 0; L.fused = items[i].fused ? 1 : 0; L.count = 0; L.grid = 1;
+        L.r = items[i].fused ? items[i].r : Fr::zero();
+        L.shifted = fr_low_limbs_zero(L.r) ? 1 : 0;
+        uint32_t cursor = 0;
         for (size_t j = i; j < n; ++j) {
             jolt_member* mj = members[j];
-            if (done[j] || mj->kind != jolt_member::kExpr) continue;
-            if ((int)items[j].ne != L.ne || mj->order != L.order || (mj->skip_one ? 1 : 0) != L.skip) continue;
-            if (L.count == kMaxGroupMembers || tab_cursor + mj->tables.size() > (size_t)kMaxGroupTables) break;
-            L.args.desc[L.count] = mj->d_desc;
-            L.args.half[L.count] = mj->len / 2;
-            L.args.tab_off[L.count] = tab_cursor;
-            for (jolt_table* t : mj->tables) L.args.tabs[tab_cursor++] = t->data();
+            Item& it = items[j];
+            if (it.done || mj->kind != jolt_member::kExpr) continue;
+            if ((int)it.ne != L.ne || mj->order != L.order || (mj->skip_one ? 1 : 0) != L.skip || !same_challenge(items[i], it)) continue;
+            if (L.count == kMaxGroupMembers || cursor + mj->tables.size() > (size_t)kMaxGroupTables) break;
+            int c = L.count++;
+            L.args.desc[c] = mj->d_desc;
+            L.args.half[c] = mj->len / 2;
+            L.args.tab_off[c] = cursor;
+            for (size_t k = 0; k < mj->tables.size(); ++k) { L.args.tabs[cursor] = it.in[k]; L.args.outs[cursor] = it.out[k]; cursor++; }
+            L.args.ticket[c] = (uint32_t)j;
+            L.args.slot[c] = (uint32_t)it.slot;
             L.grid = std::max<unsigned>(L.grid, (unsigned)sweep_grid(ctx, (mj->len / 2) * std::max<uint32_t>(1, mj->desc.n_groups)));
-            in_class.push_back(j);
-            done[j] = true;
-            L.count++;
+            L.who.push_back(j);
+            it.done = true;
         }
         for (int c = 0; c < L.count; ++c) {
-            size_t j = in_class[c];
-            items[j].grid = (int)L.grid;
-            items[j].part_off = (uint32_t)part_total;
+            Item& it = items[L.who[c]];
+            it.grid = (int)L.grid;
+            it.part_off = (uint32_t)part_total;
             L.args.part_off[c] = (uint32_t)part_total;
-            L.args.ticket[c] = (uint32_t)(j % kGroupTicket);
-            L.args.slot[c] = (uint32_t)items[j].slot;
-            part_total += (size_t)L.grid * items[j].ne;
+            part_total += (size_t)L.grid * it.ne;
         }
-        launches.push_back(L);
+        launches.push_back(std::move(L));
     }
     for (size_t i = 0; i < n; ++i) {
         if (members[i]->kind != jolt_member::kSplitEqProduct) continue;
@@ -877,7 +917,6 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         part_total += (size_t)items[i].grid * 2;
     }
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, part_total + 8, slot + 8));
-    if (n > (size_t)kGroupTicket || slot > ctx->round_cap) { ctx->last_error = "batch round too large (members/evals)"; return JOLT_ERR_UNSUPPORTED; }
     RoundDone rd;
     rd.counters = ctx->d_counters;
     rd.results = ctx->h_round;
@@ -885,28 +924,39 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     rd.seq = ++ctx->seq;
     rd.group_total = (uint32_t)n;
     for (TailLaunch& T : tails) {
-        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, ctx->stream, T.args, ctx->d_partials, rd);
+        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, ctx->stream, T.args, T.r, T.shifted, ctx->d_partials, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     for (Launch& L : launches) {
         dim3 grid(L.grid, (unsigned)L.count);
         if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
-            if (L.skip) launch_round_group<0, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
-            else launch_round_group<0, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
+            if (L.fused) {
+                if (L.skip) launch_round_group<0, true, true>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
+                else launch_round_group<0, false, true>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
+            } else {
+                if (L.skip) launch_round_group<0, true, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
+                else launch_round_group<0, false, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
+            }
         } else {
-            if (L.skip) launch_round_group<1, true>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
-            else launch_round_group<1, false>(L.ne, grid, ctx->stream, L.args, ctx->d_partials, rd);
+            if (L.skip) launch_round_group<1, true, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
+            else launch_round_group<1, false, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
         }
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
         if (m->kind != jolt_member::kSplitEqProduct) continue;
+        const Item& it = items[i];
         const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
-        hipLaunchKernelGGL(k_split_eq_product, dim3(items[i].grid), dim3(kBlock), 0, ctx->stream, (const Fr*)m->tables[0]->data(),
-                           (const Fr*)m->tables[1]->data(), e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + items[i].part_off,
-                           (uint32_t)(i % kGroupTicket), (uint32_t)items[i].slot, rd);
+        Fr r = it.fused ? it.r : Fr::zero();
+        int shifted = fr_low_limbs_zero(r) ? 1 : 0;
+        if (it.fused)
+            hipLaunchKernelGGL(k_split_eq_product<true>, dim3(it.grid), dim3(kBlock), 0, ctx->stream, it.in[0], it.in[1], it.out[0], it.out[1], r, shifted,
+                               e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
+        else
+            hipLaunchKernelGGL(k_split_eq_product<false>, dim3(it.grid), dim3(kBlock), 0, ctx->stream, it.in[0], it.in[1], (Fr*)nullptr, (Fr*)nullptr, r,
+                               shifted, e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     return JOLT_OK;
@@ -1067,7 +1117,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     md.n_groups = 1; md.n_factors = 3; md.n_lc = 3;
     md.grp_fac_off[0] = 0; md.grp_fac_off[1] = 3;
     for (uint32_t f = 0; f <= 3; ++f) md.fac_lc_off[f] = f;
-    for (uint32_t k = 0; k < 3; ++k) { md.lc_tab[k] = k; md.lc_one[k] = 1; md.lc_coeff[k] = Fr::one(); }
+    for (uint32_t k = 0; k < 3; ++k) { md.lc_tab[k] = k; md.lc_one[k] = 1; md.lc_owner[k] = 1; md.lc_coeff[k] = Fr::one(); }
     MemberDesc* dd = nullptr;
     JOLT_HIP_TRY(ctx, hipMalloc((void**)&dd, sizeof(MemberDesc)));
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(dd, &md, sizeof(md), hipMemcpyHostToDevice, ctx->stream));

@@ -20,6 +20,7 @@ struct MemberDesc {
     uint32_t fac_has_const[kMaxFactors];
     uint32_t lc_tab[kMaxLc];
     uint32_t lc_one[kMaxLc];  // coefficient == 1 -> skip the multiply
+    uint32_t lc_owner[kMaxLc];  // first entry mentioning its table: in a fused bind+evaluate round it stores the bound values
     Fr fac_const[kMaxFactors];
     Fr lc_coeff[kMaxLc];
 };

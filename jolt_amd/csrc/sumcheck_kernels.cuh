@@ -19,9 +19,43 @@ namespace jolt {
 // s(t) partial sums for t = 0..NE-1 (or, with SKIP1, for t in {0,2,3,..,NE}: slot k>=1 holds s(k+1) -- the
 // optimized tier's skipped-evals form, crates/jolt-kernels/src/optimized/support.rs:450-459).
 // ORDER 0: LowToHigh pairs (2y, 2y+1); ORDER 1: HighToLow pairs (y, y+half).
-template <int NE, int ORDER, bool SKIP1>
-__device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ d, const Fr* const* __restrict__ tabs, size_t half,
-                                                 Fr* __restrict__ partials) {
+// lo + r*(hi-lo) with the challenge shape decided at run time (wave-uniform branch)
+__device__ __forceinline__ Fr bind_pair_rt(const Fr& lo, const Fr& hi, const Fr& r, bool shifted) {
+    Fr d = sub(hi, lo);
+    Fr m;
+    if (shifted) {
+        uint32_t chi[4] = {r.l[4], r.l[5], r.l[6], r.l[7]};
+        m = mul_shifted(d, chi);
+    } else {
+        m = mul(d, r);
+    }
+    return add(lo, m);
+}
+// The (lo, hi) pair of table `tp` at pair index y.  FUSED (LowToHigh only): the table has NOT been bound with the
+// previous challenge yet -- read the four entries 4y..4y+3, bind them on the fly (the fused contract of
+// ProveRounds::prove_round, crates/jolt-sumcheck/src/prover.rs:45-51) and, for the table's owner entry, store the two
+// bound values so that the next round finds the bound table: one pass over memory per round instead of a bind-write
+// pass followed by an evaluate-read pass.
+template <int ORDER, bool FUSED>
+__device__ __forceinline__ void load_pair(const Fr* __restrict__ tp, Fr* __restrict__ op, bool owner, size_t y, size_t half, const Fr& r, bool shifted,
+                                          Fr& lo, Fr& hi) {
+    if constexpr (FUSED) {
+        Fr a0 = ld_fr(tp + 4 * y), a1 = ld_fr(tp + 4 * y + 1), a2 = ld_fr(tp + 4 * y + 2), a3 = ld_fr(tp + 4 * y + 3);
+        lo = bind_pair_rt(a0, a1, r, shifted);
+        hi = bind_pair_rt(a2, a3, r, shifted);
+        if (owner) { st_fr(op + 2 * y, lo); st_fr(op + 2 * y + 1, hi); }
+    } else if constexpr (ORDER == 0) {
+        lo = ld_fr(tp + 2 * y);
+        hi = ld_fr(tp + 2 * y + 1);
+    } else {
+        lo = ld_fr(tp + y);
+        hi = ld_fr(tp + y + half);
+    }
+}
+
+template <int NE, int ORDER, bool SKIP1, bool FUSED>
+__device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ d, const Fr* const* __restrict__ tabs, Fr* const* __restrict__ outs,
+                                                 size_t half, const Fr& r, bool shifted, Fr* __restrict__ partials) {
     Fr acc[NE];
 #pragma unroll
     for (int t = 0; t < NE; ++t) acc[t] = Fr::zero();
@@ -34,8 +68,6 @@ __device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ 
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += stride) {
         const uint32_t g = (uint32_t)(i / half);
         const size_t y = i - (size_t)g * half;
-        const size_t i_lo = ORDER == 0 ? 2 * y : y;
-        const size_t i_hi = ORDER == 0 ? 2 * y + 1 : y + half;
         Fr prod[NE];
         const uint32_t f0 = d->grp_fac_off[g], f1 = d->grp_fac_off[g + 1];
         for (uint32_t f = f0; f < f1; ++f) {
@@ -44,8 +76,9 @@ __device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ 
             else { lo = Fr::zero(); hi = lo; }
             const uint32_t k0 = d->fac_lc_off[f], k1 = d->fac_lc_off[f + 1];
             for (uint32_t k = k0; k < k1; ++k) {
-                const Fr* __restrict__ tp = tabs[d->lc_tab[k]];
-                Fr a = ld_fr(tp + i_lo), b = ld_fr(tp + i_hi);
+                const uint32_t ti = d->lc_tab[k];
+                Fr a, b;
+                load_pair<ORDER, FUSED>(tabs[ti], FUSED ? outs[ti] : nullptr, FUSED && d->lc_owner[k], y, half, r, shifted, a, b);
                 if (!d->lc_one[k]) {
                     Fr c = d->lc_coeff[k];
                     a = mul(a, c);
@@ -84,6 +117,7 @@ constexpr int kMaxGroupMembers = 16;
 constexpr int kMaxGroupTables = 96;
 struct RoundGroupArgs {
     const Fr* tabs[kMaxGroupTables];  // flat: member m uses tabs[tab_off[m] ...]
+    Fr* outs[kMaxGroupTables];        // fused rounds: where the bound tables go
     const MemberDesc* desc[kMaxGroupMembers];
     size_t half[kMaxGroupMembers];
     uint32_t tab_off[kMaxGroupMembers];
@@ -91,10 +125,11 @@ struct RoundGroupArgs {
     uint32_t ticket[kMaxGroupMembers];    // per-member ticket counter index
     uint32_t slot[kMaxGroupMembers];      // result slot of the member's first sum
 };
-template <int NE, int ORDER, bool SKIP1>
-static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupArgs a, Fr* __restrict__ partials, RoundDone rd) {
+template <int NE, int ORDER, bool SKIP1, bool FUSED>
+static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupArgs a, Fr r, int shifted, Fr* __restrict__ partials, RoundDone rd) {
     const int m = blockIdx.y;
-    round_evals_body<NE, ORDER, SKIP1>(a.desc[m], a.tabs + a.tab_off[m], a.half[m], partials + a.part_off[m]);
+    round_evals_body<NE, ORDER, SKIP1, FUSED>(a.desc[m], a.tabs + a.tab_off[m], a.outs + a.tab_off[m], a.half[m], r, shifted != 0,
+                                              partials + a.part_off[m]);
     finish_member(partials + a.part_off[m], NE, a.ticket[m], a.slot[m], rd);
 }
 
@@ -107,8 +142,9 @@ struct TailArgs {
     uint32_t ne[kMaxGroupMembers];
     uint32_t order[kMaxGroupMembers];
     uint32_t skip[kMaxGroupMembers];
+    uint32_t fused[kMaxGroupMembers];  // bind the previous challenge on the fly (LowToHigh members only)
 };
-static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, Fr* __restrict__ partials, RoundDone rd) {
+static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, Fr r, int shifted, Fr* __restrict__ partials, RoundDone rd) {
     const int m = blockIdx.y;
     const uint32_t t = blockIdx.z, ne = a.ne[m];
     if (t >= ne) return;
@@ -117,6 +153,8 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, 
     const size_t half = a.g.half[m];
     const uint32_t ng = d->n_groups;
     const bool l2h = a.order[m] == 0;
+    const bool fused = a.fused[m] != 0;
+    Fr* const* __restrict__ outs = a.g.outs + a.g.tab_off[m];
     const uint32_t point = (a.skip[m] && t >= 1) ? t + 1 : t;
     Fr acc[1] = {Fr::zero()};
     const size_t items = half * ng;
@@ -130,8 +168,15 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, 
         for (uint32_t f = f0; f < f1; ++f) {
             Fr lo = d->fac_has_const[f] ? d->fac_const[f] : Fr::zero(), hi = lo;
             for (uint32_t k = d->fac_lc_off[f]; k < d->fac_lc_off[f + 1]; ++k) {
-                const Fr* __restrict__ tp = tabs[d->lc_tab[k]];
-                Fr x = ld_fr(tp + i_lo), z = ld_fr(tp + i_hi);
+                const uint32_t ti = d->lc_tab[k];
+                const Fr* __restrict__ tp = tabs[ti];
+                Fr x, z;
+                if (fused) {
+                    load_pair<0, true>(tp, outs[ti], d->lc_owner[k] && t == 0, y, half, r, shifted != 0, x, z);
+                } else {
+                    x = ld_fr(tp + i_lo);
+                    z = ld_fr(tp + i_hi);
+                }
                 if (!d->lc_one[k]) {
                     Fr c = d->lc_coeff[k];
                     x = mul(x, c);
@@ -155,7 +200,9 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, 
 // q(inf) = sum_rows E_out E_in (a_hi-a_lo)(b_hi-b_lo), row = (x_out << in_bits) | x_in over LowToHigh pairs
 // (crates/jolt-kernels/src/optimized/support.rs:391-411 over crates/jolt-poly/src/split_eq.rs:449-512).
 // eq is never materialised at size N: E_out, E_in are ~sqrt(N) tables that stay cache-resident.
-static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ e_out,
+template <bool FUSED>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ a_out,
+                                                            Fr* __restrict__ b_out, Fr r, int shifted, const Fr* __restrict__ e_out,
                                                             const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials,
                                                             uint32_t ticket, uint32_t slot, RoundDone rd) {
     Fr acc[2] = {Fr::zero(), Fr::zero()};
@@ -163,8 +210,9 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __
     size_t mask = ((size_t)1 << in_bits) - 1;
     for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
         Fr e = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
-        Fr a_lo = ld_fr(a + 2 * row), a_hi = ld_fr(a + 2 * row + 1);
-        Fr b_lo = ld_fr(b + 2 * row), b_hi = ld_fr(b + 2 * row + 1);
+        Fr a_lo, a_hi, b_lo, b_hi;
+        load_pair<0, FUSED>(a, a_out, true, row, rows, r, shifted != 0, a_lo, a_hi);
+        load_pair<0, FUSED>(b, b_out, true, row, rows, r, shifted != 0, b_lo, b_hi);
         acc[0] = add(acc[0], mul(e, mul(a_lo, b_lo)));
         acc[1] = add(acc[1], mul(e, mul(sub(a_hi, a_lo), sub(b_hi, b_lo))));
     }
