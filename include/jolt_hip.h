@@ -112,6 +112,18 @@ int32_t jolt_lt_evals(jolt_ctx *ctx, const jolt_fr_t *r, size_t n, jolt_table **
 /* EqPlusOnePolynomial::evals (crates/jolt-poly/src/eq_plus_one.rs:71-130): (eq, eq+1) tables */
 int32_t jolt_eq_plus_one_evals(jolt_ctx *ctx, const jolt_fr_t *r, size_t n, const jolt_fr_t *scale, jolt_table **eq_out,
                                jolt_table **eq_plus_one_out);
+/* Derived-table builders of the reference tier (crates/jolt-kernels/src/reference/views.rs:35-138):
+ *   address_fold: out[j] = sum_k w[k] * grid[(k << log_t) | j]      (grid address-major K x T, w has K entries)
+ *   cycle_fold:   out[k] = sum_j w[j] * grid[(k << log_t) | j]      (w has T entries)
+ *   tile: `copies` concatenated copies of base;  replicate_stream_lsb: out[(t << 1) | s] = base[t] */
+int32_t jolt_address_fold(jolt_ctx *ctx, const jolt_table *grid, const jolt_table *weights, jolt_table **out);
+int32_t jolt_cycle_fold(jolt_ctx *ctx, const jolt_table *grid, const jolt_table *weights, jolt_table **out);
+int32_t jolt_tile(jolt_ctx *ctx, const jolt_table *base, size_t copies, jolt_table **out);
+int32_t jolt_replicate_stream_lsb(jolt_ctx *ctx, const jolt_table *base, jolt_table **out);
+/* Joint polynomial sum_i scalars[i] * f_i of a homomorphic batch opening: RlcSource::to_dense
+ * (crates/jolt-poly/src/multilinear.rs:159-170,358-464) as consumed by HomomorphicBatch::prove_batch
+ * (crates/jolt-openings/src/schemes.rs:487-524); k <= 40 tables of equal length. */
+int32_t jolt_rlc(jolt_ctx *ctx, jolt_table *const *tables, size_t k, const jolt_fr_t *scalars, jolt_table **out);
 /* Polynomial::evaluate (dense.rs:340-366): sum_x t[x] * eq(x, point) */
 int32_t jolt_table_evaluate(jolt_ctx *ctx, const jolt_table *t, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
 /* Sum of all entries (input claims of linear members; DenseMember::with_sum, jolt-sumcheck/src/tests.rs:1129-1135) */

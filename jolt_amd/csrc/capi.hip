@@ -598,6 +598,17 @@ extern "C" int32_t jolt_member_create_lc(jolt_ctx* ctx, jolt_table* const* table
         md.lc_owner[k] = 1u;
         for (uint32_t j = 0; j < k; ++j) if (d->lc_tables[j] == d->lc_tables[k]) { md.lc_owner[k] = 0u; break; }
     }
+    {   // multiplies per pair of the round kernel: 2 per non-unit LC coefficient + (factors - 1) per evaluation point
+        const size_t ne = m->skip_one ? d->degree : d->degree + 1;
+        size_t muls = 0;
+        for (uint32_t g = 0; ok && g < d->n_groups; ++g) {
+            uint32_t nf = md.grp_fac_off[g + 1] - md.grp_fac_off[g];
+            if (nf > 1) muls += (size_t)(nf - 1) * ne;
+            for (uint32_t f = md.grp_fac_off[g]; f < md.grp_fac_off[g + 1]; ++f)
+                for (uint32_t k = md.fac_lc_off[f]; k < md.fac_lc_off[f + 1]; ++k) muls += md.lc_one[k] ? 0 : 2;
+        }
+        m->muls_per_pair = muls;
+    }
     // every table must be mentioned by the summand: a fused round binds a table through its owner entry
     for (uint32_t t = 0; ok && t < d->n_tables; ++t) {
         bool used = false;
@@ -796,7 +807,11 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         jolt_member* m = members[i];
         Item& it = items[i];
         if (binds && binds[i]) {
-            const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && m->len >= 4 && (m->kind == jolt_member::kSplitEqProduct || m->all_tables_used);
+            // Fuse only where it pays: the separate bind kernel runs at the HBM roofline with its multiplies hidden, so moving
+            // them into an ALU-bound round kernel (many multiplies per table) costs more than the saved pass; fuse the
+            // bandwidth-bound members (<= 2 multiplies per table per pair) and never the latency-bound tail rounds.
+            const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && m->len / 4 > kTailPairs &&
+                                  (m->kind == jolt_member::kSplitEqProduct || (m->all_tables_used && m->muls_per_pair <= 2 * m->tables.size()));
             JOLT_TRY(member_note_bind(m, *binds[i]));  // m->len is now the bound length
             if (can_fuse) {
                 it.fused = true;

@@ -13,6 +13,7 @@ struct jolt_member {
     uint32_t degree = 0;
     int32_t order = JOLT_ORDER_LOW_TO_HIGH;
     bool skip_one = false;
+    size_t muls_per_pair = 0;     // field multiplies of the round kernel per pair (decides whether fusing the bind pays)
     bool all_tables_used = true;  // every table is mentioned by the summand (needed to fuse binds into the round kernel)
     bool borrowed = false;  // tables are views of caller-owned tables (never written); scratch is owned
     std::vector<jolt_table*> tables;  // owned

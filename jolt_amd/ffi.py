@@ -533,3 +533,38 @@ def host_g1_serialize_compressed(p):
     out = (C.c_uint8 * 32)()
     _ck(lib().jolt_host_g1_serialize_compressed(_p(np.ascontiguousarray(p, dtype=np.uint64)), out), "jolt_host_g1_serialize_compressed")
     return bytes(out)
+
+
+def _table_op2(name):
+    def f(self, a, b):
+        h = C.c_void_p()
+        _ck(getattr(lib(), name)(self.h, a.h, b.h, C.byref(h)), name, self)
+        return Table(self, h)
+    return f
+
+
+def _tile(self, base, copies):
+    h = C.c_void_p()
+    _ck(lib().jolt_tile(self.h, base.h, C.c_size_t(copies), C.byref(h)), "jolt_tile", self)
+    return Table(self, h)
+
+
+def _replicate_stream_lsb(self, base):
+    h = C.c_void_p()
+    _ck(lib().jolt_replicate_stream_lsb(self.h, base.h, C.byref(h)), "jolt_replicate_stream_lsb", self)
+    return Table(self, h)
+
+
+def _rlc(self, tables, scalars):
+    hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+    sc = fr(scalars).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_rlc(self.h, hs, C.c_size_t(len(tables)), _p(sc), C.byref(h)), "jolt_rlc", self)
+    return Table(self, h)
+
+
+Context.address_fold = _table_op2("jolt_address_fold")
+Context.cycle_fold = _table_op2("jolt_cycle_fold")
+Context.tile = _tile
+Context.replicate_stream_lsb = _replicate_stream_lsb
+Context.rlc = _rlc

@@ -127,3 +127,45 @@ def test_full_size_bind_chain_equals_evaluate(ctx):
     tab2 = ctx.upload(t)
     ctx.bind([tab2], pt[n - 1], ffi.ORDER_LOW_TO_HIGH)
     assert np.array_equal(tab2.download(0, 1 << 11), O.bind_low_to_high(t[: 1 << 12], pt[n - 1]))
+
+
+def test_views_and_rlc_match_reference_definitions(ctx):
+    """address_fold / cycle_fold / tile / replicate_stream_lsb (reference/views.rs:35-138) and the RLC joint polynomial
+    (multilinear.rs:358-464), checked against their defining sums computed with the oracle's field ops."""
+    log_k, log_t = 3, 6
+    K, T = 1 << log_k, 1 << log_t
+    grid = rand_fr(K * T, 900)
+    pk, pt = rand_fr(log_k, 901), rand_fr(log_t, 902)
+    eqk, eqt = O.eq_evals(pk), O.eq_evals(pt)
+    g = grid.reshape(K, T, 4)
+    want_a = np.zeros((T, 4), dtype=np.uint64)
+    for k in range(K):
+        want_a = O.fr_add(want_a, O.fr_mul(g[k], np.repeat(eqk[k:k + 1], T, axis=0)))
+    want_c = np.zeros((K, 4), dtype=np.uint64)
+    for k in range(K):
+        prod = O.fr_mul(g[k], eqt)
+        acc = np.zeros((1, 4), dtype=np.uint64)
+        for row in prod:
+            acc = O.fr_add(acc, row.reshape(1, 4))
+        want_c[k] = acc[0]
+    dg = ctx.upload(grid)
+    assert np.array_equal(ctx.address_fold(dg, ctx.eq_evals(pk)).download(), want_a)
+    assert np.array_equal(ctx.cycle_fold(dg, ctx.eq_evals(pt)).download(), want_c)
+    with pytest.raises(ffi.JoltError):
+        ctx.address_fold(dg, ctx.upload(grid[:7]))
+    base = rand_fr(16, 903)
+    db = ctx.upload(base)
+    assert np.array_equal(ctx.tile(db, 5).download(), np.tile(base, (5, 1)))
+    assert np.array_equal(ctx.replicate_stream_lsb(db).download(), np.repeat(base, 2, axis=0))
+    tabs = [rand_fr(256, 910 + i) for i in range(5)]
+    gamma = rand_fr(1, 920)
+    sc = [O.to_mont([1])]
+    for _ in range(4):
+        sc.append(O.fr_mul(sc[-1], gamma))
+    sc = np.concatenate(sc, axis=0)
+    want = np.zeros((256, 4), dtype=np.uint64)
+    for t, s in zip(tabs, sc):
+        want = O.fr_add(want, O.fr_mul(t, np.repeat(s.reshape(1, 4), 256, axis=0)))
+    assert np.array_equal(ctx.rlc([ctx.upload(t) for t in tabs], sc).download(), want)
+    with pytest.raises(ffi.JoltError):
+        ctx.rlc([ctx.upload(tabs[0]), ctx.upload(tabs[1][:128])], sc[:2])
