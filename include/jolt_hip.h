@@ -185,6 +185,15 @@ int32_t jolt_member_create_split_eq_product(jolt_ctx *ctx, jolt_table *a, jolt_t
                                             const jolt_fr_t *scale, jolt_member **out);
 int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx *ctx, jolt_table *a, jolt_table *b, const jolt_fr_t *w, size_t n,
                                                      const jolt_fr_t *scale, jolt_member **out);
+/* eq(w, j) * sum_{v<V} coeffs[v] * prod_{i<F} tables[v*F+i](j), eq served from split tables -- the optimized tier's form of
+ * instruction_ra_virtualization / ram_ra_virtualization / ram_hamming_booleanity.  F in {2,3,4},
+ * V <= 16, degree F+1.  prove_round returns the F eq-stripped sums q(0), q(2), .., q(F); aux_out = {current_scalar,
+ * w[current_index-1], 0}; the caller recovers q(1) from the running claim and multiplies by the linear eq factor
+ * (GruenSplitEqPolynomial::gruen_poly_from_evals, crates/jolt-poly/src/split_eq.rs:419-447).
+ * flags: JOLT_MEMBER_FLAG_BORROW_TABLES.  shard_scale may be NULL (see the sharded product variant below). */
+int32_t jolt_member_create_split_eq_uniform(jolt_ctx *ctx, jolt_table *const *tables, uint32_t V, uint32_t F, const jolt_fr_t *coeffs,
+                                            const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, const jolt_fr_t *shard_scale,
+                                            uint32_t flags, jolt_member **out);
 /* Sharded variant (one process per GPU): this rank holds rows of the block selected by the top log2 G
  * variables; `w` are the n local coordinates (the low ones), `scale` the global initial scalar and `shard_scale` =
  * eq(w_hi, rank) multiplies the E_out tables so that the ranks' partial sums simply add. Borrows a and b. */
@@ -265,6 +274,10 @@ int32_t jolt_host_fr_mul_shifted(const jolt_fr_t *a, const jolt_fr_t *c, jolt_fr
 /* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
 int32_t jolt_host_univariate_from_evals(const jolt_fr_t *evals, size_t n, jolt_fr_t *coeffs_out);
 int32_t jolt_host_univariate_evaluate(const jolt_fr_t *coeffs, size_t n, const jolt_fr_t *x, jolt_fr_t *out);
+/* s(t) = l(t) q(t) from q(0), q(2), .., q(dq) and the claim s(0)+s(1) (split_eq.rs:419-447 gruen_poly_from_evals, with the
+ * evaluation set of the device kernel): dq + 2 coefficients. */
+int32_t jolt_host_gruen_poly_from_q(const jolt_fr_t *current_scalar, const jolt_fr_t *point_i, const jolt_fr_t *q_evals, size_t dq,
+                                    const jolt_fr_t *s0_plus_s1, jolt_fr_t *coeffs_out);
 /* GruenSplitEqPolynomial::gruen_poly_deg_3 (split_eq.rs:383-417): 4 coefficients */
 int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t *current_scalar, const jolt_fr_t *point_i, const jolt_fr_t *q_constant,
                                    const jolt_fr_t *q_quadratic, const jolt_fr_t *s0_plus_s1, jolt_fr_t *coeffs_out);

@@ -19,7 +19,7 @@ struct jolt_batch {
     bool full_width = false;
     MockTranscript transcript{0};
     std::vector<BatchMember> described;
-    std::vector<int32_t> kind;        // 0 expr, 1 expr with skipped s(1), 2 split-eq product
+    std::vector<int32_t> kind;        // 0 expr, 1 expr with skipped s(1), 2 split-eq product, 3 split-eq uniform product
     std::vector<uint32_t> degree;
     std::vector<std::vector<Fr>> w;   // split-eq: global point (rounds coordinates)
     std::vector<Fr> current_scalar;   // split-eq: GruenSplitEqPolynomial::current_scalar
@@ -29,7 +29,7 @@ struct jolt_batch {
     Fr running_claim;
     std::vector<Fr> challenges;
     std::vector<UnivariatePoly> round_polys;
-    size_t n_evals(size_t i) const { return kind[i] == 2 ? 2 : (kind[i] == 1 ? degree[i] : degree[i] + 1); }
+    size_t n_evals(size_t i) const { return kind[i] == 2 ? 2 : (kind[i] == 3 ? degree[i] - 1 : (kind[i] == 1 ? degree[i] : degree[i] + 1)); }
 };
 
 extern "C" int32_t jolt_host_batch_begin(jolt_ctx* ctx, size_t n_members, const jolt_fr_t* input_claims, const jolt_fr_t* coefficients,
@@ -53,7 +53,7 @@ extern "C" int32_t jolt_host_batch_begin(jolt_ctx* ctx, size_t n_members, const 
         b->degree.push_back(degrees[i]);
         std::vector<Fr> w;
         Fr scalar = Fr::one();
-        if (kinds[i] == 2) {
+        if (kinds[i] >= 2) {
             if (!split_eq_points || !split_eq_points[i]) { delete b; return JOLT_ERR_INVALID_ARG; }
             for (size_t k = 0; k < rounds[i]; ++k) w.push_back(fr_from_abi(&split_eq_points[i][k]));
             if (split_eq_scales) scalar = fr_from_abi(&split_eq_scales[i]);
@@ -77,7 +77,7 @@ typedef int32_t (*jolt_local_round_fn)(void* user, const size_t* active, size_t 
 typedef int32_t (*jolt_gather_fn)(void* user, const jolt_fr_t* local, size_t count, jolt_fr_t* gathered);
 
 static void note_bind(jolt_batch* b, size_t i, const Fr& c) {
-    if (b->kind[i] == 2) {  // split_eq.rs:334-337
+    if (b->kind[i] >= 2) {  // split_eq.rs:334-337
         size_t current_index = b->described[i].rounds - b->bound[i];
         Fr p = b->w[i][current_index - 1];
         Fr prod = mul(p, c);
@@ -90,6 +90,10 @@ static int32_t assemble(const jolt_batch* b, size_t i, const Fr* ev, const Fr& c
     if (b->kind[i] == 2) {
         size_t current_index = b->described[i].rounds - b->bound[i];
         return gruen_poly_deg_3(b->current_scalar[i], b->w[i][current_index - 1], ev[0], ev[1], claim, out);
+    }
+    if (b->kind[i] == 3) {
+        size_t current_index = b->described[i].rounds - b->bound[i];
+        return gruen_poly_from_q(b->current_scalar[i], b->w[i][current_index - 1], ev, b->degree[i] - 1, claim, out);
     }
     std::vector<Fr> full;
     if (b->kind[i] == 1) {

@@ -666,6 +666,54 @@ extern "C" int32_t jolt_member_create_expr(jolt_ctx* ctx, jolt_table* const* tab
     return jolt_member_create_lc(ctx, tables, &lc, out);
 }
 
+// GruenSplitEqPolynomial::new_with_scaling(w, LowToHigh, scale) (split_eq.rs:187-236): head = w[..n-1], out_point = head[..split],
+// in_point = rest; evals_cached -> one device table per prefix length.  shard_scale multiplies the E_out tables.
+static int32_t init_split_eq(jolt_ctx* ctx, jolt_member* m, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale) {
+    JOLT_TRY(read_point(ctx, w, n, m->w));
+    m->current_scalar = scale ? fr_from_abi(scale) : Fr::one();
+    m->initial_scalar = m->current_scalar;
+    if (n > 0) {
+        size_t split = n / 2, head_len = n - 1;
+        m->out_len = std::min(split, head_len);
+        m->in_len = head_len - m->out_len;
+        jolt_table* last = nullptr;
+        Fr e_out_scale = shard_scale ? fr_from_abi(shard_scale) : Fr::one();
+        JOLT_TRY(eq_build(ctx, m->w.data(), m->out_len, e_out_scale, 1, &m->e_out_cache, &last));
+        JOLT_TRY(eq_build(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), 1, &m->e_in_cache, &last));
+        m->e_out_bits = m->out_len;
+        m->e_in_bits = m->in_len;
+    }
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_member_create_split_eq_uniform(jolt_ctx* ctx, jolt_table* const* tables, uint32_t V, uint32_t F, const jolt_fr_t* coeffs,
+                                                       const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale, uint32_t flags,
+                                                       jolt_member** out) {
+    if (!ctx || !tables || !coeffs || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
+    if (F < 2 || F > 4 || V < 1 || V > (uint32_t)kMaxGroups || (size_t)V * F > (size_t)kMaxBatchTables || n == 0) return JOLT_ERR_UNSUPPORTED;
+    const bool borrow = (flags & JOLT_MEMBER_FLAG_BORROW_TABLES) != 0;
+    jolt_member* m = new (std::nothrow) jolt_member();
+    if (!m) return JOLT_ERR_OOM;
+    int32_t s = member_common_init(ctx, tables, V * F, m, borrow);
+    if (s == JOLT_OK && m->rounds != n) s = JOLT_ERR_SIZE_MISMATCH;
+    if (s == JOLT_OK) {
+        m->kind = jolt_member::kSplitEqUniform;
+        m->degree = F + 1;
+        m->order = JOLT_ORDER_LOW_TO_HIGH;
+        m->uni_V = V;
+        m->uni_F = F;
+        for (uint32_t v = 0; v < V && s == JOLT_OK; ++v) {
+            Fr c = fr_from_abi(&coeffs[v]);
+            if (!fr_is_canonical(c)) s = JOLT_ERR_INVALID_ARG;
+            m->uni_coeff.push_back(c);
+        }
+    }
+    if (s == JOLT_OK) s = init_split_eq(ctx, m, w, n, scale, shard_scale);
+    if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
+    *out = m;
+    return JOLT_OK;
+}
+
 static int32_t create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale,
                                        bool borrow, jolt_member** out, const jolt_fr_t* shard_scale = nullptr) {
     if (!ctx || !a || !b || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
@@ -678,24 +726,8 @@ static int32_t create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table*
     m->kind = jolt_member::kSplitEqProduct;
     m->degree = 3;
     m->order = JOLT_ORDER_LOW_TO_HIGH;
-    s = read_point(ctx, w, n, m->w);
+    s = init_split_eq(ctx, m, w, n, scale, shard_scale);
     if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
-    m->current_scalar = scale ? fr_from_abi(scale) : Fr::one();
-    m->initial_scalar = m->current_scalar;
-    // GruenSplitEqPolynomial::new (split_eq.rs:214-236): head = w[..n-1], out_point = head[..split], in_point = rest;
-    // evals_cached -> one table per prefix length.
-    if (n > 0) {
-        size_t split = n / 2, head_len = n - 1;
-        m->out_len = std::min(split, head_len);
-        m->in_len = head_len - m->out_len;
-        jolt_table* last = nullptr;
-        Fr e_out_scale = shard_scale ? fr_from_abi(shard_scale) : Fr::one();
-        s = eq_build(ctx, m->w.data(), m->out_len, e_out_scale, 1, &m->e_out_cache, &last);
-        if (s == JOLT_OK) s = eq_build(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), 1, &m->e_in_cache, &last);
-        if (s != JOLT_OK) { if (!borrow) m->tables.clear(); jolt_member_destroy(m); return s; }
-        m->e_out_bits = m->out_len;
-        m->e_in_bits = m->in_len;
-    }
     *out = m;
     return JOLT_OK;
 }
@@ -742,7 +774,7 @@ extern "C" int32_t jolt_member_degree(const jolt_member* m, uint32_t* degree) {
 // binds themselves are enqueued by the caller (grouped over members)
 static int32_t member_note_bind(jolt_member* m, const Fr& c) {
     if (m->bound >= m->rounds) { m->ctx->last_error = "member already fully bound"; return JOLT_ERR_INVALID_ARG; }
-    if (m->kind == jolt_member::kSplitEqProduct) {
+    if (m->kind != jolt_member::kExpr) {
         size_t n = m->rounds;
         size_t current_index = n - m->bound;
         Fr p = m->w[current_index - 1];
@@ -764,6 +796,7 @@ static int32_t member_bind(jolt_member* m, const Fr& c) {
 
 size_t jolt_internal_member_n_evals(const jolt_member* m) {
     if (m->kind == jolt_member::kSplitEqProduct) return 2;
+    if (m->kind == jolt_member::kSplitEqUniform) return m->uni_F;
     return m->skip_one ? m->degree : m->degree + 1;
 }
 
@@ -811,7 +844,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             // them into an ALU-bound round kernel (many multiplies per table) costs more than the saved pass; fuse the
             // bandwidth-bound members (<= 2 multiplies per table per pair) and never the latency-bound tail rounds.
             const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && m->len / 4 > kTailPairs &&
-                                  (m->kind == jolt_member::kSplitEqProduct || (m->all_tables_used && m->muls_per_pair <= 2 * m->tables.size()));
+                                  (m->kind == jolt_member::kSplitEqProduct || (m->kind == jolt_member::kExpr && m->all_tables_used && m->muls_per_pair <= 2 * m->tables.size()));
             JOLT_TRY(member_note_bind(m, *binds[i]));  // m->len is now the bound length
             if (can_fuse) {
                 it.fused = true;
@@ -926,10 +959,12 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         launches.push_back(std::move(L));
     }
     for (size_t i = 0; i < n; ++i) {
-        if (members[i]->kind != jolt_member::kSplitEqProduct) continue;
-        items[i].grid = sweep_grid(ctx, members[i]->len / 2);
+        if (members[i]->kind == jolt_member::kExpr) continue;
+        size_t work = members[i]->len / 2;
+        if (members[i]->kind == jolt_member::kSplitEqUniform) work *= members[i]->uni_V;
+        items[i].grid = sweep_grid(ctx, work);
         items[i].part_off = (uint32_t)part_total;
-        part_total += (size_t)items[i].grid * 2;
+        part_total += (size_t)items[i].grid * items[i].ne;
     }
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, part_total + 8, slot + 8));
     RoundDone rd;
@@ -956,6 +991,26 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             if (L.skip) launch_round_group<1, true, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
             else launch_round_group<1, false, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
         }
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    for (size_t i = 0; i < n; ++i) {
+        jolt_member* m = members[i];
+        if (m->kind != jolt_member::kSplitEqUniform) continue;
+        const Item& it = items[i];
+        UniformArgs ua;
+        ua.V = (int)m->uni_V;
+        for (size_t k = 0; k < (size_t)kMaxBatchTables; ++k) ua.tabs[k] = k < it.in.size() ? it.in[k] : nullptr;
+        for (size_t v = 0; v < (size_t)kMaxGroups; ++v) {
+            ua.coeff[v] = v < m->uni_coeff.size() ? m->uni_coeff[v] : Fr::zero();
+            ua.coeff_one[v] = v < m->uni_coeff.size() && m->uni_coeff[v] == Fr::one() ? 1u : 0u;
+        }
+        const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
+        const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
+        dim3 g(it.grid), b(kBlock);
+        Fr* part = ctx->d_partials + it.part_off;
+        if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform<2>, g, b, 0, ctx->stream, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+        else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform<3>, g, b, 0, ctx->stream, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+        else hipLaunchKernelGGL(k_split_eq_uniform<4>, g, b, 0, ctx->stream, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     for (size_t i = 0; i < n; ++i) {
@@ -1003,7 +1058,7 @@ static int32_t round_wait(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
 static void member_aux(const jolt_member* m, jolt_fr_t* aux) {
     if (!aux) return;
     Fr z = Fr::zero();
-    if (m->kind == jolt_member::kSplitEqProduct && m->bound < m->rounds) {
+    if (m->kind != jolt_member::kExpr && m->bound < m->rounds) {
         fr_to_abi(&aux[0], m->current_scalar);
         fr_to_abi(&aux[1], m->w[m->rounds - m->bound - 1]);
     } else {
@@ -1082,14 +1137,14 @@ extern "C" int32_t jolt_member_finish(jolt_member* m, const jolt_fr_t* bind) {
 extern "C" int32_t jolt_member_final_values(jolt_member* m, jolt_fr_t* out, size_t k) {
     if (!m || !out) return JOLT_ERR_INVALID_ARG;
     if (m->bound != m->rounds) return JOLT_ERR_NOT_FULLY_BOUND;
-    size_t need = m->tables.size() + (m->kind == jolt_member::kSplitEqProduct ? 1 : 0);
+    size_t need = m->tables.size() + (m->kind != jolt_member::kExpr ? 1 : 0);
     if (k != need) return JOLT_ERR_SIZE_MISMATCH;
     jolt_ctx* ctx = m->ctx;
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, need));
     for (size_t i = 0; i < m->tables.size(); ++i)
         JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_results + i, m->tables[i]->data(), sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
     JOLT_TRY(fetch_results(ctx, m->tables.size(), out));
-    if (m->kind == jolt_member::kSplitEqProduct) fr_to_abi(&out[m->tables.size()], m->current_scalar);
+    if (m->kind != jolt_member::kExpr) fr_to_abi(&out[m->tables.size()], m->current_scalar);
     return JOLT_OK;
 }
 
@@ -1123,23 +1178,31 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
         JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
         return fetch_results(ctx, 1, out);
     }
-    // split-eq product: sum_x scale * eq(w[..remaining], x) a(x) b(x) with the dense eq table (claim helper only)
+    // split-eq members: sum_x scale * eq(w[..remaining], x) * (product terms) with the dense eq table (claim helper only)
     size_t rem = m->rounds - m->bound;
     jolt_table* eq = nullptr;
     JOLT_TRY(eq_build(ctx, m->w.data(), rem, m->current_scalar, 8, nullptr, &eq));
     MemberDesc md;
     std::memset(&md, 0, sizeof(md));
-    md.n_groups = 1; md.n_factors = 3; md.n_lc = 3;
-    md.grp_fac_off[0] = 0; md.grp_fac_off[1] = 3;
-    for (uint32_t f = 0; f <= 3; ++f) md.fac_lc_off[f] = f;
-    for (uint32_t k = 0; k < 3; ++k) { md.lc_tab[k] = k; md.lc_one[k] = 1; md.lc_owner[k] = 1; md.lc_coeff[k] = Fr::one(); }
+    const uint32_t V = m->kind == jolt_member::kSplitEqUniform ? m->uni_V : 1, F = m->kind == jolt_member::kSplitEqUniform ? m->uni_F : 2;
+    if ((size_t)V * (F + 1) > (size_t)kMaxLc || m->tables.size() + 1 > (size_t)kMaxBatchTables) { jolt_table_free(ctx, eq); return JOLT_ERR_UNSUPPORTED; }
+    md.n_groups = V; md.n_factors = V * (F + 1); md.n_lc = V * (F + 1);
+    for (uint32_t v = 0; v <= V; ++v) md.grp_fac_off[v] = v * (F + 1);
+    for (uint32_t f = 0; f <= md.n_factors; ++f) md.fac_lc_off[f] = f;
+    for (uint32_t v = 0; v < V; ++v) {
+        uint32_t base = v * (F + 1);
+        Fr c = m->kind == jolt_member::kSplitEqUniform ? m->uni_coeff[v] : Fr::one();
+        md.lc_tab[base] = 0; md.lc_coeff[base] = c; md.lc_one[base] = c == Fr::one() ? 1u : 0u;  // table 0 = dense eq
+        for (uint32_t k = 0; k < F; ++k) { md.lc_tab[base + 1 + k] = 1 + v * F + k; md.lc_one[base + 1 + k] = 1; md.lc_coeff[base + 1 + k] = Fr::one(); }
+    }
     MemberDesc* dd = nullptr;
     JOLT_HIP_TRY(ctx, hipMalloc((void**)&dd, sizeof(MemberDesc)));
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(dd, &md, sizeof(md), hipMemcpyHostToDevice, ctx->stream));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     TablePtrs tp;
     for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = nullptr;
-    tp.p[0] = eq->data(); tp.p[1] = m->tables[0]->data(); tp.p[2] = m->tables[1]->data();
+    tp.p[0] = eq->data();
+    for (size_t k = 0; k < m->tables.size(); ++k) tp.p[1 + k] = m->tables[k]->data();
     hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)dd, tp, m->len, ctx->d_partials);
     JOLT_HIP_TRY(ctx, hipGetLastError());
     JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));

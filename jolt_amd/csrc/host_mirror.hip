@@ -101,6 +101,28 @@ int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& 
     return JOLT_OK;
 }
 
+// s(t) = l(t) q(t) with l(0) = scalar (1 - w_i), l(1) = scalar w_i, from q(0), q(2), .., q(dq) and claim = s(0) + s(1):
+// q(1) = (claim - l(0) q(0)) / l(1), interpolate q on {0..dq}, multiply by the linear factor.  Same polynomial as
+// GruenSplitEqPolynomial::gruen_poly_from_evals (split_eq.rs:419-447) produces from its own evaluation set.
+int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr* q_evals, size_t dq, const Fr& s0_plus_s1, UnivariatePoly* out) {
+    Fr l1 = mul(current_scalar, point_i);
+    Fr l0 = sub(current_scalar, l1);
+    if (l1.is_zero()) return JOLT_ERR_NOT_INVERTIBLE;
+    std::vector<Fr> q(dq + 1);
+    q[0] = q_evals[0];
+    q[1] = mul(sub(s0_plus_s1, mul(l0, q[0])), inv(l1));
+    for (size_t t = 2; t <= dq; ++t) q[t] = q_evals[t - 1];
+    UnivariatePoly qp = UnivariatePoly::from_evals(q.data(), q.size());
+    Fr lc1 = sub(l1, l0);
+    std::vector<Fr> sc(dq + 2, Fr::zero());
+    for (size_t k = 0; k <= dq; ++k) {
+        sc[k] = add(sc[k], mul(qp.coefficients[k], l0));
+        sc[k + 1] = add(sc[k + 1], mul(qp.coefficients[k], lc1));
+    }
+    out->coefficients = std::move(sc);
+    return JOLT_OK;
+}
+
 // ---- transcript ----------------------------------------------------------------------------------------------
 void Transcript::append_fr(const Fr& v) {
     uint8_t b[32];
@@ -160,6 +182,10 @@ int32_t DeviceMember::assemble(const Fr* evals, const Fr& previous_claim, Univar
         // ram_hamming_booleanity.rs:128-135: message = gruen_poly_deg_3(q(0), q(inf), previous_claim)
         size_t current_index = m->rounds - m->bound;
         return gruen_poly_deg_3(m->current_scalar, m->w[current_index - 1], evals[0], evals[1], previous_claim, out);
+    }
+    if (m->kind == jolt_member::kSplitEqUniform) {
+        size_t current_index = m->rounds - m->bound;
+        return gruen_poly_from_q(m->current_scalar, m->w[current_index - 1], evals, m->uni_F, previous_claim, out);
     }
     std::vector<Fr> full;
     if (m->skip_one) {
@@ -400,6 +426,17 @@ extern "C" int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t* current_scalar, c
     JOLT_TRY(gruen_poly_deg_3(fr_from_abi(current_scalar), fr_from_abi(point_i), fr_from_abi(q_constant), fr_from_abi(q_quadratic),
                               fr_from_abi(s0_plus_s1), &p));
     for (size_t i = 0; i < 4; ++i) fr_to_abi(&coeffs_out[i], p.coefficients[i]);
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_host_gruen_poly_from_q(const jolt_fr_t* current_scalar, const jolt_fr_t* point_i, const jolt_fr_t* q_evals, size_t dq,
+                                               const jolt_fr_t* s0_plus_s1, jolt_fr_t* coeffs_out) {
+    if (!current_scalar || !point_i || !q_evals || !s0_plus_s1 || !coeffs_out || dq < 1 || dq > 8) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> q(dq);
+    for (size_t i = 0; i < dq; ++i) q[i] = fr_from_abi(&q_evals[i]);
+    UnivariatePoly p;
+    JOLT_TRY(gruen_poly_from_q(fr_from_abi(current_scalar), fr_from_abi(point_i), q.data(), dq, fr_from_abi(s0_plus_s1), &p));
+    for (size_t i = 0; i < dq + 2; ++i) fr_to_abi(&coeffs_out[i], p.coefficients[i]);
     return JOLT_OK;
 }
 

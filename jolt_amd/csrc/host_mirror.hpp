@@ -134,6 +134,7 @@ int32_t prove_batch(const BatchPrelude& prelude, std::vector<ProveRounds*>& memb
 Fr fr_mul_pow_2(Fr a, size_t k);
 int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& q_constant, const Fr& q_quadratic, const Fr& s0_plus_s1,
                          UnivariatePoly* out);
+int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr* q_evals, size_t dq, const Fr& s0_plus_s1, UnivariatePoly* out);
 void fr_to_bytes_le(const Fr& a, uint8_t out[32]);
 Fr fr_from_challenge_bytes(const uint8_t* b, size_t n);
 Fr fr_from_scalar_challenge_bytes(const uint8_t* b, size_t n);

@@ -5,7 +5,7 @@
 #include "desc.hpp"
 
 struct jolt_member {
-    enum Kind { kExpr = 0, kSplitEqProduct = 1 };
+    enum Kind { kExpr = 0, kSplitEqProduct = 1, kSplitEqUniform = 2 };
     jolt_ctx* ctx = nullptr;
     int kind = kExpr;
     size_t rounds = 0, bound = 0;
@@ -25,6 +25,9 @@ struct jolt_member {
     size_t out_len = 0, in_len = 0;        // lengths of out_point / in_point
     size_t e_out_bits = 0, e_in_bits = 0;  // prefix lengths of the CURRENT E_out / E_in tables
     std::vector<jolt_table*> e_out_cache, e_in_cache;  // evals_cached: index j = eq over the first j coordinates
+    // split-eq uniform product: eq * sum_v coeff[v] * prod_{i<F} tables[v*F+i]
+    uint32_t uni_V = 0, uni_F = 0;
+    std::vector<Fr> uni_coeff;
 };
 
 size_t jolt_internal_member_n_evals(const jolt_member* m);

@@ -220,6 +220,90 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_product(const Fr* __
     finish_member(partials, 2, ticket, slot, rd);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-eq "uniform product" member:  eq(w, j) * sum_{v<V} c_v * prod_{i<F} T_{v,i}(j)   (degree F+1)
+// -- the shape of instruction_ra_virtualization (V = 8, F = 4), ram_ra_virtualization (V = 1, F = d) and
+// ram_hamming_booleanity (V = 1, F = 2) in SURVEY.md section 8 a13, the optimized tier's split-eq form
+// (crates/jolt-kernels/src/optimized/ram_hamming_booleanity.rs:111-135, crates/jolt-poly/src/split_eq.rs:449-512).
+// eq never enters the per-pair product: the kernel returns the eq-stripped q(t) = sum_rows E_out E_in sum_v c_v prod_i T(t)
+// at t in {0, 2, .., F} and the host restores s(t) = l(t) q(t) from the running claim.  F is a compile-time constant, so
+// the F pair loads of an item are issued back to back (memory-level parallelism the generic interpreter cannot get) and
+// the product of F linear factors is built as a tree on evaluation points (finite-difference extension costs only adds):
+// F = 4 takes 10 multiplies per item instead of 15.
+// ---------------------------------------------------------------------------------------------------------------------
+struct UniformArgs {
+    const Fr* tabs[kMaxBatchTables];  // V*F tables, v-major
+    Fr coeff[kMaxGroups];             // c_v
+    uint32_t coeff_one[kMaxGroups];
+    int V;
+};
+template <int F>
+__device__ __forceinline__ void uniform_item(const Fr (&lo)[F], const Fr (&hi)[F], Fr (&q)[F]);
+template <>
+__device__ __forceinline__ void uniform_item<2>(const Fr (&lo)[2], const Fr (&hi)[2], Fr (&q)[2]) {
+    Fr a2 = add(hi[0], sub(hi[0], lo[0])), b2 = add(hi[1], sub(hi[1], lo[1]));
+    q[0] = mul(lo[0], lo[1]);
+    q[1] = mul(a2, b2);  // t = 2
+}
+template <>
+__device__ __forceinline__ void uniform_item<3>(const Fr (&lo)[3], const Fr (&hi)[3], Fr (&q)[3]) {
+    Fr s0 = sub(hi[0], lo[0]), s1 = sub(hi[1], lo[1]), s2 = sub(hi[2], lo[2]);
+    Fr a2 = add(hi[0], s0), b2 = add(hi[1], s1), c2 = add(hi[2], s2);
+    Fr a3 = add(a2, s0), b3 = add(b2, s1), c3 = add(c2, s2);
+    q[0] = mul(mul(lo[0], lo[1]), lo[2]);
+    q[1] = mul(mul(a2, b2), c2);
+    q[2] = mul(mul(a3, b3), c3);
+}
+template <>
+__device__ __forceinline__ void uniform_item<4>(const Fr (&lo)[4], const Fr (&hi)[4], Fr (&q)[4]) {
+    // A = f0*f1, B = f2*f3 as quadratics on {0,1,2}; extend both to {3,4} by second differences; q = A*B on {0,2,3,4}
+    Fr v2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v2[i] = add(hi[i], sub(hi[i], lo[i]));
+    Fr A0 = mul(lo[0], lo[1]), A1 = mul(hi[0], hi[1]), A2 = mul(v2[0], v2[1]);
+    Fr B0 = mul(lo[2], lo[3]), B1 = mul(hi[2], hi[3]), B2 = mul(v2[2], v2[3]);
+    Fr dA = sub(A2, A1), ddA = sub(dA, sub(A1, A0));
+    Fr dB = sub(B2, B1), ddB = sub(dB, sub(B1, B0));
+    Fr dA3 = add(dA, ddA), A3 = add(A2, dA3), A4 = add(A3, add(dA3, ddA));
+    Fr dB3 = add(dB, ddB), B3 = add(B2, dB3), B4 = add(B3, add(dB3, ddB));
+    q[0] = mul(A0, B0);
+    q[1] = mul(A2, B2);
+    q[2] = mul(A3, B3);
+    q[3] = mul(A4, B4);
+}
+
+template <int F>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform(UniformArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,
+                                                                    size_t rows, Fr* __restrict__ partials, uint32_t ticket, uint32_t slot, RoundDone rd) {
+    Fr acc[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) acc[t] = Fr::zero();
+    const size_t items = rows * (size_t)a.V;
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += stride) {
+        const uint32_t v = (uint32_t)(i / rows);  // v slowest: a wave shares v
+        const size_t row = i - (size_t)v * rows;
+        Fr lo[F], hi[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) {  // all F pair loads in flight before the first multiply
+            const Fr* __restrict__ tp = a.tabs[v * F + k];
+            lo[k] = ld_fr(tp + 2 * row);
+            hi[k] = ld_fr(tp + 2 * row + 1);
+        }
+        Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+        if (!a.coeff_one[v]) w = mul(w, a.coeff[v]);
+        lo[0] = mul(lo[0], w);
+        hi[0] = mul(hi[0], w);
+        Fr q[F];
+        uniform_item<F>(lo, hi, q);
+#pragma unroll
+        for (int t = 0; t < F; ++t) acc[t] = add(acc[t], q[t]);
+    }
+    block_reduce_store<F>(acc, partials);
+    finish_member(partials, F, ticket, slot, rd);
+}
+
 // summand summed over the whole hypercube (member input claim): same descriptor, no pairing
 static __global__ __launch_bounds__(kBlock) void k_member_claim(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t len, Fr* __restrict__ partials) {
     Fr acc[1] = {Fr::zero()};

@@ -21,7 +21,7 @@ import numpy as np
 from . import ffi
 from . import workload as W
 
-KIND_EXPR, KIND_EXPR_SKIP, KIND_SPLIT_EQ = 0, 1, 2
+KIND_EXPR, KIND_EXPR_SKIP, KIND_SPLIT_EQ, KIND_SPLIT_EQ_UNIFORM = 0, 1, 2, 3
 
 LOCAL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t)
 GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -54,6 +54,8 @@ class MemberInfo:
 
     @property
     def n_evals(self):
+        if self.kind == KIND_SPLIT_EQ_UNIFORM:
+            return self.degree - 1
         return 2 if self.kind == KIND_SPLIT_EQ else (self.degree if self.kind == KIND_EXPR_SKIP else self.degree + 1)
 
 
@@ -134,7 +136,7 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
         gathered = coll.all_gather_u64(finals).reshape(world, -1, 4)
         scalars = []
         for i, info in enumerate(infos):
-            if info.kind == KIND_SPLIT_EQ:
+            if info.kind in (KIND_SPLIT_EQ, KIND_SPLIT_EQ_UNIFORM):
                 o = ffi.fr_array(1)
                 lib.jolt_host_batch_split_eq_scalar(batch, C.c_size_t(i), _p(o))
                 scalars.append(o[0])
@@ -236,7 +238,11 @@ class ShardedWorkload:
         zero = np.zeros(4, dtype=np.uint64)
         self.resolver = W.Resolver(spec["gammas"], one, ffi.host_fr_mul, lambda x: ffi.host_fr_sub(zero, x))
         self.tables = {}
+        skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None}
+        skip -= {t for ms in self.members_spec for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
         for name, t in spec["tables"].items():
+            if name in skip:
+                continue
             if t["kind"] == "u64":
                 self.tables[name] = ctx.from_u64(t["data"])
             elif t["kind"] == "i64":
@@ -244,8 +250,25 @@ class ShardedWorkload:
             else:  # the aligned block of eq(point, .) owned by this rank (EqPolynomial::evals_for_aligned_block)
                 self.tables[name] = ctx.eq_evals_aligned_block(t["point"], rank << n_local, 1 << n_local)
         self.members, self.infos, self.stages = [], [], {}
+        def shard_scale_of(w):
+            sc = one
+            for j in range(log_g):  # eq(w_hi, rank), big-endian
+                bit = (rank >> (log_g - 1 - j)) & 1
+                sc = ffi.host_fr_mul(sc, w[j] if bit else ffi.host_fr_sub(one, w[j]))
+            return sc
+
         for k, ms in enumerate(self.members_spec):
-            tabs = [self.tables[t] for t in ms.tables]
+            tabs = [self.tables.get(t) for t in ms.tables]
+            if ms.uniform is not None:
+                V, F, csyms = ms.uniform
+                w = spec["tables"][ms.tables[0]]["point"]  # the eq leaf's global point
+                coeffs = [self.resolver.coeff(c) for c in csyms]
+                m = ctx.member_split_eq_uniform(tabs[1:], V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w), borrow=True)
+                m._uniform = (V, F, coeffs)
+                self.infos.append(MemberInfo(KIND_SPLIT_EQ_UNIFORM, F + 1, self.n_total, V * F, w=w))
+                self.members.append(m)
+                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+                continue
             if ms.split_eq is not None:
                 a, b, _ = ms.split_eq
                 w = spec["split_points"][k]
@@ -272,7 +295,7 @@ class ShardedWorkload:
         ctx.synchronize()
         # global input claims = sum over ranks of the local claims (one all-gather at setup; in the real prover they are
         # the previous stage's output claims)
-        local_claims = np.stack([m.input_claim() if not m.split_eq else self._split_claim(m) for m in self.members])
+        local_claims = np.stack([self._local_claim(i) for i in range(len(self.members))])
         allc = self.coll.all_gather_u64(local_claims).reshape(world, len(self.members), 4)
         self.claims = []
         for i in range(len(self.members)):
@@ -284,18 +307,23 @@ class ShardedWorkload:
         self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
         self._tails = {}
 
-    def _split_claim(self, m):
-        # local claim of the sharded split-eq member = shard_scale * sum_x eq(w_lo, x) a(x) b(x); the member's own claim
-        # helper ignores the E_out shard scale, so evaluate q(0)+... through one prove_round instead: s(0)+s(1) = claim.
-        # Simpler and exact: sum over the block with a dense eq table scaled by shard_scale.
-        spec_idx = self.members.index(m)
-        ms = self.members_spec[spec_idx]
-        a, b, _ = ms.split_eq
-        info_w = self.infos[spec_idx].w
-        eq = self.ctx.eq_evals_aligned_block(info_w, self.rank << self.n_local, 1 << self.n_local)
+    def _local_claim(self, i):
+        """This rank's share of member i's input claim.  Split-eq members are summed against the rank's aligned block of the
+        dense eq table (the members' own claim helper does not know the shard scale)."""
+        m, ms = self.members[i], self.members_spec[i]
+        if not m.split_eq:
+            return m.input_claim()
         one = ffi.host_fr_from_u64(1)
-        tabs = [eq, self.tables[ms.tables[a]], self.tables[ms.tables[b]]]
-        tmp = self.ctx.member_lc(tabs, [[(None, [(one, 0)]), (None, [(one, 1)]), (None, [(one, 2)])]], 3, borrow=True)
+        eq = self.ctx.eq_evals_aligned_block(self.infos[i].w, self.rank << self.n_local, 1 << self.n_local)
+        if ms.uniform is not None:
+            V, F, coeffs = m._uniform
+            tabs = [eq] + [self.tables[t] for t in ms.tables[1:]]
+            groups = [[(None, [(coeffs[v], 0)])] + [(None, [(one, 1 + v * F + k)]) for k in range(F)] for v in range(V)]
+            tmp = self.ctx.member_lc(tabs, groups, F + 1, borrow=True)
+        else:
+            a, b, _ = ms.split_eq
+            tabs = [eq, self.tables[ms.tables[a]], self.tables[ms.tables[b]]]
+            tmp = self.ctx.member_lc(tabs, [[(None, [(one, 0)]), (None, [(one, 1)]), (None, [(one, 2)])]], 3, borrow=True)
         c = tmp.input_claim()
         tmp.destroy()
         eq.free()
@@ -326,7 +354,10 @@ class ShardedWorkload:
                     tabs.append(ffi.Table(ctx, h))
                     pos += 1
                 slices.extend(tabs)
-                if m.split_eq:
+                if getattr(m, "uniform", False):
+                    V, F, coeffs = m._uniform
+                    tm = ctx.member_split_eq_uniform(tabs, V, F, coeffs, self.infos[i].w[:log_g], scale=scalars[idxs.index(i)], borrow=True)
+                elif m.split_eq:
                     tm = ctx.member_split_eq_product(tabs[0], tabs[1], self.infos[i].w[:log_g], scale=scalars[idxs.index(i)], borrow=True)
                 else:
                     tm = ctx.member_lc(tabs, m._groups, m.degree, borrow=True, skip_one=True)
@@ -341,7 +372,11 @@ class ShardedWorkload:
                 if self.members[i].split_eq:  # its initial scalar depends on this proof's challenges: rebuild that member
                     members[k].destroy()
                     base = sum(self.members[j].n_tables for j in idxs[:k])
-                    members[k] = ctx.member_split_eq_product(slices[base], slices[base + 1], self.infos[i].w[:log_g], scale=scalars[k], borrow=True)
+                    if getattr(self.members[i], "uniform", False):
+                        V, F, coeffs = self.members[i]._uniform
+                        members[k] = ctx.member_split_eq_uniform(slices[base:base + V * F], V, F, coeffs, self.infos[i].w[:log_g], scale=scalars[k], borrow=True)
+                    else:
+                        members[k] = ctx.member_split_eq_product(slices[base], slices[base + 1], self.infos[i].w[:log_g], scale=scalars[k], borrow=True)
                 else:
                     members[k].reset()
         return DeviceShard(ctx, members)

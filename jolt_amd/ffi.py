@@ -235,6 +235,27 @@ class Context:
             b.h = None
         return m
 
+    def member_split_eq_uniform(self, tables, V, F, coeffs, w, scale=None, shard_scale=None, borrow=False):
+        """eq(w,.) * sum_v coeffs[v] * prod_{i<F} tables[v*F+i]; prove_round returns q(0), q(2), .., q(F)."""
+        w = fr(w).reshape(-1, 4)
+        co = np.ascontiguousarray(np.stack([fr(c) for c in coeffs])).reshape(-1, 4)
+        hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        h = C.c_void_p()
+        _ck(lib().jolt_member_create_split_eq_uniform(self.h, hs, C.c_uint32(V), C.c_uint32(F), _p(co), _p(w), C.c_size_t(w.shape[0]),
+                                                      _p(fr(scale)) if scale is not None else None,
+                                                      _p(fr(shard_scale)) if shard_scale is not None else None,
+                                                      C.c_uint32(MEMBER_FLAG_BORROW_TABLES if borrow else 0), C.byref(h)),
+            "jolt_member_create_split_eq_uniform", self)
+        m = Member(self, h, F + 1, len(tables), True, False)
+        m.n_evals = F
+        m.uniform = True
+        if borrow:
+            m._keepalive = list(tables)
+        else:
+            for t in tables:
+                t.h = None
+        return m
+
     def round_group_prove(self, members, binds):
         hs = (C.c_void_p * len(members))(*[m.h for m in members])
         bstore = [None if b is None else fr(b) for b in binds]
@@ -318,6 +339,7 @@ class Member:
     def __init__(self, ctx, handle, degree, n_tables, split_eq, skip_one):
         self.ctx, self.h, self.degree, self.n_tables, self.split_eq, self.skip_one = ctx, handle, degree, n_tables, split_eq, skip_one
         self.n_evals = 2 if split_eq else (degree if skip_one else degree + 1)
+        self.uniform = False
 
     def num_rounds(self):
         n = C.c_size_t()
@@ -396,6 +418,14 @@ def host_univariate_evaluate(coeffs, x):
     o = fr_array(1)
     _ck(lib().jolt_host_univariate_evaluate(_p(c), C.c_size_t(c.shape[0]), _p(fr(x)), _p(o)), "jolt_host_univariate_evaluate")
     return o[0]
+
+
+def host_gruen_poly_from_q(scalar, point_i, q_evals, claim):
+    q = fr(q_evals).reshape(-1, 4)
+    o = fr_array(q.shape[0] + 2)
+    _ck(lib().jolt_host_gruen_poly_from_q(_p(fr(scalar)), _p(fr(point_i)), _p(q), C.c_size_t(q.shape[0]), _p(fr(claim)), _p(o)),
+        "jolt_host_gruen_poly_from_q")
+    return o
 
 
 def host_gruen_poly_deg_3(scalar, point_i, q0, qinf, claim):

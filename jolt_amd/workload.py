@@ -30,10 +30,12 @@ class TableSpec:
 
 
 class MemberSpec:
-    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, reference=""):
+    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, uniform=None, reference=""):
         self.name, self.stage, self.degree, self.tables = name, stage, degree, tables
         self.groups = groups        # LC form: [[(const|None, [(coeff, local_table_idx), ...]), ...], ...]
         self.split_eq = split_eq    # (a_idx, b_idx, w) for the split-eq product member
+        self.uniform = uniform      # (V, F, [coeff symbols]): tables[0] is eq(w,.), tables[1 + v*F + i] the product tables;
+                                    # the device serves eq from split tables (split-eq uniform member), the oracle uses `groups`
         self.reference = reference  # reference file of the relation
 
 
@@ -118,12 +120,14 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
     t = [derived("s6.eq_rv", "eq")] + [derived(f"s6.ram_ra{i}", "eq") for i in range(d_ram)]
     members.append(MemberSpec("ram_ra_virtualization", 6, 1 + d_ram, t,
                               groups=[[(None, [("one", i)]) for i in range(1 + d_ram)]],
+                              uniform=(1, d_ram, ["one"]) if 2 <= d_ram <= 4 else None,
                               reference="crates/jolt-kernels/src/reference/ram_ra_virtualization.rs"))
     # ---- stage 6b: instruction_ra_virtualization  eq * sum_v g^v prod_{i<4} ra_{4v+i}            deg 5, 1+32 tables
     t = [derived("s6.eq_iv", "eq")] + [derived(f"s6.ins_ra{i}", "eq") for i in range(n_instruction_ra)]
     members.append(MemberSpec("instruction_ra_virtualization", 6, 5, t,
                               groups=[[(None, [(("gpow", 7, v), 0)])] + [(None, [("one", 1 + 4 * v + i)]) for i in range(4)]
                                       for v in range(n_instruction_ra // 4)],
+                              uniform=(n_instruction_ra // 4, 4, [("gpow", 7, v) for v in range(n_instruction_ra // 4)]),
                               reference="crates/jolt-kernels/src/reference/instruction_ra_virtualization.rs"))
     gammas = [scalar() for _ in range(8)]
     return tables, members, gammas
@@ -196,10 +200,21 @@ class DeviceWorkload:
         self.resolver = Resolver(gammas, one, ffi.host_fr_mul, lambda x: ffi.host_fr_sub(zero, x))
         self.one = one
         self.tables = {}
+        # eq tables that only feed split-eq uniform members are never materialised on the device
+        skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None}
+        skip -= {t for ms in self.members_spec for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
         for name, spec in self.tables_spec.items():
-            self.tables[name] = self._make_table(spec)
+            if name not in skip:
+                self.tables[name] = self._make_table(spec)
         self.members, self.stages = [], {}
         for ms in self.members_spec:
+            if ms.uniform is not None:
+                V, F, csyms = ms.uniform
+                tabs = [self.tables[t] for t in ms.tables[1:]]
+                m = ctx.member_split_eq_uniform(tabs, V, F, [self.resolver.coeff(c) for c in csyms], self.tables_spec[ms.tables[0]].point, borrow=True)
+                self.members.append(m)
+                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+                continue
             tabs = [self.tables[t] for t in ms.tables]
             if ms.split_eq is not None:
                 a, b, w = ms.split_eq

@@ -37,7 +37,9 @@ def lockstep(dev, orc, n_vars, seed, shifted=True):
         want = orc.prove_round(bind, claim)
         got = dev.prove_round(bind, want_aux=True)
         evals, aux = got
-        if dev.split_eq:
+        if dev.uniform:
+            coeffs = ffi.host_gruen_poly_from_q(aux[0], aux[1], evals, claim)
+        elif dev.split_eq:
             coeffs = ffi.host_gruen_poly_deg_3(aux[0], aux[1], evals[0], evals[1], claim)
         elif dev.skip_one:
             full = np.concatenate([evals[:1], O.fr_sub(claim.reshape(1, 4), evals[:1]), evals[1:]])
@@ -219,3 +221,33 @@ def test_borrowed_members_leave_tables_intact_and_can_be_reset(ctx):
     owned = ctx.member_expr([ctx.upload(a)], [(one(), [0])], 1)
     with pytest.raises(ffi.JoltError):
         owned.reset()
+
+
+@pytest.mark.parametrize("V,F,n_vars", [(1, 2, 6), (1, 3, 7), (3, 3, 5), (1, 4, 8), (8, 4, 7), (2, 4, 1), (8, 4, 13)])
+def test_split_eq_uniform_product_member_lockstep(ctx, V, F, n_vars):
+    """eq * sum_v c_v prod_{i<F} T_{v,i} served from split tables with the product tree on evaluation points must emit the
+    polynomials of the oracle's flat Expr member over the dense eq table (optimized tier vs reference tier)."""
+    N = 1 << n_vars
+    w = rand_fr(n_vars, 9000 + F)
+    tabs = [rand_fr(N, 9100 + k) for k in range(V * F)]
+    coeffs = rand_fr(V, 9200 + V)
+    coeffs[0] = one()
+    scale = rand_fr(1, 9300)[0] if V == 3 else None
+    eq = O.eq_evals(w, scale)
+    terms = [(coeffs[v], [0] + [1 + v * F + k for k in range(F)]) for v in range(V)]
+    orc = O.Member.expr([eq] + tabs, terms, F + 1)
+    dev = ctx.member_split_eq_uniform([ctx.upload(t) for t in tabs], V, F, coeffs, w, scale=scale)
+    claim = orc.input_claim()
+    assert np.array_equal(dev.input_claim(), claim)
+    bind = None
+    for rnd in range(n_vars):
+        want = orc.prove_round(bind, claim)
+        evals, aux = dev.prove_round(bind, want_aux=True)
+        got = ffi.host_gruen_poly_from_q(aux[0], aux[1], evals, claim)
+        assert np.array_equal(got, want), f"round {rnd}"
+        bind = rand_challenge(9400 + rnd)
+        claim = O.univariate_evaluate(want, bind)
+    orc.finish_rounds(bind)
+    dev.finish(bind)
+    fv, ofv = dev.final_values(), orc.final_values()
+    assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])  # bound tables, then the bound eq scalar
