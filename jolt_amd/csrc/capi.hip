@@ -62,6 +62,9 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
             s = JOLT_ERR_HIP;
         else
             *ctx->h_flag = 0;
+        for (int k = 0; k < 3 && s == JOLT_OK; ++k)
+            if (hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) != hipSuccess) s = JOLT_ERR_HIP;
+        if (s == JOLT_OK && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) s = JOLT_ERR_HIP;
     }
     if (s != JOLT_OK) { jolt_ctx_destroy(ctx); return s; }
     *out = ctx;
@@ -72,6 +75,8 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     if (!ctx) return JOLT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 3; ++k) if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -87,6 +92,7 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
 
 extern "C" int32_t jolt_ctx_synchronize(jolt_ctx* ctx) {
     if (!ctx) return JOLT_ERR_INVALID_ARG;
+    for (int k = 0; k < 3; ++k) if (ctx->side[k]) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side[k]));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return JOLT_OK;
 }
@@ -106,7 +112,10 @@ extern "C" int32_t jolt_timer_end(jolt_ctx* ctx, float* ms) {
 }
 
 int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t results) {
+    if (partials > ctx->partials_cap || results > ctx->results_cap)
+        for (int k = 0; k < 3; ++k) if (ctx->side[k]) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side[k]));
     if (partials > ctx->partials_cap) {
+        partials = partials + partials / 2;  // grow geometrically: a reallocation stalls every stream
         if (ctx->d_partials) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(ctx->d_partials)); }
         ctx->d_partials = nullptr;
         JOLT_HIP_TRY(ctx, hipMalloc((void**)&ctx->d_partials, partials * sizeof(Fr)));
@@ -973,26 +982,18 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     rd.flag = ctx->h_flag;
     rd.seq = ++ctx->seq;
     rd.group_total = (uint32_t)n;
-    for (TailLaunch& T : tails) {
-        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, ctx->stream, T.args, T.r, T.shifted, ctx->d_partials, rd);
-        JOLT_HIP_TRY(ctx, hipGetLastError());
+    // fork: the round's independent kernels go round-robin over main + side streams, all ordered after the binds above
+    int n_kernels = (int)tails.size() + (int)launches.size();
+    for (size_t i = 0; i < n; ++i) if (members[i]->kind != jolt_member::kExpr) n_kernels++;
+    int rr = 0;
+    hipStream_t streams[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]};
+    const int n_streams = n_kernels > 1 ? std::min(4, n_kernels) : 1;
+    if (n_streams > 1) {
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int k = 1; k < n_streams; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(streams[k], ctx->ev_fork, 0));
     }
-    for (Launch& L : launches) {
-        dim3 grid(L.grid, (unsigned)L.count);
-        if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
-            if (L.fused) {
-                if (L.skip) launch_round_group<0, true, true>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
-                else launch_round_group<0, false, true>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
-            } else {
-                if (L.skip) launch_round_group<0, true, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
-                else launch_round_group<0, false, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
-            }
-        } else {
-            if (L.skip) launch_round_group<1, true, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
-            else launch_round_group<1, false, false>(L.ne, grid, ctx->stream, L.args, L.r, L.shifted, ctx->d_partials, rd);
-        }
-        JOLT_HIP_TRY(ctx, hipGetLastError());
-    }
+    auto next_stream = [&]() { hipStream_t st = streams[rr % n_streams]; rr++; return st; };
+    // longest kernels first so that they overlap with the short ones
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
         if (m->kind != jolt_member::kSplitEqUniform) continue;
@@ -1008,9 +1009,31 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
         dim3 g(it.grid), b(kBlock);
         Fr* part = ctx->d_partials + it.part_off;
-        if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform<2>, g, b, 0, ctx->stream, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
-        else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform<3>, g, b, 0, ctx->stream, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
-        else hipLaunchKernelGGL(k_split_eq_uniform<4>, g, b, 0, ctx->stream, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+        hipStream_t st = next_stream();
+        if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform<2>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+        else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform<3>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+        else hipLaunchKernelGGL(k_split_eq_uniform<4>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    for (TailLaunch& T : tails) {
+        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, next_stream(), T.args, T.r, T.shifted, ctx->d_partials, rd);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    for (Launch& L : launches) {
+        dim3 grid(L.grid, (unsigned)L.count);
+        hipStream_t lst = next_stream();
+        if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
+            if (L.fused) {
+                if (L.skip) launch_round_group<0, true, true>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
+                else launch_round_group<0, false, true>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
+            } else {
+                if (L.skip) launch_round_group<0, true, false>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
+                else launch_round_group<0, false, false>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
+            }
+        } else {
+            if (L.skip) launch_round_group<1, true, false>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
+            else launch_round_group<1, false, false>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
+        }
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     for (size_t i = 0; i < n; ++i) {
@@ -1021,11 +1044,12 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
         Fr r = it.fused ? it.r : Fr::zero();
         int shifted = fr_low_limbs_zero(r) ? 1 : 0;
+        hipStream_t sst = next_stream();
         if (it.fused)
-            hipLaunchKernelGGL(k_split_eq_product<true>, dim3(it.grid), dim3(kBlock), 0, ctx->stream, it.in[0], it.in[1], it.out[0], it.out[1], r, shifted,
+            hipLaunchKernelGGL(k_split_eq_product<true>, dim3(it.grid), dim3(kBlock), 0, sst, it.in[0], it.in[1], it.out[0], it.out[1], r, shifted,
                                e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
         else
-            hipLaunchKernelGGL(k_split_eq_product<false>, dim3(it.grid), dim3(kBlock), 0, ctx->stream, it.in[0], it.in[1], (Fr*)nullptr, (Fr*)nullptr, r,
+            hipLaunchKernelGGL(k_split_eq_product<false>, dim3(it.grid), dim3(kBlock), 0, sst, it.in[0], it.in[1], (Fr*)nullptr, (Fr*)nullptr, r,
                                shifted, e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }

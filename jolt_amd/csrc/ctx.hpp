@@ -36,6 +36,10 @@ struct jolt_ctx {
     uint32_t* d_counters = nullptr; // [0..31] per-member tickets, [32] group ticket
     uint64_t seq = 0;
     size_t round_cap = 0;
+    // independent kernels of one batch round run concurrently: the main stream plus three side streams, forked after the
+    // round's bind launches (completion is tracked by the in-kernel tickets, not by stream order)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 };
 
