@@ -83,6 +83,10 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     if (ctx->h_round) (void)hipHostFree(ctx->h_round);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (int k = 0; k < 4; ++k) {
+        if (ctx->msm_ws[k]) (void)hipFree(ctx->msm_ws[k]);
+        if (ctx->msm_host[k]) (void)hipHostFree(ctx->msm_host[k]);
+    }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

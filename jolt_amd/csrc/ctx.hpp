@@ -40,6 +40,11 @@ struct jolt_ctx {
     // round's bind launches (completion is tracked by the in-kernel tickets, not by stream order)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr;
+    // MSM lanes: lane 0 runs on `stream`, lanes 1..3 on side[0..2]; each has a grow-only device workspace and a pinned
+    // host buffer for the window sums, so independent MSMs (the HyperKZG level commitments) overlap
+    void* msm_ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t msm_ws_cap[4] = {0, 0, 0, 0};
+    void* msm_host[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 };
 

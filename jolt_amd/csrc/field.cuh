@@ -169,8 +169,64 @@ JOLT_HD Fp<PR> mont_rows(const Fp<PR>& a, const uint32_t* b) {
     return reduce_once(r, t[8]);
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host-side multiplication (transcript/round-message assembly, the MSM's final Horner): the same Montgomery product over
+// 4 x u64 limbs with 128-bit partial products -- x86 has a 64x64->128 multiplier, the GPU does not.  Same canonical result.
 template <class PR>
-JOLT_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) { return mont_rows<PR, 8>(a, b.l); }
+constexpr uint64_t host_neg_inv64() {
+    uint64_t p0 = (uint64_t)PR::P[0] | ((uint64_t)PR::P[1] << 32);
+    uint64_t y = 1;  // Newton: y <- y * (2 - p0 * y) doubles the number of correct low bits
+    for (int i = 0; i < 6; ++i) y *= 2 - p0 * y;
+    return 0 - y;
+}
+template <class PR>
+inline Fp<PR> host_mul64(const Fp<PR>& a, const Fp<PR>& b) {
+    typedef unsigned __int128 u128;
+    constexpr uint64_t NINV = host_neg_inv64<PR>();
+    uint64_t A[4], B[4], P[4], t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        P[i] = (uint64_t)PR::P[2 * i] | ((uint64_t)PR::P[2 * i + 1] << 32);
+    }
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) {
+            c += (u128)A[j] * B[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * NINV;
+        c = ((u128)m * P[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) {
+            c += (u128)m * P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fp<PR> r;
+    for (int i = 0; i < 4; ++i) {
+        r.l[2 * i] = (uint32_t)t[i];
+        r.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    return reduce_once(r, (uint32_t)t[4]);
+}
+#endif
+
+template <class PR>
+JOLT_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return mont_rows<PR, 8>(a, b.l);
+#else
+    return host_mul64(a, b);
+#endif
+}
 template <class PR>
 JOLT_HD Fp<PR> sqr(const Fp<PR>& a) { return mul(a, a); }
 

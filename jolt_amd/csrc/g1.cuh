@@ -134,7 +134,10 @@ JOLT_HD bool g1_eq(const G1Jac& p, const G1Jac& q) {
 // k * p for a small non-negative integer k (bucket weights in the window reduction)
 JOLT_HD G1Jac g1_mul_small(const G1Jac& p, uint32_t k) {
     G1Jac acc = g1_identity();
-    for (int i = 31; i >= 0; --i) {
+    if (k == 0) return acc;
+    int top = 31;
+    while (!((k >> top) & 1)) --top;
+    for (int i = top; i >= 0; --i) {
         acc = g1_double(acc);
         if ((k >> i) & 1) acc = g1_add(acc, p);
     }

@@ -18,6 +18,7 @@ using namespace jolt;
 
 struct jolt_srs;
 int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out);
+int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out);
 
 namespace {
 
@@ -270,8 +271,11 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
     int32_t s = jolt_hyperkzg_fold(ctx, evals, point, ell, polys.data());  // phase 1
     if (s != JOLT_OK) { cleanup(); return s; }
     std::vector<G1Jac> coms(ell > 1 ? ell - 1 : 0);
-    for (size_t i = 1; i < ell; ++i) {  // scheme.rs:141-145
-        s = jolt_internal_msm(ctx, srs, polys[i]->data(), polys[i]->len, &coms[i - 1]);
+    {  // scheme.rs:141-145: the ell-1 level commitments are independent MSMs -> pipelined over the MSM lanes
+        std::vector<const Fr*> ptrs;
+        std::vector<size_t> lens;
+        for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+        s = jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), ptrs.size(), coms.data());
         if (s != JOLT_OK) { cleanup(); return s; }
     }
     for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
@@ -290,11 +294,16 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
     s = jolt_hyperkzg_rlc(ctx, polys.data(), ell, &q_abi, &b_poly);  // kzg.rs:95-105
     if (s != JOLT_OK) { cleanup(); return s; }
     G1Jac ws[3];
-    for (int t = 0; t < 3; ++t) {  // kzg.rs:108-116
-        jolt_table* h = nullptr;
-        s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[t], &h);
-        if (s == JOLT_OK) s = jolt_internal_msm(ctx, srs, h->data(), h->len, &ws[t]);
-        if (h) jolt_table_free(ctx, h);
+    {  // kzg.rs:108-116: three witness polynomials, then their three independent MSMs on the MSM lanes
+        jolt_table* h[3] = {nullptr, nullptr, nullptr};
+        const Fr* ptrs[3];
+        size_t lens[3];
+        for (int t = 0; t < 3 && s == JOLT_OK; ++t) {
+            s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[t], &h[t]);
+            if (s == JOLT_OK) { ptrs[t] = h[t]->data(); lens[t] = h[t]->len; }
+        }
+        if (s == JOLT_OK) s = jolt_internal_msm_many(ctx, srs, ptrs, lens, 3, ws);
+        for (int t = 0; t < 3; ++t) if (h[t]) jolt_table_free(ctx, h[t]);
         if (s != JOLT_OK) { cleanup(b_poly); return s; }
     }
     for (int t = 0; t < 3; ++t) append_g1(tr, ws[t]);  // kzg.rs:118-124

@@ -6,11 +6,11 @@
 //
 // Pipeline (all integer VALU work, v_mad_u64_u32 bound; no MFMA):
 //   1. digits   : scalar -> canonical integer -> W signed c-bit digits; per-(window,|digit|) histogram (atomics)
-//   2. scan     : exclusive prefix sums per window (bucket start offsets); buckets with > kHeavy points are listed
+//   2. scan     : exclusive prefix sums per window (bucket start offsets); over-full buckets are listed per segment
 //   3. scatter  : counting-sort the point indices into bucket order
-//   4. buckets  : one thread per light bucket / one workgroup per heavy bucket sums its points (mixed Jacobian+affine adds)
+//   4. buckets  : L lanes per light bucket / one wavefront per heavy-bucket segment sum the points (mixed Jacobian+affine adds)
 //   5. windows  : sum_b b*B_b per window by running sums over bucket ranges, tree-reduced in LDS
-//   6. host     : Horner over the W window sums (c doublings each) -- W*c ~ 256 doublings on the host
+//   6. host     : Horner over the W window sums (c doublings each) -- W*c ~ 256 doublings on the host (64-bit limbs there)
 // Corner cases (P+P, P+(-P), infinity) are handled inside the group law (g1.cuh); the result is the same POINT as
 // the reference's, in some Jacobian representation.
 #include <algorithm>
@@ -31,7 +31,9 @@ struct jolt_srs {
 
 namespace {
 
-constexpr int kHeavy = 512;  // buckets with more points than this get a whole workgroup
+constexpr int kLaneCap = 128;    // a bucket whose points-per-lane would exceed max(this, 4x the average) is heavy ...
+constexpr int kHeavySeg = 1024;  // ... and is summed by one wavefront per segment of this many points, segment sums combined afterwards
+constexpr int kPeelMax = 16;     // max rounds of same-key aggregation before falling back to per-lane atomics
 
 __device__ __forceinline__ G1Affine ld_aff(const G1Affine* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -64,13 +66,44 @@ __global__ __launch_bounds__(kBlock) void k_srs_powers(Fr beta, G1Jac g, G1Affin
     out[i] = g1_to_affine(g1_mul_canonical(g, k.l));
 }
 
+// Same-key aggregation inside a wavefront for the histogram / scatter atomics.  Small scalars put half of all points into
+// one bucket (the carry window) and the top window of 254-bit scalars has a handful of distinct digits: without this the
+// same-address atomics serialise (measured 6 ms of a 2^20 MSM).  Rounds: the lanes sharing the key of the first pending
+// lane elect it as their leader; stops after kPeelMax rounds or once a round past the first found no duplicate (random keys).
+// Afterwards each lane with `do_atomic` issues ONE atomicAdd(&base[key], count); a lane's slot = leader's old value + rank.
+struct WaveAgg {
+    int src;         // lane holding the atomic's return value for this lane
+    uint32_t rank;   // position among the lanes sharing the key
+    uint32_t count;  // lanes folded into this lane's atomic (meaningful when do_atomic)
+    bool do_atomic;
+};
+__device__ __forceinline__ WaveAgg wave_aggregate(uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63;
+    WaveAgg r{(int)lane, 0u, 1u, valid};
+    uint64_t todo = __ballot(valid);
+    for (int it = 0; it < kPeelMax && todo; ++it) {
+        int leader = __ffsll((unsigned long long)todo) - 1;
+        uint32_t lkey = (uint32_t)__shfl((int)key, leader, 64);
+        uint64_t same = __ballot(valid && key == lkey) & todo;
+        if ((same >> lane) & 1) {
+            r.src = leader;
+            r.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            r.count = (uint32_t)__popcll(same);
+            r.do_atomic = (int)lane == leader;
+        }
+        todo &= ~same;
+        if (it >= 1 && __popcll(same) < 2) break;
+    }
+    return r;
+}
+
 // ---- 1. digits + histogram -------------------------------------------------------------------------------------
 // keys[w*n + i] = |digit| | (negative << 31); hist[w*(B+1) + |digit|] counts non-zero digits
 __global__ __launch_bounds__(kBlock) void k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t* __restrict__ keys,
                                                       uint32_t* __restrict__ hist) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    Fr s = from_mont(ld_fr(scalars + i));
+    const bool live = i < n;
+    Fr s = live ? from_mont(ld_fr(scalars + i)) : Fr::zero();
     const uint32_t B = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; ++w) {
@@ -85,15 +118,16 @@ __global__ __launch_bounds__(kBlock) void k_msm_digits(const Fr* __restrict__ sc
         uint32_t mag, negf;
         if (raw > B) { mag = (1u << c) - raw; negf = 1; carry = 1; }
         else { mag = raw; negf = 0; carry = 0; }
-        keys[(size_t)w * n + i] = mag | (negf << 31);
-        if (mag) atomicAdd(&hist[(size_t)w * (B + 1) + mag], 1u);
+        if (live) keys[(size_t)w * n + i] = mag | (negf << 31);
+        WaveAgg ag = wave_aggregate(mag, live && mag != 0);
+        if (ag.do_atomic) atomicAdd(&hist[(size_t)w * (B + 1) + mag], ag.count);
     }
 }
 
 // ---- 2. per-window exclusive scan of the histogram ---------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_msm_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                    uint32_t B, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
-                                                    uint32_t heavy_cap) {
+                                                    uint32_t B, uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list,
+                                                    uint32_t* __restrict__ heavy_count, uint32_t heavy_cap) {
     __shared__ uint32_t sm[kBlock];
     const int w = blockIdx.x;
     const uint32_t* h = hist + (size_t)w * (B + 1);
@@ -114,9 +148,13 @@ __global__ __launch_bounds__(kBlock) void k_msm_scan(const uint32_t* __restrict_
         uint32_t cnt = h[k];
         offsets[(size_t)w * (B + 1) + k] = run;
         cursor[(size_t)w * (B + 1) + k] = run;
-        if (cnt > (uint32_t)kHeavy) {
-            uint32_t slot = atomicAdd(heavy_count, 1u);
-            if (slot < heavy_cap) heavy_list[slot] = (uint32_t)((size_t)w * (B + 1) + k);
+        if (cnt > heavy_threshold) {  // one list entry per segment: (bucket slot, segment index), contiguous per bucket
+            uint32_t nseg = (cnt + kHeavySeg - 1) / kHeavySeg;
+            uint32_t first = atomicAdd(heavy_count, nseg);
+            for (uint32_t sgi = 0; sgi < nseg && first + sgi < heavy_cap; ++sgi) {
+                heavy_list[2 * (first + sgi)] = (uint32_t)((size_t)w * (B + 1) + k);
+                heavy_list[2 * (first + sgi) + 1] = sgi;
+            }
         }
         run += cnt;
     }
@@ -127,61 +165,88 @@ __global__ __launch_bounds__(kBlock) void k_msm_scatter(const uint32_t* __restri
                                                        uint32_t* __restrict__ sorted) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const int w = blockIdx.y;
-    if (i >= n) return;
-    uint32_t key = keys[(size_t)w * n + i];
+    uint32_t key = i < n ? keys[(size_t)w * n + i] : 0u;
     uint32_t mag = key & 0x7FFFFFFFu;
-    if (!mag) return;
-    uint32_t pos = atomicAdd(&cursor[(size_t)w * (B + 1) + mag], 1u);
-    sorted[(size_t)w * n + pos] = (uint32_t)i | (key & 0x80000000u);
+    WaveAgg ag = wave_aggregate(mag, mag != 0);
+    uint32_t first = 0;
+    if (ag.do_atomic) first = atomicAdd(&cursor[(size_t)w * (B + 1) + mag], ag.count);
+    uint32_t pos = (uint32_t)__shfl((int)first, ag.src, 64) + ag.rank;
+    if (mag) sorted[(size_t)w * n + pos] = (uint32_t)i | (key & 0x80000000u);
 }
 
-// ---- 4a. light buckets: one thread per bucket --------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_msm_buckets_light(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
-                                                             const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
-                                                             uint32_t B, G1Jac* __restrict__ buckets) {
-    uint32_t b = blockIdx.x * kBlock + threadIdx.x + 1;  // bucket magnitude 1..B
-    const int w = blockIdx.y;
-    if (b > B) return;
-    size_t slot = (size_t)w * (B + 1) + b;
-    uint32_t cnt = hist[slot];
-    if (cnt > (uint32_t)kHeavy) return;  // the heavy kernel owns it
+// Butterfly sum of a G1 accumulator over `width` (power of two <= 64) adjacent lanes; every lane of the wave must call it.
+__device__ __forceinline__ G1Jac wave_sum_g1(G1Jac acc, int width) {
+    for (int off = width >> 1; off >= 1; off >>= 1) {
+        G1Jac o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o.x.l[k] = (uint32_t)__shfl_xor((int)acc.x.l[k], off, 64);
+            o.y.l[k] = (uint32_t)__shfl_xor((int)acc.y.l[k], off, 64);
+            o.z.l[k] = (uint32_t)__shfl_xor((int)acc.z.l[k], off, 64);
+        }
+        acc = g1_add(acc, o);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ G1Jac sum_bucket_points(const uint32_t* __restrict__ src, const G1Affine* __restrict__ bases, uint32_t lo, uint32_t hi,
+                                                   uint32_t stride) {
     G1Jac acc = g1_identity();
-    const uint32_t* src = sorted + (size_t)w * n + offsets[slot];
-    for (uint32_t k = 0; k < cnt; ++k) {
+    for (uint32_t k = lo; k < hi; k += stride) {
         uint32_t v = src[k];
         G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
         if (v >> 31) p.y = neg(p.y);
         acc = g1_add_mixed(acc, p);
     }
-    buckets[slot] = acc;
+    return acc;
 }
 
-// ---- 4b. heavy buckets: one workgroup per bucket, LDS tree reduction ------------------------------------------------
+// ---- 4a. light buckets: L adjacent lanes per bucket (L = 1 when there are enough buckets to fill the chip) ----------
+__global__ __launch_bounds__(kBlock) void k_msm_buckets_light(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
+                                                             uint32_t B, int L, uint32_t heavy_threshold, G1Jac* __restrict__ buckets) {
+    uint32_t gt = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t b = gt / L + 1, sub = gt % L;  // bucket magnitude 1..B
+    const int w = gridDim.y - 1 - blockIdx.y;  // top window first: its buckets are the fullest for 254-bit scalars
+    bool mine = b <= B;
+    size_t slot = (size_t)w * (B + 1) + (mine ? b : 0);
+    uint32_t cnt = mine ? hist[slot] : 0;
+    if (cnt > heavy_threshold) { cnt = 0; mine = false; }  // the heavy kernels own it
+    G1Jac acc = sum_bucket_points(sorted + (size_t)w * n + offsets[slot], bases, sub, cnt, (uint32_t)L);
+    acc = wave_sum_g1(acc, L);
+    if (mine && sub == 0) buckets[slot] = acc;
+}
+
+// ---- 4b. heavy buckets: one wavefront per kHeavySeg-point segment, then one wavefront per bucket adds its segment sums ----
 __global__ __launch_bounds__(kBlock) void k_msm_buckets_heavy(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count,
                                                              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
-                                                             uint32_t B, G1Jac* __restrict__ buckets) {
-    __shared__ G1Jac sm[kBlock];
-    for (uint32_t h = blockIdx.x; h < *heavy_count; h += gridDim.x) {
-        uint32_t slot = heavy_list[h];
+                                                             uint32_t B, G1Jac* __restrict__ seg_sums) {
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t total = *heavy_count;
+    for (uint32_t h = wave; h < total; h += n_waves) {
+        uint32_t slot = heavy_list[2 * h], sgi = heavy_list[2 * h + 1];
         uint32_t w = slot / (B + 1);
         uint32_t cnt = hist[slot];
-        const uint32_t* src = sorted + (size_t)w * n + offsets[slot];
+        uint32_t lo = sgi * kHeavySeg, hi = min(lo + (uint32_t)kHeavySeg, cnt);
+        G1Jac acc = sum_bucket_points(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u);
+        acc = wave_sum_g1(acc, 64);
+        if (lane == 0) seg_sums[h] = acc;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_msm_heavy_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count,
+                                                             const uint32_t* __restrict__ hist, const G1Jac* __restrict__ seg_sums,
+                                                             G1Jac* __restrict__ buckets) {
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t total = *heavy_count;
+    for (uint32_t h = wave; h < total; h += n_waves) {
+        if (heavy_list[2 * h + 1] != 0) continue;  // only the first segment entry of a bucket combines (wave-uniform)
+        uint32_t slot = heavy_list[2 * h];
+        uint32_t nseg = (hist[slot] + kHeavySeg - 1) / kHeavySeg;
         G1Jac acc = g1_identity();
-        for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) {
-            uint32_t v = src[k];
-            G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
-            if (v >> 31) p.y = neg(p.y);
-            acc = g1_add_mixed(acc, p);
-        }
-        sm[threadIdx.x] = acc;
-        __syncthreads();
-        for (int off = kBlock / 2; off >= 1; off >>= 1) {
-            if ((int)threadIdx.x < off) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + off]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) buckets[slot] = sm[0];
-        __syncthreads();
+        for (uint32_t k = lane; k < nseg; k += 64) acc = g1_add(acc, seg_sums[h + k]);
+        acc = wave_sum_g1(acc, 64);
+        if (lane == 0) buckets[slot] = acc;
     }
 }
 
@@ -201,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_msm_window_reduce(const G1Jac* __res
             acc = g1_add(acc, running);
         }
         // sum (b - lo + 1) B_b = acc  ->  sum b B_b = acc + (lo - 1) * running
-        contrib = g1_add(acc, g1_mul_small(running, (uint32_t)(lo - 1)));
+        contrib = g1_add(acc, g1_mul_small(running, (uint32_t)(lo - 1)));  // skips the leading zero bits
     }
     sm[threadIdx.x] = contrib;
     __syncthreads();
@@ -212,9 +277,25 @@ __global__ __launch_bounds__(kBlock) void k_msm_window_reduce(const G1Jac* __res
     if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = sm[0];
 }
 
+}  // namespace
+struct MsmJob {
+    size_t n = 0;
+    int lane = 0, c = 0, W = 0;
+    uint32_t nb = 0;
+};
+namespace {
+// ---- 5b. one wavefront per window adds that window's nb block partials ---------------------------------------------------
+__global__ __launch_bounds__(64) void k_msm_window_combine(const G1Jac* __restrict__ partial, uint32_t nb, G1Jac* __restrict__ window_sums) {
+    const int w = blockIdx.x;
+    G1Jac acc = g1_identity();
+    for (uint32_t k = threadIdx.x; k < nb; k += 64) acc = g1_add(acc, partial[(size_t)w * nb + k]);
+    acc = wave_sum_g1(acc, 64);
+    if (threadIdx.x == 0) window_sums[w] = acc;
+}
+
 struct MsmPlan {
-    int c, W;
-    uint32_t B, G, nb;
+    int c, W, L;  // window bits, windows, lanes per light bucket
+    uint32_t B, G, nb, heavy_threshold;
 };
 MsmPlan plan_for(size_t n) {
     int lg = 0;
@@ -224,9 +305,15 @@ MsmPlan plan_for(size_t n) {
     p.W = (255 + p.c - 1) / p.c;
     p.B = 1u << (p.c - 1);
     // window reduction: nb blocks of 256 threads per window, G buckets per thread
-    uint32_t threads = std::min<uint32_t>(p.B, 2048);
+    uint32_t threads = std::min<uint32_t>(p.B, 8192);
     p.nb = (threads + kBlock - 1) / kBlock;
     p.G = (p.B + p.nb * kBlock - 1) / (p.nb * kBlock);
+    // lanes per light bucket: enough threads to fill 256 CUs x 4 SIMDs x 8 waves when W*B alone is too small
+    size_t wb = (size_t)p.W * p.B;
+    p.L = 1;
+    while (p.L < 64 && wb * (size_t)(2 * p.L) <= 524288) p.L *= 2;
+    size_t avg = (n + 2 * (size_t)p.B - 1) / (2 * (size_t)p.B);
+    p.heavy_threshold = (uint32_t)std::min<size_t>((size_t)p.L * std::max<size_t>(kLaneCap, 4 * avg), 0x7FFFFFFFu);
     return p;
 }
 
@@ -319,21 +406,41 @@ extern "C" int32_t jolt_srs_free(jolt_ctx* ctx, jolt_srs* srs) {
 // ------------------------------------------------------------------------------------------------------------------
 // MSM
 // ------------------------------------------------------------------------------------------------------------------
-int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out) {
+constexpr size_t kMsmHostEntries = 128;  // >= W for every plan (c = 2: 128 windows)
+
+// Enqueue one MSM on lane `lane` (its stream, workspace and pinned result buffer); nothing blocks the host.
+int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job) {
+    job->n = n;
+    job->lane = lane;
     if (n > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
-    if (n == 0) { *out = g1_identity(); return JOLT_OK; }
+    if (n == 0) return JOLT_OK;
     if (n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
     MsmPlan p = plan_for(n);
+    job->c = p.c;
+    job->W = p.W;
+    job->nb = p.nb;
     const size_t WB = (size_t)p.W * (p.B + 1);
-    const uint32_t heavy_cap = (uint32_t)((size_t)p.W * n / kHeavy + 1);
-    // workspace (one allocation)
+    // heavy buckets hold > heavy_threshold points each: at most W*n/threshold of them, W*n/kHeavySeg + one entry per bucket
+    const uint32_t heavy_cap = (uint32_t)((size_t)p.W * n / kHeavySeg + (size_t)p.W * n / p.heavy_threshold + 16);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t o_keys = take((size_t)p.W * n * 4), o_sorted = take((size_t)p.W * n * 4), o_hist = take(WB * 4), o_offs = take(WB * 4),
-           o_cur = take(WB * 4), o_heavy = take((size_t)heavy_cap * 4), o_hcnt = take(256), o_buckets = take(WB * sizeof(G1Jac)),
-           o_part = take((size_t)p.W * p.nb * sizeof(G1Jac));
-    char* ws = nullptr;
-    JOLT_HIP_TRY(ctx, hipMalloc((void**)&ws, off));
+           o_cur = take(WB * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256), o_buckets = take(WB * sizeof(G1Jac)),
+           o_part = take((size_t)p.W * p.nb * sizeof(G1Jac)), o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_wsum = take((size_t)p.W * sizeof(G1Jac));
+    hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
+    if (off > ctx->msm_ws_cap[lane]) {  // grow-only (hipMalloc / hipFree per MSM cost more than a small MSM itself)
+        if (ctx->msm_ws[lane]) {
+            JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
+            JOLT_HIP_TRY(ctx, hipFree(ctx->msm_ws[lane]));
+            ctx->msm_ws[lane] = nullptr;
+            ctx->msm_ws_cap[lane] = 0;
+        }
+        JOLT_HIP_TRY(ctx, hipMalloc(&ctx->msm_ws[lane], off));
+        ctx->msm_ws_cap[lane] = off;
+    }
+    if (!ctx->msm_host[lane]) JOLT_HIP_TRY(ctx, hipHostMalloc(&ctx->msm_host[lane], kMsmHostEntries * sizeof(G1Jac), hipHostMallocDefault));
+    if ((size_t)p.W > kMsmHostEntries) return JOLT_ERR_UNSUPPORTED;
+    char* ws = (char*)ctx->msm_ws[lane];
     uint32_t* keys = (uint32_t*)(ws + o_keys);
     uint32_t* sorted = (uint32_t*)(ws + o_sorted);
     uint32_t* hist = (uint32_t*)(ws + o_hist);
@@ -343,41 +450,71 @@ int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalar
     uint32_t* hcnt = (uint32_t*)(ws + o_hcnt);
     G1Jac* buckets = (G1Jac*)(ws + o_buckets);
     G1Jac* part = (G1Jac*)(ws + o_part);
-    hipStream_t st = ctx->stream;
-    int32_t status = JOLT_OK;
-    std::vector<G1Jac> hpart((size_t)p.W * p.nb);
+    G1Jac* seg = (G1Jac*)(ws + o_seg);
+    G1Jac* wsum = (G1Jac*)(ws + o_wsum);
     hipError_t e = hipMemsetAsync(hist, 0, WB * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(hcnt, 0, 256, st);
     if (e == hipSuccess) e = hipMemsetAsync(buckets, 0, WB * sizeof(G1Jac), st);  // z = 0: identity
     if (e == hipSuccess) {
         unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
+        unsigned gh = std::min<uint32_t>((heavy_cap + 3) / 4, 4096);
         hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, p.c, p.W, keys, hist);
-        hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(kBlock), 0, st, (const uint32_t*)hist, offs, cur, p.B, heavy, hcnt, heavy_cap);
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(kBlock), 0, st, (const uint32_t*)hist, offs, cur, p.B, p.heavy_threshold, heavy, hcnt, heavy_cap);
         hipLaunchKernelGGL(k_msm_scatter, dim3(gn, p.W), dim3(kBlock), 0, st, (const uint32_t*)keys, n, p.B, cur, sorted);
-        hipLaunchKernelGGL(k_msm_buckets_light, dim3((p.B + kBlock - 1) / kBlock, p.W), dim3(kBlock), 0, st, (const uint32_t*)hist, (const uint32_t*)offs,
-                           (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, buckets);
-        hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(std::min<uint32_t>(heavy_cap, 4096)), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt,
-                           (const uint32_t*)hist, (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, buckets);
+        hipLaunchKernelGGL(k_msm_buckets_light, dim3((unsigned)(((size_t)p.B * p.L + kBlock - 1) / kBlock), p.W), dim3(kBlock), 0, st, (const uint32_t*)hist,
+                           (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, p.L, p.heavy_threshold, buckets);
+        hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist,
+                           (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, seg);
+        hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist,
+                           (const G1Jac*)seg, buckets);
         hipLaunchKernelGGL(k_msm_window_reduce, dim3(p.nb, p.W), dim3(kBlock), 0, st, (const G1Jac*)buckets, p.B, p.G, part);
+        hipLaunchKernelGGL(k_msm_window_combine, dim3(p.W), dim3(64), 0, st, (const G1Jac*)part, p.nb, wsum);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(hpart.data(), part, hpart.size() * sizeof(G1Jac), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->msm_host[lane], wsum, (size_t)p.W * sizeof(G1Jac), hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) {
         ctx->last_error = std::string("msm: ") + hipGetErrorString(e);
-        status = e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
-    } else {
-        // 6. Horner over the windows on the host: acc = 2^c * acc + S_w
-        G1Jac acc = g1_identity();
-        for (int w = p.W - 1; w >= 0; --w) {
-            for (int k = 0; k < p.c; ++k) acc = g1_double(acc);
-            G1Jac sw = g1_identity();
-            for (uint32_t b = 0; b < p.nb; ++b) sw = g1_add(sw, hpart[(size_t)w * p.nb + b]);
-            acc = g1_add(acc, sw);
-        }
-        *out = acc;
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
     }
-    (void)hipFree(ws);
+    return JOLT_OK;
+}
+
+// Wait for the lane and finish on the host: Horner over the windows, acc = 2^c * acc + S_w.
+int32_t jolt_internal_msm_collect(jolt_ctx* ctx, const MsmJob* job, G1Jac* out) {
+    if (job->n == 0) { *out = g1_identity(); return JOLT_OK; }
+    hipStream_t st = job->lane == 0 ? ctx->stream : ctx->side[job->lane - 1];
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
+    const G1Jac* wsum = (const G1Jac*)ctx->msm_host[job->lane];
+    G1Jac acc = g1_identity();
+    for (int w = job->W - 1; w >= 0; --w) {
+        for (int k = 0; k < job->c; ++k) acc = g1_double(acc);
+        acc = g1_add(acc, wsum[w]);
+    }
+    *out = acc;
+    return JOLT_OK;
+}
+
+int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out) {
+    MsmJob job;
+    JOLT_TRY(jolt_internal_msm_enqueue(ctx, srs, d_scalars, n, 0, &job));
+    return jolt_internal_msm_collect(ctx, &job, out);
+}
+
+// `count` independent MSMs over the same bases, pipelined over the four lanes (results in order).  The side lanes wait
+// for the work already queued on the main stream (the tables being committed are produced there).
+int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out) {
+    if (count == 0) return JOLT_OK;
+    JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int k = 0; k < 3; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+    MsmJob jobs[4];
+    int32_t status = JOLT_OK;
+    for (size_t i = 0; i < count + 4; ++i) {
+        int lane = (int)(i % 4);
+        if (i >= 4 && i - 4 < count && status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &jobs[lane], &out[i - 4]);
+        if (i < count && status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, srs, d_scalars[i], n[i], lane, &jobs[lane]);
+    }
+    if (status != JOLT_OK)
+        for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->side[k]);
     return status;
 }
 

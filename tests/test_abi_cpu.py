@@ -42,7 +42,8 @@ def test_no_cpu_fallback_without_device():
 
 
 def test_host_field_ops_match_oracle():
-    # same field.cuh source that the kernels use, compiled for the host: exercises mont_rows<8> / <4>
+    # field.cuh compiled for the host: the 64-bit-limb host product (host_mul64) and the shared add/sub/inv code;
+    # the kernels' 32-bit mont_rows<8> is covered by the GPU tests, mont_rows<4> below
     a, b = rand_fr(200, 1), rand_fr(200, 2)
     edge = O.to_mont([0, 1, O.R_MOD - 1, 2, O.R_MOD - 2])
     a[:5], b[:5] = edge, edge[::-1]
@@ -85,3 +86,18 @@ def test_host_round_message_assembly_matches_oracle():
         assert np.array_equal(ffi.host_univariate_evaluate(co, x), O.univariate_evaluate(co, x))
     args = rand_fr(5, 30)
     assert np.array_equal(ffi.host_gruen_poly_deg_3(*args), O.gruen_poly_deg_3(*args))
+
+
+def test_host_g1_ops_match_oracle():
+    """The host mirror's G1 helpers (Fq arithmetic through the 64-bit host product): add / equality / compressed wire
+    form against the oracle, including doubling, inverse pairs and the identity."""
+    g = O.g1_generator()
+    pts = [O.g1_scalar_mul(g, O.to_mont([k])[0]) for k in (1, 2, 3, 12345, O.R_MOD - 1)]
+    pts.append(O.g1_identity())
+    for p in pts:
+        for q in pts:
+            got, want = ffi.host_g1_add(p, q), O.g1_add(p, q)
+            assert O.g1_eq(got, want)
+            assert ffi.host_g1_eq(got, want)
+            assert ffi.host_g1_serialize_compressed(got) == O.g1_serialize_compressed(want)
+    assert not ffi.host_g1_eq(pts[0], pts[1])

@@ -82,6 +82,24 @@ def test_msm_corner_scalars_and_repeated_bases(ctx):
     assert e.value.status == 9
 
 
+@pytest.mark.parametrize("n", [5000, 70001])
+def test_msm_skewed_scalars_multi_segment_buckets(ctx, n):
+    """Boolean / tiny / mostly-equal scalars (witness-like): buckets far above the per-lane cap, split into several
+    wavefront segments and recombined; the histogram and scatter see the same-address atomics path."""
+    srs = ctx.srs_setup_from_secret(rand_fr(1, 11)[0], n, O.g1_generator())
+    host = srs.download()
+    rng = np.random.default_rng(n)
+    bits = O.fr_from_u64(rng.integers(0, 2, size=n, dtype=np.uint64))
+    assert same_point(ctx.msm(srs, bits), O.g1_msm_pippenger(host, bits))
+    tiny = O.fr_from_u64(rng.integers(0, 4, size=n, dtype=np.uint64) * np.uint64(0x10001))
+    assert same_point(ctx.msm(srs, tiny), O.g1_msm_pippenger(host, tiny))
+    mixed = rand_fr(n, 12)
+    mixed[rng.random(n) < 0.7] = rand_fr(1, 13)[0]  # 70 % of the scalars equal, the rest uniform
+    assert same_point(ctx.msm(srs, mixed), O.g1_msm_pippenger(host, mixed))
+    neg_one = np.repeat(O.to_mont([R - 1]), n, axis=0)  # every window all-ones -> carries ripple to the top window
+    assert same_point(ctx.msm(srs, neg_one), O.g1_msm_pippenger(host, neg_one))
+
+
 def test_msm_small_scalars_and_device_table(ctx, srs_small):
     _, host, dev = srs_small
     small = O.fr_from_u64(np.arange(300, dtype=np.uint64) * 977 % 65536)  # witness-like <= 16-bit scalars
