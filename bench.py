@@ -146,7 +146,7 @@ def main():
 
     if sharded:
         from jolt_amd.distributed import ShardedWorkload
-        wl = ShardedWorkload(ctx, args.scale, rank, world, dist)
+        wl = ShardedWorkload(ctx, args.scale, rank, world, dist, force_gather=(world == 1))
     else:
         wl = DeviceWorkload(ctx, args.scale)
 
@@ -160,6 +160,10 @@ def main():
     for i in range(args.warmup):
         wl.prove(label=1000 + i)
     barrier()
+    if sharded:
+        from jolt_amd import distributed as _D
+        for k in _D.TIMINGS:
+            _D.TIMINGS[k] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         wl.prove(label=2000 + i)
@@ -190,6 +194,10 @@ def main():
                                f"(BASELINE configs[1])",
                    "trace_length_per_gpu": 1 << args.scale, "parallelism": f"hypercube sharded over {world} GPU(s)"},
     }
+    if sharded:
+        out["config"]["collective"] = type(wl.coll).__name__ + " (RCCL all-gather of the round sums, then of the 2^tail_log-entry tables)"
+        out["config"]["tail_log"] = wl.tail_log
+        out["config"]["ms_per_step_split"] = {k: round(v / args.steps * 1e3, 3) for k, v in _D.TIMINGS.items()}
     if rank == 0:
         out["roofline"] = bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)
         if not args.no_cpu_baseline:
@@ -197,8 +205,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_scale)
             except Exception as e:  # the oracle is optional infrastructure: never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "cycles/s", "cores": None, "kind": "port", "sample": f"unavailable: {e}"}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -316,6 +316,27 @@ int32_t jolt_host_batch_flush_binds(jolt_batch *b, jolt_member *const *members, 
 int32_t jolt_host_batch_split_eq_scalar(const jolt_batch *b, size_t member, jolt_fr_t *out);
 int32_t jolt_host_batch_end(jolt_batch *b, jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
                             jolt_fr_t *out_final_claim);
+/* Multi-GPU data path (one process per GPU).  The collectives are RCCL calls on the context's stream;
+ * librccl.so.1 is resolved with dlopen at first use (`rccl_path` may name it explicitly, NULL = the copy already mapped into
+ * the process / the default search path).  Rank 0 draws the id, the launcher broadcasts its 128 bytes (torch.distributed
+ * in this repo, any side channel in the Rust host), every rank then calls jolt_comm_create (collective).
+ * Replaces nothing in the reference -- the reference prover is single-process. */
+typedef struct jolt_comm jolt_comm;
+int32_t jolt_comm_unique_id(const char *rccl_path, uint8_t out[128]);
+int32_t jolt_comm_create(jolt_ctx *ctx, const char *rccl_path, const uint8_t unique_id[128], int32_t rank, int32_t world, jolt_comm **out);
+int32_t jolt_comm_destroy(jolt_comm *comm);
+int32_t jolt_comm_world(const jolt_comm *comm, int32_t *rank, int32_t *world);
+/* gathered = world blocks of `bytes` in rank order.  _host: small host payload (per-round partial sums), synchronous;
+ * _device / _table: device buffers, asynchronous on the context stream. */
+int32_t jolt_comm_all_gather_host(jolt_comm *comm, const void *local, size_t bytes, void *gathered);
+int32_t jolt_comm_all_gather_device(jolt_comm *comm, const void *d_local, size_t bytes, void *d_gathered);
+int32_t jolt_comm_all_gather_table(jolt_comm *comm, const jolt_table *local, size_t n, jolt_table *gathered);
+/* A jolt_gather_fn for jolt_host_batch_run with user = jolt_comm*. */
+int32_t jolt_comm_gather_round_sums(void *user, const jolt_fr_t *local, size_t count, jolt_fr_t *gathered);
+/* Hand-over to the redundant tail: pack the current tables (`entries` values each) of several members table-major into dst;
+ * after the all-gather, dst[t][r*entries + j] = gathered[r][t][j] (rank = top variables). */
+int32_t jolt_round_group_pack_tables(jolt_ctx *ctx, jolt_member *const *members, size_t n_members, size_t entries, jolt_table *dst);
+int32_t jolt_tail_interleave(jolt_ctx *ctx, const jolt_table *gathered, size_t world, size_t n_tables, size_t entries, jolt_table *dst);
 /* The fully bound values of several members with one copy and one synchronisation (concatenated in member order). */
 int32_t jolt_round_group_final_values(jolt_ctx *ctx, jolt_member *const *members, size_t n_members, jolt_fr_t *out, size_t capacity);
 

@@ -113,7 +113,7 @@ static int32_t assemble(const jolt_batch* b, size_t i, const Fr* ev, const Fr& c
 // and added (RCCL has no mod-r reduction: all-gather of a few KiB + local modular sum).
 extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* members, size_t n_rounds, int32_t world, jolt_gather_fn gather,
                                        jolt_local_round_fn local_fn, void* user) {
-    if (!b || (!members && !local_fn) || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
+    if (!b || (!members && !local_fn) || world < 1 || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     static const Fr two_inv = inv(fr_from_u64(2));
     for (size_t step = 0; step < n_rounds; ++step) {
         if (b->round >= b->max_num_vars) return JOLT_ERR_INVALID_ARG;
@@ -149,7 +149,7 @@ extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* member
         }
         std::vector<Fr> sums(total);
         for (size_t k = 0; k < total; ++k) sums[k] = fr_from_abi(&local[k]);
-        if (world > 1) {
+        if (gather) {  // also with world == 1 when the caller asks for it (exercises the exchange on a one-GPU box)
             std::vector<jolt_fr_t> gathered((size_t)world * total);
             JOLT_TRY(gather(user, local.data(), total, gathered.data()));
             for (size_t k = 0; k < total; ++k) {

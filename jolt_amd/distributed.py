@@ -6,15 +6,20 @@ jolt_amd/csrc/batch.hip:
   phase A  rounds 0 .. n_local-1: every rank computes the round sums of its block (LowToHigh binds pair (2y, 2y+1), so
            they stay local); ONE all-gather of a few hundred bytes per batch round, modular sum on every rank, identical
            transcripts -> identical challenges;
-  phase B  the single remaining entry of every local table is all-gathered once, each rank rebuilds the G-entry tables
-           and finishes the last log2(G) rounds redundantly (no communication).
-The collective is torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests); the
-payload is latency-bound (RCCL has no mod-r reduction, hence all-gather + local sum).
+  phase B  once the local tables are down to 2^tail_log entries they are all-gathered once, each rank rebuilds the
+           G * 2^tail_log-entry tables (rank = top variables) and finishes the last tail_log + log2(G) rounds
+           redundantly, without communication.  The per-round exchange is latency-bound (a few hundred bytes), and the
+           late rounds are tiny, so handing over early halves the number of exchanges; tail_log is chosen so that the
+           tail still fits the single-launch tail kernel (G * 2^tail_log <= 8192 entries).
+The collectives are RCCL over xGMI: called natively on the context's stream (jolt_amd/csrc/comm.hip, `NativeCollective`,
+rendezvous through torch.distributed) on the GPU box, or through torch.distributed itself (`Collective`: "nccl", or "gloo"
+in the CPU tests).  RCCL has no mod-r reduction, hence all-gather + local modular sum.
 
 The local compute is pluggable so that the N>1 logic can be tested on CPU ranks: `DeviceShard` drives device members
 through the C ABI; tests substitute an oracle-backed shard.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -48,6 +53,90 @@ class Collective:
         return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
 
 
+def _loaded_rccl_path():
+    """The librccl that torch already mapped into this process (so that the native communicator shares it)."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+class NativeCollective:
+    """RCCL communicator owned by libjolt_hip.so (jolt_comm_*): rank 0 draws the ncclUniqueId, torch.distributed
+    broadcasts it, every rank joins.  The round loop then calls RCCL without going through Python."""
+
+    def __init__(self, ctx, dist, rank, world, device=None):
+        import torch
+        lib = ffi.lib()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        path = _loaded_rccl_path()
+        self._path = path.encode() if path else None
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            st = lib.jolt_comm_unique_id(self._path, uid)
+            if st:
+                raise ffi.JoltError(st, "jolt_comm_unique_id")
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+        if device is not None:
+            t = t.to(device)
+        if world > 1:
+            dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        uid = (C.c_uint8 * 128)(*raw)
+        h = C.c_void_p()
+        # RCCL prints its version banner on C stdout at communicator creation; bench.py's stdout carries exactly one JSON
+        # line, so fd 1 points at stderr while the communicator is built (and the C stdio buffer is flushed there)
+        import os
+        import sys
+        sys.stdout.flush()
+        libc = C.CDLL(None)
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            st = lib.jolt_comm_create(ctx.h, self._path, uid, C.c_int32(rank), C.c_int32(world), C.byref(h))
+        finally:
+            libc.fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
+        if st:
+            ffi._ck(st, "jolt_comm_create", ctx)
+        self.h = h
+
+    def all_gather_u64(self, arr):
+        flat = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+        out = np.empty(self.world * flat.size, dtype=np.uint64)
+        st = ffi.lib().jolt_comm_all_gather_host(self.h, _p(flat), C.c_size_t(flat.nbytes), _p(out))
+        if st:
+            ffi._ck(st, "jolt_comm_all_gather_host", self.ctx)
+        return out.reshape(self.world, -1)
+
+    def all_gather_table(self, local, n, gathered):
+        st = ffi.lib().jolt_comm_all_gather_table(self.h, local.h, C.c_size_t(n), gathered.h)
+        if st:
+            ffi._ck(st, "jolt_comm_all_gather_table", self.ctx)
+
+    def close(self):
+        if self.h:
+            ffi.lib().jolt_comm_destroy(self.h)
+            self.h = None
+
+
+def tail_log_for(n_local, world, max_tail_entries=8192):
+    """Local table size (log2) at which a shard hands over to the redundant tail: the largest k <= n_local with
+    world * 2^k <= max_tail_entries (the tail kernel's single-launch range), never below 0."""
+    log_g = world.bit_length() - 1
+    k = max_tail_entries.bit_length() - 1 - log_g
+    return max(0, min(n_local, k))
+
+
+# wall-clock split of prove_batch_sharded, accumulated over calls (seconds); bench.py reports it per step
+TIMINGS = {"sharded_rounds": 0.0, "hand_over": 0.0, "tail_rounds": 0.0, "setup_and_end": 0.0}
+
+
 class MemberInfo:
     def __init__(self, kind, degree, rounds, n_tables, w=None, scale=None):
         self.kind, self.degree, self.rounds, self.n_tables, self.w, self.scale = kind, degree, rounds, n_tables, w, scale
@@ -60,11 +149,15 @@ class MemberInfo:
 
 
 def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max_degree, world, coll, shard, label=0,
-                        challenge_mode=0):
+                        challenge_mode=0, tail_log=0, force_gather=False):
     """infos: [MemberInfo] (global rounds = n_total for every member here); shard: local backend with
-         round(active_idx, binds) -> np (total,4);  flush(binds) ; finals() -> np (sum n_tables, 4);
-         make_tail(gathered_finals (world, sum n_tables, 4), split_eq_scalars) -> tail backend with .round()/.flush()/.close()
+         round(active_idx, binds) -> np (total,4);  flush(binds);
+         make_tail(coll, split_eq_scalars) -> tail backend over the gathered world * 2^tail_log-entry tables
+       A backend exposing `handles` (device members, C array indexed like infos) is driven natively by the C++ round loop;
+       with a NativeCollective the per-round all-gather is native too, so no Python runs inside the rounds.
        Returns dict(polys, challenges, member_claims, final_claim)."""
+    import time
+    t_begin = time.perf_counter()
     lib = ffi.lib()
     n = len(infos)
     ic = np.ascontiguousarray(np.stack(claims), dtype=np.uint64)
@@ -112,15 +205,28 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
             return 4
 
     lcb, gcb = LOCAL_FN(local_cb), GATHER_FN(gather_cb)
+    native_gather = C.cast(lib.jolt_comm_gather_round_sums, GATHER_FN) if isinstance(coll, NativeCollective) else None
 
-    def run(n_rounds, w):
-        st = lib.jolt_host_batch_run(batch, None, C.c_size_t(n_rounds), C.c_int32(w), gcb if w > 1 else None, lcb, None)
+    def run(n_rounds, w, exchange=True):
+        if n_rounds == 0:
+            return
+        handles = getattr(state["backend"], "handles", None)
+        gather, user = (None, None)
+        if w > 1 or (force_gather and exchange):  # force_gather: run the exchange even with a single rank
+            gather, user = (native_gather, coll.h) if native_gather is not None else (gcb, None)
+        st = lib.jolt_host_batch_run(batch, handles, C.c_size_t(n_rounds), C.c_int32(w), gather, None if handles is not None else lcb, user)
         if st:
             if state["err"] is not None:
                 raise state["err"]
             raise ffi.JoltError(st, "jolt_host_batch_run")
 
     def flush():
+        handles = getattr(state["backend"], "handles", None)
+        if handles is not None:  # the C++ loop applies the pending binds to the device members itself
+            st = lib.jolt_host_batch_flush_binds(batch, handles, None, None)
+            if st:
+                raise ffi.JoltError(st, "jolt_host_batch_flush_binds")
+            return
         binds = ffi.fr_array(n)
         has = (C.c_int32 * n)()
         st = lib.jolt_host_batch_flush_binds(batch, None, _p(binds), has)
@@ -129,11 +235,13 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
         state["backend"].flush([binds[i] if has[i] else None for i in range(n)])
 
     log_g = n_total - n_local
-    run(n_local, world)
+    assert 0 <= tail_log <= n_local
+    t0 = time.perf_counter()
+    run(n_local - tail_log, world)
     flush()
-    if log_g > 0:
-        finals = np.ascontiguousarray(shard.finals(), dtype=np.uint64).reshape(-1, 4)
-        gathered = coll.all_gather_u64(finals).reshape(world, -1, 4)
+    t1 = time.perf_counter()
+    t2 = t1
+    if log_g + tail_log > 0:
         scalars = []
         for i, info in enumerate(infos):
             if info.kind in (KIND_SPLIT_EQ, KIND_SPLIT_EQ_UNIFORM):
@@ -142,16 +250,22 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
                 scalars.append(o[0])
             else:
                 scalars.append(None)
-        tail = shard.make_tail(gathered, scalars)
+        tail = shard.make_tail(coll, scalars)
+        t2 = time.perf_counter()
         state["backend"] = tail
-        run(log_g, 1)
+        run(log_g + tail_log, 1, exchange=False)
         flush()
         tail.close()
+    t3 = time.perf_counter()
+    TIMINGS["sharded_rounds"] += t1 - t0
+    TIMINGS["hand_over"] += t2 - t1
+    TIMINGS["tail_rounds"] += t3 - t2
     polys, chal = ffi.fr_array(n_total * (max_degree + 1)), ffi.fr_array(n_total)
     mclaims, final = ffi.fr_array(n), ffi.fr_array(1)
     st = lib.jolt_host_batch_end(batch, _p(polys), _p(chal), _p(mclaims), _p(final))
     if st:
         raise ffi.JoltError(st, "jolt_host_batch_end")
+    TIMINGS["setup_and_end"] += (time.perf_counter() - t3) + (t0 - t_begin)
     return dict(polys=polys.reshape(n_total, max_degree + 1, 4), challenges=chal, member_claims=mclaims, final_claim=final[0])
 
 
@@ -159,10 +273,13 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
 # device backend
 # ---------------------------------------------------------------------------------------------------------------------
 class DeviceShard:
-    """Local backend over device members (jolt_round_group_prove / jolt_round_group_finish / ..._final_values)."""
+    """Local backend over device members: the C++ round loop drives them directly through `handles`
+    (jolt_round_group_prove / jolt_round_group_finish); round()/flush() are the same operations for callers that step
+    the loop from Python."""
 
     def __init__(self, ctx, members, rebuild=None):
         self.ctx, self.members, self.rebuild = ctx, members, rebuild
+        self.handles = (C.c_void_p * len(members))(*[m.h for m in members])
 
     def round(self, idx, binds):
         res = self.ctx.round_group_prove([self.members[i] for i in idx], binds)
@@ -180,17 +297,8 @@ class DeviceShard:
         if st:
             raise ffi.JoltError(st, "jolt_round_group_finish")
 
-    def finals(self):
-        total = sum(m.n_tables for m in self.members)
-        out = ffi.fr_array(total)
-        hs = (C.c_void_p * len(self.members))(*[m.h for m in self.members])
-        st = ffi.lib().jolt_round_group_final_values(self.ctx.h, hs, C.c_size_t(len(self.members)), _p(out), C.c_size_t(total))
-        if st:
-            raise ffi.JoltError(st, "jolt_round_group_final_values")
-        return out
-
-    def make_tail(self, gathered, scalars):
-        return self.rebuild(gathered, scalars)
+    def make_tail(self, coll, scalars):
+        return self.rebuild(coll, scalars)
 
     def close(self):
         pass
@@ -223,14 +331,24 @@ class ShardedWorkload:
     of a global point (EqPolynomial::evals_for_aligned_block); LT / eq+1 leaves are replaced by eq blocks of the same
     size (the arithmetic per entry is identical, their global structure is exercised by the single-GPU tests)."""
 
-    def __init__(self, ctx, n_local, rank, world, dist, seed=2026, coll=None):
+    def __init__(self, ctx, n_local, rank, world, dist, seed=2026, coll=None, tail_log=None, force_gather=False):
         self.ctx, self.n_local, self.rank, self.world = ctx, n_local, rank, world
         log_g = world.bit_length() - 1
         assert (1 << log_g) == world, "world size must be a power of two"
         self.n_total = n_local + log_g
+        if tail_log is None and os.environ.get("JOLT_TAIL_LOG"):  # measurement knob (DESIGN.md section 6)
+            tail_log = min(n_local, int(os.environ["JOLT_TAIL_LOG"]))
+        self.tail_log = tail_log_for(n_local, world) if tail_log is None else tail_log
+        self.force_gather = force_gather
         if coll is None:
             import torch
-            coll = Collective(dist, world, torch.device("cuda", torch.cuda.current_device()))
+            dev = torch.device("cuda", torch.cuda.current_device())
+            try:  # RCCL called natively from the C++ round loop; torch.distributed only carries the rendezvous
+                coll = NativeCollective(ctx, dist, rank, world, dev)
+            except ffi.JoltError as e:
+                if e.status != 6:  # anything but "RCCL not available" is a real failure
+                    raise
+                coll = Collective(dist, world, dev)
         self.coll = coll
         spec = build_sharded_spec(n_local, rank, world, seed)
         self.members_spec = spec["members"]
@@ -329,57 +447,67 @@ class ShardedWorkload:
         eq.free()
         return c
 
-    def _tail_backend(self, stage, idxs, gathered, scalars):
-        """G-entry tables rebuilt from the gathered finals; the arena and the tail members are created once per stage and
-        only refilled afterwards."""
-        ctx, world = self.ctx, self.world
+    def _tail_backend(self, stage, idxs, coll, scalars):
+        """Hand-over to the redundant tail (phase B): pack this rank's 2^tail_log-entry tables, all-gather them, rebuild the
+        world * 2^tail_log-entry tables with the rank as the top variables.  Buffers, table views and tail members are created
+        once per stage and only refilled afterwards (split-eq members are rebuilt: their scalar depends on the challenges)."""
+        ctx, world, lib = self.ctx, self.world, ffi.lib()
         log_g = world.bit_length() - 1
-        key = stage
-        order = []  # (member idx, table k) in finals order
-        for i in idxs:
-            for k in range(self.members[i].n_tables):
-                order.append((i, k))
-        flat = np.ascontiguousarray(gathered.transpose(1, 0, 2))  # (n_tables_total, world, 4): table-major, rank = top variables
-        if key not in self._tails:
-            arena = ctx.upload(flat.reshape(-1, 4))
+        E = 1 << self.tail_log
+        n_tab = sum(self.members[i].n_tables for i in idxs)
+        rem = log_g + self.tail_log  # variables left: the top coordinates of every global point
+        if stage not in self._tails:
+            self._tails[stage] = {"pack": ctx.alloc(n_tab * E), "gath": ctx.alloc(world * n_tab * E), "arena": ctx.alloc(world * n_tab * E),
+                                  "slices": None, "members": None}
+        T = self._tails[stage]
+        hs = (C.c_void_p * len(idxs))(*[self.members[i].h for i in idxs])
+        st = lib.jolt_round_group_pack_tables(ctx.h, hs, C.c_size_t(len(idxs)), C.c_size_t(E), T["pack"].h)
+        if st:
+            ffi._ck(st, "jolt_round_group_pack_tables", ctx)
+        if isinstance(coll, NativeCollective):
+            coll.all_gather_table(T["pack"], n_tab * E, T["gath"])
+        else:  # torch.distributed fallback: through the host
+            g = coll.all_gather_u64(T["pack"].download())
+            st = lib.jolt_table_write(ctx.h, T["gath"].h, C.c_size_t(0), _p(np.ascontiguousarray(g.reshape(-1, 4))), C.c_size_t(world * n_tab * E))
+            if st:
+                ffi._ck(st, "jolt_table_write", ctx)
+        st = lib.jolt_tail_interleave(ctx.h, T["gath"].h, C.c_size_t(world), C.c_size_t(n_tab), C.c_size_t(E), T["arena"].h)
+        if st:
+            ffi._ck(st, "jolt_tail_interleave", ctx)
+
+        def build_split(i, tabs, scalar):
+            m = self.members[i]
+            if getattr(m, "uniform", False):
+                V, F, coeffs = m._uniform
+                return ctx.member_split_eq_uniform(tabs, V, F, coeffs, self.infos[i].w[:rem], scale=scalar, borrow=True)
+            return ctx.member_split_eq_product(tabs[0], tabs[1], self.infos[i].w[:rem], scale=scalar, borrow=True)
+
+        if T["members"] is None:
             slices, members, pos = [], [], 0
-            for i in idxs:
+            for k, i in enumerate(idxs):
                 m = self.members[i]
                 tabs = []
                 for _ in range(m.n_tables):
                     h = C.c_void_p()
-                    st = ffi.lib().jolt_table_slice(ctx.h, arena.h, C.c_size_t(pos * world), C.c_size_t(world), C.byref(h))
+                    st = lib.jolt_table_slice(ctx.h, T["arena"].h, C.c_size_t(pos * world * E), C.c_size_t(world * E), C.byref(h))
                     if st:
-                        raise ffi.JoltError(st, "jolt_table_slice")
+                        ffi._ck(st, "jolt_table_slice", ctx)
                     tabs.append(ffi.Table(ctx, h))
                     pos += 1
-                slices.extend(tabs)
-                if getattr(m, "uniform", False):
-                    V, F, coeffs = m._uniform
-                    tm = ctx.member_split_eq_uniform(tabs, V, F, coeffs, self.infos[i].w[:log_g], scale=scalars[idxs.index(i)], borrow=True)
-                elif m.split_eq:
-                    tm = ctx.member_split_eq_product(tabs[0], tabs[1], self.infos[i].w[:log_g], scale=scalars[idxs.index(i)], borrow=True)
+                slices.append(tabs)
+                if m.split_eq:
+                    members.append(build_split(i, tabs, scalars[k]))
                 else:
-                    tm = ctx.member_lc(tabs, m._groups, m.degree, borrow=True, skip_one=True)
-                members.append(tm)
-            self._tails[key] = (arena, slices, members)
+                    members.append(ctx.member_lc(tabs, m._groups, m.degree, borrow=True, skip_one=True))
+            T["slices"], T["members"] = slices, members
         else:
-            arena, slices, members = self._tails[key]
-            st = ffi.lib().jolt_table_write(ctx.h, arena.h, C.c_size_t(0), _p(flat.reshape(-1, 4)), C.c_size_t(flat.shape[0] * world))
-            if st:
-                raise ffi.JoltError(st, "jolt_table_write")
             for k, i in enumerate(idxs):
-                if self.members[i].split_eq:  # its initial scalar depends on this proof's challenges: rebuild that member
-                    members[k].destroy()
-                    base = sum(self.members[j].n_tables for j in idxs[:k])
-                    if getattr(self.members[i], "uniform", False):
-                        V, F, coeffs = self.members[i]._uniform
-                        members[k] = ctx.member_split_eq_uniform(slices[base:base + V * F], V, F, coeffs, self.infos[i].w[:log_g], scale=scalars[k], borrow=True)
-                    else:
-                        members[k] = ctx.member_split_eq_product(slices[base], slices[base + 1], self.infos[i].w[:log_g], scale=scalars[k], borrow=True)
+                if self.members[i].split_eq:
+                    T["members"][k].destroy()
+                    T["members"][k] = build_split(i, T["slices"][k], scalars[k])
                 else:
-                    members[k].reset()
-        return DeviceShard(ctx, members)
+                    T["members"][k].reset()
+        return DeviceShard(ctx, T["members"])
 
     def prove(self, label=0):
         outs = {}
@@ -387,9 +515,10 @@ class ShardedWorkload:
             ms = [self.members[i] for i in idxs]
             infos = [self.infos[i] for i in idxs]
             deg = max(m.degree for m in ms)
-            shard = DeviceShard(self.ctx, ms, rebuild=lambda g, s, stage=stage, idxs=idxs: self._tail_backend(stage, idxs, g, s))
+            shard = DeviceShard(self.ctx, ms, rebuild=lambda c, s, stage=stage, idxs=idxs: self._tail_backend(stage, idxs, c, s))
             outs[stage] = prove_batch_sharded(self.ctx.h, infos, [self.claims[i] for i in idxs], [self.batch_coeffs[i] for i in idxs],
-                                              self.n_total, self.n_local, deg, self.world, self.coll, shard, label=label + stage)
+                                              self.n_total, self.n_local, deg, self.world, self.coll, shard, label=label + stage,
+                                              tail_log=self.tail_log, force_gather=self.force_gather)
         for m in self.members:
             m.reset()
         return outs

@@ -290,6 +290,14 @@ EXPORT int orc_member_final_values(const orc_member *m, fr_t *out) {
     return ORC_OK;
 }
 
+/* Current (partially bound) evaluations of table t: `len >> rounds_bound` values (test hook for the sharded tail hand-over). */
+EXPORT size_t orc_member_current_len(const orc_member *m) { return m->len; }
+EXPORT int orc_member_copy_table(const orc_member *m, uint32_t t, fr_t *out, size_t cap) {
+    if (t >= m->n_tables || cap < m->len) return ORC_ERR_ARG;
+    memcpy(out, m->tables[t], m->len * sizeof(fr_t));
+    return ORC_OK;
+}
+
 /* The member's input claim = sum over the hypercube of its summand (what the stage would consume).
  * For EXPR: sum_x Expr(x); for GRUEN: sum_x scale*eq(w,x) a(x) b(x). */
 EXPORT void orc_member_input_claim(const orc_member *m, fr_t *out) {

@@ -364,6 +364,16 @@ class Member:
         assert rc == 0
         return o
 
+    def current_tables(self):
+        """The partially bound evaluations of every table: (n_tables, current_len, 4)."""
+        lib().orc_member_current_len.restype = C.c_size_t
+        n = lib().orc_member_current_len(self.h)
+        o = fr_array(self.n_tables * n).reshape(self.n_tables, n, 4)
+        for t in range(self.n_tables):
+            rc = lib().orc_member_copy_table(self.h, C.c_uint32(t), _p(o[t]), C.c_size_t(n))
+            assert rc == 0
+        return o
+
     def input_claim(self):
         o = fr_array(1)
         lib().orc_member_input_claim(self.h, _p(o))

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU ranks (gloo, world_size 2): the hypercube-sharded batched sumcheck -- partial round sums per
+"""N > 1 path on CPU ranks (gloo, world_size 2 and 4): the hypercube-sharded batched sumcheck -- partial round sums per
 shard, all-gather + modular sum, shard-local rounds then the gathered tail rounds -- must reproduce the transcript of
 the single-process prover over the global tables bit for bit.  The local compute is the CPU oracle here (there is no GPU
 in this container); the sharding / collective / round-loop logic under test is the product code of
@@ -13,7 +13,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, tail_log):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,15 +57,15 @@ def _worker(rank, world, port, tmpdir):
                 if bnd is not None:
                     m.finish_rounds(bnd)
 
-        def finals(self):
-            return np.concatenate([m.final_values()[: m.n_tables] for m in self.members], axis=0)
-
-        def make_tail(self, gathered, scalars):
-            # gathered: (world, n_tables_total, 4) -> G-entry tables, rank = top variable(s)
-            tabs = [np.ascontiguousarray(gathered[:, k, :]) for k in range(gathered.shape[1])]
+        def make_tail(self, coll, scalars):
+            # every rank's partially bound tables (2^tail_log entries each), all-gathered; rank = top variable(s)
+            mine = np.concatenate([m.current_tables() for m in self.members], axis=0)  # (n_tables_total, E, 4)
+            assert mine.shape[1] == 1 << tail_log
+            gathered = coll.all_gather_u64(mine).reshape(world, mine.shape[0], mine.shape[1], 4)
+            tabs = [np.ascontiguousarray(gathered[:, k]).reshape(-1, 4) for k in range(mine.shape[0])]
             m0 = O.Member.expr(tabs[0:3], flat, 2)
             m1 = O.Member.expr(tabs[3:6], cubic, 3)
-            m2 = O.Member.gruen_product(tabs[6], tabs[7], w[:log_g], scalars[2])
+            m2 = O.Member.gruen_product(tabs[6], tabs[7], w[: log_g + tail_log], scalars[2])
             return OracleShard([m0, m1, m2], [None, None, None])
 
         def close(self):
@@ -85,18 +85,20 @@ def _worker(rank, world, port, tmpdir):
     infos = [D.MemberInfo(D.KIND_EXPR_SKIP, 2, n_total, 3), D.MemberInfo(D.KIND_EXPR_SKIP, 3, n_total, 3),
              D.MemberInfo(D.KIND_SPLIT_EQ, 3, n_total, 2, w=w)]
     coll = D.Collective(dist, world, None)
-    got = D.prove_batch_sharded(None, infos, claims, coeffs, n_total, n_local, 3, world, coll, local, label=11)
+    got = D.prove_batch_sharded(None, infos, claims, coeffs, n_total, n_local, 3, world, coll, local, label=11, tail_log=tail_log)
     ok = (np.array_equal(got["polys"], want["polys"]) and np.array_equal(got["challenges"], want["challenges"])
           and np.array_equal(got["final_claim"], want["final_claim"]) and np.array_equal(got["member_claims"], want["member_claims"]))
     open(os.path.join(tmpdir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_prove_batch_matches_single_process(world):
+@pytest.mark.parametrize("world,tail_log", [(2, 0), (2, 2), (4, 0), (4, 1), (4, 3)])
+def test_sharded_prove_batch_matches_single_process(world, tail_log):
+    """tail_log = 0: the shards run all their local rounds and hand over single entries; tail_log > 0: early hand-over of
+    2^tail_log-entry tables (fewer exchanges); tail_log = n_local (world 4, 3): everything runs in the redundant tail."""
     import torch.multiprocessing as mp
-    port = 29500 + os.getpid() % 1000 + world
+    port = 29500 + os.getpid() % 1000 + 7 * world + tail_log
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, port, tmp), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, tmp, tail_log), nprocs=world, join=True)
         for r in range(world):
             assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"

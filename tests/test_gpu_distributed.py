@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, tmpdir, n_local):
+def _worker(rank, world, port, tmpdir, n_local, tail_log):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -24,7 +24,7 @@ def _worker(rank, world, port, tmpdir, n_local):
     from jolt_amd import ffi
     ctx = ffi.Context(0)
     coll = D.Collective(dist, world, None)
-    wl = D.ShardedWorkload(ctx, n_local, rank, world, dist, seed=31, coll=coll)
+    wl = D.ShardedWorkload(ctx, n_local, rank, world, dist, seed=31, coll=coll, tail_log=tail_log)
     outs = [wl.prove(label=50), wl.prove(label=50)]  # second pass reuses the cached tail members
     if rank == 0:
         np.savez(os.path.join(tmpdir, "got.npz"), **{f"{p}_{st}_{k}": v for p, o in enumerate(outs) for st, d in o.items() for k, v in d.items()})
@@ -32,15 +32,18 @@ def _worker(rank, world, port, tmpdir, n_local):
     dist.destroy_process_group()
 
 
-def test_sharded_device_workload_matches_global_oracle():
+@pytest.mark.parametrize("tail_log", [0, 3, 6])
+def test_sharded_device_workload_matches_global_oracle(tail_log):
+    """tail_log 0: all local rounds sharded, single entries handed over; 3: early hand-over of 8-entry tables (packed,
+    gathered, interleaved on the device); 6 = n_local: everything in the redundant tail."""
     import torch.multiprocessing as mp
     import oracle_lib as O
     from jolt_amd import distributed as D
     from jolt_amd import workload as W
     world, n_local = 2, 6
-    port = 29800 + os.getpid() % 1000
+    port = 29800 + os.getpid() % 1000 + tail_log
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, port, tmp, n_local), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, tmp, n_local, tail_log), nprocs=world, join=True)
         got = np.load(os.path.join(tmp, "got.npz"))
     # ---- global reference on the CPU oracle
     specs = [D.build_sharded_spec(n_local, r, world, seed=31) for r in range(world)]
@@ -76,3 +79,31 @@ def test_sharded_device_workload_matches_global_oracle():
             assert np.array_equal(got[f"{p}_{stage}_polys"], want["polys"]), (p, stage)
             assert np.array_equal(got[f"{p}_{stage}_challenges"], want["challenges"]), (p, stage)
             assert np.array_equal(got[f"{p}_{stage}_final_claim"], want["final_claim"]), (p, stage)
+
+
+def test_native_rccl_communicator_single_rank():
+    """The RCCL communicator owned by the library (dlopen'd librccl, ncclCommInitRank, ncclAllGather on the context stream)
+    with world = 1 -- the only size a one-GPU box can run: host and table all-gathers are identities, and the sharded
+    workload proved through it (native gather hook + device hand-over) gives the same transcript for every tail_log."""
+    from jolt_amd import distributed as D
+    from jolt_amd import ffi
+    from util import rand_fr
+    ctx = ffi.Context(0)
+    coll = D.NativeCollective(ctx, None, 0, 1)
+    x = rand_fr(37, 5)
+    assert np.array_equal(coll.all_gather_u64(x).reshape(-1, 4), x)
+    big = rand_fr(5000, 6)  # forces the staging buffers to grow
+    assert np.array_equal(coll.all_gather_u64(big).reshape(-1, 4), big)
+    src, dst = ctx.upload(big), ctx.alloc(5000)
+    coll.all_gather_table(src, 5000, dst)
+    assert np.array_equal(dst.download(), big)
+    outs = []
+    for tail_log in (0, 4, 7):
+        wl = D.ShardedWorkload(ctx, 7, 0, 1, None, seed=33, coll=coll, tail_log=tail_log, force_gather=True)
+        outs.append(wl.prove(label=3))
+    for o in outs[1:]:
+        for stage in outs[0]:
+            for k in ("polys", "challenges", "member_claims", "final_claim"):
+                assert np.array_equal(o[stage][k], outs[0][stage][k]), (stage, k)
+    coll.close()
+    ctx.close()
