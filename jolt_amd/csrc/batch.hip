@@ -86,14 +86,14 @@ static void note_bind(jolt_batch* b, size_t i, const Fr& c) {
     b->bound[i] += 1;
 }
 
-static int32_t assemble(const jolt_batch* b, size_t i, const Fr* ev, const Fr& claim, UnivariatePoly* out) {
+static int32_t assemble(const jolt_batch* b, size_t i, const Fr* ev, const Fr& claim, UnivariatePoly* out, const Fr* inv_l1) {
     if (b->kind[i] == 2) {
         size_t current_index = b->described[i].rounds - b->bound[i];
-        return gruen_poly_deg_3(b->current_scalar[i], b->w[i][current_index - 1], ev[0], ev[1], claim, out);
+        return gruen_poly_deg_3(b->current_scalar[i], b->w[i][current_index - 1], ev[0], ev[1], claim, out, inv_l1);
     }
     if (b->kind[i] == 3) {
         size_t current_index = b->described[i].rounds - b->bound[i];
-        return gruen_poly_from_q(b->current_scalar[i], b->w[i][current_index - 1], ev, b->degree[i] - 1, claim, out);
+        return gruen_poly_from_q(b->current_scalar[i], b->w[i][current_index - 1], ev, b->degree[i] - 1, claim, out, inv_l1);
     }
     std::vector<Fr> full;
     if (b->kind[i] == 1) {
@@ -140,12 +140,26 @@ extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* member
             }
         }
         std::vector<jolt_fr_t> local(total ? total : 1);
+        // the inversion of every split-eq message depends only on the challenge already noted: done while the device works
+        std::vector<Fr> l1(active.size()), inv_l1(active.size());
+        std::vector<char> has_l1(active.size(), 0);
+        for (size_t a = 0; a < active.size(); ++a) {
+            size_t i = active[a];
+            if (b->kind[i] < 2 || b->bound[i] >= b->described[i].rounds) continue;
+            l1[a] = mul(b->current_scalar[i], b->w[i][b->described[i].rounds - b->bound[i] - 1]);
+            has_l1[a] = l1[a].is_zero() ? 0 : 1;
+        }
+        const std::function<void()> overlap = [&]() {
+            for (size_t a = 0; a < active.size(); ++a)
+                if (has_l1[a]) inv_l1[a] = inv(l1[a]);
+        };
         if (local_fn) {
             JOLT_TRY(local_fn(user, active.data(), active.size(), binds.data(), local.data(), total));
+            overlap();
         } else {
             std::vector<jolt_member*> ms;
             for (size_t i : active) ms.push_back(members[i]);
-            JOLT_TRY(jolt_round_group_prove(b->ctx, ms.data(), ms.size(), binds.data(), local.data(), total));
+            JOLT_TRY(jolt_internal_round_group_prove(b->ctx, ms.data(), ms.size(), binds.data(), local.data(), total, &overlap));
         }
         std::vector<Fr> sums(total);
         for (size_t k = 0; k < total; ++k) sums[k] = fr_from_abi(&local[k]);
@@ -162,7 +176,7 @@ extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* member
         size_t off = 0;
         for (size_t a = 0; a < active.size(); ++a) {
             size_t i = active[a];
-            JOLT_TRY(assemble(b, i, sums.data() + off, b->member_claims[i], &msgs[a]));
+            JOLT_TRY(assemble(b, i, sums.data() + off, b->member_claims[i], &msgs[a], has_l1[a] ? &inv_l1[a] : nullptr));
             off += b->n_evals(i);
             if (msgs[a].degree() > b->max_degree) return JOLT_ERR_UNSUPPORTED;
             for (size_t k = 0; k < msgs[a].coefficients.size(); ++k)

@@ -1,11 +1,12 @@
 // jolt_amd/csrc/capi.hip -- implementation of include/jolt_hip.h: context, tables, bind/eq kernels launches and the
 // sumcheck members.  (MSM / HyperKZG device pieces live in msm.hip, the host-side mirror in host_mirror.hip.)
 #include <algorithm>
+#include <chrono>
 
-#include "ctx.hpp"
+#include "host_mirror.hpp"
 #include "member.hpp"
 #include "poly_kernels.cuh"
-#include "sumcheck_kernels.cuh"
+#include "engine_kernel.cuh"
 
 using namespace jolt;
 
@@ -71,9 +72,13 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     return JOLT_OK;
 }
 
+void jolt_internal_engine_free(jolt_ctx* ctx);
+
 extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     if (!ctx) return JOLT_OK;
     (void)hipSetDevice(ctx->device);
+    (void)jolt_internal_engine_quiesce(ctx);
+    jolt_internal_engine_free(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 3; ++k) if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -96,6 +101,7 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
 
 extern "C" int32_t jolt_ctx_synchronize(jolt_ctx* ctx) {
     if (!ctx) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     for (int k = 0; k < 3; ++k) if (ctx->side[k]) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side[k]));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return JOLT_OK;
@@ -152,6 +158,7 @@ static int32_t reduce_into_results(jolt_ctx* ctx, int nblocks, int ne, size_t sl
 }
 // copy results[0..count) to the host and wait (the protocol's per-round sync point)
 static int32_t fetch_results(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
+    (void)jolt_internal_engine_quiesce(ctx);
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, count * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(out, ctx->h_results, count * sizeof(Fr));
@@ -247,6 +254,7 @@ extern "C" int32_t jolt_table_from_i64(jolt_ctx* ctx, const int64_t* host, size_
     return table_from_small(ctx, host, len, out, k_from_i64);
 }
 extern "C" int32_t jolt_table_download(jolt_ctx* ctx, const jolt_table* t, size_t offset, size_t len, jolt_fr_t* host) {
+    (void)jolt_internal_engine_quiesce(ctx);
     if (!ctx || !t || (!host && len)) return JOLT_ERR_INVALID_ARG;
     if (offset + len > t->len) return JOLT_ERR_SIZE_MISMATCH;
     if (len) {
@@ -266,6 +274,7 @@ extern "C" int32_t jolt_table_device_ptr(const jolt_table* t, void** p) {
     return JOLT_OK;
 }
 extern "C" int32_t jolt_table_free(jolt_ctx* ctx, jolt_table* t) {
+    (void)jolt_internal_engine_quiesce(ctx ? ctx : (t ? t->ctx : nullptr));
     if (!t) return JOLT_OK;
     jolt_ctx* c = ctx ? ctx : t->ctx;
     if (c) (void)hipStreamSynchronize(c->stream);
@@ -289,6 +298,7 @@ extern "C" int32_t jolt_table_slice(jolt_ctx* ctx, const jolt_table* parent, siz
     return JOLT_OK;
 }
 extern "C" int32_t jolt_table_write(jolt_ctx* ctx, jolt_table* t, size_t offset, const jolt_fr_t* host, size_t len) {
+    (void)jolt_internal_engine_quiesce(ctx);
     if (!ctx || !t || (!host && len)) return JOLT_ERR_INVALID_ARG;
     if (offset + len > t->len) return JOLT_ERR_SIZE_MISMATCH;
     if (len) {
@@ -305,6 +315,7 @@ extern "C" int32_t jolt_table_write(jolt_ctx* ctx, jolt_table* t, size_t offset,
 // challenge: ceil(k/40) launches, blockIdx.y = table.
 int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r, int32_t order) {
     if (k == 0) return JOLT_OK;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     for (size_t i = 0; i < k; ++i) {
         if (!tables[i]) return JOLT_ERR_INVALID_ARG;
         if (tables[i]->len < 2) { ctx->last_error = "cannot bind a zero-variable polynomial"; return JOLT_ERR_INVALID_ARG; }  // dense.rs:190,225 assert
@@ -761,6 +772,7 @@ extern "C" int32_t jolt_member_create_split_eq_product_sharded(jolt_ctx* ctx, jo
 
 // rewind a member that borrows its tables to round 0 (no device work): re-prove with fresh challenges
 extern "C" int32_t jolt_member_reset(jolt_member* m) {
+    (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m) return JOLT_ERR_INVALID_ARG;
     if (!m->borrowed) { m->ctx->last_error = "only members that borrow their tables can be reset"; return JOLT_ERR_UNSUPPORTED; }
     for (jolt_table* t : m->tables) { t->cur = -1; t->len = t->view_len; }
@@ -835,6 +847,7 @@ static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGrou
 // publishes its sums into host-mapped memory (finish_member).
 static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
     constexpr size_t kTailPairs = 4096;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     if (n > (size_t)kGroupTicket) { ctx->last_error = "batch round has too many members"; return JOLT_ERR_UNSUPPORTED; }
     struct Item {
         size_t ne, slot;
@@ -1097,6 +1110,7 @@ static void member_aux(const jolt_member* m, jolt_fr_t* aux) {
 }
 
 extern "C" int32_t jolt_member_prove_round(jolt_member* m, const jolt_fr_t* bind, jolt_fr_t* evals_out, size_t n_evals, jolt_fr_t* aux_out) {
+    (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m || !evals_out) return JOLT_ERR_INVALID_ARG;
     jolt_ctx* ctx = m->ctx;
     if (n_evals != jolt_internal_member_n_evals(m)) return JOLT_ERR_SIZE_MISMATCH;
@@ -1112,8 +1126,314 @@ extern "C" int32_t jolt_member_prove_round(jolt_member* m, const jolt_fr_t* bind
     return round_wait(ctx, n_evals, evals_out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent round engine (engine_kernel.cuh): host side
+// ------------------------------------------------------------------------------------------------------------------
+struct jolt_engine {
+    bool active = false;
+    std::vector<jolt_member*> members;
+    int n_rounds = 0, round = 0;
+    uint32_t binds_posted = 0;
+    size_t total = 0;  // round sums per round
+    uint64_t seq0 = 0;
+    EngDesc* h_desc = nullptr;  // pinned staging
+    EngDesc* d_desc = nullptr;
+    EngCtl* h_ctl = nullptr;    // pinned, device-mapped
+    EngSync* d_sync = nullptr;
+    Fr* d_partials = nullptr;
+    // policy (environment: JOLT_ENGINE=1 enables, JOLT_ENGINE_PAIRS=<n> sets the size at which a batch switches over).
+    // Off by default: measured within +-1 % of the per-round kernels at T = 2^20 -- the late rounds
+    // are bound by the serial multiply chain and the host<->device handshake, not by launch overhead.
+    bool enabled = false, trace = false;
+    size_t max_pairs = 1024;
+    uint32_t task_blocks = 32, max_blocks = kEngMaxBlocks;
+    // JOLT_ENGINE_TRACE: host-side split per round (ns): posted -> sums seen (device + PCIe), sums seen -> next post (host)
+    std::vector<long long> t_device, t_host;
+    long long t_last_seen = 0;
+};
+
+static jolt_engine* engine_get(jolt_ctx* ctx) {
+    if (ctx->engine) return ctx->engine;
+    jolt_engine* e = new (std::nothrow) jolt_engine();
+    if (!e) return nullptr;
+    const char* en = std::getenv("JOLT_ENGINE");
+    e->enabled = en && en[0] == '1';
+    const char* mp = std::getenv("JOLT_ENGINE_PAIRS");
+    if (mp && std::atoll(mp) > 0) e->max_pairs = (size_t)std::atoll(mp);
+    const char* tb = std::getenv("JOLT_ENGINE_TASK_BLOCKS");
+    if (tb && std::atoi(tb) > 0) e->task_blocks = (uint32_t)std::min(64, std::atoi(tb));
+    const char* mb = std::getenv("JOLT_ENGINE_MAX_BLOCKS");
+    if (mb && std::atoi(mb) > 0) e->max_blocks = (uint32_t)std::min(kEngMaxBlocks, std::atoi(mb));
+    const char* tr = std::getenv("JOLT_ENGINE_TRACE");
+    e->trace = tr && tr[0] == '1';
+    bool ok = hipHostMalloc((void**)&e->h_desc, sizeof(EngDesc), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void**)&e->d_desc, sizeof(EngDesc)) == hipSuccess &&
+              hipHostMalloc((void**)&e->h_ctl, sizeof(EngCtl), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipMalloc((void**)&e->d_sync, sizeof(EngSync)) == hipSuccess &&
+              hipMalloc((void**)&e->d_partials, (size_t)kEngMaxSlots * kEngMaxBlocks * sizeof(Fr)) == hipSuccess;
+    if (!ok) e->enabled = false;  // the per-round kernels still work
+    ctx->engine = e;
+    return e;
+}
+
+void jolt_internal_engine_free(jolt_ctx* ctx) {
+    jolt_engine* e = ctx->engine;
+    if (!e) return;
+    if (e->h_desc) (void)hipHostFree(e->h_desc);
+    if (e->d_desc) (void)hipFree(e->d_desc);
+    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+    if (e->d_sync) (void)hipFree(e->d_sync);
+    if (e->d_partials) (void)hipFree(e->d_partials);
+    delete e;
+    ctx->engine = nullptr;
+}
+
+int32_t jolt_internal_engine_quiesce(jolt_ctx* ctx) {
+    jolt_engine* e = ctx ? ctx->engine : nullptr;
+    if (!e || !e->active) return JOLT_OK;
+    __atomic_store_n(&e->h_ctl->abort, (uint64_t)1, __ATOMIC_RELEASE);
+    e->active = false;
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JOLT_OK;
+}
+
+// Post bind number `binds_posted` into its mailbox: challenge first, then both sequence copies.
+static void engine_post(jolt_engine* e, const Fr& c) {
+    EngMail& mb = e->h_ctl->mail[e->binds_posted];
+    for (int k = 0; k < 8; ++k) mb.challenge[k] = c.l[k];
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const uint64_t seq = (uint64_t)e->binds_posted + 1;
+    __atomic_store_n(&mb.seq_b, seq, __ATOMIC_RELEASE);
+    __atomic_store_n(&mb.seq_a, seq, __ATOMIC_RELEASE);
+    e->binds_posted += 1;
+}
+
+// How many rounds the engine could take over from here (0 = not eligible).
+static int engine_eligible(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* members, size_t n, const Fr* const* binds) {
+    if (!e || !e->enabled || n == 0 || n > (size_t)kEngMaxMembers) return 0;
+    const bool has_bind = binds && binds[0];
+    size_t tables = 0, slots = 0, tasks = 0;
+    int rounds = -1;
+    for (size_t i = 0; i < n; ++i) {
+        const jolt_member* m = members[i];
+        if (m->order != JOLT_ORDER_LOW_TO_HIGH) return 0;
+        if ((binds && binds[i] != nullptr) != has_bind) return 0;
+        if (has_bind && !(*binds[i] == *binds[0])) return 0;
+        size_t len = has_bind ? m->len / 2 : m->len;
+        if (len < 2 || len / 2 > e->max_pairs) return 0;
+        int r = 0;
+        while (((size_t)1 << r) < len) ++r;
+        if (((size_t)1 << r) != len) return 0;
+        if ((size_t)r != m->rounds - m->bound - (has_bind ? 1 : 0)) return 0;  // the member must run to its end
+        if (rounds < 0) rounds = r;
+        if (r != rounds) return 0;
+        for (const jolt_table* t : m->tables) if (t->len != m->len) return 0;
+        size_t ne = jolt_internal_member_n_evals(m);
+        tables += m->tables.size();
+        slots += ne;
+        tasks += m->kind == jolt_member::kExpr ? ne : 1;
+        if (m->kind == jolt_member::kSplitEqUniform && (m->uni_F < 2 || m->uni_F > 4 || m->uni_V > (uint32_t)kMaxGroups)) return 0;
+        if (m->kind == jolt_member::kExpr && (ne > 8 || !m->all_tables_used)) return 0;  // the fused bind writes through the summand's table references
+    }
+    if (rounds < 3 || rounds > kEngMaxRounds) return 0;  // not worth a launch for one or two rounds
+    if (tables > (size_t)kEngMaxTables || slots > (size_t)kEngMaxSlots || tasks > (size_t)kEngMaxTasks || slots > ctx->round_cap) return 0;
+    return rounds;
+}
+
+static int32_t engine_start(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* members, size_t n, const Fr* const* binds, int rounds) {
+    const bool has_bind = binds && binds[0];
+    EngDesc& D = *e->h_desc;
+    std::memset(&D, 0, sizeof(D));
+    D.n_members = (int32_t)n;
+    D.n_rounds = rounds;
+    D.first_has_bind = has_bind ? 1 : 0;
+    uint32_t tab = 0, slot = 0, task = 0;
+    std::vector<size_t> work;
+    for (size_t i = 0; i < n; ++i) {
+        jolt_member* m = members[i];
+        EngMember& M = D.m[i];
+        M.kind = m->kind;
+        M.n_tables = (uint32_t)m->tables.size();
+        M.tab_off = tab;
+        M.ne = (uint32_t)jolt_internal_member_n_evals(m);
+        M.slot = slot;
+        M.skip_one = m->skip_one ? 1u : 0u;
+        M.desc = m->d_desc;
+        for (jolt_table* t : m->tables) {
+            EngTable& T = D.t[tab++];
+            // capacities for the ping-pong: the first bind writes len/2 entries into the alternate buffer, the second
+            // len/4 into the other one (which a borrowed view does not own yet)
+            JOLT_TRY(jolt_internal_table_ensure_alt(t, t->len / 2));
+            const int first = t->cur < 0 ? 0 : 1 - t->cur;
+            const int second = 1 - first;
+            if (t->cap[second] < std::max<size_t>(t->len / 4, 1)) {
+                if (t->cur == second) { ctx->last_error = "round engine: table buffer smaller than its contents"; return JOLT_ERR_INVALID_ARG; }
+                if (t->buf[second]) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(t->buf[second])); t->buf[second] = nullptr; t->cap[second] = 0; }
+                JOLT_HIP_TRY(ctx, hipMalloc((void**)&t->buf[second], std::max<size_t>(t->len / 4, 1) * sizeof(Fr)));
+                t->cap[second] = std::max<size_t>(t->len / 4, 1);
+            }
+            T.src = t->data();
+            T.buf[0] = t->buf[0];
+            T.buf[1] = t->buf[1];
+            T.first_out = (uint32_t)first;
+            T.len0 = (uint32_t)t->len;
+        }
+        const size_t pairs0 = (has_bind ? m->len / 2 : m->len) / 2;
+        if (m->kind == jolt_member::kExpr) {
+            for (uint32_t t = 0; t < M.ne; ++t) {
+                D.task[task] = EngTask{(uint32_t)i, t, 0, 0, slot + t, 1, (uint32_t)(pairs0 * std::max<uint32_t>(1, m->desc.n_groups))};
+                D.slot_task[slot + t] = task;
+                work.push_back(pairs0 * std::max<uint32_t>(1, m->desc.n_groups));
+                task++;
+            }
+        } else {
+            M.V = m->kind == jolt_member::kSplitEqUniform ? m->uni_V : 1;
+            M.F = m->kind == jolt_member::kSplitEqUniform ? m->uni_F : 2;
+            for (uint32_t v = 0; v < M.V && m->kind == jolt_member::kSplitEqUniform; ++v) {
+                M.coeff[v] = m->uni_coeff[v];
+                M.coeff_one[v] = m->uni_coeff[v] == Fr::one() ? 1u : 0u;
+            }
+            // E_out / E_in schedule (member_note_bind's bookkeeping, replayed ahead of time)
+            size_t bound = m->bound, in_bits = m->e_in_bits, out_bits = m->e_out_bits;
+            auto step = [&]() {
+                size_t ci = m->rounds - bound - 1;
+                if (m->rounds / 2 < ci && in_bits > 0) in_bits -= 1;
+                else if (0 < ci && out_bits > 0) out_bits -= 1;
+                bound += 1;
+            };
+            if (has_bind) step();
+            for (int k = 0; k < rounds; ++k) {
+                if (out_bits >= m->e_out_cache.size() || in_bits >= m->e_in_cache.size()) { ctx->last_error = "round engine: split-eq cache"; return JOLT_ERR_INVALID_ARG; }
+                M.e_out[k] = m->e_out_cache[out_bits]->data();
+                M.e_in[k] = m->e_in_cache[in_bits]->data();
+                M.in_bits[k] = (int32_t)in_bits;
+                step();
+            }
+            for (uint32_t a = 0; a < M.ne; ++a) D.slot_task[slot + a] = task;
+            D.task[task] = EngTask{(uint32_t)i, 0, 0, 0, slot, M.ne, (uint32_t)(pairs0 * M.V)};
+            work.push_back(pairs0 * M.V);
+            task++;
+        }
+        slot += M.ne;
+    }
+    D.n_tables = (int32_t)tab;
+    D.n_tasks = (int32_t)task;
+    D.n_slots = (int32_t)slot;
+    // workgroups per task: ~2 items per thread in the first engine round, 1..32 each, kEngMaxBlocks in total
+    std::vector<uint32_t> nb(task);
+    uint32_t total_blocks = 0;
+    for (uint32_t k = 0; k < task; ++k) {
+        nb[k] = eng_active_chunks((uint32_t)work[k], e->task_blocks, 0);
+        total_blocks += nb[k];
+    }
+    while (total_blocks > e->max_blocks && total_blocks > task) {
+        total_blocks = 0;
+        for (uint32_t k = 0; k < task; ++k) { nb[k] = std::max<uint32_t>(1, nb[k] / 2); total_blocks += nb[k]; }
+    }
+    uint32_t fb = 0;
+    for (uint32_t k = 0; k < task; ++k) { D.task[k].first_block = fb; D.task[k].n_blocks = nb[k]; fb += nb[k]; }
+    // control block: clear the mailboxes; the pending challenge (if any) is posted before the launch
+    std::memset(e->h_ctl, 0, sizeof(EngCtl));
+    e->binds_posted = 0;
+    if (has_bind) engine_post(e, *binds[0]);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    void* d_ctl = nullptr;
+    void *d_round = nullptr, *d_flag = nullptr;
+    JOLT_HIP_TRY(ctx, hipHostGetDevicePointer(&d_ctl, e->h_ctl, 0));
+    JOLT_HIP_TRY(ctx, hipHostGetDevicePointer(&d_round, ctx->h_round, 0));
+    JOLT_HIP_TRY(ctx, hipHostGetDevicePointer(&d_flag, ctx->h_flag, 0));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(e->d_desc, e->h_desc, sizeof(EngDesc), hipMemcpyHostToDevice, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(e->d_sync, 0, sizeof(EngSync), ctx->stream));
+    if (e->trace) {
+        const uint32_t one = 1;
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(&e->d_sync->trace, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
+    }
+    e->seq0 = ctx->seq + 1;
+    hipLaunchKernelGGL(k_round_engine, dim3(total_blocks), dim3(kBlock), 0, ctx->stream, (const EngDesc*)e->d_desc, (const EngCtl*)d_ctl, e->d_sync, e->d_partials,
+                       (Fr*)d_round, (uint64_t*)d_flag, e->seq0);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    e->members.assign(members, members + n);
+    e->n_rounds = rounds;
+    e->round = 0;
+    e->total = slot;
+    e->active = true;
+    return JOLT_OK;
+}
+
+// One engine round.  Returns JOLT_OK with the sums, or `*gone = true` when the engine is no longer running (it gave up
+// waiting, or was never started): the caller then runs the round through the per-round kernels -- nothing of this round
+// has been applied to the host-side state yet.
+static int32_t engine_round(jolt_ctx* ctx, jolt_engine* e, const Fr* const* binds, jolt_fr_t* out, bool* gone, const std::function<void()>* overlap) {
+    *gone = false;
+    const bool has_bind = binds && binds[0];
+    auto now_ns = []() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const long long t_post = e->trace ? now_ns() : 0;
+    if (e->trace && e->round > 0) e->t_host.push_back(t_post - e->t_last_seen);
+    if (e->round > 0) engine_post(e, *binds[0]);  // the challenge of the previous round
+    if (overlap && *overlap) (*overlap)();        // host work that does not need the sums
+    const uint64_t want = e->seq0 + (uint64_t)e->round;
+    volatile uint64_t* flag = ctx->h_flag;
+    uint64_t spins = 0;
+    while (*flag != want) {
+        if (++spins > (1ull << 20)) {
+            spins = 0;
+            hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (*flag == want) break;
+                e->active = false;  // the engine left (spin limit): not an error, the per-round kernels take over
+                *gone = true;
+                return JOLT_OK;
+            }
+            if (q != hipErrorNotReady) { e->active = false; ctx->last_error = std::string("round engine: ") + hipGetErrorString(q); return JOLT_ERR_HIP; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (e->trace) { e->t_last_seen = now_ns(); e->t_device.push_back(e->t_last_seen - t_post); }
+    std::memcpy(out, ctx->h_round, e->total * sizeof(Fr));
+    ctx->seq = want;
+    // host-side bookkeeping of the bind the engine applied at the start of this round
+    if (has_bind) {
+        for (jolt_member* m : e->members) {
+            JOLT_TRY(member_note_bind(m, *binds[0]));
+            for (jolt_table* t : m->tables) {
+                t->cur = t->cur < 0 ? 0 : 1 - t->cur;
+                t->len /= 2;
+            }
+        }
+    }
+    e->round += 1;
+    if (e->round == e->n_rounds) {
+        e->active = false;  // the kernel returns by itself after its last round
+        if (e->trace) {     // per-round phase timestamps of block 0 / the publishing block, in shader cycles
+            static EngSync snap;
+            JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            JOLT_HIP_TRY(ctx, hipMemcpy(&snap, e->d_sync, sizeof(EngSync), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[engine] host view (us): posted->seen");
+            for (long long v : e->t_device) std::fprintf(stderr, " %.1f", v / 1e3);
+            std::fprintf(stderr, " | seen->next post");
+            for (long long v : e->t_host) std::fprintf(stderr, " %.1f", v / 1e3);
+            std::fprintf(stderr, "\n");
+            e->t_device.clear();
+            e->t_host.clear();
+            for (int r = 0; r < e->n_rounds; ++r) {
+                const uint64_t* st = snap.stamps[r];
+                const uint64_t prev = r ? snap.stamps[r - 1][5] : st[0];
+                std::fprintf(stderr, "[engine] round %2d  wait %6lld  setup %6lld  task %6lld  ticket %6lld  (other block) %6lld  reduce+publish %6lld  (cycles)\n", r,
+                             (long long)(st[0] - prev), (long long)(st[1] - st[0]), (long long)(st[2] - st[1]), (long long)(st[3] - st[2]),
+                             (long long)(st[4] - st[3]), (long long)(st[5] - st[4]));
+            }
+        }
+    }
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_round_group_prove(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds, jolt_fr_t* evals_out,
                                           size_t cap) {
+    return jolt_internal_round_group_prove(ctx, members, n, binds, evals_out, cap, nullptr);
+}
+
+int32_t jolt_internal_round_group_prove(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds, jolt_fr_t* evals_out,
+                                        size_t cap, const std::function<void()>* overlap) {
     if (!ctx || (!members && n) || !evals_out) return JOLT_ERR_INVALID_ARG;
     size_t total = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -1130,7 +1450,24 @@ extern "C" int32_t jolt_round_group_prove(jolt_ctx* ctx, jolt_member* const* mem
             bptr[i] = &bstore[i];
         }
     }
+    // late rounds: the persistent round engine (no launches per round)
+    jolt_engine* eng = engine_get(ctx);
+    if (eng && eng->active) {
+        bool same = eng->members.size() == n && bptr[0] != nullptr;
+        for (size_t i = 0; same && i < n; ++i) same = eng->members[i] == members[i] && bptr[i] && *bptr[i] == *bptr[0];
+        if (!same) JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    } else if (eng) {
+        int r = engine_eligible(ctx, eng, members, n, bptr.data());
+        if (r > 0) JOLT_TRY(engine_start(ctx, eng, members, n, bptr.data(), r));
+    }
+    if (eng && eng->active) {
+        bool gone = false;
+        JOLT_TRY(engine_round(ctx, eng, bptr.data(), evals_out, &gone, overlap));
+        if (!gone) return JOLT_OK;
+        overlap = nullptr;  // already ran
+    }
     JOLT_TRY(group_enqueue(ctx, members, n, bptr.data()));
+    if (overlap && *overlap) (*overlap)();
     return round_wait(ctx, total, evals_out);  // no copy, no stream sync: the last workgroup published the sums
 }
 
@@ -1194,6 +1531,7 @@ extern "C" int32_t jolt_round_group_final_values(jolt_ctx* ctx, jolt_member* con
 }
 
 extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
+    (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m || !out) return JOLT_ERR_INVALID_ARG;
     jolt_ctx* ctx = m->ctx;
     int grid = sweep_grid(ctx, m->len);
@@ -1241,6 +1579,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
 }
 
 extern "C" int32_t jolt_member_destroy(jolt_member* m) {
+    (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m) return JOLT_OK;
     jolt_ctx* ctx = m->ctx;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);

@@ -254,6 +254,7 @@ extern "C" int32_t jolt_round_group_pack_tables(jolt_ctx* ctx, jolt_member* cons
         total += members[i]->tables.size();
     }
     if (dst->cur < 0 || dst->len < total * entries) return JOLT_ERR_SIZE_MISMATCH;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     std::vector<const Fr*> ptrs;
     for (size_t i = 0; i < n; ++i)
         for (jolt_table* t : members[i]->tables) ptrs.push_back(t->data());

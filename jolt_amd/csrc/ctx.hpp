@@ -46,7 +46,12 @@ struct jolt_ctx {
     size_t msm_ws_cap[4] = {0, 0, 0, 0};
     void* msm_host[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // persistent round engine for the late rounds of a batch (engine_kernel.cuh); owned by capi.hip
+    struct jolt_engine* engine = nullptr;
 };
+
+// Stop a running round engine (if any) so that other work may use the stream / the members' tables.
+int32_t jolt_internal_engine_quiesce(jolt_ctx* ctx);
 
 struct jolt_table {
     jolt_ctx* ctx = nullptr;

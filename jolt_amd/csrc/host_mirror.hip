@@ -82,8 +82,13 @@ Fr UnivariatePoly::evaluate(const Fr& x) const {
 size_t UnivariatePoly::degree() const { return coefficients.empty() ? 0 : coefficients.size() - 1; }
 
 // split_eq.rs:383-417
+Fr inverse_or_given(const Fr& x, const Fr* given) {
+    if (given && mul(x, *given) == Fr::one()) return *given;
+    return inv(x);
+}
+
 int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& q_constant, const Fr& q_quadratic, const Fr& s0_plus_s1,
-                         UnivariatePoly* out) {
+                         UnivariatePoly* out, const Fr* inv_l1) {
     Fr eq1 = mul(current_scalar, point_i);
     Fr eq0 = sub(current_scalar, eq1);
     Fr eqm = sub(eq1, eq0);
@@ -92,7 +97,7 @@ int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& 
     Fr cubic0 = mul(eq0, q_constant);
     Fr cubic1 = sub(s0_plus_s1, cubic0);
     if (eq1.is_zero()) return JOLT_ERR_NOT_INVERTIBLE;
-    Fr quad1 = mul(cubic1, inv(eq1));
+    Fr quad1 = mul(cubic1, inverse_or_given(eq1, inv_l1));
     Fr e2 = add(q_quadratic, q_quadratic);
     Fr quad2 = add(sub(add(quad1, quad1), q_constant), e2);
     Fr quad3 = add(add(sub(add(quad2, quad1), q_constant), e2), e2);
@@ -104,13 +109,14 @@ int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& 
 // s(t) = l(t) q(t) with l(0) = scalar (1 - w_i), l(1) = scalar w_i, from q(0), q(2), .., q(dq) and claim = s(0) + s(1):
 // q(1) = (claim - l(0) q(0)) / l(1), interpolate q on {0..dq}, multiply by the linear factor.  Same polynomial as
 // GruenSplitEqPolynomial::gruen_poly_from_evals (split_eq.rs:419-447) produces from its own evaluation set.
-int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr* q_evals, size_t dq, const Fr& s0_plus_s1, UnivariatePoly* out) {
+int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr* q_evals, size_t dq, const Fr& s0_plus_s1, UnivariatePoly* out,
+                          const Fr* inv_l1) {
     Fr l1 = mul(current_scalar, point_i);
     Fr l0 = sub(current_scalar, l1);
     if (l1.is_zero()) return JOLT_ERR_NOT_INVERTIBLE;
     std::vector<Fr> q(dq + 1);
     q[0] = q_evals[0];
-    q[1] = mul(sub(s0_plus_s1, mul(l0, q[0])), inv(l1));
+    q[1] = mul(sub(s0_plus_s1, mul(l0, q[0])), inverse_or_given(l1, inv_l1));
     for (size_t t = 2; t <= dq; ++t) q[t] = q_evals[t - 1];
     UnivariatePoly qp = UnivariatePoly::from_evals(q.data(), q.size());
     Fr lc1 = sub(l1, l0);
@@ -177,15 +183,31 @@ Fr MockTranscript::challenge_scalar() {
 size_t DeviceMember::num_rounds() const { return m->rounds; }
 size_t DeviceMember::n_evals() const { return jolt_internal_member_n_evals(m); }
 
-int32_t DeviceMember::assemble(const Fr* evals, const Fr& previous_claim, UnivariatePoly* out) const {
+bool DeviceMember::next_l1(bool has_bind, const Fr& c, Fr* l1) const {
+    if (m->kind == jolt_member::kExpr) return false;
+    size_t bound = m->bound;
+    Fr scalar = m->current_scalar;
+    if (has_bind) {  // split_eq.rs:334-337, as member_note_bind will apply it
+        if (bound >= m->rounds) return false;
+        Fr p = m->w[m->rounds - bound - 1];
+        Fr prod = mul(p, c);
+        scalar = mul(scalar, add(add(sub(sub(Fr::one(), p), c), prod), prod));
+        bound += 1;
+    }
+    if (bound >= m->rounds) return false;
+    *l1 = mul(scalar, m->w[m->rounds - bound - 1]);
+    return true;
+}
+
+int32_t DeviceMember::assemble(const Fr* evals, const Fr& previous_claim, UnivariatePoly* out, const Fr* inv_l1) const {
     if (m->kind == jolt_member::kSplitEqProduct) {
         // ram_hamming_booleanity.rs:128-135: message = gruen_poly_deg_3(q(0), q(inf), previous_claim)
         size_t current_index = m->rounds - m->bound;
-        return gruen_poly_deg_3(m->current_scalar, m->w[current_index - 1], evals[0], evals[1], previous_claim, out);
+        return gruen_poly_deg_3(m->current_scalar, m->w[current_index - 1], evals[0], evals[1], previous_claim, out, inv_l1);
     }
     if (m->kind == jolt_member::kSplitEqUniform) {
         size_t current_index = m->rounds - m->bound;
-        return gruen_poly_from_q(m->current_scalar, m->w[current_index - 1], evals, m->uni_F, previous_claim, out);
+        return gruen_poly_from_q(m->current_scalar, m->w[current_index - 1], evals, m->uni_F, previous_claim, out, inv_l1);
     }
     std::vector<Fr> full;
     if (m->skip_one) {
@@ -244,14 +266,23 @@ int32_t DeviceGroupedRounds::batch_prove_round(std::vector<MemberRound>& work) {
         total += dm->n_evals();
     }
     std::vector<jolt_fr_t> evals(total ? total : 1);
-    JOLT_TRY(jolt_round_group_prove(ctx, ms.data(), ms.size(), binds.data(), evals.data(), evals.size()));
+    // the one inversion of each split-eq message depends only on the challenge: compute it while the device runs the round
+    std::vector<Fr> l1(work.size()), inv_l1(work.size());
+    std::vector<char> has_l1(work.size(), 0);
+    for (size_t i = 0; i < work.size(); ++i)
+        has_l1[i] = static_cast<DeviceMember*>(work[i].member)->next_l1(work[i].has_bind, work[i].bind, &l1[i]) && !l1[i].is_zero() ? 1 : 0;
+    const std::function<void()> overlap = [&]() {
+        for (size_t i = 0; i < work.size(); ++i)
+            if (has_l1[i]) inv_l1[i] = inv(l1[i]);
+    };
+    JOLT_TRY(jolt_internal_round_group_prove(ctx, ms.data(), ms.size(), binds.data(), evals.data(), evals.size(), &overlap));
     size_t off = 0;
     for (size_t i = 0; i < work.size(); ++i) {
         DeviceMember* dm = static_cast<DeviceMember*>(work[i].member);
         Fr ev[JOLT_MAX_DEGREE + 1];
         for (size_t k = 0; k < dm->n_evals(); ++k) ev[k] = fr_from_abi(&evals[off + k]);
         off += dm->n_evals();
-        JOLT_TRY(dm->assemble(ev, work[i].claim, &work[i].message));
+        JOLT_TRY(dm->assemble(ev, work[i].claim, &work[i].message, has_l1[i] ? &inv_l1[i] : nullptr));
         work[i].has_message = true;
     }
     return JOLT_OK;

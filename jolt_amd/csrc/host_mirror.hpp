@@ -9,10 +9,16 @@
 //   GruenSplitEqPolynomial::gruen_poly_deg_3                         crates/jolt-poly/src/split_eq.rs:383-417
 //   Transcript                                                       crates/jolt-transcript/src/legacy.rs:55-100
 #pragma once
+#include <functional>
 #include <memory>
 #include <vector>
 
 #include "ctx.hpp"
+
+// jolt_round_group_prove with a host callback that runs after the round has been enqueued and before its sums are awaited
+// (capi.hip): work that does not depend on the sums overlaps with the device.
+int32_t jolt_internal_round_group_prove(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds, jolt_fr_t* evals_out,
+                                        size_t cap, const std::function<void()>* overlap);
 
 namespace jolt_host {
 
@@ -72,7 +78,9 @@ struct DeviceMember final : ProveRounds {
     int32_t prove_round(const Fr* bind, size_t round, const Fr& previous_claim, UnivariatePoly* out) override;
     int32_t finish_rounds(const Fr& bind) override;
     // message assembly from the device sums (shared with the grouped scheduler)
-    int32_t assemble(const Fr* evals, const Fr& previous_claim, UnivariatePoly* out) const;
+    int32_t assemble(const Fr* evals, const Fr& previous_claim, UnivariatePoly* out, const Fr* inv_l1 = nullptr) const;
+    // l(1) = scalar * w_i of the NEXT round message, given the bind that the round applies first (split-eq members)
+    bool next_l1(bool has_bind, const Fr& bind, Fr* l1) const;
     size_t n_evals() const;
 };
 
@@ -132,9 +140,13 @@ int32_t prove_batch(const BatchPrelude& prelude, std::vector<ProveRounds*>& memb
                     bool full_width_challenges, ProvedBatch* out, SumcheckError* err);
 
 Fr fr_mul_pow_2(Fr a, size_t k);
+// `inv_l1` (optional): 1 / (current_scalar * point_i), computed by the caller while the device was busy with the round
+// (the one field inversion of the message assembly; it does not depend on the round sums).  Verified before use.
 int32_t gruen_poly_deg_3(const Fr& current_scalar, const Fr& point_i, const Fr& q_constant, const Fr& q_quadratic, const Fr& s0_plus_s1,
-                         UnivariatePoly* out);
-int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr* q_evals, size_t dq, const Fr& s0_plus_s1, UnivariatePoly* out);
+                         UnivariatePoly* out, const Fr* inv_l1 = nullptr);
+int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr* q_evals, size_t dq, const Fr& s0_plus_s1, UnivariatePoly* out,
+                          const Fr* inv_l1 = nullptr);
+Fr inverse_or_given(const Fr& x, const Fr* given);
 void fr_to_bytes_le(const Fr& a, uint8_t out[32]);
 Fr fr_from_challenge_bytes(const uint8_t* b, size_t n);
 Fr fr_from_scalar_challenge_bytes(const uint8_t* b, size_t n);

@@ -343,11 +343,30 @@ class ShardedWorkload:
         if coll is None:
             import torch
             dev = torch.device("cuda", torch.cuda.current_device())
-            try:  # RCCL called natively from the C++ round loop; torch.distributed only carries the rendezvous
-                coll = NativeCollective(ctx, dist, rank, world, dev)
-            except ffi.JoltError as e:
-                if e.status != 6:  # anything but "RCCL not available" is a real failure
-                    raise
+            # RCCL called natively from the C++ round loop; torch.distributed only carries the rendezvous.  All ranks must
+            # agree on the choice: if the native communicator fails anywhere, everybody falls back to torch.distributed.
+            native, err = None, None
+            try:
+                native = NativeCollective(ctx, dist, rank, world, dev)
+            except Exception as e:  # noqa: BLE001 -- reported below, decision taken collectively
+                err = e
+            ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=dev)
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1 and world > 1:  # probe: the native all-gather must agree with torch.distributed's
+                probe = np.arange(8, dtype=np.uint64) + np.uint64(1000 * rank)
+                same = np.array_equal(native.all_gather_u64(probe), Collective(dist, world, dev).all_gather_u64(probe))
+                ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not same:
+                    err = "probe all-gather mismatch"
+            if int(ok.item()) == 1:
+                coll = native
+            else:
+                if native is not None:
+                    native.close()
+                import sys
+                print(f"[jolt_amd] rank {rank}: native RCCL communicator unavailable ({err}); using torch.distributed", file=sys.stderr)
                 coll = Collective(dist, world, dev)
         self.coll = coll
         spec = build_sharded_spec(n_local, rank, world, seed)

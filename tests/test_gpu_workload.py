@@ -7,6 +7,7 @@ import pytest
 
 from jolt_amd import ffi
 from jolt_amd.workload import DeviceWorkload
+from util import rand_challenge
 from workload_oracle import OracleWorkload
 
 pytestmark = pytest.mark.gpu
@@ -28,3 +29,37 @@ def test_catalogue_stage_transcripts_match_oracle(n_vars):
         st = dev.members_spec[i].stage
         assert np.array_equal(c, want[st]["claims"][dev.stages[st].index(i)])
     ctx.close()
+
+
+def test_persistent_round_engine_matches_per_round_kernels(monkeypatch):
+    """JOLT_ENGINE=1: the late rounds of every stage run inside the persistent round-engine kernel (engine_kernel.cuh:
+    fused binds, mailbox handshake per challenge).  All 11 relations, borrowed tables, expression / split-eq product /
+    uniform members: transcripts must be bit-identical to the per-round kernels', also after a reset, and a caller that
+    walks away mid-batch must not wedge the stream."""
+    from jolt_amd.workload import DeviceWorkload
+    base_ctx = ffi.Context(0)
+    want = DeviceWorkload(base_ctx, 12).prove(label=77)
+    base_ctx.close()
+    for pairs in ("64", "1024"):
+        monkeypatch.setenv("JOLT_ENGINE", "1")
+        monkeypatch.setenv("JOLT_ENGINE_PAIRS", pairs)
+        ctx = ffi.Context(0)  # the policy is read when the context first needs the engine
+        wl = DeviceWorkload(ctx, 12)
+        for rep in range(2):
+            got = wl.prove(label=77)
+            for stage in want:
+                for k in ("polys", "challenges", "member_claims", "final_claim"):
+                    assert np.array_equal(got[stage][k], want[stage][k]), (pairs, rep, stage, k)
+        # abandon a batch while the engine is waiting for its next challenge: the next call quiesces it
+        ms = [wl.members[i] for i in wl.stages[min(wl.stages)]]
+        sums = ctx.round_group_prove(ms, [None] * len(ms))
+        r = rand_challenge(5)
+        for _ in range(9):  # 2^12 -> 2^3 entries: the engine has taken over for both thresholds and is mid-batch
+            sums = ctx.round_group_prove(ms, [r] * len(ms))
+        assert all(len(s) for s in sums)
+        for m in ms:
+            m.reset()
+        again = wl.prove(label=77)
+        for stage in want:
+            assert np.array_equal(again[stage]["polys"], want[stage]["polys"]), (pairs, stage)
+        ctx.close()
