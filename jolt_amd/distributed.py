@@ -133,6 +133,18 @@ def tail_log_for(n_local, world, max_tail_entries=8192):
     return max(0, min(n_local, k))
 
 
+def msm_sharded(coll, local_point):
+    """Term-range sharded G1 MSM: every rank runs the full bucket method over its own slice of
+    the scalars against its resident slice of the bases (jolt_msm_g1_table) and passes the partial sum here; ONE
+    all-gather of `world` Jacobian points (96 bytes each) and world - 1 point additions give the total on every rank.
+    Same POINT as the single-process MSM (the Jacobian representative is free)."""
+    pts = coll.all_gather_u64(np.ascontiguousarray(local_point, dtype=np.uint64).reshape(-1)).reshape(-1, 12)
+    acc = pts[0].copy()
+    for r in range(1, pts.shape[0]):
+        acc = ffi.host_g1_add(acc, pts[r])
+    return acc
+
+
 # wall-clock split of prove_batch_sharded, accumulated over calls (seconds); bench.py reports it per step
 TIMINGS = {"sharded_rounds": 0.0, "hand_over": 0.0, "tail_rounds": 0.0, "setup_and_end": 0.0}
 

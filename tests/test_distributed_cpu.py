@@ -102,3 +102,37 @@ def test_sharded_prove_batch_matches_single_process(world, tail_log):
         mp.spawn(_worker, args=(world, port, tmp, tail_log), nprocs=world, join=True)
         for r in range(world):
             assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"
+
+
+def _msm_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from jolt_amd import distributed as D
+    from util import rand_fr
+    n = 96
+    srs = O.srs_setup_from_secret(rand_fr(1, 50)[0], n)
+    scalars = rand_fr(n, 51)
+    scalars[5] = 0
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    local = O.g1_msm_pippenger(srs[lo:hi], scalars[lo:hi])  # the rank's full Pippenger over its term range (oracle on CPU ranks)
+    got = D.msm_sharded(D.Collective(dist, world, None), local)
+    want = O.g1_msm_pippenger(srs, scalars)
+    ok = O.g1_eq(got, want) and O.g1_serialize_compressed(got) == O.g1_serialize_compressed(want)
+    open(os.path.join(tmpdir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_msm_combines_to_the_single_process_point(world):
+    """Term-range sharded MSM: per-rank partial sums, one all-gather of `world` Jacobian points, world-1 additions."""
+    import torch.multiprocessing as mp
+    port = 29700 + os.getpid() % 1000 + world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_msm_worker, args=(world, port, tmp), nprocs=world, join=True)
+        for r in range(world):
+            assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"

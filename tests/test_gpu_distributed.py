@@ -97,6 +97,12 @@ def test_native_rccl_communicator_single_rank():
     src, dst = ctx.upload(big), ctx.alloc(5000)
     coll.all_gather_table(src, 5000, dst)
     assert np.array_equal(dst.download(), big)
+    # term-range sharded MSM through the same communicator (world = 1: the partial sum is the total)
+    import oracle_lib as O
+    srs_host = O.srs_setup_from_secret(rand_fr(1, 60)[0], 300)
+    sc = rand_fr(300, 61)
+    part = ctx.msm(ctx.srs_upload(srs_host), sc)
+    assert O.g1_eq(D.msm_sharded(coll, part), O.g1_msm_pippenger(srs_host, sc))
     outs = []
     for tail_log in (0, 4, 7):
         wl = D.ShardedWorkload(ctx, 7, 0, 1, None, seed=33, coll=coll, tail_log=tail_log, force_gather=True)
@@ -107,3 +113,39 @@ def test_native_rccl_communicator_single_rank():
                 assert np.array_equal(o[stage][k], outs[0][stage][k]), (stage, k)
     coll.close()
     ctx.close()
+
+
+def _msm_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from jolt_amd import distributed as D
+    from jolt_amd import ffi
+    from util import rand_fr
+    n = 4096
+    ctx = ffi.Context(0)
+    beta = rand_fr(1, 70)[0]
+    full = ctx.srs_setup_from_secret(beta, n, O.g1_generator()).download()  # beta^i * G, same on every rank
+    scalars = rand_fr(n, 71)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    part = ctx.msm(ctx.srs_upload(full[lo:hi]), ctx.upload(scalars[lo:hi]))  # device Pippenger over the rank's term range
+    got = D.msm_sharded(D.Collective(dist, world, None), part)
+    # size-independent identity: the commitment to p with bases beta^i G is p(beta) G
+    want = O.g1_scalar_mul(O.g1_generator(), O.kzg_eval_univariate(scalars, beta))
+    ok = O.g1_eq(got, want)
+    open(os.path.join(tmpdir, f"msm{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_device_msm_two_ranks():
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 1000
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_msm_worker, args=(2, port, tmp), nprocs=2, join=True)
+        for r in range(2):
+            assert open(os.path.join(tmp, f"msm{r}.txt")).read() == "ok", f"rank {r}"
