@@ -184,6 +184,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
+    n_onehot = getattr(wl, "n_onehot", 0)
+    onehot_note = f" of which {n_onehot} are one-hot RA selector columns kept as 1-byte hot indices until their fourth bind" if n_onehot else ""
     total_cycles = (1 << args.scale) * world
     out = {
         "metric": "prover trace cycles/sec (sha3-shaped synthetic trace, sumcheck hot path)",
@@ -199,7 +201,7 @@ def main():
         "dtype": "u256 (BN254 Fr, 8x u32 Montgomery limbs; integer, bit-exact)",
         "data": "synthetic",
         "config": {"workload": f"sha3-shaped synthetic trace, T=2^{args.scale} per GPU: stages 2-6b cycle-domain sumchecks "
-                               f"(11 relations, {wl.n_tables} T-sized tables, degree 2-5), bind + round-poly HIP kernels; MSM not in the timed region "
+                               f"(11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5), bind + round-poly HIP kernels; MSM not in the timed region "
                                f"(BASELINE configs[1])",
                    "trace_length_per_gpu": 1 << args.scale, "parallelism": f"hypercube sharded over {world} GPU(s)"},
     }

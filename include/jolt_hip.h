@@ -316,6 +316,23 @@ int32_t jolt_host_batch_flush_binds(jolt_batch *b, jolt_member *const *members, 
 int32_t jolt_host_batch_split_eq_scalar(const jolt_batch *b, size_t member, jolt_fr_t *out);
 int32_t jolt_host_batch_end(jolt_batch *b, jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
                             jolt_fr_t *out_final_claim);
+/* One-hot (Twist/Shout) selector columns as per-cycle hot indices.  Replaces ChunkIndexSource /
+ * LazyFoldedRa (crates/jolt-kernels/src/optimized/lazy_ra.rs:39-268) and the pushforward G tables of the booleanity address
+ * phase (optimized/booleanity.rs:24-31).  indices[p*cycles + j] in [0, k) or 0xFF on a cold cycle; k <= 255. */
+typedef struct jolt_onehot jolt_onehot;
+int32_t jolt_onehot_upload(jolt_ctx *ctx, const uint8_t *indices, size_t n_polys, size_t cycles, uint32_t k, jolt_onehot **out);
+int32_t jolt_onehot_free(jolt_ctx *ctx, jolt_onehot *source);
+/* dense address-folded column: out[j] = scale_table[index(poly, j)], zero on cold cycles (the N x T "direct shape") */
+int32_t jolt_onehot_materialize(jolt_ctx *ctx, const jolt_onehot *source, size_t poly, const jolt_table *scale_table, jolt_table **out);
+/* out[p*k + a] = sum_j weights[j] * [index(p, j) == a]   (G_p = pushforward of the cycle weights to the address domain) */
+int32_t jolt_onehot_pushforward(jolt_ctx *ctx, const jolt_onehot *source, const jolt_table *weights, jolt_table **out);
+/* Member eq(w,j) * sum_v coeffs[v] * prod_{i<F} ra_{vF+i}(j), ra_p(j) = scale_tables[p*k + index(p,j)] (host array n_polys*k), with
+ * the selector columns bound lazily: rounds 0..3 gather through the indices, the fourth bind materialises cycles/16-entry tables
+ * (LazyFoldedRa::bind).  Round sums, binds and final values are those of jolt_member_create_split_eq_uniform over the
+ * materialised columns, bit for bit.  n = log2(cycles) >= 4.  The source must outlive the member. */
+int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, uint32_t V, uint32_t F,
+                                           const jolt_fr_t *coeffs, const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, jolt_member **out);
+
 /* Multi-GPU data path (one process per GPU).  The collectives are RCCL calls on the context's stream;
  * librccl.so.1 is resolved with dlopen at first use (`rccl_path` may name it explicitly, NULL = the copy already mapped into
  * the process / the default search path).  Rank 0 draws the id, the launcher broadcasts its 128 bytes (torch.distributed

@@ -7,6 +7,7 @@
 #include "member.hpp"
 #include "poly_kernels.cuh"
 #include "engine_kernel.cuh"
+#include "onehot_kernels.cuh"
 
 using namespace jolt;
 
@@ -738,6 +739,93 @@ extern "C" int32_t jolt_member_create_split_eq_uniform(jolt_ctx* ctx, jolt_table
     return JOLT_OK;
 }
 
+// eq(w, j) * sum_v c_v * prod_{i<F} ra_{vF+i}(j) with ra_p(j) = scale_tables[p][index(p, j)]: the RA-virtualization summand over
+// lazily bound one-hot selector columns (crates/jolt-kernels/src/optimized/lazy_ra.rs:55-182; consumers
+// optimized/{ram,instruction}_ra_virtualization.rs).  The selector columns are never materialised at T entries: the first four
+// rounds gather through the hot indices, the fourth bind writes them dense at T/16.
+extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F,
+                                                      const jolt_fr_t* coeffs, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
+    if (!ctx || !source || !scale_tables || !coeffs || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
+    if (F < 2 || F > 4 || V < 1 || V > (uint32_t)kMaxGroups || (size_t)V * F > (size_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
+    if (source->n_polys != (size_t)V * F) return JOLT_ERR_SIZE_MISMATCH;
+    if (n < 4 || ((size_t)1 << n) != source->cycles) return JOLT_ERR_SIZE_MISMATCH;  // dense from the fourth bind on
+    const size_t N = source->n_polys, K = source->k;
+    jolt_member* m = new (std::nothrow) jolt_member();
+    if (!m) return JOLT_ERR_OOM;
+    m->ctx = ctx;
+    m->kind = jolt_member::kSplitEqUniform;
+    m->rounds = n;
+    m->len = source->cycles;
+    m->degree = F + 1;
+    m->order = JOLT_ORDER_LOW_TO_HIGH;
+    m->uni_V = V;
+    m->uni_F = F;
+    m->onehot = source;
+    m->lazy_width = 1;
+    int32_t s = JOLT_OK;
+    for (uint32_t v = 0; v < V && s == JOLT_OK; ++v) {
+        Fr c = fr_from_abi(&coeffs[v]);
+        if (!fr_is_canonical(c)) s = JOLT_ERR_INVALID_ARG;
+        m->uni_coeff.push_back(c);
+    }
+    for (size_t i = 0; i < N * K && s == JOLT_OK; ++i)
+        if (!fr_is_canonical(fr_from_abi(&scale_tables[i]))) s = JOLT_ERR_INVALID_ARG;
+    // dense targets of the fourth bind (cycles/16 entries each); until then `len` is bookkeeping only
+    for (size_t p = 0; p < N && s == JOLT_OK; ++p) {
+        jolt_table* t = nullptr;
+        s = jolt_internal_table_new(ctx, source->cycles / 16, &t);
+        if (s == JOLT_OK) { t->len = source->cycles; m->tables.push_back(t); }
+    }
+    if (s == JOLT_OK) {
+        hipError_t e = hipMalloc((void**)&m->d_base, N * K * sizeof(Fr));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[0], N * 16 * K * sizeof(Fr));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[1], N * 16 * K * sizeof(Fr));
+        if (e == hipSuccess) e = hipMemcpyAsync(m->d_base, scale_tables, N * K * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(m->d_branch[0], m->d_base, N * K * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host buffer may be short-lived
+        if (e != hipSuccess) { ctx->last_error = std::string("lazy member: ") + hipGetErrorString(e); s = e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP; }
+    }
+    if (s == JOLT_OK) s = init_split_eq(ctx, m, w, n, scale, nullptr);
+    if (s != JOLT_OK) { jolt_member_destroy(m); return s; }
+    *out = m;
+    return JOLT_OK;
+}
+
+// One LowToHigh bind of a lazily bound member (LazyFoldedRa::bind, lazy_ra.rs:153-182): double the branch tables; at the fourth
+// bind gather every column dense at cycles/16 and leave the lazy state.  Device work only -- member_note_bind keeps the books.
+static int32_t lazy_bind_enqueue(jolt_member* m, const Fr& c) {
+    jolt_ctx* ctx = m->ctx;
+    const jolt_onehot* src = m->onehot;
+    const size_t N = src->n_polys, K = src->k;
+    const uint32_t width = m->lazy_width;
+    const size_t per_poly = (size_t)width * K;
+    const Fr* in = m->d_branch[m->branch_cur];
+    Fr* outb = m->d_branch[1 - m->branch_cur];
+    const size_t work = per_poly * N;
+    hipLaunchKernelGGL(k_onehot_double_branches, dim3((unsigned)((work + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, in, outb, per_poly, N, c,
+                       fr_low_limbs_zero(c) ? 1 : 0);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    m->branch_cur = 1 - m->branch_cur;
+    if (width < 8) {
+        m->lazy_width = width * 2;
+        for (jolt_table* t : m->tables) t->len /= 2;
+        return JOLT_OK;
+    }
+    const uint32_t branches = 16;
+    const size_t new_len = src->cycles / branches;
+    for (size_t base = 0; base < N; base += kMaxBatchTables) {
+        size_t cnt = std::min<size_t>(kMaxBatchTables, N - base);
+        OneHotDense o;
+        for (size_t i = 0; i < (size_t)kMaxBatchTables; ++i) o.out[i] = i < cnt ? m->tables[base + i]->buf[0] : nullptr;
+        hipLaunchKernelGGL(k_onehot_materialize, dim3((unsigned)((new_len + kBlock - 1) / kBlock), (unsigned)cnt), dim3(kBlock), 0, ctx->stream,
+                           (const Fr*)outb, (size_t)branches * K, (const uint8_t*)src->idx, src->cycles, branches, (uint32_t)K, base, o);
+    }
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    for (jolt_table* t : m->tables) { t->cur = 0; t->len = new_len; }
+    m->lazy_width = 0;
+    return JOLT_OK;
+}
+
 static int32_t create_split_eq_product(jolt_ctx* ctx, jolt_table* a, jolt_table* b, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale,
                                        bool borrow, jolt_member** out, const jolt_fr_t* shard_scale = nullptr) {
     if (!ctx || !a || !b || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
@@ -774,6 +862,19 @@ extern "C" int32_t jolt_member_create_split_eq_product_sharded(jolt_ctx* ctx, jo
 extern "C" int32_t jolt_member_reset(jolt_member* m) {
     (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m) return JOLT_ERR_INVALID_ARG;
+    if (m->onehot) {  // lazily bound member: back to the index-encoded state with the unbound scale tables
+        const size_t N = m->onehot->n_polys, K = m->onehot->k;
+        JOLT_HIP_TRY(m->ctx, hipMemcpyAsync(m->d_branch[0], m->d_base, N * K * sizeof(Fr), hipMemcpyDeviceToDevice, m->ctx->stream));
+        m->branch_cur = 0;
+        m->lazy_width = 1;
+        for (jolt_table* t : m->tables) { t->cur = 0; t->len = m->onehot->cycles; }
+        m->len = m->onehot->cycles;
+        m->bound = 0;
+        m->current_scalar = m->initial_scalar;
+        m->e_out_bits = m->out_len;
+        m->e_in_bits = m->in_len;
+        return JOLT_OK;
+    }
     if (!m->borrowed) { m->ctx->last_error = "only members that borrow their tables can be reset"; return JOLT_ERR_UNSUPPORTED; }
     for (jolt_table* t : m->tables) { t->cur = -1; t->len = t->view_len; }
     m->len = m->tables[0]->view_len;
@@ -814,8 +915,13 @@ static int32_t member_note_bind(jolt_member* m, const Fr& c) {
     m->bound += 1;
     return JOLT_OK;
 }
+static int32_t lazy_bind_enqueue(jolt_member* m, const Fr& c);
 static int32_t member_bind(jolt_member* m, const Fr& c) {
     JOLT_TRY(member_note_bind(m, c));
+    if (m->lazy_width) {
+        JOLT_TRY(jolt_internal_engine_quiesce(m->ctx));
+        return lazy_bind_enqueue(m, c);
+    }
     return jolt_internal_bind(m->ctx, m->tables.data(), m->tables.size(), c, m->order);
 }
 
@@ -884,6 +990,8 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
                     t->cur = t->cur < 0 ? 0 : 1 - t->cur;  // the round kernel fills it
                     t->len = half;
                 }
+            } else if (m->lazy_width) {
+                JOLT_TRY(lazy_bind_enqueue(m, *binds[i]));  // index-encoded selector columns: re-scale the branch tables / materialise
             } else {
                 BindGroup* g = nullptr;
                 for (BindGroup& c : bgs) if (c.order == m->order && c.r == *binds[i]) { g = &c; break; }
@@ -1027,6 +1135,21 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         dim3 g(it.grid), b(kBlock);
         Fr* part = ctx->d_partials + it.part_off;
         hipStream_t st = next_stream();
+        if (m->lazy_width) {  // selector columns still index-encoded: gather instead of loading dense pairs
+            LazyArgs la;
+            la.idx = m->onehot->idx;
+            la.branch = m->d_branch[m->branch_cur];
+            la.cycles0 = m->onehot->cycles;
+            la.width = m->lazy_width;
+            la.K = m->onehot->k;
+            la.V = ua.V;
+            for (size_t v = 0; v < (size_t)kMaxGroups; ++v) { la.coeff[v] = ua.coeff[v]; la.coeff_one[v] = ua.coeff_one[v]; }
+            if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy<2>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_lazy<3>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            else hipLaunchKernelGGL(k_split_eq_uniform_lazy<4>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            JOLT_HIP_TRY(ctx, hipGetLastError());
+            continue;
+        }
         if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform<2>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
         else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform<3>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
         else hipLaunchKernelGGL(k_split_eq_uniform<4>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
@@ -1216,7 +1339,7 @@ static int engine_eligible(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* me
     int rounds = -1;
     for (size_t i = 0; i < n; ++i) {
         const jolt_member* m = members[i];
-        if (m->order != JOLT_ORDER_LOW_TO_HIGH) return 0;
+        if (m->order != JOLT_ORDER_LOW_TO_HIGH || m->lazy_width) return 0;
         if ((binds && binds[i] != nullptr) != has_bind) return 0;
         if (has_bind && !(*binds[i] == *binds[0])) return 0;
         size_t len = has_bind ? m->len / 2 : m->len;
@@ -1483,7 +1606,12 @@ extern "C" int32_t jolt_round_group_finish(jolt_ctx* ctx, jolt_member* const* me
         std::vector<jolt_table*> tabs;
         while (j < n && members[j] && binds[j] && fr_from_abi(binds[j]) == b && members[j]->order == members[i]->order) {
             JOLT_TRY(member_note_bind(members[j], b));
-            tabs.insert(tabs.end(), members[j]->tables.begin(), members[j]->tables.end());
+            if (members[j]->lazy_width) {
+                JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+                JOLT_TRY(lazy_bind_enqueue(members[j], b));
+            } else {
+                tabs.insert(tabs.end(), members[j]->tables.begin(), members[j]->tables.end());
+            }
             ++j;
         }
         JOLT_TRY(jolt_internal_bind(ctx, tabs.data(), tabs.size(), b, members[i]->order));
@@ -1568,11 +1696,30 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     TablePtrs tp;
     for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = nullptr;
     tp.p[0] = eq->data();
-    for (size_t k = 0; k < m->tables.size(); ++k) tp.p[1 + k] = m->tables[k]->data();
+    std::vector<jolt_table*> temp;  // index-encoded selector columns: gathered dense for this helper only (setup-time, untimed)
+    if (m->lazy_width) {
+        const jolt_onehot* src = m->onehot;
+        const size_t per_poly = (size_t)m->lazy_width * src->k;
+        for (size_t k = 0; k < m->tables.size(); ++k) {
+            jolt_table* t = nullptr;
+            int32_t st = jolt_internal_table_new(ctx, m->len, &t);
+            if (st != JOLT_OK) { for (jolt_table* x : temp) jolt_table_free(ctx, x); (void)hipFree(dd); jolt_table_free(ctx, eq); return st; }
+            temp.push_back(t);
+            OneHotDense o;
+            for (int i = 0; i < kMaxBatchTables; ++i) o.out[i] = i == 0 ? t->data() : nullptr;
+            hipLaunchKernelGGL(k_onehot_materialize, dim3((unsigned)((m->len + kBlock - 1) / kBlock), 1), dim3(kBlock), 0, ctx->stream,
+                               (const Fr*)m->d_branch[m->branch_cur], per_poly, (const uint8_t*)src->idx, src->cycles, m->lazy_width, src->k, k, o);
+            tp.p[1 + k] = t->data();
+        }
+    } else {
+        for (size_t k = 0; k < m->tables.size(); ++k) tp.p[1 + k] = m->tables[k]->data();
+    }
     hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)dd, tp, m->len, ctx->d_partials);
-    JOLT_HIP_TRY(ctx, hipGetLastError());
-    JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
-    int32_t s = fetch_results(ctx, 1, out);
+    int32_t s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
+    if (s == JOLT_OK) s = reduce_into_results(ctx, grid, 1, 0);
+    if (s == JOLT_OK) s = fetch_results(ctx, 1, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (jolt_table* x : temp) jolt_table_free(ctx, x);
     (void)hipFree(dd);
     jolt_table_free(ctx, eq);
     return s;
@@ -1587,6 +1734,8 @@ extern "C" int32_t jolt_member_destroy(jolt_member* m) {
     for (jolt_table* t : m->e_out_cache) jolt_table_free(ctx, t);
     for (jolt_table* t : m->e_in_cache) jolt_table_free(ctx, t);
     if (m->d_desc) (void)hipFree(m->d_desc);
+    for (int k = 0; k < 2; ++k) if (m->d_branch[k]) (void)hipFree(m->d_branch[k]);
+    if (m->d_base) (void)hipFree(m->d_base);
     delete m;
     return JOLT_OK;
 }

@@ -251,6 +251,7 @@ extern "C" int32_t jolt_round_group_pack_tables(jolt_ctx* ctx, jolt_member* cons
     for (size_t i = 0; i < n; ++i) {
         if (!members[i]) return JOLT_ERR_INVALID_ARG;
         if (members[i]->len != entries) return JOLT_ERR_SIZE_MISMATCH;
+        if (members[i]->lazy_width) return JOLT_ERR_UNSUPPORTED;  // index-encoded columns have no table to pack yet
         total += members[i]->tables.size();
     }
     if (dst->cur < 0 || dst->len < total * entries) return JOLT_ERR_SIZE_MISMATCH;

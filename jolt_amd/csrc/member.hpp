@@ -28,6 +28,15 @@ struct jolt_member {
     // split-eq uniform product: eq * sum_v coeff[v] * prod_{i<F} tables[v*F+i]
     uint32_t uni_V = 0, uni_F = 0;
     std::vector<Fr> uni_coeff;
+    // lazily bound one-hot selector columns (LazyFoldedRa, crates/jolt-kernels/src/optimized/lazy_ra.rs:55-182): until the fourth
+    // bind table p is index-encoded, value(p, j) = sum_{off<width} branch[p][off*K + index(p, j*width + off)]; `tables` then
+    // only carry the bookkeeping length.  The fourth bind materialises them dense at cycles/16 and the member continues as a
+    // plain split-eq uniform member.
+    const struct jolt_onehot* onehot = nullptr;
+    uint32_t lazy_width = 0;  // 0: dense state; 1, 2, 4, 8: index-encoded with that many branches
+    Fr* d_branch[2] = {nullptr, nullptr};  // ping-pong branch tables [poly][width*K] (capacity 16*K per polynomial)
+    int branch_cur = 0;
+    Fr* d_base = nullptr;     // the unbound scale tables [poly][K] (kept for jolt_member_reset)
 };
 
 size_t jolt_internal_member_n_evals(const jolt_member* m);

@@ -1,0 +1,137 @@
+// jolt_amd/csrc/onehot_kernels.cuh -- gathers over hot-index columns (LazyFoldedRa, crates/jolt-kernels/src/optimized/lazy_ra.rs).
+// All of them are lookups + additions: the eq weights of the bound bits are pre-scaled into the branch tables, exactly as the
+// reference does (lazy_ra.rs:17-24), so the per-cycle work has no multiplication and reads 1 byte instead of 32 per entry.
+#pragma once
+#include "onehot.hpp"
+#include "sumcheck_kernels.cuh"
+
+namespace jolt {
+
+// value(p, j) at branch width `width` (lazy_ra.rs:184-209 `gather`):
+//   sum_{off < width} branch[off * K + index(p, j * width + off)]        (cold cycles contribute nothing)
+__device__ __forceinline__ Fr onehot_gather(const Fr* __restrict__ branch, const uint8_t* __restrict__ idx, uint32_t width, uint32_t K, size_t j) {
+    Fr sum = Fr::zero();
+    const uint8_t* p = idx + j * width;
+    for (uint32_t off = 0; off < width; ++off) {
+        uint8_t k = p[off];
+        if (k != kOneHotCold) sum = add(sum, ld_fr(branch + (size_t)off * K + k));
+    }
+    return sum;
+}
+
+// double_branches (lazy_ra.rs:211-231): next = [(1 - c) * table ; c * table], for all polynomials at once.
+// in/out: [poly][width * K] resp. [poly][2 * width * K]
+static __global__ __launch_bounds__(kBlock) void k_onehot_double_branches(const Fr* __restrict__ in, Fr* __restrict__ out, size_t per_poly_in, size_t n_polys, Fr c,
+                                                                         int shifted) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= per_poly_in * n_polys) return;
+    size_t p = i / per_poly_in, e = i - p * per_poly_in;
+    Fr v = ld_fr(in + i);
+    Fr hi;
+    if (shifted) {
+        uint32_t chi[4] = {c.l[4], c.l[5], c.l[6], c.l[7]};
+        hi = mul_shifted(v, chi);
+    } else {
+        hi = mul(v, c);
+    }
+    // (1 - c) * v = v - c * v: the same field element as the reference's one_minus * value (exact arithmetic)
+    st_fr(out + p * 2 * per_poly_in + e, sub(v, hi));
+    st_fr(out + p * 2 * per_poly_in + per_poly_in + e, hi);
+}
+
+// materialize (lazy_ra.rs:233-268): dense[p][j] = gather(branch_p, width, j) for j < cycles / width; blockIdx.y = polynomial
+struct OneHotDense {
+    Fr* out[kMaxBatchTables];
+};
+static __global__ __launch_bounds__(kBlock) void k_onehot_materialize(const Fr* __restrict__ branch, size_t per_poly, const uint8_t* __restrict__ idx, size_t cycles,
+                                                                     uint32_t width, uint32_t K, size_t first_poly, OneHotDense o) {
+    const size_t p = blockIdx.y;
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= cycles / width) return;
+    st_fr(o.out[p] + j, onehot_gather(branch + (first_poly + p) * per_poly, idx + (first_poly + p) * cycles, width, K, j));
+}
+
+// Pushforward tables (optimized/booleanity.rs:24-31): G_p[k] = sum_j w[j] * [index(p, j) == k].  One block accumulates a
+// slice of the cycles into K buckets in LDS (one owner lane per bucket and pass: no atomics on 256-bit values), partial
+// tables are summed by k_onehot_pushforward_reduce.  blockIdx.y = polynomial.
+static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward(const uint8_t* __restrict__ idx, const Fr* __restrict__ w, size_t cycles, uint32_t K,
+                                                                     Fr* __restrict__ partials /* [poly][block][K] */) {
+    extern __shared__ unsigned char smem_raw[];
+    Fr* buckets = reinterpret_cast<Fr*>(smem_raw);  // K entries
+    const size_t p = blockIdx.y;
+    for (uint32_t k = threadIdx.x; k < K; k += kBlock) buckets[k] = Fr::zero();
+    __syncthreads();
+    const uint8_t* col = idx + p * cycles;
+    const size_t per_block = (cycles + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < cycles ? lo + per_block : cycles;
+    // lane k owns bucket k: every lane scans the block's slice in chunks of kBlock cycles staged through LDS indices
+    __shared__ uint8_t s_idx[kBlock];
+    for (size_t base = lo; base < hi; base += kBlock) {
+        size_t j = base + threadIdx.x;
+        s_idx[threadIdx.x] = j < hi ? col[j] : kOneHotCold;
+        __syncthreads();
+        const size_t n = hi - base < (size_t)kBlock ? hi - base : (size_t)kBlock;
+        for (uint32_t k = threadIdx.x; k < K; k += kBlock) {
+            Fr acc = buckets[k];
+            for (size_t t = 0; t < n; ++t)
+                if (s_idx[t] == (uint8_t)k) acc = add(acc, ld_fr(w + base + t));
+            buckets[k] = acc;
+        }
+        __syncthreads();
+    }
+    for (uint32_t k = threadIdx.x; k < K; k += kBlock) st_fr(partials + ((size_t)p * gridDim.x + blockIdx.x) * K + k, buckets[k]);
+}
+static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward_reduce(const Fr* __restrict__ partials, int nblocks, uint32_t K, Fr* __restrict__ out) {
+    const size_t p = blockIdx.y;
+    uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= K) return;
+    Fr s = Fr::zero();
+    for (int b = 0; b < nblocks; ++b) s = add(s, ld_fr(partials + ((size_t)p * nblocks + b) * K + k));
+    st_fr(out + p * K + k, s);
+}
+
+// Round sums of eq(w, j) * sum_v c_v * prod_{i<F} ra_{vF+i}(j) while the selector columns are still index-encoded: the same
+// sums as k_split_eq_uniform<F> over dense tables, with every (lo, hi) pair gathered (lazy_ra.rs:116-149 lo_hi_all).
+struct LazyArgs {
+    const uint8_t* idx;   // [poly][cycles0]
+    const Fr* branch;     // [poly][width * K]
+    size_t cycles0;       // unbound cycle count (row stride of idx)
+    uint32_t width, K;
+    Fr coeff[kMaxGroups];
+    uint32_t coeff_one[kMaxGroups];
+    int V;
+};
+template <int F>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy(LazyArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,
+                                                                         size_t rows, Fr* __restrict__ partials, uint32_t ticket, uint32_t slot, RoundDone rd) {
+    Fr acc[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) acc[t] = Fr::zero();
+    const size_t items = rows * (size_t)a.V;
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    const size_t per_poly = (size_t)a.width * a.K;
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < items; i += stride) {
+        const uint32_t v = (uint32_t)(i / rows);
+        const size_t row = i - (size_t)v * rows;
+        Fr lo[F], hi[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+            const size_t p = (size_t)v * F + k;
+            lo[k] = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row);
+            hi[k] = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row + 1);
+        }
+        Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+        if (!a.coeff_one[v]) w = mul(w, a.coeff[v]);
+        lo[0] = mul(lo[0], w);
+        hi[0] = mul(hi[0], w);
+        Fr q[F];
+        uniform_item<F>(lo, hi, q);
+#pragma unroll
+        for (int t = 0; t < F; ++t) acc[t] = add(acc[t], q[t]);
+    }
+    block_reduce_store<F>(acc, partials);
+    finish_member(partials, F, ticket, slot, rd);
+}
+
+}  // namespace jolt

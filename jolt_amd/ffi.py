@@ -565,6 +565,53 @@ def host_g1_serialize_compressed(p):
     return bytes(out)
 
 
+class OneHot:
+    """Hot indices of N one-hot selector columns (uint8 [n_polys, cycles], 0xFF = cold cycle) resident on the device."""
+
+    def __init__(self, ctx, indices, k):
+        idx = np.ascontiguousarray(indices, dtype=np.uint8)
+        assert idx.ndim == 2
+        self.ctx, self.n_polys, self.cycles, self.k = ctx, idx.shape[0], idx.shape[1], k
+        h = C.c_void_p()
+        _ck(lib().jolt_onehot_upload(ctx.h, idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), C.c_size_t(idx.shape[1]), C.c_uint32(k), C.byref(h)),
+            "jolt_onehot_upload", ctx)
+        self.h = h
+
+    def materialize(self, poly, scale_table):
+        h = C.c_void_p()
+        _ck(lib().jolt_onehot_materialize(self.ctx.h, self.h, C.c_size_t(poly), scale_table.h, C.byref(h)), "jolt_onehot_materialize", self.ctx)
+        return Table(self.ctx, h)
+
+    def pushforward(self, weights):
+        h = C.c_void_p()
+        _ck(lib().jolt_onehot_pushforward(self.ctx.h, self.h, weights.h, C.byref(h)), "jolt_onehot_pushforward", self.ctx)
+        return Table(self.ctx, h)
+
+    def free(self):
+        if self.h:
+            lib().jolt_onehot_free(self.ctx.h, self.h)
+            self.h = None
+
+
+def _member_lazy_ra_uniform(self, source, scale_tables, V, F, coeffs, w, scale=None):
+    """eq(w,.) * sum_v coeffs[v] * prod_{i<F} ra_{vF+i}, ra_p(j) = scale_tables[p][index(p,j)], lazily bound (LazyFoldedRa)."""
+    w = fr(w).reshape(-1, 4)
+    co = np.ascontiguousarray(np.stack([fr(c) for c in coeffs])).reshape(-1, 4)
+    st = np.ascontiguousarray(scale_tables, dtype=np.uint64).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_member_create_lazy_ra_uniform(self.h, source.h, _p(st), C.c_uint32(V), C.c_uint32(F), _p(co), _p(w), C.c_size_t(w.shape[0]),
+                                                 _p(fr(scale)) if scale is not None else None, C.byref(h)), "jolt_member_create_lazy_ra_uniform", self)
+    m = Member(self, h, F + 1, V * F, True, False)
+    m.n_evals = F
+    m.uniform = True
+    m._keepalive = [source]
+    return m
+
+
+Context.member_lazy_ra_uniform = _member_lazy_ra_uniform
+Context.onehot = lambda self, indices, k: OneHot(self, indices, k)
+
+
 def _table_op2(name):
     def f(self, a, b):
         h = C.c_void_p()

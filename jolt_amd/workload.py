@@ -23,7 +23,9 @@ def rand_fr(n, rng):
 
 
 class TableSpec:
-    """kind: 'u64' (witness column, values < 2^bits), 'eq', 'eq1' (eq+1), 'lt' -- derived tables carry their point."""
+    """kind: 'u64' (witness column, values < 2^bits), 'eq', 'eq1' (eq+1), 'lt' -- derived tables carry their point;
+    'onehot': an address-folded one-hot selector column ra(j) = eq(point, .)[data[j]] -- `data` = uint8 hot indices in
+    [0, 2^len(point)) or 0xFF on a cold cycle, `point` = the chunk point (log_k_chunk coordinates)."""
 
     def __init__(self, name, kind, bits=64, point=None, data=None):
         self.name, self.kind, self.bits, self.point, self.data = name, kind, bits, point, data
@@ -53,6 +55,14 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
 
     def derived(name, kind):
         tables[name] = TableSpec(name, kind, point=rand_fr(n_vars, rng))
+        return name
+
+    def onehot(name, cold=0.0, log_k=4):
+        """committed RA polynomial chunk, address-folded: K = 2^log_k = 16 (crates/jolt-prover/src/config.rs:175-186)"""
+        idx = rng.integers(0, 1 << log_k, size=T, dtype=np.uint8)
+        if cold:
+            idx[rng.random(T) < cold] = 0xFF
+        tables[name] = TableSpec(name, "onehot", point=rand_fr(log_k, rng), data=idx)
         return name
 
     def scalar():
@@ -117,13 +127,14 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
     members.append(MemberSpec("ram_hamming_booleanity", 6, 3, t, split_eq=(0, 1, rand_fr(n_vars, rng)),
                               reference="crates/jolt-kernels/src/optimized/ram_hamming_booleanity.rs:111-135"))
     # ---- stage 6b: ram_ra_virtualization  eq(r,j) * prod_{i<d} ra_i                             deg 1+d, 1+d tables
-    t = [derived("s6.eq_rv", "eq")] + [derived(f"s6.ram_ra{i}", "eq") for i in range(d_ram)]
+    #      ra_i(j) = eq(r_chunk_i, chunk_i(j)): one-hot selector columns, ~40 % cold cycles (specs/byte-addressable-memory.md:119)
+    t = [derived("s6.eq_rv", "eq")] + [onehot(f"s6.ram_ra{i}", cold=0.4) for i in range(d_ram)]
     members.append(MemberSpec("ram_ra_virtualization", 6, 1 + d_ram, t,
                               groups=[[(None, [("one", i)]) for i in range(1 + d_ram)]],
                               uniform=(1, d_ram, ["one"]) if 2 <= d_ram <= 4 else None,
                               reference="crates/jolt-kernels/src/reference/ram_ra_virtualization.rs"))
     # ---- stage 6b: instruction_ra_virtualization  eq * sum_v g^v prod_{i<4} ra_{4v+i}            deg 5, 1+32 tables
-    t = [derived("s6.eq_iv", "eq")] + [derived(f"s6.ins_ra{i}", "eq") for i in range(n_instruction_ra)]
+    t = [derived("s6.eq_iv", "eq")] + [onehot(f"s6.ins_ra{i}") for i in range(n_instruction_ra)]
     members.append(MemberSpec("instruction_ra_virtualization", 6, 5, t,
                               groups=[[(None, [(("gpow", 7, v), 0)])] + [(None, [("one", 1 + 4 * v + i)]) for i in range(4)]
                                       for v in range(n_instruction_ra // 4)],
@@ -203,15 +214,28 @@ class DeviceWorkload:
         # eq tables that only feed split-eq uniform members are never materialised on the device
         skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None}
         skip -= {t for ms in self.members_spec for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
+        # one-hot selector columns that only feed uniform members stay index-encoded (1 byte per cycle, LazyFoldedRa)
+        lazy = lambda ms: ms.uniform is not None and n_vars >= 4 and all(self.tables_spec[t].kind == "onehot" for t in ms.tables[1:])
+        skip |= {t for ms in self.members_spec if lazy(ms) for t in ms.tables[1:]}
+        skip -= {t for ms in self.members_spec if not lazy(ms) for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
         for name, spec in self.tables_spec.items():
             if name not in skip:
                 self.tables[name] = self._make_table(spec)
-        self.members, self.stages = [], {}
+        self.members, self.stages, self.sources = [], {}, []
         for ms in self.members_spec:
             if ms.uniform is not None:
                 V, F, csyms = ms.uniform
-                tabs = [self.tables[t] for t in ms.tables[1:]]
-                m = ctx.member_split_eq_uniform(tabs, V, F, [self.resolver.coeff(c) for c in csyms], self.tables_spec[ms.tables[0]].point, borrow=True)
+                coeffs = [self.resolver.coeff(c) for c in csyms]
+                w = self.tables_spec[ms.tables[0]].point
+                if lazy(ms):
+                    specs = [self.tables_spec[t] for t in ms.tables[1:]]
+                    src = ctx.onehot(np.stack([sp.data for sp in specs]), 1 << len(specs[0].point))
+                    scale_tables = np.stack([self._scale_table(sp) for sp in specs])
+                    m = ctx.member_lazy_ra_uniform(src, scale_tables, V, F, coeffs, w)
+                    self.sources.append(src)
+                else:
+                    tabs = [self.tables[t] for t in ms.tables[1:]]
+                    m = ctx.member_split_eq_uniform(tabs, V, F, coeffs, w, borrow=True)
                 self.members.append(m)
                 self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
                 continue
@@ -229,9 +253,25 @@ class DeviceWorkload:
         rng = np.random.default_rng(seed + 1)
         self.batch_coeffs = [rand_fr(1, rng)[0] for _ in self.members]
         self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
+        self.n_onehot = sum(len(ms.tables) - 1 for ms in self.members_spec if lazy(ms))
+
+    def _scale_table(self, spec):
+        """eq(r_chunk, .) over the chunk domain (K entries), built on the device, as host limbs"""
+        t = self.ctx.eq_evals(spec.point)
+        out = t.download()
+        t.free()
+        return out
 
     def _make_table(self, spec):
         c = self.ctx
+        if spec.kind == "onehot":  # dense address-folded column (only when a non-lazy member needs it)
+            src = c.onehot(spec.data.reshape(1, -1), 1 << len(spec.point))
+            st = c.eq_evals(spec.point)
+            out = src.materialize(0, st)
+            c.synchronize()
+            st.free()
+            src.free()
+            return out
         if spec.kind == "u64":
             return c.from_u64(spec.data)
         if spec.kind == "i64":

@@ -644,3 +644,27 @@ def baseline_member_sumcheck(tables, groups, degree, challenges):
                                        _p(foff), _p(consts_a), _p(has_a), _p(ltab_a), _p(lcoef_a), _p(lone_a), C.c_uint32(degree),
                                        _p(ch), C.c_size_t(n_rounds), _p(out))
     return out[:degree]
+
+
+# ---- one-hot selector columns (oracle/onehot.c) ---------------------------------------------------------------------
+def onehot_values(table, width, k_entries, col, cycles):
+    table = np.ascontiguousarray(table, dtype=np.uint64)
+    col = np.ascontiguousarray(col, dtype=np.uint8)
+    out = fr_array(cycles // width)
+    lib().orc_onehot_values(_p(table), C.c_size_t(width), C.c_size_t(k_entries), col.ctypes.data_as(C.c_void_p), C.c_size_t(cycles), _p(out))
+    return out
+
+
+def onehot_double_branches(table, challenge):
+    table = np.ascontiguousarray(table, dtype=np.uint64)
+    out = fr_array(2 * table.shape[0])
+    lib().orc_onehot_double_branches(_p(table), C.c_size_t(table.shape[0]), _p(np.ascontiguousarray(challenge, dtype=np.uint64)), _p(out))
+    return out
+
+
+def onehot_pushforward(col, k_entries, w):
+    col = np.ascontiguousarray(col, dtype=np.uint8)
+    w = np.ascontiguousarray(w, dtype=np.uint64)
+    out = fr_array(k_entries)
+    lib().orc_onehot_pushforward(col.ctypes.data_as(C.c_void_p), C.c_size_t(col.shape[0]), C.c_size_t(k_entries), _p(w), _p(out))
+    return out

@@ -1,0 +1,120 @@
+"""GPU parity for the one-hot (Twist/Shout) path through the C ABI: address-folded materialisation,
+pushforward G tables, and the lazily bound RA-virtualization member (LazyFoldedRa) -- bit-exact against the oracle and against
+the dense split-eq uniform member over the materialised columns (the reference's own parity statement, lazy_ra.rs:26-32)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from jolt_amd import ffi
+from util import rand_challenge, rand_fr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ffi.Context(0)
+    yield c
+    c.close()
+
+
+def make_columns(n_polys, T, K, seed, cold=0.0):
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, K, size=(n_polys, T), dtype=np.uint8)
+    if cold:
+        idx[rng.random((n_polys, T)) < cold] = 0xFF
+    return idx
+
+
+def dense_column(idx_row, table):
+    out = np.zeros((idx_row.shape[0], 4), dtype=np.uint64)
+    hot = idx_row != 0xFF
+    out[hot] = table[idx_row[hot]]
+    return out
+
+
+@pytest.mark.parametrize("K,n_vars,cold", [(16, 10, 0.0), (16, 9, 0.4), (255, 12, 0.1), (3, 4, 0.5)])
+def test_materialize_and_pushforward_match_oracle(ctx, K, n_vars, cold):
+    T, N = 1 << n_vars, 5
+    idx = make_columns(N, T, K, 10 + K, cold)
+    src = ctx.onehot(idx, K)
+    tables = rand_fr(N * K, 20 + K).reshape(N, K, 4)
+    for p in (0, N - 1):
+        got = src.materialize(p, ctx.upload(tables[p])).download()
+        assert np.array_equal(got, dense_column(idx[p], tables[p]))
+        assert np.array_equal(got, O.onehot_values(tables[p], 1, K, idx[p], T))
+    w = rand_fr(T, 30 + K)
+    G = src.pushforward(ctx.upload(w)).download().reshape(N, K, 4)
+    for p in range(N):
+        assert np.array_equal(G[p], O.onehot_pushforward(idx[p], K, w)), p
+    if K < 255:
+        with pytest.raises(ffi.JoltError):
+            ctx.onehot(np.full((1, 16), K, dtype=np.uint8), K)  # hot index outside the scale table
+    src.free()
+
+
+@pytest.mark.parametrize("V,F,K,n_vars,cold", [(1, 2, 16, 6, 0.0), (2, 3, 16, 7, 0.3), (8, 4, 16, 9, 0.0), (1, 4, 255, 13, 0.2), (3, 2, 5, 4, 0.5)])
+def test_lazy_ra_member_equals_dense_uniform_member_and_oracle(ctx, V, F, K, n_vars, cold):
+    """Every round message, bind and final value of the lazily bound member equals (a) the oracle's flat Expr member over the
+    dense eq table and the materialised selector columns and (b) the device's dense split-eq uniform member -- through the
+    index-encoded rounds (widths 1, 2, 4, 8), the materialising fourth bind and the dense rounds after it; then again after
+    a reset."""
+    T, N = 1 << n_vars, V * F
+    idx = make_columns(N, T, K, 50 + K + F, cold)
+    tables = rand_fr(N * K, 60 + F).reshape(N, K, 4)
+    w = rand_fr(n_vars, 70 + F)
+    coeffs = rand_fr(V, 80 + V)
+    coeffs[0] = O.to_mont([1])[0]
+    scale = rand_fr(1, 90)[0] if V == 2 else None
+    dense = [dense_column(idx[p], tables[p]) for p in range(N)]
+    src = ctx.onehot(idx, K)
+    lazy = ctx.member_lazy_ra_uniform(src, tables, V, F, coeffs, w, scale=scale)
+    twin = ctx.member_split_eq_uniform([ctx.upload(t) for t in dense], V, F, coeffs, w, scale=scale)
+    eq = O.eq_evals(w, scale)
+    terms = [(coeffs[v], [0] + [1 + v * F + k for k in range(F)]) for v in range(V)]
+    for rep in range(2):
+        orc = O.Member.expr([eq] + dense, terms, F + 1)
+        claim = orc.input_claim()
+        bind = None
+        for rnd in range(n_vars):
+            want = orc.prove_round(bind, claim)
+            evals, aux = lazy.prove_round(bind, want_aux=True)
+            if rep == 0:
+                t_evals, _ = twin.prove_round(bind, want_aux=True)
+                assert np.array_equal(evals, t_evals), f"round {rnd} vs dense member"
+            got = ffi.host_gruen_poly_from_q(aux[0], aux[1], evals, claim)
+            assert np.array_equal(got, want), f"rep {rep} round {rnd}"
+            bind = rand_challenge(100 + rnd) if rnd % 3 else rand_fr(1, 100 + rnd)[0]  # 125-bit and full-width challenges
+            claim = O.univariate_evaluate(want, bind)
+        orc.finish_rounds(bind)
+        lazy.finish(bind)
+        fv, ofv = lazy.final_values(), orc.final_values()
+        assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])
+        if rep == 0:
+            twin.finish(bind)
+            assert np.array_equal(fv, twin.final_values())
+        lazy.reset()
+
+
+def test_lazy_ra_member_in_a_batch_with_dense_members(ctx):
+    """prove_batch (grouped launches) over a lazy member next to an ordinary expression member: transcript equals the oracle's."""
+    n_vars, V, F, K = 8, 2, 4, 16
+    T, N = 1 << n_vars, V * F
+    idx = make_columns(N, T, K, 501, 0.1)
+    tables = rand_fr(N * K, 502).reshape(N, K, 4)
+    w = rand_fr(n_vars, 503)
+    coeffs = rand_fr(V, 504)
+    dense = [dense_column(idx[p], tables[p]) for p in range(N)]
+    a, b = rand_fr(T, 505), rand_fr(T, 506)
+    one = O.to_mont([1])[0]
+    src = ctx.onehot(idx, K)
+    lazy = ctx.member_lazy_ra_uniform(src, tables, V, F, coeffs, w)
+    flat = ctx.member_expr([ctx.upload(a), ctx.upload(b)], [(one, [0, 1])], 2)
+    terms = [(coeffs[v], [0] + [1 + v * F + k for k in range(F)]) for v in range(V)]
+    orcs = [O.Member.expr([O.eq_evals(w)] + dense, terms, F + 1), O.Member.expr([a, b], [(one, [0, 1])], 2)]
+    claims = [o.input_claim() for o in orcs]
+    cf = list(rand_fr(2, 507))
+    want = O.prove_batch(orcs, claims, cf, [0, 0], n_vars, F + 1, label=9)
+    got = ctx.prove_batch([lazy, flat], claims, cf, [0, 0], n_vars, F + 1, label=9)
+    for k in ("polys", "challenges", "member_claims", "final_claim"):
+        assert np.array_equal(got[k], want[k]), k

@@ -16,6 +16,12 @@ def make_table(spec):
         return O.lt_evals(spec.point)
     if spec.kind == "eq1":
         return O.eq_plus_one_evals(spec.point)[1]
+    if spec.kind == "onehot":  # the dense address-folded column the lazy member never materialises at this size
+        table = O.eq_evals(spec.point)
+        out = np.zeros((spec.data.shape[0], 4), dtype=np.uint64)
+        hot = spec.data != 0xFF
+        out[hot] = table[spec.data[hot]]
+        return out
     raise ValueError(spec.kind)
 
 
