@@ -1205,7 +1205,10 @@ static int32_t round_wait(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
     while (*flag != want) {
         if (++spins > (1ull << 22)) {  // ~ tens of ms: something is off, ask the runtime
             spins = 0;
+            // the round's kernels run on the main stream AND the side streams: all of them must have drained
             hipError_t q = hipStreamQuery(ctx->stream);
+            for (int k = 0; k < 3 && q == hipSuccess; ++k)
+                if (ctx->side[k]) q = hipStreamQuery(ctx->side[k]);
             if (q == hipSuccess) {
                 if (*flag == want) break;
                 ctx->last_error = "batch round finished without publishing its completion flag";

@@ -63,3 +63,17 @@ def test_persistent_round_engine_matches_per_round_kernels(monkeypatch):
         for stage in want:
             assert np.array_equal(again[stage]["polys"], want[stage]["polys"]), (pairs, stage)
         ctx.close()
+
+
+def test_large_trace_waits_for_side_stream_kernels():
+    """T = 2^22 (BASELINE configs[2] scale): a round's kernels run for milliseconds on the side streams while the main stream is
+    already idle; the completion wait must consult every stream before declaring a round lost (regression: 'batch round finished
+    without publishing its completion flag').  No oracle at this size: the run must pass the prover's own round checks and be
+    reproducible bit for bit."""
+    ctx = ffi.Context(0)
+    wl = DeviceWorkload(ctx, 22)
+    a = wl.prove(label=5)
+    b = wl.prove(label=5)
+    for stage in a:
+        assert np.array_equal(a[stage]["polys"], b[stage]["polys"]) and np.array_equal(a[stage]["final_claim"], b[stage]["final_claim"])
+    ctx.close()
