@@ -46,6 +46,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
     if (!ctx) return JOLT_ERR_OOM;
     ctx->device = device_id;
+    if (const char* rp = std::getenv("JOLT_UNIFORM_ROWS_PAIRS")) { if (std::atoll(rp) > 0) ctx->uniform_rows_pairs = (size_t)std::atoll(rp); }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
@@ -768,8 +769,26 @@ extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_
         if (!fr_is_canonical(c)) s = JOLT_ERR_INVALID_ARG;
         m->uni_coeff.push_back(c);
     }
-    for (size_t i = 0; i < N * K && s == JOLT_OK; ++i)
-        if (!fr_is_canonical(fr_from_abi(&scale_tables[i]))) s = JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> host_tables(N * K);
+    for (size_t i = 0; i < N * K && s == JOLT_OK; ++i) {
+        host_tables[i] = fr_from_abi(&scale_tables[i]);
+        if (!fr_is_canonical(host_tables[i])) s = JOLT_ERR_INVALID_ARG;
+    }
+    // fold c_v into the scale table of product v's first factor: the round kernels then need no coefficient multiply; the
+    // reported final values of those columns are multiplied back by 1 / c_v (exact: same canonical value)
+    if (s == JOLT_OK) {
+        bool all_invertible = true;
+        for (uint32_t v = 0; v < V; ++v) all_invertible = all_invertible && !m->uni_coeff[v].is_zero();
+        if (all_invertible) {
+            m->uni_prescaled = true;
+            m->final_unscale.assign(N, Fr::one());
+            for (uint32_t v = 0; v < V; ++v) {
+                if (m->uni_coeff[v] == Fr::one()) continue;
+                for (size_t k = 0; k < K; ++k) host_tables[(size_t)v * F * K + k] = mul(host_tables[(size_t)v * F * K + k], m->uni_coeff[v]);
+                m->final_unscale[(size_t)v * F] = inv(m->uni_coeff[v]);
+            }
+        }
+    }
     // dense targets of the fourth bind (cycles/16 entries each); until then `len` is bookkeeping only
     for (size_t p = 0; p < N && s == JOLT_OK; ++p) {
         jolt_table* t = nullptr;
@@ -780,7 +799,7 @@ extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_
         hipError_t e = hipMalloc((void**)&m->d_base, N * K * sizeof(Fr));
         if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[0], N * 16 * K * sizeof(Fr));
         if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[1], N * 16 * K * sizeof(Fr));
-        if (e == hipSuccess) e = hipMemcpyAsync(m->d_base, scale_tables, N * K * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(m->d_base, host_tables.data(), N * K * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(m->d_branch[0], m->d_base, N * K * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host buffer may be short-lived
         if (e != hipSuccess) { ctx->last_error = std::string("lazy member: ") + hipGetErrorString(e); s = e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP; }
@@ -953,11 +972,12 @@ static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGrou
 // publishes its sums into host-mapped memory (finish_member).
 static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
     constexpr size_t kTailPairs = 4096;
+    const size_t kUniformRowsMajorPairs = ctx->uniform_rows_pairs;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     if (n > (size_t)kGroupTicket) { ctx->last_error = "batch round has too many members"; return JOLT_ERR_UNSUPPORTED; }
     struct Item {
         size_t ne, slot;
-        bool fused = false, tail = false, done = false;
+        bool fused = false, tail = false, done = false, rows_major = false;
         Fr r;                      // challenge of the fused bind
         std::vector<const Fr*> in; // table pointers the round kernel reads
         std::vector<Fr*> out;      // fused: where the bound tables go
@@ -1095,7 +1115,11 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     for (size_t i = 0; i < n; ++i) {
         if (members[i]->kind == jolt_member::kExpr) continue;
         size_t work = members[i]->len / 2;
-        if (members[i]->kind == jolt_member::kSplitEqUniform) work *= members[i]->uni_V;
+        // uniform members: one item per pair (the V products inside) while the pairs alone fill the chip, (v, pair) items below
+        if (members[i]->kind == jolt_member::kSplitEqUniform) {
+            items[i].rows_major = work >= kUniformRowsMajorPairs && members[i]->uni_V > 1;
+            if (!items[i].rows_major) work *= members[i]->uni_V;
+        }
         items[i].grid = sweep_grid(ctx, work);
         items[i].part_off = (uint32_t)part_total;
         part_total += (size_t)items[i].grid * items[i].ne;
@@ -1127,8 +1151,8 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         ua.V = (int)m->uni_V;
         for (size_t k = 0; k < (size_t)kMaxBatchTables; ++k) ua.tabs[k] = k < it.in.size() ? it.in[k] : nullptr;
         for (size_t v = 0; v < (size_t)kMaxGroups; ++v) {
-            ua.coeff[v] = v < m->uni_coeff.size() ? m->uni_coeff[v] : Fr::zero();
-            ua.coeff_one[v] = v < m->uni_coeff.size() && m->uni_coeff[v] == Fr::one() ? 1u : 0u;
+            ua.coeff[v] = v < m->uni_coeff.size() ? (m->uni_prescaled ? Fr::one() : m->uni_coeff[v]) : Fr::zero();
+            ua.coeff_one[v] = v < m->uni_coeff.size() && (m->uni_prescaled || m->uni_coeff[v] == Fr::one()) ? 1u : 0u;
         }
         const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
@@ -1144,9 +1168,20 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             la.K = m->onehot->k;
             la.V = ua.V;
             for (size_t v = 0; v < (size_t)kMaxGroups; ++v) { la.coeff[v] = ua.coeff[v]; la.coeff_one[v] = ua.coeff_one[v]; }
-            if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy<2>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            if (it.rows_major) {
+                if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<2>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+                else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<3>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+                else hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<4>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            } else if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy<2>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
             else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_lazy<3>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
             else hipLaunchKernelGGL(k_split_eq_uniform_lazy<4>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            JOLT_HIP_TRY(ctx, hipGetLastError());
+            continue;
+        }
+        if (it.rows_major) {
+            if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_rows<2>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_rows<3>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            else hipLaunchKernelGGL(k_split_eq_uniform_rows<4>, g, b, 0, st, ua, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
             JOLT_HIP_TRY(ctx, hipGetLastError());
             continue;
         }
@@ -1416,8 +1451,8 @@ static int32_t engine_start(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* m
             M.V = m->kind == jolt_member::kSplitEqUniform ? m->uni_V : 1;
             M.F = m->kind == jolt_member::kSplitEqUniform ? m->uni_F : 2;
             for (uint32_t v = 0; v < M.V && m->kind == jolt_member::kSplitEqUniform; ++v) {
-                M.coeff[v] = m->uni_coeff[v];
-                M.coeff_one[v] = m->uni_coeff[v] == Fr::one() ? 1u : 0u;
+                M.coeff[v] = m->uni_prescaled ? Fr::one() : m->uni_coeff[v];
+                M.coeff_one[v] = (m->uni_prescaled || m->uni_coeff[v] == Fr::one()) ? 1u : 0u;
             }
             // E_out / E_in schedule (member_note_bind's bookkeeping, replayed ahead of time)
             size_t bound = m->bound, in_bits = m->e_in_bits, out_bits = m->e_out_bits;
@@ -1640,6 +1675,8 @@ extern "C" int32_t jolt_member_final_values(jolt_member* m, jolt_fr_t* out, size
     for (size_t i = 0; i < m->tables.size(); ++i)
         JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_results + i, m->tables[i]->data(), sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
     JOLT_TRY(fetch_results(ctx, m->tables.size(), out));
+    for (size_t i = 0; i < m->final_unscale.size(); ++i)
+        if (!(m->final_unscale[i] == Fr::one())) fr_to_abi(&out[i], mul(fr_from_abi(&out[i]), m->final_unscale[i]));
     if (m->kind != jolt_member::kExpr) fr_to_abi(&out[m->tables.size()], m->current_scalar);
     return JOLT_OK;
 }
@@ -1658,7 +1695,15 @@ extern "C" int32_t jolt_round_group_final_values(jolt_ctx* ctx, jolt_member* con
     for (size_t i = 0; i < n; ++i)
         for (jolt_table* t : members[i]->tables)
             JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_results + k++, t->data(), sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    return fetch_results(ctx, total, out);
+    JOLT_TRY(fetch_results(ctx, total, out));
+    k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const jolt_member* m = members[i];
+        for (size_t j = 0; j < m->final_unscale.size(); ++j)
+            if (!(m->final_unscale[j] == Fr::one())) fr_to_abi(&out[k + j], mul(fr_from_abi(&out[k + j]), m->final_unscale[j]));
+        k += m->tables.size();
+    }
+    return JOLT_OK;
 }
 
 extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
@@ -1688,7 +1733,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     for (uint32_t f = 0; f <= md.n_factors; ++f) md.fac_lc_off[f] = f;
     for (uint32_t v = 0; v < V; ++v) {
         uint32_t base = v * (F + 1);
-        Fr c = m->kind == jolt_member::kSplitEqUniform ? m->uni_coeff[v] : Fr::one();
+        Fr c = m->kind == jolt_member::kSplitEqUniform && !m->uni_prescaled ? m->uni_coeff[v] : Fr::one();
         md.lc_tab[base] = 0; md.lc_coeff[base] = c; md.lc_one[base] = c == Fr::one() ? 1u : 0u;  // table 0 = dense eq
         for (uint32_t k = 0; k < F; ++k) { md.lc_tab[base + 1 + k] = 1 + v * F + k; md.lc_one[base + 1 + k] = 1; md.lc_coeff[base + 1 + k] = Fr::one(); }
     }

@@ -48,6 +48,9 @@ struct jolt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // persistent round engine for the late rounds of a batch (engine_kernel.cuh); owned by capi.hip
     struct jolt_engine* engine = nullptr;
+    // uniform split-eq members switch from (product, pair) work items to one item per pair at this many pairs
+    // (JOLT_UNIFORM_ROWS_PAIRS overrides; tests lower it to run the row-major kernels at small sizes)
+    size_t uniform_rows_pairs = (size_t)1 << 16;
 };
 
 // Stop a running round engine (if any) so that other work may use the stream / the members' tables.

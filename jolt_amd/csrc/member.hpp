@@ -36,7 +36,11 @@ struct jolt_member {
     uint32_t lazy_width = 0;  // 0: dense state; 1, 2, 4, 8: index-encoded with that many branches
     Fr* d_branch[2] = {nullptr, nullptr};  // ping-pong branch tables [poly][width*K] (capacity 16*K per polynomial)
     int branch_cur = 0;
-    Fr* d_base = nullptr;     // the unbound scale tables [poly][K] (kept for jolt_member_reset)
+    Fr* d_base = nullptr;     // the unbound scale tables [poly][K] (kept for jolt_member_reset), product coefficients folded in
+    // c_v is pre-scaled into the scale table of product v's first factor (the reference's gamma pre-scaling,
+    // optimized/booleanity.rs:32-38): kernels see coefficient one, the reported final values are multiplied by unscale[table]
+    bool uni_prescaled = false;
+    std::vector<Fr> final_unscale;  // per table, empty = none
 };
 
 size_t jolt_internal_member_n_evals(const jolt_member* m);

@@ -134,4 +134,22 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy(LazyArg
     finish_member(partials, F, ticket, slot, rd);
 }
 
+// row-major form (uniform_rows_body): one item per pair, the V products inside; used while a round has enough pairs to fill the chip
+template <int F>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy_rows(LazyArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,
+                                                                              size_t rows, Fr* __restrict__ partials, uint32_t ticket, uint32_t slot, RoundDone rd) {
+    Fr acc[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) acc[t] = Fr::zero();
+    const size_t per_poly = (size_t)a.width * a.K;
+    auto load = [&](int v, int k, size_t row, Fr& lo, Fr& hi) {
+        const size_t p = (size_t)v * F + k;
+        lo = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row);
+        hi = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row + 1);
+    };
+    uniform_rows_body<F>(load, a.V, a.coeff, a.coeff_one, e_out, e_in, in_bits, rows, acc);
+    block_reduce_store<F>(acc, partials);
+    finish_member(partials, F, ticket, slot, rd);
+}
+
 }  // namespace jolt

@@ -304,6 +304,56 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform(UniformArgs 
     finish_member(partials, F, ticket, slot, rd);
 }
 
+// Row-major form for the big rounds: one work item per pair, the V products inside.  The eq weight w = E_out*E_in is formed
+// once per pair and multiplies the SUM over v of the product evaluations (F multiplies per pair instead of 2V + V), and a
+// coefficient c_v costs two multiplies per product -- none when the caller pre-scaled it into the first factor's table.
+// Per pair: 1 + V*(tree + 2*[c_v != 1]) + F multiplies (V = 8, F = 4: 101, pre-scaled 85, against 112+ for the (v, pair) items of
+// k_split_eq_uniform, which stays the better shape once a round has too few pairs to fill the chip).
+// `load(v, k, row, lo, hi)` yields the pair of factor k of product v.
+template <int F, class Load>
+__device__ __forceinline__ void uniform_rows_body(const Load& load, int V, const Fr* __restrict__ coeff, const uint32_t* __restrict__ coeff_one,
+                                                  const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr (&acc)[F]) {
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
+        Fr s[F];
+#pragma unroll
+        for (int t = 0; t < F; ++t) s[t] = Fr::zero();
+        for (int v = 0; v < V; ++v) {
+            Fr lo[F], hi[F];
+#pragma unroll
+            for (int k = 0; k < F; ++k) load(v, k, row, lo[k], hi[k]);
+            if (!coeff_one[v]) {
+                const Fr c = coeff[v];
+                lo[0] = mul(lo[0], c);
+                hi[0] = mul(hi[0], c);
+            }
+            Fr q[F];
+            uniform_item<F>(lo, hi, q);
+#pragma unroll
+            for (int t = 0; t < F; ++t) s[t] = add(s[t], q[t]);
+        }
+        const Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+#pragma unroll
+        for (int t = 0; t < F; ++t) acc[t] = add(acc[t], mul(s[t], w));
+    }
+}
+template <int F>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_rows(UniformArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,
+                                                                         size_t rows, Fr* __restrict__ partials, uint32_t ticket, uint32_t slot, RoundDone rd) {
+    Fr acc[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) acc[t] = Fr::zero();
+    auto load = [&](int v, int k, size_t row, Fr& lo, Fr& hi) {
+        const Fr* __restrict__ tp = a.tabs[v * F + k];
+        lo = ld_fr(tp + 2 * row);
+        hi = ld_fr(tp + 2 * row + 1);
+    };
+    uniform_rows_body<F>(load, a.V, a.coeff, a.coeff_one, e_out, e_in, in_bits, rows, acc);
+    block_reduce_store<F>(acc, partials);
+    finish_member(partials, F, ticket, slot, rd);
+}
+
 // summand summed over the whole hypercube (member input claim): same descriptor, no pairing
 static __global__ __launch_bounds__(kBlock) void k_member_claim(const MemberDesc* __restrict__ d, TablePtrs tabs, size_t len, Fr* __restrict__ partials) {
     Fr acc[1] = {Fr::zero()};

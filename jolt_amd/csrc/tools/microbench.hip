@@ -51,6 +51,60 @@ __global__ void k_frmul(Fr* out, Fr seed, Fr c, int iters) {
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = add(x, y);
 }
 
+// multiply throughput against occupancy and instruction-level parallelism: CHAINS independent multiply chains per thread,
+// occupancy limited through the dynamic LDS request (blocks per CU = 160 KB / lds bytes)
+template <int CHAINS>
+__global__ __launch_bounds__(256) void k_frmul_ilp(Fr* out, Fr seed, Fr c, int iters) {
+    extern __shared__ unsigned char lds_pad[];
+    Fr x[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; ++k) {
+        x[k] = seed;
+        x[k].l[0] ^= threadIdx.x + blockIdx.x * 977 + k * 131;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < CHAINS; ++k) x[k] = mul(x[k], c);
+    }
+    Fr s = x[0];
+#pragma unroll
+    for (int k = 1; k < CHAINS; ++k) s = add(s, x[k]);
+    if (lds_pad[threadIdx.x] == 77) s.l[0] ^= 1;  // keep the LDS request alive
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// code-size sensitivity: the loop body holds N fully inlined multiplies (~3.7 KB of code each); the instruction cache is 64 KB
+// per CU pair, so bodies beyond ~16 multiplies no longer fit
+template <int N>
+__global__ __launch_bounds__(256) void k_frmul_body(Fr* out, Fr seed, Fr c, int iters) {
+    Fr x = seed, y = c;
+    x.l[0] ^= threadIdx.x + blockIdx.x * 977;
+    y.l[1] ^= threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            x = mul(x, y);
+            y.l[0] ^= k + 1;  // keeps the N multiplies distinct instruction sequences
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = add(x, y);
+}
+__device__ __noinline__ Fr mul_call(const Fr& a, const Fr& b) { return mul(a, b); }
+template <int N>
+__global__ __launch_bounds__(256) void k_frmul_body_call(Fr* out, Fr seed, Fr c, int iters) {
+    Fr x = seed, y = c;
+    x.l[0] ^= threadIdx.x + blockIdx.x * 977;
+    y.l[1] ^= threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            x = mul_call(x, y);
+            y.l[0] ^= k + 1;
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = add(x, y);
+}
+
 // ---- bind variants -----------------------------------------------------------------------------------------
 template <bool SHIFTED>
 __device__ __forceinline__ Fr bind_one(const Fr& lo, const Fr& hi, const Fr& r) {
@@ -155,7 +209,7 @@ int main(int argc, char** argv) {
         printf("copy   grid %5d: %.3f ms  %.2f TB/s (r+w)\n", blocks, ms, 2.0 * n * 32 / ms / 1e9);
     }
     {
-        uint64_t* o; CK(hipMalloc(&o, 256 * 8 * 256 * 8 * sizeof(uint64_t)));
+        uint64_t* o; CK(hipMalloc(&o, (size_t)256 * 32 * 256 * sizeof(Fr)));  // room for the largest grid below (8192 blocks x 256 threads)
         int iters = 4096;
         int blocks = 256 * 8;
         double ms = time_ms(s, 5, [&] { k_mad<<<blocks, 256, 0, s>>>(o, 12345, 67891, iters); });
@@ -171,6 +225,35 @@ int main(int argc, char** argv) {
         printf("Fr mul full:    %.3f ms  %.1f Gmul/s\n", m0, muls / m0 / 1e6);
         printf("Fr mul shifted: %.3f ms  %.1f Gmul/s\n", m1, muls / m1 / 1e6);
         printf("Fr add/sub:     %.3f ms  %.1f Gop/s\n", m2, muls / m2 / 1e6);
+        // occupancy x ILP matrix (waves per SIMD = blocks per CU for 256-thread blocks)
+        for (int wps : {1, 2, 4, 8}) {
+            size_t lds = wps == 8 ? 0 : (size_t)(160 * 1024 / wps) - 1024;
+            int grid = 256 * wps * 4;
+            auto run = [&](auto kern, int chains) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                double ms = time_ms(s, 3, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, fo, r, r, 256); });
+                printf("  waves/SIMD %d chains %d: %.1f Gmul/s\n", wps, chains, (double)grid * 256 * 256 * chains / ms / 1e6);
+            };
+            run(k_frmul_ilp<1>, 1);
+            run(k_frmul_ilp<2>, 2);
+            run(k_frmul_ilp<4>, 4);
+        }
+        {
+            int grid = 256 * 16;
+            auto run = [&](auto kern, int nmul, const char* what) {
+                int iters = 2048 / nmul;
+                double ms = time_ms(s, 3, [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, fo, r, r, iters); });
+                printf("  loop body of %2d %s multiplies: %.1f Gmul/s\n", nmul, what, (double)grid * 256 * iters * nmul / ms / 1e6);
+            };
+            run(k_frmul_body<2>, 2, "inlined");
+            run(k_frmul_body<8>, 8, "inlined");
+            run(k_frmul_body<16>, 16, "inlined");
+            run(k_frmul_body<32>, 32, "inlined");
+            run(k_frmul_body<64>, 64, "inlined");
+            run(k_frmul_body_call<2>, 2, "called ");
+            run(k_frmul_body_call<16>, 16, "called ");
+            run(k_frmul_body_call<64>, 64, "called ");
+        }
         CK(hipFree(o));
     }
     size_t half = n / 2;

@@ -118,3 +118,41 @@ def test_lazy_ra_member_in_a_batch_with_dense_members(ctx):
     got = ctx.prove_batch([lazy, flat], claims, cf, [0, 0], n_vars, F + 1, label=9)
     for k in ("polys", "challenges", "member_claims", "final_claim"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_row_major_uniform_kernels_match_oracle(monkeypatch):
+    """The big-round form of the uniform members (one work item per pair, eq weight applied to the sum over the products,
+    coefficients pre-scaled into the lazy member's scale tables) is selected by size; JOLT_UNIFORM_ROWS_PAIRS=2 forces it at
+    test sizes for both the dense and the lazily bound member, each round checked against the oracle."""
+    monkeypatch.setenv("JOLT_UNIFORM_ROWS_PAIRS", "2")
+    c = ffi.Context(0)
+    try:
+        for V, F, n_vars in ((8, 4, 9), (3, 3, 6), (2, 2, 5)):
+            T, N, K = 1 << n_vars, V * F, 16
+            idx = make_columns(N, T, K, 900 + F, 0.2)
+            tables = rand_fr(N * K, 901 + F).reshape(N, K, 4)
+            w = rand_fr(n_vars, 902 + F)
+            coeffs = rand_fr(V, 903 + V)
+            dense = [dense_column(idx[p], tables[p]) for p in range(N)]
+            src = c.onehot(idx, K)
+            lazy = c.member_lazy_ra_uniform(src, tables, V, F, coeffs, w)
+            twin = c.member_split_eq_uniform([c.upload(t) for t in dense], V, F, coeffs, w)
+            terms = [(coeffs[v], [0] + [1 + v * F + k for k in range(F)]) for v in range(V)]
+            orc = O.Member.expr([O.eq_evals(w)] + dense, terms, F + 1)
+            claim = orc.input_claim()
+            assert np.array_equal(lazy.input_claim(), claim) and np.array_equal(twin.input_claim(), claim)
+            bind = None
+            for rnd in range(n_vars):
+                want = orc.prove_round(bind, claim)
+                for dev in (lazy, twin):
+                    evals, aux = dev.prove_round(bind, want_aux=True)
+                    assert np.array_equal(ffi.host_gruen_poly_from_q(aux[0], aux[1], evals, claim), want), (V, F, rnd)
+                bind = rand_challenge(950 + rnd)
+                claim = O.univariate_evaluate(want, bind)
+            orc.finish_rounds(bind)
+            for dev in (lazy, twin):
+                dev.finish(bind)
+                fv, ofv = dev.final_values(), orc.final_values()
+                assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])
+    finally:
+        c.close()
