@@ -333,6 +333,13 @@ int32_t jolt_onehot_pushforward(jolt_ctx *ctx, const jolt_onehot *source, const 
 int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, uint32_t V, uint32_t F,
                                            const jolt_fr_t *coeffs, const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, jolt_member **out);
 
+/* Booleanity cycle phase over the same lazily bound columns (crates/jolt-kernels/src/optimized/booleanity.rs:436-633):
+ * eq(w,j) * sum_i (H_i(j)^2 - rho[i]*H_i(j)), H_i(j) = scale_tables[i*k + index(i,j)] (the caller passes the gamma^i-pre-scaled
+ * address tables and rho[i] = gamma^i).  prove_round returns (q(0), q(inf)) of the inner quadratic; the cubic is
+ * gruen_poly_deg_3 on the host.  final_values: the bound H_i (the host divides by rho[i], booleanity.rs:652-657) + the eq scalar. */
+int32_t jolt_member_create_lazy_booleanity(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, const jolt_fr_t *rho,
+                                           const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, jolt_member **out);
+
 /* Multi-GPU data path (one process per GPU).  The collectives are RCCL calls on the context's stream;
  * librccl.so.1 is resolved with dlopen at first use (`rccl_path` may name it explicitly, NULL = the copy already mapped into
  * the process / the default search path).  Rank 0 draws the id, the launcher broadcasts its 128 bytes (torch.distributed

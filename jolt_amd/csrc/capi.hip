@@ -744,20 +744,41 @@ extern "C" int32_t jolt_member_create_split_eq_uniform(jolt_ctx* ctx, jolt_table
 // lazily bound one-hot selector columns (crates/jolt-kernels/src/optimized/lazy_ra.rs:55-182; consumers
 // optimized/{ram,instruction}_ra_virtualization.rs).  The selector columns are never materialised at T entries: the first four
 // rounds gather through the hot indices, the fourth bind writes them dense at T/16.
+// shared by the two lazily bound members: `rho` != NULL selects the booleanity summand (then V, F, coeffs are ignored)
+static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F, const jolt_fr_t* coeffs,
+                                  const jolt_fr_t* rho, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out);
+
 extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F,
                                                       const jolt_fr_t* coeffs, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
-    if (!ctx || !source || !scale_tables || !coeffs || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
+    if (!coeffs) return JOLT_ERR_INVALID_ARG;
     if (F < 2 || F > 4 || V < 1 || V > (uint32_t)kMaxGroups || (size_t)V * F > (size_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
-    if (source->n_polys != (size_t)V * F) return JOLT_ERR_SIZE_MISMATCH;
+    if (source && source->n_polys != (size_t)V * F) return JOLT_ERR_SIZE_MISMATCH;
+    return create_lazy_member(ctx, source, scale_tables, V, F, coeffs, nullptr, w, n, scale, out);
+}
+
+// eq(w, j) * sum_i (H_i(j)^2 - rho[i] * H_i(j)), H_i(j) = scale_tables[i][index(i, j)]: the booleanity cycle-phase summand over the
+// gamma-pre-scaled address-folded selector columns (crates/jolt-kernels/src/optimized/booleanity.rs:436-633), bound lazily like
+// the RA-virtualization member.  Two round sums (constant and leading coefficient of the inner quadratic) -> gruen_poly_deg_3.
+extern "C" int32_t jolt_member_create_lazy_booleanity(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, const jolt_fr_t* rho,
+                                                      const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
+    if (!rho) return JOLT_ERR_INVALID_ARG;
+    if (source && source->n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
+    return create_lazy_member(ctx, source, scale_tables, 0, 0, nullptr, rho, w, n, scale, out);
+}
+
+static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F, const jolt_fr_t* coeffs,
+                                  const jolt_fr_t* rho, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
+    if (!ctx || !source || !scale_tables || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
+    const bool booleanity = rho != nullptr;
     if (n < 4 || ((size_t)1 << n) != source->cycles) return JOLT_ERR_SIZE_MISMATCH;  // dense from the fourth bind on
     const size_t N = source->n_polys, K = source->k;
     jolt_member* m = new (std::nothrow) jolt_member();
     if (!m) return JOLT_ERR_OOM;
     m->ctx = ctx;
-    m->kind = jolt_member::kSplitEqUniform;
+    m->kind = booleanity ? jolt_member::kSplitEqBooleanity : jolt_member::kSplitEqUniform;
     m->rounds = n;
     m->len = source->cycles;
-    m->degree = F + 1;
+    m->degree = booleanity ? 3 : F + 1;
     m->order = JOLT_ORDER_LOW_TO_HIGH;
     m->uni_V = V;
     m->uni_F = F;
@@ -769,6 +790,11 @@ extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_
         if (!fr_is_canonical(c)) s = JOLT_ERR_INVALID_ARG;
         m->uni_coeff.push_back(c);
     }
+    for (size_t i = 0; booleanity && i < N && s == JOLT_OK; ++i) {
+        Fr c = fr_from_abi(&rho[i]);
+        if (!fr_is_canonical(c)) s = JOLT_ERR_INVALID_ARG;
+        m->bool_rho.push_back(c);
+    }
     std::vector<Fr> host_tables(N * K);
     for (size_t i = 0; i < N * K && s == JOLT_OK; ++i) {
         host_tables[i] = fr_from_abi(&scale_tables[i]);
@@ -776,7 +802,7 @@ extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_
     }
     // fold c_v into the scale table of product v's first factor: the round kernels then need no coefficient multiply; the
     // reported final values of those columns are multiplied back by 1 / c_v (exact: same canonical value)
-    if (s == JOLT_OK) {
+    if (s == JOLT_OK && !booleanity) {
         bool all_invertible = true;
         for (uint32_t v = 0; v < V; ++v) all_invertible = all_invertible && !m->uni_coeff[v].is_zero();
         if (all_invertible) {
@@ -945,7 +971,7 @@ static int32_t member_bind(jolt_member* m, const Fr& c) {
 }
 
 size_t jolt_internal_member_n_evals(const jolt_member* m) {
-    if (m->kind == jolt_member::kSplitEqProduct) return 2;
+    if (m->kind == jolt_member::kSplitEqProduct || m->kind == jolt_member::kSplitEqBooleanity) return 2;
     if (m->kind == jolt_member::kSplitEqUniform) return m->uni_F;
     return m->skip_one ? m->degree : m->degree + 1;
 }
@@ -1213,6 +1239,32 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     }
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
+        if (m->kind != jolt_member::kSplitEqBooleanity) continue;
+        const Item& it = items[i];
+        BooleanityArgs ba;
+        ba.n = (int)m->tables.size();
+        for (size_t k = 0; k < (size_t)kMaxBatchTables; ++k) {
+            ba.tabs[k] = k < it.in.size() ? it.in[k] : nullptr;
+            ba.rho[k] = k < m->bool_rho.size() ? m->bool_rho[k] : Fr::zero();
+        }
+        ba.idx = m->onehot ? m->onehot->idx : nullptr;
+        ba.branch = m->d_branch[m->branch_cur];
+        ba.cycles0 = m->onehot ? m->onehot->cycles : 0;
+        ba.width = m->lazy_width;
+        ba.K = m->onehot ? m->onehot->k : 0;
+        const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
+        const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
+        hipStream_t bst = next_stream();
+        if (m->lazy_width)
+            hipLaunchKernelGGL(k_split_eq_booleanity<true>, dim3(it.grid), dim3(kBlock), 0, bst, ba, e_out, e_in, (int)m->e_in_bits, m->len / 2,
+                               ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
+        else
+            hipLaunchKernelGGL(k_split_eq_booleanity<false>, dim3(it.grid), dim3(kBlock), 0, bst, ba, e_out, e_in, (int)m->e_in_bits, m->len / 2,
+                               ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    for (size_t i = 0; i < n; ++i) {
+        jolt_member* m = members[i];
         if (m->kind != jolt_member::kSplitEqProduct) continue;
         const Item& it = items[i];
         const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
@@ -1377,7 +1429,7 @@ static int engine_eligible(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* me
     int rounds = -1;
     for (size_t i = 0; i < n; ++i) {
         const jolt_member* m = members[i];
-        if (m->order != JOLT_ORDER_LOW_TO_HIGH || m->lazy_width) return 0;
+        if (m->order != JOLT_ORDER_LOW_TO_HIGH || m->lazy_width || m->kind == jolt_member::kSplitEqBooleanity) return 0;
         if ((binds && binds[i] != nullptr) != has_bind) return 0;
         if (has_bind && !(*binds[i] == *binds[0])) return 0;
         size_t len = has_bind ? m->len / 2 : m->len;
@@ -1720,6 +1772,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
         JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
         return fetch_results(ctx, 1, out);
     }
+    if (m->kind == jolt_member::kSplitEqBooleanity) { ctx->last_error = "input_claim helper: not provided for the booleanity member (its claim is the zero check's)"; return JOLT_ERR_UNSUPPORTED; }
     // split-eq members: sum_x scale * eq(w[..remaining], x) * (product terms) with the dense eq table (claim helper only)
     size_t rem = m->rounds - m->bound;
     jolt_table* eq = nullptr;

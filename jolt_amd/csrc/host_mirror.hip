@@ -200,8 +200,8 @@ bool DeviceMember::next_l1(bool has_bind, const Fr& c, Fr* l1) const {
 }
 
 int32_t DeviceMember::assemble(const Fr* evals, const Fr& previous_claim, UnivariatePoly* out, const Fr* inv_l1) const {
-    if (m->kind == jolt_member::kSplitEqProduct) {
-        // ram_hamming_booleanity.rs:128-135: message = gruen_poly_deg_3(q(0), q(inf), previous_claim)
+    if (m->kind == jolt_member::kSplitEqProduct || m->kind == jolt_member::kSplitEqBooleanity) {
+        // ram_hamming_booleanity.rs:128-135 / booleanity.rs:628-632: message = gruen_poly_deg_3(q(0), q(inf), previous_claim)
         size_t current_index = m->rounds - m->bound;
         return gruen_poly_deg_3(m->current_scalar, m->w[current_index - 1], evals[0], evals[1], previous_claim, out, inv_l1);
     }

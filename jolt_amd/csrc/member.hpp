@@ -5,7 +5,7 @@
 #include "desc.hpp"
 
 struct jolt_member {
-    enum Kind { kExpr = 0, kSplitEqProduct = 1, kSplitEqUniform = 2 };
+    enum Kind { kExpr = 0, kSplitEqProduct = 1, kSplitEqUniform = 2, kSplitEqBooleanity = 3 };
     jolt_ctx* ctx = nullptr;
     int kind = kExpr;
     size_t rounds = 0, bound = 0;
@@ -39,6 +39,8 @@ struct jolt_member {
     Fr* d_base = nullptr;     // the unbound scale tables [poly][K] (kept for jolt_member_reset), product coefficients folded in
     // c_v is pre-scaled into the scale table of product v's first factor (the reference's gamma pre-scaling,
     // optimized/booleanity.rs:32-38): kernels see coefficient one, the reported final values are multiplied by unscale[table]
+    // kSplitEqBooleanity: eq(w,j) * sum_i H_i(j) * (H_i(j) - rho[i]) over the member's columns (two round sums, like the product member)
+    std::vector<Fr> bool_rho;
     bool uni_prescaled = false;
     std::vector<Fr> final_unscale;  // per table, empty = none
 };

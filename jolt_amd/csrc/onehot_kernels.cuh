@@ -134,6 +134,49 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy(LazyArg
     finish_member(partials, F, ticket, slot, rd);
 }
 
+// Booleanity cycle phase (crates/jolt-kernels/src/optimized/booleanity.rs:574-633): inner quadratic
+//   q(X) = sum_rows E(row) * sum_i (H_i(X)^2 - rho_i H_i(X)),   q(0) from H at 0, q(inf) from the pair delta,
+// with H_i the gamma-pre-scaled address-folded selector columns (rho_i = gamma^i), index-encoded (LAZY) or dense.
+struct BooleanityArgs {
+    const Fr* tabs[kMaxBatchTables];  // dense state: column i
+    Fr rho[kMaxBatchTables];
+    int n;
+    // lazy state
+    const uint8_t* idx;
+    const Fr* branch;
+    size_t cycles0;
+    uint32_t width, K;
+};
+template <bool LAZY>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_booleanity(BooleanityArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,
+                                                                       size_t rows, Fr* __restrict__ partials, uint32_t ticket, uint32_t slot, RoundDone rd) {
+    Fr acc[2] = {Fr::zero(), Fr::zero()};
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    const size_t per_poly = (size_t)a.width * a.K;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
+        Fr constant = Fr::zero(), leading = Fr::zero();
+        for (int i = 0; i < a.n; ++i) {
+            Fr h0, h1;
+            if constexpr (LAZY) {
+                h0 = onehot_gather(a.branch + (size_t)i * per_poly, a.idx + (size_t)i * a.cycles0, a.width, a.K, 2 * row);
+                h1 = onehot_gather(a.branch + (size_t)i * per_poly, a.idx + (size_t)i * a.cycles0, a.width, a.K, 2 * row + 1);
+            } else {
+                h0 = ld_fr(a.tabs[i] + 2 * row);
+                h1 = ld_fr(a.tabs[i] + 2 * row + 1);
+            }
+            Fr delta = sub(h1, h0);
+            constant = add(constant, mul(h0, sub(h0, a.rho[i])));
+            leading = add(leading, sqr(delta));
+        }
+        const Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+        acc[0] = add(acc[0], mul(w, constant));
+        acc[1] = add(acc[1], mul(w, leading));
+    }
+    block_reduce_store<2>(acc, partials);
+    finish_member(partials, 2, ticket, slot, rd);
+}
+
 // row-major form (uniform_rows_body): one item per pair, the V products inside; used while a round has enough pairs to fill the chip
 template <int F>
 static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy_rows(LazyArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,

@@ -608,6 +608,21 @@ def _member_lazy_ra_uniform(self, source, scale_tables, V, F, coeffs, w, scale=N
     return m
 
 
+def _member_lazy_booleanity(self, source, scale_tables, rho, w, scale=None):
+    """eq(w,.) * sum_i (H_i^2 - rho_i H_i), H_i(j) = scale_tables[i][index(i,j)] (gamma-pre-scaled), lazily bound; 2 sums per round."""
+    w = fr(w).reshape(-1, 4)
+    st = np.ascontiguousarray(scale_tables, dtype=np.uint64).reshape(-1, 4)
+    rh = np.ascontiguousarray(np.stack([fr(c) for c in rho])).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_member_create_lazy_booleanity(self.h, source.h, _p(st), _p(rh), _p(w), C.c_size_t(w.shape[0]),
+                                                 _p(fr(scale)) if scale is not None else None, C.byref(h)), "jolt_member_create_lazy_booleanity", self)
+    m = Member(self, h, 3, rh.shape[0], True, False)
+    m.n_evals = 2
+    m._keepalive = [source]
+    return m
+
+
+Context.member_lazy_booleanity = _member_lazy_booleanity
 Context.member_lazy_ra_uniform = _member_lazy_ra_uniform
 Context.onehot = lambda self, indices, k: OneHot(self, indices, k)
 

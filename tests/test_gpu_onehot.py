@@ -156,3 +156,55 @@ def test_row_major_uniform_kernels_match_oracle(monkeypatch):
                 assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("N,K,n_vars,cold", [(3, 16, 6, 0.0), (8, 16, 9, 0.3), (40, 16, 7, 0.1), (2, 255, 12, 0.2)])
+def test_lazy_booleanity_member_matches_oracle(ctx, N, K, n_vars, cold):
+    """Booleanity cycle phase eq(w,j) * sum_i (H_i^2 - rho_i H_i) over gamma-pre-scaled, lazily bound selector columns: each round's
+    cubic (gruen_poly_deg_3 of the two device sums) equals the oracle's flat Expr member over the dense eq table and the
+    materialised columns; final values are the bound H_i.  Also inside prove_batch, and again after a reset."""
+    T = 1 << n_vars
+    idx = make_columns(N, T, K, 700 + N, cold)
+    gamma = rand_fr(1, 701)[0]
+    one = O.to_mont([1])[0]
+    rho = [one]
+    for _ in range(N - 1):
+        rho.append(O.fr_mul(rho[-1].reshape(1, 4), gamma.reshape(1, 4))[0])
+    eq_address = rand_fr(K, 702)
+    tables = np.stack([O.fr_mul(eq_address, np.repeat(r.reshape(1, 4), K, axis=0)) for r in rho])  # rho_i * eq_address
+    w = rand_fr(n_vars, 703)
+    scale = rand_fr(1, 704)[0]
+    dense = [dense_column(idx[p], tables[p]) for p in range(N)]
+    neg = lambda x: O.fr_neg(np.asarray(x).reshape(1, 4))[0]
+    # flat terms: eq*H_i*H_i - rho_i * eq*H_i
+    terms = []
+    for i in range(N):
+        terms.append((one, [0, 1 + i, 1 + i]))
+        terms.append((neg(rho[i]), [0, 1 + i]))
+    src = ctx.onehot(idx, K)
+    dev = ctx.member_lazy_booleanity(src, tables, rho, w, scale=scale)
+    eq = O.eq_evals(w, scale)
+    for rep in range(2):
+        orc = O.Member.expr([eq] + dense, terms, 3)
+        claim = orc.input_claim()
+        bind = None
+        for rnd in range(n_vars):
+            want = orc.prove_round(bind, claim)
+            evals, aux = dev.prove_round(bind, want_aux=True)
+            got = ffi.host_gruen_poly_deg_3(aux[0], aux[1], evals[0], evals[1], claim)
+            assert np.array_equal(got, want), f"rep {rep} round {rnd}"
+            bind = rand_challenge(710 + rnd) if rnd % 2 else rand_fr(1, 710 + rnd)[0]
+            claim = O.univariate_evaluate(want, bind)
+        orc.finish_rounds(bind)
+        dev.finish(bind)
+        fv, ofv = dev.final_values(), orc.final_values()
+        assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])
+        dev.reset()
+    # in a batch (grouped launches, message assembly on the host mirror)
+    orc = O.Member.expr([eq] + dense, terms, 3)
+    claim = orc.input_claim()
+    cf = [rand_fr(1, 720)[0]]
+    want = O.prove_batch([orc], [claim], cf, [0], n_vars, 3, label=4)
+    got = ctx.prove_batch([dev], [claim], cf, [0], n_vars, 3, label=4)
+    for k in ("polys", "challenges", "member_claims", "final_claim"):
+        assert np.array_equal(got[k], want[k]), k
