@@ -316,6 +316,11 @@ int32_t jolt_host_batch_flush_binds(jolt_batch *b, jolt_member *const *members, 
 int32_t jolt_host_batch_split_eq_scalar(const jolt_batch *b, size_t member, jolt_fr_t *out);
 int32_t jolt_host_batch_end(jolt_batch *b, jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
                             jolt_fr_t *out_final_claim);
+/* sum_k a[k]*b[k] with ONE deferred Montgomery reduction per block of products: the deferred-reduction accumulator the round
+ * kernels use for sums of products (WideAccumulator, crates/jolt-field/src/bn254/mont.rs:334-602; Accumulator contract
+ * crates/jolt-field/src/algebra.rs:362-433).  Host build of the kernels' code; the value equals the plain field sum. */
+int32_t jolt_host_fr_wide_dot(const jolt_fr_t *a, const jolt_fr_t *b, size_t n, jolt_fr_t *out);
+
 /* One-hot (Twist/Shout) selector columns as per-cycle hot indices.  Replaces ChunkIndexSource /
  * LazyFoldedRa (crates/jolt-kernels/src/optimized/lazy_ra.rs:39-268) and the pushforward G tables of the booleanity address
  * phase (optimized/booleanity.rs:24-31).  indices[p*cycles + j] in [0, k) or 0xFF on a cold cycle; k <= 255. */

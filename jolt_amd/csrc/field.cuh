@@ -237,6 +237,77 @@ JOLT_HD Fp<PR> sqr(const Fp<PR>& a) { return mul(a, a); }
 template <class PR>
 JOLT_HD Fp<PR> mul_shifted(const Fp<PR>& a, const uint32_t chi[4]) { return mont_rows<PR, 4>(a, chi); }
 
+// ---- deferred-reduction accumulator ---------------------------------------------------------------------------------------
+// The device analogue of WideAccumulator / FrSignedProductAccumulator (crates/jolt-field/src/bn254/mont.rs:334-602, trait
+// crates/jolt-field/src/algebra.rs:362-433): sum_k a_k*b_k is accumulated as an UNREDUCED 512-bit integer (fmadd = the 8x8 product
+// rows only, half the multiply-adds of a Montgomery product) and reduced once (one REDC).  Same canonical value as the sum of the
+// reduced products -- deferred reduction is exact mod p.  Headroom: every product is < p^2 < 2^508 and the REDC output is
+// < (0.19 n + 1) p for n products, so `reduce` (four conditional subtractions) is valid for n <= kWideMaxProducts.
+// Measured on gfx950: NOT a win inside the round kernels (the carry ripples of the 17-limb accumulator and its registers cost
+// more than the REDC rows it saves -- v_mad_u64_u32 is cheap next to the carry chains), so the kernels keep plain field sums and
+// this stays the tested restatement of the accumulator contract (jolt_host_fr_wide_dot).
+constexpr int kWideMaxProducts = 20;
+template <class PR>
+struct WideAcc {
+    uint32_t l[17];
+};
+template <class PR>
+JOLT_HD WideAcc<PR> wide_zero() {
+    WideAcc<PR> w;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) w.l[i] = 0;
+    return w;
+}
+template <class PR>
+JOLT_HD void wide_fmadd(WideAcc<PR>& acc, const Fp<PR>& a, const Fp<PR>& b) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = (uint64_t)a.l[j] * b.l[i] + acc.l[i + j];
+        uint32_t c = 0;
+        acc.l[i] = (uint32_t)p[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc.l[i + j] = __builtin_addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c, &c);
+        acc.l[i + 8] = __builtin_addc(acc.l[i + 8], (uint32_t)(p[7] >> 32), c, &c);
+#pragma unroll
+        for (int k = i + 9; k < 17; ++k) acc.l[k] = __builtin_addc(acc.l[k], 0u, c, &c);
+    }
+}
+template <class PR>
+JOLT_HD Fp<PR> wide_reduce(const WideAcc<PR>& acc) {
+    uint32_t t[18];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) t[i] = acc.l[i];
+    t[17] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t m = t[i] * PR::INV;
+        uint64_t q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = (uint64_t)m * (uint32_t)PR::P[j] + t[i + j];
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t[i + j] = __builtin_addc((uint32_t)q[j], (uint32_t)(q[j - 1] >> 32), c, &c);
+        t[i + 8] = __builtin_addc(t[i + 8], (uint32_t)(q[7] >> 32), c, &c);
+#pragma unroll
+        for (int k = i + 9; k < 18; ++k) t[k] = __builtin_addc(t[k], 0u, c, &c);
+    }
+    Fp<PR> r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = t[8 + i];
+    uint32_t top = t[16];  // bits above 2^256 of the REDC output (t[17] stays zero within the documented headroom)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        Fp<PR> d;
+        const uint32_t borrow = sub_p(d, r);
+        const bool take = top != 0 || borrow == 0;
+        r = select(take, d, r);
+        top = take ? top - borrow : top;
+    }
+    return r;
+}
+
 // Montgomery form -> canonical integer (REDC of the bare limbs) and back
 template <class PR>
 JOLT_HD Fp<PR> from_mont(const Fp<PR>& a) {

@@ -505,3 +505,26 @@ extern "C" int32_t jolt_host_prove_batch(jolt_ctx* ctx, jolt_member* const* memb
     fr_to_abi(out_final_claim, proved.final_claim);
     return JOLT_OK;
 }
+
+// sum_k a[k]*b[k] through the deferred-reduction accumulator of field.cuh (wide_fmadd / wide_reduce), flushed every
+// kWideMaxProducts products: the host build of the same code the kernels use (algebra.rs:362-433 Accumulator contract).
+extern "C" int32_t jolt_host_fr_wide_dot(const jolt_fr_t* a, const jolt_fr_t* b, size_t n, jolt_fr_t* out) {
+    if ((!a || !b) && n) return JOLT_ERR_INVALID_ARG;
+    if (!out) return JOLT_ERR_INVALID_ARG;
+    Fr total = Fr::zero();
+    jolt::WideAcc<jolt::FrParams> acc = jolt::wide_zero<jolt::FrParams>();
+    int pending = 0;
+    for (size_t k = 0; k < n; ++k) {
+        Fr x = fr_from_abi(&a[k]), y = fr_from_abi(&b[k]);
+        if (!fr_is_canonical(x) || !fr_is_canonical(y)) return JOLT_ERR_INVALID_ARG;
+        jolt::wide_fmadd(acc, x, y);
+        if (++pending == jolt::kWideMaxProducts) {
+            total = add(total, jolt::wide_reduce(acc));
+            acc = jolt::wide_zero<jolt::FrParams>();
+            pending = 0;
+        }
+    }
+    if (pending) total = add(total, jolt::wide_reduce(acc));
+    fr_to_abi(out, total);
+    return JOLT_OK;
+}

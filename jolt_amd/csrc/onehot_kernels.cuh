@@ -155,7 +155,7 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_booleanity(Booleanit
     const size_t per_poly = (size_t)a.width * a.K;
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
-        Fr constant = Fr::zero(), leading = Fr::zero();
+        Fr constant = Fr::zero(), leading = Fr::zero();  // plain field sums: the reference's deferred-reduction lanes give the same values
         for (int i = 0; i < a.n; ++i) {
             Fr h0, h1;
             if constexpr (LAZY) {

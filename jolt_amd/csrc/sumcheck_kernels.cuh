@@ -316,6 +316,8 @@ __device__ __forceinline__ void uniform_rows_body(const Load& load, int V, const
     const size_t mask = ((size_t)1 << in_bits) - 1;
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
+        // (Summing the V products in deferred-reduction accumulators -- field.cuh WideAcc -- was measured SLOWER here: 1335 vs
+        // 1062 us for round 0 at T = 2^20; the 17-limb carry ripples and 132 VGPRs cost more than the saved REDC rows.)
         Fr s[F];
 #pragma unroll
         for (int t = 0; t < F; ++t) s[t] = Fr::zero();

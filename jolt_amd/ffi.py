@@ -389,6 +389,16 @@ def host_fr_binop(name, a, b):
 
 
 def host_fr_mul(a, b): return host_fr_binop("jolt_host_fr_mul", a, b)
+
+
+def host_fr_wide_dot(a, b):
+    """sum_k a[k]*b[k] through the deferred-reduction accumulator (one REDC per block of products)"""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    o = fr_array(1)
+    _ck(lib().jolt_host_fr_wide_dot(_p(a), _p(b), C.c_size_t(a.shape[0]), _p(o)), "jolt_host_fr_wide_dot")
+    return o[0]
+
 def host_fr_add(a, b): return host_fr_binop("jolt_host_fr_add", a, b)
 def host_fr_sub(a, b): return host_fr_binop("jolt_host_fr_sub", a, b)
 def host_fr_mul_shifted(a, c): return host_fr_binop("jolt_host_fr_mul_shifted", a, c)

@@ -101,3 +101,28 @@ def test_host_g1_ops_match_oracle():
             assert ffi.host_g1_eq(got, want)
             assert ffi.host_g1_serialize_compressed(got) == O.g1_serialize_compressed(want)
     assert not ffi.host_g1_eq(pts[0], pts[1])
+
+
+def test_deferred_reduction_accumulator_equals_plain_field_sum():
+    """wide_fmadd / wide_reduce (the kernels' WideAccumulator analogue, host build): sum a_k*b_k with one REDC per block equals the
+    sum of the reduced products and the oracle's restatement of the reference accumulator, including maximal operands
+    (p-1)*(p-1) repeated up to the documented headroom and lengths around the flush boundary."""
+    pm1 = O.to_mont([O.R_MOD - 1])[0]
+    for n in (0, 1, 2, 7, 19, 20, 21, 40, 45):
+        a, b = rand_fr(n, 600 + n), rand_fr(n, 700 + n)
+        if n >= 2:
+            a[0], b[0] = pm1, pm1
+            a[n - 1], b[n - 1] = pm1, O.to_mont([1])[0]
+        want = np.zeros((1, 4), dtype=np.uint64)
+        if n:
+            for row in O.fr_mul(a, b):
+                want = O.fr_add(want, row.reshape(1, 4))
+        assert np.array_equal(ffi.host_fr_wide_dot(a, b), want[0]), n
+    worst = np.repeat(pm1.reshape(1, 4), 20, axis=0)  # 20 maximal products in one block: the headroom bound
+    want = np.zeros((1, 4), dtype=np.uint64)
+    for row in O.fr_mul(worst, worst):
+        want = O.fr_add(want, row.reshape(1, 4))
+    assert np.array_equal(ffi.host_fr_wide_dot(worst, worst), want[0])
+    if hasattr(O, "wide_accumulate"):
+        a, b = rand_fr(33, 800), rand_fr(33, 801)
+        assert np.array_equal(ffi.host_fr_wide_dot(a, b), O.wide_accumulate(a, b))
