@@ -338,6 +338,12 @@ int32_t jolt_onehot_pushforward(jolt_ctx *ctx, const jolt_onehot *source, const 
 int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, uint32_t V, uint32_t F,
                                            const jolt_fr_t *coeffs, const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, jolt_member **out);
 
+/* One shard of a hypercube-sharded batch: the source holds this rank's block of cycles, w its n local coordinates, shard_scale =
+ * eq(w_hi, rank) (as jolt_member_create_split_eq_product_sharded).  After the fourth bind the tables (what
+ * jolt_round_group_pack_tables hands over) carry coeffs[v] folded into the first factor of product v. */
+int32_t jolt_member_create_lazy_ra_uniform_sharded(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, uint32_t V, uint32_t F,
+                                                   const jolt_fr_t *coeffs, const jolt_fr_t *w, size_t n, const jolt_fr_t *scale,
+                                                   const jolt_fr_t *shard_scale, jolt_member **out);
 /* Booleanity cycle phase over the same lazily bound columns (crates/jolt-kernels/src/optimized/booleanity.rs:436-633):
  * eq(w,j) * sum_i (H_i(j)^2 - rho[i]*H_i(j)), H_i(j) = scale_tables[i*k + index(i,j)] (the caller passes the gamma^i-pre-scaled
  * address tables and rho[i] = gamma^i).  prove_round returns (q(0), q(inf)) of the inner quadratic; the cubic is

@@ -746,14 +746,24 @@ extern "C" int32_t jolt_member_create_split_eq_uniform(jolt_ctx* ctx, jolt_table
 // rounds gather through the hot indices, the fourth bind writes them dense at T/16.
 // shared by the two lazily bound members: `rho` != NULL selects the booleanity summand (then V, F, coeffs are ignored)
 static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F, const jolt_fr_t* coeffs,
-                                  const jolt_fr_t* rho, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out);
+                                  const jolt_fr_t* rho, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale, jolt_member** out);
 
 extern "C" int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F,
                                                       const jolt_fr_t* coeffs, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
     if (!coeffs) return JOLT_ERR_INVALID_ARG;
     if (F < 2 || F > 4 || V < 1 || V > (uint32_t)kMaxGroups || (size_t)V * F > (size_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
     if (source && source->n_polys != (size_t)V * F) return JOLT_ERR_SIZE_MISMATCH;
-    return create_lazy_member(ctx, source, scale_tables, V, F, coeffs, nullptr, w, n, scale, out);
+    return create_lazy_member(ctx, source, scale_tables, V, F, coeffs, nullptr, w, n, scale, nullptr, out);
+}
+// One shard of a hypercube-sharded batch: `source` holds this rank's block of cycles, w its n LOCAL
+// coordinates, shard_scale = eq(w_hi, rank) multiplies E_out -- as jolt_member_create_split_eq_product_sharded.
+extern "C" int32_t jolt_member_create_lazy_ra_uniform_sharded(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F,
+                                                              const jolt_fr_t* coeffs, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale,
+                                                              const jolt_fr_t* shard_scale, jolt_member** out) {
+    if (!coeffs) return JOLT_ERR_INVALID_ARG;
+    if (F < 2 || F > 4 || V < 1 || V > (uint32_t)kMaxGroups || (size_t)V * F > (size_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
+    if (source && source->n_polys != (size_t)V * F) return JOLT_ERR_SIZE_MISMATCH;
+    return create_lazy_member(ctx, source, scale_tables, V, F, coeffs, nullptr, w, n, scale, shard_scale, out);
 }
 
 // eq(w, j) * sum_i (H_i(j)^2 - rho[i] * H_i(j)), H_i(j) = scale_tables[i][index(i, j)]: the booleanity cycle-phase summand over the
@@ -763,11 +773,11 @@ extern "C" int32_t jolt_member_create_lazy_booleanity(jolt_ctx* ctx, const jolt_
                                                       const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
     if (!rho) return JOLT_ERR_INVALID_ARG;
     if (source && source->n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
-    return create_lazy_member(ctx, source, scale_tables, 0, 0, nullptr, rho, w, n, scale, out);
+    return create_lazy_member(ctx, source, scale_tables, 0, 0, nullptr, rho, w, n, scale, nullptr, out);
 }
 
 static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, const jolt_fr_t* scale_tables, uint32_t V, uint32_t F, const jolt_fr_t* coeffs,
-                                  const jolt_fr_t* rho, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, jolt_member** out) {
+                                  const jolt_fr_t* rho, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale, jolt_member** out) {
     if (!ctx || !source || !scale_tables || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
     const bool booleanity = rho != nullptr;
     if (n < 4 || ((size_t)1 << n) != source->cycles) return JOLT_ERR_SIZE_MISMATCH;  // dense from the fourth bind on
@@ -830,7 +840,7 @@ static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, cons
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host buffer may be short-lived
         if (e != hipSuccess) { ctx->last_error = std::string("lazy member: ") + hipGetErrorString(e); s = e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP; }
     }
-    if (s == JOLT_OK) s = init_split_eq(ctx, m, w, n, scale, nullptr);
+    if (s == JOLT_OK) s = init_split_eq(ctx, m, w, n, scale, shard_scale);
     if (s != JOLT_OK) { jolt_member_destroy(m); return s; }
     *out = m;
     return JOLT_OK;

@@ -329,6 +329,8 @@ def build_sharded_spec(n_local, rank, world, seed=2026):
     for name, spec in tables_spec.items():
         if spec.kind in ("u64", "i64"):
             tables[name] = {"kind": spec.kind, "data": spec.data}
+        elif spec.kind == "onehot":  # hot indices are witness data (seeded per rank); the chunk point is global
+            tables[name] = {"kind": "onehot", "data": spec.data, "point": W.rand_fr(len(spec.point), g_rng)}
         else:
             tables[name] = {"kind": "eqblock", "point": W.rand_fr(n_total, g_rng)}
     split_points = {k: W.rand_fr(n_total, g_rng) for k, ms in enumerate(members_spec) if ms.split_eq is not None}
@@ -389,8 +391,22 @@ class ShardedWorkload:
         self.tables = {}
         skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None}
         skip -= {t for ms in self.members_spec for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
+        # one-hot selector columns of uniform members stay index-encoded on every rank (lazily bound members, as on one GPU)
+        # (only when the fourth bind -- the one that writes them dense -- comes before the hand-over to the tail)
+        lazy = lambda ms: (ms.uniform is not None and n_local - self.tail_log >= 4
+                           and all(spec["tables"][t]["kind"] == "onehot" for t in ms.tables[1:]))
+        skip |= {t for ms in self.members_spec if lazy(ms) for t in ms.tables[1:]}
+        self.sources = []
         for name, t in spec["tables"].items():
             if name in skip:
+                continue
+            if t["kind"] == "onehot":
+                src = ctx.onehot(t["data"].reshape(1, -1), 1 << len(t["point"]))
+                st = ctx.eq_evals(t["point"])
+                self.tables[name] = src.materialize(0, st)
+                ctx.synchronize()
+                st.free()
+                src.free()
                 continue
             if t["kind"] == "u64":
                 self.tables[name] = ctx.from_u64(t["data"])
@@ -412,8 +428,22 @@ class ShardedWorkload:
                 V, F, csyms = ms.uniform
                 w = spec["tables"][ms.tables[0]]["point"]  # the eq leaf's global point
                 coeffs = [self.resolver.coeff(c) for c in csyms]
-                m = ctx.member_split_eq_uniform(tabs[1:], V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w), borrow=True)
-                m._uniform = (V, F, coeffs)
+                if lazy(ms):
+                    specs = [spec["tables"][t] for t in ms.tables[1:]]
+                    src = ctx.onehot(np.stack([sp["data"] for sp in specs]), 1 << len(specs[0]["point"]))
+                    scale_tables = []
+                    for sp in specs:
+                        st = ctx.eq_evals(sp["point"])
+                        scale_tables.append(st.download())
+                        st.free()
+                    m = ctx.member_lazy_ra_uniform(src, np.stack(scale_tables), V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w))
+                    self.sources.append(src)
+                    # the tables this member hands over to the tail carry c_v folded into the first factor of product v
+                    m._uniform = (V, F, [one] * V)
+                    m._lazy = (src, np.stack(scale_tables), coeffs)
+                else:
+                    m = ctx.member_split_eq_uniform(tabs[1:], V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w), borrow=True)
+                    m._uniform = (V, F, coeffs)
                 self.infos.append(MemberInfo(KIND_SPLIT_EQ_UNIFORM, F + 1, self.n_total, V * F, w=w))
                 self.members.append(m)
                 self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
@@ -464,9 +494,20 @@ class ShardedWorkload:
             return m.input_claim()
         one = ffi.host_fr_from_u64(1)
         eq = self.ctx.eq_evals_aligned_block(self.infos[i].w, self.rank << self.n_local, 1 << self.n_local)
+        temp = []
         if ms.uniform is not None:
             V, F, coeffs = m._uniform
-            tabs = [eq] + [self.tables[t] for t in ms.tables[1:]]
+            if getattr(m, "_lazy", None) is not None:  # index-encoded columns: gathered dense for this setup-time helper only
+                src, scale_tables, coeffs = m._lazy
+                for p in range(V * F):
+                    st = self.ctx.upload(scale_tables[p])
+                    temp.append(src.materialize(p, st))
+                    self.ctx.synchronize()
+                    st.free()
+                cols = temp
+            else:
+                cols = [self.tables[t] for t in ms.tables[1:]]
+            tabs = [eq] + cols
             groups = [[(None, [(coeffs[v], 0)])] + [(None, [(one, 1 + v * F + k)]) for k in range(F)] for v in range(V)]
             tmp = self.ctx.member_lc(tabs, groups, F + 1, borrow=True)
         else:
@@ -476,6 +517,8 @@ class ShardedWorkload:
         c = tmp.input_claim()
         tmp.destroy()
         eq.free()
+        for t in temp:
+            t.free()
         return c
 
     def _tail_backend(self, stage, idxs, coll, scalars):

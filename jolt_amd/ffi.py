@@ -603,14 +603,19 @@ class OneHot:
             self.h = None
 
 
-def _member_lazy_ra_uniform(self, source, scale_tables, V, F, coeffs, w, scale=None):
+def _member_lazy_ra_uniform(self, source, scale_tables, V, F, coeffs, w, scale=None, shard_scale=None):
     """eq(w,.) * sum_v coeffs[v] * prod_{i<F} ra_{vF+i}, ra_p(j) = scale_tables[p][index(p,j)], lazily bound (LazyFoldedRa)."""
     w = fr(w).reshape(-1, 4)
     co = np.ascontiguousarray(np.stack([fr(c) for c in coeffs])).reshape(-1, 4)
     st = np.ascontiguousarray(scale_tables, dtype=np.uint64).reshape(-1, 4)
     h = C.c_void_p()
-    _ck(lib().jolt_member_create_lazy_ra_uniform(self.h, source.h, _p(st), C.c_uint32(V), C.c_uint32(F), _p(co), _p(w), C.c_size_t(w.shape[0]),
-                                                 _p(fr(scale)) if scale is not None else None, C.byref(h)), "jolt_member_create_lazy_ra_uniform", self)
+    if shard_scale is not None:
+        _ck(lib().jolt_member_create_lazy_ra_uniform_sharded(self.h, source.h, _p(st), C.c_uint32(V), C.c_uint32(F), _p(co), _p(w), C.c_size_t(w.shape[0]),
+                                                             _p(fr(scale)) if scale is not None else None, _p(fr(shard_scale)), C.byref(h)),
+            "jolt_member_create_lazy_ra_uniform_sharded", self)
+    else:
+        _ck(lib().jolt_member_create_lazy_ra_uniform(self.h, source.h, _p(st), C.c_uint32(V), C.c_uint32(F), _p(co), _p(w), C.c_size_t(w.shape[0]),
+                                                     _p(fr(scale)) if scale is not None else None, C.byref(h)), "jolt_member_create_lazy_ra_uniform", self)
     m = Member(self, h, F + 1, V * F, True, False)
     m.n_evals = F
     m.uniform = True

@@ -56,6 +56,13 @@ def test_sharded_device_workload_matches_global_oracle(tail_log):
     for name, t in specs[0]["tables"].items():
         if t["kind"] == "eqblock":
             tables[name] = O.eq_evals(t["point"])
+        elif t["kind"] == "onehot":  # address-folded selector column: eq(chunk point, .)[hot index], zero on cold cycles
+            scale_table = O.eq_evals(t["point"])
+            idx = np.concatenate([specs[r]["tables"][name]["data"] for r in range(world)])
+            col = np.zeros((idx.shape[0], 4), dtype=np.uint64)
+            hot = idx != 0xFF
+            col[hot] = scale_table[idx[hot]]
+            tables[name] = col
         else:
             conv = O.fr_from_u64 if t["kind"] == "u64" else O.fr_from_i64
             tables[name] = np.concatenate([conv(specs[r]["tables"][name]["data"]) for r in range(world)], axis=0)
