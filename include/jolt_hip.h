@@ -201,6 +201,9 @@ int32_t jolt_member_create_split_eq_product_sharded(jolt_ctx *ctx, jolt_table *a
                                                     const jolt_fr_t *scale, const jolt_fr_t *shard_scale, jolt_member **out);
 /* Rewind a BORROW member to round 0 (no device work). */
 int32_t jolt_member_reset(jolt_member *m);
+/* New scaling factor for a split-eq member that has bound nothing yet (GruenSplitEqPolynomial::new_with_scaling,
+ * crates/jolt-poly/src/split_eq.rs:180-215): lets a reset member serve the next proof with another eq scalar. */
+int32_t jolt_member_set_scale(jolt_member *member, const jolt_fr_t *scale);
 int32_t jolt_member_num_rounds(const jolt_member *m, size_t *rounds);
 int32_t jolt_member_degree(const jolt_member *m, uint32_t *degree);
 

@@ -61,6 +61,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
         if (hipHostMalloc((void**)&ctx->h_round, ctx->round_cap * sizeof(Fr), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipMalloc((void**)&ctx->d_counters, 64 * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&ctx->d_round, ctx->round_cap * sizeof(Fr)) != hipSuccess ||
             hipMemset(ctx->d_counters, 0, 64 * sizeof(uint32_t)) != hipSuccess)
             s = JOLT_ERR_HIP;
         else
@@ -90,6 +91,7 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     if (ctx->h_round) (void)hipHostFree(ctx->h_round);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_round) (void)hipFree(ctx->d_round);
     for (int k = 0; k < 4; ++k) {
         if (ctx->msm_ws[k]) (void)hipFree(ctx->msm_ws[k]);
         if (ctx->msm_host[k]) (void)hipHostFree(ctx->msm_host[k]);
@@ -940,6 +942,20 @@ extern "C" int32_t jolt_member_reset(jolt_member* m) {
     return JOLT_OK;
 }
 
+// Replace the scaling factor of a split-eq member that has not bound anything yet (GruenSplitEqPolynomial::new_with_scaling,
+// crates/jolt-poly/src/split_eq.rs:180-215): the E tables do not depend on it, so a reset member can be re-used with the scalar of
+// the next proof (the tail members of a sharded batch, whose scalar is the product of the shard-local challenges).
+extern "C" int32_t jolt_member_set_scale(jolt_member* m, const jolt_fr_t* scale) {
+    if (!m || !scale) return JOLT_ERR_INVALID_ARG;
+    if (m->kind == jolt_member::kExpr) return JOLT_ERR_UNSUPPORTED;
+    if (m->bound != 0) { m->ctx->last_error = "set_scale on a member that has already bound a variable"; return JOLT_ERR_INVALID_ARG; }
+    Fr c = fr_from_abi(scale);
+    JOLT_REQUIRE(m->ctx, fr_is_canonical(c), "scale is not a canonical Fr");
+    m->initial_scalar = c;
+    m->current_scalar = c;
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_member_num_rounds(const jolt_member* m, size_t* rounds) {
     if (!m || !rounds) return JOLT_ERR_INVALID_ARG;
     *rounds = m->rounds;
@@ -1164,6 +1180,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     RoundDone rd;
     rd.counters = ctx->d_counters;
     rd.results = ctx->h_round;
+    rd.results_dev = ctx->d_round;
     rd.flag = ctx->h_flag;
     rd.seq = ++ctx->seq;
     rd.group_total = (uint32_t)n;
@@ -1316,6 +1333,7 @@ static int32_t round_wait(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     std::memcpy(out, ctx->h_round, count * sizeof(Fr));
+    ctx->d_round_count = count;  // the same sums sit in d_round (written by the publishing workgroups)
     return JOLT_OK;
 }
 
@@ -1613,6 +1631,7 @@ static int32_t engine_round(jolt_ctx* ctx, jolt_engine* e, const Fr* const* bind
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (e->trace) { e->t_last_seen = now_ns(); e->t_device.push_back(e->t_last_seen - t_post); }
     std::memcpy(out, ctx->h_round, e->total * sizeof(Fr));
+    ctx->d_round_count = 0;  // the engine publishes to the host only
     ctx->seq = want;
     // host-side bookkeeping of the bind the engine applied at the start of this round
     if (has_bind) {

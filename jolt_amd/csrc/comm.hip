@@ -63,6 +63,7 @@ struct jolt_comm {
     char *h_send = nullptr, *h_recv = nullptr, *d_send = nullptr, *d_recv = nullptr;
     size_t cap = 0;  // bytes per rank
     uint64_t* h_flag = nullptr;  // pinned, device-mapped: the publish kernel stores `seq` after the gathered bytes landed
+    const void* round_sums_host = nullptr;  // set by jolt_comm_gather_round_sums: the host copy of what ctx->d_round holds
     uint64_t seq = 0;
 };
 
@@ -178,9 +179,17 @@ extern "C" int32_t jolt_comm_all_gather_host(jolt_comm* c, const void* local, si
     if (!bytes) return JOLT_OK;
     jolt_ctx* ctx = c->ctx;
     JOLT_TRY(comm_reserve(c, bytes));
-    std::memcpy(c->h_send, local, bytes);
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, ctx->stream));
-    JOLT_NCCL_TRY(c, c->api->all_gather(c->d_send, c->d_recv, bytes, ncclUint8, c->comm, ctx->stream));
+    // the round sums of the last batch round already sit in device memory (written next to the host copy by the publishing
+    // workgroups): send from there and skip the staging copy
+    const void* send = c->d_send;
+    static const bool force_stage = std::getenv("JOLT_COMM_STAGE") != nullptr;
+    if (!force_stage && local == c->round_sums_host && ctx->d_round && ctx->d_round_count * sizeof(Fr) == bytes) {
+        send = ctx->d_round;
+    } else {
+        std::memcpy(c->h_send, local, bytes);
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(c->d_send, c->h_send, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    JOLT_NCCL_TRY(c, c->api->all_gather(send, c->d_recv, bytes, ncclUint8, c->comm, ctx->stream));
     const size_t total = bytes * c->world;
     if (total % 4 == 0 && total <= (1u << 16)) {  // the per-round payload: publish + spin (no stream synchronisation)
         void *d_host = nullptr, *d_flag = nullptr;
@@ -223,7 +232,12 @@ extern "C" int32_t jolt_comm_all_gather_device(jolt_comm* c, const void* d_local
 
 // jolt_gather_fn for jolt_host_batch_run: user = jolt_comm*
 extern "C" int32_t jolt_comm_gather_round_sums(void* user, const jolt_fr_t* local, size_t count, jolt_fr_t* gathered) {
-    return jolt_comm_all_gather_host(static_cast<jolt_comm*>(user), local, count * sizeof(jolt_fr_t), gathered);
+    jolt_comm* c = static_cast<jolt_comm*>(user);
+    if (!c) return JOLT_ERR_INVALID_ARG;
+    c->round_sums_host = local;  // these are the sums of the round that just completed: ctx->d_round mirrors them on the device
+    int32_t s = jolt_comm_all_gather_host(c, local, count * sizeof(jolt_fr_t), gathered);
+    c->round_sums_host = nullptr;
+    return s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

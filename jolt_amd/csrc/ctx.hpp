@@ -33,6 +33,8 @@ struct jolt_ctx {
     // into host-mapped pinned memory and then publishes a sequence number the host spins on
     Fr* h_round = nullptr;          // pinned, device-mapped (fine-grained)
     uint64_t* h_flag = nullptr;     // pinned, device-mapped
+    Fr* d_round = nullptr;          // device copy of the last round's sums (what a sharded prover all-gathers)
+    size_t d_round_count = 0;       // sums of the last completed round held by d_round (0: none)
     uint32_t* d_counters = nullptr; // [0..31] per-member tickets, [32] group ticket
     uint64_t seq = 0;
     size_t round_cap = 0;

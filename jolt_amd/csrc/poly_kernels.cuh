@@ -198,6 +198,7 @@ constexpr int kGroupTicket = 32;
 struct RoundDone {
     uint32_t* counters;   // device memory, zero between rounds
     Fr* results;          // host-mapped pinned memory
+    Fr* results_dev;      // device copy of the same sums (send buffer of the multi-GPU all-gather), may be null
     uint64_t* flag;       // host-mapped pinned memory
     uint64_t seq;
     uint32_t group_total; // members in this batch round
@@ -236,6 +237,7 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
             Fr tot = s_red[0];
             for (int w = 1; w < kBlock / 64; ++w) tot = add(tot, s_red[w]);
             st_fr(rd.results + slot + t, tot);
+            if (rd.results_dev) st_fr(rd.results_dev + slot + t, tot);
         }
         __syncthreads();
     }

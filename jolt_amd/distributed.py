@@ -576,11 +576,9 @@ class ShardedWorkload:
             T["slices"], T["members"] = slices, members
         else:
             for k, i in enumerate(idxs):
-                if self.members[i].split_eq:
-                    T["members"][k].destroy()
-                    T["members"][k] = build_split(i, T["slices"][k], scalars[k])
-                else:
-                    T["members"][k].reset()
+                T["members"][k].reset()
+                if self.members[i].split_eq:  # same point, new eq scalar (the product of this proof's shard-local challenges)
+                    T["members"][k].set_scale(scalars[k])
         return DeviceShard(ctx, T["members"])
 
     def prove(self, label=0):

@@ -341,6 +341,9 @@ class Member:
         self.n_evals = 2 if split_eq else (degree if skip_one else degree + 1)
         self.uniform = False
 
+    def set_scale(self, scale):
+        _ck(lib().jolt_member_set_scale(self.h, _p(fr(scale))), "jolt_member_set_scale", self.ctx)
+
     def num_rounds(self):
         n = C.c_size_t()
         _ck(lib().jolt_member_num_rounds(self.h, C.byref(n)), "jolt_member_num_rounds", self.ctx)
