@@ -274,6 +274,8 @@ int32_t jolt_host_fr_sub(const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out)
 int32_t jolt_host_fr_inv(const jolt_fr_t *a, jolt_fr_t *out);
 int32_t jolt_host_fr_from_u64(uint64_t v, jolt_fr_t *out);
 int32_t jolt_host_fr_mul_shifted(const jolt_fr_t *a, const jolt_fr_t *c, jolt_fr_t *out); /* c low limbs must be 0 */
+/* the kernels' multiplication algorithm (nine 29-bit limbs, product scanning) compiled for the host; field 0 = Fr, 1 = Fq */
+int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out);
 /* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
 int32_t jolt_host_univariate_from_evals(const jolt_fr_t *evals, size_t n, jolt_fr_t *coeffs_out);
 int32_t jolt_host_univariate_evaluate(const jolt_fr_t *coeffs, size_t n, const jolt_fr_t *x, jolt_fr_t *out);

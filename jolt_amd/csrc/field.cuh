@@ -219,10 +219,90 @@ inline Fp<PR> host_mul64(const Fp<PR>& a, const Fp<PR>& b) {
 }
 #endif
 
+// ---- device multiplication: product scanning over nine 29-bit limbs ------------------------------------------------------
+// The row-wise form above spends most of its instructions on carry handling: per 256-bit product 128 v_mad_u64_u32 but also
+// ~140 v_addc, ~135 v_mov (zeroing the high half of every 64-bit addend) and ~150 s_nop.  In radix 2^29 a whole product-scanning
+// column -- at most 9 partial products a_i*b_j plus 9 reduction products m_i*p_j, each below 2^58 -- fits the 64-bit accumulator
+// of v_mad_u64_u32, so a column is a bare chain of mads through the accumulator: no carries, no moves (162 mads + ~110 other
+// instructions; measured 1.22x the throughput of the row-wise form in a mul+add chain, same canonical result).
+// The limb structure's Montgomery radix is 2^(9*29) = 2^261, not 2^256: feeding b << 5 squares that away
+// (a * 32b * 2^-261 = a * b * 2^-256); 32b < 2^259 still fits nine limbs and the output stays below 2p.
+constexpr uint32_t kMask29 = (1u << 29) - 1;
+template <class PR>
+struct Limbs29 {
+    static constexpr uint32_t limb(int k) {  // bits [29k, 29k+29) of p
+        const int bit = 29 * k, w = bit >> 5, s = bit & 31;
+        uint64_t lo = w < 8 ? (uint64_t)PR::P[w] : 0, hi = w + 1 < 8 ? (uint64_t)PR::P[w + 1] : 0;
+        return (uint32_t)(((lo | (hi << 32)) >> s) & kMask29);
+    }
+    static constexpr uint32_t neg_inv() {  // -p^-1 mod 2^29 (Newton on the low limb)
+        uint32_t p0 = limb(0), y = 1;
+        for (int i = 0; i < 5; ++i) y *= 2u - p0 * y;
+        return (0u - y) & kMask29;
+    }
+};
+// limbs of (x << SH) in radix 2^29 (x < 2^256, SH <= 5: nine limbs)
+template <int SH>
+JOLT_HD void to_limbs29(const uint32_t (&x)[8], uint32_t (&o)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int bit = 29 * k - SH;  // first source bit of limb k
+        uint32_t v;
+        if (bit < 0) {
+            v = x[0] << (-bit);  // k = 0 with SH > 0
+        } else {
+            const int w = bit >> 5, s = bit & 31;
+            const uint32_t lo = w < 8 ? x[w] : 0u, hi = w + 1 < 8 ? x[w + 1] : 0u;
+            v = s == 0 ? lo : (uint32_t)((((uint64_t)hi << 32) | lo) >> s);  // one v_alignbit_b32
+        }
+        o[k] = v & kMask29;
+    }
+}
+template <class PR>
+JOLT_HD Fp<PR> mul_limbs29(const Fp<PR>& a, const Fp<PR>& b) {
+    constexpr uint32_t P0 = Limbs29<PR>::limb(0), P1 = Limbs29<PR>::limb(1), P2 = Limbs29<PR>::limb(2), P3 = Limbs29<PR>::limb(3), P4 = Limbs29<PR>::limb(4),
+                       P5 = Limbs29<PR>::limb(5), P6 = Limbs29<PR>::limb(6), P7 = Limbs29<PR>::limb(7), P8 = Limbs29<PR>::limb(8);
+    constexpr uint32_t PL[9] = {P0, P1, P2, P3, P4, P5, P6, P7, P8};
+    constexpr uint32_t NINV = Limbs29<PR>::neg_inv();
+    uint32_t A[9], B[9], M[9], R[9];
+    to_limbs29<0>(a.l, A);
+    to_limbs29<5>(b.l, B);
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)A[i] * B[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)M[i] * PL[k - i];
+        M[k] = ((uint32_t)acc * NINV) & kMask29;
+        acc += (uint64_t)M[k] * PL[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 18; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)A[i] * B[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) acc += (uint64_t)M[i] * PL[k - i];
+        R[k - 9] = (uint32_t)acc & kMask29;
+        acc >>= 29;
+    }
+    Fp<PR> out;  // nine 29-bit limbs of a value below 2p < 2^256 -> eight 32-bit words
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = (32 * j) / 29, s = 32 * j - 29 * k;  // word j starts inside limb k at bit s
+        uint32_t v = R[k] >> s;
+        v |= R[k + 1] << (29 - s);
+        if (58 - s < 32 && k + 2 < 9) v |= R[k + 2] << (58 - s);
+        out.l[j] = v;
+    }
+    return reduce_once(out, 0u);
+}
+
 template <class PR>
 JOLT_HD Fp<PR> mul(const Fp<PR>& a, const Fp<PR>& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return mont_rows<PR, 8>(a, b.l);
+    return mul_limbs29<PR>(a, b);
 #else
     return host_mul64(a, b);
 #endif

@@ -405,6 +405,23 @@ extern "C" int32_t jolt_host_fr_mul(const jolt_fr_t* a, const jolt_fr_t* b, jolt
     fr_to_abi(out, mul(fr_from_abi(a), fr_from_abi(b)));
     return JOLT_OK;
 }
+// The kernels' multiplication algorithm (field.cuh mul_limbs29: product scanning over nine 29-bit limbs), compiled for the host
+// so that the CPU suite pins it against the oracle; field 0 = Fr, 1 = Fq.  Operands must be canonical.
+extern "C" int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
+    if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
+    if (field == 0) {
+        fr_to_abi(out, jolt::mul_limbs29(fr_from_abi(a), fr_from_abi(b)));
+    } else if (field == 1) {
+        jolt::Fq x, y;
+        std::memcpy(&x, a, sizeof(x));
+        std::memcpy(&y, b, sizeof(y));
+        jolt::Fq r = jolt::mul_limbs29(x, y);
+        std::memcpy(out, &r, sizeof(r));
+    } else {
+        return JOLT_ERR_INVALID_ARG;
+    }
+    return JOLT_OK;
+}
 extern "C" int32_t jolt_host_fr_add(const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
     if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
     fr_to_abi(out, add(fr_from_abi(a), fr_from_abi(b)));

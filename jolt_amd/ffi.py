@@ -394,6 +394,13 @@ def host_fr_binop(name, a, b):
 def host_fr_mul(a, b): return host_fr_binop("jolt_host_fr_mul", a, b)
 
 
+def host_mul_limbs29(field, a, b):
+    """the device multiplication algorithm (29-bit limbs) built for the host; field 0 = Fr, 1 = Fq"""
+    o = fr_array(1)
+    _ck(lib().jolt_host_mul_limbs29(C.c_int32(field), _p(fr(a)), _p(fr(b)), _p(o)), "jolt_host_mul_limbs29")
+    return o[0]
+
+
 def host_fr_wide_dot(a, b):
     """sum_k a[k]*b[k] through the deferred-reduction accumulator (one REDC per block of products)"""
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)

@@ -126,3 +126,18 @@ def test_deferred_reduction_accumulator_equals_plain_field_sum():
     if hasattr(O, "wide_accumulate"):
         a, b = rand_fr(33, 800), rand_fr(33, 801)
         assert np.array_equal(ffi.host_fr_wide_dot(a, b), O.wide_accumulate(a, b))
+
+
+def test_device_multiplication_algorithm_matches_oracle_on_host():
+    """mul_limbs29 (what `mul` is on the device: nine 29-bit limbs, product scanning, b << 5 to square away the 2^261 radix) built
+    for the host: Fr and Fq products against the oracle, including 0, 1, p-1, p-2 and operands with all-ones limb patterns that
+    maximise every column sum."""
+    rng = np.random.default_rng(29)
+    for field, mod, omul in ((0, O.R_MOD, O.fr_mul), (1, O.Q_MOD, O.fq_mul)):
+        ints = [0, 1, 2, mod - 1, mod - 2, (1 << 253) - 1, (1 << 254) - 1 if (1 << 254) - 1 < mod else mod - 3, 0x1FFFFFFF, (1 << 29), ((1 << 232) - 1)]
+        ints += [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(150)]
+        vals = np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in ints], dtype=np.uint64)  # raw limbs = Montgomery residues
+        for i in range(len(ints)):
+            for j in (i, (i * 7 + 3) % len(ints), len(ints) - 1 - i):
+                want = omul(vals[i:i + 1], vals[j:j + 1])[0]
+                assert np.array_equal(ffi.host_mul_limbs29(field, vals[i], vals[j]), want), (field, i, j)
