@@ -321,6 +321,16 @@ int32_t jolt_host_batch_flush_binds(jolt_batch *b, jolt_member *const *members, 
 int32_t jolt_host_batch_split_eq_scalar(const jolt_batch *b, size_t member, jolt_fr_t *out);
 int32_t jolt_host_batch_end(jolt_batch *b, jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
                             jolt_fr_t *out_final_claim);
+/* SplitLt (crates/jolt-kernels/src/optimized/support.rs:640-760): LT(., r_cycle) + constant from ~sqrt(T) split tables, bound
+ * low-to-high; values equal the dense jolt_lt_evals table (plus the constant) bound identically.  constant may be NULL. */
+typedef struct jolt_split_lt jolt_split_lt;
+int32_t jolt_split_lt_create(jolt_ctx *ctx, const jolt_fr_t *r_cycle, size_t n, const jolt_fr_t *constant, jolt_split_lt **out);
+int32_t jolt_split_lt_bind(jolt_ctx *ctx, jolt_split_lt *s, const jolt_fr_t *r);
+int32_t jolt_split_lt_len(const jolt_split_lt *s, size_t *len);
+int32_t jolt_split_lt_to_dense(jolt_ctx *ctx, const jolt_split_lt *s, jolt_table **out); /* all current evaluations (pair(y) for every y) */
+int32_t jolt_split_lt_final_value(jolt_ctx *ctx, const jolt_split_lt *s, jolt_fr_t *out); /* JOLT_ERR_NOT_FULLY_BOUND before the last bind */
+int32_t jolt_split_lt_free(jolt_ctx *ctx, jolt_split_lt *s);
+
 /* sum_k a[k]*b[k] with ONE deferred Montgomery reduction per block of products: the deferred-reduction accumulator the round
  * kernels use for sums of products (WideAccumulator, crates/jolt-field/src/bn254/mont.rs:334-602; Accumulator contract
  * crates/jolt-field/src/algebra.rs:362-433).  Host build of the kernels' code; the value equals the plain field sum. */

@@ -163,3 +163,121 @@ extern "C" int32_t jolt_rlc(jolt_ctx* ctx, jolt_table* const* tables, size_t k, 
     *out = r;
     return JOLT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// SplitLt: LT(., r) + constant served from ~sqrt(T) split tables and bound low-to-high
+// (crates/jolt-kernels/src/optimized/support.rs:640-760).  Big-endian index j = j_hi || j_lo, r = r_hi || r_lo:
+//   LT(j, r) = LT(j_hi, r_hi) + eq(j_hi, r_hi) * LT(j_lo, r_lo);  the additive constant rides in the hi table; low-to-high binds
+// touch lt_lo only; once the lo variables are exhausted the lo scalar folds into the hi table and binding continues densely.
+// ------------------------------------------------------------------------------------------------------------------
+int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r, int32_t order);
+int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out);
+
+struct jolt_split_lt {
+    jolt_ctx* ctx = nullptr;
+    jolt_table *lt_lo = nullptr, *lt_hi = nullptr, *eq_hi = nullptr;  // split state
+    jolt_table* dense = nullptr;                                      // dense state
+};
+
+namespace {
+static __global__ __launch_bounds__(kBlock) void k_add_constant(Fr* __restrict__ t, size_t n, Fr c) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) st_fr(t + i, add(ld_fr(t + i), c));
+}
+// out[j] = lt_hi[j / lo_len] + eq_hi[j / lo_len] * lt_lo[j % lo_len]   (lo_len a power of two)
+static __global__ __launch_bounds__(kBlock) void k_split_lt_expand(const Fr* __restrict__ lt_lo, const Fr* __restrict__ lt_hi, const Fr* __restrict__ eq_hi,
+                                                                   size_t lo_len, size_t total, Fr* __restrict__ out) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= total) return;
+    size_t hi = j / lo_len, lo = j & (lo_len - 1);
+    st_fr(out + j, add(ld_fr(lt_hi + hi), mul(ld_fr(eq_hi + hi), ld_fr(lt_lo + lo))));
+}
+}  // namespace
+
+extern "C" int32_t jolt_split_lt_free(jolt_ctx* ctx, jolt_split_lt* s) {
+    if (!s) return JOLT_OK;
+    jolt_ctx* c = ctx ? ctx : s->ctx;
+    for (jolt_table* t : {s->lt_lo, s->lt_hi, s->eq_hi, s->dense}) if (t) jolt_table_free(c, t);
+    delete s;
+    return JOLT_OK;
+}
+
+// SplitLt::new_plus_constant (support.rs:683-703); constant may be NULL (= 0)
+extern "C" int32_t jolt_split_lt_create(jolt_ctx* ctx, const jolt_fr_t* r_cycle, size_t n, const jolt_fr_t* constant, jolt_split_lt** out) {
+    if (!ctx || !out || (!r_cycle && n) || n > 40) return JOLT_ERR_INVALID_ARG;
+    jolt_split_lt* s = new (std::nothrow) jolt_split_lt();
+    if (!s) return JOLT_ERR_OOM;
+    s->ctx = ctx;
+    const size_t mid = n / 2, hi_len = n - mid;  // r_hi = r[..hi_len], r_lo = r[hi_len..]
+    int32_t st = jolt_lt_evals(ctx, r_cycle, hi_len, &s->lt_hi);
+    if (st == JOLT_OK && constant) {
+        Fr c = fr_from_abi(constant);
+        if (!fr_is_canonical(c)) st = JOLT_ERR_INVALID_ARG;
+        else {
+            size_t len = s->lt_hi->len;
+            hipLaunchKernelGGL(k_add_constant, dim3((unsigned)((len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, s->lt_hi->data(), len, c);
+            if (hipGetLastError() != hipSuccess) st = JOLT_ERR_HIP;
+        }
+    }
+    if (st == JOLT_OK && mid == 0) {  // no lo variables: dense from the start
+        s->dense = s->lt_hi;
+        s->lt_hi = nullptr;
+    } else if (st == JOLT_OK) {
+        st = jolt_lt_evals(ctx, r_cycle + hi_len, mid, &s->lt_lo);
+        if (st == JOLT_OK) st = jolt_eq_evals(ctx, r_cycle, hi_len, nullptr, &s->eq_hi);
+    }
+    if (st != JOLT_OK) { jolt_split_lt_free(ctx, s); return st; }
+    *out = s;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_split_lt_len(const jolt_split_lt* s, size_t* len) {
+    if (!s || !len) return JOLT_ERR_INVALID_ARG;
+    *len = s->dense ? s->dense->len : s->lt_hi->len * s->lt_lo->len;
+    return JOLT_OK;
+}
+
+// SplitLt::bind (support.rs:727-748), LowToHigh
+extern "C" int32_t jolt_split_lt_bind(jolt_ctx* ctx, jolt_split_lt* s, const jolt_fr_t* r) {
+    if (!ctx || !s || !r) return JOLT_ERR_INVALID_ARG;
+    Fr c = fr_from_abi(r);
+    JOLT_REQUIRE(ctx, fr_is_canonical(c), "bind challenge is not a canonical Fr");
+    if (s->dense) {
+        if (s->dense->len < 2) { ctx->last_error = "cannot bind a zero-variable polynomial"; return JOLT_ERR_INVALID_ARG; }
+        return jolt_internal_bind(ctx, &s->dense, 1, c, JOLT_ORDER_LOW_TO_HIGH);
+    }
+    JOLT_TRY(jolt_internal_bind(ctx, &s->lt_lo, 1, c, JOLT_ORDER_LOW_TO_HIGH));
+    if (s->lt_lo->len == 1) {  // lo variables exhausted: dense[hi] = lt_hi[hi] + eq_hi[hi] * lo_scalar
+        jolt_table* d = nullptr;
+        JOLT_TRY(jolt_internal_table_new(ctx, s->lt_hi->len, &d));
+        hipLaunchKernelGGL(k_split_lt_expand, dim3((unsigned)((d->len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const Fr*)s->lt_lo->data(),
+                           (const Fr*)s->lt_hi->data(), (const Fr*)s->eq_hi->data(), (size_t)1, d->len, d->data());
+        if (hipGetLastError() != hipSuccess) { jolt_table_free(ctx, d); return JOLT_ERR_HIP; }
+        JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (jolt_table* t : {s->lt_lo, s->lt_hi, s->eq_hi}) jolt_table_free(ctx, t);
+        s->lt_lo = s->lt_hi = s->eq_hi = nullptr;
+        s->dense = d;
+    }
+    return JOLT_OK;
+}
+
+// every current evaluation ((LT[2y], LT[2y+1]) = SplitLt::pair for all y, support.rs:705-725) as a dense table
+extern "C" int32_t jolt_split_lt_to_dense(jolt_ctx* ctx, const jolt_split_lt* s, jolt_table** out) {
+    if (!ctx || !s || !out) return JOLT_ERR_INVALID_ARG;
+    if (s->dense) return jolt_table_clone(ctx, s->dense, out);
+    const size_t lo_len = s->lt_lo->len, total = lo_len * s->lt_hi->len;
+    jolt_table* d = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, total, &d));
+    hipLaunchKernelGGL(k_split_lt_expand, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const Fr*)s->lt_lo->data(),
+                       (const Fr*)s->lt_hi->data(), (const Fr*)s->eq_hi->data(), lo_len, total, d->data());
+    if (hipGetLastError() != hipSuccess) { jolt_table_free(ctx, d); return JOLT_ERR_HIP; }
+    *out = d;
+    return JOLT_OK;
+}
+
+// SplitLt::final_value (support.rs:750-758): defined once fully bound (always dense by then)
+extern "C" int32_t jolt_split_lt_final_value(jolt_ctx* ctx, const jolt_split_lt* s, jolt_fr_t* out) {
+    if (!ctx || !s || !out) return JOLT_ERR_INVALID_ARG;
+    if (!s->dense || s->dense->len != 1) return JOLT_ERR_NOT_FULLY_BOUND;
+    return jolt_table_download(ctx, s->dense, 0, 1, out);
+}

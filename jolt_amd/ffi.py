@@ -585,6 +585,40 @@ def host_g1_serialize_compressed(p):
     return bytes(out)
 
 
+class SplitLt:
+    """LT(., r) + constant from split tables, bound low-to-high (optimized/support.rs:640-760)."""
+
+    def __init__(self, ctx, r_cycle, constant=None):
+        r = fr(r_cycle).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_split_lt_create(ctx.h, _p(r) if r.shape[0] else None, C.c_size_t(r.shape[0]), _p(fr(constant)) if constant is not None else None,
+                                       C.byref(h)), "jolt_split_lt_create", ctx)
+        self.ctx, self.h = ctx, h
+
+    def __len__(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_split_lt_len(self.h, C.byref(n)), "jolt_split_lt_len", self.ctx)
+        return n.value
+
+    def bind(self, r):
+        _ck(lib().jolt_split_lt_bind(self.ctx.h, self.h, _p(fr(r))), "jolt_split_lt_bind", self.ctx)
+
+    def to_dense(self):
+        h = C.c_void_p()
+        _ck(lib().jolt_split_lt_to_dense(self.ctx.h, self.h, C.byref(h)), "jolt_split_lt_to_dense", self.ctx)
+        return Table(self.ctx, h)
+
+    def final_value(self):
+        o = fr_array(1)
+        _ck(lib().jolt_split_lt_final_value(self.ctx.h, self.h, _p(o)), "jolt_split_lt_final_value", self.ctx)
+        return o[0]
+
+    def free(self):
+        if self.h:
+            lib().jolt_split_lt_free(self.ctx.h, self.h)
+            self.h = None
+
+
 class OneHot:
     """Hot indices of N one-hot selector columns (uint8 [n_polys, cycles], 0xFF = cold cycle) resident on the device."""
 

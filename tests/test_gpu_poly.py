@@ -169,3 +169,30 @@ def test_views_and_rlc_match_reference_definitions(ctx):
     assert np.array_equal(ctx.rlc([ctx.upload(t) for t in tabs], sc).download(), want)
     with pytest.raises(ffi.JoltError):
         ctx.rlc([ctx.upload(tabs[0]), ctx.upload(tabs[1][:128])], sc[:2])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 8, 11])
+def test_split_lt_equals_dense_lt_plus_constant_bound_identically(ctx, n):
+    """SplitLt (optimized/support.rs:640-760): at every stage -- split state, the fold of the lo scalar into the hi table, dense
+    state -- the served evaluations equal LtPolynomial::evaluations(r) + constant bound low-to-high with the same challenges."""
+    r = rand_fr(n, 1300 + n)
+    c = rand_fr(1, 1310)[0]
+    for constant in (None, c):
+        want = O.lt_evals(r) if n else np.zeros((1, 4), dtype=np.uint64)
+        if constant is not None:
+            want = O.fr_add(want, np.repeat(constant.reshape(1, 4), want.shape[0], axis=0))
+        s = ffi.SplitLt(ctx, r, constant)
+        assert len(s) == 1 << n
+        assert np.array_equal(s.to_dense().download(), want)
+        if n:
+            with pytest.raises(ffi.JoltError) as e:
+                s.final_value()
+            assert e.value.status == 7  # NotFullyBound
+        for k in range(n):
+            ch = rand_challenge(1320 + k) if k % 2 == 0 else rand_fr(1, 1320 + k)[0]
+            s.bind(ch)
+            want = O.bind_low_to_high(want, ch)
+            assert len(s) == want.shape[0]
+            assert np.array_equal(s.to_dense().download(), want), (n, k)
+        assert np.array_equal(s.final_value(), want[0])
+        s.free()
