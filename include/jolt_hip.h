@@ -359,6 +359,21 @@ int32_t jolt_member_create_lazy_ra_uniform(jolt_ctx *ctx, const jolt_onehot *sou
 int32_t jolt_member_create_lazy_ra_uniform_sharded(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, uint32_t V, uint32_t F,
                                                    const jolt_fr_t *coeffs, const jolt_fr_t *w, size_t n, const jolt_fr_t *scale,
                                                    const jolt_fr_t *shard_scale, jolt_member **out);
+/* Packed typed witness rows: ONE upload of the per-cycle records the committed columns derive from
+ * (CommittedColumnsWitness, crates/jolt-kernels/src/commitment.rs:25-32; InstructionCycleRow) instead of a materialised field
+ * column per polynomial; columns are expanded on the device.  Fields are little-endian integers inside a row of row_bytes bytes. */
+typedef struct jolt_rows jolt_rows;
+int32_t jolt_rows_upload(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t row_bytes, jolt_rows **out);
+int32_t jolt_rows_free(jolt_ctx *ctx, jolt_rows *rows);
+/* integer field (width 1/2/4/8 bytes at `offset`, optionally two's complement) -> Fr table (Polynomial::bind_to_field promotion) */
+int32_t jolt_table_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table **out);
+/* n_polys hot-index columns from ONE address field (<= 16 bytes): index_i = (field >> shifts[i]) & (2^log_k - 1)
+ * (RaChunkSelector::chunk_u128, crates/jolt-witness/src/witnesses/one_hot.rs:14-52); a row whose byte at valid_offset is 0 is a
+ * cold cycle (Option::None, e.g. no RAM access); valid_offset = SIZE_MAX: every row is hot.  log_k <= 7. */
+int32_t jolt_onehot_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, const uint32_t *shifts, size_t n_polys,
+                              uint32_t log_k, size_t valid_offset, jolt_onehot **out);
+int32_t jolt_onehot_download(jolt_ctx *ctx, const jolt_onehot *source, uint8_t *out /* n_polys * cycles */);
+
 /* Booleanity cycle phase over the same lazily bound columns (crates/jolt-kernels/src/optimized/booleanity.rs:436-633):
  * eq(w,j) * sum_i (H_i(j)^2 - rho[i]*H_i(j)), H_i(j) = scale_tables[i*k + index(i,j)] (the caller passes the gamma^i-pre-scaled
  * address tables and rho[i] = gamma^i).  prove_round returns (q(0), q(inf)) of the inner quadratic; the cubic is

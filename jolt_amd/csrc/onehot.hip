@@ -82,3 +82,138 @@ extern "C" int32_t jolt_onehot_pushforward(jolt_ctx* ctx, const jolt_onehot* s, 
     *out = t;
     return JOLT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Packed typed witness rows -> device tables: one upload of the trace-derived per-cycle records
+// (e.g. CommittedColumnsWitness, crates/jolt-kernels/src/commitment.rs:25-32: rd_inc, ram_inc, lookup_index, bytecode_pc,
+// ram_address) instead of one materialised field column per polynomial; the columns the members read are expanded on the
+// device: integer fields promote to Fr (Polynomial::bind_to_field's compact scalars), address fields become hot-index columns
+// through RaChunkSelector::chunk_u128 (crates/jolt-witness/src/witnesses/one_hot.rs:14-52).
+// ------------------------------------------------------------------------------------------------------------------
+struct jolt_rows {
+    jolt_ctx* ctx = nullptr;
+    uint8_t* data = nullptr;  // device, n_rows * row_bytes
+    size_t n_rows = 0, row_bytes = 0;
+};
+
+namespace {
+__device__ __forceinline__ uint64_t load_le(const uint8_t* p, uint32_t width) {
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < width && k < 8; ++k) v |= (uint64_t)p[k] << (8 * k);
+    return v;
+}
+static __global__ __launch_bounds__(kBlock) void k_rows_to_fr(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width,
+                                                              int is_signed, Fr* __restrict__ out) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_rows) return;
+    uint64_t v = load_le(rows + j * row_bytes + offset, width);
+    bool negative = false;
+    if (is_signed) {
+        const int bits = (int)width * 8;
+        if (bits < 64 && (v >> (bits - 1)) & 1) v |= ~0ull << bits;  // sign-extend
+        if ((int64_t)v < 0) { negative = true; v = 0ull - v; }
+    }
+    Fr x = fr_from_u64(v);
+    st_fr(out + j, negative ? neg(x) : x);
+}
+struct ChunkShifts {
+    uint32_t shift[kMaxBatchTables];
+};
+static __global__ __launch_bounds__(kBlock) void k_rows_to_hot_indices(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width,
+                                                                       ChunkShifts sh, uint32_t log_k, size_t valid_offset, uint8_t* __restrict__ idx) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t p = blockIdx.y;
+    if (j >= n_rows) return;
+    const uint8_t* row = rows + j * row_bytes;
+    if (valid_offset != ~(size_t)0 && row[valid_offset] == 0) { idx[p * n_rows + j] = kOneHotCold; return; }
+    // (field >> shift) & mask on a little-endian field of up to 16 bytes: the chunk spans at most two bytes for log_k <= 8
+    const uint32_t s = sh.shift[p], byte = s >> 3, bit = s & 7;
+    uint32_t v = byte < width ? row[offset + byte] : 0u;
+    if (byte + 1 < width) v |= (uint32_t)row[offset + byte + 1] << 8;
+    idx[p * n_rows + j] = (uint8_t)((v >> bit) & ((1u << log_k) - 1));
+}
+}  // namespace
+
+extern "C" int32_t jolt_rows_upload(jolt_ctx* ctx, const void* rows, size_t n_rows, size_t row_bytes, jolt_rows** out) {
+    if (!ctx || !rows || !out || n_rows == 0 || row_bytes == 0) return JOLT_ERR_INVALID_ARG;
+    jolt_rows* r = new (std::nothrow) jolt_rows();
+    if (!r) return JOLT_ERR_OOM;
+    r->ctx = ctx;
+    r->n_rows = n_rows;
+    r->row_bytes = row_bytes;
+    hipError_t e = hipMalloc((void**)&r->data, n_rows * row_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->data, rows, n_rows * row_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("rows upload: ") + hipGetErrorString(e);
+        if (r->data) (void)hipFree(r->data);
+        delete r;
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    *out = r;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_rows_free(jolt_ctx* ctx, jolt_rows* r) {
+    if (!r) return JOLT_OK;
+    jolt_ctx* c = ctx ? ctx : r->ctx;
+    if (c) { (void)jolt_internal_engine_quiesce(c); (void)hipStreamSynchronize(c->stream); }
+    if (r->data) (void)hipFree(r->data);
+    delete r;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_table_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table** out) {
+    if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, rows->n_rows, &t));
+    hipLaunchKernelGGL(k_rows_to_fr, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const uint8_t*)rows->data, rows->n_rows,
+                       rows->row_bytes, offset, width, is_signed ? 1 : 0, t->data());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    *out = t;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
+                                         uint32_t log_k, size_t valid_offset, jolt_onehot** out) {
+    if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
+    if (log_k == 0 || log_k > 7 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;  // k <= 128 < 0xFF
+    if (valid_offset != ~(size_t)0 && valid_offset >= rows->row_bytes) return JOLT_ERR_INVALID_ARG;
+    ChunkShifts sh;
+    for (size_t p = 0; p < (size_t)kMaxBatchTables; ++p) {
+        sh.shift[p] = p < n_polys ? shifts[p] : 0;
+        if (p < n_polys && shifts[p] + log_k > width * 8) return JOLT_ERR_INVALID_ARG;
+    }
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_onehot* s = new (std::nothrow) jolt_onehot();
+    if (!s) return JOLT_ERR_OOM;
+    s->ctx = ctx;
+    s->n_polys = n_polys;
+    s->cycles = rows->n_rows;
+    s->k = 1u << log_k;
+    hipError_t e = hipMalloc((void**)&s->idx, n_polys * rows->n_rows);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rows_to_hot_indices, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock), (unsigned)n_polys), dim3(kBlock), 0, ctx->stream,
+                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, valid_offset, s->idx);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("onehot from rows: ") + hipGetErrorString(e);
+        if (s->idx) (void)hipFree(s->idx);
+        delete s;
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    *out = s;
+    return JOLT_OK;
+}
+
+// the hot indices back on the host (tests, debugging)
+extern "C" int32_t jolt_onehot_download(jolt_ctx* ctx, const jolt_onehot* s, uint8_t* out) {
+    if (!ctx || !s || !out) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(out, s->idx, s->n_polys * s->cycles, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JOLT_OK;
+}

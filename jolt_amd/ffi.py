@@ -585,6 +585,38 @@ def host_g1_serialize_compressed(p):
     return bytes(out)
 
 
+class Rows:
+    """Packed typed witness rows (numpy structured or 2-D uint8 array) resident on the device; columns are expanded there."""
+
+    def __init__(self, ctx, rows):
+        raw = np.ascontiguousarray(rows)
+        self.n_rows, self.row_bytes = raw.shape[0], raw.dtype.itemsize if raw.ndim == 1 else raw.shape[1]
+        h = C.c_void_p()
+        _ck(lib().jolt_rows_upload(ctx.h, raw.ctypes.data_as(C.c_void_p), C.c_size_t(self.n_rows), C.c_size_t(self.row_bytes), C.byref(h)), "jolt_rows_upload", ctx)
+        self.ctx, self.h = ctx, h
+
+    def table(self, offset, width, signed=False):
+        h = C.c_void_p()
+        _ck(lib().jolt_table_from_rows(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), C.c_int32(1 if signed else 0), C.byref(h)), "jolt_table_from_rows",
+            self.ctx)
+        return Table(self.ctx, h)
+
+    def onehot(self, offset, width, shifts, log_k, valid_offset=None):
+        sh = (C.c_uint32 * len(shifts))(*shifts)
+        h = C.c_void_p()
+        vo = C.c_size_t(valid_offset if valid_offset is not None else 2**64 - 1)
+        _ck(lib().jolt_onehot_from_rows(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), sh, C.c_size_t(len(shifts)), C.c_uint32(log_k), vo, C.byref(h)),
+            "jolt_onehot_from_rows", self.ctx)
+        src = OneHot.__new__(OneHot)
+        src.ctx, src.n_polys, src.cycles, src.k, src.h = self.ctx, len(shifts), self.n_rows, 1 << log_k, h
+        return src
+
+    def free(self):
+        if self.h:
+            lib().jolt_rows_free(self.ctx.h, self.h)
+            self.h = None
+
+
 class SplitLt:
     """LT(., r) + constant from split tables, bound low-to-high (optimized/support.rs:640-760)."""
 
@@ -630,6 +662,11 @@ class OneHot:
         _ck(lib().jolt_onehot_upload(ctx.h, idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), C.c_size_t(idx.shape[1]), C.c_uint32(k), C.byref(h)),
             "jolt_onehot_upload", ctx)
         self.h = h
+
+    def download(self):
+        out = np.empty((self.n_polys, self.cycles), dtype=np.uint8)
+        _ck(lib().jolt_onehot_download(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)), "jolt_onehot_download", self.ctx)
+        return out
 
     def materialize(self, poly, scale_table):
         h = C.c_void_p()

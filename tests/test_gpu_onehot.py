@@ -208,3 +208,57 @@ def test_lazy_booleanity_member_matches_oracle(ctx, N, K, n_vars, cold):
     got = ctx.prove_batch([dev], [claim], cf, [0], n_vars, 3, label=4)
     for k in ("polys", "challenges", "member_claims", "final_claim"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_packed_witness_rows_expand_to_tables_and_hot_indices(ctx):
+    """One upload of packed per-cycle records (the CommittedColumnsWitness shape: rd_inc i64, ram_inc i64, lookup_index u128,
+    bytecode_pc u32, ram_address Option<u32>) expanded on the device: integer fields promote to the same Fr tables as
+    jolt_table_from_u64 / _i64, the address fields become the hot-index columns of RaChunkSelector (chunk i of `chunks` 4-bit
+    chunks = (value >> (chunks-1-i)*4) & 15), cold where the Option is None; a lazy member over them matches one over explicit
+    indices."""
+    T = 1 << 10
+    rng = np.random.default_rng(77)
+    dt = np.dtype([("rd_inc", "<i8"), ("ram_inc", "<i8"), ("lookup_lo", "<u8"), ("lookup_hi", "<u8"), ("pc", "<u4"), ("ram_addr", "<u4"),
+                   ("ram_valid", "u1"), ("pad", "u1", 7)])
+    rows = np.zeros(T, dtype=dt)
+    rows["rd_inc"] = rng.integers(-2**62, 2**62, size=T)
+    rows["ram_inc"] = rng.integers(-2**40, 2**40, size=T)
+    rows["lookup_lo"] = rng.integers(0, 2**64, size=T, dtype=np.uint64)
+    rows["lookup_hi"] = rng.integers(0, 2**64, size=T, dtype=np.uint64)
+    rows["pc"] = rng.integers(0, 2**20, size=T)
+    rows["ram_addr"] = rng.integers(0, 2**16, size=T)
+    rows["ram_valid"] = rng.random(T) < 0.6
+    R = ffi.Rows(ctx, rows)
+    assert R.row_bytes == dt.itemsize
+    assert np.array_equal(R.table(dt.fields["rd_inc"][1], 8, signed=True).download(), O.fr_from_i64(rows["rd_inc"]))
+    assert np.array_equal(R.table(dt.fields["ram_inc"][1], 8, signed=True).download(), O.fr_from_i64(rows["ram_inc"]))
+    assert np.array_equal(R.table(dt.fields["pc"][1], 4).download(), O.fr_from_u64(rows["pc"].astype(np.uint64)))
+    assert np.array_equal(R.table(dt.fields["ram_valid"][1], 1).download(), O.fr_from_u64(rows["ram_valid"].astype(np.uint64)))
+    # instruction RA: 32 chunks of 4 bits of the 128-bit lookup index, most significant chunk first
+    chunks, bits = 32, 4
+    shifts = [(chunks - 1 - i) * bits for i in range(chunks)]
+    src = R.onehot(dt.fields["lookup_lo"][1], 16, shifts, bits)
+    got = src.download()
+    value = [int(lo) | (int(hi) << 64) for lo, hi in zip(rows["lookup_lo"], rows["lookup_hi"])]
+    want = np.array([[(v >> s) & 15 for v in value] for s in shifts], dtype=np.uint8)
+    assert np.array_equal(got, want)
+    # RAM RA: 4 chunks of the 16-bit remapped address, cold when the cycle has no RAM access
+    ram_shifts = [(4 - 1 - i) * bits for i in range(4)]
+    ram = R.onehot(dt.fields["ram_addr"][1], 4, ram_shifts, bits, valid_offset=dt.fields["ram_valid"][1])
+    want_ram = np.array([[(int(a) >> s) & 15 for a in rows["ram_addr"]] for s in ram_shifts], dtype=np.uint8)
+    want_ram[:, rows["ram_valid"] == 0] = 0xFF
+    assert np.array_equal(ram.download(), want_ram)
+    # the lazily bound member is indifferent to where its indices came from
+    V, F, K, n_vars = 8, 4, 16, 10
+    tables = rand_fr(V * F * K, 78).reshape(V * F, K, 4)
+    w, coeffs = rand_fr(n_vars, 79), rand_fr(V, 80)
+    a = ctx.member_lazy_ra_uniform(src, tables, V, F, coeffs, w)
+    b = ctx.member_lazy_ra_uniform(ctx.onehot(want, K), tables, V, F, coeffs, w)
+    bind = None
+    for rnd in range(n_vars):
+        ea, _ = a.prove_round(bind, want_aux=True)
+        eb, _ = b.prove_round(bind, want_aux=True)
+        assert np.array_equal(ea, eb), rnd
+        bind = rand_challenge(81 + rnd)
+    with pytest.raises(ffi.JoltError):
+        R.onehot(0, 4, [30], 4)  # chunk beyond the field
