@@ -191,6 +191,13 @@ int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx *ctx, jolt_table *
  * w[current_index-1], 0}; the caller recovers q(1) from the running claim and multiplies by the linear eq factor
  * (GruenSplitEqPolynomial::gruen_poly_from_evals, crates/jolt-poly/src/split_eq.rs:419-447).
  * flags: JOLT_MEMBER_FLAG_BORROW_TABLES.  shard_scale may be NULL (see the sharded product variant below). */
+/* eq(w,j) * q(j) for an arbitrary inner summand q in jolt_member_lc_desc form (degree = the INNER degree dq): the optimized tier's
+ * shape for every "eq times something" relation (GruenRoundMessage, crates/jolt-kernels/src/optimized/support.rs:340-412;
+ * instruction_input.rs:1-22, instruction_claim_reduction.rs).  No T-sized eq table is read or bound; prove_round returns
+ * q(0), q(2), .., q(dq) (dq values); the round polynomial is l(t)*q(t) (jolt_host_gruen_poly_from_q).  LowToHigh only.
+ * shard_scale (may be NULL) as in jolt_member_create_split_eq_product_sharded.  final_values appends the bound eq scalar. */
+int32_t jolt_member_create_split_eq_lc(jolt_ctx *ctx, jolt_table *const *tables, const jolt_member_lc_desc *desc, const jolt_fr_t *w, size_t n,
+                                       const jolt_fr_t *scale, const jolt_fr_t *shard_scale, jolt_member **out);
 int32_t jolt_member_create_split_eq_uniform(jolt_ctx *ctx, jolt_table *const *tables, uint32_t V, uint32_t F, const jolt_fr_t *coeffs,
                                             const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, const jolt_fr_t *shard_scale,
                                             uint32_t flags, jolt_member **out);

@@ -694,6 +694,31 @@ extern "C" int32_t jolt_member_create_expr(jolt_ctx* ctx, jolt_table* const* tab
     return jolt_member_create_lc(ctx, tables, &lc, out);
 }
 
+static int32_t init_split_eq(jolt_ctx* ctx, jolt_member* m, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale);
+
+// eq(w, j) * q(j) with q in "sum of products of linear combinations" form: the eq weight is factored out as in the optimized tier
+// (GruenRoundMessage, crates/jolt-kernels/src/optimized/support.rs:340-412; consumers instruction_input.rs, instruction_claim_reduction.rs):
+// no T-sized eq table is read or bound, each round returns q(0), q(2), .., q(dq) (dq = d->degree, the INNER degree; s(1) is
+// recovered from the claim), the host assembles s = l * q with gruen_poly_from_q.  LowToHigh only.
+extern "C" int32_t jolt_member_create_split_eq_lc(jolt_ctx* ctx, jolt_table* const* tables, const jolt_member_lc_desc* d, const jolt_fr_t* w, size_t n,
+                                                  const jolt_fr_t* scale, const jolt_fr_t* shard_scale, jolt_member** out) {
+    if (!ctx || !tables || !d || (!w && n) || !out) return JOLT_ERR_INVALID_ARG;
+    if (d->order != JOLT_ORDER_LOW_TO_HIGH || n == 0 || d->degree + 1 > JOLT_MAX_DEGREE) return JOLT_ERR_UNSUPPORTED;
+    jolt_member_lc_desc inner = *d;
+    inner.flags |= JOLT_MEMBER_FLAG_SKIP_ONE;
+    jolt_member* m = nullptr;
+    JOLT_TRY(jolt_member_create_lc(ctx, tables, &inner, &m));
+    int32_t s = m->rounds == n ? JOLT_OK : JOLT_ERR_SIZE_MISMATCH;
+    if (s == JOLT_OK) {
+        m->eq_weighted = true;
+        m->muls_per_pair += (size_t)d->n_groups * d->degree + 1;  // the row weight
+        s = init_split_eq(ctx, m, w, n, scale, shard_scale);
+    }
+    if (s != JOLT_OK) { if (m->borrowed) { /* views only */ } else m->tables.clear(); jolt_member_destroy(m); return s; }
+    *out = m;
+    return JOLT_OK;
+}
+
 // GruenSplitEqPolynomial::new_with_scaling(w, LowToHigh, scale) (split_eq.rs:187-236): head = w[..n-1], out_point = head[..split],
 // in_point = rest; evals_cached -> one device table per prefix length.  shard_scale multiplies the E_out tables.
 static int32_t init_split_eq(jolt_ctx* ctx, jolt_member* m, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale) {
@@ -947,7 +972,7 @@ extern "C" int32_t jolt_member_reset(jolt_member* m) {
 // the next proof (the tail members of a sharded batch, whose scalar is the product of the shard-local challenges).
 extern "C" int32_t jolt_member_set_scale(jolt_member* m, const jolt_fr_t* scale) {
     if (!m || !scale) return JOLT_ERR_INVALID_ARG;
-    if (m->kind == jolt_member::kExpr) return JOLT_ERR_UNSUPPORTED;
+    if (!m->has_split_eq()) return JOLT_ERR_UNSUPPORTED;
     if (m->bound != 0) { m->ctx->last_error = "set_scale on a member that has already bound a variable"; return JOLT_ERR_INVALID_ARG; }
     Fr c = fr_from_abi(scale);
     JOLT_REQUIRE(m->ctx, fr_is_canonical(c), "scale is not a canonical Fr");
@@ -963,7 +988,7 @@ extern "C" int32_t jolt_member_num_rounds(const jolt_member* m, size_t* rounds) 
 }
 extern "C" int32_t jolt_member_degree(const jolt_member* m, uint32_t* degree) {
     if (!m || !degree) return JOLT_ERR_INVALID_ARG;
-    *degree = m->degree;
+    *degree = m->degree + (m->eq_weighted ? 1u : 0u);  // message degree
     return JOLT_OK;
 }
 
@@ -971,7 +996,7 @@ extern "C" int32_t jolt_member_degree(const jolt_member* m, uint32_t* degree) {
 // binds themselves are enqueued by the caller (grouped over members)
 static int32_t member_note_bind(jolt_member* m, const Fr& c) {
     if (m->bound >= m->rounds) { m->ctx->last_error = "member already fully bound"; return JOLT_ERR_INVALID_ARG; }
-    if (m->kind != jolt_member::kExpr) {
+    if (m->has_split_eq()) {
         size_t n = m->rounds;
         size_t current_index = n - m->bound;
         Fr p = m->w[current_index - 1];
@@ -1112,6 +1137,9 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             T.args.fused[c] = it.fused ? 1u : 0u;
             T.args.g.ticket[c] = (uint32_t)j;
             T.args.g.slot[c] = (uint32_t)it.slot;
+            T.args.g.e_out[c] = m->eq_weighted ? m->e_out_cache[m->e_out_bits]->data() : nullptr;
+            T.args.g.e_in[c] = m->eq_weighted ? m->e_in_cache[m->e_in_bits]->data() : nullptr;
+            T.args.g.in_bits[c] = (int32_t)m->e_in_bits;
             size_t work = (m->len / 2) * std::max<uint32_t>(1, m->desc.n_groups);
             T.gx = std::max<unsigned>(T.gx, (unsigned)std::min<size_t>((work + kBlock - 1) / kBlock, 256));
             T.gz = std::max<unsigned>(T.gz, (unsigned)it.ne);
@@ -1151,6 +1179,9 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             for (size_t k = 0; k < mj->tables.size(); ++k) { L.args.tabs[cursor] = it.in[k]; L.args.outs[cursor] = it.out[k]; cursor++; }
             L.args.ticket[c] = (uint32_t)j;
             L.args.slot[c] = (uint32_t)it.slot;
+            L.args.e_out[c] = mj->eq_weighted ? mj->e_out_cache[mj->e_out_bits]->data() : nullptr;
+            L.args.e_in[c] = mj->eq_weighted ? mj->e_in_cache[mj->e_in_bits]->data() : nullptr;
+            L.args.in_bits[c] = (int32_t)mj->e_in_bits;
             L.grid = std::max<unsigned>(L.grid, (unsigned)sweep_grid(ctx, (mj->len / 2) * std::max<uint32_t>(1, mj->desc.n_groups)));
             L.who.push_back(j);
             it.done = true;
@@ -1340,7 +1371,7 @@ static int32_t round_wait(jolt_ctx* ctx, size_t count, jolt_fr_t* out) {
 static void member_aux(const jolt_member* m, jolt_fr_t* aux) {
     if (!aux) return;
     Fr z = Fr::zero();
-    if (m->kind != jolt_member::kExpr && m->bound < m->rounds) {
+    if (m->has_split_eq() && m->bound < m->rounds) {
         fr_to_abi(&aux[0], m->current_scalar);
         fr_to_abi(&aux[1], m->w[m->rounds - m->bound - 1]);
     } else {
@@ -1457,7 +1488,7 @@ static int engine_eligible(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* me
     int rounds = -1;
     for (size_t i = 0; i < n; ++i) {
         const jolt_member* m = members[i];
-        if (m->order != JOLT_ORDER_LOW_TO_HIGH || m->lazy_width || m->kind == jolt_member::kSplitEqBooleanity) return 0;
+        if (m->order != JOLT_ORDER_LOW_TO_HIGH || m->lazy_width || m->kind == jolt_member::kSplitEqBooleanity || m->eq_weighted) return 0;
         if ((binds && binds[i] != nullptr) != has_bind) return 0;
         if (has_bind && !(*binds[i] == *binds[0])) return 0;
         size_t len = has_bind ? m->len / 2 : m->len;
@@ -1749,7 +1780,7 @@ extern "C" int32_t jolt_member_finish(jolt_member* m, const jolt_fr_t* bind) {
 extern "C" int32_t jolt_member_final_values(jolt_member* m, jolt_fr_t* out, size_t k) {
     if (!m || !out) return JOLT_ERR_INVALID_ARG;
     if (m->bound != m->rounds) return JOLT_ERR_NOT_FULLY_BOUND;
-    size_t need = m->tables.size() + (m->kind != jolt_member::kExpr ? 1 : 0);
+    size_t need = m->tables.size() + (m->has_split_eq() ? 1 : 0);
     if (k != need) return JOLT_ERR_SIZE_MISMATCH;
     jolt_ctx* ctx = m->ctx;
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, need));
@@ -1758,7 +1789,7 @@ extern "C" int32_t jolt_member_final_values(jolt_member* m, jolt_fr_t* out, size
     JOLT_TRY(fetch_results(ctx, m->tables.size(), out));
     for (size_t i = 0; i < m->final_unscale.size(); ++i)
         if (!(m->final_unscale[i] == Fr::one())) fr_to_abi(&out[i], mul(fr_from_abi(&out[i]), m->final_unscale[i]));
-    if (m->kind != jolt_member::kExpr) fr_to_abi(&out[m->tables.size()], m->current_scalar);
+    if (m->has_split_eq()) fr_to_abi(&out[m->tables.size()], m->current_scalar);
     return JOLT_OK;
 }
 
@@ -1793,13 +1824,66 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     jolt_ctx* ctx = m->ctx;
     int grid = sweep_grid(ctx, m->len);
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid, 8));
-    if (m->kind == jolt_member::kExpr) {
+    if (m->kind == jolt_member::kExpr && !m->eq_weighted) {
         TablePtrs tp;
         for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
         hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)m->d_desc, tp, m->len, ctx->d_partials);
         JOLT_HIP_TRY(ctx, hipGetLastError());
         JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
         return fetch_results(ctx, 1, out);
+    }
+    if (m->eq_weighted) {  // sum_x scale * eq(w[..remaining], x) * q(x): the inner descriptor with the dense eq table as one more factor
+        size_t rem = m->rounds - m->bound;
+        jolt_table* eq = nullptr;
+        JOLT_TRY(eq_build(ctx, m->w.data(), rem, m->current_scalar, 8, nullptr, &eq));
+        MemberDesc md = m->desc;  // groups g: factors [f0, f1) ++ one new factor {eq}
+        const uint32_t G = md.n_groups, eq_tab = (uint32_t)m->tables.size();
+        int32_t st = JOLT_OK;
+        if (md.n_factors + G > (uint32_t)kMaxFactors || md.n_lc + G > (uint32_t)kMaxLc || eq_tab + 1 > (uint32_t)kMaxBatchTables) st = JOLT_ERR_UNSUPPORTED;
+        MemberDesc nd;
+        std::memset(&nd, 0, sizeof(nd));
+        if (st == JOLT_OK) {
+            nd.n_groups = G;
+            uint32_t nf = 0, nl = 0;
+            for (uint32_t g = 0; g < G; ++g) {
+                nd.grp_fac_off[g] = nf;
+                for (uint32_t f = md.grp_fac_off[g]; f < md.grp_fac_off[g + 1]; ++f) {
+                    nd.fac_lc_off[nf] = nl;
+                    nd.fac_has_const[nf] = md.fac_has_const[f];
+                    nd.fac_const[nf] = md.fac_const[f];
+                    for (uint32_t k = md.fac_lc_off[f]; k < md.fac_lc_off[f + 1]; ++k) {
+                        nd.lc_tab[nl] = md.lc_tab[k]; nd.lc_one[nl] = md.lc_one[k]; nd.lc_coeff[nl] = md.lc_coeff[k]; nd.lc_owner[nl] = 0;
+                        nl++;
+                    }
+                    nf++;
+                }
+                nd.fac_lc_off[nf] = nl;  // the eq factor
+                nd.lc_tab[nl] = eq_tab; nd.lc_one[nl] = 1; nd.lc_coeff[nl] = Fr::one();
+                nl++;
+                nf++;
+            }
+            nd.grp_fac_off[G] = nf;
+            nd.fac_lc_off[nf] = nl;
+            nd.n_factors = nf;
+            nd.n_lc = nl;
+        }
+        MemberDesc* dd = nullptr;
+        if (st == JOLT_OK && hipMalloc((void**)&dd, sizeof(MemberDesc)) != hipSuccess) st = JOLT_ERR_OOM;
+        if (st == JOLT_OK && hipMemcpyAsync(dd, &nd, sizeof(nd), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
+        if (st == JOLT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
+        if (st == JOLT_OK) {
+            TablePtrs tp;
+            for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
+            tp.p[eq_tab] = eq->data();
+            hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)dd, tp, m->len, ctx->d_partials);
+            if (hipGetLastError() != hipSuccess) st = JOLT_ERR_HIP;
+        }
+        if (st == JOLT_OK) st = reduce_into_results(ctx, grid, 1, 0);
+        if (st == JOLT_OK) st = fetch_results(ctx, 1, out);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (dd) (void)hipFree(dd);
+        jolt_table_free(ctx, eq);
+        return st;
     }
     if (m->kind == jolt_member::kSplitEqBooleanity) { ctx->last_error = "input_claim helper: not provided for the booleanity member (its claim is the zero check's)"; return JOLT_ERR_UNSUPPORTED; }
     // split-eq members: sum_x scale * eq(w[..remaining], x) * (product terms) with the dense eq table (claim helper only)

@@ -184,7 +184,7 @@ size_t DeviceMember::num_rounds() const { return m->rounds; }
 size_t DeviceMember::n_evals() const { return jolt_internal_member_n_evals(m); }
 
 bool DeviceMember::next_l1(bool has_bind, const Fr& c, Fr* l1) const {
-    if (m->kind == jolt_member::kExpr) return false;
+    if (!m->has_split_eq()) return false;
     size_t bound = m->bound;
     Fr scalar = m->current_scalar;
     if (has_bind) {  // split_eq.rs:334-337, as member_note_bind will apply it
@@ -208,6 +208,10 @@ int32_t DeviceMember::assemble(const Fr* evals, const Fr& previous_claim, Univar
     if (m->kind == jolt_member::kSplitEqUniform) {
         size_t current_index = m->rounds - m->bound;
         return gruen_poly_from_q(m->current_scalar, m->w[current_index - 1], evals, m->uni_F, previous_claim, out, inv_l1);
+    }
+    if (m->eq_weighted) {  // eq * q members: q(0), q(2), .., q(dq) -> s = l * q (GruenRoundMessage::checked_round_poly, support.rs:340-412)
+        size_t current_index = m->rounds - m->bound;
+        return gruen_poly_from_q(m->current_scalar, m->w[current_index - 1], evals, m->degree, previous_claim, out, inv_l1);
     }
     std::vector<Fr> full;
     if (m->skip_one) {

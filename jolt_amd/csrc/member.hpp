@@ -19,6 +19,11 @@ struct jolt_member {
     std::vector<jolt_table*> tables;  // owned
     jolt::MemberDesc desc;            // host copy
     jolt::MemberDesc* d_desc = nullptr;
+    // kExpr with the eq weight factored out (the optimized tier's eq(r,j) * q(j) members, e.g. optimized/instruction_input.rs:1-22):
+    // `desc` is the INNER summand q of degree `degree` (s(1) skipped), every pair's product values are multiplied by E_out*E_in of
+    // its row, the host assembles s(t) = l(t) q(t) (gruen_poly_from_q); the message degree is degree + 1.
+    bool eq_weighted = false;
+    bool has_split_eq() const { return kind != kExpr || eq_weighted; }
     // split-eq state (GruenSplitEqPolynomial, crates/jolt-poly/src/split_eq.rs:159-166)
     std::vector<Fr> w;
     Fr current_scalar, initial_scalar;

@@ -53,9 +53,12 @@ __device__ __forceinline__ void load_pair(const Fr* __restrict__ tp, Fr* __restr
     }
 }
 
+// e_out != nullptr: eq-weighted member -- the product values of pair y are multiplied by E_out[y >> in_bits] * E_in[y & mask]
+// (GruenSplitEqPolynomial::par_fold_out_in's row weight, crates/jolt-poly/src/split_eq.rs:449-512) and `d` is the inner summand.
 template <int NE, int ORDER, bool SKIP1, bool FUSED>
 __device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ d, const Fr* const* __restrict__ tabs, Fr* const* __restrict__ outs,
-                                                 size_t half, const Fr& r, bool shifted, Fr* __restrict__ partials) {
+                                                 size_t half, const Fr& r, bool shifted, Fr* __restrict__ partials, const Fr* __restrict__ e_out = nullptr,
+                                                 const Fr* __restrict__ e_in = nullptr, int in_bits = 0) {
     Fr acc[NE];
 #pragma unroll
     for (int t = 0; t < NE; ++t) acc[t] = Fr::zero();
@@ -105,6 +108,11 @@ __device__ __forceinline__ void round_evals_body(const MemberDesc* __restrict__ 
 #pragma unroll
             for (int t = 0; t < NE; ++t) prod[t] = Fr::one();
         }
+        if (e_out) {
+            const Fr e = mul(ld_fr(e_out + (y >> in_bits)), ld_fr(e_in + (y & (((size_t)1 << in_bits) - 1))));
+#pragma unroll
+            for (int t = 0; t < NE; ++t) prod[t] = mul(prod[t], e);
+        }
 #pragma unroll
         for (int t = 0; t < NE; ++t) acc[t] = add(acc[t], prod[t]);
     }
@@ -124,12 +132,15 @@ struct RoundGroupArgs {
     uint32_t part_off[kMaxGroupMembers];  // offset (in Fr) of the member's partial sums
     uint32_t ticket[kMaxGroupMembers];    // per-member ticket counter index
     uint32_t slot[kMaxGroupMembers];      // result slot of the member's first sum
+    const Fr* e_out[kMaxGroupMembers];    // eq-weighted members: E tables in force this round (null otherwise)
+    const Fr* e_in[kMaxGroupMembers];
+    int32_t in_bits[kMaxGroupMembers];
 };
 template <int NE, int ORDER, bool SKIP1, bool FUSED>
 static __global__ __launch_bounds__(kBlock) void k_round_evals_group(RoundGroupArgs a, Fr r, int shifted, Fr* __restrict__ partials, RoundDone rd) {
     const int m = blockIdx.y;
     round_evals_body<NE, ORDER, SKIP1, FUSED>(a.desc[m], a.tabs + a.tab_off[m], a.outs + a.tab_off[m], a.half[m], r, shifted != 0,
-                                              partials + a.part_off[m]);
+                                              partials + a.part_off[m], a.e_out[m], a.e_in[m], a.in_bits[m]);
     finish_member(partials + a.part_off[m], NE, a.ticket[m], a.slot[m], rd);
 }
 
@@ -188,6 +199,10 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, 
             Fr step = sub(hi, lo), v = lo;
             for (uint32_t q = 0; q < point; ++q) v = add(v, step);
             prod = f == f0 ? v : mul(prod, v);
+        }
+        if (a.g.e_out[m]) {  // eq-weighted member
+            const int ib = a.g.in_bits[m];
+            prod = mul(prod, mul(ld_fr(a.g.e_out[m] + (y >> ib)), ld_fr(a.g.e_in[m] + (y & (((size_t)1 << ib) - 1)))));
         }
         acc[0] = add(acc[0], prod);
     }

@@ -389,8 +389,8 @@ class ShardedWorkload:
         zero = np.zeros(4, dtype=np.uint64)
         self.resolver = W.Resolver(spec["gammas"], one, ffi.host_fr_mul, lambda x: ffi.host_fr_sub(zero, x))
         self.tables = {}
-        skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None}
-        skip -= {t for ms in self.members_spec for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
+        skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None or ms.eq_inner is not None}
+        skip -= {t for ms in self.members_spec for t in (ms.tables if (ms.uniform is None and ms.eq_inner is None) else ms.tables[1:])}
         # one-hot selector columns of uniform members stay index-encoded on every rank (lazily bound members, as on one GPU)
         # (only when the fourth bind -- the one that writes them dense -- comes before the hand-over to the tail)
         lazy = lambda ms: (ms.uniform is not None and n_local - self.tail_log >= 4
@@ -448,6 +448,16 @@ class ShardedWorkload:
                 self.members.append(m)
                 self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
                 continue
+            if ms.eq_inner is not None:  # eq(w, j) * q(j), the eq weight factored out on every rank (shard scale = eq(w_hi, rank))
+                dq, inner = ms.eq_inner
+                w = spec["tables"][ms.tables[0]]["point"]
+                groups = self.resolver.groups(inner)
+                m = ctx.member_lc(tabs[1:], groups, dq, borrow=True, eq_point=w[log_g:], shard_scale=shard_scale_of(w))
+                m._groups, m._dq = groups, dq
+                self.infos.append(MemberInfo(KIND_SPLIT_EQ_UNIFORM, dq + 1, self.n_total, len(tabs) - 1, w=w))
+                self.members.append(m)
+                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+                continue
             if ms.split_eq is not None:
                 a, b, _ = ms.split_eq
                 w = spec["split_points"][k]
@@ -495,7 +505,12 @@ class ShardedWorkload:
         one = ffi.host_fr_from_u64(1)
         eq = self.ctx.eq_evals_aligned_block(self.infos[i].w, self.rank << self.n_local, 1 << self.n_local)
         temp = []
-        if ms.uniform is not None:
+        if ms.eq_inner is not None:  # eq block as one more factor of every inner group
+            dq, _ = ms.eq_inner
+            cols = [self.tables[t] for t in ms.tables[1:]]
+            groups = [[(None, [(one, 0)])] + [(c, [(cf, 1 + ti) for cf, ti in ents]) for c, ents in g] for g in m._groups]
+            tmp = self.ctx.member_lc([eq] + cols, groups, dq + 1, borrow=True)
+        elif ms.uniform is not None:
             V, F, coeffs = m._uniform
             if getattr(m, "_lazy", None) is not None:  # index-encoded columns: gathered dense for this setup-time helper only
                 src, scale_tables, coeffs = m._lazy
@@ -551,6 +566,9 @@ class ShardedWorkload:
 
         def build_split(i, tabs, scalar):
             m = self.members[i]
+            if getattr(m, "eq_weighted", False):
+                tm = ctx.member_lc(tabs, m._groups, m._dq, borrow=True, eq_point=self.infos[i].w[:rem], eq_scale=scalar)
+                return tm
             if getattr(m, "uniform", False):
                 V, F, coeffs = m._uniform
                 return ctx.member_split_eq_uniform(tabs, V, F, coeffs, self.infos[i].w[:rem], scale=scalar, borrow=True)

@@ -189,9 +189,12 @@ class Context:
             t.h = None  # ownership moved into the member
         return Member(self, h, degree, len(tables), False, False)
 
-    def member_lc(self, tables, groups, degree, order=ORDER_LOW_TO_HIGH, skip_one=False, borrow=False):
+    def member_lc(self, tables, groups, degree, order=ORDER_LOW_TO_HIGH, skip_one=False, borrow=False, eq_point=None, eq_scale=None,
+                  shard_scale=None):
         """groups = [[factor, ...], ...]; factor = (const_limbs_or_None, [(coeff_limbs, table_idx), ...]).
-        borrow=True: the member only reads `tables` (caller keeps ownership, tables must outlive the member)."""
+        borrow=True: the member only reads `tables` (caller keeps ownership, tables must outlive the member).
+        eq_point: the summand is eq(eq_point, j) * (these groups) with the eq weight factored out (jolt_member_create_split_eq_lc);
+        `degree` is then the inner degree and prove_round returns q(0), q(2), .., q(degree)."""
         goff, foff, consts, ltab, lcoef = [0], [0], [], [], []
         zero = np.zeros(4, dtype=np.uint64)
         for g in groups:
@@ -212,8 +215,17 @@ class Context:
                          goff.ctypes.data, foff.ctypes.data, consts_a.ctypes.data, ltab_a.ctypes.data, lcoef_a.ctypes.data)
         hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
         h = C.c_void_p()
-        _ck(lib().jolt_member_create_lc(self.h, hs, C.byref(d), C.byref(h)), "jolt_member_create_lc", self)
-        m = Member(self, h, degree, len(tables), False, skip_one)
+        if eq_point is not None:
+            w = fr(eq_point).reshape(-1, 4)
+            _ck(lib().jolt_member_create_split_eq_lc(self.h, hs, C.byref(d), _p(w), C.c_size_t(w.shape[0]), _p(fr(eq_scale)) if eq_scale is not None else None,
+                                                     _p(fr(shard_scale)) if shard_scale is not None else None, C.byref(h)), "jolt_member_create_split_eq_lc", self)
+            m = Member(self, h, degree + 1, len(tables), True, True)
+            m.n_evals = degree
+            m.uniform = True  # same host-side shape as the uniform member: dq sums, gruen_poly_from_q
+            m.eq_weighted = True
+        else:
+            _ck(lib().jolt_member_create_lc(self.h, hs, C.byref(d), C.byref(h)), "jolt_member_create_lc", self)
+            m = Member(self, h, degree, len(tables), False, skip_one)
         if borrow:
             m._keepalive = list(tables)
         else:

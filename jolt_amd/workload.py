@@ -32,12 +32,14 @@ class TableSpec:
 
 
 class MemberSpec:
-    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, uniform=None, reference=""):
+    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, uniform=None, eq_inner=None, reference=""):
         self.name, self.stage, self.degree, self.tables = name, stage, degree, tables
         self.groups = groups        # LC form: [[(const|None, [(coeff, local_table_idx), ...]), ...], ...]
         self.split_eq = split_eq    # (a_idx, b_idx, w) for the split-eq product member
         self.uniform = uniform      # (V, F, [coeff symbols]): tables[0] is eq(w,.), tables[1 + v*F + i] the product tables;
                                     # the device serves eq from split tables (split-eq uniform member), the oracle uses `groups`
+        self.eq_inner = eq_inner    # (dq, inner groups over tables[1:]): the summand is eq(tables[0]) * q with the eq weight factored out
+                                    # on the device (jolt_member_create_split_eq_lc); `groups` stays the oracle's full form
         self.reference = reference  # reference file of the relation
 
 
@@ -77,7 +79,8 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
     t = [derived("s2.eq", "eq")] + [wit(f"s2.o{k}") for k in range(5)]
     members.append(MemberSpec("instruction_claim_reduction", 2, 2, t,
                               groups=[[(None, [("one", 0)]), (None, [(("gpow", 0, k), 1 + k) for k in range(5)])]],
-                              reference="crates/jolt-kernels/src/reference/instruction_claim_reduction.rs"))
+                              eq_inner=(1, [[(None, [(("gpow", 0, k), k) for k in range(5)])]]),
+                              reference="crates/jolt-kernels/src/optimized/instruction_claim_reduction.rs"))
     # ---- stage 3: spartan_shift  eq+1(tau,j)*(upc + g pc + g^2 virt + g^3 first) + g^4 eq+1(r,j)*(1 - noop)   deg 2, 7 tables
     t = [derived("s3.eq1a", "eq1"), wit("s3.upc"), wit("s3.pc"), wit("s3.virt", 1), wit("s3.first", 1), derived("s3.eq1b", "eq1"),
          wit("s3.noop", 1)]
@@ -93,11 +96,16 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
                                       [(None, [("one", 0)]), (None, [("one", 3)]), (None, [("one", 4)])],
                                       [(None, [(("gpow", 2, 1), 0)]), (None, [("one", 5)]), (None, [("one", 6)])],
                                       [(None, [(("gpow", 2, 1), 0)]), (None, [("one", 7)]), (None, [("one", 8)])]],
-                              reference="crates/jolt-kernels/src/reference/instruction_input.rs"))
+                              eq_inner=(2, [[(None, [("one", 0)]), (None, [("one", 1)])],
+                                            [(None, [("one", 2)]), (None, [("one", 3)])],
+                                            [(None, [(("gpow", 2, 1), 4)]), (None, [("one", 5)])],
+                                            [(None, [(("gpow", 2, 1), 6)]), (None, [("one", 7)])]]),
+                              reference="crates/jolt-kernels/src/optimized/instruction_input.rs:1-22"))
     # ---- stage 3: registers_claim_reduction  eq*(rd_w + g rs1 + g^2 rs2)                        deg 2, 4 tables
     t = [derived("s3.eq_reg", "eq"), wit("s3.rd_w"), wit("s3.rs1v"), wit("s3.rs2v")]
     members.append(MemberSpec("registers_claim_reduction", 3, 2, t,
                               groups=[[(None, [("one", 0)]), (None, [(("gpow", 3, k), 1 + k) for k in range(3)])]],
+                              eq_inner=(1, [[(None, [(("gpow", 3, k), k) for k in range(3)])]]),
                               reference="crates/jolt-kernels/src/reference/registers_claim_reduction.rs"))
     # ---- stage 4: ram_val_check  inc(j) * ra(j) * (LT(j,r) + g)                                  deg 3, 3 tables
     t = [wit("s4.inc"), derived("s4.ra", "eq"), derived("s4.lt", "lt")]
@@ -217,7 +225,9 @@ class DeviceWorkload:
         # one-hot selector columns that only feed uniform members stay index-encoded (1 byte per cycle, LazyFoldedRa)
         lazy = lambda ms: ms.uniform is not None and n_vars >= 4 and all(self.tables_spec[t].kind == "onehot" for t in ms.tables[1:])
         skip |= {t for ms in self.members_spec if lazy(ms) for t in ms.tables[1:]}
-        skip -= {t for ms in self.members_spec if not lazy(ms) for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
+        skip |= {ms.tables[0] for ms in self.members_spec if ms.eq_inner is not None}  # eq weight factored out: never materialised
+        used = lambda ms: ms.tables[1:] if (ms.uniform is not None or ms.eq_inner is not None) else ms.tables
+        skip -= {t for ms in self.members_spec if not lazy(ms) for t in used(ms)}
         for name, spec in self.tables_spec.items():
             if name not in skip:
                 self.tables[name] = self._make_table(spec)
@@ -236,6 +246,13 @@ class DeviceWorkload:
                 else:
                     tabs = [self.tables[t] for t in ms.tables[1:]]
                     m = ctx.member_split_eq_uniform(tabs, V, F, coeffs, w, borrow=True)
+                self.members.append(m)
+                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+                continue
+            if ms.eq_inner is not None:
+                dq, inner = ms.eq_inner
+                m = ctx.member_lc([self.tables[t] for t in ms.tables[1:]], self.resolver.groups(inner), dq, borrow=True,
+                                  eq_point=self.tables_spec[ms.tables[0]].point)
                 self.members.append(m)
                 self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
                 continue

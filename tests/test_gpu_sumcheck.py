@@ -251,3 +251,54 @@ def test_split_eq_uniform_product_member_lockstep(ctx, V, F, n_vars):
     dev.finish(bind)
     fv, ofv = dev.final_values(), orc.final_values()
     assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])  # bound tables, then the bound eq scalar
+
+
+@pytest.mark.parametrize("n_vars", [1, 5, 9, 14])
+def test_eq_weighted_lc_member_matches_oracle(ctx, n_vars):
+    """eq(w,j) * q(j) with the eq weight factored out (jolt_member_create_split_eq_lc): q = (f1*a + f2*b) + g*(f3*c) + const-factor
+    group, inner degree 2 -> two sums per round, s = l*q on the host.  Lock-step against the oracle's flat Expr member over the
+    dense eq table; borrowed tables, both challenge shapes, tail and grouped kernels (n_vars 14 crosses the tail threshold), and
+    again inside prove_batch next to an ordinary member."""
+    N = 1 << n_vars
+    w = rand_fr(n_vars, 5100)
+    scale = rand_fr(1, 5101)[0]
+    tabs = [rand_fr(N, 5110 + k) for k in range(6)]
+    g, c0 = rand_fr(1, 5120)[0], rand_fr(1, 5121)[0]
+    o = one()
+    dev_tabs = [ctx.upload(t) for t in tabs]
+    inner = [[(None, [(o, 0)]), (None, [(o, 1)])],          # f1 * a
+             [(None, [(o, 2)]), (None, [(o, 3)])],          # f2 * b
+             [(None, [(g, 4)]), (c0, [(o, 5)])]]            # g*f3 * (c0 + c)
+    dev = ctx.member_lc(dev_tabs, inner, 2, borrow=True, eq_point=w, eq_scale=scale)
+    eq = O.eq_evals(w, scale)
+    mul = lambda a, b: O.fr_mul(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+    terms = [(o, [0, 1, 2]), (o, [0, 3, 4]), (g, [0, 5, 6]), (mul(g, c0), [0, 5])]
+    def fresh():
+        return O.Member.expr([eq] + tabs, terms, 3)
+    for rep in range(2):
+        orc = fresh()
+        claim = orc.input_claim()
+        if rep == 0:
+            assert np.array_equal(dev.input_claim(), claim)
+        bind = None
+        for rnd in range(n_vars):
+            want = orc.prove_round(bind, claim)
+            evals, aux = dev.prove_round(bind, want_aux=True)
+            got = ffi.host_gruen_poly_from_q(aux[0], aux[1], evals, claim)
+            assert np.array_equal(got, want), f"rep {rep} round {rnd}"
+            bind = rand_challenge(5130 + rnd) if rnd % 2 == 0 else rand_fr(1, 5130 + rnd)[0]
+            claim = O.univariate_evaluate(want, bind)
+        orc.finish_rounds(bind)
+        dev.finish(bind)
+        fv, ofv = dev.final_values(), orc.final_values()
+        assert np.array_equal(fv[:-1], ofv[1:]) and np.array_equal(fv[-1], ofv[0])
+        dev.reset()
+    a, b = rand_fr(N, 5140), rand_fr(N, 5141)
+    flat = ctx.member_expr([ctx.upload(a), ctx.upload(b)], [(o, [0, 1])], 2)
+    orcs = [fresh(), O.Member.expr([a, b], [(o, [0, 1])], 2)]
+    claims = [m.input_claim() for m in orcs]
+    cf = list(rand_fr(2, 5150))
+    want = O.prove_batch(orcs, claims, cf, [0, 0], n_vars, 3, label=6)
+    got = ctx.prove_batch([dev, flat], claims, cf, [0, 0], n_vars, 3, label=6)
+    for k in ("polys", "challenges", "member_claims", "final_claim"):
+        assert np.array_equal(got[k], want[k]), k
