@@ -54,7 +54,9 @@ class Collective:
 
 
 def _loaded_rccl_path():
-    """The librccl that torch already mapped into this process (so that the native communicator shares it)."""
+    """The librccl the native communicator should share with torch.distributed: the copy torch already mapped into this process,
+    else torch's bundled one (the system RCCL under /opt/rocm is built against another HIP/HSA runtime than the one torch
+    brought into the process and fails to find a device)."""
     try:
         with open("/proc/self/maps") as f:
             for line in f:
@@ -62,12 +64,24 @@ def _loaded_rccl_path():
                     return line.split()[-1]
     except OSError:
         pass
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            return cand
+    except ImportError:
+        pass
     return None
 
 
 class NativeCollective:
     """RCCL communicator owned by libjolt_hip.so (jolt_comm_*): rank 0 draws the ncclUniqueId, torch.distributed
-    broadcasts it, every rank joins.  The round loop then calls RCCL without going through Python."""
+    broadcasts it, every rank joins.  The round loop then calls RCCL without going through Python.
+
+    Load order: the RCCL used is the one bundled with torch, which resolves its own copy of the HSA runtime; `import torch` (as
+    every torch.distributed launcher does) must therefore happen BEFORE libjolt_hip.so is loaded, so that one HIP/HSA runtime
+    serves both -- otherwise ncclCommInitRank reports "no ROCm-capable device".  ShardedWorkload falls back to the
+    torch.distributed collective (collectively, on every rank) when the native communicator cannot be created."""
 
     def __init__(self, ctx, dist, rank, world, device=None):
         import torch
@@ -455,6 +469,20 @@ class ShardedWorkload:
                 m = ctx.member_lc(tabs[1:], groups, dq, borrow=True, eq_point=w[log_g:], shard_scale=shard_scale_of(w))
                 m._groups, m._dq = groups, dq
                 self.infos.append(MemberInfo(KIND_SPLIT_EQ_UNIFORM, dq + 1, self.n_total, len(tabs) - 1, w=w))
+                self.members.append(m)
+                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+                continue
+            if ms.fused is not None:  # linear-leaf fusion on every rank: the fused leaf is the same combination of the rank's blocks
+                parts, names, fgroups = ms.fused
+                for fname, entries in parts:
+                    srcs = [self.tables[ms.tables[ti]] for _, ti in entries]
+                    self.tables[fname] = ctx.rlc(srcs, np.stack([self.resolver.coeff(c) for c, _ in entries]))
+                ctx.synchronize()
+                groups = self.resolver.groups(fgroups)
+                ftabs = [self.tables[t] for t in names]
+                m = ctx.member_lc(ftabs, groups, ms.degree, borrow=True, skip_one=True)
+                m._groups = groups
+                self.infos.append(MemberInfo(KIND_EXPR_SKIP, ms.degree, self.n_total, len(ftabs)))
                 self.members.append(m)
                 self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
                 continue

@@ -32,7 +32,7 @@ class TableSpec:
 
 
 class MemberSpec:
-    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, uniform=None, eq_inner=None, reference=""):
+    def __init__(self, name, stage, degree, tables, groups=None, split_eq=None, uniform=None, eq_inner=None, fused=None, reference=""):
         self.name, self.stage, self.degree, self.tables = name, stage, degree, tables
         self.groups = groups        # LC form: [[(const|None, [(coeff, local_table_idx), ...]), ...], ...]
         self.split_eq = split_eq    # (a_idx, b_idx, w) for the split-eq product member
@@ -40,6 +40,8 @@ class MemberSpec:
                                     # the device serves eq from split tables (split-eq uniform member), the oracle uses `groups`
         self.eq_inner = eq_inner    # (dq, inner groups over tables[1:]): the summand is eq(tables[0]) * q with the eq weight factored out
                                     # on the device (jolt_member_create_split_eq_lc); `groups` stays the oracle's full form
+        self.fused = fused          # linear-leaf fusion (optimized/inc_claim_reduction.rs:6-13,68-89): ([(fused name, [(coeff, local idx), ..]) ..],
+                                    # device table list (names or fused names), device groups) -- A = sum_i s_i * eq(p_i) built once per proof
         self.reference = reference  # reference file of the relation
 
 
@@ -121,6 +123,8 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
     t = [derived("s5.eq1", "eq"), derived("s5.eq2", "eq"), derived("s5.eq3", "eq"), derived("s5.ra", "eq")]
     members.append(MemberSpec("ram_ra_claim_reduction", 5, 2, t,
                               groups=[[(None, [(("gpow", 5, k), k) for k in range(3)]), (None, [("one", 3)])]],
+                              fused=([("s5.eqA", [(("gpow", 5, k), k) for k in range(3)])], ["s5.eqA", "s5.ra"],
+                                     [[(None, [("one", 0)]), (None, [("one", 1)])]]),
                               reference="crates/jolt-kernels/src/reference/ram_ra_claim_reduction.rs"))
     # ---- stage 6b: inc_claim_reduction  (eq1 + g eq2) RamInc + g^2 (eq3 + g eq4) RdInc           deg 2, 6 tables
     t = [derived("s6.eq1", "eq"), derived("s6.eq2", "eq"), wit("s6.ram_inc"), derived("s6.eq3", "eq"), derived("s6.eq4", "eq"),
@@ -128,6 +132,9 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
     members.append(MemberSpec("inc_claim_reduction", 6, 2, t,
                               groups=[[(None, [("one", 0), (("gpow", 6, 1), 1)]), (None, [("one", 2)])],
                                       [(None, [(("gpow", 6, 2), 3), (("gpow", 6, 3), 4)]), (None, [("one", 5)])]],
+                              fused=([("s6.eqA", [("one", 0), (("gpow", 6, 1), 1)]), ("s6.eqB", [(("gpow", 6, 2), 3), (("gpow", 6, 3), 4)])],
+                                     ["s6.eqA", "s6.ram_inc", "s6.eqB", "s6.rd_inc"],
+                                     [[(None, [("one", 0)]), (None, [("one", 1)])], [(None, [("one", 2)]), (None, [("one", 3)])]]),
                               reference="crates/jolt-kernels/src/optimized/inc_claim_reduction.rs:6-13,68-89"))
     # ---- stage 6b: ram_hamming_booleanity  eq(r,j) * (H^2 - H) = eq * H * (H - 1)                deg 3, split-eq member
     t = [wit("s6.H", 1), "s6.H_minus_1"]
@@ -253,6 +260,16 @@ class DeviceWorkload:
                 dq, inner = ms.eq_inner
                 m = ctx.member_lc([self.tables[t] for t in ms.tables[1:]], self.resolver.groups(inner), dq, borrow=True,
                                   eq_point=self.tables_spec[ms.tables[0]].point)
+                self.members.append(m)
+                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+                continue
+            if ms.fused is not None:  # A = sum_i s_i * leaf_i as ONE resident table (jolt_rlc), then the ordinary member over fewer tables
+                parts, names, groups = ms.fused
+                for fname, entries in parts:
+                    srcs = [self.tables[ms.tables[ti]] for _, ti in entries]
+                    self.tables[fname] = ctx.rlc(srcs, np.stack([self.resolver.coeff(c) for c, _ in entries]))
+                ctx.synchronize()
+                m = ctx.member_lc([self.tables[t] for t in names], self.resolver.groups(groups), ms.degree, borrow=True, skip_one=True)
                 self.members.append(m)
                 self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
                 continue
