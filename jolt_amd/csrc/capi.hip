@@ -852,6 +852,19 @@ static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, cons
             }
         }
     }
+    // first-round pair tables (F = 4, K <= 16, coefficients folded in): P[v][h][a*17+b] = T_{4v+2h}[a] * T_{4v+2h+1}[b], row/column 16 = 0
+    std::vector<Fr> host_pair;
+    if (s == JOLT_OK && !booleanity && F == 4 && K <= 16 && m->uni_prescaled) {
+        host_pair.assign((size_t)V * 2 * 289, Fr::zero());
+        for (uint32_t v = 0; v < V; ++v)
+            for (int h = 0; h < 2; ++h) {
+                const Fr* T0 = &host_tables[((size_t)v * 4 + 2 * h) * K];
+                const Fr* T1 = &host_tables[((size_t)v * 4 + 2 * h + 1) * K];
+                Fr* P = &host_pair[((size_t)v * 2 + h) * 289];
+                for (size_t x = 0; x < K; ++x)
+                    for (size_t y = 0; y < K; ++y) P[x * 17 + y] = mul(T0[x], T1[y]);
+            }
+    }
     // dense targets of the fourth bind (cycles/16 entries each); until then `len` is bookkeeping only
     for (size_t p = 0; p < N && s == JOLT_OK; ++p) {
         jolt_table* t = nullptr;
@@ -863,6 +876,8 @@ static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, cons
         if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[0], N * 16 * K * sizeof(Fr));
         if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[1], N * 16 * K * sizeof(Fr));
         if (e == hipSuccess) e = hipMemcpyAsync(m->d_base, host_tables.data(), N * K * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && !host_pair.empty()) e = hipMalloc((void**)&m->d_pair, host_pair.size() * sizeof(Fr));
+        if (e == hipSuccess && !host_pair.empty()) e = hipMemcpyAsync(m->d_pair, host_pair.data(), host_pair.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(m->d_branch[0], m->d_base, N * K * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host buffer may be short-lived
         if (e != hipSuccess) { ctx->last_error = std::string("lazy member: ") + hipGetErrorString(e); s = e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP; }
@@ -1252,7 +1267,14 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             la.K = m->onehot->k;
             la.V = ua.V;
             for (size_t v = 0; v < (size_t)kMaxGroups; ++v) { la.coeff[v] = ua.coeff[v]; la.coeff_one[v] = ua.coeff_one[v]; }
-            if (it.rows_major) {
+            if (m->lazy_width == 1 && m->d_pair && m->uni_F == 4) {  // unbound columns: quadratic halves from the pair tables, no multiplies
+                LazyPairArgs pa;
+                pa.idx = m->onehot->idx;
+                pa.pair = m->d_pair;
+                pa.cycles0 = m->onehot->cycles;
+                pa.V = ua.V;
+                hipLaunchKernelGGL(k_split_eq_uniform_lazy_first, g, b, 0, st, pa, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            } else if (it.rows_major) {
                 if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<2>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
                 else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<3>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
                 else hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<4>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
@@ -1950,6 +1972,7 @@ extern "C" int32_t jolt_member_destroy(jolt_member* m) {
     if (m->d_desc) (void)hipFree(m->d_desc);
     for (int k = 0; k < 2; ++k) if (m->d_branch[k]) (void)hipFree(m->d_branch[k]);
     if (m->d_base) (void)hipFree(m->d_base);
+    if (m->d_pair) (void)hipFree(m->d_pair);
     delete m;
     return JOLT_OK;
 }

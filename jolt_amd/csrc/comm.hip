@@ -6,8 +6,9 @@
 // exchange than the round kernels themselves at the late rounds, so the data path calls RCCL directly: rendezvous stays
 // with torch.distributed (it broadcasts the ncclUniqueId), the collectives are enqueued on the context's own stream.
 //
-// RCCL is resolved at run time with dlopen (the library that torch already mapped, same SONAME), so libjolt_hip.so has no
-// link-time dependency on it and still loads in the CPU-only container.
+// RCCL is resolved at run time with dlopen, so libjolt_hip.so has no link-time dependency on it and still loads in the CPU-only
+// container.  The caller names the library: it must be the RCCL built against the HIP runtime THIS library uses (the system one);
+// a process that imported torch also holds torch's private HIP/HSA runtime and librccl, and streams do not cross runtimes.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 

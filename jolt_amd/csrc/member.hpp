@@ -41,6 +41,9 @@ struct jolt_member {
     uint32_t lazy_width = 0;  // 0: dense state; 1, 2, 4, 8: index-encoded with that many branches
     Fr* d_branch[2] = {nullptr, nullptr};  // ping-pong branch tables [poly][width*K] (capacity 16*K per polynomial)
     int branch_cur = 0;
+    // F = 4, unbound state only: pair tables P[v][h][a*17+b] = T_{4v+2h}[a] * T_{4v+2h+1}[b] (index 16 = cold = 0), so that the first
+    // round's quadratic halves (f0*f1 at 0, 1, 2) are gathers and additions instead of three multiplies each
+    Fr* d_pair = nullptr;
     Fr* d_base = nullptr;     // the unbound scale tables [poly][K] (kept for jolt_member_reset), product coefficients folded in
     // c_v is pre-scaled into the scale table of product v's first factor (the reference's gamma pre-scaling,
     // optimized/booleanity.rs:32-38): kernels see coefficient one, the reported final values are multiplied by unscale[table]

@@ -269,6 +269,17 @@ __device__ __forceinline__ void uniform_item<3>(const Fr (&lo)[3], const Fr (&hi
     q[1] = mul(mul(a2, b2), c2);
     q[2] = mul(mul(a3, b3), c3);
 }
+// q = A*B on {0,2,3,4} from the quadratic halves A = f0*f1, B = f2*f3 given on {0,1,2} (extended to {3,4} by second differences)
+__device__ __forceinline__ void uniform_quadratic_halves(const Fr& A0, const Fr& A1, const Fr& A2, const Fr& B0, const Fr& B1, const Fr& B2, Fr (&q)[4]) {
+    Fr dA = sub(A2, A1), ddA = sub(dA, sub(A1, A0));
+    Fr dB = sub(B2, B1), ddB = sub(dB, sub(B1, B0));
+    Fr dA3 = add(dA, ddA), A3 = add(A2, dA3), A4 = add(A3, add(dA3, ddA));
+    Fr dB3 = add(dB, ddB), B3 = add(B2, dB3), B4 = add(B3, add(dB3, ddB));
+    q[0] = mul(A0, B0);
+    q[1] = mul(A2, B2);
+    q[2] = mul(A3, B3);
+    q[3] = mul(A4, B4);
+}
 template <>
 __device__ __forceinline__ void uniform_item<4>(const Fr (&lo)[4], const Fr (&hi)[4], Fr (&q)[4]) {
     // A = f0*f1, B = f2*f3 as quadratics on {0,1,2}; extend both to {3,4} by second differences; q = A*B on {0,2,3,4}

@@ -53,24 +53,31 @@ class Collective:
         return out.cpu().numpy().view(np.uint64).reshape(self.world, -1)
 
 
-def _loaded_rccl_path():
-    """The librccl the native communicator should share with torch.distributed: the copy torch already mapped into this process,
-    else torch's bundled one (the system RCCL under /opt/rocm is built against another HIP/HSA runtime than the one torch
-    brought into the process and fails to find a device)."""
+def _system_rccl_path():
+    """The RCCL that lives next to the HIP runtime libjolt_hip.so itself uses.
+
+    libjolt_hip.so is linked against the system libamdhip64 (under $ROCM_PATH), torch ships its own copy of the HIP and HSA runtimes
+    with a different SONAME, so a process that imports torch holds TWO runtimes.  The context's stream and buffers belong to the
+    system runtime; handing them to torch's bundled librccl (linked against torch's runtime) would cross runtimes.  The native
+    communicator therefore opens the system librccl by ABSOLUTE path (a bare "librccl.so.1" would be de-duplicated by SONAME to
+    the copy torch mapped).  JOLT_RCCL_PATH overrides."""
+    env = os.environ.get("JOLT_RCCL_PATH")
+    if env:
+        return env
+    hip_dir = None
     try:
         with open("/proc/self/maps") as f:
             for line in f:
-                if "librccl" in line:
-                    return line.split()[-1]
+                path = line.split()[-1] if line.strip() else ""
+                if "libamdhip64" in path and "/torch/" not in path:
+                    hip_dir = os.path.dirname(path)
+                    break
     except OSError:
         pass
-    try:
-        import torch
-        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    for d in ([hip_dir] if hip_dir else []) + [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]:
+        cand = os.path.join(d, "librccl.so.1")
         if os.path.exists(cand):
             return cand
-    except ImportError:
-        pass
     return None
 
 
@@ -78,29 +85,27 @@ class NativeCollective:
     """RCCL communicator owned by libjolt_hip.so (jolt_comm_*): rank 0 draws the ncclUniqueId, torch.distributed
     broadcasts it, every rank joins.  The round loop then calls RCCL without going through Python.
 
-    Load order: the RCCL used is the one bundled with torch, which resolves its own copy of the HSA runtime; `import torch` (as
-    every torch.distributed launcher does) must therefore happen BEFORE libjolt_hip.so is loaded, so that one HIP/HSA runtime
-    serves both -- otherwise ncclCommInitRank reports "no ROCm-capable device".  ShardedWorkload falls back to the
-    torch.distributed collective (collectively, on every rank) when the native communicator cannot be created."""
+    Which RCCL: the system one next to the HIP runtime the context lives in (`_system_rccl_path`), never torch's bundled copy.
+    ShardedWorkload falls back to the torch.distributed collective (collectively, on every rank) when the native communicator
+    cannot be created."""
 
     def __init__(self, ctx, dist, rank, world, device=None):
-        import torch
         lib = ffi.lib()
         self.ctx, self.rank, self.world = ctx, rank, world
-        path = _loaded_rccl_path()
+        path = _system_rccl_path()
         self._path = path.encode() if path else None
         uid = (C.c_uint8 * 128)()
         if rank == 0:
             st = lib.jolt_comm_unique_id(self._path, uid)
             if st:
                 raise ffi.JoltError(st, "jolt_comm_unique_id")
-        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
-        if device is not None:
-            t = t.to(device)
-        if world > 1:
+        if world > 1:  # torch.distributed carries the 128 bytes to the other ranks (and is already imported by the launcher)
+            import torch
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8)
+            if device is not None:
+                t = t.to(device)
             dist.broadcast(t, src=0)
-        raw = bytes(t.cpu().tolist())
-        uid = (C.c_uint8 * 128)(*raw)
+            uid = (C.c_uint8 * 128)(*bytes(t.cpu().tolist()))
         h = C.c_void_p()
         # RCCL prints its version banner on C stdout at communicator creation; bench.py's stdout carries exactly one JSON
         # line, so fd 1 points at stderr while the communicator is built (and the C stdio buffer is flushed there)

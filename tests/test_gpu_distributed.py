@@ -92,7 +92,6 @@ def test_native_rccl_communicator_single_rank():
     """The RCCL communicator owned by the library (dlopen'd librccl, ncclCommInitRank, ncclAllGather on the context stream)
     with world = 1 -- the only size a one-GPU box can run: host and table all-gathers are identities, and the sharded
     workload proved through it (native gather hook + device hand-over) gives the same transcript for every tail_log."""
-    import torch  # noqa: F401 -- FIRST: torch's bundled RCCL must find torch's own HIP/HSA runtime initialised (see distributed.py)
     from jolt_amd import distributed as D
     from jolt_amd import ffi
     from util import rand_fr
