@@ -165,10 +165,11 @@ def test_hyperkzg_commit_open_bit_exact_with_oracle(ctx, ell):
     assert e.value.status == 9
 
 
-def test_full_size_msm_is_the_kzg_commitment(ctx):
-    """N = 2^20 terms (BASELINE configs[2] scale): commit(p) with bases beta^i*G must equal p(beta)*G
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_full_size_msm_is_the_kzg_commitment(ctx, log_n):
+    """N = 2^20 / 2^22 terms (BASELINE configs[2] scale): commit(p) with bases beta^i*G must equal p(beta)*G
     (size-independent identity; p(beta) from the oracle's Horner evaluation, one scalar multiplication)."""
-    n = 1 << 20
+    n = 1 << log_n
     beta = rand_fr(1, 400)[0]
     g = O.g1_generator()
     srs = ctx.srs_setup_from_secret(beta, n, g)
