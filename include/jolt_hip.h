@@ -388,6 +388,23 @@ int32_t jolt_onehot_download(jolt_ctx *ctx, const jolt_onehot *source, uint8_t *
 int32_t jolt_member_create_lazy_booleanity(jolt_ctx *ctx, const jolt_onehot *source, const jolt_fr_t *scale_tables, const jolt_fr_t *rho,
                                            const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, jolt_member **out);
 
+/* Dory tier-1 (G1) streaming row commitments -- SURVEY.md section 8(f) row 2.  Replaces the MSM work of
+ * DoryScheme::{feed_u64, feed_i128, feed_i128_rows_with} (crates/jolt-dory/src/streaming.rs:115-205: one ark msm_u64 / msm_i128
+ * per row_width window over the first row_width G1 bases) and of process_one_hot_chunk(s_with) -> one_hot_chunk_commitments
+ * (:230-275, :366-419: per chunk, commitment[k] = sum of the bases of the columns whose hot row is k).  The tier-2 pairing
+ * product stays with the caller.  Integers are little-endian machine integers (i128 = two u64, low first, two's complement). */
+enum { JOLT_INT_U64 = 0, JOLT_INT_I64 = 1, JOLT_INT_I128 = 2 };
+typedef struct jolt_ints jolt_ints;
+int32_t jolt_ints_upload(jolt_ctx *ctx, const void *host, int32_t kind, size_t count, jolt_ints **out);
+int32_t jolt_ints_free(jolt_ctx *ctx, jolt_ints *values);
+/* out[r] = sum_j values[r*row_width + j] * srs[j] for the count / row_width rows, in row order.  row_width must be a power of
+ * two (JOLT_ERR_INVALID_ARG, streaming.rs:99-102), <= the SRS length (JOLT_ERR_SRS_TOO_SMALL, :103-108) and divide count
+ * (JOLT_ERR_SIZE_MISMATCH, :192-195). */
+int32_t jolt_dory_commit_rows(jolt_ctx *ctx, const jolt_srs *srs, const jolt_ints *values, size_t row_width, jolt_g1_t *out);
+/* out[chunk*k + row] for the cycles / chunk_width chunks of hot-index column `poly`; an empty row gives the identity
+ * (Bn254G1::default(), streaming.rs:409-418).  Same argument checks as above (:376-392). */
+int32_t jolt_dory_commit_onehot(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, size_t poly, size_t chunk_width, jolt_g1_t *out);
+
 /* Multi-GPU data path (one process per GPU).  The collectives are RCCL calls on the context's stream;
  * librccl.so.1 is resolved with dlopen at first use (`rccl_path` may name it explicitly, NULL = the copy already mapped into
  * the process / the default search path).  Rank 0 draws the id, the launcher broadcasts its 128 bytes (torch.distributed

@@ -1,0 +1,253 @@
+// jolt_amd/csrc/msm_kernels.cuh -- the bucket-method kernels shared by the G1 MSM (msm.hip) and the Dory tier-1 row
+// commitments (dory.hip).  A "window" here is any independent bucket set: window w of one MSM, or (row, window) of a
+// batch of row MSMs over the same bases, or one chunk of a one-hot column.  Arrays are window-major:
+// keys/sorted[w*n + i] (n = points per window), hist/offsets/cursor/buckets[w*(B+1) + |digit|].
+#pragma once
+#include "g1.cuh"
+#include "poly_kernels.cuh"
+
+namespace jolt {
+namespace msmk {
+namespace {  // kernels have internal linkage: each including .hip carries its own copies
+
+constexpr int kLaneCap = 128;    // a bucket whose points-per-lane would exceed max(this, 4x the average) is heavy ...
+constexpr int kHeavySeg = 1024;  // ... and is summed by one wavefront per segment of this many points, segment sums combined afterwards
+constexpr int kPeelMax = 16;     // max rounds of same-key aggregation before falling back to per-lane atomics
+
+__device__ __forceinline__ G1Affine ld_aff(const G1Affine* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    G1Affine r;
+    r.x.l[0] = a.x; r.x.l[1] = a.y; r.x.l[2] = a.z; r.x.l[3] = a.w; r.x.l[4] = b.x; r.x.l[5] = b.y; r.x.l[6] = b.z; r.x.l[7] = b.w;
+    r.y.l[0] = c.x; r.y.l[1] = c.y; r.y.l[2] = c.z; r.y.l[3] = c.w; r.y.l[4] = d.x; r.y.l[5] = d.y; r.y.l[6] = d.z; r.y.l[7] = d.w;
+    return r;
+}
+
+// Same-key aggregation inside a wavefront for the histogram / scatter atomics.  Small scalars put half of all points into
+// one bucket (the carry window) and the top window of 254-bit scalars has a handful of distinct digits: without this the
+// same-address atomics serialise (measured 6 ms of a 2^20 MSM).  Rounds: the lanes sharing the key of the first pending
+// lane elect it as their leader; stops after kPeelMax rounds or once a round past the first found no duplicate (random keys).
+// Afterwards each lane with `do_atomic` issues ONE atomicAdd(&base[key], count); a lane's slot = leader's old value + rank.
+struct WaveAgg {
+    int src;         // lane holding the atomic's return value for this lane
+    uint32_t rank;   // position among the lanes sharing the key
+    uint32_t count;  // lanes folded into this lane's atomic (meaningful when do_atomic)
+    bool do_atomic;
+};
+__device__ __forceinline__ WaveAgg wave_aggregate(uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63;
+    WaveAgg r{(int)lane, 0u, 1u, valid};
+    uint64_t todo = __ballot(valid);
+    for (int it = 0; it < kPeelMax && todo; ++it) {
+        int leader = __ffsll((unsigned long long)todo) - 1;
+        uint32_t lkey = (uint32_t)__shfl((int)key, leader, 64);
+        uint64_t same = __ballot(valid && key == lkey) & todo;
+        if ((same >> lane) & 1) {
+            r.src = leader;
+            r.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            r.count = (uint32_t)__popcll(same);
+            r.do_atomic = (int)lane == leader;
+        }
+        todo &= ~same;
+        if (it >= 1 && __popcll(same) < 2) break;
+    }
+    return r;
+}
+
+// ---- 1. digits + histogram -------------------------------------------------------------------------------------
+// keys[w*n + i] = |digit| | (negative << 31); hist[w*(B+1) + |digit|] counts non-zero digits
+__global__ __launch_bounds__(kBlock) void k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ hist) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    Fr s = live ? from_mont(ld_fr(scalars + i)) : Fr::zero();
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        int bit = w * c;
+        uint32_t raw = 0;
+        if (bit < 256) {
+            int limb = bit >> 5, off = bit & 31;
+            uint64_t two = (uint64_t)s.l[limb] | (limb + 1 < 8 ? (uint64_t)s.l[limb + 1] << 32 : 0ull);
+            raw = (uint32_t)(two >> off) & ((1u << c) - 1);
+        }
+        raw += carry;
+        uint32_t mag, negf;
+        if (raw > B) { mag = (1u << c) - raw; negf = 1; carry = 1; }
+        else { mag = raw; negf = 0; carry = 0; }
+        if (live) keys[(size_t)w * n + i] = mag | (negf << 31);
+        WaveAgg ag = wave_aggregate(mag, live && mag != 0);
+        if (ag.do_atomic) atomicAdd(&hist[(size_t)w * (B + 1) + mag], ag.count);
+    }
+}
+
+// ---- 2. per-window exclusive scan of the histogram ---------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_msm_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                    uint32_t B, uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list,
+                                                    uint32_t* __restrict__ heavy_count, uint32_t heavy_cap) {
+    __shared__ uint32_t sm[kBlock];
+    const int w = blockIdx.x;
+    const uint32_t* h = hist + (size_t)w * (B + 1);
+    uint32_t per = (B + kBlock) / kBlock;  // entries 0..B inclusive
+    uint32_t lo = threadIdx.x * per, hi = min(lo + per, B + 1);
+    uint32_t local = 0;
+    for (uint32_t k = lo; k < hi; ++k) local += h[k];
+    sm[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = sm[threadIdx.x] - local;
+    for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t cnt = h[k];
+        offsets[(size_t)w * (B + 1) + k] = run;
+        cursor[(size_t)w * (B + 1) + k] = run;
+        if (cnt > heavy_threshold) {  // one list entry per segment: (bucket slot, segment index), contiguous per bucket
+            uint32_t nseg = (cnt + kHeavySeg - 1) / kHeavySeg;
+            uint32_t first = atomicAdd(heavy_count, nseg);
+            for (uint32_t sgi = 0; sgi < nseg && first + sgi < heavy_cap; ++sgi) {
+                heavy_list[2 * (first + sgi)] = (uint32_t)((size_t)w * (B + 1) + k);
+                heavy_list[2 * (first + sgi) + 1] = sgi;
+            }
+        }
+        run += cnt;
+    }
+}
+
+// ---- 3. scatter into bucket order -------------------------------------------------------------------------------
+// (windows beyond the 65535 limit of gridDim.y continue in gridDim.z: window = z * gridDim.y + y, n_windows of them)
+__global__ __launch_bounds__(kBlock) void k_msm_scatter(const uint32_t* __restrict__ keys, size_t n, uint32_t B, uint32_t* __restrict__ cursor,
+                                                       uint32_t* __restrict__ sorted, size_t n_windows) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t w = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
+    if (w >= n_windows) return;  // block-uniform
+    uint32_t key = i < n ? keys[(size_t)w * n + i] : 0u;
+    uint32_t mag = key & 0x7FFFFFFFu;
+    WaveAgg ag = wave_aggregate(mag, mag != 0);
+    uint32_t first = 0;
+    if (ag.do_atomic) first = atomicAdd(&cursor[(size_t)w * (B + 1) + mag], ag.count);
+    uint32_t pos = (uint32_t)__shfl((int)first, ag.src, 64) + ag.rank;
+    if (mag) sorted[(size_t)w * n + pos] = (uint32_t)i | (key & 0x80000000u);
+}
+
+// Butterfly sum of a G1 accumulator over `width` (power of two <= 64) adjacent lanes; every lane of the wave must call it.
+__device__ __forceinline__ G1Jac wave_sum_g1(G1Jac acc, int width) {
+    for (int off = width >> 1; off >= 1; off >>= 1) {
+        G1Jac o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o.x.l[k] = (uint32_t)__shfl_xor((int)acc.x.l[k], off, 64);
+            o.y.l[k] = (uint32_t)__shfl_xor((int)acc.y.l[k], off, 64);
+            o.z.l[k] = (uint32_t)__shfl_xor((int)acc.z.l[k], off, 64);
+        }
+        acc = g1_add(acc, o);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ G1Jac sum_bucket_points(const uint32_t* __restrict__ src, const G1Affine* __restrict__ bases, uint32_t lo, uint32_t hi,
+                                                   uint32_t stride) {
+    G1Jac acc = g1_identity();
+    for (uint32_t k = lo; k < hi; k += stride) {
+        uint32_t v = src[k];
+        G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
+        if (v >> 31) p.y = neg(p.y);
+        acc = g1_add_mixed(acc, p);
+    }
+    return acc;
+}
+
+// ---- 4a. light buckets: L adjacent lanes per bucket (L = 1 when there are enough buckets to fill the chip) ----------
+__global__ __launch_bounds__(kBlock) void k_msm_buckets_light(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
+                                                             uint32_t B, int L, uint32_t heavy_threshold, G1Jac* __restrict__ buckets,
+                                                             size_t n_windows) {
+    uint32_t gt = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t b = gt / L + 1, sub = gt % L;  // bucket magnitude 1..B
+    const size_t wi = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
+    if (wi >= n_windows) return;  // block-uniform
+    const size_t w = n_windows - 1 - wi;  // top window first: its buckets are the fullest for 254-bit scalars
+    bool mine = b <= B;
+    size_t slot = (size_t)w * (B + 1) + (mine ? b : 0);
+    uint32_t cnt = mine ? hist[slot] : 0;
+    if (cnt > heavy_threshold) { cnt = 0; mine = false; }  // the heavy kernels own it
+    G1Jac acc = sum_bucket_points(sorted + (size_t)w * n + offsets[slot], bases, sub, cnt, (uint32_t)L);
+    acc = wave_sum_g1(acc, L);
+    if (mine && sub == 0) buckets[slot] = acc;
+}
+
+// ---- 4b. heavy buckets: one wavefront per kHeavySeg-point segment, then one wavefront per bucket adds its segment sums ----
+__global__ __launch_bounds__(kBlock) void k_msm_buckets_heavy(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count,
+                                                             const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
+                                                             uint32_t B, G1Jac* __restrict__ seg_sums) {
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t total = *heavy_count;
+    for (uint32_t h = wave; h < total; h += n_waves) {
+        uint32_t slot = heavy_list[2 * h], sgi = heavy_list[2 * h + 1];
+        uint32_t w = slot / (B + 1);
+        uint32_t cnt = hist[slot];
+        uint32_t lo = sgi * kHeavySeg, hi = min(lo + (uint32_t)kHeavySeg, cnt);
+        G1Jac acc = sum_bucket_points(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u);
+        acc = wave_sum_g1(acc, 64);
+        if (lane == 0) seg_sums[h] = acc;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_msm_heavy_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count,
+                                                             const uint32_t* __restrict__ hist, const G1Jac* __restrict__ seg_sums,
+                                                             G1Jac* __restrict__ buckets) {
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t total = *heavy_count;
+    for (uint32_t h = wave; h < total; h += n_waves) {
+        if (heavy_list[2 * h + 1] != 0) continue;  // only the first segment entry of a bucket combines (wave-uniform)
+        uint32_t slot = heavy_list[2 * h];
+        uint32_t nseg = (hist[slot] + kHeavySeg - 1) / kHeavySeg;
+        G1Jac acc = g1_identity();
+        for (uint32_t k = lane; k < nseg; k += 64) acc = g1_add(acc, seg_sums[h + k]);
+        acc = wave_sum_g1(acc, 64);
+        if (lane == 0) buckets[slot] = acc;
+    }
+}
+
+// ---- 5. window reduction: partial[w][blockIdx.x] = sum over this block's bucket range of b * bucket[b] ------------------
+__global__ __launch_bounds__(kBlock) void k_msm_window_reduce(const G1Jac* __restrict__ buckets, uint32_t B, uint32_t G, G1Jac* __restrict__ partial) {
+    __shared__ G1Jac sm[kBlock];
+    const int w = blockIdx.y;
+    uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    uint64_t lo = (uint64_t)t * G + 1, hi = lo + G - 1;  // inclusive bucket range
+    G1Jac contrib = g1_identity();
+    if (lo <= B) {
+        if (hi > B) hi = B;
+        const G1Jac* bk = buckets + (size_t)w * (B + 1);
+        G1Jac running = g1_identity(), acc = g1_identity();
+        for (uint64_t b = hi; b >= lo; --b) {
+            running = g1_add(running, bk[b]);
+            acc = g1_add(acc, running);
+        }
+        // sum (b - lo + 1) B_b = acc  ->  sum b B_b = acc + (lo - 1) * running
+        contrib = g1_add(acc, g1_mul_small(running, (uint32_t)(lo - 1)));  // skips the leading zero bits
+    }
+    sm[threadIdx.x] = contrib;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] = g1_add(sm[threadIdx.x], sm[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = sm[0];
+}
+
+// ---- 5b. one wavefront per window adds that window's nb block partials ---------------------------------------------------
+__global__ __launch_bounds__(64) void k_msm_window_combine(const G1Jac* __restrict__ partial, uint32_t nb, G1Jac* __restrict__ window_sums) {
+    const int w = blockIdx.x;
+    G1Jac acc = g1_identity();
+    for (uint32_t k = threadIdx.x; k < nb; k += 64) acc = g1_add(acc, partial[(size_t)w * nb + k]);
+    acc = wave_sum_g1(acc, 64);
+    if (threadIdx.x == 0) window_sums[w] = acc;
+}
+
+}  // namespace
+}  // namespace msmk
+}  // namespace jolt

@@ -696,6 +696,45 @@ class OneHot:
             self.h = None
 
 
+class Ints:
+    """Small machine integers resident on the device for the Dory tier-1 row commitments: uint64 / int64 numpy arrays, or
+    i128 as an (n, 2) uint64 array (low, high; two's complement) / a list of Python ints with kind="i128"."""
+    KINDS = {"u64": 0, "i64": 1, "i128": 2}
+
+    def __init__(self, ctx, values, kind=None):
+        if kind == "i128" and not isinstance(values, np.ndarray):
+            values = np.array([[int(v) & (2**64 - 1), (int(v) >> 64) & (2**64 - 1)] for v in values], dtype=np.uint64).reshape(-1, 2)
+        v = np.ascontiguousarray(values)
+        if kind is None:
+            kind = {np.dtype(np.uint64): "u64", np.dtype(np.int64): "i64"}[v.dtype] if v.ndim == 1 else "i128"
+        self.ctx, self.kind = ctx, kind
+        self.count = v.shape[0]
+        h = C.c_void_p()
+        _ck(lib().jolt_ints_upload(ctx.h, v.ctypes.data_as(C.c_void_p), C.c_int32(self.KINDS[kind]), C.c_size_t(self.count), C.byref(h)), "jolt_ints_upload", ctx)
+        self.h = h
+
+    def free(self):
+        if self.h:
+            lib().jolt_ints_free(self.ctx.h, self.h)
+            self.h = None
+
+
+def _dory_commit_rows(self, srs, values, row_width):
+    """DoryScheme::feed_u64 / feed_i128 over every row_width window of `values` (an Ints): one G1 point per row."""
+    rows = values.count // row_width if row_width else 0
+    out = g1_array(max(rows, 1))
+    _ck(lib().jolt_dory_commit_rows(self.h, srs.h, values.h, C.c_size_t(row_width), _p(out)), "jolt_dory_commit_rows", self)
+    return out[:rows]
+
+
+def _dory_commit_onehot(self, srs, source, poly, chunk_width):
+    """DoryScheme::process_one_hot_chunks_with for hot-index column `poly`: (chunks, k) G1 points."""
+    chunks = source.cycles // chunk_width if chunk_width else 0
+    out = g1_array(max(chunks * source.k, 1))
+    _ck(lib().jolt_dory_commit_onehot(self.h, srs.h, source.h, C.c_size_t(poly), C.c_size_t(chunk_width), _p(out)), "jolt_dory_commit_onehot", self)
+    return out[:chunks * source.k].reshape(chunks, source.k, -1)
+
+
 def _member_lazy_ra_uniform(self, source, scale_tables, V, F, coeffs, w, scale=None, shard_scale=None):
     """eq(w,.) * sum_v coeffs[v] * prod_{i<F} ra_{vF+i}, ra_p(j) = scale_tables[p][index(p,j)], lazily bound (LazyFoldedRa)."""
     w = fr(w).reshape(-1, 4)
@@ -733,6 +772,9 @@ def _member_lazy_booleanity(self, source, scale_tables, rho, w, scale=None):
 Context.member_lazy_booleanity = _member_lazy_booleanity
 Context.member_lazy_ra_uniform = _member_lazy_ra_uniform
 Context.onehot = lambda self, indices, k: OneHot(self, indices, k)
+Context.ints = lambda self, values, kind=None: Ints(self, values, kind)
+Context.dory_commit_rows = _dory_commit_rows
+Context.dory_commit_onehot = _dory_commit_onehot
 
 
 def _table_op2(name):

@@ -234,3 +234,54 @@ EXPORT void orc_srs_setup_from_secret(const fr_t *beta, size_t count, g1_t *out)
         cur = g1_scalar_mul(&cur, beta);
     }
 }
+
+/* ---- Dory tier-1 (G1) streaming row commitments: crates/jolt-dory/src/streaming.rs ------------------------------------
+ * feed_u64 / feed_i128 / feed_i128_rows_with (:115-205): row r of the batch commits to
+ *     sum_j values[r*row_width + j] * bases[j]      (ark msm_u64 / msm_i128; a negative value contributes -(|v| * G_j)),
+ * evaluated here the slow way: MSB-first double-and-add over the 128-bit magnitude of each value.
+ * kind: 0 = u64, 1 = i64, 2 = i128 (two u64, low first, two's complement) -- the encodings of include/jolt_hip.h.
+ * The reference pins this path only through commit -> open -> verify round trips (crates/jolt-dory/tests); there are no
+ * golden points, so tests pin this function against orc_g1_msm_naive on the same integers lifted to Fr. */
+EXPORT void orc_dory_commit_rows(const g1_t *bases, const void *values, int kind, size_t count, size_t row_width, g1_t *out) {
+    size_t rows = row_width ? count / row_width : 0;
+    for (size_t r = 0; r < rows; ++r) {
+        g1_t acc = g1_identity();
+        for (size_t j = 0; j < row_width; ++j) {
+            size_t i = r * row_width + j;
+            uint64_t lo, hi = 0;
+            int negative = 0;
+            if (kind == 2) {
+                lo = ((const uint64_t *)values)[2 * i];
+                hi = ((const uint64_t *)values)[2 * i + 1];
+                negative = (int)(hi >> 63);
+                if (negative) { lo = ~lo + 1; hi = ~hi + (lo == 0); }
+            } else {
+                lo = ((const uint64_t *)values)[i];
+                negative = kind == 1 ? (int)(lo >> 63) : 0;
+                if (negative) lo = ~lo + 1;
+            }
+            if (!lo && !hi) continue;
+            g1_t t = g1_identity();
+            for (int b = 127; b >= 0; --b) {
+                t = g1_double(&t);
+                uint64_t limb = b >= 64 ? hi : lo;
+                if ((limb >> (b & 63)) & 1) t = g1_add(&t, &bases[j]);
+            }
+            if (negative) t = g1_neg(&t);
+            acc = g1_add(&acc, &t);
+        }
+        out[r] = acc;
+    }
+}
+
+/* one_hot_chunk_commitments (:366-419): indices_per_k[hot_row].push(column) for every hot column, then the per-row sums of
+ * bases (batch_g1_additions_multi_affine); rows nobody hits stay Bn254G1::default() = identity.  idx: one byte per column,
+ * 0xFF = None.  out: k points for this chunk. */
+EXPORT void orc_dory_onehot_chunk(const g1_t *bases, const uint8_t *idx, size_t one_hot_k, size_t chunk_width, g1_t *out) {
+    for (size_t k = 0; k < one_hot_k; ++k) out[k] = g1_identity();
+    for (size_t col = 0; col < chunk_width; ++col) {
+        uint8_t hot = idx[col];
+        if (hot == 0xFF) continue;
+        out[hot] = g1_add(&out[hot], &bases[col]);
+    }
+}

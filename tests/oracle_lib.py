@@ -526,6 +526,25 @@ def g1_msm_pippenger(bases, scalars):
     return o[0]
 
 
+def dory_commit_rows(bases, values, kind, row_width):
+    """streaming.rs feed_u64 / feed_i128 per row: values = uint64 / int64 array, or (n,2) uint64 for i128."""
+    b = _g1(bases).reshape(-1, 12)
+    v = np.ascontiguousarray(values)
+    count = v.shape[0]
+    rows = count // row_width
+    o = g1_array(max(rows, 1))
+    lib().orc_dory_commit_rows(_p(b), v.ctypes.data_as(C.c_void_p), C.c_int({"u64": 0, "i64": 1, "i128": 2}[kind]), C.c_size_t(count), C.c_size_t(row_width), _p(o))
+    return o[:rows]
+
+
+def dory_onehot_chunk(bases, idx, k):
+    b = _g1(bases).reshape(-1, 12)
+    i = np.ascontiguousarray(idx, dtype=np.uint8)
+    o = g1_array(k)
+    lib().orc_dory_onehot_chunk(_p(b), i.ctypes.data_as(C.c_void_p), C.c_size_t(k), C.c_size_t(i.shape[0]), _p(o))
+    return o
+
+
 def srs_setup_from_secret(beta, count):
     o = g1_array(count)
     lib().orc_srs_setup_from_secret(_p(np.ascontiguousarray(beta, dtype=np.uint64)), C.c_size_t(count), _p(o))
