@@ -138,6 +138,32 @@ __global__ __launch_bounds__(kBlock) void k_rows_fold(const G1Jac* __restrict__ 
     }
 }
 
+// The same fold for small bucket sets (B <= 128, row widths up to 4096): sum_w 2^(cw) sum_b b B_(w,b) = sum_b b H_b with
+// H_b = sum_w 2^(cw) B_(w,b).  Lane b runs the Horner recombination over the windows for ITS bucket -- all lanes in
+// lockstep, so the W*c doublings cost one wavefront pass instead of one idle-lane pass per row on top of W butterfly
+// reductions -- then a single weighted reduction over the lanes.  Measured 5.3 -> see DESIGN.md on 2048 rows x 2048 u64.
+__global__ __launch_bounds__(128) void k_rows_fold_lanes(const G1Jac* __restrict__ buckets, uint32_t B, int c, int W, G1Jac* __restrict__ out) {
+    __shared__ G1Jac sm[2];
+    const size_t row = blockIdx.x;
+    const uint32_t b = threadIdx.x + 1;
+    G1Jac h = g1_identity();
+    if (b <= B) {
+        const G1Jac* bk = buckets + row * (size_t)W * (B + 1) + b;
+        for (int w = W - 1; w >= 0; --w) {
+            for (int k = 0; k < c; ++k) h = g1_double(h);
+            h = g1_add(h, bk[(size_t)w * (B + 1)]);
+        }
+        h = g1_mul_small(h, b);
+    }
+    h = wave_sum_g1(h, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        G1Jac acc = blockDim.x > 64 ? g1_add(sm[0], sm[1]) : sm[0];
+        out[row] = g1_is_identity(acc) ? g1_identity() : acc;
+    }
+}
+
 // One-hot chunks: window = chunk, key = hot row + 1 (0 = cold cycle, skipped), no signs.
 __global__ __launch_bounds__(kBlock) void k_onehot_keys(const uint8_t* __restrict__ idx, size_t n, uint32_t width_log, uint32_t K,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ hist) {
@@ -328,7 +354,10 @@ extern "C" int32_t jolt_dory_commit_rows(jolt_ctx* ctx, const jolt_srs* srs, con
         else
             hipLaunchKernelGGL(k_rows_digits<JOLT_INT_I128>, dim3(gv), dim3(kBlock), 0, st, (const void*)values->data, first, nvals, (uint32_t)wl, c, W, w.keys, w.hist);
         launch_bucket_sums(ctx, w, srs->pts, V, row_width, B, p);
-        hipLaunchKernelGGL(k_rows_fold, dim3((unsigned)nr), dim3(kBlock), 0, st, (const G1Jac*)w.buckets, B, c, W, w.out);
+        if (B <= 128)
+            hipLaunchKernelGGL(k_rows_fold_lanes, dim3((unsigned)nr), dim3(B <= 64 ? 64 : 128), 0, st, (const G1Jac*)w.buckets, B, c, W, w.out);
+        else
+            hipLaunchKernelGGL(k_rows_fold, dim3((unsigned)nr), dim3(kBlock), 0, st, (const G1Jac*)w.buckets, B, c, W, w.out);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(out + r0, w.out, nr * sizeof(G1Jac), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -104,6 +104,19 @@ def test_rows_identity_at_scale(ctx, srs):
         assert O.g1_eq(got[r], _eval_point(beta, big[r * width:(r + 1) * width]))
 
 
+def test_rows_wide_rows(ctx):
+    """8192-column rows (256 buckets per window: the per-window fold kernel), mixed magnitudes, against p_row(beta) G."""
+    beta = rand_fr(1, 92)[0]
+    width = 1 << 13
+    dev = ctx.srs_setup_from_secret(beta, width, O.g1_generator())
+    rng = np.random.default_rng(13)
+    v = rng.integers(-2**63, 2**63, size=3 * width, dtype=np.int64)
+    v[width:2 * width] = rng.integers(-3, 4, size=width)
+    got = ctx.dory_commit_rows(dev, ctx.ints(v), width)
+    for r in range(3):
+        assert O.g1_eq(got[r], _eval_point(beta, [int(x) for x in v[r * width:(r + 1) * width]]))
+
+
 def test_rows_argument_checks(ctx, srs):
     _, _, dev = srs
     v = ctx.ints(np.arange(96, dtype=np.uint64))
