@@ -46,6 +46,9 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
     if (!ctx) return JOLT_ERR_OOM;
     ctx->device = device_id;
+    if (const char* gm = std::getenv("JOLT_GRID_MULT")) { if (std::atoi(gm) > 0) ctx->grid_mult = (size_t)std::atoi(gm); }
+    if (const char* ss = std::getenv("JOLT_SERIAL_STREAMS")) ctx->serial_streams = std::atoi(ss) != 0;
+    if (const char* ll = std::getenv("JOLT_LAZY_LDS")) ctx->lazy_lds = std::atoi(ll) != 0;
     if (const char* rp = std::getenv("JOLT_UNIFORM_ROWS_PAIRS")) { if (std::atoll(rp) > 0) ctx->uniform_rows_pairs = (size_t)std::atoll(rp); }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
@@ -60,9 +63,9 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
         ctx->round_cap = 1024;
         if (hipHostMalloc((void**)&ctx->h_round, ctx->round_cap * sizeof(Fr), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-            hipMalloc((void**)&ctx->d_counters, 64 * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&ctx->d_counters, kTicketWords * sizeof(uint32_t)) != hipSuccess ||
             hipMalloc((void**)&ctx->d_round, ctx->round_cap * sizeof(Fr)) != hipSuccess ||
-            hipMemset(ctx->d_counters, 0, 64 * sizeof(uint32_t)) != hipSuccess)
+            hipMemset(ctx->d_counters, 0, kTicketWords * sizeof(uint32_t)) != hipSuccess)
             s = JOLT_ERR_HIP;
         else
             *ctx->h_flag = 0;
@@ -147,10 +150,25 @@ int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t resu
     return JOLT_OK;
 }
 
+// LDS bytes of one product group's branch tables (k_split_eq_uniform_lazy_lds): F polynomials x width x (K + 1) entries
+constexpr size_t kLazyLdsMax = 48 * 1024;
+static inline size_t lazy_lds_bytes(const jolt_member* m) {
+    return (size_t)m->uni_F * m->lazy_width * ((size_t)m->onehot->k + 1) * sizeof(Fr);
+}
+
 // grid for a grid-stride sweep over n work items: enough blocks to fill 256 CUs x 8, never more than needed
 static inline int sweep_grid(const jolt_ctx* ctx, size_t n) {
     size_t need = (n + kBlock - 1) / kBlock;
     size_t cap = (size_t)ctx->num_cus * 8;
+    return (int)std::max<size_t>(1, std::min(need, cap));
+}
+// grid of a round-sum kernel: ONE workgroup per CU.  Every wavefront of these kernels ends with a shuffle reduction of its NE
+// 256-bit accumulators, a device-scope fence and a ticket; measured on the bench workload, 256 workgroups beat 512 / 1024 /
+// 2048 at T = 2^20 (7.6 / 8.1 / 7.9 / 8.1 ms per pass) and at 2^22 (17.0 / 18.1 / 17.6 / 19.3): the per-wavefront epilogue
+// costs more than the extra memory-level parallelism buys.
+static inline int round_grid(const jolt_ctx* ctx, size_t n) {
+    size_t need = (n + kBlock - 1) / kBlock;
+    size_t cap = (size_t)ctx->num_cus * ctx->grid_mult;
     return (int)std::max<size_t>(1, std::min(need, cap));
 }
 
@@ -1070,6 +1088,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     struct Item {
         size_t ne, slot;
         bool fused = false, tail = false, done = false, rows_major = false;
+        uint32_t lds_blocks = 0;   // > 0: k_split_eq_uniform_lazy_lds with this many workgroups per product group
         Fr r;                      // challenge of the fused bind
         std::vector<const Fr*> in; // table pointers the round kernel reads
         std::vector<Fr*> out;      // fused: where the bound tables go
@@ -1197,7 +1216,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             L.args.e_out[c] = mj->eq_weighted ? mj->e_out_cache[mj->e_out_bits]->data() : nullptr;
             L.args.e_in[c] = mj->eq_weighted ? mj->e_in_cache[mj->e_in_bits]->data() : nullptr;
             L.args.in_bits[c] = (int32_t)mj->e_in_bits;
-            L.grid = std::max<unsigned>(L.grid, (unsigned)sweep_grid(ctx, (mj->len / 2) * std::max<uint32_t>(1, mj->desc.n_groups)));
+            L.grid = std::max<unsigned>(L.grid, (unsigned)round_grid(ctx, (mj->len / 2) * std::max<uint32_t>(1, mj->desc.n_groups)));
             L.who.push_back(j);
             it.done = true;
         }
@@ -1218,7 +1237,13 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             items[i].rows_major = work >= kUniformRowsMajorPairs && members[i]->uni_V > 1;
             if (!items[i].rows_major) work *= members[i]->uni_V;
         }
-        items[i].grid = sweep_grid(ctx, work);
+        items[i].grid = round_grid(ctx, work);
+        // index-encoded selector columns past the first bind: one product group per workgroup, its branch tables in LDS
+        if (members[i]->kind == jolt_member::kSplitEqUniform && members[i]->lazy_width >= 2 && lazy_lds_bytes(members[i]) <= kLazyLdsMax && ctx->lazy_lds) {
+            items[i].rows_major = false;
+            items[i].lds_blocks = (uint32_t)std::max<size_t>(1, (size_t)round_grid(ctx, (members[i]->len / 2) * members[i]->uni_V) / members[i]->uni_V);
+            items[i].grid = (int)(items[i].lds_blocks * members[i]->uni_V);
+        }
         items[i].part_off = (uint32_t)part_total;
         part_total += (size_t)items[i].grid * items[i].ne;
     }
@@ -1235,7 +1260,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     for (size_t i = 0; i < n; ++i) if (members[i]->kind != jolt_member::kExpr) n_kernels++;
     int rr = 0;
     hipStream_t streams[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]};
-    const int n_streams = n_kernels > 1 ? std::min(4, n_kernels) : 1;
+    const int n_streams = n_kernels > 1 && !ctx->serial_streams ? std::min(4, n_kernels) : 1;
     if (n_streams > 1) {
         JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int k = 1; k < n_streams; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(streams[k], ctx->ev_fork, 0));
@@ -1274,6 +1299,11 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
                 pa.cycles0 = m->onehot->cycles;
                 pa.V = ua.V;
                 hipLaunchKernelGGL(k_split_eq_uniform_lazy_first, g, b, 0, st, pa, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+            } else if (it.lds_blocks) {
+                const size_t lds = lazy_lds_bytes(m);
+                if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy_lds<2>, g, b, lds, st, la, it.lds_blocks, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+                else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_lazy_lds<3>, g, b, lds, st, la, it.lds_blocks, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
+                else hipLaunchKernelGGL(k_split_eq_uniform_lazy_lds<4>, g, b, lds, st, la, it.lds_blocks, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
             } else if (it.rows_major) {
                 if (m->uni_F == 2) hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<2>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);
                 else if (m->uni_F == 3) hipLaunchKernelGGL(k_split_eq_uniform_lazy_rows<3>, g, b, 0, st, la, e_out, e_in, (int)m->e_in_bits, m->len / 2, part, (uint32_t)i, (uint32_t)it.slot, rd);

@@ -134,6 +134,64 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy(LazyArg
     finish_member(partials, F, ticket, slot, rd);
 }
 
+// The same sums with the branch tables of ONE product group staged in LDS (F * width * (K + 1) entries; entry K of every
+// block is zero, so a cold cycle is a lookup like any other and the gather has no branch).  The branch tables outgrow the
+// 32 KiB L1 after the first bind and every 32-byte lookup then drags a 128-byte line out of L2: at T = 2^20 the 33.5 M
+// lookups of a round of the 32-column member cost ~270 us regardless of how few pairs were left.
+// blockIdx.x = v * blocks_per_v + block within the group; the 2 * width index bytes of a pair are one aligned load.
+template <int F>
+static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy_lds(LazyArgs a, uint32_t blocks_per_v, const Fr* __restrict__ e_out,
+                                                                             const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials,
+                                                                             uint32_t ticket, uint32_t slot, RoundDone rd) {
+    extern __shared__ uint4 lazy_lds_raw[];
+    Fr* tab = reinterpret_cast<Fr*>(lazy_lds_raw);
+    const uint32_t v = blockIdx.x / blocks_per_v, bx = blockIdx.x - v * blocks_per_v;
+    const uint32_t KP = a.K + 1, per_poly_lds = a.width * KP, per_poly = a.width * a.K;
+    for (uint32_t e = threadIdx.x; e < F * per_poly_lds; e += kBlock) {
+        uint32_t k = e / per_poly_lds, r = e - k * per_poly_lds, off = r / KP, entry = r - off * KP;
+        tab[e] = entry < a.K ? ld_fr(a.branch + ((size_t)v * F + k) * per_poly + (size_t)off * a.K + entry) : Fr::zero();
+    }
+    __syncthreads();
+    Fr acc[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) acc[t] = Fr::zero();
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    const uint32_t width = a.width;
+    for (size_t row = (size_t)bx * kBlock + threadIdx.x; row < rows; row += (size_t)blocks_per_v * kBlock) {
+        Fr lo[F], hi[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+            const uint8_t* col = a.idx + ((size_t)v * F + k) * a.cycles0 + 2 * row * width;  // lo: bytes [0, width), hi: [width, 2 width)
+            uint64_t b_lo, b_hi;  // the index bytes, little-endian
+            if (width == 8) { uint4 q = *reinterpret_cast<const uint4*>(col); b_lo = (uint64_t)q.x | ((uint64_t)q.y << 32); b_hi = (uint64_t)q.z | ((uint64_t)q.w << 32); }
+            else if (width == 4) { uint2 q = *reinterpret_cast<const uint2*>(col); b_lo = q.x; b_hi = q.y; }
+            else if (width == 2) { uint32_t q = *reinterpret_cast<const uint32_t*>(col); b_lo = q & 0xFFFFu; b_hi = q >> 16; }
+            else { uint32_t q = *reinterpret_cast<const uint16_t*>(col); b_lo = q & 0xFFu; b_hi = q >> 8; }
+            const Fr* tk = tab + (uint32_t)k * per_poly_lds;
+            Fr s0 = Fr::zero(), s1 = Fr::zero();
+            for (uint32_t off = 0; off < width; ++off) {
+                uint32_t i0 = (uint32_t)(b_lo >> (8 * off)) & 0xFFu, i1 = (uint32_t)(b_hi >> (8 * off)) & 0xFFu;
+                i0 = i0 == kOneHotCold ? a.K : i0;
+                i1 = i1 == kOneHotCold ? a.K : i1;
+                s0 = add(s0, tk[off * KP + i0]);
+                s1 = add(s1, tk[off * KP + i1]);
+            }
+            lo[k] = s0;
+            hi[k] = s1;
+        }
+        Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+        if (!a.coeff_one[v]) w = mul(w, a.coeff[v]);
+        lo[0] = mul(lo[0], w);
+        hi[0] = mul(hi[0], w);
+        Fr q[F];
+        uniform_item<F>(lo, hi, q);
+#pragma unroll
+        for (int t = 0; t < F; ++t) acc[t] = add(acc[t], q[t]);
+    }
+    block_reduce_store<F>(acc, partials);
+    finish_member(partials, F, ticket, slot, rd);
+}
+
 // Booleanity cycle phase (crates/jolt-kernels/src/optimized/booleanity.rs:574-633): inner quadratic
 //   q(X) = sum_rows E(row) * sum_i (H_i(X)^2 - rho_i H_i(X)),   q(0) from H at 0, q(inf) from the pair delta,
 // with H_i the gamma-pre-scaled address-folded selector columns (rho_i = gamma^i), index-encoded (LAZY) or dense.

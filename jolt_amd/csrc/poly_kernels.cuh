@@ -204,16 +204,38 @@ struct RoundDone {
     uint32_t group_total; // members in this batch round
 };
 // LAYOUT_T_MAJOR = false: partials[b*ne + t] from gridDim.x blocks; true: partials[t*nblocks + b] with `expected` tickets.
+// Tickets are two-level above kSubTickets workgroups: a same-address device-scope atomic costs ~35-40 ns of serialised time
+// on this part (8 XCDs: it is resolved on the memory side), so 2048 workgroups on ONE counter put a ~80 us floor under every
+// round kernel however little data it touched (measured: kernel time linear in the workgroup count).  Workgroup p takes a
+// ticket on counter p % 64 of its member (one 128-byte line each); the last of each takes one of 64 top-level tickets.
+constexpr uint32_t kSubTickets = 64;
+constexpr uint32_t kSubTicketStride = 32;   // u32 per sub counter: its own cache line
+constexpr uint32_t kSubTicketBase = 64;     // counters[0..31] member tickets, [32] group ticket, sub counters from [64]
+constexpr size_t kTicketWords = kSubTicketBase + (size_t)kGroupTicket * kSubTickets * kSubTicketStride;
 template <bool LAYOUT_T_MAJOR = false>
 __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, int ne, uint32_t member_ticket, uint32_t slot, const RoundDone& rd,
-                                              int nblocks_arg = 0, uint32_t expected = 0) {
+                                              int nblocks_arg = 0, uint32_t expected = 0, uint32_t pidx = 0xFFFFFFFFu) {
     __shared__ uint32_t s_last;
     __shared__ Fr s_red[kBlock / 64];
     __syncthreads();  // this block's partials are written (block_reduce_store ends with the stores of threads < NE)
     if (threadIdx.x == 0) {
         __threadfence();  // release: partials visible at agent scope before the ticket
-        uint32_t t = atomicAdd(&rd.counters[member_ticket], 1u);
-        s_last = (t == (LAYOUT_T_MAJOR ? expected : gridDim.x) - 1) ? 1u : 0u;
+        const uint32_t total = LAYOUT_T_MAJOR ? expected : gridDim.x;
+        uint32_t last = 0;
+        if (total <= kSubTickets) {
+            last = atomicAdd(&rd.counters[member_ticket], 1u) == total - 1 ? 1u : 0u;
+        } else {
+            const uint32_t p = pidx == 0xFFFFFFFFu ? blockIdx.x : pidx;
+            const uint32_t r = p % kSubTickets;
+            const uint32_t in_sub = (total - r + kSubTickets - 1) / kSubTickets;
+            uint32_t* sub = rd.counters + kSubTicketBase + ((size_t)member_ticket * kSubTickets + r) * kSubTicketStride;
+            if (atomicAdd(sub, 1u) == in_sub - 1) {
+                *sub = 0;         // ready for the next round
+                __threadfence();
+                last = atomicAdd(&rd.counters[member_ticket], 1u) == kSubTickets - 1 ? 1u : 0u;
+            }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;

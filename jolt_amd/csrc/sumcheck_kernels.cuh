@@ -208,7 +208,7 @@ static __global__ __launch_bounds__(kBlock) void k_round_evals_tail(TailArgs a, 
     }
     Fr* mine = partials + a.g.part_off[m];
     block_reduce_store<1>(acc, mine + (size_t)t * gridDim.x);
-    finish_member<true>(mine, (int)ne, a.g.ticket[m], a.g.slot[m], rd, (int)gridDim.x, gridDim.x * ne);
+    finish_member<true>(mine, (int)ne, a.g.ticket[m], a.g.slot[m], rd, (int)gridDim.x, gridDim.x * ne, t * gridDim.x + blockIdx.x);
 }
 
 // Split-eq product member (a6): q(0) = sum_rows E_out[x_out] E_in[x_in] a_lo b_lo,
