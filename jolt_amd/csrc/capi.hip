@@ -46,6 +46,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
     if (!ctx) return JOLT_ERR_OOM;
     ctx->device = device_id;
+    if (const char* rt = std::getenv("JOLT_ROUND_TRACE")) ctx->round_trace = std::atoi(rt) != 0;
     if (const char* gm = std::getenv("JOLT_GRID_MULT")) { if (std::atoi(gm) > 0) ctx->grid_mult = (size_t)std::atoi(gm); }
     if (const char* ss = std::getenv("JOLT_SERIAL_STREAMS")) ctx->serial_streams = std::atoi(ss) != 0;
     if (const char* ll = std::getenv("JOLT_LAZY_LDS")) ctx->lazy_lds = std::atoi(ll) != 0;
@@ -1791,9 +1792,33 @@ int32_t jolt_internal_round_group_prove(jolt_ctx* ctx, jolt_member* const* membe
         if (!gone) return JOLT_OK;
         overlap = nullptr;  // already ran
     }
+    if (!ctx->round_trace) {
+        JOLT_TRY(group_enqueue(ctx, members, n, bptr.data()));
+        if (overlap && *overlap) (*overlap)();
+        return round_wait(ctx, total, evals_out);  // no copy, no stream sync: the last workgroup published the sums
+    }
+    // JOLT_ROUND_TRACE=1: where a round's host time goes (between calls / enqueue / overlapped host work / waiting for the flag)
+    using clk = std::chrono::steady_clock;
+    static clk::time_point last_return;
+    static double acc[4] = {0, 0, 0, 0};
+    static size_t rounds = 0;
+    auto t0 = clk::now();
+    if (rounds) acc[0] += std::chrono::duration<double, std::micro>(t0 - last_return).count();
     JOLT_TRY(group_enqueue(ctx, members, n, bptr.data()));
+    auto t1 = clk::now();
     if (overlap && *overlap) (*overlap)();
-    return round_wait(ctx, total, evals_out);  // no copy, no stream sync: the last workgroup published the sums
+    auto t2 = clk::now();
+    int32_t st = round_wait(ctx, total, evals_out);
+    auto t3 = clk::now();
+    acc[1] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    acc[2] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+    acc[3] += std::chrono::duration<double, std::micro>(t3 - t2).count();
+    last_return = t3;
+    if (++rounds % 500 == 0) {
+        std::fprintf(stderr, "[jolt round trace] %zu rounds: between calls %.1f us, enqueue %.1f us, overlapped host work %.1f us, wait %.1f us (averages)\n", rounds,
+                     acc[0] / rounds, acc[1] / rounds, acc[2] / rounds, acc[3] / rounds);
+    }
+    return st;
 }
 
 // finish_rounds for a whole batch: every table of every member in ceil(tables/40) launches
