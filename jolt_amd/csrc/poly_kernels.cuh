@@ -216,7 +216,6 @@ template <bool LAYOUT_T_MAJOR = false>
 __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, int ne, uint32_t member_ticket, uint32_t slot, const RoundDone& rd,
                                               int nblocks_arg = 0, uint32_t expected = 0, uint32_t pidx = 0xFFFFFFFFu) {
     __shared__ uint32_t s_last;
-    __shared__ Fr s_red[kBlock / 64];
     __syncthreads();  // this block's partials are written (block_reduce_store ends with the stores of threads < NE)
     if (threadIdx.x == 0) {
         __threadfence();  // release: partials visible at agent scope before the ticket
@@ -240,11 +239,13 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
     __syncthreads();
     if (!s_last) return;
     __threadfence();  // acquire: drop stale L1 lines before reading the other blocks' partials
+    // one wavefront per sum: the ne sums are reduced side by side instead of one after the other (this epilogue is on the
+    // critical path of every round: the host is spinning on the flag)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblocks = LAYOUT_T_MAJOR ? nblocks_arg : (int)gridDim.x;
-    for (int t = 0; t < ne; ++t) {
+    for (int t = wave; t < ne; t += kBlock / 64) {
         Fr s = Fr::zero();
-        for (int b = threadIdx.x; b < nblocks; b += kBlock)
+        for (int b = lane; b < nblocks; b += 64)
             s = add(s, ld_fr(partials + (LAYOUT_T_MAJOR ? (size_t)t * nblocks + b : (size_t)b * ne + t)));
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -253,24 +254,20 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
             for (int k = 0; k < 8; ++k) o.l[k] = __shfl_xor(s.l[k], off, 64);
             s = add(s, o);
         }
-        if (lane == 0) s_red[wave] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            Fr tot = s_red[0];
-            for (int w = 1; w < kBlock / 64; ++w) tot = add(tot, s_red[w]);
-            st_fr(rd.results + slot + t, tot);
-            if (rd.results_dev) st_fr(rd.results_dev + slot + t, tot);
+        if (lane == 0) {
+            st_fr(rd.results + slot + t, s);
+            if (rd.results_dev) st_fr(rd.results_dev + slot + t, s);
+            __threadfence_system();  // this wavefront's sums reach host memory before the barrier below releases thread 0
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         rd.counters[member_ticket] = 0;  // ready for the next round
         __threadfence_system();          // round sums reach host memory before the group ticket / flag
         uint32_t g = atomicAdd(&rd.counters[kGroupTicket], 1u);
         if (g == rd.group_total - 1) {
             rd.counters[kGroupTicket] = 0;
-            __threadfence_system();
-            __hip_atomic_store(rd.flag, rd.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(rd.flag, rd.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // release: after the sums and the reset
         }
     }
 }
