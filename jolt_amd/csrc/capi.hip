@@ -46,6 +46,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
     if (!ctx) return JOLT_ERR_OOM;
     ctx->device = device_id;
+    if (const char* ft = std::getenv("JOLT_FUSE_TAIL")) ctx->fuse_tail = std::atoi(ft) != 0;
     if (const char* rt = std::getenv("JOLT_ROUND_TRACE")) ctx->round_trace = std::atoi(rt) != 0;
     if (const char* gm = std::getenv("JOLT_GRID_MULT")) { if (std::atoi(gm) > 0) ctx->grid_mult = (size_t)std::atoi(gm); }
     if (const char* ss = std::getenv("JOLT_SERIAL_STREAMS")) ctx->serial_streams = std::atoi(ss) != 0;
@@ -1107,7 +1108,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             // Fuse only where it pays: the separate bind kernel runs at the HBM roofline with its multiplies hidden, so moving
             // them into an ALU-bound round kernel (many multiplies per table) costs more than the saved pass; fuse the
             // bandwidth-bound members (<= 2 multiplies per table per pair) and never the latency-bound tail rounds.
-            const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && m->len / 4 > kTailPairs &&
+            const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && (m->len / 4 > kTailPairs || (ctx->fuse_tail && m->kind == jolt_member::kExpr)) &&
                                   (m->kind == jolt_member::kSplitEqProduct || (m->kind == jolt_member::kExpr && m->all_tables_used && m->muls_per_pair <= 2 * m->tables.size()));
             JOLT_TRY(member_note_bind(m, *binds[i]));  // m->len is now the bound length
             if (can_fuse) {

@@ -54,6 +54,7 @@ struct jolt_ctx {
     // (JOLT_UNIFORM_ROWS_PAIRS overrides; tests lower it to run the row-major kernels at small sizes)
     size_t uniform_rows_pairs = (size_t)1 << 16;
     size_t grid_mult = 1;         // workgroups per CU of a round-sum kernel (JOLT_GRID_MULT)
+    bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
     bool round_trace = false;     // JOLT_ROUND_TRACE=1: print where the host time of a batch round goes
     bool serial_streams = false;  // JOLT_SERIAL_STREAMS=1: a round's kernels on one stream (standalone kernel durations under rocprof)
     bool lazy_lds = true;  // index-encoded members past the first bind: branch tables staged in LDS (JOLT_LAZY_LDS=0: global gathers)
