@@ -46,6 +46,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
     if (!ctx) return JOLT_ERR_OOM;
     ctx->device = device_id;
+    if (const char* tp = std::getenv("JOLT_TAIL_PAIRS")) { if (std::atoll(tp) > 0) ctx->tail_pairs = (size_t)std::atoll(tp); }
     if (const char* ft = std::getenv("JOLT_FUSE_TAIL")) ctx->fuse_tail = std::atoi(ft) != 0;
     if (const char* rt = std::getenv("JOLT_ROUND_TRACE")) ctx->round_trace = std::atoi(rt) != 0;
     if (const char* gm = std::getenv("JOLT_GRID_MULT")) { if (std::atoi(gm) > 0) ctx->grid_mult = (size_t)std::atoi(gm); }
@@ -1083,7 +1084,7 @@ static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGrou
 // left go into the tail kernel (all members, pair x group x point work items).  The last workgroup of every member
 // publishes its sums into host-mapped memory (finish_member).
 static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
-    constexpr size_t kTailPairs = 4096;
+    const size_t kTailPairs = ctx->tail_pairs;
     const size_t kUniformRowsMajorPairs = ctx->uniform_rows_pairs;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     if (n > (size_t)kGroupTicket) { ctx->last_error = "batch round has too many members"; return JOLT_ERR_UNSUPPORTED; }

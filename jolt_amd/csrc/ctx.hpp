@@ -54,6 +54,7 @@ struct jolt_ctx {
     // (JOLT_UNIFORM_ROWS_PAIRS overrides; tests lower it to run the row-major kernels at small sizes)
     size_t uniform_rows_pairs = (size_t)1 << 16;
     size_t grid_mult = 1;         // workgroups per CU of a round-sum kernel (JOLT_GRID_MULT)
+    size_t tail_pairs = 16384;    // rounds with at most this many pairs use the tail kernel (JOLT_TAIL_PAIRS; 4096..65536 measure within 2 %)
     bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
     bool round_trace = false;     // JOLT_ROUND_TRACE=1: print where the host time of a batch round goes
     bool serial_streams = false;  // JOLT_SERIAL_STREAMS=1: a round's kernels on one stream (standalone kernel durations under rocprof)
