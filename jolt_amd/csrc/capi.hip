@@ -54,6 +54,8 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* ll = std::getenv("JOLT_LAZY_LDS")) ctx->lazy_lds = std::atoi(ll) != 0;
     if (const char* rp = std::getenv("JOLT_UNIFORM_ROWS_PAIRS")) { if (std::atoll(rp) > 0) ctx->uniform_rows_pairs = (size_t)std::atoll(rp); }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.sharedMemPerBlock > 0) ctx->max_lds_per_block = prop.sharedMemPerBlock;
+    if (const char* ml = std::getenv("JOLT_MSM_LDS_SORT")) ctx->msm_lds_sort = std::atoi(ml) != 0;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {

@@ -21,6 +21,7 @@ struct jolt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
+    size_t max_lds_per_block = 65536;  // hipDeviceProp::sharedMemPerBlock (gfx950: 160 KiB)
     std::string last_error;
     // reduction scratch: per-block partial sums, final results (device) and their pinned host mirror
     Fr* d_partials = nullptr;
@@ -56,6 +57,7 @@ struct jolt_ctx {
     size_t grid_mult = 1;         // workgroups per CU of a round-sum kernel (JOLT_GRID_MULT)
     size_t tail_pairs = 16384;    // rounds with at most this many pairs use the tail kernel (JOLT_TAIL_PAIRS; 4096..65536 measure within 2 %)
     bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
+    bool msm_lds_sort = true;     // MSM counting sort with per-workgroup LDS histograms (JOLT_MSM_LDS_SORT=0: global atomics per key)
     bool round_trace = false;     // JOLT_ROUND_TRACE=1: print where the host time of a batch round goes
     bool serial_streams = false;  // JOLT_SERIAL_STREAMS=1: a round's kernels on one stream (standalone kernel durations under rocprof)
     bool lazy_lds = true;  // index-encoded members past the first bind: branch tables staged in LDS (JOLT_LAZY_LDS=0: global gathers)
