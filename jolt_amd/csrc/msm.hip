@@ -74,7 +74,9 @@ MsmPlan plan_for(size_t n) {
     size_t wb = (size_t)p.W * p.B;
     p.L = 1;
     while (p.L < 64 && wb * (size_t)(2 * p.L) <= 524288) p.L *= 2;
-    size_t avg = (n + 2 * (size_t)p.B - 1) / (2 * (size_t)p.B);
+    // n points over B magnitudes per window; the top window of 254-bit scalars only has ~12.4 k distinct digits (2.6x the
+    // average per bucket) and must stay on the light path: one wavefront per 340-point bucket spends its time in the butterfly
+    size_t avg = (n + (size_t)p.B - 1) / (size_t)p.B;
     p.heavy_threshold = (uint32_t)std::min<size_t>((size_t)p.L * std::max<size_t>(kLaneCap, 4 * avg), 0x7FFFFFFFu);
     return p;
 }
