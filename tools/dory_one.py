@@ -1,3 +1,5 @@
+"""One jolt_dory_commit_rows call (2048 x 2048 u64) and one jolt_dory_commit_onehot call -- the rocprofv3 target behind
+profiles/r01_dory_tier1.txt."""
 import sys, os
 sys.path.insert(0, "/root/repo")
 import numpy as np

@@ -1,3 +1,5 @@
+# rocprofv3 --kernel-trace of bench.py (1 warm-up + 3 timed passes), per-kernel stats into gpurun_out/ and the kernel
+# timeline of stage 6b of the last pass on stdout.  SERIAL=1: all kernels of a round on one stream (standalone durations).
 cd /tmp && export TMPDIR=/tmp
 JOLT_SERIAL_STREAMS=${SERIAL:-0} timeout 200 rocprofv3 --kernel-trace -d /tmp/prof -o b -- python /root/repo/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /tmp/o.txt 2>&1
 f=$(find /tmp/prof -name "*.db" | head -1)
