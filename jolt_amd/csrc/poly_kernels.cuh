@@ -31,6 +31,12 @@ __device__ __forceinline__ void st_fr_agent(Fr* p, const Fr& v) {
     for (int k = 0; k < 4; ++k)
         __hip_atomic_store(q + k, (unsigned long long)v.l[2 * k] | ((unsigned long long)v.l[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_fr_system(Fr* p, const Fr& v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        __hip_atomic_store(q + k, (unsigned long long)v.l[2 * k] | ((unsigned long long)v.l[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ Fr ld_fr_agent(const Fr* p) {
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
     Fr v;
@@ -275,19 +281,20 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
             s = add(s, o);
         }
         if (lane == 0) {
-            st_fr(rd.results + slot + t, s);
+            st_fr_system(rd.results + slot + t, s);  // written through to host memory; the barrier below waits for the write
             if (rd.results_dev) st_fr(rd.results_dev + slot + t, s);
-            __threadfence_system();  // this wavefront's sums reach host memory before the barrier below releases thread 0
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        rd.counters[member_ticket] = 0;  // ready for the next round
-        __threadfence_system();          // round sums reach host memory before the group ticket / flag
+        rd.counters[member_ticket] = 0;  // ready for the next round (the kernel boundary publishes it)
+        // No system-scope fence (an L2 write-back of all dirty data on the critical path of the round): this member's sums have
+        // been written through and acknowledged before the group ticket is taken, so the flag -- written the same way by
+        // whoever takes the last ticket -- is issued after every member's sums.
         uint32_t g = atomicAdd(&rd.counters[kGroupTicket], 1u);
         if (g == rd.group_total - 1) {
             rd.counters[kGroupTicket] = 0;
-            __hip_atomic_store(rd.flag, rd.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // release: after the sums and the reset
+            __hip_atomic_store(rd.flag, rd.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
