@@ -77,6 +77,8 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
         for (int k = 0; k < 3 && s == JOLT_OK; ++k)
             if (hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) != hipSuccess) s = JOLT_ERR_HIP;
         if (s == JOLT_OK && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) s = JOLT_ERR_HIP;
+        for (int k = 0; k < 3 && s == JOLT_OK; ++k)
+            if (hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) != hipSuccess) s = JOLT_ERR_HIP;
     }
     if (s != JOLT_OK) { jolt_ctx_destroy(ctx); return s; }
     *out = ctx;
@@ -93,6 +95,7 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 3; ++k) if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int k = 0; k < 3; ++k) if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -1085,10 +1088,20 @@ static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGrou
 // Round sums: one launch per (NE, order, skip, fused, challenge) class with blockIdx.y = member; rounds with few pairs
 // left go into the tail kernel (all members, pair x group x point work items).  The last workgroup of every member
 // publishes its sums into host-mapped memory (finish_member).
+// The main stream waits for the side streams that ran table-writing kernels in the previous batch round.
+int32_t jolt_internal_join_side_writers(jolt_ctx* ctx) {
+    for (int k = 0; k < 3; ++k) {
+        if (!ctx->join_pending[k]) continue;
+        JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
+        ctx->join_pending[k] = false;
+    }
+    return JOLT_OK;
+}
+
 static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
     const size_t kTailPairs = ctx->tail_pairs;
     const size_t kUniformRowsMajorPairs = ctx->uniform_rows_pairs;
-    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));  // also joins the side streams that wrote tables last round
     if (n > (size_t)kGroupTicket) { ctx->last_error = "batch round has too many members"; return JOLT_ERR_UNSUPPORTED; }
     struct Item {
         size_t ne, slot;
@@ -1270,7 +1283,13 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int k = 1; k < n_streams; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(streams[k], ctx->ev_fork, 0));
     }
-    auto next_stream = [&]() { hipStream_t st = streams[rr % n_streams]; rr++; return st; };
+    bool wrote[4] = {false, false, false, false};
+    auto next_stream = [&](bool writes_tables = false) {
+        int k = rr % n_streams;
+        rr++;
+        if (writes_tables) wrote[k] = true;
+        return streams[k];
+    };
     // longest kernels first so that they overlap with the short ones
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
@@ -1332,12 +1351,12 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     for (TailLaunch& T : tails) {
-        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, next_stream(), T.args, T.r, T.shifted, ctx->d_partials, rd);
+        hipLaunchKernelGGL(k_round_evals_tail, dim3(T.gx, (unsigned)T.count, T.gz), dim3(kBlock), 0, next_stream(ctx->fuse_tail), T.args, T.r, T.shifted, ctx->d_partials, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
     }
     for (Launch& L : launches) {
         dim3 grid(L.grid, (unsigned)L.count);
-        hipStream_t lst = next_stream();
+        hipStream_t lst = next_stream(L.fused);
         if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
             if (L.fused) {
                 if (L.skip) launch_round_group<0, true, true>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
@@ -1386,7 +1405,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
         Fr r = it.fused ? it.r : Fr::zero();
         int shifted = fr_low_limbs_zero(r) ? 1 : 0;
-        hipStream_t sst = next_stream();
+        hipStream_t sst = next_stream(it.fused);
         if (it.fused)
             hipLaunchKernelGGL(k_split_eq_product<true>, dim3(it.grid), dim3(kBlock), 0, sst, it.in[0], it.in[1], it.out[0], it.out[1], r, shifted,
                                e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
@@ -1394,6 +1413,11 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             hipLaunchKernelGGL(k_split_eq_product<false>, dim3(it.grid), dim3(kBlock), 0, sst, it.in[0], it.in[1], (Fr*)nullptr, (Fr*)nullptr, r,
                                shifted, e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    for (int k = 1; k < n_streams; ++k) {
+        if (!wrote[k]) continue;
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k - 1], streams[k]));
+        ctx->join_pending[k - 1] = true;
     }
     return JOLT_OK;
 }
@@ -1518,6 +1542,7 @@ void jolt_internal_engine_free(jolt_ctx* ctx) {
 }
 
 int32_t jolt_internal_engine_quiesce(jolt_ctx* ctx) {
+    if (ctx) JOLT_TRY(jolt_internal_join_side_writers(ctx));  // every entry point that touches tables passes through here
     jolt_engine* e = ctx ? ctx->engine : nullptr;
     if (!e || !e->active) return JOLT_OK;
     __atomic_store_n(&e->h_ctl->abort, (uint64_t)1, __ATOMIC_RELEASE);
@@ -1828,6 +1853,7 @@ int32_t jolt_internal_round_group_prove(jolt_ctx* ctx, jolt_member* const* membe
 // finish_rounds for a whole batch: every table of every member in ceil(tables/40) launches
 extern "C" int32_t jolt_round_group_finish(jolt_ctx* ctx, jolt_member* const* members, size_t n, const jolt_fr_t* const* binds) {
     if (!ctx || (!members && n) || !binds) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_join_side_writers(ctx));
     for (size_t i = 0; i < n; ++i) {
         if (!members[i] || !binds[i]) return JOLT_ERR_INVALID_ARG;
         Fr b = fr_from_abi(binds[i]);

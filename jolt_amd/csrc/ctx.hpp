@@ -43,6 +43,10 @@ struct jolt_ctx {
     // round's bind launches (completion is tracked by the in-kernel tickets, not by stream order)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr;
+    // a side stream that ran a table-WRITING kernel (fused bind) records ev_join[k]; the main stream waits for it before the next
+    // operation that touches tables (the host only knows that kernel took its tickets, not that its write-back completed)
+    hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr};
+    bool join_pending[3] = {false, false, false};
     // MSM lanes: lane 0 runs on `stream`, lanes 1..3 on side[0..2]; each has a grow-only device workspace and a pinned
     // host buffer for the window sums, so independent MSMs (the HyperKZG level commitments) overlap
     void* msm_ws[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -65,6 +69,7 @@ struct jolt_ctx {
 
 // Stop a running round engine (if any) so that other work may use the stream / the members' tables.
 int32_t jolt_internal_engine_quiesce(jolt_ctx* ctx);
+int32_t jolt_internal_join_side_writers(jolt_ctx* ctx);
 
 struct jolt_table {
     jolt_ctx* ctx = nullptr;

@@ -282,7 +282,7 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
         }
         if (lane == 0) {
             st_fr_system(rd.results + slot + t, s);  // written through to host memory; the barrier below waits for the write
-            if (rd.results_dev) st_fr(rd.results_dev + slot + t, s);
+            if (rd.results_dev) st_fr_system(rd.results_dev + slot + t, s);  // RCCL send buffer: read by other streams / peers
         }
     }
     __syncthreads();
