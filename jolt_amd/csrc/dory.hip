@@ -105,6 +105,105 @@ __global__ __launch_bounds__(kBlock) void k_rows_digits(const void* __restrict__
     }
 }
 
+// The signed digit of window w of a 128-bit magnitude (the carry chain is replayed from window 0: W <= 48 cheap steps)
+__device__ __forceinline__ void digit_at(const uint32_t m[4], int c, int w, uint32_t& mag, uint32_t& negf) {
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    mag = 0;
+    negf = 0;
+    for (int v = 0; v <= w; ++v) {
+        int bit = v * c;
+        uint32_t raw = 0;
+        if (bit < 128) {
+            int limb = bit >> 5, off = bit & 31;
+            uint64_t two = (uint64_t)m[limb] | (limb + 1 < 4 ? (uint64_t)m[limb + 1] << 32 : 0ull);
+            raw = (uint32_t)(two >> off) & ((1u << c) - 1);
+        }
+        raw += carry;
+        if (raw > B) { mag = (1u << c) - raw; negf = 1; carry = 1; }
+        else { mag = raw; negf = 0; carry = 0; }
+    }
+}
+
+// Counting sort of one row's digits, window after window, entirely in LDS: blockIdx.x = row.  Replaces digits -> scan -> scatter
+// with their two global atomics per key (device-scope atomics cost ~90 ps each on this part: 1.7 of the 11 ms of a
+// 2048 x 2048 u64 batch); writes hist / offsets / sorted for the row's W windows and lists the over-full buckets.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_rows_sort_lds(const void* __restrict__ data, size_t first, uint32_t width_log, int c, int W,
+                                                         uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
+                                                         uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
+                                                         uint32_t heavy_cap) {
+    extern __shared__ uint32_t rows_sh[];  // B + 1 counters, then kBlock scan cells
+    const uint32_t B = 1u << (c - 1), width = 1u << width_log;
+    uint32_t* cnt = rows_sh;
+    uint32_t* cell = rows_sh + B + 1;
+    const size_t row = blockIdx.x;
+    const size_t base = first + (row << width_log);
+    const uint32_t per = (B + kBlock) / kBlock;  // bins per thread in the scan, bins 0..B
+    for (int w = 0; w < W; ++w) {
+        for (uint32_t b = threadIdx.x; b <= B; b += kBlock) cnt[b] = 0;
+        __syncthreads();
+        for (uint32_t col0 = 0; col0 < width; col0 += kBlock) {  // whole wavefronts walk the loop together (ballots inside)
+            const uint32_t col = col0 + threadIdx.x;
+            uint32_t mag = 0, negf = 0;
+            if (col < width) {
+                uint32_t m[4], negv;
+                load_magnitude<KIND>(data, base + col, m, negv);
+                digit_at(m, c, w, mag, negf);
+            }
+            WaveAgg ag = wave_aggregate(mag, mag != 0);
+            if (ag.do_atomic) atomicAdd(&cnt[mag], ag.count);
+        }
+        __syncthreads();
+        // exclusive scan of the counters (bin 0 stays empty) -> global hist / offsets; the counters become the scatter cursors
+        const uint32_t lo = threadIdx.x * per, hi = min(lo + per, B + 1);
+        uint32_t local = 0;
+        for (uint32_t k = lo; k < hi; ++k) local += cnt[k];
+        cell[threadIdx.x] = local;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) {
+            uint32_t v = (int)threadIdx.x >= off ? cell[threadIdx.x - off] : 0;
+            __syncthreads();
+            cell[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = cell[threadIdx.x] - local;
+        const size_t win = row * (size_t)W + w;
+        for (uint32_t k = lo; k < hi; ++k) {
+            const uint32_t n_k = cnt[k];
+            const uint32_t slot = (uint32_t)(win * (B + 1) + k);
+            hist[slot] = n_k;
+            offsets[slot] = run;
+            cnt[k] = run;
+            if (n_k > heavy_threshold) {
+                uint32_t nseg = (n_k + kHeavySeg - 1) / kHeavySeg;
+                uint32_t f0 = atomicAdd(heavy_count, nseg);
+                for (uint32_t sgi = 0; sgi < nseg && f0 + sgi < heavy_cap; ++sgi) {
+                    heavy_list[2 * (f0 + sgi)] = slot;
+                    heavy_list[2 * (f0 + sgi) + 1] = sgi;
+                }
+            }
+            run += n_k;
+        }
+        __syncthreads();
+        for (uint32_t col0 = 0; col0 < width; col0 += kBlock) {
+            const uint32_t col = col0 + threadIdx.x;
+            uint32_t mag = 0, negf = 0, negv = 0;
+            if (col < width) {
+                uint32_t m[4];
+                load_magnitude<KIND>(data, base + col, m, negv);
+                digit_at(m, c, w, mag, negf);
+            }
+            WaveAgg ag = wave_aggregate(mag, mag != 0);
+            uint32_t f0 = 0;
+            if (ag.do_atomic) f0 = atomicAdd(&cnt[mag], ag.count);
+            uint32_t pos = (uint32_t)__shfl((int)f0, ag.src, 64) + ag.rank;
+            if (mag) sorted[(win << width_log) + pos] = col | ((negf ^ negv) << 31);
+        }
+        __syncthreads();
+    }
+}
+
 // One workgroup per row: each wavefront folds whole windows (running sums over its lanes' bucket ranges, butterfly over the
 // lanes), then one lane runs the Horner recombination acc = 2^c acc + S_w over the row's W window sums.
 __global__ __launch_bounds__(kBlock) void k_rows_fold(const G1Jac* __restrict__ buckets, uint32_t B, int c, int W, G1Jac* __restrict__ out) {
@@ -235,15 +334,19 @@ int32_t carve(jolt_ctx* ctx, size_t V, size_t n, uint32_t B, uint32_t heavy_cap,
     return JOLT_OK;
 }
 
-// scan -> scatter -> light / heavy bucket sums for V windows whose keys and histogram are in place
-void launch_bucket_sums(jolt_ctx* ctx, const Workspace& w, const G1Affine* bases, size_t V, size_t n, uint32_t B, const BucketPlan& p) {
+// scan -> scatter -> light / heavy bucket sums for V windows whose keys and histogram are in place (already_sorted: hist / offsets /
+// sorted / heavy list were produced by k_rows_sort_lds)
+void launch_bucket_sums(jolt_ctx* ctx, const Workspace& w, const G1Affine* bases, size_t V, size_t n, uint32_t B, const BucketPlan& p,
+                        bool already_sorted = false) {
     hipStream_t st = ctx->stream;
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned gy = (unsigned)std::min<size_t>(V, 32768), gz = (unsigned)((V + gy - 1) / gy);
     const unsigned gh = std::min<uint32_t>((p.heavy_cap + 3) / 4, 4096);
-    hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)V), dim3(kBlock), 0, st, (const uint32_t*)w.hist, w.offs, w.cur, B, p.heavy_threshold, w.heavy, w.hcnt,
-                       p.heavy_cap);
-    hipLaunchKernelGGL(k_msm_scatter, dim3(gn, gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.keys, n, B, w.cur, w.sorted, V);
+    if (!already_sorted) {
+        hipLaunchKernelGGL(k_msm_scan, dim3((unsigned)V), dim3(kBlock), 0, st, (const uint32_t*)w.hist, w.offs, w.cur, B, p.heavy_threshold, w.heavy, w.hcnt,
+                           p.heavy_cap);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(gn, gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.keys, n, B, w.cur, w.sorted, V);
+    }
     hipLaunchKernelGGL(k_msm_buckets_light, dim3((unsigned)(((size_t)B * p.L + kBlock - 1) / kBlock), gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.hist,
                        (const uint32_t*)w.offs, (const uint32_t*)w.sorted, bases, n, B, p.L, p.heavy_threshold, w.buckets, V);
     hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)w.heavy, (const uint32_t*)w.hcnt, (const uint32_t*)w.hist,
@@ -347,13 +450,26 @@ extern "C" int32_t jolt_dory_commit_rows(jolt_ctx* ctx, const jolt_srs* srs, con
         if (e != hipSuccess) return hip_fail(ctx, "dory rows", e);
         const unsigned gv = (unsigned)((nvals + kBlock - 1) / kBlock);
         const size_t first = r0 * row_width;
-        if (kind == JOLT_INT_U64)
+        const size_t sort_lds = ((size_t)B + 1 + kBlock) * sizeof(uint32_t);
+        const bool lds_sort = ctx->msm_lds_sort && sort_lds <= 64 * 1024;
+        if (lds_sort) {  // one workgroup per row sorts its W windows in LDS
+            const void* vd = (const void*)values->data;
+            if (kind == JOLT_INT_U64)
+                hipLaunchKernelGGL(k_rows_sort_lds<JOLT_INT_U64>, dim3((unsigned)nr), dim3(kBlock), sort_lds, st, vd, first, (uint32_t)wl, c, W, w.hist, w.offs, w.sorted,
+                                   p.heavy_threshold, w.heavy, w.hcnt, p.heavy_cap);
+            else if (kind == JOLT_INT_I64)
+                hipLaunchKernelGGL(k_rows_sort_lds<JOLT_INT_I64>, dim3((unsigned)nr), dim3(kBlock), sort_lds, st, vd, first, (uint32_t)wl, c, W, w.hist, w.offs, w.sorted,
+                                   p.heavy_threshold, w.heavy, w.hcnt, p.heavy_cap);
+            else
+                hipLaunchKernelGGL(k_rows_sort_lds<JOLT_INT_I128>, dim3((unsigned)nr), dim3(kBlock), sort_lds, st, vd, first, (uint32_t)wl, c, W, w.hist, w.offs, w.sorted,
+                                   p.heavy_threshold, w.heavy, w.hcnt, p.heavy_cap);
+        } else if (kind == JOLT_INT_U64)
             hipLaunchKernelGGL(k_rows_digits<JOLT_INT_U64>, dim3(gv), dim3(kBlock), 0, st, (const void*)values->data, first, nvals, (uint32_t)wl, c, W, w.keys, w.hist);
         else if (kind == JOLT_INT_I64)
             hipLaunchKernelGGL(k_rows_digits<JOLT_INT_I64>, dim3(gv), dim3(kBlock), 0, st, (const void*)values->data, first, nvals, (uint32_t)wl, c, W, w.keys, w.hist);
         else
             hipLaunchKernelGGL(k_rows_digits<JOLT_INT_I128>, dim3(gv), dim3(kBlock), 0, st, (const void*)values->data, first, nvals, (uint32_t)wl, c, W, w.keys, w.hist);
-        launch_bucket_sums(ctx, w, srs->pts, V, row_width, B, p);
+        launch_bucket_sums(ctx, w, srs->pts, V, row_width, B, p, lds_sort);
         if (B <= 128)
             hipLaunchKernelGGL(k_rows_fold_lanes, dim3((unsigned)nr), dim3(B <= 64 ? 64 : 128), 0, st, (const G1Jac*)w.buckets, B, c, W, w.out);
         else
