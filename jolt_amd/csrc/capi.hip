@@ -1099,6 +1099,12 @@ int32_t jolt_internal_join_side_writers(jolt_ctx* ctx) {
 }
 
 static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t n, const Fr* const* binds) {
+    using eclk = std::chrono::steady_clock;
+    static double eacc[4] = {0, 0, 0, 0};
+    static size_t ecalls = 0;
+    const bool etrace = ctx->round_trace;
+    eclk::time_point e0, e1, e2, e3;
+    if (etrace) e0 = eclk::now();
     const size_t kTailPairs = ctx->tail_pairs;
     const size_t kUniformRowsMajorPairs = ctx->uniform_rows_pairs;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));  // also joins the side streams that wrote tables last round
@@ -1149,7 +1155,9 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             }
         }
     }
+    if (etrace) e1 = eclk::now();
     for (BindGroup& g : bgs) JOLT_TRY(jolt_internal_bind(ctx, g.tabs.data(), g.tabs.size(), g.r, g.order));
+    if (etrace) e2 = eclk::now();
     size_t slot = 0, part_total = 0;
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
@@ -1273,6 +1281,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     rd.flag = ctx->h_flag;
     rd.seq = ++ctx->seq;
     rd.group_total = (uint32_t)n;
+    if (etrace) e3 = eclk::now();
     // fork: the round's independent kernels go round-robin over main + side streams, all ordered after the binds above
     int n_kernels = (int)tails.size() + (int)launches.size();
     for (size_t i = 0; i < n; ++i) if (members[i]->kind != jolt_member::kExpr) n_kernels++;
@@ -1413,6 +1422,14 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             hipLaunchKernelGGL(k_split_eq_product<false>, dim3(it.grid), dim3(kBlock), 0, sst, it.in[0], it.in[1], (Fr*)nullptr, (Fr*)nullptr, r,
                                shifted, e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
         JOLT_HIP_TRY(ctx, hipGetLastError());
+    }
+    if (etrace) {
+        auto e4 = eclk::now();
+        auto us = [](eclk::time_point a, eclk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        eacc[0] += us(e0, e1); eacc[1] += us(e1, e2); eacc[2] += us(e2, e3); eacc[3] += us(e3, e4);
+        if (++ecalls % 500 == 0)
+            std::fprintf(stderr, "[jolt enqueue trace] %zu rounds: bind bookkeeping %.1f us, bind launches %.1f us, launch preparation %.1f us, fork + round launches %.1f us\n",
+                         ecalls, eacc[0] / ecalls, eacc[1] / ecalls, eacc[2] / ecalls, eacc[3] / ecalls);
     }
     for (int k = 1; k < n_streams; ++k) {
         if (!wrote[k]) continue;
