@@ -1288,15 +1288,17 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     int rr = 0;
     hipStream_t streams[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]};
     const int n_streams = n_kernels > 1 && !ctx->serial_streams ? std::min(4, n_kernels) : 1;
-    if (n_streams > 1) {
-        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        for (int k = 1; k < n_streams; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(streams[k], ctx->ev_fork, 0));
-    }
+    if (n_streams > 1) JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     bool wrote[4] = {false, false, false, false};
+    bool forked[4] = {true, false, false, false};
     auto next_stream = [&](bool writes_tables = false) {
         int k = rr % n_streams;
         rr++;
         if (writes_tables) wrote[k] = true;
+        if (!forked[k]) {  // a side stream waits for the binds only when it gets its first kernel: the round's first (longest) kernel
+            (void)hipStreamWaitEvent(streams[k], ctx->ev_fork, 0);  // goes to the main stream before any of these calls
+            forked[k] = true;
+        }
         return streams[k];
     };
     // longest kernels first so that they overlap with the short ones
