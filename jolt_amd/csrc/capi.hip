@@ -46,6 +46,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     jolt_ctx* ctx = new (std::nothrow) jolt_ctx();
     if (!ctx) return JOLT_ERR_OOM;
     ctx->device = device_id;
+    if (const char* fr_ = std::getenv("JOLT_FUSE_RATIO")) ctx->fuse_ratio = (size_t)std::max(0, std::atoi(fr_));
     if (const char* tp = std::getenv("JOLT_TAIL_PAIRS")) { if (std::atoll(tp) > 0) ctx->tail_pairs = (size_t)std::atoll(tp); }
     if (const char* ft = std::getenv("JOLT_FUSE_TAIL")) ctx->fuse_tail = std::atoi(ft) != 0;
     if (const char* rt = std::getenv("JOLT_ROUND_TRACE")) ctx->round_trace = std::atoi(rt) != 0;
@@ -1131,7 +1132,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             // them into an ALU-bound round kernel (many multiplies per table) costs more than the saved pass; fuse the
             // bandwidth-bound members (<= 2 multiplies per table per pair) and never the latency-bound tail rounds.
             const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && (m->len / 4 > kTailPairs || (ctx->fuse_tail && m->kind == jolt_member::kExpr)) &&
-                                  (m->kind == jolt_member::kSplitEqProduct || (m->kind == jolt_member::kExpr && m->all_tables_used && m->muls_per_pair <= 2 * m->tables.size()));
+                                  (m->kind == jolt_member::kSplitEqProduct || (m->kind == jolt_member::kExpr && m->all_tables_used && m->muls_per_pair <= ctx->fuse_ratio * m->tables.size()));
             JOLT_TRY(member_note_bind(m, *binds[i]));  // m->len is now the bound length
             if (can_fuse) {
                 it.fused = true;
