@@ -347,7 +347,7 @@ void launch_bucket_sums(jolt_ctx* ctx, const Workspace& w, const G1Affine* bases
                            p.heavy_cap);
         hipLaunchKernelGGL(k_msm_scatter, dim3(gn, gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.keys, n, B, w.cur, w.sorted, V);
     }
-    hipLaunchKernelGGL(k_msm_buckets_light, dim3((unsigned)(((size_t)B * p.L + kBlock - 1) / kBlock), gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.hist,
+    hipLaunchKernelGGL(k_msm_buckets_light<false>, dim3((unsigned)(((size_t)B * p.L + kBlock - 1) / kBlock), gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.hist,
                        (const uint32_t*)w.offs, (const uint32_t*)w.sorted, bases, n, B, p.L, p.heavy_threshold, w.buckets, V);
     hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)w.heavy, (const uint32_t*)w.hcnt, (const uint32_t*)w.hist,
                        (const uint32_t*)w.offs, (const uint32_t*)w.sorted, bases, n, B, w.seg);

@@ -242,7 +242,7 @@ int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* 
         hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(kBlock), 0, st, (const uint32_t*)hist, offs, cur, p.B, p.heavy_threshold, heavy, hcnt, heavy_cap);
         if (lds_sort) hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, p.W), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, n, p.B, cur, sorted);
         else hipLaunchKernelGGL(k_msm_scatter, dim3(gn, p.W), dim3(kBlock), 0, st, (const uint32_t*)keys, n, p.B, cur, sorted, (size_t)p.W);
-        hipLaunchKernelGGL(k_msm_buckets_light, dim3((unsigned)(((size_t)p.B * p.L + kBlock - 1) / kBlock), p.W), dim3(kBlock), 0, st, (const uint32_t*)hist,
+        hipLaunchKernelGGL(k_msm_buckets_light<true>, dim3((unsigned)(((size_t)p.B * p.L + kBlock - 1) / kBlock), p.W), dim3(kBlock), 0, st, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, p.L, p.heavy_threshold, buckets, (size_t)p.W);
         hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, seg);

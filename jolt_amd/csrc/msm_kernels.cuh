@@ -205,19 +205,47 @@ __device__ __forceinline__ G1Jac wave_sum_g1(G1Jac acc, int width) {
     return acc;
 }
 
+// PIPELINED: the next point's index and coordinates are in flight while the current mixed addition runs.  It pays on the
+// long lists of the MSM (2^22 u64 scalars: 6.07 -> 5.2 ms; uniform 254-bit scalars: neutral) and costs occupancy where one lane
+// walks a short bucket (Dory rows, ~32 points per bucket: 9.6 -> 12.6 ms), so the row commitments use the plain loop.
+template <bool PIPELINED>
 __device__ __forceinline__ G1Jac sum_bucket_points(const uint32_t* __restrict__ src, const G1Affine* __restrict__ bases, uint32_t lo, uint32_t hi,
                                                    uint32_t stride) {
     G1Jac acc = g1_identity();
-    for (uint32_t k = lo; k < hi; k += stride) {
-        uint32_t v = src[k];
+    if constexpr (!PIPELINED) {
+        for (uint32_t k = lo; k < hi; k += stride) {
+            uint32_t v = src[k];
+            G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
+            if (v >> 31) p.y = neg(p.y);
+            acc = g1_add_mixed(acc, p);
+        }
+        return acc;
+    } else {
+        if (lo >= hi) return acc;
+        uint32_t v = src[lo];
         G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
-        if (v >> 31) p.y = neg(p.y);
-        acc = g1_add_mixed(acc, p);
+        for (uint32_t k = lo;;) {
+            const uint32_t kn = k + stride;
+            const bool more = kn < hi;
+            uint32_t vn = 0;
+            G1Affine pn = p;
+            if (more) {
+                vn = src[kn];
+                pn = ld_aff(bases + (vn & 0x7FFFFFFFu));
+            }
+            if (v >> 31) p.y = neg(p.y);
+            acc = g1_add_mixed(acc, p);
+            if (!more) break;
+            v = vn;
+            p = pn;
+            k = kn;
+        }
+        return acc;
     }
-    return acc;
 }
 
 // ---- 4a. light buckets: L adjacent lanes per bucket (L = 1 when there are enough buckets to fill the chip) ----------
+template <bool PIPELINED>
 __global__ __launch_bounds__(kBlock) void k_msm_buckets_light(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
                                                              uint32_t B, int L, uint32_t heavy_threshold, G1Jac* __restrict__ buckets,
@@ -231,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_msm_buckets_light(const uint32_t* __
     size_t slot = (size_t)w * (B + 1) + (mine ? b : 0);
     uint32_t cnt = mine ? hist[slot] : 0;
     if (cnt > heavy_threshold) { cnt = 0; mine = false; }  // the heavy kernels own it
-    G1Jac acc = sum_bucket_points(sorted + (size_t)w * n + offsets[slot], bases, sub, cnt, (uint32_t)L);
+    G1Jac acc = sum_bucket_points<PIPELINED>(sorted + (size_t)w * n + offsets[slot], bases, sub, cnt, (uint32_t)L);
     acc = wave_sum_g1(acc, L);
     if (mine && sub == 0) buckets[slot] = acc;
 }
@@ -248,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_msm_buckets_heavy(const uint32_t* __
         uint32_t w = slot / (B + 1);
         uint32_t cnt = hist[slot];
         uint32_t lo = sgi * kHeavySeg, hi = min(lo + (uint32_t)kHeavySeg, cnt);
-        G1Jac acc = sum_bucket_points(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u);
+        G1Jac acc = sum_bucket_points<true>(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u);
         acc = wave_sum_g1(acc, 64);
         if (lane == 0) seg_sums[h] = acc;
     }
