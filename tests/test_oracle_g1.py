@@ -59,6 +59,24 @@ def test_generator_and_small_multiples_vs_affine_model():
         assert to_model(O.g1_scalar_mul(g, O.to_mont([k])[0])) == aff_mul(k, G)
 
 
+def test_public_known_answers():
+    """Known-answer pins that do not come from this repository: 2*(1,2) on alt_bn128 as it appears in the EIP-196 precompile test
+    vectors, and r*G = infinity for the BN254 group order (the modulus pinned by crates/jolt-field/tests/bn254_differential.rs:21-36)."""
+    g = O.g1_generator()
+    two_g = (0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3,
+             0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4)
+    assert to_model(O.g1_double(g)) == two_g
+    assert to_model(O.g1_add(g, g)) == two_g
+    assert to_model(O.g1_scalar_mul(g, O.to_mont([2])[0])) == two_g
+    assert O.g1_is_identity(O.g1_scalar_mul(g, O.to_mont([0])[0]))
+    # (r - 1) G = -G, hence r G = infinity
+    minus_g = O.g1_scalar_mul(g, O.to_mont([R - 1])[0])
+    assert to_model(minus_g) == (1, Q - 2)
+    assert O.g1_is_identity(O.g1_add(minus_g, g))
+    # compressed form of G: x = 1, y = 2 is the smaller root -> no sign flag
+    assert O.g1_serialize_compressed(g) == (1).to_bytes(32, "little")
+
+
 def test_group_laws_and_corner_cases():
     g = O.g1_generator()
     ident = O.g1_identity()
