@@ -11,7 +11,8 @@
  * PARITY UNPINNED by vectors: the reference's tests hold no golden G1 points (group_laws.rs
  * checks msm == sum s_i P_i only).  Pinned here by: on-curve checks, group laws, msm_pippenger == naive
  * sum (the reference's own property, crates/jolt-crypto/tests/group_laws.rs:69-78,135-146) and
- * [k]G == known small multiples computed with Python big-int affine arithmetic (tests/test_oracle_g1.py).
+ * [k]G == known small multiples computed with Python big-int affine arithmetic, plus public known answers -- 2G as in the
+ * EIP-196 alt_bn128 vectors, (r-1)G = -G, the compressed form of G (tests/test_oracle_g1.py::test_public_known_answers).
  */
 #include "fr.h"
 #include <stdlib.h>

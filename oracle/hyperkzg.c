@@ -12,7 +12,7 @@
  *   open                       scheme.rs:122-158
  *
  * PARITY UNPINNED by vectors: the reference tests only round-trip commit->open->verify; there
- * are no golden commitments.  Pinned by algebraic identities in tests/test_oracle_hyperkzg.py:
+ * are no golden commitments.  Pinned by algebraic identities in tests/test_oracle_g1.py:
  * commit(p) == p(beta)*G, witness-polynomial division identity (kzg.rs:229-264), fold == multilinear
  * partial evaluation, and the verifier's folding-consistency relation (scheme.rs:226-240) on (v, point, eval).
  */
