@@ -67,7 +67,7 @@ MsmPlan plan_for(size_t n) {
     p.W = (255 + p.c - 1) / p.c;
     p.B = 1u << (p.c - 1);
     // window reduction: nb blocks of 256 threads per window, G buckets per thread
-    uint32_t threads = std::min<uint32_t>(p.B, 8192);
+    uint32_t threads = std::min<uint32_t>(p.B, 4096);
     p.nb = (threads + kBlock - 1) / kBlock;
     p.G = (p.B + p.nb * kBlock - 1) / (p.nb * kBlock);
     // lanes per light bucket: enough threads to fill 256 CUs x 4 SIMDs x 8 waves when W*B alone is too small
