@@ -178,3 +178,20 @@ def test_full_size_msm_is_the_kzg_commitment(ctx, log_n):
         got = ctx.msm(srs, ctx.upload(scalars))
         pbeta = O.kzg_eval_univariate(scalars, beta)
         assert same_point(got, O.g1_scalar_mul(g, pbeta)), kind
+
+
+@pytest.mark.parametrize("lds_sort", ["0", "1"])
+def test_msm_sort_paths_agree(monkeypatch, lds_sort):
+    """Both counting sorts of the MSM (per-workgroup LDS histograms / one global atomic per key) give the point
+    p(beta) G for uniform, 64-bit and all-equal scalars at 2^17 terms (above the size where the LDS path switches on)."""
+    monkeypatch.setenv("JOLT_MSM_LDS_SORT", lds_sort)
+    c = ffi.Context(0)
+    n = 1 << 17
+    beta = rand_fr(1, 301)[0]
+    srs = c.srs_setup_from_secret(beta, n, O.g1_generator())
+    cases = [rand_fr(n, 302), O.fr_from_u64(np.random.default_rng(303).integers(0, 2**64, size=n, dtype=np.uint64)), O.fr_from_u64(np.full(n, 3, dtype=np.uint64))]
+    for scalars in cases:
+        got = c.msm(srs, c.upload(scalars))
+        want = O.g1_scalar_mul(O.g1_generator(), O.kzg_eval_univariate(scalars, beta))
+        assert same_point(got, want)
+    c.close()

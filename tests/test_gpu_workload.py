@@ -77,3 +77,27 @@ def test_large_trace_waits_for_side_stream_kernels():
     for stage in a:
         assert np.array_equal(a[stage]["polys"], b[stage]["polys"]) and np.array_equal(a[stage]["final_claim"], b[stage]["final_claim"])
     ctx.close()
+
+
+@pytest.mark.parametrize("knobs", [
+    {"JOLT_GRID_MULT": "8"},          # 2048 workgroups per round kernel: the two-level completion tickets
+    {"JOLT_LAZY_LDS": "0"},           # index-encoded members gather their branch tables from global memory
+    {"JOLT_SERIAL_STREAMS": "1"},     # every kernel of a round on the main stream
+    {"JOLT_TAIL_PAIRS": "256", "JOLT_FUSE_RATIO": "100"},  # group kernels (bind fused everywhere) down to small rounds
+    {"JOLT_FUSE_TAIL": "1"},          # pending binds applied inside the tail kernel
+    {"JOLT_UNIFORM_ROWS_PAIRS": "64", "JOLT_LAZY_LDS": "0"},  # one-item-per-pair forms of the uniform and lazy kernels
+])
+def test_alternate_kernel_paths_give_the_same_transcript(monkeypatch, knobs):
+    """The measurement knobs of DESIGN.md section 6b select other kernels / grids / streams for the same sums: every one of them must
+    reproduce the default path's transcript bit for bit (T = 2^16: above every switch-over threshold, two-level tickets included)."""
+    base = ffi.Context(0)
+    want = DeviceWorkload(base, 16, seed=5).prove(label=9)
+    base.close()
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    ctx = ffi.Context(0)  # the knobs are read when the context is created
+    got = DeviceWorkload(ctx, 16, seed=5).prove(label=9)
+    ctx.close()
+    for stage in want:
+        for key in ("polys", "challenges", "final_claim"):
+            assert np.array_equal(got[stage][key], want[stage][key]), (knobs, stage, key)
