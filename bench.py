@@ -206,7 +206,8 @@ def main():
                    "trace_length_per_gpu": 1 << args.scale, "parallelism": f"hypercube sharded over {world} GPU(s)"},
     }
     if sharded:
-        out["config"]["collective"] = type(wl.coll).__name__ + " (RCCL all-gather of the round sums, then of the 2^tail_log-entry tables)"
+        rounds = "shared-memory exchange of the round sums between the ranks of the node" if wl.round_exchange is not None else "RCCL all-gather of the round sums"
+        out["config"]["collective"] = f"{rounds}; {type(wl.coll).__name__}: RCCL all-gather of the 2^tail_log-entry tables"
         out["config"]["tail_log"] = wl.tail_log
         out["config"]["ms_per_step_split"] = {k: round(v / args.steps * 1e3, 3) for k, v in _D.TIMINGS.items()}
     if rank == 0:

@@ -36,6 +36,61 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class ShmExchange:
+    """The per-round exchange of partial round sums between the ranks of one node through POSIX shared memory (jolt_shm_*,
+    csrc/shm_exchange.hip): a memcpy and a sequence number per rank instead of an RCCL all-gather on the critical path of every
+    sharded round.  Host memory only, so it also runs (and is tested) without a GPU.  `name` must be the same on every rank."""
+    MAX_BYTES = 64 * 1024
+
+    def __init__(self, name, rank, world, max_bytes=MAX_BYTES):
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        st = ffi.lib().jolt_shm_create(name.encode(), C.c_int32(rank), C.c_int32(world), C.c_size_t(max_bytes), C.byref(h))
+        if st:
+            raise ffi.JoltError(st, "jolt_shm_create")
+        self.h = h
+
+    def all_gather_u64(self, arr):
+        flat = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+        out = np.empty(self.world * flat.size, dtype=np.uint64)
+        st = ffi.lib().jolt_shm_all_gather(self.h, _p(flat), C.c_size_t(flat.nbytes), _p(out))
+        if st:
+            raise ffi.JoltError(st, "jolt_shm_all_gather")
+        return out.reshape(self.world, -1)
+
+    def close(self):
+        if self.h:
+            ffi.lib().jolt_shm_destroy(self.h)
+            self.h = None
+
+
+def make_shm_exchange(dist, rank, world):
+    """Collective: every rank attaches to one segment (name drawn by rank 0, carried by torch.distributed) and the ranks agree --
+    all or none -- that it works (a probe exchange included).  Returns a ShmExchange or None (then the RCCL exchange stays)."""
+    if os.environ.get("JOLT_ROUND_EXCHANGE", "shm") != "shm":
+        return None
+    name = [f"/jolt_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little'):08x}"]
+    if world > 1:
+        dist.broadcast_object_list(name, src=0)
+    shm = None
+    try:
+        shm = ShmExchange(name[0], rank, world)
+        probe = np.arange(4, dtype=np.uint64) + np.uint64(100 * rank)
+        got = shm.all_gather_u64(probe)
+        ok = all(np.array_equal(got[r], np.arange(4, dtype=np.uint64) + np.uint64(100 * r)) for r in range(world))
+    except Exception:  # noqa: BLE001 -- decided collectively below
+        ok = False
+    if world > 1:
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        ok = all(flags)
+    if not ok:
+        if shm is not None:
+            shm.close()
+        return None
+    return shm
+
+
 class Collective:
     """all_gather of small uint64 arrays over torch.distributed (device tensors for nccl, host tensors for gloo)."""
 
@@ -180,7 +235,7 @@ class MemberInfo:
 
 
 def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max_degree, world, coll, shard, label=0,
-                        challenge_mode=0, tail_log=0, force_gather=False):
+                        challenge_mode=0, tail_log=0, force_gather=False, round_exchange=None):
     """infos: [MemberInfo] (global rounds = n_total for every member here); shard: local backend with
          round(active_idx, binds) -> np (total,4);  flush(binds);
          make_tail(coll, split_eq_scalars) -> tail backend over the gathered world * 2^tail_log-entry tables
@@ -237,6 +292,9 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
 
     lcb, gcb = LOCAL_FN(local_cb), GATHER_FN(gather_cb)
     native_gather = C.cast(lib.jolt_comm_gather_round_sums, GATHER_FN) if isinstance(coll, NativeCollective) else None
+    native_user = coll.h if native_gather is not None else None
+    if round_exchange is not None:  # the round sums go through shared memory; `coll` keeps the table hand-over
+        native_gather, native_user = C.cast(lib.jolt_shm_gather_round_sums, GATHER_FN), round_exchange.h
 
     def run(n_rounds, w, exchange=True):
         if n_rounds == 0:
@@ -244,7 +302,7 @@ def prove_batch_sharded(ctx_handle, infos, claims, coeffs, n_total, n_local, max
         handles = getattr(state["backend"], "handles", None)
         gather, user = (None, None)
         if w > 1 or (force_gather and exchange):  # force_gather: run the exchange even with a single rank
-            gather, user = (native_gather, coll.h) if native_gather is not None else (gcb, None)
+            gather, user = (native_gather, native_user) if native_gather is not None else (gcb, None)
         st = lib.jolt_host_batch_run(batch, handles, C.c_size_t(n_rounds), C.c_int32(w), gather, None if handles is not None else lcb, user)
         if st:
             if state["err"] is not None:
@@ -402,6 +460,8 @@ class ShardedWorkload:
                 print(f"[jolt_amd] rank {rank}: native RCCL communicator unavailable ({err}); using torch.distributed", file=sys.stderr)
                 coll = Collective(dist, world, dev)
         self.coll = coll
+        # round sums: shared memory between the ranks of the node when every rank can map it, else the collective above
+        self.round_exchange = make_shm_exchange(dist, rank, world) if (world > 1 or force_gather) else None
         spec = build_sharded_spec(n_local, rank, world, seed)
         self.members_spec = spec["members"]
         one = ffi.host_fr_from_u64(1)
@@ -641,7 +701,7 @@ class ShardedWorkload:
             shard = DeviceShard(self.ctx, ms, rebuild=lambda c, s, stage=stage, idxs=idxs: self._tail_backend(stage, idxs, c, s))
             outs[stage] = prove_batch_sharded(self.ctx.h, infos, [self.claims[i] for i in idxs], [self.batch_coeffs[i] for i in idxs],
                                               self.n_total, self.n_local, deg, self.world, self.coll, shard, label=label + stage,
-                                              tail_log=self.tail_log, force_gather=self.force_gather)
+                                              tail_log=self.tail_log, force_gather=self.force_gather, round_exchange=self.round_exchange)
         for m in self.members:
             m.reset()
         return outs

@@ -76,8 +76,10 @@ def _worker(rank, world, port, tmpdir, tail_log):
         bit = (rank >> (log_g - 1 - k)) & 1
         f = w[k].reshape(1, 4) if bit else O.fr_sub(one.reshape(1, 4), w[k].reshape(1, 4))
         shard_scale = O.fr_mul(shard_scale, f)
-    local = OracleShard([O.Member.expr([eq[lo:hi], a[lo:hi], b[lo:hi]], flat, 2), O.Member.expr([a[lo:hi], b[lo:hi], c[lo:hi]], cubic, 3),
-                         O.Member.gruen_product(a[lo:hi], c[lo:hi], w[log_g:])], [None, None, shard_scale[0]])
+    def make_local():
+        return OracleShard([O.Member.expr([eq[lo:hi], a[lo:hi], b[lo:hi]], flat, 2), O.Member.expr([a[lo:hi], b[lo:hi], c[lo:hi]], cubic, 3),
+                            O.Member.gruen_product(a[lo:hi], c[lo:hi], w[log_g:])], [None, None, shard_scale[0]])
+    local, local_again = make_local(), make_local()
     # global reference run (every rank computes it; cheap at 2^5)
     gm = [O.Member.expr([eq, a, b], flat, 2), O.Member.expr([a, b, c], cubic, 3), O.Member.gruen_product(a, c, w)]
     claims = [m.input_claim() for m in gm]
@@ -86,7 +88,14 @@ def _worker(rank, world, port, tmpdir, tail_log):
              D.MemberInfo(D.KIND_SPLIT_EQ, 3, n_total, 2, w=w)]
     coll = D.Collective(dist, world, None)
     got = D.prove_batch_sharded(None, infos, claims, coeffs, n_total, n_local, 3, world, coll, local, label=11, tail_log=tail_log)
-    ok = (np.array_equal(got["polys"], want["polys"]) and np.array_equal(got["challenges"], want["challenges"])
+    # the same proof with the round sums exchanged through shared memory (the default between the ranks of a node)
+    shm = D.make_shm_exchange(dist, rank, world)
+    assert shm is not None
+    got_shm = D.prove_batch_sharded(None, infos, claims, coeffs, n_total, n_local, 3, world, coll, local_again, label=11, tail_log=tail_log,
+                                    round_exchange=shm)
+    shm.close()
+    same = all(np.array_equal(got[k], got_shm[k]) for k in ("polys", "challenges", "final_claim", "member_claims"))
+    ok = same and (np.array_equal(got["polys"], want["polys"]) and np.array_equal(got["challenges"], want["challenges"])
           and np.array_equal(got["final_claim"], want["final_claim"]) and np.array_equal(got["member_claims"], want["member_claims"]))
     open(os.path.join(tmpdir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
     dist.destroy_process_group()
@@ -136,3 +145,44 @@ def test_sharded_msm_combines_to_the_single_process_point(world):
         mp.spawn(_msm_worker, args=(world, port, tmp), nprocs=world, join=True)
         for r in range(world):
             assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "ok", f"rank {r}"
+
+
+def _shm_worker(rank, world, name, tmpdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from jolt_amd import distributed as D
+    shm = D.ShmExchange(name, rank, world, max_bytes=4096)
+    rng = np.random.default_rng(1000 + rank)
+    ok = True
+    for it in range(3000):  # back-to-back exchanges of varying size: the two slots per rank must never be overwritten early
+        n = 1 + (it * 7) % 500
+        mine = (np.arange(n, dtype=np.uint64) * np.uint64(it + 1)) ^ np.uint64(rank << 40)
+        got = shm.all_gather_u64(mine)
+        for r in range(world):
+            ok = ok and np.array_equal(got[r], (np.arange(n, dtype=np.uint64) * np.uint64(it + 1)) ^ np.uint64(r << 40))
+        if rank == it % world and it % 97 == 0:
+            import time
+            time.sleep(0.002 * rng.random())  # a straggler now and then
+    shm.close()
+    open(os.path.join(tmpdir, f"shm{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_shared_memory_round_exchange(world):
+    """jolt_shm_* (csrc/shm_exchange.hip): the per-round exchange between the ranks of one node, host memory only -- 3000 exchanges of
+    varying size between `world` processes, stragglers included, every rank sees every rank's payload of the same exchange; an
+    oversized payload and a second creator are refused."""
+    import torch.multiprocessing as mp
+    from jolt_amd import distributed as D
+    from jolt_amd import ffi
+    name = f"/jolt_test_{os.getpid()}_{world}"
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_shm_worker, args=(world, name, tmp), nprocs=world, join=True)
+        for r in range(world):
+            assert open(os.path.join(tmp, f"shm{r}.txt")).read() == "ok", f"rank {r}"
+    solo = D.ShmExchange(name + "_solo", 0, 1, max_bytes=64)
+    assert np.array_equal(solo.all_gather_u64(np.arange(8, dtype=np.uint64))[0], np.arange(8, dtype=np.uint64))
+    with pytest.raises(ffi.JoltError) as e:
+        solo.all_gather_u64(np.arange(9, dtype=np.uint64))  # 72 bytes > max_bytes
+    assert e.value.status == 5
+    solo.close()
