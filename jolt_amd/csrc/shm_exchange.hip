@@ -49,7 +49,7 @@ struct jolt_shm {
     size_t max_bytes = 0, map_bytes = 0;
     char* base = nullptr;
     uint64_t seq = 0;
-    bool owner = false;
+    bool owner = false, unlinked = false;
     ShmHeader* header() const { return reinterpret_cast<ShmHeader*>(base); }
     ShmSlot* slot(int r, uint64_t s) const {
         return reinterpret_cast<ShmSlot*>(base + sizeof(ShmHeader) + ((size_t)r * 2 + (s & 1)) * header()->slot_stride);
@@ -124,7 +124,7 @@ extern "C" int32_t jolt_shm_create(const char* name, int32_t rank, int32_t world
 extern "C" int32_t jolt_shm_destroy(jolt_shm* s) {
     if (!s) return JOLT_OK;
     if (s->base) munmap(s->base, s->map_bytes);
-    if (s->owner) (void)shm_unlink(s->name.c_str());
+    if (s->owner && !s->unlinked) (void)shm_unlink(s->name.c_str());
     delete s;
     return JOLT_OK;
 }
@@ -149,6 +149,10 @@ extern "C" int32_t jolt_shm_all_gather(jolt_shm* s, const void* local, size_t by
         }
         if (o->bytes != bytes) return JOLT_ERR_SIZE_MISMATCH;
         if (bytes) std::memcpy(static_cast<char*>(gathered) + (size_t)r * bytes, reinterpret_cast<const char*>(o) + sizeof(ShmSlot), bytes);
+    }
+    if (s->owner && !s->unlinked) {  // every rank has taken part in an exchange, i.e. has the segment mapped: the name can go now,
+        (void)shm_unlink(s->name.c_str());  // so that a run that is killed later leaves nothing behind in /dev/shm
+        s->unlinked = true;
     }
     return JOLT_OK;
 }
