@@ -117,6 +117,27 @@ def test_rows_wide_rows(ctx):
         assert O.g1_eq(got[r], _eval_point(beta, [int(x) for x in v[r * width:(r + 1) * width]]))
 
 
+def test_rows_multiple_batches(ctx, srs):
+    """2^22 i128 values as 1024 rows x 4096: more keys than one workspace batch holds (the rows are committed in several passes);
+    first, middle and last row against p_row(beta) G, and equal to the same rows committed on their own."""
+    beta, _, dev = srs
+    width, rows = 1 << 12, 1 << 10
+    rng = np.random.default_rng(17)
+    lo = rng.integers(0, 2**64, size=rows * width, dtype=np.uint64)
+    hi = rng.integers(0, 2**64, size=rows * width, dtype=np.uint64)
+    packed = np.stack([lo, hi], axis=1)
+    got = ctx.dory_commit_rows(dev, ctx.ints(packed, "i128"), width)
+    assert got.shape[0] == rows
+
+    def as_int(r, j):
+        v = int(lo[r * width + j]) | (int(hi[r * width + j]) << 64)
+        return v - (1 << 128) if v >> 127 else v
+    for r in (0, 511, 1023):
+        assert O.g1_eq(got[r], _eval_point(beta, [as_int(r, j) for j in range(width)])), r
+    tail = ctx.dory_commit_rows(dev, ctx.ints(packed[(rows - 2) * width:], "i128"), width)
+    assert O.g1_eq(tail[0], got[rows - 2]) and O.g1_eq(tail[1], got[rows - 1])
+
+
 def test_rows_argument_checks(ctx, srs):
     _, _, dev = srs
     v = ctx.ints(np.arange(96, dtype=np.uint64))
