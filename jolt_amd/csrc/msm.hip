@@ -227,20 +227,24 @@ int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* 
         const size_t lds_bytes = ((size_t)p.B + 1) * sizeof(uint32_t);
         const bool lds_sort = ctx->msm_lds_sort && n >= ((size_t)1 << 16) && lds_bytes <= ctx->max_lds_per_block;
         const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus / p.W, n / 8192));
-        if (lds_sort) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-                (void)hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-                attr_set = true;
+        if (lds_sort && !ctx->msm_lds_attr_set) {  // once per context (= per device): allow more than 64 KiB of dynamic LDS
+            hipError_t a1 = hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+            hipError_t a2 = hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+            if (a1 != hipSuccess || a2 != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->msm_lds_sort = false;  // this runtime refuses the large allocation: keep the per-key path
             }
+            ctx->msm_lds_attr_set = true;
+        }
+        const bool use_lds_sort = lds_sort && ctx->msm_lds_sort;
+        if (use_lds_sort) {
             hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, p.c, p.W, keys, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(slices, p.W), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, n, p.B, hist);
         } else {
             hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, p.c, p.W, keys, hist);
         }
         hipLaunchKernelGGL(k_msm_scan, dim3(p.W), dim3(kBlock), 0, st, (const uint32_t*)hist, offs, cur, p.B, p.heavy_threshold, heavy, hcnt, heavy_cap);
-        if (lds_sort) hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, p.W), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, n, p.B, cur, sorted);
+        if (use_lds_sort) hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, p.W), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, n, p.B, cur, sorted);
         else hipLaunchKernelGGL(k_msm_scatter, dim3(gn, p.W), dim3(kBlock), 0, st, (const uint32_t*)keys, n, p.B, cur, sorted, (size_t)p.W);
         hipLaunchKernelGGL(k_msm_buckets_light<true>, dim3((unsigned)(((size_t)p.B * p.L + kBlock - 1) / kBlock), p.W), dim3(kBlock), 0, st, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, p.L, p.heavy_threshold, buckets, (size_t)p.W);
