@@ -68,13 +68,21 @@ extern "C" int32_t jolt_onehot_pushforward(jolt_ctx* ctx, const jolt_onehot* s, 
     if (!ctx || !s || !weights || !out) return JOLT_ERR_INVALID_ARG;
     if (weights->len != s->cycles) return JOLT_ERR_SIZE_MISMATCH;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
-    const int nblocks = (int)std::max<size_t>(1, std::min<size_t>((s->cycles + 4 * kBlock - 1) / (4 * kBlock), 256));
+    const bool lanes = s->k <= 32;  // per-lane buckets in LDS (K * 2 KiB per wavefront): every column the reference folds this way has K = 16
+    size_t per_block = 4096;        // cycles per wavefront: 64 per lane
+    while ((s->cycles + per_block - 1) / per_block > 1024) per_block *= 2;
+    const int nblocks = lanes ? (int)std::max<size_t>(1, (s->cycles + per_block - 1) / per_block)
+                              : (int)std::max<size_t>(1, std::min<size_t>((s->cycles + 4 * kBlock - 1) / (4 * kBlock), 256));
     const size_t part = s->n_polys * (size_t)nblocks * s->k;
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, part + 8, 8));
     jolt_table* t = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, s->n_polys * s->k, &t));
-    hipLaunchKernelGGL(k_onehot_pushforward, dim3(nblocks, (unsigned)s->n_polys), dim3(kBlock), s->k * sizeof(Fr), ctx->stream, (const uint8_t*)s->idx,
-                       (const Fr*)weights->data(), s->cycles, s->k, ctx->d_partials);
+    if (lanes)
+        hipLaunchKernelGGL(k_onehot_pushforward_lanes, dim3((unsigned)s->n_polys, nblocks), dim3(64), (size_t)s->k * 2 * 64 * sizeof(uint4), ctx->stream,
+                           (const uint8_t*)s->idx, (const Fr*)weights->data(), s->cycles, s->k, per_block, ctx->d_partials);
+    else
+        hipLaunchKernelGGL(k_onehot_pushforward, dim3(nblocks, (unsigned)s->n_polys), dim3(kBlock), s->k * sizeof(Fr), ctx->stream, (const uint8_t*)s->idx,
+                           (const Fr*)weights->data(), s->cycles, s->k, ctx->d_partials);
     hipLaunchKernelGGL(k_onehot_pushforward_reduce, dim3((s->k + kBlock - 1) / kBlock, (unsigned)s->n_polys), dim3(kBlock), 0, ctx->stream,
                        (const Fr*)ctx->d_partials, nblocks, s->k, t->data());
     hipError_t e = hipGetLastError();

@@ -81,6 +81,66 @@ static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward(const uint
     }
     for (uint32_t k = threadIdx.x; k < K; k += kBlock) st_fr(partials + ((size_t)p * gridDim.x + blockIdx.x) * K + k, buckets[k]);
 }
+// The same partial tables for small K (<= 32: every RA column of the reference, K = 16), one wavefront per (polynomial, slice of
+// cycles): each LANE keeps its own K buckets in LDS ([bucket][half][lane] -> conflict-free 16-byte accesses) and walks the slice
+// with coalesced index / weight loads, so all 64 lanes add weights all the time -- the kernel above has K lanes working per
+// workgroup and re-scans the slice once per bucket (36 columns at T = 2^20: 6.0 ms there, see DESIGN.md 3.4b for this one).
+// blockIdx.x = polynomial (fastest: the columns of one slice run together and share its weights in L2), blockIdx.y = slice.
+static __global__ __launch_bounds__(64) void k_onehot_pushforward_lanes(const uint8_t* __restrict__ idx, const Fr* __restrict__ w, size_t cycles, uint32_t K,
+                                                                        size_t per_block, Fr* __restrict__ partials /* [poly][slice][K] */) {
+    extern __shared__ uint4 push_sh[];  // K * 2 * 64 uint4
+    const uint32_t lane = threadIdx.x;
+    const size_t p = blockIdx.x, slice = blockIdx.y, nslices = gridDim.y;
+    for (uint32_t e = lane; e < K * 2 * 64; e += 64) push_sh[e] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint8_t* col = idx + p * cycles;
+    const size_t lo = slice * per_block, hi = lo + per_block < cycles ? lo + per_block : cycles;
+    for (size_t j = lo + lane; j < hi; j += 64) {
+        const uint8_t k = col[j];
+        if (k == kOneHotCold) continue;
+        const Fr x = ld_fr(w + j);
+        uint4* b0 = push_sh + ((uint32_t)k * 2) * 64 + lane;
+        uint4* b1 = b0 + 64;
+        uint4 a0 = *b0, a1 = *b1;
+        Fr acc;
+        acc.l[0] = a0.x; acc.l[1] = a0.y; acc.l[2] = a0.z; acc.l[3] = a0.w; acc.l[4] = a1.x; acc.l[5] = a1.y; acc.l[6] = a1.z; acc.l[7] = a1.w;
+        acc = add(acc, x);
+        *b0 = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
+        *b1 = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+    }
+    __syncthreads();
+    auto load_lds = [&](uint32_t k, uint32_t l) {
+        const uint4 a0 = push_sh[(k * 2) * 64 + l], a1 = push_sh[(k * 2 + 1) * 64 + l];
+        Fr s;
+        s.l[0] = a0.x; s.l[1] = a0.y; s.l[2] = a0.z; s.l[3] = a0.w; s.l[4] = a1.x; s.l[5] = a1.y; s.l[6] = a1.z; s.l[7] = a1.w;
+        return s;
+    };
+    if (64 % K == 0) {
+        // g = 64 / K lanes per bucket: lane (b, q) adds K of the 64 per-lane values of bucket b, the g parts meet in log2 g shuffles
+        const uint32_t g = 64 / K, b = lane / g, q = lane % g;
+        Fr s = Fr::zero();
+        for (uint32_t i = 0; i < K; ++i) s = add(s, load_lds(b, q * K + i));
+        for (uint32_t off = g >> 1; off >= 1; off >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o.l[t] = __shfl_xor(s.l[t], off, 64);
+            s = add(s, o);
+        }
+        if (q == 0) st_fr(partials + (p * nslices + slice) * K + b, s);
+    } else {
+        for (uint32_t k = 0; k < K; ++k) {
+            Fr s = load_lds(k, lane);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                Fr o;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o.l[t] = __shfl_xor(s.l[t], off, 64);
+                s = add(s, o);
+            }
+            if (lane == 0) st_fr(partials + (p * nslices + slice) * K + k, s);
+        }
+    }
+}
 static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward_reduce(const Fr* __restrict__ partials, int nblocks, uint32_t K, Fr* __restrict__ out) {
     const size_t p = blockIdx.y;
     uint32_t k = blockIdx.x * kBlock + threadIdx.x;
