@@ -50,6 +50,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* tp = std::getenv("JOLT_TAIL_PAIRS")) { if (std::atoll(tp) > 0) ctx->tail_pairs = (size_t)std::atoll(tp); }
     if (const char* ft = std::getenv("JOLT_FUSE_TAIL")) ctx->fuse_tail = std::atoi(ft) != 0;
     if (const char* rt = std::getenv("JOLT_ROUND_TRACE")) ctx->round_trace = std::atoi(rt) != 0;
+    if (const char* gf = std::getenv("JOLT_GRID_FLOOR")) { if (std::atoi(gf) > 0) ctx->grid_floor = (size_t)std::atoi(gf); }
     if (const char* gm = std::getenv("JOLT_GRID_MULT")) { if (std::atoi(gm) > 0) ctx->grid_mult = (size_t)std::atoi(gm); }
     if (const char* ss = std::getenv("JOLT_SERIAL_STREAMS")) ctx->serial_streams = std::atoi(ss) != 0;
     if (const char* ll = std::getenv("JOLT_LAZY_LDS")) ctx->lazy_lds = std::atoi(ll) != 0;
@@ -171,13 +172,16 @@ static inline int sweep_grid(const jolt_ctx* ctx, size_t n) {
     size_t cap = (size_t)ctx->num_cus * 8;
     return (int)std::max<size_t>(1, std::min(need, cap));
 }
-// grid of a round-sum kernel: ONE workgroup per CU.  Every wavefront of these kernels ends with a shuffle reduction of its NE
-// 256-bit accumulators, a device-scope fence and a ticket; measured on the bench workload, 256 workgroups beat 512 / 1024 /
-// 2048 at T = 2^20 (7.6 / 8.1 / 7.9 / 8.1 ms per pass) and at 2^22 (17.0 / 18.1 / 17.6 / 19.3): the per-wavefront epilogue
-// costs more than the extra memory-level parallelism buys.
+// grid of a round-sum kernel: three workgroups per CU (fewer when the round is smaller), up to eight once every thread would
+// still have ~16 items.  Every wavefront of these kernels ends with a shuffle reduction of its NE 256-bit accumulators and a
+// ticket: with the fenced completion path of the first version small rounds wanted ONE workgroup per CU (T = 2^20, per pass: 7.6 /
+// 8.1 / 7.9 / 8.1 ms for 1 / 2 / 4 / 8); without the fences 1..4 per CU measure the same at 2^20 and the big rounds of long traces
+// want the memory-level parallelism of more (T = 2^22: 16.0 / 15.5 / 15.0 ms for 1 / 4 / 8, T = 2^24: 52.6 / 49.9 / 47.8 for 1 / 4 /
+// this rule).  JOLT_GRID_MULT fixes the count per CU, JOLT_GRID_FLOOR the lower bound.
 static inline int round_grid(const jolt_ctx* ctx, size_t n) {
     size_t need = (n + kBlock - 1) / kBlock;
-    size_t cap = (size_t)ctx->num_cus * ctx->grid_mult;
+    size_t cus = (size_t)ctx->num_cus;
+    size_t cap = ctx->grid_mult ? cus * ctx->grid_mult : std::min(cus * 8, std::max(cus * ctx->grid_floor, need / 16));
     return (int)std::max<size_t>(1, std::min(need, cap));
 }
 

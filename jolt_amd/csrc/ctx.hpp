@@ -58,7 +58,8 @@ struct jolt_ctx {
     // uniform split-eq members switch from (product, pair) work items to one item per pair at this many pairs
     // (JOLT_UNIFORM_ROWS_PAIRS overrides; tests lower it to run the row-major kernels at small sizes)
     size_t uniform_rows_pairs = (size_t)1 << 16;
-    size_t grid_mult = 1;         // workgroups per CU of a round-sum kernel (JOLT_GRID_MULT)
+    size_t grid_floor = 3;        // adaptive grid: workgroups per CU before the items-per-thread rule adds more (JOLT_GRID_FLOOR; 1..4 equal at 2^20, 3 is 4 % ahead at 2^22)
+    size_t grid_mult = 0;         // workgroups per CU of a round-sum kernel (JOLT_GRID_MULT); 0 = by size (round_grid)
     size_t fuse_ratio = 2;        // an expression member's pending bind is fused into its round kernel when multiplies per pair <= ratio x tables (JOLT_FUSE_RATIO)
     size_t tail_pairs = 16384;    // rounds with at most this many pairs use the tail kernel (JOLT_TAIL_PAIRS; 4096..65536 measure within 2 %)
     bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
