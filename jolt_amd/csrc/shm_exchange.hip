@@ -144,7 +144,9 @@ extern "C" int32_t jolt_shm_all_gather(jolt_shm* s, const void* local, size_t by
         uint64_t spins = 0;
         while (o->seq.load(std::memory_order_acquire) != seq) {
             __builtin_ia32_pause();
-            if ((++spins & 0xFFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutSeconds)
+            ++spins;
+            if ((spins & 0x3FFF) == 0) sched_yield();  // more ranks than free cores: give the one we are waiting for a chance to run
+            if ((spins & 0xFFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutSeconds)
                 return JOLT_ERR_HIP;  // a rank stopped taking part: fail instead of spinning forever
         }
         if (o->bytes != bytes) return JOLT_ERR_SIZE_MISMATCH;
