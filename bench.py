@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- prover trace cycles/sec of the sumcheck hot path on MI355X (BASELINE.json metric).
+"""bench.py -- prover trace cycles/sec of the sumcheck + HyperKZG hot path on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one synthetic sha3-shaped trace of T = 2^scale cycles: every cycle-domain
-relation of the reference's stages 2..6b (jolt_amd/workload.py) proved as per-stage batched
-sumchecks through the C ABI, all tables resident in HBM before the timed region starts.
+A "step" is one proof's worth of hot-path work over one synthetic sha3-shaped trace of T = 2^scale cycles
+(jolt_amd/workload.py, DeviceWorkload.step), everything a proof needs inside the timed region:
+  prepare  witness promotion + every T-sized derived table (eq / eq+1 / LT expansions, linear-leaf fusions) + members
+  commit   the committed columns over the shared 2^(4+scale) commitment grid (HyperKZG: MSMs / sums of bases)
+  prove    the cycle-domain relations of stages 2..6b as per-stage batched sumchecks
+  open     joint polynomial of the homomorphic batch + ONE HyperKZG opening (fold, 4N-term MSM work, Horner, division)
+Resident before the timed region: the witness as 64-bit integer columns and hot indices, the SRS ("inputs in HBM").
 
-    python bench.py                                   # N=1, configs[1]: sha3 T=2^20, sumcheck bind + round-poly kernels
+    python bench.py                         # N=1, BASELINE configs[2]: T=2^22, sumcheck + HyperKZG commit/open end-to-end
+    python bench.py --scale 20 --no-msm     # BASELINE configs[1]: T=2^20, sumcheck bind + round-poly kernels only
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N    # hypercube sharded over N GPUs (weak)
 
 Prints ONE JSON line (rank 0) with `roofline` (bind kernel, HIP-event timed live) and `cpu_baseline` (the oracle's
@@ -30,12 +35,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scale", type=int, default=20, help="log2 of the per-GPU trace length T")
+    ap.add_argument("--scale", type=int, default=22, help="log2 of the per-GPU trace length T")
+    ap.add_argument("--no-msm", action="store_true", help="sumcheck legs only (BASELINE configs[1]); default: commit + open inside the step")
+    ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
     ap.add_argument("--roofline-only", action="store_true", help="only run the bind-kernel roofline loop (rocprof target)")
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scale", type=int, default=17, help="log2 T of the CPU baseline sample")
+    ap.add_argument("--cpu-scale", type=int, default=0, help="log2 T of the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     return ap.parse_args()
 
 
@@ -78,57 +85,92 @@ def bind_roofline(ctx, ffi, log_n, reps):
             "avg_launch_ms": round(ms, 5)}
 
 
-def cpu_baseline(log_t):
-    """The oracle's OpenMP port of the same member mix (kind = "port": the reference is Rust+rayon and cannot be built in
-    this image), on all host cores, over a bounded sample: the full catalogue at T = 2^log_t."""
+def cpu_baseline(log_t, srs_host, with_pcs):
+    """The same step on the host cores through the oracle's OpenMP restatement (kind = "port": the reference is Rust + rayon and
+    cannot be built in this image; its arithmetic lives in an un-vendored arkworks fork): per-proof tables, the 11 relations in the
+    optimized tier's fused form (skipped s(1), linear combinations folded; the RA columns dense), and -- with_pcs -- the
+    commitments on the K x T grid, the joint polynomial and ONE HyperKZG opening with a window-parallel bucket MSM.
+    A bounded sample: T = 2^log_t cycles (log_t = 0: sized from a probe to ~10-30 s), thread count calibrated at that size."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from workload_oracle import OracleWorkload
+    from jolt_amd import workload as W
+    from workload_oracle import make_table, resolver
 
-    def run(scale, min_seconds=0.0):
-        w = OracleWorkload(scale, seed=2026)
-        members = []
-        for ms in w.members_spec:
-            tabs = [w.tables[t] for t in ms.tables]
-            if ms.split_eq is not None:
-                a, b, pt = ms.split_eq
-                one = w.one
-                members.append(([O.eq_evals(pt), tabs[a], tabs[b]], [[(None, [(one, 0)]), (None, [(one, 1)]), (None, [(one, 2)])]], 3))
-            else:
-                members.append((tabs, w.res.groups(ms.groups), ms.degree))
-        rng = np.random.default_rng(5)
-        chal = rng.integers(0, 2**64, size=(scale, 4), dtype=np.uint64)
-        chal[:, 0] = 0
-        chal[:, 1] = 0
-        chal[:, 3] &= np.uint64((1 << 61) - 1)
-        total, reps = 0.0, 0
-        while reps == 0 or total < min_seconds:
+    K = 16
+
+    class Sample:
+        def __init__(self, scale):
+            self.scale, self.T = scale, 1 << scale
+            self.spec, self.members_spec, gammas = W.build(scale, 2026)
+            self.res, self.one, _ = resolver(gammas)
+            rng = np.random.default_rng(5)
+            self.chal = rng.integers(0, 2**64, size=(scale, 4), dtype=np.uint64)
+            self.chal[:, 0] = 0
+            self.chal[:, 1] = 0
+            self.chal[:, 3] &= np.uint64((1 << 61) - 1)
+            prng = np.random.default_rng(6)
+            self.idx = np.stack([self.spec[t].data for ms in self.members_spec if ms.uniform is not None for t in ms.tables[1:]])
+            self.s_oh, self.s_d = W.rand_fr(self.idx.shape[0], prng), W.rand_fr(2, prng)
+            self.point = W.rand_fr(scale + 4, prng)
+            if with_pcs:
+                self.bases = O.baseline_prepare_bases(srs_host[: K * self.T])  # affine conversion once (not timed)
+
+        def step(self):
             t0 = time.perf_counter()
-            for tabs, groups, deg in members:
-                O.baseline_member_sumcheck(tabs, groups, deg, chal)
-            total += time.perf_counter() - t0
-            reps += 1
-        return total, reps
+            tables = {name: make_table(sp) for name, sp in self.spec.items()}  # witness promotion + every derived table
+            for ms in self.members_spec:
+                tabs = [tables[t] for t in ms.tables]
+                if ms.split_eq is not None:
+                    a, b, pt = ms.split_eq
+                    O.baseline_member_sumcheck([O.eq_evals(pt), tabs[a], tabs[b]], [[(None, [(self.one, 0)]), (None, [(self.one, 1)]), (None, [(self.one, 2)])]], 3, self.chal)
+                else:
+                    O.baseline_member_sumcheck(tabs, self.res.groups(ms.groups), ms.degree, self.chal)
+            if with_pcs:
+                dense = [tables["s6.ram_inc"], tables["s6.rd_inc"]]
+                for d in dense:
+                    O.baseline_msm(self.bases, d)
+                for p in range(self.idx.shape[0]):
+                    O.baseline_grid_onehot_sum(self.bases, self.idx[p])
+                joint = O.baseline_grid_joint(self.idx, K, self.s_oh, dense, self.s_d)
+                O.hyperkzg_open(self.bases, joint, self.point, label=1)
+            return time.perf_counter() - t0
 
-    # containers often expose more logical CPUs than they may use: calibrate the thread count on a tiny instance
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    best_n, best_t = 1, None
-    for n in sorted({1, min(hw, 8), min(hw, 16), min(hw, 32), min(hw, 64), max(1, hw // 2), hw}):
-        O.baseline_set_threads(n)
-        t, _ = run(min(log_t, 14))
-        if best_t is None or t < best_t:
-            best_n, best_t = n, t
-    O.baseline_set_threads(best_n)
-    # bounded sample of ~10-20 s of CPU work: probe at 2^log_t, then the largest T <= 2^20 that fits, repeated to >= 10 s
-    probe, _ = run(log_t)
-    scale = log_t
-    while scale < 20 and probe * (1 << (scale + 1 - log_t)) <= 12.0:
-        scale += 1
-    dt, reps = run(scale, min_seconds=10.0)
-    return {"value": round(reps * (1 << scale) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
-            "sample": f"same 11-relation member mix at T=2^{scale}, all rounds (bind + round sums), {reps} pass(es), C port with OpenMP on "
-                      f"{best_n} of {hw} host threads (fastest of 1/8/16/32/64/{max(1, hw // 2)}/{hw} threads at T=2^14); {dt:.1f}s of CPU work"}
+    O.baseline_use_parallel_msm(True)
+    try:
+        # size the sample: probe at 2^10 with a moderate thread count, then the largest T whose step should stay under ~25 s
+        O.baseline_set_threads(min(hw, 32))
+        probe_scale = 10
+        probe = Sample(probe_scale).step()
+        if log_t <= 0:
+            log_t = probe_scale
+            cap = 18 if with_pcs else 20
+            max_grid = int(np.log2(max(len(srs_host), 1))) - 4 if with_pcs else cap
+            while log_t < min(cap, max_grid) and probe * (1 << (log_t + 1 - probe_scale)) <= 12.0:
+                log_t += 1
+        smp = Sample(log_t)
+        best_n, best_t = None, None
+        for n in sorted({min(hw, 8), min(hw, 16), min(hw, 32), min(hw, 64), max(1, hw // 2), hw}, reverse=True):
+            O.baseline_set_threads(n)
+            t = smp.step()
+            if best_t is None or t < best_t:
+                best_n, best_t = n, t
+            if t > 30.0:
+                break
+        O.baseline_set_threads(best_n)
+        dt, reps = 0.0, 0
+        while reps == 0 or (dt < 10.0 and reps < 4):
+            dt += smp.step()
+            reps += 1
+    finally:
+        O.baseline_use_parallel_msm(False)
+    pcs_note = (f" + commitments of 38 columns on the 2^{log_t + 4} grid + joint polynomial + one HyperKZG opening (bucket MSM parallel over windows x point chunks, "
+                f"affine bases prepared outside the timed region)") if with_pcs else ""
+    return {"value": round(reps * (1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
+            "sample": f"the same step at T=2^{log_t}: per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
+                      f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs) with OpenMP on {best_n} of {hw} host threads "
+                      f"(nproc {os.cpu_count()}; fastest of the thread counts tried at this size); {dt:.1f}s of CPU work"}
 
 
 def main():
@@ -153,11 +195,14 @@ def main():
         print(json.dumps(bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)))
         return
 
+    pcs = None if (args.no_msm or sharded) else "grid"  # the sharded path does not carry the PCS legs yet
     if sharded:
         from jolt_amd.distributed import ShardedWorkload
         wl = ShardedWorkload(ctx, args.scale, rank, world, dist, force_gather=(world == 1))
+        step = wl.prove
     else:
-        wl = DeviceWorkload(ctx, args.scale)
+        wl = DeviceWorkload(ctx, args.scale, pcs=pcs)
+        step = wl.step
 
     def barrier():
         ctx.synchronize()
@@ -167,7 +212,7 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        wl.prove(label=1000 + i)
+        step(label=1000 + i)
     barrier()
     if sharded:
         from jolt_amd import distributed as _D
@@ -175,7 +220,7 @@ def main():
             _D.TIMINGS[k] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        wl.prove(label=2000 + i)
+        step(label=2000 + i)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -184,11 +229,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
+    # where the step time goes: two more steps (outside the timed region) with a synchronisation after each leg
+    split = None
+    if not sharded and not args.no_split:
+        legs = [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + [("prove", lambda: wl.prove(label=3000))] + \
+               ([("open", lambda: wl.open(label=3000))] if pcs else [])
+        acc = {k: 0.0 for k, _ in legs}
+        reps = 2
+        for _ in range(reps):
+            for k, fn in legs:
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                ctx.synchronize()
+                acc[k] += time.perf_counter() - t1
+        split = {k: round(v / reps * 1e3, 3) for k, v in acc.items()}
     n_onehot = getattr(wl, "n_onehot", 0)
     onehot_note = f" of which {n_onehot} are one-hot RA selector columns kept as 1-byte hot indices until their fourth bind" if n_onehot else ""
     total_cycles = (1 << args.scale) * world
+    if pcs:
+        what = (f"BASELINE configs[2]: sha3-shaped synthetic trace, T=2^{args.scale} per GPU, sumcheck + HyperKZG end-to-end -- every step rebuilds the "
+                f"per-proof tables (witness promotion, eq / eq+1 / LT expansions, linear-leaf fusions, members), commits the {n_onehot + 2} committed columns "
+                f"on the 2^{wl.grid_vars} commitment grid (2 dense MSMs of T 64-bit scalars + {n_onehot} one-hot columns as sums of bases), proves the "
+                f"stage 2-6b cycle-domain sumchecks (11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5) and opens the joint polynomial "
+                f"(2^{wl.grid_vars} coefficients) with ONE HyperKZG opening (MSM, commit and open inside the timed region)")
+    else:
+        what = (f"sha3-shaped synthetic trace, T=2^{args.scale} per GPU: per-proof tables + stages 2-6b cycle-domain sumchecks "
+                f"(11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5), bind + round-poly HIP kernels; MSM not in the timed region "
+                f"(BASELINE configs[1] shape)")
     out = {
-        "metric": "prover trace cycles/sec (sha3-shaped synthetic trace, sumcheck hot path)",
+        "metric": "prover trace cycles/sec (sha3-shaped synthetic trace, sumcheck + HyperKZG hot path)",
         "value": round(total_cycles / (dt / args.steps), 1),
         "unit": "cycles/s",
         "n_gpus": world,
@@ -198,13 +268,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u256 (BN254 Fr, 8x u32 Montgomery limbs; integer, bit-exact)",
+        "dtype": "u256 (BN254 Fr / Fq, 8x u32 Montgomery limbs; integer, bit-exact)",
         "data": "synthetic",
-        "config": {"workload": f"sha3-shaped synthetic trace, T=2^{args.scale} per GPU: stages 2-6b cycle-domain sumchecks "
-                               f"(11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5), bind + round-poly HIP kernels; MSM not in the timed region "
-                               f"(BASELINE configs[1])",
-                   "trace_length_per_gpu": 1 << args.scale, "parallelism": f"hypercube sharded over {world} GPU(s)"},
+        "config": {"workload": what, "trace_length_per_gpu": 1 << args.scale, "parallelism": f"hypercube sharded over {world} GPU(s)"},
     }
+    if split is not None:
+        out["config"]["ms_per_step_split"] = split
+    if not sharded:
+        out["config"]["device_pool_gib"] = {k.replace("_bytes", ""): round(v / 2**30, 2) for k, v in ctx.memory_stats().items()}
     if sharded:
         rounds = "shared-memory exchange of the round sums between the ranks of the node" if wl.round_exchange is not None else "RCCL all-gather of the round sums"
         out["config"]["collective"] = f"{rounds}; {type(wl.coll).__name__}: RCCL all-gather of the 2^tail_log-entry tables"
@@ -214,7 +285,11 @@ def main():
         out["roofline"] = bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_scale)
+                srs_host = None
+                if pcs:
+                    n_cpu = min(len(wl.srs), 1 << 22)  # SRS prefix for the CPU sample's grid (the bases are inputs, not product work)
+                    srs_host = wl.srs.download(0, n_cpu)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_host, bool(pcs))
             except Exception as e:  # the oracle is optional infrastructure: never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "cycles/s", "cores": None, "kind": "port", "sample": f"unavailable: {e}"}
         print(json.dumps(out), flush=True)

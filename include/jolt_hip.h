@@ -72,6 +72,12 @@ int32_t jolt_ctx_create(int32_t device_id, void *stream, jolt_ctx **out);
 int32_t jolt_ctx_destroy(jolt_ctx *ctx);
 int32_t jolt_ctx_synchronize(jolt_ctx *ctx);
 const char *jolt_last_error(const jolt_ctx *ctx);
+/* Device memory of tables, members and temporaries comes from a per-context pool (a proof builds and drops dozens of T-sized
+ * derived tables -- the Vec<Fr> allocations of EqPolynomial::evals & co. in the reference; hipMalloc / hipFree cost 0.1-1 ms each
+ * and synchronise the device).  _trim returns the cached blocks to the runtime (synchronises); _memory_stats reports the bytes held
+ * by live handles, cached by the pool, and the high-water mark of both (any pointer may be NULL). */
+int32_t jolt_ctx_trim(jolt_ctx *ctx);
+int32_t jolt_ctx_memory_stats(const jolt_ctx *ctx, size_t *live_bytes, size_t *cached_bytes, size_t *peak_bytes);
 /* Device-event timing of everything enqueued between begin and end on the context's stream (milliseconds). */
 int32_t jolt_timer_begin(jolt_ctx *ctx);
 int32_t jolt_timer_end(jolt_ctx *ctx, float *elapsed_ms);
@@ -281,6 +287,8 @@ int32_t jolt_host_fr_sub(const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out)
 int32_t jolt_host_fr_inv(const jolt_fr_t *a, jolt_fr_t *out);
 int32_t jolt_host_fr_from_u64(uint64_t v, jolt_fr_t *out);
 int32_t jolt_host_fr_mul_shifted(const jolt_fr_t *a, const jolt_fr_t *c, jolt_fr_t *out); /* c low limbs must be 0 */
+/* EqPolynomial::evals_serial (crates/jolt-poly/src/eq.rs:299-315) on the host, n <= 20: the K-entry address tables of one-hot members */
+int32_t jolt_host_eq_evals(const jolt_fr_t *r, size_t n, const jolt_fr_t *scale, jolt_fr_t *out);
 /* the kernels' multiplication algorithm (nine 29-bit limbs, product scanning) compiled for the host; field 0 = Fr, 1 = Fq */
 int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out);
 /* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
@@ -404,6 +412,27 @@ int32_t jolt_dory_commit_rows(jolt_ctx *ctx, const jolt_srs *srs, const jolt_int
 /* out[chunk*k + row] for the cycles / chunk_width chunks of hot-index column `poly`; an empty row gives the identity
  * (Bn254G1::default(), streaming.rs:409-418).  Same argument checks as above (:376-392). */
 int32_t jolt_dory_commit_onehot(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, size_t poly, size_t chunk_width, jolt_g1_t *out);
+
+/* Promotion of device-resident integers (entries [offset, offset+len) of `values`) to a field table: Ring::from_u64 / from_i64 /
+ * from_i128 per entry (crates/jolt-field/src/bn254/mod.rs:265-328), the From<T> of Polynomial<T>::bind_to_field (dense.rs:129-142)
+ * for witness columns that already sit in HBM (no host round trip; jolt_table_from_u64 is the same from host memory). */
+int32_t jolt_table_from_ints(jolt_ctx *ctx, const jolt_ints *values, size_t offset, size_t len, jolt_table **out);
+
+/* The committed trace polynomials over the proof's shared commitment grid, for a KZG-type scheme (HyperKZG).  Every witness
+ * polynomial is committed in one grid of log_k + log_t variables (crates/jolt-kernels/src/commitment.rs:1-8,86-130); cycle-major
+ * placement: coefficient (address k, cycle j) at index k*T + j, dense columns at k = 0 (TracePlacement / TraceOpeningPoly::entry,
+ * crates/jolt-kernels/src/optimized/opening.rs:340-372,404-420).
+ *   jolt_grid_commit_onehot: out[p] = sum over the hot cycles j of column p of srs[hot_p(j)*T + j] -- kzg_commit
+ *     (crates/jolt-hyperkzg/src/kzg.rs:15-27) of a polynomial whose coefficients are 0/1 with one 1 per hot cycle: additions only.
+ *     source->k * T > srs length is JOLT_ERR_SRS_TOO_SMALL.
+ *   jolt_grid_joint_polynomial: the joint polynomial of HomomorphicBatch::prove_batch (crates/jolt-openings/src/schemes.rs:487-524,
+ *     RlcSource::to_dense crates/jolt-poly/src/multilinear.rs:159-170) over the 2^log_k * T grid:
+ *     out[k*T + j] = sum_p onehot_scalars[p] * [hot_p(j) == k] + [k == 0] * sum_d dense_scalars[d] * dense[d][j];
+ *     onehot_scalars runs over the polynomials of sources[0], sources[1], ... in order.  <= 4 sources, <= 8 dense columns. */
+int32_t jolt_grid_commit_onehot(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, jolt_g1_t *out /* n_polys */);
+int32_t jolt_grid_joint_polynomial(jolt_ctx *ctx, const jolt_onehot *const *sources, size_t n_sources, const jolt_fr_t *onehot_scalars,
+                                   jolt_table *const *dense, size_t n_dense, const jolt_fr_t *dense_scalars, uint32_t log_k,
+                                   jolt_table **out);
 
 /* Multi-GPU data path (one process per GPU).  The collectives are RCCL calls on the context's stream;
  * librccl.so.1 is resolved with dlopen at first use (`rccl_path` may name it explicitly, NULL = the copy already mapped into

@@ -58,6 +58,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (prop.sharedMemPerBlock > 0) ctx->max_lds_per_block = prop.sharedMemPerBlock;
     if (const char* ml = std::getenv("JOLT_MSM_LDS_SORT")) ctx->msm_lds_sort = std::atoi(ml) != 0;
+    if (const char* pe = std::getenv("JOLT_POOL")) ctx->pool_enabled = std::atoi(pe) != 0;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
@@ -98,6 +99,9 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     for (int k = 0; k < 3; ++k) if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (int k = 0; k < 3; ++k) if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+    (void)jolt_internal_pool_trim(ctx);
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);  // blocks of handles the caller never freed
+    ctx->pool_live.clear();
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_results) (void)hipFree(ctx->d_results);
     if (ctx->h_results) (void)hipHostFree(ctx->h_results);
@@ -135,6 +139,78 @@ extern "C" int32_t jolt_timer_end(jolt_ctx* ctx, float* ms) {
     JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     JOLT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
     JOLT_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end));
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// device-memory pool (see ctx.hpp)
+// ------------------------------------------------------------------------------------------------------------------
+static inline size_t pool_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    size_t top = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));  // largest power of two <= bytes
+    size_t step = top >> 2;                                                         // classes at 1, 1.25, 1.5, 1.75 x 2^k: <= 25 % slack
+    return (bytes + step - 1) / step * step;
+}
+int32_t jolt_internal_pool_trim(jolt_ctx* ctx) {
+    if (ctx->pool_free.empty()) return JOLT_OK;
+    (void)hipDeviceSynchronize();  // cached blocks may still be read by work in flight
+    for (auto& kv : ctx->pool_free)
+        for (void* p : kv.second) (void)hipFree(p);
+    ctx->pool_free.clear();
+    ctx->pool_cached_bytes = 0;
+    return JOLT_OK;
+}
+int32_t jolt_internal_dev_alloc(jolt_ctx* ctx, size_t bytes, void** out) {
+    const size_t cls = pool_class(std::max<size_t>(bytes, 1));
+    auto it = ctx->pool_free.find(cls);
+    if (it != ctx->pool_free.end() && !it->second.empty()) {
+        // a recycled block may have been written by a side stream in the previous batch round: the main stream joins those first
+        JOLT_TRY(jolt_internal_join_side_writers(ctx));
+        *out = it->second.back();
+        it->second.pop_back();
+        ctx->pool_cached_bytes -= cls;
+    } else {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, cls);
+        if (e == hipErrorOutOfMemory && ctx->pool_cached_bytes) {  // give the cached blocks back and retry once
+            (void)hipGetLastError();
+            JOLT_TRY(jolt_internal_pool_trim(ctx));
+            e = hipMalloc(&p, cls);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->last_error = std::string("hipMalloc(") + std::to_string(cls) + "): " + hipGetErrorString(e);
+            return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+        }
+        *out = p;
+    }
+    ctx->pool_live[*out] = cls;
+    ctx->pool_live_bytes += cls;
+    ctx->pool_peak_bytes = std::max(ctx->pool_peak_bytes, ctx->pool_live_bytes + ctx->pool_cached_bytes);
+    return JOLT_OK;
+}
+void jolt_internal_dev_free(jolt_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx ? ctx->pool_live.find(p) : std::unordered_map<void*, size_t>::iterator();
+    if (!ctx || it == ctx->pool_live.end()) { (void)hipFree(p); return; }  // not ours (should not happen): the runtime's free synchronises
+    const size_t cls = it->second;
+    ctx->pool_live.erase(it);
+    ctx->pool_live_bytes -= cls;
+    if (!ctx->pool_enabled) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); return; }
+    ctx->pool_free[cls].push_back(p);
+    ctx->pool_cached_bytes += cls;
+}
+/* Release the cached device blocks of the context's pool back to the runtime (synchronises the device). */
+extern "C" int32_t jolt_ctx_trim(jolt_ctx* ctx) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    return jolt_internal_pool_trim(ctx);
+}
+/* Bytes held by live pool blocks / cached by the pool / high-water mark of both (device memory accounting of a proof). */
+extern "C" int32_t jolt_ctx_memory_stats(const jolt_ctx* ctx, size_t* live_bytes, size_t* cached_bytes, size_t* peak_bytes) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    if (live_bytes) *live_bytes = ctx->pool_live_bytes;
+    if (cached_bytes) *cached_bytes = ctx->pool_cached_bytes;
+    if (peak_bytes) *peak_bytes = ctx->pool_peak_bytes;
     return JOLT_OK;
 }
 
@@ -209,11 +285,10 @@ int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out) {
     t->ctx = ctx;
     t->len = len;
     size_t bytes = std::max<size_t>(len, 1) * sizeof(Fr);
-    hipError_t e = hipMalloc((void**)&t->buf[0], bytes);
-    if (e != hipSuccess) {
+    int32_t st = jolt_internal_dev_alloc(ctx, bytes, (void**)&t->buf[0]);
+    if (st != JOLT_OK) {
         delete t;
-        ctx->last_error = std::string("hipMalloc table: ") + hipGetErrorString(e);
-        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+        return st;
     }
     t->cap[0] = std::max<size_t>(len, 1);
     *out = t;
@@ -223,8 +298,8 @@ int32_t jolt_internal_table_ensure_alt(jolt_table* t, size_t need) {
     int alt = t->cur < 0 ? 0 : 1 - t->cur;
     if (t->cap[alt] >= need) return JOLT_OK;
     jolt_ctx* ctx = t->ctx;
-    if (t->buf[alt]) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(t->buf[alt])); t->buf[alt] = nullptr; t->cap[alt] = 0; }
-    JOLT_HIP_TRY(ctx, hipMalloc((void**)&t->buf[alt], std::max<size_t>(need, 1) * sizeof(Fr)));
+    if (t->buf[alt]) { jolt_internal_dev_free(ctx, t->buf[alt]); t->buf[alt] = nullptr; t->cap[alt] = 0; }
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(need, 1) * sizeof(Fr), (void**)&t->buf[alt]));
     t->cap[alt] = std::max<size_t>(need, 1);
     return JOLT_OK;
 }
@@ -269,14 +344,14 @@ static int32_t table_from_small(jolt_ctx* ctx, const T* host, size_t len, jolt_t
     JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
     if (len) {
         T* staging = nullptr;
-        hipError_t e = hipMalloc((void**)&staging, len * sizeof(T));
+        hipError_t e = jolt_internal_dev_alloc(ctx, len * sizeof(T), (void**)&staging) == JOLT_OK ? hipSuccess : hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMemcpyAsync(staging, host, len * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(kernel, dim3(sweep_grid(ctx, len)), dim3(kBlock), 0, ctx->stream, (const T*)staging, t->buf[0], len);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (staging) (void)hipFree(staging);
+        if (staging) jolt_internal_dev_free(ctx, staging);
         if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     }
     *out = t;
@@ -311,10 +386,10 @@ extern "C" int32_t jolt_table_device_ptr(const jolt_table* t, void** p) {
 extern "C" int32_t jolt_table_free(jolt_ctx* ctx, jolt_table* t) {
     (void)jolt_internal_engine_quiesce(ctx ? ctx : (t ? t->ctx : nullptr));
     if (!t) return JOLT_OK;
-    jolt_ctx* c = ctx ? ctx : t->ctx;
-    if (c) (void)hipStreamSynchronize(c->stream);
-    if (t->buf[0]) (void)hipFree(t->buf[0]);
-    if (t->buf[1]) (void)hipFree(t->buf[1]);
+    jolt_ctx* c = t->ctx ? t->ctx : ctx;
+    // no synchronisation: the blocks go back to the context's pool and are reused in stream order (ctx.hpp)
+    if (t->buf[0]) jolt_internal_dev_free(c, t->buf[0]);
+    if (t->buf[1]) jolt_internal_dev_free(c, t->buf[1]);
     delete t;
     return JOLT_OK;
 }
@@ -414,8 +489,8 @@ static int32_t eq_build(jolt_ctx* ctx, const Fr* r, size_t n, const Fr& scale, s
                         jolt_table** out) {
     jolt_table* cur = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, 1, &cur));
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(cur->buf[0], &scale, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `scale` is a host temporary
+    hipLaunchKernelGGL(k_fill_fr, dim3(1), dim3(64), 0, ctx->stream, cur->buf[0], scale, (size_t)1);  // by value: no host source to wait for
+    JOLT_HIP_TRY(ctx, hipGetLastError());
     if (levels) levels->push_back(cur);
     size_t done = 0;
     while (done < n) {
@@ -483,10 +558,9 @@ extern "C" int32_t jolt_lt_evals(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, jo
     jolt_table *lt = nullptr, *eq = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, 1, &lt));
     JOLT_TRY(jolt_internal_table_new(ctx, 1, &eq));
-    Fr zero = Fr::zero(), one = Fr::one();
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(lt->buf[0], &zero, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(eq->buf[0], &one, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(k_fill_fr, dim3(1), dim3(64), 0, ctx->stream, lt->buf[0], Fr::zero(), (size_t)1);
+    hipLaunchKernelGGL(k_fill_fr, dim3(1), dim3(64), 0, ctx->stream, eq->buf[0], Fr::one(), (size_t)1);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
     size_t done = 0;
     while (done < n) {
         size_t c = std::min<size_t>(8, n - done);
@@ -573,9 +647,9 @@ extern "C" int32_t jolt_table_evaluate(jolt_ctx* ctx, const jolt_table* t, const
 // ------------------------------------------------------------------------------------------------------------------
 static int32_t member_upload_desc(jolt_member* m) {
     jolt_ctx* ctx = m->ctx;
-    JOLT_HIP_TRY(ctx, hipMalloc((void**)&m->d_desc, sizeof(MemberDesc)));
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, sizeof(MemberDesc), (void**)&m->d_desc));
+    // m->desc lives as long as the member and is not modified after this point: no synchronisation needed for the host source
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(m->d_desc, &m->desc, sizeof(MemberDesc), hipMemcpyHostToDevice, ctx->stream));
-    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return JOLT_OK;
 }
 
@@ -903,11 +977,12 @@ static int32_t create_lazy_member(jolt_ctx* ctx, const jolt_onehot* source, cons
         if (s == JOLT_OK) { t->len = source->cycles; m->tables.push_back(t); }
     }
     if (s == JOLT_OK) {
-        hipError_t e = hipMalloc((void**)&m->d_base, N * K * sizeof(Fr));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[0], N * 16 * K * sizeof(Fr));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->d_branch[1], N * 16 * K * sizeof(Fr));
+        auto palloc = [&](void** p, size_t bytes) { return jolt_internal_dev_alloc(ctx, bytes, p) == JOLT_OK ? hipSuccess : hipErrorOutOfMemory; };
+        hipError_t e = palloc((void**)&m->d_base, N * K * sizeof(Fr));
+        if (e == hipSuccess) e = palloc((void**)&m->d_branch[0], N * 16 * K * sizeof(Fr));
+        if (e == hipSuccess) e = palloc((void**)&m->d_branch[1], N * 16 * K * sizeof(Fr));
         if (e == hipSuccess) e = hipMemcpyAsync(m->d_base, host_tables.data(), N * K * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && !host_pair.empty()) e = hipMalloc((void**)&m->d_pair, host_pair.size() * sizeof(Fr));
+        if (e == hipSuccess && !host_pair.empty()) e = palloc((void**)&m->d_pair, host_pair.size() * sizeof(Fr));
         if (e == hipSuccess && !host_pair.empty()) e = hipMemcpyAsync(m->d_pair, host_pair.data(), host_pair.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(m->d_branch[0], m->d_base, N * K * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host buffer may be short-lived
@@ -1646,8 +1721,8 @@ static int32_t engine_start(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* m
             const int second = 1 - first;
             if (t->cap[second] < std::max<size_t>(t->len / 4, 1)) {
                 if (t->cur == second) { ctx->last_error = "round engine: table buffer smaller than its contents"; return JOLT_ERR_INVALID_ARG; }
-                if (t->buf[second]) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(t->buf[second])); t->buf[second] = nullptr; t->cap[second] = 0; }
-                JOLT_HIP_TRY(ctx, hipMalloc((void**)&t->buf[second], std::max<size_t>(t->len / 4, 1) * sizeof(Fr)));
+                if (t->buf[second]) { jolt_internal_dev_free(ctx, t->buf[second]); t->buf[second] = nullptr; t->cap[second] = 0; }
+                JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(t->len / 4, 1) * sizeof(Fr), (void**)&t->buf[second]));
                 t->cap[second] = std::max<size_t>(t->len / 4, 1);
             }
             T.src = t->data();
@@ -1999,7 +2074,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
             nd.n_lc = nl;
         }
         MemberDesc* dd = nullptr;
-        if (st == JOLT_OK && hipMalloc((void**)&dd, sizeof(MemberDesc)) != hipSuccess) st = JOLT_ERR_OOM;
+        if (st == JOLT_OK) st = jolt_internal_dev_alloc(ctx, sizeof(MemberDesc), (void**)&dd);
         if (st == JOLT_OK && hipMemcpyAsync(dd, &nd, sizeof(nd), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
         if (st == JOLT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
         if (st == JOLT_OK) {
@@ -2012,7 +2087,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
         if (st == JOLT_OK) st = reduce_into_results(ctx, grid, 1, 0);
         if (st == JOLT_OK) st = fetch_results(ctx, 1, out);
         (void)hipStreamSynchronize(ctx->stream);
-        if (dd) (void)hipFree(dd);
+        if (dd) jolt_internal_dev_free(ctx, dd);
         jolt_table_free(ctx, eq);
         return st;
     }
@@ -2035,7 +2110,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
         for (uint32_t k = 0; k < F; ++k) { md.lc_tab[base + 1 + k] = 1 + v * F + k; md.lc_one[base + 1 + k] = 1; md.lc_coeff[base + 1 + k] = Fr::one(); }
     }
     MemberDesc* dd = nullptr;
-    JOLT_HIP_TRY(ctx, hipMalloc((void**)&dd, sizeof(MemberDesc)));
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, sizeof(MemberDesc), (void**)&dd));
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(dd, &md, sizeof(md), hipMemcpyHostToDevice, ctx->stream));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     TablePtrs tp;
@@ -2048,7 +2123,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
         for (size_t k = 0; k < m->tables.size(); ++k) {
             jolt_table* t = nullptr;
             int32_t st = jolt_internal_table_new(ctx, m->len, &t);
-            if (st != JOLT_OK) { for (jolt_table* x : temp) jolt_table_free(ctx, x); (void)hipFree(dd); jolt_table_free(ctx, eq); return st; }
+            if (st != JOLT_OK) { for (jolt_table* x : temp) jolt_table_free(ctx, x); jolt_internal_dev_free(ctx, dd); jolt_table_free(ctx, eq); return st; }
             temp.push_back(t);
             OneHotDense o;
             for (int i = 0; i < kMaxBatchTables; ++i) o.out[i] = i == 0 ? t->data() : nullptr;
@@ -2065,7 +2140,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     if (s == JOLT_OK) s = fetch_results(ctx, 1, out);
     (void)hipStreamSynchronize(ctx->stream);
     for (jolt_table* x : temp) jolt_table_free(ctx, x);
-    (void)hipFree(dd);
+    jolt_internal_dev_free(ctx, dd);
     jolt_table_free(ctx, eq);
     return s;
 }
@@ -2074,14 +2149,14 @@ extern "C" int32_t jolt_member_destroy(jolt_member* m) {
     (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m) return JOLT_OK;
     jolt_ctx* ctx = m->ctx;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    // no synchronisation: everything the member owns goes back to the context's pool and is reused in stream order
     for (jolt_table* t : m->tables) jolt_table_free(ctx, t);
     for (jolt_table* t : m->e_out_cache) jolt_table_free(ctx, t);
     for (jolt_table* t : m->e_in_cache) jolt_table_free(ctx, t);
-    if (m->d_desc) (void)hipFree(m->d_desc);
-    for (int k = 0; k < 2; ++k) if (m->d_branch[k]) (void)hipFree(m->d_branch[k]);
-    if (m->d_base) (void)hipFree(m->d_base);
-    if (m->d_pair) (void)hipFree(m->d_pair);
+    if (m->d_desc) jolt_internal_dev_free(m->ctx, m->d_desc);
+    for (int k = 0; k < 2; ++k) if (m->d_branch[k]) jolt_internal_dev_free(m->ctx, m->d_branch[k]);
+    if (m->d_base) jolt_internal_dev_free(m->ctx, m->d_base);
+    if (m->d_pair) jolt_internal_dev_free(m->ctx, m->d_pair);
     delete m;
     return JOLT_OK;
 }

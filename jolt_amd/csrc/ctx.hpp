@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/jolt_hip.h"
@@ -68,6 +69,15 @@ struct jolt_ctx {
     bool round_trace = false;     // JOLT_ROUND_TRACE=1: print where the host time of a batch round goes
     bool serial_streams = false;  // JOLT_SERIAL_STREAMS=1: a round's kernels on one stream (standalone kernel durations under rocprof)
     bool lazy_lds = true;  // index-encoded members past the first bind: branch tables staged in LDS (JOLT_LAZY_LDS=0: global gathers)
+    // Device-memory pool for tables, member descriptors and per-call temporaries (jolt_internal_dev_alloc / _free): a proof builds
+    // and drops dozens of T-sized derived tables (eq / eq+1 / LT expansions, linear-leaf fusions, bind scratch), and hipMalloc /
+    // hipFree cost 0.1-1 ms each and synchronise the device.  Freed blocks are kept per size class and handed out again WITHOUT a
+    // synchronisation: every consumer enqueues on the context's main stream (or on a side stream forked from it after the
+    // allocation), so reuse is stream-ordered.  JOLT_POOL=0 disables caching (every free is a hipFree).
+    bool pool_enabled = true;
+    std::unordered_map<void*, size_t> pool_live;               // block -> size class (bytes)
+    std::unordered_map<size_t, std::vector<void*>> pool_free;  // size class -> cached blocks
+    size_t pool_cached_bytes = 0, pool_live_bytes = 0, pool_peak_bytes = 0;
 };
 
 // Stop a running round engine (if any) so that other work may use the stream / the members' tables.
@@ -121,6 +131,9 @@ static inline bool fr_is_canonical(const Fr& v) {
 }
 
 // internal helpers implemented in capi.hip
+int32_t jolt_internal_dev_alloc(jolt_ctx* ctx, size_t bytes, void** out);
+void jolt_internal_dev_free(jolt_ctx* ctx, void* p);
+int32_t jolt_internal_pool_trim(jolt_ctx* ctx);
 int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t results);
 int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out);
 int32_t jolt_internal_table_ensure_alt(jolt_table* t, size_t need);

@@ -22,12 +22,7 @@
 using namespace jolt;
 using namespace jolt::msmk;
 
-struct jolt_ints {
-    jolt_ctx* ctx = nullptr;
-    void* data = nullptr;  // device
-    size_t count = 0;
-    int32_t kind = 0;
-};
+#include "ints.hpp"
 
 namespace {
 

@@ -448,6 +448,28 @@ extern "C" int32_t jolt_host_fr_from_u64(uint64_t v, jolt_fr_t* out) {
     fr_to_abi(out, fr_from_u64(v));
     return JOLT_OK;
 }
+// EqPolynomial::evals_serial (crates/jolt-poly/src/eq.rs:299-315) on the host: the K-entry address tables (K = 16 / 256) a
+// one-hot member pre-scales are too small to be worth a device round trip.  Big-endian index, optional scale.
+extern "C" int32_t jolt_host_eq_evals(const jolt_fr_t* r, size_t n, const jolt_fr_t* scale, jolt_fr_t* out) {
+    if ((!r && n) || !out || n > 20) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> e((size_t)1 << n);
+    e[0] = scale ? fr_from_abi(scale) : Fr::one();
+    size_t size = 1;
+    for (size_t j = 0; j < n; ++j) {
+        const Fr rj = fr_from_abi(&r[j]);
+        if (!fr_is_canonical(rj)) return JOLT_ERR_INVALID_ARG;
+        for (size_t i = size; i-- > 0;) {  // eq.rs:306-313: evals[2i+1] = s * r_j, evals[2i] = s - evals[2i+1]
+            const Fr s = e[i];
+            const Fr hi = mul(s, rj);
+            e[2 * i + 1] = hi;
+            e[2 * i] = sub(s, hi);
+        }
+        size *= 2;
+    }
+    for (size_t i = 0; i < size; ++i) fr_to_abi(&out[i], e[i]);
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_host_fr_mul_shifted(const jolt_fr_t* a, const jolt_fr_t* c, jolt_fr_t* out) {
     if (!a || !c || !out) return JOLT_ERR_INVALID_ARG;
     Fr cc = fr_from_abi(c);

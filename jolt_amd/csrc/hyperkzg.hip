@@ -109,9 +109,8 @@ int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* ou
         return JOLT_OK;
     }
     Fr *heads = nullptr, *S = nullptr;
-    JOLT_HIP_TRY(ctx, hipMalloc((void**)&heads, nchunks * sizeof(Fr)));
-    hipError_t e = hipMalloc((void**)&S, nchunks * sizeof(Fr));
-    if (e != hipSuccess) { (void)hipFree(heads); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_OOM; }
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, nchunks * sizeof(Fr), (void**)&heads));
+    if (jolt_internal_dev_alloc(ctx, nchunks * sizeof(Fr), (void**)&S) != JOLT_OK) { jolt_internal_dev_free(ctx, heads); return JOLT_ERR_OOM; }
     hipLaunchKernelGGL(k_suffix_heads, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, heads, nchunks);
     Fr mu_c = mu;
     for (int i = 0; i < 6; ++i) mu_c = sqr(mu_c);  // mu^64
@@ -120,9 +119,8 @@ int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* ou
         hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift);
         if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(heads);
-    (void)hipFree(S);
+    jolt_internal_dev_free(ctx, heads);  // pool blocks: reused in stream order, no synchronisation
+    jolt_internal_dev_free(ctx, S);
     return s;
 }
 

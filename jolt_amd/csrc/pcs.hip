@@ -1,0 +1,213 @@
+// jolt_amd/csrc/pcs.hip -- the committed trace polynomials over the proof's shared commitment grid, for a KZG-type scheme
+// (HyperKZG: commit = one MSM against the SRS prefix, crates/jolt-hyperkzg/src/kzg.rs:15-27).
+//
+// Every witness polynomial is committed in ONE grid shape of total_vars = log_k_chunk + log_t variables
+// (crates/jolt-kernels/src/commitment.rs:1-8,86-130); with the cycle-major placement the coefficient of (address k, cycle j)
+// sits at index k * T + j and dense columns live at k = 0 (TracePlacement, crates/jolt-kernels/src/optimized/opening.rs:340-372;
+// TraceOpeningPoly::entry :404-420).  On that grid
+//   * a one-hot RA column has exactly one unit coefficient per hot cycle: its commitment is a plain SUM of T selected bases --
+//     no scalar work at all (the KZG twin of the one-hot batch additions of crates/jolt-dory/src/streaming.rs:230-275);
+//   * the joint polynomial of the stage-8 batch opening, sum_i gamma_i * f_i (HomomorphicBatch::prove_batch,
+//     crates/jolt-openings/src/schemes.rs:487-524 -> RlcSource::to_dense, crates/jolt-poly/src/multilinear.rs:159-170), is
+//     written in one pass from the hot indices and the dense columns: J[k*T + j] = sum_p s_p [hot_p(j) = k] + [k = 0] sum_d c_d f_d[j].
+// Also here: the promotion of device-resident integer columns to field tables (Polynomial::bind_to_field's From<T>,
+// crates/jolt-poly/src/dense.rs:129-142) for inputs that are already in HBM.
+#include <algorithm>
+
+#include "ints.hpp"
+#include "msm_kernels.cuh"
+#include "onehot.hpp"
+#include "srs.hpp"
+
+using namespace jolt;
+using namespace jolt::msmk;
+
+int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out);
+
+namespace {
+
+constexpr int kGridSumBlocks = 512;  // workgroups per column: 2048 wavefront partial sums, folded by the second kernel
+
+// partial[(p * gridDim.x + block) * 4 + wave] = sum over this wavefront's cycles of bases[hot_p(j) * T + j]
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_grid_onehot_sum(
+    const uint8_t* __restrict__ idx, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial) {
+    const size_t p = blockIdx.y;
+    const uint8_t* col = idx + p * cycles;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    G1Jac acc = g1_identity();
+    // software pipeline as in sum_bucket_points<true>: the next index byte and point are in flight during the mixed addition
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    uint8_t a = j < cycles ? col[j] : kOneHotCold;
+    G1Affine pt;
+    pt.x = Fq::zero();
+    pt.y = Fq::zero();
+    if (a != kOneHotCold) pt = ld_aff(bases + (size_t)a * cycles + j);
+    while (j < cycles) {
+        const size_t jn = j + stride;
+        uint8_t an = jn < cycles ? col[jn] : kOneHotCold;
+        G1Affine pn;
+        pn.x = Fq::zero();
+        pn.y = Fq::zero();
+        if (an != kOneHotCold) pn = ld_aff(bases + (size_t)an * cycles + jn);
+        acc = g1_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
+        pt = pn;
+        j = jn;
+    }
+    acc = wave_sum_g1(acc, 64);
+    if ((threadIdx.x & 63) == 0) partial[(p * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = acc;
+}
+// out[p] = sum of the column's `count` partial sums (one wavefront per column)
+__global__ __launch_bounds__(64) void k_grid_onehot_fold(const G1Jac* __restrict__ partial, uint32_t count, G1Jac* __restrict__ out) {
+    const size_t p = blockIdx.x;
+    G1Jac acc = g1_identity();
+    for (uint32_t k = threadIdx.x; k < count; k += 64) acc = g1_add(acc, partial[p * count + k]);
+    acc = wave_sum_g1(acc, 64);
+    if (threadIdx.x == 0) out[p] = acc;
+}
+
+constexpr int kJointMaxSources = 4;
+constexpr int kJointMaxDense = 8;
+struct JointArgs {
+    const uint8_t* idx[kJointMaxSources];  // [polys of the source][cycles]
+    uint32_t n_polys[kJointMaxSources];
+    uint32_t first[kJointMaxSources];      // offset of the source's first polynomial in `scalars`
+    int n_sources;
+    const Fr* dense[kJointMaxDense];
+    Fr dense_scalar[kJointMaxDense];
+    uint32_t dense_one[kJointMaxDense];
+    int n_dense;
+};
+// out[k * T + j] = sum_p scalars[p] * [hot_p(j) == k]  (+ the dense columns on row k = 0); blockIdx.y = k
+__global__ __launch_bounds__(kBlock) void k_grid_joint(JointArgs a, const Fr* __restrict__ scalars, size_t cycles, Fr* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t k = blockIdx.y;
+    if (j >= cycles) return;
+    Fr acc = Fr::zero();
+    for (int s = 0; s < a.n_sources; ++s) {
+        const uint8_t* col = a.idx[s] + j;
+        for (uint32_t p = 0; p < a.n_polys[s]; ++p)
+            if (col[(size_t)p * cycles] == k && k != kOneHotCold) acc = add(acc, scalars[a.first[s] + p]);  // scalar (wave-uniform) load of the coefficient
+    }
+    if (k == 0)
+        for (int d = 0; d < a.n_dense; ++d) {
+            Fr v = ld_fr(a.dense[d] + j);
+            acc = add(acc, a.dense_one[d] ? v : mul(v, a.dense_scalar[d]));
+        }
+    st_fr(out + (size_t)k * cycles + j, acc);
+}
+
+// Ring::from_u64 / from_i64 / from_i128 per entry (crates/jolt-field/src/bn254/mod.rs:265-328) from device-resident integers
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_promote_ints(const void* __restrict__ data, size_t offset, size_t n, Fr two64, Fr* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint64_t lo, hi = 0;
+        bool negative = false;
+        if (KIND == JOLT_INT_I128) {
+            const uint64_t* p = reinterpret_cast<const uint64_t*>(data) + 2 * (offset + i);
+            lo = p[0];
+            hi = p[1];
+            negative = (hi >> 63) != 0;
+            if (negative) {
+                lo = ~lo + 1;
+                hi = ~hi + (lo == 0 ? 1 : 0);
+            }
+        } else {
+            lo = reinterpret_cast<const uint64_t*>(data)[offset + i];
+            negative = KIND == JOLT_INT_I64 && (lo >> 63) != 0;
+            if (negative) lo = ~lo + 1;
+        }
+        Fr m = fr_from_u64(lo);
+        if (KIND == JOLT_INT_I128 && hi) m = add(m, mul(fr_from_u64(hi), two64));
+        st_fr(out + i, negative ? neg(m) : m);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// entry points
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t jolt_table_from_ints(jolt_ctx* ctx, const jolt_ints* values, size_t offset, size_t len, jolt_table** out) {
+    if (!ctx || !values || !out) return JOLT_ERR_INVALID_ARG;
+    if (offset + len > values->count) return JOLT_ERR_SIZE_MISMATCH;
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
+    if (len) {
+        const Fr t32 = fr_from_u64((uint64_t)1 << 32);
+        const Fr two64 = mul(t32, t32);
+        const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((len + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 8));
+        switch (values->kind) {
+            case JOLT_INT_U64: hipLaunchKernelGGL(k_promote_ints<JOLT_INT_U64>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const void*)values->data, offset, len, two64, t->data()); break;
+            case JOLT_INT_I64: hipLaunchKernelGGL(k_promote_ints<JOLT_INT_I64>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const void*)values->data, offset, len, two64, t->data()); break;
+            default: hipLaunchKernelGGL(k_promote_ints<JOLT_INT_I128>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const void*)values->data, offset, len, two64, t->data()); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    }
+    *out = t;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_grid_commit_onehot(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, jolt_g1_t* out) {
+    if (!ctx || !srs || !source || !out) return JOLT_ERR_INVALID_ARG;
+    const size_t T = source->cycles, N = source->n_polys;
+    if ((size_t)source->k * T > srs->n) return JOLT_ERR_SRS_TOO_SMALL;  // HyperKZGError::SrsTooSmall (kzg.rs:19-24)
+    if (N > 65535) return JOLT_ERR_UNSUPPORTED;
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((T + kBlock - 1) / kBlock, kGridSumBlocks));
+    const uint32_t per_col = blocks * (kBlock / 64);
+    G1Jac *partial = nullptr, *sums = nullptr;
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, N * per_col * sizeof(G1Jac), (void**)&partial));
+    int32_t st = jolt_internal_dev_alloc(ctx, N * sizeof(G1Jac), (void**)&sums);
+    if (st != JOLT_OK) { jolt_internal_dev_free(ctx, partial); return st; }
+    hipLaunchKernelGGL(k_grid_onehot_sum, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, T, (const G1Affine*)srs->pts, partial);
+    hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)N), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, sums, N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    jolt_internal_dev_free(ctx, partial);
+    jolt_internal_dev_free(ctx, sums);
+    if (e != hipSuccess) { ctx->last_error = std::string("grid one-hot commit: ") + hipGetErrorString(e); return JOLT_ERR_HIP; }
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_grid_joint_polynomial(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars,
+                                              jolt_table* const* dense, size_t n_dense, const jolt_fr_t* dense_scalars, uint32_t log_k, jolt_table** out) {
+    if (!ctx || !out || (n_sources && (!sources || !onehot_scalars)) || (n_dense && (!dense || !dense_scalars))) return JOLT_ERR_INVALID_ARG;
+    if (n_sources > (size_t)kJointMaxSources || n_dense > (size_t)kJointMaxDense || log_k > 8 || n_sources + n_dense == 0) return JOLT_ERR_UNSUPPORTED;
+    const uint32_t K = 1u << log_k;
+    JointArgs a;
+    std::memset(&a, 0, sizeof(a));
+    size_t T = n_sources ? sources[0]->cycles : dense[0]->len, total = 0;
+    for (size_t s = 0; s < n_sources; ++s) {
+        if (!sources[s]) return JOLT_ERR_INVALID_ARG;
+        if (sources[s]->cycles != T) return JOLT_ERR_SIZE_MISMATCH;
+        if (sources[s]->k > K) return JOLT_ERR_SIZE_MISMATCH;  // a hot address outside the grid
+        a.idx[s] = sources[s]->idx;
+        a.n_polys[s] = (uint32_t)sources[s]->n_polys;
+        a.first[s] = (uint32_t)total;
+        total += sources[s]->n_polys;
+    }
+    a.n_sources = (int)n_sources;
+    for (size_t d = 0; d < n_dense; ++d) {
+        if (!dense[d]) return JOLT_ERR_INVALID_ARG;
+        if (dense[d]->len != T) return JOLT_ERR_SIZE_MISMATCH;
+        a.dense[d] = dense[d]->data();
+        a.dense_scalar[d] = fr_from_abi(&dense_scalars[d]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(a.dense_scalar[d]), "scalar is not a canonical Fr");
+        a.dense_one[d] = a.dense_scalar[d] == Fr::one() ? 1u : 0u;
+    }
+    a.n_dense = (int)n_dense;
+    for (size_t p = 0; p < total; ++p) JOLT_REQUIRE(ctx, fr_is_canonical(fr_from_abi(&onehot_scalars[p])), "scalar is not a canonical Fr");
+    jolt_table *r = nullptr, *ds = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, (size_t)K * T, &r));
+    int32_t st = JOLT_OK;
+    if (total) st = jolt_table_upload(ctx, onehot_scalars, total, &ds);  // synchronises: the caller's array may be short-lived
+    if (st != JOLT_OK) { jolt_table_free(ctx, r); return st; }
+    hipLaunchKernelGGL(k_grid_joint, dim3((unsigned)((T + kBlock - 1) / kBlock), K), dim3(kBlock), 0, ctx->stream, a, ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, r->data());
+    hipError_t e = hipGetLastError();
+    if (ds) jolt_table_free(ctx, ds);
+    if (e != hipSuccess) { jolt_table_free(ctx, r); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    *out = r;
+    return JOLT_OK;
+}

@@ -37,6 +37,12 @@ __device__ __forceinline__ void st_fr_system(Fr* p, const Fr& v) {
     for (int k = 0; k < 4; ++k)
         __hip_atomic_store(q + k, (unsigned long long)v.l[2 * k] | ((unsigned long long)v.l[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Wait until every store this lane has issued is acknowledged.  The written-through stores above (sc1 / sc0 sc1) are
+// acknowledged once they have reached the coherence point of their scope; a workgroup barrier alone only orders LDS traffic
+// (s_waitcnt lgkmcnt), so the lanes that stored partial sums, round sums or counter resets drain vmcnt themselves before the
+// barrier / ticket that publishes them.  Far cheaper than a release fence (no L2 write-back of bound tables).
+__device__ __forceinline__ void wait_stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void st_u32_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ Fr ld_fr_agent(const Fr* p) {
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
     Fr v;
@@ -214,6 +220,7 @@ __device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict
         Fr s = sm[0][threadIdx.x];
         for (int w = 1; w < kBlock / 64; ++w) s = add(s, sm[w][threadIdx.x]);
         st_fr_agent(partials + (size_t)blockIdx.x * NE + threadIdx.x, s);
+        wait_stores_acked();  // acknowledged before the barrier in front of this workgroup's ticket (finish_member)
     }
 }
 
@@ -244,9 +251,9 @@ template <bool LAYOUT_T_MAJOR = false>
 __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, int ne, uint32_t member_ticket, uint32_t slot, const RoundDone& rd,
                                               int nblocks_arg = 0, uint32_t expected = 0, uint32_t pidx = 0xFFFFFFFFu) {
     __shared__ uint32_t s_last;
-    __syncthreads();  // this block's partials are written (block_reduce_store ends with the stores of threads < NE)
+    __syncthreads();  // this block's partials are written and acknowledged (block_reduce_store: st_fr_agent + wait_stores_acked)
     if (threadIdx.x == 0) {
-        // no release fence: the partials were stored device-coherently (st_fr_agent) and the barrier above waited for them
+        // no release fence: the partials were stored device-coherently and their lanes drained vmcnt before the barrier above
         const uint32_t total = LAYOUT_T_MAJOR ? expected : gridDim.x;
         uint32_t last = 0;
         if (total <= kSubTickets) {
@@ -257,7 +264,8 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
             const uint32_t in_sub = (total - r + kSubTickets - 1) / kSubTickets;
             uint32_t* sub = rd.counters + kSubTicketBase + ((size_t)member_ticket * kSubTickets + r) * kSubTicketStride;
             if (atomicAdd(sub, 1u) == in_sub - 1) {
-                *sub = 0;         // ready for the next round
+                st_u32_agent(sub, 0u);  // ready for the next round: acknowledged before the ticket that leads to the host flag
+                wait_stores_acked();
                 last = atomicAdd(&rd.counters[member_ticket], 1u) == kSubTickets - 1 ? 1u : 0u;
             }
         }
@@ -283,20 +291,27 @@ __device__ __forceinline__ void finish_member(const Fr* __restrict__ partials, i
         if (lane == 0) {
             st_fr_system(rd.results + slot + t, s);  // written through to host memory; the barrier below waits for the write
             if (rd.results_dev) st_fr_system(rd.results_dev + slot + t, s);  // RCCL send buffer: read by other streams / peers
+            wait_stores_acked();  // every wave's sums are acknowledged before the barrier below
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        rd.counters[member_ticket] = 0;  // ready for the next round (the kernel boundary publishes it)
+        st_u32_agent(&rd.counters[member_ticket], 0u);  // ready for the next round
+        wait_stores_acked();
         // No system-scope fence (an L2 write-back of all dirty data on the critical path of the round): this member's sums have
         // been written through and acknowledged before the group ticket is taken, so the flag -- written the same way by
         // whoever takes the last ticket -- is issued after every member's sums.
         uint32_t g = atomicAdd(&rd.counters[kGroupTicket], 1u);
         if (g == rd.group_total - 1) {
-            rd.counters[kGroupTicket] = 0;
+            st_u32_agent(&rd.counters[kGroupTicket], 0u);
+            wait_stores_acked();  // the next round (possibly on another stream) starts only after the host has seen the flag
             __hip_atomic_store(rd.flag, rd.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+static __global__ void k_fill_fr(Fr* __restrict__ out, Fr v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fr(out + i, v);
 }
 
 // second stage: out[t] = sum_b partials[b*ne + t]   (one block)

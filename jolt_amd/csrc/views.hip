@@ -53,18 +53,20 @@ static __global__ __launch_bounds__(kBlock) void k_replicate_lsb(const Fr* __res
     if (i < total) st_fr(out + i, ld_fr(base + (i >> 1)));
 }
 
+// pointers, scalars and unit flags by value (wave-uniform kernel arguments): no device staging, nothing to wait for on the host
 struct RlcTables {
     const Fr* t[kMaxBatchTables];
+    Fr s[kMaxBatchTables];
+    uint32_t one[kMaxBatchTables];
     int k;
 };
-static __global__ __launch_bounds__(kBlock) void k_rlc_equal(RlcTables a, const Fr* __restrict__ scalars, const uint32_t* __restrict__ is_one, size_t n,
-                                                             Fr* __restrict__ out) {
+static __global__ __launch_bounds__(kBlock) void k_rlc_equal(RlcTables a, size_t n, Fr* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Fr acc = Fr::zero();
     for (int j = 0; j < a.k; ++j) {
         Fr v = ld_fr(a.t[j] + i);
-        if (!is_one[j]) v = mul(v, ld_fr(scalars + j));
+        if (!a.one[j]) v = mul(v, a.s[j]);
         acc = add(acc, v);
     }
     st_fr(out + i, acc);
@@ -137,29 +139,20 @@ extern "C" int32_t jolt_rlc(jolt_ctx* ctx, jolt_table* const* tables, size_t k, 
     size_t n = tables[0]->len;
     RlcTables a;
     a.k = (int)k;
-    std::vector<uint32_t> ones(k);
+    for (size_t j = 0; j < (size_t)kMaxBatchTables; ++j) { a.t[j] = nullptr; a.s[j] = Fr::zero(); a.one[j] = 0; }
     for (size_t j = 0; j < k; ++j) {
         if (!tables[j]) return JOLT_ERR_INVALID_ARG;
         if (tables[j]->len != n) return JOLT_ERR_SIZE_MISMATCH;  // RlcSource::new assert (multilinear.rs:380-383)
         a.t[j] = tables[j]->data();
-        Fr s = fr_from_abi(&scalars[j]);
-        JOLT_REQUIRE(ctx, fr_is_canonical(s), "scalar is not a canonical Fr");
-        ones[j] = s == Fr::one() ? 1u : 0u;
+        a.s[j] = fr_from_abi(&scalars[j]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(a.s[j]), "scalar is not a canonical Fr");
+        a.one[j] = a.s[j] == Fr::one() ? 1u : 0u;
     }
-    jolt_table *r = nullptr, *ds = nullptr;
-    uint32_t* d_one = nullptr;
+    jolt_table* r = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, n, &r));
-    int32_t st = jolt_table_upload(ctx, scalars, k, &ds);
-    hipError_t e = st == JOLT_OK ? hipMalloc((void**)&d_one, k * sizeof(uint32_t)) : hipErrorUnknown;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_one, ones.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_rlc_equal, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, a, (const Fr*)ds->data(), (const uint32_t*)d_one, n, r->data());
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (d_one) (void)hipFree(d_one);
-    if (ds) jolt_table_free(ctx, ds);
-    if (e != hipSuccess) { jolt_table_free(ctx, r); ctx->last_error = hipGetErrorString(e); return st != JOLT_OK ? st : JOLT_ERR_HIP; }
+    hipLaunchKernelGGL(k_rlc_equal, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, a, n, r->data());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { jolt_table_free(ctx, r); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     *out = r;
     return JOLT_OK;
 }
@@ -253,8 +246,7 @@ extern "C" int32_t jolt_split_lt_bind(jolt_ctx* ctx, jolt_split_lt* s, const jol
         hipLaunchKernelGGL(k_split_lt_expand, dim3((unsigned)((d->len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const Fr*)s->lt_lo->data(),
                            (const Fr*)s->lt_hi->data(), (const Fr*)s->eq_hi->data(), (size_t)1, d->len, d->data());
         if (hipGetLastError() != hipSuccess) { jolt_table_free(ctx, d); return JOLT_ERR_HIP; }
-        JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (jolt_table* t : {s->lt_lo, s->lt_hi, s->eq_hi}) jolt_table_free(ctx, t);
+        for (jolt_table* t : {s->lt_lo, s->lt_hi, s->eq_hi}) jolt_table_free(ctx, t);  // back to the pool: reused in stream order
         s->lt_lo = s->lt_hi = s->eq_hi = nullptr;
         s->dense = d;
     }

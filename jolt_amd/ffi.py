@@ -438,6 +438,15 @@ def host_fr_from_u64(v):
     return o[0]
 
 
+def host_eq_evals(r, scale=None):
+    p = fr(r).reshape(-1, 4)
+    out = fr_array(1 << p.shape[0])
+    st = lib().jolt_host_eq_evals(_p(p), C.c_size_t(p.shape[0]), _p(fr(scale)) if scale is not None else None, _p(out))
+    if st != 0:
+        raise JoltError(st, "jolt_host_eq_evals")
+    return out
+
+
 def host_univariate_from_evals(evals):
     e = fr(evals).reshape(-1, 4)
     o = fr_array(e.shape[0])
@@ -810,3 +819,48 @@ Context.cycle_fold = _table_op2("jolt_cycle_fold")
 Context.tile = _tile
 Context.replicate_stream_lsb = _replicate_stream_lsb
 Context.rlc = _rlc
+
+
+# ---- device-resident integer promotion, commitment-grid pieces (pcs.hip), memory pool
+def _table_from_ints(self, values, offset=0, length=None):
+    """Ring::from_u64 / from_i64 / from_i128 of entries [offset, offset+length) of an Ints (already in HBM) as a field table."""
+    length = values.count - offset if length is None else length
+    h = C.c_void_p()
+    _ck(lib().jolt_table_from_ints(self.h, values.h, C.c_size_t(offset), C.c_size_t(length), C.byref(h)), "jolt_table_from_ints", self)
+    return Table(self, h)
+
+
+def _grid_commit_onehot(self, srs, source):
+    """KZG commitments of the one-hot columns of `source` over the K x T commitment grid (index k*T + j): (n_polys, 12)."""
+    out = g1_array(source.n_polys)
+    _ck(lib().jolt_grid_commit_onehot(self.h, srs.h, source.h, _p(out)), "jolt_grid_commit_onehot", self)
+    return out
+
+
+def _grid_joint_polynomial(self, sources, onehot_scalars, dense, dense_scalars, log_k):
+    """Joint polynomial of the stage-8 batch opening over the 2^log_k x T grid (HomomorphicBatch::prove_batch's RLC)."""
+    hs = (C.c_void_p * max(len(sources), 1))(*[s.h for s in sources])
+    ds = (C.c_void_p * max(len(dense), 1))(*[t.h for t in dense])
+    osc = fr(np.stack([fr(c) for c in onehot_scalars])).reshape(-1, 4) if len(onehot_scalars) else None
+    dsc = fr(np.stack([fr(c) for c in dense_scalars])).reshape(-1, 4) if len(dense_scalars) else None
+    h = C.c_void_p()
+    _ck(lib().jolt_grid_joint_polynomial(self.h, hs if sources else None, C.c_size_t(len(sources)), _p(osc), ds if dense else None, C.c_size_t(len(dense)),
+                                         _p(dsc), C.c_uint32(log_k), C.byref(h)), "jolt_grid_joint_polynomial", self)
+    return Table(self, h)
+
+
+def _trim(self):
+    _ck(lib().jolt_ctx_trim(self.h), "jolt_ctx_trim", self)
+
+
+def _memory_stats(self):
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _ck(lib().jolt_ctx_memory_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "jolt_ctx_memory_stats", self)
+    return {"live_bytes": a.value, "cached_bytes": b.value, "peak_bytes": c.value}
+
+
+Context.table_from_ints = _table_from_ints
+Context.grid_commit_onehot = _grid_commit_onehot
+Context.grid_joint_polynomial = _grid_joint_polynomial
+Context.trim = _trim
+Context.memory_stats = _memory_stats

@@ -214,89 +214,94 @@ def expand_to_flat_terms(groups, mul, one):
 # GPU instantiation through the C ABI (product path; no oracle involved)
 # ---------------------------------------------------------------------------------------------------------------------
 class DeviceWorkload:
-    """Resident tables + BORROW members for every relation, grouped by stage; `prove()` runs one batched sumcheck per
-    stage through jolt_host_prove_batch (grouped scheduler: one device->host copy and one sync per batch round)."""
+    """One synthetic proof after another on the device, with the life cycle of the reference prover
+    (crates/jolt-prover/src/dory/prover.rs:133-252; metric window crates/jolt-prover/src/profile.rs:590-601):
 
-    def __init__(self, ctx, n_vars, seed=2026, **kw):
+      resident inputs (constructor, untimed -- "inputs already in HBM"): the witness columns as 64-bit integers, the hot indices
+        of the one-hot RA columns, the SRS;
+      prepare()  -- PrepareKernel::prepare of every member (crates/jolt-kernels/src/backend.rs:98-111): witness promotion to field
+        tables, every T-sized derived table (eq / eq+1 / LT expansions from the stage's points, the address tables of the one-hot
+        columns, linear-leaf fusions through jolt_rlc), descriptor upload, split-eq tables;
+      commit()   -- stage 0: the committed columns over the shared K x T commitment grid (pcs="grid");
+      prove()    -- stages 2..6b: one batched sumcheck per stage through jolt_host_prove_batch;
+      open()     -- stage 8: joint polynomial of the homomorphic batch + ONE HyperKZG opening (crates/jolt-openings/src/schemes.rs:487-524);
+      release()  -- drop members and per-proof tables (back into the context's pool).
+    step() runs all of them: that is one timed step of bench.py.  The stage points are fixed per workload (the same tables are
+    REBUILT every step); the input claims -- in a real proof the previous stage's output claims -- are computed once.
+
+    pcs: None (sumcheck only: BASELINE configs[1]) or "grid" (configs[2]: every committed polynomial lives on the 2^(log_k + n_vars)
+    commitment grid of crates/jolt-kernels/src/commitment.rs:86-130 -- the two dense increment columns at address 0, the one-hot
+    RA columns as 0/1 coefficients -- committed with HyperKZG and opened jointly at one point)."""
+
+    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, **kw):
         from . import ffi
-        self.ctx, self.n_vars, self.ffi = ctx, n_vars, ffi
+        self.ctx, self.n_vars, self.ffi, self.pcs = ctx, n_vars, ffi, pcs
         self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
         self.resolver = Resolver(gammas, one, ffi.host_fr_mul, lambda x: ffi.host_fr_sub(zero, x))
         self.one = one
-        self.tables = {}
-        # eq tables that only feed split-eq uniform members are never materialised on the device
+        # which tables are materialised per proof: eq tables that only feed split-eq members never are; one-hot selector columns
+        # that only feed uniform members stay index-encoded (1 byte per cycle, LazyFoldedRa)
         skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None}
         skip -= {t for ms in self.members_spec for t in (ms.tables if ms.uniform is None else ms.tables[1:])}
-        # one-hot selector columns that only feed uniform members stay index-encoded (1 byte per cycle, LazyFoldedRa)
-        lazy = lambda ms: ms.uniform is not None and n_vars >= 4 and all(self.tables_spec[t].kind == "onehot" for t in ms.tables[1:])
-        skip |= {t for ms in self.members_spec if lazy(ms) for t in ms.tables[1:]}
+        self._lazy = lambda ms: ms.uniform is not None and n_vars >= 4 and all(self.tables_spec[t].kind == "onehot" for t in ms.tables[1:])
+        skip |= {t for ms in self.members_spec if self._lazy(ms) for t in ms.tables[1:]}
         skip |= {ms.tables[0] for ms in self.members_spec if ms.eq_inner is not None}  # eq weight factored out: never materialised
         used = lambda ms: ms.tables[1:] if (ms.uniform is not None or ms.eq_inner is not None) else ms.tables
-        skip -= {t for ms in self.members_spec if not lazy(ms) for t in used(ms)}
+        skip -= {t for ms in self.members_spec if not self._lazy(ms) for t in used(ms)}
+        self._skip = skip
+        # ---- resident inputs
+        self.ints = {}
         for name, spec in self.tables_spec.items():
-            if name not in skip:
-                self.tables[name] = self._make_table(spec)
-        self.members, self.stages, self.sources = [], {}, []
-        for ms in self.members_spec:
-            if ms.uniform is not None:
-                V, F, csyms = ms.uniform
-                coeffs = [self.resolver.coeff(c) for c in csyms]
-                w = self.tables_spec[ms.tables[0]].point
-                if lazy(ms):
-                    specs = [self.tables_spec[t] for t in ms.tables[1:]]
-                    src = ctx.onehot(np.stack([sp.data for sp in specs]), 1 << len(specs[0].point))
-                    scale_tables = np.stack([self._scale_table(sp) for sp in specs])
-                    m = ctx.member_lazy_ra_uniform(src, scale_tables, V, F, coeffs, w)
-                    self.sources.append(src)
-                else:
-                    tabs = [self.tables[t] for t in ms.tables[1:]]
-                    m = ctx.member_split_eq_uniform(tabs, V, F, coeffs, w, borrow=True)
-                self.members.append(m)
-                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+            if name in skip:
                 continue
-            if ms.eq_inner is not None:
-                dq, inner = ms.eq_inner
-                m = ctx.member_lc([self.tables[t] for t in ms.tables[1:]], self.resolver.groups(inner), dq, borrow=True,
-                                  eq_point=self.tables_spec[ms.tables[0]].point)
-                self.members.append(m)
-                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
-                continue
-            if ms.fused is not None:  # A = sum_i s_i * leaf_i as ONE resident table (jolt_rlc), then the ordinary member over fewer tables
-                parts, names, groups = ms.fused
-                for fname, entries in parts:
-                    srcs = [self.tables[ms.tables[ti]] for _, ti in entries]
-                    self.tables[fname] = ctx.rlc(srcs, np.stack([self.resolver.coeff(c) for c, _ in entries]))
+            if spec.kind in ("u64", "i64"):
+                self.ints[name] = ctx.ints(spec.data.astype(np.uint64 if spec.kind == "u64" else np.int64))
+        self.sources = {}  # member index -> OneHot (lazy members); dense one-hot tables get theirs in _make_table
+        for i, ms in enumerate(self.members_spec):
+            if self._lazy(ms):
+                specs = [self.tables_spec[t] for t in ms.tables[1:]]
+                self.sources[i] = ctx.onehot(np.stack([sp.data for sp in specs]), 1 << len(specs[0].point))
+        rng = np.random.default_rng(seed + 1)
+        self.batch_coeffs = [rand_fr(1, rng)[0] for _ in self.members_spec]
+        self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
+        self.n_onehot = sum(len(ms.tables) - 1 for ms in self.members_spec if self._lazy(ms))
+        self.stages = {}
+        for i, ms in enumerate(self.members_spec):
+            self.stages.setdefault(ms.stage, []).append(i)
+        # ---- PCS side (pcs="grid")
+        self.srs, self.own_srs = srs, False
+        if pcs == "grid":
+            self.log_k = 4
+            assert all(len(self.tables_spec[t].point) == self.log_k for ms in self.members_spec if self._lazy(ms) for t in ms.tables[1:])
+            self.grid_vars = self.log_k + n_vars
+            self.committed_dense = ["s6.ram_inc", "s6.rd_inc"]  # RamInc, RdInc (CommittedColumnsWitness, crates/jolt-kernels/src/commitment.rs:25-32)
+            if self.srs is None:
+                prng = np.random.default_rng(seed + 2)
+                self.beta = rand_fr(1, prng)[0]
+                self.srs = ctx.srs_setup_from_secret(self.beta, 1 << self.grid_vars, G1_GENERATOR)
+                self.own_srs = True
                 ctx.synchronize()
-                m = ctx.member_lc([self.tables[t] for t in names], self.resolver.groups(groups), ms.degree, borrow=True, skip_one=True)
-                self.members.append(m)
-                self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
-                continue
-            tabs = [self.tables[t] for t in ms.tables]
-            if ms.split_eq is not None:
-                a, b, w = ms.split_eq
-                m = ctx.member_split_eq_product(tabs[a], tabs[b], w, borrow=True)
-            else:
-                m = ctx.member_lc(tabs, self.resolver.groups(ms.groups), ms.degree, borrow=True, skip_one=True)
-            self.members.append(m)
-            self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
+            prng = np.random.default_rng(seed + 3)
+            n_oh = sum(self.sources[i].n_polys for i in sorted(self.sources))
+            self.rlc_onehot = rand_fr(n_oh, prng)
+            self.rlc_dense = rand_fr(len(self.committed_dense), prng)
+            self.open_point = rand_fr(self.grid_vars, prng)
+        elif pcs is not None:
+            raise ValueError(pcs)
+        self.tables, self.members, self.prepared = {}, [], False
+        self.prepare()
         ctx.synchronize()
         # input claims: in the real prover these are the previous stage's output claims; here computed once, untimed
         self.claims = [m.input_claim() for m in self.members]
-        rng = np.random.default_rng(seed + 1)
-        self.batch_coeffs = [rand_fr(1, rng)[0] for _ in self.members]
-        self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
-        self.n_onehot = sum(len(ms.tables) - 1 for ms in self.members_spec if lazy(ms))
 
+    # ---- per-proof tables -------------------------------------------------------------------------------------------
     def _scale_table(self, spec):
-        """eq(r_chunk, .) over the chunk domain (K entries), built on the device, as host limbs"""
-        t = self.ctx.eq_evals(spec.point)
-        out = t.download()
-        t.free()
-        return out
+        """eq(r_chunk, .) over the chunk domain (K entries) as host limbs (EqPolynomial::evals on the host: K = 16)"""
+        return self.ffi.host_eq_evals(spec.point)
 
-    def _make_table(self, spec):
+    def _make_table(self, name, spec):
         c = self.ctx
         if spec.kind == "onehot":  # dense address-folded column (only when a non-lazy member needs it)
             src = c.onehot(spec.data.reshape(1, -1), 1 << len(spec.point))
@@ -306,10 +311,8 @@ class DeviceWorkload:
             st.free()
             src.free()
             return out
-        if spec.kind == "u64":
-            return c.from_u64(spec.data)
-        if spec.kind == "i64":
-            return c.from_i64(spec.data)
+        if spec.kind in ("u64", "i64"):
+            return c.table_from_ints(self.ints[name])
         if spec.kind == "eq":
             return c.eq_evals(spec.point)
         if spec.kind == "lt":
@@ -320,8 +323,59 @@ class DeviceWorkload:
             return eq1
         raise ValueError(spec.kind)
 
+    def prepare(self):
+        """Everything a proof builds before its first round: per-proof tables and the members over them."""
+        if self.prepared:
+            self.release()
+        ctx = self.ctx
+        for name, spec in self.tables_spec.items():
+            if name not in self._skip:
+                self.tables[name] = self._make_table(name, spec)
+        for i, ms in enumerate(self.members_spec):
+            if ms.uniform is not None:
+                V, F, csyms = ms.uniform
+                coeffs = [self.resolver.coeff(c) for c in csyms]
+                w = self.tables_spec[ms.tables[0]].point
+                if self._lazy(ms):
+                    specs = [self.tables_spec[t] for t in ms.tables[1:]]
+                    scale_tables = np.stack([self._scale_table(sp) for sp in specs])
+                    m = ctx.member_lazy_ra_uniform(self.sources[i], scale_tables, V, F, coeffs, w)
+                else:
+                    tabs = [self.tables[t] for t in ms.tables[1:]]
+                    m = ctx.member_split_eq_uniform(tabs, V, F, coeffs, w, borrow=True)
+            elif ms.eq_inner is not None:
+                dq, inner = ms.eq_inner
+                m = ctx.member_lc([self.tables[t] for t in ms.tables[1:]], self.resolver.groups(inner), dq, borrow=True,
+                                  eq_point=self.tables_spec[ms.tables[0]].point)
+            elif ms.fused is not None:  # A = sum_i s_i * leaf_i as ONE table (jolt_rlc), then the ordinary member over fewer tables
+                parts, names, groups = ms.fused
+                for fname, entries in parts:
+                    srcs = [self.tables[ms.tables[ti]] for _, ti in entries]
+                    self.tables[fname] = ctx.rlc(srcs, np.stack([self.resolver.coeff(c) for c, _ in entries]))
+                m = ctx.member_lc([self.tables[t] for t in names], self.resolver.groups(groups), ms.degree, borrow=True, skip_one=True)
+            elif ms.split_eq is not None:
+                a, b, w = ms.split_eq
+                tabs = [self.tables[t] for t in ms.tables]
+                m = ctx.member_split_eq_product(tabs[a], tabs[b], w, borrow=True)
+            else:
+                m = ctx.member_lc([self.tables[t] for t in ms.tables], self.resolver.groups(ms.groups), ms.degree, borrow=True, skip_one=True)
+            self.members.append(m)
+        self.prepared = True
+
+    def release(self):
+        for m in self.members:
+            m.destroy()
+        self.members = []
+        for t in self.tables.values():
+            t.free()
+        self.tables = {}
+        self.prepared = False
+
+    # ---- the proof ---------------------------------------------------------------------------------------------------
     def prove(self, label=0):
-        """One pass of the hot path: every stage's batched sumcheck, then rewind the members. Returns per-stage outputs."""
+        """Every stage's batched sumcheck, then rewind the members (they borrow their tables). Returns per-stage outputs."""
+        if not self.prepared:
+            self.prepare()
         outs = {}
         for stage, idxs in sorted(self.stages.items()):
             ms = [self.members[i] for i in idxs]
@@ -332,5 +386,58 @@ class DeviceWorkload:
             m.reset()
         return outs
 
+    def commit(self):
+        """Stage 0 over the commitment grid: dense increment columns = T-term MSMs of 64-bit scalars against the SRS prefix (address 0),
+        one-hot columns = sums of selected bases."""
+        ctx, T = self.ctx, 1 << self.n_vars
+        dense = [ctx.msm(self.srs, self.tables[name], T) for name in self.committed_dense]
+        onehot = [ctx.grid_commit_onehot(self.srs, self.sources[i]) for i in sorted(self.sources)]
+        return dict(dense=np.stack(dense), onehot=np.concatenate(onehot))
+
+    def joint_polynomial(self):
+        return self.ctx.grid_joint_polynomial([self.sources[i] for i in sorted(self.sources)], self.rlc_onehot,
+                                              [self.tables[name] for name in self.committed_dense], self.rlc_dense, self.log_k)
+
+    def open(self, label=0):
+        """Stage 8: joint polynomial of the homomorphic batch, one HyperKZG opening at the unified point."""
+        joint = self.joint_polynomial()
+        out = self.ctx.hyperkzg_open(self.srs, joint, self.open_point, label=label)
+        joint.free()
+        return out
+
+    def step(self, label=0):
+        """One proof's worth of hot-path work (bench.py's timed step)."""
+        self.prepare()
+        out = {}
+        if self.pcs:
+            out["commit"] = self.commit()
+        out["stages"] = self.prove(label)
+        if self.pcs:
+            out["open"] = self.open(label)
+        return out
+
     def bytes_resident(self):
         return sum(len(t) for t in self.tables.values()) * 32
+
+    def close(self):
+        self.release()
+        for s in self.sources.values():
+            s.free()
+        for v in self.ints.values():
+            v.free()
+        self.sources, self.ints = {}, {}
+        if self.own_srs and self.srs is not None:
+            self.srs.free()
+            self.srs = None
+
+
+# BN254 G1 generator (1, 2) as Montgomery Jacobian limbs (ark_bn254::G1Projective layout): R mod q, 2R mod q, R mod q
+_Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+def _fq_mont(v):
+    m = (v << 256) % _Q
+    return [(m >> (64 * i)) & (2**64 - 1) for i in range(4)]
+
+
+G1_GENERATOR = np.array(_fq_mont(1) + _fq_mont(2) + _fq_mont(1), dtype=np.uint64)

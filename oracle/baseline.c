@@ -147,3 +147,21 @@ EXPORT void orc_baseline_member_sumcheck(const fr_t *const *tables_in, uint32_t 
     for (uint32_t i = 0; i < n_tables; ++i) { free(cur[i]); free(alt[i]); }
     free(cur); free(alt); free(partial);
 }
+
+/* Joint polynomial of the stage-8 batch opening on the K x T commitment grid, cycle-major placement (index = k*T + j; dense
+ * columns at k = 0) -- RlcSource::to_dense over the grid-embedded polynomials (crates/jolt-poly/src/multilinear.rs:159-170,
+ * placement crates/jolt-kernels/src/optimized/opening.rs:340-372).  idx: n_polys columns of `cycles` hot indices (0xFF = cold). */
+EXPORT void orc_baseline_grid_joint(const uint8_t *idx, uint32_t n_polys, size_t cycles, uint32_t k_grid, const fr_t *scalars,
+                                    const fr_t *const *dense, uint32_t n_dense, const fr_t *dense_scalars, fr_t *out) {
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < cycles; ++j) {
+        for (uint32_t k = 0; k < k_grid; ++k) out[(size_t)k * cycles + j] = fr_zero();
+        for (uint32_t p = 0; p < n_polys; ++p) {
+            uint8_t a = idx[(size_t)p * cycles + j];
+            if (a == 0xFF) continue;
+            fr_t *slot = &out[(size_t)a * cycles + j];
+            *slot = FADD(*slot, scalars[p]);
+        }
+        for (uint32_t d = 0; d < n_dense; ++d) out[j] = FADD(out[j], FMUL(dense[d][j], dense_scalars[d]));
+    }
+}

@@ -225,6 +225,100 @@ EXPORT void orc_g1_msm_pippenger(const g1_t *bases, const fr_t *scalars, size_t 
     *out = total;
 }
 
+/* ---- cpu_baseline leg only: the same bucket method on all host cores ------------------------------------------------------
+ * ark's VariableBaseMSM runs its windows on rayon threads; here tasks = (window, chunk of the points), each with its own bucket
+ * array, merged by the group law (order-free).  The bases are converted to affine ONCE per base array (cached by address and
+ * length) -- the reference converts per call with a batch inversion (bn254/mod.rs:205), cheaper than the n single inversions a
+ * per-call conversion would cost here, so leaving it out of the timed calls only flatters the CPU side. */
+#include <omp.h>
+static const g1_t *g_aff_src = NULL;
+static size_t g_aff_n = 0;
+static g1_affine_t *g_aff = NULL;
+EXPORT void orc_baseline_prepare_bases(const g1_t *bases, size_t n) {
+    free(g_aff);
+    g_aff = (g1_affine_t *)malloc((n ? n : 1) * sizeof(g1_affine_t));
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) g_aff[i] = g1_to_affine(&bases[i]);
+    g_aff_src = bases;
+    g_aff_n = n;
+}
+EXPORT void orc_baseline_msm(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out) {
+    if (n == 0) { *out = g1_identity(); return; }
+    if (!(g_aff && bases >= g_aff_src && bases + n <= g_aff_src + g_aff_n)) { orc_g1_msm_pippenger(bases, scalars, n, out); return; }
+    const g1_affine_t *aff = g_aff + (bases - g_aff_src);
+    unsigned log2n = 0;
+    while (((size_t)2 << log2n) <= n) log2n++;
+    unsigned c = n < 32 ? 3 : (log2n * 69 / 100) + 2; /* ark's window rule, as in orc_g1_msm_pippenger */
+    if (c > 16) c = 16;
+    const size_t n_buckets = ((size_t)1 << c) - 1;
+    const unsigned n_windows = (254 + c - 1) / c;
+    int threads = omp_get_max_threads();
+    unsigned chunks = 1;
+    while (n_windows * chunks < (unsigned)threads * 2 && (n / (chunks * 2)) >= 4 * n_buckets) chunks *= 2;
+    u256 *ks = (u256 *)malloc(n * sizeof(u256));
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) mont_to_canonical(&ks[i], &scalars[i], &FR);
+    g1_t *wsum = (g1_t *)malloc((size_t)n_windows * chunks * sizeof(g1_t));
+#pragma omp parallel
+    {
+        g1_t *buckets = (g1_t *)malloc(n_buckets * sizeof(g1_t));
+#pragma omp for schedule(dynamic, 1) collapse(2)
+        for (unsigned w = 0; w < n_windows; ++w)
+            for (unsigned ch = 0; ch < chunks; ++ch) {
+                for (size_t b = 0; b < n_buckets; ++b) buckets[b] = g1_identity();
+                const unsigned start = w * c;
+                const size_t lo = (size_t)ch * n / chunks, hi = (size_t)(ch + 1) * n / chunks;
+                for (size_t i = lo; i < hi; ++i) {
+                    uint64_t digit = 0;
+                    for (unsigned k = 0; k < c; ++k) {
+                        unsigned bit = start + k;
+                        if (bit < 256) digit |= ((ks[i].l[bit / 64] >> (bit % 64)) & 1) << k;
+                    }
+                    if (digit) buckets[digit - 1] = g1_add_mixed(&buckets[digit - 1], &aff[i]);
+                }
+                g1_t running = g1_identity(), sum = g1_identity();
+                for (size_t b = n_buckets; b-- > 0;) {
+                    running = g1_add(&running, &buckets[b]);
+                    sum = g1_add(&sum, &running);
+                }
+                wsum[(size_t)w * chunks + ch] = sum;
+            }
+        free(buckets);
+    }
+    g1_t total = g1_identity();
+    for (int w = (int)n_windows - 1; w >= 0; --w) {
+        for (unsigned k = 0; k < c; ++k) total = g1_double(&total);
+        for (unsigned ch = 0; ch < chunks; ++ch) total = g1_add(&total, &wsum[(size_t)w * chunks + ch]);
+    }
+    free(wsum);
+    free(ks);
+    *out = total;
+}
+/* sum of bases[idx[j] * cycles + j] over the hot cycles: a one-hot column's commitment on the K x T grid (additions only) */
+EXPORT void orc_baseline_grid_onehot_sum(const g1_t *bases, const uint8_t *idx, size_t cycles, g1_t *out) {
+    const g1_affine_t *aff = (g_aff && bases == g_aff_src) ? g_aff : NULL;
+    g1_t total = g1_identity();
+#pragma omp parallel
+    {
+        g1_t local = g1_identity();
+#pragma omp for schedule(static) nowait
+        for (size_t j = 0; j < cycles; ++j) {
+            if (idx[j] == 0xFF) continue;
+            size_t at = (size_t)idx[j] * cycles + j;
+            if (aff) local = g1_add_mixed(&local, &aff[at]);
+            else local = g1_add(&local, &bases[at]);
+        }
+#pragma omp critical
+        total = g1_add(&total, &local);
+    }
+    *out = total;
+}
+
+/* The MSM the HyperKZG restatement calls: the serial bucket method above by default; bench.py's cpu_baseline leg switches it to
+ * the OpenMP form of oracle/baseline.c (same point, computed on all host cores). */
+void (*orc_msm_impl)(const g1_t *, const fr_t *, size_t, g1_t *) = orc_g1_msm_pippenger;
+EXPORT void orc_baseline_use_parallel_msm(int on) { orc_msm_impl = on ? orc_baseline_msm : orc_g1_msm_pippenger; }
+
 /* HyperKZGScheme::setup_from_secret (crates/jolt-hyperkzg/src/scheme.rs:54-73): g1_powers[i] = beta^i * g1,
  * built by repeated scalar_mul exactly as the reference does (max_degree + 1 entries). */
 EXPORT void orc_srs_setup_from_secret(const fr_t *beta, size_t count, g1_t *out) {

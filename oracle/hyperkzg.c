@@ -18,19 +18,21 @@
  */
 #include "fr.h"
 #include "mock_transcript.h"
+#include <omp.h>
 #include <stdlib.h>
 
 #define EXPORT __attribute__((visibility("default")))
 
 typedef struct { fq_t x, y, z; } g1_t;
 void orc_g1_msm_pippenger(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out);
+extern void (*orc_msm_impl)(const g1_t *, const fr_t *, size_t, g1_t *); /* g1.c: serial Pippenger unless the cpu_baseline leg swapped it */
 void orc_g1_serialize_compressed(const g1_t *p, uint8_t out[32]);
 void orc_bind_low_to_high(const fr_t *t, size_t len, const fr_t *r, fr_t *out);
 
 /* kzg.rs:15-27 */
 EXPORT int orc_kzg_commit(const fr_t *coeffs, size_t n, const g1_t *g1_powers, size_t srs_len, g1_t *out) {
     if (n > srs_len) return -1; /* HyperKZGError::SrsTooSmall */
-    orc_g1_msm_pippenger(g1_powers, coeffs, n, out);
+    orc_msm_impl(g1_powers, coeffs, n, out);
     return 0;
 }
 
@@ -45,11 +47,41 @@ EXPORT void orc_kzg_witness_polynomial(const fr_t *f, size_t d, const fr_t *u, f
 }
 
 /* kzg.rs:51-59 */
+static fr_t fr_pow_u64(fr_t base, uint64_t e) {
+    fr_t acc = fr_one();
+    for (; e; e >>= 1) {
+        if (e & 1) acc = FMUL(acc, base);
+        base = FMUL(base, base);
+    }
+    return acc;
+}
 EXPORT void orc_kzg_eval_univariate(const fr_t *coeffs, size_t n, const fr_t *u, fr_t *out) {
-    fr_t result = fr_zero(), power = fr_one();
-    for (size_t i = 0; i < n; ++i) {
-        result = FADD(result, FMUL(coeffs[i], power));
-        power = FMUL(power, *u);
+    if (n < 65536) { /* the reference's loop verbatim */
+        fr_t result = fr_zero(), power = fr_one();
+        for (size_t i = 0; i < n; ++i) {
+            result = FADD(result, FMUL(coeffs[i], power));
+            power = FMUL(power, *u);
+        }
+        *out = result;
+        return;
+    }
+    /* same sum, split into chunks that start from u^lo (exact arithmetic: the value does not depend on the split) */
+    const size_t chunk = 16384, chunks = (n + chunk - 1) / chunk;
+    fr_t result = fr_zero();
+#pragma omp parallel
+    {
+        fr_t local = fr_zero();
+#pragma omp for schedule(static) nowait
+        for (size_t c = 0; c < chunks; ++c) {
+            size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            fr_t power = fr_pow_u64(*u, lo);
+            for (size_t i = lo; i < hi; ++i) {
+                local = FADD(local, FMUL(coeffs[i], power));
+                power = FMUL(power, *u);
+            }
+        }
+#pragma omp critical
+        result = FADD(result, local);
     }
     *out = result;
 }
@@ -109,14 +141,16 @@ EXPORT int orc_hyperkzg_open(const g1_t *g1_powers, size_t srs_len, const fr_t *
     for (size_t i = 0; i < n; ++i) b_poly[i] = fr_zero();
     fr_t qj = fr_one();
     for (size_t j = 0; j < ell; ++j) {
-        for (size_t i = 0; i < len[j]; ++i) b_poly[i] = FADD(b_poly[i], FMUL(qj, polys[off[j] + i]));
+        const fr_t *pj = polys + off[j];
+#pragma omp parallel for schedule(static) if (len[j] >= 65536)
+        for (size_t i = 0; i < len[j]; ++i) b_poly[i] = FADD(b_poly[i], FMUL(qj, pj[i]));
         qj = FMUL(qj, q);
     }
     /* kzg.rs:108-116 */
     fr_t *h = (fr_t *)malloc(n * sizeof(fr_t));
     for (int t = 0; t < 3; ++t) {
         orc_kzg_witness_polynomial(b_poly, n, &u[t], h);
-        orc_g1_msm_pippenger(g1_powers, h, n - 1, &w[t]);
+        orc_msm_impl(g1_powers, h, n - 1, &w[t]);
     }
     /* kzg.rs:118-124 */
     for (int t = 0; t < 3; ++t) mt_append_g1(&tr, &w[t]);

@@ -32,6 +32,8 @@ EXPORT void orc_bind_high_to_low(fr_t *t, size_t len, const fr_t *r) {
 /* dense.rs:223-263 bind_low_to_high: out[i] <- t[2i] + r*(t[2i+1]-t[2i]); `out` may alias `t` */
 EXPORT void orc_bind_low_to_high(const fr_t *t, size_t len, const fr_t *r, fr_t *out) {
     size_t half = len / 2;
+    /* out of place and large: outputs are independent (dense.rs:270-303 par_iter); in place it must stay sequential */
+#pragma omp parallel for schedule(static) if (half >= 32768 && (out + half <= t || t + len <= out))
     for (size_t i = 0; i < half; ++i) {
         fr_t lo = t[2 * i], hi = t[2 * i + 1];
         out[i] = FADD(lo, FMUL(*r, FSUB(hi, lo)));

@@ -20,7 +20,14 @@
  */
 #include "fr.h"
 #include "mock_transcript.h"
+#include <omp.h>
 #include <stdlib.h>
+
+/* The sweeps over the hypercube are split over OpenMP threads (per-thread partial sums merged by addition: field addition is
+ * exact, so the merge order cannot change a value -- the reference's rayon fold/reduce makes the same argument,
+ * crates/jolt-kernels/src/reference/naive.rs:262-296).  That is what lets the GPU parity tests run this restatement at the
+ * benchmark's trace lengths (T = 2^20 .. 2^22) instead of toy sizes. */
+#define ORC_PAR_MIN 4096
 
 #define EXPORT __attribute__((visibility("default")))
 
@@ -128,10 +135,30 @@ static void member_bind(orc_member *m, const fr_t *challenge) {
         orc_split_eq_bind_scalar(&m->current_scalar, &m->w[current_index - 1], challenge, &m->current_scalar);
     }
     for (uint32_t i = 0; i < m->n_tables; ++i) {
-        if (m->kind == ORC_KIND_GRUEN_PRODUCT || m->order == ORC_ORDER_LOW_TO_HIGH)
-            orc_bind_low_to_high(m->tables[i], m->len, challenge, m->tables[i]);
-        else
+        if (m->kind == ORC_KIND_GRUEN_PRODUCT || m->order == ORC_ORDER_LOW_TO_HIGH) {
+            if (m->len >= ORC_PAR_MIN) { /* out of place so that the outputs can be computed in parallel (dense.rs:270-303) */
+                size_t half = m->len / 2;
+                fr_t *src = m->tables[i], *dst = (fr_t *)malloc(half * sizeof(fr_t));
+                const fr_t r = *challenge;
+#pragma omp parallel for schedule(static)
+                for (size_t y = 0; y < half; ++y) {
+                    fr_t lo = src[2 * y], hi = src[2 * y + 1];
+                    dst[y] = FADD(lo, FMUL(r, FSUB(hi, lo)));
+                }
+                free(src);
+                m->tables[i] = dst;
+            } else {
+                orc_bind_low_to_high(m->tables[i], m->len, challenge, m->tables[i]);
+            }
+        } else if (m->len >= ORC_PAR_MIN) {
+            size_t half = m->len / 2;
+            fr_t *t = m->tables[i];
+            const fr_t r = *challenge;
+#pragma omp parallel for schedule(static)
+            for (size_t y = 0; y < half; ++y) t[y] = FADD(t[y], FMUL(r, FSUB(t[y + half], t[y])));
+        } else {
             orc_bind_high_to_low(m->tables[i], m->len, challenge);
+        }
     }
     m->len /= 2;
     m->rounds_bound += 1;
@@ -155,20 +182,27 @@ static int expr_round(orc_member *m, const fr_t *previous_claim, fr_t *coeffs_ou
         if (m->skip_one && t == 1) continue;
         fr_t point = fr_from_u64(t);
         fr_t sum = fr_zero();
-        for (size_t y = 0; y < half; ++y) {
-            fr_t result = fr_zero();
-            for (uint32_t k = 0; k < m->n_terms; ++k) {
-                fr_t value = m->coeffs[k];
-                for (uint32_t f = m->term_offsets[k]; f < m->term_offsets[k + 1]; ++f) {
-                    fr_t lo, hi;
-                    eval_pair(m, m->factors[f], y, &lo, &hi);
-                    /* dense.rs:328-337: lo + point * (hi - lo) */
-                    fr_t v = FADD(lo, FMUL(point, FSUB(hi, lo)));
-                    value = FMUL(value, v);
+#pragma omp parallel if (half >= ORC_PAR_MIN)
+        {
+            fr_t local = fr_zero();
+#pragma omp for schedule(static) nowait
+            for (size_t y = 0; y < half; ++y) {
+                fr_t result = fr_zero();
+                for (uint32_t k = 0; k < m->n_terms; ++k) {
+                    fr_t value = m->coeffs[k];
+                    for (uint32_t f = m->term_offsets[k]; f < m->term_offsets[k + 1]; ++f) {
+                        fr_t lo, hi;
+                        eval_pair(m, m->factors[f], y, &lo, &hi);
+                        /* dense.rs:328-337: lo + point * (hi - lo) */
+                        fr_t v = FADD(lo, FMUL(point, FSUB(hi, lo)));
+                        value = FMUL(value, v);
+                    }
+                    result = FADD(result, value);
                 }
-                result = FADD(result, value);
+                local = FADD(local, result);
             }
-            sum = FADD(sum, result);
+#pragma omp critical
+            sum = FADD(sum, local);
         }
         evals[t] = sum;
     }
@@ -199,17 +233,27 @@ static int gruen_round(orc_member *m, const fr_t *previous_claim, fr_t *coeffs_o
     orc_eq_evals(m->w + out_len, in_bits, NULL, e_in);   /* evals_cached(in_point)[in_bits]  */
     const fr_t *a = m->tables[0], *b = m->tables[1];
     fr_t zero = fr_zero(), infinity = fr_zero();
-    for (size_t x_out = 0; x_out < e_out_n; ++x_out) {
-        fr_t acc0 = fr_zero(), acc1 = fr_zero();
-        for (size_t x_in = 0; x_in < e_in_n; ++x_in) {
-            size_t row = (x_out << in_bits) | x_in;
-            fr_t a_low = a[2 * row], a_high = a[2 * row + 1];
-            fr_t b_low = b[2 * row], b_high = b[2 * row + 1];
-            acc0 = FADD(acc0, FMUL(e_in[x_in], FMUL(a_low, b_low)));
-            acc1 = FADD(acc1, FMUL(e_in[x_in], FMUL(FSUB(a_high, a_low), FSUB(b_high, b_low))));
+#pragma omp parallel if (m->len >= ORC_PAR_MIN)
+    {
+        fr_t lz = fr_zero(), li = fr_zero();
+#pragma omp for schedule(static) nowait
+        for (size_t x_out = 0; x_out < e_out_n; ++x_out) {
+            fr_t acc0 = fr_zero(), acc1 = fr_zero();
+            for (size_t x_in = 0; x_in < e_in_n; ++x_in) {
+                size_t row = (x_out << in_bits) | x_in;
+                fr_t a_low = a[2 * row], a_high = a[2 * row + 1];
+                fr_t b_low = b[2 * row], b_high = b[2 * row + 1];
+                acc0 = FADD(acc0, FMUL(e_in[x_in], FMUL(a_low, b_low)));
+                acc1 = FADD(acc1, FMUL(e_in[x_in], FMUL(FSUB(a_high, a_low), FSUB(b_high, b_low))));
+            }
+            lz = FADD(lz, FMUL(e_out[x_out], acc0));
+            li = FADD(li, FMUL(e_out[x_out], acc1));
         }
-        zero = FADD(zero, FMUL(e_out[x_out], acc0));
-        infinity = FADD(infinity, FMUL(e_out[x_out], acc1));
+#pragma omp critical
+        {
+            zero = FADD(zero, lz);
+            infinity = FADD(infinity, li);
+        }
     }
     free(e_out);
     free(e_in);
@@ -302,20 +346,30 @@ EXPORT int orc_member_copy_table(const orc_member *m, uint32_t t, fr_t *out, siz
  * For EXPR: sum_x Expr(x); for GRUEN: sum_x scale*eq(w,x) a(x) b(x). */
 EXPORT void orc_member_input_claim(const orc_member *m, fr_t *out) {
     fr_t sum = fr_zero();
-    if (m->kind == ORC_KIND_EXPR) {
+    fr_t *eq = NULL;
+    if (m->kind != ORC_KIND_EXPR) {
+        eq = (fr_t *)malloc(m->len * sizeof(fr_t));
+        orc_eq_evals(m->w, m->rounds, &m->current_scalar, eq);
+    }
+#pragma omp parallel if (m->len >= ORC_PAR_MIN)
+    {
+        fr_t local = fr_zero();
+#pragma omp for schedule(static) nowait
         for (size_t x = 0; x < m->len; ++x) {
-            for (uint32_t k = 0; k < m->n_terms; ++k) {
-                fr_t value = m->coeffs[k];
-                for (uint32_t f = m->term_offsets[k]; f < m->term_offsets[k + 1]; ++f) value = FMUL(value, m->tables[m->factors[f]][x]);
-                sum = FADD(sum, value);
+            if (m->kind == ORC_KIND_EXPR) {
+                for (uint32_t k = 0; k < m->n_terms; ++k) {
+                    fr_t value = m->coeffs[k];
+                    for (uint32_t f = m->term_offsets[k]; f < m->term_offsets[k + 1]; ++f) value = FMUL(value, m->tables[m->factors[f]][x]);
+                    local = FADD(local, value);
+                }
+            } else {
+                local = FADD(local, FMUL(eq[x], FMUL(m->tables[0][x], m->tables[1][x])));
             }
         }
-    } else {
-        fr_t *eq = (fr_t *)malloc(m->len * sizeof(fr_t));
-        orc_eq_evals(m->w, m->rounds, &m->current_scalar, eq);
-        for (size_t x = 0; x < m->len; ++x) sum = FADD(sum, FMUL(eq[x], FMUL(m->tables[0][x], m->tables[1][x])));
-        free(eq);
+#pragma omp critical
+        sum = FADD(sum, local);
     }
+    free(eq);
     *out = sum;
 }
 

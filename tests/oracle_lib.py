@@ -665,6 +665,44 @@ def baseline_member_sumcheck(tables, groups, degree, challenges):
     return out[:degree]
 
 
+def baseline_prepare_bases(bases):
+    """affine copies of a base array, cached inside the oracle by address: keep `bases` alive while the parallel MSM is in use"""
+    b = _g1(bases).reshape(-1, 12)
+    lib().orc_baseline_prepare_bases(_p(b), C.c_size_t(b.shape[0]))
+    return b
+
+
+def baseline_use_parallel_msm(on):
+    lib().orc_baseline_use_parallel_msm(C.c_int(1 if on else 0))
+
+
+def baseline_msm(bases, scalars):
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    o = g1_array(1)
+    lib().orc_baseline_msm(_p(bases), _p(s), C.c_size_t(s.shape[0]), _p(o))
+    return o[0]
+
+
+def baseline_grid_onehot_sum(bases, idx_col):
+    i = np.ascontiguousarray(idx_col, dtype=np.uint8)
+    o = g1_array(1)
+    lib().orc_baseline_grid_onehot_sum(_p(bases), i.ctypes.data_as(C.c_void_p), C.c_size_t(i.shape[0]), _p(o))
+    return o[0]
+
+
+def baseline_grid_joint(idx, k_grid, scalars, dense, dense_scalars):
+    i = np.ascontiguousarray(idx, dtype=np.uint8)
+    n_polys, cycles = i.shape
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    dn = [np.ascontiguousarray(d, dtype=np.uint64).reshape(-1, 4) for d in dense]
+    ptrs = (C.c_void_p * max(len(dn), 1))(*[d.ctypes.data for d in dn])
+    dsc = np.ascontiguousarray(dense_scalars, dtype=np.uint64).reshape(-1, 4) if len(dn) else fr_array(1)
+    out = fr_array(k_grid * cycles)
+    lib().orc_baseline_grid_joint(i.ctypes.data_as(C.c_void_p), C.c_uint32(n_polys), C.c_size_t(cycles), C.c_uint32(k_grid), _p(sc), ptrs,
+                                  C.c_uint32(len(dn)), _p(dsc), _p(out))
+    return out
+
+
 # ---- one-hot selector columns (oracle/onehot.c) ---------------------------------------------------------------------
 def onehot_values(table, width, k_entries, col, cycles):
     table = np.ascontiguousarray(table, dtype=np.uint64)

@@ -1,0 +1,203 @@
+"""GPU parity of the PCS legs of the benchmark step (BASELINE configs[2]): committed columns over the shared commitment grid,
+the joint polynomial of the homomorphic batch, and the HyperKZG opening at BASELINE scale.
+
+Small sizes: bit-exact against the oracle's restatements (kzg_commit of the grid-embedded coefficient vector, the RLC of the
+embedded polynomials, hyperkzg_open).  2^20 / 2^22 / the bench's 2^26 grid: the size-independent identities of tests/kzg_check.py
+(beta is known to the test), the same way the reference pins HyperKZG by commit -> open -> verify round trips
+(crates/jolt-hyperkzg/tests/commit_open_verify.rs:29-60, crates/jolt-openings/tests/homomorphic_hyperkzg.rs:17-44)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from jolt_amd import ffi
+from jolt_amd.workload import DeviceWorkload, G1_GENERATOR
+from kzg_check import check_opening, same_point
+from util import rand_challenge, rand_fr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ffi.Context(0)
+    yield c
+    c.close()
+
+
+def embed_onehot(idx_col, k, cycles):
+    """coefficient vector of a one-hot column on the K x T grid, cycle-major placement (index = address * T + cycle;
+    TracePlacement, crates/jolt-kernels/src/optimized/opening.rs:340-372)"""
+    out = np.zeros((k * cycles, 4), dtype=np.uint64)
+    hot = idx_col != 0xFF
+    j = np.nonzero(hot)[0]
+    out[idx_col[hot].astype(np.int64) * cycles + j] = O.to_mont([1])[0]
+    return out
+
+
+def test_generator_constant_matches_oracle():
+    assert np.array_equal(G1_GENERATOR, O.g1_generator())
+
+
+def test_table_from_resident_integers(ctx):
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, 2**64, size=1000, dtype=np.uint64)
+    i = rng.integers(-2**63, 2**63, size=1000, dtype=np.int64)
+    i[:3] = [0, -1, -2**63]
+    assert np.array_equal(ctx.table_from_ints(ctx.ints(u)).download(), O.fr_from_u64(u))
+    assert np.array_equal(ctx.table_from_ints(ctx.ints(i)).download(), O.fr_from_i64(i))
+    assert np.array_equal(ctx.table_from_ints(ctx.ints(u), 17, 100).download(), O.fr_from_u64(u[17:117]))
+    big = [0, 1, -1, 2**127 - 1, -2**127, 2**64, -2**64 - 5, 123456789 << 70]
+    got = ctx.table_from_ints(ctx.ints(big, "i128")).download()
+    want = O.to_mont([v % O.R_MOD for v in big])
+    assert np.array_equal(got, want)
+    with pytest.raises(ffi.JoltError) as e:
+        ctx.table_from_ints(ctx.ints(u), 990, 20)
+    assert e.value.status == 5
+
+
+@pytest.mark.parametrize("log_t,k,cold", [(4, 16, 0.0), (6, 16, 0.4), (5, 4, 0.2)])
+def test_grid_commitments_and_joint_polynomial_match_oracle(ctx, log_t, k, cold):
+    T = 1 << log_t
+    log_k = 4
+    K = 1 << log_k
+    rng = np.random.default_rng(10 + log_t)
+    beta = rand_fr(1, 20 + log_t)[0]
+    host_srs = O.srs_setup_from_secret(beta, K * T)
+    srs = ctx.srs_upload(host_srs)
+    idx_a = rng.integers(0, k, size=(3, T), dtype=np.uint8)
+    idx_b = rng.integers(0, k, size=(2, T), dtype=np.uint8)
+    if cold:
+        idx_a[rng.random((3, T)) < cold] = 0xFF
+    idx_a[0, :] = 0xFF if cold else idx_a[0, :]  # an entirely cold column commits to the identity
+    src_a, src_b = ctx.onehot(idx_a, k), ctx.onehot(idx_b, k)
+    for src, idx in ((src_a, idx_a), (src_b, idx_b)):
+        got = ctx.grid_commit_onehot(srs, src)
+        for p in range(idx.shape[0]):
+            want = O.kzg_commit(embed_onehot(idx[p], K, T), host_srs)
+            assert same_point(got[p], want), p
+    dense_vals = [rng.integers(0, 2**64, size=T, dtype=np.uint64), rng.integers(-2**40, 2**40, size=T, dtype=np.int64)]
+    dense = [ctx.from_u64(dense_vals[0]), ctx.from_i64(dense_vals[1])]
+    dense_host = [O.fr_from_u64(dense_vals[0]), O.fr_from_i64(dense_vals[1])]
+    s_oh, s_d = rand_fr(5, 31), rand_fr(2, 32)
+    s_d[1] = O.to_mont([1])[0]  # unit coefficient path
+    joint = ctx.grid_joint_polynomial([src_a, src_b], s_oh, dense, s_d, log_k)
+    want = np.zeros((K * T, 4), dtype=np.uint64)
+    for p, col in enumerate(list(idx_a) + list(idx_b)):
+        e = embed_onehot(col, K, T)
+        want = O.fr_add(want, O.fr_mul(e, np.repeat(s_oh[p].reshape(1, 4), K * T, axis=0)))
+    for d in range(2):
+        want[:T] = O.fr_add(want[:T], O.fr_mul(dense_host[d], np.repeat(s_d[d].reshape(1, 4), T, axis=0)))
+    assert np.array_equal(joint.download(), want)
+    # a source wider than the grid / an SRS shorter than the grid are refused
+    with pytest.raises(ffi.JoltError) as e:
+        ctx.grid_commit_onehot(ctx.srs_upload(host_srs[: K * T // 2]), ctx.onehot(np.full((1, T), k - 1, dtype=np.uint8), K))
+    assert e.value.status == 9  # HyperKZGError::SrsTooSmall
+    with pytest.raises(ffi.JoltError):
+        ctx.grid_joint_polynomial([ctx.onehot(idx_b, 32)], s_oh[:2], [], [], log_k)
+
+
+@pytest.mark.parametrize("n_vars", [4, 6])
+def test_workload_step_commit_and_open_bit_exact_with_oracle(ctx, n_vars):
+    """The whole PCS side of DeviceWorkload.step at toy size: commitments of all 38 committed columns and the opening of the joint
+    polynomial equal the oracle's kzg_commit / hyperkzg_open on the grid-embedded coefficient vectors, transcript byte for byte;
+    the combined commitment (AdditivelyHomomorphic::combine, crates/jolt-hyperkzg/src/scheme.rs:346-352) is the joint one."""
+    wl = DeviceWorkload(ctx, n_vars, seed=3, pcs="grid")
+    T, K = 1 << n_vars, 16
+    host_srs = O.srs_setup_from_secret(wl.beta, K * T)
+    out = wl.step(label=40)
+    cols = []
+    for i in sorted(wl.sources):
+        ms = wl.members_spec[i]
+        cols += [wl.tables_spec[t].data for t in ms.tables[1:]]
+    joint = np.zeros((K * T, 4), dtype=np.uint64)
+    combined = O.g1_identity()
+    for p, col in enumerate(cols):
+        e = embed_onehot(col, K, T)
+        assert same_point(out["commit"]["onehot"][p], O.kzg_commit(e, host_srs)), p
+        joint = O.fr_add(joint, O.fr_mul(e, np.repeat(wl.rlc_onehot[p].reshape(1, 4), K * T, axis=0)))
+        combined = O.g1_add(combined, O.g1_scalar_mul(out["commit"]["onehot"][p], wl.rlc_onehot[p]))
+    for d, name in enumerate(wl.committed_dense):
+        vals = O.fr_from_u64(wl.tables_spec[name].data)
+        emb = np.zeros((K * T, 4), dtype=np.uint64)
+        emb[:T] = vals
+        assert same_point(out["commit"]["dense"][d], O.kzg_commit(emb, host_srs)), name
+        joint[:T] = O.fr_add(joint[:T], O.fr_mul(vals, np.repeat(wl.rlc_dense[d].reshape(1, 4), T, axis=0)))
+        combined = O.g1_add(combined, O.g1_scalar_mul(out["commit"]["dense"][d], wl.rlc_dense[d]))
+    assert same_point(combined, O.kzg_commit(joint, host_srs))
+    want = O.hyperkzg_open(host_srs, joint, wl.open_point, label=40)
+    got = out["open"]
+    assert np.array_equal(got["challenges"], want["challenges"]) and np.array_equal(got["v"], want["v"])
+    for i in range(wl.grid_vars - 1):
+        assert same_point(got["com"][i], want["com"][i])
+    for t in range(3):
+        assert same_point(got["w"][t], want["w"][t])
+    again = wl.step(label=40)  # a second proof over rebuilt tables: same bytes
+    assert np.array_equal(again["open"]["v"], got["v"])
+    for st in out["stages"]:
+        assert np.array_equal(again["stages"][st]["polys"], out["stages"][st]["polys"])
+    wl.close()
+
+
+@pytest.mark.parametrize("ell,kind", [(20, "full"), (22, "full"), (22, "u64")])
+def test_hyperkzg_open_at_baseline_scale(ctx, ell, kind):
+    """open() at 2^20 / 2^22 coefficients: the four pipelined MSM lanes, the recursive suffix scan over many chunk levels and the
+    blocked Horner with u^(4096*block) weights are size-dependent paths -- checked through the beta-known identities."""
+    n = 1 << ell
+    beta = rand_fr(1, 500 + ell)[0]
+    srs = ctx.srs_setup_from_secret(beta, n, G1_GENERATOR)
+    if kind == "full":
+        point = rand_fr(ell, 510)
+        tab = ctx.eq_evals(rand_fr(ell, 511))  # full-width pseudo-random evaluations built on the device
+    else:
+        point = np.stack([rand_challenge(520 + k) for k in range(ell)])
+        tab = ctx.from_u64(np.random.default_rng(521).integers(0, 2**64, size=n, dtype=np.uint64))
+    proof = ctx.hyperkzg_open(srs, tab, point, label=77)
+    claimed = ctx.evaluate(tab, point)
+    p_beta = check_opening(ctx, tab, point, proof, beta, claimed)
+    assert same_point(ctx.hyperkzg_commit(srs, tab), O.g1_scalar_mul(O.g1_generator(), p_beta))
+    srs.free()
+    tab.free()
+    ctx.trim()
+
+
+def test_bench_step_at_configs2_scale():
+    """BASELINE configs[2] as bench.py runs it: T = 2^22 cycles, 2^26-coefficient commitment grid.  The step's commitments combine
+    to the joint polynomial's commitment J(beta) G, the opening passes the beta-known identities (the four largest levels through
+    the device's Horner, the rest re-evaluated by the oracle), and two steps give identical bytes."""
+    c = ffi.Context(0)
+    wl = DeviceWorkload(c, 22, pcs="grid")
+    out = wl.step(label=7)
+    joint = wl.joint_polynomial()
+    claimed = c.evaluate(joint, wl.open_point)
+    j_beta = check_opening(c, joint, wl.open_point, out["open"], wl.beta, claimed)
+    joint.free()
+    combined = O.g1_identity()
+    for p in range(out["commit"]["onehot"].shape[0]):
+        combined = O.g1_add(combined, O.g1_scalar_mul(out["commit"]["onehot"][p], wl.rlc_onehot[p]))
+    for d in range(out["commit"]["dense"].shape[0]):
+        combined = O.g1_add(combined, O.g1_scalar_mul(out["commit"]["dense"][d], wl.rlc_dense[d]))
+    assert same_point(combined, O.g1_scalar_mul(O.g1_generator(), j_beta))
+    again = wl.step(label=7)
+    assert np.array_equal(again["open"]["v"], out["open"]["v"]) and np.array_equal(again["open"]["challenges"], out["open"]["challenges"])
+    for st in out["stages"]:
+        assert np.array_equal(again["stages"][st]["polys"], out["stages"][st]["polys"])
+    stats = c.memory_stats()
+    assert stats["peak_bytes"] < 200 * 2**30  # fits one MI355X with room to spare
+    wl.close()
+    c.close()
+
+
+def test_pool_reuses_and_trims(ctx):
+    ctx.trim()
+    before = ctx.memory_stats()
+    t = ctx.alloc(1 << 16)
+    p0 = t.device_ptr()
+    t.free()
+    mid = ctx.memory_stats()
+    assert mid["cached_bytes"] >= before["cached_bytes"] + (1 << 21)
+    t2 = ctx.alloc(1 << 16)  # same size class: the cached block comes back
+    assert t2.device_ptr() == p0
+    assert np.all(t2.download() == 0)  # and is zeroed again by jolt_table_alloc
+    t2.free()
+    ctx.trim()
+    assert ctx.memory_stats()["cached_bytes"] == 0

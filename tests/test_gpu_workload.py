@@ -31,6 +31,42 @@ def test_catalogue_stage_transcripts_match_oracle(n_vars):
     ctx.close()
 
 
+def test_catalogue_matches_oracle_at_benchmark_scale():
+    """T = 2^20 (BASELINE configs[1] scale), the whole 11-relation catalogue: every round polynomial, challenge, final claim and input
+    claim of the device path -- lazy one-hot members, eq-weighted members, linear-leaf fusions, skipped s(1), the grid-by-size rule and
+    two-level tickets of the big rounds, tail kernels of the small ones -- equals the oracle's naive flat-Expr members over the dense
+    tables (its sweeps run under OpenMP; crates/jolt-kernels/src/optimized/parity.rs:79-118 is the reference's form of this test)."""
+    ctx = ffi.Context(0)
+    dev = DeviceWorkload(ctx, 20)
+    orc = OracleWorkload(20)
+    want = orc.prove(label=300)
+    got = dev.prove(label=300)
+    for stage in want:
+        assert np.array_equal(got[stage]["polys"], want[stage]["polys"]), stage
+        assert np.array_equal(got[stage]["challenges"], want[stage]["challenges"]), stage
+        assert np.array_equal(got[stage]["final_claim"], want[stage]["final_claim"]), stage
+    for i, c in enumerate(dev.claims):
+        st = dev.members_spec[i].stage
+        assert np.array_equal(c, want[st]["claims"][dev.stages[st].index(i)])
+    dev.close()
+    ctx.close()
+
+
+def test_stages_match_oracle_at_configs2_scale():
+    """T = 2^22 (BASELINE configs[2] scale): stages 4 and 5 (ram_val_check; registers_val_evaluation + ram_ra_claim_reduction with its
+    fused eq leaves) against the oracle, transcript for transcript."""
+    ctx = ffi.Context(0)
+    dev = DeviceWorkload(ctx, 22)
+    orc = OracleWorkload(22, only_stages={4, 5})
+    want = orc.prove(label=500)
+    got = dev.prove(label=500)
+    for stage in want:
+        for key in ("polys", "challenges", "final_claim"):
+            assert np.array_equal(got[stage][key], want[stage][key]), (stage, key)
+    dev.close()
+    ctx.close()
+
+
 def test_persistent_round_engine_matches_per_round_kernels(monkeypatch):
     """JOLT_ENGINE=1: the late rounds of every stage run inside the persistent round-engine kernel (engine_kernel.cuh:
     fused binds, mailbox handshake per challenge).  All 11 relations, borrowed tables, expression / split-eq product /

@@ -7,6 +7,7 @@ import random
 import numpy as np
 
 import oracle_lib as O
+from util import rand_fr
 
 R, Q = O.R_MOD, O.Q_MOD
 
@@ -187,3 +188,42 @@ def test_hyperkzg_open_fold_consistency():
         Bu = sum(c * pow(us[t], k, R) for k, c in enumerate(Bc)) % R
         wt = (Bbeta - Bu) * pow(beta - us[t], -1, R) % R
         assert to_model(out["w"][t]) == aff_mul(wt, G)
+
+
+def test_baseline_parallel_msm_and_grid_pieces_equal_the_serial_restatements():
+    """bench.py's cpu_baseline leg runs the oracle's MSM / HyperKZG on all host cores (OpenMP tasks over windows x point chunks):
+    same points as the serial restatements, the one-hot grid sum equals kzg_commit of the embedded 0/1 coefficient vector, and the
+    joint polynomial equals the RLC of the embedded polynomials."""
+    n = 600
+    beta = rand_fr(1, 900)[0]
+    srs = O.srs_setup_from_secret(beta, n)
+    bases = O.baseline_prepare_bases(srs)
+    for scalars in (rand_fr(n, 901), O.fr_from_u64(np.arange(n, dtype=np.uint64) * 7 % 5)):
+        assert O.g1_eq(O.baseline_msm(bases, scalars), O.g1_msm_pippenger(srs, scalars))
+    assert O.g1_eq(O.baseline_msm(bases[10:], rand_fr(50, 902)), O.g1_msm_pippenger(srs[10:60], rand_fr(50, 902)))
+    ell = 5
+    evals, point = rand_fr(1 << ell, 903), rand_fr(ell, 904)
+    want = O.hyperkzg_open(srs, evals, point, label=3)
+    O.baseline_use_parallel_msm(True)
+    try:
+        got = O.hyperkzg_open(bases, evals, point, label=3)
+    finally:
+        O.baseline_use_parallel_msm(False)
+    assert np.array_equal(got["v"], want["v"]) and np.array_equal(got["challenges"], want["challenges"])
+    for a, b in zip(list(got["com"]) + list(got["w"]), list(want["com"]) + list(want["w"])):
+        assert O.g1_eq(a, b)
+    T, K = 32, 16
+    rng = np.random.default_rng(905)
+    idx = rng.integers(0, K, size=(3, T), dtype=np.uint8)
+    idx[1, rng.random(T) < 0.5] = 0xFF
+    one = O.to_mont([1])[0]
+    s, dense, ds = rand_fr(3, 906), [rand_fr(T, 907)], rand_fr(1, 908)
+    want_j = np.zeros((K * T, 4), dtype=np.uint64)
+    for p in range(3):
+        emb = np.zeros((K * T, 4), dtype=np.uint64)
+        hot = idx[p] != 0xFF
+        emb[idx[p][hot].astype(np.int64) * T + np.nonzero(hot)[0]] = one
+        assert O.g1_eq(O.baseline_grid_onehot_sum(bases, idx[p]), O.kzg_commit(emb, srs[: K * T]))
+        want_j = O.fr_add(want_j, O.fr_mul(emb, np.repeat(s[p].reshape(1, 4), K * T, axis=0)))
+    want_j[:T] = O.fr_add(want_j[:T], O.fr_mul(dense[0], np.repeat(ds[0].reshape(1, 4), T, axis=0)))
+    assert np.array_equal(O.baseline_grid_joint(idx, K, s, dense, ds), want_j)

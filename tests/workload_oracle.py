@@ -33,16 +33,19 @@ def resolver(gammas):
 
 
 class OracleWorkload:
-    def __init__(self, n_vars, seed=2026, **kw):
+    def __init__(self, n_vars, seed=2026, only_stages=None, **kw):
+        """only_stages: materialise (and prove) just these stages -- the T = 2^22 parity test checks a stage, not the catalogue"""
         self.n_vars = n_vars
         self.tables_spec, self.members_spec, gammas = W.build(n_vars, seed, **kw)
         self.res, self.one, self.mul = resolver(gammas)
-        self.tables = {name: make_table(spec) for name, spec in self.tables_spec.items()}
+        wanted = {t for ms in self.members_spec if only_stages is None or ms.stage in only_stages for t in ms.tables}
+        self.tables = {name: make_table(spec) for name, spec in self.tables_spec.items() if name in wanted}
         rng = np.random.default_rng(seed + 1)
         self.batch_coeffs = [W.rand_fr(1, rng)[0] for _ in self.members_spec]
         self.stages = {}
         for i, ms in enumerate(self.members_spec):
-            self.stages.setdefault(ms.stage, []).append(i)
+            if only_stages is None or ms.stage in only_stages:
+                self.stages.setdefault(ms.stage, []).append(i)
 
     def member(self, i):
         ms = self.members_spec[i]
