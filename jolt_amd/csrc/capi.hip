@@ -59,6 +59,8 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (prop.sharedMemPerBlock > 0) ctx->max_lds_per_block = prop.sharedMemPerBlock;
     if (const char* ml = std::getenv("JOLT_MSM_LDS_SORT")) ctx->msm_lds_sort = std::atoi(ml) != 0;
     if (const char* pe = std::getenv("JOLT_POOL")) ctx->pool_enabled = std::atoi(pe) != 0;
+    if (const char* la = std::getenv("JOLT_MSM_LANES")) ctx->msm_lanes = std::max(1, std::min(4, std::atoi(la)));
+    if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {

@@ -65,6 +65,9 @@ struct jolt_ctx {
     size_t tail_pairs = 16384;    // rounds with at most this many pairs use the tail kernel (JOLT_TAIL_PAIRS; 4096..65536 measure within 2 %)
     bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
     bool msm_lds_attr_set = false;
+    bool msm_fx_attr_set = false;
+    int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
+    bool msm_fixed = true;        // JOLT_MSM_FIXED=0: ignore window-precomputed bases (A/B of msm_fixed.hip)
     bool msm_lds_sort = true;     // MSM counting sort with per-workgroup LDS histograms (JOLT_MSM_LDS_SORT=0: global atomics per key)
     bool round_trace = false;     // JOLT_ROUND_TRACE=1: print where the host time of a batch round goes
     bool serial_streams = false;  // JOLT_SERIAL_STREAMS=1: a round's kernels on one stream (standalone kernel durations under rocprof)

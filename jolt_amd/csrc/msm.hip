@@ -54,6 +54,7 @@ struct MsmJob {
     int lane = 0, c = 0, W = 0;
     uint32_t nb = 0;
 };
+int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job);  // msm_fixed.hip
 namespace {
 struct MsmPlan {
     int c, W, L;  // window bits, windows, lanes per light bucket
@@ -163,6 +164,7 @@ extern "C" int32_t jolt_srs_free(jolt_ctx* ctx, jolt_srs* srs) {
     jolt_ctx* c = ctx ? ctx : srs->ctx;
     if (c) (void)hipStreamSynchronize(c->stream);
     if (srs->pts) (void)hipFree(srs->pts);
+    if (srs->pre) (void)hipFree(srs->pre);
     delete srs;
     return JOLT_OK;
 }
@@ -179,6 +181,10 @@ int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* 
     if (n > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
     if (n == 0) return JOLT_OK;
     if (n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
+    if (srs->pre && ctx->msm_fixed && n >= srs->pre_min_n) {  // window-precomputed bases: one bucket set for all windows (msm_fixed.hip)
+        int32_t fs = jolt_internal_msm_fixed_enqueue(ctx, srs, d_scalars, n, lane, job);
+        if (fs != JOLT_ERR_UNSUPPORTED) return fs;  // skewed scalars fall through to the per-window method and its heavy-bucket kernels
+    }
     MsmPlan p = plan_for(n);
     job->c = p.c;
     job->W = p.W;
@@ -293,9 +299,10 @@ int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* con
     for (int k = 0; k < 3; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     MsmJob jobs[4];
     int32_t status = JOLT_OK;
-    for (size_t i = 0; i < count + 4; ++i) {
-        int lane = (int)(i % 4);
-        if (i >= 4 && i - 4 < count && status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &jobs[lane], &out[i - 4]);
+    const size_t L = (size_t)ctx->msm_lanes;
+    for (size_t i = 0; i < count + L; ++i) {
+        int lane = (int)(i % L);
+        if (i >= L && i - L < count && status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &jobs[lane], &out[i - L]);
         if (i < count && status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, srs, d_scalars[i], n[i], lane, &jobs[lane]);
     }
     if (status != JOLT_OK)

@@ -1,0 +1,328 @@
+// jolt_amd/csrc/msm_fixed.hip -- fixed-base G1 MSM over window-precomputed bases (the HyperKZG SRS never changes between proofs).
+//
+// JoltGroup::msm (crates/jolt-crypto/src/ec/group.rs:63-70) as called by kzg_commit / kzg_open_batch
+// (crates/jolt-hyperkzg/src/kzg.rs:15-27,108-116) always multiplies prefixes of ONE long-lived base vector (g1_powers).  With
+// pre[w][i] = 2^(c*w) * P_i resident (jolt_srs_precompute_windows), digit w of scalar i addresses base pre[w][i] and ALL windows
+// share one bucket set:
+//     sum_i s_i P_i = sum_b b * ( sum_{(i,w): |digit_w(s_i)| = b} sign * pre[w][i] )
+// The bucket additions are the same W*n as in the per-window method, but there is ONE bucket reduction of 2^(c-1) buckets instead
+// of W of them, so c can grow to 24 bits (W = 11 windows instead of 16 at c = 16: 31 % fewer point additions for 254-bit scalars)
+// and the host-side Horner over the windows disappears.  Cost: W copies of the bases in HBM (11 x 4 GiB for 2^26 points).
+//
+// Pipeline (integer VALU work, no MFMA):
+//   1. digits   : k_msm_digits (shared with msm.hip) -> keys[w*n + i] = |digit| | sign << 31
+//   2. partition: counting sort of the W*n keys by the high bits of |digit| (<= 16385 bins: per-workgroup LDS histograms, one global
+//                 atomic per non-empty bin and slice) into segments of 512 buckets; entries carry (low 9 bits, base index | sign)
+//   3. segments : ONE workgroup per segment sorts it by the low bits in LDS (histogram, scan, scatter) and emits the bucket table
+//   4. buckets  : k_msm_buckets_light / _heavy / _heavy_combine of the per-window method with one "window" of 2^(c-1) buckets and
+//                 the window tables as bases (a bucket kernel fused into step 3 measured 7x slower per addition and was dropped)
+//   5. reduce   : sum_b b * B_b by running sums over bucket ranges (k_msm_window_reduce / k_msm_window_combine, shared)
+// Skew needs no special casing: over-full buckets (the partial top window of 254-bit scalars, the carry window of 64-bit witness
+// scalars) go down the segmented heavy-bucket path exactly as in msm.hip.
+#include <algorithm>
+
+#include "ctx.hpp"
+#include "msm_kernels.cuh"
+#include "srs.hpp"
+
+using namespace jolt;
+using namespace jolt::msmk;
+
+struct MsmJob {
+    size_t n = 0;
+    int lane = 0, c = 0, W = 0;
+    uint32_t nb = 0;
+};
+
+namespace {
+
+constexpr int kLoBits = 9;              // buckets per segment = 512
+constexpr int kSegBuckets = 1 << kLoBits;
+
+// next[i] = 2^c * prev[i]
+__global__ __launch_bounds__(kBlock) void k_fx_next_window(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next, size_t n, int c) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    G1Jac p = g1_from_affine(ld_aff(prev + i));
+    for (int k = 0; k < c; ++k) p = g1_double(p);
+    next[i] = g1_to_affine(p);
+}
+
+// ---- 2. partition by the high bits of |digit| ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSortBlock) void k_fx_hist(const uint32_t* __restrict__ keys, size_t total, uint32_t nb1, uint32_t* __restrict__ hist1) {
+    extern __shared__ uint32_t fx_sh[];
+    for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
+    __syncthreads();
+    const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+    for (size_t base = lo; base < hi; base += kSortBlock) {  // whole wavefronts walk the loop together (ballots inside)
+        size_t k = base + threadIdx.x;
+        uint32_t mag = k < hi ? keys[k] & 0x7FFFFFFFu : 0u;
+        WaveAgg ag = wave_aggregate(mag >> kLoBits, mag != 0);
+        if (ag.do_atomic) atomicAdd(&fx_sh[mag >> kLoBits], ag.count);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) {
+        uint32_t cnt = fx_sh[b];
+        if (cnt) atomicAdd(&hist1[b], cnt);
+    }
+}
+// exclusive scan of the nb1 segment counts (one workgroup); info[0] = largest segment, info[1] = non-zero digits in total
+__global__ __launch_bounds__(kSortBlock) void k_fx_scan(const uint32_t* __restrict__ hist1, uint32_t nb1, uint32_t* __restrict__ offs1, uint32_t* __restrict__ cursor1,
+                                                       uint32_t* __restrict__ info) {
+    __shared__ uint32_t sm[kSortBlock];
+    __shared__ uint32_t smax[kSortBlock];
+    const uint32_t per = (nb1 + kSortBlock - 1) / kSortBlock;
+    const uint32_t lo = min(threadIdx.x * per, nb1), hi = min(lo + per, nb1);
+    uint32_t local = 0, mx = 0;
+    for (uint32_t k = lo; k < hi; ++k) { local += hist1[k]; mx = max(mx, hist1[k]); }
+    sm[threadIdx.x] = local;
+    smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 1; off < kSortBlock; off <<= 1) {
+        uint32_t v = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        uint32_t m = (int)threadIdx.x >= off ? smax[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += v;
+        smax[threadIdx.x] = max(smax[threadIdx.x], m);
+        __syncthreads();
+    }
+    uint32_t run = sm[threadIdx.x] - local;
+    for (uint32_t k = lo; k < hi; ++k) {
+        offs1[k] = run;
+        cursor1[k] = run;
+        run += hist1[k];
+    }
+    if (threadIdx.x == kSortBlock - 1) { info[0] = smax[threadIdx.x]; info[1] = sm[threadIdx.x]; }
+}
+// entries[pos] = (low bits of |digit|) << 32 | (w * stride + i) | sign << 31, grouped by segment
+__global__ __launch_bounds__(kSortBlock) void k_fx_scatter(const uint32_t* __restrict__ keys, size_t total, size_t n, size_t stride, uint32_t nb1,
+                                                          uint32_t* __restrict__ cursor1, uint64_t* __restrict__ entries) {
+    extern __shared__ uint32_t fx_sh[];
+    for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
+    __syncthreads();
+    const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+    for (size_t base = lo; base < hi; base += kSortBlock) {
+        size_t k = base + threadIdx.x;
+        uint32_t mag = k < hi ? keys[k] & 0x7FFFFFFFu : 0u;
+        WaveAgg ag = wave_aggregate(mag >> kLoBits, mag != 0);
+        if (ag.do_atomic) atomicAdd(&fx_sh[mag >> kLoBits], ag.count);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) {  // reserve this slice's range of every non-empty segment
+        uint32_t cnt = fx_sh[b];
+        fx_sh[b] = cnt ? atomicAdd(&cursor1[b], cnt) : 0u;
+    }
+    __syncthreads();
+    for (size_t base = lo; base < hi; base += kSortBlock) {
+        size_t k = base + threadIdx.x;
+        uint32_t key = k < hi ? keys[k] : 0u;
+        uint32_t mag = key & 0x7FFFFFFFu;
+        WaveAgg ag = wave_aggregate(mag >> kLoBits, mag != 0);
+        uint32_t first = 0;
+        if (ag.do_atomic) first = atomicAdd(&fx_sh[mag >> kLoBits], ag.count);
+        uint32_t pos = (uint32_t)__shfl((int)first, ag.src, 64) + ag.rank;
+        if (mag) {
+            const size_t w = k / n, i = k - w * n;
+            const uint32_t value = (uint32_t)(w * stride + i) | (key & 0x80000000u);
+            entries[pos] = ((uint64_t)(mag & (kSegBuckets - 1)) << 32) | value;
+        }
+    }
+}
+
+// ---- 3. one workgroup per segment: counting sort by the low bits in LDS; emits the bucket table of the shared bucket kernels ----
+// hist[b] / offsets[b] for bucket b = seg * 512 + low bits (the layout k_msm_buckets_light / _heavy read with one "window"), the base
+// indices of every bucket contiguous in `sorted`, and one heavy-list entry per kHeavySeg points of an over-full bucket (what
+// k_msm_scan emits for the per-window method).
+__global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ offs1, const uint64_t* __restrict__ entries,
+                                                           uint32_t* __restrict__ sorted, uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets,
+                                                           uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
+                                                           uint32_t heavy_cap) {
+    __shared__ uint32_t cnt[kSegBuckets], cur[kSegBuckets];
+    __shared__ uint32_t scan_sm[kBlock];
+    const uint32_t seg = blockIdx.x;
+    const uint32_t total = hist1[seg];
+    const uint32_t base = offs1[seg];
+    for (uint32_t b = threadIdx.x; b < kSegBuckets; b += kBlock) cnt[b] = 0;
+    __syncthreads();
+    // plain LDS atomics, four entries in flight per thread: with 512 bins same-address lanes are rare for uniform digits, and where
+    // they are not (the carry bucket of small scalars) the LDS serialises 64 lanes in about the time the ballot peeling would take
+    for (uint32_t k0 = 0; k0 < total; k0 += 4 * kBlock) {
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + u * kBlock + threadIdx.x;
+            e[u] = k < total ? entries[base + k] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32)], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of the 512 counts: two per thread
+        const uint32_t a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
+        scan_sm[threadIdx.x] = a + b;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) {
+            uint32_t v = (int)threadIdx.x >= off ? scan_sm[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan_sm[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = scan_sm[threadIdx.x] - (a + b);
+        cur[2 * threadIdx.x] = excl;
+        cur[2 * threadIdx.x + 1] = excl + a;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t slot = seg * kSegBuckets + 2 * threadIdx.x + h, c = h ? b : a, st = base + (h ? excl + a : excl);
+            hist[slot] = c;
+            offsets[slot] = st;
+            if (c > heavy_threshold) {
+                const uint32_t nseg = (c + kHeavySeg - 1) / kHeavySeg;
+                const uint32_t first = atomicAdd(heavy_count, nseg);
+                for (uint32_t sgi = 0; sgi < nseg && first + sgi < heavy_cap; ++sgi) {
+                    heavy_list[2 * (first + sgi)] = slot;
+                    heavy_list[2 * (first + sgi) + 1] = sgi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = sorted + base;
+    for (uint32_t k0 = 0; k0 < total; k0 += 4 * kBlock) {
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + u * kBlock + threadIdx.x;
+            e[u] = k < total ? entries[base + k] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e[u] != ~0ull) out[atomicAdd(&cur[(uint32_t)(e[u] >> 32)], 1u)] = (uint32_t)e[u];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// precomputation
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms) {
+    if (!ctx || !srs) return JOLT_ERR_INVALID_ARG;
+    if (srs->pre) return JOLT_OK;
+    if (srs->n == 0) return JOLT_ERR_INVALID_ARG;
+    int lg = 0;
+    while (((size_t)2 << lg) <= srs->n) lg++;
+    int c = window_bits ? (int)window_bits : std::max(kLoBits + 1, std::min(24, lg - 2));
+    if (c <= kLoBits || c > 24) return JOLT_ERR_UNSUPPORTED;
+    const int W = (255 + c - 1) / c;
+    if ((size_t)W * srs->n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;  // base index + sign share 32 bits
+    G1Affine* pre = nullptr;
+    hipError_t e = hipMalloc((void**)&pre, (size_t)W * srs->n * sizeof(G1Affine));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->last_error = std::string("precompute windows: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    e = hipMemcpyAsync(pre, srs->pts, srs->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream);
+    const unsigned grid = (unsigned)((srs->n + kBlock - 1) / kBlock);
+    for (int w = 1; w < W && e == hipSuccess; ++w) {
+        hipLaunchKernelGGL(k_fx_next_window, dim3(grid), dim3(kBlock), 0, ctx->stream, (const G1Affine*)(pre + (size_t)(w - 1) * srs->n), pre + (size_t)w * srs->n, srs->n, c);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(pre); ctx->last_error = std::string("precompute windows: ") + hipGetErrorString(e); return JOLT_ERR_HIP; }
+    srs->pre = pre;
+    srs->pre_c = c;
+    srs->pre_W = W;
+    srs->pre_min_n = min_terms ? min_terms : std::max<size_t>((size_t)1 << (c - 1), 1024);
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one MSM on lane `lane`; JOLT_ERR_UNSUPPORTED (W*n >= 2^32, or the runtime refuses the LDS the partition needs) sends the caller back
+// to the per-window method
+// ------------------------------------------------------------------------------------------------------------------
+constexpr size_t kMsmHostEntries = 128;
+
+int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job) {
+    const int c = srs->pre_c, W = srs->pre_W;
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t nb1 = (B >> kLoBits) + 1;               // the segment of |digit| = B included
+    const size_t total = (size_t)W * n;
+    if (total >= ((size_t)1 << 32)) return JOLT_ERR_UNSUPPORTED;
+    const size_t n_buckets = (size_t)nb1 * kSegBuckets;    // >= B + 1
+    // reduction: sum_b b * B_b over buckets 1..B with up to 65536 threads, G buckets each
+    const uint32_t threads = (uint32_t)std::min<size_t>(B, 65536);
+    const uint32_t nb = (threads + kBlock - 1) / kBlock;
+    const uint32_t G = (B + nb * kBlock - 1) / (nb * kBlock);
+    // a bucket holding more than max(kLaneCap, 4x the average) points is summed per 1024-point segment by whole wavefronts: the
+    // partial top window of 254-bit scalars (14 bits at c = 24) piles ~n / 2^14 extra points on each of the lowest 2^14 buckets,
+    // and small (witness) scalars fill the carry window's bucket 1 -- both take that path, as in the per-window method
+    const size_t avg = (total + B - 1) / B;
+    const uint32_t heavy_threshold = (uint32_t)std::min<size_t>(std::max<size_t>(kLaneCap, 4 * avg), 0x7FFFFFFFu);
+    const uint32_t heavy_cap = (uint32_t)(total / kHeavySeg + total / heavy_threshold + 16);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_keys = take(total * 4), o_entries = take(total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
+                 o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(sizeof(G1Jac)),
+                 o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
+                 o_seg = take((size_t)heavy_cap * sizeof(G1Jac));
+    hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
+    if (off > ctx->msm_ws_cap[lane]) {
+        if (ctx->msm_ws[lane]) {
+            JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
+            JOLT_HIP_TRY(ctx, hipFree(ctx->msm_ws[lane]));
+            ctx->msm_ws[lane] = nullptr;
+            ctx->msm_ws_cap[lane] = 0;
+        }
+        JOLT_HIP_TRY(ctx, hipMalloc(&ctx->msm_ws[lane], off));
+        ctx->msm_ws_cap[lane] = off;
+    }
+    if (!ctx->msm_host[lane]) JOLT_HIP_TRY(ctx, hipHostMalloc(&ctx->msm_host[lane], kMsmHostEntries * sizeof(G1Jac), hipHostMallocDefault));
+    char* ws = (char*)ctx->msm_ws[lane];
+    uint32_t* keys = (uint32_t*)(ws + o_keys);  // after the partition the same buffer holds the per-segment sorted base indices
+    uint64_t* entries = (uint64_t*)(ws + o_entries);
+    uint32_t *hist1 = (uint32_t*)(ws + o_hist), *offs1 = (uint32_t*)(ws + o_offs), *cur1 = (uint32_t*)(ws + o_cur), *info = (uint32_t*)(ws + o_info);
+    G1Jac *buckets = (G1Jac*)(ws + o_buckets), *part = (G1Jac*)(ws + o_part), *wsum = (G1Jac*)(ws + o_wsum), *seg = (G1Jac*)(ws + o_seg);
+    uint32_t *hist = (uint32_t*)(ws + o_bhist), *offs = (uint32_t*)(ws + o_boffs), *heavy = (uint32_t*)(ws + o_heavy), *hcnt = (uint32_t*)(ws + o_hcnt);
+    const size_t lds_bytes = (size_t)nb1 * sizeof(uint32_t);
+    if (lds_bytes > ctx->max_lds_per_block) return JOLT_ERR_UNSUPPORTED;
+    if (!ctx->msm_fx_attr_set) {
+        hipError_t a1 = hipFuncSetAttribute((const void*)k_fx_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t a2 = hipFuncSetAttribute((const void*)k_fx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        if (a1 != hipSuccess || a2 != hipSuccess) {
+            (void)hipGetLastError();
+            if (lds_bytes > 64 * 1024) return JOLT_ERR_UNSUPPORTED;
+        }
+        ctx->msm_fx_attr_set = true;
+    }
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, st));
+    const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
+    const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
+    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, c, W, keys, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_fx_hist, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
+    hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, st, (const uint32_t*)hist1, nb1, offs1, cur1, info);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), st));  // z = 0: identity
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, st));
+    hipLaunchKernelGGL(k_fx_scatter, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->n, nb1, cur1, entries);
+    hipLaunchKernelGGL(k_fx_segment_sort, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
+                       heavy_threshold, heavy, hcnt, heavy_cap);
+    // bucket sums: the kernels of the per-window method with ONE window of B buckets (bases = the window tables)
+    const unsigned gh = std::min<uint32_t>((heavy_cap + 3) / 4, 4096);
+    hipLaunchKernelGGL(k_msm_buckets_light<true>, dim3((unsigned)(((size_t)B + kBlock - 1) / kBlock), 1), dim3(kBlock), 0, st, (const uint32_t*)hist, (const uint32_t*)offs,
+                       (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, 1, heavy_threshold, buckets, (size_t)1);
+    hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
+                       (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg);
+    hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const G1Jac*)seg, buckets);
+    hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, G, part);
+    hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)part, nb, wsum);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, sizeof(G1Jac), hipMemcpyDeviceToHost, st));
+    job->n = n;
+    job->lane = lane;
+    job->c = 0;  // a single "window": the collect step's Horner loop adds it once
+    job->W = 1;
+    job->nb = nb;
+    return JOLT_OK;
+}

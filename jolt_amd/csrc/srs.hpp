@@ -7,4 +7,10 @@ struct jolt_srs {
     jolt_ctx* ctx = nullptr;
     jolt::G1Affine* pts = nullptr;
     size_t n = 0;
+    // Fixed-base tables (jolt_srs_precompute_windows, msm_fixed.hip): pre[w * n + i] = 2^(pre_c * w) * pts[i] for w < pre_W, so that
+    // every c-bit window of a scalar addresses the SAME bucket set (one bucket reduction per MSM instead of one per window, which
+    // is what makes 24-bit windows affordable).  pre_W * n * 64 bytes: the table is sized for 288 GB of HBM, not for a PCIe card.
+    jolt::G1Affine* pre = nullptr;
+    int pre_c = 0, pre_W = 0;
+    size_t pre_min_n = 0;  // MSMs shorter than this keep the per-window bucket method
 };

@@ -577,6 +577,12 @@ def _hyperkzg_open(self, srs, evals, point, label=0):
     return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
 
 
+def _srs_precompute_windows(self, srs, window_bits=0, min_terms=0):
+    """Fixed-base tables 2^(c*w) * srs[i] (one bucket set for all windows of an MSM): ceil(255/c) copies of the bases in HBM."""
+    _ck(lib().jolt_srs_precompute_windows(self.h, srs.h, C.c_uint32(window_bits), C.c_size_t(min_terms)), "jolt_srs_precompute_windows", self)
+
+
+Context.srs_precompute_windows = _srs_precompute_windows
 Context.srs_upload = _srs_upload
 Context.srs_setup_from_secret = _srs_setup_from_secret
 Context.msm = _msm

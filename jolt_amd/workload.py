@@ -233,7 +233,7 @@ class DeviceWorkload:
     commitment grid of crates/jolt-kernels/src/commitment.rs:86-130 -- the two dense increment columns at address 0, the one-hot
     RA columns as 0/1 coefficients -- committed with HyperKZG and opened jointly at one point)."""
 
-    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, **kw):
+    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, **kw):
         from . import ffi
         self.ctx, self.n_vars, self.ffi, self.pcs = ctx, n_vars, ffi, pcs
         self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
@@ -283,6 +283,8 @@ class DeviceWorkload:
                 self.srs = ctx.srs_setup_from_secret(self.beta, 1 << self.grid_vars, G1_GENERATOR)
                 self.own_srs = True
                 ctx.synchronize()
+                if fixed_base and self.grid_vars >= 12:  # setup-time (like the SRS itself): window-precomputed bases for the big MSMs
+                    ctx.srs_precompute_windows(self.srs)
             prng = np.random.default_rng(seed + 3)
             n_oh = sum(self.sources[i].n_polys for i in sorted(self.sources))
             self.rlc_onehot = rand_fr(n_oh, prng)

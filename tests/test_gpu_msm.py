@@ -195,3 +195,48 @@ def test_msm_sort_paths_agree(monkeypatch, lds_sort):
         want = O.g1_scalar_mul(O.g1_generator(), O.kzg_eval_univariate(scalars, beta))
         assert same_point(got, want)
     c.close()
+
+
+def test_fixed_base_msm_matches_oracle_and_per_window_path(ctx):
+    """jolt_srs_precompute_windows: with 2^(c*w) * P_i resident all windows of an MSM share one bucket set (msm_fixed.hip).  Same
+    points as the oracle's Pippenger for uniform scalars of every length class, the field's corner values, repeated bases and an
+    identity among the bases; skewed (witness-like) scalars are routed back to the per-window method and agree as well."""
+    n_srs = 2200
+    beta = rand_fr(1, 600)[0]
+    host = O.srs_setup_from_secret(beta, n_srs)
+    host[7] = host[3]            # repeated base
+    host[11] = O.g1_identity()   # identity among the bases
+    host[12] = O.g1_neg(host[5])
+    dev = ctx.srs_upload(host)
+    ctx.srs_precompute_windows(dev, 10, 1)  # c = 10: 26 windows, 2 segments of 512 buckets, every MSM length takes the new path
+    for n in (1, 2, 63, 64, 65, 1000, 2048, 2200):
+        scalars = rand_fr(n, 610 + n)
+        assert same_point(ctx.msm(dev, scalars), O.g1_msm_pippenger(host[:n], scalars)), n
+    corner = O.to_mont([0, 1, R - 1, 2, R - 2, (R - 1) // 2, 1 << 253, (1 << 200) - 1, 511, 512, 513, 1 << 9, (1 << 10) - 1, 1 << 10])
+    assert same_point(ctx.msm(dev, corner), O.g1_msm_pippenger(host[: len(corner)], corner))
+    same = np.repeat(rand_fr(1, 620), 2048, axis=0)  # every digit equal: 26 buckets of 2048 points (the workgroup-wide bucket sum)
+    assert same_point(ctx.msm(dev, same), O.g1_msm_pippenger(host[:2048], same))
+    five = O.to_mont([sum(5 << (10 * w) for w in range(25))] * 2048)  # every window's digit is 5: ONE bucket of 25 * 2048 points
+    assert same_point(ctx.msm(dev, five), O.g1_msm_pippenger(host[:2048], five))
+    small = O.fr_from_u64(np.random.default_rng(621).integers(0, 2, size=2048, dtype=np.uint64))  # 0/1 flags: one huge bucket -> fallback
+    assert same_point(ctx.msm(dev, small), O.g1_msm_pippenger(host[:2048], small))
+    zeros = np.zeros((500, 4), dtype=np.uint64)
+    assert O.g1_is_identity(ctx.msm(dev, zeros))
+
+
+@pytest.mark.parametrize("window_bits", [0, 13])
+def test_fixed_base_msm_at_2_20_is_the_kzg_commitment(ctx, window_bits):
+    """2^20 terms over window-precomputed bases (auto: c = 18, 15 windows; c = 13: 20 windows): commit(p) == p(beta) G, for uniform
+    scalars (new path) and 64-bit scalars (skew fallback), and a prefix MSM of 2^19 + 5 terms."""
+    n = 1 << 20
+    beta = rand_fr(1, 630)[0]
+    g = O.g1_generator()
+    srs = ctx.srs_setup_from_secret(beta, n, g)
+    ctx.srs_precompute_windows(srs, window_bits, 1 << 12)
+    full = rand_fr(n, 631)
+    assert same_point(ctx.msm(srs, ctx.upload(full)), O.g1_scalar_mul(g, O.kzg_eval_univariate(full, beta)))
+    m = (1 << 19) + 5
+    assert same_point(ctx.msm(srs, ctx.upload(full[:m])), O.g1_scalar_mul(g, O.kzg_eval_univariate(full[:m], beta)))
+    u64 = O.fr_from_u64(np.random.default_rng(632).integers(0, 2**64, size=n, dtype=np.uint64))
+    assert same_point(ctx.msm(srs, ctx.upload(u64)), O.g1_scalar_mul(g, O.kzg_eval_univariate(u64, beta)))
+    srs.free()

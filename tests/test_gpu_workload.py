@@ -2,9 +2,12 @@
 LC-form device members with skipped s(1) must reproduce, bit for bit, the transcript of the oracle's naive flat-Expr
 members -- the same claim the reference makes for its optimized tier vs its reference tier
 (crates/jolt-kernels/src/optimized/parity.rs:79-118, tests/dory_byte_diff.rs)."""
+import os
+
 import numpy as np
 import pytest
 
+import oracle_lib as O
 from jolt_amd import ffi
 from jolt_amd.workload import DeviceWorkload
 from util import rand_challenge
@@ -36,6 +39,7 @@ def test_catalogue_matches_oracle_at_benchmark_scale():
     claim of the device path -- lazy one-hot members, eq-weighted members, linear-leaf fusions, skipped s(1), the grid-by-size rule and
     two-level tickets of the big rounds, tail kernels of the small ones -- equals the oracle's naive flat-Expr members over the dense
     tables (its sweeps run under OpenMP; crates/jolt-kernels/src/optimized/parity.rs:79-118 is the reference's form of this test)."""
+    O.baseline_set_threads(min(48, os.cpu_count() or 1))  # the oracle's OpenMP sweeps: more threads than this only add merge overhead
     ctx = ffi.Context(0)
     dev = DeviceWorkload(ctx, 20)
     orc = OracleWorkload(20)
@@ -55,6 +59,7 @@ def test_catalogue_matches_oracle_at_benchmark_scale():
 def test_stages_match_oracle_at_configs2_scale():
     """T = 2^22 (BASELINE configs[2] scale): stages 4 and 5 (ram_val_check; registers_val_evaluation + ram_ra_claim_reduction with its
     fused eq leaves) against the oracle, transcript for transcript."""
+    O.baseline_set_threads(min(48, os.cpu_count() or 1))
     ctx = ffi.Context(0)
     dev = DeviceWorkload(ctx, 22)
     orc = OracleWorkload(22, only_stages={4, 5})
