@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 def _headers():
     out = [os.path.join(HERE, "..", "include", "jolt_hip.h")]
     for f in os.listdir(CSRC):
-        if f.endswith((".cuh", ".hpp", ".h")):
+        if f.endswith((".hip.h", ".hpp", ".h")):
             out.append(os.path.join(CSRC, f))
     return out
 

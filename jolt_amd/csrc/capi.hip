@@ -5,9 +5,9 @@
 
 #include "host_mirror.hpp"
 #include "member.hpp"
-#include "poly_kernels.cuh"
-#include "engine_kernel.cuh"
-#include "onehot_kernels.cuh"
+#include "poly_kernels.hip.h"
+#include "engine_kernel.hip.h"
+#include "onehot_kernels.hip.h"
 
 using namespace jolt;
 
@@ -1581,7 +1581,7 @@ extern "C" int32_t jolt_member_prove_round(jolt_member* m, const jolt_fr_t* bind
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Persistent round engine (engine_kernel.cuh): host side
+// Persistent round engine (engine_kernel.hip.h): host side
 // ------------------------------------------------------------------------------------------------------------------
 struct jolt_engine {
     bool active = false;

@@ -14,7 +14,7 @@
 
 #include "desc.hpp"
 #include "member.hpp"
-#include "poly_kernels.cuh"
+#include "poly_kernels.hip.h"
 
 using namespace jolt;
 

@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "../../include/jolt_hip.h"
-#include "field.cuh"
+#include "field.hip.h"
 
 using jolt::Fq;
 using jolt::Fr;
@@ -54,7 +54,7 @@ struct jolt_ctx {
     size_t msm_ws_cap[4] = {0, 0, 0, 0};
     void* msm_host[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    // persistent round engine for the late rounds of a batch (engine_kernel.cuh); owned by capi.hip
+    // persistent round engine for the late rounds of a batch (engine_kernel.hip.h); owned by capi.hip
     struct jolt_engine* engine = nullptr;
     // uniform split-eq members switch from (product, pair) work items to one item per pair at this many pairs
     // (JOLT_UNIFORM_ROWS_PAIRS overrides; tests lower it to run the row-major kernels at small sizes)

@@ -1,6 +1,6 @@
 // jolt_amd/csrc/desc.hpp -- plain descriptor structs shared by the kernels (device) and the member objects (host).
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace jolt {
 

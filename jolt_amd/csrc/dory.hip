@@ -15,7 +15,7 @@
 #include <algorithm>
 
 #include "ctx.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hip.h"
 #include "onehot.hpp"
 #include "srs.hpp"
 

@@ -1,4 +1,4 @@
-// jolt_amd/csrc/engine_kernel.cuh -- persistent "round engine" for the late, latency-bound sumcheck rounds.
+// jolt_amd/csrc/engine_kernel.hip.h -- persistent "round engine" for the late, latency-bound sumcheck rounds.
 //
 // Once every member of a batch is down to a few thousand pairs, a round's arithmetic takes a few microseconds while
 // the host pays ~10 HIP API calls (bind launches, stream fork, one launch per member class) for it: measured 50-115 us
@@ -17,7 +17,7 @@
 #pragma once
 #include <type_traits>
 
-#include "sumcheck_kernels.cuh"
+#include "sumcheck_kernels.hip.h"
 
 namespace jolt {
 

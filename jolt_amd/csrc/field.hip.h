@@ -1,4 +1,4 @@
-// jolt_amd/csrc/field.cuh -- BN254 Fr / Fq arithmetic for gfx950 (and for the host-side mirror code).
+// jolt_amd/csrc/field.hip.h -- BN254 Fr / Fq arithmetic for gfx950 (and for the host-side mirror code).
 //
 // Representation: 8 x u32 little-endian limbs holding a*R mod p, R = 2^256, always canonical (< p).  The bytes are
 // identical to the reference's `Fr` (4 x u64 Montgomery limbs, crates/jolt-field/src/bn254/mod.rs:33-43), so tables
@@ -11,7 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "bn254_constants.cuh"
+#include "bn254_constants.hip.h"
 
 #define JOLT_HD __host__ __device__ __forceinline__
 

@@ -1,4 +1,4 @@
-// jolt_amd/csrc/g1.cuh -- BN254 G1 group law for device and host (y^2 = x^3 + 3 over Fq, a = 0).
+// jolt_amd/csrc/g1.hip.h -- BN254 G1 group law for device and host (y^2 = x^3 + 3 over Fq, a = 0).
 //
 // Jacobian (X, Y, Z) with ark's conventions: identity <=> Z == 0; layout = ark_bn254::G1Projective, which the
 // reference wraps transparently (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24).  Affine points carry (0,0) for
@@ -6,7 +6,7 @@
 // so every formula handles its special cases explicitly; results are the same POINT as the reference's, the
 // projective representative is free (serialisation is compressed affine).
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace jolt {
 

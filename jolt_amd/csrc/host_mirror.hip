@@ -409,7 +409,7 @@ extern "C" int32_t jolt_host_fr_mul(const jolt_fr_t* a, const jolt_fr_t* b, jolt
     fr_to_abi(out, mul(fr_from_abi(a), fr_from_abi(b)));
     return JOLT_OK;
 }
-// The kernels' multiplication algorithm (field.cuh mul_limbs29: product scanning over nine 29-bit limbs), compiled for the host
+// The kernels' multiplication algorithm (field.hip.h mul_limbs29: product scanning over nine 29-bit limbs), compiled for the host
 // so that the CPU suite pins it against the oracle; field 0 = Fr, 1 = Fq.  Operands must be canonical.
 extern "C" int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
     if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
@@ -549,7 +549,7 @@ extern "C" int32_t jolt_host_prove_batch(jolt_ctx* ctx, jolt_member* const* memb
     return JOLT_OK;
 }
 
-// sum_k a[k]*b[k] through the deferred-reduction accumulator of field.cuh (wide_fmadd / wide_reduce), flushed every
+// sum_k a[k]*b[k] through the deferred-reduction accumulator of field.hip.h (wide_fmadd / wide_reduce), flushed every
 // kWideMaxProducts products: the host build of the same code the kernels use (algebra.rs:362-433 Accumulator contract).
 extern "C" int32_t jolt_host_fr_wide_dot(const jolt_fr_t* a, const jolt_fr_t* b, size_t n, jolt_fr_t* out) {
     if ((!a || !b) && n) return JOLT_ERR_INVALID_ARG;

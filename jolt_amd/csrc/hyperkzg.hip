@@ -10,9 +10,9 @@
 #include <algorithm>
 
 #include "ctx.hpp"
-#include "g1.cuh"
+#include "g1.hip.h"
 #include "host_mirror.hpp"
-#include "poly_kernels.cuh"
+#include "poly_kernels.hip.h"
 
 using namespace jolt;
 

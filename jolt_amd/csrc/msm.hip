@@ -11,12 +11,12 @@
 //   4. buckets  : L lanes per light bucket / one wavefront per heavy-bucket segment sum the points (mixed Jacobian+affine adds)
 //   5. windows  : sum_b b*B_b per window by running sums over bucket ranges, tree-reduced in LDS
 //   6. host     : Horner over the W window sums (c doublings each) -- W*c ~ 256 doublings on the host (64-bit limbs there)
-// Corner cases (P+P, P+(-P), infinity) are handled inside the group law (g1.cuh); the result is the same POINT as
+// Corner cases (P+P, P+(-P), infinity) are handled inside the group law (g1.hip.h); the result is the same POINT as
 // the reference's, in some Jacobian representation.
 #include <algorithm>
 
 #include "ctx.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hip.h"
 #include "srs.hpp"
 
 using namespace jolt;

@@ -22,7 +22,7 @@
 #include <algorithm>
 
 #include "ctx.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hip.h"
 #include "srs.hpp"
 
 using namespace jolt;

@@ -1,10 +1,10 @@
-// jolt_amd/csrc/msm_kernels.cuh -- the bucket-method kernels shared by the G1 MSM (msm.hip) and the Dory tier-1 row
+// jolt_amd/csrc/msm_kernels.hip.h -- the bucket-method kernels shared by the G1 MSM (msm.hip) and the Dory tier-1 row
 // commitments (dory.hip).  A "window" here is any independent bucket set: window w of one MSM, or (row, window) of a
 // batch of row MSMs over the same bases, or one chunk of a one-hot column.  Arrays are window-major:
 // keys/sorted[w*n + i] (n = points per window), hist/offsets/cursor/buckets[w*(B+1) + |digit|].
 #pragma once
-#include "g1.cuh"
-#include "poly_kernels.cuh"
+#include "g1.hip.h"
+#include "poly_kernels.hip.h"
 
 #ifndef JOLT_BUCKET_WAVES
 #define JOLT_BUCKET_WAVES 3  /* light bucket kernel: 168 VGPRs + 44 B of scratch at 3 waves per SIMD measured 2 % faster than 177 VGPRs at 2; 4 (128 VGPRs, 208 B scratch) is slower */

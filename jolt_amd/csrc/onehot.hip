@@ -5,7 +5,7 @@
 // The lazily bound member that consumes the source lives with the other members in capi.hip.
 #include <algorithm>
 
-#include "onehot_kernels.cuh"
+#include "onehot_kernels.hip.h"
 
 using namespace jolt;
 

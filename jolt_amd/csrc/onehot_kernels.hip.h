@@ -1,9 +1,9 @@
-// jolt_amd/csrc/onehot_kernels.cuh -- gathers over hot-index columns (LazyFoldedRa, crates/jolt-kernels/src/optimized/lazy_ra.rs).
+// jolt_amd/csrc/onehot_kernels.hip.h -- gathers over hot-index columns (LazyFoldedRa, crates/jolt-kernels/src/optimized/lazy_ra.rs).
 // All of them are lookups + additions: the eq weights of the bound bits are pre-scaled into the branch tables, exactly as the
 // reference does (lazy_ra.rs:17-24), so the per-cycle work has no multiplication and reads 1 byte instead of 32 per entry.
 #pragma once
 #include "onehot.hpp"
-#include "sumcheck_kernels.cuh"
+#include "sumcheck_kernels.hip.h"
 
 namespace jolt {
 

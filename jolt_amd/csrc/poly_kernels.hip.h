@@ -1,4 +1,4 @@
-// jolt_amd/csrc/poly_kernels.cuh -- dense-table kernels: bind, eq/LT/eq+1 expansion, small-scalar promotion, sums.
+// jolt_amd/csrc/poly_kernels.hip.h -- dense-table kernels: bind, eq/LT/eq+1 expansion, small-scalar promotion, sums.
 //
 // Layout in HBM: a table is a contiguous array of 32-byte Fr (the reference's Vec<Fr>), index = big-endian boolean
 // point.  All of these kernels are HBM-bandwidth bound (1 Fr multiply per 96 B for bind) -- no MFMA, no GEMM shape.

@@ -1,4 +1,4 @@
-// jolt_amd/csrc/sumcheck_kernels.cuh -- round-polynomial accumulation kernels.
+// jolt_amd/csrc/sumcheck_kernels.hip.h -- round-polynomial accumulation kernels.
 //
 // One kernel family serves every dense sumcheck member.  The summand is held in "sum of products of linear
 // combinations" form
@@ -12,7 +12,7 @@
 // Work is ALU-bound on v_mad_u64_u32 for all but the smallest summands; HBM traffic is 64 B per table per pair.
 #pragma once
 #include "desc.hpp"
-#include "poly_kernels.cuh"
+#include "poly_kernels.hip.h"
 
 namespace jolt {
 
@@ -342,7 +342,7 @@ __device__ __forceinline__ void uniform_rows_body(const Load& load, int V, const
     const size_t mask = ((size_t)1 << in_bits) - 1;
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
-        // (Summing the V products in deferred-reduction accumulators -- field.cuh WideAcc -- was measured SLOWER here: 1335 vs
+        // (Summing the V products in deferred-reduction accumulators -- field.hip.h WideAcc -- was measured SLOWER here: 1335 vs
         // 1062 us for round 0 at T = 2^20; the 17-limb carry ripples and 132 VGPRs cost more than the saved REDC rows.)
         Fr s[F];
 #pragma unroll

@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../field.cuh"
+#include "../field.hip.h"
 
 using namespace jolt;
 

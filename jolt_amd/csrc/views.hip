@@ -6,7 +6,7 @@
 #include <algorithm>
 
 #include "ctx.hpp"
-#include "poly_kernels.cuh"
+#include "poly_kernels.hip.h"
 
 using namespace jolt;
 

@@ -1,0 +1,123 @@
+//! Owning wrappers of the opaque handles: one [`HipContext`] per GPU per process, device-resident [`HipTable`]s.
+use std::ptr;
+use std::sync::Arc;
+
+use jolt_field::Fr;
+
+use crate::ffi;
+use crate::status::{check, HipError};
+
+/// `jolt_ctx`: device + stream + scratch.  One per GPU per process; ranks shard the hypercube (`DESIGN.md` section 6).
+pub struct HipContext {
+    pub(crate) raw: *mut ffi::jolt_ctx,
+}
+
+// SAFETY: the C library serialises nothing internally, so a context is used from one thread at a time (`prove_batch` is
+// single-threaded, `crates/jolt-sumcheck/src/prover.rs:124-146`); handing it to another thread between calls is sound.
+unsafe impl Send for HipContext {}
+
+impl HipContext {
+    /// `JOLT_ERR_NO_DEVICE` (no gfx950) is recoverable: the caller keeps the `optimized()` slots.
+    pub fn new(device_id: i32) -> Result<Arc<Self>, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: `raw` is a valid out-pointer; a null stream asks the library to create its own.
+        check(unsafe { ffi::jolt_ctx_create(device_id, ptr::null_mut(), &mut raw) }, ptr::null())?;
+        Ok(Arc::new(Self { raw }))
+    }
+
+    pub fn synchronize(&self) -> Result<(), HipError> {
+        // SAFETY: live context.
+        check(unsafe { ffi::jolt_ctx_synchronize(self.raw) }, self.raw)
+    }
+
+    /// Cached device blocks back to the runtime (between proofs of very different sizes).
+    pub fn trim(&self) -> Result<(), HipError> {
+        // SAFETY: live context.
+        check(unsafe { ffi::jolt_ctx_trim(self.raw) }, self.raw)
+    }
+
+    /// `witness.oracle_table(id)` materialised once and uploaded (`crates/jolt-witness/src/backend/mod.rs:50-53`).
+    pub fn upload(self: &Arc<Self>, evals: &[Fr]) -> Result<HipTable, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: `Fr` is `#[repr(transparent)]` over 4 x u64 Montgomery limbs (crates/jolt-field/src/bn254/mod.rs:33-43), the layout
+        // of `jolt_fr_t`; the slice outlives the (synchronous) upload.
+        check(unsafe { ffi::jolt_table_upload(self.raw, evals.as_ptr().cast(), evals.len(), &mut raw) }, self.raw)?;
+        Ok(HipTable { ctx: Arc::clone(self), raw })
+    }
+
+    /// Small-scalar witness column: 8 bytes per entry over PCIe, promoted on the device (`Polynomial::bind_to_field`'s `From<u64>`).
+    pub fn upload_u64(self: &Arc<Self>, values: &[u64]) -> Result<HipTable, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: plain integers; the slice outlives the synchronous upload.
+        check(unsafe { ffi::jolt_table_from_u64(self.raw, values.as_ptr(), values.len(), &mut raw) }, self.raw)?;
+        Ok(HipTable { ctx: Arc::clone(self), raw })
+    }
+
+    /// `EqPolynomial::evals(r, scale)` built on the device (`crates/jolt-poly/src/eq.rs:221-231`).
+    pub fn eq_evals(self: &Arc<Self>, r: &[Fr], scale: Option<Fr>) -> Result<HipTable, HipError> {
+        let mut raw = ptr::null_mut();
+        let scale_ptr = scale.as_ref().map_or(ptr::null(), |s| (s as *const Fr).cast());
+        // SAFETY: layouts as above; pointers valid for the call.
+        check(unsafe { ffi::jolt_eq_evals(self.raw, r.as_ptr().cast(), r.len(), scale_ptr, &mut raw) }, self.raw)?;
+        Ok(HipTable { ctx: Arc::clone(self), raw })
+    }
+
+    /// `LtPolynomial::evaluations` (`crates/jolt-poly/src/lt.rs:115-117,144-156`).
+    pub fn lt_evals(self: &Arc<Self>, r: &[Fr]) -> Result<HipTable, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: as above.
+        check(unsafe { ffi::jolt_lt_evals(self.raw, r.as_ptr().cast(), r.len(), &mut raw) }, self.raw)?;
+        Ok(HipTable { ctx: Arc::clone(self), raw })
+    }
+}
+
+impl Drop for HipContext {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_ctx_create; every handle holds an Arc to the context, so none outlives it.
+        let _ = unsafe { ffi::jolt_ctx_destroy(self.raw) };
+    }
+}
+
+/// `jolt_table`: a `Polynomial<Fr>` resident in HBM.
+pub struct HipTable {
+    pub(crate) ctx: Arc<HipContext>,
+    pub(crate) raw: *mut ffi::jolt_table,
+}
+
+// SAFETY: see HipContext.
+unsafe impl Send for HipTable {}
+
+impl HipTable {
+    pub fn len(&self) -> usize {
+        let mut n = 0usize;
+        // SAFETY: live handle, valid out-pointer.
+        let _ = unsafe { ffi::jolt_table_len(self.raw, &mut n) };
+        n
+    }
+
+    pub fn is_empty(&self) -> bool {
+        self.len() == 0
+    }
+
+    pub fn download(&self) -> Result<Vec<Fr>, HipError> {
+        let n = self.len();
+        let mut out = vec![Fr::default(); n];
+        // SAFETY: `out` has room for n elements of the same layout.
+        check(unsafe { ffi::jolt_table_download(self.ctx.raw, self.raw, 0, n, out.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+
+    /// Hand the handle to a member that takes ownership (`jolt_member_create_expr`): the table is then freed with the member.
+    pub(crate) fn into_raw(self) -> *mut ffi::jolt_table {
+        let raw = self.raw;
+        std::mem::forget(self);
+        raw
+    }
+}
+
+impl Drop for HipTable {
+    fn drop(&mut self) {
+        // SAFETY: owned handle of a live context.
+        let _ = unsafe { ffi::jolt_table_free(self.ctx.raw, self.raw) };
+    }
+}

@@ -1,0 +1,257 @@
+//! Raw FFI declarations of `libjolt_hip.so` -- GENERATED from `include/jolt_hip.h` by `tools/gen_rust_ffi.py`; do not edit.
+//! One declaration per entry point of the C header, same order, same arity, same types (checked by tests/test_abi_cpu.py).
+//! `jolt_fr_t` is bit-identical to `jolt_field::Fr` (4 x u64 Montgomery limbs, crates/jolt-field/src/bn254/mod.rs:33-43) and
+//! `jolt_g1_t` to `jolt_crypto::Bn254G1` (ark_bn254::G1Projective, crates/jolt-crypto/src/ec/bn254/mod.rs:17-24).
+#![allow(non_camel_case_types, clippy::too_many_arguments, clippy::missing_safety_doc)]
+use core::ffi::{c_char, c_void};
+
+pub const JOLT_HIP_ABI_VERSION: i32 = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct jolt_fr_t {
+    pub l: [u64; 4],
+}
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct jolt_fq_t {
+    pub l: [u64; 4],
+}
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct jolt_g1_t {
+    pub x: jolt_fq_t,
+    pub y: jolt_fq_t,
+    pub z: jolt_fq_t,
+}
+#[repr(C)]
+pub struct jolt_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_table {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_member {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_srs {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_batch {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_split_lt {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_onehot {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_rows {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_ints {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_comm {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_shm {
+    _private: [u8; 0],
+}
+
+/// Status codes (`enum` of the header); see `crate::status` for the mapping onto the reference's error types.
+pub const JOLT_OK: i32 = 0;
+pub const JOLT_ERR_INVALID_ARG: i32 = 1;
+pub const JOLT_ERR_NO_DEVICE: i32 = 2;
+pub const JOLT_ERR_OOM: i32 = 3;
+pub const JOLT_ERR_HIP: i32 = 4;
+pub const JOLT_ERR_SIZE_MISMATCH: i32 = 5;
+pub const JOLT_ERR_UNSUPPORTED: i32 = 6;
+pub const JOLT_ERR_NOT_FULLY_BOUND: i32 = 7;
+pub const JOLT_ERR_ROUND_CHECK: i32 = 8;
+pub const JOLT_ERR_SRS_TOO_SMALL: i32 = 9;
+pub const JOLT_ERR_EMPTY_POINT: i32 = 10;
+pub const JOLT_ERR_NOT_INVERTIBLE: i32 = 11;
+pub const JOLT_ORDER_LOW_TO_HIGH: i32 = 0;
+pub const JOLT_ORDER_HIGH_TO_LOW: i32 = 1;
+pub const JOLT_MEMBER_FLAG_SKIP_ONE: u32 = 1;
+pub const JOLT_MEMBER_FLAG_BORROW_TABLES: u32 = 2;
+pub const JOLT_INT_U64: i32 = 0;
+pub const JOLT_INT_I64: i32 = 1;
+pub const JOLT_INT_I128: i32 = 2;
+pub const JOLT_MAX_MEMBER_TABLES: usize = 40;
+pub const JOLT_MAX_MEMBER_TERMS: usize = 16;
+pub const JOLT_MAX_MEMBER_FACTORS: usize = 64;
+pub const JOLT_MAX_DEGREE: usize = 7;
+
+#[repr(C)]
+pub struct jolt_member_desc {
+    pub n_tables: u32,
+    pub n_terms: u32,
+    pub degree: u32,
+    pub order: i32,
+    pub term_offsets: *const u32,
+    pub factors: *const u32,
+    pub coeffs: *const jolt_fr_t,
+}
+#[repr(C)]
+pub struct jolt_member_lc_desc {
+    pub n_tables: u32,
+    pub n_groups: u32,
+    pub n_factors: u32,
+    pub n_lc: u32,
+    pub degree: u32,
+    pub order: i32,
+    pub flags: u32,
+    pub group_factor_offsets: *const u32,
+    pub factor_lc_offsets: *const u32,
+    pub factor_consts: *const jolt_fr_t,
+    pub lc_tables: *const u32,
+    pub lc_coeffs: *const jolt_fr_t,
+}
+pub type jolt_local_round_fn = Option<
+    unsafe extern "C" fn(user: *mut c_void, active: *const usize, n_active: usize, binds: *const *const jolt_fr_t, evals_out: *mut jolt_fr_t, evals_count: usize) -> i32,
+>;
+pub type jolt_gather_fn = Option<unsafe extern "C" fn(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32>;
+
+#[link(name = "jolt_hip")]
+extern "C" {
+    pub fn jolt_status_string(status: i32) -> *const c_char;
+    pub fn jolt_abi_version() -> i32;
+    pub fn jolt_ctx_create(device_id: i32, stream: *mut c_void, out: *mut *mut jolt_ctx) -> i32;
+    pub fn jolt_ctx_destroy(ctx: *mut jolt_ctx) -> i32;
+    pub fn jolt_ctx_synchronize(ctx: *mut jolt_ctx) -> i32;
+    pub fn jolt_last_error(ctx: *const jolt_ctx) -> *const c_char;
+    pub fn jolt_ctx_trim(ctx: *mut jolt_ctx) -> i32;
+    pub fn jolt_ctx_memory_stats(ctx: *const jolt_ctx, live_bytes: *mut usize, cached_bytes: *mut usize, peak_bytes: *mut usize) -> i32;
+    pub fn jolt_timer_begin(ctx: *mut jolt_ctx) -> i32;
+    pub fn jolt_timer_end(ctx: *mut jolt_ctx, elapsed_ms: *mut f32) -> i32;
+    pub fn jolt_table_upload(ctx: *mut jolt_ctx, host: *const jolt_fr_t, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_from_device(ctx: *mut jolt_ctx, device_ptr: *const c_void, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_alloc(ctx: *mut jolt_ctx, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_clone(ctx: *mut jolt_ctx, src: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_from_u64(ctx: *mut jolt_ctx, host: *const u64, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_from_i64(ctx: *mut jolt_ctx, host: *const i64, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_download(ctx: *mut jolt_ctx, t: *const jolt_table, offset: usize, len: usize, host: *mut jolt_fr_t) -> i32;
+    pub fn jolt_table_len(t: *const jolt_table, len: *mut usize) -> i32;
+    pub fn jolt_table_device_ptr(t: *const jolt_table, device_ptr: *mut *mut c_void) -> i32;
+    pub fn jolt_table_free(ctx: *mut jolt_ctx, t: *mut jolt_table) -> i32;
+    pub fn jolt_table_slice(ctx: *mut jolt_ctx, parent: *const jolt_table, offset: usize, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_write(ctx: *mut jolt_ctx, t: *mut jolt_table, offset: usize, host: *const jolt_fr_t, len: usize) -> i32;
+    pub fn jolt_bind(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, k: usize, r: *const jolt_fr_t, order: i32) -> i32;
+    pub fn jolt_eq_evals(ctx: *mut jolt_ctx, r: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_eq_evals_aligned_block(ctx: *mut jolt_ctx, r: *const jolt_fr_t, n: usize, start: usize, block: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_lt_evals(ctx: *mut jolt_ctx, r: *const jolt_fr_t, n: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_eq_plus_one_evals(ctx: *mut jolt_ctx, r: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, eq_out: *mut *mut jolt_table, eq_plus_one_out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_address_fold(ctx: *mut jolt_ctx, grid: *const jolt_table, weights: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_cycle_fold(ctx: *mut jolt_ctx, grid: *const jolt_table, weights: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_tile(ctx: *mut jolt_ctx, base: *const jolt_table, copies: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_replicate_stream_lsb(ctx: *mut jolt_ctx, base: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_rlc(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, k: usize, scalars: *const jolt_fr_t, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_table_evaluate(ctx: *mut jolt_ctx, t: *const jolt_table, point: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_table_sum(ctx: *mut jolt_ctx, t: *const jolt_table, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_member_create_expr(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, desc: *const jolt_member_desc, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_lc(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, desc: *const jolt_member_lc_desc, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_split_eq_product(ctx: *mut jolt_ctx, a: *mut jolt_table, b: *mut jolt_table, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_split_eq_product_borrowed(ctx: *mut jolt_ctx, a: *mut jolt_table, b: *mut jolt_table, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_split_eq_lc(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, desc: *const jolt_member_lc_desc, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_split_eq_uniform(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, V: u32, F: u32, coeffs: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, flags: u32, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_split_eq_product_sharded(ctx: *mut jolt_ctx, a: *mut jolt_table, b: *mut jolt_table, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_reset(m: *mut jolt_member) -> i32;
+    pub fn jolt_member_set_scale(member: *mut jolt_member, scale: *const jolt_fr_t) -> i32;
+    pub fn jolt_member_num_rounds(m: *const jolt_member, rounds: *mut usize) -> i32;
+    pub fn jolt_member_degree(m: *const jolt_member, degree: *mut u32) -> i32;
+    pub fn jolt_member_prove_round(m: *mut jolt_member, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, n_evals: usize, aux_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_round_group_prove(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, binds: *const *const jolt_fr_t, evals_out: *mut jolt_fr_t, evals_capacity: usize) -> i32;
+    pub fn jolt_member_finish(m: *mut jolt_member, bind: *const jolt_fr_t) -> i32;
+    pub fn jolt_round_group_finish(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, binds: *const *const jolt_fr_t) -> i32;
+    pub fn jolt_member_final_values(m: *mut jolt_member, out: *mut jolt_fr_t, k: usize) -> i32;
+    pub fn jolt_member_input_claim(m: *mut jolt_member, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_member_destroy(m: *mut jolt_member) -> i32;
+    pub fn jolt_srs_upload_g1(ctx: *mut jolt_ctx, bases: *const jolt_g1_t, n: usize, out: *mut *mut jolt_srs) -> i32;
+    pub fn jolt_srs_setup_from_secret(ctx: *mut jolt_ctx, beta: *const jolt_fr_t, count: usize, g1: *const jolt_g1_t, out: *mut *mut jolt_srs) -> i32;
+    pub fn jolt_srs_len(srs: *const jolt_srs, n: *mut usize) -> i32;
+    pub fn jolt_srs_download(ctx: *mut jolt_ctx, srs: *const jolt_srs, offset: usize, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_srs_free(ctx: *mut jolt_ctx, srs: *mut jolt_srs) -> i32;
+    pub fn jolt_srs_precompute_windows(ctx: *mut jolt_ctx, srs: *mut jolt_srs, window_bits: u32, min_terms: usize) -> i32;
+    pub fn jolt_msm_g1(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_fr_t, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_msm_g1_table(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_hyperkzg_fold(ctx: *mut jolt_ctx, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, levels_out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_hyperkzg_eval3(ctx: *mut jolt_ctx, levels: *const *mut jolt_table, ell: usize, u: *const jolt_fr_t, v_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_hyperkzg_rlc(ctx: *mut jolt_ctx, levels: *const *mut jolt_table, ell: usize, q: *const jolt_fr_t, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_hyperkzg_witness_poly(ctx: *mut jolt_ctx, f: *const jolt_table, u: *const jolt_fr_t, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_host_fr_mul(a: *const jolt_fr_t, b: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_fr_add(a: *const jolt_fr_t, b: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_fr_sub(a: *const jolt_fr_t, b: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_fr_inv(a: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_fr_from_u64(v: u64, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_fr_mul_shifted(a: *const jolt_fr_t, c: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_eq_evals(r: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_mul_limbs29(field: i32, a: *const jolt_fr_t, b: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_univariate_from_evals(evals: *const jolt_fr_t, n: usize, coeffs_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_univariate_evaluate(coeffs: *const jolt_fr_t, n: usize, x: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_gruen_poly_from_q(current_scalar: *const jolt_fr_t, point_i: *const jolt_fr_t, q_evals: *const jolt_fr_t, dq: usize, s0_plus_s1: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_gruen_poly_deg_3(current_scalar: *const jolt_fr_t, point_i: *const jolt_fr_t, q_constant: *const jolt_fr_t, q_quadratic: *const jolt_fr_t, s0_plus_s1: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_g1_add(p: *const jolt_g1_t, q: *const jolt_g1_t, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_host_g1_eq(p: *const jolt_g1_t, q: *const jolt_g1_t, equal: *mut i32) -> i32;
+    pub fn jolt_host_g1_serialize_compressed(p: *const jolt_g1_t, out: *mut u8) -> i32;
+    pub fn jolt_host_prove_batch(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, offsets: *const usize, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, use_round_group: i32, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_batch_begin(ctx: *mut jolt_ctx, n_members: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, rounds: *const usize, offsets: *const usize, kinds: *const i32, degrees: *const u32, split_eq_points: *const *const jolt_fr_t, split_eq_scales: *const jolt_fr_t, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, out: *mut *mut jolt_batch) -> i32;
+    pub fn jolt_host_batch_run(b: *mut jolt_batch, members: *const *mut jolt_member, n_rounds: usize, world: i32, gather: jolt_gather_fn, local_fn: jolt_local_round_fn, user: *mut c_void) -> i32;
+    pub fn jolt_host_batch_flush_binds(b: *mut jolt_batch, members: *const *mut jolt_member, binds_out: *mut jolt_fr_t, has_bind_out: *mut i32) -> i32;
+    pub fn jolt_host_batch_split_eq_scalar(b: *const jolt_batch, member: usize, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_batch_end(b: *mut jolt_batch, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
+    pub fn jolt_split_lt_create(ctx: *mut jolt_ctx, r_cycle: *const jolt_fr_t, n: usize, constant: *const jolt_fr_t, out: *mut *mut jolt_split_lt) -> i32;
+    pub fn jolt_split_lt_bind(ctx: *mut jolt_ctx, s: *mut jolt_split_lt, r: *const jolt_fr_t) -> i32;
+    pub fn jolt_split_lt_len(s: *const jolt_split_lt, len: *mut usize) -> i32;
+    pub fn jolt_split_lt_to_dense(ctx: *mut jolt_ctx, s: *const jolt_split_lt, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_split_lt_final_value(ctx: *mut jolt_ctx, s: *const jolt_split_lt, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_split_lt_free(ctx: *mut jolt_ctx, s: *mut jolt_split_lt) -> i32;
+    pub fn jolt_host_fr_wide_dot(a: *const jolt_fr_t, b: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_onehot_upload(ctx: *mut jolt_ctx, indices: *const u8, n_polys: usize, cycles: usize, k: u32, out: *mut *mut jolt_onehot) -> i32;
+    pub fn jolt_onehot_free(ctx: *mut jolt_ctx, source: *mut jolt_onehot) -> i32;
+    pub fn jolt_onehot_materialize(ctx: *mut jolt_ctx, source: *const jolt_onehot, poly: usize, scale_table: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_onehot_pushforward(ctx: *mut jolt_ctx, source: *const jolt_onehot, weights: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_member_create_lazy_ra_uniform(ctx: *mut jolt_ctx, source: *const jolt_onehot, scale_tables: *const jolt_fr_t, V: u32, F: u32, coeffs: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_lazy_ra_uniform_sharded(ctx: *mut jolt_ctx, source: *const jolt_onehot, scale_tables: *const jolt_fr_t, V: u32, F: u32, coeffs: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_rows_upload(ctx: *mut jolt_ctx, rows: *const c_void, n_rows: usize, row_bytes: usize, out: *mut *mut jolt_rows) -> i32;
+    pub fn jolt_rows_free(ctx: *mut jolt_ctx, rows: *mut jolt_rows) -> i32;
+    pub fn jolt_table_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, is_signed: i32, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_onehot_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, shifts: *const u32, n_polys: usize, log_k: u32, valid_offset: usize, out: *mut *mut jolt_onehot) -> i32;
+    pub fn jolt_onehot_download(ctx: *mut jolt_ctx, source: *const jolt_onehot, out: *mut u8) -> i32;
+    pub fn jolt_member_create_lazy_booleanity(ctx: *mut jolt_ctx, source: *const jolt_onehot, scale_tables: *const jolt_fr_t, rho: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_ints_upload(ctx: *mut jolt_ctx, host: *const c_void, kind: i32, count: usize, out: *mut *mut jolt_ints) -> i32;
+    pub fn jolt_ints_free(ctx: *mut jolt_ctx, values: *mut jolt_ints) -> i32;
+    pub fn jolt_dory_commit_rows(ctx: *mut jolt_ctx, srs: *const jolt_srs, values: *const jolt_ints, row_width: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_dory_commit_onehot(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, poly: usize, chunk_width: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_table_from_ints(ctx: *mut jolt_ctx, values: *const jolt_ints, offset: usize, len: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_grid_commit_onehot(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_grid_joint_polynomial(ctx: *mut jolt_ctx, sources: *const *const jolt_onehot, n_sources: usize, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, log_k: u32, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_comm_unique_id(rccl_path: *const c_char, out: *mut u8) -> i32;
+    pub fn jolt_comm_create(ctx: *mut jolt_ctx, rccl_path: *const c_char, unique_id: *const u8, rank: i32, world: i32, out: *mut *mut jolt_comm) -> i32;
+    pub fn jolt_comm_destroy(comm: *mut jolt_comm) -> i32;
+    pub fn jolt_comm_world(comm: *const jolt_comm, rank: *mut i32, world: *mut i32) -> i32;
+    pub fn jolt_comm_all_gather_host(comm: *mut jolt_comm, local: *const c_void, bytes: usize, gathered: *mut c_void) -> i32;
+    pub fn jolt_comm_all_gather_device(comm: *mut jolt_comm, d_local: *const c_void, bytes: usize, d_gathered: *mut c_void) -> i32;
+    pub fn jolt_comm_all_gather_table(comm: *mut jolt_comm, local: *const jolt_table, n: usize, gathered: *mut jolt_table) -> i32;
+    pub fn jolt_comm_gather_round_sums(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32;
+    pub fn jolt_shm_create(name: *const c_char, rank: i32, world: i32, max_bytes: usize, out: *mut *mut jolt_shm) -> i32;
+    pub fn jolt_shm_destroy(shm: *mut jolt_shm) -> i32;
+    pub fn jolt_shm_all_gather(shm: *mut jolt_shm, local: *const c_void, bytes: usize, gathered: *mut c_void) -> i32;
+    pub fn jolt_shm_gather_round_sums(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32;
+    pub fn jolt_round_group_pack_tables(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, entries: usize, dst: *mut jolt_table) -> i32;
+    pub fn jolt_tail_interleave(ctx: *mut jolt_ctx, gathered: *const jolt_table, world: usize, n_tables: usize, entries: usize, dst: *mut jolt_table) -> i32;
+    pub fn jolt_round_group_final_values(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, out: *mut jolt_fr_t, capacity: usize) -> i32;
+    pub fn jolt_host_hyperkzg_commit(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_host_hyperkzg_open(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+}

@@ -1,0 +1,31 @@
+//! `jolt-kernels-hip`: the MI355X backend of the Jolt prover's sumcheck and polynomial-commitment hot path.
+//!
+//! The crate is a thin, safe layer over the C ABI of `libjolt_hip.so` (`include/jolt_hip.h`, raw declarations in [`ffi`]) that
+//! implements the reference's OWN trait surface for this path, so `jolt-prover`'s stage drivers call it as a drop-in:
+//!
+//! | reference seam | here |
+//! |---|---|
+//! | `jolt_sumcheck::ProveRounds` (`crates/jolt-sumcheck/src/prover.rs:52-72`) | [`member::HipMember`] |
+//! | `jolt_kernels::SumcheckKernel` (`crates/jolt-kernels/src/kernel.rs:72-126`) | [`member::HipSumcheckProver`] |
+//! | `jolt_kernels::PrepareKernel` (`crates/jolt-kernels/src/backend.rs:98-111`) | [`member::HipPrepare`] (device twin of `NaiveSumcheckProver::new`) |
+//! | `jolt_sumcheck::RoundScheduler` / `BuildRoundScheduler` (`prover.rs:110-120`, `backend.rs:68-70`) | [`scheduler::HipRoundScheduler`] |
+//! | `JoltGroup::msm` for `Bn254G1` (`crates/jolt-crypto/src/ec/group.rs:63-70`) | [`msm::msm_g1`] |
+//! | HyperKZG prover pieces (`crates/jolt-hyperkzg/src/{kzg,scheme}.rs`) | [`msm::HipSrs`], `ffi::jolt_hyperkzg_*` |
+//!
+//! Host code stays Rust: Fiat-Shamir, claim wiring, round-polynomial assembly (`UnivariatePoly::from_evals`,
+//! `gruen_poly_deg_3`) and error types are the reference's; only table-sized work crosses the boundary, and per round only
+//! `Option<F>` goes down and `degree + 1` field elements come back (`specs/clean-slate-prover.md:565-573`).
+#![deny(unsafe_op_in_unsafe_fn)]
+
+pub mod ffi;
+pub mod context;
+pub mod member;
+pub mod msm;
+pub mod scheduler;
+pub mod status;
+
+pub use context::{HipContext, HipTable};
+pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape};
+pub use msm::{msm_g1, HipSrs};
+pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
+pub use status::HipError;

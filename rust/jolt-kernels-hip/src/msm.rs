@@ -1,0 +1,96 @@
+//! `JoltGroup::msm` for `Bn254G1` on the device (`crates/jolt-crypto/src/ec/group.rs:63-70`, `ec/bn254/mod.rs:195-212`).
+//!
+//! HyperKZG only ever multiplies prefixes of one long-lived `g1_powers` vector (`crates/jolt-hyperkzg/src/kzg.rs:19-26,114`), whose
+//! field is `pub(crate)` (`types.rs:105-108`): an out-of-crate backend sees it only as the `bases` argument.  The device copy is
+//! therefore cached by `(bases.as_ptr(), len)`: the first MSM over a base vector uploads it (converted to affine ONCE, where the
+//! reference converts every base on every call, `bn254/mod.rs:205`), later prefix MSMs reuse it.
+use std::collections::HashMap;
+use std::ptr;
+use std::sync::{Arc, Mutex, OnceLock};
+
+use jolt_crypto::Bn254G1;
+use jolt_field::Fr;
+
+use crate::context::HipContext;
+use crate::ffi;
+use crate::status::{check, HipError};
+
+/// `jolt_srs`: affine bases resident in HBM (+ optional fixed-base window tables).
+pub struct HipSrs {
+    ctx: Arc<HipContext>,
+    raw: *mut ffi::jolt_srs,
+    len: usize,
+}
+
+// SAFETY: see HipContext.
+unsafe impl Send for HipSrs {}
+
+impl HipSrs {
+    pub fn upload(ctx: &Arc<HipContext>, bases: &[Bn254G1]) -> Result<Self, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: `Bn254G1` is `#[repr(transparent)]` over `ark_bn254::G1Projective` = three Montgomery Fq = `jolt_g1_t`
+        // (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24, layout assertions :21-24).
+        check(unsafe { ffi::jolt_srs_upload_g1(ctx.raw, bases.as_ptr().cast(), bases.len(), &mut raw) }, ctx.raw)?;
+        Ok(Self { ctx: Arc::clone(ctx), raw, len: bases.len() })
+    }
+
+    /// Window-precomputed tables for a long-lived SRS (`jolt_srs_precompute_windows`): ceil(255 / c) copies of the bases in HBM buy
+    /// one shared bucket set per MSM and 24-bit windows.  Opt-in: worth it when the same SRS serves many large MSMs.
+    pub fn precompute_windows(&mut self) -> Result<(), HipError> {
+        // SAFETY: live handles.
+        check(unsafe { ffi::jolt_srs_precompute_windows(self.ctx.raw, self.raw, 0, 0) }, self.ctx.raw)
+    }
+
+    /// `sum_i scalars[i] * bases[i]` over the prefix `bases[..scalars.len()]`.
+    pub fn msm(&self, scalars: &[Fr]) -> Result<Bn254G1, HipError> {
+        let mut out = Bn254G1::default();
+        // SAFETY: layouts as above; `out` is one jolt_g1_t.
+        check(unsafe { ffi::jolt_msm_g1(self.ctx.raw, self.raw, scalars.as_ptr().cast(), scalars.len(), (&mut out as *mut Bn254G1).cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+
+    pub fn len(&self) -> usize {
+        self.len
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len == 0
+    }
+}
+
+impl Drop for HipSrs {
+    fn drop(&mut self) {
+        // SAFETY: owned handle of a live context.
+        let _ = unsafe { ffi::jolt_srs_free(self.ctx.raw, self.raw) };
+    }
+}
+
+fn cache() -> &'static Mutex<HashMap<(usize, usize), Arc<HipSrs>>> {
+    static CACHE: OnceLock<Mutex<HashMap<(usize, usize), Arc<HipSrs>>>> = OnceLock::new();
+    CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+}
+
+/// Drop-in body for `impl JoltGroup for Bn254G1 { fn msm(..) }`: same panic on a length mismatch, the device result on success,
+/// `None` when the device path is unavailable (the caller keeps arkworks' `VariableBaseMSM`).
+///
+/// Prefix reuse: a base slice that starts where a cached vector starts and is no longer than it is served from that vector.
+#[must_use]
+pub fn msm_g1(ctx: &Arc<HipContext>, bases: &[Bn254G1], scalars: &[Fr]) -> Option<Bn254G1> {
+    assert_eq!(bases.len(), scalars.len(), "msm: bases/scalars length mismatch"); // group.rs:66-69
+    if bases.is_empty() {
+        return Some(Bn254G1::default());
+    }
+    let key_ptr = bases.as_ptr() as usize;
+    let srs = {
+        let mut map = cache().lock().ok()?;
+        let hit = map.iter().find(|((p, len), _)| *p == key_ptr && *len >= bases.len()).map(|(_, v)| Arc::clone(v));
+        match hit {
+            Some(v) => v,
+            None => {
+                let v = Arc::new(HipSrs::upload(ctx, bases).ok()?);
+                let _ = map.insert((key_ptr, bases.len()), Arc::clone(&v));
+                v
+            }
+        }
+    };
+    srs.msm(scalars).ok()
+}

@@ -1,0 +1,71 @@
+//! Status codes of the C ABI mapped onto the reference's error types (`include/jolt_hip.h:44-59`).
+use core::ffi::CStr;
+
+use jolt_field::Fr;
+use jolt_kernels::{KernelError, SumcheckKernelError};
+use jolt_sumcheck::SumcheckError;
+
+use crate::ffi;
+
+/// A non-zero status together with the context's `jolt_last_error` text.
+#[derive(Debug, Clone, thiserror::Error)]
+#[error("libjolt_hip status {status} ({name}): {detail}")]
+pub struct HipError {
+    pub status: i32,
+    pub name: &'static str,
+    pub detail: String,
+}
+
+impl HipError {
+    /// `Unsupported`-class statuses are recoverable: the caller falls back to another backend's slot
+    /// (`crates/jolt-kernels/src/optimized/mod.rs:136-196` composes backends slot by slot).
+    pub fn is_recoverable(&self) -> bool {
+        matches!(self.status, ffi::JOLT_ERR_NO_DEVICE | ffi::JOLT_ERR_OOM | ffi::JOLT_ERR_UNSUPPORTED)
+    }
+}
+
+pub(crate) fn check(status: i32, ctx: *const ffi::jolt_ctx) -> Result<(), HipError> {
+    if status == ffi::JOLT_OK {
+        return Ok(());
+    }
+    // SAFETY: jolt_status_string returns a pointer to a static NUL-terminated string for every status value.
+    let name = unsafe { CStr::from_ptr(ffi::jolt_status_string(status)) }.to_str().unwrap_or("?");
+    let detail = if ctx.is_null() {
+        String::new()
+    } else {
+        // SAFETY: `ctx` is a live context (callers hold an Arc<HipContext>); the returned string is owned by it and copied here.
+        unsafe { CStr::from_ptr(ffi::jolt_last_error(ctx)) }.to_string_lossy().into_owned()
+    };
+    Err(HipError { status, name, detail })
+}
+
+impl From<HipError> for KernelError<Fr> {
+    /// `crates/jolt-kernels/src/error.rs:11-90`: capability gaps are `Unsupported` (the caller may retry the slot against another
+    /// backend), everything else is a bug.  The detailed text goes to the tracing span, the variants carry `&'static str`.
+    fn from(e: HipError) -> Self {
+        tracing::error!(status = e.status, detail = %e.detail, "libjolt_hip call failed");
+        match e.status {
+            ffi::JOLT_ERR_NO_DEVICE => KernelError::Unsupported { reason: "no usable gfx950 device" },
+            ffi::JOLT_ERR_OOM => KernelError::Unsupported { reason: "out of device memory" },
+            ffi::JOLT_ERR_UNSUPPORTED => KernelError::Unsupported { reason: "descriptor beyond the compiled limits of libjolt_hip" },
+            ffi::JOLT_ERR_SIZE_MISMATCH => KernelError::InvariantViolation { reason: "table sizes disagree with the relation's rounds" },
+            _ => KernelError::InvariantViolation { reason: "libjolt_hip reported an error (see the tracing log)" },
+        }
+    }
+}
+
+/// `SumcheckKernel::output_claims` failures (`crates/jolt-kernels/src/kernel.rs:25-53`).
+pub(crate) fn to_kernel_seam_error(e: HipError, remaining: usize) -> SumcheckKernelError<Fr> {
+    tracing::error!(status = e.status, detail = %e.detail, "libjolt_hip call failed");
+    match e.status {
+        ffi::JOLT_ERR_NOT_FULLY_BOUND => SumcheckKernelError::NotFullyBound { remaining },
+        _ => SumcheckKernelError::InvariantViolation { reason: "libjolt_hip reported an error (see the tracing log)" },
+    }
+}
+
+/// `prove_round` / `finish_rounds` report through `SumcheckError` (`crates/jolt-sumcheck/src/error.rs:12-110`): a device failure
+/// between construction and the round loop is the "evaluation source went missing" case of the reference tier.
+pub(crate) fn to_sumcheck_error(e: HipError) -> SumcheckError<Fr> {
+    tracing::error!(status = e.status, detail = %e.detail, "libjolt_hip call failed");
+    SumcheckError::MissingEvaluationSource { kind: "device" }
+}

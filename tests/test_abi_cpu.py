@@ -42,7 +42,7 @@ def test_no_cpu_fallback_without_device():
 
 
 def test_host_field_ops_match_oracle():
-    # field.cuh compiled for the host: the 64-bit-limb host product (host_mul64) and the shared add/sub/inv code;
+    # field.hip.h compiled for the host: the 64-bit-limb host product (host_mul64) and the shared add/sub/inv code;
     # the kernels' 32-bit mont_rows<8> is covered by the GPU tests, mont_rows<4> below
     a, b = rand_fr(200, 1), rand_fr(200, 2)
     edge = O.to_mont([0, 1, O.R_MOD - 1, 2, O.R_MOD - 2])
@@ -141,3 +141,27 @@ def test_device_multiplication_algorithm_matches_oracle_on_host():
             for j in (i, (i * 7 + 3) % len(ints), len(ints) - 1 - i):
                 want = omul(vals[i:i + 1], vals[j:j + 1])[0]
                 assert np.array_equal(ffi.host_mul_limbs29(field, vals[i], vals[j]), want), (field, i, j)
+
+
+def test_rust_ffi_crate_agrees_with_the_header():
+    """rust/jolt-kernels-hip/src/ffi.rs (the crate a16z/jolt would link; it cannot be compiled in this image) declares every entry
+    point of include/jolt_hip.h with the same name, arity, parameter names and types, in the same order, and is up to date with its
+    generator."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(root, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    header, rust = gen.parse_header(), gen.parse_rust()
+    assert len(header) > 100
+    assert [d[0] for d in header] == [d[0] for d in rust]
+    for h, r in zip(header, rust):
+        assert h[1].replace("c_void", "()") == r[1].replace("c_void", "()") or (h[1] == "c_void" and r[1] == "()"), h[0]
+        assert [(p.replace("r#", ""), t) for p, t in r[2]] == h[2], h[0]
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0
+    # every declared symbol is also what the shared library exports (the other half is test_library_exports_every_declared_symbol)
+    lib_rs = open(os.path.join(root, "rust", "jolt-kernels-hip", "src", "lib.rs")).read()
+    for module in ("context", "member", "msm", "scheduler", "status", "ffi"):
+        assert f"pub mod {module};" in lib_rs and os.path.exists(os.path.join(root, "rust", "jolt-kernels-hip", "src", module + ".rs"))

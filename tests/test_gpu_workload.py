@@ -73,7 +73,7 @@ def test_stages_match_oracle_at_configs2_scale():
 
 
 def test_persistent_round_engine_matches_per_round_kernels(monkeypatch):
-    """JOLT_ENGINE=1: the late rounds of every stage run inside the persistent round-engine kernel (engine_kernel.cuh:
+    """JOLT_ENGINE=1: the late rounds of every stage run inside the persistent round-engine kernel (engine_kernel.hip.h:
     fused binds, mailbox handshake per challenge).  All 11 relations, borrowed tables, expression / split-eq product /
     uniform members: transcripts must be bit-identical to the per-round kernels', also after a reset, and a caller that
     walks away mid-batch must not wedge the stream."""
