@@ -328,7 +328,8 @@ int32_t jolt_host_prove_batch(jolt_ctx *ctx, jolt_member *const *members, size_t
 /* Resumable form of the same round loop for the hypercube-sharded prover: local round sums come
  * from the device members (local_fn == NULL) or from a callback, are all-gathered over the ranks through `gather` and added
  * mod r; the loop can be paused after the shard-local rounds and resumed on members built from the gathered tables.
- * kinds: 0 = expr (degree+1 sums), 1 = expr with skipped s(1) (degree sums), 2 = split-eq product (2 sums). */
+ * kinds: 0 = expr (degree+1 sums), 1 = expr with skipped s(1) (degree sums), 2 = split-eq product (2 sums: q(0), q(inf) -> gruen_poly_deg_3),
+ * 3 = split-eq uniform product or eq-weighted member (degrees[i] - 1 sums q(0), q(2), .., q(degree-1) -> gruen_poly_from_q). */
 typedef struct jolt_batch jolt_batch;
 typedef int32_t (*jolt_local_round_fn)(void *user, const size_t *active, size_t n_active, const jolt_fr_t *const *binds,
                                        jolt_fr_t *evals_out, size_t evals_count);
@@ -339,6 +340,12 @@ int32_t jolt_host_batch_begin(jolt_ctx *ctx, size_t n_members, const jolt_fr_t *
                               size_t max_degree, uint64_t transcript_label, int32_t challenge_mode, jolt_batch **out);
 int32_t jolt_host_batch_run(jolt_batch *b, jolt_member *const *members, size_t n_rounds, int32_t world, jolt_gather_fn gather,
                             jolt_local_round_fn local_fn, void *user);
+/* The batch's Fiat-Shamir: by default the deterministic test transcript; with a callback the CALLER's transcript
+ * (ClearSumcheckRecorder::absorb_round, crates/jolt-sumcheck/src/recorder.rs:118-130): every round the loop hands over the batched
+ * round polynomial in compressed form (coefficients without the linear term) and takes the challenge back.  All ranks of a sharded
+ * batch must return the same challenge (they absorb the same summed polynomial).  fn = NULL restores the test transcript. */
+typedef int32_t (*jolt_round_transcript_fn)(void *user, const jolt_fr_t *compressed_coeffs, size_t n_coeffs, jolt_fr_t *challenge_out);
+int32_t jolt_host_batch_set_transcript(jolt_batch *b, jolt_round_transcript_fn fn, void *user);
 int32_t jolt_host_batch_flush_binds(jolt_batch *b, jolt_member *const *members, jolt_fr_t *binds_out, int32_t *has_bind_out);
 int32_t jolt_host_batch_split_eq_scalar(const jolt_batch *b, size_t member, jolt_fr_t *out);
 int32_t jolt_host_batch_end(jolt_batch *b, jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims,
@@ -464,6 +471,9 @@ int32_t jolt_comm_gather_round_sums(void *user, const jolt_fr_t *local, size_t c
  * RCCL exchange on every rank).  max_bytes bounds one rank's payload. */
 typedef struct jolt_shm jolt_shm;
 int32_t jolt_shm_create(const char *name, int32_t rank, int32_t world, size_t max_bytes, jolt_shm **out);
+/* The same with a per-run nonce (non-zero; the launcher draws it on rank 0 and distributes it with the name): an attaching rank
+ * accepts only the segment rank 0 initialised with this value, never a stale one a crashed run left under the same name. */
+int32_t jolt_shm_create_nonce(const char *name, uint64_t nonce, int32_t rank, int32_t world, size_t max_bytes, jolt_shm **out);
 int32_t jolt_shm_destroy(jolt_shm *shm);
 int32_t jolt_shm_all_gather(jolt_shm *shm, const void *local, size_t bytes, void *gathered);
 /* A jolt_gather_fn for jolt_host_batch_run with user = jolt_shm*. */

@@ -18,6 +18,9 @@ struct jolt_batch {
     size_t n = 0, max_num_vars = 0, max_degree = 0, round = 0;
     bool full_width = false;
     MockTranscript transcript{0};
+    // caller-owned Fiat-Shamir (jolt_host_batch_set_transcript): absorbs the round's compressed polynomial, returns the challenge
+    jolt_round_transcript_fn round_transcript = nullptr;
+    void* round_transcript_user = nullptr;
     std::vector<BatchMember> described;
     std::vector<int32_t> kind;        // 0 expr, 1 expr with skipped s(1), 2 split-eq product, 3 split-eq uniform product
     std::vector<uint32_t> degree;
@@ -75,6 +78,7 @@ extern "C" int32_t jolt_host_batch_begin(jolt_ctx* ctx, size_t n_members, const 
 typedef int32_t (*jolt_local_round_fn)(void* user, const size_t* active, size_t n_active, const jolt_fr_t* const* binds, jolt_fr_t* evals_out,
                                        size_t evals_count);
 typedef int32_t (*jolt_gather_fn)(void* user, const jolt_fr_t* local, size_t count, jolt_fr_t* gathered);
+typedef int32_t (*jolt_round_transcript_fn)(void* user, const jolt_fr_t* compressed_coeffs, size_t n_coeffs, jolt_fr_t* challenge_out);
 
 static void note_bind(jolt_batch* b, size_t i, const Fr& c) {
     if (b->kind[i] >= 2) {  // split_eq.rs:334-337
@@ -109,6 +113,13 @@ static int32_t assemble(const jolt_batch* b, size_t i, const Fr* ev, const Fr& c
 }
 
 // Run the next `n_rounds` rounds.  Local sums come from `members` (device members, jolt_round_group_prove) when
+extern "C" int32_t jolt_host_batch_set_transcript(jolt_batch* b, jolt_round_transcript_fn fn, void* user) {
+    if (!b) return JOLT_ERR_INVALID_ARG;
+    b->round_transcript = fn;
+    b->round_transcript_user = user;
+    return JOLT_OK;
+}
+
 // local_fn is NULL, else from the callback.  With world > 1 the local sums of all ranks are gathered through `gather`
 // and added (RCCL has no mod-r reduction: all-gather of a few KiB + local modular sum).
 extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* members, size_t n_rounds, int32_t world, jolt_gather_fn gather,
@@ -154,6 +165,9 @@ extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* member
                 if (has_l1[a]) inv_l1[a] = inv(l1[a]);
         };
         if (local_fn) {
+            // the sums come from the callback, not from the context's last device round: a gather hook must not mistake a stale
+            // device mirror of the same size for them (jolt_comm_gather_round_sums sends ctx->d_round when it mirrors `local`)
+            if (b->ctx) b->ctx->d_round_count = 0;
             JOLT_TRY(local_fn(user, active.data(), active.size(), binds.data(), local.data(), total));
             overlap();
         } else {
@@ -186,9 +200,25 @@ extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* member
         UnivariatePoly poly;
         poly.coefficients = batched;
         if (add(poly.evaluate(Fr::zero()), poly.evaluate(Fr::one())) != b->running_claim) return JOLT_ERR_ROUND_CHECK;
-        b->transcript.append_fr(poly.coefficients[0]);
-        for (size_t k = 2; k < poly.coefficients.size(); ++k) b->transcript.append_fr(poly.coefficients[k]);
-        Fr challenge = b->full_width ? b->transcript.challenge_scalar() : b->transcript.challenge();
+        Fr challenge;
+        if (b->round_transcript) {  // the host's real transcript (spongefish in the reference): compressed poly in, challenge out
+            std::vector<jolt_fr_t> compressed;
+            compressed.reserve(poly.coefficients.size());
+            for (size_t k = 0; k < poly.coefficients.size(); ++k) {
+                if (k == 1) continue;  // recorder.rs:118-130: the linear term is omitted
+                jolt_fr_t c;
+                fr_to_abi(&c, poly.coefficients[k]);
+                compressed.push_back(c);
+            }
+            jolt_fr_t ch;
+            JOLT_TRY(b->round_transcript(b->round_transcript_user, compressed.data(), compressed.size(), &ch));
+            challenge = fr_from_abi(&ch);
+            JOLT_REQUIRE(b->ctx, fr_is_canonical(challenge), "transcript callback returned a non-canonical challenge");
+        } else {
+            b->transcript.append_fr(poly.coefficients[0]);
+            for (size_t k = 2; k < poly.coefficients.size(); ++k) b->transcript.append_fr(poly.coefficients[k]);
+            challenge = b->full_width ? b->transcript.challenge_scalar() : b->transcript.challenge();
+        }
         b->running_claim = poly.evaluate(challenge);
         b->challenges.push_back(challenge);
         b->round_polys.push_back(poly);

@@ -1191,6 +1191,18 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     const size_t kUniformRowsMajorPairs = ctx->uniform_rows_pairs;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));  // also joins the side streams that wrote tables last round
     if (n > (size_t)kGroupTicket) { ctx->last_error = "batch round has too many members"; return JOLT_ERR_UNSUPPORTED; }
+    {   // validate BEFORE anything is bound: an error below must leave every member exactly as it was (a caller may fall back)
+        size_t sums = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const jolt_member* m = members[i];
+            if (!m) return JOLT_ERR_INVALID_ARG;
+            const bool binds_now = binds && binds[i];
+            if (binds_now && m->bound >= m->rounds) { ctx->last_error = "member already fully bound"; return JOLT_ERR_INVALID_ARG; }
+            if ((binds_now ? m->len / 2 : m->len) < 2) { ctx->last_error = "prove_round on a fully bound member"; return JOLT_ERR_INVALID_ARG; }
+            sums += jolt_internal_member_n_evals(m);
+        }
+        if (sums > ctx->round_cap) { ctx->last_error = "batch round returns too many sums"; return JOLT_ERR_UNSUPPORTED; }
+    }
     struct Item {
         size_t ne, slot;
         bool fused = false, tail = false, done = false, rows_major = false;

@@ -238,6 +238,7 @@ extern "C" int32_t jolt_comm_gather_round_sums(void* user, const jolt_fr_t* loca
     c->round_sums_host = local;  // these are the sums of the round that just completed: ctx->d_round mirrors them on the device
     int32_t s = jolt_comm_all_gather_host(c, local, count * sizeof(jolt_fr_t), gathered);
     c->round_sums_host = nullptr;
+    c->ctx->d_round_count = 0;  // the device mirror is consumed: the next gather must not send it again by accident
     return s;
 }
 

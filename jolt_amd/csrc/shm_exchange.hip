@@ -33,7 +33,8 @@ constexpr double kShmTimeoutSeconds = 60.0;
 struct ShmHeader {
     std::atomic<uint64_t> magic;
     uint64_t world, max_bytes, slot_stride;
-    char pad[64 - 4 * sizeof(uint64_t)];
+    uint64_t nonce;  // per-run value chosen by the launcher: tells this run's segment from a stale one of the same name
+    char pad[64 - 5 * sizeof(uint64_t)];
 };
 struct ShmSlot {  // followed by max_bytes of payload; slot_stride keeps every slot on its own cache lines
     std::atomic<uint64_t> seq;
@@ -57,7 +58,9 @@ struct jolt_shm {
 };
 
 // Collective over the ranks of one node: rank 0 creates `name` (a POSIX shm name, "/...") and the others attach to it.
-extern "C" int32_t jolt_shm_create(const char* name, int32_t rank, int32_t world, size_t max_bytes, jolt_shm** out) {
+// nonce != 0: an attaching rank only accepts a segment whose header carries this value -- a stale segment of a crashed run with the
+// same name (magic, world and max_bytes all plausible) is unmapped and the open retried until rank 0 has replaced it.
+extern "C" int32_t jolt_shm_create_nonce(const char* name, uint64_t nonce, int32_t rank, int32_t world, size_t max_bytes, jolt_shm** out) {
     if (!name || name[0] != '/' || !out || rank < 0 || world < 1 || rank >= world || max_bytes == 0) return JOLT_ERR_INVALID_ARG;
     jolt_shm* s = new (std::nothrow) jolt_shm();
     if (!s) return JOLT_ERR_OOM;
@@ -67,58 +70,61 @@ extern "C" int32_t jolt_shm_create(const char* name, int32_t rank, int32_t world
     s->max_bytes = max_bytes;
     const size_t stride = (sizeof(ShmSlot) + max_bytes + 63) & ~(size_t)63;
     s->map_bytes = sizeof(ShmHeader) + (size_t)world * 2 * stride;
-    int fd = -1;
     const auto t0 = std::chrono::steady_clock::now();
+    auto timed_out = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutSeconds; };
     if (rank == 0) {
         (void)shm_unlink(name);  // a stale segment of a crashed run
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd >= 0 && ftruncate(fd, (off_t)s->map_bytes) != 0) { close(fd); fd = -1; (void)shm_unlink(name); }
-        s->owner = fd >= 0;
-    } else {
-        for (;;) {  // wait for rank 0 to create and size it
-            fd = shm_open(name, O_RDWR, 0600);
-            if (fd >= 0) {
-                struct stat sb;
-                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= s->map_bytes) break;
-                close(fd);
-                fd = -1;
-            }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutSeconds) break;
-            usleep(200);
-        }
-    }
-    if (fd < 0) { delete s; return JOLT_ERR_UNSUPPORTED; }
-    void* p = mmap(nullptr, s->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) {
-        if (s->owner) (void)shm_unlink(name);
-        delete s;
-        return JOLT_ERR_UNSUPPORTED;
-    }
-    s->base = static_cast<char*>(p);
-    ShmHeader* h = s->header();
-    if (rank == 0) {  // a fresh segment is zero-filled: every seq starts at 0
+        if (fd < 0) { delete s; return JOLT_ERR_UNSUPPORTED; }
+        s->owner = true;
+        void* p = mmap(nullptr, s->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { (void)shm_unlink(name); delete s; return JOLT_ERR_UNSUPPORTED; }
+        s->base = static_cast<char*>(p);
+        ShmHeader* h = s->header();  // a fresh segment is zero-filled: every seq starts at 0
         h->world = (uint64_t)world;
         h->max_bytes = max_bytes;
         h->slot_stride = stride;
+        h->nonce = nonce;
         h->magic.store(kShmMagic, std::memory_order_release);
-    } else {
-        while (h->magic.load(std::memory_order_acquire) != kShmMagic) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kShmTimeoutSeconds) {
-                munmap(p, s->map_bytes);
-                delete s;
-                return JOLT_ERR_UNSUPPORTED;
-            }
-            sched_yield();
-        }
-        if (h->world != (uint64_t)world || h->max_bytes != max_bytes) {
-            munmap(p, s->map_bytes);
-            delete s;
-            return JOLT_ERR_SIZE_MISMATCH;
-        }
+        *out = s;
+        return JOLT_OK;
     }
-    *out = s;
-    return JOLT_OK;
+    for (;;) {  // wait for rank 0 to create, size and initialise THIS run's segment
+        int fd = shm_open(name, O_RDWR, 0600);
+        if (fd >= 0) {
+            struct stat sb;
+            void* p = MAP_FAILED;
+            if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= s->map_bytes) p = mmap(nullptr, s->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p != MAP_FAILED) {
+                ShmHeader* h = reinterpret_cast<ShmHeader*>(p);
+                bool ready = false;
+                for (int spin = 0; spin < 2000 && !ready; ++spin) {  // ~ a few ms: rank 0 initialises right after the create
+                    ready = h->magic.load(std::memory_order_acquire) == kShmMagic;
+                    if (!ready) sched_yield();
+                }
+                if (ready && (nonce == 0 || h->nonce == nonce)) {
+                    if (h->world != (uint64_t)world || h->max_bytes != max_bytes) {
+                        munmap(p, s->map_bytes);
+                        delete s;
+                        return JOLT_ERR_SIZE_MISMATCH;
+                    }
+                    s->base = static_cast<char*>(p);
+                    *out = s;
+                    return JOLT_OK;
+                }
+                munmap(p, s->map_bytes);  // not initialised yet, or another run's segment: look again
+            }
+        }
+        if (timed_out()) { delete s; return JOLT_ERR_UNSUPPORTED; }
+        usleep(200);
+    }
+}
+
+extern "C" int32_t jolt_shm_create(const char* name, int32_t rank, int32_t world, size_t max_bytes, jolt_shm** out) {
+    return jolt_shm_create_nonce(name, 0, rank, world, max_bytes, out);
 }
 
 extern "C" int32_t jolt_shm_destroy(jolt_shm* s) {

@@ -42,12 +42,12 @@ class ShmExchange:
     sharded round.  Host memory only, so it also runs (and is tested) without a GPU.  `name` must be the same on every rank."""
     MAX_BYTES = 64 * 1024
 
-    def __init__(self, name, rank, world, max_bytes=MAX_BYTES):
+    def __init__(self, name, rank, world, max_bytes=MAX_BYTES, nonce=0):
         self.rank, self.world = rank, world
         h = C.c_void_p()
-        st = ffi.lib().jolt_shm_create(name.encode(), C.c_int32(rank), C.c_int32(world), C.c_size_t(max_bytes), C.byref(h))
+        st = ffi.lib().jolt_shm_create_nonce(name.encode(), C.c_uint64(nonce), C.c_int32(rank), C.c_int32(world), C.c_size_t(max_bytes), C.byref(h))
         if st:
-            raise ffi.JoltError(st, "jolt_shm_create")
+            raise ffi.JoltError(st, "jolt_shm_create_nonce")
         self.h = h
 
     def all_gather_u64(self, arr):
@@ -69,12 +69,12 @@ def make_shm_exchange(dist, rank, world):
     all or none -- that it works (a probe exchange included).  Returns a ShmExchange or None (then the RCCL exchange stays)."""
     if os.environ.get("JOLT_ROUND_EXCHANGE", "shm") != "shm":
         return None
-    name = [f"/jolt_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little'):08x}"]
+    name = [f"/jolt_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little'):08x}", int.from_bytes(os.urandom(8), "little") | 1]  # name, per-run nonce
     if world > 1:
         dist.broadcast_object_list(name, src=0)
     shm = None
     try:
-        shm = ShmExchange(name[0], rank, world)
+        shm = ShmExchange(name[0], rank, world, nonce=name[1])
         probe = np.arange(4, dtype=np.uint64) + np.uint64(100 * rank)
         got = shm.all_gather_u64(probe)
         ok = all(np.array_equal(got[r], np.arange(4, dtype=np.uint64) + np.uint64(100 * r)) for r in range(world))

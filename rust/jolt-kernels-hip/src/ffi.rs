@@ -123,6 +123,7 @@ pub type jolt_local_round_fn = Option<
     unsafe extern "C" fn(user: *mut c_void, active: *const usize, n_active: usize, binds: *const *const jolt_fr_t, evals_out: *mut jolt_fr_t, evals_count: usize) -> i32,
 >;
 pub type jolt_gather_fn = Option<unsafe extern "C" fn(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32>;
+pub type jolt_round_transcript_fn = Option<unsafe extern "C" fn(user: *mut c_void, compressed_coeffs: *const jolt_fr_t, n_coeffs: usize, challenge_out: *mut jolt_fr_t) -> i32>;
 
 #[link(name = "jolt_hip")]
 extern "C" {
@@ -208,6 +209,7 @@ extern "C" {
     pub fn jolt_host_prove_batch(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, offsets: *const usize, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, use_round_group: i32, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_batch_begin(ctx: *mut jolt_ctx, n_members: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, rounds: *const usize, offsets: *const usize, kinds: *const i32, degrees: *const u32, split_eq_points: *const *const jolt_fr_t, split_eq_scales: *const jolt_fr_t, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, out: *mut *mut jolt_batch) -> i32;
     pub fn jolt_host_batch_run(b: *mut jolt_batch, members: *const *mut jolt_member, n_rounds: usize, world: i32, gather: jolt_gather_fn, local_fn: jolt_local_round_fn, user: *mut c_void) -> i32;
+    pub fn jolt_host_batch_set_transcript(b: *mut jolt_batch, r#fn: jolt_round_transcript_fn, user: *mut c_void) -> i32;
     pub fn jolt_host_batch_flush_binds(b: *mut jolt_batch, members: *const *mut jolt_member, binds_out: *mut jolt_fr_t, has_bind_out: *mut i32) -> i32;
     pub fn jolt_host_batch_split_eq_scalar(b: *const jolt_batch, member: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_batch_end(b: *mut jolt_batch, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
@@ -246,6 +248,7 @@ extern "C" {
     pub fn jolt_comm_all_gather_table(comm: *mut jolt_comm, local: *const jolt_table, n: usize, gathered: *mut jolt_table) -> i32;
     pub fn jolt_comm_gather_round_sums(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32;
     pub fn jolt_shm_create(name: *const c_char, rank: i32, world: i32, max_bytes: usize, out: *mut *mut jolt_shm) -> i32;
+    pub fn jolt_shm_create_nonce(name: *const c_char, nonce: u64, rank: i32, world: i32, max_bytes: usize, out: *mut *mut jolt_shm) -> i32;
     pub fn jolt_shm_destroy(shm: *mut jolt_shm) -> i32;
     pub fn jolt_shm_all_gather(shm: *mut jolt_shm, local: *const c_void, bytes: usize, gathered: *mut c_void) -> i32;
     pub fn jolt_shm_gather_round_sums(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32;

@@ -186,3 +186,32 @@ def test_shared_memory_round_exchange(world):
         solo.all_gather_u64(np.arange(9, dtype=np.uint64))  # 72 bytes > max_bytes
     assert e.value.status == 5
     solo.close()
+
+
+def test_shared_memory_exchange_ignores_a_stale_segment():
+    """A crashed run leaves its segment behind under the same name: magic, world and max_bytes all match.  With the per-run nonce an
+    attaching rank that gets there BEFORE this run's rank 0 keeps looking until rank 0 has replaced the segment, instead of mapping
+    the orphan (jolt_shm_create_nonce)."""
+    import threading
+    import time
+    from jolt_amd import distributed as D
+    name = f"/jolt_stale_{os.getpid()}"
+    stale = D.ShmExchange(name, 0, 2, max_bytes=256, nonce=0x1111)  # "previous run": never closed, so the file stays in /dev/shm
+    result = {}
+
+    def late_rank_one():
+        shm = D.ShmExchange(name, 1, 2, max_bytes=256, nonce=0x2222)
+        result["got"] = shm.all_gather_u64(np.array([7, 8], dtype=np.uint64))
+        shm.close()
+
+    t = threading.Thread(target=late_rank_one)
+    t.start()
+    time.sleep(0.3)  # rank 1 is already polling and has seen the stale segment
+    assert t.is_alive()
+    fresh = D.ShmExchange(name, 0, 2, max_bytes=256, nonce=0x2222)
+    mine = fresh.all_gather_u64(np.array([1, 2], dtype=np.uint64))
+    t.join(timeout=30)
+    assert not t.is_alive()
+    assert np.array_equal(mine, np.array([[1, 2], [7, 8]], dtype=np.uint64)) and np.array_equal(result["got"], mine)
+    fresh.close()
+    stale.h = None  # its file was unlinked by the fresh run's rank 0; drop the handle without touching the new segment

@@ -19,7 +19,7 @@ FFI_RS = os.path.join(ROOT, "rust", "jolt-kernels-hip", "src", "ffi.rs")
 SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "size_t": "usize", "float": "f32",
            "void": "c_void", "char": "c_char"}
 OPAQUE = ["jolt_ctx", "jolt_table", "jolt_member", "jolt_srs", "jolt_batch", "jolt_split_lt", "jolt_onehot", "jolt_rows", "jolt_ints", "jolt_comm", "jolt_shm"]
-FNPTR = {"jolt_local_round_fn", "jolt_gather_fn"}
+FNPTR = {"jolt_local_round_fn", "jolt_gather_fn", "jolt_round_transcript_fn"}
 
 
 def strip_comments(src):
@@ -89,7 +89,7 @@ def parse_rust(path=FFI_RS):
         name, params, ret = m.group(1), " ".join(m.group(2).split()), (m.group(3) or "()").strip()
         plist = []
         if params:
-            for p in re.split(r",\s*(?=\w+\s*:)", params.rstrip(", ")):
+            for p in re.split(r",\s*(?=(?:r#)?\w+\s*:)", params.rstrip(", ")):
                 pname, ptype = p.split(":", 1)
                 plist.append((pname.strip(), ptype.strip()))
         decls.append((name, ret, plist))
@@ -132,6 +132,7 @@ def render(decls):
                "    pub lc_tables: *const u32,\n    pub lc_coeffs: *const jolt_fr_t,\n}")
     out.append("pub type jolt_local_round_fn = Option<\n    unsafe extern \"C\" fn(user: *mut c_void, active: *const usize, n_active: usize, binds: *const *const jolt_fr_t, evals_out: *mut jolt_fr_t, evals_count: usize) -> i32,\n>;")
     out.append("pub type jolt_gather_fn = Option<unsafe extern \"C\" fn(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32>;")
+    out.append("pub type jolt_round_transcript_fn = Option<unsafe extern \"C\" fn(user: *mut c_void, compressed_coeffs: *const jolt_fr_t, n_coeffs: usize, challenge_out: *mut jolt_fr_t) -> i32>;")
     out.append("")
     out.append('#[link(name = "jolt_hip")]\nextern "C" {')
     for name, ret, params in decls:
