@@ -448,6 +448,28 @@ int32_t jolt_grid_joint_polynomial(jolt_ctx *ctx, const jolt_onehot *const *sour
                                    jolt_table *const *dense, size_t n_dense, const jolt_fr_t *dense_scalars, uint32_t log_k,
                                    jolt_table **out);
 
+/* Sparse (K x T) read-write matrix of RAM read/write checking (stage 2) -- SURVEY.md section 8(f) row 4.  Replaces
+ * CycleMajorMatrix / AddressMajorMatrix and the round messages of RamReadWriteKernel (crates/jolt-kernels/src/optimized/rw_matrix.rs,
+ * optimized/ram_read_write.rs:58-330): summand eq(tau_low, j) * ra(k,j) * (val(k,j) + gamma * (val(k,j) + inc(j))) over
+ * (address || cycle), bound low-to-high with the log_t cycle variables first (the default read-write config, the only one the
+ * reference kernels support, ram_read_write.rs:281-286); one entry per RAM access, never a K x T grid.
+ *   create: addresses[j] = remapped word address of cycle j or UINT64_MAX (RamAccessColumns, optimized/ram_trace.rs:22-75),
+ *     pre / post = the word before / after the access; inc (T entries) and val_init (K entries) are copied.
+ *   prove_round: ProveRounds::prove_round, device half.  Rounds < log_t return (q(0), q_inf) of the quadratic factor and
+ *     aux_out = {current_scalar, tau_low[current_index - 1], 0}: the caller completes the cubic with gruen_poly_deg_3
+ *     (split_eq.rs:383-417); later rounds return (s(0), s(2)), s(1) comes from the claim (UnivariatePoly::from_evals_and_hint).
+ *   final_values: {ra, val, inc, bound cycle-eq factor} (RamReadWriteOutputClaims + validate_derived_tables). */
+typedef struct jolt_rw_matrix jolt_rw_matrix;
+int32_t jolt_rw_matrix_create(jolt_ctx *ctx, const uint64_t *addresses, const uint64_t *pre_values, const uint64_t *post_values, size_t cycles,
+                              const jolt_table *inc, const jolt_table *val_init, const jolt_fr_t *tau_low, const jolt_fr_t *gamma,
+                              jolt_rw_matrix **out);
+int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix *m, const jolt_fr_t *bind, jolt_fr_t *evals_out /* 2 */, jolt_fr_t *aux_out /* 3 or NULL */);
+int32_t jolt_rw_matrix_finish(jolt_rw_matrix *m, const jolt_fr_t *bind);
+int32_t jolt_rw_matrix_final_values(jolt_rw_matrix *m, jolt_fr_t *out /* 4 */);
+int32_t jolt_rw_matrix_len(const jolt_rw_matrix *m, size_t *entries);
+int32_t jolt_rw_matrix_download(jolt_rw_matrix *m, uint64_t *rows, uint64_t *cols, jolt_fr_t *val, jolt_fr_t *ra, jolt_fr_t *prev, jolt_fr_t *next);
+int32_t jolt_rw_matrix_destroy(jolt_rw_matrix *m);
+
 /* Multi-GPU data path (one process per GPU).  The collectives are RCCL calls on the context's stream;
  * librccl.so.1 is resolved with dlopen at first use (`rccl_path` may name it explicitly, NULL = the copy already mapped into
  * the process / the default search path).  Rank 0 draws the id, the launcher broadcasts its 128 bytes (torch.distributed

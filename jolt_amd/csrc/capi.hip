@@ -515,6 +515,12 @@ static int32_t eq_build(jolt_ctx* ctx, const Fr* r, size_t n, const Fr& scale, s
     return JOLT_OK;
 }
 
+// evals_cached (crates/jolt-poly/src/eq.rs:317-340) on the device: levels[j] = eq over the first j coordinates (used by rw_matrix.hip)
+int32_t jolt_internal_eq_levels(jolt_ctx* ctx, const Fr* r, size_t n, const Fr& scale, std::vector<jolt_table*>* levels) {
+    jolt_table* last = nullptr;
+    return eq_build(ctx, r, n, scale, 1, levels, &last);
+}
+
 static int32_t read_point(jolt_ctx* ctx, const jolt_fr_t* r, size_t n, std::vector<Fr>& out) {
     out.resize(n);
     for (size_t i = 0; i < n; ++i) {

@@ -870,3 +870,56 @@ Context.grid_commit_onehot = _grid_commit_onehot
 Context.grid_joint_polynomial = _grid_joint_polynomial
 Context.trim = _trim
 Context.memory_stats = _memory_stats
+
+
+class RwMatrix:
+    """Device twin of the optimized RAM read/write-checking kernel's sparse matrix (jolt_rw_matrix_*): same interface as the oracle's
+    RwMatrix wrapper plus the fused prove_round."""
+
+    def __init__(self, ctx, addresses, pre, post, inc, val_init, tau_low, gamma):
+        a, p, q = (np.ascontiguousarray(x, dtype=np.uint64) for x in (addresses, pre, post))
+        tau = fr(tau_low).reshape(-1, 4)
+        self.ctx = ctx
+        h = C.c_void_p()
+        _ck(lib().jolt_rw_matrix_create(ctx.h, _p(a), _p(p), _p(q), C.c_size_t(a.shape[0]), inc.h, val_init.h, _p(tau), _p(fr(gamma)), C.byref(h)),
+            "jolt_rw_matrix_create", ctx)
+        self.h = h
+
+    def __len__(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_rw_matrix_len(self.h, C.byref(n)), "jolt_rw_matrix_len", self.ctx)
+        return n.value
+
+    def prove_round(self, bind=None):
+        evals, aux = fr_array(2), fr_array(3)
+        _ck(lib().jolt_rw_matrix_prove_round(self.h, _p(fr(bind)) if bind is not None else None, _p(evals), _p(aux)), "jolt_rw_matrix_prove_round", self.ctx)
+        return evals, aux
+
+    def finish(self, bind):
+        _ck(lib().jolt_rw_matrix_finish(self.h, _p(fr(bind))), "jolt_rw_matrix_finish", self.ctx)
+
+    def final_values(self):
+        out = fr_array(4)
+        _ck(lib().jolt_rw_matrix_final_values(self.h, _p(out)), "jolt_rw_matrix_final_values", self.ctx)
+        return out
+
+    def download(self):
+        n = len(self)
+        rows, cols = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint64)
+        val, ra, prev, nxt = fr_array(max(n, 1)), fr_array(max(n, 1)), fr_array(max(n, 1)), fr_array(max(n, 1))
+        _ck(lib().jolt_rw_matrix_download(self.h, _p(rows), _p(cols), _p(val), _p(ra), _p(prev), _p(nxt)), "jolt_rw_matrix_download", self.ctx)
+        return dict(rows=rows[:n], cols=cols[:n], val=val[:n], ra=ra[:n], prev=prev[:n], next=nxt[:n])
+
+    def free(self):
+        if self.h:
+            lib().jolt_rw_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+Context.rw_matrix = lambda self, *a, **k: RwMatrix(self, *a, **k)

@@ -68,6 +68,10 @@ pub struct jolt_comm {
 pub struct jolt_shm {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct jolt_rw_matrix {
+    _private: [u8; 0],
+}
 
 /// Status codes (`enum` of the header); see `crate::status` for the mapping onto the reference's error types.
 pub const JOLT_OK: i32 = 0;
@@ -239,6 +243,13 @@ extern "C" {
     pub fn jolt_table_from_ints(ctx: *mut jolt_ctx, values: *const jolt_ints, offset: usize, len: usize, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_grid_commit_onehot(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_joint_polynomial(ctx: *mut jolt_ctx, sources: *const *const jolt_onehot, n_sources: usize, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, log_k: u32, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_rw_matrix_create(ctx: *mut jolt_ctx, addresses: *const u64, pre_values: *const u64, post_values: *const u64, cycles: usize, inc: *const jolt_table, val_init: *const jolt_table, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
+    pub fn jolt_rw_matrix_prove_round(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, aux_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_rw_matrix_finish(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t) -> i32;
+    pub fn jolt_rw_matrix_final_values(m: *mut jolt_rw_matrix, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_rw_matrix_len(m: *const jolt_rw_matrix, entries: *mut usize) -> i32;
+    pub fn jolt_rw_matrix_download(m: *mut jolt_rw_matrix, rows: *mut u64, cols: *mut u64, val: *mut jolt_fr_t, ra: *mut jolt_fr_t, prev: *mut jolt_fr_t, next: *mut jolt_fr_t) -> i32;
+    pub fn jolt_rw_matrix_destroy(m: *mut jolt_rw_matrix) -> i32;
     pub fn jolt_comm_unique_id(rccl_path: *const c_char, out: *mut u8) -> i32;
     pub fn jolt_comm_create(ctx: *mut jolt_ctx, rccl_path: *const c_char, unique_id: *const u8, rank: i32, world: i32, out: *mut *mut jolt_comm) -> i32;
     pub fn jolt_comm_destroy(comm: *mut jolt_comm) -> i32;

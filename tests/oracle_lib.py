@@ -725,3 +725,89 @@ def onehot_pushforward(col, k_entries, w):
     out = fr_array(k_entries)
     lib().orc_onehot_pushforward(col.ctypes.data_as(C.c_void_p), C.c_size_t(col.shape[0]), C.c_size_t(k_entries), _p(w), _p(out))
     return out
+
+
+# ---- sparse read-write matrix (oracle/rw_matrix.c) --------------------------------------------------------------------
+RW_NO_ACCESS = 0xFFFFFFFFFFFFFFFF
+
+
+def split_eq_bind_scalar(scalar, point_i, challenge):
+    o = fr_array(1)
+    lib().orc_split_eq_bind_scalar(*[_p(np.ascontiguousarray(x, dtype=np.uint64)) for x in (scalar, point_i, challenge)], _p(o))
+    return o[0]
+
+
+class SplitEqState:
+    """Host half of GruenSplitEqPolynomial::new(w, LowToHigh) (crates/jolt-poly/src/split_eq.rs:187-363): current scalar, current
+    E_out / E_in tables, the coordinate the next round binds."""
+
+    def __init__(self, w):
+        self.w = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
+        self.n, self.bound = self.w.shape[0], 0
+        self.scalar = to_mont([1])[0]
+
+    def tables(self):
+        out_bits, in_bits = split_eq_current_dims(self.n, self.bound)
+        out_len = min(self.n // 2, self.n - 1 if self.n else 0)
+        return eq_evals(self.w[:out_bits]), eq_evals(self.w[out_len:out_len + in_bits]), in_bits
+
+    def point(self):
+        return self.w[self.n - self.bound - 1]
+
+    def bind(self, r):
+        self.scalar = split_eq_bind_scalar(self.scalar, self.point(), r)
+        self.bound += 1
+
+
+class RwMatrix:
+    """CycleMajorMatrix / AddressMajorMatrix of the RAM read/write-checking kernel (crates/jolt-kernels/src/optimized/rw_matrix.rs)"""
+
+    def __init__(self, addresses, pre, post):
+        a, p, q = (np.ascontiguousarray(x, dtype=np.uint64) for x in (addresses, pre, post))
+        lib().orc_rw_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_rw_create(_p(a), _p(p), _p(q), C.c_size_t(a.shape[0])))
+
+    def __len__(self):
+        lib().orc_rw_len.restype = C.c_size_t
+        return lib().orc_rw_len(self.h)
+
+    def export(self):
+        n = len(self)
+        rows, cols = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        val, ra, prev, nxt = fr_array(n), fr_array(n), fr_array(n), fr_array(n)
+        lib().orc_rw_export(self.h, _p(rows), _p(cols), _p(val), _p(ra), _p(prev), _p(nxt))
+        return dict(rows=rows, cols=cols, val=val, ra=ra, prev=prev, next=nxt)
+
+    def cycle_round(self, e_out, e_in, in_bits, inc, gamma):
+        o = fr_array(2)
+        lib().orc_rw_cycle_round(self.h, _p(np.ascontiguousarray(e_out)), _p(np.ascontiguousarray(e_in)), C.c_size_t(in_bits), _p(np.ascontiguousarray(inc)),
+                                 _p(np.ascontiguousarray(gamma)), _p(o))
+        return o
+
+    def cycle_bind(self, r):
+        lib().orc_rw_cycle_bind(self.h, _p(np.ascontiguousarray(r, dtype=np.uint64)))
+
+    def into_address_major(self):
+        assert lib().orc_rw_into_address_major(self.h) == 0
+
+    def address_round(self, val_init, inc, eq, gamma):
+        o = fr_array(2)
+        lib().orc_rw_address_round(self.h, _p(np.ascontiguousarray(val_init)), _p(np.ascontiguousarray(inc)), _p(np.ascontiguousarray(eq)),
+                                   _p(np.ascontiguousarray(gamma)), _p(o))
+        return o
+
+    def address_bind(self, r, val_init):
+        """binds the matrix and `val_init` (returned, half as long)"""
+        v = np.ascontiguousarray(val_init, dtype=np.uint64).copy()
+        lib().orc_rw_address_bind(self.h, _p(np.ascontiguousarray(r, dtype=np.uint64)), _p(v), C.c_size_t(v.shape[0]))
+        return v[: v.shape[0] // 2].copy()
+
+    def final_values(self, val_init):
+        ra, val = fr_array(1), fr_array(1)
+        lib().orc_rw_final_values(self.h, _p(np.ascontiguousarray(val_init)), _p(ra), _p(val))
+        return ra[0], val[0]
+
+    def close(self):
+        if self.h:
+            lib().orc_rw_destroy(self.h)
+            self.h = None
