@@ -364,6 +364,10 @@ int32_t jolt_split_lt_free(jolt_ctx *ctx, jolt_split_lt *s);
  * kernels use for sums of products (WideAccumulator, crates/jolt-field/src/bn254/mont.rs:334-602; Accumulator contract
  * crates/jolt-field/src/algebra.rs:362-433).  Host build of the kernels' code; the value equals the plain field sum. */
 int32_t jolt_host_fr_wide_dot(const jolt_fr_t *a, const jolt_fr_t *b, size_t n, jolt_fr_t *out);
+/* The same accumulator ON THE DEVICE: sum_i a[i] * b[i] over two tables with plain field sums (deferred = 0) or per-thread
+ * unreduced 512-bit sums of products reduced once per block of products (deferred = 1) -- equal canonical values
+ * (Accumulator contract, crates/jolt-field/src/algebra.rs:362-433). */
+int32_t jolt_table_dot(jolt_ctx *ctx, const jolt_table *a, const jolt_table *b, int32_t deferred, jolt_fr_t *out);
 
 /* One-hot (Twist/Shout) selector columns as per-cycle hot indices.  Replaces ChunkIndexSource /
  * LazyFoldedRa (crates/jolt-kernels/src/optimized/lazy_ra.rs:39-268) and the pushforward G tables of the booleanity address
@@ -512,6 +516,20 @@ int32_t jolt_round_group_final_values(jolt_ctx *ctx, jolt_member *const *members
 int32_t jolt_host_hyperkzg_commit(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, jolt_g1_t *out);
 int32_t jolt_host_hyperkzg_open(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
                                 uint64_t transcript_label, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
+
+/* Term-range pieces of a commitment / opening sharded over the ranks of a node (the reference is single
+ * process): an MSM of n terms against srs[base_offset .. base_offset + n) with the scalars scalars[scalar_offset ..]; the partial
+ * one-hot commitments over cycles [cycle_lo, cycle_hi); and HyperKZGScheme::open with EVERY MSM split by term range over `world`
+ * ranks -- each rank holds the polynomial and the bases, multiplies terms [n*rank/world, n*(rank+1)/world), the partial points are
+ * all-gathered through `gather` (a jolt_gather_fn moving 32-byte words: jolt_comm_gather_round_sums, jolt_shm_gather_round_sums)
+ * and added in rank order, so every rank absorbs the same commitments and returns the same proof as jolt_host_hyperkzg_open. */
+int32_t jolt_msm_g1_table_range(jolt_ctx *ctx, const jolt_srs *srs, size_t base_offset, const jolt_table *scalars, size_t scalar_offset,
+                                size_t n, jolt_g1_t *out);
+int32_t jolt_grid_commit_onehot_range(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, size_t cycle_lo, size_t cycle_hi,
+                                      jolt_g1_t *out /* n_polys */);
+int32_t jolt_host_hyperkzg_open_sharded(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
+                                        uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void *user,
+                                        jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,8 @@ using namespace jolt;
 
 struct jolt_srs;
 int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out);
-int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out);
+int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
+                               const size_t* base_offsets = nullptr);
 
 namespace {
 
@@ -253,10 +254,40 @@ extern "C" int32_t jolt_host_hyperkzg_commit(jolt_ctx* ctx, const jolt_srs* srs,
     return JOLT_OK;
 }
 
+// The MSMs of an opening over `world` ranks: rank g multiplies terms [n*g/world, n*(g+1)/world) of every MSM
+// against the same range of the bases, the partial points are all-gathered (96 bytes each) and added in rank order on every rank,
+// so all ranks absorb identical commitments and draw identical challenges.  world = 1: the plain opening.
+static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::vector<const Fr*>& ptrs, const std::vector<size_t>& lens, int rank, int world,
+                                jolt_gather_fn gather, void* user, G1Jac* out) {
+    const size_t count = ptrs.size();
+    if (count == 0) return JOLT_OK;
+    if (world <= 1) return jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), count, out);
+    std::vector<const Fr*> p(count);
+    std::vector<size_t> n(count), off(count);
+    for (size_t i = 0; i < count; ++i) {
+        const size_t lo = lens[i] * (size_t)rank / (size_t)world, hi = lens[i] * (size_t)(rank + 1) / (size_t)world;
+        p[i] = ptrs[i] + lo;
+        n[i] = hi - lo;
+        off[i] = lo;
+    }
+    std::vector<G1Jac> partial(count), all((size_t)world * count);
+    JOLT_TRY(jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data(), off.data()));
+    static_assert(sizeof(G1Jac) == 3 * sizeof(jolt_fr_t), "a Jacobian point travels as three 32-byte words");
+    ctx->d_round_count = 0;  // these words are not the round sums of the context's last batch round (jolt_comm_gather_round_sums' shortcut)
+    JOLT_TRY(gather(user, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, reinterpret_cast<jolt_fr_t*>(all.data())));
+    for (size_t i = 0; i < count; ++i) {
+        G1Jac acc = all[i];
+        for (int r = 1; r < world; ++r) acc = g1_add(acc, all[(size_t)r * count + i]);
+        out[i] = acc;
+    }
+    return JOLT_OK;
+}
+
 // HyperKZGScheme::open (scheme.rs:122-158) + kzg_open_batch (kzg.rs:69-126)
-extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
-                                           uint64_t transcript_label, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell, uint64_t transcript_label,
+                                  int rank, int world, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
     if (!ctx || !srs || !evals || !point || !w || !v || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     if (ell == 0) return JOLT_ERR_EMPTY_POINT;
     if (ell > 40) return JOLT_ERR_UNSUPPORTED;
     MockTranscript tr(transcript_label);
@@ -273,7 +304,7 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
         for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
-        s = jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), ptrs.size(), coms.data());
+        s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, gather, user, coms.data());
         if (s != JOLT_OK) { cleanup(); return s; }
     }
     for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
@@ -294,13 +325,13 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
     G1Jac ws[3];
     {  // kzg.rs:108-116: three witness polynomials, then their three independent MSMs on the MSM lanes
         jolt_table* h[3] = {nullptr, nullptr, nullptr};
-        const Fr* ptrs[3];
-        size_t lens[3];
+        std::vector<const Fr*> ptrs;
+        std::vector<size_t> lens;
         for (int t = 0; t < 3 && s == JOLT_OK; ++t) {
             s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[t], &h[t]);
-            if (s == JOLT_OK) { ptrs[t] = h[t]->data(); lens[t] = h[t]->len; }
+            if (s == JOLT_OK) { ptrs.push_back(h[t]->data()); lens.push_back(h[t]->len); }
         }
-        if (s == JOLT_OK) s = jolt_internal_msm_many(ctx, srs, ptrs, lens, 3, ws);
+        if (s == JOLT_OK) s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, gather, user, ws);
         for (int t = 0; t < 3; ++t) if (h[t]) jolt_table_free(ctx, h[t]);
         if (s != JOLT_OK) { cleanup(b_poly); return s; }
     }
@@ -311,4 +342,18 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
     if (challenges_out) { fr_to_abi(&challenges_out[0], r); fr_to_abi(&challenges_out[1], q); fr_to_abi(&challenges_out[2], d0); }
     cleanup(b_poly);
     return JOLT_OK;
+}
+
+extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                           uint64_t transcript_label, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, nullptr, nullptr, com, w, v, challenges_out);
+}
+
+// The same opening with its MSMs sharded over `world` ranks by term range (every rank holds the polynomial and the SRS; `gather` is a
+// jolt_gather_fn moving world x count 32-byte words -- jolt_comm_gather_round_sums / jolt_shm_gather_round_sums fit).  Every rank
+// returns the same proof.
+extern "C" int32_t jolt_host_hyperkzg_open_sharded(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                                   uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void* user, jolt_g1_t* com,
+                                                   jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, rank, world, gather, user, com, w, v, challenges_out);
 }

@@ -293,7 +293,8 @@ int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalar
 
 // `count` independent MSMs over the same bases, pipelined over the four lanes (results in order).  The side lanes wait
 // for the work already queued on the main stream (the tables being committed are produced there).
-int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out) {
+int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
+                               const size_t* base_offsets /* per MSM, or nullptr: every MSM multiplies the prefix */) {
     if (count == 0) return JOLT_OK;
     JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int k = 0; k < 3; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
@@ -303,7 +304,11 @@ int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* con
     for (size_t i = 0; i < count + L; ++i) {
         int lane = (int)(i % L);
         if (i >= L && i - L < count && status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &jobs[lane], &out[i - L]);
-        if (i < count && status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, srs, d_scalars[i], n[i], lane, &jobs[lane]);
+        if (i < count && status == JOLT_OK) {
+            if (base_offsets && base_offsets[i] + n[i] > srs->n) status = JOLT_ERR_SRS_TOO_SMALL;
+            const jolt_srs view = jolt_srs_range_view(*srs, base_offsets && status == JOLT_OK ? base_offsets[i] : 0);  // consumed by the enqueue itself
+            if (status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, &view, d_scalars[i], n[i], lane, &jobs[lane]);
+        }
     }
     if (status != JOLT_OK)
         for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->side[k]);
@@ -315,6 +320,19 @@ extern "C" int32_t jolt_msm_g1_table(jolt_ctx* ctx, const jolt_srs* srs, const j
     if (n > scalars->len) return JOLT_ERR_SIZE_MISMATCH;
     G1Jac r;
     JOLT_TRY(jolt_internal_msm(ctx, srs, scalars->data(), n, &r));
+    std::memcpy(out, &r, sizeof(r));
+    return JOLT_OK;
+}
+
+// sum_i scalars[scalar_offset + i] * srs[base_offset + i], i < n: one rank's term range of a sharded MSM
+extern "C" int32_t jolt_msm_g1_table_range(jolt_ctx* ctx, const jolt_srs* srs, size_t base_offset, const jolt_table* scalars, size_t scalar_offset, size_t n,
+                                           jolt_g1_t* out) {
+    if (!ctx || !srs || !scalars || !out) return JOLT_ERR_INVALID_ARG;
+    if (scalar_offset + n > scalars->len) return JOLT_ERR_SIZE_MISMATCH;
+    if (base_offset + n > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+    const jolt_srs view = jolt_srs_range_view(*srs, base_offset);
+    G1Jac r;
+    JOLT_TRY(jolt_internal_msm(ctx, &view, scalars->data() + scalar_offset, n, &r));
     std::memcpy(out, &r, sizeof(r));
     return JOLT_OK;
 }

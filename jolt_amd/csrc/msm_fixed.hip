@@ -234,6 +234,7 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
     srs->pre = pre;
     srs->pre_c = c;
     srs->pre_W = W;
+    srs->pre_stride = srs->n;
     srs->pre_min_n = min_terms ? min_terms : std::max<size_t>((size_t)1 << (c - 1), 1024);
     return JOLT_OK;
 }
@@ -305,7 +306,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     JOLT_HIP_TRY(ctx, hipGetLastError());
     JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), st));  // z = 0: identity
     JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, st));
-    hipLaunchKernelGGL(k_fx_scatter, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->n, nb1, cur1, entries);
+    hipLaunchKernelGGL(k_fx_scatter, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
     hipLaunchKernelGGL(k_fx_segment_sort, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
                        heavy_threshold, heavy, hcnt, heavy_cap);
     // bucket sums: the kernels of the per-window method with ONE window of B buckets (bases = the window tables)

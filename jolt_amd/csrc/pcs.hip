@@ -23,32 +23,34 @@ using namespace jolt;
 using namespace jolt::msmk;
 
 int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out);
+extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, size_t cycle_lo, size_t cycle_hi, jolt_g1_t* out);
 
 namespace {
 
 constexpr int kGridSumBlocks = 512;  // workgroups per column: 2048 wavefront partial sums, folded by the second kernel
 
 // partial[(p * gridDim.x + block) * 4 + wave] = sum over this wavefront's cycles of bases[hot_p(j) * T + j]
+// (lo, hi): the cycle range this launch sums -- the whole column, or one rank's block of a sharded commitment
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_grid_onehot_sum(
-    const uint8_t* __restrict__ idx, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial) {
+    const uint8_t* __restrict__ idx, size_t grid_cycles, size_t lo, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial) {
     const size_t p = blockIdx.y;
-    const uint8_t* col = idx + p * cycles;
+    const uint8_t* col = idx + p * grid_cycles;
     const size_t stride = (size_t)gridDim.x * kBlock;
     G1Jac acc = g1_identity();
     // software pipeline as in sum_bucket_points<true>: the next index byte and point are in flight during the mixed addition
-    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t j = lo + (size_t)blockIdx.x * kBlock + threadIdx.x;
     uint8_t a = j < cycles ? col[j] : kOneHotCold;
     G1Affine pt;
     pt.x = Fq::zero();
     pt.y = Fq::zero();
-    if (a != kOneHotCold) pt = ld_aff(bases + (size_t)a * cycles + j);
+    if (a != kOneHotCold) pt = ld_aff(bases + (size_t)a * grid_cycles + j);
     while (j < cycles) {
         const size_t jn = j + stride;
         uint8_t an = jn < cycles ? col[jn] : kOneHotCold;
         G1Affine pn;
         pn.x = Fq::zero();
         pn.y = Fq::zero();
-        if (an != kOneHotCold) pn = ld_aff(bases + (size_t)an * cycles + jn);
+        if (an != kOneHotCold) pn = ld_aff(bases + (size_t)an * grid_cycles + jn);
         acc = g1_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
         pt = pn;
         j = jn;
@@ -150,17 +152,25 @@ extern "C" int32_t jolt_table_from_ints(jolt_ctx* ctx, const jolt_ints* values, 
 }
 
 extern "C" int32_t jolt_grid_commit_onehot(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, jolt_g1_t* out) {
+    if (!source) return JOLT_ERR_INVALID_ARG;
+    return jolt_grid_commit_onehot_range(ctx, srs, source, 0, source->cycles, out);
+}
+
+// the partial commitments over cycles [cycle_lo, cycle_hi): one rank's share of a commitment sharded over the cycles (the ranks'
+// partial points add up to jolt_grid_commit_onehot's)
+extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, size_t cycle_lo, size_t cycle_hi, jolt_g1_t* out) {
     if (!ctx || !srs || !source || !out) return JOLT_ERR_INVALID_ARG;
     const size_t T = source->cycles, N = source->n_polys;
+    if (cycle_lo > cycle_hi || cycle_hi > T) return JOLT_ERR_SIZE_MISMATCH;
     if ((size_t)source->k * T > srs->n) return JOLT_ERR_SRS_TOO_SMALL;  // HyperKZGError::SrsTooSmall (kzg.rs:19-24)
     if (N > 65535) return JOLT_ERR_UNSUPPORTED;
-    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((T + kBlock - 1) / kBlock, kGridSumBlocks));
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((cycle_hi - cycle_lo + kBlock - 1) / kBlock, kGridSumBlocks));
     const uint32_t per_col = blocks * (kBlock / 64);
     G1Jac *partial = nullptr, *sums = nullptr;
     JOLT_TRY(jolt_internal_dev_alloc(ctx, N * per_col * sizeof(G1Jac), (void**)&partial));
     int32_t st = jolt_internal_dev_alloc(ctx, N * sizeof(G1Jac), (void**)&sums);
     if (st != JOLT_OK) { jolt_internal_dev_free(ctx, partial); return st; }
-    hipLaunchKernelGGL(k_grid_onehot_sum, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, T, (const G1Affine*)srs->pts, partial);
+    hipLaunchKernelGGL(k_grid_onehot_sum, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, T, cycle_lo, cycle_hi, (const G1Affine*)srs->pts, partial);
     hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)N), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, sums, N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);

@@ -12,5 +12,15 @@ struct jolt_srs {
     // is what makes 24-bit windows affordable).  pre_W * n * 64 bytes: the table is sized for 288 GB of HBM, not for a PCIe card.
     jolt::G1Affine* pre = nullptr;
     int pre_c = 0, pre_W = 0;
+    size_t pre_stride = 0;  // points per window table (= n of the SRS the tables were built for; a range view keeps the parent's)
     size_t pre_min_n = 0;  // MSMs shorter than this keep the per-window bucket method
 };
+
+// bases [offset, n) of `parent` as an SRS of their own (no ownership): term-range MSMs of a sharded opening
+static inline jolt_srs jolt_srs_range_view(const jolt_srs& parent, size_t offset) {
+    jolt_srs v = parent;
+    v.pts = parent.pts + offset;
+    v.n = parent.n - offset;
+    if (parent.pre) v.pre = parent.pre + offset;
+    return v;
+}

@@ -72,6 +72,25 @@ static __global__ __launch_bounds__(kBlock) void k_rlc_equal(RlcTables a, size_t
     st_fr(out + i, acc);
 }
 
+// sum_i a[i] * b[i] through the deferred-reduction accumulator (WideAccumulator::fmadd / reduce, crates/jolt-field/src/bn254/mont.rs:
+// 334-602): per thread an unreduced 512-bit sum of products, ONE Montgomery reduction per kWideMaxProducts products
+static __global__ __launch_bounds__(kBlock) void k_dot_wide(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ partials) {
+    Fr acc[1] = {Fr::zero()};
+    WideAcc<FrParams> w = wide_zero<FrParams>();
+    int pending = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        wide_fmadd(w, ld_fr(a + i), ld_fr(b + i));
+        if (++pending == kWideMaxProducts) {
+            acc[0] = add(acc[0], wide_reduce(w));
+            w = wide_zero<FrParams>();
+            pending = 0;
+        }
+    }
+    if (pending) acc[0] = add(acc[0], wide_reduce(w));
+    block_reduce_store<1>(acc, partials);
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)std::max<size_t>(1, (n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -154,6 +173,23 @@ extern "C" int32_t jolt_rlc(jolt_ctx* ctx, jolt_table* const* tables, size_t k, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { jolt_table_free(ctx, r); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     *out = r;
+    return JOLT_OK;
+}
+
+// sum_i a[i] * b[i]: plain field sums (deferred = 0) or the deferred-reduction accumulator (deferred = 1); same canonical value
+extern "C" int32_t jolt_table_dot(jolt_ctx* ctx, const jolt_table* a, const jolt_table* b, int32_t deferred, jolt_fr_t* out) {
+    if (!ctx || !a || !b || !out) return JOLT_ERR_INVALID_ARG;
+    if (a->len != b->len) return JOLT_ERR_SIZE_MISMATCH;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((a->len + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 8));
+    JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid + 8, 8));
+    if (deferred) hipLaunchKernelGGL(k_dot_wide, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)a->data(), (const Fr*)b->data(), a->len, ctx->d_partials);
+    else hipLaunchKernelGGL(k_sum_or_dot<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)a->data(), (const Fr*)b->data(), a->len, ctx->d_partials);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 1, ctx->d_results);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->h_results, sizeof(Fr));
     return JOLT_OK;
 }
 

@@ -705,3 +705,107 @@ class ShardedWorkload:
         for m in self.members:
             m.reset()
         return outs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# PCS legs of the sharded step (BASELINE configs[2] at N > 1): commitments and ONE HyperKZG opening over the global commitment grid
+# ---------------------------------------------------------------------------------------------------------------------------------
+class ShardedPcs:
+    """The committed columns of a trace of world * T cycles over the shared 2^(log_k) x (world * T) commitment grid, with the MSM
+    work sharded over the ranks by TERM RANGE (north_star: "the MSM scalar set shards naturally across the GPUs, bucket sums
+    reduced with RCCL"):
+
+      resident on every rank (inputs, before the timed region): the raw committed columns of the WHOLE trace -- 36 hot-index bytes
+        and two 64-bit increments per cycle (52 B per cycle, 1.7 GB at 8 x 2^22 cycles) -- and the SRS;
+      commit(): rank g multiplies / sums the bases of ITS block of cycles for every column; one all-gather of 38 partial points;
+      open():   every rank builds the joint polynomial and runs the HyperKZG polynomial arithmetic (folds, Horner, RLC, divisions:
+        HBM-bound passes, ~10 % of an opening) redundantly; every MSM is split by term range over the ranks and the partial points
+        are all-gathered (two exchanges per opening: ell - 1 level commitments, 3 witness commitments).
+    Every rank ends up with the same commitments and the same proof as a single process over the global trace (tests/
+    test_gpu_distributed.py).  `gather(points)` all-gathers (count, 12) uint64 arrays; `gather_fn / gather_user` are the C-level
+    jolt_gather_fn the opening calls."""
+
+    def __init__(self, ctx, rank, world, n_local, onehot_global, dense_global, gather_points, gather_fn, gather_user, seed=2026, log_k=4, fixed_base=False):
+        from .workload import G1_GENERATOR, rand_fr
+        self.ctx, self.rank, self.world, self.n_local, self.log_k = ctx, rank, world, n_local, log_k
+        self.T_local, self.T_global = 1 << n_local, world << n_local
+        self.grid_vars = log_k + n_local + (world.bit_length() - 1)
+        self.gather_points, self.gather_fn, self.gather_user = gather_points, gather_fn, gather_user
+        self.sources = [ctx.onehot(idx, 1 << log_k) for idx in onehot_global]  # (polys, world * T) hot indices, cycle-major blocks by rank
+        self.dense_ints = [ctx.ints(np.ascontiguousarray(d)) for d in dense_global]
+        prng = np.random.default_rng(seed + 2)
+        self.beta = rand_fr(1, prng)[0]
+        self.srs = ctx.srs_setup_from_secret(self.beta, 1 << self.grid_vars, G1_GENERATOR)
+        ctx.synchronize()
+        if fixed_base and self.grid_vars >= 12:
+            ctx.srs_precompute_windows(self.srs)
+        prng = np.random.default_rng(seed + 3)
+        self.rlc_onehot = rand_fr(sum(s.n_polys for s in self.sources), prng)
+        self.rlc_dense = rand_fr(len(self.dense_ints), prng)
+        self.open_point = rand_fr(self.grid_vars, prng)
+
+    def commit(self):
+        ctx, lo = self.ctx, self.rank * self.T_local
+        self.dense_tables = [ctx.table_from_ints(d) for d in self.dense_ints]  # the global columns, promoted (needed by the joint polynomial too)
+        parts = []
+        for t in self.dense_tables:
+            out = ffi.g1_array(1)
+            ffi._ck(ffi.lib().jolt_msm_g1_table_range(ctx.h, self.srs.h, C.c_size_t(lo), t.h, C.c_size_t(lo), C.c_size_t(self.T_local), ffi._p(out)),
+                    "jolt_msm_g1_table_range", ctx)
+            parts.append(out)
+        for s in self.sources:
+            out = ffi.g1_array(s.n_polys)
+            ffi._ck(ffi.lib().jolt_grid_commit_onehot_range(ctx.h, self.srs.h, s.h, C.c_size_t(lo), C.c_size_t(lo + self.T_local), ffi._p(out)),
+                    "jolt_grid_commit_onehot_range", ctx)
+            parts.append(out)
+        local = np.concatenate(parts)
+        allp = self.gather_points(local)  # (world, count, 12)
+        total = allp[0].copy()
+        for r in range(1, self.world):
+            for i in range(total.shape[0]):
+                total[i] = ffi.host_g1_add(total[i], allp[r][i])
+        nd = len(self.dense_tables)
+        return dict(dense=total[:nd], onehot=total[nd:])
+
+    def open(self, label=0):
+        ctx = self.ctx
+        joint = ctx.grid_joint_polynomial(self.sources, self.rlc_onehot, self.dense_tables, self.rlc_dense, self.log_k)
+        p = ffi.fr(self.open_point).reshape(-1, 4)
+        ell = p.shape[0]
+        com, w, v, ch = ffi.g1_array(max(ell - 1, 1)), ffi.g1_array(3), ffi.fr_array(3 * ell), ffi.fr_array(3)
+        ffi._ck(ffi.lib().jolt_host_hyperkzg_open_sharded(ctx.h, self.srs.h, joint.h, ffi._p(p), C.c_size_t(ell), C.c_uint64(label), C.c_int32(self.rank),
+                                                           C.c_int32(self.world), self.gather_fn, self.gather_user, ffi._p(com), ffi._p(w), ffi._p(v), ffi._p(ch)),
+                "jolt_host_hyperkzg_open_sharded", ctx)
+        joint.free()
+        for t in self.dense_tables:
+            t.free()
+        self.dense_tables = []
+        return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
+
+    def step(self, label=0):
+        return dict(commit=self.commit(), open=self.open(label))
+
+
+def make_point_gather(coll, world):
+    """(gather_points, gather_fn, gather_user) over a Collective / NativeCollective: Python-level all-gather of (count, 12) point
+    arrays and the C-level jolt_gather_fn for the opening."""
+    lib = ffi.lib()
+
+    def gather_points(local):
+        flat = np.ascontiguousarray(local, dtype=np.uint64).reshape(-1)
+        return np.ascontiguousarray(coll.all_gather_u64(flat)).reshape(world, -1, 12)
+
+    if isinstance(coll, NativeCollective):
+        return gather_points, C.cast(lib.jolt_comm_gather_round_sums, GATHER_FN), coll.h
+
+    def gather_cb(user, local, count, gathered):
+        try:
+            loc = np.ctypeslib.as_array(C.cast(local, C.POINTER(C.c_uint64)), shape=(count * 4,)).copy()
+            g = np.ascontiguousarray(coll.all_gather_u64(loc))
+            C.memmove(gathered, g.ctypes.data, g.nbytes)
+            return 0
+        except Exception:  # noqa: BLE001 -- never unwind through the C frame
+            return 4
+
+    cb = GATHER_FN(gather_cb)
+    return gather_points, cb, None

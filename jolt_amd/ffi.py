@@ -923,3 +923,12 @@ class RwMatrix:
 
 
 Context.rw_matrix = lambda self, *a, **k: RwMatrix(self, *a, **k)
+
+
+def _table_dot(self, a, b, deferred=False):
+    out = fr_array(1)
+    _ck(lib().jolt_table_dot(self.h, a.h, b.h, C.c_int32(1 if deferred else 0), _p(out)), "jolt_table_dot", self)
+    return out[0]
+
+
+Context.table_dot = _table_dot

@@ -224,6 +224,7 @@ extern "C" {
     pub fn jolt_split_lt_final_value(ctx: *mut jolt_ctx, s: *const jolt_split_lt, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_split_lt_free(ctx: *mut jolt_ctx, s: *mut jolt_split_lt) -> i32;
     pub fn jolt_host_fr_wide_dot(a: *const jolt_fr_t, b: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_table_dot(ctx: *mut jolt_ctx, a: *const jolt_table, b: *const jolt_table, deferred: i32, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_onehot_upload(ctx: *mut jolt_ctx, indices: *const u8, n_polys: usize, cycles: usize, k: u32, out: *mut *mut jolt_onehot) -> i32;
     pub fn jolt_onehot_free(ctx: *mut jolt_ctx, source: *mut jolt_onehot) -> i32;
     pub fn jolt_onehot_materialize(ctx: *mut jolt_ctx, source: *const jolt_onehot, poly: usize, scale_table: *const jolt_table, out: *mut *mut jolt_table) -> i32;
@@ -268,4 +269,7 @@ extern "C" {
     pub fn jolt_round_group_final_values(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, out: *mut jolt_fr_t, capacity: usize) -> i32;
     pub fn jolt_host_hyperkzg_commit(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_msm_g1_table_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, base_offset: usize, scalars: *const jolt_table, scalar_offset: usize, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_grid_commit_onehot_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, cycle_lo: usize, cycle_hi: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_host_hyperkzg_open_sharded(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
 }

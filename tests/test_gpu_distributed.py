@@ -156,3 +156,70 @@ def test_sharded_device_msm_two_ranks():
         mp.spawn(_msm_worker, args=(2, port, tmp), nprocs=2, join=True)
         for r in range(2):
             assert open(os.path.join(tmp, f"msm{r}.txt")).read() == "ok", f"rank {r}"
+
+
+def _pcs_worker(rank, world, port, tmpdir, n_local):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jolt_amd import distributed as D
+    from jolt_amd import ffi
+    ctx = ffi.Context(0)
+    coll = D.Collective(dist, world, None)
+    rng = np.random.default_rng(77)  # the GLOBAL raw columns, identical on every rank
+    T = world << n_local
+    ram = rng.integers(0, 16, size=(3, T), dtype=np.uint8)
+    ram[rng.random((3, T)) < 0.4] = 0xFF
+    ins = rng.integers(0, 16, size=(5, T), dtype=np.uint8)
+    dense = [rng.integers(0, 2**64, size=T, dtype=np.uint64), rng.integers(-2**62, 2**62, size=T, dtype=np.int64)]
+    gp, gfn, guser = D.make_point_gather(coll, world)
+    pcs = D.ShardedPcs(ctx, rank, world, n_local, [ram, ins], dense, gp, gfn, guser, seed=5, fixed_base=(n_local >= 6))
+    out = pcs.step(label=9)
+    again = pcs.step(label=9)
+    assert np.array_equal(out["open"]["v"], again["open"]["v"])
+    np.savez(os.path.join(tmpdir, f"pcs{rank}.npz"), dense=out["commit"]["dense"], onehot=out["commit"]["onehot"], com=out["open"]["com"], w=out["open"]["w"],
+             v=out["open"]["v"], ch=out["open"]["challenges"], beta=pcs.beta, rlc_onehot=pcs.rlc_onehot, rlc_dense=pcs.rlc_dense, point=pcs.open_point,
+             ram=ram, ins=ins, d0=dense[0], d1=dense[1])
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_local", [(2, 4), (4, 4), (2, 7)])
+def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local):
+    """Term-range sharded PCS legs (ShardedPcs: partial commitments per block of cycles, every MSM of the HyperKZG opening split over
+    the ranks, partial points all-gathered): every rank returns the commitments and the opening the ORACLE computes in one process
+    over the global trace -- same transcript bytes, same points."""
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    port = 29900 + os.getpid() % 1000 + world * 10 + n_local
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_pcs_worker, args=(world, port, tmp, n_local), nprocs=world, join=True)
+        got = [np.load(os.path.join(tmp, f"pcs{r}.npz")) for r in range(world)]
+    g0 = got[0]
+    T, K = world << n_local, 16
+    host_srs = O.srs_setup_from_secret(g0["beta"], K * T)
+    one = O.to_mont([1])[0]
+    joint = np.zeros((K * T, 4), dtype=np.uint64)
+    cols = list(g0["ram"]) + list(g0["ins"])
+    for p, col in enumerate(cols):
+        emb = np.zeros((K * T, 4), dtype=np.uint64)
+        hot = col != 0xFF
+        emb[col[hot].astype(np.int64) * T + np.nonzero(hot)[0]] = one
+        assert O.g1_eq(g0["onehot"][p], O.kzg_commit(emb, host_srs)), p
+        joint = O.fr_add(joint, O.fr_mul(emb, np.repeat(g0["rlc_onehot"][p].reshape(1, 4), K * T, axis=0)))
+    for d, vals in enumerate([O.fr_from_u64(g0["d0"]), O.fr_from_i64(g0["d1"])]):
+        emb = np.zeros((K * T, 4), dtype=np.uint64)
+        emb[:T] = vals
+        assert O.g1_eq(g0["dense"][d], O.kzg_commit(emb, host_srs)), d
+        joint[:T] = O.fr_add(joint[:T], O.fr_mul(vals, np.repeat(g0["rlc_dense"][d].reshape(1, 4), T, axis=0)))
+    want = O.hyperkzg_open(host_srs, joint, g0["point"], label=9)
+    for r in range(world):
+        g = got[r]
+        assert np.array_equal(g["ch"], want["challenges"]) and np.array_equal(g["v"], want["v"]), r
+        for a, b in zip(list(g["com"]) + list(g["w"]), list(want["com"]) + list(want["w"])):
+            assert O.g1_eq(a, b), r
+        for key in ("dense", "onehot"):
+            assert all(O.g1_eq(a, b) for a, b in zip(g[key], g0[key]))

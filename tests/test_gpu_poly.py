@@ -196,3 +196,30 @@ def test_split_lt_equals_dense_lt_plus_constant_bound_identically(ctx, n):
             assert np.array_equal(s.to_dense().download(), want), (n, k)
         assert np.array_equal(s.final_value(), want[0])
         s.free()
+
+
+def test_deferred_reduction_accumulator_on_the_device():
+    """WideAccumulator on the device (field.hip.h WideAcc: unreduced 512-bit sums of products, one REDC per 20 products): equal to
+    the plain field dot product and to the oracle's restatement, including the headroom worst case (every operand r - 1) and lengths
+    that leave partial blocks of products (crates/jolt-field/src/bn254/mont.rs:630-735 tests the same contract)."""
+    c = ffi.Context(0)
+    for n in (1, 19, 20, 21, 1000, 65537):
+        a, b = rand_fr(n, 900 + n), rand_fr(n, 901 + n)
+        ta, tb = c.upload(a), c.upload(b)
+        want = O.fr_mul(a, b)
+        acc = np.zeros((1, 4), dtype=np.uint64)
+        for k in range(0, n, 4096):
+            chunk = want[k:k + 4096]
+            while chunk.shape[0] > 1:
+                if chunk.shape[0] % 2:
+                    chunk = np.concatenate([chunk, np.zeros((1, 4), dtype=np.uint64)])
+                chunk = O.fr_add(chunk[0::2], chunk[1::2])
+            acc = O.fr_add(acc, chunk)
+        assert np.array_equal(c.table_dot(ta, tb, deferred=True), acc[0]), n
+        assert np.array_equal(c.table_dot(ta, tb, deferred=False), acc[0]), n
+    top = O.to_mont([O.R_MOD - 1] * 4096)  # the largest products: the accumulator's documented headroom
+    t = c.upload(top)
+    one = O.to_mont([1])[0]
+    want = O.to_mont([4096 % O.R_MOD])[0]  # (r-1)^2 = 1 mod r, summed 4096 times
+    assert np.array_equal(c.table_dot(t, t, deferred=True), want) and np.array_equal(one, O.fr_mul(top[:1], top[:1])[0])
+    c.close()
