@@ -463,6 +463,10 @@ class ShardedWorkload:
         # round sums: shared memory between the ranks of the node when every rank can map it, else the collective above
         self.round_exchange = make_shm_exchange(dist, rank, world) if (world > 1 or force_gather) else None
         spec = build_sharded_spec(n_local, rank, world, seed)
+        # the raw committed columns of this rank's block (what ShardedPcs commits to): hot indices per lazy member, the two increments
+        self.committed_onehot = [np.stack([spec["tables"][t]["data"] for t in ms.tables[1:]]) for ms in spec["members"]
+                                 if ms.uniform is not None and all(spec["tables"][t]["kind"] == "onehot" for t in ms.tables[1:])]
+        self.committed_dense = [spec["tables"]["s6.ram_inc"]["data"], spec["tables"]["s6.rd_inc"]["data"]]
         self.members_spec = spec["members"]
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
