@@ -452,6 +452,23 @@ int32_t jolt_grid_joint_polynomial(jolt_ctx *ctx, const jolt_onehot *const *sour
                                    jolt_table *const *dense, size_t n_dense, const jolt_fr_t *dense_scalars, uint32_t log_k,
                                    jolt_table **out);
 
+/* Spartan outer (stage 1) T-scale sums -- SURVEY.md section 8(f) row 3 (crates/jolt-kernels/src/{reference,optimized}/spartan_outer.rs).
+ * The constraint list, spartan_outer_row_weights and the Lagrange interpolation stay in Rust (O(rows) work); the caller folds the
+ * per-(node, stream) row weights into per-column weights (ConstraintMatrices::weighted_columns + public_column_contributions,
+ * reference/spartan_outer.rs:246-256): weights are laid out [node][stream][1 + n_inputs], column 0 = the constant.
+ *   jolt_r1cs_uniskip_sums: out[node] = sum_t sum_s eq[(t << 1) | s] * Az(node,s,t) * Bz(node,s,t), Az(node,s,t) = c_0 + sum_v c_v z_v(t)
+ *     -- the extended-node evaluations t1 of uniskip_first_round_poly (:172-221); eq has 2 * cycles entries (tau_low, stream = LSB).
+ *   jolt_r1cs_materialize: az[(t << 1) | s], bz[(t << 1) | s] for ONE (node =) uni-skip challenge: the remainder member's linear
+ *     forms over the joint (cycle || stream) domain (:236-300); feed them to jolt_member_create_split_eq_product with w = tau_low
+ *     and scale = the Lagrange kernel value for all log_t + 1 remainder rounds.
+ *   jolt_tables_evaluate: out[k] = tables[k] evaluated at `point`, all from one eq expansion (the post-hoc opening evaluation of
+ *     the 35 inputs, optimized/spartan_outer.rs:41-43; Polynomial::evaluate, dense.rs:340-366).  <= 64 tables. */
+int32_t jolt_r1cs_uniskip_sums(jolt_ctx *ctx, jolt_table *const *inputs, size_t n_inputs, const jolt_table *eq, const jolt_fr_t *a_weights,
+                               const jolt_fr_t *b_weights, size_t n_nodes, jolt_fr_t *out);
+int32_t jolt_r1cs_materialize(jolt_ctx *ctx, jolt_table *const *inputs, size_t n_inputs, const jolt_fr_t *a_weights, const jolt_fr_t *b_weights,
+                              jolt_table **az_out, jolt_table **bz_out);
+int32_t jolt_tables_evaluate(jolt_ctx *ctx, jolt_table *const *tables, size_t k, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
+
 /* Sparse (K x T) read-write matrix of RAM read/write checking (stage 2) -- SURVEY.md section 8(f) row 4.  Replaces
  * CycleMajorMatrix / AddressMajorMatrix and the round messages of RamReadWriteKernel (crates/jolt-kernels/src/optimized/rw_matrix.rs,
  * optimized/ram_read_write.rs:58-330): summand eq(tau_low, j) * ra(k,j) * (val(k,j) + gamma * (val(k,j) + inc(j))) over

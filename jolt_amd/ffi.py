@@ -932,3 +932,35 @@ def _table_dot(self, a, b, deferred=False):
 
 
 Context.table_dot = _table_dot
+
+
+# ---- Spartan outer T-scale sums (r1cs.hip)
+def _handles(tables):
+    return (C.c_void_p * max(len(tables), 1))(*[t.h for t in tables])
+
+
+def _r1cs_uniskip_sums(self, inputs, eq, a_weights, b_weights):
+    wa = fr(a_weights).reshape(-1, 2, 1 + len(inputs), 4)
+    wb = fr(b_weights).reshape(-1, 2, 1 + len(inputs), 4)
+    out = fr_array(wa.shape[0])
+    _ck(lib().jolt_r1cs_uniskip_sums(self.h, _handles(inputs), C.c_size_t(len(inputs)), eq.h, _p(wa), _p(wb), C.c_size_t(wa.shape[0]), _p(out)), "jolt_r1cs_uniskip_sums", self)
+    return out
+
+
+def _r1cs_materialize(self, inputs, a_weights, b_weights):
+    wa, wb = fr(a_weights).reshape(2, 1 + len(inputs), 4), fr(b_weights).reshape(2, 1 + len(inputs), 4)
+    az, bz = C.c_void_p(), C.c_void_p()
+    _ck(lib().jolt_r1cs_materialize(self.h, _handles(inputs), C.c_size_t(len(inputs)), _p(wa), _p(wb), C.byref(az), C.byref(bz)), "jolt_r1cs_materialize", self)
+    return Table(self, az), Table(self, bz)
+
+
+def _tables_evaluate(self, tables, point):
+    p = fr(point).reshape(-1, 4)
+    out = fr_array(len(tables))
+    _ck(lib().jolt_tables_evaluate(self.h, _handles(tables), C.c_size_t(len(tables)), _p(p), C.c_size_t(p.shape[0]), _p(out)), "jolt_tables_evaluate", self)
+    return out
+
+
+Context.r1cs_uniskip_sums = _r1cs_uniskip_sums
+Context.r1cs_materialize = _r1cs_materialize
+Context.tables_evaluate = _tables_evaluate

@@ -811,3 +811,53 @@ class RwMatrix:
         if self.h:
             lib().orc_rw_destroy(self.h)
             self.h = None
+
+
+# ---- Spartan outer T-scale sums (oracle/r1cs.c) ---------------------------------------------------------------------------------
+def _ptrs(tables):
+    tabs = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+    return tabs, (C.c_void_p * max(len(tabs), 1))(*[t.ctypes.data for t in tabs])
+
+
+def r1cs_row_values(inputs, rows):
+    """rows: [[(column, coeff), ...], ...] with column 0 = the constant -> (n_rows, cycles, 4)"""
+    tabs, ptrs = _ptrs(inputs)
+    cycles = tabs[0].shape[0]
+    offs, cols, coefs = [0], [], []
+    for row in rows:
+        for c, a in row:
+            cols.append(c)
+            coefs.append(np.asarray(a, dtype=np.uint64))
+        offs.append(len(cols))
+    out = fr_array(len(rows) * cycles)
+    lib().orc_r1cs_row_values(ptrs, C.c_size_t(cycles), C.c_uint32(len(rows)), _p(np.array(offs, dtype=np.uint32)), _p(np.array(cols if cols else [0], dtype=np.uint32)),
+                              _p(np.ascontiguousarray(np.stack(coefs)) if coefs else fr_array(1)), _p(out))
+    return out.reshape(len(rows), cycles, 4)
+
+
+def r1cs_uniskip_sums_rows(az_rows, bz_rows, eq, row_weights):
+    n_rows, cycles = az_rows.shape[0], az_rows.shape[1]
+    w = np.ascontiguousarray(row_weights, dtype=np.uint64).reshape(-1, 2, n_rows, 4)
+    out = fr_array(w.shape[0])
+    lib().orc_r1cs_uniskip_sums_rows(_p(np.ascontiguousarray(az_rows)), _p(np.ascontiguousarray(bz_rows)), C.c_uint32(n_rows), C.c_size_t(cycles),
+                                     _p(np.ascontiguousarray(eq)), _p(w), C.c_uint32(w.shape[0]), _p(out))
+    return out
+
+
+def r1cs_uniskip_sums(inputs, eq, a_weights, b_weights):
+    tabs, ptrs = _ptrs(inputs)
+    wa = np.ascontiguousarray(a_weights, dtype=np.uint64).reshape(-1, 2, 1 + len(tabs), 4)
+    wb = np.ascontiguousarray(b_weights, dtype=np.uint64).reshape(-1, 2, 1 + len(tabs), 4)
+    out = fr_array(wa.shape[0])
+    lib().orc_r1cs_uniskip_sums(ptrs, C.c_uint32(len(tabs)), C.c_size_t(tabs[0].shape[0]), _p(np.ascontiguousarray(eq)), _p(wa), _p(wb), C.c_uint32(wa.shape[0]), _p(out))
+    return out
+
+
+def r1cs_materialize(inputs, a_weights, b_weights):
+    tabs, ptrs = _ptrs(inputs)
+    cycles = tabs[0].shape[0]
+    wa = np.ascontiguousarray(a_weights, dtype=np.uint64).reshape(2, 1 + len(tabs), 4)
+    wb = np.ascontiguousarray(b_weights, dtype=np.uint64).reshape(2, 1 + len(tabs), 4)
+    az, bz = fr_array(2 * cycles), fr_array(2 * cycles)
+    lib().orc_r1cs_materialize(ptrs, C.c_uint32(len(tabs)), C.c_size_t(cycles), _p(wa), _p(wb), _p(az), _p(bz))
+    return az, bz
