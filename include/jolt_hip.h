@@ -406,6 +406,17 @@ int32_t jolt_table_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset
 int32_t jolt_onehot_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, const uint32_t *shifts, size_t n_polys,
                               uint32_t log_k, size_t valid_offset, jolt_onehot **out);
 int32_t jolt_onehot_download(jolt_ctx *ctx, const jolt_onehot *source, uint8_t *out /* n_polys * cycles */);
+/* The extractors' one-row lookahead window over a physical trace shorter than the padded cycle domain (RandomAccessRows::window /
+ * WitnessBundle::from_row(current, next, env), crates/jolt-kernels/src/optimized/rows.rs:22-72): out[j], j < cycles, reads the field of
+ * row j (lookahead = 0) or row j + 1 (lookahead = 1); rows at or beyond n_rows are padding rows (the field of TraceRow::default():
+ * padding_value), and the last cycle has no next row (none_value).  n_rows > cycles is JOLT_ERR_SIZE_MISMATCH (rows.rs:44-53). */
+int32_t jolt_table_from_rows_window(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, int32_t lookahead,
+                                    size_t cycles, int64_t padding_value, int64_t none_value, jolt_table **out);
+/* Hot-index columns from a sentinel-packed address field (InstructionCycleRow::{pc_plus_one, ram_address_plus_one},
+ * crates/jolt-kernels/src/optimized/instruction_read_raf.rs:82-123): 0 = no access (cold cycle), v > 0 = address v - 1 whose chunks
+ * index_i = ((v - 1) >> shifts[i]) & (2^log_k - 1) become the columns; cycles beyond the physical rows are cold. */
+int32_t jolt_onehot_from_rows_sentinel(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, const uint32_t *shifts, size_t n_polys,
+                                       uint32_t log_k, size_t cycles, jolt_onehot **out);
 
 /* Booleanity cycle phase over the same lazily bound columns (crates/jolt-kernels/src/optimized/booleanity.rs:436-633):
  * eq(w,j) * sum_i (H_i(j)^2 - rho[i]*H_i(j)), H_i(j) = scale_tables[i*k + index(i,j)] (the caller passes the gamma^i-pre-scaled

@@ -124,9 +124,61 @@ static __global__ __launch_bounds__(kBlock) void k_rows_to_fr(const uint8_t* __r
     Fr x = fr_from_u64(v);
     st_fr(out + j, negative ? neg(x) : x);
 }
+// The one-row lookahead window of the witness extractors (RandomAccessRows::window, crates/jolt-kernels/src/optimized/rows.rs:58-66):
+// cycle j reads row j (lookahead = 0) or row j + 1 (lookahead = 1); rows at and beyond the physical trace are padding rows, and the
+// last cycle of the domain has no next row at all (`None`).
+static __global__ __launch_bounds__(kBlock) void k_rows_window_to_fr(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width,
+                                                                     int is_signed, int lookahead, size_t cycles, int64_t padding_value, int64_t none_value,
+                                                                     Fr* __restrict__ out) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= cycles) return;
+    const size_t src = j + (size_t)lookahead;
+    int64_t sv;
+    if (lookahead && src >= cycles) {
+        sv = none_value;
+    } else if (src >= n_rows) {
+        sv = padding_value;
+    } else {
+        uint64_t v = load_le(rows + src * row_bytes + offset, width);
+        if (is_signed) {
+            const int bits = (int)width * 8;
+            if (bits < 64 && (v >> (bits - 1)) & 1) v |= ~0ull << bits;
+            sv = (int64_t)v;
+        } else {
+            if (width == 8 && (v >> 63)) {  // a full-width unsigned value does not fit the signed path
+                st_fr(out + j, fr_from_u64(v));
+                return;
+            }
+            sv = (int64_t)v;
+        }
+    }
+    const bool negative = sv < 0;
+    const Fr x = fr_from_u64(negative ? 0ull - (uint64_t)sv : (uint64_t)sv);
+    st_fr(out + j, negative ? neg(x) : x);
+}
 struct ChunkShifts {
     uint32_t shift[kMaxBatchTables];
 };
+// Sentinel-packed address fields (InstructionCycleRow::{pc_plus_one, ram_address_plus_one}, optimized/instruction_read_raf.rs:82-123):
+// 0 = no access (cold), v > 0 = address v - 1; chunk p = ((v - 1) >> shift[p]) & mask.  Fields of up to 16 bytes.
+static __global__ __launch_bounds__(kBlock) void k_rows_sentinel_to_hot_indices(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset,
+                                                                                uint32_t width, ChunkShifts sh, uint32_t log_k, size_t cycles, uint8_t* __restrict__ idx) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t p = blockIdx.y;
+    if (j >= cycles) return;
+    uint64_t lo = 0, hi = 0;
+    if (j < n_rows) {
+        const uint8_t* f = rows + j * row_bytes + offset;
+        lo = load_le(f, width < 8 ? width : 8);
+        if (width > 8) hi = load_le(f + 8, width - 8);
+    }
+    if ((lo | hi) == 0) { idx[p * cycles + j] = kOneHotCold; return; }
+    if (lo == 0) hi -= 1;  // borrow
+    lo -= 1;
+    const uint32_t s = sh.shift[p];
+    uint64_t v = s < 64 ? (lo >> s) | (s ? hi << (64 - s) : 0ull) : hi >> (s - 64);
+    idx[p * cycles + j] = (uint8_t)(v & ((1u << log_k) - 1));
+}
 static __global__ __launch_bounds__(kBlock) void k_rows_to_hot_indices(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width,
                                                                        ChunkShifts sh, uint32_t log_k, size_t valid_offset, uint8_t* __restrict__ idx) {
     size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -209,6 +261,57 @@ extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, s
     }
     if (e != hipSuccess) {
         ctx->last_error = std::string("onehot from rows: ") + hipGetErrorString(e);
+        if (s->idx) (void)hipFree(s->idx);
+        delete s;
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    *out = s;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_table_from_rows_window(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, int32_t lookahead, size_t cycles,
+                                               int64_t padding_value, int64_t none_value, jolt_table** out) {
+    if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || offset + width > rows->row_bytes || (lookahead != 0 && lookahead != 1)) return JOLT_ERR_INVALID_ARG;
+    if (rows->n_rows > cycles) return JOLT_ERR_SIZE_MISMATCH;  // rows.rs:44-53: the physical trace must fit the cycle domain
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_table* t = nullptr;
+    JOLT_TRY(jolt_internal_table_new(ctx, cycles, &t));
+    if (cycles) {
+        hipLaunchKernelGGL(k_rows_window_to_fr, dim3((unsigned)((cycles + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const uint8_t*)rows->data, rows->n_rows,
+                           rows->row_bytes, offset, width, is_signed ? 1 : 0, lookahead, cycles, padding_value, none_value, t->data());
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    }
+    *out = t;
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
+                                                  uint32_t log_k, size_t cycles, jolt_onehot** out) {
+    if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
+    if (log_k == 0 || log_k > 7 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;
+    if (rows->n_rows > cycles || cycles == 0) return JOLT_ERR_SIZE_MISMATCH;
+    ChunkShifts sh;
+    for (size_t p = 0; p < (size_t)kMaxBatchTables; ++p) {
+        sh.shift[p] = p < n_polys ? shifts[p] : 0;
+        if (p < n_polys && shifts[p] + log_k > width * 8) return JOLT_ERR_INVALID_ARG;
+    }
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_onehot* s = new (std::nothrow) jolt_onehot();
+    if (!s) return JOLT_ERR_OOM;
+    s->ctx = ctx;
+    s->n_polys = n_polys;
+    s->cycles = cycles;
+    s->k = 1u << log_k;
+    hipError_t e = hipMalloc((void**)&s->idx, n_polys * cycles);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rows_sentinel_to_hot_indices, dim3((unsigned)((cycles + kBlock - 1) / kBlock), (unsigned)n_polys), dim3(kBlock), 0, ctx->stream,
+                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, cycles, s->idx);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("onehot from sentinel rows: ") + hipGetErrorString(e);
         if (s->idx) (void)hipFree(s->idx);
         delete s;
         return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;

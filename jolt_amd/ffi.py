@@ -964,3 +964,28 @@ def _tables_evaluate(self, tables, point):
 Context.r1cs_uniskip_sums = _r1cs_uniskip_sums
 Context.r1cs_materialize = _r1cs_materialize
 Context.tables_evaluate = _tables_evaluate
+
+
+def _rows_window_table(self, offset, width, signed=False, lookahead=0, cycles=None, padding_value=0, none_value=0):
+    """RandomAccessRows::window: field of row j (or j + 1) for every cycle of the padded domain, padding / None rows as given."""
+    cycles = self.n_rows if cycles is None else cycles
+    h = C.c_void_p()
+    _ck(lib().jolt_table_from_rows_window(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), C.c_int32(1 if signed else 0), C.c_int32(lookahead),
+                                          C.c_size_t(cycles), C.c_int64(padding_value), C.c_int64(none_value), C.byref(h)), "jolt_table_from_rows_window", self.ctx)
+    return Table(self.ctx, h)
+
+
+def _rows_onehot_sentinel(self, offset, width, shifts, log_k, cycles=None):
+    """hot-index columns from a `value + 1, 0 = none` packed address field (InstructionCycleRow)"""
+    cycles = self.n_rows if cycles is None else cycles
+    sh = (C.c_uint32 * len(shifts))(*shifts)
+    h = C.c_void_p()
+    _ck(lib().jolt_onehot_from_rows_sentinel(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), sh, C.c_size_t(len(shifts)), C.c_uint32(log_k),
+                                             C.c_size_t(cycles), C.byref(h)), "jolt_onehot_from_rows_sentinel", self.ctx)
+    src = OneHot.__new__(OneHot)
+    src.ctx, src.n_polys, src.cycles, src.k, src.h = self.ctx, len(shifts), cycles, 1 << log_k, h
+    return src
+
+
+Rows.window_table = _rows_window_table
+Rows.onehot_sentinel = _rows_onehot_sentinel

@@ -236,6 +236,8 @@ extern "C" {
     pub fn jolt_table_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, is_signed: i32, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_onehot_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, shifts: *const u32, n_polys: usize, log_k: u32, valid_offset: usize, out: *mut *mut jolt_onehot) -> i32;
     pub fn jolt_onehot_download(ctx: *mut jolt_ctx, source: *const jolt_onehot, out: *mut u8) -> i32;
+    pub fn jolt_table_from_rows_window(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, is_signed: i32, lookahead: i32, cycles: usize, padding_value: i64, none_value: i64, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_onehot_from_rows_sentinel(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, shifts: *const u32, n_polys: usize, log_k: u32, cycles: usize, out: *mut *mut jolt_onehot) -> i32;
     pub fn jolt_member_create_lazy_booleanity(ctx: *mut jolt_ctx, source: *const jolt_onehot, scale_tables: *const jolt_fr_t, rho: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_ints_upload(ctx: *mut jolt_ctx, host: *const c_void, kind: i32, count: usize, out: *mut *mut jolt_ints) -> i32;
     pub fn jolt_ints_free(ctx: *mut jolt_ctx, values: *mut jolt_ints) -> i32;

@@ -262,3 +262,61 @@ def test_packed_witness_rows_expand_to_tables_and_hot_indices(ctx):
         bind = rand_challenge(81 + rnd)
     with pytest.raises(ffi.JoltError):
         R.onehot(0, 4, [30], 4)  # chunk beyond the field
+
+
+def test_lookahead_windows_and_sentinel_rows(ctx):
+    """The extractors' window over a physical trace shorter than the padded domain (RandomAccessRows::window, optimized/rows.rs:58-66:
+    current row or the NEXT row, padding rows beyond the trace, no next row at the last cycle) and InstructionCycleRow's sentinel
+    packing (pc_plus_one / ram_address_plus_one: 0 = None, optimized/instruction_read_raf.rs:82-123)."""
+    n_rows, cycles = 700, 1024
+    rng = np.random.default_rng(90)
+    dt = np.dtype([("lookup_lo", "<u8"), ("lookup_hi", "<u8"), ("pc_plus_one", "<u8"), ("ram_plus_one", "<u8"), ("next_pc", "<u8"), ("imm", "<i4"), ("flag", "u1"), ("pad", "u1", 3)])
+    rows = np.zeros(n_rows, dtype=dt)
+    rows["next_pc"] = rng.integers(0, 2**64, size=n_rows, dtype=np.uint64)
+    rows["imm"] = rng.integers(-2**31, 2**31, size=n_rows)
+    rows["flag"] = rng.integers(0, 2, size=n_rows)
+    rows["pc_plus_one"] = rng.integers(0, 2**20, size=n_rows)
+    rows["pc_plus_one"][rng.random(n_rows) < 0.1] = 0
+    rows["ram_plus_one"] = rng.integers(1, 2**16 + 1, size=n_rows)
+    rows["ram_plus_one"][rng.random(n_rows) < 0.5] = 0
+    rows["ram_plus_one"][:3] = [1, 2**16, 0]  # address 0, the largest address, no access
+    R = ffi.Rows(ctx, rows)
+
+    def want(field, lookahead, padding_value, none_value, signed):
+        vals = []
+        for j in range(cycles):
+            src = j + lookahead
+            if lookahead and src >= cycles:
+                vals.append(none_value)
+            elif src >= n_rows:
+                vals.append(padding_value)
+            else:
+                vals.append(int(rows[field][src]))
+        return O.to_mont([v % O.R_MOD for v in vals])
+
+    for field, width, signed in (("next_pc", 8, False), ("imm", 4, True), ("flag", 1, False)):
+        off = dt.fields[field][1]
+        for lookahead, pad, none in ((0, 0, 0), (1, 0, 0), (1, 1, -5), (0, 7, 0)):
+            got = R.window_table(off, width, signed=signed, lookahead=lookahead, cycles=cycles, padding_value=pad, none_value=none).download()
+            assert np.array_equal(got, want(field, lookahead, pad, none, signed)), (field, lookahead, pad, none)
+    with pytest.raises(ffi.JoltError) as e:
+        R.window_table(0, 8, cycles=512)  # the physical trace does not fit the cycle domain
+    assert e.value.status == 5
+    # sentinel-packed addresses -> hot-index columns: bytecode pc (5 chunks of 4 bits), RAM address (4 chunks)
+    for field, chunks in (("pc_plus_one", 5), ("ram_plus_one", 4)):
+        shifts = [(chunks - 1 - i) * 4 for i in range(chunks)]
+        got = R.onehot_sentinel(dt.fields[field][1], 8, shifts, 4, cycles=cycles).download()
+        exp = np.full((chunks, cycles), 0xFF, dtype=np.uint8)
+        for j in range(n_rows):
+            v = int(rows[field][j])
+            if v:
+                for i, s in enumerate(shifts):
+                    exp[i, j] = ((v - 1) >> s) & 15
+        assert np.array_equal(got, exp), field
+    # a 16-byte field whose decrement borrows across the 64-bit halves
+    wide = np.zeros(4, dtype=np.dtype([("lo", "<u8"), ("hi", "<u8")]))
+    wide["lo"], wide["hi"] = [0, 1, 0, 5], [1, 0, 0, 2]
+    got = ffi.Rows(ctx, wide).onehot_sentinel(0, 16, [60, 64, 0], 4).download()
+    vals = [(int(lo) | (int(hi) << 64)) for lo, hi in zip(wide["lo"], wide["hi"])]
+    exp = np.array([[0xFF if v == 0 else ((v - 1) >> s) & 15 for v in vals] for s in (60, 64, 0)], dtype=np.uint8)
+    assert np.array_equal(got, exp)
