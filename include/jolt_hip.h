@@ -371,9 +371,14 @@ int32_t jolt_table_dot(jolt_ctx *ctx, const jolt_table *a, const jolt_table *b, 
 
 /* One-hot (Twist/Shout) selector columns as per-cycle hot indices.  Replaces ChunkIndexSource /
  * LazyFoldedRa (crates/jolt-kernels/src/optimized/lazy_ra.rs:39-268) and the pushforward G tables of the booleanity address
- * phase (optimized/booleanity.rs:24-31).  indices[p*cycles + j] in [0, k) or 0xFF on a cold cycle; k <= 255. */
+ * phase (optimized/booleanity.rs:24-31).  indices[p*cycles + j] in [0, k) or 0xFF on a cold cycle; k <= 255 (jolt_onehot_upload16 beyond). */
 typedef struct jolt_onehot jolt_onehot;
 int32_t jolt_onehot_upload(jolt_ctx *ctx, const uint8_t *indices, size_t n_polys, size_t cycles, uint32_t k, jolt_onehot **out);
+/* The same with 16-bit indices (0xFFFF on a cold cycle, k <= 1024): the K = 256 chunks of long traces (log_k_chunk = 8 at log T >= 25,
+ * crates/jolt-prover/src/config.rs:175-186), where index 255 is a valid address.  Every operator below accepts either width; the
+ * LDS-staged and pair-table kernels of the lazily bound members are K <= 16 specialisations and are simply not selected. */
+int32_t jolt_onehot_upload16(jolt_ctx *ctx, const uint16_t *indices, size_t n_polys, size_t cycles, uint32_t k, jolt_onehot **out);
+int32_t jolt_onehot_download16(jolt_ctx *ctx, const jolt_onehot *source, uint16_t *out /* n_polys * cycles */);
 int32_t jolt_onehot_free(jolt_ctx *ctx, jolt_onehot *source);
 /* dense address-folded column: out[j] = scale_table[index(poly, j)], zero on cold cycles (the N x T "direct shape") */
 int32_t jolt_onehot_materialize(jolt_ctx *ctx, const jolt_onehot *source, size_t poly, const jolt_table *scale_table, jolt_table **out);
@@ -402,7 +407,7 @@ int32_t jolt_rows_free(jolt_ctx *ctx, jolt_rows *rows);
 int32_t jolt_table_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table **out);
 /* n_polys hot-index columns from ONE address field (<= 16 bytes): index_i = (field >> shifts[i]) & (2^log_k - 1)
  * (RaChunkSelector::chunk_u128, crates/jolt-witness/src/witnesses/one_hot.rs:14-52); a row whose byte at valid_offset is 0 is a
- * cold cycle (Option::None, e.g. no RAM access); valid_offset = SIZE_MAX: every row is hot.  log_k <= 7. */
+ * cold cycle (Option::None, e.g. no RAM access); valid_offset = SIZE_MAX: every row is hot.  log_k <= 8 (log_k = 8 gives a 16-bit source). */
 int32_t jolt_onehot_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, const uint32_t *shifts, size_t n_polys,
                               uint32_t log_k, size_t valid_offset, jolt_onehot **out);
 int32_t jolt_onehot_download(jolt_ctx *ctx, const jolt_onehot *source, uint8_t *out /* n_polys * cycles */);

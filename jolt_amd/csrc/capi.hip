@@ -1029,7 +1029,7 @@ static int32_t lazy_bind_enqueue(jolt_member* m, const Fr& c) {
         OneHotDense o;
         for (size_t i = 0; i < (size_t)kMaxBatchTables; ++i) o.out[i] = i < cnt ? m->tables[base + i]->buf[0] : nullptr;
         hipLaunchKernelGGL(k_onehot_materialize, dim3((unsigned)((new_len + kBlock - 1) / kBlock), (unsigned)cnt), dim3(kBlock), 0, ctx->stream,
-                           (const Fr*)outb, (size_t)branches * K, (const uint8_t*)src->idx, src->cycles, branches, (uint32_t)K, base, o);
+                           (const Fr*)outb, (size_t)branches * K, (const uint8_t*)src->idx, src->cycles, branches, (uint32_t)K, base, o, src->wide);
     }
     JOLT_HIP_TRY(ctx, hipGetLastError());
     for (jolt_table* t : m->tables) { t->cur = 0; t->len = new_len; }
@@ -1365,7 +1365,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         }
         items[i].grid = round_grid(ctx, work);
         // index-encoded selector columns past the first bind: one product group per workgroup, its branch tables in LDS
-        if (members[i]->kind == jolt_member::kSplitEqUniform && members[i]->lazy_width >= 2 && lazy_lds_bytes(members[i]) <= kLazyLdsMax && ctx->lazy_lds) {
+        if (members[i]->kind == jolt_member::kSplitEqUniform && members[i]->lazy_width >= 2 && !members[i]->onehot->wide && lazy_lds_bytes(members[i]) <= kLazyLdsMax && ctx->lazy_lds) {
             items[i].rows_major = false;
             items[i].lds_blocks = (uint32_t)std::max<size_t>(1, (size_t)round_grid(ctx, (members[i]->len / 2) * members[i]->uni_V) / members[i]->uni_V);
             items[i].grid = (int)(items[i].lds_blocks * members[i]->uni_V);
@@ -1421,13 +1421,14 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         if (m->lazy_width) {  // selector columns still index-encoded: gather instead of loading dense pairs
             LazyArgs la;
             la.idx = m->onehot->idx;
+            la.wide = m->onehot->wide;
             la.branch = m->d_branch[m->branch_cur];
             la.cycles0 = m->onehot->cycles;
             la.width = m->lazy_width;
             la.K = m->onehot->k;
             la.V = ua.V;
             for (size_t v = 0; v < (size_t)kMaxGroups; ++v) { la.coeff[v] = ua.coeff[v]; la.coeff_one[v] = ua.coeff_one[v]; }
-            if (m->lazy_width == 1 && m->d_pair && m->uni_F == 4) {  // unbound columns: quadratic halves from the pair tables, no multiplies
+            if (m->lazy_width == 1 && m->d_pair && m->uni_F == 4 && !m->onehot->wide) {  // unbound columns: quadratic halves from the pair tables, no multiplies
                 LazyPairArgs pa;
                 pa.idx = m->onehot->idx;
                 pa.pair = m->d_pair;
@@ -1493,6 +1494,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             ba.rho[k] = k < m->bool_rho.size() ? m->bool_rho[k] : Fr::zero();
         }
         ba.idx = m->onehot ? m->onehot->idx : nullptr;
+        ba.wide = m->onehot ? m->onehot->wide : 0u;
         ba.branch = m->d_branch[m->branch_cur];
         ba.cycles0 = m->onehot ? m->onehot->cycles : 0;
         ba.width = m->lazy_width;
@@ -2148,7 +2150,7 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
             OneHotDense o;
             for (int i = 0; i < kMaxBatchTables; ++i) o.out[i] = i == 0 ? t->data() : nullptr;
             hipLaunchKernelGGL(k_onehot_materialize, dim3((unsigned)((m->len + kBlock - 1) / kBlock), 1), dim3(kBlock), 0, ctx->stream,
-                               (const Fr*)m->d_branch[m->branch_cur], per_poly, (const uint8_t*)src->idx, src->cycles, m->lazy_width, src->k, k, o);
+                               (const Fr*)m->d_branch[m->branch_cur], per_poly, (const uint8_t*)src->idx, src->cycles, m->lazy_width, src->k, k, o, src->wide);
             tp.p[1 + k] = t->data();
         }
     } else {

@@ -259,12 +259,12 @@ __global__ __launch_bounds__(128) void k_rows_fold_lanes(const G1Jac* __restrict
 }
 
 // One-hot chunks: window = chunk, key = hot row + 1 (0 = cold cycle, skipped), no signs.
-__global__ __launch_bounds__(kBlock) void k_onehot_keys(const uint8_t* __restrict__ idx, size_t n, uint32_t width_log, uint32_t K,
+__global__ __launch_bounds__(kBlock) void k_onehot_keys(const uint8_t* __restrict__ idx, uint32_t wide, size_t n, uint32_t width_log, uint32_t K,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ hist) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < n;
-    uint8_t v = live ? idx[i] : kOneHotCold;
-    uint32_t mag = v == kOneHotCold ? 0u : (uint32_t)v + 1;
+    const uint32_t v = live ? hot_load(idx, i, wide) : kColdIdx;
+    uint32_t mag = v == kColdIdx ? 0u : v + 1;
     if (live) keys[i] = mag;
     const uint32_t slot = (uint32_t)((i >> width_log) * (K + 1) + mag);
     WaveAgg ag = wave_aggregate(slot, mag != 0);
@@ -499,8 +499,8 @@ extern "C" int32_t jolt_dory_commit_onehot(jolt_ctx* ctx, const jolt_srs* srs, c
         if (e == hipSuccess) e = hipMemsetAsync(w.hcnt, 0, 256, st);
         if (e == hipSuccess) e = hipMemsetAsync(w.buckets, 0, VB * sizeof(G1Jac), st);
         if (e != hipSuccess) return hip_fail(ctx, "dory one-hot", e);
-        const uint8_t* idx = source->idx + poly * source->cycles + c0 * chunk_width;
-        hipLaunchKernelGGL(k_onehot_keys, dim3((unsigned)((nvals + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, idx, nvals, (uint32_t)wl, K, w.keys, w.hist);
+        const uint8_t* idx = source->idx + ((poly * source->cycles + c0 * chunk_width) << source->wide);
+        hipLaunchKernelGGL(k_onehot_keys, dim3((unsigned)((nvals + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, idx, source->wide, nvals, (uint32_t)wl, K, w.keys, w.hist);
         launch_bucket_sums(ctx, w, srs->pts, V, chunk_width, K, p);
         hipLaunchKernelGGL(k_onehot_emit, dim3((unsigned)((V * K + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const G1Jac*)w.buckets, K, V * K, w.out);
         e = hipGetLastError();

@@ -36,6 +36,33 @@ extern "C" int32_t jolt_onehot_upload(jolt_ctx* ctx, const uint8_t* indices, siz
     return JOLT_OK;
 }
 
+// 16-bit hot indices: k up to 65535 with 0xFFFF = cold -- the K = 256 chunks of log T >= 25 (crates/jolt-prover/src/config.rs:175-186), where
+// index 255 is a valid address and the one-byte cold marker is not available
+extern "C" int32_t jolt_onehot_upload16(jolt_ctx* ctx, const uint16_t* indices, size_t n_polys, size_t cycles, uint32_t k, jolt_onehot** out) {
+    if (!ctx || !indices || !out || n_polys == 0 || cycles == 0) return JOLT_ERR_INVALID_ARG;
+    if (k == 0 || k > 1024) return JOLT_ERR_UNSUPPORTED;  // consumers keep K field elements in LDS; the reference never exceeds K = 256 chunks
+    for (size_t i = 0; i < n_polys * cycles; ++i)
+        if (indices[i] != kOneHotCold16 && indices[i] >= k) { ctx->last_error = "hot index outside the scale table"; return JOLT_ERR_INVALID_ARG; }
+    jolt_onehot* s = new (std::nothrow) jolt_onehot();
+    if (!s) return JOLT_ERR_OOM;
+    s->ctx = ctx;
+    s->n_polys = n_polys;
+    s->cycles = cycles;
+    s->k = k;
+    s->wide = 1;
+    hipError_t e = hipMalloc((void**)&s->idx, n_polys * cycles * 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->idx, indices, n_polys * cycles * 2, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("onehot upload: ") + hipGetErrorString(e);
+        if (s->idx) (void)hipFree(s->idx);
+        delete s;
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    *out = s;
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_onehot_free(jolt_ctx* ctx, jolt_onehot* s) {
     if (!s) return JOLT_OK;
     jolt_ctx* c = ctx ? ctx : s->ctx;
@@ -56,7 +83,7 @@ extern "C" int32_t jolt_onehot_materialize(jolt_ctx* ctx, const jolt_onehot* s, 
     OneHotDense o;
     for (int i = 0; i < kMaxBatchTables; ++i) o.out[i] = i == 0 ? t->data() : nullptr;
     hipLaunchKernelGGL(k_onehot_materialize, dim3((unsigned)((s->cycles + kBlock - 1) / kBlock), 1), dim3(kBlock), 0, ctx->stream, (const Fr*)scale_table->data(),
-                       (size_t)0, (const uint8_t*)s->idx, s->cycles, 1u, s->k, poly, o);
+                       (size_t)0, (const uint8_t*)s->idx, s->cycles, 1u, s->k, poly, o, s->wide);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     *out = t;
@@ -68,7 +95,7 @@ extern "C" int32_t jolt_onehot_pushforward(jolt_ctx* ctx, const jolt_onehot* s, 
     if (!ctx || !s || !weights || !out) return JOLT_ERR_INVALID_ARG;
     if (weights->len != s->cycles) return JOLT_ERR_SIZE_MISMATCH;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
-    const bool lanes = s->k <= 32;  // per-lane buckets in LDS (K * 2 KiB per wavefront): every column the reference folds this way has K = 16
+    const bool lanes = s->k <= 32 && !s->wide;  // per-lane buckets in LDS (K * 2 KiB per wavefront): every column the reference folds this way has K = 16
     size_t per_block = 4096;        // cycles per wavefront: 64 per lane
     while ((s->cycles + per_block - 1) / per_block > 1024) per_block *= 2;
     const int nblocks = lanes ? (int)std::max<size_t>(1, (s->cycles + per_block - 1) / per_block)
@@ -81,7 +108,7 @@ extern "C" int32_t jolt_onehot_pushforward(jolt_ctx* ctx, const jolt_onehot* s, 
         hipLaunchKernelGGL(k_onehot_pushforward_lanes, dim3((unsigned)s->n_polys, nblocks), dim3(64), (size_t)s->k * 2 * 64 * sizeof(uint4), ctx->stream,
                            (const uint8_t*)s->idx, (const Fr*)weights->data(), s->cycles, s->k, per_block, ctx->d_partials);
     else
-        hipLaunchKernelGGL(k_onehot_pushforward, dim3(nblocks, (unsigned)s->n_polys), dim3(kBlock), s->k * sizeof(Fr), ctx->stream, (const uint8_t*)s->idx,
+        hipLaunchKernelGGL(k_onehot_pushforward, dim3(nblocks, (unsigned)s->n_polys), dim3(kBlock), s->k * sizeof(Fr), ctx->stream, (const uint8_t*)s->idx, s->wide,
                            (const Fr*)weights->data(), s->cycles, s->k, ctx->d_partials);
     hipLaunchKernelGGL(k_onehot_pushforward_reduce, dim3((s->k + kBlock - 1) / kBlock, (unsigned)s->n_polys), dim3(kBlock), 0, ctx->stream,
                        (const Fr*)ctx->d_partials, nblocks, s->k, t->data());
@@ -162,35 +189,43 @@ struct ChunkShifts {
 // Sentinel-packed address fields (InstructionCycleRow::{pc_plus_one, ram_address_plus_one}, optimized/instruction_read_raf.rs:82-123):
 // 0 = no access (cold), v > 0 = address v - 1; chunk p = ((v - 1) >> shift[p]) & mask.  Fields of up to 16 bytes.
 static __global__ __launch_bounds__(kBlock) void k_rows_sentinel_to_hot_indices(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset,
-                                                                                uint32_t width, ChunkShifts sh, uint32_t log_k, size_t cycles, uint8_t* __restrict__ idx) {
+                                                                                uint32_t width, ChunkShifts sh, uint32_t log_k, size_t cycles, uint8_t* __restrict__ idx, uint32_t wide) {
     size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t p = blockIdx.y;
     if (j >= cycles) return;
+    auto put = [&](uint32_t v, bool cold) {
+        if (wide) reinterpret_cast<uint16_t*>(idx)[p * cycles + j] = cold ? kOneHotCold16 : (uint16_t)v;
+        else idx[p * cycles + j] = cold ? kOneHotCold : (uint8_t)v;
+    };
     uint64_t lo = 0, hi = 0;
     if (j < n_rows) {
         const uint8_t* f = rows + j * row_bytes + offset;
         lo = load_le(f, width < 8 ? width : 8);
         if (width > 8) hi = load_le(f + 8, width - 8);
     }
-    if ((lo | hi) == 0) { idx[p * cycles + j] = kOneHotCold; return; }
+    if ((lo | hi) == 0) { put(0, true); return; }
     if (lo == 0) hi -= 1;  // borrow
     lo -= 1;
     const uint32_t s = sh.shift[p];
     uint64_t v = s < 64 ? (lo >> s) | (s ? hi << (64 - s) : 0ull) : hi >> (s - 64);
-    idx[p * cycles + j] = (uint8_t)(v & ((1u << log_k) - 1));
+    put((uint32_t)(v & ((1u << log_k) - 1)), false);
 }
 static __global__ __launch_bounds__(kBlock) void k_rows_to_hot_indices(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width,
-                                                                       ChunkShifts sh, uint32_t log_k, size_t valid_offset, uint8_t* __restrict__ idx) {
+                                                                       ChunkShifts sh, uint32_t log_k, size_t valid_offset, uint8_t* __restrict__ idx, uint32_t wide) {
     size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t p = blockIdx.y;
     if (j >= n_rows) return;
     const uint8_t* row = rows + j * row_bytes;
-    if (valid_offset != ~(size_t)0 && row[valid_offset] == 0) { idx[p * n_rows + j] = kOneHotCold; return; }
+    auto put = [&](uint32_t v, bool cold) {
+        if (wide) reinterpret_cast<uint16_t*>(idx)[p * n_rows + j] = cold ? kOneHotCold16 : (uint16_t)v;
+        else idx[p * n_rows + j] = cold ? kOneHotCold : (uint8_t)v;
+    };
+    if (valid_offset != ~(size_t)0 && row[valid_offset] == 0) { put(0, true); return; }
     // (field >> shift) & mask on a little-endian field of up to 16 bytes: the chunk spans at most two bytes for log_k <= 8
     const uint32_t s = sh.shift[p], byte = s >> 3, bit = s & 7;
     uint32_t v = byte < width ? row[offset + byte] : 0u;
     if (byte + 1 < width) v |= (uint32_t)row[offset + byte + 1] << 8;
-    idx[p * n_rows + j] = (uint8_t)((v >> bit) & ((1u << log_k) - 1));
+    put((v >> bit) & ((1u << log_k) - 1), false);
 }
 }  // namespace
 
@@ -239,7 +274,7 @@ extern "C" int32_t jolt_table_from_rows(jolt_ctx* ctx, const jolt_rows* rows, si
 extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
                                          uint32_t log_k, size_t valid_offset, jolt_onehot** out) {
     if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
-    if (log_k == 0 || log_k > 7 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;  // k <= 128 < 0xFF
+    if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;  // log_k = 8: 16-bit indices
     if (valid_offset != ~(size_t)0 && valid_offset >= rows->row_bytes) return JOLT_ERR_INVALID_ARG;
     ChunkShifts sh;
     for (size_t p = 0; p < (size_t)kMaxBatchTables; ++p) {
@@ -253,10 +288,11 @@ extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, s
     s->n_polys = n_polys;
     s->cycles = rows->n_rows;
     s->k = 1u << log_k;
-    hipError_t e = hipMalloc((void**)&s->idx, n_polys * rows->n_rows);
+    s->wide = log_k > 7 ? 1u : 0u;
+    hipError_t e = hipMalloc((void**)&s->idx, (n_polys * rows->n_rows) << s->wide);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rows_to_hot_indices, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock), (unsigned)n_polys), dim3(kBlock), 0, ctx->stream,
-                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, valid_offset, s->idx);
+                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, valid_offset, s->idx, s->wide);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -290,7 +326,7 @@ extern "C" int32_t jolt_table_from_rows_window(jolt_ctx* ctx, const jolt_rows* r
 extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
                                                   uint32_t log_k, size_t cycles, jolt_onehot** out) {
     if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
-    if (log_k == 0 || log_k > 7 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;
+    if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;
     if (rows->n_rows > cycles || cycles == 0) return JOLT_ERR_SIZE_MISMATCH;
     ChunkShifts sh;
     for (size_t p = 0; p < (size_t)kMaxBatchTables; ++p) {
@@ -304,10 +340,11 @@ extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows
     s->n_polys = n_polys;
     s->cycles = cycles;
     s->k = 1u << log_k;
-    hipError_t e = hipMalloc((void**)&s->idx, n_polys * cycles);
+    s->wide = log_k > 7 ? 1u : 0u;
+    hipError_t e = hipMalloc((void**)&s->idx, (n_polys * cycles) << s->wide);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rows_sentinel_to_hot_indices, dim3((unsigned)((cycles + kBlock - 1) / kBlock), (unsigned)n_polys), dim3(kBlock), 0, ctx->stream,
-                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, cycles, s->idx);
+                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, cycles, s->idx, s->wide);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -324,7 +361,17 @@ extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows
 extern "C" int32_t jolt_onehot_download(jolt_ctx* ctx, const jolt_onehot* s, uint8_t* out) {
     if (!ctx || !s || !out) return JOLT_ERR_INVALID_ARG;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    if (s->wide) { ctx->last_error = "16-bit source: use jolt_onehot_download16"; return JOLT_ERR_INVALID_ARG; }
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(out, s->idx, s->n_polys * s->cycles, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_onehot_download16(jolt_ctx* ctx, const jolt_onehot* s, uint16_t* out) {
+    if (!ctx || !s || !out) return JOLT_ERR_INVALID_ARG;
+    if (!s->wide) { ctx->last_error = "8-bit source: use jolt_onehot_download"; return JOLT_ERR_INVALID_ARG; }
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(out, s->idx, s->n_polys * s->cycles * 2, hipMemcpyDeviceToHost, ctx->stream));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return JOLT_OK;
 }

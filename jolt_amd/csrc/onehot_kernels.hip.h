@@ -9,12 +9,12 @@ namespace jolt {
 
 // value(p, j) at branch width `width` (lazy_ra.rs:184-209 `gather`):
 //   sum_{off < width} branch[off * K + index(p, j * width + off)]        (cold cycles contribute nothing)
-__device__ __forceinline__ Fr onehot_gather(const Fr* __restrict__ branch, const uint8_t* __restrict__ idx, uint32_t width, uint32_t K, size_t j) {
+// idx = the column's first entry; wide = 1 for 16-bit indices
+__device__ __forceinline__ Fr onehot_gather(const Fr* __restrict__ branch, const uint8_t* __restrict__ idx, uint32_t width, uint32_t K, size_t j, uint32_t wide = 0) {
     Fr sum = Fr::zero();
-    const uint8_t* p = idx + j * width;
     for (uint32_t off = 0; off < width; ++off) {
-        uint8_t k = p[off];
-        if (k != kOneHotCold) sum = add(sum, ld_fr(branch + (size_t)off * K + k));
+        const uint32_t k = hot_load(idx, j * width + off, wide);
+        if (k != kColdIdx) sum = add(sum, ld_fr(branch + (size_t)off * K + k));
     }
     return sum;
 }
@@ -44,37 +44,37 @@ struct OneHotDense {
     Fr* out[kMaxBatchTables];
 };
 static __global__ __launch_bounds__(kBlock) void k_onehot_materialize(const Fr* __restrict__ branch, size_t per_poly, const uint8_t* __restrict__ idx, size_t cycles,
-                                                                     uint32_t width, uint32_t K, size_t first_poly, OneHotDense o) {
+                                                                     uint32_t width, uint32_t K, size_t first_poly, OneHotDense o, uint32_t wide = 0) {
     const size_t p = blockIdx.y;
     size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= cycles / width) return;
-    st_fr(o.out[p] + j, onehot_gather(branch + (first_poly + p) * per_poly, idx + (first_poly + p) * cycles, width, K, j));
+    st_fr(o.out[p] + j, onehot_gather(branch + (first_poly + p) * per_poly, hot_col(idx, (first_poly + p) * cycles, wide), width, K, j, wide));
 }
 
 // Pushforward tables (optimized/booleanity.rs:24-31): G_p[k] = sum_j w[j] * [index(p, j) == k].  One block accumulates a
 // slice of the cycles into K buckets in LDS (one owner lane per bucket and pass: no atomics on 256-bit values), partial
 // tables are summed by k_onehot_pushforward_reduce.  blockIdx.y = polynomial.
-static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward(const uint8_t* __restrict__ idx, const Fr* __restrict__ w, size_t cycles, uint32_t K,
+static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward(const uint8_t* __restrict__ idx, uint32_t wide, const Fr* __restrict__ w, size_t cycles, uint32_t K,
                                                                      Fr* __restrict__ partials /* [poly][block][K] */) {
     extern __shared__ unsigned char smem_raw[];
     Fr* buckets = reinterpret_cast<Fr*>(smem_raw);  // K entries
     const size_t p = blockIdx.y;
     for (uint32_t k = threadIdx.x; k < K; k += kBlock) buckets[k] = Fr::zero();
     __syncthreads();
-    const uint8_t* col = idx + p * cycles;
+    const uint8_t* col = hot_col(idx, p * cycles, wide);
     const size_t per_block = (cycles + gridDim.x - 1) / gridDim.x;
     const size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < cycles ? lo + per_block : cycles;
     // lane k owns bucket k: every lane scans the block's slice in chunks of kBlock cycles staged through LDS indices
-    __shared__ uint8_t s_idx[kBlock];
+    __shared__ uint32_t s_idx[kBlock];
     for (size_t base = lo; base < hi; base += kBlock) {
         size_t j = base + threadIdx.x;
-        s_idx[threadIdx.x] = j < hi ? col[j] : kOneHotCold;
+        s_idx[threadIdx.x] = j < hi ? hot_load(col, j, wide) : kColdIdx;
         __syncthreads();
         const size_t n = hi - base < (size_t)kBlock ? hi - base : (size_t)kBlock;
         for (uint32_t k = threadIdx.x; k < K; k += kBlock) {
             Fr acc = buckets[k];
             for (size_t t = 0; t < n; ++t)
-                if (s_idx[t] == (uint8_t)k) acc = add(acc, ld_fr(w + base + t));
+                if (s_idx[t] == (uint32_t)k) acc = add(acc, ld_fr(w + base + t));
             buckets[k] = acc;
         }
         __syncthreads();
@@ -154,6 +154,7 @@ static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward_reduce(con
 // sums as k_split_eq_uniform<F> over dense tables, with every (lo, hi) pair gathered (lazy_ra.rs:116-149 lo_hi_all).
 struct LazyArgs {
     const uint8_t* idx;   // [poly][cycles0]
+    uint32_t wide;        // 16-bit indices (K > 255)
     const Fr* branch;     // [poly][width * K]
     size_t cycles0;       // unbound cycle count (row stride of idx)
     uint32_t width, K;
@@ -178,8 +179,8 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy(LazyArg
 #pragma unroll
         for (int k = 0; k < F; ++k) {
             const size_t p = (size_t)v * F + k;
-            lo[k] = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row);
-            hi[k] = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row + 1);
+            lo[k] = onehot_gather(a.branch + p * per_poly, hot_col(a.idx, p * a.cycles0, a.wide), a.width, a.K, 2 * row, a.wide);
+            hi[k] = onehot_gather(a.branch + p * per_poly, hot_col(a.idx, p * a.cycles0, a.wide), a.width, a.K, 2 * row + 1, a.wide);
         }
         Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
         if (!a.coeff_one[v]) w = mul(w, a.coeff[v]);
@@ -261,6 +262,7 @@ struct BooleanityArgs {
     int n;
     // lazy state
     const uint8_t* idx;
+    uint32_t wide;
     const Fr* branch;
     size_t cycles0;
     uint32_t width, K;
@@ -277,8 +279,8 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_booleanity(Booleanit
         for (int i = 0; i < a.n; ++i) {
             Fr h0, h1;
             if constexpr (LAZY) {
-                h0 = onehot_gather(a.branch + (size_t)i * per_poly, a.idx + (size_t)i * a.cycles0, a.width, a.K, 2 * row);
-                h1 = onehot_gather(a.branch + (size_t)i * per_poly, a.idx + (size_t)i * a.cycles0, a.width, a.K, 2 * row + 1);
+                h0 = onehot_gather(a.branch + (size_t)i * per_poly, hot_col(a.idx, (size_t)i * a.cycles0, a.wide), a.width, a.K, 2 * row, a.wide);
+                h1 = onehot_gather(a.branch + (size_t)i * per_poly, hot_col(a.idx, (size_t)i * a.cycles0, a.wide), a.width, a.K, 2 * row + 1, a.wide);
             } else {
                 h0 = ld_fr(a.tabs[i] + 2 * row);
                 h1 = ld_fr(a.tabs[i] + 2 * row + 1);
@@ -305,8 +307,8 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy_rows(La
     const size_t per_poly = (size_t)a.width * a.K;
     auto load = [&](int v, int k, size_t row, Fr& lo, Fr& hi) {
         const size_t p = (size_t)v * F + k;
-        lo = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row);
-        hi = onehot_gather(a.branch + p * per_poly, a.idx + p * a.cycles0, a.width, a.K, 2 * row + 1);
+        lo = onehot_gather(a.branch + p * per_poly, hot_col(a.idx, p * a.cycles0, a.wide), a.width, a.K, 2 * row, a.wide);
+        hi = onehot_gather(a.branch + p * per_poly, hot_col(a.idx, p * a.cycles0, a.wide), a.width, a.K, 2 * row + 1, a.wide);
     };
     uniform_rows_body<F>(load, a.V, a.coeff, a.coeff_one, e_out, e_in, in_bits, rows, acc);
     block_reduce_store<F>(acc, partials);

@@ -32,25 +32,25 @@ constexpr int kGridSumBlocks = 512;  // workgroups per column: 2048 wavefront pa
 // partial[(p * gridDim.x + block) * 4 + wave] = sum over this wavefront's cycles of bases[hot_p(j) * T + j]
 // (lo, hi): the cycle range this launch sums -- the whole column, or one rank's block of a sharded commitment
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_grid_onehot_sum(
-    const uint8_t* __restrict__ idx, size_t grid_cycles, size_t lo, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial) {
+    const uint8_t* __restrict__ idx, uint32_t wide, size_t grid_cycles, size_t lo, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial) {
     const size_t p = blockIdx.y;
-    const uint8_t* col = idx + p * grid_cycles;
+    const uint8_t* col = hot_col(idx, p * grid_cycles, wide);
     const size_t stride = (size_t)gridDim.x * kBlock;
     G1Jac acc = g1_identity();
     // software pipeline as in sum_bucket_points<true>: the next index byte and point are in flight during the mixed addition
     size_t j = lo + (size_t)blockIdx.x * kBlock + threadIdx.x;
-    uint8_t a = j < cycles ? col[j] : kOneHotCold;
+    uint32_t a = j < cycles ? hot_load(col, j, wide) : kColdIdx;
     G1Affine pt;
     pt.x = Fq::zero();
     pt.y = Fq::zero();
-    if (a != kOneHotCold) pt = ld_aff(bases + (size_t)a * grid_cycles + j);
+    if (a != kColdIdx) pt = ld_aff(bases + (size_t)a * grid_cycles + j);
     while (j < cycles) {
         const size_t jn = j + stride;
-        uint8_t an = jn < cycles ? col[jn] : kOneHotCold;
+        const uint32_t an = jn < cycles ? hot_load(col, jn, wide) : kColdIdx;
         G1Affine pn;
         pn.x = Fq::zero();
         pn.y = Fq::zero();
-        if (an != kOneHotCold) pn = ld_aff(bases + (size_t)an * grid_cycles + jn);
+        if (an != kColdIdx) pn = ld_aff(bases + (size_t)an * grid_cycles + jn);
         acc = g1_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
         pt = pn;
         j = jn;
@@ -71,6 +71,7 @@ constexpr int kJointMaxSources = 4;
 constexpr int kJointMaxDense = 8;
 struct JointArgs {
     const uint8_t* idx[kJointMaxSources];  // [polys of the source][cycles]
+    uint32_t wide[kJointMaxSources];
     uint32_t n_polys[kJointMaxSources];
     uint32_t first[kJointMaxSources];      // offset of the source's first polynomial in `scalars`
     int n_sources;
@@ -86,9 +87,8 @@ __global__ __launch_bounds__(kBlock) void k_grid_joint(JointArgs a, const Fr* __
     if (j >= cycles) return;
     Fr acc = Fr::zero();
     for (int s = 0; s < a.n_sources; ++s) {
-        const uint8_t* col = a.idx[s] + j;
         for (uint32_t p = 0; p < a.n_polys[s]; ++p)
-            if (col[(size_t)p * cycles] == k && k != kOneHotCold) acc = add(acc, scalars[a.first[s] + p]);  // scalar (wave-uniform) load of the coefficient
+            if (hot_load(a.idx[s], (size_t)p * cycles + j, a.wide[s]) == k) acc = add(acc, scalars[a.first[s] + p]);  // scalar (wave-uniform) load of the coefficient
     }
     if (k == 0)
         for (int d = 0; d < a.n_dense; ++d) {
@@ -170,7 +170,7 @@ extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* 
     JOLT_TRY(jolt_internal_dev_alloc(ctx, N * per_col * sizeof(G1Jac), (void**)&partial));
     int32_t st = jolt_internal_dev_alloc(ctx, N * sizeof(G1Jac), (void**)&sums);
     if (st != JOLT_OK) { jolt_internal_dev_free(ctx, partial); return st; }
-    hipLaunchKernelGGL(k_grid_onehot_sum, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, T, cycle_lo, cycle_hi, (const G1Affine*)srs->pts, partial);
+    hipLaunchKernelGGL(k_grid_onehot_sum, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo, cycle_hi, (const G1Affine*)srs->pts, partial);
     hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)N), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, sums, N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);
@@ -194,6 +194,7 @@ extern "C" int32_t jolt_grid_joint_polynomial(jolt_ctx* ctx, const jolt_onehot* 
         if (sources[s]->cycles != T) return JOLT_ERR_SIZE_MISMATCH;
         if (sources[s]->k > K) return JOLT_ERR_SIZE_MISMATCH;  // a hot address outside the grid
         a.idx[s] = sources[s]->idx;
+        a.wide[s] = sources[s]->wide;
         a.n_polys[s] = (uint32_t)sources[s]->n_polys;
         a.first[s] = (uint32_t)total;
         total += sources[s]->n_polys;

@@ -30,7 +30,6 @@ int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t resu
 namespace {
 
 constexpr uint64_t kNoAccess = 0xFFFFFFFFFFFFFFFFull;  // ram_trace.rs:22
-constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 
 // one state of the matrix (structure of arrays); cycle phase: key = row << 32 | col, checkpoints raw u64; address phase: key = col,
 // checkpoints promoted to Fr (CycleMajorEntry / AddressMajorEntry, rw_matrix.rs:26-55)

@@ -635,7 +635,7 @@ class Rows:
         _ck(lib().jolt_onehot_from_rows(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), sh, C.c_size_t(len(shifts)), C.c_uint32(log_k), vo, C.byref(h)),
             "jolt_onehot_from_rows", self.ctx)
         src = OneHot.__new__(OneHot)
-        src.ctx, src.n_polys, src.cycles, src.k, src.h = self.ctx, len(shifts), self.n_rows, 1 << log_k, h
+        src.ctx, src.n_polys, src.cycles, src.k, src.h, src.wide = self.ctx, len(shifts), self.n_rows, 1 << log_k, h, log_k > 7
         return src
 
     def free(self):
@@ -682,17 +682,21 @@ class OneHot:
     """Hot indices of N one-hot selector columns (uint8 [n_polys, cycles], 0xFF = cold cycle) resident on the device."""
 
     def __init__(self, ctx, indices, k):
-        idx = np.ascontiguousarray(indices, dtype=np.uint8)
+        """indices: uint8 (0xFF = cold, k <= 255) or uint16 (0xFFFF = cold: the K = 256 chunks of long traces)"""
+        wide = np.asarray(indices).dtype == np.uint16
+        idx = np.ascontiguousarray(indices, dtype=np.uint16 if wide else np.uint8)
         assert idx.ndim == 2
-        self.ctx, self.n_polys, self.cycles, self.k = ctx, idx.shape[0], idx.shape[1], k
+        self.ctx, self.n_polys, self.cycles, self.k, self.wide = ctx, idx.shape[0], idx.shape[1], k, wide
         h = C.c_void_p()
-        _ck(lib().jolt_onehot_upload(ctx.h, idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), C.c_size_t(idx.shape[1]), C.c_uint32(k), C.byref(h)),
-            "jolt_onehot_upload", ctx)
+        fn = lib().jolt_onehot_upload16 if wide else lib().jolt_onehot_upload
+        _ck(fn(ctx.h, idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), C.c_size_t(idx.shape[1]), C.c_uint32(k), C.byref(h)), "jolt_onehot_upload", ctx)
         self.h = h
 
     def download(self):
-        out = np.empty((self.n_polys, self.cycles), dtype=np.uint8)
-        _ck(lib().jolt_onehot_download(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)), "jolt_onehot_download", self.ctx)
+        wide = self.wide
+        out = np.empty((self.n_polys, self.cycles), dtype=np.uint16 if wide else np.uint8)
+        fn = lib().jolt_onehot_download16 if wide else lib().jolt_onehot_download
+        _ck(fn(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)), "jolt_onehot_download", self.ctx)
         return out
 
     def materialize(self, poly, scale_table):
@@ -983,7 +987,7 @@ def _rows_onehot_sentinel(self, offset, width, shifts, log_k, cycles=None):
     _ck(lib().jolt_onehot_from_rows_sentinel(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), sh, C.c_size_t(len(shifts)), C.c_uint32(log_k),
                                              C.c_size_t(cycles), C.byref(h)), "jolt_onehot_from_rows_sentinel", self.ctx)
     src = OneHot.__new__(OneHot)
-    src.ctx, src.n_polys, src.cycles, src.k, src.h = self.ctx, len(shifts), cycles, 1 << log_k, h
+    src.ctx, src.n_polys, src.cycles, src.k, src.h, src.wide = self.ctx, len(shifts), cycles, 1 << log_k, h, log_k > 7
     return src
 
 

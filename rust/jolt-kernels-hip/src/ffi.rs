@@ -226,6 +226,8 @@ extern "C" {
     pub fn jolt_host_fr_wide_dot(a: *const jolt_fr_t, b: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_table_dot(ctx: *mut jolt_ctx, a: *const jolt_table, b: *const jolt_table, deferred: i32, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_onehot_upload(ctx: *mut jolt_ctx, indices: *const u8, n_polys: usize, cycles: usize, k: u32, out: *mut *mut jolt_onehot) -> i32;
+    pub fn jolt_onehot_upload16(ctx: *mut jolt_ctx, indices: *const u16, n_polys: usize, cycles: usize, k: u32, out: *mut *mut jolt_onehot) -> i32;
+    pub fn jolt_onehot_download16(ctx: *mut jolt_ctx, source: *const jolt_onehot, out: *mut u16) -> i32;
     pub fn jolt_onehot_free(ctx: *mut jolt_ctx, source: *mut jolt_onehot) -> i32;
     pub fn jolt_onehot_materialize(ctx: *mut jolt_ctx, source: *const jolt_onehot, poly: usize, scale_table: *const jolt_table, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_onehot_pushforward(ctx: *mut jolt_ctx, source: *const jolt_onehot, weights: *const jolt_table, out: *mut *mut jolt_table) -> i32;

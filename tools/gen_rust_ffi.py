@@ -16,7 +16,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 HEADER = os.path.join(ROOT, "include", "jolt_hip.h")
 FFI_RS = os.path.join(ROOT, "rust", "jolt-kernels-hip", "src", "ffi.rs")
 
-SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "size_t": "usize", "float": "f32",
+SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "size_t": "usize", "float": "f32",
            "void": "c_void", "char": "c_char"}
 OPAQUE = ["jolt_ctx", "jolt_table", "jolt_member", "jolt_srs", "jolt_batch", "jolt_split_lt", "jolt_onehot", "jolt_rows", "jolt_ints", "jolt_comm", "jolt_shm", "jolt_rw_matrix"]
 FNPTR = {"jolt_local_round_fn", "jolt_gather_fn", "jolt_round_transcript_fn"}
