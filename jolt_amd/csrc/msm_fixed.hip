@@ -36,8 +36,14 @@ struct MsmJob {
 
 namespace {
 
-constexpr int kLoBits = 9;              // buckets per segment = 512
-constexpr int kSegBuckets = 1 << kLoBits;
+// buckets per segment = 2^LO: 512 up to 24-bit windows, 2048 for 25/26-bit windows (keeps the partition at <= 16385 bins of LDS)
+constexpr int kLoBitsMin = 9;
+static inline int fx_lo_bits(int c) { return c > 24 ? 11 : 9; }
+// list-length classes of the bucket order: exact lengths up to kClasses - 1; empty and heavy buckets share class 0 (no light work)
+constexpr uint32_t kClasses = 512;
+__device__ __forceinline__ uint32_t bucket_class(uint32_t count, uint32_t heavy_threshold) {
+    return count > heavy_threshold ? 0u : (count < kClasses ? count : kClasses - 1);
+}
 
 // next[i] = 2^c * prev[i]
 __global__ __launch_bounds__(kBlock) void k_fx_next_window(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next, size_t n, int c) {
@@ -49,6 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_fx_next_window(const G1Affine* __res
 }
 
 // ---- 2. partition by the high bits of |digit| ------------------------------------------------------------------------------
+template <int LO>
 __global__ __launch_bounds__(kSortBlock) void k_fx_hist(const uint32_t* __restrict__ keys, size_t total, uint32_t nb1, uint32_t* __restrict__ hist1) {
     extern __shared__ uint32_t fx_sh[];
     for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
@@ -57,8 +64,8 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist(const uint32_t* __restri
     for (size_t base = lo; base < hi; base += kSortBlock) {  // whole wavefronts walk the loop together (ballots inside)
         size_t k = base + threadIdx.x;
         uint32_t mag = k < hi ? keys[k] & 0x7FFFFFFFu : 0u;
-        WaveAgg ag = wave_aggregate(mag >> kLoBits, mag != 0);
-        if (ag.do_atomic) atomicAdd(&fx_sh[mag >> kLoBits], ag.count);
+        WaveAgg ag = wave_aggregate(mag >> LO, mag != 0);
+        if (ag.do_atomic) atomicAdd(&fx_sh[mag >> LO], ag.count);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) {
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_scan(const uint32_t* __restri
     if (threadIdx.x == kSortBlock - 1) { info[0] = smax[threadIdx.x]; info[1] = sm[threadIdx.x]; }
 }
 // entries[pos] = (low bits of |digit|) << 32 | (w * stride + i) | sign << 31, grouped by segment
+template <int LO>
 __global__ __launch_bounds__(kSortBlock) void k_fx_scatter(const uint32_t* __restrict__ keys, size_t total, size_t n, size_t stride, uint32_t nb1,
                                                           uint32_t* __restrict__ cursor1, uint64_t* __restrict__ entries) {
     extern __shared__ uint32_t fx_sh[];
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_scatter(const uint32_t* __res
     for (size_t base = lo; base < hi; base += kSortBlock) {
         size_t k = base + threadIdx.x;
         uint32_t mag = k < hi ? keys[k] & 0x7FFFFFFFu : 0u;
-        WaveAgg ag = wave_aggregate(mag >> kLoBits, mag != 0);
-        if (ag.do_atomic) atomicAdd(&fx_sh[mag >> kLoBits], ag.count);
+        WaveAgg ag = wave_aggregate(mag >> LO, mag != 0);
+        if (ag.do_atomic) atomicAdd(&fx_sh[mag >> LO], ag.count);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) {  // reserve this slice's range of every non-empty segment
@@ -117,14 +125,14 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_scatter(const uint32_t* __res
         size_t k = base + threadIdx.x;
         uint32_t key = k < hi ? keys[k] : 0u;
         uint32_t mag = key & 0x7FFFFFFFu;
-        WaveAgg ag = wave_aggregate(mag >> kLoBits, mag != 0);
+        WaveAgg ag = wave_aggregate(mag >> LO, mag != 0);
         uint32_t first = 0;
-        if (ag.do_atomic) first = atomicAdd(&fx_sh[mag >> kLoBits], ag.count);
+        if (ag.do_atomic) first = atomicAdd(&fx_sh[mag >> LO], ag.count);
         uint32_t pos = (uint32_t)__shfl((int)first, ag.src, 64) + ag.rank;
         if (mag) {
             const size_t w = k / n, i = k - w * n;
             const uint32_t value = (uint32_t)(w * stride + i) | (key & 0x80000000u);
-            entries[pos] = ((uint64_t)(mag & (kSegBuckets - 1)) << 32) | value;
+            entries[pos] = ((uint64_t)(mag & ((1u << LO) - 1)) << 32) | value;
         }
     }
 }
@@ -133,10 +141,15 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_scatter(const uint32_t* __res
 // hist[b] / offsets[b] for bucket b = seg * 512 + low bits (the layout k_msm_buckets_light / _heavy read with one "window"), the base
 // indices of every bucket contiguous in `sorted`, and one heavy-list entry per kHeavySeg points of an over-full bucket (what
 // k_msm_scan emits for the per-window method).
+template <int LO>
 __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ offs1, const uint64_t* __restrict__ entries,
                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets,
                                                            uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
-                                                           uint32_t heavy_cap) {
+                                                           uint32_t heavy_cap, uint32_t* __restrict__ class_hist) {
+    constexpr uint32_t kSegBuckets = 1u << LO;
+    __shared__ uint32_t cls[kClasses];
+    for (uint32_t b = threadIdx.x; b < kClasses; b += kBlock) cls[b] = 0;
+    constexpr uint32_t PER = kSegBuckets / kBlock;  // counts per thread in the scan
     __shared__ uint32_t cnt[kSegBuckets], cur[kSegBuckets];
     __shared__ uint32_t scan_sm[kBlock];
     const uint32_t seg = blockIdx.x;
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
     const uint32_t base = offs1[seg];
     for (uint32_t b = threadIdx.x; b < kSegBuckets; b += kBlock) cnt[b] = 0;
     __syncthreads();
-    // plain LDS atomics, four entries in flight per thread: with 512 bins same-address lanes are rare for uniform digits, and where
+    // plain LDS atomics, four entries in flight per thread: with >= 512 bins same-address lanes are rare for uniform digits, and where
     // they are not (the carry bucket of small scalars) the LDS serialises 64 lanes in about the time the ballot peeling would take
     for (uint32_t k0 = 0; k0 < total; k0 += 4 * kBlock) {
         uint64_t e[4];
@@ -158,9 +171,11 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
             if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32)], 1u);
     }
     __syncthreads();
-    {   // exclusive scan of the 512 counts: two per thread
-        const uint32_t a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
-        scan_sm[threadIdx.x] = a + b;
+    {   // exclusive scan of the counts: PER consecutive buckets per thread
+        uint32_t c_loc[PER], sum = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < PER; ++h) { c_loc[h] = cnt[PER * threadIdx.x + h]; sum += c_loc[h]; }
+        scan_sm[threadIdx.x] = sum;
         __syncthreads();
         for (int off = 1; off < kBlock; off <<= 1) {
             uint32_t v = (int)threadIdx.x >= off ? scan_sm[threadIdx.x - off] : 0;
@@ -168,14 +183,15 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
             scan_sm[threadIdx.x] += v;
             __syncthreads();
         }
-        const uint32_t excl = scan_sm[threadIdx.x] - (a + b);
-        cur[2 * threadIdx.x] = excl;
-        cur[2 * threadIdx.x + 1] = excl + a;
+        uint32_t run = scan_sm[threadIdx.x] - sum;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t slot = seg * kSegBuckets + 2 * threadIdx.x + h, c = h ? b : a, st = base + (h ? excl + a : excl);
+        for (uint32_t h = 0; h < PER; ++h) {
+            const uint32_t slot = seg * kSegBuckets + PER * threadIdx.x + h, c = c_loc[h], st = base + run;
+            cur[PER * threadIdx.x + h] = run;
+            run += c;
             hist[slot] = c;
             offsets[slot] = st;
+            atomicAdd(&cls[bucket_class(c, heavy_threshold)], 1u);
             if (c > heavy_threshold) {
                 const uint32_t nseg = (c + kHeavySeg - 1) / kHeavySeg;
                 const uint32_t first = atomicAdd(heavy_count, nseg);
@@ -187,6 +203,8 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
         }
     }
     __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kClasses; b += kBlock)
+        if (cls[b]) atomicAdd(&class_hist[b], cls[b]);
     uint32_t* out = sorted + base;
     for (uint32_t k0 = 0; k0 < total; k0 += 4 * kBlock) {
         uint64_t e[4];
@@ -201,6 +219,62 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
     }
 }
 
+
+// ---- 3b. bucket order: longest lists first, equal lengths side by side -----------------------------------------------------
+// One lane sums one bucket, so a wavefront takes as long as its fullest bucket: with Poisson-distributed list lengths (mean 88 at
+// c = 24, 2^26 terms) the 64 lanes of a wavefront idle ~22 % of the time when buckets are taken in index order.  Buckets are therefore
+// handed out in order of decreasing length (counting sort over kClasses length classes; empty and heavy buckets last), which makes the
+// trip count wave-uniform.  8 M bucket ids per MSM: noise next to the 738 M additions it balances.
+__global__ __launch_bounds__(kClasses) void k_fx_order_scan(const uint32_t* __restrict__ class_hist, uint32_t* __restrict__ class_cursor) {
+    __shared__ uint32_t sm[kClasses];
+    const uint32_t mine = class_hist[kClasses - 1 - threadIdx.x];  // thread 0 = longest class
+    sm[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < (int)kClasses; off <<= 1) {
+        uint32_t v = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += v;
+        __syncthreads();
+    }
+    class_cursor[kClasses - 1 - threadIdx.x] = sm[threadIdx.x] - mine;
+}
+constexpr uint32_t kOrderPer = 8;  // buckets per thread
+__global__ __launch_bounds__(kBlock) void k_fx_order(const uint32_t* __restrict__ hist, uint32_t n_buckets, uint32_t heavy_threshold, uint32_t* __restrict__ class_cursor,
+                                                    uint32_t* __restrict__ order) {
+    __shared__ uint32_t cls[kClasses];
+    for (uint32_t b = threadIdx.x; b < kClasses; b += kBlock) cls[b] = 0;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * (kBlock * kOrderPer);
+    uint32_t k_cls[kOrderPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kOrderPer; ++u) {
+        const uint32_t slot = first + u * kBlock + threadIdx.x;
+        k_cls[u] = slot < n_buckets ? bucket_class(hist[slot], heavy_threshold) : kClasses;
+        if (k_cls[u] < kClasses) atomicAdd(&cls[k_cls[u]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kClasses; b += kBlock) {
+        const uint32_t cnt = cls[b];
+        cls[b] = cnt ? atomicAdd(&class_cursor[b], cnt) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kOrderPer; ++u)
+        if (k_cls[u] < kClasses) order[atomicAdd(&cls[k_cls[u]], 1u)] = first + u * kBlock + threadIdx.x;
+}
+
+// ---- 4. light buckets in that order (the heavy ones keep k_msm_buckets_heavy / _heavy_combine) ---------------------------
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_fx_buckets_ordered(
+    const uint32_t* __restrict__ order, uint32_t n_buckets, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ sorted,
+    const G1Affine* __restrict__ bases, uint32_t heavy_threshold, G1Jac* __restrict__ buckets) {
+    const uint32_t gt = blockIdx.x * kBlock + threadIdx.x;
+    if (gt >= n_buckets) return;
+    const uint32_t slot = order[gt];
+    const uint32_t cnt = hist[slot];
+    if (cnt == 0 || cnt > heavy_threshold) return;  // empty: the memset identity stands; heavy: the segmented kernels own it
+    buckets[slot] = sum_bucket_points<true>(sorted + offsets[slot], bases, 0u, cnt, 1u);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -212,8 +286,9 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
     if (srs->n == 0) return JOLT_ERR_INVALID_ARG;
     int lg = 0;
     while (((size_t)2 << lg) <= srs->n) lg++;
-    int c = window_bits ? (int)window_bits : std::max(kLoBits + 1, std::min(24, lg - 2));
-    if (c <= kLoBits || c > 24) return JOLT_ERR_UNSUPPORTED;
+    // measured at 2^26 terms: c = 26 (10 windows) 104.9 ms, c = 24 (11 windows, whose 14-bit top window piles onto 2^13 buckets) 116.8 ms
+    int c = window_bits ? (int)window_bits : (lg >= 26 ? 26 : std::max(kLoBitsMin + 1, std::min(24, lg - 2)));
+    if (c <= kLoBitsMin || c > 26) return JOLT_ERR_UNSUPPORTED;
     const int W = (255 + c - 1) / c;
     if ((size_t)W * srs->n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;  // base index + sign share 32 bits
     G1Affine* pre = nullptr;
@@ -235,7 +310,8 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
     srs->pre_c = c;
     srs->pre_W = W;
     srs->pre_stride = srs->n;
-    srs->pre_min_n = min_terms ? min_terms : std::max<size_t>((size_t)1 << (c - 1), 1024);
+    // crossover against the per-window method (prefix MSMs over 2^26-point tables): 2^22 terms at c = 24, 2^24 at c = 26
+    srs->pre_min_n = min_terms ? min_terms : std::max<size_t>((size_t)1 << (c - 2), 256);
     return JOLT_OK;
 }
 
@@ -247,13 +323,15 @@ constexpr size_t kMsmHostEntries = 128;
 
 int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job) {
     const int c = srs->pre_c, W = srs->pre_W;
+    const int lo_bits = fx_lo_bits(c);
+    const uint32_t kSegBuckets = 1u << lo_bits;
     const uint32_t B = 1u << (c - 1);
-    const uint32_t nb1 = (B >> kLoBits) + 1;               // the segment of |digit| = B included
+    const uint32_t nb1 = (B >> lo_bits) + 1;               // the segment of |digit| = B included
     const size_t total = (size_t)W * n;
     if (total >= ((size_t)1 << 32)) return JOLT_ERR_UNSUPPORTED;
     const size_t n_buckets = (size_t)nb1 * kSegBuckets;    // >= B + 1
-    // reduction: sum_b b * B_b over buckets 1..B with up to 65536 threads, G buckets each
-    const uint32_t threads = (uint32_t)std::min<size_t>(B, 65536);
+    // reduction: sum_b b * B_b over buckets 1..B with up to 262144 threads, G buckets each (a serial chain of 2G additions per thread)
+    const uint32_t threads = (uint32_t)std::min<size_t>(B, 262144);
     const uint32_t nb = (threads + kBlock - 1) / kBlock;
     const uint32_t G = (B + nb * kBlock - 1) / (nb * kBlock);
     // a bucket holding more than max(kLaneCap, 4x the average) points is summed per 1024-point segment by whole wavefronts: the
@@ -267,7 +345,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const size_t o_keys = take(total * 4), o_entries = take(total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
                  o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(sizeof(G1Jac)),
                  o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
-                 o_seg = take((size_t)heavy_cap * sizeof(G1Jac));
+                 o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4);
     hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
     if (off > ctx->msm_ws_cap[lane]) {
         if (ctx->msm_ws[lane]) {
@@ -286,12 +364,15 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     uint32_t *hist1 = (uint32_t*)(ws + o_hist), *offs1 = (uint32_t*)(ws + o_offs), *cur1 = (uint32_t*)(ws + o_cur), *info = (uint32_t*)(ws + o_info);
     G1Jac *buckets = (G1Jac*)(ws + o_buckets), *part = (G1Jac*)(ws + o_part), *wsum = (G1Jac*)(ws + o_wsum), *seg = (G1Jac*)(ws + o_seg);
     uint32_t *hist = (uint32_t*)(ws + o_bhist), *offs = (uint32_t*)(ws + o_boffs), *heavy = (uint32_t*)(ws + o_heavy), *hcnt = (uint32_t*)(ws + o_hcnt);
+    uint32_t *class_hist = (uint32_t*)(ws + o_cls), *class_cursor = class_hist + kClasses, *order = (uint32_t*)(ws + o_order);
     const size_t lds_bytes = (size_t)nb1 * sizeof(uint32_t);
     if (lds_bytes > ctx->max_lds_per_block) return JOLT_ERR_UNSUPPORTED;
     if (!ctx->msm_fx_attr_set) {
-        hipError_t a1 = hipFuncSetAttribute((const void*)k_fx_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-        hipError_t a2 = hipFuncSetAttribute((const void*)k_fx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-        if (a1 != hipSuccess || a2 != hipSuccess) {
+        hipError_t a1 = hipFuncSetAttribute((const void*)k_fx_hist<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t a2 = hipFuncSetAttribute((const void*)k_fx_scatter<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t a3 = hipFuncSetAttribute((const void*)k_fx_hist<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t a4 = hipFuncSetAttribute((const void*)k_fx_scatter<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) {
             (void)hipGetLastError();
             if (lds_bytes > 64 * 1024) return JOLT_ERR_UNSUPPORTED;
         }
@@ -301,18 +382,29 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
     hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, c, W, keys, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_fx_hist, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
+    if (lo_bits == 9) hipLaunchKernelGGL(k_fx_hist<9>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
+    else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
     hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, st, (const uint32_t*)hist1, nb1, offs1, cur1, info);
     JOLT_HIP_TRY(ctx, hipGetLastError());
     JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), st));  // z = 0: identity
     JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, st));
-    hipLaunchKernelGGL(k_fx_scatter, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
-    hipLaunchKernelGGL(k_fx_segment_sort, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
-                       heavy_threshold, heavy, hcnt, heavy_cap);
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(class_hist, 0, kClasses * 4, st));
+    if (lo_bits == 9) {
+        hipLaunchKernelGGL(k_fx_scatter<9>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
+        hipLaunchKernelGGL(k_fx_segment_sort<9>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
+                           heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
+    } else {
+        hipLaunchKernelGGL(k_fx_scatter<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
+        hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
+                           heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
+    }
     // bucket sums: the kernels of the per-window method with ONE window of B buckets (bases = the window tables)
     const unsigned gh = std::min<uint32_t>((heavy_cap + 3) / 4, 4096);
-    hipLaunchKernelGGL(k_msm_buckets_light<true>, dim3((unsigned)(((size_t)B + kBlock - 1) / kBlock), 1), dim3(kBlock), 0, st, (const uint32_t*)hist, (const uint32_t*)offs,
-                       (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, 1, heavy_threshold, buckets, (size_t)1);
+    hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, st, (const uint32_t*)class_hist, class_cursor);
+    hipLaunchKernelGGL(k_fx_order, dim3((unsigned)((n_buckets + kBlock * kOrderPer - 1) / (kBlock * kOrderPer))), dim3(kBlock), 0, st, (const uint32_t*)hist, (uint32_t)n_buckets,
+                       heavy_threshold, class_cursor, order);
+    hipLaunchKernelGGL(k_fx_buckets_ordered, dim3((unsigned)((n_buckets + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets,
+                       (const uint32_t*)hist, (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets);
     hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
                        (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg);
     hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const G1Jac*)seg, buckets);

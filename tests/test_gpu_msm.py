@@ -224,9 +224,27 @@ def test_fixed_base_msm_matches_oracle_and_per_window_path(ctx):
     assert O.g1_is_identity(ctx.msm(dev, zeros))
 
 
-@pytest.mark.parametrize("window_bits", [0, 13])
+@pytest.mark.parametrize("window_bits", [25, 26])
+def test_fixed_base_msm_wide_windows_match_oracle(ctx, window_bits):
+    """25/26-bit windows (segments of 2048 buckets, 10 windows at c = 26): same points as the oracle's Pippenger on uniform, corner
+    and all-equal scalars"""
+    n_srs = 3000
+    host = O.srs_setup_from_secret(rand_fr(1, 640)[0], n_srs)
+    dev = ctx.srs_upload(host)
+    ctx.srs_precompute_windows(dev, window_bits, 1)
+    for n in (1, 65, 3000):
+        scalars = rand_fr(n, 641 + n)
+        assert same_point(ctx.msm(dev, scalars), O.g1_msm_pippenger(host[:n], scalars)), n
+    corner = O.to_mont([0, 1, R - 1, 2, R - 2, (R - 1) // 2, 1 << 253, (1 << 25) - 1, 1 << 25, (1 << 25) + 1, (1 << 26) - 1, 1 << 24, 2047, 2048, 2049])
+    assert same_point(ctx.msm(dev, corner), O.g1_msm_pippenger(host[: len(corner)], corner))
+    same = np.repeat(rand_fr(1, 650), 3000, axis=0)
+    assert same_point(ctx.msm(dev, same), O.g1_msm_pippenger(host, same))
+    dev.free()
+
+
+@pytest.mark.parametrize("window_bits", [0, 13, 26])
 def test_fixed_base_msm_at_2_20_is_the_kzg_commitment(ctx, window_bits):
-    """2^20 terms over window-precomputed bases (auto: c = 18, 15 windows; c = 13: 20 windows): commit(p) == p(beta) G, for uniform
+    """2^20 terms over window-precomputed bases (auto: c = 18, 15 windows; c = 13: 20 windows; c = 26: 10): commit(p) == p(beta) G, for uniform
     scalars (new path) and 64-bit scalars (skew fallback), and a prefix MSM of 2^19 + 5 terms."""
     n = 1 << 20
     beta = rand_fr(1, 630)[0]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fixed-base (window-precomputed) MSM vs the per-window bucket method at several sizes / window widths.
-usage: bench_msm_fixed.py <log_n> [window_bits ...]   -- prints one JSON line per measurement"""
+usage: bench_msm_fixed.py <log_n> [window_bits ...]   -- prints one JSON line per measurement
+       JOLT_BENCH_PREFIXES="20 22 24" adds prefix MSMs of those log-lengths over the same tables (per-window vs fixed-base)"""
 import json
 import os
 import sys
@@ -33,6 +34,10 @@ def main():
     srs = ctx.srs_setup_from_secret(beta, n, G1_GENERATOR)
     ctx.synchronize()
     print(json.dumps({"what": "per-window", "n": n, "ms": round(timed(ctx, srs, tab), 3)}), flush=True)
+    prefixes = [int(x) for x in os.environ.get("JOLT_BENCH_PREFIXES", "").split()]
+    tabs = {lg: ctx.eq_evals(rand_fr(lg, rng)) for lg in prefixes}
+    for lg, t in tabs.items():
+        print(json.dumps({"what": "per-window prefix", "n": 1 << lg, "ms": round(timed(ctx, srs, t), 3)}), flush=True)
     srs.free()
     for c in widths:
         srs = ctx.srs_setup_from_secret(beta, n, G1_GENERATOR)
@@ -40,6 +45,8 @@ def main():
         ctx.srs_precompute_windows(srs, c, 1)
         pre_ms = (time.perf_counter() - t0) * 1e3
         print(json.dumps({"what": "fixed-base", "n": n, "window_bits": c, "precompute_ms": round(pre_ms, 1), "ms": round(timed(ctx, srs, tab), 3)}), flush=True)
+        for lg, t in tabs.items():
+            print(json.dumps({"what": "fixed-base prefix", "n": 1 << lg, "window_bits": c, "ms": round(timed(ctx, srs, t), 3)}), flush=True)
         srs.free()
 
 
