@@ -137,6 +137,134 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_scatter(const uint32_t* __res
     }
 }
 
+// ---- 2b. the same partition in two coalesced passes (JOLT_FX_PARTITION=2, the default) ---------------------------------------
+// k_fx_scatter writes each 8-byte entry to one of 16385 open segments: with (slices x segments) write fronts nothing merges in L2 and
+// the 5.4 GB of entries go out as isolated 8-byte stores (14.6 ms at 2^26 terms, c = 26).  Here a workgroup takes a tile of 8192
+// entries, ranks them by bin with LDS atomics, lays the tile out bin-major in LDS and copies it out so that adjacent lanes write
+// adjacent addresses (runs of ~64 entries = 512 B per bin and tile): pass 1 over the 129 groups of 128 segments, pass 2 over the 128
+// segments inside each group.  Every pass reserves its output range with ONE global atomic per non-empty bin and tile.
+constexpr int kPartThreads = 1024, kPartPer = 8, kPartTile = kPartThreads * kPartPer;
+constexpr int kGroupBits = 7, kGroupBins = 1 << kGroupBits;  // segments per group
+constexpr int kPartBins = 256;                                // >= groups (129) and >= kGroupBins
+
+struct PartShared {
+    uint64_t stage[kPartTile];
+    uint32_t cnt[kPartBins], lstart[kPartBins], gbase[kPartBins], wsum[4];
+};
+
+// one tile: `item[u]` (~0 = dropped) with bin `bin[u]`; cursors[bin] are the global write positions
+__device__ __forceinline__ void partition_tile(PartShared& sh, const uint64_t (&item)[kPartPer], const uint32_t (&bin)[kPartPer], uint32_t nbins,
+                                               uint32_t* __restrict__ cursors, uint64_t* __restrict__ out, int bin_shift, uint32_t bin_mask) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < kPartBins) sh.cnt[tid] = 0;
+    __syncthreads();
+    uint32_t rank[kPartPer];
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u) rank[u] = item[u] != ~0ull ? atomicAdd(&sh.cnt[bin[u]], 1u) : 0u;
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < kPartBins) {  // exclusive scan of the bin counts: wave scans + 4 wave totals
+        v = tid < nbins ? sh.cnt[tid] : 0u;
+        incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)(tid & 63) >= off) incl += o;
+        }
+        if ((tid & 63) == 63) sh.wsum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < kPartBins) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < (tid >> 6); ++k) before += sh.wsum[k];
+        sh.lstart[tid] = before + incl - v;
+        sh.gbase[tid] = v ? atomicAdd(&cursors[tid], v) : 0u;
+    }
+    __syncthreads();
+    const uint32_t valid = sh.lstart[kPartBins - 1] + sh.cnt[kPartBins - 1];  // bins >= nbins are empty
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u)
+        if (item[u] != ~0ull) sh.stage[sh.lstart[bin[u]] + rank[u]] = item[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u) {
+        const uint32_t j = u * kPartThreads + tid;
+        if (j < valid) {
+            const uint64_t it = sh.stage[j];
+            const uint32_t b = ((uint32_t)(it >> 32) >> bin_shift) & bin_mask;
+            out[sh.gbase[b] + (j - sh.lstart[b])] = it;
+        }
+    }
+    __syncthreads();
+}
+
+// pass 1: keys -> entries grouped by segment group; entry = |digit| << 32 | (w * stride + i) | sign << 31
+template <int LO>
+__global__ __launch_bounds__(kPartThreads) void k_fx_partition_groups(const uint32_t* __restrict__ keys, size_t total, size_t n, size_t stride, uint32_t n_groups,
+                                                                     uint32_t* __restrict__ group_cursor, uint64_t* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char fx_part_raw[];
+    PartShared& sh = *reinterpret_cast<PartShared*>(fx_part_raw);
+    const size_t n_tiles = (total + kPartTile - 1) / kPartTile;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        uint64_t item[kPartPer];
+        uint32_t bin[kPartPer];
+#pragma unroll
+        for (int u = 0; u < kPartPer; ++u) {
+            const size_t k = t * kPartTile + (size_t)u * kPartThreads + threadIdx.x;
+            const uint32_t key = k < total ? keys[k] : 0u;
+            const uint32_t mag = key & 0x7FFFFFFFu;
+            const size_t w = k / n, i = k - w * n;
+            item[u] = mag ? ((uint64_t)mag << 32) | (uint32_t)(w * stride + i) | (key & 0x80000000u) : ~0ull;
+            bin[u] = mag >> (LO + kGroupBits);
+        }
+        partition_tile(sh, item, bin, n_groups, group_cursor, out, LO + kGroupBits, 0xFFFFFFFFu);
+    }
+}
+// group_cursor[g] = offset of the group's first segment
+__global__ __launch_bounds__(kPartBins) void k_fx_group_cursors(const uint32_t* __restrict__ offs1, uint32_t n_groups, uint32_t* __restrict__ group_cursor) {
+    if (threadIdx.x < n_groups) group_cursor[threadIdx.x] = offs1[threadIdx.x << kGroupBits];
+}
+// pass 2: inside every group, by segment (cursor1[segment] starts at the segment's offset)
+template <int LO>
+__global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments(const uint64_t* __restrict__ grouped, const uint32_t* __restrict__ offs1, uint32_t nb1, const uint32_t* __restrict__ info,
+                                                                       uint32_t* __restrict__ cursor1, uint64_t* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char fx_part_raw[];
+    PartShared& sh = *reinterpret_cast<PartShared*>(fx_part_raw);
+    __shared__ uint32_t tiles_before[kPartBins + 1];
+    const uint32_t n_groups = (nb1 + kGroupBins - 1) >> kGroupBits;
+    const uint32_t total = info[1];  // non-zero digits (k_fx_scan)
+    if (threadIdx.x == 0) {  // tiles of the groups, prefix-summed (129 entries: serial is fine)
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            const uint32_t lo = offs1[g << kGroupBits], hi = ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+            tiles_before[g] = run;
+            run += (hi - lo + kPartTile - 1) / kPartTile;
+        }
+        tiles_before[n_groups] = run;
+    }
+    __syncthreads();
+    const uint32_t n_tiles = tiles_before[n_groups];
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        uint32_t g_lo = 0, g_hi = n_groups;  // last group whose first tile is <= t
+        while (g_hi - g_lo > 1) {
+            const uint32_t mid = (g_lo + g_hi) >> 1;
+            if (tiles_before[mid] <= t) g_lo = mid; else g_hi = mid;
+        }
+        const uint32_t g = g_lo;
+        const uint32_t lo = offs1[g << kGroupBits], hi = ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+        const uint32_t first = lo + (t - tiles_before[g]) * kPartTile;
+        const uint32_t nbins = min((uint32_t)kGroupBins, nb1 - (g << kGroupBits));
+        uint64_t item[kPartPer];
+        uint32_t bin[kPartPer];
+#pragma unroll
+        for (int u = 0; u < kPartPer; ++u) {
+            const uint32_t k = first + u * kPartThreads + threadIdx.x;
+            item[u] = k < hi ? grouped[k] : ~0ull;
+            bin[u] = ((uint32_t)(item[u] >> 32) >> LO) & (kGroupBins - 1);
+        }
+        partition_tile(sh, item, bin, nbins, cursor1 + (g << kGroupBits), out, LO, kGroupBins - 1);
+    }
+}
+
 // ---- 3. one workgroup per segment: counting sort by the low bits in LDS; emits the bucket table of the shared bucket kernels ----
 // hist[b] / offsets[b] for bucket b = seg * 512 + low bits (the layout k_msm_buckets_light / _heavy read with one "window"), the base
 // indices of every bucket contiguous in `sorted`, and one heavy-list entry per kHeavySeg points of an over-full bucket (what
@@ -168,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32)], 1u);
+            if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (kSegBuckets - 1)], 1u);
     }
     __syncthreads();
     {   // exclusive scan of the counts: PER consecutive buckets per thread
@@ -215,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (e[u] != ~0ull) out[atomicAdd(&cur[(uint32_t)(e[u] >> 32)], 1u)] = (uint32_t)e[u];
+            if (e[u] != ~0ull) out[atomicAdd(&cur[(uint32_t)(e[u] >> 32) & (kSegBuckets - 1)], 1u)] = (uint32_t)e[u];
     }
 }
 
@@ -345,7 +473,8 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const size_t o_keys = take(total * 4), o_entries = take(total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
                  o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(sizeof(G1Jac)),
                  o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
-                 o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4);
+                 o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4),
+                 o_grouped = take(ctx->msm_fx_partition == 2 ? total * 8 : 256), o_gcur = take(kPartBins * 4);
     hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
     if (off > ctx->msm_ws_cap[lane]) {
         if (ctx->msm_ws[lane]) {
@@ -365,6 +494,9 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     G1Jac *buckets = (G1Jac*)(ws + o_buckets), *part = (G1Jac*)(ws + o_part), *wsum = (G1Jac*)(ws + o_wsum), *seg = (G1Jac*)(ws + o_seg);
     uint32_t *hist = (uint32_t*)(ws + o_bhist), *offs = (uint32_t*)(ws + o_boffs), *heavy = (uint32_t*)(ws + o_heavy), *hcnt = (uint32_t*)(ws + o_hcnt);
     uint32_t *class_hist = (uint32_t*)(ws + o_cls), *class_cursor = class_hist + kClasses, *order = (uint32_t*)(ws + o_order);
+    uint64_t* grouped = (uint64_t*)(ws + o_grouped);
+    uint32_t* group_cursor = (uint32_t*)(ws + o_gcur);
+    const uint32_t n_groups = (nb1 + kGroupBins - 1) >> kGroupBits;
     const size_t lds_bytes = (size_t)nb1 * sizeof(uint32_t);
     if (lds_bytes > ctx->max_lds_per_block) return JOLT_ERR_UNSUPPORTED;
     if (!ctx->msm_fx_attr_set) {
@@ -372,6 +504,14 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         hipError_t a2 = hipFuncSetAttribute((const void*)k_fx_scatter<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         hipError_t a3 = hipFuncSetAttribute((const void*)k_fx_hist<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         hipError_t a4 = hipFuncSetAttribute((const void*)k_fx_scatter<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t p1 = hipFuncSetAttribute((const void*)k_fx_partition_groups<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        hipError_t p2 = hipFuncSetAttribute((const void*)k_fx_partition_groups<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        hipError_t p3 = hipFuncSetAttribute((const void*)k_fx_partition_segments<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        hipError_t p4 = hipFuncSetAttribute((const void*)k_fx_partition_segments<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        if (p1 != hipSuccess || p2 != hipSuccess || p3 != hipSuccess || p4 != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->msm_fx_partition = 1;  // the one-pass scatter needs no more LDS than the histogram
+        }
         if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess || a4 != hipSuccess) {
             (void)hipGetLastError();
             if (lds_bytes > 64 * 1024) return JOLT_ERR_UNSUPPORTED;
@@ -389,15 +529,32 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), st));  // z = 0: identity
     JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, st));
     JOLT_HIP_TRY(ctx, hipMemsetAsync(class_hist, 0, kClasses * 4, st));
-    if (lo_bits == 9) {
+    const bool two_pass = ctx->msm_fx_partition == 2 && n_groups <= (uint32_t)kPartBins && sizeof(PartShared) + 2048 <= ctx->max_lds_per_block;
+    const unsigned part_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, (total + kPartTile - 1) / kPartTile));
+    if (two_pass) {
+        hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, st, (const uint32_t*)offs1, n_groups, group_cursor);
+        if (lo_bits == 9) {
+            hipLaunchKernelGGL(k_fx_partition_groups<9>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
+                               group_cursor, grouped);
+            hipLaunchKernelGGL(k_fx_partition_segments<9>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
+                               (const uint32_t*)info, cur1, entries);
+        } else {
+            hipLaunchKernelGGL(k_fx_partition_groups<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
+                               group_cursor, grouped);
+            hipLaunchKernelGGL(k_fx_partition_segments<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
+                               (const uint32_t*)info, cur1, entries);
+        }
+    } else if (lo_bits == 9) {
         hipLaunchKernelGGL(k_fx_scatter<9>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
-        hipLaunchKernelGGL(k_fx_segment_sort<9>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
-                           heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
     } else {
         hipLaunchKernelGGL(k_fx_scatter<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
+    }
+    if (lo_bits == 9)
+        hipLaunchKernelGGL(k_fx_segment_sort<9>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
+                           heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
+    else
         hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
                            heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
-    }
     // bucket sums: the kernels of the per-window method with ONE window of B buckets (bases = the window tables)
     const unsigned gh = std::min<uint32_t>((heavy_cap + 3) / 4, 4096);
     hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, st, (const uint32_t*)class_hist, class_cursor);
