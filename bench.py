@@ -312,6 +312,10 @@ def main():
     if sharded:
         rounds = "shared-memory exchange of the round sums between the ranks of the node" if wl.round_exchange is not None else "RCCL all-gather of the round sums"
         out["config"]["collective"] = f"{rounds}; {type(wl.coll).__name__}: RCCL all-gather of the 2^tail_log-entry tables"
+        # what actually ran (a silent fallback would change what is measured): the exchange of the per-round sums and the communicator
+        out["config"]["round_exchange"] = ("shm" if wl.round_exchange is not None else ("rccl" if type(wl.coll).__name__ == "NativeCollective" else "torch.distributed")) \
+            + (" (JOLT_ROUND_EXCHANGE=%s)" % os.environ["JOLT_ROUND_EXCHANGE"] if os.environ.get("JOLT_ROUND_EXCHANGE") else "")
+        out["config"]["communicator"] = getattr(wl, "communicator_note", type(wl.coll).__name__)
         out["config"]["tail_log"] = wl.tail_log
         if pcs_sharded is not None:
             out["config"]["pcs"] = f"term-range sharded MSMs, partial points through {type(wl.coll).__name__}; fixed-base window tables {'on' if world <= 2 else 'off (memory)'}"

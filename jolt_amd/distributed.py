@@ -451,14 +451,18 @@ class ShardedWorkload:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if not same:
                     err = "probe all-gather mismatch"
+            self.communicator_note = "native RCCL communicator (jolt_comm_*, system librccl, %d rank(s))" % world
             if int(ok.item()) == 1:
                 coll = native
             else:
+                self.communicator_note = f"torch.distributed fallback: native RCCL communicator unavailable ({err})"
                 if native is not None:
                     native.close()
                 import sys
                 print(f"[jolt_amd] rank {rank}: native RCCL communicator unavailable ({err}); using torch.distributed", file=sys.stderr)
                 coll = Collective(dist, world, dev)
+        if not hasattr(self, "communicator_note"):
+            self.communicator_note = f"caller-supplied {type(coll).__name__}"
         self.coll = coll
         # round sums: shared memory between the ranks of the node when every rank can map it, else the collective above
         self.round_exchange = make_shm_exchange(dist, rank, world) if (world > 1 or force_gather) else None

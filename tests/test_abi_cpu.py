@@ -165,3 +165,14 @@ def test_rust_ffi_crate_agrees_with_the_header():
     lib_rs = open(os.path.join(root, "rust", "jolt-kernels-hip", "src", "lib.rs")).read()
     for module in ("context", "member", "msm", "scheduler", "status", "ffi"):
         assert f"pub mod {module};" in lib_rs and os.path.exists(os.path.join(root, "rust", "jolt-kernels-hip", "src", module + ".rs"))
+
+
+def test_integration_doc_lists_the_sources_the_build_compiles():
+    """INTEGRATION.md section 4 names exactly jolt_amd/build.py:SOURCES (round-1 review: the list had gone stale)"""
+    import re
+    from jolt_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"jolt_amd/csrc/\{([a-z_0-9,]+)\}\.hip", doc)
+    assert m, "source list not found in INTEGRATION.md"
+    assert m.group(1).split(",") == [os.path.basename(s)[:-4] for s in build.SOURCES]
