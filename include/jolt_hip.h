@@ -485,6 +485,23 @@ int32_t jolt_r1cs_materialize(jolt_ctx *ctx, jolt_table *const *inputs, size_t n
                               jolt_table **az_out, jolt_table **bz_out);
 int32_t jolt_tables_evaluate(jolt_ctx *ctx, jolt_table *const *tables, size_t k, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
 
+/* The same three operators straight off the INTEGER witness columns (jolt_ints of kind u64 / i64 / i128), as the optimized tier runs
+ * them (crates/jolt-kernels/src/optimized/spartan_outer.rs:6-43,276-370,780-850) on FrSmallScalarAccumulator-style deferred reduction
+ * (crates/jolt-field/src/bn254/mont.rs:286-305,343-427): the 35 inputs are never promoted to field tables.
+ *   jolt_r1cs_uniskip_sums_small: INTEGER weights (the exact integer Lagrange extension coefficients folded into column weights,
+ *     extension_coefficients :276-306): Az / Bz are integer dot products, their product times eq is one field multiply per
+ *     (node, cycle, stream).  Contract (the caller's, as in the reference: |az| < 2^22, |bz| < 2^152 there): |Az| < 2^127,
+ *     |Bz| < 2^255, |Az * Bz| < 2^254, no weight equal to INT64_MIN.
+ *   jolt_r1cs_materialize_small: FIELD weights (they carry the Lagrange kernel at the uni-skip challenge) x integer values, one
+ *     reduction per output (fold_group :363-370).
+ *   jolt_ints_evaluate: out[k] = sum_t eq(point, t) * z_k(t) (compute_claimed_inputs :780-850; Polynomial::<T>::evaluate).
+ * Results equal the field-arithmetic operators above on the promoted columns (exact algebra). */
+int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, const jolt_table *eq, const int64_t *a_weights,
+                                     const int64_t *b_weights, size_t n_nodes, jolt_fr_t *out);
+int32_t jolt_r1cs_materialize_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, const jolt_fr_t *a_weights,
+                                    const jolt_fr_t *b_weights, jolt_table **az_out, jolt_table **bz_out);
+int32_t jolt_ints_evaluate(jolt_ctx *ctx, const jolt_ints *const *columns, size_t k, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
+
 /* Sparse (K x T) read-write matrix of RAM read/write checking (stage 2) -- SURVEY.md section 8(f) row 4.  Replaces
  * CycleMajorMatrix / AddressMajorMatrix and the round messages of RamReadWriteKernel (crates/jolt-kernels/src/optimized/rw_matrix.rs,
  * optimized/ram_read_write.rs:58-330): summand eq(tau_low, j) * ra(k,j) * (val(k,j) + gamma * (val(k,j) + inc(j))) over

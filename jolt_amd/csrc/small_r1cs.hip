@@ -1,0 +1,300 @@
+// jolt_amd/csrc/small_r1cs.hip -- the T-scale sums of Spartan outer straight off the INTEGER witness columns (SURVEY.md 8a2 + 8f row 3).
+//
+// The optimized tier never materialises the 35 R1CS inputs as field vectors (crates/jolt-kernels/src/optimized/spartan_outer.rs:6-43):
+//   * uni-skip first round (:276-350, extension_coefficients / RowGroupValues::extended_products): Az and Bz at the 9 extended nodes are
+//     INTEGER Lagrange extensions of the row values -- "9 integer dot products and one field fmadd per (cycle, stream)".  Here in the
+//     column form of r1cs.hip with integer weights: Az(node,s,t) = a_0 + sum_v a_v * z_v(t) as a 128-bit integer, Bz likewise as a
+//     signed 256-bit integer (S192 magnitudes in the reference), their product (< 2^254, S256) times eq[(t << 1) | s] is ONE field
+//     multiply per (node, cycle, stream) instead of 4 per input and node;
+//   * the remainder's bound Az / Bz under the challenge's Lagrange weights (fold_group :363-370: fmadd_i64 / fmadd_s256 into an
+//     unreduced accumulator): field weight x integer value products with ONE reduction per output (small_scalar.hip.h);
+//   * the post-hoc opening evaluation z_v(r_cycle) (compute_claimed_inputs :780-850: fmadd_u64 / fmadd_s256 per input): the same
+//     accumulator over eq(r_cycle, .) -- 8 bytes read per input and cycle instead of 32.
+// Values equal the field-arithmetic operators of r1cs.hip on the promoted columns (exact integer / field algebra: the integer
+// coefficients' field images are the field weights), which is how the tests pin them; the integer ranges are the caller's contract
+// (|Az| < 2^127, |Bz| < 2^255, |Az * Bz| < 2^254; the reference's rows stay below 2^22, 2^152 and 2^174).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+#include "ints.hpp"
+#include "poly_kernels.hip.h"
+#include "small_scalar.hip.h"
+
+using namespace jolt;
+
+int32_t jolt_internal_table_new(jolt_ctx* ctx, size_t len, jolt_table** out);
+int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t results);
+
+namespace {
+
+constexpr int kMaxSmallInputs = 64;
+struct IntInputs {
+    const void* z[kMaxSmallInputs];
+    uint8_t kind[kMaxSmallInputs];
+    int n;
+};
+
+__device__ __forceinline__ __int128 to_i128(const SmallInt& s) {
+    const unsigned __int128 mag = ((unsigned __int128)(((uint64_t)s.m[3] << 32) | s.m[2]) << 64) | (((uint64_t)s.m[1] << 32) | s.m[0]);
+    return s.neg ? -(__int128)mag : (__int128)mag;
+}
+__device__ __forceinline__ Fr fr_from_u256(const U256& x) {
+    Fr f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.l[i] = x.l[i];
+    return reduce_once(f, 0u);  // < 2^254 < 2p by contract
+}
+
+// partials[node * gridDim.x + block] = this block's share of t1(node) = sum_t sum_s eq[(t << 1) | s] * Az(node,s,t) * Bz(node,s,t)
+// wa / wb: [node][stream][1 + n] signed 64-bit integer weights (wave-uniform reads)
+__global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr* __restrict__ eq, size_t cycles, const int64_t* __restrict__ wa,
+                                                          const int64_t* __restrict__ wb, Fr* __restrict__ partials) {
+    const size_t node = blockIdx.y, stride_w = 1 + (size_t)in.n;
+    const int64_t* a0 = wa + (node * 2) * stride_w;
+    const int64_t* a1 = a0 + stride_w;
+    const int64_t* b0 = wb + (node * 2) * stride_w;
+    const int64_t* b1 = b0 + stride_w;
+    Fr pos = Fr::zero(), neg_sum = Fr::zero();  // sums of eq * |Az * Bz| in PLAIN form (Montgomery eq x plain integer), by sign
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < cycles; t += stride) {
+        __int128 az[2] = {(__int128)a0[0], (__int128)a1[0]};
+        U256 bp[2] = {u256_zero(), u256_zero()}, bn[2] = {u256_zero(), u256_zero()};
+        {
+            const uint32_t one[4] = {1u, 0u, 0u, 0u};
+            const int64_t c0 = b0[0], c1 = b1[0];
+            if (c0 > 0) u256_fmadd<2>(bp[0], (uint64_t)c0, one);
+            if (c0 < 0) u256_fmadd<2>(bn[0], (uint64_t)0 - (uint64_t)c0, one);
+            if (c1 > 0) u256_fmadd<2>(bp[1], (uint64_t)c1, one);
+            if (c1 < 0) u256_fmadd<2>(bn[1], (uint64_t)0 - (uint64_t)c1, one);
+        }
+        for (int v = 0; v < in.n; ++v) {
+            const int64_t wa0 = a0[1 + v], wa1 = a1[1 + v], wb0 = b0[1 + v], wb1 = b1[1 + v];
+            if ((wa0 | wa1 | wb0 | wb1) == 0) continue;  // wave-uniform: most columns do not enter a given node's rows
+            const int kind = in.kind[v];
+            const SmallInt z = load_small(in.z[v], kind, t);
+            if (wa0 | wa1) {
+                const __int128 zi = to_i128(z);
+                az[0] += (__int128)wa0 * zi;
+                az[1] += (__int128)wa1 * zi;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int64_t w = s ? wb1 : wb0;
+                if (w == 0) continue;
+                const uint64_t mag = w < 0 ? (uint64_t)0 - (uint64_t)w : (uint64_t)w;
+                const bool negative = (w < 0) != (z.neg != 0);
+                if (kind == kIntKindI128) {
+                    if (negative) u256_fmadd<4>(bn[s], mag, z.m); else u256_fmadd<4>(bp[s], mag, z.m);
+                } else {
+                    if (negative) u256_fmadd<2>(bn[s], mag, z.m); else u256_fmadd<2>(bp[s], mag, z.m);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bool b_neg = !u256_geq(bp[s], bn[s]);
+            const U256 bmag = b_neg ? u256_sub(bn[s], bp[s]) : u256_sub(bp[s], bn[s]);
+            const bool a_neg = az[s] < 0;
+            const unsigned __int128 amag = a_neg ? (unsigned __int128)(-az[s]) : (unsigned __int128)az[s];
+            const U256 prod = u256_mul_u128(bmag, (uint64_t)amag, (uint64_t)(amag >> 64));
+            const Fr term = mul(ld_fr(eq + 2 * t + s), fr_from_u256(prod));
+            if (a_neg != b_neg) neg_sum = add(neg_sum, term); else pos = add(pos, term);
+        }
+    }
+    Fr acc[1] = {mul(sub(pos, neg_sum), Fr::r2())};  // plain -> Montgomery, once per thread
+    block_reduce_store<1>(acc, partials + node * gridDim.x);
+}
+
+// ws[i] = w[i] * R (Montgomery form of w*R: REDC of sum ws*z lands in Montgomery form), nws[i] = -ws[i]; mask bit per weight != 0
+__global__ __launch_bounds__(kBlock) void k_small_prescale(const Fr* __restrict__ w, size_t count, Fr* __restrict__ ws, Fr* __restrict__ nws) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const Fr s = mul(ld_fr(w + i), Fr::r2());
+    st_fr(ws + i, s);
+    st_fr(nws + i, neg(s));
+}
+
+// az[(t << 1) | s] = wa[s][0] + sum_v wa[s][1 + v] * z_v(t); likewise bz.  w: the caller's weights [A s0, A s1, B s0, B s1][1 + n],
+// ws / nws: pre-scaled (see above); nz[v]: bit o set when weight o of input v is non-zero
+__global__ __launch_bounds__(kBlock) void k_small_materialize(IntInputs in, size_t cycles, const Fr* __restrict__ w, const Fr* __restrict__ ws, const Fr* __restrict__ nws,
+                                                              const uint8_t* __restrict__ nz, Fr* __restrict__ az, Fr* __restrict__ bz) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= cycles) return;
+    const size_t stride_w = 1 + (size_t)in.n;
+    SmallAcc acc[4] = {small_zero(), small_zero(), small_zero(), small_zero()};
+    for (int v = 0; v < in.n; ++v) {
+        const uint32_t mask = nz[v];
+        if (mask == 0) continue;
+        const int kind = in.kind[v];
+        const SmallInt z = load_small(in.z[v], kind, t);
+        const Fr* src = z.neg ? nws : ws;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (!((mask >> o) & 1)) continue;
+            const Fr a = ld_fr(src + o * stride_w + 1 + v);
+            if (kind == kIntKindI128) small_fmadd<4>(acc[o], a, z.m); else small_fmadd<2>(acc[o], a, z.m);
+        }
+    }
+    st_fr(az + 2 * t, add(small_redc<FrParams>(acc[0]), ld_fr(w)));
+    st_fr(az + 2 * t + 1, add(small_redc<FrParams>(acc[1]), ld_fr(w + stride_w)));
+    st_fr(bz + 2 * t, add(small_redc<FrParams>(acc[2]), ld_fr(w + 2 * stride_w)));
+    st_fr(bz + 2 * t + 1, add(small_redc<FrParams>(acc[3]), ld_fr(w + 3 * stride_w)));
+}
+
+// partials[(group * gridDim.x + block) * 4 + u] = this block's share of sum_t eq[t] * z_{4 group + u}(t)
+__global__ __launch_bounds__(kBlock) void k_small_evaluate(IntInputs in, const Fr* __restrict__ eq, size_t len, Fr* __restrict__ partials) {
+    const int first = blockIdx.y * 4;
+    SmallAcc acc[4] = {small_zero(), small_zero(), small_zero(), small_zero()};
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < len; t += stride) {
+        const Fr e = ld_fr(eq + t);
+        const Fr ne = neg(e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = first + u;
+            if (v >= in.n) continue;
+            const int kind = in.kind[v];
+            const SmallInt z = load_small(in.z[v], kind, t);
+            const Fr a = z.neg ? ne : e;
+            if (kind == kIntKindI128) small_fmadd<4>(acc[u], a, z.m); else small_fmadd<2>(acc[u], a, z.m);
+        }
+    }
+    Fr out[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = mul(small_redc<FrParams>(acc[u]), Fr::r2());  // (sum e z) R^-1 * R^2 -> Montgomery
+    block_reduce_store<4>(out, partials + (size_t)blockIdx.y * gridDim.x * 4);
+}
+
+int32_t gather_ints(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, IntInputs* out, size_t* cycles) {
+    if (n_inputs == 0 || n_inputs > (size_t)kMaxSmallInputs) return JOLT_ERR_UNSUPPORTED;
+    out->n = (int)n_inputs;
+    for (int v = 0; v < kMaxSmallInputs; ++v) { out->z[v] = nullptr; out->kind[v] = 0; }
+    for (size_t v = 0; v < n_inputs; ++v) {
+        if (!inputs[v]) return JOLT_ERR_INVALID_ARG;
+        if (inputs[v]->count != inputs[0]->count) return JOLT_ERR_SIZE_MISMATCH;
+        if (inputs[v]->kind != JOLT_INT_U64 && inputs[v]->kind != JOLT_INT_I64 && inputs[v]->kind != JOLT_INT_I128) return JOLT_ERR_INVALID_ARG;
+        out->z[v] = inputs[v]->data;
+        out->kind[v] = (uint8_t)inputs[v]->kind;
+    }
+    *cycles = inputs[0]->count;
+    return JOLT_OK;
+}
+
+int32_t upload_bytes(jolt_ctx* ctx, const void* host, size_t bytes, void** out) {
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, bytes, out));
+    hipError_t e = hipMemcpyAsync(*out, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the caller's array may be short-lived
+    if (e != hipSuccess) { jolt_internal_dev_free(ctx, *out); *out = nullptr; ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
+    return JOLT_OK;
+}
+
+int32_t reduce_rows_to_host(jolt_ctx* ctx, size_t rows, int nblocks, int ne, jolt_fr_t* out) {
+    for (size_t k = 0; k < rows; ++k)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)(ctx->d_partials + k * (size_t)nblocks * ne), nblocks, ne, ctx->d_results + k * ne);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, rows * ne * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->h_results, rows * ne * sizeof(Fr));
+    return JOLT_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, const jolt_table* eq, const int64_t* a_weights,
+                                                const int64_t* b_weights, size_t n_nodes, jolt_fr_t* out) {
+    if (!ctx || !inputs || !eq || !a_weights || !b_weights || !out || n_nodes == 0 || n_nodes > 64) return JOLT_ERR_INVALID_ARG;
+    IntInputs in;
+    size_t cycles = 0;
+    JOLT_TRY(gather_ints(ctx, inputs, n_inputs, &in, &cycles));
+    if (eq->len != 2 * cycles) return JOLT_ERR_SIZE_MISMATCH;
+    const size_t wcount = n_nodes * 2 * (1 + n_inputs);
+    for (size_t i = 0; i < wcount; ++i)  // |w| must have a magnitude: INT64_MIN has none in 63 bits, and is far outside any Lagrange coefficient
+        JOLT_REQUIRE(ctx, a_weights[i] != INT64_MIN && b_weights[i] != INT64_MIN, "integer weight out of range");
+    int64_t *wa = nullptr, *wb = nullptr;
+    JOLT_TRY(upload_bytes(ctx, a_weights, wcount * sizeof(int64_t), (void**)&wa));
+    int32_t s = upload_bytes(ctx, b_weights, wcount * sizeof(int64_t), (void**)&wb);
+    if (s != JOLT_OK) { jolt_internal_dev_free(ctx, wa); return s; }
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 4));
+    s = jolt_internal_ensure_scratch(ctx, n_nodes * (size_t)grid + 8, n_nodes + 8);
+    if (s == JOLT_OK) {
+        hipLaunchKernelGGL(k_small_uniskip, dim3(grid, (unsigned)n_nodes), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
+                           (const int64_t*)wb, ctx->d_partials);
+        s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
+    }
+    if (s == JOLT_OK) s = reduce_rows_to_host(ctx, n_nodes, grid, 1, out);
+    jolt_internal_dev_free(ctx, wa);
+    jolt_internal_dev_free(ctx, wb);
+    return s;
+}
+
+extern "C" int32_t jolt_r1cs_materialize_small(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, const jolt_fr_t* a_weights, const jolt_fr_t* b_weights,
+                                               jolt_table** az_out, jolt_table** bz_out) {
+    if (!ctx || !inputs || !a_weights || !b_weights || !az_out || !bz_out) return JOLT_ERR_INVALID_ARG;
+    IntInputs in;
+    size_t cycles = 0;
+    JOLT_TRY(gather_ints(ctx, inputs, n_inputs, &in, &cycles));
+    const size_t per = 1 + n_inputs, wcount = 4 * per;
+    std::vector<jolt_fr_t> w(wcount);
+    std::memcpy(w.data(), a_weights, 2 * per * sizeof(jolt_fr_t));
+    std::memcpy(w.data() + 2 * per, b_weights, 2 * per * sizeof(jolt_fr_t));
+    std::vector<uint8_t> nz(kMaxSmallInputs, 0);
+    for (size_t i = 0; i < wcount; ++i) {
+        const Fr f = fr_from_abi(&w[i]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(f), "weight is not a canonical Fr");
+        const size_t o = i / per, k = i % per;
+        if (k >= 1 && !(f == Fr::zero())) nz[k - 1] |= (uint8_t)(1u << o);
+    }
+    Fr *dw = nullptr, *ws = nullptr, *nws = nullptr;
+    uint8_t* dnz = nullptr;
+    jolt_table *az = nullptr, *bz = nullptr;
+    int32_t s = upload_bytes(ctx, w.data(), wcount * sizeof(Fr), (void**)&dw);
+    if (s == JOLT_OK) s = upload_bytes(ctx, nz.data(), nz.size(), (void**)&dnz);
+    if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, wcount * sizeof(Fr), (void**)&ws);
+    if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, wcount * sizeof(Fr), (void**)&nws);
+    if (s == JOLT_OK) s = jolt_internal_table_new(ctx, 2 * cycles, &az);
+    if (s == JOLT_OK) s = jolt_internal_table_new(ctx, 2 * cycles, &bz);
+    if (s == JOLT_OK) {
+        hipLaunchKernelGGL(k_small_prescale, dim3((unsigned)((wcount + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const Fr*)dw, wcount, ws, nws);
+        hipLaunchKernelGGL(k_small_materialize, dim3((unsigned)((cycles + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, in, cycles, (const Fr*)dw, (const Fr*)ws,
+                           (const Fr*)nws, (const uint8_t*)dnz, az->data(), bz->data());
+        if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
+    }
+    if (dw) jolt_internal_dev_free(ctx, dw);
+    if (dnz) jolt_internal_dev_free(ctx, dnz);
+    if (ws) jolt_internal_dev_free(ctx, ws);
+    if (nws) jolt_internal_dev_free(ctx, nws);
+    if (s != JOLT_OK) {
+        if (az) jolt_table_free(ctx, az);
+        if (bz) jolt_table_free(ctx, bz);
+        return s;
+    }
+    *az_out = az;
+    *bz_out = bz;
+    return JOLT_OK;
+}
+
+// out[k] = sum_t eq(point, t) * z_k(t): Polynomial::<T>::evaluate of compact integer columns (crates/jolt-poly/src/dense.rs:129-142,
+// 341-369) through the small-scalar accumulator, all columns sharing ONE eq expansion
+extern "C" int32_t jolt_ints_evaluate(jolt_ctx* ctx, const jolt_ints* const* columns, size_t k, const jolt_fr_t* point, size_t n, jolt_fr_t* out) {
+    if (!ctx || !columns || !out || (!point && n)) return JOLT_ERR_INVALID_ARG;
+    IntInputs in;
+    size_t len = 0;
+    JOLT_TRY(gather_ints(ctx, columns, k, &in, &len));
+    if (len != ((size_t)1 << n)) return JOLT_ERR_SIZE_MISMATCH;  // dense.rs:341-345 assert
+    jolt_table* eq = nullptr;
+    JOLT_TRY(jolt_eq_evals(ctx, point, n, nullptr, &eq));
+    const size_t groups = (k + 3) / 4;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((len + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 2));
+    int32_t s = jolt_internal_ensure_scratch(ctx, groups * (size_t)grid * 4 + 8, groups * 4 + 8);
+    std::vector<jolt_fr_t> tmp(groups * 4);
+    if (s == JOLT_OK) {
+        hipLaunchKernelGGL(k_small_evaluate, dim3(grid, (unsigned)groups), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), len, ctx->d_partials);
+        s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
+    }
+    if (s == JOLT_OK) s = reduce_rows_to_host(ctx, groups, grid, 4, tmp.data());
+    if (s == JOLT_OK) std::memcpy(out, tmp.data(), k * sizeof(jolt_fr_t));
+    jolt_table_free(ctx, eq);
+    return s;
+}

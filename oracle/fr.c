@@ -225,3 +225,58 @@ EXPORT void orc_wide_accumulate(const fr_t *a, const fr_t *b, size_t n_fmadd, co
     out[8] = (uint64_t)carry;
     *o = fr_from_montgomery_reduce(out, 9);
 }
+
+/* FrSmallScalarAccumulator (mont.rs:343-427): sum_k value_k * scalar_k for signed 64-bit scalars; positive and negative terms are
+ * held separately as unreduced FIVE-limb integers (add_assign_trunc: wraps at 2^320 like the reference) and reduced once
+ * (reduce: Barrett of |pos - neg|, negated when neg > pos).  fmadd_i64 (:417-426), fmadd_magnitude (:369-379), reduce (:397-409). */
+static void limbs5_add(uint64_t acc[5], const uint64_t v[5]) {
+    u128 c = 0;
+    for (int i = 0; i < 5; ++i) {
+        c += (u128)acc[i] + v[i];
+        acc[i] = (uint64_t)c;
+        c >>= 64;
+    }
+}
+static int limbs5_geq(const uint64_t a[5], const uint64_t b[5]) {
+    for (int i = 4; i >= 0; --i)
+        if (a[i] != b[i]) return a[i] > b[i];
+    return 1;
+}
+static void limbs5_sub(uint64_t o[5], const uint64_t a[5], const uint64_t b[5]) {
+    u128 br = 0;
+    for (int i = 0; i < 5; ++i) {
+        u128 d = (u128)a[i] - b[i] - br;
+        o[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+}
+EXPORT void orc_small_scalar_accumulate(const fr_t *values, const int64_t *scalars, size_t n, fr_t *o) {
+    uint64_t pos[5] = {0}, neg[5] = {0};
+    for (size_t k = 0; k < n; ++k) {
+        const int64_t sc = scalars[k];
+        const uint64_t mag = sc < 0 ? (uint64_t)0 - (uint64_t)sc : (uint64_t)sc;
+        uint64_t *slots = sc >= 0 ? pos : neg;
+        if (mag == 0) continue;
+        uint64_t prod[5] = {0};
+        if (mag == 1) {
+            for (int i = 0; i < 4; ++i) prod[i] = values[k].l[i];
+        } else { /* bigint4_mul_u64 */
+            u128 c = 0;
+            for (int i = 0; i < 4; ++i) {
+                c += (u128)values[k].l[i] * mag;
+                prod[i] = (uint64_t)c;
+                c >>= 64;
+            }
+            prod[4] = (uint64_t)c;
+        }
+        limbs5_add(slots, prod);
+    }
+    uint64_t d[5];
+    if (limbs5_geq(pos, neg)) {
+        limbs5_sub(d, pos, neg);
+        *o = fr_barrett_reduce_5(d);
+    } else {
+        limbs5_sub(d, neg, pos);
+        *o = FNEG(fr_barrett_reduce_5(d));
+    }
+}

@@ -861,3 +861,12 @@ def r1cs_materialize(inputs, a_weights, b_weights):
     az, bz = fr_array(2 * cycles), fr_array(2 * cycles)
     lib().orc_r1cs_materialize(ptrs, C.c_uint32(len(tabs)), C.c_size_t(cycles), _p(wa), _p(wb), _p(az), _p(bz))
     return az, bz
+
+
+def small_scalar_accumulate(values, scalars):
+    """FrSmallScalarAccumulator: sum_k values[k] * scalars[k] (int64 scalars), one deferred reduction"""
+    v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+    sc = np.ascontiguousarray(scalars, dtype=np.int64)
+    o = fr_array(1)
+    lib().orc_small_scalar_accumulate(_p(v), sc.ctypes.data_as(C.c_void_p), C.c_size_t(v.shape[0]), _p(o))
+    return o[0]

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from util import rand_fr
 
 R, Q = O.R_MOD, O.Q_MOD
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn254_golden_bytes.json")))["tables"]
@@ -125,3 +126,22 @@ def test_spread_recipe_matches_model():
         am, bm = O.fr_from_u64([a]), O.fr_from_u64([b])
         got = O.fr_add(O.fr_mul(O.fr_mul(am, bm), bm), am)
         assert O.from_mont(got) == [(a * b * b + a) % R]
+
+
+def test_small_scalar_accumulator_restatement_equals_plain_sums():
+    """FrSmallScalarAccumulator (mont.rs:343-427) as restated in oracle/fr.c: positive / negative five-limb sums with ONE Barrett
+    reduction give the same value as the sum of reduced products -- over the scalar corners 0, +-1, i64::MIN / MAX.  The five
+    limbs wrap at 2^320 (add_assign_trunc), i.e. the sums of |scalars| must stay below ~2^66: full-range scalars for a handful of
+    terms, 48-bit scalars for long sums (the witness columns it is used on are flags and register-sized values)."""
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 5, 300, 5000):
+        values = rand_fr(n, 40 + n)
+        if n <= 5:
+            scalars = rng.integers(-2**63, 2**63 - 1, size=n, dtype=np.int64)
+            scalars[: min(n, 5)] = [0, 1, -1, -2**63, 2**63 - 1][: min(n, 5)]
+        else:
+            scalars = rng.integers(-2**48, 2**48, size=n, dtype=np.int64)
+        want = np.zeros((1, 4), dtype=np.uint64)
+        for k in range(n):
+            want = O.fr_add(want, O.fr_mul(values[k].reshape(1, 4), O.fr_from_i64(scalars[k: k + 1])))
+        assert np.array_equal(O.small_scalar_accumulate(values, scalars), want[0]), n
