@@ -495,10 +495,14 @@ int32_t jolt_tables_evaluate(jolt_ctx *ctx, jolt_table *const *tables, size_t k,
  *   jolt_r1cs_materialize_small: FIELD weights (they carry the Lagrange kernel at the uni-skip challenge) x integer values, one
  *     reduction per output (fold_group :363-370).
  *   jolt_ints_evaluate: out[k] = sum_t eq(point, t) * z_k(t) (compute_claimed_inputs :780-850; Polynomial::<T>::evaluate).
+ * n_streams = 2: Spartan outer (weights [node][stream][1 + n], eq over (cycle || stream), outputs az[(t << 1) | s]).
+ * n_streams = 1: Spartan PRODUCT virtualization (stage 2, crates/jolt-kernels/src/optimized/spartan_product.rs:86-230,321-437): "A" = the
+ *   left factor lanes, "B" = the right factor lanes, 5 extended nodes of the 3-node window, eq = eq(tau_low, .) over the cycles, and the
+ *   two outputs of jolt_r1cs_materialize_small are the remainder's left / right tables (feed jolt_member_create_split_eq_product).
  * Results equal the field-arithmetic operators above on the promoted columns (exact algebra). */
-int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, const jolt_table *eq, const int64_t *a_weights,
-                                     const int64_t *b_weights, size_t n_nodes, jolt_fr_t *out);
-int32_t jolt_r1cs_materialize_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, const jolt_fr_t *a_weights,
+int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, const jolt_table *eq, uint32_t n_streams,
+                                     const int64_t *a_weights, const int64_t *b_weights, size_t n_nodes, jolt_fr_t *out);
+int32_t jolt_r1cs_materialize_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, uint32_t n_streams, const jolt_fr_t *a_weights,
                                     const jolt_fr_t *b_weights, jolt_table **az_out, jolt_table **bz_out);
 int32_t jolt_ints_evaluate(jolt_ctx *ctx, const jolt_ints *const *columns, size_t k, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
 

@@ -49,13 +49,14 @@ __device__ __forceinline__ Fr fr_from_u256(const U256& x) {
 
 // partials[node * gridDim.x + block] = this block's share of t1(node) = sum_t sum_s eq[(t << 1) | s] * Az(node,s,t) * Bz(node,s,t)
 // wa / wb: [node][stream][1 + n] signed 64-bit integer weights (wave-uniform reads)
+template <int STREAMS>
 __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr* __restrict__ eq, size_t cycles, const int64_t* __restrict__ wa,
                                                           const int64_t* __restrict__ wb, Fr* __restrict__ partials) {
     const size_t node = blockIdx.y, stride_w = 1 + (size_t)in.n;
-    const int64_t* a0 = wa + (node * 2) * stride_w;
-    const int64_t* a1 = a0 + stride_w;
-    const int64_t* b0 = wb + (node * 2) * stride_w;
-    const int64_t* b1 = b0 + stride_w;
+    const int64_t* a0 = wa + (node * STREAMS) * stride_w;
+    const int64_t* a1 = a0 + (STREAMS - 1) * stride_w;  // STREAMS = 1 (product virtualization: no stream variable): stream 1 aliases stream 0 and is skipped
+    const int64_t* b0 = wb + (node * STREAMS) * stride_w;
+    const int64_t* b1 = b0 + (STREAMS - 1) * stride_w;
     Fr pos = Fr::zero(), neg_sum = Fr::zero();  // sums of eq * |Az * Bz| in PLAIN form (Montgomery eq x plain integer), by sign
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < cycles; t += stride) {
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr
             const int64_t c0 = b0[0], c1 = b1[0];
             if (c0 > 0) u256_fmadd<2>(bp[0], (uint64_t)c0, one);
             if (c0 < 0) u256_fmadd<2>(bn[0], (uint64_t)0 - (uint64_t)c0, one);
-            if (c1 > 0) u256_fmadd<2>(bp[1], (uint64_t)c1, one);
-            if (c1 < 0) u256_fmadd<2>(bn[1], (uint64_t)0 - (uint64_t)c1, one);
+            if (STREAMS == 2 && c1 > 0) u256_fmadd<2>(bp[1], (uint64_t)c1, one);
+            if (STREAMS == 2 && c1 < 0) u256_fmadd<2>(bn[1], (uint64_t)0 - (uint64_t)c1, one);
         }
         for (int v = 0; v < in.n; ++v) {
             const int64_t wa0 = a0[1 + v], wa1 = a1[1 + v], wb0 = b0[1 + v], wb1 = b1[1 + v];
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr
             if (wa0 | wa1) {
                 const __int128 zi = to_i128(z);
                 az[0] += (__int128)wa0 * zi;
-                az[1] += (__int128)wa1 * zi;
+                if (STREAMS == 2) az[1] += (__int128)wa1 * zi;
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < STREAMS; ++s) {
                 const int64_t w = s ? wb1 : wb0;
                 if (w == 0) continue;
                 const uint64_t mag = w < 0 ? (uint64_t)0 - (uint64_t)w : (uint64_t)w;
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr
             }
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < STREAMS; ++s) {
             const bool b_neg = !u256_geq(bp[s], bn[s]);
             const U256 bmag = b_neg ? u256_sub(bn[s], bp[s]) : u256_sub(bp[s], bn[s]);
             const bool a_neg = az[s] < 0;
             const unsigned __int128 amag = a_neg ? (unsigned __int128)(-az[s]) : (unsigned __int128)az[s];
             const U256 prod = u256_mul_u128(bmag, (uint64_t)amag, (uint64_t)(amag >> 64));
-            const Fr term = mul(ld_fr(eq + 2 * t + s), fr_from_u256(prod));
+            const Fr term = mul(ld_fr(eq + STREAMS * t + s), fr_from_u256(prod));
             if (a_neg != b_neg) neg_sum = add(neg_sum, term); else pos = add(pos, term);
         }
     }
@@ -118,12 +119,16 @@ __global__ __launch_bounds__(kBlock) void k_small_prescale(const Fr* __restrict_
 
 // az[(t << 1) | s] = wa[s][0] + sum_v wa[s][1 + v] * z_v(t); likewise bz.  w: the caller's weights [A s0, A s1, B s0, B s1][1 + n],
 // ws / nws: pre-scaled (see above); nz[v]: bit o set when weight o of input v is non-zero
+template <int STREAMS>
 __global__ __launch_bounds__(kBlock) void k_small_materialize(IntInputs in, size_t cycles, const Fr* __restrict__ w, const Fr* __restrict__ ws, const Fr* __restrict__ nws,
                                                               const uint8_t* __restrict__ nz, Fr* __restrict__ az, Fr* __restrict__ bz) {
     const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= cycles) return;
     const size_t stride_w = 1 + (size_t)in.n;
-    SmallAcc acc[4] = {small_zero(), small_zero(), small_zero(), small_zero()};
+    constexpr int OUT = 2 * STREAMS;  // [A s.., B s..]
+    SmallAcc acc[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) acc[o] = small_zero();
     for (int v = 0; v < in.n; ++v) {
         const uint32_t mask = nz[v];
         if (mask == 0) continue;
@@ -131,16 +136,17 @@ __global__ __launch_bounds__(kBlock) void k_small_materialize(IntInputs in, size
         const SmallInt z = load_small(in.z[v], kind, t);
         const Fr* src = z.neg ? nws : ws;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < OUT; ++o) {
             if (!((mask >> o) & 1)) continue;
             const Fr a = ld_fr(src + o * stride_w + 1 + v);
             if (kind == kIntKindI128) small_fmadd<4>(acc[o], a, z.m); else small_fmadd<2>(acc[o], a, z.m);
         }
     }
-    st_fr(az + 2 * t, add(small_redc<FrParams>(acc[0]), ld_fr(w)));
-    st_fr(az + 2 * t + 1, add(small_redc<FrParams>(acc[1]), ld_fr(w + stride_w)));
-    st_fr(bz + 2 * t, add(small_redc<FrParams>(acc[2]), ld_fr(w + 2 * stride_w)));
-    st_fr(bz + 2 * t + 1, add(small_redc<FrParams>(acc[3]), ld_fr(w + 3 * stride_w)));
+#pragma unroll
+    for (int s = 0; s < STREAMS; ++s) {
+        st_fr(az + STREAMS * t + s, add(small_redc<FrParams>(acc[s]), ld_fr(w + s * stride_w)));
+        st_fr(bz + STREAMS * t + s, add(small_redc<FrParams>(acc[STREAMS + s]), ld_fr(w + (STREAMS + s) * stride_w)));
+    }
 }
 
 // partials[(group * gridDim.x + block) * 4 + u] = this block's share of sum_t eq[t] * z_{4 group + u}(t)
@@ -202,14 +208,14 @@ int32_t reduce_rows_to_host(jolt_ctx* ctx, size_t rows, int nblocks, int ne, jol
 
 }  // namespace
 
-extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, const jolt_table* eq, const int64_t* a_weights,
-                                                const int64_t* b_weights, size_t n_nodes, jolt_fr_t* out) {
-    if (!ctx || !inputs || !eq || !a_weights || !b_weights || !out || n_nodes == 0 || n_nodes > 64) return JOLT_ERR_INVALID_ARG;
+extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, const jolt_table* eq, uint32_t n_streams,
+                                                const int64_t* a_weights, const int64_t* b_weights, size_t n_nodes, jolt_fr_t* out) {
+    if (!ctx || !inputs || !eq || !a_weights || !b_weights || !out || n_nodes == 0 || n_nodes > 64 || (n_streams != 1 && n_streams != 2)) return JOLT_ERR_INVALID_ARG;
     IntInputs in;
     size_t cycles = 0;
     JOLT_TRY(gather_ints(ctx, inputs, n_inputs, &in, &cycles));
-    if (eq->len != 2 * cycles) return JOLT_ERR_SIZE_MISMATCH;
-    const size_t wcount = n_nodes * 2 * (1 + n_inputs);
+    if (eq->len != n_streams * cycles) return JOLT_ERR_SIZE_MISMATCH;
+    const size_t wcount = n_nodes * n_streams * (1 + n_inputs);
     for (size_t i = 0; i < wcount; ++i)  // |w| must have a magnitude: INT64_MIN has none in 63 bits, and is far outside any Lagrange coefficient
         JOLT_REQUIRE(ctx, a_weights[i] != INT64_MIN && b_weights[i] != INT64_MIN, "integer weight out of range");
     int64_t *wa = nullptr, *wb = nullptr;
@@ -219,8 +225,12 @@ extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* 
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 4));
     s = jolt_internal_ensure_scratch(ctx, n_nodes * (size_t)grid + 8, n_nodes + 8);
     if (s == JOLT_OK) {
-        hipLaunchKernelGGL(k_small_uniskip, dim3(grid, (unsigned)n_nodes), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
-                           (const int64_t*)wb, ctx->d_partials);
+        if (n_streams == 2)
+            hipLaunchKernelGGL(k_small_uniskip<2>, dim3(grid, (unsigned)n_nodes), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
+                               (const int64_t*)wb, ctx->d_partials);
+        else
+            hipLaunchKernelGGL(k_small_uniskip<1>, dim3(grid, (unsigned)n_nodes), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
+                               (const int64_t*)wb, ctx->d_partials);
         s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
     }
     if (s == JOLT_OK) s = reduce_rows_to_host(ctx, n_nodes, grid, 1, out);
@@ -229,16 +239,16 @@ extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* 
     return s;
 }
 
-extern "C" int32_t jolt_r1cs_materialize_small(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, const jolt_fr_t* a_weights, const jolt_fr_t* b_weights,
-                                               jolt_table** az_out, jolt_table** bz_out) {
-    if (!ctx || !inputs || !a_weights || !b_weights || !az_out || !bz_out) return JOLT_ERR_INVALID_ARG;
+extern "C" int32_t jolt_r1cs_materialize_small(jolt_ctx* ctx, const jolt_ints* const* inputs, size_t n_inputs, uint32_t n_streams, const jolt_fr_t* a_weights,
+                                               const jolt_fr_t* b_weights, jolt_table** az_out, jolt_table** bz_out) {
+    if (!ctx || !inputs || !a_weights || !b_weights || !az_out || !bz_out || (n_streams != 1 && n_streams != 2)) return JOLT_ERR_INVALID_ARG;
     IntInputs in;
     size_t cycles = 0;
     JOLT_TRY(gather_ints(ctx, inputs, n_inputs, &in, &cycles));
-    const size_t per = 1 + n_inputs, wcount = 4 * per;
+    const size_t per = 1 + n_inputs, wcount = 2 * n_streams * per;
     std::vector<jolt_fr_t> w(wcount);
-    std::memcpy(w.data(), a_weights, 2 * per * sizeof(jolt_fr_t));
-    std::memcpy(w.data() + 2 * per, b_weights, 2 * per * sizeof(jolt_fr_t));
+    std::memcpy(w.data(), a_weights, n_streams * per * sizeof(jolt_fr_t));
+    std::memcpy(w.data() + n_streams * per, b_weights, n_streams * per * sizeof(jolt_fr_t));
     std::vector<uint8_t> nz(kMaxSmallInputs, 0);
     for (size_t i = 0; i < wcount; ++i) {
         const Fr f = fr_from_abi(&w[i]);
@@ -253,12 +263,16 @@ extern "C" int32_t jolt_r1cs_materialize_small(jolt_ctx* ctx, const jolt_ints* c
     if (s == JOLT_OK) s = upload_bytes(ctx, nz.data(), nz.size(), (void**)&dnz);
     if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, wcount * sizeof(Fr), (void**)&ws);
     if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, wcount * sizeof(Fr), (void**)&nws);
-    if (s == JOLT_OK) s = jolt_internal_table_new(ctx, 2 * cycles, &az);
-    if (s == JOLT_OK) s = jolt_internal_table_new(ctx, 2 * cycles, &bz);
+    if (s == JOLT_OK) s = jolt_internal_table_new(ctx, n_streams * cycles, &az);
+    if (s == JOLT_OK) s = jolt_internal_table_new(ctx, n_streams * cycles, &bz);
     if (s == JOLT_OK) {
         hipLaunchKernelGGL(k_small_prescale, dim3((unsigned)((wcount + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const Fr*)dw, wcount, ws, nws);
-        hipLaunchKernelGGL(k_small_materialize, dim3((unsigned)((cycles + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, in, cycles, (const Fr*)dw, (const Fr*)ws,
-                           (const Fr*)nws, (const uint8_t*)dnz, az->data(), bz->data());
+        if (n_streams == 2)
+            hipLaunchKernelGGL(k_small_materialize<2>, dim3((unsigned)((cycles + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, in, cycles, (const Fr*)dw, (const Fr*)ws,
+                               (const Fr*)nws, (const uint8_t*)dnz, az->data(), bz->data());
+        else
+            hipLaunchKernelGGL(k_small_materialize<1>, dim3((unsigned)((cycles + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, in, cycles, (const Fr*)dw, (const Fr*)ws,
+                               (const Fr*)nws, (const uint8_t*)dnz, az->data(), bz->data());
         if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
     }
     if (dw) jolt_internal_dev_free(ctx, dw);

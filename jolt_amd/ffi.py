@@ -965,20 +965,22 @@ def _tables_evaluate(self, tables, point):
     return out
 
 
-def _r1cs_uniskip_sums_small(self, inputs, eq, a_weights, b_weights):
-    """inputs: Ints columns; a_weights / b_weights: int64 [node][stream][1 + n] (integer Lagrange-extension column weights)"""
-    wa = np.ascontiguousarray(a_weights, dtype=np.int64).reshape(-1, 2, 1 + len(inputs))
-    wb = np.ascontiguousarray(b_weights, dtype=np.int64).reshape(-1, 2, 1 + len(inputs))
+def _r1cs_uniskip_sums_small(self, inputs, eq, a_weights, b_weights, streams=2):
+    """inputs: Ints columns; a_weights / b_weights: int64 [node][stream][1 + n] (integer Lagrange-extension column weights);
+    streams = 2: Spartan outer, streams = 1: product virtualization (no stream variable)"""
+    wa = np.ascontiguousarray(a_weights, dtype=np.int64).reshape(-1, streams, 1 + len(inputs))
+    wb = np.ascontiguousarray(b_weights, dtype=np.int64).reshape(-1, streams, 1 + len(inputs))
     out = fr_array(wa.shape[0])
-    _ck(lib().jolt_r1cs_uniskip_sums_small(self.h, _handles(inputs), C.c_size_t(len(inputs)), eq.h, wa.ctypes.data_as(C.c_void_p), wb.ctypes.data_as(C.c_void_p),
-                                           C.c_size_t(wa.shape[0]), _p(out)), "jolt_r1cs_uniskip_sums_small", self)
+    _ck(lib().jolt_r1cs_uniskip_sums_small(self.h, _handles(inputs), C.c_size_t(len(inputs)), eq.h, C.c_uint32(streams), wa.ctypes.data_as(C.c_void_p),
+                                           wb.ctypes.data_as(C.c_void_p), C.c_size_t(wa.shape[0]), _p(out)), "jolt_r1cs_uniskip_sums_small", self)
     return out
 
 
-def _r1cs_materialize_small(self, inputs, a_weights, b_weights):
-    wa, wb = fr(a_weights).reshape(2, 1 + len(inputs), 4), fr(b_weights).reshape(2, 1 + len(inputs), 4)
+def _r1cs_materialize_small(self, inputs, a_weights, b_weights, streams=2):
+    wa, wb = fr(a_weights).reshape(streams, 1 + len(inputs), 4), fr(b_weights).reshape(streams, 1 + len(inputs), 4)
     az, bz = C.c_void_p(), C.c_void_p()
-    _ck(lib().jolt_r1cs_materialize_small(self.h, _handles(inputs), C.c_size_t(len(inputs)), _p(wa), _p(wb), C.byref(az), C.byref(bz)), "jolt_r1cs_materialize_small", self)
+    _ck(lib().jolt_r1cs_materialize_small(self.h, _handles(inputs), C.c_size_t(len(inputs)), C.c_uint32(streams), _p(wa), _p(wb), C.byref(az), C.byref(bz)),
+        "jolt_r1cs_materialize_small", self)
     return Table(self, az), Table(self, bz)
 
 

@@ -88,3 +88,83 @@ EXPORT void orc_r1cs_materialize(const fr_t *const *inputs, uint32_t n_inputs, s
             bz_out[(t << 1) | s] = bz;
         }
 }
+
+/* ---- Spartan product virtualization (stage 2): crates/jolt-kernels/src/optimized/spartan_product.rs ------------------------------
+ * Three factor lanes on a 3-node centered uni-skip window {-1, 0, 1}, extended to {-2 .. 2}.  Per cycle (extended_products :113-141):
+ *   left(node)  = c0 * left_instruction_input + c1 * lookup_output + c2 * jump_flag
+ *   right(node) = c0 * right_instruction_input + c1 * branch_flag + c2 * (1 - next_is_noop)
+ * with c = extension_coefficients()[node] (:86-105: the integer Lagrange basis of the window at the node; 0/1 selectors inside the
+ * window).  The reference computes these as exact integers (S128 x S192 -> S256); here they are taken mod p first -- the same
+ * field values (ring homomorphism), which is the relation its own parity test asserts. */
+#define PRODUCT_DOMAIN 3
+#define PRODUCT_EXTENDED 5
+static void product_extension_coefficients(int64_t out[PRODUCT_EXTENDED][PRODUCT_DOMAIN]) {
+    const int64_t domain_start = -((PRODUCT_DOMAIN - 1) / 2), extended_start = -((PRODUCT_EXTENDED - 1) / 2);
+    for (int position = 0; position < PRODUCT_EXTENDED; ++position) {
+        const int64_t node = extended_start + position;
+        for (int i = 0; i < PRODUCT_DOMAIN; ++i) {
+            int64_t numerator = 1, denominator = 1;
+            for (int j = 0; j < PRODUCT_DOMAIN; ++j) {
+                if (j == i) continue;
+                numerator *= node - (domain_start + j);
+                denominator *= (int64_t)i - j;
+            }
+            out[position][i] = numerator / denominator; /* exact: consecutive-integer domain */
+        }
+    }
+}
+EXPORT void orc_spartan_product_extension_coefficients(int64_t *out /* 5 x 3 */) {
+    int64_t c[PRODUCT_EXTENDED][PRODUCT_DOMAIN];
+    product_extension_coefficients(c);
+    for (int p = 0; p < PRODUCT_EXTENDED; ++p)
+        for (int i = 0; i < PRODUCT_DOMAIN; ++i) out[p * PRODUCT_DOMAIN + i] = c[p][i];
+}
+static void product_lanes(const uint64_t *left_input, const uint64_t *lookup_output, const uint8_t *jump, const uint64_t *right_input /* i128 two's complement: lo, hi */,
+                          const uint8_t *branch, const uint8_t *next_is_noop, size_t j, fr_t left[3], fr_t right[3]) {
+    left[0] = fr_from_u64(left_input[j]);
+    left[1] = fr_from_u64(lookup_output[j]);
+    left[2] = fr_from_u64(jump[j]);
+    uint64_t lo = right_input[2 * j], hi = right_input[2 * j + 1];
+    const int negative = (int)(hi >> 63);
+    if (negative) {
+        lo = ~lo + 1;
+        hi = ~hi + (lo == 0 ? 1 : 0);
+    }
+    right[0] = fr_from_i128(lo, hi, negative);
+    right[1] = fr_from_u64(branch[j]);
+    right[2] = fr_from_u64(1 - (uint64_t)next_is_noop[j]);
+}
+/* extended_t1_values (:203-230): t1(node) = sum_j eq(tau_low, j) * left_node(j) * right_node(j) for all 5 extended nodes */
+EXPORT void orc_spartan_product_t1(const uint64_t *left_input, const uint64_t *lookup_output, const uint8_t *jump, const uint64_t *right_input, const uint8_t *branch,
+                                   const uint8_t *next_is_noop, size_t cycles, const fr_t *eq, fr_t *out /* 5 */) {
+    int64_t c[PRODUCT_EXTENDED][PRODUCT_DOMAIN];
+    product_extension_coefficients(c);
+    for (int p = 0; p < PRODUCT_EXTENDED; ++p) out[p] = fr_zero();
+    for (size_t j = 0; j < cycles; ++j) {
+        fr_t l[3], r[3];
+        product_lanes(left_input, lookup_output, jump, right_input, branch, next_is_noop, j, l, r);
+        for (int p = 0; p < PRODUCT_EXTENDED; ++p) {
+            fr_t left = fr_zero(), right = fr_zero();
+            for (int i = 0; i < PRODUCT_DOMAIN; ++i) {
+                const fr_t ci = fr_from_i64(c[p][i]);
+                left = FADD(left, FMUL(ci, l[i]));
+                right = FADD(right, FMUL(ci, r[i]));
+            }
+            out[p] = FADD(out[p], FMUL(eq[j], FMUL(left, right)));
+        }
+    }
+}
+/* ProductRemainderKernel::prepare's cell() (:358-378): the remainder's left / right tables under the uni-skip challenge's Lagrange weights */
+EXPORT void orc_spartan_product_tables(const uint64_t *left_input, const uint64_t *lookup_output, const uint8_t *jump, const uint64_t *right_input, const uint8_t *branch,
+                                       const uint8_t *next_is_noop, size_t cycles, const fr_t *weights /* 3 */, fr_t *left, fr_t *right) {
+    for (size_t j = 0; j < cycles; ++j) {
+        fr_t l[3], r[3];
+        product_lanes(left_input, lookup_output, jump, right_input, branch, next_is_noop, j, l, r);
+        left[j] = fr_zero();
+        right[j] = fr_zero();
+        for (int i = 0; i < 3; ++i) {
+            left[j] = FADD(left[j], FMUL(weights[i], l[i]));
+            right[j] = FADD(right[j], FMUL(weights[i], r[i]));
+        }
+    }
+}

@@ -870,3 +870,34 @@ def small_scalar_accumulate(values, scalars):
     o = fr_array(1)
     lib().orc_small_scalar_accumulate(_p(v), sc.ctypes.data_as(C.c_void_p), C.c_size_t(v.shape[0]), _p(o))
     return o[0]
+
+
+# ---- Spartan product virtualization (oracle/r1cs.c) -------------------------------------------------------------------------------
+def spartan_product_extension_coefficients():
+    out = np.zeros((5, 3), dtype=np.int64)
+    lib().orc_spartan_product_extension_coefficients(out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def _product_args(rows):
+    """rows: dict of numpy columns left_input u64, lookup_output u64, jump u8, right_input (n, 2) u64 (i128 two's complement), branch u8, next_is_noop u8"""
+    cols = [np.ascontiguousarray(rows["left_input"], dtype=np.uint64), np.ascontiguousarray(rows["lookup_output"], dtype=np.uint64),
+            np.ascontiguousarray(rows["jump"], dtype=np.uint8), np.ascontiguousarray(rows["right_input"], dtype=np.uint64).reshape(-1, 2),
+            np.ascontiguousarray(rows["branch"], dtype=np.uint8), np.ascontiguousarray(rows["next_is_noop"], dtype=np.uint8)]
+    return cols, [c.ctypes.data_as(C.c_void_p) for c in cols], C.c_size_t(cols[0].shape[0])
+
+
+def spartan_product_t1(rows, eq):
+    cols, ptrs, n = _product_args(rows)
+    e = np.ascontiguousarray(eq, dtype=np.uint64).reshape(-1, 4)
+    out = fr_array(5)
+    lib().orc_spartan_product_t1(*ptrs, n, _p(e), _p(out))
+    return out
+
+
+def spartan_product_tables(rows, weights):
+    cols, ptrs, n = _product_args(rows)
+    w = np.ascontiguousarray(weights, dtype=np.uint64).reshape(3, 4)
+    left, right = fr_array(cols[0].shape[0]), fr_array(cols[0].shape[0])
+    lib().orc_spartan_product_tables(*ptrs, n, _p(w), _p(left), _p(right))
+    return left, right
