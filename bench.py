@@ -180,13 +180,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     sharded = world > 1 or os.environ.get("JOLT_FORCE_SHARDED") == "1"  # the env var exercises the RCCL path with one rank
+    # JOLT_BENCH_SHARE_GPU=1: every rank on device 0 with gloo as the rendezvous backend -- exercises the N > 1 code path of this
+    # file on a one-GPU box (tests/test_gpu_distributed.py); timings in that mode mean nothing
+    share_gpu = os.environ.get("JOLT_BENCH_SHARE_GPU") == "1"
     if sharded:
         import torch
         import torch.distributed as dist
+        if share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from jolt_amd import ffi
     from jolt_amd.workload import DeviceWorkload
 
@@ -198,16 +206,20 @@ def main():
     pcs = None if (args.no_msm or sharded) else "grid"  # (set below for the sharded path once its PCS legs exist)
     if sharded:
         from jolt_amd.distributed import ShardedPcs, ShardedWorkload, make_point_gather
-        wl = ShardedWorkload(ctx, args.scale, rank, world, dist, force_gather=(world == 1))
+        from jolt_amd.distributed import Collective
+        wl = ShardedWorkload(ctx, args.scale, rank, world, dist, force_gather=(world == 1), coll=Collective(dist, world, None) if share_gpu else None)
         pcs_sharded = None
         if not args.no_msm:
             # every rank keeps the raw committed columns of the WHOLE trace resident (inputs: 52 B per cycle), gathered here once
             import torch
 
             def gather_blocks(local):  # (polys, T_local) or (T_local,) -> the same with world * T_local cycles, blocks in rank order
-                t = torch.from_numpy(np.ascontiguousarray(local)).cuda()
-                out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                t = torch.from_numpy(np.ascontiguousarray(local))
+                if not share_gpu:
+                    t = t.cuda()
+                out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)  # concatenated along dim 0 (both backends accept it)
                 dist.all_gather_into_tensor(out, t)
+                out = out.reshape((world,) + tuple(t.shape))
                 if out.dim() == 3:
                     out = out.permute(1, 0, 2).reshape(t.shape[0], -1)
                 else:
@@ -236,6 +248,7 @@ def main():
             import torch
             dist.barrier()
             torch.cuda.synchronize()
+            ctx.synchronize()
 
     for i in range(args.warmup):
         step(label=1000 + i)
@@ -251,7 +264,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3

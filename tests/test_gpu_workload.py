@@ -57,12 +57,12 @@ def test_catalogue_matches_oracle_at_benchmark_scale():
 
 
 def test_stages_match_oracle_at_configs2_scale():
-    """T = 2^22 (BASELINE configs[2] scale): stages 4 and 5 (ram_val_check; registers_val_evaluation + ram_ra_claim_reduction with its
-    fused eq leaves) against the oracle, transcript for transcript."""
+    """T = 2^22 (BASELINE configs[2] scale, the benchmarked size): ALL five stages of the 11-relation catalogue against the oracle,
+    transcript for transcript (every round polynomial, challenge and final claim)."""
     O.baseline_set_threads(min(48, os.cpu_count() or 1))
     ctx = ffi.Context(0)
     dev = DeviceWorkload(ctx, 22)
-    orc = OracleWorkload(22, only_stages={4, 5})
+    orc = OracleWorkload(22)
     want = orc.prove(label=500)
     got = dev.prove(label=500)
     for stage in want:
