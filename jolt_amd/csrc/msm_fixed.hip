@@ -10,7 +10,7 @@
 // and the host-side Horner over the windows disappears.  Cost: W copies of the bases in HBM (11 x 4 GiB for 2^26 points).
 //
 // Pipeline (integer VALU work, no MFMA):
-//   1. digits   : k_msm_digits (shared with msm.hip) -> keys[w*n + i] = |digit| | sign << 31
+//   1. digits   : k_fx_digits -> keys[w*n + i] = |digit| | sign << 31 (scalars above r/2 negated, unsigned top window)
 //   2. partition: counting sort of the W*n keys by the high bits of |digit| (<= 16385 bins: per-workgroup LDS histograms, one global
 //                 atomic per non-empty bin and slice) into segments of 512 buckets; entries carry (low 9 bits, base index | sign)
 //   3. segments : ONE workgroup per segment sorts it by the low bits in LDS (histogram, scan, scatter) and emits the bucket table
@@ -52,6 +52,43 @@ __global__ __launch_bounds__(kBlock) void k_fx_next_window(const G1Affine* __res
     G1Jac p = g1_from_affine(ld_aff(prev + i));
     for (int k = 0; k < c; ++k) p = g1_double(p);
     next[i] = g1_to_affine(p);
+}
+
+// ---- 1. digits: scalars above (r - 1) / 2 are negated (s P = (r - s)(-P)), c-bit signed windows, UNSIGNED top window -----------------
+// After the negation a scalar has at most 253 bits, so W = ceil(253 / c) windows suffice and the top window needs no carry out: its
+// digit is taken as is (raw + carry in, < top_max).  With c = 23 the 253 bits are exactly 11 windows -- no short top window piling its n
+// digits onto a few thousand buckets (c = 24: 14 bits -> 2^13 buckets) -- and the bucket set is max(2^(c-1), top_max) = 6.34 M
+// buckets instead of the 2^25 of c = 26, whose running-sum reduction cost 10.4 ms per MSM however short the MSM was.
+__global__ __launch_bounds__(kBlock) void k_fx_digits(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t* __restrict__ keys) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Fr s = from_mont(ld_fr(scalars + i));
+    bool flip = false;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {  // s > (r - 1) / 2 ?   ((r - 1) / 2 = r >> 1, r odd)
+        const uint32_t half = ((uint32_t)FrParams::P[j] >> 1) | (j < 7 ? (uint32_t)FrParams::P[j + 1] << 31 : 0u);
+        if (s.l[j] != half) { flip = s.l[j] > half; break; }
+    }
+    if (flip) {
+        uint32_t br = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s.l[j] = __builtin_subc((uint32_t)FrParams::P[j], s.l[j], br, &br);
+    }
+    const uint32_t B = 1u << (c - 1), fl = flip ? 0x80000000u : 0u;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        const int bit = w * c, limb = bit >> 5, off = bit & 31;
+        const uint64_t two = (uint64_t)s.l[limb] | (limb + 1 < 8 ? (uint64_t)s.l[limb + 1] << 32 : 0ull);
+        if (w + 1 < W) {
+            uint32_t raw = ((uint32_t)(two >> off) & ((1u << c) - 1)) + carry;
+            uint32_t mag, negf;
+            if (raw > B) { mag = (1u << c) - raw; negf = 0x80000000u; carry = 1; }
+            else { mag = raw; negf = 0u; carry = 0; }
+            keys[(size_t)w * n + i] = mag | (negf ^ fl);
+        } else {
+            keys[(size_t)w * n + i] = (((uint32_t)(two >> off) & 0x7FFFFFFFu) + carry) | fl;  // everything that is left of the <= 253 bits
+        }
+    }
 }
 
 // ---- 2. partition by the high bits of |digit| ------------------------------------------------------------------------------
@@ -414,10 +451,17 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
     if (srs->n == 0) return JOLT_ERR_INVALID_ARG;
     int lg = 0;
     while (((size_t)2 << lg) <= srs->n) lg++;
-    // measured at 2^26 terms: c = 26 (10 windows) 104.9 ms, c = 24 (11 windows, whose 14-bit top window piles onto 2^13 buckets) 116.8 ms
-    int c = window_bits ? (int)window_bits : (lg >= 26 ? 26 : std::max(kLoBitsMin + 1, std::min(24, lg - 2)));
+    // c = 23: the 253 bits of a (negated where needed) scalar are exactly 11 windows and the bucket set stays small (k_fx_digits)
+    int c = window_bits ? (int)window_bits : (lg >= 24 ? 23 : std::max(kLoBitsMin + 1, std::min(24, lg - 2)));
     if (c <= kLoBitsMin || c > 26) return JOLT_ERR_UNSUPPORTED;
-    const int W = (255 + c - 1) / c;
+    const int W = (253 + c - 1) / c;
+    // buckets: magnitudes of the signed windows (<= 2^(c-1)) and of the unsigned top window (<= ((r - 1) / 2 >> c (W - 1)) + 1)
+    const int shift = c * (W - 1) + 1;  // (r - 1) / 2 >> k = r >> (k + 1), r odd
+    if (254 - shift > 31) return JOLT_ERR_UNSUPPORTED;  // the top window must fit a 31-bit magnitude
+    auto limb32 = [](int j) -> uint64_t { return j < 8 ? (uint64_t)(uint32_t)FrParams::P[j] : 0ull; };
+    const uint64_t top_max = ((limb32(shift >> 5) | (limb32((shift >> 5) + 1) << 32)) >> (shift & 31)) + 1;  // <= 31 significant bits: two limbs cover them
+    if (top_max >= ((uint64_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
+    const uint32_t n_bucket_max = (uint32_t)std::max<uint64_t>((uint64_t)1 << (c - 1), top_max);
     if ((size_t)W * srs->n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;  // base index + sign share 32 bits
     G1Affine* pre = nullptr;
     hipError_t e = hipMalloc((void**)&pre, (size_t)W * srs->n * sizeof(G1Affine));
@@ -437,8 +481,9 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
     srs->pre = pre;
     srs->pre_c = c;
     srs->pre_W = W;
+    srs->pre_B = n_bucket_max;
     srs->pre_stride = srs->n;
-    // crossover against the per-window method (prefix MSMs over 2^26-point tables): 2^22 terms at c = 24, 2^24 at c = 26
+    // crossover against the per-window method (prefix MSMs over 2^26-point tables)
     srs->pre_min_n = min_terms ? min_terms : std::max<size_t>((size_t)1 << (c - 2), 256);
     return JOLT_OK;
 }
@@ -453,7 +498,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const int c = srs->pre_c, W = srs->pre_W;
     const int lo_bits = fx_lo_bits(c);
     const uint32_t kSegBuckets = 1u << lo_bits;
-    const uint32_t B = 1u << (c - 1);
+    const uint32_t B = srs->pre_B;                          // largest |digit| (signed windows: 2^(c-1); unsigned top window: top_max)
     const uint32_t nb1 = (B >> lo_bits) + 1;               // the segment of |digit| = B included
     const size_t total = (size_t)W * n;
     if (total >= ((size_t)1 << 32)) return JOLT_ERR_UNSUPPORTED;
@@ -521,7 +566,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, st));
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
-    hipLaunchKernelGGL(k_msm_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, c, W, keys, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, c, W, keys);
     if (lo_bits == 9) hipLaunchKernelGGL(k_fx_hist<9>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
     else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
     hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, st, (const uint32_t*)hist1, nb1, offs1, cur1, info);
