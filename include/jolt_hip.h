@@ -468,6 +468,33 @@ int32_t jolt_grid_joint_polynomial(jolt_ctx *ctx, const jolt_onehot *const *sour
                                    jolt_table *const *dense, size_t n_dense, const jolt_fr_t *dense_scalars, uint32_t log_k,
                                    jolt_table **out);
 
+/* Instruction read+RAF checking (stage 5) -- SURVEY.md section 8(f) row 4.  Replaces the T-scale scans of
+ * OptimizedInstructionReadRafKernel (crates/jolt-kernels/src/optimized/instruction_read_raf.rs): per prefix-suffix phase the
+ * condensation of the per-cycle mass (:750-758), the fused RAF scan (:770-812) and the per-table suffix accumulators
+ * (init_suffix_tables :901-971), and after the address rounds the combined-value / ra_i columns of the cycle rounds
+ * (pending_combined_base / pending_ra_base :1203-1232; sum them with jolt_member_create_split_eq_lc: one group of 1 + ra_count factors).
+ * The 256-entry prefix polynomials, checkpoints and address-round messages stay in Rust; the flag claims of output_claims are
+ * jolt_onehot_pushforward over the table-index column.
+ *   rows: lookup_index as (lo, hi) u64 pairs, table_index (0xFF = no lookup table; < n_tables <= 126), raf_flag (0 / 1).
+ *   suffix_offsets[n_tables + 1] / suffix_kinds[]: LookupTableKind::suffixes() of every table, flattened; a kind is the discriminant of
+ *     `enum Suffixes` (crates/jolt-lookup-tables/src/tables/suffixes/mod.rs:120-170, all 48 built; XLEN = 64).
+ *   jolt_read_raf_phase_scan: raf_out[q * 256 + chunk], q = left, right, identity, shift_half, shift_full, upper_all_ones (raw sums: the
+ *     caller applies mul_pow_2 to the shift sums, :814-823; upper_all_ones only with canonical != 0, the `akita` feature);
+ *     suffix_out[(suffix_offsets[t] + s) * 256 + chunk]; chunk = (lookup_index >> suffix_len) & 255, suffix_len = address_bits - 8 (phase + 1).
+ *   jolt_read_raf_condense: u[j] *= v_table[(lookup_index[j] >> shift) & 255].
+ *   jolt_read_raf_cycle_tables: v_tables = the `phases` bound-challenge eq tables (256 entries each), phases * 8 = address_bits. */
+typedef struct jolt_read_raf jolt_read_raf;
+int32_t jolt_read_raf_create(jolt_ctx *ctx, const uint64_t *lookup_index, const uint8_t *table_index, const uint8_t *raf_flag, size_t cycles, uint32_t n_tables,
+                             jolt_read_raf **out);
+int32_t jolt_read_raf_destroy(jolt_ctx *ctx, jolt_read_raf *rr);
+int32_t jolt_read_raf_cycles(const jolt_read_raf *rr, size_t *cycles, uint32_t *n_tables);
+int32_t jolt_read_raf_phase_scan(jolt_ctx *ctx, jolt_read_raf *rr, const jolt_table *u, uint32_t suffix_len, uint32_t address_bits, int32_t canonical,
+                                 const uint32_t *suffix_offsets, const uint8_t *suffix_kinds, jolt_fr_t *raf_out, jolt_fr_t *suffix_out);
+int32_t jolt_read_raf_condense(jolt_ctx *ctx, jolt_read_raf *rr, jolt_table *u, const jolt_fr_t *v_table, uint32_t shift);
+int32_t jolt_read_raf_cycle_tables(jolt_ctx *ctx, jolt_read_raf *rr, const jolt_fr_t *table_values, const jolt_fr_t *raf_interleaved, const jolt_fr_t *raf_identity,
+                                   const jolt_fr_t *v_tables, uint32_t phases, uint32_t address_bits, uint32_t ra_count, jolt_table **combined_out,
+                                   jolt_table **ra_out);
+
 /* Spartan outer (stage 1) T-scale sums -- SURVEY.md section 8(f) row 3 (crates/jolt-kernels/src/{reference,optimized}/spartan_outer.rs).
  * The constraint list, spartan_outer_row_weights and the Lagrange interpolation stay in Rust (O(rows) work); the caller folds the
  * per-(node, stream) row weights into per-column weights (ConstraintMatrices::weighted_columns + public_column_contributions,

@@ -1022,3 +1022,52 @@ def _rows_onehot_sentinel(self, offset, width, shifts, log_k, cycles=None):
 
 Rows.window_table = _rows_window_table
 Rows.onehot_sentinel = _rows_onehot_sentinel
+
+
+# ---- instruction read+RAF checking scans (read_raf.hip) ---------------------------------------------------------------------------
+class ReadRaf:
+    """lookup_index: (T, 2) uint64 (lo, hi); table_index: uint8 (0xFF = none); raf_flag: uint8"""
+
+    def __init__(self, ctx, lookup_index, table_index, raf_flag, n_tables):
+        idx = np.ascontiguousarray(lookup_index, dtype=np.uint64).reshape(-1, 2)
+        tab = np.ascontiguousarray(table_index, dtype=np.uint8)
+        raf = np.ascontiguousarray(raf_flag, dtype=np.uint8)
+        assert idx.shape[0] == tab.shape[0] == raf.shape[0]
+        self.ctx, self.cycles, self.n_tables = ctx, idx.shape[0], n_tables
+        h = C.c_void_p()
+        _ck(lib().jolt_read_raf_create(ctx.h, idx.ctypes.data_as(C.c_void_p), tab.ctypes.data_as(C.c_void_p), raf.ctypes.data_as(C.c_void_p), C.c_size_t(self.cycles),
+                                       C.c_uint32(n_tables), C.byref(h)), "jolt_read_raf_create", ctx)
+        self.h = h
+
+    def phase_scan(self, u, suffix_len, address_bits, suffix_lists, canonical=False):
+        """suffix_lists: per table the list of suffix kind ids -> (raf (6, 256, 4), suffix sums (total, 256, 4))"""
+        offs = np.zeros(self.n_tables + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(l) for l in suffix_lists])
+        kinds = np.array([k for l in suffix_lists for k in l], dtype=np.uint8)
+        raf = fr_array(6 * 256)
+        suf = fr_array(max(int(offs[-1]) * 256, 1))
+        _ck(lib().jolt_read_raf_phase_scan(self.ctx.h, self.h, u.h, C.c_uint32(suffix_len), C.c_uint32(address_bits), C.c_int32(1 if canonical else 0),
+                                           offs.ctypes.data_as(C.c_void_p), kinds.ctypes.data_as(C.c_void_p) if kinds.size else None, _p(raf), _p(suf)),
+            "jolt_read_raf_phase_scan", self.ctx)
+        return raf.reshape(6, 256, 4), suf[: int(offs[-1]) * 256].reshape(-1, 256, 4)
+
+    def condense(self, u, v_table, shift):
+        v = fr(v_table).reshape(256, 4)
+        _ck(lib().jolt_read_raf_condense(self.ctx.h, self.h, u.h, _p(v), C.c_uint32(shift)), "jolt_read_raf_condense", self.ctx)
+
+    def cycle_tables(self, table_values, raf_interleaved, raf_identity, v_tables, address_bits, ra_count):
+        tv = fr(table_values).reshape(self.n_tables, 4)
+        vt = fr(v_tables).reshape(-1, 256, 4)
+        combined = C.c_void_p()
+        ra = (C.c_void_p * ra_count)()
+        _ck(lib().jolt_read_raf_cycle_tables(self.ctx.h, self.h, _p(tv), _p(fr(raf_interleaved).reshape(4)), _p(fr(raf_identity).reshape(4)), _p(vt), C.c_uint32(vt.shape[0]),
+                                             C.c_uint32(address_bits), C.c_uint32(ra_count), C.byref(combined), ra), "jolt_read_raf_cycle_tables", self.ctx)
+        return Table(self.ctx, combined), [Table(self.ctx, C.c_void_p(p)) for p in ra]
+
+    def free(self):
+        if self.h:
+            lib().jolt_read_raf_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+Context.read_raf = lambda self, lookup_index, table_index, raf_flag, n_tables: ReadRaf(self, lookup_index, table_index, raf_flag, n_tables)

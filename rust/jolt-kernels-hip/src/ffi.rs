@@ -248,6 +248,12 @@ extern "C" {
     pub fn jolt_table_from_ints(ctx: *mut jolt_ctx, values: *const jolt_ints, offset: usize, len: usize, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_grid_commit_onehot(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_joint_polynomial(ctx: *mut jolt_ctx, sources: *const *const jolt_onehot, n_sources: usize, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, log_k: u32, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_read_raf_create(ctx: *mut jolt_ctx, lookup_index: *const u64, table_index: *const u8, raf_flag: *const u8, cycles: usize, n_tables: u32, out: *mut *mut jolt_read_raf) -> i32;
+    pub fn jolt_read_raf_destroy(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf) -> i32;
+    pub fn jolt_read_raf_cycles(rr: *const jolt_read_raf, cycles: *mut usize, n_tables: *mut u32) -> i32;
+    pub fn jolt_read_raf_phase_scan(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, u: *const jolt_table, suffix_len: u32, address_bits: u32, canonical: i32, suffix_offsets: *const u32, suffix_kinds: *const u8, raf_out: *mut jolt_fr_t, suffix_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_read_raf_condense(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, u: *mut jolt_table, v_table: *const jolt_fr_t, shift: u32) -> i32;
+    pub fn jolt_read_raf_cycle_tables(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, table_values: *const jolt_fr_t, raf_interleaved: *const jolt_fr_t, raf_identity: *const jolt_fr_t, v_tables: *const jolt_fr_t, phases: u32, address_bits: u32, ra_count: u32, combined_out: *mut *mut jolt_table, ra_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_r1cs_uniskip_sums(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, eq: *const jolt_table, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, n_nodes: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_r1cs_materialize(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, az_out: *mut *mut jolt_table, bz_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_tables_evaluate(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, k: usize, point: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;

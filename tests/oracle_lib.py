@@ -901,3 +901,57 @@ def spartan_product_tables(rows, weights):
     left, right = fr_array(cols[0].shape[0]), fr_array(cols[0].shape[0])
     lib().orc_spartan_product_tables(*ptrs, n, _p(w), _p(left), _p(right))
     return left, right
+
+
+# ---- instruction read+RAF checking scans (oracle/read_raf.c) ------------------------------------------------------------------------
+NUM_SUFFIX_KINDS = 48
+
+
+def suffix_mle(kind, bits, length):
+    lib().orc_suffix_mle.restype = C.c_uint64
+    b = bits % (1 << length) if length < 128 else bits
+    return int(lib().orc_suffix_mle(C.c_uint32(kind), C.c_uint64(b & (2**64 - 1)), C.c_uint64(b >> 64), C.c_uint32(length)))
+
+
+def suffix_is_01_valued(kind):
+    return bool(lib().orc_suffix_is_01_valued(C.c_uint32(kind)))
+
+
+def _rr_args(lookup_index, table_index, raf_flag):
+    idx = np.ascontiguousarray(lookup_index, dtype=np.uint64).reshape(-1, 2)
+    tab = np.ascontiguousarray(table_index, dtype=np.uint8)
+    raf = np.ascontiguousarray(raf_flag, dtype=np.uint8)
+    return idx, tab, raf
+
+
+def read_raf_phase_scan(lookup_index, table_index, raf_flag, n_tables, u, suffix_len, address_bits, suffix_lists, canonical=False):
+    idx, tab, raf = _rr_args(lookup_index, table_index, raf_flag)
+    offs = np.zeros(n_tables + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(l) for l in suffix_lists])
+    kinds = np.array([k for l in suffix_lists for k in l] + [0], dtype=np.uint8)
+    uu = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, 4)
+    raf_out, suf = fr_array(6 * 256), fr_array(max(int(offs[-1]) * 256, 1))
+    lib().orc_read_raf_phase_scan(idx.ctypes.data_as(C.c_void_p), tab.ctypes.data_as(C.c_void_p), raf.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), C.c_uint32(n_tables),
+                                  _p(uu), C.c_uint32(suffix_len), C.c_uint32(address_bits), C.c_int(1 if canonical else 0), offs.ctypes.data_as(C.c_void_p),
+                                  kinds.ctypes.data_as(C.c_void_p), _p(raf_out), _p(suf))
+    return raf_out.reshape(6, 256, 4), suf[: int(offs[-1]) * 256].reshape(-1, 256, 4)
+
+
+def read_raf_condense(lookup_index, u, v_table, shift):
+    idx = np.ascontiguousarray(lookup_index, dtype=np.uint64).reshape(-1, 2)
+    out = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, 4).copy()
+    v = np.ascontiguousarray(v_table, dtype=np.uint64).reshape(256, 4)
+    lib().orc_read_raf_condense(idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), _p(v), C.c_uint32(shift), _p(out))
+    return out
+
+
+def read_raf_cycle_tables(lookup_index, table_index, raf_flag, table_values, raf_interleaved, raf_identity, v_tables, address_bits, ra_count):
+    idx, tab, raf = _rr_args(lookup_index, table_index, raf_flag)
+    tv = np.ascontiguousarray(table_values, dtype=np.uint64).reshape(-1, 4)
+    vt = np.ascontiguousarray(v_tables, dtype=np.uint64).reshape(-1, 256, 4)
+    T = idx.shape[0]
+    combined, ra = fr_array(T), fr_array(ra_count * T)
+    lib().orc_read_raf_cycle_tables(idx.ctypes.data_as(C.c_void_p), tab.ctypes.data_as(C.c_void_p), raf.ctypes.data_as(C.c_void_p), C.c_size_t(T), _p(tv),
+                                    _p(np.ascontiguousarray(raf_interleaved, dtype=np.uint64).reshape(4)), _p(np.ascontiguousarray(raf_identity, dtype=np.uint64).reshape(4)),
+                                    _p(vt), C.c_uint32(vt.shape[0]), C.c_uint32(address_bits), C.c_uint32(ra_count), _p(combined), _p(ra))
+    return combined, ra.reshape(ra_count, T, 4)

@@ -25,6 +25,8 @@ JOLT_MSM_LANES=1 bash tools/prof_msm_fixed.sh 26 26 30 > "$OUT/msm_fixed_kernels
 timeout 300 python tools/bench_rw.py 20 16 > "$OUT/rw_matrix.txt" 2>&1
 timeout 300 python tools/bench_rw.py 22 16 >> "$OUT/rw_matrix.txt" 2>&1
 [ -f tools/bench_r1cs.py ] && timeout 300 python tools/bench_r1cs.py 22 > "$OUT/r1cs.txt" 2>&1
+timeout 300 python tools/bench_read_raf.py 20 > "$OUT/read_raf.txt" 2>&1
+timeout 300 python tools/bench_read_raf.py 22 >> "$OUT/read_raf.txt" 2>&1
 # bind kernel: HIP-event roofline leg, the same command under rocprofv3, and its HBM traffic from PMC (separate passes)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_bind

@@ -10,6 +10,7 @@ cp $SRC/msm_fixed.jsonl profiles/${TAG}_msm_fixed_base.jsonl
 cp $SRC/msm_fixed_kernels.txt profiles/${TAG}_msm_fixed_base_kernels.txt
 cp $SRC/rw_matrix.txt profiles/${TAG}_rw_matrix.txt
 [ -f $SRC/r1cs.txt ] && cp $SRC/r1cs.txt profiles/${TAG}_spartan_outer.txt
+[ -f $SRC/read_raf.txt ] && cp $SRC/read_raf.txt profiles/${TAG}_read_raf.txt
 cp $SRC/bind_roofline_bench.json profiles/${TAG}_bind_roofline_bench.json
 cp $SRC/bind_roofline_kernel_stats.txt profiles/${TAG}_bind_roofline_kernel_stats.txt
 cp $SRC/bind_traffic.json profiles/bind_traffic.json
