@@ -36,9 +36,10 @@ struct MsmJob {
 
 namespace {
 
-// buckets per segment = 2^LO: 512 up to 24-bit windows, 2048 for 25/26-bit windows (keeps the partition at <= 16385 bins of LDS)
-constexpr int kLoBitsMin = 9;
-static inline int fx_lo_bits(int c) { return c > 24 ? 11 : 9; }
+// buckets per segment = 2^LO: 256 up to 24-bit windows (a whole sorted segment then fits the LDS of a CU: k_fx_segment_sort_staged),
+// 2048 for 25/26-bit windows (keeps the partition at <= 16385 bins of LDS)
+constexpr int kLoBitsMin = 8;
+static inline int fx_lo_bits(int c) { return c > 24 ? 11 : 8; }
 // list-length classes of the bucket order: exact lengths up to kClasses - 1; empty and heavy buckets share class 0 (no light work)
 constexpr uint32_t kClasses = 512;
 __device__ __forceinline__ uint32_t bucket_class(uint32_t count, uint32_t heavy_threshold) {
@@ -385,6 +386,120 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
 }
 
 
+// ---- 3'. the same with the sorted segment STAGED IN LDS (LO = 8: ~30 K base indices per segment at 2^26 terms = 120 KB) --------------
+// k_fx_segment_sort scatters each 4-byte base index straight to global memory: with ~2000 segments in flight (0.5 GB of open output)
+// nothing merges in L2 and the 738 M isolated stores made the kernel the slowest of the sort (11.3 ms at 1.3 TB/s).  Here one
+// 1024-thread workgroup owns the LDS of a CU, scatters into it and copies the finished segment out with adjacent lanes on adjacent
+// addresses.  Segments that do not fit (skewed digits) fall back to the direct scatter.
+constexpr int kSegThreads = 1024;
+template <int LO>
+__global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ offs1, const uint64_t* __restrict__ entries,
+                                                                       uint32_t* __restrict__ sorted, uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets,
+                                                                       uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
+                                                                       uint32_t heavy_cap, uint32_t* __restrict__ class_hist, uint32_t stage_cap) {
+    constexpr uint32_t kSegBuckets = 1u << LO;
+    static_assert(kSegBuckets <= (uint32_t)kSegThreads, "one bucket per thread in the scan");
+    extern __shared__ uint32_t fx_stage[];
+    __shared__ uint32_t cnt[kSegBuckets], cur[kSegBuckets], first_pos[kSegBuckets], cls[kClasses], wsum[kSegThreads / 64], s_max;
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t total = hist1[seg], base = offs1[seg];
+    if (tid < kSegBuckets) cnt[tid] = 0;
+    if (tid < kClasses) cls[tid] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + u * kSegThreads + tid;
+            e[u] = k < total ? entries[base + k] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (kSegBuckets - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t c = 0, incl = 0;
+    if (tid < kSegBuckets) {  // exclusive scan of the bucket counts: one bucket per thread, wave scans + wave totals
+        c = cnt[tid];
+        incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)(tid & 63) >= off) incl += o;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        atomicMax(&s_max, c);
+    }
+    __syncthreads();
+    if (tid < kSegBuckets) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < (tid >> 6); ++k) before += wsum[k];
+        const uint32_t excl = before + incl - c, slot = seg * kSegBuckets + tid;
+        cur[tid] = excl;
+        first_pos[tid] = excl;
+        hist[slot] = c;
+        offsets[slot] = base + excl;
+        atomicAdd(&cls[bucket_class(c, heavy_threshold)], 1u);
+        if (c > heavy_threshold) {
+            const uint32_t nseg = (c + kHeavySeg - 1) / kHeavySeg;
+            const uint32_t first = atomicAdd(heavy_count, nseg);
+            for (uint32_t sgi = 0; sgi < nseg && first + sgi < heavy_cap; ++sgi) {
+                heavy_list[2 * (first + sgi)] = slot;
+                heavy_list[2 * (first + sgi) + 1] = sgi;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kClasses && cls[tid]) atomicAdd(&class_hist[tid], cls[tid]);
+    // The staged output is produced in windows of `span` positions: window h takes the buckets whose first position lies in
+    // [h * span, (h + 1) * span); their entries end before (h + 1) * span + (largest bucket), which fits the stage by the choice of span.
+    // A segment of 43.7 K entries (the low 2^22 buckets at c = 23, 2^26 terms) needs two windows of the 37 K-entry stage.
+    const uint32_t largest = s_max;
+    const bool staged = stage_cap > 2 * largest && stage_cap >= 4096;  // block-uniform; else: the direct scatter
+    const uint32_t span = staged ? stage_cap - largest : total + 1;
+    uint32_t* out = sorted + base;
+    const uint32_t n_stage_windows = staged ? (total + span - 1) / span : 1;
+    uint32_t copied = 0;  // positions already written out (the previous window's last bucket may reach into this window's range)
+    for (uint32_t wi = 0; wi < n_stage_windows; ++wi) {
+        const uint32_t w_lo = wi * span;
+        for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
+            uint64_t e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + u * kSegThreads + tid;
+                e[u] = k < total ? entries[base + k] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e[u] == ~0ull) continue;
+                const uint32_t bk = (uint32_t)(e[u] >> 32) & (kSegBuckets - 1);
+                if (staged) {
+                    const uint32_t fp = first_pos[bk];
+                    if (fp < w_lo || fp >= w_lo + span) continue;
+                    fx_stage[atomicAdd(&cur[bk], 1u) - w_lo] = (uint32_t)e[u];
+                } else {
+                    out[atomicAdd(&cur[bk], 1u)] = (uint32_t)e[u];
+                }
+            }
+        }
+        if (!staged) break;
+        __syncthreads();
+        // this window's entries: from w_lo to the end of its last bucket = the first position of the next window's first bucket
+        uint32_t w_hi = total;
+        {   // the smallest first position >= w_lo + span (positions are increasing in the bucket index)
+            __shared__ uint32_t s_hi;
+            if (tid == 0) s_hi = total;
+            __syncthreads();
+            if (tid < kSegBuckets && first_pos[tid] >= w_lo + span) atomicMin(&s_hi, first_pos[tid]);
+            __syncthreads();
+            w_hi = s_hi;
+        }
+        for (uint32_t k = copied + tid; k < w_hi; k += kSegThreads) out[k] = fx_stage[k - w_lo];
+        copied = w_hi;
+        __syncthreads();
+    }
+}
+
 // ---- 3b. bucket order: longest lists first, equal lengths side by side -----------------------------------------------------
 // One lane sums one bucket, so a wavefront takes as long as its fullest bucket: with Poisson-distributed list lengths (mean 88 at
 // c = 24, 2^26 terms) the 64 lanes of a wavefront idle ~22 % of the time when buckets are taken in index order.  Buckets are therefore
@@ -547,13 +662,15 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const size_t lds_bytes = (size_t)nb1 * sizeof(uint32_t);
     if (lds_bytes > ctx->max_lds_per_block) return JOLT_ERR_UNSUPPORTED;
     if (!ctx->msm_fx_attr_set) {
-        hipError_t a1 = hipFuncSetAttribute((const void*)k_fx_hist<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-        hipError_t a2 = hipFuncSetAttribute((const void*)k_fx_scatter<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t a1 = hipFuncSetAttribute((const void*)k_fx_hist<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t a2 = hipFuncSetAttribute((const void*)k_fx_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         hipError_t a3 = hipFuncSetAttribute((const void*)k_fx_hist<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         hipError_t a4 = hipFuncSetAttribute((const void*)k_fx_scatter<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-        hipError_t p1 = hipFuncSetAttribute((const void*)k_fx_partition_groups<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        (void)hipFuncSetAttribute((const void*)k_fx_segment_sort_staged<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0));
+        (void)hipGetLastError();
+        hipError_t p1 = hipFuncSetAttribute((const void*)k_fx_partition_groups<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t p2 = hipFuncSetAttribute((const void*)k_fx_partition_groups<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
-        hipError_t p3 = hipFuncSetAttribute((const void*)k_fx_partition_segments<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        hipError_t p3 = hipFuncSetAttribute((const void*)k_fx_partition_segments<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t p4 = hipFuncSetAttribute((const void*)k_fx_partition_segments<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         if (p1 != hipSuccess || p2 != hipSuccess || p3 != hipSuccess || p4 != hipSuccess) {
             (void)hipGetLastError();
@@ -569,7 +686,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
     hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, c, W, keys);
-    if (lo_bits == 9) hipLaunchKernelGGL(k_fx_hist<9>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
+    if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
     else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
     hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, st, (const uint32_t*)hist1, nb1, offs1, cur1, info);
     JOLT_HIP_TRY(ctx, hipGetLastError());
@@ -580,10 +697,10 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned part_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, (total + kPartTile - 1) / kPartTile));
     if (two_pass) {
         hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, st, (const uint32_t*)offs1, n_groups, group_cursor);
-        if (lo_bits == 9) {
-            hipLaunchKernelGGL(k_fx_partition_groups<9>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
+        if (lo_bits == 8) {
+            hipLaunchKernelGGL(k_fx_partition_groups<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
                                group_cursor, grouped);
-            hipLaunchKernelGGL(k_fx_partition_segments<9>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
+            hipLaunchKernelGGL(k_fx_partition_segments<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
                                (const uint32_t*)info, cur1, entries);
         } else {
             hipLaunchKernelGGL(k_fx_partition_groups<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
@@ -591,14 +708,19 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
             hipLaunchKernelGGL(k_fx_partition_segments<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
                                (const uint32_t*)info, cur1, entries);
         }
-    } else if (lo_bits == 9) {
-        hipLaunchKernelGGL(k_fx_scatter<9>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
+    } else if (lo_bits == 8) {
+        hipLaunchKernelGGL(k_fx_scatter<8>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
     } else {
         hipLaunchKernelGGL(k_fx_scatter<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
     }
-    if (lo_bits == 9)
-        hipLaunchKernelGGL(k_fx_segment_sort<9>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
-                           heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
+    if (lo_bits == 8) {
+        // LDS for the staged segment: twice the average segment (uniform digits spread by ~1 %), at most what a CU has
+        const size_t lds_max = ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0;  // cnt / cur / cls / wave sums live next to it
+        const size_t want = (2 * (total / nb1) + 2048) * 4;
+        const size_t stage_bytes = ctx->msm_fx_stage ? std::min(lds_max, want) : 0;
+        hipLaunchKernelGGL(k_fx_segment_sort_staged<8>, dim3(nb1), dim3(kSegThreads), stage_bytes, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys,
+                           hist, offs, heavy_threshold, heavy, hcnt, heavy_cap, class_hist, (uint32_t)(stage_bytes / 4));
+    }
     else
         hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
                            heavy_threshold, heavy, hcnt, heavy_cap, class_hist);

@@ -19,8 +19,8 @@ cut -c1-260 "$OUT/bench.json"
 bash tools/prof_step.sh "$TAG/step" > /dev/null 2>&1
 head -12 "$OUT/step/bench_kernel_stats.txt" | cut -c1-150
 # fixed-base MSM: timings (full length + prefixes) and the kernel sequence of one 2^26-term MSM
-JOLT_BENCH_PREFIXES="20 22 23 24 25" timeout 600 python tools/bench_msm_fixed.py 26 26 > "$OUT/msm_fixed.jsonl" 2> "$OUT/msm_fixed.err"
-JOLT_MSM_LANES=1 bash tools/prof_msm_fixed.sh 26 26 30 > "$OUT/msm_fixed_kernels.txt" 2>&1
+JOLT_BENCH_PREFIXES="20 21 22 23 24 25" timeout 600 python tools/bench_msm_fixed.py 26 23 26 > "$OUT/msm_fixed.jsonl" 2> "$OUT/msm_fixed.err"
+JOLT_MSM_LANES=1 bash tools/prof_msm_fixed.sh 26 23 30 > "$OUT/msm_fixed_kernels.txt" 2>&1
 # sparse read-write matrix and Spartan outer sums at trace scale
 timeout 300 python tools/bench_rw.py 20 16 > "$OUT/rw_matrix.txt" 2>&1
 timeout 300 python tools/bench_rw.py 22 16 >> "$OUT/rw_matrix.txt" 2>&1
