@@ -13,6 +13,9 @@ namespace jolt {
 namespace msmk {
 namespace {  // kernels have internal linkage: each including .hip carries its own copies
 
+#ifndef JOLT_BUCKET_XYZZ
+#define JOLT_BUCKET_XYZZ 1  // bucket accumulators in XYZZ coordinates (g1.hip.h); 0: Jacobian madd-2007-bl, for A/B builds
+#endif
 constexpr int kLaneCap = 128;    // a bucket whose points-per-lane would exceed max(this, 4x the average) is heavy ...
 constexpr int kHeavySeg = 1024;  // ... and is summed by one wavefront per segment of this many points, segment sums combined afterwards
 constexpr int kPeelMax = 16;     // max rounds of same-key aggregation before falling back to per-lane atomics
@@ -214,17 +217,25 @@ __device__ __forceinline__ G1Jac wave_sum_g1(G1Jac acc, int width) {
 template <bool PIPELINED>
 __device__ __forceinline__ G1Jac sum_bucket_points(const uint32_t* __restrict__ src, const G1Affine* __restrict__ bases, uint32_t lo, uint32_t hi,
                                                    uint32_t stride) {
+#if JOLT_BUCKET_XYZZ
+    G1Xyzz acc = g1x_identity();
+#define JOLT_BUCKET_ADD(a, p) g1x_add_mixed(a, p)
+#define JOLT_BUCKET_OUT(a) g1x_to_jac(a)
+#else
     G1Jac acc = g1_identity();
+#define JOLT_BUCKET_ADD(a, p) g1_add_mixed(a, p)
+#define JOLT_BUCKET_OUT(a) (a)
+#endif
     if constexpr (!PIPELINED) {
         for (uint32_t k = lo; k < hi; k += stride) {
             uint32_t v = src[k];
             G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
             if (v >> 31) p.y = neg(p.y);
-            acc = g1_add_mixed(acc, p);
+            acc = JOLT_BUCKET_ADD(acc, p);
         }
-        return acc;
+        return JOLT_BUCKET_OUT(acc);
     } else {
-        if (lo >= hi) return acc;
+        if (lo >= hi) return JOLT_BUCKET_OUT(acc);
         uint32_t v = src[lo];
         G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
         for (uint32_t k = lo;;) {
@@ -237,14 +248,16 @@ __device__ __forceinline__ G1Jac sum_bucket_points(const uint32_t* __restrict__ 
                 pn = ld_aff(bases + (vn & 0x7FFFFFFFu));
             }
             if (v >> 31) p.y = neg(p.y);
-            acc = g1_add_mixed(acc, p);
+            acc = JOLT_BUCKET_ADD(acc, p);
             if (!more) break;
             v = vn;
             p = pn;
             k = kn;
         }
-        return acc;
+        return JOLT_BUCKET_OUT(acc);
     }
+#undef JOLT_BUCKET_ADD
+#undef JOLT_BUCKET_OUT
 }
 
 // ---- 4a. light buckets: L adjacent lanes per bucket (L = 1 when there are enough buckets to fill the chip) ----------

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
     const size_t p = blockIdx.y;
     const uint8_t* col = hot_col(idx, p * grid_cycles, wide);
     const size_t stride = (size_t)gridDim.x * kBlock;
-    G1Jac acc = g1_identity();
+    G1Xyzz acc = g1x_identity();  // XYZZ accumulator: 8M + 2S per mixed addition (g1.hip.h)
     // software pipeline as in sum_bucket_points<true>: the next index byte and point are in flight during the mixed addition
     size_t j = lo + (size_t)blockIdx.x * kBlock + threadIdx.x;
     uint32_t a = j < cycles ? hot_load(col, j, wide) : kColdIdx;
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
         pn.x = Fq::zero();
         pn.y = Fq::zero();
         if (an != kColdIdx) pn = ld_aff(bases + (size_t)an * grid_cycles + jn);
-        acc = g1_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
+        acc = g1x_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
         pt = pn;
         j = jn;
     }
-    acc = wave_sum_g1(acc, 64);
-    if ((threadIdx.x & 63) == 0) partial[(p * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = acc;
+    const G1Jac total = wave_sum_g1(g1x_to_jac(acc), 64);
+    if ((threadIdx.x & 63) == 0) partial[(p * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = total;
 }
 // out[p] = sum of the column's `count` partial sums (one wavefront per column)
 __global__ __launch_bounds__(64) void k_grid_onehot_fold(const G1Jac* __restrict__ partial, uint32_t count, G1Jac* __restrict__ out) {
