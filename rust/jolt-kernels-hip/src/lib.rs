@@ -10,6 +10,7 @@
 //! | `jolt_kernels::PrepareKernel` (`crates/jolt-kernels/src/backend.rs:98-111`) | [`member::HipPrepare`] (device twin of `NaiveSumcheckProver::new`) |
 //! | `jolt_sumcheck::RoundScheduler` / `BuildRoundScheduler` (`prover.rs:110-120`, `backend.rs:68-70`) | [`scheduler::HipRoundScheduler`] |
 //! | `JoltGroup::msm` for `Bn254G1` (`crates/jolt-crypto/src/ec/group.rs:63-70`) | [`msm::msm_g1`] |
+//! | `optimized::{spartan_outer, spartan_product, ram_read_write, instruction_read_raf}` T-scale loops | [`ops::SpartanSums`], [`ops::HipRwMatrix`], [`ops::HipReadRaf`] |
 //! | HyperKZG prover pieces (`crates/jolt-hyperkzg/src/{kzg,scheme}.rs`) | [`msm::HipSrs`], `ffi::jolt_hyperkzg_*` |
 //!
 //! Host code stays Rust: Fiat-Shamir, claim wiring, round-polynomial assembly (`UnivariatePoly::from_evals`,
@@ -21,11 +22,13 @@ pub mod ffi;
 pub mod context;
 pub mod member;
 pub mod msm;
+pub mod ops;
 pub mod scheduler;
 pub mod status;
 
 pub use context::{HipContext, HipTable};
 pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape};
 pub use msm::{msm_g1, HipSrs};
+pub use ops::{HipInts, HipReadRaf, HipRwMatrix, SpartanSums};
 pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
 pub use status::HipError;

@@ -1,0 +1,231 @@
+//! Safe wrappers of the T-scale operators outside the generic member interface (`SURVEY.md` section 8f): integer witness columns,
+//! the Spartan outer / product sums, the sparse read-write matrix and the instruction read-RAF scans.  Each is what the corresponding
+//! kernel of `jolt_kernels::optimized` calls in place of its rayon loop; host-side O(rounds) / O(256) work stays in that kernel.
+use std::ptr;
+use std::sync::Arc;
+
+use jolt_field::Fr;
+
+use crate::context::{HipContext, HipTable};
+use crate::ffi;
+use crate::status::{check, HipError};
+
+/// Device-resident machine integers: the compact scalars of `Polynomial<T>` (`crates/jolt-poly/src/dense.rs:129-142`).
+pub struct HipInts {
+    ctx: Arc<HipContext>,
+    pub(crate) raw: *mut ffi::jolt_ints,
+}
+// SAFETY: see HipContext.
+unsafe impl Send for HipInts {}
+
+impl HipInts {
+    pub fn from_u64(ctx: &Arc<HipContext>, values: &[u64]) -> Result<Self, HipError> {
+        Self::upload(ctx, values.as_ptr().cast(), ffi::JOLT_INT_U64, values.len())
+    }
+    pub fn from_i64(ctx: &Arc<HipContext>, values: &[i64]) -> Result<Self, HipError> {
+        Self::upload(ctx, values.as_ptr().cast(), ffi::JOLT_INT_I64, values.len())
+    }
+    pub fn from_i128(ctx: &Arc<HipContext>, values: &[i128]) -> Result<Self, HipError> {
+        Self::upload(ctx, values.as_ptr().cast(), ffi::JOLT_INT_I128, values.len())
+    }
+    fn upload(ctx: &Arc<HipContext>, host: *const core::ffi::c_void, kind: i32, count: usize) -> Result<Self, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: `host` points at `count` little-endian integers of the stated width; the upload is synchronous.
+        check(unsafe { ffi::jolt_ints_upload(ctx.raw, host, kind, count, &mut raw) }, ctx.raw)?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
+    /// `Polynomial::bind_to_field`'s promotion of a window of the column.
+    pub fn to_table(&self, offset: usize, len: usize) -> Result<HipTable, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: live handles, valid out-pointer.
+        check(unsafe { ffi::jolt_table_from_ints(self.ctx.raw, self.raw, offset, len, &mut raw) }, self.ctx.raw)?;
+        Ok(HipTable { ctx: Arc::clone(&self.ctx), raw })
+    }
+}
+impl Drop for HipInts {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_ints_upload.
+        let _ = unsafe { ffi::jolt_ints_free(self.ctx.raw, self.raw) };
+    }
+}
+
+fn raw_ints(columns: &[&HipInts]) -> Vec<*const ffi::jolt_ints> {
+    columns.iter().map(|c| c.raw.cast_const()).collect()
+}
+
+/// Stage-1 / stage-2 Spartan sums off the typed integer columns (`optimized/spartan_outer.rs:276-370,780-850`,
+/// `optimized/spartan_product.rs:86-230,321-437`).  `streams` = 2 for outer (cycle || stream), 1 for product virtualization.
+pub struct SpartanSums<'a> {
+    pub ctx: &'a Arc<HipContext>,
+    pub inputs: &'a [&'a HipInts],
+    pub streams: u32,
+}
+
+impl SpartanSums<'_> {
+    /// `t1(node)` for every extended node; `a` / `b`: integer column weights `[node][stream][1 + inputs]`
+    /// (the integer Lagrange extension coefficients folded over the constraint rows).
+    pub fn uniskip_sums(&self, eq: &HipTable, a: &[i64], b: &[i64], nodes: usize) -> Result<Vec<Fr>, HipError> {
+        debug_assert_eq!(a.len(), nodes * self.streams as usize * (1 + self.inputs.len()));
+        let cols = raw_ints(self.inputs);
+        let mut out = vec![Fr::default(); nodes];
+        // SAFETY: array lengths as asserted; layouts as in context.rs.
+        check(
+            unsafe {
+                ffi::jolt_r1cs_uniskip_sums_small(self.ctx.raw, cols.as_ptr(), cols.len(), eq.raw, self.streams, a.as_ptr(), b.as_ptr(), nodes, out.as_mut_ptr().cast())
+            },
+            self.ctx.raw,
+        )?;
+        Ok(out)
+    }
+
+    /// The remainder's bound Az / Bz (left / right) tables under the uni-skip challenge's Lagrange weights (`fold_group`, `cell()`).
+    pub fn materialize(&self, a: &[Fr], b: &[Fr]) -> Result<(HipTable, HipTable), HipError> {
+        let cols = raw_ints(self.inputs);
+        let (mut az, mut bz) = (ptr::null_mut(), ptr::null_mut());
+        // SAFETY: as above.
+        check(
+            unsafe { ffi::jolt_r1cs_materialize_small(self.ctx.raw, cols.as_ptr(), cols.len(), self.streams, a.as_ptr().cast(), b.as_ptr().cast(), &mut az, &mut bz) },
+            self.ctx.raw,
+        )?;
+        Ok((HipTable { ctx: Arc::clone(self.ctx), raw: az }, HipTable { ctx: Arc::clone(self.ctx), raw: bz }))
+    }
+
+    /// `compute_claimed_inputs`: every input evaluated at `r_cycle` from one eq table.
+    pub fn claimed_inputs(&self, r_cycle: &[Fr]) -> Result<Vec<Fr>, HipError> {
+        let cols = raw_ints(self.inputs);
+        let mut out = vec![Fr::default(); cols.len()];
+        // SAFETY: as above.
+        check(unsafe { ffi::jolt_ints_evaluate(self.ctx.raw, cols.as_ptr(), cols.len(), r_cycle.as_ptr().cast(), r_cycle.len(), out.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+}
+
+/// `CycleMajorMatrix` / `AddressMajorMatrix` of RAM read/write checking (`optimized/rw_matrix.rs`, `optimized/ram_read_write.rs:58-330`).
+pub struct HipRwMatrix {
+    ctx: Arc<HipContext>,
+    raw: *mut ffi::jolt_rw_matrix,
+}
+// SAFETY: see HipContext.
+unsafe impl Send for HipRwMatrix {}
+
+impl HipRwMatrix {
+    /// `addresses[j] = u64::MAX` on a cycle without RAM access (`ram_trace.rs:22`).
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(ctx: &Arc<HipContext>, addresses: &[u64], pre: &[u64], post: &[u64], inc: &HipTable, val_init: &HipTable, tau_low: &[Fr], gamma: Fr) -> Result<Self, HipError> {
+        debug_assert!(addresses.len() == pre.len() && pre.len() == post.len() && addresses.len() == 1 << tau_low.len());
+        let mut raw = ptr::null_mut();
+        // SAFETY: slices of equal length, tables on the same context.
+        check(
+            unsafe {
+                ffi::jolt_rw_matrix_create(ctx.raw, addresses.as_ptr(), pre.as_ptr(), post.as_ptr(), addresses.len(), inc.raw, val_init.raw, tau_low.as_ptr().cast(),
+                                           (&gamma as *const Fr).cast(), &mut raw)
+            },
+            ctx.raw,
+        )?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
+    /// One round: the two sums of the message -- `(q(0), q(inf))` in the cycle rounds, `(s(0), s(2))` in the address rounds -- and
+    /// `{current_scalar, tau_low[current_index - 1], 0}` for `gruen_poly_deg_3`.
+    pub fn prove_round(&mut self, bind: Option<Fr>) -> Result<([Fr; 2], [Fr; 3]), HipError> {
+        let (mut evals, mut aux) = ([Fr::default(); 2], [Fr::default(); 3]);
+        let bind_ptr = bind.as_ref().map_or(ptr::null(), |b| (b as *const Fr).cast());
+        // SAFETY: out-arrays of the documented size.
+        check(unsafe { ffi::jolt_rw_matrix_prove_round(self.raw, bind_ptr, evals.as_mut_ptr().cast(), aux.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok((evals, aux))
+    }
+    pub fn finish(&mut self, bind: Fr) -> Result<(), HipError> {
+        // SAFETY: live handle.
+        check(unsafe { ffi::jolt_rw_matrix_finish(self.raw, (&bind as *const Fr).cast()) }, self.ctx.raw)
+    }
+    /// `{ra, val, inc, bound cycle-eq factor}` at the bound point: `RamReadWriteOutputClaims` + `validate_derived_tables`.
+    pub fn final_values(&mut self) -> Result<[Fr; 4], HipError> {
+        let mut out = [Fr::default(); 4];
+        // SAFETY: four elements as documented.
+        check(unsafe { ffi::jolt_rw_matrix_final_values(self.raw, out.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+}
+impl Drop for HipRwMatrix {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_rw_matrix_create.
+        let _ = unsafe { ffi::jolt_rw_matrix_destroy(self.raw) };
+    }
+}
+
+/// The packed rows of instruction read+RAF checking on the device (`InstructionCycleRow`, `optimized/instruction_read_raf.rs:86-125`).
+pub struct HipReadRaf {
+    ctx: Arc<HipContext>,
+    raw: *mut ffi::jolt_read_raf,
+    n_tables: u32,
+}
+// SAFETY: see HipContext.
+unsafe impl Send for HipReadRaf {}
+
+/// One phase's accumulators: `raf[q][chunk]` with q = left, right, identity, shift_half, shift_full, upper_all_ones, and
+/// `suffix[(offset of the table + s)][chunk]`.
+pub struct PhaseScan {
+    pub raf: Vec<Fr>,
+    pub suffix: Vec<Fr>,
+}
+
+impl HipReadRaf {
+    /// `table_index[j] = 0xFF` for a cycle without a lookup table.
+    pub fn new(ctx: &Arc<HipContext>, lookup_index: &[u128], table_index: &[u8], raf_flag: &[bool], n_tables: u32) -> Result<Self, HipError> {
+        let flags: Vec<u8> = raf_flag.iter().map(|&f| u8::from(f)).collect();
+        let mut raw = ptr::null_mut();
+        // SAFETY: u128 is two little-endian u64 words on every target the prover runs on; slices of equal length.
+        check(
+            unsafe { ffi::jolt_read_raf_create(ctx.raw, lookup_index.as_ptr().cast(), table_index.as_ptr(), flags.as_ptr(), lookup_index.len(), n_tables, &mut raw) },
+            ctx.raw,
+        )?;
+        Ok(Self { ctx: Arc::clone(ctx), raw, n_tables })
+    }
+    /// `init_phase`'s scans (`:770-812`, `:901-971`).  `suffix_kinds[t]` = `table.suffixes()` as `Suffixes as u8`.
+    pub fn phase_scan(&mut self, u: &HipTable, suffix_len: u32, address_bits: u32, canonical: bool, suffix_kinds: &[Vec<u8>]) -> Result<PhaseScan, HipError> {
+        debug_assert_eq!(suffix_kinds.len(), self.n_tables as usize);
+        let mut offsets = Vec::with_capacity(suffix_kinds.len() + 1);
+        let mut kinds = Vec::new();
+        offsets.push(0u32);
+        for list in suffix_kinds {
+            kinds.extend_from_slice(list);
+            offsets.push(kinds.len() as u32);
+        }
+        let mut scan = PhaseScan { raf: vec![Fr::default(); 6 * 256], suffix: vec![Fr::default(); kinds.len() * 256] };
+        // SAFETY: arrays sized as the header documents.
+        check(
+            unsafe {
+                ffi::jolt_read_raf_phase_scan(self.ctx.raw, self.raw, u.raw, suffix_len, address_bits, i32::from(canonical), offsets.as_ptr(), kinds.as_ptr(),
+                                              scan.raf.as_mut_ptr().cast(), scan.suffix.as_mut_ptr().cast())
+            },
+            self.ctx.raw,
+        )?;
+        Ok(scan)
+    }
+    /// Condensation (`:750-758`): `u[j] *= v_prev[(lookup_index[j] >> shift) & 255]`.
+    pub fn condense(&mut self, u: &mut HipTable, v_prev: &[Fr; 256], shift: u32) -> Result<(), HipError> {
+        // SAFETY: 256 elements.
+        check(unsafe { ffi::jolt_read_raf_condense(self.ctx.raw, self.raw, u.raw, v_prev.as_ptr().cast(), shift) }, self.ctx.raw)
+    }
+    /// The combined-value column and the `ra_i` columns of the cycle rounds (`pending_combined_base` / `pending_ra_base`).
+    pub fn cycle_tables(&mut self, table_values: &[Fr], raf_interleaved: Fr, raf_identity: Fr, v_tables: &[Fr], address_bits: u32, ra_count: u32) -> Result<(HipTable, Vec<HipTable>), HipError> {
+        let phases = (v_tables.len() / 256) as u32;
+        let mut combined = ptr::null_mut();
+        let mut ra = vec![ptr::null_mut(); ra_count as usize];
+        // SAFETY: arrays sized as the header documents.
+        check(
+            unsafe {
+                ffi::jolt_read_raf_cycle_tables(self.ctx.raw, self.raw, table_values.as_ptr().cast(), (&raf_interleaved as *const Fr).cast(), (&raf_identity as *const Fr).cast(),
+                                                v_tables.as_ptr().cast(), phases, address_bits, ra_count, &mut combined, ra.as_mut_ptr())
+            },
+            self.ctx.raw,
+        )?;
+        let wrap = |raw| HipTable { ctx: Arc::clone(&self.ctx), raw };
+        Ok((wrap(combined), ra.into_iter().map(wrap).collect()))
+    }
+}
+impl Drop for HipReadRaf {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_read_raf_create.
+        let _ = unsafe { ffi::jolt_read_raf_destroy(self.ctx.raw, self.raw) };
+    }
+}
