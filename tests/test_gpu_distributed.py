@@ -187,7 +187,7 @@ def _pcs_worker(rank, world, port, tmpdir, n_local):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_local", [(2, 4), (4, 4), (2, 7)])
+@pytest.mark.parametrize("world,n_local", [(2, 4), (4, 4), (2, 7), (2, 11), (4, 9)])
 def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local):
     """Term-range sharded PCS legs (ShardedPcs: partial commitments per block of cycles, every MSM of the HyperKZG opening split over
     the ranks, partial points all-gathered): every rank returns the commitments and the opening the ORACLE computes in one process
