@@ -29,9 +29,31 @@ struct Fr3 {
     Fr v[3];
 };
 
+// table[t * 256 + i] = base_t^i for i < 256 (one workgroup): the per-thread weights (u^16)^tid of k_horner3, computed ONCE per evaluation
+// point instead of by every thread of every level (which cost 2.5x the Horner steps themselves: 12.8 ms of a 2^26-coefficient opening)
+static __global__ __launch_bounds__(kBlock) void k_power_table3(Fr3 base, Fr* __restrict__ table) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        Fr w = Fr::one(), b = base.v[t];
+        for (unsigned e = threadIdx.x; e; e >>= 1) {
+            if (e & 1) w = mul(w, b);
+            b = sqr(b);
+        }
+        st_fr(table + t * kBlock + threadIdx.x, w);
+    }
+}
 // partials[block*3 + t] = sum over this block's coefficients c[i] * u_t^i
-static __global__ __launch_bounds__(kBlock) void k_horner3(const Fr* __restrict__ c, size_t n, Fr3 u, Fr3 u_chunk /* u^16 */, Fr3 u_block /* u^4096 */,
-                                                           Fr* __restrict__ partials) {
+static __global__ __launch_bounds__(kBlock) void k_horner3(const Fr* __restrict__ c, size_t n, Fr3 u, const Fr* __restrict__ chunk_weights /* (u^16)^tid */,
+                                                           Fr3 u_block /* u^4096 */, Fr* __restrict__ partials) {
+    __shared__ Fr block_weight[3];
+    if (threadIdx.x < 3) {  // (u^4096)^blockIdx, once per workgroup
+        Fr w = Fr::one(), b = u_block.v[threadIdx.x];
+        for (unsigned e = blockIdx.x; e; e >>= 1) {
+            if (e & 1) w = mul(w, b);
+            b = sqr(b);
+        }
+        block_weight[threadIdx.x] = w;
+    }
     size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHornerChunk;
     Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
     if (base < n) {
@@ -41,21 +63,11 @@ static __global__ __launch_bounds__(kBlock) void k_horner3(const Fr* __restrict_
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[t] = add(mul(acc[t], u.v[t]), ci);
         }
-        // weight = (u^16)^tid * (u^4096)^blockIdx
+    }
+    __syncthreads();
+    if (base < n) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            Fr w = Fr::one(), b = u_chunk.v[t];
-            for (unsigned e = threadIdx.x; e; e >>= 1) {
-                if (e & 1) w = mul(w, b);
-                b = sqr(b);
-            }
-            b = u_block.v[t];
-            for (unsigned e = blockIdx.x; e; e >>= 1) {
-                if (e & 1) w = mul(w, b);
-                b = sqr(b);
-            }
-            acc[t] = mul(acc[t], w);
-        }
+        for (int t = 0; t < 3; ++t) acc[t] = mul(mul(acc[t], ld_fr(chunk_weights + t * kBlock + threadIdx.x)), block_weight[t]);
     }
     block_reduce_store<3>(acc, partials);
 }
@@ -168,13 +180,17 @@ extern "C" int32_t jolt_hyperkzg_eval3(jolt_ctx* ctx, jolt_table* const* levels,
         u4096.v[t] = p;
     }
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
+    Fr* chunk_weights = nullptr;
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, 3 * kBlock * sizeof(Fr), (void**)&chunk_weights));
+    hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
+    struct FreeWeights { jolt_ctx* c; Fr* p; ~FreeWeights() { jolt_internal_dev_free(c, p); } } free_weights{ctx, chunk_weights};  // stream-ordered: safe right after the last launch
     for (size_t j = 0; j < ell; ++j) {
         const jolt_table* t = levels[j];
         if (!t) return JOLT_ERR_INVALID_ARG;
         size_t per_block = (size_t)kBlock * kHornerChunk;
         int grid = (int)std::max<size_t>(1, (t->len + per_block - 1) / per_block);
         JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 3, 3 * ell + 8));
-        hipLaunchKernelGGL(k_horner3, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, u16, u4096, ctx->d_partials);
+        hipLaunchKernelGGL(k_horner3, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, (const Fr*)chunk_weights, u4096, ctx->d_partials);
         JOLT_HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * j);
         JOLT_HIP_TRY(ctx, hipGetLastError());
