@@ -89,9 +89,14 @@ static __global__ __launch_bounds__(kBlock) void k_rlc(RlcArgs a, const Fr* __re
     st_fr(out + i, acc);
 }
 
-constexpr int kScanChunk = 64;
+// elements per thread of the blocked suffix scan (a power of two; JOLT_SCAN_CHUNK overrides).  8 / 16 / 32 / 64 measure the same
+// (141 ms of suffix + Horner kernel time over three 2^26-coefficient openings each): the scans are not bound by their access pattern
+static int scan_chunk_log() {
+    static int v = [] { const char* e = std::getenv("JOLT_SCAN_CHUNK"); int c = e ? std::atoi(e) : 64; int lg = 0; while ((1 << (lg + 1)) <= c) ++lg; return std::max(1, std::min(8, lg)); }();
+    return v;
+}
 // heads[c] = Horner of chunk c with zero carry-in: sum_{k in chunk} a[k] mu^(k - chunk_start)
-static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __restrict__ a, size_t m, Fr mu, Fr* __restrict__ heads, size_t nchunks) {
+static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __restrict__ a, size_t m, Fr mu, Fr* __restrict__ heads, size_t nchunks, size_t kScanChunk) {
     size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (c >= nchunks) return;
     size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
@@ -101,7 +106,7 @@ static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __rest
 }
 // s[k] = a[k] + mu*s[k+1] inside chunk c, starting from the true carry-in S[c+1]; writes s[k] to out[k - shift] (k >= shift)
 static __global__ __launch_bounds__(kBlock) void k_suffix_apply(const Fr* __restrict__ a, size_t m, Fr mu, const Fr* __restrict__ S, size_t nchunks,
-                                                                Fr* __restrict__ out, size_t shift) {
+                                                                Fr* __restrict__ out, size_t shift, size_t kScanChunk) {
     size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (c >= nchunks) return;
     size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
@@ -114,22 +119,24 @@ static __global__ __launch_bounds__(kBlock) void k_suffix_apply(const Fr* __rest
 
 // s = suffix Horner of a (length m) with multiplier mu, written to out[k - shift]
 int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift) {
+    const int chunk_log = scan_chunk_log();
+    const size_t kScanChunk = (size_t)1 << chunk_log;
     size_t nchunks = (m + kScanChunk - 1) / kScanChunk;
     unsigned grid = (unsigned)((nchunks + kBlock - 1) / kBlock);
     if (nchunks <= 1) {
-        hipLaunchKernelGGL(k_suffix_apply, dim3(1), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)nullptr, (size_t)1, out, shift);
+        hipLaunchKernelGGL(k_suffix_apply, dim3(1), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)nullptr, (size_t)1, out, shift, kScanChunk);
         JOLT_HIP_TRY(ctx, hipGetLastError());
         return JOLT_OK;
     }
     Fr *heads = nullptr, *S = nullptr;
     JOLT_TRY(jolt_internal_dev_alloc(ctx, nchunks * sizeof(Fr), (void**)&heads));
     if (jolt_internal_dev_alloc(ctx, nchunks * sizeof(Fr), (void**)&S) != JOLT_OK) { jolt_internal_dev_free(ctx, heads); return JOLT_ERR_OOM; }
-    hipLaunchKernelGGL(k_suffix_heads, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, heads, nchunks);
+    hipLaunchKernelGGL(k_suffix_heads, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, heads, nchunks, kScanChunk);
     Fr mu_c = mu;
-    for (int i = 0; i < 6; ++i) mu_c = sqr(mu_c);  // mu^64
+    for (int i = 0; i < chunk_log; ++i) mu_c = sqr(mu_c);  // mu^chunk
     int32_t s = suffix_horner(ctx, heads, nchunks, mu_c, S, 0);
     if (s == JOLT_OK) {
-        hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift);
+        hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift, kScanChunk);
         if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
     }
     jolt_internal_dev_free(ctx, heads);  // pool blocks: reused in stream order, no synchronisation
