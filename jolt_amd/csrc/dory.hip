@@ -344,8 +344,8 @@ void launch_bucket_sums(jolt_ctx* ctx, const Workspace& w, const G1Affine* bases
     }
     hipLaunchKernelGGL(k_msm_buckets_light<false>, dim3((unsigned)(((size_t)B * p.L + kBlock - 1) / kBlock), gy, gz), dim3(kBlock), 0, st, (const uint32_t*)w.hist,
                        (const uint32_t*)w.offs, (const uint32_t*)w.sorted, bases, n, B, p.L, p.heavy_threshold, w.buckets, V);
-    hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)w.heavy, (const uint32_t*)w.hcnt, (const uint32_t*)w.hist,
-                       (const uint32_t*)w.offs, (const uint32_t*)w.sorted, bases, n, B, w.seg);
+    hipLaunchKernelGGL(k_msm_buckets_heavy<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)w.heavy, (const uint32_t*)w.hcnt, (const uint32_t*)w.hist,
+                       (const uint32_t*)w.offs, (const uint32_t*)w.sorted, bases, n, B, w.seg, LformConsts{});
     hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)w.heavy, (const uint32_t*)w.hcnt, (const uint32_t*)w.hist,
                        (const G1Jac*)w.seg, w.buckets);
 }

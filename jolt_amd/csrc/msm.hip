@@ -254,8 +254,8 @@ int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* 
         else hipLaunchKernelGGL(k_msm_scatter, dim3(gn, p.W), dim3(kBlock), 0, st, (const uint32_t*)keys, n, p.B, cur, sorted, (size_t)p.W);
         hipLaunchKernelGGL(k_msm_buckets_light<true>, dim3((unsigned)(((size_t)p.B * p.L + kBlock - 1) / kBlock), p.W), dim3(kBlock), 0, st, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, p.L, p.heavy_threshold, buckets, (size_t)p.W);
-        hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist,
-                           (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, seg);
+        hipLaunchKernelGGL(k_msm_buckets_heavy<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist,
+                           (const uint32_t*)offs, (const uint32_t*)sorted, (const G1Affine*)srs->pts, n, p.B, seg, LformConsts{});
         hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist,
                            (const G1Jac*)seg, buckets);
         hipLaunchKernelGGL(k_msm_window_reduce, dim3(p.nb, p.W), dim3(kBlock), 0, st, (const G1Jac*)buckets, p.B, p.G, part);

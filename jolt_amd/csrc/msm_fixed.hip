@@ -544,15 +544,26 @@ __global__ __launch_bounds__(kBlock) void k_fx_order(const uint32_t* __restrict_
 }
 
 // ---- 4. light buckets in that order (the heavy ones keep k_msm_buckets_heavy / _heavy_combine) ---------------------------
+template <bool LFORM>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_fx_buckets_ordered(
     const uint32_t* __restrict__ order, uint32_t n_buckets, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ sorted,
-    const G1Affine* __restrict__ bases, uint32_t heavy_threshold, G1Jac* __restrict__ buckets) {
+    const G1Affine* __restrict__ bases, uint32_t heavy_threshold, G1Jac* __restrict__ buckets, LformConsts lc) {
     const uint32_t gt = blockIdx.x * kBlock + threadIdx.x;
     if (gt >= n_buckets) return;
     const uint32_t slot = order[gt];
     const uint32_t cnt = hist[slot];
     if (cnt == 0 || cnt > heavy_threshold) return;  // empty: the memset identity stands; heavy: the segmented kernels own it
-    buckets[slot] = sum_bucket_points<true>(sorted + offsets[slot], bases, 0u, cnt, 1u);
+    buckets[slot] = LFORM ? sum_bucket_points_lform(sorted + offsets[slot], bases, 0u, cnt, 1u, lc) : sum_bucket_points<true>(sorted + offsets[slot], bases, 0u, cnt, 1u);
+}
+
+// window tables -> L-form (fq_limb.hip.h): every coordinate times 32, i.e. a product with the Montgomery form of 32; (0, 0) stays (0, 0)
+__global__ __launch_bounds__(kBlock) void k_fx_to_lform(G1Affine* __restrict__ pts, size_t count, Fq mont32) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    G1Affine p = ld_aff(pts + i);
+    p.x = mul(p.x, mont32);
+    p.y = mul(p.y, mont32);
+    pts[i] = p;
 }
 
 }  // namespace
@@ -591,9 +602,18 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
         hipLaunchKernelGGL(k_fx_next_window, dim3(grid), dim3(kBlock), 0, ctx->stream, (const G1Affine*)(pre + (size_t)(w - 1) * srs->n), pre + (size_t)w * srs->n, srs->n, c);
         e = hipGetLastError();
     }
+    const bool lform = ctx->msm_fx_lform;
+    if (e == hipSuccess && lform) {  // the tables are only ever read by the limb-form bucket sums: store them in L-form
+        Fq thirty_two = Fq::zero();
+        thirty_two.l[0] = 32;
+        const size_t count = (size_t)W * srs->n;
+        hipLaunchKernelGGL(k_fx_to_lform, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, pre, count, to_mont(thirty_two));
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(pre); ctx->last_error = std::string("precompute windows: ") + hipGetErrorString(e); return JOLT_ERR_HIP; }
     srs->pre = pre;
+    srs->pre_lform = lform;
     srs->pre_c = c;
     srs->pre_W = W;
     srs->pre_B = n_bucket_max;
@@ -729,10 +749,25 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, st, (const uint32_t*)class_hist, class_cursor);
     hipLaunchKernelGGL(k_fx_order, dim3((unsigned)((n_buckets + kBlock * kOrderPer - 1) / (kBlock * kOrderPer))), dim3(kBlock), 0, st, (const uint32_t*)hist, (uint32_t)n_buckets,
                        heavy_threshold, class_cursor, order);
-    hipLaunchKernelGGL(k_fx_buckets_ordered, dim3((unsigned)((n_buckets + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets,
-                       (const uint32_t*)hist, (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets);
-    hipLaunchKernelGGL(k_msm_buckets_heavy, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
-                       (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg);
+    LformConsts lc;
+    {
+        Fq thirty_two = Fq::zero();
+        thirty_two.l[0] = 32;
+        lc.one_l = to_mont(thirty_two);
+        lc.r256 = Fq::one();
+    }
+    const unsigned bucket_grid = (unsigned)((n_buckets + kBlock - 1) / kBlock);
+    if (srs->pre_lform) {
+        hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+                           (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
+        hipLaunchKernelGGL(k_msm_buckets_heavy<true>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
+                           (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg, lc);
+    } else {
+        hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+                           (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
+        hipLaunchKernelGGL(k_msm_buckets_heavy<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
+                           (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg, lc);
+    }
     hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const G1Jac*)seg, buckets);
     hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, G, part);
     hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)part, nb, wsum);

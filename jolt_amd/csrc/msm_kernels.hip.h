@@ -4,6 +4,7 @@
 // keys/sorted[w*n + i] (n = points per window), hist/offsets/cursor/buckets[w*(B+1) + |digit|].
 #pragma once
 #include "g1.hip.h"
+#include "fq_limb.hip.h"
 #include "poly_kernels.hip.h"
 
 #ifndef JOLT_BUCKET_WAVES
@@ -260,6 +261,46 @@ __device__ __forceinline__ G1Jac sum_bucket_points(const uint32_t* __restrict__ 
 #undef JOLT_BUCKET_OUT
 }
 
+// The same sum with the bases in L-FORM (fq_limb.hip.h: coordinates held as x * 2^261 mod p, i.e. the window tables of msm_fixed.hip) and
+// the accumulator in limb-form XYZZ: ~2300 instead of ~3000 VALU instructions per point.  Returns a standard Jacobian point.
+struct LformConsts {
+    Fq one_l;  // L-form of 1 = the standard Montgomery form of 32
+    Fq r256;   // 2^256 mod p = the words of Fq::one(): multiplying an L-form value by it gives the standard form
+};
+__device__ __forceinline__ G1Jac sum_bucket_points_lform(const uint32_t* __restrict__ src, const G1Affine* __restrict__ bases, uint32_t lo, uint32_t hi, uint32_t stride,
+                                                         const LformConsts& lc) {
+    G1XyzzL acc = g1xl_identity();
+    if (lo >= hi) return g1_identity();
+    const FqL one = fql_from_words(lc.one_l);
+    uint32_t v = src[lo];
+    G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
+    for (uint32_t k = lo;;) {  // software pipeline: the next index and point are in flight during the addition
+        const uint32_t kn = k + stride;
+        const bool more = kn < hi;
+        uint32_t vn = 0;
+        G1Affine pn = p;
+        if (more) {
+            vn = src[kn];
+            pn = ld_aff(bases + (vn & 0x7FFFFFFFu));
+        }
+        if (!g1_aff_is_inf(p)) {
+            if (v >> 31) p.y = neg(p.y);  // the words are a canonical field element (the L-form of y): negation commutes
+            acc = g1xl_add_mixed(acc, fql_from_words(p.x), fql_from_words(p.y), one);
+        }
+        if (!more) break;
+        v = vn;
+        p = pn;
+        k = kn;
+    }
+    if (g1xl_is_identity(acc)) return g1_identity();
+    const FqL r256 = fql_from_words(lc.r256);
+    G1Jac out;  // (X, Y, ZZ, ZZZ) ~ Jacobian (X ZZ^2, Y ZZZ^2, ZZZ)
+    out.x = fql_to_std(fql_mul(acc.x, fql_sqr(acc.zz)), r256);
+    out.y = fql_to_std(fql_mul(acc.y, fql_sqr(acc.zzz)), r256);
+    out.z = fql_to_std(acc.zzz, r256);
+    return out;
+}
+
 // ---- 4a. light buckets: L adjacent lanes per bucket (L = 1 when there are enough buckets to fill the chip) ----------
 template <bool PIPELINED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_msm_buckets_light(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
@@ -281,10 +322,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
 }
 
 // ---- 4b. heavy buckets: one wavefront per kHeavySeg-point segment, then one wavefront per bucket adds its segment sums ----
+template <bool LFORM = false>
 __global__ __launch_bounds__(kBlock) void k_msm_buckets_heavy(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count,
                                                              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, size_t n,
-                                                             uint32_t B, G1Jac* __restrict__ seg_sums) {
+                                                             uint32_t B, G1Jac* __restrict__ seg_sums, LformConsts lc = LformConsts{}) {
     const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
     const uint32_t total = *heavy_count;
     for (uint32_t h = wave; h < total; h += n_waves) {
@@ -292,7 +334,8 @@ __global__ __launch_bounds__(kBlock) void k_msm_buckets_heavy(const uint32_t* __
         uint32_t w = slot / (B + 1);
         uint32_t cnt = hist[slot];
         uint32_t lo = sgi * kHeavySeg, hi = min(lo + (uint32_t)kHeavySeg, cnt);
-        G1Jac acc = sum_bucket_points<true>(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u);
+        G1Jac acc = LFORM ? sum_bucket_points_lform(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u, lc)
+                          : sum_bucket_points<true>(sorted + (size_t)w * n + offsets[slot], bases, lo + lane, hi, 64u);
         acc = wave_sum_g1(acc, 64);
         if (lane == 0) seg_sums[h] = acc;
     }

@@ -12,6 +12,7 @@ struct jolt_srs {
     // is what makes 24-bit windows affordable).  pre_W * n * 64 bytes: the table is sized for 288 GB of HBM, not for a PCIe card.
     jolt::G1Affine* pre = nullptr;
     int pre_c = 0, pre_W = 0;
+    bool pre_lform = false;  // the tables hold L-form coordinates (fq_limb.hip.h): x * 2^261 mod p
     uint32_t pre_B = 0;     // bucket count = the largest digit magnitude (k_fx_digits)
     size_t pre_stride = 0;  // points per window table (= n of the SRS the tables were built for; a range view keeps the parent's)
     size_t pre_min_n = 0;  // MSMs shorter than this keep the per-window bucket method
