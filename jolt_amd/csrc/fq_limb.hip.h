@@ -33,7 +33,18 @@ constexpr uint32_t P2(int k) {
     return (uint32_t)v;
 }
 constexpr uint32_t NINV = Limbs29<FqParams>::neg_inv();
+// limb k of m * p (m <= 9: below 2^258, the top limb keeps what is left)
+constexpr uint32_t PM(int m, int k) {
+    uint64_t carry = 0, v = 0;
+    for (int i = 0; i <= k; ++i) {
+        v = (uint64_t)m * P(i) + carry;
+        carry = v >> 29;
+        if (i < 8) v &= kMask29;
+    }
+    return (uint32_t)v;
+}
 }  // namespace fql
+#define JOLT_FQL_MP(m) {fql::PM(m, 0), fql::PM(m, 1), fql::PM(m, 2), fql::PM(m, 3), fql::PM(m, 4), fql::PM(m, 5), fql::PM(m, 6), fql::PM(m, 7), fql::PM(m, 8)}
 // function-local constexpr tables (indexed by unrolled constants: folded into immediates)
 #define JOLT_FQL_P {fql::P(0), fql::P(1), fql::P(2), fql::P(3), fql::P(4), fql::P(5), fql::P(6), fql::P(7), fql::P(8)}
 #define JOLT_FQL_2P {fql::P2(0), fql::P2(1), fql::P2(2), fql::P2(3), fql::P2(4), fql::P2(5), fql::P2(6), fql::P2(7), fql::P2(8)}
@@ -181,6 +192,38 @@ __device__ __forceinline__ Fq fql_to_std(const FqL& a, const FqL& r256) {
     return reduce_once(out, 0u);
 }
 
+// ---- lazily reduced differences: ONE carry pass, no comparison ------------------------------------------------------------------
+// fql_mul / fql_sqr accept any operands a, b with a b < 169 p^2 (output < p (a b / (p 2^261) + 1) < 2p) as long as the limbs are
+// normalised, so a difference does not have to come back into [0, 2p): a + M p - b with M p >= b is positive and simply a few p larger.
+// g1xl_add_mixed tracks the ranges (comments there).  a + M p - b - 2 c in one pass (c may be absent).
+template <int M, bool WITH_C>
+__device__ __forceinline__ FqL fql_diff(const FqL& a, const FqL& b, const FqL& c) {
+    constexpr uint32_t MP[9] = JOLT_FQL_MP(M);
+    FqL r;
+    int32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int32_t t = (int32_t)a.l[k] + (int32_t)MP[k] - (int32_t)b.l[k] + carry;  // every term below 2^29 (the top limbs far below): no overflow
+        if (WITH_C) t -= (int32_t)(c.l[k] << 1);
+        r.l[k] = k < 8 ? ((uint32_t)t & kMask29) : (uint32_t)t;  // the value is positive: the top limb takes what is left
+        carry = t >> 29;
+    }
+    return r;
+}
+// is a == m p for some 1 <= m <= MAX (a is known to be below (MAX + 1) p and a multiple check is all that is needed)?
+template <int MAX>
+__device__ __forceinline__ bool fql_is_multiple_of_p(const FqL& a) {
+    bool hit = false;
+#pragma unroll
+    for (int m = 1; m <= MAX; ++m) {
+        uint32_t diff = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) diff |= a.l[k] ^ fql::PM(m, k);
+        hit = hit || diff == 0;
+    }
+    return hit;
+}
+
 // ---- XYZZ accumulator in limb form (see g1.hip.h for the coordinates) ----------------------------------------------------------
 struct G1XyzzL {
     FqL x, y, zz, zzz;
@@ -210,6 +253,11 @@ __device__ __forceinline__ G1XyzzL g1xl_double_affine(const FqL& x, const FqL& y
     return r;
 }
 // madd-2008-s: 8M + 2S; `one` = the L-form of 1.  (qx, qy) must not be the point at infinity (the caller skips (0, 0)).
+// Ranges (multiples of p; products are below 1.6 p for every operand pair that occurs): X < 7.6, Y < 3.6, ZZ, ZZZ < 1.6 on entry and on
+// exit; P = U2 + 8p - X in (0.4, 9.6), R = S2 + 4p - Y in (0.4, 5.6), X3 = R^2 + 6p - PPP - 2Q in (1.2, 7.6), Q + 8p - X3 in (0.4, 9.6),
+// Y3 = R (Q - X3) + 2p - Y PPP in (0.4, 3.6); the largest product, P^2 < 92.2 p^2, stays below 1.55 p.
+// P = 0 mod p (the same x: the point itself or its negative) shows as ZZ3 = ZZ PP = 0 mod p, tested on a product (0 or p) AFTER the
+// common path instead of on the lazily reduced P before it.
 __device__ __forceinline__ G1XyzzL g1xl_add_mixed(const G1XyzzL& p, const FqL& qx, const FqL& qy, const FqL& one) {
     if (g1xl_is_identity(p)) {
         G1XyzzL r;
@@ -221,19 +269,19 @@ __device__ __forceinline__ G1XyzzL g1xl_add_mixed(const G1XyzzL& p, const FqL& q
     }
     const FqL U2 = fql_mul(qx, p.zz);
     const FqL S2 = fql_mul(qy, p.zzz);
-    const FqL P = fql_sub(U2, p.x);
-    const FqL R = fql_sub(S2, p.y);
-    if (fql_is_zero(P)) {
-        if (fql_is_zero(R)) return g1xl_double_affine(qx, qy);
-        return g1xl_identity();
-    }
+    const FqL P = fql_diff<8, false>(U2, p.x, U2);
+    const FqL R = fql_diff<4, false>(S2, p.y, S2);
     const FqL PP = fql_sqr(P);
     const FqL PPP = fql_mul(P, PP);
     const FqL Q = fql_mul(p.x, PP);
     G1XyzzL r;
-    r.x = fql_sub(fql_sub(fql_sqr(R), PPP), fql_dbl(Q));
-    r.y = fql_sub(fql_mul(R, fql_sub(Q, r.x)), fql_mul(p.y, PPP));
     r.zz = fql_mul(p.zz, PP);
+    if (fql_is_zero(r.zz)) {  // P = 0 mod p
+        if (fql_is_multiple_of_p<5>(R)) return g1xl_double_affine(qx, qy);  // the same point again
+        return g1xl_identity();                                             // its negative
+    }
+    r.x = fql_diff<6, true>(fql_sqr(R), PPP, Q);
+    r.y = fql_diff<2, false>(fql_mul(R, fql_diff<8, false>(Q, r.x, Q)), fql_mul(p.y, PPP), Q);
     r.zzz = fql_mul(p.zzz, PPP);
     return r;
 }
