@@ -31,12 +31,18 @@ constexpr int kGridSumBlocks = 512;  // workgroups per column: 2048 wavefront pa
 
 // partial[(p * gridDim.x + block) * 4 + wave] = sum over this wavefront's cycles of bases[hot_p(j) * T + j]
 // (lo, hi): the cycle range this launch sums -- the whole column, or one rank's block of a sharded commitment
+template <bool LFORM>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_grid_onehot_sum(
-    const uint8_t* __restrict__ idx, uint32_t wide, size_t grid_cycles, size_t lo, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial) {
+    const uint8_t* __restrict__ idx, uint32_t wide, size_t grid_cycles, size_t lo, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial,
+    LformConsts lc) {
     const size_t p = blockIdx.y;
     const uint8_t* col = hot_col(idx, p * grid_cycles, wide);
     const size_t stride = (size_t)gridDim.x * kBlock;
-    G1Xyzz acc = g1x_identity();  // XYZZ accumulator: 8M + 2S per mixed addition (g1.hip.h)
+    // XYZZ accumulator: 8M + 2S per mixed addition (g1.hip.h); LFORM: the bases are window 0 of the SRS's L-form tables and the
+    // accumulator stays in limb form (fq_limb.hip.h)
+    G1Xyzz acc = g1x_identity();
+    G1XyzzL acc_l = g1xl_identity();
+    const FqL one = fql_from_words(lc.one_l);
     // software pipeline as in sum_bucket_points<true>: the next index byte and point are in flight during the mixed addition
     size_t j = lo + (size_t)blockIdx.x * kBlock + threadIdx.x;
     uint32_t a = j < cycles ? hot_load(col, j, wide) : kColdIdx;
@@ -51,11 +57,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
         pn.x = Fq::zero();
         pn.y = Fq::zero();
         if (an != kColdIdx) pn = ld_aff(bases + (size_t)an * grid_cycles + jn);
-        acc = g1x_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
+        if (LFORM) {
+            if (!g1_aff_is_inf(pt)) acc_l = g1xl_add_mixed(acc_l, fql_from_words(pt.x), fql_from_words(pt.y), one);
+        } else {
+            acc = g1x_add_mixed(acc, pt);  // (0, 0) = infinity: a cold cycle adds nothing
+        }
         pt = pn;
         j = jn;
     }
-    const G1Jac total = wave_sum_g1(g1x_to_jac(acc), 64);
+    G1Jac mine = g1x_to_jac(acc);
+    if (LFORM) {
+        mine = g1_identity();
+        if (!g1xl_is_identity(acc_l)) {
+            const FqL r256 = fql_from_words(lc.r256);
+            mine.x = fql_to_std(fql_mul(acc_l.x, fql_sqr(acc_l.zz)), r256);
+            mine.y = fql_to_std(fql_mul(acc_l.y, fql_sqr(acc_l.zzz)), r256);
+            mine.z = fql_to_std(acc_l.zzz, r256);
+        }
+    }
+    const G1Jac total = wave_sum_g1(mine, 64);
     if ((threadIdx.x & 63) == 0) partial[(p * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = total;
 }
 // out[p] = sum of the column's `count` partial sums (one wavefront per column)
@@ -170,7 +190,20 @@ extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* 
     JOLT_TRY(jolt_internal_dev_alloc(ctx, N * per_col * sizeof(G1Jac), (void**)&partial));
     int32_t st = jolt_internal_dev_alloc(ctx, N * sizeof(G1Jac), (void**)&sums);
     if (st != JOLT_OK) { jolt_internal_dev_free(ctx, partial); return st; }
-    hipLaunchKernelGGL(k_grid_onehot_sum, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo, cycle_hi, (const G1Affine*)srs->pts, partial);
+    LformConsts lc;
+    {
+        Fq thirty_two = Fq::zero();
+        thirty_two.l[0] = 32;
+        lc.one_l = to_mont(thirty_two);
+        lc.r256 = Fq::one();
+    }
+    // window 0 of the fixed-base tables IS the SRS in L-form (msm_fixed.hip): the sums then run on the limb-form accumulator
+    if (srs->pre && srs->pre_lform && srs->pre_stride >= (size_t)source->k * T)
+        hipLaunchKernelGGL(k_grid_onehot_sum<true>, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo, cycle_hi,
+                           (const G1Affine*)srs->pre, partial, lc);
+    else
+        hipLaunchKernelGGL(k_grid_onehot_sum<false>, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo, cycle_hi,
+                           (const G1Affine*)srs->pts, partial, lc);
     hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)N), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, sums, N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);

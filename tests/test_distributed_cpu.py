@@ -10,16 +10,16 @@ import tempfile
 import numpy as np
 import pytest
 
+from util import free_port
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _worker(rank, world, port, tmpdir, tail_log):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
     import oracle_lib as O
     from jolt_amd import distributed as D
     from util import rand_fr
@@ -106,7 +106,7 @@ def test_sharded_prove_batch_matches_single_process(world, tail_log):
     """tail_log = 0: the shards run all their local rounds and hand over single entries; tail_log > 0: early hand-over of
     2^tail_log-entry tables (fewer exchanges); tail_log = n_local (world 4, 3): everything runs in the redundant tail."""
     import torch.multiprocessing as mp
-    port = 29500 + os.getpid() % 1000 + 7 * world + tail_log
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(world, port, tmp, tail_log), nprocs=world, join=True)
         for r in range(world):
@@ -116,10 +116,8 @@ def test_sharded_prove_batch_matches_single_process(world, tail_log):
 def _msm_worker(rank, world, port, tmpdir):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
     import oracle_lib as O
     from jolt_amd import distributed as D
     from util import rand_fr
@@ -140,7 +138,7 @@ def _msm_worker(rank, world, port, tmpdir):
 def test_sharded_msm_combines_to_the_single_process_point(world):
     """Term-range sharded MSM: per-rank partial sums, one all-gather of `world` Jacobian points, world-1 additions."""
     import torch.multiprocessing as mp
-    port = 29700 + os.getpid() % 1000 + world
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_msm_worker, args=(world, port, tmp), nprocs=world, join=True)
         for r in range(world):

@@ -9,6 +9,8 @@ import tempfile
 import numpy as np
 import pytest
 
+from util import free_port
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -16,10 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _worker(rank, world, port, tmpdir, n_local, tail_log):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
     from jolt_amd import distributed as D
     from jolt_amd import ffi
     ctx = ffi.Context(0)
@@ -41,7 +41,7 @@ def test_sharded_device_workload_matches_global_oracle(world, n_local, tail_log)
     import oracle_lib as O
     from jolt_amd import distributed as D
     from jolt_amd import workload as W
-    port = 29800 + os.getpid() % 1000 + tail_log + 16 * world
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(world, port, tmp, n_local, tail_log), nprocs=world, join=True)
         got = np.load(os.path.join(tmp, "got.npz"))
@@ -125,10 +125,8 @@ def test_native_rccl_communicator_single_rank():
 def _msm_worker(rank, world, port, tmpdir):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
     import oracle_lib as O
     from jolt_amd import distributed as D
     from jolt_amd import ffi
@@ -151,7 +149,7 @@ def _msm_worker(rank, world, port, tmpdir):
 
 def test_sharded_device_msm_two_ranks():
     import torch.multiprocessing as mp
-    port = 29900 + os.getpid() % 1000
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_msm_worker, args=(2, port, tmp), nprocs=2, join=True)
         for r in range(2):
@@ -161,10 +159,8 @@ def test_sharded_device_msm_two_ranks():
 def _pcs_worker(rank, world, port, tmpdir, n_local):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
     from jolt_amd import distributed as D
     from jolt_amd import ffi
     ctx = ffi.Context(0)
@@ -194,7 +190,7 @@ def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local):
     over the global trace -- same transcript bytes, same points."""
     import torch.multiprocessing as mp
     import oracle_lib as O
-    port = 29900 + os.getpid() % 1000 + world * 10 + n_local
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_pcs_worker, args=(world, port, tmp, n_local), nprocs=world, join=True)
         got = [np.load(os.path.join(tmp, f"pcs{r}.npz")) for r in range(world)]
@@ -271,10 +267,8 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world):
 def _rccl_same_device_worker(rank, world, port, out_path):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
     from jolt_amd import distributed as D
     from jolt_amd import ffi
     ctx = ffi.Context(0)
@@ -300,7 +294,7 @@ def test_native_rccl_with_two_ranks_on_one_device_is_refused_or_works_but_never_
             "mp.spawn(t._rccl_same_device_worker, args=(2, %d, %r), nprocs=2, join=True)")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "outcome")
-        port = 29700 + os.getpid() % 200
+        port = free_port()
         try:
             r = subprocess.run([sys.executable, "-c", code % (HERE, port, out)], capture_output=True, text=True, timeout=120)
         except subprocess.TimeoutExpired:

@@ -25,3 +25,22 @@ def rand_challenge(seed, shifted=True):
 
 def small_fr(vals, oracle):
     return oracle.fr_from_u64(np.asarray(vals, dtype=np.uint64))
+
+
+def free_port():
+    """a TCP port nobody listens on right now (the multi-process tests used to derive ports from the pid: a collision hangs the rendezvous)"""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def init_gloo(rank, world, port, seconds=120):
+    """gloo process group on 127.0.0.1 with a bounded rendezvous / collective timeout: a rank that died must fail the test, not hang it"""
+    import datetime
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=seconds))
+    return dist
