@@ -436,9 +436,17 @@ class ShardedWorkload:
             dev = torch.device("cuda", torch.cuda.current_device())
             # RCCL called natively from the C++ round loop; torch.distributed only carries the rendezvous.  All ranks must
             # agree on the choice: if the native communicator fails anywhere, everybody falls back to torch.distributed.
+            # With more than one rank the native communicator is OPT-IN (JOLT_NATIVE_RCCL=1): it has only ever run with one rank (the
+            # development box has one GPU and RCCL refuses two ranks per device), and a process that imports torch already holds torch's
+            # own RCCL.  The default for N > 1 is therefore torch.distributed's nccl backend -- which IS RCCL over xGMI -- for the table
+            # hand-over and the partial-point gathers; the per-round sums go through shared memory either way.
             native, err = None, None
+            want_native = world == 1 or os.environ.get("JOLT_NATIVE_RCCL") == "1"
             try:
-                native = NativeCollective(ctx, dist, rank, world, dev)
+                if want_native:
+                    native = NativeCollective(ctx, dist, rank, world, dev)
+                else:
+                    err = "not requested (JOLT_NATIVE_RCCL=1 enables it)"
             except Exception as e:  # noqa: BLE001 -- reported below, decision taken collectively
                 err = e
             ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=dev)
@@ -455,11 +463,13 @@ class ShardedWorkload:
             if int(ok.item()) == 1:
                 coll = native
             else:
-                self.communicator_note = f"torch.distributed fallback: native RCCL communicator unavailable ({err})"
+                self.communicator_note = (f"torch.distributed nccl backend (= RCCL), {world} ranks" if not want_native
+                                          else f"torch.distributed fallback: native RCCL communicator unavailable ({err})")
                 if native is not None:
                     native.close()
-                import sys
-                print(f"[jolt_amd] rank {rank}: native RCCL communicator unavailable ({err}); using torch.distributed", file=sys.stderr)
+                if want_native:
+                    import sys
+                    print(f"[jolt_amd] rank {rank}: native RCCL communicator unavailable ({err}); using torch.distributed", file=sys.stderr)
                 coll = Collective(dist, world, dev)
         if not hasattr(self, "communicator_note"):
             self.communicator_note = f"caller-supplied {type(coll).__name__}"
