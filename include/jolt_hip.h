@@ -298,6 +298,11 @@ int32_t jolt_host_fr_mul_shifted(const jolt_fr_t *a, const jolt_fr_t *c, jolt_fr
 int32_t jolt_host_eq_evals(const jolt_fr_t *r, size_t n, const jolt_fr_t *scale, jolt_fr_t *out);
 /* the kernels' multiplication algorithm (nine 29-bit limbs, product scanning) compiled for the host; field 0 = Fr, 1 = Fq */
 int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t *a, const jolt_fr_t *b, jolt_fr_t *out);
+/* The limb-form Fq arithmetic of the MSM's bucket sums (csrc/fq_limb.hip.h: 2^261 Montgomery radix, lazy reduction, dedicated squaring,
+ * two-product reduction) and its XYZZ mixed addition, compiled for the host for the CPU suite.  Operands and results are canonical Fq /
+ * affine points in STANDARD Montgomery form.  op: 0 a*b, 1 a^2, 2 a*b + c*d, 3 (a - b)*c, 4 (a - b - 2c)*d. */
+int32_t jolt_host_fq_limb_op(int32_t op, const jolt_fr_t *a, const jolt_fr_t *b, const jolt_fr_t *c, const jolt_fr_t *d, jolt_fr_t *out);
+int32_t jolt_host_g1_sum_limb_form(const uint64_t *points, const uint8_t *negate, size_t count, jolt_g1_t *out);
 /* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
 int32_t jolt_host_univariate_from_evals(const jolt_fr_t *evals, size_t n, jolt_fr_t *coeffs_out);
 int32_t jolt_host_univariate_evaluate(const jolt_fr_t *coeffs, size_t n, const jolt_fr_t *x, jolt_fr_t *out);

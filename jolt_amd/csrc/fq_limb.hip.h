@@ -10,7 +10,8 @@
 //     5-bit pre-shift of mul_limbs29.  The L-form of x is the STANDARD Montgomery form of 32x -- tables are converted once, when they are
 //     built (k_fx_to_lform), and the 32-byte words in memory look like any other Fq;
 //   * squarings use the symmetry of their columns (45 instead of 81 partial products).
-// mulL ~ 210 instructions, sqrL ~ 175, add / sub with full carry normalisation ~ 50.
+// mulL ~ 210 instructions, sqrL ~ 175, add / sub with full carry normalisation ~ 50.  Every function also compiles for the host
+// (jolt_host_fq_limb_* / jolt_host_g1_sum_limb_form in host_mirror.hip), where the CPU suite pins it against the oracle.
 #pragma once
 #include "field.hip.h"
 
@@ -49,18 +50,18 @@ constexpr uint32_t PM(int m, int k) {
 #define JOLT_FQL_P {fql::P(0), fql::P(1), fql::P(2), fql::P(3), fql::P(4), fql::P(5), fql::P(6), fql::P(7), fql::P(8)}
 #define JOLT_FQL_2P {fql::P2(0), fql::P2(1), fql::P2(2), fql::P2(3), fql::P2(4), fql::P2(5), fql::P2(6), fql::P2(7), fql::P2(8)}
 
-__device__ __forceinline__ FqL fql_from_words(const Fq& a) {  // the words already hold the value's L-form (or any value < 2^256 to be taken as is)
+JOLT_HD FqL fql_from_words(const Fq& a) {  // the words already hold the value's L-form (or any value < 2^256 to be taken as is)
     FqL r;
     to_limbs29<0>(a.l, r.l);
     return r;
 }
-__device__ __forceinline__ FqL fql_zero() {
+JOLT_HD FqL fql_zero() {
     FqL r;
 #pragma unroll
     for (int k = 0; k < 9; ++k) r.l[k] = 0;
     return r;
 }
-__device__ __forceinline__ bool fql_is_zero(const FqL& a) {  // a in [0, 2p): zero mod p iff a == 0 or a == p
+JOLT_HD bool fql_is_zero(const FqL& a) {  // a in [0, 2p): zero mod p iff a == 0 or a == p
     constexpr uint32_t PL[9] = JOLT_FQL_P;
     uint32_t any = 0, diff = 0;
 #pragma unroll
@@ -71,7 +72,7 @@ __device__ __forceinline__ bool fql_is_zero(const FqL& a) {  // a in [0, 2p): ze
     return any == 0 || diff == 0;
 }
 // a + b, both < 2p, result < 2p
-__device__ __forceinline__ FqL fql_add(const FqL& a, const FqL& b) {
+JOLT_HD FqL fql_add(const FqL& a, const FqL& b) {
     constexpr uint32_t P2L[9] = JOLT_FQL_2P;
     uint32_t s[9], d[9];
     uint32_t carry = 0;
@@ -94,7 +95,7 @@ __device__ __forceinline__ FqL fql_add(const FqL& a, const FqL& b) {
     return r;
 }
 // a - b, both < 2p, result < 2p
-__device__ __forceinline__ FqL fql_sub(const FqL& a, const FqL& b) {
+JOLT_HD FqL fql_sub(const FqL& a, const FqL& b) {
     constexpr uint32_t P2L[9] = JOLT_FQL_2P;
     uint32_t d[9], e[9];
     int32_t borrow = 0;
@@ -116,10 +117,10 @@ __device__ __forceinline__ FqL fql_sub(const FqL& a, const FqL& b) {
     for (int k = 0; k < 9; ++k) r.l[k] = borrow ? e[k] : d[k];
     return r;
 }
-__device__ __forceinline__ FqL fql_dbl(const FqL& a) { return fql_add(a, a); }
+JOLT_HD FqL fql_dbl(const FqL& a) { return fql_add(a, a); }
 
 // a * b * 2^-261 mod p; a, b < 2p in normalised limbs; result < 1.03 p, normalised
-__device__ __forceinline__ FqL fql_mul(const FqL& a, const FqL& b) {
+JOLT_HD FqL fql_mul(const FqL& a, const FqL& b) {
     constexpr uint32_t PL[9] = JOLT_FQL_P;
     uint32_t M[9];
     FqL r;
@@ -147,7 +148,7 @@ __device__ __forceinline__ FqL fql_mul(const FqL& a, const FqL& b) {
 }
 // (a b + c d) * 2^-261: both products through the same columns and ONE reduction (81 multiply-adds saved against two fql_mul and a
 // difference); a b + c d < 169 p^2 as for fql_mul.  A column holds <= 18 partial products < 2^58 and 9 reduction products: < 2^63.
-__device__ __forceinline__ FqL fql_mul2(const FqL& a, const FqL& b, const FqL& c, const FqL& d) {
+JOLT_HD FqL fql_mul2(const FqL& a, const FqL& b, const FqL& c, const FqL& d) {
     constexpr uint32_t PL[9] = JOLT_FQL_P;
     uint32_t M[9];
     FqL r;
@@ -180,7 +181,7 @@ __device__ __forceinline__ FqL fql_mul2(const FqL& a, const FqL& b, const FqL& c
     return r;
 }
 // a^2 * 2^-261: the off-diagonal products once, against the doubled limbs (2 a_j < 2^30: a column of <= 5 products < 2^59 each still fits)
-__device__ __forceinline__ FqL fql_sqr(const FqL& a) {
+JOLT_HD FqL fql_sqr(const FqL& a) {
     constexpr uint32_t PL[9] = JOLT_FQL_P;
     uint32_t M[9], a2[9];
 #pragma unroll
@@ -212,7 +213,7 @@ __device__ __forceinline__ FqL fql_sqr(const FqL& a) {
 }
 // L-form -> the standard Montgomery words of the same field element, canonical: x 2^261 * (2^256 mod p) * 2^-261 = x 2^256.
 // `r256` = the limbs of 2^256 mod p (= the words of Fq::one())
-__device__ __forceinline__ Fq fql_to_std(const FqL& a, const FqL& r256) {
+JOLT_HD Fq fql_to_std(const FqL& a, const FqL& r256) {
     const FqL v = fql_mul(a, r256);  // < 1.03 p
     Fq out;
 #pragma unroll
@@ -231,7 +232,7 @@ __device__ __forceinline__ Fq fql_to_std(const FqL& a, const FqL& r256) {
 // normalised, so a difference does not have to come back into [0, 2p): a + M p - b with M p >= b is positive and simply a few p larger.
 // g1xl_add_mixed tracks the ranges (comments there).  a + M p - b - 2 c in one pass (c may be absent).
 template <int M, bool WITH_C>
-__device__ __forceinline__ FqL fql_diff(const FqL& a, const FqL& b, const FqL& c) {
+JOLT_HD FqL fql_diff(const FqL& a, const FqL& b, const FqL& c) {
     constexpr uint32_t MP[9] = JOLT_FQL_MP(M);
     FqL r;
     int32_t carry = 0;
@@ -246,7 +247,7 @@ __device__ __forceinline__ FqL fql_diff(const FqL& a, const FqL& b, const FqL& c
 }
 // is a == m p for some 1 <= m <= MAX (a is known to be below (MAX + 1) p and a multiple check is all that is needed)?
 template <int MAX>
-__device__ __forceinline__ bool fql_is_multiple_of_p(const FqL& a) {
+JOLT_HD bool fql_is_multiple_of_p(const FqL& a) {
     bool hit = false;
 #pragma unroll
     for (int m = 1; m <= MAX; ++m) {
@@ -262,7 +263,7 @@ __device__ __forceinline__ bool fql_is_multiple_of_p(const FqL& a) {
 struct G1XyzzL {
     FqL x, y, zz, zzz;
 };
-__device__ __forceinline__ G1XyzzL g1xl_identity() {
+JOLT_HD G1XyzzL g1xl_identity() {
     G1XyzzL r;
     r.x = fql_zero();
     r.y = fql_zero();
@@ -270,9 +271,9 @@ __device__ __forceinline__ G1XyzzL g1xl_identity() {
     r.zzz = fql_zero();
     return r;
 }
-__device__ __forceinline__ bool g1xl_is_identity(const G1XyzzL& p) { return fql_is_zero(p.zz); }
+JOLT_HD bool g1xl_is_identity(const G1XyzzL& p) { return fql_is_zero(p.zz); }
 // 2 * (x, y) for an affine point in L-form (mdbl-2008-s, a = 0): only reached when a bucket receives the same point twice in a row
-__device__ __forceinline__ G1XyzzL g1xl_double_affine(const FqL& x, const FqL& y) {
+JOLT_HD G1XyzzL g1xl_double_affine(const FqL& x, const FqL& y) {
     const FqL U = fql_dbl(y);
     const FqL V = fql_sqr(U);
     const FqL W = fql_mul(U, V);
@@ -292,7 +293,7 @@ __device__ __forceinline__ G1XyzzL g1xl_double_affine(const FqL& x, const FqL& y
 // Y3 = (R (Q - X3) + (4p - Y) PPP) 2^-261 < 1.4 (one reduction for both products); the largest product, P^2 < 92.2 p^2, stays below 1.55 p.
 // P = 0 mod p (the same x: the point itself or its negative) shows as ZZ3 = ZZ PP = 0 mod p, tested on a product (0 or p) AFTER the
 // common path instead of on the lazily reduced P before it.
-__device__ __forceinline__ G1XyzzL g1xl_add_mixed(const G1XyzzL& p, const FqL& qx, const FqL& qy, const FqL& one) {
+JOLT_HD G1XyzzL g1xl_add_mixed(const G1XyzzL& p, const FqL& qx, const FqL& qy, const FqL& one) {
     if (g1xl_is_identity(p)) {
         G1XyzzL r;
         r.x = qx;

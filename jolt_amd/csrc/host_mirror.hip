@@ -426,6 +426,63 @@ extern "C" int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t* a, cons
     }
     return JOLT_OK;
 }
+// The limb-form Fq arithmetic of the bucket sums (fq_limb.hip.h), compiled for the host so that the CPU suite pins it against the oracle.
+// Operands are canonical Fq in STANDARD Montgomery form; they are taken to L-form (x * 2^261: a product with the Montgomery form of 32),
+// combined there, and the result is brought back.  op 0: a * b   1: a^2   2: a * b + c * d (one reduction)   3: (a - b) * c through the lazily
+// reduced difference a + 8p - b   4: (a - b - 2c) * d through a + 6p - b - 2c.
+#include "g1.hip.h"
+#include "fq_limb.hip.h"
+extern "C" int32_t jolt_host_fq_limb_op(int32_t op, const jolt_fr_t* a, const jolt_fr_t* b, const jolt_fr_t* c, const jolt_fr_t* d, jolt_fr_t* out) {
+    if (!a || !out || (op != 1 && !b) || (op >= 2 && !c) || ((op == 2 || op == 4) && !d)) return JOLT_ERR_INVALID_ARG;
+    using namespace jolt;
+    Fq thirty_two = Fq::zero();
+    thirty_two.l[0] = 32;
+    const Fq m32 = to_mont(thirty_two);
+    auto load = [&](const jolt_fr_t* p) {
+        Fq x;
+        std::memcpy(&x, p, sizeof(x));
+        return fql_from_words(mul(x, m32));
+    };
+    const FqL r256 = fql_from_words(Fq::one());
+    FqL r;
+    switch (op) {
+        case 0: r = fql_mul(load(a), load(b)); break;
+        case 1: r = fql_sqr(load(a)); break;
+        case 2: r = fql_mul2(load(a), load(b), load(c), load(d)); break;
+        case 3: r = fql_mul(fql_diff<8, false>(load(a), load(b), load(a)), load(c)); break;
+        case 4: r = fql_mul(fql_diff<6, true>(load(a), load(b), load(c)), load(d)); break;
+        default: return JOLT_ERR_INVALID_ARG;
+    }
+    const Fq res = fql_to_std(r, r256);
+    std::memcpy(out, &res, sizeof(res));
+    return JOLT_OK;
+}
+// sum of `count` affine points (standard Montgomery coordinates, (0, 0) = infinity; negate[i] != 0 adds -P_i) through the limb-form XYZZ
+// accumulator of the bucket kernels: g1xl_add_mixed with its identity / doubling / P + (-P) branches, then the conversion back
+extern "C" int32_t jolt_host_g1_sum_limb_form(const uint64_t* points /* count x 8 u64: x, y */, const uint8_t* negate, size_t count, jolt_g1_t* out) {
+    if ((!points && count) || !out) return JOLT_ERR_INVALID_ARG;
+    using namespace jolt;
+    Fq thirty_two = Fq::zero();
+    thirty_two.l[0] = 32;
+    const Fq m32 = to_mont(thirty_two);
+    const FqL one = fql_from_words(m32), r256 = fql_from_words(Fq::one());
+    G1XyzzL acc = g1xl_identity();
+    for (size_t i = 0; i < count; ++i) {
+        G1Affine p;
+        std::memcpy(&p, points + 8 * i, sizeof(p));
+        if (g1_aff_is_inf(p)) continue;
+        if (negate && negate[i]) p.y = neg(p.y);
+        acc = g1xl_add_mixed(acc, fql_from_words(mul(p.x, m32)), fql_from_words(mul(p.y, m32)), one);
+    }
+    G1Jac r = g1_identity();
+    if (!g1xl_is_identity(acc)) {
+        r.x = fql_to_std(fql_mul(acc.x, fql_sqr(acc.zz)), r256);
+        r.y = fql_to_std(fql_mul(acc.y, fql_sqr(acc.zzz)), r256);
+        r.z = fql_to_std(acc.zzz, r256);
+    }
+    std::memcpy(out, &r, sizeof(r));
+    return JOLT_OK;
+}
 extern "C" int32_t jolt_host_fr_add(const jolt_fr_t* a, const jolt_fr_t* b, jolt_fr_t* out) {
     if (!a || !b || !out) return JOLT_ERR_INVALID_ARG;
     fr_to_abi(out, add(fr_from_abi(a), fr_from_abi(b)));

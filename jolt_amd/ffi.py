@@ -1071,3 +1071,20 @@ class ReadRaf:
 
 
 Context.read_raf = lambda self, lookup_index, table_index, raf_flag, n_tables: ReadRaf(self, lookup_index, table_index, raf_flag, n_tables)
+
+
+def host_fq_limb_op(op, a, b=None, c=None, d=None):
+    """fq_limb.hip.h on the host: op 0 a*b, 1 a^2, 2 a*b + c*d, 3 (a - b)*c, 4 (a - b - 2c)*d over canonical Fq (standard Montgomery limbs)"""
+    o = fr_array(1)
+    arg = lambda x: _p(fr(x)) if x is not None else None
+    _ck(lib().jolt_host_fq_limb_op(C.c_int32(op), arg(a), arg(b), arg(c), arg(d), _p(o)), "jolt_host_fq_limb_op")
+    return o[0]
+
+
+def host_g1_sum_limb_form(points, negate=None):
+    """sum of affine points ((n, 8) uint64: x, y in standard Montgomery form; (0, 0) = infinity) through the limb-form XYZZ accumulator"""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    neg = np.ascontiguousarray(negate if negate is not None else np.zeros(pts.shape[0]), dtype=np.uint8)
+    out = g1_array(1)
+    _ck(lib().jolt_host_g1_sum_limb_form(pts.ctypes.data_as(C.c_void_p), neg.ctypes.data_as(C.c_void_p), C.c_size_t(pts.shape[0]), _p(out)), "jolt_host_g1_sum_limb_form")
+    return out[0]

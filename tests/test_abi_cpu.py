@@ -176,3 +176,55 @@ def test_integration_doc_lists_the_sources_the_build_compiles():
     m = re.search(r"jolt_amd/csrc/\{([a-z_0-9,]+)\}\.hip", doc)
     assert m, "source list not found in INTEGRATION.md"
     assert m.group(1).split(",") == [os.path.basename(s)[:-4] for s in build.SOURCES]
+
+
+def test_limb_form_field_arithmetic_matches_oracle_on_host():
+    """fq_limb.hip.h (2^261 Montgomery radix, lazy reduction, dedicated squaring, two-product reduction, lazily reduced differences) built
+    for the host: every operation against the oracle's Fq arithmetic on corner values (0, 1, p - 1, all-ones limb patterns) and random
+    operands -- the differences with the subtrahend LARGER than the minuend included, which is what the added multiples of p are for."""
+    rng = np.random.default_rng(61)
+    mod = O.Q_MOD
+    ints = [0, 1, 2, mod - 1, mod - 2, (1 << 253) - 1, mod - 3, 0x1FFFFFFF, 1 << 29, (1 << 232) - 1] + [int.from_bytes(rng.bytes(32), "little") % mod for _ in range(60)]
+    vals = np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in ints], dtype=np.uint64)
+    n = len(ints)
+    mul = lambda x, y: O.fq_mul(x.reshape(1, 4), y.reshape(1, 4))[0]
+    sub = lambda x, y: O.fq_sub(x.reshape(1, 4), y.reshape(1, 4))[0]
+    add = lambda x, y: O.fq_add(x.reshape(1, 4), y.reshape(1, 4))[0]
+    for i in range(n):
+        a, b, c, d = vals[i], vals[(7 * i + 3) % n], vals[n - 1 - i], vals[(5 * i + 11) % n]
+        assert np.array_equal(ffi.host_fq_limb_op(0, a, b), mul(a, b)), i
+        assert np.array_equal(ffi.host_fq_limb_op(1, a), mul(a, a)), i
+        assert np.array_equal(ffi.host_fq_limb_op(2, a, b, c, d), add(mul(a, b), mul(c, d))), i
+        assert np.array_equal(ffi.host_fq_limb_op(3, a, b, c), mul(sub(a, b), c)), i
+        assert np.array_equal(ffi.host_fq_limb_op(4, a, b, c, d), mul(sub(sub(a, b), add(c, c)), d)), i
+
+
+def test_limb_form_bucket_sum_matches_oracle_on_host():
+    """g1xl_add_mixed (XYZZ accumulator in limb form) over lists of affine points: random points, the same point twice and three times in a
+    row (the doubling branch, then an ordinary addition onto 2P), P followed by -P (identity, then a fresh start), points at infinity in
+    the list, negated entries -- equal as group elements to the oracle's sum."""
+    rng = np.random.default_rng(62)
+    g = O.g1_generator()
+    jac = [O.g1_scalar_mul(g, np.array([int(rng.integers(1, 2**62)), 0, 0, 0], dtype=np.uint64)) for _ in range(12)]
+    aff = O.g1_to_affine(np.stack(jac))
+    inf = np.zeros(8, dtype=np.uint64)
+
+    def check(order, negate=None):
+        pts = np.stack([aff[k] if k >= 0 else inf for k in order]) if order else np.zeros((0, 8), dtype=np.uint64)
+        neg = np.zeros(len(order), dtype=np.uint8) if negate is None else np.array(negate, dtype=np.uint8)
+        want = O.g1_identity()
+        for k, s in zip(order, neg):
+            if k >= 0:
+                want = O.g1_add(want, O.g1_neg(jac[k]) if s else jac[k])
+        assert O.g1_eq(ffi.host_g1_sum_limb_form(pts, neg), want), (order, negate)
+
+    check([])
+    check([-1, -1])
+    check([3])
+    check(list(range(12)))
+    check([0, 0])                      # P + P
+    check([0, 0, 0, 1])                # 2P + P, then another point
+    check([2, 2], [0, 1])              # P + (-P) = identity
+    check([2, 2, 5, 5, 5], [0, 1, 0, 0, 0])  # identity, then a fresh start with a doubling
+    check([4, -1, 4, 7, -1, 7, 7], [1, 0, 1, 0, 0, 0, 1])
+    check([int(k) for k in rng.integers(0, 12, size=200)], [int(b) for b in rng.integers(0, 2, size=200)])
