@@ -259,10 +259,11 @@ int32_t jolt_srs_download(jolt_ctx *ctx, const jolt_srs *srs, size_t offset, siz
 int32_t jolt_srs_free(jolt_ctx *ctx, jolt_srs *srs);
 /* Fixed-base tables for an SRS that outlives many MSMs (HyperKZGProverSetup.g1_powers is built once per setup,
  * crates/jolt-hyperkzg/src/types.rs:105-108, and every kzg_commit / kzg_open_batch MSM multiplies a prefix of it): keep
- * 2^(c*w) * srs[i] for every c-bit window w resident, so that all windows of an MSM share ONE bucket set and c can grow to 26 bits
- * (10 instead of 16 windows of point additions for 254-bit scalars).  Costs ceil(255/c) copies of the bases
- * in HBM.  window_bits = 0 picks c from the SRS length (26 from 2^26 points, else <= 24); MSMs over fewer than min_terms terms
- * (0 = 2^(c-2)) keep the per-window method.  Results are the same points. */
+ * 2^(c*w) * srs[i] for every c-bit window w resident, so that all windows of an MSM share ONE bucket set and c can grow to 23-26 bits
+ * (11 instead of 16 windows of point additions for 254-bit scalars: scalars above r/2 are negated, the top window is unsigned; DESIGN.md
+ * section 3.5c).  Costs ceil(253/c) copies of the bases in HBM, stored in the limb-form Montgomery radix of the bucket kernels.
+ * window_bits = 0 picks c from the SRS length (23 from 2^24 points, else <= 24); MSMs over fewer than min_terms terms (0 = 2^(c-2)) keep
+ * the per-window method.  Results are the same points. */
 int32_t jolt_srs_precompute_windows(jolt_ctx *ctx, jolt_srs *srs, uint32_t window_bits, size_t min_terms);
 
 /* JoltGroup::msm(bases, scalars) (crates/jolt-crypto/src/ec/group.rs:63-70, bn254/mod.rs:195-212) with the bases
