@@ -304,6 +304,9 @@ int32_t jolt_host_mul_limbs29(int32_t field, const jolt_fr_t *a, const jolt_fr_t
  * affine points in STANDARD Montgomery form.  op: 0 a*b, 1 a^2, 2 a*b + c*d, 3 (a - b)*c, 4 (a - b - 2c)*d. */
 int32_t jolt_host_fq_limb_op(int32_t op, const jolt_fr_t *a, const jolt_fr_t *b, const jolt_fr_t *c, const jolt_fr_t *d, jolt_fr_t *out);
 int32_t jolt_host_g1_sum_limb_form(const uint64_t *points, const uint8_t *negate, size_t count, jolt_g1_t *out);
+/* The signed-digit recoding of the fixed-base MSM for one scalar (negation above r / 2, c-bit signed windows, unsigned top window), built for
+ * the host: keys_out[w] = |digit_w| | sign << 31 for w < ceil(253 / c); *buckets_out = the bucket count of a table set with this c. */
+int32_t jolt_host_fx_digits(const jolt_fr_t *scalar, uint32_t window_bits, uint32_t *keys_out, uint32_t *n_windows_out, uint32_t *buckets_out);
 /* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
 int32_t jolt_host_univariate_from_evals(const jolt_fr_t *evals, size_t n, jolt_fr_t *coeffs_out);
 int32_t jolt_host_univariate_evaluate(const jolt_fr_t *coeffs, size_t n, const jolt_fr_t *x, jolt_fr_t *out);

@@ -60,10 +60,8 @@ __global__ __launch_bounds__(kBlock) void k_fx_next_window(const G1Affine* __res
 // digit is taken as is (raw + carry in, < top_max).  With c = 23 the 253 bits are exactly 11 windows -- no short top window piling its n
 // digits onto a few thousand buckets (c = 24: 14 bits -> 2^13 buckets) -- and the bucket set is max(2^(c-1), top_max) = 6.34 M
 // buckets instead of the 2^25 of c = 26, whose running-sum reduction cost 10.4 ms per MSM however short the MSM was.
-__global__ __launch_bounds__(kBlock) void k_fx_digits(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t* __restrict__ keys) {
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    Fr s = from_mont(ld_fr(scalars + i));
+// keys[w] = |digit_w| | sign << 31 for one canonical scalar (also built for the host: jolt_host_fx_digits, pinned in the CPU suite)
+JOLT_HD void fx_digits_of(Fr s /* canonical integer, not Montgomery */, int c, int W, uint32_t* __restrict__ keys, size_t key_stride) {
     bool flip = false;
 #pragma unroll
     for (int j = 7; j >= 0; --j) {  // s > (r - 1) / 2 ?   ((r - 1) / 2 = r >> 1, r odd)
@@ -85,11 +83,16 @@ __global__ __launch_bounds__(kBlock) void k_fx_digits(const Fr* __restrict__ sca
             uint32_t mag, negf;
             if (raw > B) { mag = (1u << c) - raw; negf = 0x80000000u; carry = 1; }
             else { mag = raw; negf = 0u; carry = 0; }
-            keys[(size_t)w * n + i] = mag | (negf ^ fl);
+            keys[(size_t)w * key_stride] = mag | (negf ^ fl);
         } else {
-            keys[(size_t)w * n + i] = (((uint32_t)(two >> off) & 0x7FFFFFFFu) + carry) | fl;  // everything that is left of the <= 253 bits
+            keys[(size_t)w * key_stride] = (((uint32_t)(two >> off) & 0x7FFFFFFFu) + carry) | fl;  // everything that is left of the <= 253 bits
         }
     }
+}
+__global__ __launch_bounds__(kBlock) void k_fx_digits(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t* __restrict__ keys) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    fx_digits_of(from_mont(ld_fr(scalars + i)), c, W, keys + i, n);
 }
 
 // ---- 2. partition by the high bits of |digit| ------------------------------------------------------------------------------
@@ -778,5 +781,22 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     job->c = 0;  // a single "window": the collect step's Horner loop adds it once
     job->W = 1;
     job->nb = nb;
+    return JOLT_OK;
+}
+
+// The digit recoding of the fixed-base MSM for ONE scalar (Montgomery form), built for the host: keys_out[w] = |digit_w| | sign << 31 for the
+// W = ceil(253 / c) windows, *buckets_out = the bucket count a table set with this c uses (largest possible |digit|).
+extern "C" int32_t jolt_host_fx_digits(const jolt_fr_t* scalar, uint32_t window_bits, uint32_t* keys_out, uint32_t* n_windows_out, uint32_t* buckets_out) {
+    if (!scalar || !keys_out || window_bits < 2 || window_bits > 26) return JOLT_ERR_INVALID_ARG;
+    const int c = (int)window_bits, W = (253 + c - 1) / c;
+    const int shift = c * (W - 1) + 1;
+    if (254 - shift > 31) return JOLT_ERR_UNSUPPORTED;
+    auto limb32 = [](int j) -> uint64_t { return j < 8 ? (uint64_t)(uint32_t)FrParams::P[j] : 0ull; };
+    const uint64_t top_max = ((limb32(shift >> 5) | (limb32((shift >> 5) + 1) << 32)) >> (shift & 31)) + 1;
+    Fr s = fr_from_abi(scalar);
+    if (!fr_is_canonical(s)) return JOLT_ERR_INVALID_ARG;
+    fx_digits_of(from_mont(s), c, W, keys_out, 1);
+    if (n_windows_out) *n_windows_out = (uint32_t)W;
+    if (buckets_out) *buckets_out = (uint32_t)std::max<uint64_t>((uint64_t)1 << (c - 1), top_max);
     return JOLT_OK;
 }

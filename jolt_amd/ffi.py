@@ -1088,3 +1088,11 @@ def host_g1_sum_limb_form(points, negate=None):
     out = g1_array(1)
     _ck(lib().jolt_host_g1_sum_limb_form(pts.ctypes.data_as(C.c_void_p), neg.ctypes.data_as(C.c_void_p), C.c_size_t(pts.shape[0]), _p(out)), "jolt_host_g1_sum_limb_form")
     return out[0]
+
+
+def host_fx_digits(scalar, window_bits):
+    """(signed digits as Python ints, bucket count) of the fixed-base MSM's recoding of one Montgomery-form scalar"""
+    keys = np.zeros(64, dtype=np.uint32)
+    nw, nb = C.c_uint32(), C.c_uint32()
+    _ck(lib().jolt_host_fx_digits(_p(fr(scalar)), C.c_uint32(window_bits), keys.ctypes.data_as(C.c_void_p), C.byref(nw), C.byref(nb)), "jolt_host_fx_digits")
+    return [(-1 if int(k) >> 31 else 1) * (int(k) & 0x7FFFFFFF) for k in keys[: nw.value]], nb.value

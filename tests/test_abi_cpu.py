@@ -228,3 +228,23 @@ def test_limb_form_bucket_sum_matches_oracle_on_host():
     check([2, 2, 5, 5, 5], [0, 1, 0, 0, 0])  # identity, then a fresh start with a doubling
     check([4, -1, 4, 7, -1, 7, 7], [1, 0, 1, 0, 0, 0, 1])
     check([int(k) for k in rng.integers(0, 12, size=200)], [int(b) for b in rng.integers(0, 2, size=200)])
+
+
+@pytest.mark.parametrize("c", [10, 13, 19, 23, 26])
+def test_fixed_base_digit_recoding_reconstructs_the_scalar(c):
+    """k_fx_digits' recoding on the host: sum_w digit_w 2^(c w) = s mod r (scalars above r / 2 come out negated), every signed digit is
+    within +-2^(c-1), every magnitude addresses a bucket below the table set's bucket count, and the worst cases (r - 1, (r - 1) / 2 and
+    its neighbours, all-ones windows that carry through every window) are among the samples."""
+    R = O.R_MOD
+    rng = np.random.default_rng(70 + c)
+    samples = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R - 1) // 2 + 1, (R + 1) // 2 + 1, (1 << 253) - 1, (1 << 252), (1 << (c - 1)), (1 << (c - 1)) + 1, (1 << c) - 1,
+               sum(((1 << c) - 1) << (c * w) for w in range(253 // c)) % R, sum((1 << (c - 1)) << (c * w) for w in range(253 // c)) % R]
+    samples += [int.from_bytes(rng.bytes(32), "little") % R for _ in range(300)]
+    for s in samples:
+        digits, buckets = ffi.host_fx_digits(O.to_mont([s])[0], c)
+        assert len(digits) == -(-253 // c)
+        assert sum(d << (c * w) for w, d in enumerate(digits)) % R == s, hex(s)
+        assert all(abs(d) <= 1 << (c - 1) for d in digits[:-1]) and all(abs(d) <= buckets for d in digits), hex(s)
+        assert buckets >= 1 << (c - 1)
+    if c == 23:
+        assert buckets == 6342813  # ((r - 1) / 2 >> 230) + 1: DESIGN.md section 3.5c
