@@ -503,6 +503,8 @@ int32_t jolt_read_raf_condense(jolt_ctx *ctx, jolt_read_raf *rr, jolt_table *u, 
 int32_t jolt_read_raf_cycle_tables(jolt_ctx *ctx, jolt_read_raf *rr, const jolt_fr_t *table_values, const jolt_fr_t *raf_interleaved, const jolt_fr_t *raf_identity,
                                    const jolt_fr_t *v_tables, uint32_t phases, uint32_t address_bits, uint32_t ra_count, jolt_table **combined_out,
                                    jolt_table **ra_out);
+/* suffix_mle.hip.h (Suffixes::suffix_mle for the kind's discriminant) built for the host, for the CPU suite; bits are masked to `len`. */
+int32_t jolt_host_suffix_mle(uint32_t kind, uint64_t lo, uint64_t hi, uint32_t len, uint64_t *out);
 
 /* Spartan outer (stage 1) T-scale sums -- SURVEY.md section 8(f) row 3 (crates/jolt-kernels/src/{reference,optimized}/spartan_outer.rs).
  * The constraint list, spartan_outer_row_weights and the Lagrange interpolation stay in Rust (O(rows) work); the caller folds the

@@ -388,3 +388,14 @@ extern "C" int32_t jolt_read_raf_cycles(const jolt_read_raf* rr, size_t* cycles,
     if (n_tables) *n_tables = rr->n_tables;
     return JOLT_OK;
 }
+
+// suffix_mle.hip.h built for the host: the CPU suite checks the device's suffix polynomials against the oracle and its big-integer model
+extern "C" int32_t jolt_host_suffix_mle(uint32_t kind, uint64_t lo, uint64_t hi, uint32_t len, uint64_t* out) {
+    if (!out || kind >= (uint32_t)kNumSuffixKinds || len > 128) return JOLT_ERR_INVALID_ARG;
+    if (len < 128) {  // LookupBits::new masks to `len` bits
+        if (len >= 64) hi &= len == 64 ? 0ull : ((1ull << (len - 64)) - 1);
+        else { hi = 0; lo &= len == 0 ? 0ull : ((1ull << len) - 1); }
+    }
+    *out = suffix_mle(kind, lo, hi, len);
+    return JOLT_OK;
+}

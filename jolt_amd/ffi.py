@@ -1096,3 +1096,9 @@ def host_fx_digits(scalar, window_bits):
     nw, nb = C.c_uint32(), C.c_uint32()
     _ck(lib().jolt_host_fx_digits(_p(fr(scalar)), C.c_uint32(window_bits), keys.ctypes.data_as(C.c_void_p), C.byref(nw), C.byref(nb)), "jolt_host_fx_digits")
     return [(-1 if int(k) >> 31 else 1) * (int(k) & 0x7FFFFFFF) for k in keys[: nw.value]], nb.value
+
+
+def host_suffix_mle(kind, bits, length):
+    out = C.c_uint64()
+    _ck(lib().jolt_host_suffix_mle(C.c_uint32(kind), C.c_uint64(bits & (2**64 - 1)), C.c_uint64((bits >> 64) & (2**64 - 1)), C.c_uint32(length), C.byref(out)), "jolt_host_suffix_mle")
+    return out.value

@@ -257,6 +257,7 @@ extern "C" {
     pub fn jolt_read_raf_phase_scan(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, u: *const jolt_table, suffix_len: u32, address_bits: u32, canonical: i32, suffix_offsets: *const u32, suffix_kinds: *const u8, raf_out: *mut jolt_fr_t, suffix_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_read_raf_condense(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, u: *mut jolt_table, v_table: *const jolt_fr_t, shift: u32) -> i32;
     pub fn jolt_read_raf_cycle_tables(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, table_values: *const jolt_fr_t, raf_interleaved: *const jolt_fr_t, raf_identity: *const jolt_fr_t, v_tables: *const jolt_fr_t, phases: u32, address_bits: u32, ra_count: u32, combined_out: *mut *mut jolt_table, ra_out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_host_suffix_mle(kind: u32, lo: u64, hi: u64, len: u32, out: *mut u64) -> i32;
     pub fn jolt_r1cs_uniskip_sums(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, eq: *const jolt_table, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, n_nodes: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_r1cs_materialize(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, az_out: *mut *mut jolt_table, bz_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_tables_evaluate(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, k: usize, point: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;

@@ -78,3 +78,15 @@ def test_condense_and_cycle_tables_equal_their_definitions():
             for p in range(i * 4, i * 4 + 4):
                 want = want * vt_i[p][(index >> (address_bits - 8 * (p + 1))) & 255] % O.R_MOD
             assert O.from_mont(ra[i][j: j + 1])[0] == want
+
+
+@pytest.mark.parametrize("length", [0, 8, 56, 64, 72, 120])
+def test_device_suffix_code_built_for_the_host_matches_oracle_and_model(length):
+    """suffix_mle.hip.h (what the phase-scan kernel evaluates per row) compiled for the host: all 48 kinds against the C oracle and the
+    Python big-integer model on the corner / random suffixes"""
+    from jolt_amd import ffi
+    rng = np.random.default_rng(100 + length)
+    for bits in interesting_bits(rng, length):
+        for kind in range(len(KINDS)):
+            got = ffi.host_suffix_mle(kind, bits, length)
+            assert got == O.suffix_mle(kind, bits, length) == suffix_model(kind, bits, length), (KINDS[kind], hex(bits), length)
