@@ -543,6 +543,8 @@ int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx *ctx, const jolt_ints *const *inpu
 int32_t jolt_r1cs_materialize_small(jolt_ctx *ctx, const jolt_ints *const *inputs, size_t n_inputs, uint32_t n_streams, const jolt_fr_t *a_weights,
                                     const jolt_fr_t *b_weights, jolt_table **az_out, jolt_table **bz_out);
 int32_t jolt_ints_evaluate(jolt_ctx *ctx, const jolt_ints *const *columns, size_t k, const jolt_fr_t *point, size_t n, jolt_fr_t *out);
+/* csrc/small_scalar.hip.h built for the host (CPU suite): sum_k values[k] * scalars[k], scalars as signed 128-bit (lo, hi) pairs. */
+int32_t jolt_host_small_scalar_dot(const jolt_fr_t *values, const uint64_t *scalars, size_t n, jolt_fr_t *out);
 
 /* Sparse (K x T) read-write matrix of RAM read/write checking (stage 2) -- SURVEY.md section 8(f) row 4.  Replaces
  * CycleMajorMatrix / AddressMajorMatrix and the round messages of RamReadWriteKernel (crates/jolt-kernels/src/optimized/rw_matrix.rs,

@@ -312,3 +312,25 @@ extern "C" int32_t jolt_ints_evaluate(jolt_ctx* ctx, const jolt_ints* const* col
     jolt_table_free(ctx, eq);
     return s;
 }
+
+// small_scalar.hip.h built for the host: sum_k values[k] * scalars[k] for signed 128-bit scalars (lo, hi two's complement) through the
+// 13-limb accumulator and ONE REDC, brought back to Montgomery form -- the CPU suite compares it with the oracle's restatement of
+// FrSmallScalarAccumulator and with plain sums
+extern "C" int32_t jolt_host_small_scalar_dot(const jolt_fr_t* values, const uint64_t* scalars /* 2 per term */, size_t n, jolt_fr_t* out) {
+    if ((!values || !scalars) && n) return JOLT_ERR_INVALID_ARG;
+    if (!out) return JOLT_ERR_INVALID_ARG;
+    SmallAcc pos = small_zero(), neg_acc = small_zero();
+    for (size_t k = 0; k < n; ++k) {
+        uint64_t lo = scalars[2 * k], hi = scalars[2 * k + 1];
+        const bool negative = (hi >> 63) != 0;
+        if (negative) {
+            lo = ~lo + 1;
+            hi = ~hi + (lo == 0 ? 1 : 0);
+        }
+        const uint32_t m[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        small_fmadd<4>(negative ? neg_acc : pos, fr_from_abi(&values[k]), m);
+    }
+    const Fr r = mul(sub(small_redc<FrParams>(pos), small_redc<FrParams>(neg_acc)), Fr::r2());
+    fr_to_abi(out, r);
+    return JOLT_OK;
+}

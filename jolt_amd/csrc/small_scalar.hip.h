@@ -20,7 +20,7 @@ struct SmallInt {
 };
 constexpr int kIntKindU64 = 0, kIntKindI64 = 1, kIntKindI128 = 2;  // = JOLT_INT_* of include/jolt_hip.h
 
-__device__ __forceinline__ SmallInt load_small(const void* __restrict__ data, int kind, size_t i) {
+JOLT_HD SmallInt load_small(const void* __restrict__ data, int kind, size_t i) {
     SmallInt s;
     uint64_t lo, hi = 0;
     bool negative = false;
@@ -50,7 +50,7 @@ constexpr int kSmallLimbs = 13;  // 416 bits
 struct SmallAcc {
     uint32_t l[kSmallLimbs];
 };
-__device__ __forceinline__ SmallAcc small_zero() {
+JOLT_HD SmallAcc small_zero() {
     SmallAcc a;
 #pragma unroll
     for (int i = 0; i < kSmallLimbs; ++i) a.l[i] = 0;
@@ -58,7 +58,7 @@ __device__ __forceinline__ SmallAcc small_zero() {
 }
 // acc += a * m, m = LIMBS 32-bit limbs of the magnitude (2 for the 64-bit kinds, 4 for i128)
 template <int LIMBS, class PR>
-__device__ __forceinline__ void small_fmadd(SmallAcc& acc, const Fp<PR>& a, const uint32_t (&m)[4]) {
+JOLT_HD void small_fmadd(SmallAcc& acc, const Fp<PR>& a, const uint32_t (&m)[4]) {
 #pragma unroll
     for (int i = 0; i < LIMBS; ++i) {
         uint64_t p[8];
@@ -75,7 +75,7 @@ __device__ __forceinline__ void small_fmadd(SmallAcc& acc, const Fp<PR>& a, cons
 }
 // acc * 2^-256 mod p, canonical (one Montgomery REDC; the 13-limb input keeps the output below p + 2^160 < 2p)
 template <class PR>
-__device__ __forceinline__ Fp<PR> small_redc(const SmallAcc& acc) {
+JOLT_HD Fp<PR> small_redc(const SmallAcc& acc) {
     uint32_t t[kSmallLimbs + 9];
 #pragma unroll
     for (int i = 0; i < kSmallLimbs; ++i) t[i] = acc.l[i];
@@ -104,7 +104,7 @@ __device__ __forceinline__ Fp<PR> small_redc(const SmallAcc& acc) {
 struct U256 {
     uint32_t l[8];
 };
-__device__ __forceinline__ U256 u256_zero() {
+JOLT_HD U256 u256_zero() {
     U256 z;
 #pragma unroll
     for (int i = 0; i < 8; ++i) z.l[i] = 0;
@@ -112,7 +112,7 @@ __device__ __forceinline__ U256 u256_zero() {
 }
 // acc += w * m (w: 64-bit magnitude, m: LIMBS x 32 bits), truncated to 256 bits
 template <int LIMBS>
-__device__ __forceinline__ void u256_fmadd(U256& acc, uint64_t w, const uint32_t (&m)[4]) {
+JOLT_HD void u256_fmadd(U256& acc, uint64_t w, const uint32_t (&m)[4]) {
     const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
     const uint32_t wl[2] = {w0, w1};
     uint32_t prod[LIMBS + 2];
@@ -133,14 +133,14 @@ __device__ __forceinline__ void u256_fmadd(U256& acc, uint64_t w, const uint32_t
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc.l[i] = __builtin_addc(acc.l[i], i < LIMBS + 2 ? prod[i] : 0u, c, &c);
 }
-__device__ __forceinline__ bool u256_geq(const U256& a, const U256& b) {
+JOLT_HD bool u256_geq(const U256& a, const U256& b) {
 #pragma unroll
     for (int i = 7; i >= 0; --i) {
         if (a.l[i] != b.l[i]) return a.l[i] > b.l[i];
     }
     return true;
 }
-__device__ __forceinline__ U256 u256_sub(const U256& a, const U256& b) {
+JOLT_HD U256 u256_sub(const U256& a, const U256& b) {
     U256 r;
     uint32_t br = 0;
 #pragma unroll
@@ -148,7 +148,7 @@ __device__ __forceinline__ U256 u256_sub(const U256& a, const U256& b) {
     return r;
 }
 // low 256 bits of a (128-bit magnitude as two u64) * b
-__device__ __forceinline__ U256 u256_mul_u128(const U256& b, uint64_t a_lo, uint64_t a_hi) {
+JOLT_HD U256 u256_mul_u128(const U256& b, uint64_t a_lo, uint64_t a_hi) {
     const uint32_t a[4] = {(uint32_t)a_lo, (uint32_t)(a_lo >> 32), (uint32_t)a_hi, (uint32_t)(a_hi >> 32)};
     U256 r = u256_zero();
 #pragma unroll

@@ -1102,3 +1102,12 @@ def host_suffix_mle(kind, bits, length):
     out = C.c_uint64()
     _ck(lib().jolt_host_suffix_mle(C.c_uint32(kind), C.c_uint64(bits & (2**64 - 1)), C.c_uint64((bits >> 64) & (2**64 - 1)), C.c_uint32(length), C.byref(out)), "jolt_host_suffix_mle")
     return out.value
+
+
+def host_small_scalar_dot(values, scalars):
+    """sum_k values[k] * scalars[k] (Python ints within i128) through the device's small-scalar accumulator, on the host"""
+    v = fr(values).reshape(-1, 4)
+    sc = np.array([[int(x) & (2**64 - 1), (int(x) >> 64) & (2**64 - 1)] for x in scalars], dtype=np.uint64).reshape(-1, 2)
+    o = fr_array(1)
+    _ck(lib().jolt_host_small_scalar_dot(_p(v), sc.ctypes.data_as(C.c_void_p), C.c_size_t(v.shape[0]), _p(o)), "jolt_host_small_scalar_dot")
+    return o[0]

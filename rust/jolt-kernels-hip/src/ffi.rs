@@ -264,6 +264,7 @@ extern "C" {
     pub fn jolt_r1cs_uniskip_sums_small(ctx: *mut jolt_ctx, inputs: *const *const jolt_ints, n_inputs: usize, eq: *const jolt_table, n_streams: u32, a_weights: *const i64, b_weights: *const i64, n_nodes: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_r1cs_materialize_small(ctx: *mut jolt_ctx, inputs: *const *const jolt_ints, n_inputs: usize, n_streams: u32, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, az_out: *mut *mut jolt_table, bz_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_ints_evaluate(ctx: *mut jolt_ctx, columns: *const *const jolt_ints, k: usize, point: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_small_scalar_dot(values: *const jolt_fr_t, scalars: *const u64, n: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_create(ctx: *mut jolt_ctx, addresses: *const u64, pre_values: *const u64, post_values: *const u64, cycles: usize, inc: *const jolt_table, val_init: *const jolt_table, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
     pub fn jolt_rw_matrix_prove_round(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, aux_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_finish(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t) -> i32;

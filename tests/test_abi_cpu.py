@@ -248,3 +248,22 @@ def test_fixed_base_digit_recoding_reconstructs_the_scalar(c):
         assert buckets >= 1 << (c - 1)
     if c == 23:
         assert buckets == 6342813  # ((r - 1) / 2 >> 230) + 1: DESIGN.md section 3.5c
+
+
+def test_small_scalar_accumulator_built_for_the_host():
+    """small_scalar.hip.h (field x machine-integer products summed unreduced in 13 limbs, one REDC) on the host: equal to the plain sum of
+    reduced products for i128 scalars incl. the corners, to the oracle's restatement of FrSmallScalarAccumulator where that one's five limbs
+    suffice, and still exact for 5000 full-range 128-bit terms (headroom 2^34 terms)"""
+    rng = np.random.default_rng(90)
+    R = O.R_MOD
+    for n in (0, 1, 4, 300, 5000):
+        values = rand_fr(max(n, 1), 91 + n)[:n]
+        scalars = [int(rng.integers(-2**62, 2**62)) * int(rng.integers(0, 2**63)) for _ in range(n)]
+        scalars[: min(n, 4)] = [0, -(2**127), 2**127 - 1, -1][: min(n, 4)]
+        v_int = O.from_mont(values) if n else []
+        want = sum(v * s for v, s in zip(v_int, scalars)) % R
+        got = ffi.host_small_scalar_dot(values if n else np.zeros((0, 4), dtype=np.uint64), scalars)
+        assert O.from_mont(got.reshape(1, 4))[0] == want, n
+    values = rand_fr(200, 95)
+    small = rng.integers(-2**48, 2**48, size=200, dtype=np.int64)
+    assert np.array_equal(ffi.host_small_scalar_dot(values, [int(x) for x in small]), O.small_scalar_accumulate(values, small))
