@@ -68,6 +68,7 @@ struct jolt_ctx {
     bool msm_fx_attr_set = false;
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)
+    int msm_fx_reduce_div = 24;   // buckets per thread of the fixed-base bucket reduction (JOLT_FX_REDUCE_DIV)
     bool msm_fx_lform = true;     // JOLT_FX_LFORM=0: window tables in standard form, word-form XYZZ accumulators (A/B of fq_limb.hip.h)
     bool msm_fx_stage = true;     // JOLT_FX_STAGE=0: segment sort scatters straight to global memory (A/B of the LDS-staged segment)
     bool msm_fixed = true;        // JOLT_MSM_FIXED=0: ignore window-precomputed bases (A/B of msm_fixed.hip)

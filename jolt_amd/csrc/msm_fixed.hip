@@ -644,7 +644,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     // reduction: sum_b b * B_b over buckets 1..B with up to 262144 threads, G buckets each (a serial chain of 2G additions per thread, then one
     // multiplication by the range's offset; B / 96 threads measured faster at 2^26 terms (99.2 -> 96.7 ms) but slower on the short prefix
     // MSMs (2^22: 9.3 -> 10.5 ms): the chains are latency bound at one wavefront per SIMD)
-    const uint32_t threads = (uint32_t)std::min<size_t>(B, 262144);
+    const uint32_t threads = (uint32_t)std::min<size_t>(std::max<size_t>(B / (size_t)ctx->msm_fx_reduce_div, std::min<size_t>(B, 4096)), 262144);
     const uint32_t nb = (threads + kBlock - 1) / kBlock;
     const uint32_t G = (B + nb * kBlock - 1) / (nb * kBlock);
     // a bucket holding more than max(kLaneCap, 4x the average) points is summed per 1024-point segment by whole wavefronts: the
