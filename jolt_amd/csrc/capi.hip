@@ -61,6 +61,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* pe = std::getenv("JOLT_POOL")) ctx->pool_enabled = std::atoi(pe) != 0;
     if (const char* la = std::getenv("JOLT_MSM_LANES")) ctx->msm_lanes = std::max(1, std::min(4, std::atoi(la)));
     if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
+    if (const char* sg = std::getenv("JOLT_MSM_STAGGER")) ctx->msm_stagger = std::atoi(sg) != 0;
     if (const char* rd = std::getenv("JOLT_FX_REDUCE_DIV")) ctx->msm_fx_reduce_div = std::max(1, std::atoi(rd));
     if (const char* fl = std::getenv("JOLT_FX_LFORM")) ctx->msm_fx_lform = std::atoi(fl) != 0;
     if (const char* fs = std::getenv("JOLT_FX_STAGE")) ctx->msm_fx_stage = std::atoi(fs) != 0;
@@ -72,6 +73,8 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
         ctx->own_stream = true;
     }
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { delete ctx; return JOLT_ERR_HIP; }
+    for (hipEvent_t& e : ctx->ev_sort)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return JOLT_ERR_HIP; }
     int32_t s = jolt_internal_ensure_scratch(ctx, 4096 * 8, 1024);
     if (s == JOLT_OK) {
         ctx->round_cap = 1024;
@@ -121,6 +124,7 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    for (hipEvent_t e : ctx->ev_sort) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return JOLT_OK;

@@ -54,6 +54,13 @@ struct jolt_ctx {
     size_t msm_ws_cap[4] = {0, 0, 0, 0};
     void* msm_host[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // Sort token (JOLT_MSM_STAGGER): the partition / sort phase of a fixed-base MSM is HBM-bound and its bucket sums are bound by
+    // integer multiply-adds, so concurrent lanes only gain when one lane's sort runs under ANOTHER lane's bucket sums.  Equal MSMs
+    // enqueued together (the three witness MSMs of an opening) would run their sorts at the same time; each sort phase therefore
+    // waits for the previous MSM's sort phase (whatever its lane) and records the next event of this ring when it is done.
+    hipEvent_t ev_sort[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned sort_seq = 0;        // sort phases recorded so far
+    int sort_last_lane = -1;      // lane of the last recorded sort phase (no wait needed on the same stream)
     // persistent round engine for the late rounds of a batch (engine_kernel.hip.h); owned by capi.hip
     struct jolt_engine* engine = nullptr;
     // uniform split-eq members switch from (product, pair) work items to one item per pair at this many pairs
@@ -68,6 +75,7 @@ struct jolt_ctx {
     bool msm_fx_attr_set = false;
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)
+    bool msm_stagger = false;     // JOLT_MSM_STAGGER=1: serialise the sort phases of concurrent fixed-base MSMs (see ev_sort)
     int msm_fx_reduce_div = 24;   // buckets per thread of the fixed-base bucket reduction (JOLT_FX_REDUCE_DIV)
     bool msm_fx_lform = true;     // JOLT_FX_LFORM=0: window tables in standard form, word-form XYZZ accumulators (A/B of fq_limb.hip.h)
     bool msm_fx_stage = true;     // JOLT_FX_STAGE=0: segment sort scatters straight to global memory (A/B of the LDS-staged segment)

@@ -705,6 +705,10 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         }
         ctx->msm_fx_attr_set = true;
     }
+    // sort token (ctx.hpp ev_sort): this MSM's HBM-bound phase starts when the previous MSM's has finished, so that it runs under
+    // that MSM's bucket sums instead of beside its sort
+    if (ctx->msm_stagger && ctx->sort_seq > 0 && ctx->sort_last_lane != lane)
+        JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_sort[(ctx->sort_seq - 1) % 8], 0));
     JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, st));
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
@@ -752,6 +756,11 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, st, (const uint32_t*)class_hist, class_cursor);
     hipLaunchKernelGGL(k_fx_order, dim3((unsigned)((n_buckets + kBlock * kOrderPer - 1) / (kBlock * kOrderPer))), dim3(kBlock), 0, st, (const uint32_t*)hist, (uint32_t)n_buckets,
                        heavy_threshold, class_cursor, order);
+    if (ctx->msm_stagger) {
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_sort[ctx->sort_seq % 8], st));
+        ctx->sort_seq++;
+        ctx->sort_last_lane = lane;
+    }
     LformConsts lc;
     {
         Fq thirty_two = Fq::zero();
