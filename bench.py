@@ -209,6 +209,10 @@ def main():
     from jolt_amd import ffi
     from jolt_amd.workload import DeviceWorkload
 
+    if world >= 4:
+        # two MSM lanes instead of four from 4 ranks on: at 8 ranks the opening's polynomials (2^29 coefficients, replicated) take
+        # ~110 GB and the rank's window tables 51 GB, and a lane's workspace is 16 GiB; the lanes buy ~1 %
+        os.environ.setdefault("JOLT_MSM_LANES", "2")
     ctx = ffi.Context(local_rank if sharded else 0)
     if args.roofline_only:
         print(json.dumps(bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)))
@@ -240,7 +244,10 @@ def main():
             onehot_g = [gather_blocks(a) for a in wl.committed_onehot]
             dense_g = [gather_blocks(d.view(np.int64) if d.dtype == np.uint64 else d).view(d.dtype) for d in wl.committed_dense]
             gp, gfn, guser = make_point_gather(wl.coll, world)
-            pcs_sharded = ShardedPcs(ctx, rank, world, args.scale, onehot_g, dense_g, gp, gfn, guser, fixed_base=(world <= 2))
+            # block-cyclic term assignment: every rank keeps window tables over ITS 2^(4 + scale) bases at any world size;
+            # JOLT_PCS_BLOCK_CYCLIC=0: contiguous term ranges against the full SRS (tables only for world <= 2), for an A/B
+            block_cyclic = os.environ.get("JOLT_PCS_BLOCK_CYCLIC", "1") != "0"
+            pcs_sharded = ShardedPcs(ctx, rank, world, args.scale, onehot_g, dense_g, gp, gfn, guser, fixed_base=(block_cyclic or world <= 2), block_cyclic=block_cyclic)
             pcs = "grid"
 
         def step(label=0):
@@ -301,7 +308,8 @@ def main():
         what = (f"BASELINE configs[2] sharded over {world} GPU(s): sha3-shaped synthetic trace of {world} x 2^{args.scale} cycles, sumcheck + HyperKZG end-to-end -- "
                 f"every step commits the {n_onehot + 2} committed columns on the 2^{pcs_sharded.grid_vars} commitment grid (each rank its block of cycles, one all-gather of "
                 f"partial points), proves the stage 2-6b cycle-domain sumchecks hypercube-sharded (11 relations, {wl.n_tables} T-sized tables per rank) and opens the "
-                f"joint polynomial (2^{pcs_sharded.grid_vars} coefficients) with ONE HyperKZG opening whose MSMs are split over the ranks by term range (polynomial "
+                f"joint polynomial (2^{pcs_sharded.grid_vars} coefficients) with ONE HyperKZG opening whose MSMs are split over the ranks "
+                f"{'block-cyclically (term i belongs to rank (i / 2^%d) mod %d; window tables over the rank own bases)' % (args.scale, world) if pcs_sharded.block else 'by term range'} (polynomial "
                 f"arithmetic replicated); the raw committed columns of the whole trace (52 B per cycle) are resident on every rank; the per-proof table builds of the "
                 f"N=1 step (~0.7 % of it) are not repeated per step here")
     elif pcs:
@@ -342,7 +350,9 @@ def main():
         out["config"]["communicator"] = getattr(wl, "communicator_note", type(wl.coll).__name__)
         out["config"]["tail_log"] = wl.tail_log
         if pcs_sharded is not None:
-            out["config"]["pcs"] = f"term-range sharded MSMs, partial points through {type(wl.coll).__name__}; fixed-base window tables {'on' if world <= 2 else 'off (memory)'}"
+            out["config"]["pcs"] = (f"block-cyclic sharded MSMs (block 2^{args.scale} terms) over per-rank compact bases with fixed-base window tables, partial points through {type(wl.coll).__name__}"
+                                    if pcs_sharded.block else
+                                    f"term-range sharded MSMs, partial points through {type(wl.coll).__name__}; fixed-base window tables {'on' if world <= 2 else 'off (memory)'}")
         out["config"]["ms_per_step_split"] = {k: round(v / args.steps * 1e3, 3) for k, v in _D.TIMINGS.items()}
     if rank == 0:
         out["roofline"] = bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)

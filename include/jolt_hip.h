@@ -624,6 +624,24 @@ int32_t jolt_grid_commit_onehot_range(jolt_ctx *ctx, const jolt_srs *srs, const 
 int32_t jolt_host_hyperkzg_open_sharded(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
                                         uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void *user,
                                         jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
+/* The BLOCK-CYCLIC term assignment, the one that keeps the fixed-base window tables at any world size: term i
+ * of every MSM belongs to rank (i / block) % world, and a rank's jolt_srs holds exactly the bases of its terms, compacted in index
+ * order (count_global / world points; upload them with jolt_srs_upload_g1, or generate them from a test secret here).  The terms a rank
+ * owns of any prefix [0, n) are then a prefix of its compact SRS, so jolt_srs_precompute_windows over the compact SRS serves every
+ * level of an opening.  With block = the rank's cycle count T, a rank's compact SRS is the commitment grid of ITS cycles (position
+ * k*T + j), so its share of a commitment is jolt_grid_commit_onehot / jolt_msm_g1_table_range over local columns.
+ * jolt_msm_g1_table_blocks: the rank's share of sum_{i<n} scalars[i]*SRS[i] (the shares of all ranks add up to the MSM);
+ * jolt_host_hyperkzg_open_sharded_blocks: jolt_host_hyperkzg_open_sharded with this assignment. */
+/* how many of the terms [0, n) rank owns = the length of its compact prefix (host only, no GPU) */
+int32_t jolt_host_owned_terms(size_t n, size_t block, int32_t rank, int32_t world, size_t *out);
+int32_t jolt_srs_setup_from_secret_blocks(jolt_ctx *ctx, const jolt_fr_t *beta, size_t count_global, const jolt_g1_t *g1, size_t block,
+                                          int32_t rank, int32_t world, jolt_srs **out);
+int32_t jolt_msm_g1_table_blocks(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *scalars, size_t n, size_t block, int32_t rank,
+                                 int32_t world, jolt_g1_t *out);
+int32_t jolt_host_hyperkzg_open_sharded_blocks(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point,
+                                               size_t ell, uint64_t transcript_label, int32_t rank, int32_t world, size_t block,
+                                               jolt_gather_fn gather, void *user, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v,
+                                               jolt_fr_t *challenges_out);
 
 #ifdef __cplusplus
 }

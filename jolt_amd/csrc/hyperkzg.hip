@@ -13,10 +13,10 @@
 #include "g1.hip.h"
 #include "host_mirror.hpp"
 #include "poly_kernels.hip.h"
+#include "srs.hpp"
 
 using namespace jolt;
 
-struct jolt_srs;
 int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out);
 int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
                                const size_t* base_offsets = nullptr);
@@ -280,21 +280,48 @@ extern "C" int32_t jolt_host_hyperkzg_commit(jolt_ctx* ctx, const jolt_srs* srs,
 // The MSMs of an opening over `world` ranks: rank g multiplies terms [n*g/world, n*(g+1)/world) of every MSM
 // against the same range of the bases, the partial points are all-gathered (96 bytes each) and added in rank order on every rank,
 // so all ranks absorb identical commitments and draw identical challenges.  world = 1: the plain opening.
+//
+// block > 0: the BLOCK-CYCLIC assignment instead -- term i belongs to rank (i / block) % world and `srs` is the rank's compact SRS
+// (its own terms' bases in index order, msm.hip), so the rank's terms of every level are a prefix of its SRS and the window tables
+// built over it (51 GB for 2^26 points, whatever the world size) serve all of them; the rank's scalars are gathered into one
+// compact buffer first (32 B read + written per owned term).
+size_t jolt_internal_owned_terms(size_t n, size_t block, size_t rank, size_t world);
+int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n, size_t block, size_t rank, size_t world, Fr* dst);
 static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::vector<const Fr*>& ptrs, const std::vector<size_t>& lens, int rank, int world,
-                                jolt_gather_fn gather, void* user, G1Jac* out) {
+                                size_t block, jolt_gather_fn gather, void* user, G1Jac* out) {
     const size_t count = ptrs.size();
     if (count == 0) return JOLT_OK;
     if (world <= 1) return jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), count, out);
     std::vector<const Fr*> p(count);
     std::vector<size_t> n(count), off(count);
-    for (size_t i = 0; i < count; ++i) {
-        const size_t lo = lens[i] * (size_t)rank / (size_t)world, hi = lens[i] * (size_t)(rank + 1) / (size_t)world;
-        p[i] = ptrs[i] + lo;
-        n[i] = hi - lo;
-        off[i] = lo;
-    }
     std::vector<G1Jac> partial(count), all((size_t)world * count);
-    JOLT_TRY(jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data(), off.data()));
+    if (block) {
+        size_t total = 0;
+        for (size_t i = 0; i < count; ++i) {
+            n[i] = jolt_internal_owned_terms(lens[i], block, (size_t)rank, (size_t)world);
+            if (n[i] > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+            off[i] = total;
+            total += n[i];
+        }
+        Fr* compact = nullptr;
+        JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(total, 1) * sizeof(Fr), (void**)&compact));
+        int32_t s = JOLT_OK;
+        for (size_t i = 0; i < count && s == JOLT_OK; ++i) {
+            s = jolt_internal_gather_owned_terms(ctx, ptrs[i], lens[i], block, (size_t)rank, (size_t)world, compact + off[i]);
+            p[i] = compact + off[i];
+        }
+        if (s == JOLT_OK) s = jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data());  // every MSM multiplies a prefix of the compact SRS
+        jolt_internal_dev_free(ctx, compact);
+        JOLT_TRY(s);
+    } else {
+        for (size_t i = 0; i < count; ++i) {
+            const size_t lo = lens[i] * (size_t)rank / (size_t)world, hi = lens[i] * (size_t)(rank + 1) / (size_t)world;
+            p[i] = ptrs[i] + lo;
+            n[i] = hi - lo;
+            off[i] = lo;
+        }
+        JOLT_TRY(jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data(), off.data()));
+    }
     static_assert(sizeof(G1Jac) == 3 * sizeof(jolt_fr_t), "a Jacobian point travels as three 32-byte words");
     ctx->d_round_count = 0;  // these words are not the round sums of the context's last batch round (jolt_comm_gather_round_sums' shortcut)
     JOLT_TRY(gather(user, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, reinterpret_cast<jolt_fr_t*>(all.data())));
@@ -308,7 +335,7 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
 
 // HyperKZGScheme::open (scheme.rs:122-158) + kzg_open_batch (kzg.rs:69-126)
 static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell, uint64_t transcript_label,
-                                  int rank, int world, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+                                  int rank, int world, size_t block, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
     if (!ctx || !srs || !evals || !point || !w || !v || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     if (ell == 0) return JOLT_ERR_EMPTY_POINT;
@@ -327,7 +354,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
         for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
-        s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, gather, user, coms.data());
+        s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, coms.data());
         if (s != JOLT_OK) { cleanup(); return s; }
     }
     for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
@@ -354,7 +381,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
             s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[t], &h[t]);
             if (s == JOLT_OK) { ptrs.push_back(h[t]->data()); lens.push_back(h[t]->len); }
         }
-        if (s == JOLT_OK) s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, gather, user, ws);
+        if (s == JOLT_OK) s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, ws);
         for (int t = 0; t < 3; ++t) if (h[t]) jolt_table_free(ctx, h[t]);
         if (s != JOLT_OK) { cleanup(b_poly); return s; }
     }
@@ -369,7 +396,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
 
 extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
                                            uint64_t transcript_label, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
-    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, nullptr, nullptr, com, w, v, challenges_out);
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out);
 }
 
 // The same opening with its MSMs sharded over `world` ranks by term range (every rank holds the polynomial and the SRS; `gather` is a
@@ -378,5 +405,13 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
 extern "C" int32_t jolt_host_hyperkzg_open_sharded(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
                                                    uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void* user, jolt_g1_t* com,
                                                    jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
-    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, rank, world, gather, user, com, w, v, challenges_out);
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, rank, world, 0, gather, user, com, w, v, challenges_out);
+}
+// The same with the block-cyclic term assignment: `srs` is the rank's COMPACT SRS (the bases of the terms i with (i / block) % world ==
+// rank, in index order -- jolt_srs_setup_from_secret_blocks or an upload of those points), optionally with window tables.
+extern "C" int32_t jolt_host_hyperkzg_open_sharded_blocks(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                                          uint64_t transcript_label, int32_t rank, int32_t world, size_t block, jolt_gather_fn gather, void* user,
+                                                          jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    if (block == 0) return JOLT_ERR_INVALID_ARG;
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, rank, world, block, gather, user, com, w, v, challenges_out);
 }

@@ -743,7 +743,8 @@ class ShardedPcs:
     test_gpu_distributed.py).  `gather(points)` all-gathers (count, 12) uint64 arrays; `gather_fn / gather_user` are the C-level
     jolt_gather_fn the opening calls."""
 
-    def __init__(self, ctx, rank, world, n_local, onehot_global, dense_global, gather_points, gather_fn, gather_user, seed=2026, log_k=4, fixed_base=False):
+    def __init__(self, ctx, rank, world, n_local, onehot_global, dense_global, gather_points, gather_fn, gather_user, seed=2026, log_k=4, fixed_base=False,
+                 block_cyclic=True):
         from .workload import G1_GENERATOR, rand_fr
         self.ctx, self.rank, self.world, self.n_local, self.log_k = ctx, rank, world, n_local, log_k
         self.T_local, self.T_global = 1 << n_local, world << n_local
@@ -753,9 +754,20 @@ class ShardedPcs:
         self.dense_ints = [ctx.ints(np.ascontiguousarray(d)) for d in dense_global]
         prng = np.random.default_rng(seed + 2)
         self.beta = rand_fr(1, prng)[0]
-        self.srs = ctx.srs_setup_from_secret(self.beta, 1 << self.grid_vars, G1_GENERATOR)
+        # Block-cyclic term assignment: term i of every MSM belongs to rank (i / T_local) % world.  The grid
+        # position of (address k, cycle g * T_local + j) is k * T_global + g * T_local + j, i.e. block k * world + g: a rank's
+        # terms are the grid of ITS cycles, its compact SRS is that grid's bases in the single-GPU layout k * T_local + j, and the
+        # window tables over it (one set of 2^(log_k + n_local) points whatever the world size) serve the commitments and every
+        # level of the opening.  block_cyclic=False: contiguous term ranges against the full SRS (tables only for world <= 2).
+        self.block = self.T_local if block_cyclic else 0
+        if self.block:
+            lo = rank * self.T_local
+            self.local_sources = [ctx.onehot(np.ascontiguousarray(np.asarray(idx)[:, lo: lo + self.T_local]), 1 << log_k) for idx in onehot_global]
+            self.srs = ctx.srs_setup_from_secret_blocks(self.beta, 1 << self.grid_vars, G1_GENERATOR, self.block, rank, world)
+        else:
+            self.srs = ctx.srs_setup_from_secret(self.beta, 1 << self.grid_vars, G1_GENERATOR)
         ctx.synchronize()
-        if fixed_base and self.grid_vars >= 12:
+        if fixed_base and log_k + n_local >= 12:
             ctx.srs_precompute_windows(self.srs)
         prng = np.random.default_rng(seed + 3)
         self.rlc_onehot = rand_fr(sum(s.n_polys for s in self.sources), prng)
@@ -766,16 +778,23 @@ class ShardedPcs:
         ctx, lo = self.ctx, self.rank * self.T_local
         self.dense_tables = [ctx.table_from_ints(d) for d in self.dense_ints]  # the global columns, promoted (needed by the joint polynomial too)
         parts = []
+        base_lo = 0 if self.block else lo  # compact SRS: the rank's cycles of address row 0 are its first T_local bases
         for t in self.dense_tables:
             out = ffi.g1_array(1)
-            ffi._ck(ffi.lib().jolt_msm_g1_table_range(ctx.h, self.srs.h, C.c_size_t(lo), t.h, C.c_size_t(lo), C.c_size_t(self.T_local), ffi._p(out)),
+            ffi._ck(ffi.lib().jolt_msm_g1_table_range(ctx.h, self.srs.h, C.c_size_t(base_lo), t.h, C.c_size_t(lo), C.c_size_t(self.T_local), ffi._p(out)),
                     "jolt_msm_g1_table_range", ctx)
             parts.append(out)
-        for s in self.sources:
-            out = ffi.g1_array(s.n_polys)
-            ffi._ck(ffi.lib().jolt_grid_commit_onehot_range(ctx.h, self.srs.h, s.h, C.c_size_t(lo), C.c_size_t(lo + self.T_local), ffi._p(out)),
-                    "jolt_grid_commit_onehot_range", ctx)
-            parts.append(out)
+        if self.block:
+            for s in self.local_sources:  # the single-GPU commitment of the rank's own cycles over its compact SRS
+                out = ffi.g1_array(s.n_polys)
+                ffi._ck(ffi.lib().jolt_grid_commit_onehot(ctx.h, self.srs.h, s.h, ffi._p(out)), "jolt_grid_commit_onehot", ctx)
+                parts.append(out)
+        else:
+            for s in self.sources:
+                out = ffi.g1_array(s.n_polys)
+                ffi._ck(ffi.lib().jolt_grid_commit_onehot_range(ctx.h, self.srs.h, s.h, C.c_size_t(lo), C.c_size_t(lo + self.T_local), ffi._p(out)),
+                        "jolt_grid_commit_onehot_range", ctx)
+                parts.append(out)
         local = np.concatenate(parts)
         allp = self.gather_points(local)  # (world, count, 12)
         total = allp[0].copy()
@@ -791,9 +810,14 @@ class ShardedPcs:
         p = ffi.fr(self.open_point).reshape(-1, 4)
         ell = p.shape[0]
         com, w, v, ch = ffi.g1_array(max(ell - 1, 1)), ffi.g1_array(3), ffi.fr_array(3 * ell), ffi.fr_array(3)
-        ffi._ck(ffi.lib().jolt_host_hyperkzg_open_sharded(ctx.h, self.srs.h, joint.h, ffi._p(p), C.c_size_t(ell), C.c_uint64(label), C.c_int32(self.rank),
-                                                           C.c_int32(self.world), self.gather_fn, self.gather_user, ffi._p(com), ffi._p(w), ffi._p(v), ffi._p(ch)),
-                "jolt_host_hyperkzg_open_sharded", ctx)
+        if self.block:
+            ffi._ck(ffi.lib().jolt_host_hyperkzg_open_sharded_blocks(ctx.h, self.srs.h, joint.h, ffi._p(p), C.c_size_t(ell), C.c_uint64(label), C.c_int32(self.rank),
+                                                                      C.c_int32(self.world), C.c_size_t(self.block), self.gather_fn, self.gather_user, ffi._p(com),
+                                                                      ffi._p(w), ffi._p(v), ffi._p(ch)), "jolt_host_hyperkzg_open_sharded_blocks", ctx)
+        else:
+            ffi._ck(ffi.lib().jolt_host_hyperkzg_open_sharded(ctx.h, self.srs.h, joint.h, ffi._p(p), C.c_size_t(ell), C.c_uint64(label), C.c_int32(self.rank),
+                                                               C.c_int32(self.world), self.gather_fn, self.gather_user, ffi._p(com), ffi._p(w), ffi._p(v), ffi._p(ch)),
+                    "jolt_host_hyperkzg_open_sharded", ctx)
         joint.free()
         for t in self.dense_tables:
             t.free()

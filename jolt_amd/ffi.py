@@ -520,6 +520,29 @@ def _srs_setup_from_secret(self, beta, count, g1):
     return Srs(self, h)
 
 
+def host_owned_terms(n, block, rank, world):
+    """Terms of the prefix [0, n) that `rank` owns under the block-cyclic assignment (host only)."""
+    out = C.c_size_t()
+    _ck(lib().jolt_host_owned_terms(C.c_size_t(n), C.c_size_t(block), C.c_int32(rank), C.c_int32(world), C.byref(out)), "jolt_host_owned_terms")
+    return out.value
+
+
+def _srs_setup_from_secret_blocks(self, beta, count_global, g1, block, rank, world):
+    """One rank's compact share of the powers under the block-cyclic term assignment (term i belongs to rank (i / block) % world)."""
+    h = C.c_void_p()
+    _ck(lib().jolt_srs_setup_from_secret_blocks(self.h, _p(fr(beta)), C.c_size_t(count_global), _p(np.ascontiguousarray(g1, dtype=np.uint64)), C.c_size_t(block),
+                                                C.c_int32(rank), C.c_int32(world), C.byref(h)), "jolt_srs_setup_from_secret_blocks", self)
+    return Srs(self, h)
+
+
+def _msm_blocks(self, srs, table, n, block, rank, world):
+    """The rank's share of sum_{i<n} table[i] * SRS[i] under the block-cyclic assignment (srs = the rank's compact SRS)."""
+    out = g1_array(1)
+    _ck(lib().jolt_msm_g1_table_blocks(self.h, srs.h, table.h, C.c_size_t(n), C.c_size_t(block), C.c_int32(rank), C.c_int32(world), _p(out)),
+        "jolt_msm_g1_table_blocks", self)
+    return out[0]
+
+
 def _msm(self, srs, scalars, n=None):
     """JoltGroup::msm(bases = srs[..n], scalars); scalars = numpy (n,4) host array or a device Table."""
     out = g1_array(1)
@@ -586,6 +609,8 @@ Context.srs_precompute_windows = _srs_precompute_windows
 Context.srs_upload = _srs_upload
 Context.srs_setup_from_secret = _srs_setup_from_secret
 Context.msm = _msm
+Context.srs_setup_from_secret_blocks = _srs_setup_from_secret_blocks
+Context.msm_blocks = _msm_blocks
 Context.hyperkzg_fold = _hyperkzg_fold
 Context.hyperkzg_eval3 = _hyperkzg_eval3
 Context.hyperkzg_rlc = _hyperkzg_rlc

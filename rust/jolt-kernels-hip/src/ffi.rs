@@ -293,4 +293,8 @@ extern "C" {
     pub fn jolt_msm_g1_table_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, base_offset: usize, scalars: *const jolt_table, scalar_offset: usize, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_commit_onehot_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, cycle_lo: usize, cycle_hi: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open_sharded(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_owned_terms(n: usize, block: usize, rank: i32, world: i32, out: *mut usize) -> i32;
+    pub fn jolt_srs_setup_from_secret_blocks(ctx: *mut jolt_ctx, beta: *const jolt_fr_t, count_global: usize, g1: *const jolt_g1_t, block: usize, rank: i32, world: i32, out: *mut *mut jolt_srs) -> i32;
+    pub fn jolt_msm_g1_table_blocks(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, block: usize, rank: i32, world: i32, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_host_hyperkzg_open_sharded_blocks(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, block: usize, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
 }

@@ -267,3 +267,21 @@ def test_small_scalar_accumulator_built_for_the_host():
     values = rand_fr(200, 95)
     small = rng.integers(-2**48, 2**48, size=200, dtype=np.int64)
     assert np.array_equal(ffi.host_small_scalar_dot(values, [int(x) for x in small]), O.small_scalar_accumulate(values, small))
+
+
+def test_block_cyclic_ownership_partitions_every_prefix():
+    """Block-cyclic term assignment of the sharded PCS legs (term i belongs to rank (i / block) % world): the owned-term count of
+    every prefix matches a direct count, the ranks' counts add up to the prefix, and the rank's terms of a prefix are a PREFIX of
+    its compact index order (what lets one set of per-rank window tables serve every level of an opening)."""
+    from jolt_amd import ffi
+    for world, block in [(1, 4), (2, 8), (4, 4), (8, 2), (3, 5)]:
+        total = block * world * 3
+        owner = (np.arange(total) // block) % world
+        for n in list(range(0, total + 1, 3)) + [total]:
+            counts = [ffi.host_owned_terms(n, block, g, world) for g in range(world)]
+            assert counts == [int((owner[:n] == g).sum()) for g in range(world)], (world, block, n)
+            assert sum(counts) == n
+        with pytest.raises(ffi.JoltError):
+            ffi.host_owned_terms(5, 0, 0, world)
+        with pytest.raises(ffi.JoltError):
+            ffi.host_owned_terms(5, block, world, world)

@@ -156,7 +156,7 @@ def test_sharded_device_msm_two_ranks():
             assert open(os.path.join(tmp, f"msm{r}.txt")).read() == "ok", f"rank {r}"
 
 
-def _pcs_worker(rank, world, port, tmpdir, n_local):
+def _pcs_worker(rank, world, port, tmpdir, n_local, cyclic):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
     from util import init_gloo
@@ -172,7 +172,7 @@ def _pcs_worker(rank, world, port, tmpdir, n_local):
     ins = rng.integers(0, 16, size=(5, T), dtype=np.uint8)
     dense = [rng.integers(0, 2**64, size=T, dtype=np.uint64), rng.integers(-2**62, 2**62, size=T, dtype=np.int64)]
     gp, gfn, guser = D.make_point_gather(coll, world)
-    pcs = D.ShardedPcs(ctx, rank, world, n_local, [ram, ins], dense, gp, gfn, guser, seed=5, fixed_base=(n_local >= 6))
+    pcs = D.ShardedPcs(ctx, rank, world, n_local, [ram, ins], dense, gp, gfn, guser, seed=5, fixed_base=(n_local >= 6), block_cyclic=cyclic)
     out = pcs.step(label=9)
     again = pcs.step(label=9)
     assert np.array_equal(out["open"]["v"], again["open"]["v"])
@@ -183,16 +183,18 @@ def _pcs_worker(rank, world, port, tmpdir, n_local):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_local", [(2, 4), (4, 4), (2, 7), (2, 11), (4, 9)])
-def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local):
-    """Term-range sharded PCS legs (ShardedPcs: partial commitments per block of cycles, every MSM of the HyperKZG opening split over
-    the ranks, partial points all-gathered): every rank returns the commitments and the opening the ORACLE computes in one process
-    over the global trace -- same transcript bytes, same points."""
+@pytest.mark.parametrize("world,n_local,cyclic", [(2, 4, True), (4, 4, True), (2, 7, True), (2, 11, True), (4, 9, True), (8, 8, True),
+                                                  (2, 4, False), (4, 4, False), (2, 11, False)])
+def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local, cyclic):
+    """Sharded PCS legs (ShardedPcs: partial commitments per block of cycles, every MSM of the HyperKZG opening split over the ranks,
+    partial points all-gathered): every rank returns the commitments and the opening the ORACLE computes in one process over the
+    global trace -- same transcript bytes, same points.  cyclic: the block-cyclic term assignment over per-rank compact bases (the
+    default; window tables over the rank's own 2^(4 + n_local) bases from n_local = 8 on); otherwise contiguous term ranges."""
     import torch.multiprocessing as mp
     import oracle_lib as O
     port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_pcs_worker, args=(world, port, tmp, n_local), nprocs=world, join=True)
+        mp.spawn(_pcs_worker, args=(world, port, tmp, n_local, cyclic), nprocs=world, join=True)
         got = [np.load(os.path.join(tmp, f"pcs{r}.npz")) for r in range(world)]
     g0 = got[0]
     T, K = world << n_local, 16

@@ -258,3 +258,33 @@ def test_fixed_base_msm_at_2_20_is_the_kzg_commitment(ctx, window_bits):
     u64 = O.fr_from_u64(np.random.default_rng(632).integers(0, 2**64, size=n, dtype=np.uint64))
     assert same_point(ctx.msm(srs, ctx.upload(u64)), O.g1_scalar_mul(g, O.kzg_eval_univariate(u64, beta)))
     srs.free()
+
+
+@pytest.mark.parametrize("world,block,n_global", [(2, 64, 1024), (4, 32, 1024), (8, 16, 2048), (2, 2048, 16384)])
+def test_block_cyclic_shares_add_up_to_the_msm(ctx, world, block, n_global):
+    """The block-cyclic term assignment of the sharded PCS legs: rank g's compact SRS holds the powers beta^i with
+    (i / block) % world == g in index order, and the ranks' shares of any prefix MSM -- full blocks, a ragged last block, less than
+    one block -- add up to the MSM over the full SRS.  (2, 2048, 16384): the compact SRS is long enough for window tables.)"""
+    beta = rand_fr(1, 91)[0]
+    full = ctx.srs_setup_from_secret(beta, n_global, O.g1_generator())
+    full_pts = full.download()
+    shares = [ctx.srs_setup_from_secret_blocks(beta, n_global, O.g1_generator(), block, g, world) for g in range(world)]
+    for g, s in enumerate(shares):
+        assert len(s) == n_global // world
+        pts = s.download()
+        own = np.concatenate([np.arange(b * block, (b + 1) * block) for b in range(n_global // block) if b % world == g])
+        assert all(same_point(pts[j], full_pts[i]) for j, i in list(enumerate(own))[:: max(1, len(own) // 64)])
+        if len(s) >= 4096:
+            ctx.srs_precompute_windows(s, min_terms=1024)
+    scalars = rand_fr(n_global, 92)
+    scalars[5] = 0
+    scalars[7] = O.fr_array(1)[0]
+    table = ctx.upload(scalars)
+    for n in (n_global, n_global - 1, 3 * block + 17, block - 5, 1, 0):
+        want = ctx.msm(full, table, n) if n else O.g1_identity()
+        acc = O.g1_identity()
+        for g, s in enumerate(shares):
+            acc = ffi.host_g1_add(acc, ctx.msm_blocks(s, table, n, block, g, world))
+        assert same_point(acc, want), n
+    with pytest.raises(ffi.JoltError):
+        ctx.srs_setup_from_secret_blocks(beta, n_global + 1, O.g1_generator(), block, 0, world)
