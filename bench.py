@@ -209,9 +209,9 @@ def main():
     from jolt_amd import ffi
     from jolt_amd.workload import DeviceWorkload
 
-    if world >= 4:
-        # two MSM lanes instead of four from 4 ranks on: at 8 ranks the opening's polynomials (2^29 coefficients, replicated) take
-        # ~110 GB and the rank's window tables 51 GB, and a lane's workspace is 16 GiB; the lanes buy ~1 %
+    if world >= 4 and os.environ.get("JOLT_PCS_SUBTREE", "1") == "0":
+        # replicated polynomial arithmetic (A/B): two MSM lanes instead of four from 4 ranks on -- at 8 ranks the opening's polynomials
+        # (2^29 coefficients on every rank) take ~110 GB and the rank's window tables 51 GB, and a lane's workspace is 16 GiB
         os.environ.setdefault("JOLT_MSM_LANES", "2")
     ctx = ffi.Context(local_rank if sharded else 0)
     if args.roofline_only:
@@ -247,7 +247,10 @@ def main():
             # block-cyclic term assignment: every rank keeps window tables over ITS 2^(4 + scale) bases at any world size;
             # JOLT_PCS_BLOCK_CYCLIC=0: contiguous term ranges against the full SRS (tables only for world <= 2), for an A/B
             block_cyclic = os.environ.get("JOLT_PCS_BLOCK_CYCLIC", "1") != "0"
-            pcs_sharded = ShardedPcs(ctx, rank, world, args.scale, onehot_g, dense_g, gp, gfn, guser, fixed_base=(block_cyclic or world <= 2), block_cyclic=block_cyclic)
+            # JOLT_PCS_SUBTREE=0: the opening's polynomial arithmetic replicated on every rank (only its MSMs sharded) instead of the subtree-sharded opening
+            subtree = block_cyclic and world >= 2 and world & (world - 1) == 0 and os.environ.get("JOLT_PCS_SUBTREE", "1") != "0"
+            pcs_sharded = ShardedPcs(ctx, rank, world, args.scale, onehot_g, dense_g, gp, gfn, guser, fixed_base=(block_cyclic or world <= 2), block_cyclic=block_cyclic,
+                                     subtree=subtree)
             pcs = "grid"
 
         def step(label=0):
@@ -308,9 +311,11 @@ def main():
         what = (f"BASELINE configs[2] sharded over {world} GPU(s): sha3-shaped synthetic trace of {world} x 2^{args.scale} cycles, sumcheck + HyperKZG end-to-end -- "
                 f"every step commits the {n_onehot + 2} committed columns on the 2^{pcs_sharded.grid_vars} commitment grid (each rank its block of cycles, one all-gather of "
                 f"partial points), proves the stage 2-6b cycle-domain sumchecks hypercube-sharded (11 relations, {wl.n_tables} T-sized tables per rank) and opens the "
-                f"joint polynomial (2^{pcs_sharded.grid_vars} coefficients) with ONE HyperKZG opening whose MSMs are split over the ranks "
-                f"{'block-cyclically (term i belongs to rank (i / 2^%d) mod %d; window tables over the rank own bases)' % (args.scale, world) if pcs_sharded.block else 'by term range'} (polynomial "
-                f"arithmetic replicated); the raw committed columns of the whole trace (52 B per cycle) are resident on every rank; the per-proof table builds of the "
+                f"joint polynomial (2^{pcs_sharded.grid_vars} coefficients) with ONE HyperKZG opening "
+                + (f"sharded over the ranks by index subtree (every rank builds, folds, combines, divides and commits 1/{world} of the polynomial against its own "
+                   f"bases and window tables; O(ell) field elements and points exchanged)" if pcs_sharded.subtree else
+                   f"whose MSMs are split over the ranks {'block-cyclically (term i belongs to rank (i / 2^%d) mod %d; window tables over the rank own bases)' % (args.scale, world) if pcs_sharded.block else 'by term range'} (polynomial arithmetic replicated)")
+                + f"; the raw committed columns of the whole trace (52 B per cycle) are resident on every rank; the per-proof table builds of the "
                 f"N=1 step (~0.7 % of it) are not repeated per step here")
     elif pcs:
         what = (f"BASELINE configs[2]: sha3-shaped synthetic trace, T=2^{args.scale} per GPU, sumcheck + HyperKZG end-to-end -- every step rebuilds the "
@@ -350,7 +355,9 @@ def main():
         out["config"]["communicator"] = getattr(wl, "communicator_note", type(wl.coll).__name__)
         out["config"]["tail_log"] = wl.tail_log
         if pcs_sharded is not None:
-            out["config"]["pcs"] = (f"block-cyclic sharded MSMs (block 2^{args.scale} terms) over per-rank compact bases with fixed-base window tables, partial points through {type(wl.coll).__name__}"
+            out["config"]["pcs"] = (f"commitments: block-cyclic shares over per-rank compact bases; opening: polynomial sharded by index subtree, per-rank window tables, partial points and O(ell) field elements through {type(wl.coll).__name__}"
+                                    if pcs_sharded.subtree else
+                                    f"block-cyclic sharded MSMs (block 2^{args.scale} terms) over per-rank compact bases with fixed-base window tables, partial points through {type(wl.coll).__name__}"
                                     if pcs_sharded.block else
                                     f"term-range sharded MSMs, partial points through {type(wl.coll).__name__}; fixed-base window tables {'on' if world <= 2 else 'off (memory)'}")
         out["config"]["ms_per_step_split"] = {k: round(v / args.steps * 1e3, 3) for k, v in _D.TIMINGS.items()}

@@ -642,6 +642,27 @@ int32_t jolt_host_hyperkzg_open_sharded_blocks(jolt_ctx *ctx, const jolt_srs *sr
                                                size_t ell, uint64_t transcript_label, int32_t rank, int32_t world, size_t block,
                                                jolt_gather_fn gather, void *user, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v,
                                                jolt_fr_t *challenges_out);
+/* The SUBTREE assignment (world = 2^gamma ranks): the gamma bits below the leading one of an index name its owner
+ * (indices below `world`: owner = the index, slot 0; otherwise slot = the index with those bits removed).  Like the block-cyclic one it
+ * keeps every prefix of the indices a prefix of every rank's compact arrays -- one compact SRS and one set of window tables per rank
+ * -- and it is also closed under LowToHigh folding (slots 2c, 2c+1 of a level fold into slot c of the next), so the POLYNOMIAL of an
+ * opening is sharded too: jolt_host_hyperkzg_open_subtree takes the rank's compact array of the evaluations (2^ell / world
+ * coefficients: jolt_grid_joint_polynomial_subtree builds it for the commitment grid; jolt_host_subtree_term_index gives the index
+ * of a slot for any other source) and the rank's compact SRS, runs folds / RLC / Horner passes / quotient scans / MSMs on 1 / world
+ * of the data, exchanges O(ell) field elements and O(ell) points through `gather`, and returns on every rank the proof
+ * jolt_host_hyperkzg_open returns for the whole polynomial.  tests/subtree_model.py is the executable specification. */
+int32_t jolt_host_subtree_owned_terms(size_t n, int32_t rank, int32_t world, size_t *out);
+int32_t jolt_host_subtree_term_index(size_t slot, int32_t rank, int32_t world, size_t *out);
+int32_t jolt_srs_setup_from_secret_subtree(jolt_ctx *ctx, const jolt_fr_t *beta, size_t count_global, const jolt_g1_t *g1, int32_t rank,
+                                           int32_t world, jolt_srs **out);
+int32_t jolt_msm_g1_table_subtree(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *scalars, size_t n, int32_t rank, int32_t world,
+                                  jolt_g1_t *out);
+int32_t jolt_grid_joint_polynomial_subtree(jolt_ctx *ctx, const jolt_onehot *const *sources, size_t n_sources,
+                                           const jolt_fr_t *onehot_scalars, jolt_table *const *dense, size_t n_dense,
+                                           const jolt_fr_t *dense_scalars, uint32_t log_k, int32_t rank, int32_t world, jolt_table **out);
+int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
+                                        uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void *user,
+                                        jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
 
 #ifdef __cplusplus
 }

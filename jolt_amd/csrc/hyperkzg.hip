@@ -14,6 +14,7 @@
 #include "host_mirror.hpp"
 #include "poly_kernels.hip.h"
 #include "srs.hpp"
+#include "term_map.hip.h"
 
 using namespace jolt;
 
@@ -42,32 +43,59 @@ static __global__ __launch_bounds__(kBlock) void k_power_table3(Fr3 base, Fr* __
         st_fr(table + t * kBlock + threadIdx.x, w);
     }
 }
+// u^e by square-and-multiply
+__device__ __forceinline__ Fr fr_pow_u64(Fr b, uint64_t e) {
+    Fr w = Fr::one();
+    for (; e; e >>= 1) {
+        if (e & 1) w = mul(w, b);
+        b = sqr(b);
+    }
+    return w;
+}
 // partials[block*3 + t] = sum over this block's coefficients c[i] * u_t^i
+// SUBTREE: c is a rank's COMPACT array (term_map.hip.h, kSubtree) and the exponent of slot i is term_global(map, i).  Chunks of 16 slots
+// from slot 16 on and workgroups of 4096 slots from slot 4096 on lie inside one segment [2^L, 2^(L+1)) of the compact array, where the
+// index is affine in the slot: only the workgroup weight changes (u^index(4096 b) instead of (u^4096)^b); workgroup 0 weighs its chunks
+// one by one and its first chunk slot by slot.
+template <bool SUBTREE>
 static __global__ __launch_bounds__(kBlock) void k_horner3(const Fr* __restrict__ c, size_t n, Fr3 u, const Fr* __restrict__ chunk_weights /* (u^16)^tid */,
-                                                           Fr3 u_block /* u^4096 */, Fr* __restrict__ partials) {
+                                                           Fr3 u_block /* u^4096 */, Fr* __restrict__ partials, TermMap map) {
     __shared__ Fr block_weight[3];
     if (threadIdx.x < 3) {  // (u^4096)^blockIdx, once per workgroup
-        Fr w = Fr::one(), b = u_block.v[threadIdx.x];
-        for (unsigned e = blockIdx.x; e; e >>= 1) {
-            if (e & 1) w = mul(w, b);
-            b = sqr(b);
-        }
-        block_weight[threadIdx.x] = w;
+        if (SUBTREE) block_weight[threadIdx.x] = blockIdx.x ? fr_pow_u64(u.v[threadIdx.x], term_global(map, (size_t)blockIdx.x * kBlock * kHornerChunk)) : Fr::one();
+        else block_weight[threadIdx.x] = fr_pow_u64(u_block.v[threadIdx.x], blockIdx.x);
     }
     size_t base = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kHornerChunk;
     Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
     if (base < n) {
         size_t end = base + kHornerChunk < n ? base + kHornerChunk : n;
-        for (size_t i = end; i-- > base;) {
-            Fr ci = ld_fr(c + i);
+        if (SUBTREE && base == 0) {  // slots 0 .. 15: five segments and the crown slot, weighed one by one
+            for (size_t i = base; i < end; ++i) {
+                Fr ci = ld_fr(c + i);
+                const uint64_t e = term_global(map, i);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = add(mul(acc[t], u.v[t]), ci);
+                for (int t = 0; t < 3; ++t) acc[t] = add(acc[t], mul(ci, fr_pow_u64(u.v[t], e)));
+            }
+        } else {
+            for (size_t i = end; i-- > base;) {
+                Fr ci = ld_fr(c + i);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = add(mul(acc[t], u.v[t]), ci);
+            }
         }
     }
     __syncthreads();
     if (base < n) {
+        if (SUBTREE && blockIdx.x == 0) {
+            if (base) {
+                const uint64_t e = term_global(map, base);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = mul(mul(acc[t], ld_fr(chunk_weights + t * kBlock + threadIdx.x)), block_weight[t]);
+                for (int t = 0; t < 3; ++t) acc[t] = mul(acc[t], fr_pow_u64(u.v[t], e));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = mul(mul(acc[t], ld_fr(chunk_weights + t * kBlock + threadIdx.x)), block_weight[t]);
+        }
     }
     block_reduce_store<3>(acc, partials);
 }
@@ -104,13 +132,15 @@ static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __rest
     for (size_t k = hi; k-- > lo;) acc = add(mul(acc, mu), ld_fr(a + k));
     st_fr(heads + c, acc);
 }
-// s[k] = a[k] + mu*s[k+1] inside chunk c, starting from the true carry-in S[c+1]; writes s[k] to out[k - shift] (k >= shift)
+// s[k] = a[k] + mu*s[k+1] inside chunk c, starting from the true carry-in S[c+1] (the last chunk: `carry`, the value entering the
+// array from above -- zero for a whole polynomial, the suffix evaluation of the segments above for one segment of a sharded one);
+// writes s[k] to out[k - shift] (k >= shift)
 static __global__ __launch_bounds__(kBlock) void k_suffix_apply(const Fr* __restrict__ a, size_t m, Fr mu, const Fr* __restrict__ S, size_t nchunks,
-                                                                Fr* __restrict__ out, size_t shift, size_t kScanChunk) {
+                                                                Fr* __restrict__ out, size_t shift, size_t kScanChunk, Fr carry) {
     size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (c >= nchunks) return;
     size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
-    Fr acc = (S != nullptr && c + 1 < nchunks) ? ld_fr(S + c + 1) : Fr::zero();
+    Fr acc = (S != nullptr && c + 1 < nchunks) ? ld_fr(S + c + 1) : carry;
     for (size_t k = hi; k-- > lo;) {
         acc = add(mul(acc, mu), ld_fr(a + k));
         if (k >= shift) st_fr(out + (k - shift), acc);
@@ -118,13 +148,16 @@ static __global__ __launch_bounds__(kBlock) void k_suffix_apply(const Fr* __rest
 }
 
 // s = suffix Horner of a (length m) with multiplier mu, written to out[k - shift]
-int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift) {
+int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift, const Fr& carry = Fr::zero()) {
+    // a non-zero carry enters the chunk-level recurrence with the weight mu^chunk: the last chunk must be full (segments of a sharded
+    // polynomial are powers of two long)
+    if (!(carry == Fr::zero()) && (m & (m - 1)) != 0) return JOLT_ERR_UNSUPPORTED;
     const int chunk_log = scan_chunk_log();
     const size_t kScanChunk = (size_t)1 << chunk_log;
     size_t nchunks = (m + kScanChunk - 1) / kScanChunk;
     unsigned grid = (unsigned)((nchunks + kBlock - 1) / kBlock);
     if (nchunks <= 1) {
-        hipLaunchKernelGGL(k_suffix_apply, dim3(1), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)nullptr, (size_t)1, out, shift, kScanChunk);
+        hipLaunchKernelGGL(k_suffix_apply, dim3(1), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)nullptr, (size_t)1, out, shift, kScanChunk, carry);
         JOLT_HIP_TRY(ctx, hipGetLastError());
         return JOLT_OK;
     }
@@ -134,9 +167,9 @@ int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* ou
     hipLaunchKernelGGL(k_suffix_heads, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, heads, nchunks, kScanChunk);
     Fr mu_c = mu;
     for (int i = 0; i < chunk_log; ++i) mu_c = sqr(mu_c);  // mu^chunk
-    int32_t s = suffix_horner(ctx, heads, nchunks, mu_c, S, 0);
+    int32_t s = suffix_horner(ctx, heads, nchunks, mu_c, S, 0, carry);  // the carry enters the chunk-level recurrence at the same place
     if (s == JOLT_OK) {
-        hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift, kScanChunk);
+        hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift, kScanChunk, carry);
         if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
     }
     jolt_internal_dev_free(ctx, heads);  // pool blocks: reused in stream order, no synchronisation
@@ -197,7 +230,7 @@ extern "C" int32_t jolt_hyperkzg_eval3(jolt_ctx* ctx, jolt_table* const* levels,
         size_t per_block = (size_t)kBlock * kHornerChunk;
         int grid = (int)std::max<size_t>(1, (t->len + per_block - 1) / per_block);
         JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 3, 3 * ell + 8));
-        hipLaunchKernelGGL(k_horner3, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, (const Fr*)chunk_weights, u4096, ctx->d_partials);
+        hipLaunchKernelGGL(k_horner3<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, (const Fr*)chunk_weights, u4096, ctx->d_partials, TermMap{});
         JOLT_HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * j);
         JOLT_HIP_TRY(ctx, hipGetLastError());
@@ -285,8 +318,7 @@ extern "C" int32_t jolt_host_hyperkzg_commit(jolt_ctx* ctx, const jolt_srs* srs,
 // (its own terms' bases in index order, msm.hip), so the rank's terms of every level are a prefix of its SRS and the window tables
 // built over it (51 GB for 2^26 points, whatever the world size) serve all of them; the rank's scalars are gathered into one
 // compact buffer first (32 B read + written per owned term).
-size_t jolt_internal_owned_terms(size_t n, size_t block, size_t rank, size_t world);
-int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n, size_t block, size_t rank, size_t world, Fr* dst);
+int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n, const TermMap& map, Fr* dst);
 static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::vector<const Fr*>& ptrs, const std::vector<size_t>& lens, int rank, int world,
                                 size_t block, jolt_gather_fn gather, void* user, G1Jac* out) {
     const size_t count = ptrs.size();
@@ -296,9 +328,14 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
     std::vector<size_t> n(count), off(count);
     std::vector<G1Jac> partial(count), all((size_t)world * count);
     if (block) {
+        TermMap map;
+        map.kind = kBlockCyclic;
+        map.block = block;
+        map.rank = (size_t)rank;
+        map.world = (size_t)world;
         size_t total = 0;
         for (size_t i = 0; i < count; ++i) {
-            n[i] = jolt_internal_owned_terms(lens[i], block, (size_t)rank, (size_t)world);
+            n[i] = term_owned(map, lens[i]);
             if (n[i] > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
             off[i] = total;
             total += n[i];
@@ -307,7 +344,7 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
         JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(total, 1) * sizeof(Fr), (void**)&compact));
         int32_t s = JOLT_OK;
         for (size_t i = 0; i < count && s == JOLT_OK; ++i) {
-            s = jolt_internal_gather_owned_terms(ctx, ptrs[i], lens[i], block, (size_t)rank, (size_t)world, compact + off[i]);
+            s = jolt_internal_gather_owned_terms(ctx, ptrs[i], lens[i], map, compact + off[i]);
             p[i] = compact + off[i];
         }
         if (s == JOLT_OK) s = jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data());  // every MSM multiplies a prefix of the compact SRS
@@ -391,6 +428,252 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
     for (int t = 0; t < 3; ++t) std::memcpy(&w[t], &ws[t], sizeof(G1Jac));
     if (challenges_out) { fr_to_abi(&challenges_out[0], r); fr_to_abi(&challenges_out[1], q); fr_to_abi(&challenges_out[2], d0); }
     cleanup(b_poly);
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// HyperKZGScheme::open with the POLYNOMIAL sharded over the ranks (subtree assignment, term_map.hip.h; tests/subtree_model.py is the
+// executable specification this follows step by step).  Rank g holds the 2^(ell - gamma) coefficients it owns as a compact array
+// and its compact SRS; folds, RLC, Horner passes, quotient scans and MSMs all run on 1 / world of the data.  What crosses ranks, through
+// `gather` (32-byte words): ell - gamma + 1 words after the folds (subtree roots + crown), 3 (ell - 1) + 9 words of partial points,
+// 3 (ell - gamma) words of partial evaluations, 3 (ell - gamma) + 1 words of segment sums before the quotient scans.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+int32_t read_slot(jolt_ctx* ctx, const jolt_table* t, size_t slot, Fr* out) {
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(out, t->data() + slot, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    return JOLT_OK;
+}
+int32_t write_slot(jolt_ctx* ctx, Fr* dst, const Fr& v) {  // pageable source: the copy is staged before the call returns
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(dst, &v, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    return JOLT_OK;
+}
+int32_t gather_words(jolt_ctx* ctx, jolt_gather_fn gather, void* user, const std::vector<Fr>& local, int world, std::vector<Fr>* all) {
+    all->assign(local.size() * (size_t)world, Fr::zero());
+    ctx->d_round_count = 0;  // these words are not the round sums of the context's last batch round (jolt_comm_gather_round_sums' shortcut)
+    return gather(user, reinterpret_cast<const jolt_fr_t*>(local.data()), local.size(), reinterpret_cast<jolt_fr_t*>(all->data()));
+}
+// partial points of `count` MSMs -> the sums over the ranks, in rank order on every rank
+int32_t gather_points(jolt_ctx* ctx, jolt_gather_fn gather, void* user, const std::vector<G1Jac>& partial, int world, G1Jac* out) {
+    const size_t count = partial.size();
+    std::vector<G1Jac> all((size_t)world * count);
+    ctx->d_round_count = 0;
+    JOLT_TRY(gather(user, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, reinterpret_cast<jolt_fr_t*>(all.data())));
+    for (size_t i = 0; i < count; ++i) {
+        G1Jac acc = all[i];
+        for (int r = 1; r < world; ++r) acc = g1_add(acc, all[(size_t)r * count + i]);
+        out[i] = acc;
+    }
+    return JOLT_OK;
+}
+}  // namespace
+
+extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                                   uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void* user, jolt_g1_t* com,
+                                                   jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    if (!ctx || !srs || !evals || !point || !w || !v || !gather || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
+    if (world < 2 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return JOLT_ERR_INVALID_ARG;
+    if (ell > 40) return JOLT_ERR_UNSUPPORTED;
+    TermMap map;
+    map.kind = kSubtree;
+    map.gamma = (uint32_t)floor_log2_u64((uint64_t)world);
+    map.rank = (size_t)rank;
+    map.world = (size_t)world;
+    const size_t gamma = map.gamma, G = (size_t)world;
+    if (ell <= gamma) return JOLT_ERR_UNSUPPORTED;  // every rank owns at least two coefficients
+    const size_t lam = ell - gamma;
+    if (evals->len != ((size_t)1 << lam)) return JOLT_ERR_SIZE_MISMATCH;
+    if (srs->n < evals->len) return JOLT_ERR_SRS_TOO_SMALL;
+    MockTranscript tr(transcript_label);
+    std::vector<Fr> x(ell);
+    for (size_t i = 0; i < ell; ++i) {
+        x[i] = fr_from_abi(&point[i]);
+        JOLT_REQUIRE(ctx, fr_is_canonical(x[i]), "point coordinate is not a canonical Fr");
+    }
+    std::vector<jolt_table*> polys(ell, nullptr);
+    jolt_table* b_poly = nullptr;
+    jolt_table* h[3] = {nullptr, nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (jolt_table* t : polys) if (t) jolt_table_free(ctx, t);
+        if (b_poly) jolt_table_free(ctx, b_poly);
+        for (jolt_table* t : h) if (t) jolt_table_free(ctx, t);
+    };
+#define SUB_TRY(expr) do { int32_t s_ = (expr); if (s_ != JOLT_OK) { cleanup(); return s_; } } while (0)
+    // phase 1a: the local folds -- fold i uses point[ell - i]; the compact arrays of levels 0 .. lam-1 have >= 2 slots
+    SUB_TRY(jolt_hyperkzg_fold(ctx, evals, point + gamma, lam, polys.data()));
+    // phase 1b: every rank publishes slot 1 of each of those levels (its subtree's root, index G + g) and slot 0 of level 0; the
+    // crowns (indices below G) of all levels follow from these on every rank
+    std::vector<Fr> local(lam + 1), all;
+    for (size_t k = 0; k < lam; ++k) SUB_TRY(read_slot(ctx, polys[k], 1, &local[k]));
+    SUB_TRY(read_slot(ctx, polys[0], 0, &local[lam]));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+    SUB_TRY(gather_words(ctx, gather, user, local, world, &all));
+    std::vector<std::vector<Fr>> crowns(ell);
+    crowns[0].resize(G);
+    for (size_t g = 0; g < G; ++g) crowns[0][g] = all[g * (lam + 1) + lam];
+    for (size_t k = 1; k < ell; ++k) {
+        std::vector<Fr> prev = crowns[k - 1];
+        if (k - 1 < lam)
+            for (size_t g = 0; g < G; ++g) prev.push_back(all[g * (lam + 1) + (k - 1)]);  // indices [G, 2G) of level k-1
+        const Fr xk = x[ell - k];
+        crowns[k].resize(prev.size() / 2);
+        for (size_t y = 0; y < crowns[k].size(); ++y) crowns[k][y] = add(prev[2 * y], mul(xk, sub(prev[2 * y + 1], prev[2 * y])));
+    }
+    for (size_t k = 1; k < ell; ++k) {
+        if (k < lam) {
+            SUB_TRY(write_slot(ctx, polys[k]->data(), crowns[k][(size_t)rank]));
+        } else {  // levels of at most G coefficients: the crown alone
+            const size_t len = (size_t)rank < crowns[k].size() ? 1 : 0;
+            SUB_TRY(jolt_internal_table_new(ctx, len, &polys[k]));
+            if (len) SUB_TRY(write_slot(ctx, polys[k]->data(), crowns[k][(size_t)rank]));
+        }
+    }
+    // phase 1c: level commitments over the compact SRS (every level is a prefix of it)
+    std::vector<G1Jac> coms(ell > 1 ? ell - 1 : 0);
+    if (ell > 1) {
+        std::vector<const Fr*> ptrs;
+        std::vector<size_t> lens;
+        for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+        std::vector<G1Jac> partial(ell - 1);
+        SUB_TRY(jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), ell - 1, partial.data()));
+        SUB_TRY(gather_points(ctx, gather, user, partial, world, coms.data()));
+    }
+    for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
+    const Fr r = tr.challenge();
+    const Fr u[3] = {r, neg(r), mul(r, r)};
+    // evaluations (kzg.rs:84-85): levels with a compact array on the device (slot i weighs u^index(i)), crown-only levels on the host
+    std::vector<Fr> vals(3 * ell, Fr::zero());
+    {
+        Fr3 uu, u16, u4096;
+        for (int t = 0; t < 3; ++t) {
+            uu.v[t] = u[t];
+            Fr p = u[t];
+            for (int i = 0; i < 4; ++i) p = sqr(p);
+            u16.v[t] = p;
+            for (int i = 0; i < 8; ++i) p = sqr(p);
+            u4096.v[t] = p;
+        }
+        SUB_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
+        Fr* chunk_weights = nullptr;
+        SUB_TRY(jolt_internal_dev_alloc(ctx, 3 * kBlock * sizeof(Fr), (void**)&chunk_weights));
+        hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
+        int32_t es = JOLT_OK;
+        for (size_t j = 0; j < lam && es == JOLT_OK; ++j) {
+            const jolt_table* t = polys[j];
+            const size_t per_block = (size_t)kBlock * kHornerChunk;
+            const int grid = (int)std::max<size_t>(1, (t->len + per_block - 1) / per_block);
+            es = jolt_internal_ensure_scratch(ctx, (size_t)grid * 3, 3 * ell + 8);
+            if (es != JOLT_OK) break;
+            hipLaunchKernelGGL(k_horner3<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, (const Fr*)chunk_weights, u4096, ctx->d_partials, map);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * j);
+            if (hipGetLastError() != hipSuccess) es = JOLT_ERR_HIP;
+        }
+        jolt_internal_dev_free(ctx, chunk_weights);  // stream-ordered
+        SUB_TRY(es);
+        std::vector<Fr> part(3 * lam);
+        if (hipMemcpyAsync(part.data(), ctx->d_results, 3 * lam * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+        SUB_TRY(gather_words(ctx, gather, user, part, world, &all));
+        for (size_t j = 0; j < lam; ++j)
+            for (int t = 0; t < 3; ++t) {
+                Fr acc = Fr::zero();
+                for (size_t g = 0; g < G; ++g) acc = add(acc, all[g * 3 * lam + 3 * j + t]);
+                vals[(size_t)t * ell + j] = acc;
+            }
+        for (size_t j = lam; j < ell; ++j)
+            for (int t = 0; t < 3; ++t) {
+                Fr acc = Fr::zero();
+                for (size_t y = crowns[j].size(); y-- > 0;) acc = add(mul(acc, u[t]), crowns[j][y]);
+                vals[(size_t)t * ell + j] = acc;
+            }
+    }
+    for (size_t i = 0; i < 3 * ell; ++i) fr_to_abi(&v[i], vals[i]);
+    for (int t = 0; t < 3; ++t)
+        for (size_t j = 0; j < ell; ++j) tr.append_fr(vals[(size_t)t * ell + j]);  // kzg.rs:88-92
+    const Fr q = tr.challenge();
+    jolt_fr_t q_abi;
+    fr_to_abi(&q_abi, q);
+    SUB_TRY(jolt_hyperkzg_rlc(ctx, polys.data(), ell, &q_abi, &b_poly));  // kzg.rs:95-105: slot-wise on the compact arrays
+    // witness polynomials (kzg.rs:34-46, 108-116).  A rank's segments [2^L, 2^(L+1)) are contiguous index ranges; the quotient scan of a
+    // segment [a, b) starts from the carry E(b) = sum_{i >= b} B[i] u^(i - b).  Every rank publishes the Horner sum of each of its
+    // segments (three points) and its crown value; the chain of carries is evaluated identically on every rank.
+    {
+        Fr3 uu, u16, u4096;
+        for (int t = 0; t < 3; ++t) {
+            uu.v[t] = u[t];
+            Fr p = u[t];
+            for (int i = 0; i < 4; ++i) p = sqr(p);
+            u16.v[t] = p;
+            for (int i = 0; i < 8; ++i) p = sqr(p);
+            u4096.v[t] = p;
+        }
+        SUB_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
+        Fr* chunk_weights = nullptr;
+        SUB_TRY(jolt_internal_dev_alloc(ctx, 3 * kBlock * sizeof(Fr), (void**)&chunk_weights));
+        hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
+        int32_t es = JOLT_OK;
+        for (size_t L = 0; L < lam && es == JOLT_OK; ++L) {  // segment L = slots [2^L, 2^(L+1)): a plain Horner sum from its first slot
+            const size_t len = (size_t)1 << L, per_block = (size_t)kBlock * kHornerChunk;
+            const int grid = (int)std::max<size_t>(1, (len + per_block - 1) / per_block);
+            es = jolt_internal_ensure_scratch(ctx, (size_t)grid * 3, 3 * ell + 8);
+            if (es != JOLT_OK) break;
+            hipLaunchKernelGGL(k_horner3<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)(b_poly->data() + len), len, uu, (const Fr*)chunk_weights, u4096, ctx->d_partials,
+                               TermMap{});
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * L);
+            if (hipGetLastError() != hipSuccess) es = JOLT_ERR_HIP;
+        }
+        jolt_internal_dev_free(ctx, chunk_weights);
+        SUB_TRY(es);
+        std::vector<Fr> sums(3 * lam + 1);
+        if (hipMemcpyAsync(sums.data(), ctx->d_results, 3 * lam * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+        SUB_TRY(read_slot(ctx, b_poly, 0, &sums[3 * lam]));
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+        SUB_TRY(gather_words(ctx, gather, user, sums, world, &all));
+        const size_t stride = 3 * lam + 1;
+        const size_t n_h = ((size_t)1 << lam) - ((size_t)rank + 1 == G ? 1 : 0);  // the quotient has 2^ell - 1 coefficients: the owner of the last index holds one less
+        std::vector<Fr> carries[3];  // kept until the MSMs below have synchronised: sources of small host-to-device copies
+        for (int t = 0; t < 3; ++t) {
+            // carries, from the top index down: layers L = lam-1 .. 0 (ranks G-1 .. 0 inside a layer), then the crown G-1 .. 0
+            std::vector<Fr>& carry = carries[t];  // this rank's: carry[L] enters segment L, carry[lam] enters the crown slot
+            carry.assign(lam + 1, Fr::zero());
+            Fr e = Fr::zero(), upow = u[t];
+            std::vector<Fr> u_len(lam);  // u^(2^L)
+            for (size_t L = 0; L < lam; ++L) { u_len[L] = upow; upow = sqr(upow); }
+            for (size_t L = lam; L-- > 0;)
+                for (size_t g = G; g-- > 0;) {
+                    if (g == (size_t)rank) carry[L] = e;
+                    e = add(all[g * stride + 3 * L + t], mul(u_len[L], e));
+                }
+            for (size_t g = G; g-- > 0;) {
+                if (g == (size_t)rank) carry[lam] = e;
+                e = add(all[g * stride + 3 * lam], mul(u[t], e));
+            }
+            SUB_TRY(jolt_internal_table_new(ctx, (size_t)1 << lam, &h[t]));
+            Fr* hd = h[t]->data();
+            SUB_TRY(write_slot(ctx, hd, carry[lam]));  // h[g] = s[g + 1] = E(g + 1)
+            for (size_t L = 0; L < lam; ++L) {
+                const size_t lo = (size_t)1 << L, len = lo;
+                SUB_TRY(write_slot(ctx, hd + lo + len - 1, carry[L]));  // the segment's top entry is the carry itself
+                if (len > 1) SUB_TRY(suffix_horner(ctx, b_poly->data() + lo, len, u[t], hd + lo, 1, carry[L]));
+            }
+            h[t]->len = n_h;
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+    }
+    G1Jac ws[3];
+    {
+        const Fr* ptrs[3] = {h[0]->data(), h[1]->data(), h[2]->data()};
+        const size_t lens[3] = {h[0]->len, h[1]->len, h[2]->len};
+        std::vector<G1Jac> partial(3);
+        SUB_TRY(jolt_internal_msm_many(ctx, srs, ptrs, lens, 3, partial.data()));
+        SUB_TRY(gather_points(ctx, gather, user, partial, world, ws));
+    }
+#undef SUB_TRY
+    for (int t = 0; t < 3; ++t) append_g1(tr, ws[t]);  // kzg.rs:118-124
+    const Fr d0 = tr.challenge();
+    for (size_t i = 0; i + 1 < ell; ++i) std::memcpy(&com[i], &coms[i], sizeof(G1Jac));
+    for (int t = 0; t < 3; ++t) std::memcpy(&w[t], &ws[t], sizeof(G1Jac));
+    if (challenges_out) { fr_to_abi(&challenges_out[0], r); fr_to_abi(&challenges_out[1], q); fr_to_abi(&challenges_out[2], d0); }
+    cleanup();
     return JOLT_OK;
 }
 

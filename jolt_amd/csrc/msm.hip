@@ -18,6 +18,7 @@
 #include "ctx.hpp"
 #include "msm_kernels.hip.h"
 #include "srs.hpp"
+#include "term_map.hip.h"
 
 using namespace jolt;
 using namespace jolt::msmk;
@@ -36,12 +37,11 @@ __global__ __launch_bounds__(kBlock) void k_affine_to_jac(const G1Affine* __rest
 }
 
 // g1_powers[i] = beta^i * g  (HyperKZGScheme::setup_from_secret, crates/jolt-hyperkzg/src/scheme.rs:54-73)
-// block > 0: out[j] is the j-th power OWNED BY `rank` under the block-cyclic term assignment of DESIGN.md section 6 (term i belongs to
-// rank (i / block) % world): exponent ((j / block) * world + rank) * block + j % block
-__global__ __launch_bounds__(kBlock) void k_srs_powers(Fr beta, G1Jac g, G1Affine* __restrict__ out, size_t n, size_t block, size_t rank, size_t world) {
+// out[j] = beta^(the index of the rank's j-th term) * g: the rank's compact SRS under a sharded term assignment (term_map.hip.h)
+__global__ __launch_bounds__(kBlock) void k_srs_powers(Fr beta, G1Jac g, G1Affine* __restrict__ out, size_t n, TermMap map) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const size_t exponent = block ? ((i / block) * world + rank) * block + i % block : i;
+    const size_t exponent = term_global(map, i);
     Fr acc = Fr::one(), base = beta;  // beta^exponent by square-and-multiply on the index
     for (size_t e = exponent; e; e >>= 1) {
         if (e & 1) acc = mul(acc, base);
@@ -116,19 +116,44 @@ extern "C" int32_t jolt_srs_upload_g1(jolt_ctx* ctx, const jolt_g1_t* bases, siz
     return JOLT_OK;
 }
 
-static int32_t srs_setup_impl(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count, const jolt_g1_t* g1, size_t block, size_t rank, size_t world, jolt_srs** out);
+static int32_t srs_setup_impl(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count, const jolt_g1_t* g1, const TermMap& map, jolt_srs** out);
 extern "C" int32_t jolt_srs_setup_from_secret(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count, const jolt_g1_t* g1, jolt_srs** out) {
-    return srs_setup_impl(ctx, beta, count, g1, 0, 0, 1, out);
+    return srs_setup_impl(ctx, beta, count, g1, TermMap{}, out);
+}
+static bool subtree_map(int32_t rank, int32_t world, TermMap* m) {
+    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return false;
+    m->kind = kSubtree;
+    m->gamma = (uint32_t)floor_log2_u64((uint64_t)world);
+    m->rank = (size_t)rank;
+    m->world = (size_t)world;
+    return true;
+}
+static bool block_map(size_t block, int32_t rank, int32_t world, TermMap* m) {
+    if (world < 1 || rank < 0 || rank >= world || block == 0) return false;
+    m->kind = kBlockCyclic;
+    m->block = block;
+    m->rank = (size_t)rank;
+    m->world = (size_t)world;
+    return true;
 }
 // One rank's share of the same powers under the block-cyclic term assignment: the count_global / world powers
 // beta^i with (i / block) % world == rank, compacted in index order.
 extern "C" int32_t jolt_srs_setup_from_secret_blocks(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count_global, const jolt_g1_t* g1, size_t block, int32_t rank,
                                                      int32_t world, jolt_srs** out) {
-    if (world < 1 || rank < 0 || rank >= world || block == 0) return JOLT_ERR_INVALID_ARG;
+    TermMap m;
+    if (!block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     if (count_global % (block * (size_t)world) != 0) return JOLT_ERR_SIZE_MISMATCH;
-    return srs_setup_impl(ctx, beta, count_global / (size_t)world, g1, block, (size_t)rank, (size_t)world, out);
+    return srs_setup_impl(ctx, beta, count_global / (size_t)world, g1, m, out);
 }
-static int32_t srs_setup_impl(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count, const jolt_g1_t* g1, size_t block, size_t rank, size_t world, jolt_srs** out) {
+// ... and under the subtree assignment (term_map.hip.h): count_global a power of two >= world, world a power of two
+extern "C" int32_t jolt_srs_setup_from_secret_subtree(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count_global, const jolt_g1_t* g1, int32_t rank, int32_t world,
+                                                      jolt_srs** out) {
+    TermMap m;
+    if (!subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (count_global < (size_t)world || (count_global & (count_global - 1)) != 0) return JOLT_ERR_SIZE_MISMATCH;
+    return srs_setup_impl(ctx, beta, count_global / (size_t)world, g1, m, out);
+}
+static int32_t srs_setup_impl(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count, const jolt_g1_t* g1, const TermMap& map, jolt_srs** out) {
     if (!ctx || !beta || !g1 || !out) return JOLT_ERR_INVALID_ARG;
     Fr b = fr_from_abi(beta);
     JOLT_REQUIRE(ctx, fr_is_canonical(b), "beta is not a canonical Fr");
@@ -140,7 +165,7 @@ static int32_t srs_setup_impl(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count
     s->n = count;
     hipError_t e = hipMalloc((void**)&s->pts, std::max<size_t>(count, 1) * sizeof(G1Affine));
     if (e == hipSuccess && count) {
-        hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, b, g, s->pts, count, block, rank, world);
+        hipLaunchKernelGGL(k_srs_powers, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, b, g, s->pts, count, map);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -300,31 +325,40 @@ int32_t jolt_internal_msm_collect(jolt_ctx* ctx, const MsmJob* job, G1Jac* out) 
     return JOLT_OK;
 }
 
-// Block-cyclic term assignment of a sharded MSM: term i belongs to rank (i / block) % world, and a rank's SRS
-// object holds exactly its terms' bases, compacted in index order -- so the terms a rank owns of ANY prefix [0, n) are a prefix of its
-// compact arrays, and the window tables built over the compact SRS serve every level of an opening.
-size_t jolt_internal_owned_terms(size_t n, size_t block, size_t rank, size_t world) {
-    const size_t full = n / block, rem = n % block;
-    return (full / world + (rank < full % world ? 1 : 0)) * block + (full % world == rank ? rem : 0);
-}
-// host hook (no GPU): the count above, for callers sizing per-rank buffers and for the CPU tests
+// Sharded term assignments (term_map.hip.h): a rank's SRS object holds exactly its terms' bases, compacted in index order, so the
+// terms a rank owns of ANY prefix [0, n) are a prefix of its compact arrays.
+// host hooks (no GPU): the owned-term count of a prefix and the index of a compact slot, for callers sizing per-rank buffers and
+// building a rank's compact SRS from a full one, and for the CPU tests
 extern "C" int32_t jolt_host_owned_terms(size_t n, size_t block, int32_t rank, int32_t world, size_t* out) {
-    if (!out || block == 0 || world < 1 || rank < 0 || rank >= world) return JOLT_ERR_INVALID_ARG;
-    *out = jolt_internal_owned_terms(n, block, (size_t)rank, (size_t)world);
+    TermMap m;
+    if (!out || !block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    *out = term_owned(m, n);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_subtree_owned_terms(size_t n, int32_t rank, int32_t world, size_t* out) {
+    TermMap m;
+    if (!out || !subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    *out = term_owned(m, n);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_subtree_term_index(size_t slot, int32_t rank, int32_t world, size_t* out) {
+    TermMap m;
+    if (!out || !subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    *out = term_global(m, slot);
     return JOLT_OK;
 }
 namespace {
-__global__ __launch_bounds__(kBlock) void k_gather_owned_terms(const Fr* __restrict__ src, Fr* __restrict__ dst, size_t len, size_t block, size_t rank, size_t world) {
+__global__ __launch_bounds__(kBlock) void k_gather_owned_terms(const Fr* __restrict__ src, Fr* __restrict__ dst, size_t len, TermMap map) {
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= len) return;
-    dst[j] = src[((j / block) * world + rank) * block + j % block];
+    dst[j] = src[term_global(map, j)];
 }
 }  // namespace
 // dst[0 .. owned) = the scalars of the rank's terms of src[0 .. n), on the main stream
-int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n, size_t block, size_t rank, size_t world, Fr* dst) {
-    const size_t len = jolt_internal_owned_terms(n, block, rank, world);
+int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n, const TermMap& map, Fr* dst) {
+    const size_t len = term_owned(map, n);
     if (!len) return JOLT_OK;
-    hipLaunchKernelGGL(k_gather_owned_terms, dim3((unsigned)((len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, src, dst, len, block, rank, world);
+    hipLaunchKernelGGL(k_gather_owned_terms, dim3((unsigned)((len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, src, dst, len, map);
     JOLT_HIP_TRY(ctx, hipGetLastError());
     return JOLT_OK;
 }
@@ -381,22 +415,32 @@ extern "C" int32_t jolt_msm_g1_table_range(jolt_ctx* ctx, const jolt_srs* srs, s
     return JOLT_OK;
 }
 
-// rank's share of sum_{i < n} scalars[i] * SRS[i] under the block-cyclic assignment: `srs` is the rank's compact SRS
-// (jolt_srs_setup_from_secret_blocks, or an upload of the same points); the shares of all ranks add up to the MSM
-extern "C" int32_t jolt_msm_g1_table_blocks(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, size_t block, int32_t rank, int32_t world,
-                                            jolt_g1_t* out) {
-    if (!ctx || !srs || !scalars || !out || block == 0 || world < 1 || rank < 0 || rank >= world) return JOLT_ERR_INVALID_ARG;
+// rank's share of sum_{i < n} scalars[i] * SRS[i] under a sharded term assignment: `srs` is the rank's compact SRS
+// (jolt_srs_setup_from_secret_blocks / _subtree, or an upload of the same points); the shares of all ranks add up to the MSM
+static int32_t msm_share(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, const TermMap& map, jolt_g1_t* out) {
+    if (!ctx || !srs || !scalars || !out) return JOLT_ERR_INVALID_ARG;
     if (n > scalars->len) return JOLT_ERR_SIZE_MISMATCH;
-    const size_t len = jolt_internal_owned_terms(n, block, (size_t)rank, (size_t)world);
+    const size_t len = term_owned(map, n);
     if (len > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
     Fr* compact = nullptr;
     JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(len, 1) * sizeof(Fr), (void**)&compact));
-    int32_t s = jolt_internal_gather_owned_terms(ctx, scalars->data(), n, block, (size_t)rank, (size_t)world, compact);
+    int32_t s = jolt_internal_gather_owned_terms(ctx, scalars->data(), n, map, compact);
     G1Jac r;
     if (s == JOLT_OK) s = jolt_internal_msm(ctx, srs, compact, len, &r);
     jolt_internal_dev_free(ctx, compact);
     if (s == JOLT_OK) std::memcpy(out, &r, sizeof(r));
     return s;
+}
+extern "C" int32_t jolt_msm_g1_table_blocks(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, size_t block, int32_t rank, int32_t world,
+                                            jolt_g1_t* out) {
+    TermMap m;
+    if (!block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    return msm_share(ctx, srs, scalars, n, m, out);
+}
+extern "C" int32_t jolt_msm_g1_table_subtree(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, int32_t rank, int32_t world, jolt_g1_t* out) {
+    TermMap m;
+    if (!subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    return msm_share(ctx, srs, scalars, n, m, out);
 }
 
 extern "C" int32_t jolt_msm_g1(jolt_ctx* ctx, const jolt_srs* srs, const jolt_fr_t* scalars, size_t n, jolt_g1_t* out) {

@@ -18,6 +18,7 @@
 #include "msm_kernels.hip.h"
 #include "onehot.hpp"
 #include "srs.hpp"
+#include "term_map.hip.h"
 
 using namespace jolt;
 using namespace jolt::msmk;
@@ -118,6 +119,27 @@ __global__ __launch_bounds__(kBlock) void k_grid_joint(JointArgs a, const Fr* __
     st_fr(out + (size_t)k * cycles + j, acc);
 }
 
+// The same polynomial restricted to the coefficients ONE RANK owns under a sharded term assignment (term_map.hip.h), as its compact
+// array: out[c] = J[term_global(map, c)] -- every rank builds its 1 / world of the joint polynomial from the raw columns of the trace
+__global__ __launch_bounds__(kBlock) void k_grid_joint_owned(JointArgs a, const Fr* __restrict__ scalars, size_t cycles, size_t len, TermMap map, Fr* __restrict__ out) {
+    const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= len) return;
+    const size_t pos = term_global(map, c);
+    const uint32_t k = (uint32_t)(pos / cycles);
+    const size_t j = pos % cycles;
+    Fr acc = Fr::zero();
+    for (int s = 0; s < a.n_sources; ++s) {
+        for (uint32_t p = 0; p < a.n_polys[s]; ++p)
+            if (hot_load(a.idx[s], (size_t)p * cycles + j, a.wide[s]) == k) acc = add(acc, ld_fr(scalars + a.first[s] + p));
+    }
+    if (k == 0)
+        for (int d = 0; d < a.n_dense; ++d) {
+            Fr v = ld_fr(a.dense[d] + j);
+            acc = add(acc, a.dense_one[d] ? v : mul(v, a.dense_scalar[d]));
+        }
+    st_fr(out + c, acc);
+}
+
 // Ring::from_u64 / from_i64 / from_i128 per entry (crates/jolt-field/src/bn254/mod.rs:265-328) from device-resident integers
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_promote_ints(const void* __restrict__ data, size_t offset, size_t n, Fr two64, Fr* __restrict__ out) {
@@ -214,8 +236,27 @@ extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* 
     return JOLT_OK;
 }
 
+static int32_t grid_joint_impl(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars, jolt_table* const* dense,
+                               size_t n_dense, const jolt_fr_t* dense_scalars, uint32_t log_k, const TermMap& map, jolt_table** out);
 extern "C" int32_t jolt_grid_joint_polynomial(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars,
                                               jolt_table* const* dense, size_t n_dense, const jolt_fr_t* dense_scalars, uint32_t log_k, jolt_table** out) {
+    return grid_joint_impl(ctx, sources, n_sources, onehot_scalars, dense, n_dense, dense_scalars, log_k, TermMap{}, out);
+}
+// one rank's compact array of the same polynomial under the subtree assignment (the input of jolt_host_hyperkzg_open_subtree):
+// 2^log_k * T / world coefficients, built from the columns of the WHOLE trace
+extern "C" int32_t jolt_grid_joint_polynomial_subtree(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars,
+                                                      jolt_table* const* dense, size_t n_dense, const jolt_fr_t* dense_scalars, uint32_t log_k, int32_t rank,
+                                                      int32_t world, jolt_table** out) {
+    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return JOLT_ERR_INVALID_ARG;
+    TermMap m;
+    m.kind = kSubtree;
+    m.gamma = (uint32_t)floor_log2_u64((uint64_t)world);
+    m.rank = (size_t)rank;
+    m.world = (size_t)world;
+    return grid_joint_impl(ctx, sources, n_sources, onehot_scalars, dense, n_dense, dense_scalars, log_k, m, out);
+}
+static int32_t grid_joint_impl(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars, jolt_table* const* dense,
+                               size_t n_dense, const jolt_fr_t* dense_scalars, uint32_t log_k, const TermMap& map, jolt_table** out) {
     if (!ctx || !out || (n_sources && (!sources || !onehot_scalars)) || (n_dense && (!dense || !dense_scalars))) return JOLT_ERR_INVALID_ARG;
     if (n_sources > (size_t)kJointMaxSources || n_dense > (size_t)kJointMaxDense || log_k > 8 || n_sources + n_dense == 0) return JOLT_ERR_UNSUPPORTED;
     const uint32_t K = 1u << log_k;
@@ -244,11 +285,17 @@ extern "C" int32_t jolt_grid_joint_polynomial(jolt_ctx* ctx, const jolt_onehot* 
     a.n_dense = (int)n_dense;
     for (size_t p = 0; p < total; ++p) JOLT_REQUIRE(ctx, fr_is_canonical(fr_from_abi(&onehot_scalars[p])), "scalar is not a canonical Fr");
     jolt_table *r = nullptr, *ds = nullptr;
-    JOLT_TRY(jolt_internal_table_new(ctx, (size_t)K * T, &r));
+    const size_t len = term_owned(map, (size_t)K * T);
+    if (map.kind != kTermsAll && ((T & (T - 1)) != 0 || len * map.world != (size_t)K * T)) return JOLT_ERR_SIZE_MISMATCH;  // a power-of-two grid, evenly owned
+    JOLT_TRY(jolt_internal_table_new(ctx, len, &r));
     int32_t st = JOLT_OK;
     if (total) st = jolt_table_upload(ctx, onehot_scalars, total, &ds);  // synchronises: the caller's array may be short-lived
     if (st != JOLT_OK) { jolt_table_free(ctx, r); return st; }
-    hipLaunchKernelGGL(k_grid_joint, dim3((unsigned)((T + kBlock - 1) / kBlock), K), dim3(kBlock), 0, ctx->stream, a, ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, r->data());
+    if (map.kind == kTermsAll)
+        hipLaunchKernelGGL(k_grid_joint, dim3((unsigned)((T + kBlock - 1) / kBlock), K), dim3(kBlock), 0, ctx->stream, a, ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, r->data());
+    else
+        hipLaunchKernelGGL(k_grid_joint_owned, dim3((unsigned)((len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, a, ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, len, map,
+                           r->data());
     hipError_t e = hipGetLastError();
     if (ds) jolt_table_free(ctx, ds);
     if (e != hipSuccess) { jolt_table_free(ctx, r); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }

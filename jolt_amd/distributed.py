@@ -744,7 +744,7 @@ class ShardedPcs:
     jolt_gather_fn the opening calls."""
 
     def __init__(self, ctx, rank, world, n_local, onehot_global, dense_global, gather_points, gather_fn, gather_user, seed=2026, log_k=4, fixed_base=False,
-                 block_cyclic=True):
+                 block_cyclic=True, subtree=None):
         from .workload import G1_GENERATOR, rand_fr
         self.ctx, self.rank, self.world, self.n_local, self.log_k = ctx, rank, world, n_local, log_k
         self.T_local, self.T_global = 1 << n_local, world << n_local
@@ -769,6 +769,17 @@ class ShardedPcs:
         ctx.synchronize()
         if fixed_base and log_k + n_local >= 12:
             ctx.srs_precompute_windows(self.srs)
+        # Subtree assignment for the OPENING (tests/subtree_model.py): the polynomial itself is sharded -- every rank
+        # builds, folds, combines, divides and commits 1 / world of the joint polynomial against a second compact SRS (the bases of the
+        # indices it owns under that assignment) with its own window tables.  The commitments keep the block-cyclic assignment above
+        # (a rank commits its own cycles).  Default from 2 ranks on when the world size is a power of two.
+        self.subtree = (block_cyclic and world >= 2 and world & (world - 1) == 0) if subtree is None else bool(subtree)
+        self.srs_open = None
+        if self.subtree:
+            self.srs_open = ctx.srs_setup_from_secret_subtree(self.beta, 1 << self.grid_vars, G1_GENERATOR, rank, world)
+            ctx.synchronize()
+            if fixed_base and log_k + n_local >= 12:
+                ctx.srs_precompute_windows(self.srs_open)
         prng = np.random.default_rng(seed + 3)
         self.rlc_onehot = rand_fr(sum(s.n_polys for s in self.sources), prng)
         self.rlc_dense = rand_fr(len(self.dense_ints), prng)
@@ -806,6 +817,14 @@ class ShardedPcs:
 
     def open(self, label=0):
         ctx = self.ctx
+        if self.subtree:
+            joint = ctx.grid_joint_polynomial_subtree(self.sources, self.rlc_onehot, self.dense_tables, self.rlc_dense, self.log_k, self.rank, self.world)
+            out = ctx.hyperkzg_open_subtree(self.srs_open, joint, self.open_point, label, self.rank, self.world, self.gather_fn, self.gather_user)
+            joint.free()
+            for t in self.dense_tables:
+                t.free()
+            self.dense_tables = []
+            return out
         joint = ctx.grid_joint_polynomial(self.sources, self.rlc_onehot, self.dense_tables, self.rlc_dense, self.log_k)
         p = ffi.fr(self.open_point).reshape(-1, 4)
         ell = p.shape[0]

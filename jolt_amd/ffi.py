@@ -527,6 +527,45 @@ def host_owned_terms(n, block, rank, world):
     return out.value
 
 
+def host_subtree_owned_terms(n, rank, world):
+    """Terms of the prefix [0, n) that `rank` owns under the subtree assignment (host only)."""
+    out = C.c_size_t()
+    _ck(lib().jolt_host_subtree_owned_terms(C.c_size_t(n), C.c_int32(rank), C.c_int32(world), C.byref(out)), "jolt_host_subtree_owned_terms")
+    return out.value
+
+
+def host_subtree_term_index(slot, rank, world):
+    """Index of the rank's compact slot under the subtree assignment (host only)."""
+    out = C.c_size_t()
+    _ck(lib().jolt_host_subtree_term_index(C.c_size_t(slot), C.c_int32(rank), C.c_int32(world), C.byref(out)), "jolt_host_subtree_term_index")
+    return out.value
+
+
+def _srs_setup_from_secret_subtree(self, beta, count_global, g1, rank, world):
+    """One rank's compact share of the powers under the subtree assignment."""
+    h = C.c_void_p()
+    _ck(lib().jolt_srs_setup_from_secret_subtree(self.h, _p(fr(beta)), C.c_size_t(count_global), _p(np.ascontiguousarray(g1, dtype=np.uint64)), C.c_int32(rank),
+                                                 C.c_int32(world), C.byref(h)), "jolt_srs_setup_from_secret_subtree", self)
+    return Srs(self, h)
+
+
+def _msm_subtree(self, srs, table, n, rank, world):
+    """The rank's share of sum_{i<n} table[i] * SRS[i] under the subtree assignment (srs = the rank's compact SRS)."""
+    out = g1_array(1)
+    _ck(lib().jolt_msm_g1_table_subtree(self.h, srs.h, table.h, C.c_size_t(n), C.c_int32(rank), C.c_int32(world), _p(out)), "jolt_msm_g1_table_subtree", self)
+    return out[0]
+
+
+def _hyperkzg_open_subtree(self, srs, evals_compact, point, label, rank, world, gather_fn, gather_user):
+    """jolt_host_hyperkzg_open_subtree: the opening with the polynomial sharded over the ranks (evals_compact: the rank's compact array)."""
+    p = fr(point).reshape(-1, 4)
+    ell = p.shape[0]
+    com, w, v, ch = g1_array(max(ell - 1, 1)), g1_array(3), fr_array(3 * ell), fr_array(3)
+    _ck(lib().jolt_host_hyperkzg_open_subtree(self.h, srs.h, evals_compact.h, _p(p), C.c_size_t(ell), C.c_uint64(label), C.c_int32(rank), C.c_int32(world),
+                                              gather_fn, gather_user, _p(com), _p(w), _p(v), _p(ch)), "jolt_host_hyperkzg_open_subtree", self)
+    return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
+
+
 def _srs_setup_from_secret_blocks(self, beta, count_global, g1, block, rank, world):
     """One rank's compact share of the powers under the block-cyclic term assignment (term i belongs to rank (i / block) % world)."""
     h = C.c_void_p()
@@ -611,6 +650,9 @@ Context.srs_setup_from_secret = _srs_setup_from_secret
 Context.msm = _msm
 Context.srs_setup_from_secret_blocks = _srs_setup_from_secret_blocks
 Context.msm_blocks = _msm_blocks
+Context.srs_setup_from_secret_subtree = _srs_setup_from_secret_subtree
+Context.msm_subtree = _msm_subtree
+Context.hyperkzg_open_subtree = _hyperkzg_open_subtree
 Context.hyperkzg_fold = _hyperkzg_fold
 Context.hyperkzg_eval3 = _hyperkzg_eval3
 Context.hyperkzg_rlc = _hyperkzg_rlc
@@ -884,6 +926,18 @@ def _grid_joint_polynomial(self, sources, onehot_scalars, dense, dense_scalars, 
     return Table(self, h)
 
 
+def _grid_joint_polynomial_subtree(self, sources, onehot_scalars, dense, dense_scalars, log_k, rank, world):
+    """The rank's compact array (subtree assignment) of the same joint polynomial: 2^log_k * T / world coefficients."""
+    hs = (C.c_void_p * max(len(sources), 1))(*[s.h for s in sources])
+    ds = (C.c_void_p * max(len(dense), 1))(*[t.h for t in dense])
+    osc = fr(np.stack([fr(c) for c in onehot_scalars])).reshape(-1, 4) if len(onehot_scalars) else None
+    dsc = fr(np.stack([fr(c) for c in dense_scalars])).reshape(-1, 4) if len(dense_scalars) else None
+    h = C.c_void_p()
+    _ck(lib().jolt_grid_joint_polynomial_subtree(self.h, hs if sources else None, C.c_size_t(len(sources)), _p(osc), ds if dense else None, C.c_size_t(len(dense)),
+                                                 _p(dsc), C.c_uint32(log_k), C.c_int32(rank), C.c_int32(world), C.byref(h)), "jolt_grid_joint_polynomial_subtree", self)
+    return Table(self, h)
+
+
 def _trim(self):
     _ck(lib().jolt_ctx_trim(self.h), "jolt_ctx_trim", self)
 
@@ -897,6 +951,7 @@ def _memory_stats(self):
 Context.table_from_ints = _table_from_ints
 Context.grid_commit_onehot = _grid_commit_onehot
 Context.grid_joint_polynomial = _grid_joint_polynomial
+Context.grid_joint_polynomial_subtree = _grid_joint_polynomial_subtree
 Context.trim = _trim
 Context.memory_stats = _memory_stats
 

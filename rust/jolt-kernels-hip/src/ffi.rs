@@ -297,4 +297,10 @@ extern "C" {
     pub fn jolt_srs_setup_from_secret_blocks(ctx: *mut jolt_ctx, beta: *const jolt_fr_t, count_global: usize, g1: *const jolt_g1_t, block: usize, rank: i32, world: i32, out: *mut *mut jolt_srs) -> i32;
     pub fn jolt_msm_g1_table_blocks(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, block: usize, rank: i32, world: i32, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open_sharded_blocks(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, block: usize, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_subtree_owned_terms(n: usize, rank: i32, world: i32, out: *mut usize) -> i32;
+    pub fn jolt_host_subtree_term_index(slot: usize, rank: i32, world: i32, out: *mut usize) -> i32;
+    pub fn jolt_srs_setup_from_secret_subtree(ctx: *mut jolt_ctx, beta: *const jolt_fr_t, count_global: usize, g1: *const jolt_g1_t, rank: i32, world: i32, out: *mut *mut jolt_srs) -> i32;
+    pub fn jolt_msm_g1_table_subtree(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, rank: i32, world: i32, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_grid_joint_polynomial_subtree(ctx: *mut jolt_ctx, sources: *const *const jolt_onehot, n_sources: usize, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, log_k: u32, rank: i32, world: i32, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_host_hyperkzg_open_subtree(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
 }

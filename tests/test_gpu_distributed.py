@@ -156,7 +156,7 @@ def test_sharded_device_msm_two_ranks():
             assert open(os.path.join(tmp, f"msm{r}.txt")).read() == "ok", f"rank {r}"
 
 
-def _pcs_worker(rank, world, port, tmpdir, n_local, cyclic):
+def _pcs_worker(rank, world, port, tmpdir, n_local, mode):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
     from util import init_gloo
@@ -172,7 +172,8 @@ def _pcs_worker(rank, world, port, tmpdir, n_local, cyclic):
     ins = rng.integers(0, 16, size=(5, T), dtype=np.uint8)
     dense = [rng.integers(0, 2**64, size=T, dtype=np.uint64), rng.integers(-2**62, 2**62, size=T, dtype=np.int64)]
     gp, gfn, guser = D.make_point_gather(coll, world)
-    pcs = D.ShardedPcs(ctx, rank, world, n_local, [ram, ins], dense, gp, gfn, guser, seed=5, fixed_base=(n_local >= 6), block_cyclic=cyclic)
+    pcs = D.ShardedPcs(ctx, rank, world, n_local, [ram, ins], dense, gp, gfn, guser, seed=5, fixed_base=(n_local >= 6), block_cyclic=(mode != "range"),
+                       subtree=(mode == "subtree"))
     out = pcs.step(label=9)
     again = pcs.step(label=9)
     assert np.array_equal(out["open"]["v"], again["open"]["v"])
@@ -183,18 +184,21 @@ def _pcs_worker(rank, world, port, tmpdir, n_local, cyclic):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_local,cyclic", [(2, 4, True), (4, 4, True), (2, 7, True), (2, 11, True), (4, 9, True), (8, 8, True),
-                                                  (2, 4, False), (4, 4, False), (2, 11, False)])
-def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local, cyclic):
-    """Sharded PCS legs (ShardedPcs: partial commitments per block of cycles, every MSM of the HyperKZG opening split over the ranks,
-    partial points all-gathered): every rank returns the commitments and the opening the ORACLE computes in one process over the
-    global trace -- same transcript bytes, same points.  cyclic: the block-cyclic term assignment over per-rank compact bases (the
-    default; window tables over the rank's own 2^(4 + n_local) bases from n_local = 8 on); otherwise contiguous term ranges."""
+@pytest.mark.parametrize("world,n_local,mode", [(2, 4, "subtree"), (4, 4, "subtree"), (2, 7, "subtree"), (2, 11, "subtree"), (4, 9, "subtree"), (8, 8, "subtree"),
+                                                (2, 4, "cyclic"), (4, 9, "cyclic"), (8, 5, "cyclic"), (2, 4, "range"), (4, 4, "range"), (2, 11, "range")])
+def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local, mode):
+    """Sharded PCS legs (ShardedPcs): every rank returns the commitments and the opening the ORACLE computes in one process over the
+    global trace -- same transcript bytes, same points.
+      subtree (the default): commitments by block-cyclic shares; the opening with the POLYNOMIAL sharded by index subtree -- folds, RLC,
+        Horner passes, quotient scans and MSMs on 1 / world of the coefficients per rank, O(ell) field elements exchanged
+        (jolt_host_hyperkzg_open_subtree; window tables over the rank's own bases from n_local = 8 on);
+      cyclic: polynomial arithmetic replicated, every MSM split block-cyclically over per-rank compact bases;
+      range: the same with contiguous term ranges against the full SRS."""
     import torch.multiprocessing as mp
     import oracle_lib as O
     port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_pcs_worker, args=(world, port, tmp, n_local, cyclic), nprocs=world, join=True)
+        mp.spawn(_pcs_worker, args=(world, port, tmp, n_local, mode), nprocs=world, join=True)
         got = [np.load(os.path.join(tmp, f"pcs{r}.npz")) for r in range(world)]
     g0 = got[0]
     T, K = world << n_local, 16

@@ -288,3 +288,33 @@ def test_block_cyclic_shares_add_up_to_the_msm(ctx, world, block, n_global):
         assert same_point(acc, want), n
     with pytest.raises(ffi.JoltError):
         ctx.srs_setup_from_secret_blocks(beta, n_global + 1, O.g1_generator(), block, 0, world)
+
+
+@pytest.mark.parametrize("world,n_global", [(2, 256), (4, 1024), (8, 2048), (2, 16384)])
+def test_subtree_shares_add_up_to_the_msm(ctx, world, n_global):
+    """The subtree term assignment (term_map.hip.h; tests/subtree_model.py): rank g's compact SRS holds the powers of the indices it
+    owns in index order, and the ranks' shares of any prefix MSM add up to the MSM over the full SRS ((2, 16384): with window tables)."""
+    import subtree_model as M
+    gamma = world.bit_length() - 1
+    beta = rand_fr(1, 93)[0]
+    full = ctx.srs_setup_from_secret(beta, n_global, O.g1_generator())
+    full_pts = full.download()
+    shares = [ctx.srs_setup_from_secret_subtree(beta, n_global, O.g1_generator(), g, world) for g in range(world)]
+    for g, s in enumerate(shares):
+        assert len(s) == n_global // world
+        pts = s.download()
+        for c in list(range(0, len(s), max(1, len(s) // 48))) + [len(s) - 1]:
+            assert same_point(pts[c], full_pts[M.insert(c, g, gamma)]), (g, c)
+        if len(s) >= 4096:
+            ctx.srs_precompute_windows(s, min_terms=1024)
+    scalars = rand_fr(n_global, 94)
+    scalars[3] = 0
+    table = ctx.upload(scalars)
+    for n in (n_global, n_global - 1, n_global // 2, n_global // 2 + 5, world + 1, world, world - 1, 1, 0):
+        want = ctx.msm(full, table, n) if n else O.g1_identity()
+        acc = O.g1_identity()
+        for g, s in enumerate(shares):
+            acc = ffi.host_g1_add(acc, ctx.msm_subtree(s, table, n, g, world))
+        assert same_point(acc, want), n
+    with pytest.raises(ffi.JoltError):
+        ctx.srs_setup_from_secret_subtree(beta, n_global, O.g1_generator(), 0, 3)

@@ -88,6 +88,12 @@ def test_grid_commitments_and_joint_polynomial_match_oracle(ctx, log_t, k, cold)
     for d in range(2):
         want[:T] = O.fr_add(want[:T], O.fr_mul(dense_host[d], np.repeat(s_d[d].reshape(1, 4), T, axis=0)))
     assert np.array_equal(joint.download(), want)
+    # the ranks' compact arrays under the subtree assignment are the owned coefficients of the same polynomial, in index order
+    for world in (2, 4, 8):
+        for g in range(world):
+            compact = ctx.grid_joint_polynomial_subtree([src_a, src_b], s_oh, dense, s_d, log_k, g, world).download()
+            own = [ffi.host_subtree_term_index(c, g, world) for c in range(K * T // world)]
+            assert compact.shape[0] == len(own) and np.array_equal(compact, want[own]), (world, g)
     # a source wider than the grid / an SRS shorter than the grid are refused
     with pytest.raises(ffi.JoltError) as e:
         ctx.grid_commit_onehot(ctx.srs_upload(host_srs[: K * T // 2]), ctx.onehot(np.full((1, T), k - 1, dtype=np.uint8), K))
