@@ -729,16 +729,17 @@ class ShardedWorkload:
 # PCS legs of the sharded step (BASELINE configs[2] at N > 1): commitments and ONE HyperKZG opening over the global commitment grid
 # ---------------------------------------------------------------------------------------------------------------------------------
 class ShardedPcs:
-    """The committed columns of a trace of world * T cycles over the shared 2^(log_k) x (world * T) commitment grid, with the MSM
-    work sharded over the ranks by TERM RANGE (north_star: "the MSM scalar set shards naturally across the GPUs, bucket sums
-    reduced with RCCL"):
+    """The committed columns of a trace of world * T cycles over the shared 2^(log_k) x (world * T) commitment grid, with the PCS work
+    sharded over the ranks (north_star: "the MSM scalar set shards naturally across the GPUs, bucket sums reduced with RCCL"; DESIGN.md
+    section 6):
 
       resident on every rank (inputs, before the timed region): the raw committed columns of the WHOLE trace -- 36 hot-index bytes
-        and two 64-bit increments per cycle (52 B per cycle, 1.7 GB at 8 x 2^22 cycles) -- and the SRS;
+        and two 64-bit increments per cycle (52 B per cycle, 1.7 GB at 8 x 2^22 cycles) -- and the rank's compact SRS objects with
+        their window tables;
       commit(): rank g multiplies / sums the bases of ITS block of cycles for every column; one all-gather of 38 partial points;
-      open():   every rank builds the joint polynomial and runs the HyperKZG polynomial arithmetic (folds, Horner, RLC, divisions:
-        HBM-bound passes, ~10 % of an opening) redundantly; every MSM is split by term range over the ranks and the partial points
-        are all-gathered (two exchanges per opening: ell - 1 level commitments, 3 witness commitments).
+      open():   default (subtree): every rank builds ITS 1 / world of the joint polynomial and runs folds, Horner passes, RLC, quotient
+        scans and MSMs on it (jolt_host_hyperkzg_open_subtree); five small exchanges per opening.  subtree=False: the polynomial
+        arithmetic replicated, every MSM split over the ranks (block-cyclically, or by term range with block_cyclic=False).
     Every rank ends up with the same commitments and the same proof as a single process over the global trace (tests/
     test_gpu_distributed.py).  `gather(points)` all-gathers (count, 12) uint64 arrays; `gather_fn / gather_user` are the C-level
     jolt_gather_fn the opening calls."""
