@@ -285,3 +285,20 @@ def test_block_cyclic_ownership_partitions_every_prefix():
             ffi.host_owned_terms(5, 0, 0, world)
         with pytest.raises(ffi.JoltError):
             ffi.host_owned_terms(5, block, world, world)
+
+
+def test_subtree_ownership_hooks_agree_with_the_specification():
+    """jolt_host_subtree_term_index / _owned_terms (term_map.hip.h, the maps the device kernels use) against tests/subtree_model.py."""
+    import subtree_model as M
+    from jolt_amd import ffi
+    for world in (1, 2, 4, 8):
+        gamma = world.bit_length() - 1
+        for g in range(world):
+            for c in list(range(0, 300, 7)) + [4096, 4097, (1 << 26) - 1, 1 << 26]:
+                assert ffi.host_subtree_term_index(c, g, world) == M.insert(c, g, gamma)
+            for n in list(range(0, 70)) + [255, 256, 257, (1 << 20) - 1, 1 << 20, (1 << 29) - 1, 1 << 29]:
+                assert ffi.host_subtree_owned_terms(n, g, world) == M.owned(n, g, gamma), (n, g, world)
+    with pytest.raises(ffi.JoltError):
+        ffi.host_subtree_owned_terms(8, 0, 3)  # the world size must be a power of two
+    with pytest.raises(ffi.JoltError):
+        ffi.host_subtree_term_index(1, 4, 4)
