@@ -650,7 +650,8 @@ int32_t jolt_host_hyperkzg_open_sharded_blocks(jolt_ctx *ctx, const jolt_srs *sr
  * coefficients: jolt_grid_joint_polynomial_subtree builds it for the commitment grid; jolt_host_subtree_term_index gives the index
  * of a slot for any other source) and the rank's compact SRS, runs folds / RLC / Horner passes / quotient scans / MSMs on 1 / world
  * of the data, exchanges O(ell) field elements and O(ell) points through `gather`, and returns on every rank the proof
- * jolt_host_hyperkzg_open returns for the whole polynomial.  tests/subtree_model.py is the executable specification. */
+ * jolt_host_hyperkzg_open returns for the whole polynomial (world >= 2, ell > log2 world; one rank: jolt_host_hyperkzg_open).
+ * tests/subtree_model.py is the executable specification. */
 int32_t jolt_host_subtree_owned_terms(size_t n, int32_t rank, int32_t world, size_t *out);
 int32_t jolt_host_subtree_term_index(size_t slot, int32_t rank, int32_t world, size_t *out);
 int32_t jolt_srs_setup_from_secret_subtree(jolt_ctx *ctx, const jolt_fr_t *beta, size_t count_global, const jolt_g1_t *g1, int32_t rank,

@@ -329,10 +329,7 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
     std::vector<G1Jac> partial(count), all((size_t)world * count);
     if (block) {
         TermMap map;
-        map.kind = kBlockCyclic;
-        map.block = block;
-        map.rank = (size_t)rank;
-        map.world = (size_t)world;
+        if (!make_block_map(block, rank, world, &map)) return JOLT_ERR_INVALID_ARG;
         size_t total = 0;
         for (size_t i = 0; i < count; ++i) {
             n[i] = term_owned(map, lens[i]);
@@ -471,13 +468,9 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
                                                    uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void* user, jolt_g1_t* com,
                                                    jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
     if (!ctx || !srs || !evals || !point || !w || !v || !gather || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
-    if (world < 2 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return JOLT_ERR_INVALID_ARG;
-    if (ell > 40) return JOLT_ERR_UNSUPPORTED;
     TermMap map;
-    map.kind = kSubtree;
-    map.gamma = (uint32_t)floor_log2_u64((uint64_t)world);
-    map.rank = (size_t)rank;
-    map.world = (size_t)world;
+    if (world < 2 || !make_subtree_map(rank, world, &map)) return JOLT_ERR_INVALID_ARG;  // one rank: jolt_host_hyperkzg_open
+    if (ell > 40) return JOLT_ERR_UNSUPPORTED;
     const size_t gamma = map.gamma, G = (size_t)world;
     if (ell <= gamma) return JOLT_ERR_UNSUPPORTED;  // every rank owns at least two coefficients
     const size_t lam = ell - gamma;

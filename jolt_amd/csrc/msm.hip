@@ -120,28 +120,12 @@ static int32_t srs_setup_impl(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count
 extern "C" int32_t jolt_srs_setup_from_secret(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count, const jolt_g1_t* g1, jolt_srs** out) {
     return srs_setup_impl(ctx, beta, count, g1, TermMap{}, out);
 }
-static bool subtree_map(int32_t rank, int32_t world, TermMap* m) {
-    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return false;
-    m->kind = kSubtree;
-    m->gamma = (uint32_t)floor_log2_u64((uint64_t)world);
-    m->rank = (size_t)rank;
-    m->world = (size_t)world;
-    return true;
-}
-static bool block_map(size_t block, int32_t rank, int32_t world, TermMap* m) {
-    if (world < 1 || rank < 0 || rank >= world || block == 0) return false;
-    m->kind = kBlockCyclic;
-    m->block = block;
-    m->rank = (size_t)rank;
-    m->world = (size_t)world;
-    return true;
-}
 // One rank's share of the same powers under the block-cyclic term assignment: the count_global / world powers
 // beta^i with (i / block) % world == rank, compacted in index order.
 extern "C" int32_t jolt_srs_setup_from_secret_blocks(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count_global, const jolt_g1_t* g1, size_t block, int32_t rank,
                                                      int32_t world, jolt_srs** out) {
     TermMap m;
-    if (!block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!make_block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     if (count_global % (block * (size_t)world) != 0) return JOLT_ERR_SIZE_MISMATCH;
     return srs_setup_impl(ctx, beta, count_global / (size_t)world, g1, m, out);
 }
@@ -149,7 +133,7 @@ extern "C" int32_t jolt_srs_setup_from_secret_blocks(jolt_ctx* ctx, const jolt_f
 extern "C" int32_t jolt_srs_setup_from_secret_subtree(jolt_ctx* ctx, const jolt_fr_t* beta, size_t count_global, const jolt_g1_t* g1, int32_t rank, int32_t world,
                                                       jolt_srs** out) {
     TermMap m;
-    if (!subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!make_subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     if (count_global < (size_t)world || (count_global & (count_global - 1)) != 0) return JOLT_ERR_SIZE_MISMATCH;
     return srs_setup_impl(ctx, beta, count_global / (size_t)world, g1, m, out);
 }
@@ -331,19 +315,19 @@ int32_t jolt_internal_msm_collect(jolt_ctx* ctx, const MsmJob* job, G1Jac* out) 
 // building a rank's compact SRS from a full one, and for the CPU tests
 extern "C" int32_t jolt_host_owned_terms(size_t n, size_t block, int32_t rank, int32_t world, size_t* out) {
     TermMap m;
-    if (!out || !block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!out || !make_block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     *out = term_owned(m, n);
     return JOLT_OK;
 }
 extern "C" int32_t jolt_host_subtree_owned_terms(size_t n, int32_t rank, int32_t world, size_t* out) {
     TermMap m;
-    if (!out || !subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!out || !make_subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     *out = term_owned(m, n);
     return JOLT_OK;
 }
 extern "C" int32_t jolt_host_subtree_term_index(size_t slot, int32_t rank, int32_t world, size_t* out) {
     TermMap m;
-    if (!out || !subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!out || !make_subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     *out = term_global(m, slot);
     return JOLT_OK;
 }
@@ -434,12 +418,12 @@ static int32_t msm_share(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* s
 extern "C" int32_t jolt_msm_g1_table_blocks(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, size_t block, int32_t rank, int32_t world,
                                             jolt_g1_t* out) {
     TermMap m;
-    if (!block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!make_block_map(block, rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     return msm_share(ctx, srs, scalars, n, m, out);
 }
 extern "C" int32_t jolt_msm_g1_table_subtree(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, int32_t rank, int32_t world, jolt_g1_t* out) {
     TermMap m;
-    if (!subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
+    if (!make_subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     return msm_share(ctx, srs, scalars, n, m, out);
 }
 

@@ -247,12 +247,8 @@ extern "C" int32_t jolt_grid_joint_polynomial(jolt_ctx* ctx, const jolt_onehot* 
 extern "C" int32_t jolt_grid_joint_polynomial_subtree(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars,
                                                       jolt_table* const* dense, size_t n_dense, const jolt_fr_t* dense_scalars, uint32_t log_k, int32_t rank,
                                                       int32_t world, jolt_table** out) {
-    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return JOLT_ERR_INVALID_ARG;
     TermMap m;
-    m.kind = kSubtree;
-    m.gamma = (uint32_t)floor_log2_u64((uint64_t)world);
-    m.rank = (size_t)rank;
-    m.world = (size_t)world;
+    if (!make_subtree_map(rank, world, &m)) return JOLT_ERR_INVALID_ARG;
     return grid_joint_impl(ctx, sources, n_sources, onehot_scalars, dense, n_dense, dense_scalars, log_k, m, out);
 }
 static int32_t grid_joint_impl(jolt_ctx* ctx, const jolt_onehot* const* sources, size_t n_sources, const jolt_fr_t* onehot_scalars, jolt_table* const* dense,

@@ -77,4 +77,24 @@ inline size_t term_owned(const TermMap& m, size_t n) {
     return lo;
 }
 
+// the maps of one rank (false: not a valid rank / world / block)
+inline bool make_subtree_map(int32_t rank, int32_t world, TermMap* m) {
+    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1)) != 0) return false;
+    m->kind = kSubtree;
+    m->gamma = (uint32_t)floor_log2_u64((uint64_t)world);
+    m->block = 0;
+    m->rank = (size_t)rank;
+    m->world = (size_t)world;
+    return true;
+}
+inline bool make_block_map(size_t block, int32_t rank, int32_t world, TermMap* m) {
+    if (world < 1 || rank < 0 || rank >= world || block == 0) return false;
+    m->kind = kBlockCyclic;
+    m->gamma = 0;
+    m->block = block;
+    m->rank = (size_t)rank;
+    m->world = (size_t)world;
+    return true;
+}
+
 }  // namespace jolt
