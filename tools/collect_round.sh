@@ -27,6 +27,11 @@ timeout 300 python tools/bench_rw.py 22 16 >> "$OUT/rw_matrix.txt" 2>&1
 [ -f tools/bench_r1cs.py ] && timeout 300 python tools/bench_r1cs.py 22 > "$OUT/r1cs.txt" 2>&1
 timeout 300 python tools/bench_read_raf.py 20 > "$OUT/read_raf.txt" 2>&1
 timeout 300 python tools/bench_read_raf.py 22 >> "$OUT/read_raf.txt" 2>&1
+# sharded commit / open: both ranks on this GPU (a code-path / memory check at real table sizes, not a measurement), then the two-rank
+# 2^23-coefficient opening against the beta-known identities
+timeout 600 bash tools/bench_two_ranks_one_gpu.sh 20 > "$OUT/two_ranks_one_gpu.txt" 2>&1
+timeout 900 python tools/check_subtree_scale.py 18 > "$OUT/subtree_scale.txt" 2>&1
+tail -2 "$OUT/subtree_scale.txt"
 # bind kernel: HIP-event roofline leg, the same command under rocprofv3, and its HBM traffic from PMC (separate passes)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_bind
