@@ -94,3 +94,79 @@ pub fn msm_g1(ctx: &Arc<HipContext>, bases: &[Bn254G1], scalars: &[Fr]) -> Optio
     };
     srs.msm(scalars).ok()
 }
+
+/// One rank's part of a HyperKZG prover sharded over the `world` GPUs of a node (`DESIGN.md` section 6; the reference is single
+/// process).  The rank holds the bases of the indices it owns under the subtree assignment, compacted in index order, with their
+/// window tables; `HyperKZGScheme::open` (`crates/jolt-hyperkzg/src/scheme.rs:122-158`) then runs on `1 / world` of the polynomial
+/// per rank and every rank returns the same proof.
+pub struct HipShardedOpening {
+    ctx: Arc<HipContext>,
+    srs: HipSrs,
+    rank: i32,
+    world: i32,
+}
+
+impl HipShardedOpening {
+    /// The indices this rank owns of `[0, len)`, in the order of its compact arrays (slot -> index): which bases to upload and which
+    /// evaluations to send to this GPU.
+    pub fn owned_indices(len: usize, rank: i32, world: i32) -> Result<Vec<usize>, HipError> {
+        let mut count = 0usize;
+        // SAFETY: host-only entry points writing one usize.
+        check(unsafe { ffi::jolt_host_subtree_owned_terms(len, rank, world, &mut count) }, ptr::null())?;
+        (0..count)
+            .map(|slot| {
+                let mut index = 0usize;
+                check(unsafe { ffi::jolt_host_subtree_term_index(slot, rank, world, &mut index) }, ptr::null()).map(|()| index)
+            })
+            .collect()
+    }
+
+    /// Uploads this rank's bases out of the full `g1_powers` and builds the window tables over them.
+    pub fn new(ctx: &Arc<HipContext>, g1_powers: &[Bn254G1], rank: i32, world: i32) -> Result<Self, HipError> {
+        let own: Vec<Bn254G1> = Self::owned_indices(g1_powers.len(), rank, world)?.into_iter().map(|i| g1_powers[i]).collect();
+        let mut srs = HipSrs::upload(ctx, &own)?;
+        srs.precompute_windows()?;
+        Ok(Self { ctx: Arc::clone(ctx), srs, rank, world })
+    }
+
+    /// `open` over this rank's compact array of the evaluations (`evals[slot] = poly[owned_indices[slot]]`).  `gather` moves
+    /// `count` 32-byte words from every rank to every rank (rank order): the same hook as the round sums of the sharded sumcheck.
+    /// Returns (level commitments, witness commitments, evaluations `v[t][level]`) -- `HyperKZGProof`'s fields.
+    pub fn open(
+        &self,
+        evals: &crate::context::HipTable,
+        point: &[Fr],
+        transcript_label: u64,
+        gather: ffi::jolt_gather_fn,
+        gather_user: *mut core::ffi::c_void,
+    ) -> Result<(Vec<Bn254G1>, [Bn254G1; 3], Vec<Fr>), HipError> {
+        let ell = point.len();
+        let mut com = vec![Bn254G1::default(); ell.saturating_sub(1).max(1)];
+        let mut w = [Bn254G1::default(); 3];
+        let mut v = vec![Fr::default(); 3 * ell];
+        // SAFETY: live handles; output arrays sized as the header states (ell - 1 points, 3 points, 3 * ell field elements).
+        check(
+            unsafe {
+                ffi::jolt_host_hyperkzg_open_subtree(
+                    self.ctx.raw,
+                    self.srs.raw,
+                    evals.raw,
+                    point.as_ptr().cast(),
+                    ell,
+                    transcript_label,
+                    self.rank,
+                    self.world,
+                    gather,
+                    gather_user,
+                    com.as_mut_ptr().cast(),
+                    w.as_mut_ptr().cast(),
+                    v.as_mut_ptr().cast(),
+                    ptr::null_mut(),
+                )
+            },
+            self.ctx.raw,
+        )?;
+        com.truncate(ell.saturating_sub(1));
+        Ok((com, w, v))
+    }
+}
