@@ -11,7 +11,8 @@ Resident before the timed region: the witness as 64-bit integer columns and hot 
 
     python bench.py                         # N=1, BASELINE configs[2]: T=2^22, sumcheck + HyperKZG commit/open end-to-end
     python bench.py --scale 20 --no-msm     # BASELINE configs[1]: T=2^20, sumcheck bind + round-poly kernels only
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N    # hypercube sharded over N GPUs (weak)
+    python bench.py --gpus N                # hypercube sharded over N GPUs (weak): re-executes itself under torch.distributed.run
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N    # the same under the caller's launcher
 
 Prints ONE JSON line (rank 0) with `roofline` (bind kernel, HIP-event timed live) and `cpu_baseline` (the oracle's
 OpenMP port of the same member mix, bounded sample).  The oracle is used only for that baseline leg.
@@ -43,7 +44,26 @@ def parse():
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=0, help="log2 T of the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
+    ap.add_argument("--round-exchange", choices=["rccl", "shm", "both"], default="both",
+                    help="N > 1: how the per-round partial sums are exchanged.  `value` is timed with RCCL (the collective north_star names) unless "
+                         "'shm' is given; 'both' (default) times the other exchange in the same run as well and prints the pair in config.round_exchange_ab")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node (one per GPU,
+    rendezvous on 127.0.0.1) and hand its exit code back.  Under the driver's own torchrun command WORLD_SIZE is set and this is skipped."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
 
 def bind_roofline(ctx, ffi, log_n, reps):
@@ -81,7 +101,9 @@ def bind_roofline(ctx, ffi, log_n, reps):
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": "k_bind_low_to_high<shifted>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "table_len": n, "bytes_per_launch": bytes_per_launch,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/bind_traffic.json (rocprofv3 --pmc pass of `bench.py --roofline-only`, FETCH_SIZE / WRITE_SIZE corrected per the guide; not collected in this run)" if traffic is not None else None,
+            "table_len": n, "bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(ms, 5)}
 
 
@@ -186,8 +208,12 @@ def cpu_baseline(log_t, srs_host, with_pcs):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0 and not os.environ.get("JOLT_FORCE_SHARDED"):
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     sharded = world > 1 or os.environ.get("JOLT_FORCE_SHARDED") == "1"  # the env var exercises the RCCL path with one rank
@@ -253,7 +279,8 @@ def main():
                                      subtree=subtree)
             pcs = "grid"
 
-        def step(label=0):
+        def step(label=0):  # the same legs as the N = 1 step (DeviceWorkload.step): prepare, commit, prove, open
+            wl.prepare()
             if pcs_sharded is not None:
                 pcs_sharded.commit()
             wl.prove(label=label)
@@ -271,23 +298,39 @@ def main():
             torch.cuda.synchronize()
             ctx.synchronize()
 
-    for i in range(args.warmup):
-        step(label=1000 + i)
-    barrier()
+    def timed(steps, warmup, base):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over the ranks."""
+        for i in range(warmup):
+            step(label=base + 1000 + i)
+        barrier()
+        if sharded:
+            for k in _D.TIMINGS:
+                _D.TIMINGS[k] = 0.0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(label=base + 2000 + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    exchange_ab = None
     if sharded:
         from jolt_amd import distributed as _D
-        for k in _D.TIMINGS:
-            _D.TIMINGS[k] = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(label=2000 + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        shm = wl.round_exchange  # None when the ranks could not agree on a shared-memory segment (or JOLT_ROUND_EXCHANGE says otherwise)
+        primary = "shm" if (args.round_exchange == "shm" and shm is not None) else "rccl"
+        if args.round_exchange == "both" and shm is not None and world > 1:  # the exchange that is NOT reported as `value`, timed first
+            other = "shm" if primary == "rccl" else "rccl"
+            wl.round_exchange = shm if other == "shm" else None
+            exchange_ab = {other: round(timed(args.steps, args.warmup, 50000) / args.steps * 1e3, 3)}
+        wl.round_exchange = shm if primary == "shm" else None
+    dt = timed(args.steps, args.warmup, 0)
+    if exchange_ab is not None:
+        exchange_ab[primary] = round(dt / args.steps * 1e3, 3)
     ms_per_step = dt / args.steps * 1e3
     # where the step time goes: two more steps (outside the timed region) with a synchronisation after each leg
     split = None
@@ -315,8 +358,8 @@ def main():
                 + (f"sharded over the ranks by index subtree (every rank builds, folds, combines, divides and commits 1/{world} of the polynomial against its own "
                    f"bases and window tables; O(ell) field elements and points exchanged)" if pcs_sharded.subtree else
                    f"whose MSMs are split over the ranks {'block-cyclically (term i belongs to rank (i / 2^%d) mod %d; window tables over the rank own bases)' % (args.scale, world) if pcs_sharded.block else 'by term range'} (polynomial arithmetic replicated)")
-                + f"; the raw committed columns of the whole trace (52 B per cycle) are resident on every rank; the per-proof table builds of the "
-                f"N=1 step (~0.7 % of it) are not repeated per step here")
+                + f"; the raw committed columns of the whole trace (52 B per cycle) are resident on every rank; every step rebuilds the rank's "
+                f"per-proof tables (witness promotion, eq blocks, linear-leaf fusions, members) like the N=1 step")
     elif pcs:
         what = (f"BASELINE configs[2]: sha3-shaped synthetic trace, T=2^{args.scale} per GPU, sumcheck + HyperKZG end-to-end -- every step rebuilds the "
                 f"per-proof tables (witness promotion, eq / eq+1 / LT expansions, linear-leaf fusions, members), commits the {n_onehot + 2} committed columns "
@@ -352,7 +395,10 @@ def main():
         # what actually ran (a silent fallback would change what is measured): the exchange of the per-round sums and the communicator
         out["config"]["round_exchange"] = ("shm" if wl.round_exchange is not None else ("rccl" if type(wl.coll).__name__ == "NativeCollective" else "torch.distributed")) \
             + (" (JOLT_ROUND_EXCHANGE=%s)" % os.environ["JOLT_ROUND_EXCHANGE"] if os.environ.get("JOLT_ROUND_EXCHANGE") else "")
-        out["config"]["communicator"] = getattr(wl, "communicator_note", type(wl.coll).__name__)
+        out["config"]["communicator"] = getattr(wl, "communicator_note", type(wl.coll).__name__) + \
+            f"; torch.distributed backend {dist.get_backend()} with {dist.get_world_size()} rank(s)"
+        if exchange_ab is not None:  # ms per step with either exchange of the round sums, same run, same steps / warmup (`value` is the first key's)
+            out["config"]["round_exchange_ab"] = {primary: exchange_ab[primary], **{k: v for k, v in exchange_ab.items() if k != primary}}
         out["config"]["tail_log"] = wl.tail_log
         if pcs_sharded is not None:
             out["config"]["pcs"] = (f"commitments: block-cyclic shares over per-rank compact bases; opening: polynomial sharded by index subtree, per-rank window tables, partial points and O(ell) field elements through {type(wl.coll).__name__}"

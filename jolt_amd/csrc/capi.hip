@@ -376,7 +376,7 @@ extern "C" int32_t jolt_table_from_i64(jolt_ctx* ctx, const int64_t* host, size_
 extern "C" int32_t jolt_table_download(jolt_ctx* ctx, const jolt_table* t, size_t offset, size_t len, jolt_fr_t* host) {
     (void)jolt_internal_engine_quiesce(ctx);
     if (!ctx || !t || (!host && len)) return JOLT_ERR_INVALID_ARG;
-    if (offset + len > t->len) return JOLT_ERR_SIZE_MISMATCH;
+    if (len > t->len || offset > t->len - len) return JOLT_ERR_SIZE_MISMATCH;
     if (len) {
         JOLT_HIP_TRY(ctx, hipMemcpyAsync(host, t->data() + offset, len * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -406,7 +406,7 @@ extern "C" int32_t jolt_table_free(jolt_ctx* ctx, jolt_table* t) {
 
 extern "C" int32_t jolt_table_slice(jolt_ctx* ctx, const jolt_table* parent, size_t offset, size_t len, jolt_table** out) {
     if (!ctx || !parent || !out) return JOLT_ERR_INVALID_ARG;
-    if (offset + len > parent->len) return JOLT_ERR_SIZE_MISMATCH;
+    if (len > parent->len || offset > parent->len - len) return JOLT_ERR_SIZE_MISMATCH;
     jolt_table* v = new (std::nothrow) jolt_table();
     if (!v) return JOLT_ERR_OOM;
     v->ctx = ctx;
@@ -420,7 +420,7 @@ extern "C" int32_t jolt_table_slice(jolt_ctx* ctx, const jolt_table* parent, siz
 extern "C" int32_t jolt_table_write(jolt_ctx* ctx, jolt_table* t, size_t offset, const jolt_fr_t* host, size_t len) {
     (void)jolt_internal_engine_quiesce(ctx);
     if (!ctx || !t || (!host && len)) return JOLT_ERR_INVALID_ARG;
-    if (offset + len > t->len) return JOLT_ERR_SIZE_MISMATCH;
+    if (len > t->len || offset > t->len - len) return JOLT_ERR_SIZE_MISMATCH;
     if (len) {
         JOLT_HIP_TRY(ctx, hipMemcpyAsync(t->data() + offset, host, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -266,7 +266,7 @@ extern "C" int32_t jolt_hyperkzg_rlc(jolt_ctx* ctx, jolt_table* const* levels, s
     if (s != JOLT_OK) { jolt_table_free(ctx, res); return s; }
     hipLaunchKernelGGL(k_rlc, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, a, (const Fr*)dq->data(), res->data(), n);
     hipError_t e = hipGetLastError();
-    jolt_table_free(ctx, dq);  // synchronises the stream
+    jolt_table_free(ctx, dq);  // back to the pool; reused in stream order
     if (e != hipSuccess) { jolt_table_free(ctx, res); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     *out = res;
     return JOLT_OK;

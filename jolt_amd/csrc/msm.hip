@@ -170,7 +170,7 @@ extern "C" int32_t jolt_srs_len(const jolt_srs* srs, size_t* n) {
 
 extern "C" int32_t jolt_srs_download(jolt_ctx* ctx, const jolt_srs* srs, size_t offset, size_t n, jolt_g1_t* out) {
     if (!ctx || !srs || (!out && n)) return JOLT_ERR_INVALID_ARG;
-    if (offset + n > srs->n) return JOLT_ERR_SIZE_MISMATCH;
+    if (n > srs->n || offset > srs->n - n) return JOLT_ERR_SIZE_MISMATCH;
     if (!n) return JOLT_OK;
     G1Jac* tmp = nullptr;
     JOLT_HIP_TRY(ctx, hipMalloc((void**)&tmp, n * sizeof(G1Jac)));
@@ -390,8 +390,8 @@ extern "C" int32_t jolt_msm_g1_table(jolt_ctx* ctx, const jolt_srs* srs, const j
 extern "C" int32_t jolt_msm_g1_table_range(jolt_ctx* ctx, const jolt_srs* srs, size_t base_offset, const jolt_table* scalars, size_t scalar_offset, size_t n,
                                            jolt_g1_t* out) {
     if (!ctx || !srs || !scalars || !out) return JOLT_ERR_INVALID_ARG;
-    if (scalar_offset + n > scalars->len) return JOLT_ERR_SIZE_MISMATCH;
-    if (base_offset + n > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+    if (n > scalars->len || scalar_offset > scalars->len - n) return JOLT_ERR_SIZE_MISMATCH;
+    if (n > srs->n || base_offset > srs->n - n) return JOLT_ERR_SRS_TOO_SMALL;
     const jolt_srs view = jolt_srs_range_view(*srs, base_offset);
     G1Jac r;
     JOLT_TRY(jolt_internal_msm(ctx, &view, scalars->data() + scalar_offset, n, &r));

@@ -259,7 +259,7 @@ extern "C" int32_t jolt_rows_free(jolt_ctx* ctx, jolt_rows* r) {
 
 extern "C" int32_t jolt_table_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table** out) {
     if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
-    if (!(width == 1 || width == 2 || width == 4 || width == 8) || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     jolt_table* t = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, rows->n_rows, &t));
@@ -274,7 +274,7 @@ extern "C" int32_t jolt_table_from_rows(jolt_ctx* ctx, const jolt_rows* rows, si
 extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
                                          uint32_t log_k, size_t valid_offset, jolt_onehot** out) {
     if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
-    if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;  // log_k = 8: 16-bit indices
+    if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;  // log_k = 8: 16-bit indices
     if (valid_offset != ~(size_t)0 && valid_offset >= rows->row_bytes) return JOLT_ERR_INVALID_ARG;
     ChunkShifts sh;
     for (size_t p = 0; p < (size_t)kMaxBatchTables; ++p) {
@@ -308,7 +308,7 @@ extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, s
 extern "C" int32_t jolt_table_from_rows_window(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, int32_t lookahead, size_t cycles,
                                                int64_t padding_value, int64_t none_value, jolt_table** out) {
     if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
-    if (!(width == 1 || width == 2 || width == 4 || width == 8) || offset + width > rows->row_bytes || (lookahead != 0 && lookahead != 1)) return JOLT_ERR_INVALID_ARG;
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || width > rows->row_bytes || offset > rows->row_bytes - width || (lookahead != 0 && lookahead != 1)) return JOLT_ERR_INVALID_ARG;
     if (rows->n_rows > cycles) return JOLT_ERR_SIZE_MISMATCH;  // rows.rs:44-53: the physical trace must fit the cycle domain
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     jolt_table* t = nullptr;
@@ -326,7 +326,7 @@ extern "C" int32_t jolt_table_from_rows_window(jolt_ctx* ctx, const jolt_rows* r
 extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
                                                   uint32_t log_k, size_t cycles, jolt_onehot** out) {
     if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
-    if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || offset + width > rows->row_bytes) return JOLT_ERR_INVALID_ARG;
+    if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;
     if (rows->n_rows > cycles || cycles == 0) return JOLT_ERR_SIZE_MISMATCH;
     ChunkShifts sh;
     for (size_t p = 0; p < (size_t)kMaxBatchTables; ++p) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_promote_ints(const void* __restrict_
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int32_t jolt_table_from_ints(jolt_ctx* ctx, const jolt_ints* values, size_t offset, size_t len, jolt_table** out) {
     if (!ctx || !values || !out) return JOLT_ERR_INVALID_ARG;
-    if (offset + len > values->count) return JOLT_ERR_SIZE_MISMATCH;
+    if (len > values->count || offset > values->count - len) return JOLT_ERR_SIZE_MISMATCH;
     jolt_table* t = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, len, &t));
     if (len) {

@@ -485,7 +485,7 @@ class ShardedWorkload:
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
         self.resolver = W.Resolver(spec["gammas"], one, ffi.host_fr_mul, lambda x: ffi.host_fr_sub(zero, x))
-        self.tables = {}
+        self.spec = spec
         skip = {ms.tables[0] for ms in self.members_spec if ms.uniform is not None or ms.eq_inner is not None}
         skip -= {t for ms in self.members_spec for t in (ms.tables if (ms.uniform is None and ms.eq_inner is None) else ms.tables[1:])}
         # one-hot selector columns of uniform members stay index-encoded on every rank (lazily bound members, as on one GPU)
@@ -493,7 +493,49 @@ class ShardedWorkload:
         lazy = lambda ms: (ms.uniform is not None and n_local - self.tail_log >= 4
                            and all(spec["tables"][t]["kind"] == "onehot" for t in ms.tables[1:]))
         skip |= {t for ms in self.members_spec if lazy(ms) for t in ms.tables[1:]}
-        self.sources = []
+        self._skip, self._lazy_ms = skip, lazy
+        # ---- resident inputs (the witness of this rank's block): integer columns, hot indices of the lazy members
+        self.ints, self.sources, self.scale_tables = {}, {}, {}
+        for name, t in spec["tables"].items():
+            if name not in skip and t["kind"] in ("u64", "i64"):
+                self.ints[name] = ctx.ints(t["data"].astype(np.uint64 if t["kind"] == "u64" else np.int64))
+        for k, ms in enumerate(self.members_spec):
+            if lazy(ms):
+                specs = [spec["tables"][t] for t in ms.tables[1:]]
+                self.sources[k] = ctx.onehot(np.stack([sp["data"] for sp in specs]), 1 << len(specs[0]["point"]))
+        self.batch_coeffs = spec["batch_coeffs"]
+        self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
+        self.tables, self.members, self.infos, self.stages, self.prepared = {}, [], [], {}, False
+        self._tails = {}
+        self.prepare()
+        # global input claims = sum over ranks of the local claims (one all-gather at setup; in the real prover they are
+        # the previous stage's output claims)
+        local_claims = np.stack([self._local_claim(i) for i in range(len(self.members))])
+        allc = self.coll.all_gather_u64(local_claims).reshape(world, len(self.members), 4)
+        zero = np.zeros(4, dtype=np.uint64)
+        self.claims = []
+        for i in range(len(self.members)):
+            acc = zero
+            for r in range(world):
+                acc = ffi.host_fr_add(acc, allc[r, i])
+            self.claims.append(acc)
+
+    def release(self):
+        for m in self.members:
+            m.destroy()
+        for t in self.tables.values():
+            t.free()
+        self.tables, self.members, self.infos, self.stages, self.prepared = {}, [], [], {}, False
+
+    def prepare(self):
+        """Everything a proof builds before its first round, on every rank (the N = 1 step's `prepare`, DeviceWorkload.prepare): the rank's
+        block of every derived table, the promoted witness columns, the linear-leaf fusions and the members over them."""
+        if self.prepared:
+            self.release()
+        ctx, spec, rank, world, n_local = self.ctx, self.spec, self.rank, self.world, self.n_local
+        log_g = world.bit_length() - 1
+        one = ffi.host_fr_from_u64(1)
+        skip, lazy = self._skip, self._lazy_ms
         for name, t in spec["tables"].items():
             if name in skip:
                 continue
@@ -505,13 +547,10 @@ class ShardedWorkload:
                 st.free()
                 src.free()
                 continue
-            if t["kind"] == "u64":
-                self.tables[name] = ctx.from_u64(t["data"])
-            elif t["kind"] == "i64":
-                self.tables[name] = ctx.from_i64(t["data"])
+            if t["kind"] in ("u64", "i64"):
+                self.tables[name] = ctx.table_from_ints(self.ints[name])
             else:  # the aligned block of eq(point, .) owned by this rank (EqPolynomial::evals_for_aligned_block)
                 self.tables[name] = ctx.eq_evals_aligned_block(t["point"], rank << n_local, 1 << n_local)
-        self.members, self.infos, self.stages = [], [], {}
         def shard_scale_of(w):
             sc = one
             for j in range(log_g):  # eq(w_hi, rank), big-endian
@@ -527,17 +566,12 @@ class ShardedWorkload:
                 coeffs = [self.resolver.coeff(c) for c in csyms]
                 if lazy(ms):
                     specs = [spec["tables"][t] for t in ms.tables[1:]]
-                    src = ctx.onehot(np.stack([sp["data"] for sp in specs]), 1 << len(specs[0]["point"]))
-                    scale_tables = []
-                    for sp in specs:
-                        st = ctx.eq_evals(sp["point"])
-                        scale_tables.append(st.download())
-                        st.free()
-                    m = ctx.member_lazy_ra_uniform(src, np.stack(scale_tables), V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w))
-                    self.sources.append(src)
+                    src = self.sources[k]
+                    scale_tables = np.stack([ffi.host_eq_evals(sp["point"]) for sp in specs])  # eq(r_chunk, .) over K = 16 entries, on the host
+                    m = ctx.member_lazy_ra_uniform(src, scale_tables, V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w))
                     # the tables this member hands over to the tail carry c_v folded into the first factor of product v
                     m._uniform = (V, F, [one] * V)
-                    m._lazy = (src, np.stack(scale_tables), coeffs)
+                    m._lazy = (src, scale_tables, coeffs)
                 else:
                     m = ctx.member_split_eq_uniform(tabs[1:], V, F, coeffs, w[log_g:], shard_scale=shard_scale_of(w), borrow=True)
                     m._uniform = (V, F, coeffs)
@@ -592,20 +626,7 @@ class ShardedWorkload:
                 self.infos.append(MemberInfo(KIND_EXPR_SKIP, ms.degree, self.n_total, len(tabs)))
             self.members.append(m)
             self.stages.setdefault(ms.stage, []).append(len(self.members) - 1)
-        ctx.synchronize()
-        # global input claims = sum over ranks of the local claims (one all-gather at setup; in the real prover they are
-        # the previous stage's output claims)
-        local_claims = np.stack([self._local_claim(i) for i in range(len(self.members))])
-        allc = self.coll.all_gather_u64(local_claims).reshape(world, len(self.members), 4)
-        self.claims = []
-        for i in range(len(self.members)):
-            acc = zero
-            for r in range(world):
-                acc = ffi.host_fr_add(acc, allc[r, i])
-            self.claims.append(acc)
-        self.batch_coeffs = spec["batch_coeffs"]
-        self.n_tables = sum(len(ms.tables) for ms in self.members_spec)
-        self._tails = {}
+        self.prepared = True
 
     def _local_claim(self, i):
         """This rank's share of member i's input claim.  Split-eq members are summed against the rank's aligned block of the
@@ -785,10 +806,16 @@ class ShardedPcs:
         self.rlc_onehot = rand_fr(sum(s.n_polys for s in self.sources), prng)
         self.rlc_dense = rand_fr(len(self.dense_ints), prng)
         self.open_point = rand_fr(self.grid_vars, prng)
+        self.dense_tables = []
+
+    def _promote_dense(self):
+        """The global dense columns as field tables (commit's MSM scalars and a term of the joint polynomial); freed by open()."""
+        if not self.dense_tables:
+            self.dense_tables = [self.ctx.table_from_ints(d) for d in self.dense_ints]
 
     def commit(self):
         ctx, lo = self.ctx, self.rank * self.T_local
-        self.dense_tables = [ctx.table_from_ints(d) for d in self.dense_ints]  # the global columns, promoted (needed by the joint polynomial too)
+        self._promote_dense()
         parts = []
         base_lo = 0 if self.block else lo  # compact SRS: the rank's cycles of address row 0 are its first T_local bases
         for t in self.dense_tables:
@@ -818,6 +845,7 @@ class ShardedPcs:
 
     def open(self, label=0):
         ctx = self.ctx
+        self._promote_dense()  # open() without a preceding commit(), or twice in a row: the columns are promoted again
         if self.subtree:
             joint = ctx.grid_joint_polynomial_subtree(self.sources, self.rlc_onehot, self.dense_tables, self.rlc_dense, self.log_k, self.rank, self.world)
             out = ctx.hyperkzg_open_subtree(self.srs_open, joint, self.open_point, label, self.rank, self.world, self.gather_fn, self.gather_user)

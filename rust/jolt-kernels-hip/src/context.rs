@@ -10,6 +10,8 @@ use crate::status::{check, HipError};
 /// `jolt_ctx`: device + stream + scratch.  One per GPU per process; ranks shard the hypercube (`DESIGN.md` section 6).
 pub struct HipContext {
     pub(crate) raw: *mut ffi::jolt_ctx,
+    /// Serialises entry points that may be reached from several host threads at once (`JoltGroup::msm` under rayon): see `exclusive`.
+    device: std::sync::Mutex<()>,
 }
 
 // SAFETY: the C library serialises nothing internally, so a context is used from one thread at a time (`prove_batch` is
@@ -22,7 +24,13 @@ impl HipContext {
         let mut raw = ptr::null_mut();
         // SAFETY: `raw` is a valid out-pointer; a null stream asks the library to create its own.
         check(unsafe { ffi::jolt_ctx_create(device_id, ptr::null_mut(), &mut raw) }, ptr::null())?;
-        Ok(Arc::new(Self { raw }))
+        Ok(Arc::new(Self { raw, device: std::sync::Mutex::new(()) }))
+    }
+
+    /// The context's device lock.  `prove_batch` drives its members from one thread and never needs it; callers that ARE concurrent
+    /// (the MSM drop-in, `msm.rs`) hold it across their device call.  A poisoned lock is taken over: the guarded state is `()`.
+    pub(crate) fn exclusive(&self) -> std::sync::MutexGuard<'_, ()> {
+        self.device.lock().unwrap_or_else(std::sync::PoisonError::into_inner)
     }
 
     pub fn synchronize(&self) -> Result<(), HipError> {

@@ -2,8 +2,10 @@
 //!
 //! HyperKZG only ever multiplies prefixes of one long-lived `g1_powers` vector (`crates/jolt-hyperkzg/src/kzg.rs:19-26,114`), whose
 //! field is `pub(crate)` (`types.rs:105-108`): an out-of-crate backend sees it only as the `bases` argument.  The device copy is
-//! therefore cached by `(bases.as_ptr(), len)`: the first MSM over a base vector uploads it (converted to affine ONCE, where the
-//! reference converts every base on every call, `bn254/mod.rs:205`), later prefix MSMs reuse it.
+//! therefore cached by (context, `bases.as_ptr()`) with a content fingerprint (first / last base) checked on every hit: the first MSM
+//! over a base vector uploads it (converted to affine ONCE, where the reference converts every base on every call, `bn254/mod.rs:205`),
+//! later prefix MSMs reuse it.  Entries are released by `msm_cache_evict` / `msm_cache_clear` (call the former when the prover setup
+//! that owns `g1_powers` is dropped).  A prover that can keep a handle next to its setup should hold a `HipSrs` directly instead.
 use std::collections::HashMap;
 use std::ptr;
 use std::sync::{Arc, Mutex, OnceLock};
@@ -64,35 +66,106 @@ impl Drop for HipSrs {
     }
 }
 
-fn cache() -> &'static Mutex<HashMap<(usize, usize), Arc<HipSrs>>> {
-    static CACHE: OnceLock<Mutex<HashMap<(usize, usize), Arc<HipSrs>>>> = OnceLock::new();
+/// The context as the MSM drop-in shares it between rayon workers.  `HipContext` is `Send` but deliberately not `Sync` (its other
+/// methods assume one thread at a time); the ONLY operation reachable through a `SharedMsmContext` is `msm_g1`, which holds the
+/// context's device lock from the cache lookup to the end of the device call.
+pub struct SharedMsmContext(Arc<HipContext>);
+
+// SAFETY: every use of the inner context through this wrapper happens under `HipContext::exclusive` (see `msm_g1`).
+unsafe impl Send for SharedMsmContext {}
+unsafe impl Sync for SharedMsmContext {}
+
+impl SharedMsmContext {
+    pub fn new(ctx: &Arc<HipContext>) -> Self {
+        Self(Arc::clone(ctx))
+    }
+}
+
+/// What identifies a cached base vector: the context it was uploaded to, where the host slice starts, and a fingerprint of its
+/// content (first and last base, 96 bytes each) so that a NEW vector that happens to land at a freed vector's address (a second setup
+/// with another beta, tests in one process) is not served from the stale device copy.
+#[derive(Clone, PartialEq, Eq, Hash)]
+struct SrsKey {
+    ctx: usize,
+    ptr: usize,
+}
+
+struct SrsEntry {
+    len: usize,
+    first: [u8; 96],
+    last: [u8; 96],
+    /// `HipSrs` is `Send` only (one context, one thread at a time): the `Mutex` is what makes the cached handle shareable, and it is
+    /// held across the whole device MSM -- see `msm_g1`.
+    srs: Arc<Mutex<HipSrs>>,
+}
+
+fn base_bytes(b: &Bn254G1) -> [u8; 96] {
+    let mut out = [0u8; 96];
+    // SAFETY: `Bn254G1` is `#[repr(transparent)]` over three Montgomery Fq = 96 plain bytes (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24).
+    unsafe { ptr::copy_nonoverlapping((b as *const Bn254G1).cast::<u8>(), out.as_mut_ptr(), 96) };
+    out
+}
+
+fn cache() -> &'static Mutex<HashMap<SrsKey, SrsEntry>> {
+    static CACHE: OnceLock<Mutex<HashMap<SrsKey, SrsEntry>>> = OnceLock::new();
     CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+}
+
+/// Releases the device copy (bases + window tables) of a base vector, e.g. from the `Drop` of the prover setup that owns `g1_powers`.
+/// Without it an entry lives until `msm_cache_clear` or until a different vector is seen at the same address.
+pub fn msm_cache_evict(ctx: &SharedMsmContext, bases: &[Bn254G1]) {
+    let ctx = &ctx.0;
+    if let Ok(mut map) = cache().lock() {
+        let _ = map.remove(&SrsKey { ctx: ctx.raw as usize, ptr: bases.as_ptr() as usize });
+    }
+}
+
+/// Drops every cached device SRS (all contexts).
+pub fn msm_cache_clear() {
+    if let Ok(mut map) = cache().lock() {
+        map.clear();
+    }
 }
 
 /// Drop-in body for `impl JoltGroup for Bn254G1 { fn msm(..) }`: same panic on a length mismatch, the device result on success,
 /// `None` when the device path is unavailable (the caller keeps arkworks' `VariableBaseMSM`).
 ///
-/// Prefix reuse: a base slice that starts where a cached vector starts and is no longer than it is served from that vector.
+/// Prefix reuse: a base slice that starts where a cached vector of the SAME context starts, is no longer than it and has the same
+/// first base is served from that vector (`kzg_commit` / `kzg_open_batch` only ever pass prefixes of `g1_powers`).
+///
+/// Concurrency: the reference calls `msm` from rayon workers (`HyperKZGScheme::open` commits the levels with
+/// `polys.par_iter().skip(1).map(kzg_commit)`, scheme.rs:141-145), while a `jolt_ctx` is used by one thread at a time (its MSM lanes,
+/// workspace and pinned result buffer are per context).  Device MSMs are therefore serialised per context: the context's lock is held
+/// from the cache lookup to the end of `jolt_msm_g1`.  The MSM itself fills the GPU; concurrent callers only queue.
 #[must_use]
-pub fn msm_g1(ctx: &Arc<HipContext>, bases: &[Bn254G1], scalars: &[Fr]) -> Option<Bn254G1> {
+pub fn msm_g1(ctx: &SharedMsmContext, bases: &[Bn254G1], scalars: &[Fr]) -> Option<Bn254G1> {
+    let ctx = &ctx.0;
     assert_eq!(bases.len(), scalars.len(), "msm: bases/scalars length mismatch"); // group.rs:66-69
     if bases.is_empty() {
         return Some(Bn254G1::default());
     }
-    let key_ptr = bases.as_ptr() as usize;
+    let _device = ctx.exclusive(); // one device call at a time per context
+    let key = SrsKey { ctx: ctx.raw as usize, ptr: bases.as_ptr() as usize };
+    let first = base_bytes(&bases[0]);
     let srs = {
         let mut map = cache().lock().ok()?;
-        let hit = map.iter().find(|((p, len), _)| *p == key_ptr && *len >= bases.len()).map(|(_, v)| Arc::clone(v));
-        match hit {
-            Some(v) => v,
-            None => {
-                let v = Arc::new(HipSrs::upload(ctx, bases).ok()?);
-                let _ = map.insert((key_ptr, bases.len()), Arc::clone(&v));
-                v
-            }
+        let usable = match map.get(&key) {
+            // a prefix of the cached vector: same start, not longer, same first base -- and, when the lengths agree, the same last base
+            Some(e) => e.first == first && (bases.len() < e.len || (bases.len() == e.len && e.last == base_bytes(&bases[bases.len() - 1]))),
+            None => false,
+        };
+        if !usable {
+            // unseen, longer than the cached copy, or a different vector at a recycled address: (re)upload; the old entry is released
+            let fresh = HipSrs::upload(ctx, bases).ok()?;
+            let _ = map.insert(
+                key.clone(),
+                SrsEntry { len: bases.len(), first, last: base_bytes(&bases[bases.len() - 1]), srs: Arc::new(Mutex::new(fresh)) },
+            );
         }
+        Arc::clone(&map.get(&key)?.srs)
     };
-    srs.msm(scalars).ok()
+    let guard = srs.lock().ok()?;
+    guard.msm(scalars).ok()
 }
 
 /// One rank's part of a HyperKZG prover sharded over the `world` GPUs of a node (`DESIGN.md` section 6; the reference is single

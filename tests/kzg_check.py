@@ -4,7 +4,7 @@ With bases srs[i] = beta^i * G every commitment is commit(p) = p(beta) * G, so w
   com[i-1] == P_i(beta) * G                                   level commitments (crates/jolt-hyperkzg/src/scheme.rs:141-145)
   w[t]     == ((B(beta) - B(u_t)) / (beta - u_t)) * G          witness commitments (kzg.rs:108-116; B = sum_j q^j P_j, :95-105)
   2 r v2[i+1] == r (1 - x) (v0[i] + v1[i]) + x (v0[i] - v1[i])  the verifier's folding relation (scheme.rs:210-234), v2[ell] = P(point)
-  v[t][j] == P_j(u_t)                                          by the oracle's Horner on the levels small enough to download
+  v[t][j] == P_j(u_t)                                          by the oracle's Horner over the oracle's own fold of the downloaded evaluations
 The field arithmetic of the checker is the oracle's (tests only).
 """
 import numpy as np
@@ -45,20 +45,33 @@ def check_opening(ctx, evals_table, point, proof, beta, claimed_eval, max_downlo
         lhs = _m(two_r, y_sq[i + 1])
         rhs = _a(_m(_m(r, _s(one, x)), _a(v[0][i], v[1][i])), _m(x, _s(v[0][i], v[1][i])))
         assert np.array_equal(lhs, rhs), f"folding relation fails at level {i}"
-    # --- P_j(beta): oracle Horner on downloaded levels where they fit, the device's blocked Horner above that
+    # --- P_j(beta) and v[t][j] = P_j(u_t).  When level 0 fits the download bound, EVERY level is the oracle's: level 0 downloaded once, folded by
+    # the oracle (scheme.rs:88-114), each device level compared with it entry for entry, Horner by the oracle (kzg.rs:51-59) -- nothing
+    # below comes from a device kernel.  Above the bound (callers that cannot afford 32 B x 2^ell on the host) the long levels fall
+    # back on the device's blocked Horner, checked against the oracle on the levels that do fit.
     levels = ctx.hyperkzg_fold(evals_table, point)
-    dev_beta = ctx.hyperkzg_eval3(levels, np.stack([beta, beta, beta]))[0]
     p_beta = []
-    for j, lvl in enumerate(levels):
-        if len(lvl) <= (1 << max_download_log):
-            host = lvl.download()
-            pb = O.kzg_eval_univariate(host, beta)
-            assert np.array_equal(pb, dev_beta[j]), f"device Horner differs from the oracle at level {j}"
+    if len(levels[0]) <= (1 << max_download_log):
+        host_levels = O.hyperkzg_fold_polynomials(levels[0].download(), point)
+        assert np.array_equal(O.poly_evaluate(host_levels[0], point), claimed_eval), "claimed evaluation differs from the oracle's (dense.rs:340-366)"
+        for j, lvl in enumerate(levels):
+            assert np.array_equal(lvl.download(), host_levels[j]), f"device fold differs from the oracle at level {j}"
+            p_beta.append(O.kzg_eval_univariate(host_levels[j], beta))
             for t in range(3):
-                assert np.array_equal(v[t][j], O.kzg_eval_univariate(host, u[t])), f"v[{t}][{j}]"
-            p_beta.append(pb)
-        else:
-            p_beta.append(dev_beta[j])
+                assert np.array_equal(v[t][j], O.kzg_eval_univariate(host_levels[j], u[t])), f"v[{t}][{j}]"
+        del host_levels
+    else:
+        dev_beta = ctx.hyperkzg_eval3(levels, np.stack([beta, beta, beta]))[0]
+        for j, lvl in enumerate(levels):
+            if len(lvl) <= (1 << max_download_log):
+                host = lvl.download()
+                pb = O.kzg_eval_univariate(host, beta)
+                assert np.array_equal(pb, dev_beta[j]), f"device Horner differs from the oracle at level {j}"
+                for t in range(3):
+                    assert np.array_equal(v[t][j], O.kzg_eval_univariate(host, u[t])), f"v[{t}][{j}]"
+                p_beta.append(pb)
+            else:
+                p_beta.append(dev_beta[j])
     for lvl in levels:
         lvl.free()
     # --- level commitments

@@ -5,9 +5,9 @@ witness commitments, the combined commitment), and both ranks must return the sa
 
     python tools/check_subtree_scale.py [n_local = 18]
 
-Not part of the pytest suite: rank 0's check runs the oracle's Horner over 2^22-coefficient levels (minutes on the box's host cores)
-while the other rank waits; NOT YET RUN on a GPU box (written when the round's GPU budget was spent) -- the suite covers the same code
-against the oracle's full proof up to 2^16 coefficients (tests/test_gpu_distributed.py)."""
+Not part of the pytest suite: rank 0's check downloads the GLOBAL joint polynomial (2^(n_local + 5) coefficients), folds it and runs
+every Horner pass on the oracle while the other rank waits.  The suite covers the same code against the oracle's full proof up to
+2^16 coefficients (tests/test_gpu_distributed.py); tools/collect_round.sh runs this script and keeps its output under profiles/."""
 import os
 import sys
 import tempfile
@@ -46,7 +46,7 @@ def _pcs_scale_worker(rank, world, port, tmpdir, n_local):
         tables = [ctx.table_from_ints(d) for d in pcs.dense_ints]
         joint = ctx.grid_joint_polynomial(pcs.sources, pcs.rlc_onehot, tables, pcs.rlc_dense, pcs.log_k)
         claimed = ctx.evaluate(joint, pcs.open_point)
-        j_beta = check_opening(ctx, joint, pcs.open_point, out["open"], pcs.beta, claimed)
+        j_beta = check_opening(ctx, joint, pcs.open_point, out["open"], pcs.beta, claimed, max_download_log=pcs.grid_vars)  # every level from the oracle
         combined = O.g1_identity()
         for p in range(out["commit"]["onehot"].shape[0]):
             combined = O.g1_add(combined, O.g1_scalar_mul(out["commit"]["onehot"][p], pcs.rlc_onehot[p]))
