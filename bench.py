@@ -107,12 +107,20 @@ def bind_roofline(ctx, ffi, log_n, reps):
             "avg_launch_ms": round(ms, 5)}
 
 
-def cpu_baseline(log_t, srs_host, with_pcs):
+PUBLISHED_REFERENCE = {  # what the reference itself publishes (whole prover, Dory PCS, CPU; NOT this path alone, NOT this box)
+    "value": 1.5e6, "unit": "cycles/s", "what": "whole Jolt prover (all stages, Dory PCS), AMD Threadripper Pro 7975WX, 32 cores",
+    "source": "book/src/how/optimizations/inlines.md:147,151,155", "also": "~500 kHz on a MacBook M4 Max, 16 cores (same file :149-150)"}
+
+
+def cpu_baseline(log_t, srs_dev, with_pcs):
     """The same step on the host cores through the oracle's OpenMP restatement (kind = "port": the reference is Rust + rayon and
     cannot be built in this image; its arithmetic lives in an un-vendored arkworks fork): per-proof tables, the 11 relations in the
     optimized tier's fused form (skipped s(1), linear combinations folded; the RA columns dense), and -- with_pcs -- the
-    commitments on the K x T grid, the joint polynomial and ONE HyperKZG opening with a window-parallel bucket MSM.
-    A bounded sample: T = 2^log_t cycles (log_t = 0: sized from a probe to ~10-30 s), thread count calibrated at that size."""
+    commitments on the K x T grid, the joint polynomial and ONE HyperKZG opening.  The MSMs are a signed-digit XYZZ bucket method
+    scheduled as one pool of (msm, window, chunk) tasks over all host threads (oracle/g1.c orc_baseline_msm_many), the 64-bit witness
+    columns pay only their 5 windows, the one-hot columns are sums of bases (the reference's tier-1 tricks, crates/jolt-dory/src/
+    streaming.rs:115-205).  A bounded sample: T = 2^log_t cycles (log_t = 0: 2^20 when a calibration step at 2^16 predicts <= ~40 s
+    per step, else the largest T that does), thread count = the faster of all hardware threads and half of them at 2^16."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -135,8 +143,8 @@ def cpu_baseline(log_t, srs_host, with_pcs):
             self.idx = np.stack([self.spec[t].data for ms in self.members_spec if ms.uniform is not None for t in ms.tables[1:]])
             self.s_oh, self.s_d = W.rand_fr(self.idx.shape[0], prng), W.rand_fr(2, prng)
             self.point = W.rand_fr(scale + 4, prng)
-            if with_pcs:
-                self.bases = O.baseline_prepare_bases(srs_host[: K * self.T])  # affine conversion once (not timed)
+            if with_pcs:  # the first K * T powers of the device's SRS, converted to affine once (inputs, not timed)
+                self.bases = O.baseline_prepare_bases(srs_dev.download(0, K * self.T))
 
         legs = {"tables": 0.0, "sumchecks": 0.0, "pcs": 0.0}
 
@@ -154,10 +162,8 @@ def cpu_baseline(log_t, srs_host, with_pcs):
             t2 = time.perf_counter()
             if with_pcs:
                 dense = [tables["s6.ram_inc"], tables["s6.rd_inc"]]
-                for d in dense:
-                    O.baseline_msm(self.bases, d)
-                for p in range(self.idx.shape[0]):
-                    O.baseline_grid_onehot_sum(self.bases, self.idx[p])
+                O.baseline_msm_many(self.bases, dense)
+                O.baseline_grid_onehot_sums(self.bases, self.idx)
                 joint = O.baseline_grid_joint(self.idx, K, self.s_oh, dense, self.s_d)
                 O.hyperkzg_open(self.bases, joint, self.point, label=1)
             t3 = time.perf_counter()
@@ -169,26 +175,23 @@ def cpu_baseline(log_t, srs_host, with_pcs):
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     O.baseline_use_parallel_msm(True)
     try:
-        # size the sample: probe at 2^10 with a moderate thread count, then the largest T whose step should stay under ~25 s
-        O.baseline_set_threads(min(hw, 32))
-        probe_scale = 10
-        probe = Sample(probe_scale).step()
-        if log_t <= 0:
-            log_t = probe_scale
-            cap = 18 if with_pcs else 20
-            max_grid = int(np.log2(max(len(srs_host), 1))) - 4 if with_pcs else cap
-            while log_t < min(cap, max_grid) and probe * (1 << (log_t + 1 - probe_scale)) <= 12.0:
-                log_t += 1
-        smp = Sample(log_t)
+        # thread count and sample size from calibration steps at 2^16 (the round-2 sample size): all hardware threads vs half of them
+        max_grid = (int(np.log2(max(len(srs_dev), 1))) - 4) if with_pcs else 20
+        cal_scale = min(16, max_grid)
+        cal = Sample(cal_scale)
         best_n, best_t = None, None
-        for n in sorted({min(hw, 8), min(hw, 16), min(hw, 32), min(hw, 64), max(1, hw // 2), hw}, reverse=True):
+        for n in sorted({hw, max(1, hw // 2)}, reverse=True):
             O.baseline_set_threads(n)
-            t = smp.step()
-            if best_t is None or t < best_t:
+            t = cal.step()
+            if best_t is None or t < 0.97 * best_t:
                 best_n, best_t = n, t
-            if t > 30.0:
-                break
         O.baseline_set_threads(best_n)
+        if log_t <= 0:
+            log_t = cal_scale
+            while log_t < min(20, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 40.0:
+                log_t += 1
+        smp = cal if log_t == cal_scale else Sample(log_t)
+        del cal
         dt, reps = 0.0, 0
         Sample.legs = {k: 0.0 for k in Sample.legs}
         while reps == 0 or (dt < 10.0 and reps < 4):
@@ -196,14 +199,15 @@ def cpu_baseline(log_t, srs_host, with_pcs):
             reps += 1
     finally:
         O.baseline_use_parallel_msm(False)
-    pcs_note = (f" + commitments of 38 columns on the 2^{log_t + 4} grid + joint polynomial + one HyperKZG opening (bucket MSM parallel over windows x point chunks, "
-                f"affine bases prepared outside the timed region)") if with_pcs else ""
+    pcs_note = (f" + commitments of 38 columns on the 2^{log_t + 4} grid (2 MSMs of 64-bit scalars, 36 one-hot sums of bases) + joint polynomial + one HyperKZG opening "
+                f"(signed-digit XYZZ bucket MSMs, all level / witness MSMs as one pool of window x chunk tasks; affine bases prepared outside the timed region; "
+                f"Horner / RLC passes OpenMP-parallel where the reference's kzg.rs:51-105 is serial)") if with_pcs else ""
     return {"value": round(reps * (1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
             "sample": f"the same step at T=2^{log_t}: per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
-                      f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs) with OpenMP on {best_n} of {hw} host threads "
-                      f"(nproc {os.cpu_count()}; fastest of the thread counts tried at this size); {dt:.1f}s of CPU work: "
-                      f"table builds {Sample.legs['tables']:.1f}s, sumcheck legs {Sample.legs['sumchecks']:.1f}s, commit + open {Sample.legs['pcs']:.1f}s -- like the GPU step, the port "
-                      f"is bound by its MSMs; the lazily bound one-hot tier of the reference would only shorten the sumcheck legs"}
+                      f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs, ADX) with OpenMP on {best_n} of {hw} host threads "
+                      f"(nproc {os.cpu_count()}; the faster of {hw} and {max(1, hw // 2)} threads at T=2^{cal_scale}: {best_t:.2f} s per step there); {dt:.1f}s of CPU work: "
+                      f"table builds {Sample.legs['tables']:.1f}s, sumcheck legs {Sample.legs['sumchecks']:.1f}s, commit + open {Sample.legs['pcs']:.1f}s",
+            "published_reference": PUBLISHED_REFERENCE}
 
 
 def main():
@@ -411,14 +415,10 @@ def main():
         out["roofline"] = bind_roofline(ctx, ffi, args.roofline_scale, args.roofline_reps)
         if not args.no_cpu_baseline:
             try:
-                srs_host = None
-                if pcs:
-                    srs_dev = pcs_sharded.srs if sharded else wl.srs
-                    n_cpu = min(len(srs_dev), 1 << 22)  # SRS prefix for the CPU sample's grid (the bases are inputs, not product work)
-                    srs_host = srs_dev.download(0, n_cpu)
-                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_host, bool(pcs))
+                srs_dev = (pcs_sharded.srs if sharded else wl.srs) if pcs else None  # the CPU sample's grid uses a prefix of the same SRS (inputs)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs))
             except Exception as e:  # the oracle is optional infrastructure: never fail the bench on it
-                out["cpu_baseline"] = {"value": None, "unit": "cycles/s", "cores": None, "kind": "port", "sample": f"unavailable: {e}"}
+                out["cpu_baseline"] = {"value": None, "unit": "cycles/s", "cores": None, "kind": "port", "sample": f"unavailable: {e}", "published_reference": PUBLISHED_REFERENCE}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

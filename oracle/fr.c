@@ -183,8 +183,14 @@ EXPORT void orc_fq_add_vec(const fq_t *a, const fq_t *b, fq_t *o, size_t n) { fo
 EXPORT void orc_fq_sub_vec(const fq_t *a, const fq_t *b, fq_t *o, size_t n) { for (size_t i = 0; i < n; ++i) fq_sub(&o[i], &a[i], &b[i]); }
 EXPORT void orc_fq_mul_vec(const fq_t *a, const fq_t *b, fq_t *o, size_t n) { for (size_t i = 0; i < n; ++i) fq_mul(&o[i], &a[i], &b[i]); }
 EXPORT void orc_fq_inv_vec(const fq_t *a, fq_t *o, size_t n) { for (size_t i = 0; i < n; ++i) fq_inv(&o[i], &a[i]); }
-EXPORT void orc_fr_from_u64_vec(const uint64_t *v, fr_t *o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = fr_from_u64(v[i]); }
-EXPORT void orc_fr_from_i64_vec(const int64_t *v, fr_t *o, size_t n) { for (size_t i = 0; i < n; ++i) o[i] = fr_from_i64(v[i]); }
+EXPORT void orc_fr_from_u64_vec(const uint64_t *v, fr_t *o, size_t n) {
+#pragma omp parallel for schedule(static) if (n >= 65536)
+    for (size_t i = 0; i < n; ++i) o[i] = fr_from_u64(v[i]);
+}
+EXPORT void orc_fr_from_i64_vec(const int64_t *v, fr_t *o, size_t n) {
+#pragma omp parallel for schedule(static) if (n >= 65536)
+    for (size_t i = 0; i < n; ++i) o[i] = fr_from_i64(v[i]);
+}
 EXPORT void orc_fr_from_u128(uint64_t lo, uint64_t hi, fr_t *o) { *o = fr_from_u128(lo, hi); }
 EXPORT void orc_fr_from_i128(uint64_t lo, uint64_t hi, int neg, fr_t *o) { *o = fr_from_i128(lo, hi, neg); }
 EXPORT void orc_fr_mul_u64(const fr_t *a, uint64_t b, fr_t *o) { *o = fr_mul_u64(*a, b); }

@@ -242,82 +242,228 @@ EXPORT void orc_baseline_prepare_bases(const g1_t *bases, size_t n) {
     g_aff_src = bases;
     g_aff_n = n;
 }
-EXPORT void orc_baseline_msm(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out) {
-    if (n == 0) { *out = g1_identity(); return; }
-    if (!(g_aff && bases >= g_aff_src && bases + n <= g_aff_src + g_aff_n)) { orc_g1_msm_pippenger(bases, scalars, n, out); return; }
-    const g1_affine_t *aff = g_aff + (bases - g_aff_src);
-    unsigned log2n = 0;
-    while (((size_t)2 << log2n) <= n) log2n++;
-    unsigned c = n < 32 ? 3 : (log2n * 69 / 100) + 2; /* ark's window rule, as in orc_g1_msm_pippenger */
-    if (c > 16) c = 16;
-    const size_t n_buckets = ((size_t)1 << c) - 1;
-    const unsigned n_windows = (254 + c - 1) / c;
-    int threads = omp_get_max_threads();
-    unsigned chunks = 1;
-    while (n_windows * chunks < (unsigned)threads * 2 && (n / (chunks * 2)) >= 4 * n_buckets) chunks *= 2;
-    u256 *ks = (u256 *)malloc(n * sizeof(u256));
-#pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; ++i) mont_to_canonical(&ks[i], &scalars[i], &FR);
-    g1_t *wsum = (g1_t *)malloc((size_t)n_windows * chunks * sizeof(g1_t));
-#pragma omp parallel
-    {
-        g1_t *buckets = (g1_t *)malloc(n_buckets * sizeof(g1_t));
-#pragma omp for schedule(dynamic, 1) collapse(2)
-        for (unsigned w = 0; w < n_windows; ++w)
-            for (unsigned ch = 0; ch < chunks; ++ch) {
-                for (size_t b = 0; b < n_buckets; ++b) buckets[b] = g1_identity();
-                const unsigned start = w * c;
-                const size_t lo = (size_t)ch * n / chunks, hi = (size_t)(ch + 1) * n / chunks;
-                for (size_t i = lo; i < hi; ++i) {
-                    uint64_t digit = 0;
-                    for (unsigned k = 0; k < c; ++k) {
-                        unsigned bit = start + k;
-                        if (bit < 256) digit |= ((ks[i].l[bit / 64] >> (bit % 64)) & 1) << k;
-                    }
-                    if (digit) buckets[digit - 1] = g1_add_mixed(&buckets[digit - 1], &aff[i]);
-                }
-                g1_t running = g1_identity(), sum = g1_identity();
-                for (size_t b = n_buckets; b-- > 0;) {
-                    running = g1_add(&running, &buckets[b]);
-                    sum = g1_add(&sum, &running);
-                }
-                wsum[(size_t)w * chunks + ch] = sum;
-            }
-        free(buckets);
+/* XYZZ accumulators (x = X / ZZ, y = Y / ZZZ, identity <=> ZZ == 0): madd-2008-s costs 8M + 2S against the 7M + 4S of the Jacobian
+ * mixed addition and has no doubling-shaped dependency chain; this is the accumulator GPU and CPU bucket MSMs converged on. */
+typedef struct { fq_t x, y, zz, zzz; } g1_xyzz_t;
+static inline void xyzz_set_identity(g1_xyzz_t *p) { memset(p, 0, sizeof *p); }
+static inline int xyzz_is_identity(const g1_xyzz_t *p) { return u256_is_zero(&p->zz); }
+/* acc += (qx, +-qy), q affine and not infinity */
+static inline void xyzz_add_mixed(g1_xyzz_t *acc, const fq_t *qx, const fq_t *qy_in, int negate) {
+    fq_t qy = negate ? QNEG(*qy_in) : *qy_in;
+    if (xyzz_is_identity(acc)) { acc->x = *qx; acc->y = qy; acc->zz = FQ.r; acc->zzz = FQ.r; return; }
+    fq_t U2 = QMUL(*qx, acc->zz), S2 = QMUL(qy, acc->zzz);
+    fq_t P = QSUB(U2, acc->x), R = QSUB(S2, acc->y);
+    if (u256_is_zero(&P)) {
+        if (!u256_is_zero(&R)) { xyzz_set_identity(acc); return; }
+        /* mdbl-2008-s-1: doubling of the affine point */
+        fq_t U = QDBL(qy), V = QSQR(U), W = QMUL(U, V), S = QMUL(*qx, V);
+        fq_t X2 = QSQR(*qx), M = QADD(QDBL(X2), X2);
+        acc->x = QSUB(QSQR(M), QDBL(S));
+        acc->y = QSUB(QMUL(M, QSUB(S, acc->x)), QMUL(W, qy));
+        acc->zz = V; acc->zzz = W;
+        return;
     }
-    g1_t total = g1_identity();
-    for (int w = (int)n_windows - 1; w >= 0; --w) {
-        for (unsigned k = 0; k < c; ++k) total = g1_double(&total);
-        for (unsigned ch = 0; ch < chunks; ++ch) total = g1_add(&total, &wsum[(size_t)w * chunks + ch]);
-    }
-    free(wsum);
-    free(ks);
-    *out = total;
+    fq_t PP = QSQR(P), PPP = QMUL(P, PP), Q = QMUL(acc->x, PP);
+    fq_t X3 = QSUB(QSUB(QSQR(R), PPP), QDBL(Q));
+    acc->y = QSUB(QMUL(R, QSUB(Q, X3)), QMUL(acc->y, PPP));
+    acc->x = X3;
+    acc->zz = QMUL(acc->zz, PP);
+    acc->zzz = QMUL(acc->zzz, PPP);
 }
-/* sum of bases[idx[j] * cycles + j] over the hot cycles: a one-hot column's commitment on the K x T grid (additions only) */
-EXPORT void orc_baseline_grid_onehot_sum(const g1_t *bases, const uint8_t *idx, size_t cycles, g1_t *out) {
-    const g1_affine_t *aff = (g_aff && bases == g_aff_src) ? g_aff : NULL;
-    g1_t total = g1_identity();
-#pragma omp parallel
-    {
-        g1_t local = g1_identity();
-#pragma omp for schedule(static) nowait
-        for (size_t j = 0; j < cycles; ++j) {
-            if (idx[j] == 0xFF) continue;
-            size_t at = (size_t)idx[j] * cycles + j;
-            if (aff) local = g1_add_mixed(&local, &aff[at]);
-            else local = g1_add(&local, &bases[at]);
-        }
-#pragma omp critical
-        total = g1_add(&total, &local);
+/* acc += q (add-2008-s, 12M + 2S) */
+static inline void xyzz_add(g1_xyzz_t *acc, const g1_xyzz_t *q) {
+    if (xyzz_is_identity(q)) return;
+    if (xyzz_is_identity(acc)) { *acc = *q; return; }
+    fq_t U1 = QMUL(acc->x, q->zz), U2 = QMUL(q->x, acc->zz), S1 = QMUL(acc->y, q->zzz), S2 = QMUL(q->y, acc->zzz);
+    fq_t P = QSUB(U2, U1), R = QSUB(S2, S1);
+    if (u256_is_zero(&P)) {
+        if (!u256_is_zero(&R)) { xyzz_set_identity(acc); return; }
+        /* dbl-2008-s-1 */
+        fq_t U = QDBL(acc->y), V = QSQR(U), W = QMUL(U, V), S = QMUL(acc->x, V);
+        fq_t X2 = QSQR(acc->x), M = QADD(QDBL(X2), X2);
+        fq_t X3 = QSUB(QSQR(M), QDBL(S));
+        acc->y = QSUB(QMUL(M, QSUB(S, X3)), QMUL(W, acc->y));
+        acc->x = X3;
+        acc->zz = QMUL(V, acc->zz); acc->zzz = QMUL(W, acc->zzz);
+        return;
     }
-    *out = total;
+    fq_t PP = QSQR(P), PPP = QMUL(P, PP), Q = QMUL(U1, PP);
+    fq_t X3 = QSUB(QSUB(QSQR(R), PPP), QDBL(Q));
+    acc->y = QSUB(QMUL(R, QSUB(Q, X3)), QMUL(S1, PPP));
+    acc->x = X3;
+    acc->zz = QMUL(QMUL(acc->zz, q->zz), PP);
+    acc->zzz = QMUL(QMUL(acc->zzz, q->zzz), PPP);
+}
+/* (X, Y, ZZ, ZZZ) -> Jacobian with Z = ZZ: X' = X ZZ, Y' = Y ZZZ (ZZ^3 = ZZZ^2) */
+static inline g1_t xyzz_to_jacobian(const g1_xyzz_t *p) {
+    if (xyzz_is_identity(p)) return g1_identity();
+    g1_t r; r.x = QMUL(p->x, p->zz); r.y = QMUL(p->y, p->zzz); r.z = p->zz; return r;
 }
 
+/* Several MSMs over prefixes of the prepared bases as ONE pool of (msm, window, chunk) tasks scheduled dynamically over the host
+ * threads -- what the reference gets from nested rayon parallelism (scheme.rs:141-145 commits the levels with par_iter; arkworks'
+ * msm runs its windows in parallel under that).  Per MSM: ark's window rule capped at 16 bits, SIGNED digits (window value minus
+ * 2^(c-1) of s + sum_w 2^(c-1) 2^(cw): carry-free per window, 2^(c-1) buckets), XYZZ buckets, windows above the scalars' top bit
+ * skipped (64-bit witness columns cost 5 windows, not 16), chunks sized so that the pool has >= 4 tasks per thread while a chunk
+ * still holds >= 8 points per bucket.  Same group elements as orc_g1_msm_pippenger (tests/test_oracle_g1.py). */
+typedef struct { unsigned msm, window, chunk; } msm_task;
+EXPORT void orc_baseline_msm_many(const g1_t *bases, const fr_t *const *scalars, const size_t *lens, size_t count, g1_t *out) {
+    if (count == 0) return;
+    size_t max_n = 0;
+    for (size_t i = 0; i < count; ++i) if (lens[i] > max_n) max_n = lens[i];
+    if (!(g_aff && bases >= g_aff_src && bases + max_n <= g_aff_src + g_aff_n)) { /* bases not prepared: the serial restatement */
+        for (size_t i = 0; i < count; ++i) orc_g1_msm_pippenger(bases, scalars[i], lens[i], &out[i]);
+        return;
+    }
+    const g1_affine_t *aff = g_aff + (bases - g_aff_src);
+    const int threads = omp_get_max_threads();
+    unsigned *cs = (unsigned *)malloc(count * sizeof(unsigned)), *ws = (unsigned *)malloc(count * sizeof(unsigned)), *chs = (unsigned *)malloc(count * sizeof(unsigned));
+    u256 **ks = (u256 **)malloc(count * sizeof(u256 *));
+    size_t total_work = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const size_t n = lens[i];
+        ks[i] = (u256 *)malloc((n ? n : 1) * sizeof(u256));
+        unsigned log2n = 0;
+        while (((size_t)2 << log2n) <= n) log2n++;
+        unsigned c = n < 32 ? 3 : (log2n * 69 / 100) + 2; /* ark's window rule, as in orc_g1_msm_pippenger */
+        if (c > 16) c = 16;
+        cs[i] = c;
+        /* canonical scalars + the half-window offsets; top bit over the MSM */
+        u256 half;
+        memset(&half, 0, sizeof half);
+        for (unsigned bit = c - 1; bit < 256; bit += c) half.l[bit / 64] |= (uint64_t)1 << (bit % 64);
+        unsigned top = 0;
+#pragma omp parallel for schedule(static) reduction(max : top)
+        for (size_t j = 0; j < n; ++j) {
+            u256 k;
+            mont_to_canonical(&k, &scalars[i][j], &FR);
+            unsigned b = 0;
+            for (int l = 3; l >= 0; --l) if (k.l[l]) { b = 64 * (unsigned)l + 64 - (unsigned)__builtin_clzll(k.l[l]); break; }
+            if (b > top) top = b;
+            unsigned __int128 carry = 0;
+            for (int l = 0; l < 4; ++l) { carry += (unsigned __int128)k.l[l] + half.l[l]; k.l[l] = (uint64_t)carry; carry >>= 64; }
+            ks[i][j] = k;
+        }
+        unsigned full = (256 + c - 1) / c;            /* windows covering s + half < 2^256 */
+        unsigned need = top / c + 2;                   /* the window holding the top bit and the one its carry may reach */
+        ws[i] = need < full ? need : full;
+        total_work += n * ws[i];
+    }
+    /* chunks: aim at 4 tasks per thread over the pool, keep >= 8 points per bucket in a chunk */
+    size_t n_tasks = 0;
+    const size_t target = total_work / ((size_t)threads * 4) + 1; /* point-window units per task */
+    for (size_t i = 0; i < count; ++i) {
+        const size_t buckets = (size_t)1 << (cs[i] - 1);
+        size_t ch = lens[i] / (target > 8 * buckets ? target : 8 * buckets);
+        if (ch < 1) ch = 1;
+        chs[i] = (unsigned)ch;
+        n_tasks += (size_t)ws[i] * ch;
+    }
+    msm_task *tasks = (msm_task *)malloc((n_tasks ? n_tasks : 1) * sizeof(msm_task));
+    g1_xyzz_t *partial = (g1_xyzz_t *)malloc((n_tasks ? n_tasks : 1) * sizeof(g1_xyzz_t));
+    size_t *first_task = (size_t *)malloc(count * sizeof(size_t));
+    size_t t = 0;
+    for (size_t i = 0; i < count; ++i) { /* long MSMs first: their tasks are the longest */
+        first_task[i] = t;
+        for (unsigned w = 0; w < ws[i]; ++w)
+            for (unsigned ch = 0; ch < chs[i]; ++ch) { tasks[t].msm = (unsigned)i; tasks[t].window = w; tasks[t].chunk = ch; ++t; }
+    }
+#pragma omp parallel
+    {
+        g1_xyzz_t *buckets = (g1_xyzz_t *)malloc(((size_t)1 << 15) * sizeof(g1_xyzz_t));
+#pragma omp for schedule(dynamic, 1)
+        for (size_t k = 0; k < n_tasks; ++k) {
+            const unsigned i = tasks[k].msm, w = tasks[k].window, c = cs[i];
+            const size_t n = lens[i], nb = (size_t)1 << (c - 1);
+            const size_t lo = (size_t)tasks[k].chunk * n / chs[i], hi = (size_t)(tasks[k].chunk + 1) * n / chs[i];
+            for (size_t b = 0; b < nb; ++b) xyzz_set_identity(&buckets[b]);
+            const unsigned start = w * c, limb = start / 64, shift = start % 64;
+            const uint64_t mask = ((uint64_t)1 << c) - 1;
+            const u256 *k256 = ks[i];
+            for (size_t j = lo; j < hi; ++j) {
+                uint64_t v = k256[j].l[limb] >> shift;
+                if (shift + c > 64 && limb < 3) v |= k256[j].l[limb + 1] << (64 - shift);
+                /* a top window whose half-window bit would lie beyond bit 255 carries no offset: its value (< 2^(256 - start) <= nb) is the digit */
+                const int64_t d = (int64_t)(v & mask) - (start + c - 1 < 256 ? (int64_t)nb : 0);
+                if (d == 0) continue;
+                const g1_affine_t *q = &aff[j];
+                if (aff_is_inf(q)) continue;
+                if (d > 0) xyzz_add_mixed(&buckets[d - 1], &q->x, &q->y, 0);
+                else xyzz_add_mixed(&buckets[-d - 1], &q->x, &q->y, 1);
+            }
+            g1_xyzz_t running, sum;
+            xyzz_set_identity(&running);
+            xyzz_set_identity(&sum);
+            for (size_t b = nb; b-- > 0;) {
+                xyzz_add(&running, &buckets[b]);
+                xyzz_add(&sum, &running);
+            }
+            partial[k] = sum;
+        }
+        free(buckets);
+    }
+    for (size_t i = 0; i < count; ++i) {
+        g1_t total = g1_identity();
+        for (int w = (int)ws[i] - 1; w >= 0; --w) {
+            for (unsigned k = 0; k < cs[i]; ++k) total = g1_double(&total);
+            g1_xyzz_t wsum;
+            xyzz_set_identity(&wsum);
+            for (unsigned ch = 0; ch < chs[i]; ++ch) xyzz_add(&wsum, &partial[first_task[i] + (size_t)w * chs[i] + ch]);
+            g1_t wj = xyzz_to_jacobian(&wsum);
+            total = g1_add(&total, &wj);
+        }
+        out[i] = total;
+        free(ks[i]);
+    }
+    free(first_task); free(partial); free(tasks); free(ks); free(chs); free(ws); free(cs);
+}
+EXPORT void orc_baseline_msm(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out) {
+    if (n == 0) { *out = g1_identity(); return; }
+    orc_baseline_msm_many(bases, &scalars, &n, 1, out);
+}
+/* sums of bases[idx[p][j] * cycles + j] over the hot cycles of each column p: the one-hot columns' commitments on the K x T grid
+ * (additions only -- the reference's tier-1 one-hot path, crates/jolt-dory/src/streaming.rs:160-205), all columns as one task pool */
+EXPORT void orc_baseline_grid_onehot_sums(const g1_t *bases, const uint8_t *idx, size_t n_polys, size_t cycles, g1_t *out) {
+    const g1_affine_t *aff = (g_aff && bases == g_aff_src) ? g_aff : NULL;
+    if (!aff) { for (size_t p = 0; p < n_polys; ++p) out[p] = g1_identity(); return; }
+    const int threads = omp_get_max_threads();
+    size_t chunks = ((size_t)threads * 4 + n_polys - 1) / (n_polys ? n_polys : 1);
+    if (chunks < 1) chunks = 1;
+    while (chunks > 1 && cycles / chunks < 1024) chunks /= 2;
+    g1_xyzz_t *partial = (g1_xyzz_t *)malloc(n_polys * chunks * sizeof(g1_xyzz_t));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < n_polys * chunks; ++k) {
+        const size_t p = k / chunks, ch = k % chunks, lo = ch * cycles / chunks, hi = (ch + 1) * cycles / chunks;
+        const uint8_t *col = idx + p * cycles;
+        g1_xyzz_t acc;
+        xyzz_set_identity(&acc);
+        for (size_t j = lo; j < hi; ++j) {
+            if (col[j] == 0xFF) continue;
+            const g1_affine_t *q = &aff[(size_t)col[j] * cycles + j];
+            if (!aff_is_inf(q)) xyzz_add_mixed(&acc, &q->x, &q->y, 0);
+        }
+        partial[k] = acc;
+    }
+    for (size_t p = 0; p < n_polys; ++p) {
+        g1_xyzz_t acc;
+        xyzz_set_identity(&acc);
+        for (size_t ch = 0; ch < chunks; ++ch) xyzz_add(&acc, &partial[p * chunks + ch]);
+        out[p] = xyzz_to_jacobian(&acc);
+    }
+    free(partial);
+}
 /* The MSM the HyperKZG restatement calls: the serial bucket method above by default; bench.py's cpu_baseline leg switches it to
  * the OpenMP form of oracle/baseline.c (same point, computed on all host cores). */
 void (*orc_msm_impl)(const g1_t *, const fr_t *, size_t, g1_t *) = orc_g1_msm_pippenger;
-EXPORT void orc_baseline_use_parallel_msm(int on) { orc_msm_impl = on ? orc_baseline_msm : orc_g1_msm_pippenger; }
+static void msm_many_serial(const g1_t *bases, const fr_t *const *scalars, const size_t *lens, size_t count, g1_t *out) {
+    for (size_t i = 0; i < count; ++i) orc_g1_msm_pippenger(bases, scalars[i], lens[i], &out[i]);
+}
+/* several independent MSMs over prefixes of one base array (the level commitments, the three witness commitments) */
+void (*orc_msm_many_impl)(const g1_t *, const fr_t *const *, const size_t *, size_t, g1_t *) = msm_many_serial;
+EXPORT void orc_baseline_use_parallel_msm(int on) {
+    orc_msm_impl = on ? orc_baseline_msm : orc_g1_msm_pippenger;
+    orc_msm_many_impl = on ? orc_baseline_msm_many : msm_many_serial;
+}
 
 /* HyperKZGScheme::setup_from_secret (crates/jolt-hyperkzg/src/scheme.rs:54-73): g1_powers[i] = beta^i * g1,
  * built by repeated scalar_mul exactly as the reference does (max_degree + 1 entries). */

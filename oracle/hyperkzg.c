@@ -26,6 +26,7 @@
 typedef struct { fq_t x, y, z; } g1_t;
 void orc_g1_msm_pippenger(const g1_t *bases, const fr_t *scalars, size_t n, g1_t *out);
 extern void (*orc_msm_impl)(const g1_t *, const fr_t *, size_t, g1_t *); /* g1.c: serial Pippenger unless the cpu_baseline leg swapped it */
+extern void (*orc_msm_many_impl)(const g1_t *, const fr_t *const *, const size_t *, size_t, g1_t *); /* g1.c: the same, several independent MSMs */
 void orc_g1_serialize_compressed(const g1_t *p, uint8_t out[32]);
 void orc_bind_low_to_high(const fr_t *t, size_t len, const fr_t *r, fr_t *out);
 
@@ -125,7 +126,11 @@ EXPORT int orc_hyperkzg_open(const g1_t *g1_powers, size_t srs_len, const fr_t *
     off[0] = 0; len[0] = n;
     for (size_t i = 1; i < ell; ++i) { off[i] = off[i - 1] + len[i - 1]; len[i] = len[i - 1] / 2; }
     /* scheme.rs:141-145 */
-    for (size_t i = 1; i < ell; ++i) orc_kzg_commit(polys + off[i], len[i], g1_powers, srs_len, &com[i - 1]);
+    if (ell > 1) { /* ell - 1 independent kzg_commit calls (the reference maps them with par_iter) */
+        const fr_t *ptrs[64];
+        for (size_t i = 1; i < ell; ++i) { if (len[i] > srs_len) { free(polys); return -1; } ptrs[i - 1] = polys + off[i]; }
+        orc_msm_many_impl(g1_powers, ptrs, len + 1, ell - 1, com);
+    }
     /* scheme.rs:148-152 */
     for (size_t i = 1; i < ell; ++i) mt_append_g1(&tr, &com[i - 1]);
     fr_t r = mt_challenge(&tr);
@@ -147,10 +152,13 @@ EXPORT int orc_hyperkzg_open(const g1_t *g1_powers, size_t srs_len, const fr_t *
         qj = FMUL(qj, q);
     }
     /* kzg.rs:108-116 */
-    fr_t *h = (fr_t *)malloc(n * sizeof(fr_t));
-    for (int t = 0; t < 3; ++t) {
-        orc_kzg_witness_polynomial(b_poly, n, &u[t], h);
-        orc_msm_impl(g1_powers, h, n - 1, &w[t]);
+    fr_t *h = (fr_t *)malloc(3 * n * sizeof(fr_t));
+    {
+        const fr_t *ptrs[3] = {h, h + n, h + 2 * n};
+        const size_t lens[3] = {n - 1, n - 1, n - 1};
+#pragma omp parallel for schedule(static) if (n >= 65536)
+        for (int t = 0; t < 3; ++t) orc_kzg_witness_polynomial(b_poly, n, &u[t], h + (size_t)t * n);
+        orc_msm_many_impl(g1_powers, ptrs, lens, 3, w);
     }
     /* kzg.rs:118-124 */
     for (int t = 0; t < 3; ++t) mt_append_g1(&tr, &w[t]);

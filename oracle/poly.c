@@ -55,7 +55,7 @@ EXPORT void orc_bind_to_field_u64(const uint64_t *t, size_t len, const fr_t *r, 
 
 /* eq.rs:299-315 evals_serial (== evals / evals_parallel values, eq.rs:221-231,374-458): big-endian,
  * r[0] pairs the index MSB; optional scale (NULL = one). out has 2^n entries. */
-EXPORT void orc_eq_evals(const fr_t *r, size_t n, const fr_t *scale, fr_t *out) {
+static void eq_evals_serial(const fr_t *r, size_t n, const fr_t *scale, fr_t *out) {
     size_t total = (size_t)1 << n;
     fr_t s = scale ? *scale : fr_one();
     for (size_t i = 0; i < total; ++i) out[i] = s;
@@ -69,6 +69,16 @@ EXPORT void orc_eq_evals(const fr_t *r, size_t n, const fr_t *scale, fr_t *out) 
             out[i - 1] = FSUB(scalar, out[i]);
         }
     }
+}
+EXPORT void orc_eq_evals(const fr_t *r, size_t n, const fr_t *scale, fr_t *out) {
+    if (n < 16) { eq_evals_serial(r, n, scale, out); return; }
+    /* large tables (eq.rs:374-458 evals_parallel: same values): the table of the top 8 variables, then every aligned block of
+     * 2^(n-8) entries expanded independently from its prefix value (the evals_for_aligned_block identity, eq.rs:238-263) */
+    fr_t prefix[256];
+    eq_evals_serial(r, 8, scale, prefix);
+    const size_t block = (size_t)1 << (n - 8);
+#pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < 256; ++b) eq_evals_serial(r + 8, n - 8, &prefix[b], out + b * block);
 }
 
 /* eq.rs:50-98 evaluations(): the interleaved doubling form; same table as orc_eq_evals(scale=1) */
@@ -135,6 +145,7 @@ EXPORT void orc_lt_evals(const fr_t *r, size_t n, fr_t *out) {
     for (size_t i = 0; i < n; ++i) {
         fr_t ri = r[n - 1 - i];
         size_t half = (size_t)1 << i;
+#pragma omp parallel for schedule(static) if (half >= 32768) /* entry k touches only k and half + k */
         for (size_t k = 0; k < half; ++k) {
             fr_t x = out[k];
             fr_t y = FMUL(x, ri);
@@ -147,6 +158,7 @@ EXPORT void orc_lt_evals(const fr_t *r, size_t n, fr_t *out) {
 /* crates/jolt-poly/src/eq_plus_one.rs:71-130 evals: (eq table, eq+1 table), big-endian */
 EXPORT void orc_eq_plus_one_evals(const fr_t *r, size_t ell, const fr_t *scale, fr_t *eq_out, fr_t *eqp1_out) {
     size_t size = (size_t)1 << ell;
+#pragma omp parallel for schedule(static) if (size >= 65536)
     for (size_t i = 0; i < size; ++i) { eq_out[i] = fr_zero(); eqp1_out[i] = fr_zero(); }
     eq_out[0] = scale ? *scale : fr_one();
     for (size_t i = 0; i < ell; ++i) {
@@ -155,8 +167,10 @@ EXPORT void orc_eq_plus_one_evals(const fr_t *r, size_t ell, const fr_t *scale, 
         fr_t r_lower = fr_one();
         for (size_t j = i + 1; j < ell; ++j) r_lower = FMUL(r_lower, r[j]);
         r_lower = FMUL(r_lower, FSUB(fr_one(), r[i]));
+#pragma omp parallel for schedule(static) if (size / step >= 32768)
         for (size_t idx = half_step; idx < size; idx += step) eqp1_out[idx] = FMUL(eq_out[idx - half_step], r_lower);
         size_t eq_step = (size_t)1 << (ell - i - 1);
+#pragma omp parallel for schedule(static) if (size / (eq_step * 2) >= 32768)
         for (size_t k = 0; k < size; k += eq_step * 2) {
             fr_t val = FMUL(eq_out[k], r[i]);
             eq_out[k + eq_step] = val;

@@ -683,11 +683,23 @@ def baseline_msm(bases, scalars):
     return o[0]
 
 
-def baseline_grid_onehot_sum(bases, idx_col):
-    i = np.ascontiguousarray(idx_col, dtype=np.uint8)
-    o = g1_array(1)
-    lib().orc_baseline_grid_onehot_sum(_p(bases), i.ctypes.data_as(C.c_void_p), C.c_size_t(i.shape[0]), _p(o))
-    return o[0]
+def baseline_msm_many(bases, scalar_arrays):
+    """several MSMs over prefixes of the prepared bases as one pool of (msm, window, chunk) tasks"""
+    ss = [np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4) for s in scalar_arrays]
+    ptrs = (C.c_void_p * len(ss))(*[s.ctypes.data for s in ss])
+    lens = (C.c_size_t * len(ss))(*[s.shape[0] for s in ss])
+    o = g1_array(len(ss))
+    lib().orc_baseline_msm_many(_p(bases), ptrs, lens, C.c_size_t(len(ss)), _p(o))
+    return o
+
+
+def baseline_grid_onehot_sums(bases, idx):
+    """commitments of one-hot columns on the K x T grid: idx (n_polys, cycles) hot addresses (0xFF = cold), cycle-major placement"""
+    i = np.ascontiguousarray(idx, dtype=np.uint8)
+    n_polys, cycles = i.shape
+    o = g1_array(n_polys)
+    lib().orc_baseline_grid_onehot_sums(_p(bases), i.ctypes.data_as(C.c_void_p), C.c_size_t(n_polys), C.c_size_t(cycles), _p(o))
+    return o
 
 
 def baseline_grid_joint(idx, k_grid, scalars, dense, dense_scalars):

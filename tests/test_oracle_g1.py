@@ -198,9 +198,23 @@ def test_baseline_parallel_msm_and_grid_pieces_equal_the_serial_restatements():
     beta = rand_fr(1, 900)[0]
     srs = O.srs_setup_from_secret(beta, n)
     bases = O.baseline_prepare_bases(srs)
-    for scalars in (rand_fr(n, 901), O.fr_from_u64(np.arange(n, dtype=np.uint64) * 7 % 5)):
+    # signed-digit corner scalars: 0, 1, r - 1, the two halves of r, window boundaries of c = 8 (n = 600), all-ones windows
+    corner = O.to_mont([0, 1, R - 1, (R - 1) // 2, (R + 1) // 2, 127, 128, 129, 255, 256, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, (1 << 253) + 5, R - 2])
+    mixed = np.concatenate([corner, rand_fr(n - corner.shape[0], 909)])
+    for scalars in (rand_fr(n, 901), O.fr_from_u64(np.arange(n, dtype=np.uint64) * 7 % 5), mixed,
+                    O.fr_from_u64(np.random.default_rng(910).integers(0, 2**64, size=n, dtype=np.uint64))):
         assert O.g1_eq(O.baseline_msm(bases, scalars), O.g1_msm_pippenger(srs, scalars))
     assert O.g1_eq(O.baseline_msm(bases[10:], rand_fr(50, 902)), O.g1_msm_pippenger(srs[10:60], rand_fr(50, 902)))
+    # several MSMs of different lengths as one task pool (the level commitments of an opening); a repeated base makes buckets double
+    many = [rand_fr(600, 911), rand_fr(300, 912), O.fr_from_i64(np.arange(-75, 75, dtype=np.int64)), rand_fr(1, 913), mixed[:40]]
+    got_many = O.baseline_msm_many(bases, many)
+    for g, sc in zip(got_many, many):
+        assert O.g1_eq(g, O.g1_msm_pippenger(srs[: sc.shape[0]], sc))
+    dup = np.concatenate([srs[:1]] * 64)  # 64 copies of one base, equal scalars: every addition into the bucket is a doubling / identity case
+    dbases = O.baseline_prepare_bases(dup)
+    same = np.repeat(rand_fr(1, 914), 64, axis=0)
+    assert O.g1_eq(O.baseline_msm(dbases, same), O.g1_msm_naive(dup, same))
+    bases = O.baseline_prepare_bases(srs)
     ell = 5
     evals, point = rand_fr(1 << ell, 903), rand_fr(ell, 904)
     want = O.hyperkzg_open(srs, evals, point, label=3)
@@ -219,11 +233,13 @@ def test_baseline_parallel_msm_and_grid_pieces_equal_the_serial_restatements():
     one = O.to_mont([1])[0]
     s, dense, ds = rand_fr(3, 906), [rand_fr(T, 907)], rand_fr(1, 908)
     want_j = np.zeros((K * T, 4), dtype=np.uint64)
+    kt_bases = O.baseline_prepare_bases(srs[: K * T])  # the grid's bases exactly: the one-hot sums address them as k * T + j
+    sums = O.baseline_grid_onehot_sums(kt_bases, idx)
     for p in range(3):
         emb = np.zeros((K * T, 4), dtype=np.uint64)
         hot = idx[p] != 0xFF
         emb[idx[p][hot].astype(np.int64) * T + np.nonzero(hot)[0]] = one
-        assert O.g1_eq(O.baseline_grid_onehot_sum(bases, idx[p]), O.kzg_commit(emb, srs[: K * T]))
+        assert O.g1_eq(sums[p], O.kzg_commit(emb, srs[: K * T]))
         want_j = O.fr_add(want_j, O.fr_mul(emb, np.repeat(s[p].reshape(1, 4), K * T, axis=0)))
     want_j[:T] = O.fr_add(want_j[:T], O.fr_mul(dense[0], np.repeat(ds[0].reshape(1, 4), T, axis=0)))
     assert np.array_equal(O.baseline_grid_joint(idx, K, s, dense, ds), want_j)
