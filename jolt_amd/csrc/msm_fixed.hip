@@ -40,6 +40,12 @@ namespace {
 // 2048 for 25/26-bit windows (keeps the partition at <= 16385 bins of LDS)
 constexpr int kLoBitsMin = 8;
 static inline int fx_lo_bits(int c) { return c > 24 ? 11 : 8; }
+// Over-full buckets (repeated scalars: the level-1 polynomial of an opening over one-hot columns takes a few thousand distinct values
+// ~10^3..10^4 times each; the carry window of 64-bit witness scalars) are cut into segments of kFxHeavySeg entries and ONE LANE sums
+// one segment -- the same loop, trip count and gather pattern as a light bucket -- before a wavefront per bucket adds the segment
+// sums.  (The per-window method's one-wavefront-per-1024-entries kernel gives every lane 16 entries and a 6-round butterfly of full
+// additions: 60 % of the light rate; 28 ms of the configs[2] step were spent there.)
+constexpr uint32_t kFxHeavySeg = 128;
 // list-length classes of the bucket order: exact lengths up to kClasses - 1; empty and heavy buckets share class 0 (no light work)
 constexpr uint32_t kClasses = 512;
 __device__ __forceinline__ uint32_t bucket_class(uint32_t count, uint32_t heavy_threshold) {
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
             offsets[slot] = st;
             atomicAdd(&cls[bucket_class(c, heavy_threshold)], 1u);
             if (c > heavy_threshold) {
-                const uint32_t nseg = (c + kHeavySeg - 1) / kHeavySeg;
+                const uint32_t nseg = (c + kFxHeavySeg - 1) / kFxHeavySeg;
                 const uint32_t first = atomicAdd(heavy_count, nseg);
                 for (uint32_t sgi = 0; sgi < nseg && first + sgi < heavy_cap; ++sgi) {
                     heavy_list[2 * (first + sgi)] = slot;
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const ui
         offsets[slot] = base + excl;
         atomicAdd(&cls[bucket_class(c, heavy_threshold)], 1u);
         if (c > heavy_threshold) {
-            const uint32_t nseg = (c + kHeavySeg - 1) / kHeavySeg;
+            const uint32_t nseg = (c + kFxHeavySeg - 1) / kFxHeavySeg;
             const uint32_t first = atomicAdd(heavy_count, nseg);
             for (uint32_t sgi = 0; sgi < nseg && first + sgi < heavy_cap; ++sgi) {
                 heavy_list[2 * (first + sgi)] = slot;
@@ -559,6 +565,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
     buckets[slot] = LFORM ? sum_bucket_points_lform(sorted + offsets[slot], bases, 0u, cnt, 1u, lc) : sum_bucket_points<true>(sorted + offsets[slot], bases, 0u, cnt, 1u);
 }
 
+// ---- 4b. heavy buckets: one lane per kFxHeavySeg-entry segment, then one wavefront per bucket over its segment sums -------------
+template <bool LFORM>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_fx_heavy_segments(
+    const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count, uint32_t heavy_cap, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, G1Jac* __restrict__ seg_sums, LformConsts lc) {
+    const uint32_t total = min(*heavy_count, heavy_cap);
+    for (uint32_t h = blockIdx.x * kBlock + threadIdx.x; h < total; h += gridDim.x * kBlock) {
+        const uint32_t slot = heavy_list[2 * h], sgi = heavy_list[2 * h + 1];
+        const uint32_t cnt = hist[slot], lo = sgi * kFxHeavySeg, len = min(kFxHeavySeg, cnt - lo);
+        const uint32_t* src = sorted + offsets[slot] + lo;
+        seg_sums[h] = LFORM ? sum_bucket_points_lform(src, bases, 0u, len, 1u, lc) : sum_bucket_points<true>(src, bases, 0u, len, 1u);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_fx_heavy_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count, uint32_t heavy_cap,
+                                                            const uint32_t* __restrict__ hist, const G1Jac* __restrict__ seg_sums, G1Jac* __restrict__ buckets) {
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t total = min(*heavy_count, heavy_cap);
+    // the segments of a bucket are adjacent list entries; the wave that finds a bucket's FIRST segment among its 64 entries adds that bucket
+    for (uint32_t h0 = wave * 64; h0 < total; h0 += n_waves * 64) {
+        const uint32_t h = h0 + lane;
+        uint64_t firsts = __ballot(h < total && heavy_list[2 * h + 1] == 0);
+        while (firsts) {
+            const int l = __ffsll((unsigned long long)firsts) - 1;
+            firsts &= firsts - 1;
+            const uint32_t hb = h0 + (uint32_t)l, slot = heavy_list[2 * hb];
+            const uint32_t nseg = (hist[slot] + kFxHeavySeg - 1) / kFxHeavySeg;
+            G1Jac acc = g1_identity();
+            for (uint32_t k = lane; k < nseg && hb + k < total; k += 64) acc = g1_add(acc, seg_sums[hb + k]);
+            acc = wave_sum_g1(acc, 64);
+            if (lane == 0) buckets[slot] = acc;
+        }
+    }
+}
+
 // window tables -> L-form (fq_limb.hip.h): every coordinate times 32, i.e. a product with the Montgomery form of 32; (0, 0) stays (0, 0)
 __global__ __launch_bounds__(kBlock) void k_fx_to_lform(G1Affine* __restrict__ pts, size_t count, Fq mont32) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -651,8 +691,9 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     // partial top window of 254-bit scalars (14 bits at c = 24) piles ~n / 2^14 extra points on each of the lowest 2^14 buckets,
     // and small (witness) scalars fill the carry window's bucket 1 -- both take that path, as in the per-window method
     const size_t avg = (total + B - 1) / B;
-    const uint32_t heavy_threshold = (uint32_t)std::min<size_t>(std::max<size_t>(kLaneCap, 4 * avg), 0x7FFFFFFFu);
-    const uint32_t heavy_cap = (uint32_t)(total / kHeavySeg + total / heavy_threshold + 16);
+    // (at most kClasses - 2, so that every light bucket sits in the class of its exact length)
+    const uint32_t heavy_threshold = (uint32_t)std::min<size_t>(std::max<size_t>(2 * kLaneCap, 4 * avg), kClasses - 2);
+    const uint32_t heavy_cap = (uint32_t)(total / kFxHeavySeg + total / heavy_threshold + 16);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_keys = take(total * 4), o_entries = take(total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
@@ -752,7 +793,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
                            heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
     // bucket sums: the kernels of the per-window method with ONE window of B buckets (bases = the window tables)
-    const unsigned gh = std::min<uint32_t>((heavy_cap + 3) / 4, 4096);
+    const unsigned gh = std::min<uint32_t>((heavy_cap + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * 64);  // grid-stride over the heavy list (its length lives on the device)
     hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, st, (const uint32_t*)class_hist, class_cursor);
     hipLaunchKernelGGL(k_fx_order, dim3((unsigned)((n_buckets + kBlock * kOrderPer - 1) / (kBlock * kOrderPer))), dim3(kBlock), 0, st, (const uint32_t*)hist, (uint32_t)n_buckets,
                        heavy_threshold, class_cursor, order);
@@ -772,15 +813,16 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     if (srs->pre_lform) {
         hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
-        hipLaunchKernelGGL(k_msm_buckets_heavy<true>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
-                           (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg, lc);
+        hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
+                           (const uint32_t*)keys, (const G1Affine*)srs->pre, seg, lc);
     } else {
         hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
-        hipLaunchKernelGGL(k_msm_buckets_heavy<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
-                           (const uint32_t*)keys, (const G1Affine*)srs->pre, total, B, seg, lc);
+        hipLaunchKernelGGL(k_fx_heavy_segments<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
+                           (const uint32_t*)keys, (const G1Affine*)srs->pre, seg, lc);
     }
-    hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const G1Jac*)seg, buckets);
+    hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
+                       (const G1Jac*)seg, buckets);
     hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, G, part);
     hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)part, nb, wsum);
     JOLT_HIP_TRY(ctx, hipGetLastError());

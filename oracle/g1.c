@@ -307,6 +307,8 @@ static inline g1_t xyzz_to_jacobian(const g1_xyzz_t *p) {
  * skipped (64-bit witness columns cost 5 windows, not 16), chunks sized so that the pool has >= 4 tasks per thread while a chunk
  * still holds >= 8 points per bucket.  Same group elements as orc_g1_msm_pippenger (tests/test_oracle_g1.py). */
 typedef struct { unsigned msm, window, chunk; } msm_task;
+static unsigned g_baseline_max_c = 16; /* 2^15 XYZZ buckets = 4 MiB per thread; bench.py's calibration may lower it (orc_baseline_set_max_window) */
+EXPORT void orc_baseline_set_max_window(unsigned c) { g_baseline_max_c = c < 4 ? 4 : (c > 16 ? 16 : c); }
 EXPORT void orc_baseline_msm_many(const g1_t *bases, const fr_t *const *scalars, const size_t *lens, size_t count, g1_t *out) {
     if (count == 0) return;
     size_t max_n = 0;
@@ -326,7 +328,7 @@ EXPORT void orc_baseline_msm_many(const g1_t *bases, const fr_t *const *scalars,
         unsigned log2n = 0;
         while (((size_t)2 << log2n) <= n) log2n++;
         unsigned c = n < 32 ? 3 : (log2n * 69 / 100) + 2; /* ark's window rule, as in orc_g1_msm_pippenger */
-        if (c > 16) c = 16;
+        if (c > g_baseline_max_c) c = g_baseline_max_c;
         cs[i] = c;
         /* canonical scalars + the half-window offsets; top bit over the MSM */
         u256 half;
@@ -380,11 +382,22 @@ EXPORT void orc_baseline_msm_many(const g1_t *bases, const fr_t *const *scalars,
             const unsigned start = w * c, limb = start / 64, shift = start % 64;
             const uint64_t mask = ((uint64_t)1 << c) - 1;
             const u256 *k256 = ks[i];
+            const int64_t offset = start + c - 1 < 256 ? (int64_t)nb : 0;
             for (size_t j = lo; j < hi; ++j) {
+                if (j + 8 < hi) { /* the bucket of the point 8 ahead: at c = 16 a thread's 4 MiB of buckets live in L3 / DRAM, not in its L2 */
+                    uint64_t vp = k256[j + 8].l[limb] >> shift;
+                    if (shift + c > 64 && limb < 3) vp |= k256[j + 8].l[limb + 1] << (64 - shift);
+                    const int64_t dp = (int64_t)(vp & mask) - offset;
+                    if (dp) {
+                        const char *bp = (const char *)&buckets[(dp > 0 ? dp : -dp) - 1];
+                        __builtin_prefetch(bp, 1, 1);
+                        __builtin_prefetch(bp + 64, 1, 1);
+                    }
+                }
                 uint64_t v = k256[j].l[limb] >> shift;
                 if (shift + c > 64 && limb < 3) v |= k256[j].l[limb + 1] << (64 - shift);
                 /* a top window whose half-window bit would lie beyond bit 255 carries no offset: its value (< 2^(256 - start) <= nb) is the digit */
-                const int64_t d = (int64_t)(v & mask) - (start + c - 1 < 256 ? (int64_t)nb : 0);
+                const int64_t d = (int64_t)(v & mask) - offset;
                 if (d == 0) continue;
                 const g1_affine_t *q = &aff[j];
                 if (aff_is_inf(q)) continue;

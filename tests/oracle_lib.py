@@ -672,6 +672,10 @@ def baseline_prepare_bases(bases):
     return b
 
 
+def baseline_set_max_window(c):
+    lib().orc_baseline_set_max_window(C.c_uint(c))
+
+
 def baseline_use_parallel_msm(on):
     lib().orc_baseline_use_parallel_msm(C.c_int(1 if on else 0))
 
