@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=int, default=22, help="log2 of the per-GPU trace length T")
     ap.add_argument("--no-msm", action="store_true", help="sumcheck legs only (BASELINE configs[1]); default: commit + open inside the step")
+    ap.add_argument("--stages", choices=["all", "2-6b"], default="all",
+                    help="all (default): the step also runs the stage 1 / 2 / 5 operators that are not plain cycle-domain relations -- Spartan outer and product, the sparse "
+                         "RAM read-write matrix, the instruction read-RAF scans and cycle rounds (jolt_amd/stages.py); 2-6b: the round-2 step (comparable with BENCH_r02)")
     ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
     ap.add_argument("--roofline-only", action="store_true", help="only run the bind-kernel roofline loop (rocprof target)")
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
@@ -287,15 +290,24 @@ def main():
                                      subtree=subtree)
             pcs = "grid"
 
-        def step(label=0):  # the same legs as the N = 1 step (DeviceWorkload.step): prepare, commit, prove, open
+        ext = None
+        if args.stages == "all":
+            # The stage 1 / 2 / 5 operators have no cross-rank form yet: every rank proves them over ITS block of cycles as an independent
+            # sub-trace (replicas: the same work per GPU as the N = 1 step, no exchange), stated in config.workload
+            from jolt_amd.stages import DeviceExtended
+            ext = DeviceExtended(ctx, args.scale, seed=2026 + 7919 * rank)
+
+        def step(label=0):  # the same legs as the N = 1 step (DeviceWorkload.step): prepare, commit, extended operators, prove, open
             wl.prepare()
             if pcs_sharded is not None:
                 pcs_sharded.commit()
+            if ext is not None:
+                ext.prove(label)
             wl.prove(label=label)
             if pcs_sharded is not None:
                 pcs_sharded.open(label)
     else:
-        wl = DeviceWorkload(ctx, args.scale, pcs=pcs)
+        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"))
         step = wl.step
 
     def barrier():
@@ -343,7 +355,15 @@ def main():
     # where the step time goes: two more steps (outside the timed region) with a synchronisation after each leg
     split = None
     if not sharded and not args.no_split:
-        legs = [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + [("prove", lambda: wl.prove(label=3000))] + \
+        ext_legs = []
+        if wl.ext is not None:
+            e, dd = wl.ext, wl.ext.d
+            ext_legs = [("spartan_outer", lambda: e.spartan(e.outer_ints, dd["outer_iwa"], dd["outer_iwb"], dd["outer_wa"], dd["outer_wb"], dd["outer_tau"], dd["outer_kernel"],
+                                                           e.claims["outer"], 2, 3100)),
+                        ("spartan_product", lambda: e.spartan(e.product_ints, e.product_ia, e.product_ib, e.product_fa, e.product_fb, dd["product_tau"], dd["product_kernel"],
+                                                             e.claims["product"], 1, 3200)),
+                        ("ram_read_write", lambda: e.ram_read_write(3300)), ("instruction_read_raf", lambda: e.instruction_read_raf(3400))]
+        legs = [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + ext_legs + [("prove", lambda: wl.prove(label=3000))] + \
                ([("open", lambda: wl.open(label=3000))] if pcs else [])
         acc = {k: 0.0 for k, _ in legs}
         reps = 2
@@ -358,10 +378,18 @@ def main():
     n_onehot = getattr(wl, "n_onehot", 0) or sum(a.shape[0] for a in getattr(wl, "committed_onehot", []))
     onehot_note = f" of which {n_onehot} are one-hot RA selector columns kept as 1-byte hot indices until their fourth bind" if n_onehot else ""
     total_cycles = (1 << args.scale) * world
+    ext_note = ""
+    the_ext = ext if sharded else wl.ext
+    if the_ext is not None:
+        ram = the_ext.d["ram"]
+        ext_note = (f"runs the stage 1 / 2 / 5 operators outside the cycle-domain catalogue -- Spartan outer (uni-skip sums off 35 integer columns, Az / Bz, log T + 1 "
+                    f"remainder rounds, claimed inputs), Spartan product (the same over the 6 product lanes), the sparse RAM read-write matrix (K = 2^{ram['log_k']}, "
+                    f"log T + log K rounds) and the instruction read-RAF scans of all 16 address phases + log T cycle rounds"
+                    + (" (per-rank replicas over each rank's block of cycles: these four operators have no cross-rank form yet)" if sharded else "") + " -- ")
     if pcs and sharded:
         what = (f"BASELINE configs[2] sharded over {world} GPU(s): sha3-shaped synthetic trace of {world} x 2^{args.scale} cycles, sumcheck + HyperKZG end-to-end -- "
                 f"every step commits the {n_onehot + 2} committed columns on the 2^{pcs_sharded.grid_vars} commitment grid (each rank its block of cycles, one all-gather of "
-                f"partial points), proves the stage 2-6b cycle-domain sumchecks hypercube-sharded (11 relations, {wl.n_tables} T-sized tables per rank) and opens the "
+                f"partial points), {ext_note}proves the stage 2-6b cycle-domain sumchecks hypercube-sharded (11 relations, {wl.n_tables} T-sized tables per rank) and opens the "
                 f"joint polynomial (2^{pcs_sharded.grid_vars} coefficients) with ONE HyperKZG opening "
                 + (f"sharded over the ranks by index subtree (every rank builds, folds, combines, divides and commits 1/{world} of the polynomial against its own "
                    f"bases and window tables; O(ell) field elements and points exchanged)" if pcs_sharded.subtree else
@@ -371,11 +399,11 @@ def main():
     elif pcs:
         what = (f"BASELINE configs[2]: sha3-shaped synthetic trace, T=2^{args.scale} per GPU, sumcheck + HyperKZG end-to-end -- every step rebuilds the "
                 f"per-proof tables (witness promotion, eq / eq+1 / LT expansions, linear-leaf fusions, members), commits the {n_onehot + 2} committed columns "
-                f"on the 2^{wl.grid_vars} commitment grid (2 dense MSMs of T 64-bit scalars + {n_onehot} one-hot columns as sums of bases), proves the "
+                f"on the 2^{wl.grid_vars} commitment grid (2 dense MSMs of T 64-bit scalars + {n_onehot} one-hot columns as sums of bases), {ext_note}proves the "
                 f"stage 2-6b cycle-domain sumchecks (11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5) and opens the joint polynomial "
                 f"(2^{wl.grid_vars} coefficients) with ONE HyperKZG opening (MSM, commit and open inside the timed region)")
     else:
-        what = (f"sha3-shaped synthetic trace, T=2^{args.scale} per GPU: per-proof tables + stages 2-6b cycle-domain sumchecks "
+        what = (f"sha3-shaped synthetic trace, T=2^{args.scale} per GPU: per-proof tables + {ext_note}stages 2-6b cycle-domain sumchecks "
                 f"(11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5), bind + round-poly HIP kernels; MSM not in the timed region "
                 f"(BASELINE configs[1] shape)")
     out = {

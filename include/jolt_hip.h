@@ -317,6 +317,14 @@ int32_t jolt_host_gruen_poly_from_q(const jolt_fr_t *current_scalar, const jolt_
 /* GruenSplitEqPolynomial::gruen_poly_deg_3 (split_eq.rs:383-417): 4 coefficients */
 int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t *current_scalar, const jolt_fr_t *point_i, const jolt_fr_t *q_constant,
                                    const jolt_fr_t *q_quadratic, const jolt_fr_t *s0_plus_s1, jolt_fr_t *coeffs_out);
+/* The Fiat-Shamir surface of members the caller drives round by round outside prove_batch (RamReadWriteKernel's rounds, the read-RAF
+ * phases): Transcript::{append, challenge, challenge_scalar} (crates/jolt-transcript/src/legacy.rs:55-100) over the deterministic TEST
+ * transcript of jolt_host_prove_batch.  A Rust caller keeps its own Blake2b / Keccak transcript and never calls these. */
+typedef struct jolt_host_transcript jolt_host_transcript;
+int32_t jolt_host_transcript_create(uint64_t label, jolt_host_transcript **out);
+int32_t jolt_host_transcript_append_fr(jolt_host_transcript *t, const jolt_fr_t *values, size_t count); /* canonical 32-byte LE each */
+int32_t jolt_host_transcript_challenge(jolt_host_transcript *t, int32_t full_width, jolt_fr_t *out);    /* 0: 125-bit challenge shape */
+int32_t jolt_host_transcript_destroy(jolt_host_transcript *t);
 /* G1 helpers on the host: group law, equality as points, compressed serialisation
  * (crates/jolt-crypto/src/ec/bn254/mod.rs:139-171) */
 int32_t jolt_host_g1_add(const jolt_g1_t *p, const jolt_g1_t *q, jolt_g1_t *out);
@@ -561,6 +569,11 @@ typedef struct jolt_rw_matrix jolt_rw_matrix;
 int32_t jolt_rw_matrix_create(jolt_ctx *ctx, const uint64_t *addresses, const uint64_t *pre_values, const uint64_t *post_values, size_t cycles,
                               const jolt_table *inc, const jolt_table *val_init, const jolt_fr_t *tau_low, const jolt_fr_t *gamma,
                               jolt_rw_matrix **out);
+/* The same member over access columns already resident in HBM (three JOLT_INT_U64 jolt_ints of `cycles` entries, uploaded once per trace):
+ * no host pass over the columns and no upload per proof. */
+int32_t jolt_rw_matrix_create_resident(jolt_ctx *ctx, const jolt_ints *addresses, const jolt_ints *pre_values, const jolt_ints *post_values,
+                                       const jolt_table *inc, const jolt_table *val_init, const jolt_fr_t *tau_low, const jolt_fr_t *gamma,
+                                       jolt_rw_matrix **out);
 int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix *m, const jolt_fr_t *bind, jolt_fr_t *evals_out /* 2 */, jolt_fr_t *aux_out /* 3 or NULL */);
 int32_t jolt_rw_matrix_finish(jolt_rw_matrix *m, const jolt_fr_t *bind);
 int32_t jolt_rw_matrix_final_values(jolt_rw_matrix *m, jolt_fr_t *out /* 4 */);

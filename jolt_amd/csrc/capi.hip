@@ -62,6 +62,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* la = std::getenv("JOLT_MSM_LANES")) ctx->msm_lanes = std::max(1, std::min(4, std::atoi(la)));
     if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
     if (const char* sg = std::getenv("JOLT_MSM_STAGGER")) ctx->msm_stagger = std::atoi(sg) != 0;
+    if (const char* gr = std::getenv("JOLT_FX_REDUCE")) ctx->msm_fx_grid_reduce = std::atoi(gr) != 0;
     if (const char* rd = std::getenv("JOLT_FX_REDUCE_DIV")) ctx->msm_fx_reduce_div = std::max(1, std::atoi(rd));
     if (const char* fl = std::getenv("JOLT_FX_LFORM")) ctx->msm_fx_lform = std::atoi(fl) != 0;
     if (const char* fs = std::getenv("JOLT_FX_STAGE")) ctx->msm_fx_stage = std::atoi(fs) != 0;

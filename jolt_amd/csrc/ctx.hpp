@@ -75,6 +75,7 @@ struct jolt_ctx {
     bool msm_fx_attr_set = false;
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)
+    bool msm_fx_grid_reduce = true;  // fixed-base MSM: bucket reduction by rows and columns (JOLT_FX_REDUCE=0: running sums, for an A/B)
     bool msm_stagger = false;     // JOLT_MSM_STAGGER=1: serialise the sort phases of concurrent fixed-base MSMs (see ev_sort)
     int msm_fx_reduce_div = 24;   // buckets per thread of the fixed-base bucket reduction (JOLT_FX_REDUCE_DIV)
     bool msm_fx_lform = true;     // JOLT_FX_LFORM=0: window tables in standard form, word-form XYZZ accumulators (A/B of fq_limb.hip.h)

@@ -560,6 +560,36 @@ extern "C" int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t* current_scalar, c
     return JOLT_OK;
 }
 
+// ---- the caller-side Fiat-Shamir of members that are driven round by round outside prove_batch (sparse read-write matrix, read-RAF
+// phases): the deterministic test transcript behind four entry points; a Rust caller uses its own Transcript instead.
+struct jolt_host_transcript {
+    MockTranscript t;
+    explicit jolt_host_transcript(uint64_t label) : t(label) {}
+};
+extern "C" int32_t jolt_host_transcript_create(uint64_t label, jolt_host_transcript** out) {
+    if (!out) return JOLT_ERR_INVALID_ARG;
+    *out = new (std::nothrow) jolt_host_transcript(label);
+    return *out ? JOLT_OK : JOLT_ERR_OOM;
+}
+extern "C" int32_t jolt_host_transcript_append_fr(jolt_host_transcript* t, const jolt_fr_t* values, size_t count) {
+    if (!t || (!values && count)) return JOLT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < count; ++i) {
+        const Fr v = fr_from_abi(&values[i]);
+        if (!fr_is_canonical(v)) return JOLT_ERR_INVALID_ARG;
+        t->t.append_fr(v);
+    }
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_transcript_challenge(jolt_host_transcript* t, int32_t full_width, jolt_fr_t* out) {
+    if (!t || !out) return JOLT_ERR_INVALID_ARG;
+    fr_to_abi(out, full_width ? t->t.challenge_scalar() : t->t.challenge());
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_transcript_destroy(jolt_host_transcript* t) {
+    delete t;
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_host_gruen_poly_from_q(const jolt_fr_t* current_scalar, const jolt_fr_t* point_i, const jolt_fr_t* q_evals, size_t dq,
                                                const jolt_fr_t* s0_plus_s1, jolt_fr_t* coeffs_out) {
     if (!current_scalar || !point_i || !q_evals || !s0_plus_s1 || !coeffs_out || dq < 1 || dq > 8) return JOLT_ERR_INVALID_ARG;

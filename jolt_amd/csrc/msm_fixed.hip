@@ -599,6 +599,46 @@ __global__ __launch_bounds__(kBlock) void k_fx_heavy_combine(const uint32_t* __r
     }
 }
 
+// ---- 5. reduction sum_b b * B_b of ONE large bucket set, by rows and columns ------------------------------------------------------
+// With b = h * 2^S + l:   sum_b b B_b = 2^S * sum_h h R_h + sum_l l C_l,   R_h = sum_l B_(h,l) (row sums),  C_l = sum_h B_(h,l) (column sums).
+// Two additions per bucket, all of them in independent chains of 16 (k_fx_red_cols: adjacent lanes on adjacent buckets; k_fx_red_rows: a
+// lane on 16 consecutive buckets), then wave-per-item folds of the partial sums and two SMALL running-sum reductions (2^S columns,
+// B / 2^S rows) through the shared kernels; the two weighted sums leave as "windows" 0 and 1 of an S-bit Horner on the host.  The
+// running-sum kernel it replaces for B >= 2^16 gave every thread 24 buckets: a serial chain of 48 additions plus a 23-bit
+// double-and-add by the range offset, at one wavefront per SIMD -- 3.1 ms per MSM however short, 38 ms of the configs[2] step.
+constexpr int kRedS = 11;
+constexpr uint32_t kRedCols = 1u << kRedS, kRedRC = 16, kRedCW = 16;
+__global__ __launch_bounds__(kBlock) void k_fx_red_cols(const G1Jac* __restrict__ buckets, uint32_t B, uint32_t H, G1Jac* __restrict__ colpart) {
+    const uint32_t l = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t h0 = blockIdx.y * kRedRC, h1 = min(h0 + kRedRC, H);
+    G1Jac acc = g1_identity();
+    for (uint32_t h = h0; h < h1; ++h) {
+        const uint32_t b = (h << kRedS) + l;
+        if (b <= B) acc = g1_add(acc, buckets[b]);  // bucket 0 is never written: the memset identity
+    }
+    colpart[(size_t)blockIdx.y * kRedCols + l] = acc;
+}
+__global__ __launch_bounds__(kBlock) void k_fx_red_rows(const G1Jac* __restrict__ buckets, uint32_t B, uint32_t H, G1Jac* __restrict__ rowpart) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    constexpr uint32_t per_row = kRedCols / kRedCW;
+    const uint32_t h = t / per_row, cc = t % per_row;
+    if (h >= H) return;
+    const uint32_t b0 = (h << kRedS) + cc * kRedCW;
+    G1Jac acc = g1_identity();
+    for (uint32_t k = 0; k < kRedCW; ++k)
+        if (b0 + k <= B) acc = g1_add(acc, buckets[b0 + k]);
+    rowpart[t] = acc;
+}
+// out[i] = sum_k part[k * kstride + i * istride], one wavefront per item
+__global__ __launch_bounds__(kBlock) void k_fx_red_fold(const G1Jac* __restrict__ part, uint32_t items, uint32_t K, size_t kstride, size_t istride, G1Jac* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, i = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (i >= items) return;  // wave-uniform
+    G1Jac acc = g1_identity();
+    for (uint32_t k = lane; k < K; k += 64) acc = g1_add(acc, part[(size_t)k * kstride + (size_t)i * istride]);
+    acc = wave_sum_g1(acc, 64);
+    if (lane == 0) out[i] = acc;
+}
+
 // window tables -> L-form (fq_limb.hip.h): every coordinate times 32, i.e. a product with the Montgomery form of 32; (0, 0) stays (0, 0)
 __global__ __launch_bounds__(kBlock) void k_fx_to_lform(G1Affine* __restrict__ pts, size_t count, Fq mont32) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -687,6 +727,10 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const uint32_t threads = (uint32_t)std::min<size_t>(std::max<size_t>(B / (size_t)ctx->msm_fx_reduce_div, std::min<size_t>(B, 4096)), 262144);
     const uint32_t nb = (threads + kBlock - 1) / kBlock;
     const uint32_t G = (B + nb * kBlock - 1) / (nb * kBlock);
+    // large bucket sets: the row / column reduction (k_fx_red_*); JOLT_FX_REDUCE=0 keeps the running sums for an A/B
+    const bool grid_reduce = B >= (1u << 16) && ctx->msm_fx_grid_reduce;
+    const uint32_t red_H = (B >> kRedS) + 1, red_chunks = (red_H + kRedRC - 1) / kRedRC, red_per_row = kRedCols / kRedCW;
+    const size_t red_points = grid_reduce ? (size_t)red_chunks * kRedCols + (size_t)red_H * red_per_row + kRedCols + red_H + 64 : 0;
     // a bucket holding more than max(kLaneCap, 4x the average) points is summed per 1024-point segment by whole wavefronts: the
     // partial top window of 254-bit scalars (14 bits at c = 24) piles ~n / 2^14 extra points on each of the lowest 2^14 buckets,
     // and small (witness) scalars fill the carry window's bucket 1 -- both take that path, as in the per-window method
@@ -697,7 +741,8 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_keys = take(total * 4), o_entries = take(total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
-                 o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(sizeof(G1Jac)),
+                 o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(2 * sizeof(G1Jac)),
+                 o_red = take(std::max<size_t>(red_points, 1) * sizeof(G1Jac)),
                  o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
                  o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4),
                  o_grouped = take(ctx->msm_fx_partition == 2 ? total * 8 : 256), o_gcur = take(kPartBins * 4);
@@ -823,6 +868,35 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     }
     hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
                        (const G1Jac*)seg, buckets);
+    if (grid_reduce) {
+        G1Jac* colpart = (G1Jac*)(ws + o_red);
+        G1Jac* rowpart = colpart + (size_t)red_chunks * kRedCols;
+        G1Jac* cols = rowpart + (size_t)red_H * red_per_row;  // C_l, l < 2^S
+        G1Jac* rows = cols + kRedCols;                         // R_h, h < H
+        G1Jac* small_part = rows + red_H;                      // block partials of the two small reductions
+        hipLaunchKernelGGL(k_fx_red_cols, dim3(kRedCols / kBlock, red_chunks), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, red_H, colpart);
+        hipLaunchKernelGGL(k_fx_red_rows, dim3((red_H * red_per_row + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, red_H, rowpart);
+        hipLaunchKernelGGL(k_fx_red_fold, dim3(kRedCols * 64 / kBlock), dim3(kBlock), 0, st, (const G1Jac*)colpart, kRedCols, red_chunks, (size_t)kRedCols, (size_t)1, cols);
+        hipLaunchKernelGGL(k_fx_red_fold, dim3((red_H * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const G1Jac*)rowpart, red_H, red_per_row, (size_t)1, (size_t)red_per_row, rows);
+        // sum_l l C_l (weights 1 .. 2^S - 1) and sum_h h R_h (weights 1 .. H - 1): index = weight, entry 0 unused -- the layout k_msm_window_reduce reads
+        const uint32_t g_small = 8, nb_c = (kRedCols / g_small + kBlock - 1) / kBlock, nb_r = (red_H / g_small + kBlock) / kBlock;
+        hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_c, 1), dim3(kBlock), 0, st, (const G1Jac*)cols, kRedCols - 1, g_small, small_part);
+        hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)small_part, nb_c, wsum);
+        if (red_H > 1) {
+            hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_r, 1), dim3(kBlock), 0, st, (const G1Jac*)rows, red_H - 1, g_small, small_part + 32);
+            hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)(small_part + 32), nb_r, wsum + 1);
+        } else {
+            JOLT_HIP_TRY(ctx, hipMemsetAsync(wsum + 1, 0, sizeof(G1Jac), st));
+        }
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, 2 * sizeof(G1Jac), hipMemcpyDeviceToHost, st));
+        job->n = n;
+        job->lane = lane;
+        job->c = kRedS;  // the collect step's Horner: 2^S * (row-weighted sum) + (column-weighted sum)
+        job->W = 2;
+        job->nb = nb;
+        return JOLT_OK;
+    }
     hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, G, part);
     hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)part, nb, wsum);
     JOLT_HIP_TRY(ctx, hipGetLastError());

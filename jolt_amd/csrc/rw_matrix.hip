@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "ints.hpp"
 #include "poly_kernels.hip.h"
 
 using namespace jolt;
@@ -386,13 +387,14 @@ extern "C" int32_t jolt_rw_matrix_destroy(jolt_rw_matrix* m) {
     return JOLT_OK;
 }
 
-extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresses, const uint64_t* pre_values, const uint64_t* post_values, size_t cycles,
-                                         const jolt_table* inc, const jolt_table* val_init, const jolt_fr_t* tau_low, const jolt_fr_t* gamma, jolt_rw_matrix** out) {
+// the access columns either on the host (uploaded here) or already in HBM (`resident`: device pointers, `resident_cap` accesses counted by the caller)
+static int32_t rw_create_impl(jolt_ctx* ctx, const uint64_t* addresses, const uint64_t* pre_values, const uint64_t* post_values, bool resident, uint32_t resident_cap,
+                              size_t cycles, const jolt_table* inc, const jolt_table* val_init, const jolt_fr_t* tau_low, const jolt_fr_t* gamma, jolt_rw_matrix** out) {
     if (!ctx || !addresses || !pre_values || !post_values || !inc || !val_init || !tau_low || !gamma || !out) return JOLT_ERR_INVALID_ARG;
     if (cycles < 2 || (cycles & (cycles - 1)) || cycles > ((size_t)1 << 31) || inc->len != cycles) return JOLT_ERR_SIZE_MISMATCH;
     const size_t K = val_init->len;
     if (K == 0 || (K & (K - 1)) || K > ((size_t)1 << 32)) return JOLT_ERR_SIZE_MISMATCH;
-    for (size_t j = 0; j < cycles; ++j)  // RamAccessColumns::validate_addresses (ram_trace.rs:119-131)
+    for (size_t j = 0; j < cycles && !resident; ++j)  // RamAccessColumns::validate_addresses (ram_trace.rs:119-131)
         if (addresses[j] != kNoAccess && addresses[j] >= K) { ctx->last_error = "RAM address outside the address space"; return JOLT_ERR_INVALID_ARG; }
     jolt_rw_matrix* m = new (std::nothrow) jolt_rw_matrix();
     if (!m) return JOLT_ERR_OOM;
@@ -417,13 +419,13 @@ extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresse
     if (s == JOLT_OK) s = jolt_table_clone(ctx, val_init, &m->val_init);
     // device layout: uploads (3 x cycles u64) + two states of `cap` entries + scratch
     const uint32_t T = (uint32_t)cycles;
-    uint32_t cap = 0;
-    for (size_t j = 0; j < cycles; ++j) cap += addresses[j] != kNoAccess;
+    uint32_t cap = resident_cap;
+    for (size_t j = 0; j < cycles && !resident; ++j) cap += addresses[j] != kNoAccess;
     m->cap = std::max<uint32_t>(cap, 1);
     const size_t scan_len = std::max<size_t>(T, m->cap);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t o_up = take(3 * cycles * 8);
+    size_t o_up = take(resident ? 256 : 3 * cycles * 8);
     size_t o_st[2][7];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = take((size_t)m->cap * 8); o_st[b][1] = take((size_t)m->cap * 8); o_st[b][2] = take((size_t)m->cap * 8);
@@ -441,10 +443,15 @@ extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresse
     }
     m->sib_lb = (uint32_t*)(base + o_sib); m->matched = (uint32_t*)(base + o_match); m->flags = (uint64_t*)(base + o_flags); m->scan = (uint64_t*)(base + o_scan);
     m->block_sums = (uint64_t*)(base + o_bs); m->total = (uint64_t*)(base + o_total);
-    uint64_t *d_addr = (uint64_t*)(base + o_up), *d_pre = d_addr + cycles, *d_post = d_pre + cycles;
-    hipError_t e = hipMemcpyAsync(d_addr, addresses, cycles * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pre, pre_values, cycles * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_post, post_values, cycles * 8, hipMemcpyHostToDevice, ctx->stream);
+    const uint64_t *d_addr = addresses, *d_pre = pre_values, *d_post = post_values;
+    hipError_t e = hipSuccess;
+    if (!resident) {
+        uint64_t* up = (uint64_t*)(base + o_up);
+        d_addr = up; d_pre = up + cycles; d_post = up + 2 * cycles;
+        e = hipMemcpyAsync(up, addresses, cycles * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(up + cycles, pre_values, cycles * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(up + 2 * cycles, post_values, cycles * 8, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rw_access_flags, dim3(rw_grid(T)), dim3(kBlock), 0, ctx->stream, (const uint64_t*)d_addr, T, m->flags);
         e = hipGetLastError();
@@ -455,7 +462,7 @@ extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresse
                            (const uint64_t*)m->scan, m->st[0]);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host arrays may be short-lived
+    if (e == hipSuccess && !resident) e = hipStreamSynchronize(ctx->stream);  // the host arrays may be short-lived
     if (e != hipSuccess || s != JOLT_OK) {
         if (e != hipSuccess) { ctx->last_error = std::string("rw matrix: ") + hipGetErrorString(e); s = JOLT_ERR_HIP; }
         jolt_rw_matrix_destroy(m);
@@ -464,6 +471,46 @@ extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresse
     m->n = cap;
     *out = m;
     return JOLT_OK;
+}
+extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresses, const uint64_t* pre_values, const uint64_t* post_values, size_t cycles,
+                                         const jolt_table* inc, const jolt_table* val_init, const jolt_fr_t* tau_low, const jolt_fr_t* gamma, jolt_rw_matrix** out) {
+    return rw_create_impl(ctx, addresses, pre_values, post_values, false, 0, cycles, inc, val_init, tau_low, gamma, out);
+}
+// accesses and out-of-range addresses of a resident column: counters[0], counters[1]
+__global__ __launch_bounds__(kBlock) void k_rw_count_accesses(const uint64_t* __restrict__ addresses, uint32_t cycles, uint64_t K, uint32_t* __restrict__ counters) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t a = j < cycles ? addresses[j] : kNoAccess;
+    const uint64_t hit = __ballot(a != kNoAccess), bad = __ballot(a != kNoAccess && a >= K);
+    if ((threadIdx.x & 63) == 0) {
+        if (hit) atomicAdd(&counters[0], (uint32_t)__popcll(hit));
+        if (bad) atomicAdd(&counters[1], (uint32_t)__popcll(bad));
+    }
+}
+// The same member over access columns that are ALREADY in HBM (three u64 jolt_ints of `cycles` entries: the witness is uploaded once per
+// trace, not once per proof): no host pass over the columns, one 8-byte read-back for the entry count.
+extern "C" int32_t jolt_rw_matrix_create_resident(jolt_ctx* ctx, const jolt_ints* addresses, const jolt_ints* pre_values, const jolt_ints* post_values,
+                                                  const jolt_table* inc, const jolt_table* val_init, const jolt_fr_t* tau_low, const jolt_fr_t* gamma, jolt_rw_matrix** out) {
+    if (!ctx || !addresses || !pre_values || !post_values || !val_init || !out) return JOLT_ERR_INVALID_ARG;
+    if (addresses->kind != JOLT_INT_U64 || pre_values->kind != JOLT_INT_U64 || post_values->kind != JOLT_INT_U64) return JOLT_ERR_INVALID_ARG;
+    const size_t cycles = addresses->count;
+    if (pre_values->count != cycles || post_values->count != cycles) return JOLT_ERR_SIZE_MISMATCH;
+    if (cycles < 2 || cycles > ((size_t)1 << 31)) return JOLT_ERR_SIZE_MISMATCH;
+    uint32_t* d_counters = nullptr;
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, 256, (void**)&d_counters));
+    uint32_t h_counters[2] = {0, 0};
+    hipError_t e = hipMemsetAsync(d_counters, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rw_count_accesses, dim3(rw_grid((uint32_t)cycles)), dim3(kBlock), 0, ctx->stream, (const uint64_t*)addresses->data, (uint32_t)cycles,
+                           (uint64_t)val_init->len, d_counters);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_counters, d_counters, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    jolt_internal_dev_free(ctx, d_counters);
+    if (e != hipSuccess) { ctx->last_error = std::string("rw matrix: ") + hipGetErrorString(e); return JOLT_ERR_HIP; }
+    if (h_counters[1]) { ctx->last_error = "RAM address outside the address space"; return JOLT_ERR_INVALID_ARG; }
+    return rw_create_impl(ctx, (const uint64_t*)addresses->data, (const uint64_t*)pre_values->data, (const uint64_t*)post_values->data, true, h_counters[0], cycles, inc,
+                          val_init, tau_low, gamma, out);
 }
 
 // RamReadWriteKernel::ingest (ram_read_write.rs:104-143)

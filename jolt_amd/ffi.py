@@ -469,6 +469,34 @@ def host_gruen_poly_from_q(scalar, point_i, q_evals, claim):
     return o
 
 
+class HostTranscript:
+    """The deterministic test transcript of jolt_host_prove_batch for members driven round by round from here (jolt_host_transcript_*)."""
+
+    def __init__(self, label):
+        self.h = C.c_void_p()
+        _ck(lib().jolt_host_transcript_create(C.c_uint64(label), C.byref(self.h)), "jolt_host_transcript_create")
+
+    def append(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        _ck(lib().jolt_host_transcript_append_fr(self.h, _p(v), C.c_size_t(v.shape[0])), "jolt_host_transcript_append_fr")
+
+    def challenge(self, full_width=False):
+        o = fr_array(1)
+        _ck(lib().jolt_host_transcript_challenge(self.h, C.c_int32(1 if full_width else 0), _p(o)), "jolt_host_transcript_challenge")
+        return o[0]
+
+    def close(self):
+        if self.h:
+            lib().jolt_host_transcript_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def host_gruen_poly_deg_3(scalar, point_i, q0, qinf, claim):
     o = fr_array(4)
     _ck(lib().jolt_host_gruen_poly_deg_3(_p(fr(scalar)), _p(fr(point_i)), _p(fr(q0)), _p(fr(qinf)), _p(fr(claim)), _p(o)),
@@ -961,12 +989,17 @@ class RwMatrix:
     RwMatrix wrapper plus the fused prove_round."""
 
     def __init__(self, ctx, addresses, pre, post, inc, val_init, tau_low, gamma):
-        a, p, q = (np.ascontiguousarray(x, dtype=np.uint64) for x in (addresses, pre, post))
+        """addresses / pre / post: host uint64 arrays (uploaded here), or three u64 Ints already resident in HBM"""
         tau = fr(tau_low).reshape(-1, 4)
         self.ctx = ctx
         h = C.c_void_p()
-        _ck(lib().jolt_rw_matrix_create(ctx.h, _p(a), _p(p), _p(q), C.c_size_t(a.shape[0]), inc.h, val_init.h, _p(tau), _p(fr(gamma)), C.byref(h)),
-            "jolt_rw_matrix_create", ctx)
+        if isinstance(addresses, Ints):
+            _ck(lib().jolt_rw_matrix_create_resident(ctx.h, addresses.h, pre.h, post.h, inc.h, val_init.h, _p(tau), _p(fr(gamma)), C.byref(h)),
+                "jolt_rw_matrix_create_resident", ctx)
+        else:
+            a, p, q = (np.ascontiguousarray(x, dtype=np.uint64) for x in (addresses, pre, post))
+            _ck(lib().jolt_rw_matrix_create(ctx.h, _p(a), _p(p), _p(q), C.c_size_t(a.shape[0]), inc.h, val_init.h, _p(tau), _p(fr(gamma)), C.byref(h)),
+                "jolt_rw_matrix_create", ctx)
         self.h = h
 
     def __len__(self):

@@ -1,0 +1,275 @@
+"""The T-scale operators of the stages that are not plain cycle-domain relations, driven the way the prover's
+stage drivers drive them, over synthetic trace-shaped inputs:
+
+  stage 1   Spartan outer            uni-skip sums off the integer witness columns, Az / Bz of the remainder member, its log T + 1 rounds,
+                                     the claimed inputs at the bind point        (crates/jolt-kernels/src/optimized/spartan_outer.rs)
+  stage 2   Spartan product          the same three steps over the six product lanes, no stream variable  (optimized/spartan_product.rs)
+  stage 2   RAM read / write         the sparse (address x cycle) matrix: log T cycle rounds + log K address rounds
+                                     (optimized/ram_read_write.rs:58-330, optimized/rw_matrix.rs)
+  stage 5   instruction read + RAF   the 16 address phases' T-scale scans (condensation, RAF sums, per-table suffix accumulators) and the
+                                     log T cycle rounds over combined * prod ra  (optimized/instruction_read_raf.rs; the 8 address rounds
+                                     inside a phase run over 256-entry polynomials on the caller's side and are not part of this)
+
+`build_extended` is a pure description (numpy); `DeviceExtended` holds the resident inputs in HBM and proves; tests/workload_oracle.py
+instantiates the same description on the CPU oracle.  Every operator absorbs what it sends into a transcript and takes its challenges
+from it (the deterministic test transcript, jolt_host_transcript_* / jolt_host_prove_batch), so two runs agree message for message.
+"""
+import numpy as np
+
+from .workload import rand_fr
+
+NO_ACCESS = np.uint64(0xFFFFFFFFFFFFFFFF)
+ADDRESS_BITS, PHASES, CHUNK = 128, 16, 256
+# integer Lagrange basis of the 3-node window {-1, 0, 1} at the extended nodes {-2 .. 2} (spartan_product.rs:86-105 extension_coefficients)
+PRODUCT_EXTENSION = np.array([[3, -3, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, -3, 3]], dtype=np.int64)
+N_SUFFIX_KINDS = 48
+
+
+def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5):
+    """RamAccessColumns (optimized/ram_trace.rs:22-75) of a memory-consistent synthetic trace: per cycle an optional access (address, word before,
+    word after), the word before being what the previous access to that address left (or the initial memory)."""
+    K, T = 1 << log_k, 1 << log_t
+    val_init = rng.integers(0, 2**63, size=K, dtype=np.uint64)
+    addresses = rng.integers(0, K, size=T, dtype=np.uint64)
+    hit = rng.random(T) < access
+    addresses[~hit] = NO_ACCESS
+    cyc = np.nonzero(hit)[0]
+    a = addresses[cyc].astype(np.int64)
+    order = np.lexsort((cyc, a))  # by address, then by cycle: every address's accesses form one contiguous chain
+    a_s = a[order]
+    n = a_s.shape[0]
+    pre, post = np.zeros(T, dtype=np.uint64), np.zeros(T, dtype=np.uint64)
+    if n:
+        writes = rng.random(n) < write
+        fresh = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+        pos = np.arange(n)
+        chain_start = np.r_[True, a_s[1:] != a_s[:-1]]
+        start_pos = np.maximum.accumulate(np.where(chain_start, pos, 0))
+        last_write = np.maximum.accumulate(np.where(writes, pos, -1))
+        post_s = np.where(last_write >= start_pos, fresh[np.maximum(last_write, 0)], val_init[a_s])  # the last write of the chain so far, else the initial word
+        pre_s = np.where(chain_start, val_init[a_s], np.r_[post_s[:1], post_s[:-1]])
+        pre[cyc[order]] = pre_s
+        post[cyc[order]] = post_s
+    inc = post.astype(np.int64) - pre.astype(np.int64)  # RamInc: words < 2^63, so the difference fits an i64
+    return dict(log_k=log_k, log_t=log_t, val_init=val_init, addresses=addresses, pre=pre, post=post, inc=inc)
+
+
+def suffix_lists(n_tables, rng):
+    """per table the suffix kinds it reads (LookupTableKind::suffixes()): every kind appears somewhere, 1..6 per table"""
+    kinds = list(rng.permutation(N_SUFFIX_KINDS))
+    lists = [[] for _ in range(n_tables)]
+    for i, k in enumerate(kinds):
+        lists[i % n_tables].append(int(k))
+    for l in lists:
+        if 0 not in l and rng.random() < 0.5:
+            l.insert(0, 0)
+    return lists
+
+
+def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_count=4, log_k=None):
+    rng = np.random.default_rng(seed + 500)
+    T = 1 << n_vars
+    d = {"n_vars": n_vars}
+    # ---- stage 1: flags and registers of the R1CS inputs; integer uni-skip column weights (~40 % non-zero), field weights of the remainder
+    d["outer_cols"] = [rng.integers(0, 2, size=T, dtype=np.uint64) if v % 3 else rng.integers(0, 2**64, size=T, dtype=np.uint64) for v in range(n_outer)]
+    shape = (n_nodes, 2, 1 + n_outer)
+    d["outer_iwa"] = rng.integers(-2**20, 2**20, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
+    d["outer_iwb"] = rng.integers(-2**40, 2**40, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
+    d["outer_tau"] = rand_fr(n_vars + 1, rng)
+    d["outer_kernel"] = rand_fr(1, rng)[0]
+    d["outer_wa"] = rand_fr(2 * (1 + n_outer), rng).reshape(2, 1 + n_outer, 4)
+    d["outer_wb"] = rand_fr(2 * (1 + n_outer), rng).reshape(2, 1 + n_outer, 4)
+    # ---- stage 2: product lanes (SpartanProductRow, spartan_product.rs:62-84); right_instruction_input is an i128 (lo, hi two's complement)
+    right_lo = rng.integers(0, 2**64, size=T, dtype=np.uint64)
+    right_hi = rng.integers(-2**62, 2**62, size=T, dtype=np.int64).view(np.uint64)
+    d["product_rows"] = {
+        "left_input": rng.integers(0, 2**64, size=T, dtype=np.uint64), "lookup_output": rng.integers(0, 2**64, size=T, dtype=np.uint64),
+        "jump": rng.integers(0, 2, size=T).astype(np.uint8), "right_input": np.stack([right_lo, right_hi], axis=1),
+        "branch": rng.integers(0, 2, size=T).astype(np.uint8), "next_is_noop": rng.integers(0, 2, size=T).astype(np.uint8)}
+    d["product_tau"] = rand_fr(n_vars, rng)
+    d["product_kernel"] = rand_fr(1, rng)[0]
+    d["product_w"] = rand_fr(3, rng)
+    # ---- stage 2: RAM
+    d["ram"] = consistent_ram_trace(min(16, max(1, n_vars)) if log_k is None else log_k, n_vars, rng)
+    d["ram_tau"] = rand_fr(n_vars, rng)
+    d["ram_gamma"] = rand_fr(1, rng)[0]
+    # ---- stage 5: lookup rows
+    idx = np.frombuffer(rng.bytes(16 * T), dtype=np.uint64).reshape(T, 2).copy()
+    shapes = rng.integers(0, 8, size=T)
+    idx[shapes == 0] = 0
+    idx[shapes == 1, 1] = 0
+    idx[shapes == 2] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    idx[shapes == 3, 0] &= np.uint64(0xFF)
+    table = rng.integers(0, n_tables, size=T).astype(np.uint8)
+    table[rng.random(T) < 0.1] = 0xFF
+    d["lookup"] = dict(idx=idx, table=table, raf=(rng.random(T) < 0.3).astype(np.uint8), n_tables=n_tables, lists=suffix_lists(n_tables, rng))
+    d["lookup_u_point"] = rand_fr(n_vars, rng)
+    d["lookup_table_values"] = rand_fr(n_tables, rng)
+    d["lookup_raf"] = rand_fr(2, rng)
+    d["lookup_reduction"] = rand_fr(n_vars, rng)
+    d["ra_count"] = ra_count
+    return d
+
+
+def product_integer_weights():
+    """A (left) / B (right) integer column weights [node][1][1 + 6] of the product lanes in the generic column form (lane order:
+    left_input, lookup_output, jump, right_input, branch, next_is_noop; right lane 2 is 1 - next_is_noop)"""
+    nodes = PRODUCT_EXTENSION.shape[0]
+    a, b = np.zeros((nodes, 1, 7), dtype=np.int64), np.zeros((nodes, 1, 7), dtype=np.int64)
+    for p in range(nodes):
+        c0, c1, c2 = (int(x) for x in PRODUCT_EXTENSION[p])
+        a[p, 0, 1:4] = [c0, c1, c2]
+        b[p, 0, 0] = c2
+        b[p, 0, 4:7] = [c0, c1, -c2]
+    return a, b
+
+
+def product_field_weights(w, neg):
+    a, b = np.zeros((1, 7, 4), dtype=np.uint64), np.zeros((1, 7, 4), dtype=np.uint64)
+    a[0, 1], a[0, 2], a[0, 3] = w[0], w[1], w[2]
+    b[0, 0], b[0, 4], b[0, 5], b[0, 6] = w[2], w[0], w[1], neg(w[2])
+    return a, b
+
+
+def rw_rounds(matrix_round, finish, final_values, log_t, log_k, claim, transcript, gruen_deg_3, from_evals, evaluate):
+    """ProveRounds of RamReadWriteKernel driven alone (ram_read_write.rs:160-217): cycle rounds complete the cubic with gruen_poly_deg_3 from the
+    two sums and the split-eq state the member reports, address rounds interpolate (s(0), claim - s(0), s(2)); every message is absorbed
+    coefficient by coefficient, the next bind is the transcript's challenge.  The same loop runs over the device member and the oracle's."""
+    polys, chal, bind = [], [], None
+    for rnd in range(log_t + log_k):
+        evals, aux = matrix_round(rnd, bind)
+        if rnd < log_t:
+            poly = gruen_deg_3(aux[0], aux[1], evals[0], evals[1], claim)
+        else:
+            poly = from_evals(np.stack([evals[0], _sub(claim, evals[0]), evals[1]]))
+        transcript.append(poly)
+        bind = transcript.challenge()
+        claim = evaluate(poly, bind)
+        polys.append(poly)
+        chal.append(bind)
+    finish(bind)
+    return dict(polys=polys, challenges=np.stack(chal), final_claim=claim, final_values=final_values())
+
+
+_sub = None  # field subtraction of the side that runs rw_rounds (set by DeviceExtended / OracleExtended: ffi.host_fr_sub / the oracle's)
+
+
+class DeviceExtended:
+    def __init__(self, ctx, n_vars, seed=2026, **kw):
+        from . import ffi
+        self.ctx, self.ffi, self.n_vars = ctx, ffi, n_vars
+        self.d = d = build_extended(n_vars, seed, **kw)
+        self.one = ffi.host_fr_from_u64(1)
+        zero = np.zeros(4, dtype=np.uint64)
+        # ---- resident inputs: integer witness columns, RAM access columns, lookup rows
+        self.outer_ints = [ctx.ints(c) for c in d["outer_cols"]]
+        r = d["product_rows"]
+        self.product_ints = [ctx.ints(r["left_input"]), ctx.ints(r["lookup_output"]), ctx.ints(r["jump"].astype(np.uint64)), ctx.ints(r["right_input"], "i128"),
+                             ctx.ints(r["branch"].astype(np.uint64)), ctx.ints(r["next_is_noop"].astype(np.uint64))]
+        self.product_ia, self.product_ib = product_integer_weights()
+        self.product_fa, self.product_fb = product_field_weights(d["product_w"], lambda x: ffi.host_fr_sub(zero, x))
+        ram = d["ram"]
+        self.ram_inc, self.ram_val_init = ctx.ints(ram["inc"]), ctx.ints(ram["val_init"])
+        self.ram_cols = [ctx.ints(ram[k]) for k in ("addresses", "pre", "post")]  # RamAccessColumns, uploaded once per trace
+        lk = d["lookup"]
+        self.read_raf = ctx.read_raf(lk["idx"], lk["table"], lk["raf"], lk["n_tables"])
+        # ---- input claims (in a real proof the previous stage's output claims): computed once, untimed
+        self.claims = {}
+        az, bz = ctx.r1cs_materialize_small(self.outer_ints, d["outer_wa"], d["outer_wb"])
+        m = ctx.member_split_eq_product(az, bz, d["outer_tau"], scale=d["outer_kernel"])
+        self.claims["outer"] = m.input_claim()
+        m.destroy()
+        left, right = ctx.r1cs_materialize_small(self.product_ints, self.product_fa, self.product_fb, streams=1)
+        m = ctx.member_split_eq_product(left, right, d["product_tau"], scale=d["product_kernel"])
+        self.claims["product"] = m.input_claim()
+        m.destroy()
+        # RAM: sum_j eq(tau, j) * [access_j] * (pre_j + gamma * post_j)  (val = the word before the access, val + inc = the word after)
+        acc = ram["addresses"] != NO_ACCESS
+        eq = ctx.eq_evals(d["ram_tau"])
+        pre, post = ctx.from_u64(np.where(acc, ram["pre"], 0).astype(np.uint64)), ctx.from_u64(np.where(acc, ram["post"], 0).astype(np.uint64))
+        m = ctx.member_lc([eq, pre, post], [[(None, [(self.one, 0)]), (None, [(self.one, 1), (d["ram_gamma"], 2)])]], 2, borrow=True)
+        self.claims["ram"] = m.input_claim()
+        m.destroy()
+        for t in (eq, pre, post):
+            t.free()
+        self.claims["lookup"] = None  # needs the v tables of a proof: taken from the first proof's cycle member (same every proof)
+        ctx.synchronize()
+
+    # ---- the operators ---------------------------------------------------------------------------------------------------------
+    def spartan(self, cols, iwa, iwb, fa, fb, tau, kernel, claim, streams, label):
+        ctx, ffi = self.ctx, self.ffi
+        eq = ctx.eq_evals(tau)
+        sums = ctx.r1cs_uniskip_sums_small(cols, eq, iwa, iwb, streams=streams)
+        eq.free()
+        tr = ffi.HostTranscript(label)
+        tr.append(sums)
+        r0 = tr.challenge()  # the uni-skip challenge (the Lagrange weights of the remainder are a function of it; fixed weights here)
+        tr.close()
+        az, bz = ctx.r1cs_materialize_small(cols, fa, fb, streams=streams)
+        member = ctx.member_split_eq_product(az, bz, tau, scale=kernel)
+        rounds = len(tau)
+        out = ctx.prove_batch([member], [claim], [self.one], [0], rounds, 3, label=label + 1)
+        member.destroy()
+        point = out["challenges"][rounds - self.n_vars:][::-1]  # the cycle coordinates, most significant first
+        values = ctx.ints_evaluate(cols, point)
+        return dict(sums=sums, r0=r0, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], values=values)
+
+    def ram_read_write(self, label):
+        global _sub
+        ctx, ffi, d = self.ctx, self.ffi, self.d
+        ram = d["ram"]
+        inc, val_init = ctx.table_from_ints(self.ram_inc), ctx.table_from_ints(self.ram_val_init)
+        m = ctx.rw_matrix(self.ram_cols[0], self.ram_cols[1], self.ram_cols[2], inc, val_init, d["ram_tau"], d["ram_gamma"])
+        inc.free()
+        val_init.free()
+        tr = ffi.HostTranscript(label)
+        _sub = ffi.host_fr_sub
+        out = rw_rounds(lambda rnd, bind: m.prove_round(bind), m.finish, m.final_values, ram["log_t"], ram["log_k"], self.claims["ram"], tr, ffi.host_gruen_poly_deg_3,
+                        ffi.host_univariate_from_evals, ffi.host_univariate_evaluate)
+        tr.close()
+        m.free()
+        return out
+
+    def instruction_read_raf(self, label):
+        ctx, ffi, d = self.ctx, self.ffi, self.d
+        lk, rr = d["lookup"], self.read_raf
+        tr = ffi.HostTranscript(label)
+        u = ctx.eq_evals(d["lookup_u_point"])  # the per-cycle mass eq(r_reduction, j) every phase condenses
+        v_tables, scans = [], []
+        for phase in range(PHASES):
+            suffix_len = ADDRESS_BITS - 8 * (phase + 1)
+            if phase:
+                rr.condense(u, v_tables[-1], suffix_len + 8)
+            raf, suf = rr.phase_scan(u, suffix_len, ADDRESS_BITS, lk["lists"])
+            tr.append(raf.reshape(-1, 4))
+            tr.append(suf.reshape(-1, 4))
+            scans.append((raf, suf))
+            # the phase's 8 address rounds happen on 256-entry polynomials on the caller's side; their challenges give the next eq table
+            v_tables.append(ffi.host_eq_evals(np.stack([tr.challenge() for _ in range(8)])))
+        u.free()
+        vt = np.stack(v_tables)
+        combined, ra = rr.cycle_tables(d["lookup_table_values"], d["lookup_raf"][0], d["lookup_raf"][1], vt, ADDRESS_BITS, d["ra_count"])
+        n_f = 1 + d["ra_count"]
+        member = ctx.member_lc([combined] + ra, [[(None, [(self.one, i)]) for i in range(n_f)]], n_f, eq_point=d["lookup_reduction"])
+        if self.claims["lookup"] is None:
+            self.claims["lookup"] = member.input_claim()
+        out = ctx.prove_batch([member], [self.claims["lookup"]], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)
+        member.destroy()
+        tr.close()
+        return dict(scans=scans, v_tables=vt, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+
+    def prove(self, label=0):
+        d = self.d
+        return {
+            "spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
+                                          self.claims["outer"], 2, label + 100),
+            "spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"], d["product_kernel"],
+                                            self.claims["product"], 1, label + 200),
+            "ram_read_write": self.ram_read_write(label + 300),
+            "instruction_read_raf": self.instruction_read_raf(label + 400),
+        }
+
+    def close(self):
+        for c in self.outer_ints + self.product_ints + self.ram_cols + [self.ram_inc, self.ram_val_init]:
+            c.free()
+        self.read_raf.free()

@@ -233,9 +233,15 @@ class DeviceWorkload:
     commitment grid of crates/jolt-kernels/src/commitment.rs:86-130 -- the two dense increment columns at address 0, the one-hot
     RA columns as 0/1 coefficients -- committed with HyperKZG and opened jointly at one point)."""
 
-    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, **kw):
+    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, extended=False, **kw):
         from . import ffi
         self.ctx, self.n_vars, self.ffi, self.pcs = ctx, n_vars, ffi, pcs
+        # extended: the stage 1 / 2 / 5 operators that are not plain cycle-domain relations (Spartan outer / product, the sparse RAM read-write
+        # matrix, the instruction read-RAF scans + cycle rounds: jolt_amd/stages.py) inside every step, over their own resident inputs
+        self.ext = None
+        if extended:
+            from .stages import DeviceExtended
+            self.ext = DeviceExtended(ctx, n_vars, seed)
         self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
@@ -413,6 +419,8 @@ class DeviceWorkload:
         out = {}
         if self.pcs:
             out["commit"] = self.commit()
+        if self.ext is not None:
+            out["extended"] = self.ext.prove(label)
         out["stages"] = self.prove(label)
         if self.pcs:
             out["open"] = self.open(label)
@@ -423,6 +431,9 @@ class DeviceWorkload:
 
     def close(self):
         self.release()
+        if self.ext is not None:
+            self.ext.close()
+            self.ext = None
         for s in self.sources.values():
             s.free()
         for v in self.ints.values():

@@ -56,6 +56,7 @@ EXPORT void orc_r1cs_uniskip_sums_rows(const fr_t *az_rows, const fr_t *bz_rows,
 EXPORT void orc_r1cs_uniskip_sums(const fr_t *const *inputs, uint32_t n_inputs, size_t cycles, const fr_t *eq, const fr_t *a_weights, const fr_t *b_weights,
                                   uint32_t n_nodes, fr_t *out) {
     const size_t stride = 1 + (size_t)n_inputs;
+#pragma omp parallel for schedule(dynamic, 1) if (cycles >= 65536) /* the nodes are independent sums */
     for (uint32_t n = 0; n < n_nodes; ++n) {
         fr_t sum = fr_zero();
         for (size_t t = 0; t < cycles; ++t)
@@ -77,6 +78,7 @@ EXPORT void orc_r1cs_uniskip_sums(const fr_t *const *inputs, uint32_t n_inputs, 
 EXPORT void orc_r1cs_materialize(const fr_t *const *inputs, uint32_t n_inputs, size_t cycles, const fr_t *a_weights /* 2 * (1 + n_inputs) */,
                                  const fr_t *b_weights, fr_t *az_out, fr_t *bz_out) {
     const size_t stride = 1 + (size_t)n_inputs;
+#pragma omp parallel for schedule(static) if (cycles >= 65536)
     for (size_t t = 0; t < cycles; ++t)
         for (uint32_t s = 0; s < 2; ++s) {
             fr_t az = a_weights[s * stride], bz = b_weights[s * stride];

@@ -210,6 +210,10 @@ extern "C" {
     pub fn jolt_host_univariate_evaluate(coeffs: *const jolt_fr_t, n: usize, x: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_gruen_poly_from_q(current_scalar: *const jolt_fr_t, point_i: *const jolt_fr_t, q_evals: *const jolt_fr_t, dq: usize, s0_plus_s1: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_gruen_poly_deg_3(current_scalar: *const jolt_fr_t, point_i: *const jolt_fr_t, q_constant: *const jolt_fr_t, q_quadratic: *const jolt_fr_t, s0_plus_s1: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_transcript_create(label: u64, out: *mut *mut jolt_host_transcript) -> i32;
+    pub fn jolt_host_transcript_append_fr(t: *mut jolt_host_transcript, values: *const jolt_fr_t, count: usize) -> i32;
+    pub fn jolt_host_transcript_challenge(t: *mut jolt_host_transcript, full_width: i32, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_transcript_destroy(t: *mut jolt_host_transcript) -> i32;
     pub fn jolt_host_g1_add(p: *const jolt_g1_t, q: *const jolt_g1_t, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_g1_eq(p: *const jolt_g1_t, q: *const jolt_g1_t, equal: *mut i32) -> i32;
     pub fn jolt_host_g1_serialize_compressed(p: *const jolt_g1_t, out: *mut u8) -> i32;
@@ -266,6 +270,7 @@ extern "C" {
     pub fn jolt_ints_evaluate(ctx: *mut jolt_ctx, columns: *const *const jolt_ints, k: usize, point: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_small_scalar_dot(values: *const jolt_fr_t, scalars: *const u64, n: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_create(ctx: *mut jolt_ctx, addresses: *const u64, pre_values: *const u64, post_values: *const u64, cycles: usize, inc: *const jolt_table, val_init: *const jolt_table, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
+    pub fn jolt_rw_matrix_create_resident(ctx: *mut jolt_ctx, addresses: *const jolt_ints, pre_values: *const jolt_ints, post_values: *const jolt_ints, inc: *const jolt_table, val_init: *const jolt_table, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
     pub fn jolt_rw_matrix_prove_round(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, aux_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_finish(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_final_values(m: *mut jolt_rw_matrix, out: *mut jolt_fr_t) -> i32;

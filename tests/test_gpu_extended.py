@@ -1,0 +1,51 @@
+"""The stage 1 / 2 / 5 operators of jolt_amd/stages.py on the device against the same drivers on the CPU oracle (tests/workload_oracle.py
+OracleExtended): uni-skip sums, challenges, every round polynomial, claimed inputs, every phase's scans, final values -- message for message,
+the reference's optimized-vs-reference lock step (crates/jolt-kernels/src/optimized/parity.rs:79-118) over whole stage drivers."""
+import numpy as np
+import pytest
+
+from jolt_amd import ffi
+from jolt_amd.stages import DeviceExtended
+from workload_oracle import OracleExtended
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, path=""):
+    if isinstance(a, dict):
+        for k in a:
+            same(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            same(x, y, f"{path}[{i}]")
+    else:
+        assert np.array_equal(np.asarray(a), np.asarray(b)), path
+
+
+def run(n_vars, seed, **kw):
+    ctx = ffi.Context(0)
+    dev = DeviceExtended(ctx, n_vars, seed=seed, **kw)
+    got = dev.prove(label=40)
+    again = dev.prove(label=40)  # a second proof over the resident inputs: same bytes
+    want = OracleExtended(n_vars, seed=seed, **kw).prove(label=40)
+    for name in got:
+        assert np.array_equal(dev.claims[{"spartan_outer": "outer", "spartan_product": "product", "ram_read_write": "ram", "instruction_read_raf": "lookup"}[name]], want[name]["claim"]), name
+        same(got[name], {k: v for k, v in want[name].items() if k != "claim"}, name)
+        same(again[name], got[name], name + " (second proof)")
+    dev.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_vars,kw", [(6, dict(n_tables=6, log_k=4)), (9, dict(n_tables=12)), (12, dict(log_k=14)), (3, dict(n_tables=3, n_outer=5, n_nodes=3, log_k=2))])
+def test_extended_stages_match_oracle(n_vars, kw):
+    run(n_vars, 21 + n_vars, **kw)
+
+
+def test_extended_stages_match_oracle_at_trace_scale():
+    """T = 2^20 cycles (K = 2^16 RAM words, 40 lookup tables, 35 R1CS inputs): the sizes at which the scans run many workgroups per bin, the
+    sparse matrix merges hundreds of columns per group and the uni-skip kernel streams the integer columns -- transcript for transcript"""
+    import oracle_lib as O
+    import os
+    O.baseline_set_threads(min(48, os.cpu_count() or 1))
+    run(20, 2026)

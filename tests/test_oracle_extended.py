@@ -1,0 +1,50 @@
+"""The extended-stage drivers (jolt_amd/stages.py) on the CPU oracle: the stand-alone round loop of the RAM read/write member satisfies the
+sumcheck round check against the claim taken from the DENSE definition of the summand, and its last claim is the product of the final
+values -- which pins the driver, the claim formula and the memory-consistent synthetic trace without a GPU; the Spartan / read-RAF drivers
+run to completion (their members check every round inside the oracle's prove_batch)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from jolt_amd import stages as S
+from workload_oracle import OracleExtended
+
+
+def _add(a, b): return O.fr_add(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+def _mul(a, b): return O.fr_mul(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+
+
+@pytest.mark.parametrize("n_vars,log_k", [(5, 3), (6, 6), (4, 1)])
+def test_ram_rounds_check_against_the_dense_claim(n_vars, log_k):
+    ext = OracleExtended(n_vars, seed=11, log_k=log_k)
+    out = ext.ram_read_write(label=7)
+    claim = out["claim"]
+    zero, one = np.zeros(4, dtype=np.uint64), O.to_mont([1])[0]
+    for rnd, poly in enumerate(out["polys"]):
+        s0, s1 = O.univariate_evaluate(poly, zero), O.univariate_evaluate(poly, one)
+        assert np.array_equal(_add(s0, s1), claim), rnd
+        claim = O.univariate_evaluate(poly, out["challenges"][rnd])
+    ra, val, inc, eq = out["final_values"]
+    assert np.array_equal(claim, out["final_claim"])
+    assert np.array_equal(claim, _mul(eq, _mul(ra, _add(val, _mul(ext.d["ram_gamma"], _add(val, inc))))))
+
+
+def test_consistent_trace_is_consistent():
+    rng = np.random.default_rng(3)
+    tr = S.consistent_ram_trace(4, 9, rng)
+    mem = tr["val_init"].copy()
+    for j in range(1 << 9):
+        a = tr["addresses"][j]
+        if a == S.NO_ACCESS:
+            assert tr["pre"][j] == 0 and tr["post"][j] == 0 and tr["inc"][j] == 0
+            continue
+        assert tr["pre"][j] == mem[int(a)]
+        mem[int(a)] = tr["post"][j]
+        assert int(tr["inc"][j]) == int(tr["post"][j]) - int(tr["pre"][j])
+
+
+def test_all_extended_drivers_run_on_the_oracle():
+    out = OracleExtended(5, seed=12, n_tables=6).prove(label=3)
+    assert set(out) == {"spartan_outer", "spartan_product", "ram_read_write", "instruction_read_raf"}
+    assert out["spartan_outer"]["polys"].shape[0] == 6 and out["spartan_product"]["polys"].shape[0] == 5
+    assert len(out["instruction_read_raf"]["scans"]) == S.PHASES and out["instruction_read_raf"]["polys"].shape[0] == 5

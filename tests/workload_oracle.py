@@ -66,3 +66,133 @@ class OracleWorkload:
                                         label=label + stage)
             outs[stage]["claims"] = claims
         return outs
+
+
+class OracleExtended:
+    """jolt_amd.stages.DeviceExtended on the CPU oracle: the same description (build_extended), the same operator drivers, every T-scale
+    quantity from oracle/r1cs.c, rw_matrix.c, read_raf.c and the dense members of oracle/sumcheck.c."""
+
+    def __init__(self, n_vars, seed=2026, **kw):
+        from jolt_amd import stages as S
+        self.S, self.n_vars = S, n_vars
+        self.d = S.build_extended(n_vars, seed, **kw)
+        self.one = O.to_mont([1])[0]
+        self.neg = lambda a: O.fr_neg(np.asarray(a).reshape(1, 4))[0]
+
+    def _spartan(self, inputs, eq_sums, tables, tau, kernel, label):
+        sums = eq_sums()
+        tr = O.MockTranscript(label)
+        for v in sums:
+            tr.append_fr(v)
+        r0 = tr.challenge()
+        az, bz = tables()
+        member = O.Member.gruen_product(az, bz, tau, scale=kernel)
+        claim = member.input_claim()
+        rounds = len(tau)
+        out = O.prove_batch([member], [claim], [self.one], [0], rounds, 3, label=label + 1)
+        point = out["challenges"][rounds - self.n_vars:][::-1]
+        values = np.stack([O.poly_evaluate(z, point) for z in inputs]) if self.n_vars else np.stack([z[0] for z in inputs])
+        return dict(sums=sums, r0=r0, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], values=values, claim=claim)
+
+    def spartan_outer(self, label):
+        d = self.d
+        inputs = [O.fr_from_u64(c) for c in d["outer_cols"]]
+        n = len(inputs)
+        shape = d["outer_iwa"].shape
+        wa_f = O.fr_from_i64(d["outer_iwa"].reshape(-1)).reshape(shape + (4,))
+        wb_f = O.fr_from_i64(d["outer_iwb"].reshape(-1)).reshape(shape + (4,))
+        eq = O.eq_evals(d["outer_tau"])
+        return self._spartan(inputs, lambda: O.r1cs_uniskip_sums(inputs, eq, wa_f, wb_f), lambda: O.r1cs_materialize(inputs, d["outer_wa"], d["outer_wb"]),
+                             d["outer_tau"], d["outer_kernel"], label)
+
+    def spartan_product(self, label):
+        d = self.d
+        rows = d["product_rows"]
+        two64 = O.to_mont([1 << 64])[0].reshape(1, 4)
+        hi = O.fr_from_i64(rows["right_input"][:, 1].copy().view(np.int64))
+        right = O.fr_add(O.fr_mul(hi, np.repeat(two64, hi.shape[0], axis=0)), O.fr_from_u64(rows["right_input"][:, 0].copy()))
+        lanes = [O.fr_from_u64(rows["left_input"]), O.fr_from_u64(rows["lookup_output"]), O.fr_from_u64(rows["jump"].astype(np.uint64)), right,
+                 O.fr_from_u64(rows["branch"].astype(np.uint64)), O.fr_from_u64(rows["next_is_noop"].astype(np.uint64))]
+        eq = O.eq_evals(d["product_tau"]) if self.n_vars else O.to_mont([1])
+        return self._spartan(lanes, lambda: O.spartan_product_t1(rows, eq), lambda: O.spartan_product_tables(rows, d["product_w"]), d["product_tau"], d["product_kernel"], label)
+
+    def ram_read_write(self, label):
+        S, d = self.S, self.d
+        ram = d["ram"]
+        log_t, log_k = ram["log_t"], ram["log_k"]
+        gamma = d["ram_gamma"]
+        state = dict(inc=O.fr_from_i64(ram["inc"]), vi=O.fr_from_u64(ram["val_init"]))
+        orc = O.RwMatrix(ram["addresses"], ram["pre"], ram["post"])
+        eq_state = O.SplitEqState(d["ram_tau"])
+        # the input claim from the dense definition: sum_j eq(tau, j) * [access_j] * (pre_j + gamma * post_j)
+        acc = ram["addresses"] != S.NO_ACCESS
+        pre, post = O.fr_from_u64(np.where(acc, ram["pre"], 0).astype(np.uint64)), O.fr_from_u64(np.where(acc, ram["post"], 0).astype(np.uint64))
+        g = np.repeat(np.asarray(gamma).reshape(1, 4), pre.shape[0], axis=0)
+        claim = O.Member.expr([O.eq_evals(d["ram_tau"]), O.fr_add(pre, O.fr_mul(g, post))], [(self.one, [0, 1])], 2).input_claim()
+
+        def ingest(rnd_bound, bind):
+            if rnd_bound < log_t:
+                orc.cycle_bind(bind)
+                eq_state.bind(bind)
+                state["inc"] = O.bind_low_to_high(state["inc"], bind)
+                if rnd_bound == log_t - 1:
+                    orc.into_address_major()
+            else:
+                state["vi"] = orc.address_bind(bind, state["vi"])
+
+        def matrix_round(rnd, bind):
+            if bind is not None:
+                ingest(rnd - 1, bind)
+            if rnd < log_t:
+                e_out, e_in, in_bits = eq_state.tables()
+                return orc.cycle_round(e_out, e_in, in_bits, state["inc"], gamma), (eq_state.scalar, eq_state.point())
+            return orc.address_round(state["vi"], state["inc"], eq_state.scalar.reshape(1, 4), gamma), None
+
+        def final_values():
+            ra_f, val_f = orc.final_values(state["vi"])
+            return np.stack([ra_f, val_f, state["inc"][0], eq_state.scalar])
+
+        class Tr:
+            def __init__(self, label):
+                self.t = O.MockTranscript(label)
+
+            def append(self, values):
+                for v in np.asarray(values).reshape(-1, 4):
+                    self.t.append_fr(v)
+
+            def challenge(self):
+                return self.t.challenge()
+
+        S._sub = lambda a, b: O.fr_sub(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+        out = S.rw_rounds(matrix_round, lambda bind: ingest(log_t + log_k - 1, bind), final_values, log_t, log_k, claim, Tr(label), O.gruen_poly_deg_3,
+                          O.univariate_from_evals, O.univariate_evaluate)
+        out["claim"] = claim
+        orc.close()
+        return out
+
+    def instruction_read_raf(self, label):
+        S, d = self.S, self.d
+        lk = d["lookup"]
+        tr = O.MockTranscript(label)
+        u = O.eq_evals(d["lookup_u_point"])
+        v_tables, scans = [], []
+        for phase in range(S.PHASES):
+            suffix_len = S.ADDRESS_BITS - 8 * (phase + 1)
+            if phase:
+                u = O.read_raf_condense(lk["idx"], u, v_tables[-1], suffix_len + 8)
+            raf, suf = O.read_raf_phase_scan(lk["idx"], lk["table"], lk["raf"], lk["n_tables"], u, suffix_len, S.ADDRESS_BITS, lk["lists"])
+            for v in list(raf.reshape(-1, 4)) + list(suf.reshape(-1, 4)):
+                tr.append_fr(v)
+            scans.append((raf, suf))
+            v_tables.append(O.eq_evals(np.stack([tr.challenge() for _ in range(8)])))
+        vt = np.stack(v_tables)
+        combined, ra = O.read_raf_cycle_tables(lk["idx"], lk["table"], lk["raf"], d["lookup_table_values"], d["lookup_raf"][0], d["lookup_raf"][1], vt, S.ADDRESS_BITS, d["ra_count"])
+        n_f = 1 + d["ra_count"]
+        orc = O.Member.expr([O.eq_evals(d["lookup_reduction"]), combined] + [ra[i] for i in range(d["ra_count"])], [(self.one, list(range(1 + n_f)))], 1 + n_f)
+        claim = orc.input_claim()
+        out = O.prove_batch([orc], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)
+        return dict(scans=scans, v_tables=vt, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], claim=claim)
+
+    def prove(self, label=0):
+        return {"spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
+                "instruction_read_raf": self.instruction_read_raf(label + 400)}
