@@ -48,6 +48,9 @@ struct jolt_read_raf {
     Fr *bin_raf = nullptr, *d_suffix = nullptr, *d_raf = nullptr;
     uint32_t* d_cfg = nullptr;
     size_t suffix_cap = 0, cfg_cap = 0;
+    uint32_t* seg_start = nullptr;  // per bin: index of its first work item (a bin's rows are cut into items of kRafSegRows rows)
+    Fr* part = nullptr;             // per work item: the 6 RAF sums, then one sum per suffix of the bin's table
+    size_t part_cap = 0;
 };
 
 namespace {
@@ -85,16 +88,48 @@ __device__ __forceinline__ Fr wave_sum_fr(Fr v) {
 // (sum a z) held as an unreduced integer -> its Montgomery field element
 __device__ __forceinline__ Fr small_value(const SmallAcc& acc) { return mul(small_redc<FrParams>(acc), Fr::r2()); }
 
+// Work items.  Lookup indices are skewed (small operands, zero, all-ones: a third of a real trace's rows can share one chunk value), so a
+// bin is cut into items of kRafSegRows rows, one wavefront each; partial sums are folded per bin afterwards.  (One wavefront per BIN took as
+// long as the fullest bin: 9 ms per phase on a trace with 12 % zero indices where uniform indices take 1.3 ms.)
+constexpr uint32_t kRafSegRows = 1024;
+__global__ __launch_bounds__(1024) void k_rr_segments(const uint32_t* __restrict__ hist, uint32_t n_bins, uint32_t* __restrict__ seg_start) {
+    __shared__ uint32_t sm[1024];
+    const uint32_t per = (n_bins + 1023) / 1024, lo = min(threadIdx.x * per, n_bins), hi = min(lo + per, n_bins);
+    uint32_t local = 0;
+    for (uint32_t b = lo; b < hi; ++b) local += (hist[b + 1] + kRafSegRows - 1) / kRafSegRows;
+    sm[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = sm[threadIdx.x] - local;
+    for (uint32_t b = lo; b < hi; ++b) {
+        seg_start[b] = run;
+        run += (hist[b + 1] + kRafSegRows - 1) / kRafSegRows;
+    }
+    if (threadIdx.x == 1023) seg_start[n_bins] = sm[1023];
+}
+
 // cfg: [0 .. n_tables] suffix offsets, then the suffix kinds (one u32 each)
 __global__ __launch_bounds__(kBlock) void k_rr_accumulate(const uint64_t* __restrict__ index, const uint8_t* __restrict__ raf, const Fr* __restrict__ u,
                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                           uint32_t n_tables, uint32_t suffix_len, uint32_t upper_suffix_bits, int canonical,
-                                                          const uint32_t* __restrict__ cfg, Fr* __restrict__ bin_raf, Fr* __restrict__ suffix_out) {
+                                                          const uint32_t* __restrict__ cfg, const uint32_t* __restrict__ seg_start, uint32_t slots, Fr* __restrict__ part) {
     const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
-    const uint32_t n_bins = (n_tables + 1) * kRafChunk;
-    for (uint32_t bin = wave; bin < n_bins; bin += n_waves) {
-        const uint32_t bucket = bin / kRafChunk, chunk = bin % kRafChunk;
-        const uint32_t cnt = hist[bin + 1], start = offs[bin + 1];
+    const uint32_t n_bins = (n_tables + 1) * kRafChunk, n_items = seg_start[n_bins];
+    for (uint32_t item = wave; item < n_items; item += n_waves) {
+        uint32_t b_lo = 0, b_hi = n_bins;  // the bin with seg_start[bin] <= item < seg_start[bin + 1] (empty bins own no item)
+        while (b_hi - b_lo > 1) {
+            const uint32_t mid = (b_lo + b_hi) >> 1;
+            if (seg_start[mid] <= item) b_lo = mid; else b_hi = mid;
+        }
+        const uint32_t bin = b_lo, bucket = bin / kRafChunk;
+        const uint32_t first = (item - seg_start[bin]) * kRafSegRows;
+        const uint32_t cnt = min(hist[bin + 1] - first, kRafSegRows), start = offs[bin + 1] + first;
+        Fr* out = part + (size_t)item * slots;
         // ---- RAF scan, operand rows (raf_flag = 0): shift_half, left, right (:785-796)
         {
             Fr shift_half = Fr::zero();
@@ -113,9 +148,9 @@ __global__ __launch_bounds__(kBlock) void k_rr_accumulate(const uint64_t* __rest
             }
             const Fr s0 = wave_sum_fr(small_value(left)), s1 = wave_sum_fr(small_value(right)), s3 = wave_sum_fr(shift_half);
             if (lane == 0) {
-                st_fr(bin_raf + (size_t)bin * kRafSums + 0, s0);
-                st_fr(bin_raf + (size_t)bin * kRafSums + 1, s1);
-                st_fr(bin_raf + (size_t)bin * kRafSums + 3, s3);
+                st_fr(out + 0, s0);
+                st_fr(out + 1, s1);
+                st_fr(out + 3, s3);
             }
         }
         // ---- RAF scan, identity rows (raf_flag = 1): shift_full, identity, upper_all_ones (:776-784, :797-802)
@@ -145,9 +180,9 @@ __global__ __launch_bounds__(kBlock) void k_rr_accumulate(const uint64_t* __rest
             }
             const Fr s2 = wave_sum_fr(small_value(identity)), s4 = wave_sum_fr(shift_full), s5 = wave_sum_fr(upper);
             if (lane == 0) {
-                st_fr(bin_raf + (size_t)bin * kRafSums + 2, s2);
-                st_fr(bin_raf + (size_t)bin * kRafSums + 4, s4);
-                st_fr(bin_raf + (size_t)bin * kRafSums + 5, s5);
+                st_fr(out + 2, s2);
+                st_fr(out + 4, s4);
+                st_fr(out + 5, s5);
             }
         }
         // ---- suffix accumulators of this bin's table (:901-971)
@@ -166,10 +201,24 @@ __global__ __launch_bounds__(kBlock) void k_rr_accumulate(const uint64_t* __rest
                     small_fmadd<2>(acc, ld_fr(u + j), m);
                 }
                 const Fr total = wave_sum_fr(small_value(acc));
-                if (lane == 0) st_fr(suffix_out + (size_t)s * kRafChunk + chunk, total);
+                if (lane == 0) st_fr(out + kRafSums + (s - s_lo), total);
             }
         }
     }
+}
+// per bin: the sums of its items -> bin_raf[bin][6] and suffix_out[(first suffix of the bin's table + s) * 256 + chunk]
+__global__ __launch_bounds__(kBlock) void k_rr_fold_items(const Fr* __restrict__ part, const uint32_t* __restrict__ seg_start, uint32_t n_tables, uint32_t slots,
+                                                          const uint32_t* __restrict__ cfg, Fr* __restrict__ bin_raf, Fr* __restrict__ suffix_out) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x, n_bins = (n_tables + 1) * kRafChunk;
+    const uint32_t bin = t / slots, q = t % slots;
+    if (bin >= n_bins) return;
+    const uint32_t bucket = bin / kRafChunk, chunk = bin % kRafChunk;
+    Fr acc = Fr::zero();
+    for (uint32_t item = seg_start[bin]; item < seg_start[bin + 1]; ++item) acc = add(acc, ld_fr(part + (size_t)item * slots + q));
+    if (q < kRafSums) { st_fr(bin_raf + (size_t)bin * kRafSums + q, acc); return; }
+    if (bucket >= n_tables) return;
+    const uint32_t s = cfg[bucket] + (q - kRafSums);
+    if (s < cfg[bucket + 1]) st_fr(suffix_out + (size_t)s * kRafChunk + chunk, acc);
 }
 // raf_out[q * 256 + chunk] = sum over the buckets of bin_raf[(bucket * 256 + chunk) * 6 + q]
 __global__ __launch_bounds__(kBlock) void k_rr_fold_raf(const Fr* __restrict__ bin_raf, uint32_t n_buckets, Fr* __restrict__ raf_out) {
@@ -224,7 +273,7 @@ extern "C" int32_t jolt_read_raf_destroy(jolt_ctx* ctx, jolt_read_raf* rr) {
     if (!rr) return JOLT_OK;
     jolt_ctx* c = ctx ? ctx : rr->ctx;
     if (c) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {rr->index, rr->table, rr->raf, rr->keys, rr->sorted, rr->hist, rr->offs, rr->cursor, rr->bin_raf, rr->d_suffix, rr->d_raf, rr->d_cfg};
+    void* ptrs[] = {rr->index, rr->table, rr->raf, rr->keys, rr->sorted, rr->hist, rr->offs, rr->cursor, rr->bin_raf, rr->d_suffix, rr->d_raf, rr->d_cfg, rr->seg_start, rr->part};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete rr;
@@ -251,6 +300,7 @@ extern "C" int32_t jolt_read_raf_create(jolt_ctx* ctx, const uint64_t* lookup_in
     if (e == hipSuccess) e = hipMalloc((void**)&rr->hist, n_bins * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->offs, n_bins * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->cursor, n_bins * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&rr->seg_start, (n_bins + 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->bin_raf, n_bins * kRafSums * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc((void**)&rr->d_raf, kRafSums * kRafChunk * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(rr->index, lookup_index, cycles * 16, hipMemcpyHostToDevice, ctx->stream);
@@ -293,6 +343,15 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
         JOLT_HIP_TRY(ctx, hipMalloc((void**)&rr->d_suffix, (size_t)total_suffixes * kRafChunk * sizeof(Fr)));
         rr->suffix_cap = (size_t)total_suffixes * kRafChunk;
     }
+    uint32_t max_suffixes = 0;
+    for (uint32_t t = 0; t < n_tables; ++t) max_suffixes = std::max(max_suffixes, suffix_offsets[t + 1] - suffix_offsets[t]);
+    const uint32_t slots = kRafSums + max_suffixes;
+    const size_t max_items = rr->cycles / kRafSegRows + (size_t)(n_tables + 1) * kRafChunk + 1;
+    if (max_items * slots > rr->part_cap) {
+        if (rr->part) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(rr->part)); rr->part = nullptr; }
+        JOLT_HIP_TRY(ctx, hipMalloc((void**)&rr->part, max_items * slots * sizeof(Fr)));
+        rr->part_cap = max_items * slots;
+    }
     hipStream_t st = ctx->stream;
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(rr->d_cfg, cfg.data(), cfg.size() * 4, hipMemcpyHostToDevice, st));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));  // cfg is a local
@@ -312,10 +371,13 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
     hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)rr->hist, rr->offs, rr->cursor, B, 0x7FFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)rr->keys, T, B, rr->cursor, rr->sorted);
     const uint32_t upper_suffix_bits = suffix_len > address_bits / 2 ? suffix_len - address_bits / 2 : 0;  // suffix_len.saturating_sub(address_bits / 2) (:765)
-    const unsigned grid = (unsigned)std::min<size_t>(((size_t)B + 3) / 4, (size_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_rr_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)rr->hist, B, rr->seg_start);
+    const unsigned grid = (unsigned)std::min<size_t>((max_items + 3) / 4, (size_t)ctx->num_cus * 16);
     hipLaunchKernelGGL(k_rr_accumulate, dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)rr->index, (const uint8_t*)rr->raf, (const Fr*)u->data(), (const uint32_t*)rr->sorted,
-                       (const uint32_t*)rr->hist, (const uint32_t*)rr->offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg, rr->bin_raf,
-                       rr->d_suffix);
+                       (const uint32_t*)rr->hist, (const uint32_t*)rr->offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
+                       (const uint32_t*)rr->seg_start, slots, rr->part);
+    hipLaunchKernelGGL(k_rr_fold_items, dim3((unsigned)(((size_t)B * slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const Fr*)rr->part, (const uint32_t*)rr->seg_start, n_tables,
+                       slots, (const uint32_t*)rr->d_cfg, rr->bin_raf, rr->d_suffix);
     hipLaunchKernelGGL(k_rr_fold_raf, dim3(kRafSums), dim3(kRafChunk), 0, st, (const Fr*)rr->bin_raf, n_tables + 1, rr->d_raf);
     JOLT_HIP_TRY(ctx, hipGetLastError());
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(raf_out, rr->d_raf, kRafSums * kRafChunk * sizeof(Fr), hipMemcpyDeviceToHost, st));

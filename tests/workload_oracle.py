@@ -181,7 +181,7 @@ class OracleExtended:
             if phase:
                 u = O.read_raf_condense(lk["idx"], u, v_tables[-1], suffix_len + 8)
             raf, suf = O.read_raf_phase_scan(lk["idx"], lk["table"], lk["raf"], lk["n_tables"], u, suffix_len, S.ADDRESS_BITS, lk["lists"])
-            for v in list(raf.reshape(-1, 4)) + list(suf.reshape(-1, 4)):
+            for v in list(raf[:, 0]) + list(suf[:, 0]):
                 tr.append_fr(v)
             scans.append((raf, suf))
             v_tables.append(O.eq_evals(np.stack([tr.challenge() for _ in range(8)])))

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where the time of jolt_amd/stages.py's operators goes (a synchronisation after every part): time_extended.py [log_t]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from jolt_amd import ffi  # noqa: E402
+from jolt_amd import stages as S  # noqa: E402
+
+
+def main():
+    log_t = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+    ctx = ffi.Context(0)
+    e = S.DeviceExtended(ctx, log_t)
+    d, lk, rr = e.d, e.d["lookup"], e.read_raf
+    for rep in range(2):
+        acc = {}
+
+        def lap(name, t0):
+            ctx.synchronize()
+            acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+
+        tr = ffi.HostTranscript(5)
+        t0 = time.perf_counter(); u = ctx.eq_evals(d["lookup_u_point"]); lap("eq", t0)
+        v_tables = []
+        for phase in range(S.PHASES):
+            suffix_len = S.ADDRESS_BITS - 8 * (phase + 1)
+            if phase:
+                t0 = time.perf_counter(); rr.condense(u, v_tables[-1], suffix_len + 8); lap("condense", t0)
+            t0 = time.perf_counter(); raf, suf = rr.phase_scan(u, suffix_len, S.ADDRESS_BITS, lk["lists"]); lap("scan", t0)
+            t0 = time.perf_counter(); tr.append(raf.reshape(-1, 4)); tr.append(suf.reshape(-1, 4)); lap("append", t0)
+            t0 = time.perf_counter(); v_tables.append(ffi.host_eq_evals(np.stack([tr.challenge() for _ in range(8)]))); lap("challenges", t0)
+        u.free()
+        vt = np.stack(v_tables)
+        t0 = time.perf_counter(); combined, ra = rr.cycle_tables(d["lookup_table_values"], d["lookup_raf"][0], d["lookup_raf"][1], vt, S.ADDRESS_BITS, d["ra_count"]); lap("cycle_tables", t0)
+        n_f = 1 + d["ra_count"]
+        t0 = time.perf_counter(); member = ctx.member_lc([combined] + ra, [[(None, [(e.one, i)]) for i in range(n_f)]], n_f, eq_point=d["lookup_reduction"]); lap("member", t0)
+        if e.claims["lookup"] is None:
+            e.claims["lookup"] = member.input_claim()
+        t0 = time.perf_counter(); ctx.prove_batch([member], [e.claims["lookup"]], [e.one], [0], log_t, n_f + 1, label=6); lap("cycle_rounds", t0)
+        member.destroy()
+        print({k: round(v, 2) for k, v in acc.items()}, flush=True)
+    for name, fn in (("spartan_outer", lambda: e.spartan(e.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"], e.claims["outer"], 2, 7)),
+                     ("ram", lambda: e.ram_read_write(8))):
+        fn(); ctx.synchronize(); t0 = time.perf_counter(); fn(); ctx.synchronize()
+        print(name, round((time.perf_counter() - t0) * 1e3, 2), "ms")
+
+
+if __name__ == "__main__":
+    main()
