@@ -63,6 +63,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
     if (const char* sg = std::getenv("JOLT_MSM_STAGGER")) ctx->msm_stagger = std::atoi(sg) != 0;
     if (const char* gr = std::getenv("JOLT_FX_REDUCE")) ctx->msm_fx_grid_reduce = std::atoi(gr) != 0;
+    if (const char* cs = std::getenv("JOLT_MSM_CU_SPLIT")) ctx->msm_cu_split = std::max(0, std::min(7, std::atoi(cs)));
     if (const char* rd = std::getenv("JOLT_FX_REDUCE_DIV")) ctx->msm_fx_reduce_div = std::max(1, std::atoi(rd));
     if (const char* fl = std::getenv("JOLT_FX_LFORM")) ctx->msm_fx_lform = std::atoi(fl) != 0;
     if (const char* fs = std::getenv("JOLT_FX_STAGE")) ctx->msm_fx_stage = std::atoi(fs) != 0;
@@ -89,6 +90,26 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
             *ctx->h_flag = 0;
         for (int k = 0; k < 3 && s == JOLT_OK; ++k)
             if (hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) != hipSuccess) s = JOLT_ERR_HIP;
+        if (s == JOLT_OK && ctx->msm_cu_split > 0) {
+            // bit n of the mask <-> compute unit n; the split is taken inside every group of 8 consecutive bits, which gives k of 8 CUs on
+            // every XCD whether the runtime numbers the CUs XCD-major or round-robin over the XCDs
+            const int words = (ctx->num_cus + 31) / 32;
+            std::vector<uint32_t> mask_sort(words, 0u), mask_bucket(words, 0u);
+            for (int n = 0; n < ctx->num_cus; ++n) {
+                const bool sort_cu = ((n / 8) % 8) < ctx->msm_cu_split;
+                (sort_cu ? mask_sort : mask_bucket)[n / 32] |= 1u << (n % 32);
+            }
+            for (int k = 0; k < 4 && s == JOLT_OK; ++k) {
+                if (hipExtStreamCreateWithCUMask(&ctx->sort_stream[k], (uint32_t)words, mask_sort.data()) != hipSuccess ||
+                    hipExtStreamCreateWithCUMask(&ctx->bucket_stream[k], (uint32_t)words, mask_bucket.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->msm_cu_split = 0;  // the runtime refuses CU masks: keep the single-stream lanes
+                    break;
+                }
+                for (int j = 0; j < 4; ++j)
+                    if (hipEventCreateWithFlags(&ctx->ev_phase[k][j], hipEventDisableTiming) != hipSuccess) s = JOLT_ERR_HIP;
+            }
+        }
         if (s == JOLT_OK && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) s = JOLT_ERR_HIP;
         for (int k = 0; k < 3 && s == JOLT_OK; ++k)
             if (hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) != hipSuccess) s = JOLT_ERR_HIP;
@@ -107,6 +128,11 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     jolt_internal_engine_free(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 3; ++k) if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
+    for (int k = 0; k < 4; ++k) {
+        if (ctx->sort_stream[k]) { (void)hipStreamSynchronize(ctx->sort_stream[k]); (void)hipStreamDestroy(ctx->sort_stream[k]); }
+        if (ctx->bucket_stream[k]) { (void)hipStreamSynchronize(ctx->bucket_stream[k]); (void)hipStreamDestroy(ctx->bucket_stream[k]); }
+        for (int j = 0; j < 4; ++j) if (ctx->ev_phase[k][j]) (void)hipEventDestroy(ctx->ev_phase[k][j]);
+    }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (int k = 0; k < 3; ++k) if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     (void)jolt_internal_pool_trim(ctx);

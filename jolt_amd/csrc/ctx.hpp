@@ -76,6 +76,12 @@ struct jolt_ctx {
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)
     bool msm_fx_grid_reduce = true;  // fixed-base MSM: bucket reduction by rows and columns (JOLT_FX_REDUCE=0: running sums, for an A/B)
+    // JOLT_MSM_CU_SPLIT=k (experiment, off by default): the fixed-base MSM's HBM-bound phases (digits .. bucket order) and its bucket reduction run on
+    // streams confined to k compute units of every group of 8, its bucket sums on streams confined to the other 8 - k, so that one MSM's
+    // sort runs UNDER another MSM's bucket sums (the bucket kernel fills the VGPR file of every CU it can reach: nothing co-resides with it)
+    int msm_cu_split = 0;
+    hipStream_t sort_stream[4] = {nullptr, nullptr, nullptr, nullptr}, bucket_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_phase[4][4] = {};
     bool msm_stagger = false;     // JOLT_MSM_STAGGER=1: serialise the sort phases of concurrent fixed-base MSMs (see ev_sort)
     int msm_fx_reduce_div = 24;   // buckets per thread of the fixed-base bucket reduction (JOLT_FX_REDUCE_DIV)
     bool msm_fx_lform = true;     // JOLT_FX_LFORM=0: window tables in standard form, word-form XYZZ accumulators (A/B of fq_limb.hip.h)

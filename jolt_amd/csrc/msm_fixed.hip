@@ -747,9 +747,14 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
                  o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4),
                  o_grouped = take(ctx->msm_fx_partition == 2 ? total * 8 : 256), o_gcur = take(kPartBins * 4);
     hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
+    // phases: sort (HBM bound) -> bucket sums (multiply-add bound) -> reduction (latency bound).  One stream by default; with JOLT_MSM_CU_SPLIT the
+    // sort and the reduction run on the lane's CU-masked "sort" stream and the bucket sums on its "bucket" stream (ctx.hpp), chained by events
+    const bool split = ctx->msm_cu_split > 0 && ctx->sort_stream[lane] && ctx->bucket_stream[lane];
+    hipStream_t sst = split ? ctx->sort_stream[lane] : st, bst = split ? ctx->bucket_stream[lane] : st;
     if (off > ctx->msm_ws_cap[lane]) {
         if (ctx->msm_ws[lane]) {
             JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (split) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(sst)); JOLT_HIP_TRY(ctx, hipStreamSynchronize(bst)); }
             JOLT_HIP_TRY(ctx, hipFree(ctx->msm_ws[lane]));
             ctx->msm_ws[lane] = nullptr;
             ctx->msm_ws_cap[lane] = 0;
@@ -795,57 +800,65 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     // that MSM's bucket sums instead of beside its sort
     if (ctx->msm_stagger && ctx->sort_seq > 0 && ctx->sort_last_lane != lane)
         JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_sort[(ctx->sort_seq - 1) % 8], 0));
-    JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, st));
+    if (split) {  // the sort starts after whatever the lane's stream holds (the scalars' producers, the lane's previous MSM)
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][0], st));
+        JOLT_HIP_TRY(ctx, hipStreamWaitEvent(sst, ctx->ev_phase[lane][0], 0));
+    }
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, sst));
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
-    hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, st, d_scalars, n, c, W, keys);
-    if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
-    else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, nb1, hist1);
-    hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, st, (const uint32_t*)hist1, nb1, offs1, cur1, info);
+    hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, sst, d_scalars, n, c, W, keys);
+    if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
+    else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
+    hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, sst, (const uint32_t*)hist1, nb1, offs1, cur1, info);
     JOLT_HIP_TRY(ctx, hipGetLastError());
-    JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), st));  // z = 0: identity
-    JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, st));
-    JOLT_HIP_TRY(ctx, hipMemsetAsync(class_hist, 0, kClasses * 4, st));
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), sst));  // z = 0: identity
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, sst));
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(class_hist, 0, kClasses * 4, sst));
     const bool two_pass = ctx->msm_fx_partition == 2 && n_groups <= (uint32_t)kPartBins && sizeof(PartShared) + 2048 <= ctx->max_lds_per_block;
     const unsigned part_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, (total + kPartTile - 1) / kPartTile));
     if (two_pass) {
-        hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, st, (const uint32_t*)offs1, n_groups, group_cursor);
+        hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
         if (lo_bits == 8) {
-            hipLaunchKernelGGL(k_fx_partition_groups<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
+            hipLaunchKernelGGL(k_fx_partition_groups<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), sst, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
                                group_cursor, grouped);
-            hipLaunchKernelGGL(k_fx_partition_segments<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
+            hipLaunchKernelGGL(k_fx_partition_segments<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), sst, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
                                (const uint32_t*)info, cur1, entries);
         } else {
-            hipLaunchKernelGGL(k_fx_partition_groups<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
+            hipLaunchKernelGGL(k_fx_partition_groups<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), sst, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
                                group_cursor, grouped);
-            hipLaunchKernelGGL(k_fx_partition_segments<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), st, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
+            hipLaunchKernelGGL(k_fx_partition_segments<11>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), sst, (const uint64_t*)grouped, (const uint32_t*)offs1, nb1,
                                (const uint32_t*)info, cur1, entries);
         }
     } else if (lo_bits == 8) {
-        hipLaunchKernelGGL(k_fx_scatter<8>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
+        hipLaunchKernelGGL(k_fx_scatter<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
     } else {
-        hipLaunchKernelGGL(k_fx_scatter<11>, dim3(slices), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
+        hipLaunchKernelGGL(k_fx_scatter<11>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, n, srs->pre_stride, nb1, cur1, entries);
     }
     if (lo_bits == 8) {
         // LDS for the staged segment: twice the average segment (uniform digits spread by ~1 %), at most what a CU has
         const size_t lds_max = ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0;  // cnt / cur / cls / wave sums live next to it
         const size_t want = (2 * (total / nb1) + 2048) * 4;
         const size_t stage_bytes = ctx->msm_fx_stage ? std::min(lds_max, want) : 0;
-        hipLaunchKernelGGL(k_fx_segment_sort_staged<8>, dim3(nb1), dim3(kSegThreads), stage_bytes, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys,
+        hipLaunchKernelGGL(k_fx_segment_sort_staged<8>, dim3(nb1), dim3(kSegThreads), stage_bytes, sst, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys,
                            hist, offs, heavy_threshold, heavy, hcnt, heavy_cap, class_hist, (uint32_t)(stage_bytes / 4));
     }
     else
-        hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, st, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
+        hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, sst, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
                            heavy_threshold, heavy, hcnt, heavy_cap, class_hist);
     // bucket sums: the kernels of the per-window method with ONE window of B buckets (bases = the window tables)
     const unsigned gh = std::min<uint32_t>((heavy_cap + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * 64);  // grid-stride over the heavy list (its length lives on the device)
-    hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, st, (const uint32_t*)class_hist, class_cursor);
-    hipLaunchKernelGGL(k_fx_order, dim3((unsigned)((n_buckets + kBlock * kOrderPer - 1) / (kBlock * kOrderPer))), dim3(kBlock), 0, st, (const uint32_t*)hist, (uint32_t)n_buckets,
+    hipLaunchKernelGGL(k_fx_order_scan, dim3(1), dim3(kClasses), 0, sst, (const uint32_t*)class_hist, class_cursor);
+    hipLaunchKernelGGL(k_fx_order, dim3((unsigned)((n_buckets + kBlock * kOrderPer - 1) / (kBlock * kOrderPer))), dim3(kBlock), 0, sst, (const uint32_t*)hist, (uint32_t)n_buckets,
                        heavy_threshold, class_cursor, order);
     if (ctx->msm_stagger) {
-        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_sort[ctx->sort_seq % 8], st));
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_sort[ctx->sort_seq % 8], sst));
         ctx->sort_seq++;
         ctx->sort_last_lane = lane;
+    }
+    if (split) {
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][1], sst));
+        JOLT_HIP_TRY(ctx, hipStreamWaitEvent(bst, ctx->ev_phase[lane][1], 0));
     }
     LformConsts lc;
     {
@@ -856,17 +869,17 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     }
     const unsigned bucket_grid = (unsigned)((n_buckets + kBlock - 1) / kBlock);
     if (srs->pre_lform) {
-        hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+        hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
-        hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
+        hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
                            (const uint32_t*)keys, (const G1Affine*)srs->pre, seg, lc);
     } else {
-        hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, st, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+        hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                            (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
-        hipLaunchKernelGGL(k_fx_heavy_segments<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
+        hipLaunchKernelGGL(k_fx_heavy_segments<false>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
                            (const uint32_t*)keys, (const G1Affine*)srs->pre, seg, lc);
     }
-    hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
+    hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
                        (const G1Jac*)seg, buckets);
     if (grid_reduce) {
         G1Jac* colpart = (G1Jac*)(ws + o_red);
@@ -874,22 +887,23 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         G1Jac* cols = rowpart + (size_t)red_H * red_per_row;  // C_l, l < 2^S
         G1Jac* rows = cols + kRedCols;                         // R_h, h < H
         G1Jac* small_part = rows + red_H;                      // block partials of the two small reductions
-        hipLaunchKernelGGL(k_fx_red_cols, dim3(kRedCols / kBlock, red_chunks), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, red_H, colpart);
-        hipLaunchKernelGGL(k_fx_red_rows, dim3((red_H * red_per_row + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, red_H, rowpart);
-        hipLaunchKernelGGL(k_fx_red_fold, dim3(kRedCols * 64 / kBlock), dim3(kBlock), 0, st, (const G1Jac*)colpart, kRedCols, red_chunks, (size_t)kRedCols, (size_t)1, cols);
-        hipLaunchKernelGGL(k_fx_red_fold, dim3((red_H * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const G1Jac*)rowpart, red_H, red_per_row, (size_t)1, (size_t)red_per_row, rows);
+        hipLaunchKernelGGL(k_fx_red_cols, dim3(kRedCols / kBlock, red_chunks), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, red_H, colpart);
+        hipLaunchKernelGGL(k_fx_red_rows, dim3((red_H * red_per_row + kBlock - 1) / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, red_H, rowpart);
+        hipLaunchKernelGGL(k_fx_red_fold, dim3(kRedCols * 64 / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)colpart, kRedCols, red_chunks, (size_t)kRedCols, (size_t)1, cols);
+        hipLaunchKernelGGL(k_fx_red_fold, dim3((red_H * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)rowpart, red_H, red_per_row, (size_t)1, (size_t)red_per_row, rows);
         // sum_l l C_l (weights 1 .. 2^S - 1) and sum_h h R_h (weights 1 .. H - 1): index = weight, entry 0 unused -- the layout k_msm_window_reduce reads
         const uint32_t g_small = 8, nb_c = (kRedCols / g_small + kBlock - 1) / kBlock, nb_r = (red_H / g_small + kBlock) / kBlock;
-        hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_c, 1), dim3(kBlock), 0, st, (const G1Jac*)cols, kRedCols - 1, g_small, small_part);
-        hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)small_part, nb_c, wsum);
+        hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_c, 1), dim3(kBlock), 0, bst, (const G1Jac*)cols, kRedCols - 1, g_small, small_part);
+        hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)small_part, nb_c, wsum);
         if (red_H > 1) {
-            hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_r, 1), dim3(kBlock), 0, st, (const G1Jac*)rows, red_H - 1, g_small, small_part + 32);
-            hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)(small_part + 32), nb_r, wsum + 1);
+            hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_r, 1), dim3(kBlock), 0, bst, (const G1Jac*)rows, red_H - 1, g_small, small_part + 32);
+            hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)(small_part + 32), nb_r, wsum + 1);
         } else {
-            JOLT_HIP_TRY(ctx, hipMemsetAsync(wsum + 1, 0, sizeof(G1Jac), st));
+            JOLT_HIP_TRY(ctx, hipMemsetAsync(wsum + 1, 0, sizeof(G1Jac), bst));
         }
         JOLT_HIP_TRY(ctx, hipGetLastError());
-        JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, 2 * sizeof(G1Jac), hipMemcpyDeviceToHost, st));
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, 2 * sizeof(G1Jac), hipMemcpyDeviceToHost, bst));
+        if (split) { JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][3], bst)); JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_phase[lane][3], 0)); }
         job->n = n;
         job->lane = lane;
         job->c = kRedS;  // the collect step's Horner: 2^S * (row-weighted sum) + (column-weighted sum)
@@ -897,10 +911,11 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         job->nb = nb;
         return JOLT_OK;
     }
-    hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, G, part);
-    hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, st, (const G1Jac*)part, nb, wsum);
+    hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, G, part);
+    hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)part, nb, wsum);
     JOLT_HIP_TRY(ctx, hipGetLastError());
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, sizeof(G1Jac), hipMemcpyDeviceToHost, st));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, sizeof(G1Jac), hipMemcpyDeviceToHost, bst));
+    if (split) { JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][3], bst)); JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_phase[lane][3], 0)); }
     job->n = n;
     job->lane = lane;
     job->c = 0;  // a single "window": the collect step's Horner loop adds it once
