@@ -574,6 +574,25 @@ int32_t jolt_rw_matrix_create(jolt_ctx *ctx, const uint64_t *addresses, const ui
 int32_t jolt_rw_matrix_create_resident(jolt_ctx *ctx, const jolt_ints *addresses, const jolt_ints *pre_values, const jolt_ints *post_values,
                                        const jolt_table *inc, const jolt_table *val_init, const jolt_fr_t *tau_low, const jolt_fr_t *gamma,
                                        jolt_rw_matrix **out);
+
+/* Registers read/write checking (stage 4) -- SURVEY.md section 8(f) row 4.  Replaces the sparse cycle-major matrix and the round messages of
+ * OptimizedRegistersReadWrite (crates/jolt-kernels/src/optimized/registers_read_write/{mod.rs:79-402, sparse.rs, rows.rs}): summand
+ *   eq(r_cycle, j) * ( rd_wa * (rd_inc + val) + gamma * rs1_ra * val + gamma^2 * rs2_ra * val )(k, j)   (reference/registers_read_write.rs:3-10)
+ * over (register || cycle), bound low-to-high, the log T cycle variables first; <= 3 cells per cycle (RegisterCycleRow::entries), the
+ * gamma-combined read coefficient and the write coefficient as two columns of the same sparse matrix as jolt_rw_matrix, K-sized dense
+ * arrays on the host for the log K address rounds.  All inputs are resident: `regs` holds the hot-index columns rs1, rs2, rd (polys 0, 1, 2;
+ * k = 2^REGISTER_ADDRESS_BITS), the value columns are JOLT_INT_U64 jolt_ints, `inc` is RdInc (copied).
+ *   prove_round: cycle rounds return (q(0), leading coefficient) in evals_out[0..1] and aux_out = {current_scalar, r_cycle[current_index - 1], 0}
+ *     (the caller completes the cubic with gruen_poly_deg_3); address rounds return s(0), s(1), s(2), s(3) in evals_out[0..3]
+ *     (UnivariatePoly::from_evals).  finish / destroy / len: jolt_rw_matrix_finish / _destroy / _len.
+ *   final_values: {registers_val, rd_wa, gamma * rs1_ra + gamma^2 * rs2_ra, rd_inc, bound cycle-eq factor}; the operand claims rs1_ra / rs2_ra
+ *     are evaluations of the index columns at the bound point: jolt_onehot_materialize(regs, p, eq(r_address, .)) then jolt_evaluate at r_cycle. */
+int32_t jolt_registers_rw_create(jolt_ctx *ctx, const jolt_onehot *regs, const jolt_ints *rs1_val, const jolt_ints *rs2_val, const jolt_ints *rd_pre,
+                                 const jolt_ints *rd_post, const jolt_table *inc, const jolt_fr_t *r_cycle, const jolt_fr_t *gamma, jolt_rw_matrix **out);
+int32_t jolt_registers_rw_prove_round(jolt_rw_matrix *m, const jolt_fr_t *bind, jolt_fr_t *evals_out /* 4 */, jolt_fr_t *aux_out /* 3, may be NULL */);
+int32_t jolt_registers_rw_final_values(jolt_rw_matrix *m, jolt_fr_t *out /* 5 */);
+/* test hook: the cells of the cycle phase */
+int32_t jolt_registers_rw_download(jolt_rw_matrix *m, uint64_t *rows, uint64_t *cols, jolt_fr_t *val, jolt_fr_t *ra, jolt_fr_t *wa, uint64_t *prev, uint64_t *next);
 int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix *m, const jolt_fr_t *bind, jolt_fr_t *evals_out /* 2 */, jolt_fr_t *aux_out /* 3 or NULL */);
 int32_t jolt_rw_matrix_finish(jolt_rw_matrix *m, const jolt_fr_t *bind);
 int32_t jolt_rw_matrix_final_values(jolt_rw_matrix *m, jolt_fr_t *out /* 4 */);

@@ -19,6 +19,7 @@
 
 #include "ctx.hpp"
 #include "ints.hpp"
+#include "onehot.hpp"
 #include "poly_kernels.hip.h"
 
 using namespace jolt;
@@ -39,6 +40,7 @@ struct RwArrays {
     uint64_t *prev_u, *next_u;
     Fr *prev_f, *next_f;
     Fr *val, *ra;
+    Fr* wa;  // registers mode only: the rd_wa coefficient column (ra then holds gamma * rs1_ra + gamma^2 * rs2_ra)
 };
 
 __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t* __restrict__ a, uint32_t n, uint64_t x) {
@@ -71,6 +73,64 @@ __global__ __launch_bounds__(kBlock) void k_rw_build(const uint64_t* __restrict_
     o.next_u[p] = post[j];
     st_fr(o.val + p, fr_from_u64(pre[j]));
     st_fr(o.ra + p, Fr::one());
+}
+
+// ---- registers mode (optimized/registers_read_write/sparse.rs:406-466): <= 3 cells per cycle, sorted by register -------------------------
+// rs2 folds into rs1's cell (ra = gamma + gamma^2), rd into either read's cell (wa = 1, next = the written value)
+struct RegCells {
+    uint32_t col[3];
+    uint64_t prev[3], next[3], val[3];
+    uint32_t ra_kind[3];  // 0: none, 1: rs1, 2: rs2, 3: both
+    uint32_t wa[3];
+    uint32_t len;
+};
+__device__ __forceinline__ RegCells reg_cells(uint32_t rs1, uint64_t rs1_val, uint32_t rs2, uint64_t rs2_val, uint32_t rd, uint64_t rd_pre, uint64_t rd_post) {
+    RegCells c;
+    c.len = 0;
+    if (rs1 != kColdIdx) { c.col[0] = rs1; c.prev[0] = rs1_val; c.next[0] = rs1_val; c.val[0] = rs1_val; c.ra_kind[0] = 1; c.wa[0] = 0; c.len = 1; }
+    if (rs2 != kColdIdx) {
+        if (c.len && c.col[0] == rs2) c.ra_kind[0] = 3;
+        else { const uint32_t k = c.len++; c.col[k] = rs2; c.prev[k] = rs2_val; c.next[k] = rs2_val; c.val[k] = rs2_val; c.ra_kind[k] = 2; c.wa[k] = 0; }
+    }
+    if (rd != kColdIdx) {
+        uint32_t f = 0;
+        while (f < c.len && c.col[f] != rd) ++f;
+        if (f < c.len) { c.wa[f] = 1; c.next[f] = rd_post; }
+        else { const uint32_t k = c.len++; c.col[k] = rd; c.prev[k] = rd_pre; c.next[k] = rd_post; c.val[k] = rd_pre; c.ra_kind[k] = 0; c.wa[k] = 1; }
+    }
+    return c;
+}
+__global__ __launch_bounds__(kBlock) void k_reg_count(const uint8_t* __restrict__ idx, uint32_t wide, uint32_t cycles, uint64_t* __restrict__ flags) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= cycles) return;
+    const uint32_t rs1 = hot_load(hot_col(idx, 0, wide), j, wide), rs2 = hot_load(hot_col(idx, cycles, wide), j, wide), rd = hot_load(hot_col(idx, 2 * (size_t)cycles, wide), j, wide);
+    uint32_t count = rs1 != kColdIdx ? 1u : 0u;  // RegisterCycleRow::entry_count (sparse.rs:392-404)
+    if (rs2 != kColdIdx && rs2 != rs1) count += 1;
+    if (rd != kColdIdx && rd != rs1 && rd != rs2) count += 1;
+    flags[j] = count;
+}
+__global__ __launch_bounds__(kBlock) void k_reg_build(const uint8_t* __restrict__ idx, uint32_t wide, const uint64_t* __restrict__ rs1_val, const uint64_t* __restrict__ rs2_val,
+                                                      const uint64_t* __restrict__ rd_pre, const uint64_t* __restrict__ rd_post, uint32_t cycles, const uint64_t* __restrict__ pos,
+                                                      Fr gamma, Fr gamma2, RwArrays o) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= cycles) return;
+    const uint32_t rs1 = hot_load(hot_col(idx, 0, wide), j, wide), rs2 = hot_load(hot_col(idx, cycles, wide), j, wide), rd = hot_load(hot_col(idx, 2 * (size_t)cycles, wide), j, wide);
+    RegCells c = reg_cells(rs1, rs1_val[j], rs2, rs2_val[j], rd, rd_pre[j], rd_post[j]);
+    uint32_t ord[3] = {0, 1, 2};  // sort by register; len <= 3
+    for (uint32_t a = 0; a < c.len; ++a)
+        for (uint32_t b = a + 1; b < c.len; ++b)
+            if (c.col[ord[b]] < c.col[ord[a]]) { const uint32_t t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    const uint32_t p0 = (uint32_t)pos[j];
+    for (uint32_t a = 0; a < c.len; ++a) {
+        const uint32_t k = ord[a], p = p0 + a;
+        o.key[p] = ((uint64_t)j << 32) | c.col[k];
+        o.prev_u[p] = c.prev[k];
+        o.next_u[p] = c.next[k];
+        st_fr(o.val + p, fr_from_u64(c.val[k]));
+        const Fr ra = c.ra_kind[k] == 0 ? Fr::zero() : (c.ra_kind[k] == 1 ? gamma : (c.ra_kind[k] == 2 ? gamma2 : add(gamma, gamma2)));
+        st_fr(o.ra + p, ra);
+        st_fr(o.wa + p, c.wa[k] ? Fr::one() : Fr::zero());
+    }
 }
 
 // ---- exclusive scan of 64-bit counters (two packed 32-bit sums): block scan, scan of the block sums, add ---------------------------
@@ -150,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_rw_cycle_match(const uint64_t* __res
 
 // CycleMajorMatrix::quadratic_coefficients (rw_matrix.rs:287-325) with CycleMajorEntry::quadratic_evals (:116-145) per pair:
 // partial sums of head(pair) * [q(0), q_inf]; a matched pair is evaluated by its EVEN entry
+template <bool REG>
 __global__ __launch_bounds__(kBlock) void k_rw_cycle_round(RwArrays a, uint32_t n, const uint32_t* __restrict__ sib_lb, const uint32_t* __restrict__ matched,
                                                            const Fr* __restrict__ inc, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits, Fr gamma,
                                                            Fr* __restrict__ partials) {
@@ -164,7 +225,28 @@ __global__ __launch_bounds__(kBlock) void k_rw_cycle_round(RwArrays a, uint32_t 
         const Fr inc0 = ld_fr(inc + 2 * (size_t)pair), inc1 = sub(ld_fr(inc + 2 * (size_t)pair + 1), inc0);
         const Fr ra = ld_fr(a.ra + i), val = ld_fr(a.val + i);
         Fr q0, q1;
-        if (even) {
+        if constexpr (REG) {  // SparseEntry::accumulate_pair_evals (registers_read_write/sparse.rs:283-325): ra_t * val_t + wa_t * (val_t + inc_t)
+            const Fr wa = ld_fr(a.wa + i);
+            if (even) {
+                Fr ra_slope, wa_slope, val_slope;
+                if (m) {
+                    const uint32_t o = sib_lb[i];
+                    ra_slope = sub(ld_fr(a.ra + o), ra);
+                    wa_slope = sub(ld_fr(a.wa + o), wa);
+                    val_slope = sub(ld_fr(a.val + o), val);
+                } else {
+                    ra_slope = neg(ra);
+                    wa_slope = neg(wa);
+                    val_slope = sub(fr_from_u64(a.next_u[i]), val);
+                }
+                q0 = add(mul(ra, val), mul(wa, add(val, inc0)));
+                q1 = add(mul(ra_slope, val_slope), mul(wa_slope, add(val_slope, inc1)));
+            } else {
+                const Fr val_slope = sub(val, fr_from_u64(a.prev_u[i]));
+                q0 = Fr::zero();
+                q1 = add(mul(ra, val_slope), mul(wa, add(val_slope, inc1)));
+            }
+        } else if (even) {
             Fr ra_slope, val_slope;
             if (m) {
                 const uint32_t o = sib_lb[i];
@@ -188,6 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_rw_cycle_round(RwArrays a, uint32_t 
 }
 
 // CycleMajorMatrix::bind (rw_matrix.rs:268-285): every entry writes (at most) one merged entry at its merge rank
+template <bool REG>
 __global__ __launch_bounds__(kBlock) void k_rw_cycle_bind(RwArrays a, uint32_t n, const uint32_t* __restrict__ sib_lb, const uint32_t* __restrict__ matched,
                                                           const uint64_t* __restrict__ scan, Fr r, int shifted, RwArrays o) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -230,6 +313,10 @@ __global__ __launch_bounds__(kBlock) void k_rw_cycle_bind(RwArrays a, uint32_t n
     o.next_u[pos] = nn;
     st_fr(o.ra + pos, nra);
     st_fr(o.val + pos, nval);
+    if constexpr (REG) {  // the write coefficient binds like the read coefficient: a missing side is 0
+        const Fr wa = ld_fr(a.wa + i);
+        st_fr(o.wa + pos, (even && m) ? lerp(wa, ld_fr(a.wa + lb)) : (even ? lerp(wa, Fr::zero()) : lerp(Fr::zero(), wa)));
+    }
 }
 
 // CycleMajorMatrix::into_address_major (rw_matrix.rs:327-337): rows are all 0; key = col, checkpoints promoted
@@ -347,6 +434,9 @@ struct jolt_rw_matrix {
     uint64_t *flags = nullptr, *scan = nullptr, *block_sums = nullptr, *total = nullptr;
     uint64_t* h_total = nullptr;  // pinned
     bool match_valid = false;
+    bool registers = false;                 // registers read/write checking: two coefficient columns, dense K-sized address phase on the host
+    std::vector<Fr> reg_ra, reg_wa, reg_val;  // the address-phase state (ReadWriteKernel::{ra, wa, val}, registers_read_write/mod.rs:162-169)
+    Fr inc_scalar;
     jolt_table *inc = nullptr, *val_init = nullptr;
     Fr gamma;
     // GruenSplitEqPolynomial::new(tau_low, LowToHigh) host half (split_eq.rs:187-363)
@@ -426,10 +516,11 @@ static int32_t rw_create_impl(jolt_ctx* ctx, const uint64_t* addresses, const ui
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t o_up = take(resident ? 256 : 3 * cycles * 8);
-    size_t o_st[2][7];
+    size_t o_st[2][8];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = take((size_t)m->cap * 8); o_st[b][1] = take((size_t)m->cap * 8); o_st[b][2] = take((size_t)m->cap * 8);
         o_st[b][3] = take((size_t)m->cap * 32); o_st[b][4] = take((size_t)m->cap * 32); o_st[b][5] = take((size_t)m->cap * 32); o_st[b][6] = take((size_t)m->cap * 32);
+        o_st[b][7] = take(256);  // wa: registers mode only (rw_create_registers sizes its own block)
     }
     const size_t o_sib = take((size_t)m->cap * 4), o_match = take((size_t)m->cap * 4), o_flags = take(scan_len * 8), o_scan = take(scan_len * 8),
                  o_bs = take(((scan_len + kBlock * kScanItems - 1) / (kBlock * kScanItems) + 1) * 8), o_total = take(256);
@@ -440,6 +531,7 @@ static int32_t rw_create_impl(jolt_ctx* ctx, const uint64_t* addresses, const ui
     for (int b = 0; b < 2; ++b) {
         m->st[b].key = (uint64_t*)(base + o_st[b][0]); m->st[b].prev_u = (uint64_t*)(base + o_st[b][1]); m->st[b].next_u = (uint64_t*)(base + o_st[b][2]);
         m->st[b].prev_f = (Fr*)(base + o_st[b][3]); m->st[b].next_f = (Fr*)(base + o_st[b][4]); m->st[b].val = (Fr*)(base + o_st[b][5]); m->st[b].ra = (Fr*)(base + o_st[b][6]);
+        m->st[b].wa = (Fr*)(base + o_st[b][7]);
     }
     m->sib_lb = (uint32_t*)(base + o_sib); m->matched = (uint32_t*)(base + o_match); m->flags = (uint64_t*)(base + o_flags); m->scan = (uint64_t*)(base + o_scan);
     m->block_sums = (uint64_t*)(base + o_bs); m->total = (uint64_t*)(base + o_total);
@@ -525,8 +617,12 @@ static int32_t rw_ingest(jolt_rw_matrix* m, const Fr& r) {
                 JOLT_HIP_TRY(ctx, hipGetLastError());
             }
             JOLT_TRY(rw_scan(m, m->n));
-            hipLaunchKernelGGL(k_rw_cycle_bind, dim3(rw_grid(m->n)), dim3(kBlock), 0, ctx->stream, a, m->n, (const uint32_t*)m->sib_lb, (const uint32_t*)m->matched,
-                               (const uint64_t*)m->scan, r, shifted, o);
+            if (m->registers)
+                hipLaunchKernelGGL(k_rw_cycle_bind<true>, dim3(rw_grid(m->n)), dim3(kBlock), 0, ctx->stream, a, m->n, (const uint32_t*)m->sib_lb, (const uint32_t*)m->matched,
+                                   (const uint64_t*)m->scan, r, shifted, o);
+            else
+                hipLaunchKernelGGL(k_rw_cycle_bind<false>, dim3(rw_grid(m->n)), dim3(kBlock), 0, ctx->stream, a, m->n, (const uint32_t*)m->sib_lb, (const uint32_t*)m->matched,
+                                   (const uint64_t*)m->scan, r, shifted, o);
             JOLT_HIP_TRY(ctx, hipGetLastError());
             JOLT_TRY(rw_read_total(m, &m->n));
             m->cur = 1 - m->cur;
@@ -542,9 +638,40 @@ static int32_t rw_ingest(jolt_rw_matrix* m, const Fr& r) {
             if (nvar / 2 < current_index && m->e_in_bits > 0) m->e_in_bits -= 1;
             else if (0 < current_index && m->e_out_bits > 0) m->e_out_bits -= 1;
         }
-        if (m->round == m->log_t - 1 && m->n) {
+        if (m->round == m->log_t - 1 && m->registers) {
+            // SparseEntries::into_dense (registers_read_write/sparse.rs:532-561): the single remaining row scattered into K-sized arrays on the HOST
+            // ("small fixed K": the address rounds cost O(K) = 128 pairs, mod.rs:30-33); eq and inc are scalars from here on
+            const size_t K = (size_t)1 << m->log_k;
+            m->reg_ra.assign(K, Fr::zero());
+            m->reg_wa.assign(K, Fr::zero());
+            m->reg_val.assign(K, Fr::zero());
+            const uint32_t n = m->n;
+            if (n > K) { ctx->last_error = "registers matrix: more cells than registers after the cycle rounds"; return JOLT_ERR_INVALID_ARG; }
+            std::vector<uint64_t> key(n);
+            std::vector<Fr> ra(n), wa(n), val(n);
+            const RwArrays& c = m->st[m->cur];
+            if (n) {
+                JOLT_HIP_TRY(ctx, hipMemcpyAsync(key.data(), c.key, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+                JOLT_HIP_TRY(ctx, hipMemcpyAsync(ra.data(), c.ra, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+                JOLT_HIP_TRY(ctx, hipMemcpyAsync(wa.data(), c.wa, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+                JOLT_HIP_TRY(ctx, hipMemcpyAsync(val.data(), c.val, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            JOLT_HIP_TRY(ctx, hipMemcpyAsync(&m->inc_scalar, m->inc->data(), sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+            JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t col = (uint32_t)key[i];
+                if ((key[i] >> 32) != 0 || col >= K) { ctx->last_error = "registers matrix: a cell outside the single bound row"; return JOLT_ERR_INVALID_ARG; }
+                m->reg_ra[col] = ra[i]; m->reg_wa[col] = wa[i]; m->reg_val[col] = val[i];
+            }
+        } else if (m->round == m->log_t - 1 && m->n) {
             hipLaunchKernelGGL(k_rw_to_address_major, dim3(rw_grid(m->n)), dim3(kBlock), 0, ctx->stream, m->st[m->cur], m->n);
             JOLT_HIP_TRY(ctx, hipGetLastError());
+        }
+    } else if (m->registers) {  // bind_pairs over the three dense arrays (mod.rs:262-265)
+        for (std::vector<Fr>* t : {&m->reg_ra, &m->reg_wa, &m->reg_val}) {
+            const size_t half = t->size() / 2;
+            for (size_t y = 0; y < half; ++y) (*t)[y] = add((*t)[2 * y], mul(r, sub((*t)[2 * y + 1], (*t)[2 * y])));
+            t->resize(half);
         }
     } else {
         if (m->n) {
@@ -586,7 +713,7 @@ extern "C" int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix* m, const jolt_fr_t
             JOLT_HIP_TRY(ctx, hipGetLastError());
             m->match_valid = true;
         }
-        hipLaunchKernelGGL(k_rw_cycle_round, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m->n, (const uint32_t*)m->sib_lb, (const uint32_t*)m->matched,
+        hipLaunchKernelGGL(k_rw_cycle_round<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m->n, (const uint32_t*)m->sib_lb, (const uint32_t*)m->matched,
                            (const Fr*)m->inc->data(), (const Fr*)m->e_out_cache[m->e_out_bits]->data(), (const Fr*)m->e_in_cache[m->e_in_bits]->data(), (int)m->e_in_bits,
                            m->gamma, ctx->d_partials);
         if (aux_out) {
@@ -671,5 +798,173 @@ extern "C" int32_t jolt_rw_matrix_download(jolt_rw_matrix* m, uint64_t* rows, ui
             fr_to_abi(&next[i], q);
         }
     }
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Registers read/write checking (stage 4) on the same machinery: optimized/registers_read_write/{mod,sparse,rows}.rs.
+// The cycle phase is the sparse matrix above with two coefficient columns (k_rw_cycle_round<true> / k_rw_cycle_bind<true>); after the
+// log T cycle rounds at most K = 2^log_k cells are left and the address rounds run over three K-sized arrays on the host.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t jolt_registers_rw_create(jolt_ctx* ctx, const jolt_onehot* regs, const jolt_ints* rs1_val, const jolt_ints* rs2_val, const jolt_ints* rd_pre,
+                                            const jolt_ints* rd_post, const jolt_table* inc, const jolt_fr_t* r_cycle, const jolt_fr_t* gamma, jolt_rw_matrix** out) {
+    if (!ctx || !regs || !rs1_val || !rs2_val || !rd_pre || !rd_post || !inc || !r_cycle || !gamma || !out) return JOLT_ERR_INVALID_ARG;
+    if (regs->n_polys != 3) { ctx->last_error = "registers columns: a hot-index source with the three columns rs1, rs2, rd"; return JOLT_ERR_INVALID_ARG; }
+    const size_t cycles = regs->cycles, K = regs->k;
+    for (const jolt_ints* c : {rs1_val, rs2_val, rd_pre, rd_post}) {
+        if (c->kind != JOLT_INT_U64) return JOLT_ERR_INVALID_ARG;
+        if (c->count != cycles) return JOLT_ERR_SIZE_MISMATCH;
+    }
+    if (cycles < 2 || (cycles & (cycles - 1)) || cycles > ((size_t)1 << 30) || inc->len != cycles) return JOLT_ERR_SIZE_MISMATCH;
+    if (K == 0 || (K & (K - 1)) || K > 256) return JOLT_ERR_SIZE_MISMATCH;  // REGISTER_ADDRESS_BITS = 7
+    jolt_rw_matrix* m = new (std::nothrow) jolt_rw_matrix();
+    if (!m) return JOLT_ERR_OOM;
+    m->ctx = ctx;
+    m->registers = true;
+    while (((size_t)1 << m->log_t) < cycles) m->log_t++;
+    while (((size_t)1 << m->log_k) < K) m->log_k++;
+    m->gamma = fr_from_abi(gamma);
+    m->w.resize(m->log_t);
+    for (size_t i = 0; i < m->log_t; ++i) m->w[i] = fr_from_abi(&r_cycle[i]);
+    m->current_scalar = Fr::one();
+    int32_t s = fr_is_canonical(m->gamma) ? JOLT_OK : JOLT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < m->log_t && s == JOLT_OK; ++i) if (!fr_is_canonical(m->w[i])) s = JOLT_ERR_INVALID_ARG;
+    const size_t split = m->log_t / 2, head_len = m->log_t - 1;  // GruenSplitEqPolynomial::new (split_eq.rs:214-236)
+    m->out_len = std::min(split, head_len);
+    m->in_len = head_len - m->out_len;
+    m->e_out_bits = m->out_len;
+    m->e_in_bits = m->in_len;
+    if (s == JOLT_OK) s = jolt_internal_eq_levels(ctx, m->w.data(), m->out_len, Fr::one(), &m->e_out_cache);
+    if (s == JOLT_OK) s = jolt_internal_eq_levels(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), &m->e_in_cache);
+    if (s == JOLT_OK) s = jolt_table_clone(ctx, inc, &m->inc);
+    const uint32_t T = (uint32_t)cycles;
+    // the cell count needs one scan of the per-cycle counts; the states are sized for the worst case of 3 cells per cycle only if the count says so
+    const size_t scan_len0 = T;
+    uint64_t *d_flags0 = nullptr;
+    if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, (2 * scan_len0 + ((scan_len0 + kBlock * kScanItems - 1) / (kBlock * kScanItems) + 1) + 32) * 8, (void**)&d_flags0);
+    if (s == JOLT_OK && hipHostMalloc((void**)&m->h_total, 64, hipHostMallocDefault) != hipSuccess) s = JOLT_ERR_HIP;
+    if (s != JOLT_OK) { if (d_flags0) jolt_internal_dev_free(ctx, d_flags0); jolt_rw_matrix_destroy(m); return s; }
+    m->flags = d_flags0; m->scan = d_flags0 + scan_len0; m->block_sums = m->scan + scan_len0; m->total = m->block_sums + ((scan_len0 + kBlock * kScanItems - 1) / (kBlock * kScanItems) + 1);
+    hipLaunchKernelGGL(k_reg_count, dim3(rw_grid(T)), dim3(kBlock), 0, ctx->stream, (const uint8_t*)regs->idx, regs->wide, T, m->flags);
+    s = hipGetLastError() == hipSuccess ? rw_scan(m, T) : JOLT_ERR_HIP;
+    uint32_t cap = 0;
+    if (s == JOLT_OK) s = rw_read_total(m, &cap);
+    if (s != JOLT_OK) { jolt_internal_dev_free(ctx, d_flags0); m->flags = m->scan = m->block_sums = m->total = nullptr; jolt_rw_matrix_destroy(m); return s; }
+    m->cap = std::max<uint32_t>(cap, 1);
+    const size_t scan_len = std::max<size_t>(T, m->cap);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_st[2][6];
+    for (int b = 0; b < 2; ++b) {
+        o_st[b][0] = take((size_t)m->cap * 8); o_st[b][1] = take((size_t)m->cap * 8); o_st[b][2] = take((size_t)m->cap * 8);
+        o_st[b][3] = take((size_t)m->cap * 32); o_st[b][4] = take((size_t)m->cap * 32); o_st[b][5] = take((size_t)m->cap * 32);
+    }
+    const size_t o_sib = take((size_t)m->cap * 4), o_match = take((size_t)m->cap * 4), o_flags = take(scan_len * 8), o_scan = take(scan_len * 8),
+                 o_bs = take(((scan_len + kBlock * kScanItems - 1) / (kBlock * kScanItems) + 1) * 8), o_total = take(256);
+    s = jolt_internal_dev_alloc(ctx, off, &m->block);
+    if (s != JOLT_OK) { jolt_internal_dev_free(ctx, d_flags0); m->flags = m->scan = m->block_sums = m->total = nullptr; jolt_rw_matrix_destroy(m); return s; }
+    char* base = (char*)m->block;
+    for (int b = 0; b < 2; ++b) {
+        m->st[b].key = (uint64_t*)(base + o_st[b][0]); m->st[b].prev_u = (uint64_t*)(base + o_st[b][1]); m->st[b].next_u = (uint64_t*)(base + o_st[b][2]);
+        m->st[b].val = (Fr*)(base + o_st[b][3]); m->st[b].ra = (Fr*)(base + o_st[b][4]); m->st[b].wa = (Fr*)(base + o_st[b][5]);
+        m->st[b].prev_f = nullptr; m->st[b].next_f = nullptr;
+    }
+    const uint64_t* pos = m->scan;  // the scan of the counts (still in the temporary block)
+    hipLaunchKernelGGL(k_reg_build, dim3(rw_grid(T)), dim3(kBlock), 0, ctx->stream, (const uint8_t*)regs->idx, regs->wide, (const uint64_t*)rs1_val->data, (const uint64_t*)rs2_val->data,
+                       (const uint64_t*)rd_pre->data, (const uint64_t*)rd_post->data, T, pos, m->gamma, mul(m->gamma, m->gamma), m->st[0]);
+    hipError_t e = hipGetLastError();
+    jolt_internal_dev_free(ctx, d_flags0);  // stream-ordered: the build kernel above is its last reader
+    m->sib_lb = (uint32_t*)(base + o_sib); m->matched = (uint32_t*)(base + o_match); m->flags = (uint64_t*)(base + o_flags); m->scan = (uint64_t*)(base + o_scan);
+    m->block_sums = (uint64_t*)(base + o_bs); m->total = (uint64_t*)(base + o_total);
+    if (e != hipSuccess) { ctx->last_error = std::string("registers matrix: ") + hipGetErrorString(e); jolt_rw_matrix_destroy(m); return JOLT_ERR_HIP; }
+    m->n = cap;
+    *out = m;
+    return JOLT_OK;
+}
+
+// ProveRounds::prove_round (registers_read_write/mod.rs:374-389), device half.  Cycle rounds: evals_out[0..1] = (q(0), leading coefficient) of the
+// quadratic inner factor, aux_out = {current_scalar, r_cycle[current_index - 1], 0} for gruen_poly_deg_3; address rounds: evals_out[0..3] =
+// s(0), s(1), s(2), s(3) (UnivariatePoly::from_evals; s(0) + s(1) is the claim), aux_out = 0.
+extern "C" int32_t jolt_registers_rw_prove_round(jolt_rw_matrix* m, const jolt_fr_t* bind, jolt_fr_t* evals_out, jolt_fr_t* aux_out) {
+    if (!m || !evals_out || !m->registers) return JOLT_ERR_INVALID_ARG;
+    jolt_ctx* ctx = m->ctx;
+    if (bind) {
+        Fr r = fr_from_abi(bind);
+        JOLT_REQUIRE(ctx, fr_is_canonical(r), "bind challenge is not a canonical Fr");
+        if (m->round >= m->log_t + m->log_k) { ctx->last_error = "registers matrix already fully bound"; return JOLT_ERR_INVALID_ARG; }
+        JOLT_TRY(rw_ingest(m, r));
+    }
+    if (m->round >= m->log_t + m->log_k) { ctx->last_error = "prove_round on a fully bound registers matrix"; return JOLT_ERR_INVALID_ARG; }
+    const Fr zero = Fr::zero();
+    for (int k = 0; k < 4; ++k) fr_to_abi(&evals_out[k], zero);
+    if (aux_out) for (int k = 0; k < 3; ++k) fr_to_abi(&aux_out[k], zero);
+    if (m->round < m->log_t) {
+        const int grid = (int)std::max<uint32_t>(1, std::min<uint32_t>((m->n + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * 4));
+        JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 2 + 8, 8));
+        RwArrays& a = m->st[m->cur];
+        if (m->n && !m->match_valid) {
+            hipLaunchKernelGGL(k_rw_cycle_match, dim3(rw_grid(m->n)), dim3(kBlock), 0, ctx->stream, (const uint64_t*)a.key, m->n, m->sib_lb, m->matched, m->flags);
+            JOLT_HIP_TRY(ctx, hipGetLastError());
+            m->match_valid = true;
+        }
+        hipLaunchKernelGGL(k_rw_cycle_round<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m->n, (const uint32_t*)m->sib_lb, (const uint32_t*)m->matched, (const Fr*)m->inc->data(),
+                           (const Fr*)m->e_out_cache[m->e_out_bits]->data(), (const Fr*)m->e_in_cache[m->e_in_bits]->data(), (int)m->e_in_bits, m->gamma, ctx->d_partials);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 2, ctx->d_results);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results, 2 * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(evals_out, ctx->h_results, 2 * sizeof(Fr));
+        if (aux_out) {
+            fr_to_abi(&aux_out[0], m->current_scalar);
+            fr_to_abi(&aux_out[1], m->w[m->log_t - m->round - 1]);
+        }
+        return JOLT_OK;
+    }
+    // address_round_message (mod.rs:217-252): every (degree + 1) point sampled directly over the K-sized arrays
+    Fr ev[4] = {zero, zero, zero, zero};
+    const size_t half = m->reg_ra.size() / 2;
+    for (size_t y = 0; y < half; ++y) {
+        Fr ra_t = m->reg_ra[2 * y], wa_t = m->reg_wa[2 * y], val_t = m->reg_val[2 * y];
+        const Fr ra_m = sub(m->reg_ra[2 * y + 1], ra_t), wa_m = sub(m->reg_wa[2 * y + 1], wa_t), val_m = sub(m->reg_val[2 * y + 1], val_t);
+        for (int t = 0; t < 4; ++t) {
+            ev[t] = add(ev[t], add(mul(wa_t, add(m->inc_scalar, val_t)), mul(ra_t, val_t)));
+            ra_t = add(ra_t, ra_m); wa_t = add(wa_t, wa_m); val_t = add(val_t, val_m);
+        }
+    }
+    for (int t = 0; t < 4; ++t) fr_to_abi(&evals_out[t], mul(m->current_scalar, ev[t]));
+    return JOLT_OK;
+}
+
+// RegistersReadWriteOutputClaims without the operand claims (mod.rs:386-402): {registers_val, rd_wa, gamma * rs1_ra + gamma^2 * rs2_ra, rd_inc, bound eq};
+// rs1_ra / rs2_ra are one-hot evaluations of the index columns at the bound point (jolt_onehot_materialize + jolt_evaluate)
+extern "C" int32_t jolt_registers_rw_final_values(jolt_rw_matrix* m, jolt_fr_t* out) {
+    if (!m || !out || !m->registers) return JOLT_ERR_INVALID_ARG;
+    if (m->round != m->log_t + m->log_k) return JOLT_ERR_NOT_FULLY_BOUND;
+    if (m->reg_val.size() != 1) return JOLT_ERR_NOT_FULLY_BOUND;
+    fr_to_abi(&out[0], m->reg_val[0]);
+    fr_to_abi(&out[1], m->reg_wa[0]);
+    fr_to_abi(&out[2], m->reg_ra[0]);
+    fr_to_abi(&out[3], m->inc_scalar);
+    fr_to_abi(&out[4], m->current_scalar);
+    return JOLT_OK;
+}
+
+// test hook: the current cells of the cycle phase (rows, cols, raw checkpoints as u64; val, ra, wa as Fr)
+extern "C" int32_t jolt_registers_rw_download(jolt_rw_matrix* m, uint64_t* rows, uint64_t* cols, jolt_fr_t* val, jolt_fr_t* ra, jolt_fr_t* wa, uint64_t* prev, uint64_t* next) {
+    if (!m || !m->registers || !rows || !cols || !val || !ra || !wa || !prev || !next) return JOLT_ERR_INVALID_ARG;
+    jolt_ctx* ctx = m->ctx;
+    const uint32_t n = m->n;
+    if (!n || m->round >= m->log_t) return JOLT_OK;
+    const RwArrays& a = m->st[m->cur];
+    std::vector<uint64_t> key(n);
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(key.data(), a.key, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(val, a.val, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ra, a.ra, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(wa, a.wa, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(prev, a.prev_u, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(next, a.next_u, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n; ++i) { rows[i] = key[i] >> 32; cols[i] = (uint32_t)key[i]; }
     return JOLT_OK;
 }

@@ -1042,6 +1042,57 @@ class RwMatrix:
 Context.rw_matrix = lambda self, *a, **k: RwMatrix(self, *a, **k)
 
 
+class RegistersRw:
+    """Device twin of the optimized registers read/write-checking kernel (jolt_registers_rw_*): `regs` a OneHot with the columns rs1, rs2, rd,
+    the value columns u64 Ints, `inc` the RdInc table."""
+
+    def __init__(self, ctx, regs, rs1_val, rs2_val, rd_pre, rd_post, inc, r_cycle, gamma):
+        self.ctx, self.regs = ctx, regs
+        h = C.c_void_p()
+        _ck(lib().jolt_registers_rw_create(ctx.h, regs.h, rs1_val.h, rs2_val.h, rd_pre.h, rd_post.h, inc.h, _p(fr(r_cycle).reshape(-1, 4)), _p(fr(gamma)), C.byref(h)),
+            "jolt_registers_rw_create", ctx)
+        self.h = h
+
+    def __len__(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_rw_matrix_len(self.h, C.byref(n)), "jolt_rw_matrix_len", self.ctx)
+        return n.value
+
+    def prove_round(self, bind=None):
+        evals, aux = fr_array(4), fr_array(3)
+        _ck(lib().jolt_registers_rw_prove_round(self.h, _p(fr(bind)) if bind is not None else None, _p(evals), _p(aux)), "jolt_registers_rw_prove_round", self.ctx)
+        return evals, aux
+
+    def finish(self, bind):
+        _ck(lib().jolt_rw_matrix_finish(self.h, _p(fr(bind))), "jolt_rw_matrix_finish", self.ctx)
+
+    def final_values(self):
+        out = fr_array(5)
+        _ck(lib().jolt_registers_rw_final_values(self.h, _p(out)), "jolt_registers_rw_final_values", self.ctx)
+        return out
+
+    def download(self):
+        n = len(self)
+        rows, cols, prev, nxt = (np.zeros(max(n, 1), dtype=np.uint64) for _ in range(4))
+        val, ra, wa = fr_array(max(n, 1)), fr_array(max(n, 1)), fr_array(max(n, 1))
+        _ck(lib().jolt_registers_rw_download(self.h, _p(rows), _p(cols), _p(val), _p(ra), _p(wa), _p(prev), _p(nxt)), "jolt_registers_rw_download", self.ctx)
+        return dict(rows=rows[:n], cols=cols[:n], val=val[:n], ra=ra[:n], wa=wa[:n], prev=prev[:n], next=nxt[:n])
+
+    def free(self):
+        if self.h:
+            lib().jolt_rw_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+Context.registers_rw = lambda self, *a, **k: RegistersRw(self, *a, **k)
+
+
 def _table_dot(self, a, b, deferred=False):
     out = fr_array(1)
     _ck(lib().jolt_table_dot(self.h, a.h, b.h, C.c_int32(1 if deferred else 0), _p(out)), "jolt_table_dot", self)

@@ -54,6 +54,37 @@ def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5):
     return dict(log_k=log_k, log_t=log_t, val_init=val_init, addresses=addresses, pre=pre, post=post, inc=inc)
 
 
+REG_NONE = np.uint8(0xFF)
+
+
+def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None):
+    """RegisterCycleRow columns (optimized/registers_read_write/rows.rs:22-31) of a consistent synthetic trace: a read returns what the last
+    earlier write to that register left (registers start at 0), rd_pre likewise; rd_post is fresh.  hot: draw registers from the first
+    `hot` only (many cells per register pair)."""
+    K, T = 1 << log_k, 1 << log_t
+    pool = K if hot is None else min(K, hot)
+    draw = lambda p: np.where(rng.random(T) < p, rng.integers(0, pool, size=T), 0xFF).astype(np.uint8)
+    rs1, rs2, rd = draw(p_rs1), draw(p_rs2), draw(p_rd)
+    rd_post = np.where(rd != REG_NONE, rng.integers(0, 2**64, size=T, dtype=np.uint64), 0).astype(np.uint64)
+    cyc = np.arange(T, dtype=np.int64)
+    w = np.nonzero(rd != REG_NONE)[0]
+    wkey = rd[w].astype(np.int64) * T + w  # writes sorted by (register, cycle)
+    order = np.argsort(wkey, kind="stable")
+    wkey_s, wpost_s, wreg_s = wkey[order], rd_post[w][order], rd[w][order]
+
+    def value_before(reg):  # the register's value at the start of every cycle that names it (0xFF rows: 0)
+        key = reg.astype(np.int64) * T + cyc
+        pos = np.searchsorted(wkey_s, key, side="left") - 1  # the last write with (register, cycle) < (reg, j)
+        ok = (reg != REG_NONE) & (pos >= 0)
+        posc = np.maximum(pos, 0)
+        same = ok & (wreg_s[posc] == reg) if wkey_s.size else np.zeros(T, dtype=bool)
+        return np.where(same, wpost_s[posc] if wkey_s.size else 0, 0).astype(np.uint64)
+
+    rs1_val, rs2_val, rd_pre = value_before(rs1), value_before(rs2), value_before(rd)
+    # RdInc as a field table needs post - pre; values are full 64-bit words, so the signed difference is kept as (magnitude, sign)
+    return dict(log_k=log_k, log_t=log_t, rs1=rs1, rs1_val=rs1_val, rs2=rs2, rs2_val=rs2_val, rd=rd, rd_pre=rd_pre, rd_post=rd_post)
+
+
 def suffix_lists(n_tables, rng):
     """per table the suffix kinds it reads (LookupTableKind::suffixes()): every kind appears somewhere, 1..6 per table"""
     kinds = list(rng.permutation(N_SUFFIX_KINDS))

@@ -271,6 +271,10 @@ extern "C" {
     pub fn jolt_host_small_scalar_dot(values: *const jolt_fr_t, scalars: *const u64, n: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_create(ctx: *mut jolt_ctx, addresses: *const u64, pre_values: *const u64, post_values: *const u64, cycles: usize, inc: *const jolt_table, val_init: *const jolt_table, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
     pub fn jolt_rw_matrix_create_resident(ctx: *mut jolt_ctx, addresses: *const jolt_ints, pre_values: *const jolt_ints, post_values: *const jolt_ints, inc: *const jolt_table, val_init: *const jolt_table, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
+    pub fn jolt_registers_rw_create(ctx: *mut jolt_ctx, regs: *const jolt_onehot, rs1_val: *const jolt_ints, rs2_val: *const jolt_ints, rd_pre: *const jolt_ints, rd_post: *const jolt_ints, inc: *const jolt_table, r_cycle: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
+    pub fn jolt_registers_rw_prove_round(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, aux_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_registers_rw_final_values(m: *mut jolt_rw_matrix, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_registers_rw_download(m: *mut jolt_rw_matrix, rows: *mut u64, cols: *mut u64, val: *mut jolt_fr_t, ra: *mut jolt_fr_t, wa: *mut jolt_fr_t, prev: *mut u64, next: *mut u64) -> i32;
     pub fn jolt_rw_matrix_prove_round(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, aux_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_finish(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_final_values(m: *mut jolt_rw_matrix, out: *mut jolt_fr_t) -> i32;

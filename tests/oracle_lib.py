@@ -829,6 +829,62 @@ class RwMatrix:
             self.h = None
 
 
+class RegMatrix:
+    """The sparse cycle-major matrix of the registers read/write-checking kernel (oracle/registers_rw.c;
+    crates/jolt-kernels/src/optimized/registers_read_write/sparse.rs).  Columns: register indices as uint8 (0xFF = none), values uint64."""
+
+    def __init__(self, rs1, rs1_val, rs2, rs2_val, rd, rd_pre, rd_post, gamma):
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        cols = [u8(rs1), u64(rs1_val), u8(rs2), u64(rs2_val), u8(rd), u64(rd_pre), u64(rd_post)]
+        lib().orc_regrw_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_regrw_create(*[c.ctypes.data_as(C.c_void_p) for c in cols], C.c_size_t(cols[0].shape[0]), _p(np.ascontiguousarray(gamma, dtype=np.uint64))))
+
+    def __len__(self):
+        lib().orc_regrw_len.restype = C.c_size_t
+        return lib().orc_regrw_len(self.h)
+
+    def export(self):
+        n = len(self)
+        rows, cols, prev, nxt = (np.zeros(max(n, 1), dtype=np.uint64) for _ in range(4))
+        val, ra, wa = fr_array(max(n, 1)), fr_array(max(n, 1)), fr_array(max(n, 1))
+        lib().orc_regrw_export(self.h, _p(rows), _p(cols), _p(val), _p(ra), _p(wa), _p(prev), _p(nxt))
+        return dict(rows=rows[:n], cols=cols[:n], val=val[:n], ra=ra[:n], wa=wa[:n], prev=prev[:n], next=nxt[:n])
+
+    def cycle_round(self, e_out, e_in, inc):
+        o = fr_array(2)
+        e_in = np.ascontiguousarray(e_in, dtype=np.uint64).reshape(-1, 4)
+        lib().orc_regrw_cycle_round(self.h, _p(np.ascontiguousarray(e_out)), _p(e_in), C.c_size_t(e_in.shape[0]), _p(np.ascontiguousarray(inc)), _p(o))
+        return o
+
+    def cycle_bind(self, r):
+        lib().orc_regrw_cycle_bind(self.h, _p(np.ascontiguousarray(r, dtype=np.uint64)))
+
+    def into_dense(self, k):
+        ra, wa, val = fr_array(k), fr_array(k), fr_array(k)
+        assert lib().orc_regrw_into_dense(self.h, C.c_size_t(k), _p(ra), _p(wa), _p(val)) == 0
+        return ra, wa, val
+
+    def close(self):
+        if self.h:
+            lib().orc_regrw_destroy(self.h)
+            self.h = None
+
+
+def regrw_address_round(ra, wa, val, inc_scalar, eq_scalar):
+    o = fr_array(4)
+    lib().orc_regrw_address_round(_p(np.ascontiguousarray(ra)), _p(np.ascontiguousarray(wa)), _p(np.ascontiguousarray(val)), C.c_size_t(ra.shape[0]),
+                                  _p(np.ascontiguousarray(inc_scalar, dtype=np.uint64)), _p(np.ascontiguousarray(eq_scalar, dtype=np.uint64)), _p(o))
+    return o
+
+
+def regrw_operand_claim(idx, eq_address, eq_cycle):
+    i = np.ascontiguousarray(idx, dtype=np.uint8)
+    o = fr_array(1)
+    lib().orc_regrw_operand_claim(i.ctypes.data_as(C.c_void_p), C.c_size_t(i.shape[0]), _p(np.ascontiguousarray(eq_address)), _p(np.ascontiguousarray(eq_cycle)), _p(o))
+    return o[0]
+
+
 # ---- Spartan outer T-scale sums (oracle/r1cs.c) ---------------------------------------------------------------------------------
 def _ptrs(tables):
     tabs = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
