@@ -6,6 +6,9 @@ stage drivers drive them, over synthetic trace-shaped inputs:
   stage 2   Spartan product          the same three steps over the six product lanes, no stream variable  (optimized/spartan_product.rs)
   stage 2   RAM read / write         the sparse (address x cycle) matrix: log T cycle rounds + log K address rounds
                                      (optimized/ram_read_write.rs:58-330, optimized/rw_matrix.rs)
+  stage 4   registers read / write   the same sparse matrix with <= 3 cells per cycle and two coefficient columns: log T cycle rounds on the device,
+                                     log K = 7 address rounds over K-sized arrays, the two operand claims as one-hot evaluations
+                                     (optimized/registers_read_write/{mod,sparse,rows}.rs)
   stage 5   instruction read + RAF   the 16 address phases' T-scale scans (condensation, RAF sums, per-table suffix accumulators) and the
                                      log T cycle rounds over combined * prod ra  (optimized/instruction_read_raf.rs; the 8 address rounds
                                      inside a phase run over 256-entry polynomials on the caller's side and are not part of this)
@@ -124,6 +127,10 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_cou
     d["ram"] = consistent_ram_trace(min(16, max(1, n_vars)) if log_k is None else log_k, n_vars, rng)
     d["ram_tau"] = rand_fr(n_vars, rng)
     d["ram_gamma"] = rand_fr(1, rng)[0]
+    # ---- stage 4: registers (REGISTER_ADDRESS_BITS = 7)
+    d["registers"] = consistent_register_trace(7, n_vars, rng)
+    d["registers_r_cycle"] = rand_fr(n_vars, rng)
+    d["registers_gamma"] = rand_fr(1, rng)[0]
     # ---- stage 5: lookup rows
     idx = np.frombuffer(rng.bytes(16 * T), dtype=np.uint64).reshape(T, 2).copy()
     shapes = rng.integers(0, 8, size=T)
@@ -162,7 +169,7 @@ def product_field_weights(w, neg):
     return a, b
 
 
-def rw_rounds(matrix_round, finish, final_values, log_t, log_k, claim, transcript, gruen_deg_3, from_evals, evaluate):
+def rw_rounds(matrix_round, finish, final_values, log_t, log_k, claim, transcript, gruen_deg_3, from_evals, evaluate, four_point_address=False):
     """ProveRounds of RamReadWriteKernel driven alone (ram_read_write.rs:160-217): cycle rounds complete the cubic with gruen_poly_deg_3 from the
     two sums and the split-eq state the member reports, address rounds interpolate (s(0), claim - s(0), s(2)); every message is absorbed
     coefficient by coefficient, the next bind is the transcript's challenge.  The same loop runs over the device member and the oracle's."""
@@ -171,6 +178,8 @@ def rw_rounds(matrix_round, finish, final_values, log_t, log_k, claim, transcrip
         evals, aux = matrix_round(rnd, bind)
         if rnd < log_t:
             poly = gruen_deg_3(aux[0], aux[1], evals[0], evals[1], claim)
+        elif four_point_address:  # registers: every point sampled, UnivariatePoly::from_evals (registers_read_write/mod.rs:217-252)
+            poly = from_evals(np.stack([evals[k] for k in range(4)]))
         else:
             poly = from_evals(np.stack([evals[0], _sub(claim, evals[0]), evals[1]]))
         transcript.append(poly)
@@ -202,6 +211,12 @@ class DeviceExtended:
         ram = d["ram"]
         self.ram_inc, self.ram_val_init = ctx.ints(ram["inc"]), ctx.ints(ram["val_init"])
         self.ram_cols = [ctx.ints(ram[k]) for k in ("addresses", "pre", "post")]  # RamAccessColumns, uploaded once per trace
+        reg = d["registers"]
+        self.reg_idx = ctx.onehot(np.stack([reg["rs1"], reg["rs2"], reg["rd"]]), 1 << reg["log_k"])  # RegisterCycleRow index columns
+        self.reg_cols = [ctx.ints(reg[k]) for k in ("rs1_val", "rs2_val", "rd_pre", "rd_post")]
+        lo = (reg["rd_post"] - reg["rd_pre"]).astype(np.uint64)  # RdInc = post - pre as an i128 (lo, hi two's complement)
+        hi = np.where(reg["rd_post"] < reg["rd_pre"], np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0)).astype(np.uint64)
+        self.reg_inc = ctx.ints(np.stack([lo, hi], axis=1), "i128")
         lk = d["lookup"]
         self.read_raf = ctx.read_raf(lk["idx"], lk["table"], lk["raf"], lk["n_tables"])
         # ---- input claims (in a real proof the previous stage's output claims): computed once, untimed
@@ -222,6 +237,16 @@ class DeviceExtended:
         self.claims["ram"] = m.input_claim()
         m.destroy()
         for t in (eq, pre, post):
+            t.free()
+        # registers: sum_j eq(r_cycle, j) * ( [rd_j] * (inc_j + rd_pre_j) + gamma * [rs1_j] * rs1_val_j + gamma^2 * [rs2_j] * rs2_val_j ) = sum_j eq * (rd_post + g rs1_val + g^2 rs2_val)
+        # (cold rows carry zero values in the trace columns)
+        eq = ctx.eq_evals(d["registers_r_cycle"])
+        t_post, t_rs1, t_rs2 = (ctx.table_from_ints(self.reg_cols[k]) for k in (3, 0, 1))
+        g = d["registers_gamma"]
+        m = ctx.member_lc([eq, t_post, t_rs1, t_rs2], [[(None, [(self.one, 0)]), (None, [(self.one, 1), (g, 2), (ffi.host_fr_mul(g, g), 3)])]], 2, borrow=True)
+        self.claims["registers"] = m.input_claim()
+        m.destroy()
+        for t in (eq, t_post, t_rs1, t_rs2):
             t.free()
         self.claims["lookup"] = None  # needs the v tables of a proof: taken from the first proof's cycle member (same every proof)
         ctx.synchronize()
@@ -261,6 +286,32 @@ class DeviceExtended:
         m.free()
         return out
 
+    def registers_read_write(self, label):
+        global _sub
+        ctx, ffi, d = self.ctx, self.ffi, self.d
+        reg = d["registers"]
+        log_t, log_k = reg["log_t"], reg["log_k"]
+        inc = ctx.table_from_ints(self.reg_inc)
+        m = ctx.registers_rw(self.reg_idx, *self.reg_cols, inc, d["registers_r_cycle"], d["registers_gamma"])
+        inc.free()
+        tr = ffi.HostTranscript(label)
+        _sub = ffi.host_fr_sub
+        out = rw_rounds(lambda rnd, bind: m.prove_round(bind), m.finish, m.final_values, log_t, log_k, self.claims["registers"], tr, ffi.host_gruen_poly_deg_3,
+                        ffi.host_univariate_from_evals, ffi.host_univariate_evaluate, four_point_address=True)
+        tr.close()
+        m.free()
+        # RegistersReadWriteOutputClaims::{rs1_ra, rs2_ra}: the index columns evaluated at the bound point (r_address, r_cycle) = the reversed halves of the challenges
+        r_cycle = out["challenges"][:log_t][::-1]
+        eq_adr = ctx.upload(ffi.host_eq_evals(out["challenges"][log_t:][::-1]))
+        claims = []
+        for p in (0, 1):
+            col = self.reg_idx.materialize(p, eq_adr)
+            claims.append(ctx.evaluate(col, r_cycle))
+            col.free()
+        eq_adr.free()
+        out["operand_claims"] = np.stack(claims)
+        return out
+
     def instruction_read_raf(self, label):
         ctx, ffi, d = self.ctx, self.ffi, self.d
         lk, rr = d["lookup"], self.read_raf
@@ -298,10 +349,11 @@ class DeviceExtended:
             "spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"], d["product_kernel"],
                                             self.claims["product"], 1, label + 200),
             "ram_read_write": self.ram_read_write(label + 300),
+            "registers_read_write": self.registers_read_write(label + 350),
             "instruction_read_raf": self.instruction_read_raf(label + 400),
         }
 
     def close(self):
-        for c in self.outer_ints + self.product_ints + self.ram_cols + [self.ram_inc, self.ram_val_init]:
+        for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx]:
             c.free()
         self.read_raf.free()

@@ -124,6 +124,19 @@ impl HipRwMatrix {
         )?;
         Ok(Self { ctx: Arc::clone(ctx), raw })
     }
+    /// The same member over access columns that are already resident in HBM (uploaded once per trace): no host pass, no upload per proof.
+    #[allow(clippy::too_many_arguments)]
+    pub fn new_resident(ctx: &Arc<HipContext>, addresses: &HipInts, pre: &HipInts, post: &HipInts, inc: &HipTable, val_init: &HipTable, tau_low: &[Fr], gamma: Fr) -> Result<Self, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: live handles of one context; the columns are u64 `jolt_ints` (checked by the library).
+        check(
+            unsafe {
+                ffi::jolt_rw_matrix_create_resident(ctx.raw, addresses.raw, pre.raw, post.raw, inc.raw, val_init.raw, tau_low.as_ptr().cast(), (&gamma as *const Fr).cast(), &mut raw)
+            },
+            ctx.raw,
+        )?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
     /// One round: the two sums of the message -- `(q(0), q(inf))` in the cycle rounds, `(s(0), s(2))` in the address rounds -- and
     /// `{current_scalar, tau_low[current_index - 1], 0}` for `gruen_poly_deg_3`.
     pub fn prove_round(&mut self, bind: Option<Fr>) -> Result<([Fr; 2], [Fr; 3]), HipError> {
@@ -148,6 +161,83 @@ impl HipRwMatrix {
 impl Drop for HipRwMatrix {
     fn drop(&mut self) {
         // SAFETY: created by jolt_rw_matrix_create.
+        let _ = unsafe { ffi::jolt_rw_matrix_destroy(self.raw) };
+    }
+}
+
+/// Hot-index columns resident on the device (`jolt_onehot`): one byte per (column, cycle), `0xFF` on a cold cycle.
+pub struct HipHotIndices {
+    ctx: Arc<HipContext>,
+    pub(crate) raw: *mut ffi::jolt_onehot,
+}
+// SAFETY: see HipContext.
+unsafe impl Send for HipHotIndices {}
+impl HipHotIndices {
+    /// `indices[p * cycles + j]` in `[0, k)` or `0xFF`.
+    pub fn upload(ctx: &Arc<HipContext>, indices: &[u8], n_columns: usize, cycles: usize, k: u32) -> Result<Self, HipError> {
+        debug_assert_eq!(indices.len(), n_columns * cycles);
+        let mut raw = ptr::null_mut();
+        // SAFETY: `indices` holds n_columns * cycles bytes; the upload is synchronous.
+        check(unsafe { ffi::jolt_onehot_upload(ctx.raw, indices.as_ptr(), n_columns, cycles, k, &mut raw) }, ctx.raw)?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
+}
+impl Drop for HipHotIndices {
+    fn drop(&mut self) {
+        // SAFETY: owned handle of a live context.
+        let _ = unsafe { ffi::jolt_onehot_free(self.ctx.raw, self.raw) };
+    }
+}
+
+/// The sparse cycle-major matrix of registers read/write checking (`optimized/registers_read_write/{mod,sparse,rows}.rs`): what
+/// `OptimizedRegistersReadWrite::prepare` builds (`mod.rs:79-172`) and `ReadWriteKernel`'s `ProveRounds` drives (`mod.rs:374-394`).
+pub struct HipRegistersRw {
+    ctx: Arc<HipContext>,
+    raw: *mut ffi::jolt_rw_matrix,
+}
+// SAFETY: see HipContext.
+unsafe impl Send for HipRegistersRw {}
+
+impl HipRegistersRw {
+    /// `regs`: the columns rs1, rs2, rd of `RegisterCycleRow` as hot indices (k = 2^REGISTER_ADDRESS_BITS); the four value columns as u64;
+    /// `inc` = RdInc.  `r_cycle` is `inputs.points.rd_write_value` (`mod.rs:110`).
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(ctx: &Arc<HipContext>, regs: &HipHotIndices, rs1_val: &HipInts, rs2_val: &HipInts, rd_pre: &HipInts, rd_post: &HipInts, inc: &HipTable, r_cycle: &[Fr],
+               gamma: Fr) -> Result<Self, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: live handles of one context.
+        check(
+            unsafe {
+                ffi::jolt_registers_rw_create(ctx.raw, regs.raw, rs1_val.raw, rs2_val.raw, rd_pre.raw, rd_post.raw, inc.raw, r_cycle.as_ptr().cast(), (&gamma as *const Fr).cast(), &mut raw)
+            },
+            ctx.raw,
+        )?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
+    /// Cycle rounds: `[q(0), leading coefficient, 0, 0]` + `{current_scalar, r_cycle[current_index - 1], 0}` for `gruen_poly_deg_3`;
+    /// address rounds: `[s(0), s(1), s(2), s(3)]` for `UnivariatePoly::from_evals` (`mod.rs:205-252`).
+    pub fn prove_round(&mut self, bind: Option<Fr>) -> Result<([Fr; 4], [Fr; 3]), HipError> {
+        let (mut evals, mut aux) = ([Fr::default(); 4], [Fr::default(); 3]);
+        let bind_ptr = bind.as_ref().map_or(ptr::null(), |b| (b as *const Fr).cast());
+        // SAFETY: out-arrays of the documented size.
+        check(unsafe { ffi::jolt_registers_rw_prove_round(self.raw, bind_ptr, evals.as_mut_ptr().cast(), aux.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok((evals, aux))
+    }
+    pub fn finish(&mut self, bind: Fr) -> Result<(), HipError> {
+        // SAFETY: live handle.
+        check(unsafe { ffi::jolt_rw_matrix_finish(self.raw, (&bind as *const Fr).cast()) }, self.ctx.raw)
+    }
+    /// `{registers_val, rd_wa, gamma * rs1_ra + gamma^2 * rs2_ra, rd_inc, bound cycle-eq factor}` (`RegistersReadWriteOutputClaims`, `mod.rs:386-402`).
+    pub fn final_values(&mut self) -> Result<[Fr; 5], HipError> {
+        let mut out = [Fr::default(); 5];
+        // SAFETY: five elements as documented.
+        check(unsafe { ffi::jolt_registers_rw_final_values(self.raw, out.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+}
+impl Drop for HipRegistersRw {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_registers_rw_create.
         let _ = unsafe { ffi::jolt_rw_matrix_destroy(self.raw) };
     }
 }

@@ -29,6 +29,23 @@ def test_ram_rounds_check_against_the_dense_claim(n_vars, log_k):
     assert np.array_equal(claim, _mul(eq, _mul(ra, _add(val, _mul(ext.d["ram_gamma"], _add(val, inc))))))
 
 
+@pytest.mark.parametrize("n_vars", [5, 8])
+def test_registers_rounds_check_against_the_dense_claim(n_vars):
+    """the stand-alone round loop over the registers member: every message sums to the running claim, which starts at the claim taken from
+    the trace columns; the last claim is eq * (wa * (inc + val) + ra * val) of the final values"""
+    ext = OracleExtended(n_vars, seed=13)
+    out = ext.registers_read_write(label=9)
+    claim = out["claim"]
+    zero, one = np.zeros(4, dtype=np.uint64), O.to_mont([1])[0]
+    for rnd, poly in enumerate(out["polys"]):
+        assert np.array_equal(_add(O.univariate_evaluate(poly, zero), O.univariate_evaluate(poly, one)), claim), rnd
+        claim = O.univariate_evaluate(poly, out["challenges"][rnd])
+    val, wa, ra, inc, eq = out["final_values"]
+    assert np.array_equal(claim, _mul(eq, _add(_mul(wa, _add(inc, val)), _mul(ra, val))))
+    g = ext.d["registers_gamma"]
+    assert np.array_equal(ra, _add(_mul(g, out["operand_claims"][0]), _mul(_mul(g, g), out["operand_claims"][1])))
+
+
 def test_consistent_trace_is_consistent():
     rng = np.random.default_rng(3)
     tr = S.consistent_ram_trace(4, 9, rng)
@@ -45,6 +62,6 @@ def test_consistent_trace_is_consistent():
 
 def test_all_extended_drivers_run_on_the_oracle():
     out = OracleExtended(5, seed=12, n_tables=6).prove(label=3)
-    assert set(out) == {"spartan_outer", "spartan_product", "ram_read_write", "instruction_read_raf"}
+    assert set(out) == {"spartan_outer", "spartan_product", "ram_read_write", "registers_read_write", "instruction_read_raf"}
     assert out["spartan_outer"]["polys"].shape[0] == 6 and out["spartan_product"]["polys"].shape[0] == 5
     assert len(out["instruction_read_raf"]["scans"]) == S.PHASES and out["instruction_read_raf"]["polys"].shape[0] == 5

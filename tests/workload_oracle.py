@@ -170,6 +170,64 @@ class OracleExtended:
         orc.close()
         return out
 
+    def registers_read_write(self, label):
+        from registers_fixture import inc_table
+        S, d = self.S, self.d
+        reg = d["registers"]
+        log_t, log_k = reg["log_t"], reg["log_k"]
+        K = 1 << log_k
+        gamma, r_cycle = d["registers_gamma"], d["registers_r_cycle"]
+        g2 = O.fr_mul(gamma.reshape(1, 4), gamma.reshape(1, 4))[0]
+        rep = lambda v, n: np.repeat(np.asarray(v).reshape(1, 4), n, axis=0)
+        T = 1 << log_t
+        weighted = O.fr_add(O.fr_from_u64(reg["rd_post"]), O.fr_add(O.fr_mul(rep(gamma, T), O.fr_from_u64(reg["rs1_val"])), O.fr_mul(rep(g2, T), O.fr_from_u64(reg["rs2_val"]))))
+        claim = O.Member.expr([O.eq_evals(r_cycle), weighted], [(self.one, [0, 1])], 2).input_claim()
+        state = dict(inc=inc_table(reg, O), dense=None)
+        orc = O.RegMatrix(reg["rs1"], reg["rs1_val"], reg["rs2"], reg["rs2_val"], reg["rd"], reg["rd_pre"], reg["rd_post"], gamma)
+        eq_state = O.SplitEqState(r_cycle)
+
+        def ingest(bound, bind):
+            if bound < log_t:
+                orc.cycle_bind(bind)
+                eq_state.bind(bind)
+                state["inc"] = O.bind_low_to_high(state["inc"], bind)
+                if bound == log_t - 1:
+                    state["dense"] = list(orc.into_dense(K))
+            else:
+                state["dense"] = [O.bind_low_to_high(t, bind) for t in state["dense"]]
+
+        def matrix_round(rnd, bind):
+            if bind is not None:
+                ingest(rnd - 1, bind)
+            if rnd < log_t:
+                e_out, e_in, _ = eq_state.tables()
+                q = orc.cycle_round(e_out, e_in, state["inc"])
+                return np.concatenate([q, np.zeros((2, 4), dtype=np.uint64)]), (eq_state.scalar, eq_state.point())
+            return O.regrw_address_round(*state["dense"], state["inc"][0], eq_state.scalar), None
+
+        def final_values():
+            ra, wa, val = (t[0] for t in state["dense"])
+            return np.stack([val, wa, ra, state["inc"][0], eq_state.scalar])
+
+        orc_tr = O.MockTranscript(label)
+
+        class Tr:
+            def append(self, values):
+                for v in np.asarray(values).reshape(-1, 4):
+                    orc_tr.append_fr(v)
+
+            def challenge(self):
+                return orc_tr.challenge()
+
+        S._sub = lambda a, b: O.fr_sub(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+        out = S.rw_rounds(matrix_round, lambda bind: ingest(log_t + log_k - 1, bind), final_values, log_t, log_k, claim, Tr(), O.gruen_poly_deg_3, O.univariate_from_evals,
+                          O.univariate_evaluate, four_point_address=True)
+        eq_adr, eq_cyc = O.eq_evals(out["challenges"][log_t:][::-1]), O.eq_evals(out["challenges"][:log_t][::-1])
+        out["operand_claims"] = np.stack([O.regrw_operand_claim(reg["rs1"], eq_adr, eq_cyc), O.regrw_operand_claim(reg["rs2"], eq_adr, eq_cyc)])
+        out["claim"] = claim
+        orc.close()
+        return out
+
     def instruction_read_raf(self, label):
         S, d = self.S, self.d
         lk = d["lookup"]
@@ -195,4 +253,4 @@ class OracleExtended:
 
     def prove(self, label=0):
         return {"spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
-                "instruction_read_raf": self.instruction_read_raf(label + 400)}
+                "registers_read_write": self.registers_read_write(label + 350), "instruction_read_raf": self.instruction_read_raf(label + 400)}
