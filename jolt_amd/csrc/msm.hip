@@ -189,10 +189,6 @@ extern "C" int32_t jolt_srs_free(jolt_ctx* ctx, jolt_srs* srs) {
     if (c) (void)hipStreamSynchronize(c->stream);
     if (srs->pts) (void)hipFree(srs->pts);
     if (srs->pre) (void)hipFree(srs->pre);
-    if (srs->short_tables) {
-        if (srs->short_tables->pre) (void)hipFree(srs->short_tables->pre);
-        delete srs->short_tables;
-    }
     delete srs;
     return JOLT_OK;
 }
@@ -209,9 +205,8 @@ int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* 
     if (n > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
     if (n == 0) return JOLT_OK;
     if (n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
-    const jolt_srs* tables = (srs->short_tables && n <= srs->short_tables->n) ? srs->short_tables : srs;  // short prefixes: the small table set (srs.hpp)
-    if (tables->pre && ctx->msm_fixed && n >= tables->pre_min_n) {  // window-precomputed bases: one bucket set for all windows (msm_fixed.hip)
-        int32_t fs = jolt_internal_msm_fixed_enqueue(ctx, tables, d_scalars, n, lane, job);
+    if (srs->pre && ctx->msm_fixed && n >= srs->pre_min_n) {  // window-precomputed bases: one bucket set for all windows (msm_fixed.hip)
+        int32_t fs = jolt_internal_msm_fixed_enqueue(ctx, srs, d_scalars, n, lane, job);
         if (fs != JOLT_ERR_UNSUPPORTED) return fs;  // skewed scalars fall through to the per-window method and its heavy-bucket kernels
     }
     MsmPlan p = plan_for(n);

@@ -654,27 +654,9 @@ __global__ __launch_bounds__(kBlock) void k_fx_to_lform(G1Affine* __restrict__ p
 // ------------------------------------------------------------------------------------------------------------------
 // precomputation
 // ------------------------------------------------------------------------------------------------------------------
-static int32_t fx_precompute_into(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms);
 extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms) {
     if (!ctx || !srs) return JOLT_ERR_INVALID_ARG;
     if (srs->pre) return JOLT_OK;
-    JOLT_TRY(fx_precompute_into(ctx, srs, window_bits, min_terms));
-    // the small table set for short prefixes (srs.hpp): only next to a main set whose own crossover lies above it
-    constexpr size_t kShortN = (size_t)1 << 20;
-    const char* sh = std::getenv("JOLT_MSM_SHORT");
-    if (srs->n >= 4 * kShortN && srs->pre_min_n > kShortN && !(sh && std::atoi(sh) == 0) && !srs->short_tables) {
-        jolt_srs* st = new (std::nothrow) jolt_srs();
-        if (!st) return JOLT_ERR_OOM;
-        st->ctx = ctx;
-        st->pts = srs->pts;  // not owned
-        st->n = kShortN;
-        const int32_t s = fx_precompute_into(ctx, st, 0, 1024);
-        if (s != JOLT_OK) { delete st; return s == JOLT_ERR_UNSUPPORTED ? JOLT_OK : s; }
-        srs->short_tables = st;
-    }
-    return JOLT_OK;
-}
-static int32_t fx_precompute_into(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms) {
     if (srs->n == 0) return JOLT_ERR_INVALID_ARG;
     int lg = 0;
     while (((size_t)2 << lg) <= srs->n) lg++;

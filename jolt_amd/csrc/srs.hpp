@@ -16,10 +16,6 @@ struct jolt_srs {
     uint32_t pre_B = 0;     // bucket count = the largest digit magnitude (k_fx_digits)
     size_t pre_stride = 0;  // points per window table (= n of the SRS the tables were built for; a range view keeps the parent's)
     size_t pre_min_n = 0;  // MSMs shorter than this keep the per-window bucket method
-    // A second, small table set over the first 2^20 bases with 18-bit windows (15 tables, 1 GiB): the ~20 short level commitments of an
-    // opening multiply prefixes of at most 2^20 bases, where the 6.3 M buckets of the main set (sized for 2^26 terms) cost more to clear,
-    // order and reduce than the additions themselves, and where the per-window method pays one bucket reduction per window.  Owned.
-    jolt_srs* short_tables = nullptr;
 };
 
 // bases [offset, n) of `parent` as an SRS of their own (no ownership): term-range MSMs of a sharded opening
@@ -28,6 +24,5 @@ static inline jolt_srs jolt_srs_range_view(const jolt_srs& parent, size_t offset
     v.pts = parent.pts + offset;
     v.n = parent.n - offset;
     if (parent.pre) v.pre = parent.pre + offset;
-    if (offset) v.short_tables = nullptr;  // the short set covers the bases from 0
     return v;
 }
