@@ -63,6 +63,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
     if (const char* sg = std::getenv("JOLT_MSM_STAGGER")) ctx->msm_stagger = std::atoi(sg) != 0;
     if (const char* gr = std::getenv("JOLT_FX_REDUCE")) ctx->msm_fx_grid_reduce = std::atoi(gr) != 0;
+    if (const char* so = std::getenv("JOLT_FX_SOA")) ctx->msm_fx_soa = std::atoi(so) != 0;
     if (const char* cs = std::getenv("JOLT_MSM_CU_SPLIT")) ctx->msm_cu_split = std::max(0, std::min(7, std::atoi(cs)));
     if (const char* rd = std::getenv("JOLT_FX_REDUCE_DIV")) ctx->msm_fx_reduce_div = std::max(1, std::atoi(rd));
     if (const char* fl = std::getenv("JOLT_FX_LFORM")) ctx->msm_fx_lform = std::atoi(fl) != 0;

@@ -312,6 +312,163 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments(const ui
     }
 }
 
+
+// ---- 2c. the same two passes WITHOUT a key array and with split entries (JOLT_FX_SOA, the default for 8-bit segments) --------------
+// The digit / histogram / partition / segment-sort phases move ~49 GB per 2^26-term MSM in the form above (4-byte keys written once and read
+// twice, 8-byte entries written twice and read up to five times) and run at the HBM rate.  Here the digits are recomputed from the scalars
+// where they are needed (one Montgomery multiply per scalar: free next to 32 bytes of traffic), the histogram is fused into the digit
+// pass, and an entry is carried as a 4-byte value (base index | sign) plus ONLY the digit bits the remaining passes still need: 15 bits
+// (2 bytes) after the group pass, 8 bits (1 byte) after the segment pass, which the segment sort's counting pass then reads alone:
+// ~28 GB per 2^26-term MSM.
+constexpr int kPartPerS = 12;  // entries per thread of the scalar-fed group pass = windows per scalar (W <= 12)
+template <int PER>
+struct PartSharedN {
+    uint64_t stage[kPartThreads * PER];
+    uint32_t cnt[kPartBins], lstart[kPartBins], gbase[kPartBins], wsum[4];
+};
+template <int PER, typename LOW>
+__device__ __forceinline__ void partition_tile_soa(PartSharedN<PER>& sh, const uint64_t (&item)[PER], const uint32_t (&bin)[PER], uint32_t nbins, uint32_t* __restrict__ cursors,
+                                                   uint32_t* __restrict__ out_val, LOW* __restrict__ out_low, int bin_shift, uint32_t bin_mask, uint32_t low_mask) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < kPartBins) sh.cnt[tid] = 0;
+    __syncthreads();
+    uint32_t rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) rank[u] = item[u] != ~0ull ? atomicAdd(&sh.cnt[bin[u]], 1u) : 0u;
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < kPartBins) {
+        v = tid < nbins ? sh.cnt[tid] : 0u;
+        incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)(tid & 63) >= off) incl += o;
+        }
+        if ((tid & 63) == 63) sh.wsum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < kPartBins) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < (tid >> 6); ++k) before += sh.wsum[k];
+        sh.lstart[tid] = before + incl - v;
+        sh.gbase[tid] = v ? atomicAdd(&cursors[tid], v) : 0u;
+    }
+    __syncthreads();
+    const uint32_t valid = sh.lstart[kPartBins - 1] + sh.cnt[kPartBins - 1];
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (item[u] != ~0ull) sh.stage[sh.lstart[bin[u]] + rank[u]] = item[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const uint32_t j = u * kPartThreads + tid;
+        if (j < valid) {
+            const uint64_t it = sh.stage[j];
+            const uint32_t hi = (uint32_t)(it >> 32), b = (hi >> bin_shift) & bin_mask;
+            const uint32_t pos = sh.gbase[b] + (j - sh.lstart[b]);
+            out_val[pos] = (uint32_t)it;
+            out_low[pos] = (LOW)(hi & low_mask);
+        }
+    }
+    __syncthreads();
+}
+
+// digits of one scalar straight into the per-workgroup segment histogram (no key array)
+template <int LO>
+__global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t nb1, uint32_t* __restrict__ hist1) {
+    extern __shared__ uint32_t fx_sh[];
+    for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
+    __syncthreads();
+    const size_t per = (((n + gridDim.x - 1) / gridDim.x) + kSortBlock - 1) / kSortBlock * kSortBlock, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (size_t base = lo; base < hi; base += kSortBlock) {  // whole wavefronts walk the loop together (ballots inside)
+        const size_t i = base + threadIdx.x;
+        const bool live = i < hi;
+        uint32_t keys[kPartPerS];
+#pragma unroll
+        for (int w = 0; w < kPartPerS; ++w) keys[w] = 0;
+        if (live) fx_digits_of(from_mont(ld_fr(scalars + i)), c, W, keys, 1);
+#pragma unroll
+        for (int w = 0; w < kPartPerS; ++w) {
+            if (w >= W) break;  // kernel-uniform
+            const uint32_t mag = keys[w] & 0x7FFFFFFFu;
+            WaveAgg ag = wave_aggregate(mag >> LO, mag != 0);
+            if (ag.do_atomic) atomicAdd(&fx_sh[mag >> LO], ag.count);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) {
+        uint32_t cnt = fx_sh[b];
+        if (cnt) atomicAdd(&hist1[b], cnt);
+    }
+}
+// pass 1 from the scalars: entries grouped by segment group; value = (w * stride + i) | sign << 31, low = |digit| mod 2^(LO + 7)
+template <int LO>
+__global__ __launch_bounds__(kPartThreads) void k_fx_partition_groups_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, size_t stride, uint32_t n_groups,
+                                                                             uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ out_val, uint16_t* __restrict__ out_low) {
+    extern __shared__ __align__(16) unsigned char fx_part_raw[];
+    PartSharedN<kPartPerS>& sh = *reinterpret_cast<PartSharedN<kPartPerS>*>(fx_part_raw);
+    const size_t n_tiles = (n + kPartThreads - 1) / kPartThreads;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t i = t * kPartThreads + threadIdx.x;
+        uint32_t keys[kPartPerS];
+#pragma unroll
+        for (int w = 0; w < kPartPerS; ++w) keys[w] = 0;
+        if (i < n) fx_digits_of(from_mont(ld_fr(scalars + i)), c, W, keys, 1);
+        uint64_t item[kPartPerS];
+        uint32_t bin[kPartPerS];
+#pragma unroll
+        for (int u = 0; u < kPartPerS; ++u) {
+            const uint32_t key = u < W ? keys[u] : 0u, mag = key & 0x7FFFFFFFu;
+            item[u] = mag ? ((uint64_t)mag << 32) | (uint32_t)((size_t)u * stride + i) | (key & 0x80000000u) : ~0ull;
+            bin[u] = mag >> (LO + kGroupBits);
+        }
+        partition_tile_soa<kPartPerS, uint16_t>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1);
+    }
+}
+// pass 2: inside every group, by segment; low = |digit| mod 2^LO afterwards
+template <int LO>
+__global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments_soa(const uint32_t* __restrict__ g_val, const uint16_t* __restrict__ g_low, const uint32_t* __restrict__ offs1, uint32_t nb1,
+                                                                           const uint32_t* __restrict__ info, uint32_t* __restrict__ cursor1, uint32_t* __restrict__ out_val,
+                                                                           uint8_t* __restrict__ out_low) {
+    extern __shared__ __align__(16) unsigned char fx_part_raw[];
+    PartSharedN<kPartPer>& sh = *reinterpret_cast<PartSharedN<kPartPer>*>(fx_part_raw);
+    __shared__ uint32_t tiles_before[kPartBins + 1];
+    const uint32_t n_groups = (nb1 + kGroupBins - 1) >> kGroupBits;
+    const uint32_t total = info[1];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            const uint32_t lo = offs1[g << kGroupBits], hi = ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+            tiles_before[g] = run;
+            run += (hi - lo + kPartTile - 1) / kPartTile;
+        }
+        tiles_before[n_groups] = run;
+    }
+    __syncthreads();
+    const uint32_t n_tiles = tiles_before[n_groups];
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        uint32_t g_lo = 0, g_hi = n_groups;
+        while (g_hi - g_lo > 1) {
+            const uint32_t mid = (g_lo + g_hi) >> 1;
+            if (tiles_before[mid] <= t) g_lo = mid; else g_hi = mid;
+        }
+        const uint32_t g = g_lo;
+        const uint32_t lo = offs1[g << kGroupBits], hi = ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+        const uint32_t first = lo + (t - tiles_before[g]) * kPartTile;
+        const uint32_t nbins = min((uint32_t)kGroupBins, nb1 - (g << kGroupBits));
+        uint64_t item[kPartPer];
+        uint32_t bin[kPartPer];
+#pragma unroll
+        for (int u = 0; u < kPartPer; ++u) {
+            const uint32_t k = first + u * kPartThreads + threadIdx.x;
+            const uint32_t low = k < hi ? g_low[k] : 0u;
+            item[u] = k < hi ? ((uint64_t)low << 32) | g_val[k] : ~0ull;
+            bin[u] = (low >> LO) & (kGroupBins - 1);
+        }
+        partition_tile_soa<kPartPer, uint8_t>(sh, item, bin, nbins, cursor1 + (g << kGroupBits), out_val, out_low, LO, kGroupBins - 1, (1u << LO) - 1);
+    }
+}
+
 // ---- 3. one workgroup per segment: counting sort by the low bits in LDS; emits the bucket table of the shared bucket kernels ----
 // hist[b] / offsets[b] for bucket b = seg * 512 + low bits (the layout k_msm_buckets_light / _heavy read with one "window"), the base
 // indices of every bucket contiguous in `sorted`, and one heavy-list entry per kHeavySeg points of an over-full bucket (what
@@ -401,8 +558,9 @@ __global__ __launch_bounds__(kBlock) void k_fx_segment_sort(const uint32_t* __re
 // 1024-thread workgroup owns the LDS of a CU, scatters into it and copies the finished segment out with adjacent lanes on adjacent
 // addresses.  Segments that do not fit (skewed digits) fall back to the direct scatter.
 constexpr int kSegThreads = 1024;
-template <int LO>
+template <int LO, bool SOA = false>
 __global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ offs1, const uint64_t* __restrict__ entries,
+                                                                       const uint32_t* __restrict__ e_val, const uint8_t* __restrict__ e_low,
                                                                        uint32_t* __restrict__ sorted, uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets,
                                                                        uint32_t heavy_threshold, uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
                                                                        uint32_t heavy_cap, uint32_t* __restrict__ class_hist, uint32_t stage_cap) {
@@ -417,15 +575,16 @@ __global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const ui
     if (tid == 0) s_max = 0;
     __syncthreads();
     for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
-        uint64_t e[4];
+        uint32_t bk[4];  // bucket inside the segment, or ~0
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t k = k0 + u * kSegThreads + tid;
-            e[u] = k < total ? entries[base + k] : ~0ull;
+            if constexpr (SOA) bk[u] = k < total ? (uint32_t)e_low[base + k] : ~0u;  // the counting pass reads one byte per entry
+            else bk[u] = k < total ? (uint32_t)(entries[base + k] >> 32) & (kSegBuckets - 1) : ~0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> 32) & (kSegBuckets - 1)], 1u);
+            if (bk[u] != ~0u) atomicAdd(&cnt[bk[u]], 1u);
     }
     __syncthreads();
     uint32_t c = 0, incl = 0;
@@ -472,22 +631,29 @@ __global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const ui
     for (uint32_t wi = 0; wi < n_stage_windows; ++wi) {
         const uint32_t w_lo = wi * span;
         for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
-            uint64_t e[4];
+            uint32_t bks[4], vals[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t k = k0 + u * kSegThreads + tid;
-                e[u] = k < total ? entries[base + k] : ~0ull;
+                if constexpr (SOA) {
+                    bks[u] = k < total ? (uint32_t)e_low[base + k] : ~0u;
+                    vals[u] = k < total ? e_val[base + k] : 0u;
+                } else {
+                    const uint64_t e = k < total ? entries[base + k] : ~0ull;
+                    bks[u] = e != ~0ull ? (uint32_t)(e >> 32) & (kSegBuckets - 1) : ~0u;
+                    vals[u] = (uint32_t)e;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (e[u] == ~0ull) continue;
-                const uint32_t bk = (uint32_t)(e[u] >> 32) & (kSegBuckets - 1);
+                if (bks[u] == ~0u) continue;
+                const uint32_t bk = bks[u];
                 if (staged) {
                     const uint32_t fp = first_pos[bk];
                     if (fp < w_lo || fp >= w_lo + span) continue;
-                    fx_stage[atomicAdd(&cur[bk], 1u) - w_lo] = (uint32_t)e[u];
+                    fx_stage[atomicAdd(&cur[bk], 1u) - w_lo] = vals[u];
                 } else {
-                    out[atomicAdd(&cur[bk], 1u)] = (uint32_t)e[u];
+                    out[atomicAdd(&cur[bk], 1u)] = vals[u];
                 }
             }
         }
@@ -738,14 +904,17 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     // (at most kClasses - 2, so that every light bucket sits in the class of its exact length)
     const uint32_t heavy_threshold = (uint32_t)std::min<size_t>(std::max<size_t>(2 * kLaneCap, 4 * avg), kClasses - 2);
     const uint32_t heavy_cap = (uint32_t)(total / kFxHeavySeg + total / heavy_threshold + 16);
+    // split entries and no key array (section 2c): 8-bit segments, the two-pass partition, W <= 12
+    const bool soa = ctx->msm_fx_soa && lo_bits == 8 && ctx->msm_fx_partition == 2 && W <= kPartPerS && ((nb1 + kGroupBins - 1) >> kGroupBits) <= (uint32_t)kPartBins &&
+                     sizeof(PartSharedN<kPartPerS>) + 2048 <= ctx->max_lds_per_block;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_keys = take(total * 4), o_entries = take(total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
+    const size_t o_keys = take(total * 4), o_entries = take(soa ? total * 5 + 512 : total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
                  o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(2 * sizeof(G1Jac)),
                  o_red = take(std::max<size_t>(red_points, 1) * sizeof(G1Jac)),
                  o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
                  o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4),
-                 o_grouped = take(ctx->msm_fx_partition == 2 ? total * 8 : 256), o_gcur = take(kPartBins * 4);
+                 o_grouped = take(soa ? total * 6 + 512 : (ctx->msm_fx_partition == 2 ? total * 8 : 256)), o_gcur = take(kPartBins * 4);
     hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
     // phases: sort (HBM bound) -> bucket sums (multiply-add bound) -> reduction (latency bound).  One stream by default; with JOLT_MSM_CU_SPLIT the
     // sort and the reduction run on the lane's CU-masked "sort" stream and the bucket sums on its "bucket" stream (ctx.hpp), chained by events
@@ -786,6 +955,12 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         hipError_t p2 = hipFuncSetAttribute((const void*)k_fx_partition_groups<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t p3 = hipFuncSetAttribute((const void*)k_fx_partition_segments<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t p4 = hipFuncSetAttribute((const void*)k_fx_partition_segments<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
+        hipError_t q1 = hipFuncSetAttribute((const void*)k_fx_hist_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        hipError_t q2 = hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerS>));
+        hipError_t q3 = hipFuncSetAttribute((const void*)k_fx_partition_segments_soa<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPer>));
+        (void)hipFuncSetAttribute((const void*)k_fx_segment_sort_staged<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0));
+        (void)hipGetLastError();
+        if (q1 != hipSuccess || q2 != hipSuccess || q3 != hipSuccess) ctx->msm_fx_soa = false;
         if (p1 != hipSuccess || p2 != hipSuccess || p3 != hipSuccess || p4 != hipSuccess) {
             (void)hipGetLastError();
             ctx->msm_fx_partition = 1;  // the one-pass scatter needs no more LDS than the histogram
@@ -807,9 +982,14 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, sst));
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
-    hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, sst, d_scalars, n, c, W, keys);
-    if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
-    else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
+    if (soa) {  // digits straight into the segment histogram: no key array
+        const unsigned hist_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, n / 4096));
+        hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
+    } else {
+        hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, sst, d_scalars, n, c, W, keys);
+        if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
+        else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
+    }
     hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, sst, (const uint32_t*)hist1, nb1, offs1, cur1, info);
     JOLT_HIP_TRY(ctx, hipGetLastError());
     JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), sst));  // z = 0: identity
@@ -817,7 +997,19 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     JOLT_HIP_TRY(ctx, hipMemsetAsync(class_hist, 0, kClasses * 4, sst));
     const bool two_pass = ctx->msm_fx_partition == 2 && n_groups <= (uint32_t)kPartBins && sizeof(PartShared) + 2048 <= ctx->max_lds_per_block;
     const unsigned part_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, (total + kPartTile - 1) / kPartTile));
-    if (two_pass) {
+    // split-entry arrays of the SoA path inside the two entry buffers
+    uint32_t* g_val = (uint32_t*)grouped;
+    uint16_t* g_low = (uint16_t*)((char*)grouped + ((total * 4 + 255) & ~(size_t)255));
+    uint32_t* s_val = (uint32_t*)entries;
+    uint8_t* s_low = (uint8_t*)((char*)entries + ((total * 4 + 255) & ~(size_t)255));
+    if (soa) {
+        hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
+        const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, (n + kPartThreads - 1) / kPartThreads));
+        hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreads), sizeof(PartSharedN<kPartPerS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
+                           group_cursor, g_val, g_low);
+        hipLaunchKernelGGL(k_fx_partition_segments_soa<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartSharedN<kPartPer>), sst, (const uint32_t*)g_val, (const uint16_t*)g_low,
+                           (const uint32_t*)offs1, nb1, (const uint32_t*)info, cur1, s_val, s_low);
+    } else if (two_pass) {
         hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
         if (lo_bits == 8) {
             hipLaunchKernelGGL(k_fx_partition_groups<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartShared), sst, (const uint32_t*)keys, total, n, srs->pre_stride, n_groups,
@@ -840,8 +1032,12 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         const size_t lds_max = ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0;  // cnt / cur / cls / wave sums live next to it
         const size_t want = (2 * (total / nb1) + 2048) * 4;
         const size_t stage_bytes = ctx->msm_fx_stage ? std::min(lds_max, want) : 0;
-        hipLaunchKernelGGL(k_fx_segment_sort_staged<8>, dim3(nb1), dim3(kSegThreads), stage_bytes, sst, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys,
-                           hist, offs, heavy_threshold, heavy, hcnt, heavy_cap, class_hist, (uint32_t)(stage_bytes / 4));
+        if (soa)
+            hipLaunchKernelGGL((k_fx_segment_sort_staged<8, true>), dim3(nb1), dim3(kSegThreads), stage_bytes, sst, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)nullptr,
+                               (const uint32_t*)s_val, (const uint8_t*)s_low, keys, hist, offs, heavy_threshold, heavy, hcnt, heavy_cap, class_hist, (uint32_t)(stage_bytes / 4));
+        else
+            hipLaunchKernelGGL((k_fx_segment_sort_staged<8, false>), dim3(nb1), dim3(kSegThreads), stage_bytes, sst, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries,
+                               (const uint32_t*)nullptr, (const uint8_t*)nullptr, keys, hist, offs, heavy_threshold, heavy, hcnt, heavy_cap, class_hist, (uint32_t)(stage_bytes / 4));
     }
     else
         hipLaunchKernelGGL(k_fx_segment_sort<11>, dim3(nb1), dim3(kBlock), 0, sst, (const uint32_t*)hist1, (const uint32_t*)offs1, (const uint64_t*)entries, keys, hist, offs,
