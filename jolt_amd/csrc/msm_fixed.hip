@@ -321,13 +321,13 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments(const ui
 // (2 bytes) after the group pass, 8 bits (1 byte) after the segment pass, which the segment sort's counting pass then reads alone:
 // ~28 GB per 2^26-term MSM.
 constexpr int kPartPerS = 12;  // entries per thread of the scalar-fed group pass = windows per scalar (W <= 12)
-template <int PER>
+template <int PER, int THREADS = kPartThreads>
 struct PartSharedN {
-    uint64_t stage[kPartThreads * PER];
+    uint64_t stage[THREADS * PER];
     uint32_t cnt[kPartBins], lstart[kPartBins], gbase[kPartBins], wsum[4];
 };
-template <int PER, typename LOW>
-__device__ __forceinline__ void partition_tile_soa(PartSharedN<PER>& sh, const uint64_t (&item)[PER], const uint32_t (&bin)[PER], uint32_t nbins, uint32_t* __restrict__ cursors,
+template <int PER, typename LOW, int THREADS = kPartThreads>
+__device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh, const uint64_t (&item)[PER], const uint32_t (&bin)[PER], uint32_t nbins, uint32_t* __restrict__ cursors,
                                                    uint32_t* __restrict__ out_val, LOW* __restrict__ out_low, int bin_shift, uint32_t bin_mask, uint32_t low_mask) {
     const uint32_t tid = threadIdx.x;
     if (tid < kPartBins) sh.cnt[tid] = 0;
@@ -361,7 +361,7 @@ __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER>& sh, const u
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const uint32_t j = u * kPartThreads + tid;
+        const uint32_t j = u * THREADS + tid;
         if (j < valid) {
             const uint64_t it = sh.stage[j];
             const uint32_t hi = (uint32_t)(it >> 32), b = (hi >> bin_shift) & bin_mask;
@@ -402,14 +402,15 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
     }
 }
 // pass 1 from the scalars: entries grouped by segment group; value = (w * stride + i) | sign << 31, low = |digit| mod 2^(LO + 7)
+constexpr int kPartThreadsS = 512;  // 512 x 12 entries = 48 KiB of stage: three workgroups per CU (1024 x 12 would leave one)
 template <int LO>
-__global__ __launch_bounds__(kPartThreads) void k_fx_partition_groups_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, size_t stride, uint32_t n_groups,
+__global__ __launch_bounds__(kPartThreadsS) void k_fx_partition_groups_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, size_t stride, uint32_t n_groups,
                                                                              uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ out_val, uint16_t* __restrict__ out_low) {
     extern __shared__ __align__(16) unsigned char fx_part_raw[];
-    PartSharedN<kPartPerS>& sh = *reinterpret_cast<PartSharedN<kPartPerS>*>(fx_part_raw);
-    const size_t n_tiles = (n + kPartThreads - 1) / kPartThreads;
+    PartSharedN<kPartPerS, kPartThreadsS>& sh = *reinterpret_cast<PartSharedN<kPartPerS, kPartThreadsS>*>(fx_part_raw);
+    const size_t n_tiles = (n + kPartThreadsS - 1) / kPartThreadsS;
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const size_t i = t * kPartThreads + threadIdx.x;
+        const size_t i = t * kPartThreadsS + threadIdx.x;
         uint32_t keys[kPartPerS];
 #pragma unroll
         for (int w = 0; w < kPartPerS; ++w) keys[w] = 0;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_groups_scalars(co
             item[u] = mag ? ((uint64_t)mag << 32) | (uint32_t)((size_t)u * stride + i) | (key & 0x80000000u) : ~0ull;
             bin[u] = mag >> (LO + kGroupBits);
         }
-        partition_tile_soa<kPartPerS, uint16_t>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1);
+        partition_tile_soa<kPartPerS, uint16_t, kPartThreadsS>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1);
     }
 }
 // pass 2: inside every group, by segment; low = |digit| mod 2^LO afterwards
@@ -574,17 +575,30 @@ __global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const ui
     if (tid < kClasses) cls[tid] = 0;
     if (tid == 0) s_max = 0;
     __syncthreads();
-    for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
-        uint32_t bk[4];  // bucket inside the segment, or ~0
+    // SOA: a thread takes the aligned 4-entry word g / 4 (one 4-byte load of the low bytes, one 16-byte load of the values) and keeps the entries of [base, base + total)
+    const uint32_t word_lo = base >> 2, word_hi = (base + total + 3) >> 2;
+    if constexpr (SOA) {
+        const uint32_t* low_words = reinterpret_cast<const uint32_t*>(e_low);
+        for (uint32_t wd = word_lo + tid; wd < word_hi; wd += kSegThreads) {
+            const uint32_t lows = low_words[wd];  // the counting pass reads one byte per entry
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t k = k0 + u * kSegThreads + tid;
-            if constexpr (SOA) bk[u] = k < total ? (uint32_t)e_low[base + k] : ~0u;  // the counting pass reads one byte per entry
-            else bk[u] = k < total ? (uint32_t)(entries[base + k] >> 32) & (kSegBuckets - 1) : ~0u;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t g = 4 * wd + u;
+                if (g >= base && g < base + total) atomicAdd(&cnt[(lows >> (8 * u)) & 0xFFu], 1u);
+            }
         }
+    } else {
+        for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
+            uint32_t bk[4];  // bucket inside the segment, or ~0
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (bk[u] != ~0u) atomicAdd(&cnt[bk[u]], 1u);
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + u * kSegThreads + tid;
+                bk[u] = k < total ? (uint32_t)(entries[base + k] >> 32) & (kSegBuckets - 1) : ~0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (bk[u] != ~0u) atomicAdd(&cnt[bk[u]], 1u);
+        }
     }
     __syncthreads();
     uint32_t c = 0, incl = 0;
@@ -630,15 +644,26 @@ __global__ __launch_bounds__(kSegThreads) void k_fx_segment_sort_staged(const ui
     uint32_t copied = 0;  // positions already written out (the previous window's last bucket may reach into this window's range)
     for (uint32_t wi = 0; wi < n_stage_windows; ++wi) {
         const uint32_t w_lo = wi * span;
-        for (uint32_t k0 = 0; k0 < total; k0 += 4 * kSegThreads) {
+        for (uint32_t k0 = 0; k0 < (SOA ? (word_hi - word_lo) * 4 : total); k0 += 4 * kSegThreads) {
             uint32_t bks[4], vals[4];
+            if constexpr (SOA) {
+                const uint32_t wd = word_lo + k0 / 4 + tid;
+                uint32_t lows = 0;
+                uint4 v4 = make_uint4(0u, 0u, 0u, 0u);
+                if (wd < word_hi) {
+                    lows = reinterpret_cast<const uint32_t*>(e_low)[wd];
+                    v4 = reinterpret_cast<const uint4*>(e_val)[wd];
+                }
+                vals[0] = v4.x; vals[1] = v4.y; vals[2] = v4.z; vals[3] = v4.w;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t k = k0 + u * kSegThreads + tid;
-                if constexpr (SOA) {
-                    bks[u] = k < total ? (uint32_t)e_low[base + k] : ~0u;
-                    vals[u] = k < total ? e_val[base + k] : 0u;
-                } else {
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t g = 4 * wd + u;
+                    bks[u] = (wd < word_hi && g >= base && g < base + total) ? (lows >> (8 * u)) & 0xFFu : ~0u;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t k = k0 + u * kSegThreads + tid;
                     const uint64_t e = k < total ? entries[base + k] : ~0ull;
                     bks[u] = e != ~0ull ? (uint32_t)(e >> 32) & (kSegBuckets - 1) : ~0u;
                     vals[u] = (uint32_t)e;
@@ -906,7 +931,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const uint32_t heavy_cap = (uint32_t)(total / kFxHeavySeg + total / heavy_threshold + 16);
     // split entries and no key array (section 2c): 8-bit segments, the two-pass partition, W <= 12
     const bool soa = ctx->msm_fx_soa && lo_bits == 8 && ctx->msm_fx_partition == 2 && W <= kPartPerS && ((nb1 + kGroupBins - 1) >> kGroupBits) <= (uint32_t)kPartBins &&
-                     sizeof(PartSharedN<kPartPerS>) + 2048 <= ctx->max_lds_per_block;
+                     sizeof(PartSharedN<kPartPerS, kPartThreadsS>) + 2048 <= ctx->max_lds_per_block;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_keys = take(total * 4), o_entries = take(soa ? total * 5 + 512 : total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
@@ -956,7 +981,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         hipError_t p3 = hipFuncSetAttribute((const void*)k_fx_partition_segments<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t p4 = hipFuncSetAttribute((const void*)k_fx_partition_segments<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t q1 = hipFuncSetAttribute((const void*)k_fx_hist_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-        hipError_t q2 = hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerS>));
+        hipError_t q2 = hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerS, kPartThreadsS>));
         hipError_t q3 = hipFuncSetAttribute((const void*)k_fx_partition_segments_soa<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPer>));
         (void)hipFuncSetAttribute((const void*)k_fx_segment_sort_staged<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0));
         (void)hipGetLastError();
@@ -1004,8 +1029,8 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     uint8_t* s_low = (uint8_t*)((char*)entries + ((total * 4 + 255) & ~(size_t)255));
     if (soa) {
         hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
-        const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, (n + kPartThreads - 1) / kPartThreads));
-        hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreads), sizeof(PartSharedN<kPartPerS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
+        const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 3, (n + kPartThreadsS - 1) / kPartThreadsS));
+        hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerS, kPartThreadsS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
                            group_cursor, g_val, g_low);
         hipLaunchKernelGGL(k_fx_partition_segments_soa<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartSharedN<kPartPer>), sst, (const uint32_t*)g_val, (const uint16_t*)g_low,
                            (const uint32_t*)offs1, nb1, (const uint32_t*)info, cur1, s_val, s_low);
