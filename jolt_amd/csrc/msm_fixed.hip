@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
     }
 }
 // pass 1 from the scalars: entries grouped by segment group; value = (w * stride + i) | sign << 31, low = |digit| mod 2^(LO + 7)
-constexpr int kPartThreadsS = 512;  // 512 x 12 entries = 48 KiB of stage: three workgroups per CU (1024 x 12 would leave one)
+constexpr int kPartThreadsS = 1024;  // 1024 x 12 entries = 96 KiB of stage, one workgroup per CU: 3.7 ms per 2^26 terms; 512 threads (three per CU) measured 4.3 ms -- the runs per bin get too short
 template <int LO>
 __global__ __launch_bounds__(kPartThreadsS) void k_fx_partition_groups_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, size_t stride, uint32_t n_groups,
                                                                              uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ out_val, uint16_t* __restrict__ out_low) {
@@ -1029,7 +1029,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     uint8_t* s_low = (uint8_t*)((char*)entries + ((total * 4 + 255) & ~(size_t)255));
     if (soa) {
         hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
-        const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 3, (n + kPartThreadsS - 1) / kPartThreadsS));
+        const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, (n + kPartThreadsS - 1) / kPartThreadsS));
         hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerS, kPartThreadsS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
                            group_cursor, g_val, g_low);
         hipLaunchKernelGGL(k_fx_partition_segments_soa<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartSharedN<kPartPer>), sst, (const uint32_t*)g_val, (const uint16_t*)g_low,
