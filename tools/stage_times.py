@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from jolt_amd import ffi
 from jolt_amd.workload import DeviceWorkload
 ctx = ffi.Context(0)
-wl = DeviceWorkload(ctx, 20)
+wl = DeviceWorkload(ctx, int(sys.argv[1]) if len(sys.argv) > 1 else 20)
 for _ in range(3): wl.prove(label=1)
 acc = {}
 N = 10
