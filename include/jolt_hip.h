@@ -317,6 +317,14 @@ int32_t jolt_host_gruen_poly_from_q(const jolt_fr_t *current_scalar, const jolt_
 /* GruenSplitEqPolynomial::gruen_poly_deg_3 (split_eq.rs:383-417): 4 coefficients */
 int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t *current_scalar, const jolt_fr_t *point_i, const jolt_fr_t *q_constant,
                                    const jolt_fr_t *q_quadratic, const jolt_fr_t *s0_plus_s1, jolt_fr_t *coeffs_out);
+/* Booleanity address phase (stage 6a), host half: OptimizedBooleanityAddressKernel::{prove_round, bind} (crates/jolt-kernels/src/optimized/
+ * booleanity.rs:320-398) over the K-entry pushforward masses of jolt_onehot_pushforward (K = 2^log_k_chunk = 16 .. 256 points: the reference
+ * keeps this loop on the host, :46-49).  Tables are n_polys rows of `stride` entries with the first `len` live; weights[i] = gamma^(2i);
+ * round returns s(0..3) for UnivariatePoly::from_evals; bind halves `len` (linear and eq as multilinears, squared with (1-r)^2 / r^2). */
+int32_t jolt_host_booleanity_address_round(const jolt_fr_t *linear, const jolt_fr_t *squared, size_t n_polys, size_t stride, size_t len,
+                                           const jolt_fr_t *weights, const jolt_fr_t *eq_address, jolt_fr_t *evals_out);
+int32_t jolt_host_booleanity_address_bind(jolt_fr_t *linear, jolt_fr_t *squared, size_t n_polys, size_t stride, size_t len, jolt_fr_t *eq_address,
+                                          const jolt_fr_t *challenge);
 /* The Fiat-Shamir surface of members the caller drives round by round outside prove_batch (RamReadWriteKernel's rounds, the read-RAF
  * phases): Transcript::{append, challenge, challenge_scalar} (crates/jolt-transcript/src/legacy.rs:55-100) over the deterministic TEST
  * transcript of jolt_host_prove_batch.  A Rust caller keeps its own Blake2b / Keccak transcript and never calls these. */

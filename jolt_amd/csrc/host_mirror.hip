@@ -560,6 +560,54 @@ extern "C" int32_t jolt_host_gruen_poly_deg_3(const jolt_fr_t* current_scalar, c
     return JOLT_OK;
 }
 
+// ---- booleanity address phase (stage 6a), host half: OptimizedBooleanityAddressKernel::{prove_round, bind} (crates/jolt-kernels/src/optimized/
+// booleanity.rs:320-398) over the K-entry pushforward masses jolt_onehot_pushforward produced.  16 .. 256 points per table: the reference keeps this
+// loop on the host ("negligible next to the T-scale table construction", :46-49) and so does a Rust caller; these two entry points let the
+// Python stage driver (jolt_amd/stages.py) run it without per-element FFI calls.  Tables: n_polys rows of `stride` entries, the first `len` live.
+extern "C" int32_t jolt_host_booleanity_address_round(const jolt_fr_t* linear, const jolt_fr_t* squared, size_t n_polys, size_t stride, size_t len, const jolt_fr_t* weights,
+                                                      const jolt_fr_t* eq_address, jolt_fr_t* evals_out /* 4 */) {
+    if (!linear || !squared || !weights || !eq_address || !evals_out || len < 2 || (len & (len - 1)) || len > stride) return JOLT_ERR_INVALID_ARG;
+    const size_t half = len / 2;
+    for (uint64_t c = 0; c < 4; ++c) {
+        const Fr point = fr_from_u64(c), point_sqr = mul(point, point), om = sub(Fr::one(), point), one_minus_sqr = mul(om, om);
+        Fr sum = Fr::zero();
+        for (size_t y = 0; y < half; ++y) {
+            Fr inner = Fr::zero();
+            for (size_t i = 0; i < n_polys; ++i) {
+                const jolt_fr_t *sq = squared + i * stride, *lin = linear + i * stride;
+                const Fr s0 = fr_from_abi(&sq[2 * y]), s1 = fr_from_abi(&sq[2 * y + 1]), l0 = fr_from_abi(&lin[2 * y]), l1 = fr_from_abi(&lin[2 * y + 1]);
+                const Fr squared_ext = add(mul(one_minus_sqr, s0), mul(point_sqr, s1));
+                const Fr linear_ext = add(l0, mul(point, sub(l1, l0)));
+                inner = add(inner, mul(fr_from_abi(&weights[i]), sub(squared_ext, linear_ext)));
+            }
+            const Fr e0 = fr_from_abi(&eq_address[2 * y]), e1 = fr_from_abi(&eq_address[2 * y + 1]);
+            sum = add(sum, mul(add(e0, mul(point, sub(e1, e0))), inner));
+        }
+        fr_to_abi(&evals_out[c], sum);
+    }
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_booleanity_address_bind(jolt_fr_t* linear, jolt_fr_t* squared, size_t n_polys, size_t stride, size_t len, jolt_fr_t* eq_address, const jolt_fr_t* challenge) {
+    if (!linear || !squared || !eq_address || !challenge || len < 2 || (len & (len - 1)) || len > stride) return JOLT_ERR_INVALID_ARG;
+    const Fr r = fr_from_abi(challenge);
+    if (!fr_is_canonical(r)) return JOLT_ERR_INVALID_ARG;
+    const size_t half = len / 2;
+    const Fr om = sub(Fr::one(), r), one_minus_sqr = mul(om, om), challenge_sqr = mul(r, r);
+    for (size_t i = 0; i < n_polys; ++i) {
+        jolt_fr_t *lin = linear + i * stride, *sq = squared + i * stride;
+        for (size_t k = 0; k < half; ++k) {
+            const Fr l0 = fr_from_abi(&lin[2 * k]), l1 = fr_from_abi(&lin[2 * k + 1]);
+            fr_to_abi(&lin[k], add(l0, mul(r, sub(l1, l0))));
+            fr_to_abi(&sq[k], add(mul(one_minus_sqr, fr_from_abi(&sq[2 * k])), mul(challenge_sqr, fr_from_abi(&sq[2 * k + 1]))));  // squared weights: one-hot columns
+        }
+    }
+    for (size_t k = 0; k < half; ++k) {
+        const Fr e0 = fr_from_abi(&eq_address[2 * k]), e1 = fr_from_abi(&eq_address[2 * k + 1]);
+        fr_to_abi(&eq_address[k], add(e0, mul(r, sub(e1, e0))));
+    }
+    return JOLT_OK;
+}
+
 // ---- the caller-side Fiat-Shamir of members that are driven round by round outside prove_batch (sparse read-write matrix, read-RAF
 // phases): the deterministic test transcript behind four entry points; a Rust caller uses its own Transcript instead.
 struct jolt_host_transcript {

@@ -469,6 +469,41 @@ def host_gruen_poly_from_q(scalar, point_i, q_evals, claim):
     return o
 
 
+class HostBooleanityAddress:
+    """The K-domain state of the booleanity address phase on the host (jolt_host_booleanity_address_*): masses (n_polys, K, 4) from the pushforward"""
+
+    def __init__(self, masses, gamma, reference_address):
+        self.linear = np.ascontiguousarray(masses, dtype=np.uint64).copy()
+        self.squared = self.linear.copy()
+        self.n_polys, self.k = self.linear.shape[0], self.linear.shape[1]
+        self.len = self.k
+        g2 = host_fr_mul(gamma, gamma)
+        w, cur = [], host_fr_from_u64(1)
+        for _ in range(self.n_polys):
+            w.append(cur)
+            cur = host_fr_mul(cur, g2)
+        self.weights = np.ascontiguousarray(np.stack(w))
+        self.eq = np.ascontiguousarray(host_eq_evals(reference_address)).copy()
+
+    def round(self):
+        o = fr_array(4)
+        _ck(lib().jolt_host_booleanity_address_round(_p(self.linear), _p(self.squared), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(self.weights), _p(self.eq),
+                                                     _p(o)), "jolt_host_booleanity_address_round")
+        return o
+
+    def bind(self, r):
+        _ck(lib().jolt_host_booleanity_address_bind(_p(self.linear), _p(self.squared), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(self.eq), _p(fr(r))),
+            "jolt_host_booleanity_address_bind")
+        self.len //= 2
+
+    def intermediate(self):
+        assert self.len == 1
+        acc = np.zeros(4, dtype=np.uint64)
+        for i in range(self.n_polys):
+            acc = host_fr_add(acc, host_fr_mul(self.weights[i], host_fr_sub(self.squared[i, 0], self.linear[i, 0])))
+        return host_fr_mul(self.eq[0], acc)
+
+
 class HostTranscript:
     """The deterministic test transcript of jolt_host_prove_batch for members driven round by round from here (jolt_host_transcript_*)."""
 

@@ -13,6 +13,10 @@ stage drivers drive them, over synthetic trace-shaped inputs:
                                      log T cycle rounds over combined * prod ra  (optimized/instruction_read_raf.rs; the 8 address rounds
                                      inside a phase run over 256-entry polynomials on the caller's side and are not part of this)
 
+  stage 6a  booleanity, address      the pushforward masses G_i[k] = sum_j eq(r_cycle, j) [hot_i(j) = k] of all RA columns (T-scale, device), then the
+                                     log K rounds over K-entry tables with the squared-weight bind on the host, where the reference keeps them
+                                     (optimized/booleanity.rs:152-427)
+
 `build_extended` is a pure description (numpy); `DeviceExtended` holds the resident inputs in HBM and proves; tests/workload_oracle.py
 instantiates the same description on the CPU oracle.  Every operator absorbs what it sends into a transcript and takes its challenges
 from it (the deterministic test transcript, jolt_host_transcript_* / jolt_host_prove_batch), so two runs agree message for message.
@@ -146,7 +150,28 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_cou
     d["lookup_raf"] = rand_fr(2, rng)
     d["lookup_reduction"] = rand_fr(n_vars, rng)
     d["ra_count"] = ra_count
+    # ---- stage 6a: the RA selector columns of the booleanity check (instruction, bytecode, RAM chunks: 36 columns at log_k_chunk = 4; RAM cold 40 %)
+    n_ra, log_kc = (36, 4) if n_vars >= 4 else (5, 2)
+    cols = rng.integers(0, 1 << log_kc, size=(n_ra, T)).astype(np.uint8)
+    for p in range(max(1, n_ra // 12)):
+        cols[n_ra - 1 - p, rng.random(T) < 0.4] = 0xFF
+    d["booleanity"] = dict(cols=cols, log_k=log_kc, reference_cycle=rand_fr(n_vars, rng), reference_address=rand_fr(log_kc, rng), gamma=rand_fr(1, rng)[0])
     return d
+
+
+def booleanity_address_rounds(kernel, log_k, transcript, from_evals, evaluate):
+    """ProveRounds of OptimizedBooleanityAddressKernel driven alone (optimized/booleanity.rs:344-403): four sampled points per round, every message
+    absorbed coefficient by coefficient, the input claim is zero.  `kernel`: round() -> 4 evals, bind(r), intermediate()."""
+    polys, chal, claim = [], [], np.zeros(4, dtype=np.uint64)
+    for rnd in range(log_k):
+        poly = from_evals(kernel.round())
+        transcript.append(poly)
+        r = transcript.challenge()
+        claim = evaluate(poly, r)
+        kernel.bind(r)
+        polys.append(poly)
+        chal.append(r)
+    return dict(polys=polys, challenges=np.stack(chal), final_claim=claim, intermediate=kernel.intermediate())
 
 
 def product_integer_weights():
@@ -217,6 +242,8 @@ class DeviceExtended:
         lo = (reg["rd_post"] - reg["rd_pre"]).astype(np.uint64)  # RdInc = post - pre as an i128 (lo, hi two's complement)
         hi = np.where(reg["rd_post"] < reg["rd_pre"], np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0)).astype(np.uint64)
         self.reg_inc = ctx.ints(np.stack([lo, hi], axis=1), "i128")
+        bo = d["booleanity"]
+        self.bool_cols = ctx.onehot(bo["cols"], 1 << bo["log_k"])
         lk = d["lookup"]
         self.read_raf = ctx.read_raf(lk["idx"], lk["table"], lk["raf"], lk["n_tables"])
         # ---- input claims (in a real proof the previous stage's output claims): computed once, untimed
@@ -312,6 +339,20 @@ class DeviceExtended:
         out["operand_claims"] = np.stack(claims)
         return out
 
+    def booleanity_address(self, label):
+        ctx, ffi, bo = self.ctx, self.ffi, self.d["booleanity"]
+        eq = ctx.eq_evals(bo["reference_cycle"])
+        g = self.bool_cols.pushforward(eq)  # cycle_pushforward (booleanity.rs:152-237): the only T-scale work of the phase
+        eq.free()
+        masses = g.download().reshape(bo["cols"].shape[0], 1 << bo["log_k"], 4)
+        g.free()
+        tr = ffi.HostTranscript(label)
+        out = booleanity_address_rounds(ffi.HostBooleanityAddress(masses, bo["gamma"], bo["reference_address"]), bo["log_k"], tr, ffi.host_univariate_from_evals,
+                                        ffi.host_univariate_evaluate)
+        tr.close()
+        out["masses"] = masses
+        return out
+
     def instruction_read_raf(self, label):
         ctx, ffi, d = self.ctx, self.ffi, self.d
         lk, rr = d["lookup"], self.read_raf
@@ -351,9 +392,10 @@ class DeviceExtended:
             "ram_read_write": self.ram_read_write(label + 300),
             "registers_read_write": self.registers_read_write(label + 350),
             "instruction_read_raf": self.instruction_read_raf(label + 400),
+            "booleanity_address": self.booleanity_address(label + 450),
         }
 
     def close(self):
-        for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx]:
+        for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx, self.bool_cols]:
             c.free()
         self.read_raf.free()

@@ -45,3 +45,42 @@ EXPORT void orc_onehot_pushforward(const uint8_t *col, size_t cycles, size_t k_e
     for (size_t j = 0; j < cycles; ++j)
         if (col[j] != ORC_COLD) out[col[j]] = FADD(out[col[j]], w[j]);
 }
+
+/* ---- booleanity address phase (stage 6a): crates/jolt-kernels/src/optimized/booleanity.rs:283-427 ------------------------------------
+ * OptimizedBooleanityAddressKernel over the pushforward masses G_i (linear = squared = G_i at the start; gamma weights g^(2i)):
+ *   prove_round :349-398  s(c), c = 0..3, over low-to-high pairs:  sum_y eq_t(y) * sum_i w_i * ( (1-c)^2 sq_i[2y] + c^2 sq_i[2y+1] - lin_i,t(y) )
+ *   bind        :320-341  linear and eq_address as multilinears, squared with the weights (1-r)^2 / r^2 (one-hot columns: cross terms vanish)
+ *   output      :413-427  intermediate = eq[0] * sum_i w_i (sq_i[0] - lin_i[0])
+ * Tables are n_polys rows of `len` entries each (row-major), bound in place (the first len / 2 entries of a row remain). */
+EXPORT void orc_booleanity_address_round(const fr_t *linear, const fr_t *squared, size_t n_polys, size_t stride, size_t len, const fr_t *weights, const fr_t *eq_address,
+                                         fr_t evals[4]) {
+    const size_t half = len / 2;
+    for (uint64_t c = 0; c < 4; ++c) {
+        const fr_t point = fr_from_u64(c), point_sqr = FMUL(point, point), om = FSUB(fr_one(), point), one_minus_sqr = FMUL(om, om);
+        fr_t sum = fr_zero();
+        for (size_t y = 0; y < half; ++y) {
+            fr_t inner = fr_zero();
+            for (size_t i = 0; i < n_polys; ++i) {
+                const fr_t *sq = squared + i * stride, *lin = linear + i * stride;
+                const fr_t squared_ext = FADD(FMUL(one_minus_sqr, sq[2 * y]), FMUL(point_sqr, sq[2 * y + 1]));
+                const fr_t linear_ext = FADD(lin[2 * y], FMUL(point, FSUB(lin[2 * y + 1], lin[2 * y])));
+                inner = FADD(inner, FMUL(weights[i], FSUB(squared_ext, linear_ext)));
+            }
+            const fr_t eq_ext = FADD(eq_address[2 * y], FMUL(point, FSUB(eq_address[2 * y + 1], eq_address[2 * y])));
+            sum = FADD(sum, FMUL(eq_ext, inner));
+        }
+        evals[c] = sum;
+    }
+}
+EXPORT void orc_booleanity_address_bind(fr_t *linear, fr_t *squared, size_t n_polys, size_t stride, size_t len, fr_t *eq_address, const fr_t *r) {
+    const size_t half = len / 2;
+    const fr_t om = FSUB(fr_one(), *r), one_minus_sqr = FMUL(om, om), challenge_sqr = FMUL(*r, *r);
+    for (size_t i = 0; i < n_polys; ++i) {
+        fr_t *lin = linear + i * stride, *sq = squared + i * stride;
+        for (size_t k = 0; k < half; ++k) {
+            lin[k] = FADD(lin[2 * k], FMUL(*r, FSUB(lin[2 * k + 1], lin[2 * k])));
+            sq[k] = FADD(FMUL(one_minus_sqr, sq[2 * k]), FMUL(challenge_sqr, sq[2 * k + 1]));
+        }
+    }
+    for (size_t k = 0; k < half; ++k) eq_address[k] = FADD(eq_address[2 * k], FMUL(*r, FSUB(eq_address[2 * k + 1], eq_address[2 * k])));
+}

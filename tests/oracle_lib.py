@@ -743,6 +743,40 @@ def onehot_pushforward(col, k_entries, w):
     return out
 
 
+class BooleanityAddress:
+    """OptimizedBooleanityAddressKernel (crates/jolt-kernels/src/optimized/booleanity.rs:283-427) over pushforward masses (n_polys, K, 4)"""
+
+    def __init__(self, masses, gamma, reference_address):
+        self.linear = np.ascontiguousarray(masses, dtype=np.uint64).copy()
+        self.squared = self.linear.copy()
+        self.n_polys, self.k = self.linear.shape[0], self.linear.shape[1]
+        self.len = self.k
+        g2 = fr_mul(np.asarray(gamma).reshape(1, 4), np.asarray(gamma).reshape(1, 4))[0]
+        w, cur = [], to_mont([1])[0]
+        for _ in range(self.n_polys):
+            w.append(cur)
+            cur = fr_mul(cur.reshape(1, 4), g2.reshape(1, 4))[0]
+        self.weights = np.ascontiguousarray(np.stack(w))
+        self.eq = eq_evals(reference_address).copy()
+
+    def round(self):
+        o = fr_array(4)
+        lib().orc_booleanity_address_round(_p(self.linear), _p(self.squared), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(self.weights), _p(self.eq), _p(o))
+        return o
+
+    def bind(self, r):
+        lib().orc_booleanity_address_bind(_p(self.linear), _p(self.squared), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(self.eq),
+                                          _p(np.ascontiguousarray(r, dtype=np.uint64)))
+        self.len //= 2
+
+    def intermediate(self):
+        assert self.len == 1
+        acc = np.zeros(4, dtype=np.uint64)
+        for i in range(self.n_polys):
+            acc = fr_add(acc.reshape(1, 4), fr_mul(self.weights[i].reshape(1, 4), fr_sub(self.squared[i, 0].reshape(1, 4), self.linear[i, 0].reshape(1, 4))))[0]
+        return fr_mul(self.eq[0].reshape(1, 4), acc.reshape(1, 4))[0]
+
+
 # ---- sparse read-write matrix (oracle/rw_matrix.c) --------------------------------------------------------------------
 RW_NO_ACCESS = 0xFFFFFFFFFFFFFFFF
 

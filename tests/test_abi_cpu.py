@@ -302,3 +302,21 @@ def test_subtree_ownership_hooks_agree_with_the_specification():
         ffi.host_subtree_owned_terms(8, 0, 3)  # the world size must be a power of two
     with pytest.raises(ffi.JoltError):
         ffi.host_subtree_term_index(1, 4, 4)
+
+
+def test_host_booleanity_address_rounds_match_the_oracle():
+    """jolt_host_booleanity_address_{round,bind} (the K-domain loop of stage 6a the stage driver runs on the host) against oracle/onehot.c's restatement"""
+    import oracle_lib as O
+    from jolt_amd import ffi
+    from util import rand_challenge, rand_fr
+    n_polys, log_k = 5, 4
+    masses = rand_fr(n_polys * (1 << log_k), 71).reshape(n_polys, 1 << log_k, 4)
+    gamma, ref = rand_fr(1, 72)[0], rand_fr(log_k, 73)
+    dev, orc = ffi.HostBooleanityAddress(masses, gamma, ref), O.BooleanityAddress(masses, gamma, ref)
+    assert np.array_equal(dev.weights, orc.weights) and np.array_equal(dev.eq, orc.eq)
+    for rnd in range(log_k):
+        assert np.array_equal(dev.round(), orc.round()), rnd
+        r = rand_challenge(80 + rnd, shifted=(rnd % 2 == 0))
+        dev.bind(r)
+        orc.bind(r)
+    assert np.array_equal(dev.intermediate(), orc.intermediate())

@@ -30,7 +30,9 @@ def run(n_vars, seed, **kw):
     again = dev.prove(label=40)  # a second proof over the resident inputs: same bytes
     want = OracleExtended(n_vars, seed=seed, **kw).prove(label=40)
     for name in got:
-        assert np.array_equal(dev.claims[{"spartan_outer": "outer", "spartan_product": "product", "ram_read_write": "ram", "registers_read_write": "registers", "instruction_read_raf": "lookup"}[name]], want[name]["claim"]), name
+        if name != "booleanity_address":  # (its input claim is zero by construction)
+            assert np.array_equal(dev.claims[{"spartan_outer": "outer", "spartan_product": "product", "ram_read_write": "ram", "registers_read_write": "registers",
+                                              "instruction_read_raf": "lookup"}[name]], want[name]["claim"]), name
         same(got[name], {k: v for k, v in want[name].items() if k != "claim"}, name)
         same(again[name], got[name], name + " (second proof)")
     dev.close()

@@ -251,6 +251,27 @@ class OracleExtended:
         out = O.prove_batch([orc], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)
         return dict(scans=scans, v_tables=vt, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], claim=claim)
 
+    def booleanity_address(self, label):
+        S, bo = self.S, self.d["booleanity"]
+        K = 1 << bo["log_k"]
+        eq = O.eq_evals(bo["reference_cycle"])
+        masses = np.stack([O.onehot_pushforward(bo["cols"][i], K, eq) for i in range(bo["cols"].shape[0])])
+        orc_tr = O.MockTranscript(label)
+
+        class Tr:
+            def append(self, values):
+                for v in np.asarray(values).reshape(-1, 4):
+                    orc_tr.append_fr(v)
+
+            def challenge(self):
+                return orc_tr.challenge()
+
+        out = S.booleanity_address_rounds(O.BooleanityAddress(masses, bo["gamma"], bo["reference_address"]), bo["log_k"], Tr(), O.univariate_from_evals, O.univariate_evaluate)
+        out["masses"] = masses
+        out["claim"] = np.zeros(4, dtype=np.uint64)
+        return out
+
     def prove(self, label=0):
         return {"spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
-                "registers_read_write": self.registers_read_write(label + 350), "instruction_read_raf": self.instruction_read_raf(label + 400)}
+                "registers_read_write": self.registers_read_write(label + 350), "instruction_read_raf": self.instruction_read_raf(label + 400),
+                "booleanity_address": self.booleanity_address(label + 450)}
