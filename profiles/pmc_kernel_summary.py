@@ -24,6 +24,18 @@ def main(path, flt=None):
         print(f"{name[:70]:70s} dispatches={n}")
         for cname, vals in sorted(cs.items()):
             print(f"    {cname:28s} avg={sum(vals) / len(vals):16.1f} max={max(vals):16.1f}")
+        avg = {c: sum(v) / len(v) for c, v in cs.items()}
+        # derived: share of the wavefronts' resident cycles in which a VALU instruction was executing / any instruction was executing / waiting
+        # (SQ_ACTIVE_INST_* and SQ_WAIT_* count wave-cycles, as SQ_WAVE_CYCLES does; all are summed over the dispatch's dimensions)
+        if avg.get("SQ_WAVE_CYCLES"):
+            wc = avg["SQ_WAVE_CYCLES"]
+            parts = []
+            for label, key in (("VALU-active", "SQ_ACTIVE_INST_VALU"), ("any-inst-active", "SQ_ACTIVE_INST_ANY"), ("waiting", "SQ_WAIT_ANY"), ("waiting-on-inst", "SQ_WAIT_INST_ANY")):
+                if key in avg:
+                    parts.append(f"{label} {100.0 * avg[key] / wc:5.1f} %")
+            if "SQ_INSTS_VALU" in avg and avg.get("SQ_ACTIVE_INST_VALU"):
+                parts.append(f"cycles per VALU inst {avg['SQ_ACTIVE_INST_VALU'] / avg['SQ_INSTS_VALU']:4.1f}")
+            print("    derived (of wave-cycles):    " + ",  ".join(parts))
 
 
 if __name__ == "__main__":

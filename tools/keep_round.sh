@@ -1,19 +1,27 @@
 #!/bin/bash
-# copy the judged summaries of a collect_round.sh run from gpurun_out/<src>/ into profiles/ as <tag>_*:  bash tools/keep_round.sh r02a r02
+# copy the judged summaries of a collect_round.sh run from gpurun_out/<src>/ into profiles/ as <tag>_*:  bash tools/keep_round.sh r03 r03
 set -eu
 SRC=gpurun_out/${1:?source dir under gpurun_out}; TAG=${2:?tag}
 cd "$(dirname "$0")/.."
-cp $SRC/bench.json profiles/${TAG}_bench.json
-cp $SRC/step/bench_kernel_stats.txt profiles/${TAG}_bench_kernel_stats.txt
-cp $SRC/step/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
-cp $SRC/msm_fixed.jsonl profiles/${TAG}_msm_fixed_base.jsonl
-cp $SRC/msm_fixed_kernels.txt profiles/${TAG}_msm_fixed_base_kernels.txt
-cp $SRC/rw_matrix.txt profiles/${TAG}_rw_matrix.txt
-[ -f $SRC/r1cs.txt ] && cp $SRC/r1cs.txt profiles/${TAG}_spartan_outer.txt
-[ -f $SRC/read_raf.txt ] && cp $SRC/read_raf.txt profiles/${TAG}_read_raf.txt
-cp $SRC/bind_roofline_bench.json profiles/${TAG}_bind_roofline_bench.json
-cp $SRC/bind_roofline_kernel_stats.txt profiles/${TAG}_bind_roofline_kernel_stats.txt
-cp $SRC/bind_traffic.json profiles/bind_traffic.json
-cp $SRC/pmc_round_kernels.txt profiles/${TAG}_pmc_round_kernels.txt
-[ -f $SRC/pytest_gpu.txt ] && cp $SRC/pytest_gpu.txt profiles/${TAG}_pytest_gpu.txt
+keep() { [ -f "$SRC/$1" ] && cp "$SRC/$1" "profiles/${TAG}_$2" || echo "missing $1"; }
+keep bench.json bench.json
+keep bench_stages_2-6b.json bench_stages_2-6b.json
+keep bench_nomsm_22.json bench_nomsm_T22.json
+keep bench_nomsm_20.json bench_nomsm_T20.json
+keep step/bench_kernel_stats.txt bench_kernel_stats.txt
+keep step/bench_under_rocprof.json bench_under_rocprof.json
+keep seq_kernel_sums.txt step_kernel_sums_one_lane.txt
+keep msm_fixed.jsonl msm_fixed_base.jsonl
+keep msm_fixed_kernels.txt msm_fixed_base_kernels.txt
+keep extended_parts.txt extended_stage_parts.txt
+keep sumcheck/stage_times_22.txt sumcheck_stage_times_T22.txt
+keep sumcheck/sumcheck_kernel_stats_22.txt sumcheck_kernel_stats_T22.txt
+keep bench_gpus2_share_gpu.json bench_gpus2_share_gpu.json
+keep subtree_scale.txt subtree_scale_check.txt
+keep bind_roofline_bench.json bind_roofline_bench.json
+keep bind_roofline_kernel_stats.txt bind_roofline_kernel_stats.txt
+keep pmc_round_kernels.txt pmc_round_kernels.txt
+keep pytest_gpu.txt pytest_gpu.txt
+keep build_force.txt build_force.txt
+[ -f "$SRC/bind_traffic.json" ] && cp "$SRC/bind_traffic.json" profiles/bind_traffic.json
 ls profiles | grep "^${TAG}_"
