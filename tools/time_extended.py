@@ -32,7 +32,7 @@ def main():
             if phase:
                 t0 = time.perf_counter(); rr.condense(u, v_tables[-1], suffix_len + 8); lap("condense", t0)
             t0 = time.perf_counter(); raf, suf = rr.phase_scan(u, suffix_len, S.ADDRESS_BITS, lk["lists"]); lap("scan", t0)
-            t0 = time.perf_counter(); tr.append(raf.reshape(-1, 4)); tr.append(suf.reshape(-1, 4)); lap("append", t0)
+            t0 = time.perf_counter(); tr.append(raf[:, 0]); tr.append(suf[:, 0]); lap("append", t0)
             t0 = time.perf_counter(); v_tables.append(ffi.host_eq_evals(np.stack([tr.challenge() for _ in range(8)]))); lap("challenges", t0)
         u.free()
         vt = np.stack(v_tables)
