@@ -319,6 +319,9 @@ extern "C" int32_t jolt_host_hyperkzg_commit(jolt_ctx* ctx, const jolt_srs* srs,
 // built over it (51 GB for 2^26 points, whatever the world size) serve all of them; the rank's scalars are gathered into one
 // compact buffer first (32 B read + written per owned term).
 int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n, const TermMap& map, Fr* dst);
+namespace {
+int32_t gather_with_status(jolt_ctx* ctx, jolt_gather_fn gather, void* user, int32_t local_status, const jolt_fr_t* payload, size_t count, int world, std::vector<jolt_fr_t>* all);
+}
 static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::vector<const Fr*>& ptrs, const std::vector<size_t>& lens, int rank, int world,
                                 size_t block, jolt_gather_fn gather, void* user, G1Jac* out) {
     const size_t count = ptrs.size();
@@ -327,26 +330,27 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
     std::vector<const Fr*> p(count);
     std::vector<size_t> n(count), off(count);
     std::vector<G1Jac> partial(count), all((size_t)world * count);
+    int32_t ls = JOLT_OK;  // this rank's local status (see gather_with_status)
     if (block) {
         TermMap map;
-        if (!make_block_map(block, rank, world, &map)) return JOLT_ERR_INVALID_ARG;
+        if (!make_block_map(block, rank, world, &map)) return JOLT_ERR_INVALID_ARG;  // the same arguments on every rank: all of them return here
         size_t total = 0;
         for (size_t i = 0; i < count; ++i) {
             n[i] = term_owned(map, lens[i]);
-            if (n[i] > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+            if (n[i] > srs->n && ls == JOLT_OK) ls = JOLT_ERR_SRS_TOO_SMALL;  // a rank-local condition (its compact SRS): reported through the exchange
             off[i] = total;
             total += n[i];
         }
         Fr* compact = nullptr;
-        JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(total, 1) * sizeof(Fr), (void**)&compact));
-        int32_t s = JOLT_OK;
+        int32_t s = ls;
+        if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, std::max<size_t>(total, 1) * sizeof(Fr), (void**)&compact);
         for (size_t i = 0; i < count && s == JOLT_OK; ++i) {
             s = jolt_internal_gather_owned_terms(ctx, ptrs[i], lens[i], map, compact + off[i]);
             p[i] = compact + off[i];
         }
         if (s == JOLT_OK) s = jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data());  // every MSM multiplies a prefix of the compact SRS
-        jolt_internal_dev_free(ctx, compact);
-        JOLT_TRY(s);
+        if (compact) jolt_internal_dev_free(ctx, compact);
+        ls = s;
     } else {
         for (size_t i = 0; i < count; ++i) {
             const size_t lo = lens[i] * (size_t)rank / (size_t)world, hi = lens[i] * (size_t)(rank + 1) / (size_t)world;
@@ -354,11 +358,13 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
             n[i] = hi - lo;
             off[i] = lo;
         }
-        JOLT_TRY(jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data(), off.data()));
+        ls = jolt_internal_msm_many(ctx, srs, p.data(), n.data(), count, partial.data(), off.data());
     }
     static_assert(sizeof(G1Jac) == 3 * sizeof(jolt_fr_t), "a Jacobian point travels as three 32-byte words");
-    ctx->d_round_count = 0;  // these words are not the round sums of the context's last batch round (jolt_comm_gather_round_sums' shortcut)
-    JOLT_TRY(gather(user, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, reinterpret_cast<jolt_fr_t*>(all.data())));
+    // the partial points travel with this rank's status: a rank whose MSMs failed still enters the exchange and every rank returns its error
+    std::vector<jolt_fr_t> raw;
+    JOLT_TRY(gather_with_status(ctx, gather, user, ls, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, world, &raw));
+    std::memcpy(all.data(), raw.data(), raw.size() * sizeof(jolt_fr_t));
     for (size_t i = 0; i < count; ++i) {
         G1Jac acc = all[i];
         for (int r = 1; r < world; ++r) acc = g1_add(acc, all[(size_t)r * count + i]);
@@ -444,17 +450,39 @@ int32_t write_slot(jolt_ctx* ctx, Fr* dst, const Fr& v) {  // pageable source: t
     JOLT_HIP_TRY(ctx, hipMemcpyAsync(dst, &v, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     return JOLT_OK;
 }
-int32_t gather_words(jolt_ctx* ctx, jolt_gather_fn gather, void* user, const std::vector<Fr>& local, int world, std::vector<Fr>* all) {
-    all->assign(local.size() * (size_t)world, Fr::zero());
+// Every exchange of the sharded opening carries the sender's status in one extra 32-byte word.  A rank whose LOCAL work failed (an allocation, a
+// launch) still takes part in the next exchange -- with a zero payload -- and every rank leaves with the first failing rank's status, instead of
+// the healthy ranks blocking in a collective the failing rank never enters (the shared-memory exchange would time out, RCCL would hang).
+int32_t gather_with_status(jolt_ctx* ctx, jolt_gather_fn gather, void* user, int32_t local_status, const jolt_fr_t* payload, size_t count, int world, std::vector<jolt_fr_t>* all) {
+    std::vector<jolt_fr_t> send(count + 1), recv((count + 1) * (size_t)world);
+    std::memset(send.data(), 0, send.size() * sizeof(jolt_fr_t));
+    send[0].l[0] = (uint64_t)(uint32_t)local_status;
+    if (local_status == JOLT_OK && count) std::memcpy(&send[1], payload, count * sizeof(jolt_fr_t));
     ctx->d_round_count = 0;  // these words are not the round sums of the context's last batch round (jolt_comm_gather_round_sums' shortcut)
-    return gather(user, reinterpret_cast<const jolt_fr_t*>(local.data()), local.size(), reinterpret_cast<jolt_fr_t*>(all->data()));
+    const int32_t gs = gather(user, send.data(), count + 1, recv.data());
+    if (gs != JOLT_OK) return gs;  // the collective itself failed: nothing left to agree on
+    all->resize(count * (size_t)world);
+    int32_t first = JOLT_OK;
+    for (int r = 0; r < world; ++r) {
+        const int32_t st = (int32_t)(uint32_t)recv[(size_t)r * (count + 1)].l[0];
+        if (st != JOLT_OK && first == JOLT_OK) first = st;
+        if (count) std::memcpy(all->data() + (size_t)r * count, &recv[(size_t)r * (count + 1) + 1], count * sizeof(jolt_fr_t));
+    }
+    return local_status != JOLT_OK ? local_status : first;
+}
+int32_t gather_words(jolt_ctx* ctx, jolt_gather_fn gather, void* user, int32_t local_status, const std::vector<Fr>& local, int world, std::vector<Fr>* all) {
+    std::vector<jolt_fr_t> raw;
+    JOLT_TRY(gather_with_status(ctx, gather, user, local_status, reinterpret_cast<const jolt_fr_t*>(local.data()), local.size(), world, &raw));
+    all->resize(raw.size());
+    if (!raw.empty()) std::memcpy(all->data(), raw.data(), raw.size() * sizeof(jolt_fr_t));
+    return JOLT_OK;
 }
 // partial points of `count` MSMs -> the sums over the ranks, in rank order on every rank
-int32_t gather_points(jolt_ctx* ctx, jolt_gather_fn gather, void* user, const std::vector<G1Jac>& partial, int world, G1Jac* out) {
+int32_t gather_points(jolt_ctx* ctx, jolt_gather_fn gather, void* user, int32_t local_status, const std::vector<G1Jac>& partial, int world, G1Jac* out) {
     const size_t count = partial.size();
-    std::vector<G1Jac> all((size_t)world * count);
-    ctx->d_round_count = 0;
-    JOLT_TRY(gather(user, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, reinterpret_cast<jolt_fr_t*>(all.data())));
+    std::vector<jolt_fr_t> raw;
+    JOLT_TRY(gather_with_status(ctx, gather, user, local_status, reinterpret_cast<const jolt_fr_t*>(partial.data()), 3 * count, world, &raw));
+    const G1Jac* all = reinterpret_cast<const G1Jac*>(raw.data());
     for (size_t i = 0; i < count; ++i) {
         G1Jac acc = all[i];
         for (int r = 1; r < world; ++r) acc = g1_add(acc, all[(size_t)r * count + i]);
@@ -490,16 +518,19 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
         if (b_poly) jolt_table_free(ctx, b_poly);
         for (jolt_table* t : h) if (t) jolt_table_free(ctx, t);
     };
-#define SUB_TRY(expr) do { int32_t s_ = (expr); if (s_ != JOLT_OK) { cleanup(); return s_; } } while (0)
+    // local work: SUB_TRY records the first failure and skips what follows; the next exchange (gather_* with the status word) makes every rank leave together
+    int32_t ls = JOLT_OK;
+#define SUB_TRY(expr) do { if (ls == JOLT_OK) ls = (expr); } while (0)
+#define SUB_EXCHANGE(expr) do { const int32_t s_ = (expr); if (s_ != JOLT_OK) { cleanup(); return s_; } } while (0)
     // phase 1a: the local folds -- fold i uses point[ell - i]; the compact arrays of levels 0 .. lam-1 have >= 2 slots
     SUB_TRY(jolt_hyperkzg_fold(ctx, evals, point + gamma, lam, polys.data()));
     // phase 1b: every rank publishes slot 1 of each of those levels (its subtree's root, index G + g) and slot 0 of level 0; the
     // crowns (indices below G) of all levels follow from these on every rank
     std::vector<Fr> local(lam + 1), all;
-    for (size_t k = 0; k < lam; ++k) SUB_TRY(read_slot(ctx, polys[k], 1, &local[k]));
-    SUB_TRY(read_slot(ctx, polys[0], 0, &local[lam]));
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
-    SUB_TRY(gather_words(ctx, gather, user, local, world, &all));
+    for (size_t k = 0; k < lam && ls == JOLT_OK; ++k) ls = read_slot(ctx, polys[k], 1, &local[k]);
+    if (ls == JOLT_OK) ls = read_slot(ctx, polys[0], 0, &local[lam]);
+    if (ls == JOLT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) ls = JOLT_ERR_HIP;
+    SUB_EXCHANGE(gather_words(ctx, gather, user, ls, local, world, &all));
     std::vector<std::vector<Fr>> crowns(ell);
     crowns[0].resize(G);
     for (size_t g = 0; g < G; ++g) crowns[0][g] = all[g * (lam + 1) + lam];
@@ -511,13 +542,13 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
         crowns[k].resize(prev.size() / 2);
         for (size_t y = 0; y < crowns[k].size(); ++y) crowns[k][y] = add(prev[2 * y], mul(xk, sub(prev[2 * y + 1], prev[2 * y])));
     }
-    for (size_t k = 1; k < ell; ++k) {
+    for (size_t k = 1; k < ell && ls == JOLT_OK; ++k) {
         if (k < lam) {
-            SUB_TRY(write_slot(ctx, polys[k]->data(), crowns[k][(size_t)rank]));
+            ls = write_slot(ctx, polys[k]->data(), crowns[k][(size_t)rank]);
         } else {  // levels of at most G coefficients: the crown alone
             const size_t len = (size_t)rank < crowns[k].size() ? 1 : 0;
-            SUB_TRY(jolt_internal_table_new(ctx, len, &polys[k]));
-            if (len) SUB_TRY(write_slot(ctx, polys[k]->data(), crowns[k][(size_t)rank]));
+            ls = jolt_internal_table_new(ctx, len, &polys[k]);
+            if (ls == JOLT_OK && len) ls = write_slot(ctx, polys[k]->data(), crowns[k][(size_t)rank]);
         }
     }
     // phase 1c: level commitments over the compact SRS (every level is a prefix of it)
@@ -525,10 +556,12 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
     if (ell > 1) {
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
-        for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
         std::vector<G1Jac> partial(ell - 1);
-        SUB_TRY(jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), ell - 1, partial.data()));
-        SUB_TRY(gather_points(ctx, gather, user, partial, world, coms.data()));
+        if (ls == JOLT_OK) {
+            for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+            ls = jolt_internal_msm_many(ctx, srs, ptrs.data(), lens.data(), ell - 1, partial.data());
+        }
+        SUB_EXCHANGE(gather_points(ctx, gather, user, ls, partial, world, coms.data()));
     }
     for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
     const Fr r = tr.challenge();
@@ -548,8 +581,8 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
         SUB_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
         Fr* chunk_weights = nullptr;
         SUB_TRY(jolt_internal_dev_alloc(ctx, 3 * kBlock * sizeof(Fr), (void**)&chunk_weights));
-        hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
-        int32_t es = JOLT_OK;
+        if (ls == JOLT_OK) hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
+        int32_t es = ls;
         for (size_t j = 0; j < lam && es == JOLT_OK; ++j) {
             const jolt_table* t = polys[j];
             const size_t per_block = (size_t)kBlock * kHornerChunk;
@@ -560,12 +593,12 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * j);
             if (hipGetLastError() != hipSuccess) es = JOLT_ERR_HIP;
         }
-        jolt_internal_dev_free(ctx, chunk_weights);  // stream-ordered
+        if (chunk_weights) jolt_internal_dev_free(ctx, chunk_weights);  // stream-ordered
         SUB_TRY(es);
-        std::vector<Fr> part(3 * lam);
-        if (hipMemcpyAsync(part.data(), ctx->d_results, 3 * lam * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
-        SUB_TRY(gather_words(ctx, gather, user, part, world, &all));
+        std::vector<Fr> part(3 * lam, Fr::zero());
+        if (ls == JOLT_OK && (hipMemcpyAsync(part.data(), ctx->d_results, 3 * lam * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                              hipStreamSynchronize(ctx->stream) != hipSuccess)) ls = JOLT_ERR_HIP;
+        SUB_EXCHANGE(gather_words(ctx, gather, user, ls, part, world, &all));
         for (size_t j = 0; j < lam; ++j)
             for (int t = 0; t < 3; ++t) {
                 Fr acc = Fr::zero();
@@ -602,8 +635,8 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
         SUB_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
         Fr* chunk_weights = nullptr;
         SUB_TRY(jolt_internal_dev_alloc(ctx, 3 * kBlock * sizeof(Fr), (void**)&chunk_weights));
-        hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
-        int32_t es = JOLT_OK;
+        if (ls == JOLT_OK) hipLaunchKernelGGL(k_power_table3, dim3(1), dim3(kBlock), 0, ctx->stream, u16, chunk_weights);
+        int32_t es = ls;
         for (size_t L = 0; L < lam && es == JOLT_OK; ++L) {  // segment L = slots [2^L, 2^(L+1)): a plain Horner sum from its first slot
             const size_t len = (size_t)1 << L, per_block = (size_t)kBlock * kHornerChunk;
             const int grid = (int)std::max<size_t>(1, (len + per_block - 1) / per_block);
@@ -614,13 +647,13 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, grid, 3, ctx->d_results + 3 * L);
             if (hipGetLastError() != hipSuccess) es = JOLT_ERR_HIP;
         }
-        jolt_internal_dev_free(ctx, chunk_weights);
+        if (chunk_weights) jolt_internal_dev_free(ctx, chunk_weights);
         SUB_TRY(es);
-        std::vector<Fr> sums(3 * lam + 1);
-        if (hipMemcpyAsync(sums.data(), ctx->d_results, 3 * lam * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+        std::vector<Fr> sums(3 * lam + 1, Fr::zero());
+        if (ls == JOLT_OK && hipMemcpyAsync(sums.data(), ctx->d_results, 3 * lam * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ls = JOLT_ERR_HIP;
         SUB_TRY(read_slot(ctx, b_poly, 0, &sums[3 * lam]));
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
-        SUB_TRY(gather_words(ctx, gather, user, sums, world, &all));
+        if (ls == JOLT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) ls = JOLT_ERR_HIP;
+        SUB_EXCHANGE(gather_words(ctx, gather, user, ls, sums, world, &all));
         const size_t stride = 3 * lam + 1;
         const size_t n_h = ((size_t)1 << lam) - ((size_t)rank + 1 == G ? 1 : 0);  // the quotient has 2^ell - 1 coefficients: the owner of the last index holds one less
         std::vector<Fr> carries[3];  // kept until the MSMs below have synchronised: sources of small host-to-device copies
@@ -641,6 +674,7 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
                 e = add(all[g * stride + 3 * lam], mul(u[t], e));
             }
             SUB_TRY(jolt_internal_table_new(ctx, (size_t)1 << lam, &h[t]));
+            if (ls != JOLT_OK) break;
             Fr* hd = h[t]->data();
             SUB_TRY(write_slot(ctx, hd, carry[lam]));  // h[g] = s[g + 1] = E(g + 1)
             for (size_t L = 0; L < lam; ++L) {
@@ -650,17 +684,20 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
             }
             h[t]->len = n_h;
         }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return JOLT_ERR_HIP; }
+        if (ls == JOLT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) ls = JOLT_ERR_HIP;
     }
     G1Jac ws[3];
     {
-        const Fr* ptrs[3] = {h[0]->data(), h[1]->data(), h[2]->data()};
-        const size_t lens[3] = {h[0]->len, h[1]->len, h[2]->len};
         std::vector<G1Jac> partial(3);
-        SUB_TRY(jolt_internal_msm_many(ctx, srs, ptrs, lens, 3, partial.data()));
-        SUB_TRY(gather_points(ctx, gather, user, partial, world, ws));
+        if (ls == JOLT_OK) {
+            const Fr* ptrs[3] = {h[0]->data(), h[1]->data(), h[2]->data()};
+            const size_t lens[3] = {h[0]->len, h[1]->len, h[2]->len};
+            ls = jolt_internal_msm_many(ctx, srs, ptrs, lens, 3, partial.data());
+        }
+        SUB_EXCHANGE(gather_points(ctx, gather, user, ls, partial, world, ws));
     }
 #undef SUB_TRY
+#undef SUB_EXCHANGE
     for (int t = 0; t < 3; ++t) append_g1(tr, ws[t]);  // kzg.rs:118-124
     const Fr d0 = tr.challenge();
     for (size_t i = 0; i + 1 < ell; ++i) std::memcpy(&com[i], &coms[i], sizeof(G1Jac));

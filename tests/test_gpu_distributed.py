@@ -227,6 +227,52 @@ def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local, 
             assert all(O.g1_eq(a, b) for a, b in zip(g[key], g0[key]))
 
 
+def _failing_rank_worker(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
+    from jolt_amd import distributed as D
+    from jolt_amd import ffi
+    ctx = ffi.Context(0)
+    coll = D.Collective(dist, world, None)
+    rng = np.random.default_rng(79)
+    n_local = 4
+    T = world << n_local
+    ins = rng.integers(0, 16, size=(3, T), dtype=np.uint8)
+    dense = [rng.integers(0, 2**64, size=T, dtype=np.uint64)]
+    gp, gfn, guser = D.make_point_gather(coll, world)
+    pcs = D.ShardedPcs(ctx, rank, world, n_local, [ins], dense, gp, gfn, guser, seed=5, fixed_base=False, block_cyclic=True, subtree=False)
+    if rank == 1:  # this rank's compact SRS is too short for its share of the terms: a LOCAL failure inside the opening's first sharded MSM
+        short = pcs.srs.download(0, len(pcs.srs) // 2)
+        pcs.srs = ctx.srs_upload(short)
+    outcome = "returned"
+    try:
+        pcs.open(label=3)
+    except ffi.JoltError as e:
+        outcome = f"JoltError {e.status}"
+    with open(f"{out_path}.{rank}", "w") as f:
+        f.write(outcome)
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_a_local_failure_in_the_sharded_opening_reaches_every_rank():
+    """One rank fails inside the opening (its SRS is too short); the status word every exchange carries makes BOTH ranks return that error instead of
+    the healthy rank blocking in the collective (which the shared-memory exchange would time out of and RCCL would hang in)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import test_gpu_distributed as t, torch.multiprocessing as mp; "
+            "mp.spawn(t._failing_rank_worker, args=(2, %d, %r), nprocs=2, join=True)")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "outcome")
+        try:
+            r = subprocess.run([sys.executable, "-c", code % (HERE, free_port(), out)], capture_output=True, text=True, timeout=180)
+        except subprocess.TimeoutExpired:
+            pytest.fail("the healthy rank hung in a collective the failing rank never entered")
+        outcomes = [open(f"{out}.{k}").read() if os.path.exists(f"{out}.{k}") else f"no outcome (rc {r.returncode}): {r.stderr[-400:]}" for k in range(2)]
+    assert outcomes == ["JoltError 9", "JoltError 9"], outcomes  # JOLT_ERR_SRS_TOO_SMALL on both
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world):
     """`python bench.py --gpus N` with NO launcher around it (the driver's bare command shape): the script re-executes itself under
