@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 # a forced rebuild of both libraries ON THIS BOX: what __graft_entry__.build() does when the objects are stale (the snapshot ships them prebuilt)
-( /usr/bin/time -v python -m jolt_amd.build --force > "$OUT/build_force.txt" 2>&1; (cd oracle && make -B >> "$OUT/build_force.txt" 2>&1); grep -E "Elapsed|libjolt_hip|Error" "$OUT/build_force.txt" | tail -3 )
+( { time python -m jolt_amd.build --force; } > "$OUT/build_force.txt" 2>&1; { time make -C oracle -B; } >> "$OUT/build_force.txt" 2>&1; grep -E "^real|libjolt_hip.so|rror" "$OUT/build_force.txt" | tail -4 )
 if [ "${2:-}" != "notests" ]; then
   timeout 1800 python -m pytest tests -q -m gpu --durations=12 > "$OUT/pytest_gpu.txt" 2>&1
   tail -3 "$OUT/pytest_gpu.txt"

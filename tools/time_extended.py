@@ -45,7 +45,7 @@ def main():
         member.destroy()
         print({k: round(v, 2) for k, v in acc.items()}, flush=True)
     for name, fn in (("spartan_outer", lambda: e.spartan(e.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"], e.claims["outer"], 2, 7)),
-                     ("ram", lambda: e.ram_read_write(8))):
+                     ("ram", lambda: e.ram_read_write(8)), ("registers", lambda: e.registers_read_write(9)), ("booleanity_address", lambda: e.booleanity_address(10))):
         fn(); ctx.synchronize(); t0 = time.perf_counter(); fn(); ctx.synchronize()
         print(name, round((time.perf_counter() - t0) * 1e3, 2), "ms")
 
