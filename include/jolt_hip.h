@@ -604,6 +604,25 @@ int32_t jolt_registers_rw_download(jolt_rw_matrix *m, uint64_t *rows, uint64_t *
 int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix *m, const jolt_fr_t *bind, jolt_fr_t *evals_out /* 2 */, jolt_fr_t *aux_out /* 3 or NULL */);
 int32_t jolt_rw_matrix_finish(jolt_rw_matrix *m, const jolt_fr_t *bind);
 int32_t jolt_rw_matrix_final_values(jolt_rw_matrix *m, jolt_fr_t *out /* 4 */);
+
+/* Pushforwards of cycle weights onto a LARGE address domain (bytecode PCs, RAM words; K up to 2^24): the T-scale half of the joint-domain
+ * relations whose rounds run over K-sized tables.  Replaces stage_pushforwards of the bytecode read+RAF address phase
+ * (crates/jolt-kernels/src/optimized/bytecode_read_raf.rs:152-237: F_s(k) = sum_{j: pc(j) = k} eq(r_cycle_s, j) for the five stages in one
+ * trace walk) and RamAccessColumns::fold_cycles (optimized/ram_trace.rs:150-162, used by optimized/ram_raf_evaluation.rs:44-48).
+ *   jolt_key_index_create: sorts the rows of a resident key column (JOLT_INT_U64, one key per cycle; a key >= K is a cold cycle and
+ *     contributes nothing: NO_ACCESS, unmapped PCs) by key, once per trace column -- the reference shares the same scan through its
+ *     ProofSession (PcRow::shared :92-150, RamAccessColumns::shared).
+ *   jolt_key_index_pushforward: out[s][k] = sum_{j: key(j) = k} weights[s][j] for n_weights <= 8 tables of `cycles` entries at once; new
+ *     tables of K entries (the caller frees them).
+ *   jolt_key_index_last_value: out[k] = values[latest cycle with key k] as a field element, init[k] for a key that never occurs: the final
+ *     state of a memory that is only ever overwritten (the ram_val_final column of the RAM output check, optimized/ram_output_check.rs:91). */
+typedef struct jolt_key_index jolt_key_index;
+int32_t jolt_key_index_create(jolt_ctx *ctx, const jolt_ints *keys, uint64_t k, jolt_key_index **out);
+int32_t jolt_key_index_size(const jolt_key_index *index, size_t *cycles, uint64_t *k, uint32_t *items);
+int32_t jolt_key_index_pushforward(jolt_ctx *ctx, const jolt_key_index *index, jolt_table *const *weights, size_t n_weights, jolt_table **out);
+int32_t jolt_key_index_last_value(jolt_ctx *ctx, const jolt_key_index *index, const jolt_ints *values, const jolt_table *init, jolt_table **out);
+int32_t jolt_key_index_destroy(jolt_ctx *ctx, jolt_key_index *index);
+
 int32_t jolt_rw_matrix_len(const jolt_rw_matrix *m, size_t *entries);
 int32_t jolt_rw_matrix_download(jolt_rw_matrix *m, uint64_t *rows, uint64_t *cols, jolt_fr_t *val, jolt_fr_t *ra, jolt_fr_t *prev, jolt_fr_t *next);
 int32_t jolt_rw_matrix_destroy(jolt_rw_matrix *m);

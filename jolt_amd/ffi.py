@@ -1077,6 +1077,50 @@ class RwMatrix:
 Context.rw_matrix = lambda self, *a, **k: RwMatrix(self, *a, **k)
 
 
+class KeyIndex:
+    """Rows of a resident key column (u64 Ints: bytecode PCs, RAM word addresses; a key >= k is a cold cycle) sorted by key once, for pushforwards
+    of cycle weights onto the k-entry address domain (jolt_key_index_*)."""
+
+    def __init__(self, ctx, keys, k):
+        self.ctx, self.k = ctx, int(k)
+        h = C.c_void_p()
+        _ck(lib().jolt_key_index_create(ctx.h, keys.h, C.c_uint64(self.k), C.byref(h)), "jolt_key_index_create", ctx)
+        self.h = h
+
+    def size(self):
+        cycles, k, items = C.c_size_t(), C.c_uint64(), C.c_uint32()
+        _ck(lib().jolt_key_index_size(self.h, C.byref(cycles), C.byref(k), C.byref(items)), "jolt_key_index_size", self.ctx)
+        return cycles.value, k.value, items.value
+
+    def pushforward(self, weights):
+        """weights: list of <= 8 Tables over the cycles -> list of Tables of k entries, out[s][a] = sum of weights[s] over the cycles with key a"""
+        n = len(weights)
+        hs = (C.c_void_p * n)(*[w.h for w in weights])
+        out = (C.c_void_p * n)()
+        _ck(lib().jolt_key_index_pushforward(self.ctx.h, self.h, hs, C.c_size_t(n), out), "jolt_key_index_pushforward", self.ctx)
+        return [Table(self.ctx, C.c_void_p(out[i])) for i in range(n)]
+
+    def last_value(self, values, init):
+        """values: u64 Ints over the cycles; init: Table of k entries -> Table: the value at the latest cycle of every key, init where a key never occurs"""
+        h = C.c_void_p()
+        _ck(lib().jolt_key_index_last_value(self.ctx.h, self.h, values.h, init.h, C.byref(h)), "jolt_key_index_last_value", self.ctx)
+        return Table(self.ctx, h)
+
+    def free(self):
+        if self.h:
+            lib().jolt_key_index_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+Context.key_index = lambda self, keys, k: KeyIndex(self, keys, k)
+
+
 class RegistersRw:
     """Device twin of the optimized registers read/write-checking kernel (jolt_registers_rw_*): `regs` a OneHot with the columns rs1, rs2, rd,
     the value columns u64 Ints, `inc` the RdInc table."""

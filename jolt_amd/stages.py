@@ -17,6 +17,15 @@ stage drivers drive them, over synthetic trace-shaped inputs:
                                      log K rounds over K-entry tables with the squared-weight bind on the host, where the reference keeps them
                                      (optimized/booleanity.rs:152-427)
 
+  stage 2   RAM RAF evaluation       ra_folded(k) = sum_{j: address(j) = k} eq(tau_low, j) over the K RAM words (T-scale, device: a key index over the address
+                                     column), then the log K rounds of ra_folded * unmap over K-sized tables  (optimized/ram_raf_evaluation.rs)
+  stage 2   RAM output check         val_final(k) = the word of the last access to k (T-scale), then the log K rounds of eq(r_address) * io_mask * (val_final - val_io)
+                                     (optimized/ram_output_check.rs)
+  stage 6a  bytecode read+RAF, addr  the five per-stage pushforwards F_s(k) = sum_{j: pc(j) = k} eq(r_cycle_s, j) onto the bytecode domain in one pass over the
+                                     PC index (T-scale), then log K rounds over 13 K-sized tables  (optimized/bytecode_read_raf.rs:152-437)
+  stage 6b  bytecode read+RAF, cycle ra_i(j) = eq(chunk_i)[chunk_i(pc_j)] and the combined coefficient column C(j) (T-scale), log T rounds of C * prod ra_i
+                                     (optimized/bytecode_read_raf.rs:440-690)
+
 `build_extended` is a pure description (numpy); `DeviceExtended` holds the resident inputs in HBM and proves; tests/workload_oracle.py
 instantiates the same description on the CPU oracle.  Every operator absorbs what it sends into a transcript and takes its challenges
 from it (the deterministic test transcript, jolt_host_transcript_* / jolt_host_prove_batch), so two runs agree message for message.
@@ -104,7 +113,7 @@ def suffix_lists(n_tables, rng):
     return lists
 
 
-def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_count=4, log_k=None):
+def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_count=4, log_k=None, log_kb=None):
     rng = np.random.default_rng(seed + 500)
     T = 1 << n_vars
     d = {"n_vars": n_vars}
@@ -156,7 +165,135 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_cou
     for p in range(max(1, n_ra // 12)):
         cols[n_ra - 1 - p, rng.random(T) < 0.4] = 0xFF
     d["booleanity"] = dict(cols=cols, log_k=log_kc, reference_cycle=rand_fr(n_vars, rng), reference_address=rand_fr(log_kc, rng), gamma=rand_fr(1, rng)[0])
+    # ---- stage 2: RAM RAF evaluation and output check over the RAM trace above (tau_low; the IO region = words [K/4, K/4 + max(1, K/16)) with public words)
+    ram = d["ram"]
+    K_ram = 1 << ram["log_k"]
+    io_lo, io_len = K_ram // 4, max(1, K_ram // 16)
+    val_io = np.zeros(K_ram, dtype=np.uint64)
+    val_io[io_lo:io_lo + io_len] = rng.integers(0, 2**63, size=io_len, dtype=np.uint64)
+    d["ram_raf"] = dict(tau_low=rand_fr(n_vars, rng), lowest_address=np.uint64(0x80000000))
+    d["ram_output"] = dict(point=rand_fr(ram["log_k"], rng), io_lo=io_lo, io_len=io_len, val_io=val_io)
+    # ---- stage 6a / 6b: bytecode read + RAF.  A program-shaped PC column: the trace runs loops of 16 .. 512 instructions (a loop body holds most of the cycles),
+    # a tail of unmapped padding cycles (push_pc 0 in the address phase, cold in the cycle phase), five stage points and per-stage value tables
+    log_kb = log_kb if log_kb is not None else min(12, max(2, n_vars))
+    Kb, pcs, j = 1 << log_kb, np.zeros(T, dtype=np.uint64), 0
+    while j < T:
+        body = int(rng.integers(min(16, Kb), min(512, Kb) + 1))
+        start = int(rng.integers(0, Kb - body + 1))
+        run = min(T - j, body * int(rng.integers(1, 200)))
+        pcs[j:j + run] = start + (np.arange(run) % body)
+        j += run
+    mapped = rng.random(T) >= 0.01
+    mapped[T - T // 32:] = False
+    mapped[0] = True
+    chunk_bits = 4
+    n_chunks = (log_kb + chunk_bits - 1) // chunk_bits
+    chunk_cols = np.stack([np.where(mapped, (pcs >> np.uint64((n_chunks - 1 - i) * chunk_bits)) & np.uint64(15), 0xFF).astype(np.uint8) for i in range(n_chunks)])
+    d["bytecode"] = dict(log_k=log_kb, push_pc=np.where(mapped, pcs, 0).astype(np.uint64), mapped=mapped, chunk_bits=chunk_bits, chunk_cols=chunk_cols,
+                         stage_points=np.stack([rand_fr(n_vars, rng) for _ in range(5)]) if n_vars else np.zeros((5, 0, 4), dtype=np.uint64),
+                         stage_values=rand_fr(5 * Kb, rng).reshape(5, Kb, 4), gamma=rand_fr(1, rng)[0], entry_index=int(rng.integers(0, Kb)))
     return d
+
+
+def committed_address_chunks(r_address, chunk_bits):
+    """geometry::dimensions::committed_address_chunks (crates/jolt-claims/src/protocols/jolt/geometry/dimensions.rs:350-366): the big-endian address point, zero-padded
+    at the FRONT to a multiple of chunk_bits, cut into chunk points"""
+    r = np.asarray(r_address, dtype=np.uint64).reshape(-1, 4)
+    pad = (-r.shape[0]) % chunk_bits
+    padded = np.concatenate([np.zeros((pad, 4), dtype=np.uint64), r])
+    return [padded[i:i + chunk_bits] for i in range(0, padded.shape[0], chunk_bits)]
+
+
+def bytecode_read_raf(ops, bc, n_vars, label):
+    """Stage 6a then 6b of the bytecode read+RAF check over the adapter `ops` (the device or the oracle): AddressKernel (optimized/bytecode_read_raf.rs:238-437) as the
+    reference tier's dense member over the 13 address tables -- the optimized kernel's fused group_evals (:371-392) is field-identical to it, which is its own parity
+    statement -- and CycleKernel (:440-690) as C(j) * prod_i ra_i(j)."""
+    log_k, K = bc["log_k"], 1 << bc["log_k"]
+    gp = [ops.one]
+    for _ in range(7):
+        gp.append(ops.mul(gp[-1], bc["gamma"]))
+    # ---- 6a: pushforwards (T-scale) + log K rounds
+    eqs = [ops.eq(p) for p in bc["stage_points"]]
+    F = ops.pushforward("pc", eqs)
+    V = [ops.upload(bc["stage_values"][s]) for s in range(5)]
+    hot = np.zeros(K, dtype=np.uint64)
+    entry_trace, entry_expected = hot.copy(), hot.copy()
+    entry_trace[int(bc["push_pc"][0])] = 1
+    entry_expected[bc["entry_index"]] = 1
+    tables = F + V + [ops.u64_table(np.arange(K, dtype=np.uint64)), ops.u64_table(entry_trace), ops.u64_table(entry_expected)]
+    terms = [(gp[s], [s, 5 + s]) for s in range(5)] + [(gp[5], [0, 10]), (gp[6], [2, 10]), (gp[7], [11, 12])]  # stage_weights * raf_weights: g^0 g^5, g^2 g^4 (:303-311)
+    member = ops.member_expr(tables, terms, 2)
+    claim_a = member.input_claim()
+    adr = ops.prove(member, claim_a, log_k, 2, label)
+    fin = ops.final_values(member)  # bound F_0..4, V_0..4, Int, entry_trace, entry_expected
+    ops.destroy(member)
+    intermediate = ops.mul(gp[7], ops.mul(fin[11], fin[12]))
+    for s in range(5):
+        raf = gp[5] if s == 0 else (gp[4] if s == 2 else None)
+        val = fin[5 + s] if raf is None else ops.add(fin[5 + s], ops.mul(raf, fin[10]))
+        intermediate = ops.add(intermediate, ops.mul(gp[s], ops.mul(fin[s], val)))
+    r_address = adr["challenges"][::-1]  # LowToHigh rounds: the last challenge is the most significant address bit
+    # ---- 6b: ra columns and the combined coefficient column (T-scale) + log T rounds
+    chunks = committed_address_chunks(r_address, bc["chunk_bits"])
+    ra = [ops.materialize_chunk(i, ops.host_eq(chunks[i])) for i in range(len(chunks))]
+    int_r = fin[10]  # IdentityPolynomial(r_address): the bound Int table
+    weights = [ops.mul(gp[s], fin[5 + s]) for s in range(5)]
+    weights[0] = ops.add(weights[0], ops.mul(gp[5], int_r))
+    weights[2] = ops.add(weights[2], ops.mul(gp[6], int_r))
+    entry_scalar = ops.host_eq(r_address)[bc["entry_index"]]
+    spike = ops.eq(np.zeros((n_vars, 4), dtype=np.uint64))  # eq(0, j) = [j = 0]
+    combined = ops.rlc(eqs + [spike], weights + [ops.mul(gp[7], entry_scalar)])
+    for t in eqs + [spike]:
+        ops.free(t)
+    n_f = 1 + len(ra)
+    member = ops.member_expr([combined] + ra, [(ops.one, list(range(n_f)))], n_f)
+    claim_c = member.input_claim()
+    cyc = ops.prove(member, claim_c, n_vars, n_f, label + 1)
+    ra_claims = ops.final_values(member)[1:]
+    ops.destroy(member)
+    return dict(address=adr, claim_address=claim_a, intermediate=intermediate, val_stages=np.stack(fin[5:10]), r_address=r_address, cycle=cyc, claim_cycle=claim_c,
+                ra_claims=np.stack(ra_claims))
+
+
+def ram_raf_evaluation(ops, ram, raf, label):
+    """optimized/ram_raf_evaluation.rs:17-62: ra_folded = fold_cycles(eq(tau_low)) over the RAM address column, unmap(k) = 8 k + lowest_address, the reference tier's dense
+    member over the two K-sized tables, log K rounds"""
+    K = 1 << ram["log_k"]
+    eq = ops.eq(raf["tau_low"])
+    folded = ops.pushforward("ram", [eq])[0]
+    ops.free(eq)
+    unmap = ops.u64_table(np.uint64(8) * np.arange(K, dtype=np.uint64) + raf["lowest_address"])
+    member = ops.member_expr([folded, unmap], [(ops.one, [0, 1])], 2)
+    claim = member.input_claim()
+    out = ops.prove(member, claim, ram["log_k"], 2, label)
+    out["claim"] = claim
+    out["ra_claim"] = ops.final_values(member)[0]
+    ops.destroy(member)
+    return out
+
+
+def ram_output_check(ops, ram, io, label):
+    """optimized/ram_output_check.rs:50-215: eq(r_address, k) * io_mask(k) * (val_final(k) - val_io(k)) with the eq factor split (Gruen); val_final is the word every
+    address holds after its last access (the witness oracle's ram_val_final column, built here from the resident access columns)"""
+    K = 1 << ram["log_k"]
+    init = ops.u64_table(ram["val_init"])
+    val_final = ops.last_value("ram", init)
+    ops.free(init)
+    val_io = ops.u64_table(io["val_io"])
+    minus_one = ops.sub(np.zeros(4, dtype=np.uint64), ops.one)
+    diff = ops.rlc([val_final, val_io], [ops.one, minus_one])
+    ops.free(val_io)
+    mask = np.zeros(K, dtype=np.uint64)
+    mask[io["io_lo"]:io["io_lo"] + io["io_len"]] = 1
+    member = ops.member_gruen_product(ops.u64_table(mask), diff, io["point"])
+    claim = member.input_claim()
+    out = ops.prove(member, claim, ram["log_k"], 3, label)
+    out["claim"] = claim
+    point = out["challenges"][::-1]
+    out["val_final_claim"] = ops.evaluate(val_final, point)
+    ops.free(val_final)
+    ops.destroy(member)
+    return out
 
 
 def booleanity_address_rounds(kernel, log_k, transcript, from_evals, evaluate):
@@ -219,6 +356,62 @@ def rw_rounds(matrix_round, finish, final_values, log_t, log_k, claim, transcrip
 _sub = None  # field subtraction of the side that runs rw_rounds (set by DeviceExtended / OracleExtended: ffi.host_fr_sub / the oracle's)
 
 
+class DeviceOps:
+    """The adapter the address-domain drivers above run over on the device (tests/workload_oracle.py: OracleOps is its twin on the CPU oracle)."""
+
+    def __init__(self, ctx, ffi, indexes, chunk_source):
+        self.ctx, self.ffi, self.indexes, self.chunk_source = ctx, ffi, indexes, chunk_source
+        self.one = ffi.host_fr_from_u64(1)
+        self.mul, self.add, self.sub, self.host_eq = ffi.host_fr_mul, ffi.host_fr_add, ffi.host_fr_sub, ffi.host_eq_evals
+
+    def eq(self, point):
+        return self.ctx.eq_evals(point)
+
+    def upload(self, values):
+        return self.ctx.upload(values)
+
+    def u64_table(self, values):
+        return self.ctx.from_u64(np.ascontiguousarray(values, dtype=np.uint64))
+
+    def pushforward(self, which, tables):
+        return self.indexes[which].pushforward(tables)
+
+    def last_value(self, which, init):
+        index, post = self.indexes[which], self.indexes[which + "_post"]
+        return index.last_value(post, init)
+
+    def materialize_chunk(self, i, eq_chunk):
+        scale = self.ctx.upload(eq_chunk)
+        col = self.chunk_source.materialize(i, scale)
+        scale.free()
+        return col
+
+    def rlc(self, tables, scalars):
+        return self.ctx.rlc(tables, np.stack(scalars))
+
+    def member_expr(self, tables, terms, degree):
+        return self.ctx.member_expr(tables, terms, degree)
+
+    def member_gruen_product(self, a, b, w):
+        return self.ctx.member_split_eq_product(a, b, w)
+
+    def prove(self, member, claim, n_vars, degree, label):
+        out = self.ctx.prove_batch([member], [claim], [self.one], [0], n_vars, degree, label=label)
+        return dict(polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+
+    def final_values(self, member):
+        return list(member.final_values())
+
+    def evaluate(self, table, point):
+        return self.ctx.evaluate(table, point)
+
+    def destroy(self, member):
+        member.destroy()
+
+    def free(self, table):
+        table.free()
+
+
 class DeviceExtended:
     def __init__(self, ctx, n_vars, seed=2026, **kw):
         from . import ffi
@@ -246,6 +439,9 @@ class DeviceExtended:
         self.bool_cols = ctx.onehot(bo["cols"], 1 << bo["log_k"])
         lk = d["lookup"]
         self.read_raf = ctx.read_raf(lk["idx"], lk["table"], lk["raf"], lk["n_tables"])
+        bc = d["bytecode"]
+        self.pc_ints = ctx.ints(bc["push_pc"])  # the address phase's PC column (unmapped rows on 0) and the cycle phase's chunk columns (unmapped rows cold)
+        self.pc_chunks = ctx.onehot(bc["chunk_cols"], 1 << bc["chunk_bits"])
         # ---- input claims (in a real proof the previous stage's output claims): computed once, untimed
         self.claims = {}
         az, bz = ctx.r1cs_materialize_small(self.outer_ints, d["outer_wa"], d["outer_wb"])
@@ -382,9 +578,24 @@ class DeviceExtended:
         tr.close()
         return dict(scans=scans, v_tables=vt, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
 
+    def address_domain(self, label):
+        """the joint-domain relations whose rounds run over K-sized tables: bytecode read+RAF (6a, 6b), RAM RAF evaluation, RAM output check.  The key indexes are
+        per-proof work (the reference builds its PC rows / RamAccessColumns once per proof and shares them through the session)"""
+        ctx, d = self.ctx, self.d
+        ram, bc = d["ram"], d["bytecode"]
+        indexes = {"pc": ctx.key_index(self.pc_ints, 1 << bc["log_k"]), "ram": ctx.key_index(self.ram_cols[0], 1 << ram["log_k"]), "ram_post": self.ram_cols[2]}
+        ops = DeviceOps(ctx, self.ffi, indexes, self.pc_chunks)
+        out = {"bytecode_read_raf": bytecode_read_raf(ops, bc, self.n_vars, label),
+               "ram_raf_evaluation": ram_raf_evaluation(ops, ram, d["ram_raf"], label + 10),
+               "ram_output_check": ram_output_check(ops, ram, d["ram_output"], label + 20)}
+        indexes["pc"].free()
+        indexes["ram"].free()
+        return out
+
     def prove(self, label=0):
         d = self.d
         return {
+            **self.address_domain(label + 500),
             "spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
                                           self.claims["outer"], 2, label + 100),
             "spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"], d["product_kernel"],
@@ -396,6 +607,6 @@ class DeviceExtended:
         }
 
     def close(self):
-        for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx, self.bool_cols]:
+        for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx, self.bool_cols, self.pc_ints, self.pc_chunks]:
             c.free()
         self.read_raf.free()

@@ -280,6 +280,11 @@ extern "C" {
     pub fn jolt_rw_matrix_prove_round(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t, evals_out: *mut jolt_fr_t, aux_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_finish(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_final_values(m: *mut jolt_rw_matrix, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_key_index_create(ctx: *mut jolt_ctx, keys: *const jolt_ints, k: u64, out: *mut *mut jolt_key_index) -> i32;
+    pub fn jolt_key_index_size(index: *const jolt_key_index, cycles: *mut usize, k: *mut u64, items: *mut u32) -> i32;
+    pub fn jolt_key_index_pushforward(ctx: *mut jolt_ctx, index: *const jolt_key_index, weights: *const *mut jolt_table, n_weights: usize, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_key_index_last_value(ctx: *mut jolt_ctx, index: *const jolt_key_index, values: *const jolt_ints, init: *const jolt_table, out: *mut *mut jolt_table) -> i32;
+    pub fn jolt_key_index_destroy(ctx: *mut jolt_ctx, index: *mut jolt_key_index) -> i32;
     pub fn jolt_rw_matrix_len(m: *const jolt_rw_matrix, entries: *mut usize) -> i32;
     pub fn jolt_rw_matrix_download(m: *mut jolt_rw_matrix, rows: *mut u64, cols: *mut u64, val: *mut jolt_fr_t, ra: *mut jolt_fr_t, prev: *mut jolt_fr_t, next: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_destroy(m: *mut jolt_rw_matrix) -> i32;

@@ -743,6 +743,38 @@ def onehot_pushforward(col, k_entries, w):
     return out
 
 
+def fold_cycles(keys, k_entries, w):
+    """RamAccessColumns::fold_cycles (optimized/ram_trace.rs:150-162): out[k] = sum of w over the cycles with key k; keys >= k_entries are cold"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    w = np.ascontiguousarray(w, dtype=np.uint64)
+    out = fr_array(k_entries)
+    lib().orc_fold_cycles(_p(keys), C.c_size_t(keys.shape[0]), C.c_size_t(k_entries), _p(w), _p(out))
+    return out
+
+
+def stage_pushforwards(points, pcs, k_entries):
+    """stage_pushforwards (optimized/bytecode_read_raf.rs:152-237): points (n_stages, log_t, 4) big-endian; -> (n_stages, k_entries, 4)"""
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    pcs = np.ascontiguousarray(pcs, dtype=np.uint64)
+    n_stages, log_t = points.shape[0], points.shape[1]
+    assert pcs.shape[0] == 1 << log_t
+    out = fr_array(n_stages * k_entries)
+    rc = lib().orc_stage_pushforwards(_p(points), C.c_size_t(n_stages), C.c_size_t(log_t), _p(pcs), C.c_size_t(k_entries), _p(out))
+    if rc:
+        raise ValueError("bytecode index outside the padded bytecode domain" if rc == -2 else "out of memory")
+    return out.reshape(n_stages, k_entries, 4)
+
+
+def last_value(keys, post, k_entries, init):
+    """the word an address holds after its last access (ram_val_final); init where it is never accessed"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    post = np.ascontiguousarray(post, dtype=np.uint64)
+    init = np.ascontiguousarray(init, dtype=np.uint64)
+    out = fr_array(k_entries)
+    lib().orc_last_value(_p(keys), _p(post), C.c_size_t(keys.shape[0]), C.c_size_t(k_entries), _p(init), _p(out))
+    return out
+
+
 class BooleanityAddress:
     """OptimizedBooleanityAddressKernel (crates/jolt-kernels/src/optimized/booleanity.rs:283-427) over pushforward masses (n_polys, K, 4)"""
 

@@ -68,6 +68,74 @@ class OracleWorkload:
         return outs
 
 
+class OracleOps:
+    """jolt_amd.stages.DeviceOps on the CPU oracle: tables are numpy (n, 4) arrays, the pushforwards are the restatements of oracle/address_ops.c (the bytecode one in the
+    reference's split-eq two-table form when the weights are eq tables of known points, fold_cycles otherwise), members the dense ones of oracle/sumcheck.c."""
+
+    def __init__(self, indexes, chunk_cols, k_chunk):
+        self.indexes, self.chunk_cols, self.k_chunk = indexes, chunk_cols, k_chunk
+        self.one = O.to_mont([1])[0]
+        v = lambda a: np.asarray(a, dtype=np.uint64).reshape(1, 4)
+        self.mul = lambda a, b: O.fr_mul(v(a), v(b))[0]
+        self.add = lambda a, b: O.fr_add(v(a), v(b))[0]
+        self.sub = lambda a, b: O.fr_sub(v(a), v(b))[0]
+        self.host_eq = O.eq_evals
+        self.points = {}
+
+    def eq(self, point):
+        t = O.eq_evals(point) if len(point) else O.to_mont([1])
+        self.points[id(t)] = np.asarray(point)
+        return t
+
+    def upload(self, values):
+        return np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4).copy()
+
+    def u64_table(self, values):
+        return O.fr_from_u64(np.ascontiguousarray(values, dtype=np.uint64))
+
+    def pushforward(self, which, tables):
+        keys, k = self.indexes[which]
+        pts = [self.points.get(id(t)) for t in tables]
+        if which == "pc" and all(p is not None and len(p) for p in pts):  # stage_pushforwards: all stages in one walk over the split eq tables
+            return list(O.stage_pushforwards(np.stack(pts), keys, k))
+        return [O.fold_cycles(keys, k, t) for t in tables]
+
+    def last_value(self, which, init):
+        keys, k = self.indexes[which]
+        return O.last_value(keys, self.indexes[which + "_post"], k, init)
+
+    def materialize_chunk(self, i, eq_chunk):
+        return O.onehot_values(eq_chunk, 1, self.k_chunk, self.chunk_cols[i], self.chunk_cols.shape[1])
+
+    def rlc(self, tables, scalars):
+        acc = np.zeros_like(tables[0])
+        for t, c in zip(tables, scalars):
+            acc = O.fr_add(acc, O.fr_mul(t, np.repeat(np.asarray(c).reshape(1, 4), t.shape[0], axis=0)))
+        return acc
+
+    def member_expr(self, tables, terms, degree):
+        return O.Member.expr(tables, terms, degree)
+
+    def member_gruen_product(self, a, b, w):
+        return O.Member.gruen_product(a, b, w)
+
+    def prove(self, member, claim, n_vars, degree, label):
+        out = O.prove_batch([member], [claim], [self.one], [0], n_vars, degree, label=label)
+        return dict(polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+
+    def final_values(self, member):
+        return list(member.final_values())
+
+    def evaluate(self, table, point):
+        return O.poly_evaluate(table, point) if len(point) else table[0]
+
+    def destroy(self, member):
+        member.close()
+
+    def free(self, table):
+        self.points.pop(id(table), None)
+
+
 class OracleExtended:
     """jolt_amd.stages.DeviceExtended on the CPU oracle: the same description (build_extended), the same operator drivers, every T-scale
     quantity from oracle/r1cs.c, rw_matrix.c, read_raf.c and the dense members of oracle/sumcheck.c."""
@@ -271,7 +339,14 @@ class OracleExtended:
         out["claim"] = np.zeros(4, dtype=np.uint64)
         return out
 
+    def address_domain(self, label):
+        S, d = self.S, self.d
+        ram, bc = d["ram"], d["bytecode"]
+        ops = OracleOps({"pc": (bc["push_pc"], 1 << bc["log_k"]), "ram": (ram["addresses"], 1 << ram["log_k"]), "ram_post": ram["post"]}, bc["chunk_cols"], 1 << bc["chunk_bits"])
+        return {"bytecode_read_raf": S.bytecode_read_raf(ops, bc, self.n_vars, label), "ram_raf_evaluation": S.ram_raf_evaluation(ops, ram, d["ram_raf"], label + 10),
+                "ram_output_check": S.ram_output_check(ops, ram, d["ram_output"], label + 20)}
+
     def prove(self, label=0):
-        return {"spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
+        return {**self.address_domain(label + 500), "spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
                 "registers_read_write": self.registers_read_write(label + 350), "instruction_read_raf": self.instruction_read_raf(label + 400),
                 "booleanity_address": self.booleanity_address(label + 450)}
