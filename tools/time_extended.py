@@ -48,6 +48,20 @@ def main():
                      ("ram", lambda: e.ram_read_write(8)), ("registers", lambda: e.registers_read_write(9)), ("booleanity_address", lambda: e.booleanity_address(10))):
         fn(); ctx.synchronize(); t0 = time.perf_counter(); fn(); ctx.synchronize()
         print(name, round((time.perf_counter() - t0) * 1e3, 2), "ms")
+    # the address-domain relations part by part: index builds, then each driver over prebuilt indexes
+    ram, bc = d["ram"], d["bytecode"]
+    for rep in range(2):
+        acc = {}
+        def timed(name, fn):
+            ctx.synchronize(); t0 = time.perf_counter(); r = fn(); ctx.synchronize(); acc[name] = round((time.perf_counter() - t0) * 1e3, 2); return r
+        pc_ix = timed("pc_index", lambda: ctx.key_index(e.pc_ints, 1 << bc["log_k"]))
+        ram_ix = timed("ram_index", lambda: ctx.key_index(e.ram_cols[0], 1 << ram["log_k"]))
+        ops = S.DeviceOps(ctx, ffi, {"pc": pc_ix, "ram": ram_ix, "ram_post": e.ram_cols[2]}, e.pc_chunks)
+        timed("bytecode_read_raf", lambda: S.bytecode_read_raf(ops, bc, log_t, 20))
+        timed("ram_raf_evaluation", lambda: S.ram_raf_evaluation(ops, ram, d["ram_raf"], 30))
+        timed("ram_output_check", lambda: S.ram_output_check(ops, ram, d["ram_output"], 40))
+        pc_ix.free(); ram_ix.free()
+        print("address_domain", acc, "items", flush=True)
 
 
 if __name__ == "__main__":
