@@ -364,7 +364,7 @@ def main():
                                                              e.claims["product"], 1, 3200)),
                         ("ram_read_write", lambda: e.ram_read_write(3300)), ("registers_read_write", lambda: e.registers_read_write(3350)),
                         ("instruction_read_raf", lambda: e.instruction_read_raf(3400)), ("booleanity_address", lambda: e.booleanity_address(3450)),
-                        ("address_domain", lambda: e.address_domain(3500))]
+                        ("hamming_weight", lambda: e.hamming_weight(3470)), ("address_domain", lambda: e.address_domain(3500))]
         legs = [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + ext_legs + [("prove", lambda: wl.prove(label=3000))] + \
                ([("open", lambda: wl.open(label=3000))] if pcs else [])
         acc = {k: 0.0 for k, _ in legs}
@@ -384,9 +384,9 @@ def main():
     the_ext = ext if sharded else wl.ext
     if the_ext is not None:
         ram = the_ext.d["ram"]
-        ext_note = (f"runs the stage 1 / 2 / 4 / 5 / 6a / 6b operators outside the cycle-domain catalogue -- Spartan outer (uni-skip sums off 35 integer columns, Az / Bz, log T + 1 "
+        ext_note = (f"runs the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators outside the cycle-domain catalogue -- Spartan outer (uni-skip sums off 35 integer columns, Az / Bz, log T + 1 "
                     f"remainder rounds, claimed inputs), Spartan product (the same over the 6 product lanes), the sparse RAM read-write matrix (K = 2^{ram['log_k']}, "
-                    f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and the instruction read-RAF scans of all 16 address phases + log T cycle rounds, the booleanity address phase (pushforward masses of the 36 RA columns + log K host rounds), and the address-domain relations -- bytecode read+RAF (five per-stage "
+                    f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and the instruction read-RAF scans of all 16 address phases + log T cycle rounds, the booleanity address phase and the Hamming-weight claim reduction (pushforward masses of the 36 RA columns + log K host rounds each), and the address-domain relations -- bytecode read+RAF (five per-stage "
                     f"pushforwards onto the 2^{the_ext.d['bytecode']['log_k']}-entry bytecode domain + log K rounds, then C * prod ra_i over log T rounds), RAM RAF evaluation and the RAM output check "
                     f"(pushforward / final-memory column over a sorted index of the address column + log K rounds each)"
                     + (" (per-rank replicas over each rank's block of cycles: these operators have no cross-rank form yet)" if sharded else "") + " -- ")

@@ -325,6 +325,17 @@ int32_t jolt_host_booleanity_address_round(const jolt_fr_t *linear, const jolt_f
                                            const jolt_fr_t *weights, const jolt_fr_t *eq_address, jolt_fr_t *evals_out);
 int32_t jolt_host_booleanity_address_bind(jolt_fr_t *linear, jolt_fr_t *squared, size_t n_polys, size_t stride, size_t len, jolt_fr_t *eq_address,
                                           const jolt_fr_t *challenge);
+/* Hamming-weight claim reduction (stage 7), host half: HammingWeightKernel (crates/jolt-kernels/src/optimized/hamming_weight_claim_reduction.rs:150-300) over the
+ * K_chunk-entry pushforward masses G_i of all RA columns (jolt_onehot_pushforward against eq(r_cycle, .): the relation's one T-scale pass, :83-117).
+ *   weights: W_i(k) = gamma^(3i) + gamma^(3i+1) eq(r_address, k) + gamma^(3i+2) eq(virtualization_points[i], k)  (:187-207), n_polys rows of 2^log_k entries;
+ *   round:   evals_out = {s(0), s(2), sum_i sum_k G_i(k) W_i(k)} of the summand sum_i G_i W_i (group_evals :255-266; the caller recovers s(1) from the running
+ *            claim, round_poly_from_skipped_evals; the third value is the input claim before the first round);
+ *   bind:    every table bound as a multilinear, low variable first (:243-252); the output claims are the bound G_i.
+ * Tables are n_polys rows of `stride` entries with the first `len` live. */
+int32_t jolt_host_hamming_weights(const jolt_fr_t *gamma, const jolt_fr_t *r_address, const jolt_fr_t *virtualization_points, size_t n_polys, size_t log_k,
+                                  jolt_fr_t *out);
+int32_t jolt_host_pair_tables_round(const jolt_fr_t *g, const jolt_fr_t *w, size_t n_polys, size_t stride, size_t len, jolt_fr_t *evals_out /* 3 */);
+int32_t jolt_host_pair_tables_bind(jolt_fr_t *g, jolt_fr_t *w, size_t n_polys, size_t stride, size_t len, const jolt_fr_t *challenge);
 /* The Fiat-Shamir surface of members the caller drives round by round outside prove_batch (RamReadWriteKernel's rounds, the read-RAF
  * phases): Transcript::{append, challenge, challenge_scalar} (crates/jolt-transcript/src/legacy.rs:55-100) over the deterministic TEST
  * transcript of jolt_host_prove_batch.  A Rust caller keeps its own Blake2b / Keccak transcript and never calls these. */

@@ -608,6 +608,70 @@ extern "C" int32_t jolt_host_booleanity_address_bind(jolt_fr_t* linear, jolt_fr_
     return JOLT_OK;
 }
 
+// ---- Hamming-weight claim reduction (stage 7), host half: HammingWeightKernel (crates/jolt-kernels/src/optimized/hamming_weight_claim_reduction.rs:150-300)
+// over the K_chunk-entry pushforward masses G_i of ALL RA columns (jolt_onehot_pushforward against the shared eq(r_cycle, .): the one T-scale pass of the
+// relation, :83-117).  weights: W_i(k) = g^(3i) + g^(3i+1) eq(r_address, k) + g^(3i+2) eq(virt_i, k) (:187-207); round: the summand sum_i G_i W_i at
+// t = 0 and t = 2 summed over the pair groups (group_evals :255-266) plus the plain sum (the input claim before the first round); bind: every table as
+// a multilinear (:243-252).  Tables are n_polys rows of `stride` entries, the first `len` live.
+extern "C" int32_t jolt_host_hamming_weights(const jolt_fr_t* gamma, const jolt_fr_t* r_address, const jolt_fr_t* virtualization_points, size_t n_polys, size_t log_k,
+                                             jolt_fr_t* out) {
+    if (!gamma || !out || (log_k && (!r_address || !virtualization_points)) || log_k > 16) return JOLT_ERR_INVALID_ARG;
+    const size_t K = (size_t)1 << log_k;
+    auto eq_table = [&](const jolt_fr_t* point, std::vector<Fr>& t) {  // EqPolynomial::evals, big-endian point
+        t.assign(1, Fr::one());
+        for (size_t v = 0; v < log_k; ++v) {
+            const Fr r = fr_from_abi(&point[v]);
+            std::vector<Fr> next(t.size() * 2);
+            for (size_t i = 0; i < t.size(); ++i) {
+                next[2 * i + 1] = mul(t[i], r);
+                next[2 * i] = sub(t[i], next[2 * i + 1]);
+            }
+            t.swap(next);
+        }
+    };
+    std::vector<Fr> eq_bool, eq_virt;
+    eq_table(r_address, eq_bool);
+    const Fr g = fr_from_abi(gamma);
+    Fr power = Fr::one();
+    for (size_t i = 0; i < n_polys; ++i) {
+        const Fr g0 = power, g1 = mul(g0, g), g2 = mul(g1, g);
+        power = mul(g2, g);
+        eq_table(virtualization_points + i * log_k, eq_virt);
+        for (size_t k = 0; k < K; ++k) fr_to_abi(&out[i * K + k], add(g0, add(mul(g1, eq_bool[k]), mul(g2, eq_virt[k]))));
+    }
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_pair_tables_round(const jolt_fr_t* g, const jolt_fr_t* w, size_t n_polys, size_t stride, size_t len, jolt_fr_t* evals_out /* 3 */) {
+    if (!g || !w || !evals_out || len < 1 || (len & (len - 1)) || len > stride) return JOLT_ERR_INVALID_ARG;
+    Fr s0 = Fr::zero(), s2 = Fr::zero(), total = Fr::zero();
+    for (size_t i = 0; i < n_polys; ++i) {
+        const jolt_fr_t *gi = g + i * stride, *wi = w + i * stride;
+        for (size_t y = 0; y < len / 2; ++y) {
+            const Fr g_lo = fr_from_abi(&gi[2 * y]), g_hi = fr_from_abi(&gi[2 * y + 1]), w_lo = fr_from_abi(&wi[2 * y]), w_hi = fr_from_abi(&wi[2 * y + 1]);
+            s0 = add(s0, mul(g_lo, w_lo));
+            s2 = add(s2, mul(sub(add(g_hi, g_hi), g_lo), sub(add(w_hi, w_hi), w_lo)));
+            total = add(total, add(mul(g_lo, w_lo), mul(g_hi, w_hi)));
+        }
+        if (len == 1) total = add(total, mul(fr_from_abi(&gi[0]), fr_from_abi(&wi[0])));
+    }
+    fr_to_abi(&evals_out[0], s0);
+    fr_to_abi(&evals_out[1], s2);
+    fr_to_abi(&evals_out[2], total);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_pair_tables_bind(jolt_fr_t* g, jolt_fr_t* w, size_t n_polys, size_t stride, size_t len, const jolt_fr_t* challenge) {
+    if (!g || !w || !challenge || len < 2 || (len & (len - 1)) || len > stride) return JOLT_ERR_INVALID_ARG;
+    const Fr r = fr_from_abi(challenge);
+    if (!fr_is_canonical(r)) return JOLT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n_polys; ++i)
+        for (jolt_fr_t* t : {g + i * stride, w + i * stride})
+            for (size_t k = 0; k < len / 2; ++k) {
+                const Fr lo = fr_from_abi(&t[2 * k]), hi = fr_from_abi(&t[2 * k + 1]);
+                fr_to_abi(&t[k], add(lo, mul(r, sub(hi, lo))));
+            }
+    return JOLT_OK;
+}
+
 // ---- the caller-side Fiat-Shamir of members that are driven round by round outside prove_batch (sparse read-write matrix, read-RAF
 // phases): the deterministic test transcript behind four entry points; a Rust caller uses its own Transcript instead.
 struct jolt_host_transcript {

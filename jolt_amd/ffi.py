@@ -504,6 +504,34 @@ class HostBooleanityAddress:
         return host_fr_mul(self.eq[0], acc)
 
 
+class HostHammingWeight:
+    """HammingWeightKernel's K_chunk-domain state on the host (jolt_host_hamming_weights / jolt_host_pair_tables_*): masses (n_polys, K, 4) from the pushforward"""
+
+    def __init__(self, masses, gamma, r_address, virtualization_points):
+        self.g = np.ascontiguousarray(masses, dtype=np.uint64).copy()
+        self.n_polys, self.k = self.g.shape[0], self.g.shape[1]
+        self.len = self.k
+        log_k = self.k.bit_length() - 1
+        ra = np.ascontiguousarray(fr(r_address), dtype=np.uint64).reshape(-1, 4)
+        vp = np.ascontiguousarray(virtualization_points, dtype=np.uint64).reshape(-1, 4)
+        assert ra.shape[0] == log_k and vp.shape[0] == self.n_polys * log_k
+        self.w = fr_array(self.n_polys * self.k).reshape(self.n_polys, self.k, 4)
+        _ck(lib().jolt_host_hamming_weights(_p(fr(gamma)), _p(ra), _p(vp), C.c_size_t(self.n_polys), C.c_size_t(log_k), _p(self.w)), "jolt_host_hamming_weights")
+
+    def round(self):
+        o = fr_array(3)
+        _ck(lib().jolt_host_pair_tables_round(_p(self.g), _p(self.w), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(o)), "jolt_host_pair_tables_round")
+        return o
+
+    def bind(self, r):
+        _ck(lib().jolt_host_pair_tables_bind(_p(self.g), _p(self.w), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(fr(r))), "jolt_host_pair_tables_bind")
+        self.len //= 2
+
+    def output_claims(self):
+        assert self.len == 1
+        return self.g[:, 0].copy()
+
+
 class HostTranscript:
     """The deterministic test transcript of jolt_host_prove_batch for members driven round by round from here (jolt_host_transcript_*)."""
 

@@ -17,6 +17,8 @@ stage drivers drive them, over synthetic trace-shaped inputs:
                                      log K rounds over K-entry tables with the squared-weight bind on the host, where the reference keeps them
                                      (optimized/booleanity.rs:152-427)
 
+  stage 7   Hamming-weight reduction the pushforward masses of all RA columns against the shared eq(r_cycle) (T-scale, device), then log K rounds of sum_i G_i W_i on the host
+                                     (optimized/hamming_weight_claim_reduction.rs)
   stage 2   RAM RAF evaluation       ra_folded(k) = sum_{j: address(j) = k} eq(tau_low, j) over the K RAM words (T-scale, device: a key index over the address
                                      column), then the log K rounds of ra_folded * unmap over K-sized tables  (optimized/ram_raf_evaluation.rs)
   stage 2   RAM output check         val_final(k) = the word of the last access to k (T-scale), then the log K rounds of eq(r_address) * io_mask * (val_final - val_io)
@@ -165,6 +167,9 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_cou
     for p in range(max(1, n_ra // 12)):
         cols[n_ra - 1 - p, rng.random(T) < 0.4] = 0xFF
     d["booleanity"] = dict(cols=cols, log_k=log_kc, reference_cycle=rand_fr(n_vars, rng), reference_address=rand_fr(log_kc, rng), gamma=rand_fr(1, rng)[0])
+    # ---- stage 7: Hamming-weight claim reduction over the same RA columns: the shared cycle point of the stage-6b claims, the booleanity address point, one
+    # virtualization point per column
+    d["hamming"] = dict(r_cycle=rand_fr(n_vars, rng), r_address=rand_fr(log_kc, rng), virtualization_points=rand_fr(n_ra * log_kc, rng).reshape(n_ra, log_kc, 4), gamma=rand_fr(1, rng)[0])
     # ---- stage 2: RAM RAF evaluation and output check over the RAM trace above (tau_low; the IO region = words [K/4, K/4 + max(1, K/16)) with public words)
     ram = d["ram"]
     K_ram = 1 << ram["log_k"]
@@ -309,6 +314,26 @@ def booleanity_address_rounds(kernel, log_k, transcript, from_evals, evaluate):
         polys.append(poly)
         chal.append(r)
     return dict(polys=polys, challenges=np.stack(chal), final_claim=claim, intermediate=kernel.intermediate())
+
+
+def hamming_weight_rounds(kernel, log_k, transcript, from_evals, evaluate, sub):
+    """ProveRounds of HammingWeightKernel driven alone (optimized/hamming_weight_claim_reduction.rs:268-298): s(0) and s(2) per round, s(1) recovered from the running
+    claim (round_poly_from_skipped_evals), every message absorbed.  `kernel`: round() -> (s(0), s(2), plain sum), bind(r), output_claims()."""
+    polys, chal, claim, first = [], [], None, None
+    for rnd in range(log_k):
+        s0, s2, total = kernel.round()
+        if claim is None:
+            claim = first = total
+        poly = from_evals(np.stack([s0, sub(claim, s0), s2]))
+        transcript.append(poly)
+        r = transcript.challenge()
+        claim = evaluate(poly, r)
+        kernel.bind(r)
+        polys.append(poly)
+        chal.append(r)
+    if claim is None:
+        claim = first = kernel.round()[2]
+    return dict(polys=polys, challenges=np.stack(chal) if chal else np.zeros((0, 4), dtype=np.uint64), claim=first, final_claim=claim, g_claims=kernel.output_claims())
 
 
 def product_integer_weights():
@@ -549,6 +574,20 @@ class DeviceExtended:
         out["masses"] = masses
         return out
 
+    def hamming_weight(self, label):
+        ctx, ffi, bo, hw = self.ctx, self.ffi, self.d["booleanity"], self.d["hamming"]
+        eq = ctx.eq_evals(hw["r_cycle"])
+        g = self.bool_cols.pushforward(eq)  # FamilySelectors::pushforwards (hamming_weight_claim_reduction.rs:83-117): all RA columns against ONE eq table
+        eq.free()
+        masses = g.download().reshape(bo["cols"].shape[0], 1 << bo["log_k"], 4)
+        g.free()
+        tr = ffi.HostTranscript(label)
+        out = hamming_weight_rounds(ffi.HostHammingWeight(masses, hw["gamma"], hw["r_address"], hw["virtualization_points"]), bo["log_k"], tr, ffi.host_univariate_from_evals,
+                                    ffi.host_univariate_evaluate, ffi.host_fr_sub)
+        tr.close()
+        out["masses"] = masses
+        return out
+
     def instruction_read_raf(self, label):
         ctx, ffi, d = self.ctx, self.ffi, self.d
         lk, rr = d["lookup"], self.read_raf
@@ -604,6 +643,7 @@ class DeviceExtended:
             "registers_read_write": self.registers_read_write(label + 350),
             "instruction_read_raf": self.instruction_read_raf(label + 400),
             "booleanity_address": self.booleanity_address(label + 450),
+            "hamming_weight": self.hamming_weight(label + 470),
         }
 
     def close(self):

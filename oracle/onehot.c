@@ -84,3 +84,38 @@ EXPORT void orc_booleanity_address_bind(fr_t *linear, fr_t *squared, size_t n_po
     }
     for (size_t k = 0; k < half; ++k) eq_address[k] = FADD(eq_address[2 * k], FMUL(*r, FSUB(eq_address[2 * k + 1], eq_address[2 * k])));
 }
+
+/* Hamming-weight claim reduction (stage 7), crates/jolt-kernels/src/optimized/hamming_weight_claim_reduction.rs: the combined weights
+ * W_i(k) = g^(3i) + g^(3i+1) eq_bool(k) + g^(3i+2) eq_virt_i(k) (:187-207, gamma_powers = 1, g, g^2, ..), the round sums of sum_i G_i W_i at t = 0 and t = 2
+ * (group_evals :255-266) with the plain sum as a third value, and the bind of every table (:243-252).  eq tables are passed in (orc_eq_evals). */
+EXPORT void orc_hamming_weights(const fr_t *gamma, const fr_t *eq_bool, const fr_t *eq_virt /* n_polys * k */, size_t n_polys, size_t k_entries, fr_t *out) {
+    fr_t power = fr_one();
+    for (size_t i = 0; i < n_polys; ++i) {
+        fr_t g0 = power, g1 = FMUL(g0, *gamma), g2 = FMUL(g1, *gamma);
+        power = FMUL(g2, *gamma);
+        for (size_t k = 0; k < k_entries; ++k)
+            out[i * k_entries + k] = FADD(g0, FADD(FMUL(g1, eq_bool[k]), FMUL(g2, eq_virt[i * k_entries + k])));
+    }
+}
+EXPORT void orc_pair_tables_round(const fr_t *g, const fr_t *w, size_t n_polys, size_t stride, size_t len, fr_t *out /* 3 */) {
+    fr_t s0 = fr_zero(), s2 = fr_zero(), total = fr_zero();
+    for (size_t i = 0; i < n_polys; ++i) {
+        const fr_t *gi = g + i * stride, *wi = w + i * stride;
+        for (size_t y = 0; y < len / 2; ++y) {
+            fr_t g_lo = gi[2 * y], g_hi = gi[2 * y + 1], w_lo = wi[2 * y], w_hi = wi[2 * y + 1];
+            s0 = FADD(s0, FMUL(g_lo, w_lo));
+            s2 = FADD(s2, FMUL(FSUB(FADD(g_hi, g_hi), g_lo), FSUB(FADD(w_hi, w_hi), w_lo)));
+        }
+        for (size_t k = 0; k < len; ++k) total = FADD(total, FMUL(gi[k], wi[k]));
+    }
+    out[0] = s0;
+    out[1] = s2;
+    out[2] = total;
+}
+EXPORT void orc_pair_tables_bind(fr_t *g, fr_t *w, size_t n_polys, size_t stride, size_t len, const fr_t *r) {
+    for (size_t i = 0; i < n_polys; ++i) {
+        fr_t *tabs[2] = {g + i * stride, w + i * stride};
+        for (int t = 0; t < 2; ++t)
+            for (size_t k = 0; k < len / 2; ++k) tabs[t][k] = FADD(tabs[t][2 * k], FMUL(*r, FSUB(tabs[t][2 * k + 1], tabs[t][2 * k])));
+    }
+}

@@ -212,6 +212,9 @@ extern "C" {
     pub fn jolt_host_gruen_poly_deg_3(current_scalar: *const jolt_fr_t, point_i: *const jolt_fr_t, q_constant: *const jolt_fr_t, q_quadratic: *const jolt_fr_t, s0_plus_s1: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_booleanity_address_round(linear: *const jolt_fr_t, squared: *const jolt_fr_t, n_polys: usize, stride: usize, len: usize, weights: *const jolt_fr_t, eq_address: *const jolt_fr_t, evals_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_booleanity_address_bind(linear: *mut jolt_fr_t, squared: *mut jolt_fr_t, n_polys: usize, stride: usize, len: usize, eq_address: *mut jolt_fr_t, challenge: *const jolt_fr_t) -> i32;
+    pub fn jolt_host_hamming_weights(gamma: *const jolt_fr_t, r_address: *const jolt_fr_t, virtualization_points: *const jolt_fr_t, n_polys: usize, log_k: usize, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_pair_tables_round(g: *const jolt_fr_t, w: *const jolt_fr_t, n_polys: usize, stride: usize, len: usize, evals_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_pair_tables_bind(g: *mut jolt_fr_t, w: *mut jolt_fr_t, n_polys: usize, stride: usize, len: usize, challenge: *const jolt_fr_t) -> i32;
     pub fn jolt_host_transcript_create(label: u64, out: *mut *mut jolt_host_transcript) -> i32;
     pub fn jolt_host_transcript_append_fr(t: *mut jolt_host_transcript, values: *const jolt_fr_t, count: usize) -> i32;
     pub fn jolt_host_transcript_challenge(t: *mut jolt_host_transcript, full_width: i32, out: *mut jolt_fr_t) -> i32;

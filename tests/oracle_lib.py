@@ -743,6 +743,35 @@ def onehot_pushforward(col, k_entries, w):
     return out
 
 
+class HammingWeight:
+    """HammingWeightKernel (crates/jolt-kernels/src/optimized/hamming_weight_claim_reduction.rs:150-300) over pushforward masses (n_polys, K, 4)"""
+
+    def __init__(self, masses, gamma, r_address, virtualization_points):
+        self.g = np.ascontiguousarray(masses, dtype=np.uint64).copy()
+        self.n_polys, self.k = self.g.shape[0], self.g.shape[1]
+        self.len = self.k
+        log_k = self.k.bit_length() - 1
+        vp = np.ascontiguousarray(virtualization_points, dtype=np.uint64).reshape(self.n_polys, log_k, 4)
+        one = to_mont([1])
+        eq_bool = eq_evals(r_address) if log_k else one
+        eq_virt = np.ascontiguousarray(np.stack([eq_evals(vp[i]) if log_k else one for i in range(self.n_polys)]))
+        self.w = fr_array(self.n_polys * self.k).reshape(self.n_polys, self.k, 4)
+        lib().orc_hamming_weights(_p(np.ascontiguousarray(gamma, dtype=np.uint64)), _p(np.ascontiguousarray(eq_bool)), _p(eq_virt), C.c_size_t(self.n_polys), C.c_size_t(self.k), _p(self.w))
+
+    def round(self):
+        o = fr_array(3)
+        lib().orc_pair_tables_round(_p(self.g), _p(self.w), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(o))
+        return o
+
+    def bind(self, r):
+        lib().orc_pair_tables_bind(_p(self.g), _p(self.w), C.c_size_t(self.n_polys), C.c_size_t(self.k), C.c_size_t(self.len), _p(np.ascontiguousarray(r, dtype=np.uint64)))
+        self.len //= 2
+
+    def output_claims(self):
+        assert self.len == 1
+        return self.g[:, 0].copy()
+
+
 def fold_cycles(keys, k_entries, w):
     """RamAccessColumns::fold_cycles (optimized/ram_trace.rs:150-162): out[k] = sum of w over the cycles with key k; keys >= k_entries are cold"""
     keys = np.ascontiguousarray(keys, dtype=np.uint64)

@@ -148,3 +148,56 @@ def test_address_domain_drivers_against_the_dense_definitions(n_vars, kw):
     assert np.array_equal(oc["val_final_claim"], O.poly_evaluate(O.fr_from_u64(mem), point))
     closed = _mul(O.eq_mle(io["point"], point), _mul(O.poly_evaluate(O.fr_from_u64(mask), point), _sub(oc["val_final_claim"], O.poly_evaluate(O.fr_from_u64(io["val_io"]), point))))
     assert np.array_equal(last, closed)
+
+
+@pytest.mark.parametrize("n_vars", [3, 5, 8])
+def test_hamming_weight_reduction_against_its_definition(n_vars):
+    """stage 7 (optimized/hamming_weight_claim_reduction.rs): claim = sum_i sum_k G_i(k) W_i(k) with G_i the dense pushforward of the column; every message sums to the
+    running claim; the last claim is sum_i G_i(r) W_i(r) with W_i(r) = g^(3i) + g^(3i+1) eq(r_address, r) + g^(3i+2) eq(virt_i, r)"""
+    ext = OracleExtended(n_vars, seed=23, n_tables=4)
+    bo, hw = ext.d["booleanity"], ext.d["hamming"]
+    out = ext.hamming_weight(label=60)
+    K, n = 1 << bo["log_k"], bo["cols"].shape[0]
+    eq = O.eq_evals(hw["r_cycle"])
+    gp = [ONE]
+    for _ in range(3 * n):
+        gp.append(_mul(gp[-1], hw["gamma"]))
+    eq_bool = O.eq_evals(hw["r_address"])
+    claim = ZERO
+    for i in range(n):
+        g = np.zeros((K, 4), dtype=np.uint64)
+        for j, k in enumerate(bo["cols"][i]):
+            if k != 0xFF:
+                g[int(k)] = _add(g[int(k)], eq[j])
+        assert np.array_equal(out["masses"][i], g)
+        eq_virt = O.eq_evals(hw["virtualization_points"][i])
+        for k in range(K):
+            claim = _add(claim, _mul(g[k], _add(gp[3 * i], _add(_mul(gp[3 * i + 1], eq_bool[k]), _mul(gp[3 * i + 2], eq_virt[k])))))
+    assert np.array_equal(out["claim"], claim)
+    last = check_rounds(out, claim)
+    point = out["challenges"][::-1]
+    closed = ZERO
+    for i in range(n):
+        w_r = _add(gp[3 * i], _add(_mul(gp[3 * i + 1], O.eq_mle(hw["r_address"], point)), _mul(gp[3 * i + 2], O.eq_mle(hw["virtualization_points"][i], point))))
+        assert np.array_equal(out["g_claims"][i], O.poly_evaluate(out["masses"][i], point))
+        closed = _add(closed, _mul(out["g_claims"][i], w_r))
+    assert np.array_equal(last, closed)
+
+
+def test_host_hamming_helpers_of_the_library_equal_the_oracle():
+    """jolt_host_hamming_weights / jolt_host_pair_tables_* (host code of libjolt_hip.so: no GPU needed) against oracle/onehot.c, round for round"""
+    from jolt_amd import ffi
+    rng = np.random.default_rng(9)
+    for n, log_k in [(5, 2), (36, 4), (3, 1)]:
+        K = 1 << log_k
+        masses = rand_fr(n * K, rng).reshape(n, K, 4)
+        gamma, r_address, virt = rand_fr(1, rng)[0], rand_fr(log_k, rng), rand_fr(n * log_k, rng).reshape(n, log_k, 4)
+        host, orc = ffi.HostHammingWeight(masses, gamma, r_address, virt), O.HammingWeight(masses, gamma, r_address, virt)
+        assert np.array_equal(host.w, orc.w)
+        for _ in range(log_k):
+            assert np.array_equal(host.round(), orc.round())
+            r = rand_fr(1, rng)[0]
+            host.bind(r)
+            orc.bind(r)
+        assert np.array_equal(host.round()[2], orc.round()[2])
+        assert np.array_equal(host.output_claims(), orc.output_claims())

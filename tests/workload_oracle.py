@@ -339,6 +339,27 @@ class OracleExtended:
         out["claim"] = np.zeros(4, dtype=np.uint64)
         return out
 
+    def hamming_weight(self, label):
+        S, bo, hw = self.S, self.d["booleanity"], self.d["hamming"]
+        K = 1 << bo["log_k"]
+        eq = O.eq_evals(hw["r_cycle"]) if self.n_vars else O.to_mont([1])
+        masses = np.stack([O.onehot_pushforward(bo["cols"][i], K, eq) for i in range(bo["cols"].shape[0])])
+        orc_tr = O.MockTranscript(label)
+
+        class Tr:
+            def append(self, values):
+                for v in np.asarray(values).reshape(-1, 4):
+                    orc_tr.append_fr(v)
+
+            def challenge(self):
+                return orc_tr.challenge()
+
+        sub = lambda a, b: O.fr_sub(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+        out = S.hamming_weight_rounds(O.HammingWeight(masses, hw["gamma"], hw["r_address"], hw["virtualization_points"]), bo["log_k"], Tr(), O.univariate_from_evals,
+                                      O.univariate_evaluate, sub)
+        out["masses"] = masses
+        return out
+
     def address_domain(self, label):
         S, d = self.S, self.d
         ram, bc = d["ram"], d["bytecode"]
@@ -349,4 +370,4 @@ class OracleExtended:
     def prove(self, label=0):
         return {**self.address_domain(label + 500), "spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
                 "registers_read_write": self.registers_read_write(label + 350), "instruction_read_raf": self.instruction_read_raf(label + 400),
-                "booleanity_address": self.booleanity_address(label + 450)}
+                "booleanity_address": self.booleanity_address(label + 450), "hamming_weight": self.hamming_weight(label + 470)}
