@@ -29,6 +29,6 @@ pub mod status;
 pub use context::{HipContext, HipTable};
 pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape};
 pub use msm::{msm_cache_clear, msm_cache_evict, msm_g1, HipShardedOpening, HipSrs, SharedMsmContext};
-pub use ops::{HipHotIndices, HipInts, HipReadRaf, HipRegistersRw, HipRwMatrix, SpartanSums};
+pub use ops::{HipHotIndices, HipInts, HipKeyIndex, HipReadRaf, HipRegistersRw, HipRwMatrix, SpartanSums};
 pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
 pub use status::HipError;

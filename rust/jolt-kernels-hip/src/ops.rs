@@ -242,6 +242,51 @@ impl Drop for HipRegistersRw {
     }
 }
 
+/// Rows of a resident key column (bytecode PCs, RAM word addresses) sorted by key, once per proof and column -- what the reference shares through its
+/// `ProofSession` as the packed `PcRow`s (`optimized/bytecode_read_raf.rs:92-150`) and `RamAccessColumns` (`optimized/ram_trace.rs`).  Serves the pushforwards
+/// of cycle weights onto the K-entry address domain: `stage_pushforwards` (`bytecode_read_raf.rs:152-237`), `fold_cycles` (`ram_trace.rs:150-162`), and the
+/// final-memory column of the RAM output check.
+pub struct HipKeyIndex {
+    ctx: Arc<HipContext>,
+    raw: *mut ffi::jolt_key_index,
+}
+// SAFETY: see HipContext.
+unsafe impl Send for HipKeyIndex {}
+
+impl HipKeyIndex {
+    /// `keys`: one u64 per cycle; a key `>= k` is a cold cycle (`NO_ACCESS`, an unmapped PC) and contributes nothing.
+    pub fn new(ctx: &Arc<HipContext>, keys: &HipInts, k: u64) -> Result<Self, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: live handles of one context.
+        check(unsafe { ffi::jolt_key_index_create(ctx.raw, keys.raw, k, &mut raw) }, ctx.raw)?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
+
+    /// `out[s][a] = sum of weights[s] over the cycles with key a`, for up to 8 weight tables in one pass (the five stage eq tables of the bytecode
+    /// address phase; `eq(tau_low)` of RAM RAF evaluation).
+    pub fn pushforward(&self, weights: &[&HipTable]) -> Result<Vec<HipTable>, HipError> {
+        let handles: Vec<*mut ffi::jolt_table> = weights.iter().map(|t| t.raw).collect();
+        let mut out: Vec<*mut ffi::jolt_table> = vec![ptr::null_mut(); weights.len()];
+        // SAFETY: `handles` / `out` hold weights.len() pointers; the library fills `out` only on success.
+        check(unsafe { ffi::jolt_key_index_pushforward(self.ctx.raw, self.raw, handles.as_ptr(), handles.len(), out.as_mut_ptr()) }, self.ctx.raw)?;
+        Ok(out.into_iter().map(|raw| HipTable { ctx: Arc::clone(&self.ctx), raw }).collect())
+    }
+
+    /// The value at the latest cycle of every key as a field element, `init` where a key never occurs (`ram_val_final`).
+    pub fn last_value(&self, values: &HipInts, init: &HipTable) -> Result<HipTable, HipError> {
+        let mut raw = ptr::null_mut();
+        // SAFETY: live handles of one context.
+        check(unsafe { ffi::jolt_key_index_last_value(self.ctx.raw, self.raw, values.raw, init.raw, &mut raw) }, self.ctx.raw)?;
+        Ok(HipTable { ctx: Arc::clone(&self.ctx), raw })
+    }
+}
+impl Drop for HipKeyIndex {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_key_index_create.
+        let _ = unsafe { ffi::jolt_key_index_destroy(self.ctx.raw, self.raw) };
+    }
+}
+
 /// The packed rows of instruction read+RAF checking on the device (`InstructionCycleRow`, `optimized/instruction_read_raf.rs:86-125`).
 pub struct HipReadRaf {
     ctx: Arc<HipContext>,
