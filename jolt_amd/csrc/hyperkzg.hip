@@ -8,6 +8,7 @@
 //                                                     scan (exact: the recurrence is linear, chunks compose by mu^C)
 // All are HBM-bound streaming passes (<= 2 multiplies per element); the MSMs they feed dominate (msm.hip).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.hpp"
 #include "g1.hip.h"
@@ -19,6 +20,7 @@
 using namespace jolt;
 
 int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out);
+int32_t jolt_internal_msm_pair_and_one(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_a, size_t n_a, size_t shift, const Fr* d_b, size_t n_b, G1Jac* out);
 int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
                                const size_t* base_offsets = nullptr);
 
@@ -413,7 +415,45 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
     s = jolt_hyperkzg_rlc(ctx, polys.data(), ell, &q_abi, &b_poly);  // kzg.rs:95-105
     if (s != JOLT_OK) { cleanup(); return s; }
     G1Jac ws[3];
-    {  // kzg.rs:108-116: three witness polynomials, then their three independent MSMs on the MSM lanes
+    bool paired = false;
+    static const bool pair_enabled = !(std::getenv("JOLT_KZG_PAIR") && std::atoi(std::getenv("JOLT_KZG_PAIR")) == 0);
+    if (world == 1 && pair_enabled && b_poly->len >= 4) {
+        // The witness commitments at r and -r from ONE sorted scalar vector.  B = q (X^2 - r^2) + alpha X + beta gives h_r = (B - B(r)) / (X - r) = q (X + r) + alpha
+        // and h_(-r) = q (X - r) + alpha, so with Cq = commit(q) and Cxq = commit(X q) (the same scalars against the bases shifted by one):
+        //   w[0] = Cxq + r Cq + alpha G_0,   w[1] = Cxq - r Cq + alpha G_0
+        // -- the same group elements kzg.rs:108-116 commits to, from two bucket passes over one digit sort (jolt_internal_msm_fixed_enqueue, pair_shift) instead of two
+        // full MSMs.  q = (h_r - alpha) / (X + r): the quotient recurrence again, whose remainder h_r[0] + q[0] (-r) is alpha.  h_(r^2) keeps its own MSM, on a second lane.
+        jolt_table *h0 = nullptr, *qp = nullptr, *h2 = nullptr;
+        s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[0], &h0);
+        if (s == JOLT_OK) s = jolt_hyperkzg_witness_poly(ctx, h0, &u_abi[1], &qp);
+        if (s == JOLT_OK) s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[2], &h2);
+        Fr h00, q0;
+        G1Affine g0;
+        if (s == JOLT_OK) {
+            hipError_t e = hipMemcpyAsync(&h00, h0->data(), sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&q0, qp->data(), sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&g0, srs->pts, sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->last_error = std::string("hyperkzg open: ") + hipGetErrorString(e); s = JOLT_ERR_HIP; }
+        }
+        if (s == JOLT_OK) {
+            G1Jac three[3];
+            const int32_t ps = jolt_internal_msm_pair_and_one(ctx, srs, qp->data(), qp->len, 1, h2->data(), h2->len, three);
+            if (ps == JOLT_OK) {
+                const Fr alpha = add(h00, mul(q0, u[1])), r_can = from_mont(r), a_can = from_mont(alpha);
+                const G1Jac r_cq = g1_mul_canonical(three[0], r_can.l), base = g1_add(three[1], g1_mul_canonical(g1_from_affine(g0), a_can.l));
+                ws[0] = g1_add(base, r_cq);
+                ws[1] = g1_add(base, g1_neg(r_cq));
+                ws[2] = three[2];
+                paired = true;
+            } else if (ps != JOLT_ERR_UNSUPPORTED) {
+                s = ps;
+            }
+        }
+        for (jolt_table* t : {h0, qp, h2}) if (t) jolt_table_free(ctx, t);
+        if (s != JOLT_OK) { cleanup(b_poly); return s; }
+    }
+    if (!paired) {  // kzg.rs:108-116: three witness polynomials, then their three independent MSMs on the MSM lanes
         jolt_table* h[3] = {nullptr, nullptr, nullptr};
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;

@@ -56,8 +56,9 @@ struct MsmJob {
     size_t n = 0;
     int lane = 0, c = 0, W = 0;
     uint32_t nb = 0;
+    int results = 1;  // 2: a pair of MSMs over the same scalars (jolt_internal_msm_fixed_enqueue with pair_shift): the second result follows the first in msm_host
 };
-int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job);  // msm_fixed.hip
+int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job, size_t pair_shift = 0);  // msm_fixed.hip
 namespace {
 struct MsmPlan {
     int c, W, L;  // window bits, windows, lanes per light bucket
@@ -202,6 +203,7 @@ constexpr size_t kMsmHostEntries = 128;  // >= W for every plan (c = 2: 128 wind
 int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job) {
     job->n = n;
     job->lane = lane;
+    job->results = 1;
     if (n > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
     if (n == 0) return JOLT_OK;
     if (n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
@@ -295,18 +297,35 @@ int32_t jolt_internal_msm_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* 
 }
 
 // Wait for the lane and finish on the host: Horner over the windows, acc = 2^c * acc + S_w.
-int32_t jolt_internal_msm_collect(jolt_ctx* ctx, const MsmJob* job, G1Jac* out) {
-    if (job->n == 0) { *out = g1_identity(); return JOLT_OK; }
+int32_t jolt_internal_msm_collect(jolt_ctx* ctx, const MsmJob* job, G1Jac* out) {  // out: job->results points
+    if (job->n == 0) {
+        for (int r = 0; r < job->results; ++r) out[r] = g1_identity();
+        return JOLT_OK;
+    }
     hipStream_t st = job->lane == 0 ? ctx->stream : ctx->side[job->lane - 1];
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
-    const G1Jac* wsum = (const G1Jac*)ctx->msm_host[job->lane];
-    G1Jac acc = g1_identity();
-    for (int w = job->W - 1; w >= 0; --w) {
-        for (int k = 0; k < job->c; ++k) acc = g1_double(acc);
-        acc = g1_add(acc, wsum[w]);
+    for (int r = 0; r < job->results; ++r) {
+        const G1Jac* wsum = (const G1Jac*)ctx->msm_host[job->lane] + (size_t)r * job->W;
+        G1Jac acc = g1_identity();
+        for (int w = job->W - 1; w >= 0; --w) {
+            for (int k = 0; k < job->c; ++k) acc = g1_double(acc);
+            acc = g1_add(acc, wsum[w]);
+        }
+        out[r] = acc;
     }
-    *out = acc;
     return JOLT_OK;
+}
+// sum_i s_i P_i and sum_i s_i P_(i + shift) on `lane` with ONE sort of the scalars' digits (msm_fixed.hip); JOLT_ERR_UNSUPPORTED when this SRS / length does not take the
+// fixed-base method (the caller then runs two MSMs)
+int32_t jolt_internal_msm_enqueue_pair(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, size_t shift, int lane, MsmJob* job) {
+    job->n = n;
+    job->lane = lane;
+    job->results = 2;
+    if (shift > srs->n || n > srs->n - shift) return JOLT_ERR_SRS_TOO_SMALL;
+    if (n == 0) return JOLT_OK;
+    if (n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
+    if (!(srs->pre && ctx->msm_fixed && n >= srs->pre_min_n)) return JOLT_ERR_UNSUPPORTED;
+    return jolt_internal_msm_fixed_enqueue(ctx, srs, d_scalars, n, lane, job, shift);
 }
 
 // Sharded term assignments (term_map.hip.h): a rank's SRS object holds exactly its terms' bases, compacted in index order, so the
@@ -372,6 +391,26 @@ int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* con
             if (status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, &view, d_scalars[i], n[i], lane, &jobs[lane]);
         }
     }
+    if (status != JOLT_OK)
+        for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->side[k]);
+    return status;
+}
+
+// out[0] = sum_i a_i P_i, out[1] = sum_i a_i P_(i + shift) (one sort of a's digits for both: msm_fixed.hip) and out[2] = sum_i b_i P_i on a second lane beside them.
+// JOLT_ERR_UNSUPPORTED, with nothing enqueued, when the pair cannot take the fixed-base method.
+int32_t jolt_internal_msm_pair_and_one(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_a, size_t n_a, size_t shift, const Fr* d_b, size_t n_b, G1Jac* out) {
+    if (shift > srs->n || n_a > srs->n - shift) return JOLT_ERR_SRS_TOO_SMALL;
+    if (n_a == 0 || !(srs->pre && ctx->msm_fixed && n_a >= srs->pre_min_n)) return JOLT_ERR_UNSUPPORTED;
+    JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int k = 0; k < 3; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+    MsmJob pair, one;
+    int32_t status = jolt_internal_msm_enqueue_pair(ctx, srs, d_a, n_a, shift, 0, &pair);
+    if (status == JOLT_ERR_UNSUPPORTED) return status;  // (decided before any launch: window count / LDS limits)
+    const int lane_b = ctx->msm_lanes > 1 ? 1 : 0;
+    if (status == JOLT_OK && lane_b == 0) status = jolt_internal_msm_collect(ctx, &pair, out);  // one lane: its workspace serves one MSM at a time
+    if (status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, srs, d_b, n_b, lane_b, &one);
+    if (status == JOLT_OK && lane_b != 0) status = jolt_internal_msm_collect(ctx, &pair, out);
+    if (status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &one, out + 2);
     if (status != JOLT_OK)
         for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->side[k]);
     return status;

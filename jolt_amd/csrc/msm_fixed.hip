@@ -32,6 +32,7 @@ struct MsmJob {
     size_t n = 0;
     int lane = 0, c = 0, W = 0;
     uint32_t nb = 0;
+    int results = 1;  // 2: a pair of MSMs over the same scalars (jolt_internal_msm_fixed_enqueue with pair_shift): the second result follows the first in msm_host
 };
 
 namespace {
@@ -903,7 +904,10 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
 // ------------------------------------------------------------------------------------------------------------------
 constexpr size_t kMsmHostEntries = 128;
 
-int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job) {
+// pair_shift > 0: TWO MSMs over the same scalars, sum_i s_i P_i and sum_i s_i P_(i + pair_shift): the digits, and with them the whole sort, are the scalars' alone,
+// so the second MSM is one more pass of bucket sums and reduction over the same sorted lists with the table pointer moved by pair_shift points (the witness
+// commitments at r and -r of a HyperKZG opening are such a pair: hyperkzg.hip).  n + pair_shift must not exceed the tables' point count.
+int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job, size_t pair_shift) {
     const int c = srs->pre_c, W = srs->pre_W;
     const int lo_bits = fx_lo_bits(c);
     const uint32_t kSegBuckets = 1u << lo_bits;
@@ -1089,59 +1093,63 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         lc.r256 = Fq::one();
     }
     const unsigned bucket_grid = (unsigned)((n_buckets + kBlock - 1) / kBlock);
-    if (srs->pre_lform) {
-        hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
-                           (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
-        hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
-                           (const uint32_t*)keys, (const G1Affine*)srs->pre, seg, lc);
-    } else {
-        hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
-                           (const uint32_t*)offs, (const uint32_t*)keys, (const G1Affine*)srs->pre, heavy_threshold, buckets, lc);
-        hipLaunchKernelGGL(k_fx_heavy_segments<false>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
-                           (const uint32_t*)keys, (const G1Affine*)srs->pre, seg, lc);
-    }
-    hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
-                       (const G1Jac*)seg, buckets);
-    if (grid_reduce) {
-        G1Jac* colpart = (G1Jac*)(ws + o_red);
-        G1Jac* rowpart = colpart + (size_t)red_chunks * kRedCols;
-        G1Jac* cols = rowpart + (size_t)red_H * red_per_row;  // C_l, l < 2^S
-        G1Jac* rows = cols + kRedCols;                         // R_h, h < H
-        G1Jac* small_part = rows + red_H;                      // block partials of the two small reductions
-        hipLaunchKernelGGL(k_fx_red_cols, dim3(kRedCols / kBlock, red_chunks), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, red_H, colpart);
-        hipLaunchKernelGGL(k_fx_red_rows, dim3((red_H * red_per_row + kBlock - 1) / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, red_H, rowpart);
-        hipLaunchKernelGGL(k_fx_red_fold, dim3(kRedCols * 64 / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)colpart, kRedCols, red_chunks, (size_t)kRedCols, (size_t)1, cols);
-        hipLaunchKernelGGL(k_fx_red_fold, dim3((red_H * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)rowpart, red_H, red_per_row, (size_t)1, (size_t)red_per_row, rows);
-        // sum_l l C_l (weights 1 .. 2^S - 1) and sum_h h R_h (weights 1 .. H - 1): index = weight, entry 0 unused -- the layout k_msm_window_reduce reads
-        const uint32_t g_small = 8, nb_c = (kRedCols / g_small + kBlock - 1) / kBlock, nb_r = (red_H / g_small + kBlock) / kBlock;
-        hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_c, 1), dim3(kBlock), 0, bst, (const G1Jac*)cols, kRedCols - 1, g_small, small_part);
-        hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)small_part, nb_c, wsum);
-        if (red_H > 1) {
-            hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_r, 1), dim3(kBlock), 0, bst, (const G1Jac*)rows, red_H - 1, g_small, small_part + 32);
-            hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)(small_part + 32), nb_r, wsum + 1);
+    const int per_result = grid_reduce ? 2 : 1;  // partial sums a result leaves in msm_host for the collect step's Horner
+    if ((size_t)per_result * (pair_shift ? 2 : 1) > kMsmHostEntries) return JOLT_ERR_UNSUPPORTED;
+    // bucket sums + reduction over the sorted lists against the tables at `bases`; the result's partial sums go to msm_host[lane][slot ..]
+    auto sums_and_reduction = [&](const G1Affine* bases, int slot) -> int32_t {
+        if (srs->pre_lform) {
+            hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+                               (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
+            hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
+                               (const uint32_t*)keys, bases, seg, lc);
         } else {
-            JOLT_HIP_TRY(ctx, hipMemsetAsync(wsum + 1, 0, sizeof(G1Jac), bst));
+            hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+                               (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
+            hipLaunchKernelGGL(k_fx_heavy_segments<false>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
+                               (const uint32_t*)keys, bases, seg, lc);
+        }
+        hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
+                           (const G1Jac*)seg, buckets);
+        if (grid_reduce) {
+            G1Jac* colpart = (G1Jac*)(ws + o_red);
+            G1Jac* rowpart = colpart + (size_t)red_chunks * kRedCols;
+            G1Jac* cols = rowpart + (size_t)red_H * red_per_row;  // C_l, l < 2^S
+            G1Jac* rows = cols + kRedCols;                         // R_h, h < H
+            G1Jac* small_part = rows + red_H;                      // block partials of the two small reductions
+            hipLaunchKernelGGL(k_fx_red_cols, dim3(kRedCols / kBlock, red_chunks), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, red_H, colpart);
+            hipLaunchKernelGGL(k_fx_red_rows, dim3((red_H * red_per_row + kBlock - 1) / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, red_H, rowpart);
+            hipLaunchKernelGGL(k_fx_red_fold, dim3(kRedCols * 64 / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)colpart, kRedCols, red_chunks, (size_t)kRedCols, (size_t)1, cols);
+            hipLaunchKernelGGL(k_fx_red_fold, dim3((red_H * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, bst, (const G1Jac*)rowpart, red_H, red_per_row, (size_t)1, (size_t)red_per_row, rows);
+            // sum_l l C_l (weights 1 .. 2^S - 1) and sum_h h R_h (weights 1 .. H - 1): index = weight, entry 0 unused -- the layout k_msm_window_reduce reads
+            const uint32_t g_small = 8, nb_c = (kRedCols / g_small + kBlock - 1) / kBlock, nb_r = (red_H / g_small + kBlock) / kBlock;
+            hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_c, 1), dim3(kBlock), 0, bst, (const G1Jac*)cols, kRedCols - 1, g_small, small_part);
+            hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)small_part, nb_c, wsum);
+            if (red_H > 1) {
+                hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb_r, 1), dim3(kBlock), 0, bst, (const G1Jac*)rows, red_H - 1, g_small, small_part + 32);
+                hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)(small_part + 32), nb_r, wsum + 1);
+            } else {
+                JOLT_HIP_TRY(ctx, hipMemsetAsync(wsum + 1, 0, sizeof(G1Jac), bst));
+            }
+        } else {
+            hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, G, part);
+            hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)part, nb, wsum);
         }
         JOLT_HIP_TRY(ctx, hipGetLastError());
-        JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, 2 * sizeof(G1Jac), hipMemcpyDeviceToHost, bst));
-        if (split) { JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][3], bst)); JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_phase[lane][3], 0)); }
-        job->n = n;
-        job->lane = lane;
-        job->c = kRedS;  // the collect step's Horner: 2^S * (row-weighted sum) + (column-weighted sum)
-        job->W = 2;
-        job->nb = nb;
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync((G1Jac*)ctx->msm_host[lane] + slot, wsum, (size_t)per_result * sizeof(G1Jac), hipMemcpyDeviceToHost, bst));
         return JOLT_OK;
+    };
+    JOLT_TRY(sums_and_reduction((const G1Affine*)srs->pre, 0));
+    if (pair_shift) {
+        JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), bst));  // empty buckets rely on the identity the first pass overwrote nowhere; light / heavy ones are rewritten
+        JOLT_TRY(sums_and_reduction((const G1Affine*)srs->pre + pair_shift, per_result));
     }
-    hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, 1), dim3(kBlock), 0, bst, (const G1Jac*)buckets, B, G, part);
-    hipLaunchKernelGGL(k_msm_window_combine, dim3(1), dim3(64), 0, bst, (const G1Jac*)part, nb, wsum);
-    JOLT_HIP_TRY(ctx, hipGetLastError());
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_host[lane], wsum, sizeof(G1Jac), hipMemcpyDeviceToHost, bst));
     if (split) { JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][3], bst)); JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_phase[lane][3], 0)); }
     job->n = n;
     job->lane = lane;
-    job->c = 0;  // a single "window": the collect step's Horner loop adds it once
-    job->W = 1;
+    job->c = grid_reduce ? kRedS : 0;  // the collect step's Horner: 2^S * (row-weighted sum) + (column-weighted sum); or a single "window"
+    job->W = per_result;
     job->nb = nb;
+    job->results = pair_shift ? 2 : 1;
     return JOLT_OK;
 }
 
