@@ -165,6 +165,32 @@ def test_hyperkzg_commit_open_bit_exact_with_oracle(ctx, ell):
     assert e.value.status == 9
 
 
+@pytest.mark.parametrize("ell,window_bits", [(2, 10), (3, 10), (7, 10), (10, 13)])
+def test_hyperkzg_open_with_window_tables_is_the_oracle_proof(ctx, ell, window_bits):
+    """with window tables over the SRS the opening takes the fixed-base method and commits the witness polynomials at r and -r as commit(X q) +- r commit(q) + alpha G_0
+    from ONE digit sort (hyperkzg.hip): the proof must be the one kzg.rs:108-116 computes from three independent commitments -- the oracle's, point for point"""
+    n = 1 << ell
+    beta = rand_fr(1, 700 + ell)[0]
+    host_srs = O.srs_setup_from_secret(beta, n + 1)
+    srs = ctx.srs_upload(host_srs)
+    ctx.srs_precompute_windows(srs, window_bits, 1)  # min_terms = 1: every MSM of the opening, the pair included, on the tables
+    for seed, small in ((710, False), (720, True)):
+        evals = rand_fr(n, seed + ell)
+        if small:  # 64-bit coefficients with repeats: the heavy-bucket path under both passes of the pair
+            evals = O.fr_from_u64(np.random.default_rng(seed).integers(0, 5, size=n).astype(np.uint64) * np.uint64(0x0123456789ABCDEF))
+        point = np.stack([rand_challenge(730 + k) for k in range(ell)])
+        tab = ctx.upload(evals)
+        got = ctx.hyperkzg_open(srs, tab, point, label=11)
+        want = O.hyperkzg_open(host_srs, evals, point, label=11)
+        assert np.array_equal(got["challenges"], want["challenges"])
+        assert np.array_equal(got["v"], want["v"])
+        for i in range(ell - 1):
+            assert same_point(got["com"][i], want["com"][i])
+        for t in range(3):
+            assert same_point(got["w"][t], want["w"][t]), (small, t)
+        tab.free()
+
+
 @pytest.mark.parametrize("log_n", [20, 22])
 def test_full_size_msm_is_the_kzg_commitment(ctx, log_n):
     """N = 2^20 / 2^22 terms (BASELINE configs[2] scale): commit(p) with bases beta^i*G must equal p(beta)*G
