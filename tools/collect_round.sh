@@ -46,6 +46,7 @@ JOLT_BENCH_PREFIXES="20 21 22 23 24 25" timeout 600 python tools/bench_msm_fixed
 JOLT_MSM_LANES=1 bash tools/prof_msm_fixed.sh 26 23 34 > "$OUT/msm_fixed_kernels.txt" 2>&1
 # the extended-stage operators part by part, the sumcheck legs per stage and per kernel
 timeout 300 python tools/time_extended.py 22 > "$OUT/extended_parts.txt" 2>&1
+bash tools/prof_extended.sh 22 70 > "$OUT/extended_kernel_stats.txt" 2>&1
 bash tools/prof_sumcheck.sh 22 "$TAG/sumcheck" > "$OUT/sumcheck.log" 2>&1
 # sharded paths with every rank on this GPU (code-path / memory checks, not measurements): bench.py --gpus 2 launching itself, the two-rank
 # 2^23-coefficient subtree opening against the oracle

@@ -14,6 +14,7 @@ keep seq_kernel_sums.txt step_kernel_sums_one_lane.txt
 keep msm_fixed.jsonl msm_fixed_base.jsonl
 keep msm_fixed_kernels.txt msm_fixed_base_kernels.txt
 keep extended_parts.txt extended_stage_parts.txt
+keep extended_kernel_stats.txt extended_kernel_stats.txt
 keep sumcheck/stage_times_22.txt sumcheck_stage_times_T22.txt
 keep sumcheck/sumcheck_kernel_stats_22.txt sumcheck_kernel_stats_T22.txt
 keep bench_gpus2_share_gpu.json bench_gpus2_share_gpu.json
