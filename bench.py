@@ -210,7 +210,7 @@ def cpu_baseline(log_t, srs_dev, with_pcs):
                 f"(signed-digit XYZZ bucket MSMs, all level / witness MSMs as one pool of window x chunk tasks; affine bases prepared outside the timed region; "
                 f"Horner / RLC passes OpenMP-parallel where the reference's kzg.rs:51-105 is serial)") if with_pcs else ""
     return {"value": round(reps * (1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
-            "sample": f"the same step at T=2^{log_t}: per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
+            "sample": f"the `--stages 2-6b` part of the step at T=2^{log_t} (the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators of the default step are NOT in this CPU sample: the GPU value covers more work per cycle): per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
                       f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs, ADX) with OpenMP on {best_n} of {hw} host threads "
                       f"(nproc {os.cpu_count()}; the fastest of {hw} / {max(1, hw // 2)} threads x bucket windows capped at 16 / 13 bits at T=2^{cal_scale}: {best_t:.2f} s per step there, cap {best_c}); {dt:.1f}s of CPU work: "
                       f"table builds {Sample.legs['tables']:.1f}s, sumcheck legs {Sample.legs['sumchecks']:.1f}s, commit + open {Sample.legs['pcs']:.1f}s",

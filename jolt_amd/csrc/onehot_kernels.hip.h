@@ -95,18 +95,32 @@ static __global__ __launch_bounds__(64) void k_onehot_pushforward_lanes(const ui
     __syncthreads();
     const uint8_t* col = idx + p * cycles;
     const size_t lo = slice * per_block, hi = lo + per_block < cycles ? lo + per_block : cycles;
-    for (size_t j = lo + lane; j < hi; j += 64) {
-        const uint8_t k = col[j];
-        if (k == kOneHotCold) continue;
-        const Fr x = ld_fr(w + j);
-        uint4* b0 = push_sh + ((uint32_t)k * 2) * 64 + lane;
-        uint4* b1 = b0 + 64;
-        uint4 a0 = *b0, a1 = *b1;
-        Fr acc;
-        acc.l[0] = a0.x; acc.l[1] = a0.y; acc.l[2] = a0.z; acc.l[3] = a0.w; acc.l[4] = a1.x; acc.l[5] = a1.y; acc.l[6] = a1.z; acc.l[7] = a1.w;
-        acc = add(acc, x);
-        *b0 = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
-        *b1 = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+    // four cycles per lane in flight: the index byte and the 32-byte weight of a cycle are global loads, the bucket update a dependent LDS read-modify-write;
+    // at 5 wavefronts per CU (the buckets' 32 KiB each) nothing else hides the loads
+    constexpr int kFlight = 4;
+    for (size_t j0 = lo + lane; j0 < hi; j0 += 64 * kFlight) {
+        uint8_t kk[kFlight];
+        Fr xx[kFlight];
+#pragma unroll
+        for (int q = 0; q < kFlight; ++q) {
+            const size_t j = j0 + 64 * (size_t)q;
+            kk[q] = j < hi ? col[j] : kOneHotCold;
+        }
+#pragma unroll
+        for (int q = 0; q < kFlight; ++q)
+            if (kk[q] != kOneHotCold) xx[q] = ld_fr(w + j0 + 64 * (size_t)q);
+#pragma unroll
+        for (int q = 0; q < kFlight; ++q) {
+            if (kk[q] == kOneHotCold) continue;
+            uint4* b0 = push_sh + ((uint32_t)kk[q] * 2) * 64 + lane;
+            uint4* b1 = b0 + 64;
+            uint4 a0 = *b0, a1 = *b1;
+            Fr acc;
+            acc.l[0] = a0.x; acc.l[1] = a0.y; acc.l[2] = a0.z; acc.l[3] = a0.w; acc.l[4] = a1.x; acc.l[5] = a1.y; acc.l[6] = a1.z; acc.l[7] = a1.w;
+            acc = add(acc, xx[q]);
+            *b0 = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
+            *b1 = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+        }
     }
     __syncthreads();
     auto load_lds = [&](uint32_t k, uint32_t l) {
