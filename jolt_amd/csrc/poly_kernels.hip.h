@@ -197,8 +197,9 @@ static __global__ __launch_bounds__(kBlock) void k_from_i64(const int64_t* __res
 }
 
 // ---- block-level reduction of NE field accumulators (wave64 shuffles, then LDS across the block's 4 waves) ----
+// block_reduce_store_at: the block's NE sums to dst[0 .. NE); block_reduce_store: to the slot of blockIdx.x
 template <int NE>
-__device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict__ partials) {
+__device__ __forceinline__ void block_reduce_store_at(Fr (&acc)[NE], Fr* __restrict__ dst) {
     __shared__ Fr sm[kBlock / 64][NE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -219,9 +220,13 @@ __device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict
     if (threadIdx.x < NE) {
         Fr s = sm[0][threadIdx.x];
         for (int w = 1; w < kBlock / 64; ++w) s = add(s, sm[w][threadIdx.x]);
-        st_fr_agent(partials + (size_t)blockIdx.x * NE + threadIdx.x, s);
+        st_fr_agent(dst + threadIdx.x, s);
         wait_stores_acked();  // acknowledged before the barrier in front of this workgroup's ticket (finish_member)
     }
+}
+template <int NE>
+__device__ __forceinline__ void block_reduce_store(Fr (&acc)[NE], Fr* __restrict__ partials) {
+    block_reduce_store_at<NE>(acc, partials + (size_t)blockIdx.x * NE);
 }
 
 // ---- in-kernel completion of a batch round ------------------------------------------------------------------------

@@ -52,6 +52,7 @@ struct jolt_read_raf {
     uint8_t* raf_sorted = nullptr;
     Fr *bin_raf = nullptr, *d_suffix = nullptr, *d_raf = nullptr;
     uint32_t* d_cfg = nullptr;
+    std::vector<uint32_t> cfg_host;  // what d_cfg holds
     size_t suffix_cap = 0, cfg_cap = 0;
     uint32_t* seg_start = nullptr;  // per bin: index of its first work item (a bin's rows are cut into items of kRafSegRows rows)
     Fr* part = nullptr;             // per work item: the 6 RAF sums, then one sum per suffix of the bin's table
@@ -358,7 +359,7 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
         cfg[n_tables + 1 + s] = suffix_kinds[s];
     }
     if (cfg.size() > rr->cfg_cap) {
-        if (rr->d_cfg) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(rr->d_cfg)); rr->d_cfg = nullptr; }
+        if (rr->d_cfg) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(rr->d_cfg)); rr->d_cfg = nullptr; rr->cfg_host.clear(); }
         JOLT_HIP_TRY(ctx, hipMalloc((void**)&rr->d_cfg, cfg.size() * 4));
         rr->cfg_cap = cfg.size();
     }
@@ -377,8 +378,11 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
         rr->part_cap = max_items * slots;
     }
     hipStream_t st = ctx->stream;
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(rr->d_cfg, cfg.data(), cfg.size() * 4, hipMemcpyHostToDevice, st));
-    JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));  // cfg is a local
+    if (cfg != rr->cfg_host) {  // every phase of a proof passes the same suffix lists: uploaded (and waited for: cfg is a local) only when they change
+        JOLT_HIP_TRY(ctx, hipMemcpyAsync(rr->d_cfg, cfg.data(), cfg.size() * 4, hipMemcpyHostToDevice, st));
+        JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
+        rr->cfg_host = cfg;
+    }
     const uint32_t B = (n_tables + 1) * kRafChunk;  // keys 1 .. B
     const size_t T = rr->cycles;
     JOLT_HIP_TRY(ctx, hipMemsetAsync(rr->hist, 0, ((size_t)B + 1) * 4, st));

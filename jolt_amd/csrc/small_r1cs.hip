@@ -51,15 +51,19 @@ __device__ __forceinline__ Fr fr_from_u256(const U256& x) {
 // wa / wb: [node][stream][1 + n] signed 64-bit integer weights (wave-uniform reads)
 template <int STREAMS>
 __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr* __restrict__ eq, size_t cycles, const int64_t* __restrict__ wa,
-                                                          const int64_t* __restrict__ wb, Fr* __restrict__ partials) {
-    const size_t node = blockIdx.y, stride_w = 1 + (size_t)in.n;
+                                                          const int64_t* __restrict__ wb, Fr* __restrict__ partials, uint32_t n_nodes, uint32_t n_slices) {
+    // workgroup b -> (slice of cycles, node) with b = slice_lo + 8 * (node + n_nodes * slice_hi): the blocks of ONE slice for all nodes are neighbours on the SAME XCD
+    // (workgroup b runs on XCD b mod 8), read the same columns at the same time and share them in that XCD's L2 instead of fetching them from HBM once per node
+    const uint32_t b = blockIdx.x, slice = (b & 7u) + 8u * (b / (8u * n_nodes));
+    const size_t node = (b >> 3) % n_nodes, stride_w = 1 + (size_t)in.n;
+    if (slice >= n_slices) return;  // block-uniform (the slice count is padded to a multiple of 8)
     const int64_t* a0 = wa + (node * STREAMS) * stride_w;
     const int64_t* a1 = a0 + (STREAMS - 1) * stride_w;  // STREAMS = 1 (product virtualization: no stream variable): stream 1 aliases stream 0 and is skipped
     const int64_t* b0 = wb + (node * STREAMS) * stride_w;
     const int64_t* b1 = b0 + (STREAMS - 1) * stride_w;
     Fr pos = Fr::zero(), neg_sum = Fr::zero();  // sums of eq * |Az * Bz| in PLAIN form (Montgomery eq x plain integer), by sign
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < cycles; t += stride) {
+    const size_t stride = (size_t)n_slices * kBlock;
+    for (size_t t = (size_t)slice * kBlock + threadIdx.x; t < cycles; t += stride) {
         __int128 az[2] = {(__int128)a0[0], (__int128)a1[0]};
         U256 bp[2] = {u256_zero(), u256_zero()}, bn[2] = {u256_zero(), u256_zero()};
         {
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr
         }
     }
     Fr acc[1] = {mul(sub(pos, neg_sum), Fr::r2())};  // plain -> Montgomery, once per thread
-    block_reduce_store<1>(acc, partials + node * gridDim.x);
+    block_reduce_store_at<1>(acc, partials + (node * n_slices + slice));
 }
 
 // ws[i] = w[i] * R (Montgomery form of w*R: REDC of sum ws*z lands in Montgomery form), nws[i] = -ws[i]; mask bit per weight != 0
@@ -225,12 +229,13 @@ extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* 
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 4));
     s = jolt_internal_ensure_scratch(ctx, n_nodes * (size_t)grid + 8, n_nodes + 8);
     if (s == JOLT_OK) {
+        const unsigned blocks = (unsigned)(((size_t)grid + 7) / 8 * 8 * n_nodes);
         if (n_streams == 2)
-            hipLaunchKernelGGL(k_small_uniskip<2>, dim3(grid, (unsigned)n_nodes), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
-                               (const int64_t*)wb, ctx->d_partials);
+            hipLaunchKernelGGL(k_small_uniskip<2>, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
+                               (const int64_t*)wb, ctx->d_partials, (uint32_t)n_nodes, (uint32_t)grid);
         else
-            hipLaunchKernelGGL(k_small_uniskip<1>, dim3(grid, (unsigned)n_nodes), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
-                               (const int64_t*)wb, ctx->d_partials);
+            hipLaunchKernelGGL(k_small_uniskip<1>, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
+                               (const int64_t*)wb, ctx->d_partials, (uint32_t)n_nodes, (uint32_t)grid);
         s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
     }
     if (s == JOLT_OK) s = reduce_rows_to_host(ctx, n_nodes, grid, 1, out);
