@@ -9,16 +9,21 @@
 // of W of them, so c can grow to 24 bits (W = 11 windows instead of 16 at c = 16: 31 % fewer point additions for 254-bit scalars)
 // and the host-side Horner over the windows disappears.  Cost: W copies of the bases in HBM (11 x 4 GiB for 2^26 points).
 //
-// Pipeline (integer VALU work, no MFMA):
-//   1. digits   : k_fx_digits -> keys[w*n + i] = |digit| | sign << 31 (scalars above r/2 negated, unsigned top window)
-//   2. partition: counting sort of the W*n keys by the high bits of |digit| (<= 16385 bins: per-workgroup LDS histograms, one global
-//                 atomic per non-empty bin and slice) into segments of 512 buckets; entries carry (low 9 bits, base index | sign)
-//   3. segments : ONE workgroup per segment sorts it by the low bits in LDS (histogram, scan, scatter) and emits the bucket table
-//   4. buckets  : k_msm_buckets_light / _heavy / _heavy_combine of the per-window method with one "window" of 2^(c-1) buckets and
-//                 the window tables as bases (a bucket kernel fused into step 3 measured 7x slower per addition and was dropped)
-//   5. reduce   : sum_b b * B_b by running sums over bucket ranges (k_msm_window_reduce / k_msm_window_combine, shared)
-// Skew needs no special casing: over-full buckets (the partial top window of 254-bit scalars, the carry window of 64-bit witness
-// scalars) go down the segmented heavy-bucket path exactly as in msm.hip.
+// Pipeline (integer VALU work, no MFMA; DESIGN.md 3.5c has the measurements):
+//   1. histogram: k_fx_hist_scalars -- the W signed c-bit digits of every scalar (scalars above r/2 negated, unsigned top window) recomputed from the scalar
+//                 itself and counted per SEGMENT of 256 buckets in per-workgroup LDS histograms; no key array (the 8-byte-entry path behind JOLT_FX_SOA=0
+//                 keeps k_fx_digits / k_fx_hist)
+//   2. partition: two coalesced passes -- groups of 128 segments straight from the scalars (k_fx_partition_groups_scalars), then the segments of each group
+//                 (k_fx_partition_segments_soa): a workgroup ranks a tile by bin with LDS atomics, lays it out bin-major in LDS and copies it out; entries travel
+//                 as 4-byte base index | sign plus one byte of bucket-in-segment
+//   3. segments : ONE workgroup per segment sorts it by bucket INSIDE the LDS of its CU and copies the sorted base indices out coalesced
+//                 (k_fx_segment_sort_staged), emitting the bucket table, the heavy list and the length classes
+//   4. order    : buckets handed out in order of decreasing list length (k_fx_order): a wavefront's lanes sum lists of equal length
+//   5. buckets  : one lane per bucket, XYZZ accumulator in limb form over the L-form tables (k_fx_buckets_ordered); over-full buckets (repeated scalars, the
+//                 carry window of 64-bit witness scalars) as segments of 128 entries, one lane each, folded per bucket (k_fx_heavy_segments / _combine)
+//   6. reduce   : sum_b b * B_b by rows and columns of the bucket matrix (k_fx_red_cols / _rows / _fold) and two small running-sum reductions
+// With pair_shift the phases 5-6 run twice over the same sorted lists, the second time against the tables moved by pair_shift points (two MSMs over one set of
+// scalars: the witness commitments at r and -r of a HyperKZG opening).
 #include <algorithm>
 
 #include "ctx.hpp"
