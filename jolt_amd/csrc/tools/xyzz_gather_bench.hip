@@ -94,6 +94,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     out[t] = acc;
 }
 
+// two accumulators per lane over ONE index list: table[idx] into the first, table[idx + 1] into the second (two MSMs over the same scalars and shifted bases:
+// the witness commitments at r and -r of an opening) -- one index load and one 128-byte gather for two additions
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_pair(const uint32_t* __restrict__ idx, const G1Affine* __restrict__ table, size_t threads,
+                                                                                              int len, G1XyzzL* __restrict__ out, Fq one_words) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= threads) return;
+    const FqL one = fql_from_words(one_words);
+    const uint32_t* src = idx + t * (size_t)len;
+    G1XyzzL acc0 = g1xl_identity(), acc1 = g1xl_identity();
+    G1Affine a = ld_aff(table + src[0]), b = ld_aff(table + src[0] + 1);
+    for (int j = 0; j < len; ++j) {
+        const G1Affine ca = a, cb = b;
+        if (j + 1 < len) {
+            const uint32_t v = src[j + 1];
+            a = ld_aff(table + v);
+            b = ld_aff(table + v + 1);
+        }
+        acc0 = g1xl_add_mixed(acc0, fql_from_words(ca.x), fql_from_words(ca.y), one);
+        acc1 = g1xl_add_mixed(acc1, fql_from_words(cb.x), fql_from_words(cb.y), one);
+    }
+    out[2 * t] = acc0;
+    out[2 * t + 1] = acc1;
+}
+
 template <int DEPTH, int MODE>
 void run(const char* what, const uint32_t* idx, const G1Affine* table, size_t threads, int len, G1XyzzL* out, Fq one_words, double table_gib) {
     hipEvent_t e0, e1;
@@ -148,6 +172,32 @@ int main() {
         run<1, 0>("gather by index", idx, table, threads, len, out, one_words, tab * 64.0 / (1 << 30));
         run<2, 0>("gather by index", idx, table, threads, len, out, one_words, tab * 64.0 / (1 << 30));
         run<0, 0>("gather by index, rotating queue (in_flight 0 = two points + index ahead)", idx, table, threads, len, out, one_words, tab * 64.0 / (1 << 30));
+    }
+    {
+        const size_t tab = max_table - 1;
+        hipLaunchKernelGGL(k_fill_idx, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, idx, n_idx, (uint64_t)tab, 0x5555ull);
+        CK(hipDeviceSynchronize());
+        G1XyzzL* out2;
+        const size_t th = threads / 2;  // the same number of additions per launch as the other runs
+        CK(hipMalloc(&out2, 2 * th * sizeof(G1XyzzL)));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const unsigned grid = (unsigned)((th + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_chain_pair, dim3(grid), dim3(kBlock), 0, 0, (const uint32_t*)idx, (const G1Affine*)table, th, len, out2, one_words);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_chain_pair, dim3(grid), dim3(kBlock), 0, 0, (const uint32_t*)idx, (const G1Affine*)table, th, len, out2, one_words);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= 3;
+        hipFuncAttributes fa;
+        CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_chain_pair)));
+        const double adds = 2.0 * th * len;
+        printf("{\"what\": \"gather by index, two accumulators over one list (table[i], table[i + 1])\", \"table_GiB\": %.2f, \"chain\": %d, \"lanes\": %zu, \"ms\": %.3f, \"G_adds_per_s\": %.2f, \"vgprs\": %d, \"scratch_bytes_per_thread\": %zu}\n",
+               tab * 64.0 / (1 << 30), len, th, ms, adds / ms * 1e-6, fa.numRegs, (size_t)fa.localSizeBytes);
     }
     return 0;
 }
