@@ -206,7 +206,11 @@ extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* 
     if (cycle_lo > cycle_hi || cycle_hi > T) return JOLT_ERR_SIZE_MISMATCH;
     if ((size_t)source->k * T > srs->n) return JOLT_ERR_SRS_TOO_SMALL;  // HyperKZGError::SrsTooSmall (kzg.rs:19-24)
     if (N > 65535) return JOLT_ERR_UNSUPPORTED;
-    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((cycle_hi - cycle_lo + kBlock - 1) / kBlock, kGridSumBlocks));
+    // lanes per column: every lane ends with an XYZZ -> Jacobian conversion and six shuffle rounds of full additions (~11 mixed additions' worth), so a lane should own
+    // >= 128 cycles (32 cycles per lane at T = 2^22 made that a third of the kernel); enough workgroups over all columns to fill the chip all the same
+    const size_t span = cycle_hi - cycle_lo;
+    const size_t by_work = (span + (size_t)kBlock * 128 - 1) / ((size_t)kBlock * 128), fill = ((size_t)ctx->num_cus * 8 + N - 1) / std::max<size_t>(N, 1);
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>({(span + kBlock - 1) / kBlock, std::max(by_work, fill), (size_t)kGridSumBlocks}));
     const uint32_t per_col = blocks * (kBlock / 64);
     G1Jac *partial = nullptr, *sums = nullptr;
     JOLT_TRY(jolt_internal_dev_alloc(ctx, N * per_col * sizeof(G1Jac), (void**)&partial));
