@@ -525,6 +525,27 @@ extern "C" int32_t jolt_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k,
 // prefix level (used by eq+1 and by the split-eq member's cached tables when step = 1).
 static int32_t eq_build(jolt_ctx* ctx, const Fr* r, size_t n, const Fr& scale, size_t step_vars, std::vector<jolt_table*>* levels,
                         jolt_table** out) {
+    if (levels && step_vars == 1 && n >= 1 && n <= (size_t)kEqLevelsMax) {  // every level of a short point: one launch (k_eq_levels)
+        EqLevels a;
+        a.n = (int)n;
+        const size_t first = levels->size();
+        for (size_t j = 0; j <= n; ++j) {
+            jolt_table* t = nullptr;
+            const int32_t s = jolt_internal_table_new(ctx, (size_t)1 << j, &t);
+            if (s != JOLT_OK) {
+                for (size_t k = first; k < levels->size(); ++k) jolt_table_free(ctx, (*levels)[k]);
+                levels->resize(first);
+                return s;
+            }
+            levels->push_back(t);
+            a.level[j] = t->data();
+            if (j < n) a.r[j] = r[j];
+        }
+        hipLaunchKernelGGL(k_eq_levels, dim3(1), dim3(kBlock), 0, ctx->stream, a, scale);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        *out = levels->back();
+        return JOLT_OK;
+    }
     jolt_table* cur = nullptr;
     JOLT_TRY(jolt_internal_table_new(ctx, 1, &cur));
     hipLaunchKernelGGL(k_fill_fr, dim3(1), dim3(64), 0, ctx->stream, cur->buf[0], scale, (size_t)1);  // by value: no host source to wait for

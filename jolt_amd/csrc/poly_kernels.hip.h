@@ -131,6 +131,32 @@ static __global__ __launch_bounds__(kBlock) void k_eq_expand(const Fr* __restric
     }
 }
 
+// evals_cached (crates/jolt-poly/src/eq.rs:317-340) for a SHORT point in ONE launch: levels[j] = eq over the first j coordinates, j = 0 .. n, each built from the one before by
+// the reference's doubling step (out[2x] = prev[x] (1 - r_j), out[2x + 1] = prev[x] r_j: big-endian), one workgroup, a barrier per level.  The split-eq members cache the levels
+// of their two half points (n <= 13): as n launches of k_eq_expand each these were ~200 tiny launches per proof.
+constexpr int kEqLevelsMax = 14;
+struct EqLevels {
+    Fr* level[kEqLevelsMax + 1];
+    Fr r[kEqLevelsMax];
+    int n;
+};
+static __global__ __launch_bounds__(kBlock) void k_eq_levels(EqLevels a, Fr scale) {
+    if (threadIdx.x == 0) st_fr(a.level[0], scale);
+    for (int j = 0; j < a.n; ++j) {
+        __threadfence_block();
+        __syncthreads();
+        const Fr* __restrict__ prev = a.level[j];
+        Fr* __restrict__ out = a.level[j + 1];
+        const Fr rj = a.r[j];
+        const size_t len = (size_t)1 << j;
+        for (size_t x = threadIdx.x; x < len; x += kBlock) {
+            const Fr p = ld_fr(prev + x), hi = mul(p, rj);
+            st_fr(out + 2 * x + 1, hi);
+            st_fr(out + 2 * x, sub(p, hi));
+        }
+    }
+}
+
 // LtPolynomial::evaluations (crates/jolt-poly/src/lt.rs:144-156) by the split identity the reference itself states
 // (lt.rs:19-21): with r = r_hi || r_lo,  LT(j_hi||j_lo, r) = LT(j_hi, r_hi) + eq(j_hi, r_hi) * LT(j_lo, r_lo).
 // out[x] = lt_hi[x>>c] + eq_hi[x>>c] * lt_lo[x & mask]; lt_lo (<= 256 entries) is built per block in LDS from
