@@ -396,7 +396,9 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
         for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+        ctx->msm_full_width_scalars = true;  // folds by challenges: uniform field elements whatever the committed polynomial held
         s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, coms.data());
+        ctx->msm_full_width_scalars = false;
         if (s != JOLT_OK) { cleanup(); return s; }
     }
     for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)

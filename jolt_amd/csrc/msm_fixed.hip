@@ -25,6 +25,7 @@
 // With pair_shift the phases 5-6 run twice over the same sorted lists, the second time against the tables moved by pair_shift points (two MSMs over one set of
 // scalars: the witness commitments at r and -r of a HyperKZG opening).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.hpp"
 #include "msm_kernels.hip.h"
@@ -851,9 +852,27 @@ __global__ __launch_bounds__(kBlock) void k_fx_to_lform(G1Affine* __restrict__ p
 // ------------------------------------------------------------------------------------------------------------------
 // precomputation
 // ------------------------------------------------------------------------------------------------------------------
+static int32_t fx_precompute_into(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms);
 extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms) {
     if (!ctx || !srs) return JOLT_ERR_INVALID_ARG;
     if (srs->pre) return JOLT_OK;
+    JOLT_TRY(fx_precompute_into(ctx, srs, window_bits, min_terms));
+    // the mid table set (srs.hpp): only next to a main set with the wide default windows over >= 2^25 points, whose own crossover lies above the mid set's
+    constexpr size_t kMidN = (size_t)1 << 23, kMidMin = (size_t)1 << 19;
+    const char* mid = std::getenv("JOLT_MSM_MID");
+    if (window_bits == 0 && srs->n >= 4 * kMidN && srs->pre_c >= 23 && srs->pre_min_n > kMidMin && !(mid && std::atoi(mid) == 0) && !srs->mid_tables) {
+        jolt_srs* mt = new (std::nothrow) jolt_srs();
+        if (!mt) return JOLT_ERR_OOM;
+        mt->ctx = ctx;
+        mt->pts = srs->pts;  // not owned
+        mt->n = kMidN;
+        const int32_t s = fx_precompute_into(ctx, mt, 20, kMidMin);
+        if (s != JOLT_OK) { delete mt; return s == JOLT_ERR_UNSUPPORTED ? JOLT_OK : s; }
+        srs->mid_tables = mt;
+    }
+    return JOLT_OK;
+}
+static int32_t fx_precompute_into(jolt_ctx* ctx, jolt_srs* srs, uint32_t window_bits, size_t min_terms) {
     if (srs->n == 0) return JOLT_ERR_INVALID_ARG;
     int lg = 0;
     while (((size_t)2 << lg) <= srs->n) lg++;
