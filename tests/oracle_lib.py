@@ -1122,3 +1122,49 @@ def read_raf_cycle_tables(lookup_index, table_index, raf_flag, table_values, raf
                                     _p(np.ascontiguousarray(raf_interleaved, dtype=np.uint64).reshape(4)), _p(np.ascontiguousarray(raf_identity, dtype=np.uint64).reshape(4)),
                                     _p(vt), C.c_uint32(vt.shape[0]), C.c_uint32(address_bits), C.c_uint32(ra_count), _p(combined), _p(ra))
     return combined, ra.reshape(ra_count, T, 4)
+
+
+# ---- lookup tables as full multilinear extensions and the address rounds from the definition (oracle/lookup_tables.c) ---------------------------
+TABLE_KINDS = ["RangeCheck", "RangeCheckAligned", "And", "Andn", "Or", "Xor", "Equal", "SignedGreaterThanEqual", "UnsignedGreaterThanEqual", "NotEqual", "SignedLessThan",
+               "UnsignedLessThan", "SignMask", "UpperWord", "UnsignedLessThanEqual", "ValidUnsignedRemainder", "ValidDiv0", "HalfwordAlignment", "WordAlignment", "LowerHalfWord",
+               "SignExtendWord", "Pow2", "Pow2W", "ShiftRightBitmask", "VirtualRev8W", "VirtualSRL", "VirtualSRA", "VirtualROTR", "VirtualROTRW", "VirtualChangeDivisor",
+               "VirtualChangeDivisorW", "MulUNoOverflow", "VirtualXORROT32", "VirtualXORROT24", "VirtualXORROT16", "VirtualXORROT63", "VirtualXORROTW16", "VirtualXORROTW12",
+               "VirtualXORROTW8", "VirtualXORROTW7", "WindowMaskW", "PextSigned"]  # enum LookupTableKind, tables/mod.rs:121-166
+
+
+def table_count():
+    lib().orc_table_count.restype = C.c_uint32
+    return int(lib().orc_table_count())
+
+
+def table_materialize_entry(kind, index):
+    lib().orc_table_materialize_entry.restype = C.c_uint64
+    return int(lib().orc_table_materialize_entry(C.c_uint32(kind), C.c_uint64(index & (2**64 - 1)), C.c_uint64(index >> 64)))
+
+
+def table_evaluate_mle(kind, r):
+    """r: (128, 4) Montgomery limbs, r[0] the variable of index bit 127"""
+    rr = np.ascontiguousarray(r, dtype=np.uint64).reshape(128, 4)
+    out = fr_array(1)
+    lib().orc_table_evaluate_mle(C.c_uint32(kind), _p(rr), _p(out))
+    return out[0]
+
+
+def read_raf_input_claim(lookup_index, table_index, raf_flag, u, gamma, canonical=False):
+    idx, tab, raf = _rr_args(lookup_index, table_index, raf_flag)
+    uu = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, 4)
+    out = fr_array(1)
+    lib().orc_read_raf_input_claim(_p(idx), _p(tab), _p(raf), C.c_size_t(idx.shape[0]), _p(uu), _p(np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4)),
+                                   C.c_int(1 if canonical else 0), _p(out))
+    return out[0]
+
+
+def read_raf_address_rounds(lookup_index, table_index, raf_flag, u, gamma, challenges, canonical=False):
+    """-> (evals (128, 3, 4): s_i(0), s_i(1), s_i(2); table_values (42, 4); operands (4, 4): left, right, identity, upper_all_ones at r_address)"""
+    idx, tab, raf = _rr_args(lookup_index, table_index, raf_flag)
+    uu = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, 4)
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(128, 4)
+    evals, tv, ops = fr_array(128 * 3), fr_array(len(TABLE_KINDS)), fr_array(4)
+    lib().orc_read_raf_address_rounds(_p(idx), _p(tab), _p(raf), C.c_size_t(idx.shape[0]), _p(uu), _p(np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4)),
+                                      C.c_int(1 if canonical else 0), _p(ch), _p(evals), _p(tv), _p(ops))
+    return evals.reshape(128, 3, 4), tv, ops
