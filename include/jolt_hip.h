@@ -533,6 +533,38 @@ int32_t jolt_read_raf_cycle_tables(jolt_ctx *ctx, jolt_read_raf *rr, const jolt_
 /* suffix_mle.hip.h (Suffixes::suffix_mle for the kind's discriminant) built for the host, for the CPU suite; bits are masked to `len`. */
 int32_t jolt_host_suffix_mle(uint32_t kind, uint64_t lo, uint64_t hi, uint32_t len, uint64_t *out);
 
+/* The address rounds of the same kernel (host code, no device work): the 256-entry prefix polynomials of a phase, the per-table `combine`, the four RAF
+ * decompositions, the round messages and binds, checkpoints.  Replaces instruction_read_raf.rs address_message (:973-1050), the address branch of bind
+ * (:1235-1282), the prefix half of init_phase (:824-898) and init_cycle_rounds' table values (:1140-1160), and what they call in jolt-lookup-tables:
+ * Prefixes::{default_checkpoint, evaluate} (tables/prefixes/mod.rs:236-250 + the 44 prefix files) and LookupTableKind::{prefixes, suffixes, combine}
+ * (tables/mod.rs:228-246 + the 42 table files).  Table / prefix / suffix ids are the discriminants of `enum LookupTableKind` (tables/mod.rs:121-166),
+ * `enum Prefixes` (prefixes/mod.rs:104-154) and `enum Suffixes`; XLEN = 64, phases of 8 address bits.
+ *   jolt_lookup_suffix_layout: offsets[43] / kinds[]: the suffix_offsets / suffix_kinds arguments of jolt_read_raf_phase_scan for n_tables = 42 real tables.
+ *   per phase p = 0 .. 15:  jolt_read_raf_phase_scan (device) -> jolt_host_read_raf_address_init_phase(p, raf_out, suffix_out) -> 8 x { message, bind };
+ *     message: evals_out = s(0), s(1) = previous_claim - s(0), s(2) (UnivariatePoly::from_evals order); bind: *phase_done = 1 after the 8th, when
+ *     jolt_host_read_raf_address_v_table(p) is eq(phase challenges, .) for jolt_read_raf_condense / jolt_read_raf_cycle_tables.
+ *   jolt_host_read_raf_address_finish: after phase 15: table_values[42], raf_interleaved, raf_identity = the arguments of jolt_read_raf_cycle_tables.
+ *   canonical != 0 is the `akita` feature's upper-all-ones term (CANONICAL_INSTRUCTION_ADDRESS).
+ * jolt_host_lookup_prefix_evaluate / jolt_host_lookup_table_combine expose the two building blocks for the decomposition test
+ * (tables/test_utils.rs prefix_suffix_test): b of b_len <= 16 bits (even), checkpoints / prefixes = all 49 slots. */
+typedef struct jolt_read_raf_address jolt_read_raf_address;
+uint32_t jolt_lookup_table_count(void);
+uint32_t jolt_lookup_prefix_count(void);
+int32_t jolt_lookup_table_suffixes(uint32_t kind, uint8_t *kinds_out /* <= 5 */, uint32_t *n_out);
+int32_t jolt_lookup_table_prefixes(uint32_t kind, uint8_t *prefixes_out /* <= 4 */, uint32_t *n_out);
+int32_t jolt_lookup_suffix_layout(uint32_t *offsets_out /* 43 */, uint8_t *kinds_out /* offsets_out[42]; may be NULL */);
+int32_t jolt_host_lookup_prefix_default_checkpoints(jolt_fr_t *out /* 49 */);
+int32_t jolt_host_lookup_prefix_evaluate(uint32_t prefix, const jolt_fr_t *checkpoints, uint32_t b, uint32_t b_len, uint32_t suffix_len, jolt_fr_t *out);
+int32_t jolt_host_lookup_prefix_table(uint32_t prefix, const jolt_fr_t *checkpoints, uint32_t b_len, uint32_t suffix_len, jolt_fr_t *out /* 2^b_len */);
+int32_t jolt_host_lookup_table_combine(uint32_t kind, const jolt_fr_t *prefixes, const jolt_fr_t *suffixes, jolt_fr_t *out);
+int32_t jolt_host_read_raf_address_create(const jolt_fr_t *gamma, const uint8_t *table_present /* 42 */, int32_t canonical, jolt_read_raf_address **out);
+int32_t jolt_host_read_raf_address_destroy(jolt_read_raf_address *h);
+int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address *h, uint32_t phase, const jolt_fr_t *raf_sums, const jolt_fr_t *suffix_sums);
+int32_t jolt_host_read_raf_address_message(const jolt_read_raf_address *h, const jolt_fr_t *previous_claim, jolt_fr_t *evals_out /* 3 */);
+int32_t jolt_host_read_raf_address_bind(jolt_read_raf_address *h, const jolt_fr_t *challenge, int32_t *phase_done);
+int32_t jolt_host_read_raf_address_v_table(const jolt_read_raf_address *h, uint32_t phase, jolt_fr_t *out /* 256 */);
+int32_t jolt_host_read_raf_address_finish(const jolt_read_raf_address *h, jolt_fr_t *table_values /* 42 */, jolt_fr_t *raf_interleaved, jolt_fr_t *raf_identity);
+
 /* Spartan outer (stage 1) T-scale sums -- SURVEY.md section 8(f) row 3 (crates/jolt-kernels/src/{reference,optimized}/spartan_outer.rs).
  * The constraint list, spartan_outer_row_weights and the Lagrange interpolation stay in Rust (O(rows) work); the caller folds the
  * per-(node, stream) row weights into per-column weights (ConstraintMatrices::weighted_columns + public_column_contributions,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libjolt_hip.so")
-SOURCES = ["capi.hip", "host_mirror.hip", "batch.hip", "views.hip", "msm.hip", "msm_fixed.hip", "hyperkzg.hip", "comm.hip", "onehot.hip", "dory.hip", "pcs.hip", "rw_matrix.hip", "r1cs.hip", "small_r1cs.hip", "read_raf.hip", "key_index.hip", "shm_exchange.hip"]
+SOURCES = ["capi.hip", "host_mirror.hip", "batch.hip", "views.hip", "msm.hip", "msm_fixed.hip", "hyperkzg.hip", "comm.hip", "onehot.hip", "dory.hip", "pcs.hip", "rw_matrix.hip", "r1cs.hip", "small_r1cs.hip", "read_raf.hip", "key_index.hip", "shm_exchange.hip", "read_raf_address.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("JOLT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DJOLT_BUCKET_WAVES=2 for A/B builds
 

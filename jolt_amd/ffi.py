@@ -1382,3 +1382,95 @@ def host_small_scalar_dot(values, scalars):
     o = fr_array(1)
     _ck(lib().jolt_host_small_scalar_dot(_p(v), sc.ctypes.data_as(C.c_void_p), C.c_size_t(v.shape[0]), _p(o)), "jolt_host_small_scalar_dot")
     return o[0]
+
+
+# ---- instruction read+RAF: the address rounds on the host (read_raf_address.hip, lookup_tables.hpp) ---------------------------------------------------------
+NUM_LOOKUP_TABLES, NUM_LOOKUP_PREFIXES = 42, 49
+
+
+def lookup_table_suffixes(kind):
+    out, n = np.zeros(8, dtype=np.uint8), C.c_uint32()
+    _ck(lib().jolt_lookup_table_suffixes(C.c_uint32(kind), _p(out), C.byref(n)), "jolt_lookup_table_suffixes")
+    return [int(k) for k in out[: n.value]]
+
+
+def lookup_table_prefixes(kind):
+    out, n = np.zeros(8, dtype=np.uint8), C.c_uint32()
+    _ck(lib().jolt_lookup_table_prefixes(C.c_uint32(kind), _p(out), C.byref(n)), "jolt_lookup_table_prefixes")
+    return [int(k) for k in out[: n.value]]
+
+
+def lookup_suffix_lists():
+    """LookupTableKind::suffixes() of the 42 tables: the suffix_lists argument of ReadRaf.phase_scan for real tables"""
+    offs = np.zeros(NUM_LOOKUP_TABLES + 1, dtype=np.uint32)
+    _ck(lib().jolt_lookup_suffix_layout(_p(offs), None), "jolt_lookup_suffix_layout")
+    kinds = np.zeros(int(offs[-1]), dtype=np.uint8)
+    _ck(lib().jolt_lookup_suffix_layout(_p(offs), _p(kinds)), "jolt_lookup_suffix_layout")
+    return [[int(k) for k in kinds[offs[t]: offs[t + 1]]] for t in range(NUM_LOOKUP_TABLES)]
+
+
+def host_lookup_prefix_default_checkpoints():
+    out = fr_array(NUM_LOOKUP_PREFIXES)
+    _ck(lib().jolt_host_lookup_prefix_default_checkpoints(_p(out)), "jolt_host_lookup_prefix_default_checkpoints")
+    return out
+
+
+def host_lookup_prefix_evaluate(prefix, checkpoints, b, b_len, suffix_len):
+    out = fr_array(1)
+    _ck(lib().jolt_host_lookup_prefix_evaluate(C.c_uint32(prefix), _p(fr(checkpoints).reshape(NUM_LOOKUP_PREFIXES, 4)), C.c_uint32(b), C.c_uint32(b_len), C.c_uint32(suffix_len),
+                                               _p(out)), "jolt_host_lookup_prefix_evaluate")
+    return out[0]
+
+
+def host_lookup_prefix_table(prefix, checkpoints, b_len, suffix_len):
+    out = fr_array(1 << b_len)
+    _ck(lib().jolt_host_lookup_prefix_table(C.c_uint32(prefix), _p(fr(checkpoints).reshape(NUM_LOOKUP_PREFIXES, 4)), C.c_uint32(b_len), C.c_uint32(suffix_len), _p(out)),
+        "jolt_host_lookup_prefix_table")
+    return out
+
+
+def host_lookup_table_combine(kind, prefixes, suffixes):
+    out = fr_array(1)
+    _ck(lib().jolt_host_lookup_table_combine(C.c_uint32(kind), _p(fr(prefixes).reshape(NUM_LOOKUP_PREFIXES, 4)), _p(fr(suffixes).reshape(-1, 4)), _p(out)),
+        "jolt_host_lookup_table_combine")
+    return out[0]
+
+
+class HostReadRafAddress:
+    """The 256-entry state of the 16 address phases (jolt_host_read_raf_address_*): prefix polynomials, suffix accumulators, RAF decompositions, checkpoints"""
+
+    def __init__(self, gamma, table_present, canonical=False):
+        present = np.zeros(NUM_LOOKUP_TABLES, dtype=np.uint8)
+        present[: len(table_present)] = np.asarray(table_present, dtype=np.uint8)
+        h = C.c_void_p()
+        _ck(lib().jolt_host_read_raf_address_create(_p(fr(gamma).reshape(4)), _p(present), C.c_int32(1 if canonical else 0), C.byref(h)), "jolt_host_read_raf_address_create")
+        self.h = h
+
+    def init_phase(self, phase, raf_sums, suffix_sums):
+        _ck(lib().jolt_host_read_raf_address_init_phase(self.h, C.c_uint32(phase), _p(fr(raf_sums).reshape(6 * 256, 4)), _p(fr(suffix_sums).reshape(-1, 4))),
+            "jolt_host_read_raf_address_init_phase")
+
+    def message(self, previous_claim):
+        o = fr_array(3)
+        _ck(lib().jolt_host_read_raf_address_message(self.h, _p(fr(previous_claim).reshape(4)), _p(o)), "jolt_host_read_raf_address_message")
+        return o
+
+    def bind(self, r):
+        done = C.c_int32()
+        _ck(lib().jolt_host_read_raf_address_bind(self.h, _p(fr(r).reshape(4)), C.byref(done)), "jolt_host_read_raf_address_bind")
+        return bool(done.value)
+
+    def v_table(self, phase):
+        o = fr_array(256)
+        _ck(lib().jolt_host_read_raf_address_v_table(self.h, C.c_uint32(phase), _p(o)), "jolt_host_read_raf_address_v_table")
+        return o
+
+    def finish(self):
+        tv, a, b = fr_array(NUM_LOOKUP_TABLES), fr_array(1), fr_array(1)
+        _ck(lib().jolt_host_read_raf_address_finish(self.h, _p(tv), _p(a), _p(b)), "jolt_host_read_raf_address_finish")
+        return tv, a[0], b[0]
+
+    def close(self):
+        if self.h:
+            lib().jolt_host_read_raf_address_destroy(self.h)
+            self.h = None

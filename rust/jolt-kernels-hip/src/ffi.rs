@@ -41,6 +41,10 @@ pub struct jolt_srs {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct jolt_host_transcript {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct jolt_batch {
     _private: [u8; 0],
 }
@@ -61,15 +65,27 @@ pub struct jolt_ints {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct jolt_read_raf {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_read_raf_address {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_rw_matrix {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct jolt_key_index {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct jolt_comm {
     _private: [u8; 0],
 }
 #[repr(C)]
 pub struct jolt_shm {
-    _private: [u8; 0],
-}
-#[repr(C)]
-pub struct jolt_rw_matrix {
     _private: [u8; 0],
 }
 
@@ -267,6 +283,22 @@ extern "C" {
     pub fn jolt_read_raf_condense(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, u: *mut jolt_table, v_table: *const jolt_fr_t, shift: u32) -> i32;
     pub fn jolt_read_raf_cycle_tables(ctx: *mut jolt_ctx, rr: *mut jolt_read_raf, table_values: *const jolt_fr_t, raf_interleaved: *const jolt_fr_t, raf_identity: *const jolt_fr_t, v_tables: *const jolt_fr_t, phases: u32, address_bits: u32, ra_count: u32, combined_out: *mut *mut jolt_table, ra_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_host_suffix_mle(kind: u32, lo: u64, hi: u64, len: u32, out: *mut u64) -> i32;
+    pub fn jolt_lookup_table_count() -> u32;
+    pub fn jolt_lookup_prefix_count() -> u32;
+    pub fn jolt_lookup_table_suffixes(kind: u32, kinds_out: *mut u8, n_out: *mut u32) -> i32;
+    pub fn jolt_lookup_table_prefixes(kind: u32, prefixes_out: *mut u8, n_out: *mut u32) -> i32;
+    pub fn jolt_lookup_suffix_layout(offsets_out: *mut u32, kinds_out: *mut u8) -> i32;
+    pub fn jolt_host_lookup_prefix_default_checkpoints(out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_lookup_prefix_evaluate(prefix: u32, checkpoints: *const jolt_fr_t, b: u32, b_len: u32, suffix_len: u32, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_lookup_prefix_table(prefix: u32, checkpoints: *const jolt_fr_t, b_len: u32, suffix_len: u32, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_lookup_table_combine(kind: u32, prefixes: *const jolt_fr_t, suffixes: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_read_raf_address_create(gamma: *const jolt_fr_t, table_present: *const u8, canonical: i32, out: *mut *mut jolt_read_raf_address) -> i32;
+    pub fn jolt_host_read_raf_address_destroy(h: *mut jolt_read_raf_address) -> i32;
+    pub fn jolt_host_read_raf_address_init_phase(h: *mut jolt_read_raf_address, phase: u32, raf_sums: *const jolt_fr_t, suffix_sums: *const jolt_fr_t) -> i32;
+    pub fn jolt_host_read_raf_address_message(h: *const jolt_read_raf_address, previous_claim: *const jolt_fr_t, evals_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_read_raf_address_bind(h: *mut jolt_read_raf_address, challenge: *const jolt_fr_t, phase_done: *mut i32) -> i32;
+    pub fn jolt_host_read_raf_address_v_table(h: *const jolt_read_raf_address, phase: u32, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_read_raf_address_finish(h: *const jolt_read_raf_address, table_values: *mut jolt_fr_t, raf_interleaved: *mut jolt_fr_t, raf_identity: *mut jolt_fr_t) -> i32;
     pub fn jolt_r1cs_uniskip_sums(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, eq: *const jolt_table, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, n_nodes: usize, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_r1cs_materialize(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, az_out: *mut *mut jolt_table, bz_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_tables_evaluate(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, k: usize, point: *const jolt_fr_t, n: usize, out: *mut jolt_fr_t) -> i32;

@@ -1,0 +1,166 @@
+"""CPU suite for the host half of instruction read+RAF checking (jolt_amd/csrc/read_raf_address.hip, lookup_tables.hpp): no device needed.
+
+* `test_prefix_suffix_decomposition` is the reference's prefix_suffix_test (crates/jolt-lookup-tables/src/tables/test_utils.rs:86-200) with the PRODUCT's prefix
+  polynomials, suffix polynomials and `combine` on one side and the ORACLE's evaluate_mle on the other, for all 42 tables, phases of 16 and 8 bits (and 2 for
+  the table the reference also runs at 2).
+* `test_address_rounds_*` drive the product's address-round state machine through all 128 rounds with the reference kernel's own recipe
+  (instruction_read_raf.rs:1477-1522, 1579-1636) and compare every round polynomial with the oracle's from-the-definition rounds.  The T-scale sums the
+  device would produce are taken from the oracle's scan here (tests/test_gpu_read_raf.py runs the same loop with the device's)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from jolt_amd import ffi
+from lookup_table_fixture import TABLES, all_table_rows, challenge, fixture_rows, random_index
+
+R = O.R_MOD
+ADDRESS_BITS = 128
+RINV = pow(O.MONT_R, -1, R)
+
+
+def fr_int(v):
+    a = np.asarray(v, dtype=np.uint64).reshape(-1, 4)
+    return [(int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) | (int(r[3]) << 192)) * RINV % R for r in a]
+
+
+def mont(values):
+    return O.to_mont([v % R for v in values])
+
+
+def test_registry_follows_the_enums():
+    assert ffi.lib().jolt_lookup_table_count() == 42 and ffi.lib().jolt_lookup_prefix_count() == 49
+    lists = ffi.lookup_suffix_lists()
+    assert lists[0] == [0, 10] and lists[6] == [14] and lists[27] == [24, 23, 26, 0]  # RangeCheck, Equal, VirtualROTR (tables/*.rs `suffixes()`)
+    assert ffi.lookup_table_prefixes(7) == [12, 11, 8, 3]  # SignedGreaterThanEqual: RightOperandMsb, LeftOperandMsb, LessThan, Eq
+    cp = fr_int(ffi.host_lookup_prefix_default_checkpoints())
+    ones = {3, 9, 10, 13, 14, 16, 17, 19, 20, 21, 26, 27, 28, 35, 37, 46}
+    for p in range(49):
+        want = 1 if p in ones else ((2 - (1 << 64)) % R if p == 29 else 0)
+        assert cp[p] == want, p
+
+
+def decomposition_run(kind, rounds_per_phase, lookup_index, rng):
+    """one lookup index through all phases: at every round and c in {0, 2}: combine(prefixes at (r, c, b), suffixes) == evaluate_mle(r, c, b, suffix bits).
+    As in the kernel (instruction_read_raf.rs:683-697, 878-897) only the prefixes the table lists are materialised; the other checkpoints keep their defaults."""
+    suffix_kinds = ffi.lookup_suffix_lists()[kind]
+    used = ffi.lookup_table_prefixes(kind)
+    checkpoints = fr_int(ffi.host_lookup_prefix_default_checkpoints())
+    r_int = []
+    size = 1 << rounds_per_phase
+    for phase in range(ADDRESS_BITS // rounds_per_phase):
+        suffix_len = ADDRESS_BITS - (phase + 1) * rounds_per_phase
+        suffix_bits = lookup_index & ((1 << suffix_len) - 1)
+        chunk = (lookup_index >> suffix_len) & (size - 1)
+        cp = mont(checkpoints)
+        tables = {p: fr_int(ffi.host_lookup_prefix_table(p, cp, rounds_per_phase, suffix_len)) for p in used}
+        suffix_evals = mont([ffi.host_suffix_mle(k, suffix_bits, suffix_len) for k in suffix_kinds])
+        for rnd in range(rounds_per_phase):
+            remaining = rounds_per_phase - rnd - 1
+            half = 1 << remaining
+            b = chunk & (half - 1)
+            for c in (0, 2):
+                prefix_evals = list(checkpoints)
+                for p, t in tables.items():
+                    prefix_evals[p] = t[b] if c == 0 else (2 * t[b + half] - t[b]) % R
+                point = r_int + [c] + [(b >> (remaining - 1 - i)) & 1 for i in range(remaining)] + [(suffix_bits >> (suffix_len - 1 - i)) & 1 for i in range(suffix_len)]
+                combined = fr_int(ffi.host_lookup_table_combine(kind, mont(prefix_evals), suffix_evals))[0]
+                expected = fr_int(O.table_evaluate_mle(kind, mont(point)))[0]
+                assert combined == expected, (TABLES[kind], rounds_per_phase, phase, rnd, c, hex(lookup_index))
+            r_round = int(rng.integers(0, 2**64, dtype=np.uint64))
+            r_int.append(r_round)
+            tables = {p: [(t[i] + r_round * (t[i + half] - t[i])) % R for i in range(half)] for p, t in tables.items()}
+        for p, t in tables.items():
+            checkpoints[p] = t[0]
+
+
+@pytest.mark.parametrize("kind", range(42))
+def test_prefix_suffix_decomposition(kind):
+    rng = np.random.default_rng(12345 + kind)
+    decomposition_run(kind, 8, random_index(TABLES[kind], rng), rng)
+    decomposition_run(kind, 8, random_index(TABLES[kind], rng), rng)
+
+
+@pytest.mark.parametrize("kind", [0, 7, 15, 16, 20, 23, 24, 26, 27, 28, 29, 30, 35, 39, 40, 41])
+def test_prefix_suffix_decomposition_wide_phases(kind):
+    rng = np.random.default_rng(777 + kind)
+    decomposition_run(kind, 16, random_index(TABLES[kind], rng), rng)
+
+
+def test_prefix_suffix_decomposition_small_phases():
+    rng = np.random.default_rng(5)
+    decomposition_run(40, 2, random_index("WindowMaskW", rng), rng)  # window_mask_w.rs:88-91: phase boundaries inside the bits the prefix reads
+
+
+def product_address_rounds(idx, tab, raf, u, gamma, canonical, challenges, claim, scan):
+    """the product's address-round state machine; `scan(u, suffix_len)` -> (raf sums, suffix sums), `condense` as the device does it.
+    -> (evals (128, 3) ints, v_tables, (table_values, raf_interleaved, raf_identity))"""
+    present = np.zeros(42, dtype=np.uint8)
+    for t in tab:
+        if t != 0xFF:
+            present[t] = 1
+    state = ffi.HostReadRafAddress(gamma, present, canonical)
+    evals, v_tables = [], []
+    u = np.array(u, dtype=np.uint64)
+    for phase in range(16):
+        suffix_len = ADDRESS_BITS - 8 * (phase + 1)
+        if phase:
+            u = O.read_raf_condense(idx, u, v_tables[-1], suffix_len + 8)
+        raf_sums, suffix_sums = scan(u, suffix_len)
+        state.init_phase(phase, raf_sums, suffix_sums)
+        for rnd in range(8):
+            e = fr_int(state.message(mont([claim])[0]))
+            evals.append(e)
+            r = challenges[8 * phase + rnd]
+            inv2 = pow(2, -1, R)
+            a = (e[2] - 2 * e[1] + e[0]) * inv2 % R
+            claim = (a * r * r + (e[1] - e[0] - a) * r + e[0]) % R
+            done = state.bind(mont([r])[0])
+            assert done == (rnd == 7)
+        v_tables.append(state.v_table(phase))
+    out = state.finish()
+    state.close()
+    return evals, np.stack(v_tables), out, claim
+
+
+def check_against_the_definition(idx, tab, raf, log_t, gamma_int, canonical, r_reduction):
+    lists = ffi.lookup_suffix_lists()
+    u = O.eq_evals(mont(r_reduction))
+    gamma = mont([gamma_int])[0]
+    challenges = [challenge(i) for i in range(128)]
+    claim = fr_int(O.read_raf_input_claim(idx, tab, raf, u, gamma, canonical=canonical))[0]
+    scan = lambda uu, suffix_len: O.read_raf_phase_scan(idx, tab, raf, 42, uu, suffix_len, ADDRESS_BITS, lists, canonical=canonical)
+    evals, v_tables, (tv, raf_interleaved, raf_identity), final_claim = product_address_rounds(idx, tab, raf, u, gamma, canonical, challenges, claim, scan)
+    want, want_tv, ops = O.read_raf_address_rounds(idx, tab, raf, u, gamma, mont(challenges), canonical=canonical)
+    for i in range(128):
+        assert evals[i] == fr_int(want[i]), i
+    present = sorted(set(int(t) for t in tab if t != 0xFF))
+    got_tv, want_tv = fr_int(tv), fr_int(want_tv)
+    for t in present:
+        assert got_tv[t] == want_tv[t], TABLES[t]
+    left, right, identity, upper = fr_int(ops)
+    g = gamma_int
+    assert fr_int(raf_interleaved)[0] == (g * left + g * g * right) % R
+    assert fr_int(raf_identity)[0] == (g * g * identity + (g * g * g * upper if canonical else 0)) % R
+    # the phase eq tables are eq(phase challenges, .)
+    for phase in range(16):
+        assert fr_int(v_tables[phase]) == fr_int(O.eq_evals(mont(challenges[8 * phase: 8 * phase + 8])))
+    return final_claim
+
+
+@pytest.mark.parametrize("log_t,seed,canonical", [(4, 12345, False), (3, 67890, False), (4, 12345, True)])
+def test_address_rounds_reference_recipe(log_t, seed, canonical):
+    """parity_default_geometry / parity_wide_virtual_chunks_and_odd_log_t (instruction_read_raf.rs:1638-1646): same rows, reduction point, gamma, challenges"""
+    idx, tab, raf = fixture_rows(log_t, seed)
+    check_against_the_definition(idx, tab, raf, log_t, 0xACE157EF, canonical, [1000 + 37 * i for i in range(log_t)])
+
+
+def test_address_rounds_all_raf_rows():
+    """parity_all_raf_rows (:1650-1685): the identity path is the entire RAF summand"""
+    idx, tab, raf = fixture_rows(3, 555, all_raf=True)
+    check_against_the_definition(idx, tab, raf, 3, 0xBEEF, True, [2000 + 11 * i for i in range(3)])
+
+
+def test_address_rounds_every_table_present():
+    idx, tab, raf = all_table_rows(7, 11)
+    assert set(int(t) for t in tab if t != 0xFF) == set(range(42))
+    check_against_the_definition(idx, tab, raf, 7, 0xACE157EF, False, [1000 + 37 * i for i in range(7)])

@@ -18,7 +18,11 @@ FFI_RS = os.path.join(ROOT, "rust", "jolt-kernels-hip", "src", "ffi.rs")
 
 SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "size_t": "usize", "float": "f32",
            "void": "c_void", "char": "c_char"}
-OPAQUE = ["jolt_ctx", "jolt_table", "jolt_member", "jolt_srs", "jolt_batch", "jolt_split_lt", "jolt_onehot", "jolt_rows", "jolt_ints", "jolt_comm", "jolt_shm", "jolt_rw_matrix"]
+def opaque_handles(path=None):
+    """every `typedef struct X X;` of the header, in declaration order: the handle types ffi.rs must define (a hand-kept list went stale in round 3)"""
+    return re.findall(r"typedef\s+struct\s+(jolt_\w+)\s+\1\s*;", open(path or HEADER).read())
+
+
 FNPTR = {"jolt_local_round_fn", "jolt_gather_fn", "jolt_round_transcript_fn"}
 
 
@@ -113,7 +117,7 @@ def render(decls):
     out.append("#[repr(C)]\n#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]\npub struct jolt_fr_t {\n    pub l: [u64; 4],\n}")
     out.append("#[repr(C)]\n#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]\npub struct jolt_fq_t {\n    pub l: [u64; 4],\n}")
     out.append("#[repr(C)]\n#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]\npub struct jolt_g1_t {\n    pub x: jolt_fq_t,\n    pub y: jolt_fq_t,\n    pub z: jolt_fq_t,\n}")
-    for o in OPAQUE:
+    for o in opaque_handles():
         out.append(f"#[repr(C)]\npub struct {o} {{\n    _private: [u8; 0],\n}}")
     out.append("")
     out.append("/// Status codes (`enum` of the header); see `crate::status` for the mapping onto the reference's error types.")
