@@ -543,6 +543,9 @@ int32_t jolt_host_suffix_mle(uint32_t kind, uint64_t lo, uint64_t hi, uint32_t l
  *   per phase p = 0 .. 15:  jolt_read_raf_phase_scan (device) -> jolt_host_read_raf_address_init_phase(p, raf_out, suffix_out) -> 8 x { message, bind };
  *     message: evals_out = s(0), s(1) = previous_claim - s(0), s(2) (UnivariatePoly::from_evals order); bind: *phase_done = 1 after the 8th, when
  *     jolt_host_read_raf_address_v_table(p) is eq(phase challenges, .) for jolt_read_raf_condense / jolt_read_raf_cycle_tables.
+ *     message with previous_claim == NULL sums s(1) from the tables: in round 0, s(0) + s(1) is then the relation's input claim.
+ *   jolt_host_read_raf_address_prove_phase: the 8 rounds of the open phase in one call (message -> from_evals coefficients c0, c1, c2 -> transcript ->
+ *     bind); the transcript is the caller's jolt_round_transcript_fn or, with fn == NULL, the library's TEST transcript (append c0..c2, Transcript::challenge).
  *   jolt_host_read_raf_address_finish: after phase 15: table_values[42], raf_interleaved, raf_identity = the arguments of jolt_read_raf_cycle_tables.
  *   canonical != 0 is the `akita` feature's upper-all-ones term (CANONICAL_INSTRUCTION_ADDRESS).
  * jolt_host_lookup_prefix_evaluate / jolt_host_lookup_table_combine expose the two building blocks for the decomposition test
@@ -560,8 +563,10 @@ int32_t jolt_host_lookup_table_combine(uint32_t kind, const jolt_fr_t *prefixes,
 int32_t jolt_host_read_raf_address_create(const jolt_fr_t *gamma, const uint8_t *table_present /* 42 */, int32_t canonical, jolt_read_raf_address **out);
 int32_t jolt_host_read_raf_address_destroy(jolt_read_raf_address *h);
 int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address *h, uint32_t phase, const jolt_fr_t *raf_sums, const jolt_fr_t *suffix_sums);
-int32_t jolt_host_read_raf_address_message(const jolt_read_raf_address *h, const jolt_fr_t *previous_claim, jolt_fr_t *evals_out /* 3 */);
+int32_t jolt_host_read_raf_address_message(jolt_read_raf_address *h, const jolt_fr_t *previous_claim, jolt_fr_t *evals_out /* 3 */);
 int32_t jolt_host_read_raf_address_bind(jolt_read_raf_address *h, const jolt_fr_t *challenge, int32_t *phase_done);
+int32_t jolt_host_read_raf_address_prove_phase(jolt_read_raf_address *h, jolt_fr_t *claim, jolt_round_transcript_fn fn, void *user, jolt_host_transcript *test_transcript,
+                                               jolt_fr_t *coeffs_out /* 8 x 3; may be NULL */, jolt_fr_t *challenges_out /* 8; may be NULL */);
 int32_t jolt_host_read_raf_address_v_table(const jolt_read_raf_address *h, uint32_t phase, jolt_fr_t *out /* 256 */);
 int32_t jolt_host_read_raf_address_finish(const jolt_read_raf_address *h, jolt_fr_t *table_values /* 42 */, jolt_fr_t *raf_interleaved, jolt_fr_t *raf_identity);
 

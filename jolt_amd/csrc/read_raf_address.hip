@@ -7,9 +7,24 @@
 //   bind (:1235-1282)            HighToLow bind of every 256-entry polynomial; after 8 binds the phase's eq table and the new checkpoints
 //   init_cycle_rounds (:1140-1160)  table values, gamma-combined operand values for jolt_read_raf_cycle_tables
 // Per proof this is 128 rounds of O(256 x present tables) field work -- no T-sized data -- which is why it stays on the host (the reference keeps
-// it in one rayon task per 8 entries); the device part of a phase is one scan launch + one condensation.  Nothing here touches the device.
+// it in rayon tasks of 8 entries); the device part of a phase is one scan launch + one condensation.  Nothing here touches the device.
+//
+// Cost shape (all 42 tables present): per phase ~30 prefix + 94 suffix + 12 RAF polynomials of 256 entries; a round is ~60 dot products over the live half
+// (the bilinear terms of the tables' `combine`, summed term by term instead of table by table: a table's value is never formed per entry) and ~136 binds.
+// 64-bit-limb Montgomery arithmetic (x86 has the 64 x 64 -> 128 multiplier), one reduction per dot product, and SHARDS: the present tables are dealt out to a
+// handful of worker threads, each owning its tables' suffix polynomials, private copies of the prefix polynomials they read and their terms, so that a round
+// is ONE hand-off (bind with the previous challenge + extensions + partial sums) instead of three.
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <future>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -18,58 +33,265 @@
 using jolt::Fr;
 using namespace jolt_lookup;
 
+
 namespace {
 
-constexpr uint32_t kChunkLen = 8, kChunkSize = 1u << kChunkLen;
+constexpr uint32_t kChunkLen = 8, kChunkSize = 1u << kChunkLen, kPhases = (uint32_t)kLogK / kChunkLen;
+typedef unsigned __int128 u128;
 
-// prefix * q_shift + q_value, each a 256-entry polynomial of the chunk (instruction_read_raf.rs:387-445)
-struct RafDecomposition {
-    std::vector<Fr> prefix, q_shift, q_value;
-    Fr checkpoint;
-    void message(size_t b, size_t half, Fr& at0, Fr& at2) const {
-        const Fr p2 = jolt::sub(jolt::dbl(prefix[b + half]), prefix[b]), s2 = jolt::sub(jolt::dbl(q_shift[b + half]), q_shift[b]),
-                 v2 = jolt::sub(jolt::dbl(q_value[b + half]), q_value[b]);
-        at0 = jolt::add(jolt::mul(prefix[b], q_shift[b]), q_value[b]);
-        at2 = jolt::add(jolt::mul(p2, s2), v2);
+// ---- BN254 Fr on four 64-bit limbs (Montgomery form, canonical; the bytes of jolt_fr_t / jolt::Fr) ----
+struct F { uint64_t l[4]; };
+constexpr uint64_t kP[4] = {0x43E1F593F0000001ull, 0x2833E84879B97091ull, 0xB85045B68181585Dull, 0x30644E72E131A029ull};
+constexpr uint64_t kNegInv = 0xC2E1F593EFFFFFFFull;  // -p^-1 mod 2^64
+inline F from_fr(const Fr& v) { F r; std::memcpy(&r, &v, sizeof(F)); return r; }
+inline Fr to_fr(const F& v) { Fr r; std::memcpy(&r, &v, sizeof(F)); return r; }
+inline F f_zero() { return F{{0, 0, 0, 0}}; }
+inline bool geq_p(const uint64_t t[4]) {
+    for (int i = 3; i >= 0; --i) {
+        if (t[i] != kP[i]) return t[i] > kP[i];
+    }
+    return true;
+}
+inline void sub_p_inplace(uint64_t t[4]) {
+    u128 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        const u128 d = (u128)t[i] - kP[i] - (uint64_t)borrow;
+        t[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+}
+inline F f_add(const F& a, const F& b) {
+    F r;
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    if (c || geq_p(r.l)) sub_p_inplace(r.l);  // p < 2^254: the carry never survives the subtraction
+    return r;
+}
+inline F f_sub(const F& a, const F& b) {
+    F r;
+    u128 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+        const u128 d = (u128)a.l[i] - b.l[i] - (uint64_t)borrow;
+        r.l[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
+    }
+    if (borrow) {
+        u128 c = 0;
+        for (int i = 0; i < 4; ++i) { c += (u128)r.l[i] + kP[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    }
+    return r;
+}
+inline F f_mul(const F& a, const F& b) {  // CIOS, the product of jolt::host_mul64 without the 32-bit limb packing
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * kNegInv;
+        c = ((u128)m * kP[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * kP[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    F r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_p(r.l)) sub_p_inplace(r.l);
+    return r;
+}
+inline F f_ext2(const F& lo, const F& hi) { return f_sub(f_add(hi, hi), lo); }  // the line through (0, lo), (1, hi) at 2
+
+// a * r for a challenge r of the reference's 125-bit shape: Montgomery limbs (0, 0, r2, r3) (from_challenge_bytes, crates/jolt-field/src/bn254/mod.rs:171-184).
+// With r driving the outer loop the first two CIOS steps add nothing to a zero accumulator: half the work of f_mul.
+inline F f_mul_challenge(const F& a, const F& r) {
+    if (r.l[0] | r.l[1]) return f_mul(a, r);
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 2; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * r.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * kNegInv;
+        c = ((u128)m * kP[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * kP[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    F out = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_p(out.l)) sub_p_inplace(out.l);
+    return out;
+}
+
+// sum_k a_k b_k with ONE Montgomery reduction: the 512-bit products are summed in nine limbs (at most 2^7 products of canonical operands: < 2^515), four
+// reduction steps divide by 2^256, and what is left (< 33 p, five limbs) comes down by conditional subtractions of 32p, 16p, .. p.
+struct DotAcc {
+    uint64_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void fma(const F& a, const F& b) {
+        uint64_t carry_top = 0;
+        for (int i = 0; i < 4; ++i) {
+            u128 c = 0;
+            for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + w[i + j]; w[i + j] = (uint64_t)c; c >>= 64; }
+            for (int k = i + 4; k < 9 && c; ++k) { c += w[k]; w[k] = (uint64_t)c; c >>= 64; }
+            carry_top |= (uint64_t)c;
+        }
+        (void)carry_top;  // cannot happen within the stated bound
+    }
+    F reduce() {
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t m = w[i] * kNegInv;
+            u128 c = 0;
+            for (int j = 0; j < 4; ++j) { c += (u128)m * kP[j] + w[i + j]; w[i + j] = (uint64_t)c; c >>= 64; }
+            for (int k = i + 4; k < 9 && c; ++k) { c += w[k]; w[k] = (uint64_t)c; c >>= 64; }
+        }
+        uint64_t v[5] = {w[4], w[5], w[6], w[7], w[8]};
+        for (int shift = 5; shift >= 0; --shift) {  // v -= (p << shift) while that keeps v non-negative
+            uint64_t m[5];
+            m[0] = kP[0] << shift;
+            for (int i = 1; i < 4; ++i) m[i] = (kP[i] << shift) | (shift ? kP[i - 1] >> (64 - shift) : 0);
+            m[4] = shift ? kP[3] >> (64 - shift) : 0;
+            bool ge = true;
+            for (int i = 4; i >= 0; --i) {
+                if (v[i] != m[i]) { ge = v[i] > m[i]; break; }
+            }
+            if (!ge) continue;
+            u128 borrow = 0;
+            for (int i = 0; i < 5; ++i) {
+                const u128 d = (u128)v[i] - m[i] - (uint64_t)borrow;
+                v[i] = (uint64_t)d;
+                borrow = (d >> 64) & 1;
+            }
+        }
+        return F{{v[0], v[1], v[2], v[3]}};
     }
 };
 
-void bind_high_to_low(std::vector<Fr>& t, size_t half, const Fr& r) {
-    for (size_t b = 0; b < half; ++b) t[b] = jolt::add(t[b], jolt::mul(r, jolt::sub(t[b + half], t[b])));
-}
+// ---- worker threads: spin while work keeps coming, sleep when it stops ----
+// ---- worker threads (JOLT_HOST_THREADS > 1): one hand-off per round.  Workers spin for the next hand-off for a few milliseconds and block on a condition
+// variable after that; the caller does the same while it waits.
+class Pool {
+   public:
+    static Pool& get() { static Pool p; return p; }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    // f(tid) for tid = 0 .. size() - 1; tid 0 runs on the caller
+    void run(const std::function<void(unsigned)>& f) {
+        if (workers_.empty()) { f(0); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &f;
+            pending_.store((unsigned)workers_.size(), std::memory_order_relaxed);
+            generation_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        f(0);
+        for (unsigned spins = 0; pending_.load(std::memory_order_acquire); ++spins) {
+            if (spins < kSpins) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> g(m_);
+            done_cv_.wait(g, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
+    }
+
+   private:
+    static constexpr unsigned kSpins = 200000;  // some milliseconds: the device scan between two phases included
+    Pool() {
+        // One thread unless asked: the hand-offs are only cheap while the workers SPIN between them, and spinning workers are only harmless on a host with
+        // idle cores to spare (measured in a shared 8-CPU container: 4 threads 29 -> 15 ms per proof, but 2 threads 600 ms while both sat on one core).
+        unsigned n = 1;
+        if (const char* e = std::getenv("JOLT_HOST_THREADS")) n = (unsigned)std::atoi(e);
+        if (n == 0) n = 1;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && n > hw) n = hw;
+        for (unsigned t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        generation_.fetch_add(1, std::memory_order_release);
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    void loop(unsigned tid) {
+        uint64_t seen = 0;
+        for (;;) {
+            for (unsigned spins = 0; generation_.load(std::memory_order_acquire) == seen; ++spins) {
+                if (spins < kSpins) { __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return generation_.load(std::memory_order_acquire) != seen || stop_; });
+            }
+            if (stop_) return;
+            seen = generation_.load(std::memory_order_acquire);
+            (*job_)(tid);
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> g(m_);
+                done_cv_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    const std::function<void(unsigned)>* job_ = nullptr;
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<unsigned> pending_{0};
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_ = false;
+};
+
+typedef F Poly[kChunkSize];  // a polynomial of the chunk; the first 256 >> (rounds bound) entries are live
 
 // EqPolynomial::evals, big-endian (crates/jolt-poly/src/eq.rs:299-315)
-std::vector<Fr> eq_table(const std::vector<Fr>& point) {
-    std::vector<Fr> e((size_t)1 << point.size());
-    e[0] = Fr::one();
+void eq_table(const F* point, size_t n, F* e) {
+    e[0] = from_fr(Fr::one());
     size_t size = 1;
-    for (const Fr& r : point) {
+    for (size_t k = 0; k < n; ++k) {
         for (size_t i = size; i-- > 0;) {
-            const Fr hi = jolt::mul(e[i], r);
+            const F hi = f_mul(e[i], point[k]);
             e[2 * i + 1] = hi;
-            e[2 * i] = jolt::sub(e[i], hi);
+            e[2 * i] = f_sub(e[i], hi);
         }
         size *= 2;
     }
-    return e;
 }
+
+struct TermRef { int8_t coef; int32_t prefix_poly /* shard-local, -1: none */; uint32_t suffix_poly /* shard-local */; };
+
+// What one thread owns: some of the present tables -- their suffix polynomials, their terms, a private copy of every prefix polynomial they read -- and
+// possibly some of the four RAF decompositions (prefix * q_shift + q_value, instruction_read_raf.rs:387-445).
+struct Shard {
+    std::vector<uint8_t> prefixes;        // prefix ids materialised here
+    std::vector<uint32_t> suffix_source;  // per suffix polynomial: its row in the scan's layout
+    std::vector<TermRef> terms;
+    std::vector<uint8_t> raf;             // 0 = left, 1 = right, 2 = identity, 3 = upper_all_ones
+    std::vector<F> polys, ext;            // [prefixes | suffixes | 3 per RAF decomposition][256]; ext = the top variable at 2 over the live half
+    F partial[3];
+    size_t n_polys() const { return prefixes.size() + suffix_source.size() + 3 * raf.size(); }
+    F* prefix_poly(size_t i) { return polys.data() + i * kChunkSize; }
+    F* suffix_poly(size_t i) { return polys.data() + (prefixes.size() + i) * kChunkSize; }
+    F* raf_poly(size_t i, int which) { return polys.data() + (prefixes.size() + suffix_source.size() + 3 * i + which) * kChunkSize; }
+    F* ext_of(const F* poly) { return ext.data() + (poly - polys.data()); }
+};
 
 }  // namespace
 
 struct jolt_read_raf_address {
-    Fr gamma;
+    F gamma, gamma2, gamma3, c_ones64, c_pow64, c_mask32;
     bool canonical;
-    std::vector<uint8_t> present;          // table ids with at least one row
-    std::vector<uint8_t> prefix_indices;   // prefixes those tables read
+    std::vector<uint8_t> present;         // table ids with at least one row
+    std::vector<uint8_t> prefix_indices;  // prefixes those tables read, ascending
     Fr checkpoints[kNumPrefixes];
-    std::vector<std::vector<Fr>> prefix_tables;               // [position in prefix_indices][256]
-    std::vector<std::vector<std::vector<Fr>>> suffix_tables;  // [position in present][suffix][256]
-    RafDecomposition left, right, identity, upper;
-    std::vector<Fr> phase_challenges;
-    std::vector<std::vector<Fr>> v_tables;  // completed phases' eq tables
+    F raf_checkpoint[4];
+    std::vector<Shard> shards;
+    F phase_challenges[kChunkLen];
+    uint32_t bound = 0;       // binds done in the open phase
+    std::vector<F> v_tables;  // completed phases' eq tables, [phase][256]
     uint32_t phase = 0;
     bool phase_open = false;
-    uint32_t suffix_offsets[kNumTables + 1];
+    // inputs of the open phase, read by the shards in their first step
+    const jolt_fr_t *raf_sums = nullptr, *suffix_sums = nullptr;
+    // The prefix polynomials of the NEXT phase depend on the checkpoints only, not on the scan: they are built on a background thread from the moment a phase
+    // closes, i.e. while the caller condenses and scans on the device.
+    std::future<void> prefixes_ready;
+    ~jolt_read_raf_address() { if (prefixes_ready.valid()) prefixes_ready.wait(); }
 };
 
 extern "C" uint32_t jolt_lookup_table_count(void) { return kNumTables; }
@@ -119,36 +341,8 @@ extern "C" int32_t jolt_host_lookup_table_combine(uint32_t kind, const jolt_fr_t
     return JOLT_OK;
 }
 
-extern "C" int32_t jolt_host_read_raf_address_create(const jolt_fr_t* gamma, const uint8_t* table_present, int32_t canonical, jolt_read_raf_address** out) {
-    if (!gamma || !table_present || !out) return JOLT_ERR_INVALID_ARG;
-    auto* h = new (std::nothrow) jolt_read_raf_address();
-    if (!h) return JOLT_ERR_OOM;
-    h->gamma = fr_from_abi(gamma);
-    if (!fr_is_canonical(h->gamma)) { delete h; return JOLT_ERR_INVALID_ARG; }
-    h->canonical = canonical != 0;
-    bool reads[kNumPrefixes] = {};
-    h->suffix_offsets[0] = 0;
-    for (int t = 0; t < kNumTables; ++t) {
-        const TableDesc& d = table_descs()[t];
-        h->suffix_offsets[t + 1] = h->suffix_offsets[t] + d.n_suffixes;
-        if (!table_present[t]) continue;
-        h->present.push_back((uint8_t)t);
-        for (uint32_t k = 0; k < d.n_prefixes; ++k) reads[d.prefixes[k]] = true;
-    }
-    for (int p = 0; p < kNumPrefixes; ++p) {
-        h->checkpoints[p] = prefix_default_checkpoint(p);
-        if (reads[p]) h->prefix_indices.push_back((uint8_t)p);
-    }
-    h->left.checkpoint = h->right.checkpoint = h->identity.checkpoint = Fr::zero();
-    h->upper.checkpoint = Fr::one();  // an AND over address bits: the empty product (:417-423)
-    *out = h;
-    return JOLT_OK;
-}
-extern "C" int32_t jolt_host_read_raf_address_destroy(jolt_read_raf_address* h) {
-    delete h;
-    return JOLT_OK;
-}
-// offsets of a table's suffix accumulators in the flattened layout jolt_read_raf_phase_scan writes (n_tables = 42, LookupTableKind order)
+
+// offsets of a table's suffix accumulators in the flattened layout jolt_read_raf_phase_scan writes for n_tables = 42 (LookupTableKind order), and the kinds
 extern "C" int32_t jolt_lookup_suffix_layout(uint32_t* offsets_out /* 43 */, uint8_t* kinds_out /* offsets[42] */) {
     if (!offsets_out) return JOLT_ERR_INVALID_ARG;
     uint32_t at = 0;
@@ -162,114 +356,283 @@ extern "C" int32_t jolt_lookup_suffix_layout(uint32_t* offsets_out /* 43 */, uin
     return JOLT_OK;
 }
 
-// init_phase: raf_sums[q * 256 + chunk], q = left, right, identity, shift_half, shift_full, upper_all_ones (raw, as jolt_read_raf_phase_scan returns them);
-// suffix_sums[(offsets[t] + s) * 256 + chunk] in the layout of jolt_lookup_suffix_layout.
-extern "C" int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address* h, uint32_t phase, const jolt_fr_t* raf_sums, const jolt_fr_t* suffix_sums) {
-    if (!h || !raf_sums || !suffix_sums || phase != h->phase || h->phase_open || phase >= (uint32_t)kLogK / kChunkLen) return JOLT_ERR_INVALID_ARG;
-    const uint32_t suffix_len = kLogK - (phase + 1) * kChunkLen;
-    auto column = [&](uint32_t q) {
-        std::vector<Fr> v(kChunkSize);
-        for (uint32_t x = 0; x < kChunkSize; ++x) v[x] = fr_from_abi(&raf_sums[(size_t)q * kChunkSize + x]);
-        return v;
-    };
-    const Fr half_scale = fr_pow2(suffix_len / 2), full_scale = fr_pow2(suffix_len);
-    std::vector<Fr> q_shift_half = column(3), q_shift_full = column(4);
-    for (Fr& v : q_shift_half) v = jolt::mul(v, half_scale);
-    for (Fr& v : q_shift_full) v = jolt::mul(v, full_scale);
-    // operand prefixes: the bound part moves up by the chunk's share of bits, the chunk's own bits are added (:826-842)
-    const Fr up_half = fr_pow2(kChunkLen / 2), up_full = fr_pow2(kChunkLen);
-    h->left.prefix.assign(kChunkSize, Fr::zero());
-    h->right.prefix.assign(kChunkSize, Fr::zero());
-    h->identity.prefix.assign(kChunkSize, Fr::zero());
-    for (uint32_t x = 0; x < kChunkSize; ++x) {
-        const Chunk c = make_chunk(x, kChunkLen, suffix_len);
-        h->left.prefix[x] = jolt::add(jolt::mul(h->left.checkpoint, up_half), jolt::fr_from_u64(c.x));
-        h->right.prefix[x] = jolt::add(jolt::mul(h->right.checkpoint, up_half), jolt::fr_from_u64(c.y));
-        h->identity.prefix[x] = jolt::add(jolt::mul(h->identity.checkpoint, up_full), jolt::fr_from_u64(x));
-    }
-    h->left.q_shift = q_shift_half;
-    h->left.q_value = column(0);
-    h->right.q_shift = q_shift_half;
-    h->right.q_value = column(1);
-    h->identity.q_shift = q_shift_full;
-    h->identity.q_value = column(2);
-    if (h->canonical) {  // the chunk's share of the upper word must be all ones (:857-876)
-        const uint32_t done = phase * kChunkLen, upper_bits = (uint32_t)kLogK / 2 > done ? ((uint32_t)kLogK / 2 - done < kChunkLen ? (uint32_t)kLogK / 2 - done : kChunkLen) : 0;
-        h->upper.prefix.assign(kChunkSize, Fr::zero());
-        for (uint32_t x = 0; x < kChunkSize; ++x)
-            if (upper_bits == 0 || (x >> (kChunkLen - upper_bits)) == (1u << upper_bits) - 1) h->upper.prefix[x] = h->upper.checkpoint;
-        h->upper.q_shift = column(5);
-        h->upper.q_value.assign(kChunkSize, Fr::zero());
-    }
-    h->suffix_tables.clear();
-    for (uint8_t t : h->present) {
+namespace { void build_prefixes(jolt_read_raf_address* h); }
+
+extern "C" int32_t jolt_host_read_raf_address_create(const jolt_fr_t* gamma, const uint8_t* table_present, int32_t canonical, jolt_read_raf_address** out) {
+    if (!gamma || !table_present || !out) return JOLT_ERR_INVALID_ARG;
+    const Fr g = fr_from_abi(gamma);
+    if (!fr_is_canonical(g)) return JOLT_ERR_INVALID_ARG;
+    auto* h = new (std::nothrow) jolt_read_raf_address();
+    if (!h) return JOLT_ERR_OOM;
+    h->gamma = from_fr(g);
+    h->gamma2 = f_mul(h->gamma, h->gamma);
+    h->gamma3 = f_mul(h->gamma2, h->gamma);
+    h->c_ones64 = from_fr(jolt::fr_from_u64(~0ull));
+    h->c_pow64 = from_fr(fr_pow2(64));
+    h->c_mask32 = from_fr(jolt::fr_from_u64(0xFFFFFFFFull));
+    h->canonical = canonical != 0;
+    bool reads[kNumPrefixes] = {};
+    for (int t = 0; t < kNumTables; ++t) {
+        if (!table_present[t]) continue;
         const TableDesc& d = table_descs()[t];
-        std::vector<std::vector<Fr>> polys(d.n_suffixes, std::vector<Fr>(kChunkSize));
-        for (uint32_t s = 0; s < d.n_suffixes; ++s)
-            for (uint32_t x = 0; x < kChunkSize; ++x) polys[s][x] = fr_from_abi(&suffix_sums[((size_t)h->suffix_offsets[t] + s) * kChunkSize + x]);
-        h->suffix_tables.push_back(std::move(polys));
+        h->present.push_back((uint8_t)t);
+        for (uint32_t k = 0; k < d.n_prefixes; ++k) reads[d.prefixes[k]] = true;
     }
-    h->prefix_tables.clear();
-    for (uint8_t p : h->prefix_indices) {
-        std::vector<Fr> table(kChunkSize);
-        for (uint32_t x = 0; x < kChunkSize; ++x) table[x] = prefix_evaluate(p, h->checkpoints, x, kChunkLen, suffix_len);
-        h->prefix_tables.push_back(std::move(table));
+    for (int p = 0; p < kNumPrefixes; ++p) {
+        h->checkpoints[p] = prefix_default_checkpoint(p);
+        if (reads[p]) h->prefix_indices.push_back((uint8_t)p);
     }
-    h->phase_challenges.clear();
-    h->phase_open = true;
+    for (int q = 0; q < 3; ++q) h->raf_checkpoint[q] = f_zero();
+    h->raf_checkpoint[3] = from_fr(Fr::one());  // an AND over address bits: the empty product (:417-423)
+    // deal the work out: the RAF decompositions first (one shard each, from the last shard down), then the tables, heaviest first, each to the lightest shard
+    const unsigned n_shards = Pool::get().size();
+    h->shards.resize(n_shards);
+    std::vector<uint32_t> load(n_shards, 0);
+    const int n_raf = h->canonical ? 4 : 3;
+    for (int q = 0; q < n_raf; ++q) {
+        const unsigned s = (n_shards - 1 - (unsigned)q % n_shards);
+        h->shards[s].raf.push_back((uint8_t)q);
+        load[s] += 5;
+    }
+    uint32_t layout[kNumTables + 1];
+    layout[0] = 0;
+    for (int t = 0; t < kNumTables; ++t) layout[t + 1] = layout[t] + table_descs()[t].n_suffixes;
+    auto cost = [](const TableDesc& d) { return 2u * d.n_terms + d.n_suffixes + d.n_prefixes; };
+    std::vector<uint8_t> order = h->present;
+    std::stable_sort(order.begin(), order.end(), [&](uint8_t a, uint8_t b) { return cost(table_descs()[a]) > cost(table_descs()[b]); });
+    for (uint8_t t : order) {
+        const TableDesc& d = table_descs()[t];
+        unsigned s = 0;
+        for (unsigned k = 1; k < n_shards; ++k)
+            if (load[k] < load[s]) s = k;
+        load[s] += cost(d);
+        Shard& sh = h->shards[s];
+        const uint32_t base = (uint32_t)sh.suffix_source.size();
+        for (uint32_t k = 0; k < d.n_suffixes; ++k) sh.suffix_source.push_back(layout[t] + k);
+        for (uint32_t k = 0; k < d.n_terms; ++k) {
+            const Term& term = d.terms[k];
+            if (term.suffix < 0) { delete h; return JOLT_ERR_UNSUPPORTED; }  // every term carries the rows' mass through a suffix
+            int32_t slot = -1;
+            if (term.prefix >= 0) {
+                for (size_t i = 0; i < sh.prefixes.size(); ++i)
+                    if (sh.prefixes[i] == (uint8_t)term.prefix) slot = (int32_t)i;
+                if (slot < 0) { slot = (int32_t)sh.prefixes.size(); sh.prefixes.push_back((uint8_t)term.prefix); }
+            }
+            sh.terms.push_back(TermRef{term.coef, slot, base + (uint32_t)term.suffix});
+        }
+        // prefixes a table lists only because another of its prefixes reads their checkpoint (Eq under LessThan, ...) must be bound too: materialise all it lists
+        for (uint32_t k = 0; k < d.n_prefixes; ++k) {
+            bool have = false;
+            for (uint8_t p : sh.prefixes) have |= p == d.prefixes[k];
+            if (!have) sh.prefixes.push_back(d.prefixes[k]);
+        }
+    }
+    for (Shard& sh : h->shards) {
+        sh.polys.resize(sh.n_polys() * kChunkSize);
+        sh.ext.resize(sh.polys.size());
+    }
+    h->prefixes_ready = std::async(std::launch::async, [h] { build_prefixes(h); });
+    *out = h;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_read_raf_address_destroy(jolt_read_raf_address* h) {
+    delete h;
     return JOLT_OK;
 }
 
-// address_message: evals_out = s(0), s(1), s(2) (UnivariatePoly::from_evals order)
-extern "C" int32_t jolt_host_read_raf_address_message(const jolt_read_raf_address* h, const jolt_fr_t* previous_claim, jolt_fr_t* evals_out) {
-    if (!h || !previous_claim || !evals_out || !h->phase_open) return JOLT_ERR_INVALID_ARG;
-    const size_t half = (kChunkSize >> h->phase_challenges.size()) / 2;
-    Fr read0 = Fr::zero(), read2 = Fr::zero(), sums[8];
-    for (Fr& s : sums) s = Fr::zero();
-    Fr p0[kNumPrefixes], p2[kNumPrefixes], s0[5], s2[5];
-    for (int p = 0; p < kNumPrefixes; ++p) p0[p] = p2[p] = Fr::zero();
-    for (size_t b = 0; b < half; ++b) {
-        for (size_t i = 0; i < h->prefix_indices.size(); ++i) {
-            const std::vector<Fr>& t = h->prefix_tables[i];
-            p0[h->prefix_indices[i]] = t[b];
-            p2[h->prefix_indices[i]] = jolt::sub(jolt::dbl(t[b + half]), t[b]);
+namespace {
+
+// The first step of a phase on one shard: its polynomials from the scan's sums and the checkpoints (init_phase :814-898)
+void build_prefixes(jolt_read_raf_address* h) {  // init_phase :878-897; a prefix shared by several shards is evaluated once and copied
+    const uint32_t suffix_len = kLogK - (h->phase + 1) * kChunkLen;
+    F* built[kNumPrefixes] = {};
+    for (Shard& sh : h->shards)
+        for (size_t i = 0; i < sh.prefixes.size(); ++i) {
+            F* table = sh.prefix_poly(i);
+            const uint8_t p = sh.prefixes[i];
+            if (built[p]) { std::memcpy(table, built[p], sizeof(Poly)); continue; }
+            for (uint32_t x = 0; x < kChunkSize; ++x) table[x] = from_fr(prefix_evaluate(p, h->checkpoints, x, kChunkLen, suffix_len));
+            built[p] = table;
         }
-        for (size_t i = 0; i < h->present.size(); ++i) {
-            const TableDesc& d = table_descs()[h->present[i]];
-            for (uint32_t s = 0; s < d.n_suffixes; ++s) {
-                const std::vector<Fr>& q = h->suffix_tables[i][s];
-                s0[s] = q[b];
-                s2[s] = jolt::sub(jolt::dbl(q[b + half]), q[b]);
+}
+void shard_init(jolt_read_raf_address* h, Shard& sh) {
+    const uint32_t suffix_len = kLogK - (h->phase + 1) * kChunkLen;
+    for (size_t i = 0; i < sh.suffix_source.size(); ++i) std::memcpy(sh.suffix_poly(i), &h->suffix_sums[(size_t)sh.suffix_source[i] * kChunkSize], sizeof(Poly));
+    for (size_t i = 0; i < sh.raf.size(); ++i) {
+        const uint8_t q = sh.raf[i];
+        F *prefix = sh.raf_poly(i, 0), *q_shift = sh.raf_poly(i, 1), *q_value = sh.raf_poly(i, 2);
+        auto column = [&](uint32_t c, F* out) { std::memcpy(out, &h->raf_sums[(size_t)c * kChunkSize], sizeof(Poly)); };
+        if (q == 3) {  // the chunk's share of the upper word must be all ones (:857-876)
+            const uint32_t done = h->phase * kChunkLen, word = (uint32_t)kLogK / 2;
+            const uint32_t upper_bits = word > done ? (word - done < kChunkLen ? word - done : kChunkLen) : 0;
+            for (uint32_t x = 0; x < kChunkSize; ++x) {
+                prefix[x] = (upper_bits == 0 || (x >> (kChunkLen - upper_bits)) == (1u << upper_bits) - 1) ? h->raf_checkpoint[3] : f_zero();
+                q_value[x] = f_zero();
             }
-            read0 = jolt::add(read0, table_combine(d, p0, s0));
-            read2 = jolt::add(read2, table_combine(d, p2, s2));
+            column(5, q_shift);
+            continue;
         }
-        Fr a0, a2;
-        h->left.message(b, half, a0, a2);
-        sums[0] = jolt::add(sums[0], a0);
-        sums[1] = jolt::add(sums[1], a2);
-        h->right.message(b, half, a0, a2);
-        sums[2] = jolt::add(sums[2], a0);
-        sums[3] = jolt::add(sums[3], a2);
-        h->identity.message(b, half, a0, a2);
-        sums[4] = jolt::add(sums[4], a0);
-        sums[5] = jolt::add(sums[5], a2);
-        if (h->canonical) {
-            h->upper.message(b, half, a0, a2);
-            sums[6] = jolt::add(sums[6], a0);
-            sums[7] = jolt::add(sums[7], a2);
+        // operand prefixes: the bound part moves up by the chunk's share of bits, the chunk's own bits are added (:826-842); shift sums scaled (:814-823)
+        const bool full = q == 2;
+        const F scale = from_fr(fr_pow2(full ? suffix_len : suffix_len / 2));
+        const F base = f_mul(h->raf_checkpoint[q], from_fr(fr_pow2(full ? kChunkLen : kChunkLen / 2)));
+        column(full ? 4 : 3, q_shift);
+        column(q, q_value);
+        F small[kChunkSize];
+        for (uint32_t x = 0; x < (full ? kChunkSize : 1u << (kChunkLen / 2)); ++x) small[x] = from_fr(jolt::fr_from_u64(x));
+        for (uint32_t x = 0; x < kChunkSize; ++x) {
+            const Chunk c = make_chunk(x, kChunkLen, suffix_len);
+            prefix[x] = f_add(base, small[q == 0 ? c.x : (q == 1 ? c.y : x)]);
+            q_shift[x] = f_mul(q_shift[x], scale);
         }
     }
-    const Fr g = h->gamma, g2 = jolt::mul(g, g), g3 = jolt::mul(g2, g);
-    Fr e0 = jolt::add(read0, jolt::add(jolt::mul(g, sums[0]), jolt::mul(g2, jolt::add(sums[2], sums[4]))));
-    Fr e2 = jolt::add(read2, jolt::add(jolt::mul(g, sums[1]), jolt::mul(g2, jolt::add(sums[3], sums[5]))));
-    if (h->canonical) {
-        e0 = jolt::add(e0, jolt::mul(g3, sums[6]));
-        e2 = jolt::add(e2, jolt::mul(g3, sums[7]));
+}
+
+void shard_bind(Shard& sh, size_t half, const F& r) {
+    for (size_t i = 0; i < sh.n_polys(); ++i) {
+        F* t = sh.polys.data() + i * kChunkSize;
+        for (size_t b = 0; b < half; ++b) t[b] = f_add(t[b], f_mul_challenge(f_sub(t[b + half], t[b]), r));
     }
-    fr_to_abi(&evals_out[0], e0);
-    fr_to_abi(&evals_out[1], jolt::sub(fr_from_abi(previous_claim), e0));
-    fr_to_abi(&evals_out[2], e2);
+}
+void shard_extend(Shard& sh, size_t half) {
+    for (size_t i = 0; i < sh.n_polys(); ++i) {
+        const F* t = sh.polys.data() + i * kChunkSize;
+        F* e = sh.ext.data() + i * kChunkSize;
+        for (size_t b = 0; b < half; ++b) e[b] = f_ext2(t[b], t[b + half]);
+    }
+}
+
+// the shard's share of s(0), s(2) (and s(1) when the caller has no running claim): one dot product per bilinear term and point
+void shard_message(const jolt_read_raf_address* h, Shard& sh, size_t half, bool with_one) {
+    F e[3] = {f_zero(), f_zero(), f_zero()};
+    for (const TermRef& term : sh.terms) {  // sum_b P(c, b) Q(c, b) of one term of one table's combine
+        const F* q = sh.suffix_poly(term.suffix_poly);
+        F acc[3] = {f_zero(), f_zero(), f_zero()};
+        if (term.prefix_poly < 0) {
+            for (size_t b = 0; b < half; ++b) {
+                acc[0] = f_add(acc[0], q[b]);
+                acc[1] = f_add(acc[1], q[b + half]);
+            }
+            acc[2] = f_sub(f_add(acc[1], acc[1]), acc[0]);  // linear in c
+        } else {
+            const F *p = sh.prefix_poly((size_t)term.prefix_poly), *p2 = sh.ext_of(p), *q2 = sh.ext_of(q);
+            DotAcc a0, a1, a2;
+            for (size_t b = 0; b < half; ++b) {
+                a0.fma(p[b], q[b]);
+                a2.fma(p2[b], q2[b]);
+                if (with_one) a1.fma(p[b + half], q[b + half]);
+            }
+            acc[0] = a0.reduce();
+            acc[2] = a2.reduce();
+            if (with_one) acc[1] = a1.reduce();
+        }
+        for (int c = 0; c < 3; ++c) {
+            if (c == 1 && !with_one) continue;
+            switch (term.coef) {
+                case kPlus: e[c] = f_add(e[c], acc[c]); break;
+                case kMinus: e[c] = f_sub(e[c], acc[c]); break;
+                case kOnes64: e[c] = f_add(e[c], f_mul(acc[c], h->c_ones64)); break;
+                case kPow64: e[c] = f_add(e[c], f_mul(acc[c], h->c_pow64)); break;
+                default: e[c] = f_add(e[c], f_mul(acc[c], h->c_mask32)); break;
+            }
+        }
+    }
+    const F weight[4] = {h->gamma, h->gamma2, h->gamma2, h->gamma3};  // gamma * left + gamma^2 (right + identity) (+ gamma^3 upper)
+    for (size_t i = 0; i < sh.raf.size(); ++i) {
+        const F *prefix = sh.raf_poly(i, 0), *q_shift = sh.raf_poly(i, 1), *q_value = sh.raf_poly(i, 2);
+        const F *prefix2 = sh.ext_of(prefix), *q_shift2 = sh.ext_of(q_shift), *q_value2 = sh.ext_of(q_value);
+        DotAcc a0, a1, a2;
+        F v0 = f_zero(), v1 = f_zero(), v2 = f_zero();
+        for (size_t b = 0; b < half; ++b) {
+            a0.fma(prefix[b], q_shift[b]);
+            a2.fma(prefix2[b], q_shift2[b]);
+            v0 = f_add(v0, q_value[b]);
+            v2 = f_add(v2, q_value2[b]);
+            if (with_one) {
+                a1.fma(prefix[b + half], q_shift[b + half]);
+                v1 = f_add(v1, q_value[b + half]);
+            }
+        }
+        const F w = weight[sh.raf[i]];
+        e[0] = f_add(e[0], f_mul(f_add(a0.reduce(), v0), w));
+        e[2] = f_add(e[2], f_mul(f_add(a2.reduce(), v2), w));
+        if (with_one) e[1] = f_add(e[1], f_mul(f_add(a1.reduce(), v1), w));
+    }
+    for (int c = 0; c < 3; ++c) sh.partial[c] = e[c];
+}
+
+// One hand-off: [first step of the phase: build] [bind with r] extensions, partial sums.  Each shard touches only what it owns.
+enum : unsigned { kStepInit = 1, kStepBind = 2, kStepMessage = 4, kStepWithOne = 8 };
+void step(jolt_read_raf_address* h, unsigned what, const F* r, F out[3]) {
+    const size_t live = kChunkSize >> h->bound;  // before the bind of this step
+    const std::function<void(unsigned)> work = [&](unsigned tid) {
+        if (tid >= h->shards.size()) return;
+        Shard& sh = h->shards[tid];
+        size_t now = live;
+        if (what & kStepInit) shard_init(h, sh);
+        if (what & kStepBind) { shard_bind(sh, live / 2, *r); now = live / 2; }
+        if (what & kStepMessage) {
+            shard_extend(sh, now / 2);
+            shard_message(h, sh, now / 2, (what & kStepWithOne) != 0);
+        }
+    };
+    if (live <= 8 && !(what & kStepInit)) {  // the last rounds of a phase are a handful of entries: not worth a hand-off
+        for (unsigned t = 0; t < h->shards.size(); ++t) work(t);
+    } else {
+        Pool::get().run(work);
+    }
+    if (what & kStepBind) h->phase_challenges[h->bound++] = *r;
+    if (what & kStepMessage)
+        for (int c = 0; c < 3; ++c) {
+            out[c] = f_zero();
+            for (const Shard& sh : h->shards) out[c] = f_add(out[c], sh.partial[c]);
+        }
+}
+
+// after the 8th bind: the phase's eq table and the new checkpoints (:1262-1275)
+void close_phase(jolt_read_raf_address* h) {
+    h->v_tables.resize((size_t)(h->phase + 1) * kChunkSize);
+    eq_table(h->phase_challenges, kChunkLen, h->v_tables.data() + (size_t)h->phase * kChunkSize);
+    for (Shard& sh : h->shards) {
+        for (size_t i = 0; i < sh.prefixes.size(); ++i) h->checkpoints[sh.prefixes[i]] = to_fr(sh.prefix_poly(i)[0]);  // copies in other shards hold the same value
+        for (size_t i = 0; i < sh.raf.size(); ++i) h->raf_checkpoint[sh.raf[i]] = sh.raf_poly(i, 0)[0];
+    }
+    h->phase += 1;
+    h->phase_open = false;
+    h->raf_sums = h->suffix_sums = nullptr;
+    if (h->phase < kPhases) h->prefixes_ready = std::async(std::launch::async, [h] { build_prefixes(h); });
+}
+
+}  // namespace
+
+// init_phase: raf_sums[q * 256 + chunk], q = left, right, identity, shift_half, shift_full, upper_all_ones (raw, as jolt_read_raf_phase_scan returns them);
+// suffix_sums[(offsets[t] + s) * 256 + chunk] in the layout of jolt_lookup_suffix_layout.  The sums are copied into the phase's polynomials here.
+extern "C" int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address* h, uint32_t phase, const jolt_fr_t* raf_sums, const jolt_fr_t* suffix_sums) {
+    if (!h || !raf_sums || !suffix_sums || phase != h->phase || h->phase_open || phase >= kPhases) return JOLT_ERR_INVALID_ARG;
+    if (h->prefixes_ready.valid()) h->prefixes_ready.get();
+    else build_prefixes(h);
+    h->raf_sums = raf_sums;
+    h->suffix_sums = suffix_sums;
+    h->bound = 0;
+    h->phase_open = true;
+    F unused[3];
+    step(h, kStepInit, nullptr, unused);
+    h->raf_sums = h->suffix_sums = nullptr;
+    return JOLT_OK;
+}
+
+// address_message: evals_out = s(0), s(1), s(2) (UnivariatePoly::from_evals order).  previous_claim == NULL: s(1) is summed from the tables instead of
+// taken from the running claim -- in round 0 that makes s(0) + s(1) the relation's input claim.
+extern "C" int32_t jolt_host_read_raf_address_message(jolt_read_raf_address* h, const jolt_fr_t* previous_claim, jolt_fr_t* evals_out) {
+    if (!h || !evals_out || !h->phase_open) return JOLT_ERR_INVALID_ARG;
+    F e[3];
+    step(h, kStepMessage | (previous_claim ? 0u : (unsigned)kStepWithOne), nullptr, e);
+    if (previous_claim) {
+        F claim;
+        std::memcpy(&claim, previous_claim, sizeof(F));
+        e[1] = f_sub(claim, e[0]);
+    }
+    std::memcpy(evals_out, e, sizeof(e));
     return JOLT_OK;
 }
 
@@ -278,50 +641,78 @@ extern "C" int32_t jolt_host_read_raf_address_bind(jolt_read_raf_address* h, con
     if (!h || !challenge || !h->phase_open) return JOLT_ERR_INVALID_ARG;
     const Fr r = fr_from_abi(challenge);
     if (!fr_is_canonical(r)) return JOLT_ERR_INVALID_ARG;
-    const size_t half = (kChunkSize >> h->phase_challenges.size()) / 2;
-    for (auto& t : h->prefix_tables) bind_high_to_low(t, half, r);
-    for (auto& polys : h->suffix_tables)
-        for (auto& q : polys) bind_high_to_low(q, half, r);
-    for (RafDecomposition* d : {&h->left, &h->right, &h->identity, &h->upper}) {
-        if (d == &h->upper && !h->canonical) continue;
-        bind_high_to_low(d->prefix, half, r);
-        bind_high_to_low(d->q_shift, half, r);
-        bind_high_to_low(d->q_value, half, r);
-    }
-    h->phase_challenges.push_back(r);
-    const bool done = h->phase_challenges.size() == kChunkLen;
-    if (done) {
-        h->v_tables.push_back(eq_table(h->phase_challenges));
-        for (size_t i = 0; i < h->prefix_indices.size(); ++i) h->checkpoints[h->prefix_indices[i]] = h->prefix_tables[i][0];
-        h->left.checkpoint = h->left.prefix[0];
-        h->right.checkpoint = h->right.prefix[0];
-        h->identity.checkpoint = h->identity.prefix[0];
-        if (h->canonical) h->upper.checkpoint = h->upper.prefix[0];
-        h->phase += 1;
-        h->phase_open = false;
-    }
+    const F rf = from_fr(r);
+    F unused[3];
+    step(h, kStepBind, &rf, unused);
+    const bool done = h->bound == kChunkLen;
+    if (done) close_phase(h);
     if (phase_done) *phase_done = done ? 1 : 0;
     return JOLT_OK;
 }
+
+// The 8 rounds of the open phase in one call: message -> UnivariatePoly::from_evals coefficients [c0, c1, c2] -> transcript -> bind.  The transcript is the
+// caller's hook (jolt_round_transcript_fn: absorbs the coefficients, returns the challenge) or, with fn == NULL, the library's test transcript `test_transcript`
+// (append the three coefficients, Transcript::challenge).  claim: in = the running claim before the phase, out = after it.  A round's bind shares its
+// hand-off with the next round's sums.
+extern "C" int32_t jolt_host_read_raf_address_prove_phase(jolt_read_raf_address* h, jolt_fr_t* claim, jolt_round_transcript_fn fn, void* user, jolt_host_transcript* test_transcript,
+                                                          jolt_fr_t* coeffs_out /* 8 x 3 */, jolt_fr_t* challenges_out /* 8 */) {
+    if (!h || !claim || (!fn && !test_transcript) || !h->phase_open || h->bound != 0) return JOLT_ERR_INVALID_ARG;
+    static const F inv2 = from_fr(jolt::inv(jolt::fr_from_u64(2)));
+    F running, rf = f_zero();
+    std::memcpy(&running, claim, sizeof(F));
+    for (uint32_t round = 0; round < kChunkLen; ++round) {
+        F e[3];
+        step(h, round ? (kStepBind | kStepMessage) : (unsigned)kStepMessage, &rf, e);
+        e[1] = f_sub(running, e[0]);
+        // the quadratic through (0, e0), (1, e1), (2, e2): c2 = (e2 - 2 e1 + e0) / 2, c1 = e1 - e0 - c2
+        F c[3];
+        c[0] = e[0];
+        c[2] = f_mul(f_add(f_sub(e[2], f_add(e[1], e[1])), e[0]), inv2);
+        c[1] = f_sub(f_sub(e[1], e[0]), c[2]);
+        jolt_fr_t coeffs[3], challenge;
+        std::memcpy(coeffs, c, sizeof(c));
+        if (fn) {
+            const int32_t st = fn(user, coeffs, 3, &challenge);
+            if (st != JOLT_OK) return st;
+        } else {
+            int32_t st = jolt_host_transcript_append_fr(test_transcript, coeffs, 3);
+            if (st == JOLT_OK) st = jolt_host_transcript_challenge(test_transcript, 0, &challenge);
+            if (st != JOLT_OK) return st;
+        }
+        const Fr r = fr_from_abi(&challenge);
+        if (!fr_is_canonical(r)) return JOLT_ERR_INVALID_ARG;
+        rf = from_fr(r);
+        running = f_add(c[0], f_mul(rf, f_add(c[1], f_mul(rf, c[2]))));
+        if (coeffs_out) std::memcpy(&coeffs_out[3 * round], coeffs, sizeof(coeffs));
+        if (challenges_out) challenges_out[round] = challenge;
+    }
+    F unused[3];
+    step(h, kStepBind, &rf, unused);
+    close_phase(h);
+    std::memcpy(claim, &running, sizeof(F));
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_host_read_raf_address_v_table(const jolt_read_raf_address* h, uint32_t phase, jolt_fr_t* out) {
-    if (!h || !out || phase >= h->v_tables.size()) return JOLT_ERR_INVALID_ARG;
-    for (uint32_t x = 0; x < kChunkSize; ++x) fr_to_abi(&out[x], h->v_tables[phase][x]);
+    if (!h || !out || (size_t)(phase + 1) * kChunkSize > h->v_tables.size()) return JOLT_ERR_INVALID_ARG;
+    std::memcpy(out, h->v_tables.data() + (size_t)phase * kChunkSize, sizeof(Poly));
     return JOLT_OK;
 }
 // init_cycle_rounds (:1140-1160): every table's value at r_address (its combine over the final checkpoints and the suffixes of the empty string), and the
 // gamma-combined operand values the two RAF branches add
 extern "C" int32_t jolt_host_read_raf_address_finish(const jolt_read_raf_address* h, jolt_fr_t* table_values, jolt_fr_t* raf_interleaved, jolt_fr_t* raf_identity) {
-    if (!h || !table_values || !raf_interleaved || !raf_identity || h->phase != (uint32_t)kLogK / kChunkLen) return JOLT_ERR_INVALID_ARG;
+    if (!h || !table_values || !raf_interleaved || !raf_identity || h->phase != kPhases) return JOLT_ERR_INVALID_ARG;
     for (int t = 0; t < kNumTables; ++t) {
         const TableDesc& d = table_descs()[t];
         Fr s[5];
         for (uint32_t k = 0; k < d.n_suffixes; ++k) s[k] = jolt::fr_from_u64(jolt::suffix_mle(d.suffixes[k], 0, 0, 0));
         fr_to_abi(&table_values[t], table_combine(d, h->checkpoints, s));
     }
-    const Fr g = h->gamma, g2 = jolt::mul(g, g);
-    fr_to_abi(raf_interleaved, jolt::add(jolt::mul(g, h->left.checkpoint), jolt::mul(g2, h->right.checkpoint)));
-    Fr id = jolt::mul(g2, h->identity.checkpoint);
-    if (h->canonical) id = jolt::add(id, jolt::mul(jolt::mul(g2, g), h->upper.checkpoint));
-    fr_to_abi(raf_identity, id);
+    const F interleaved = f_add(f_mul(h->gamma, h->raf_checkpoint[0]), f_mul(h->gamma2, h->raf_checkpoint[1]));
+    F id = f_mul(h->gamma2, h->raf_checkpoint[2]);
+    if (h->canonical) id = f_add(id, f_mul(h->gamma3, h->raf_checkpoint[3]));
+    std::memcpy(raf_interleaved, &interleaved, sizeof(F));
+    std::memcpy(raf_identity, &id, sizeof(F));
     return JOLT_OK;
 }
+

@@ -1450,15 +1450,23 @@ class HostReadRafAddress:
         _ck(lib().jolt_host_read_raf_address_init_phase(self.h, C.c_uint32(phase), _p(fr(raf_sums).reshape(6 * 256, 4)), _p(fr(suffix_sums).reshape(-1, 4))),
             "jolt_host_read_raf_address_init_phase")
 
-    def message(self, previous_claim):
+    def message(self, previous_claim=None):
+        """s(0), s(1), s(2); without a running claim s(1) is summed from the tables (round 0: s(0) + s(1) = the input claim)"""
         o = fr_array(3)
-        _ck(lib().jolt_host_read_raf_address_message(self.h, _p(fr(previous_claim).reshape(4)), _p(o)), "jolt_host_read_raf_address_message")
+        _ck(lib().jolt_host_read_raf_address_message(self.h, _p(fr(previous_claim).reshape(4)) if previous_claim is not None else None, _p(o)), "jolt_host_read_raf_address_message")
         return o
 
     def bind(self, r):
         done = C.c_int32()
         _ck(lib().jolt_host_read_raf_address_bind(self.h, _p(fr(r).reshape(4)), C.byref(done)), "jolt_host_read_raf_address_bind")
         return bool(done.value)
+
+    def prove_phase(self, claim, transcript):
+        """the 8 rounds of the open phase against a HostTranscript: -> (claim after the phase, coefficients (8, 3, 4), challenges (8, 4))"""
+        c = fr(claim).reshape(4).copy()
+        coeffs, challenges = fr_array(24), fr_array(8)
+        _ck(lib().jolt_host_read_raf_address_prove_phase(self.h, _p(c), None, None, transcript.h, _p(coeffs), _p(challenges)), "jolt_host_read_raf_address_prove_phase")
+        return c, coeffs.reshape(8, 3, 4), challenges
 
     def v_table(self, phase):
         o = fr_array(256)

@@ -295,8 +295,9 @@ extern "C" {
     pub fn jolt_host_read_raf_address_create(gamma: *const jolt_fr_t, table_present: *const u8, canonical: i32, out: *mut *mut jolt_read_raf_address) -> i32;
     pub fn jolt_host_read_raf_address_destroy(h: *mut jolt_read_raf_address) -> i32;
     pub fn jolt_host_read_raf_address_init_phase(h: *mut jolt_read_raf_address, phase: u32, raf_sums: *const jolt_fr_t, suffix_sums: *const jolt_fr_t) -> i32;
-    pub fn jolt_host_read_raf_address_message(h: *const jolt_read_raf_address, previous_claim: *const jolt_fr_t, evals_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_read_raf_address_message(h: *mut jolt_read_raf_address, previous_claim: *const jolt_fr_t, evals_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_bind(h: *mut jolt_read_raf_address, challenge: *const jolt_fr_t, phase_done: *mut i32) -> i32;
+    pub fn jolt_host_read_raf_address_prove_phase(h: *mut jolt_read_raf_address, claim: *mut jolt_fr_t, r#fn: jolt_round_transcript_fn, user: *mut c_void, test_transcript: *mut jolt_host_transcript, coeffs_out: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_v_table(h: *const jolt_read_raf_address, phase: u32, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_finish(h: *const jolt_read_raf_address, table_values: *mut jolt_fr_t, raf_interleaved: *mut jolt_fr_t, raf_identity: *mut jolt_fr_t) -> i32;
     pub fn jolt_r1cs_uniskip_sums(ctx: *mut jolt_ctx, inputs: *const *mut jolt_table, n_inputs: usize, eq: *const jolt_table, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, n_nodes: usize, out: *mut jolt_fr_t) -> i32;
