@@ -9,9 +9,10 @@ stage drivers drive them, over synthetic trace-shaped inputs:
   stage 4   registers read / write   the same sparse matrix with <= 3 cells per cycle and two coefficient columns: log T cycle rounds on the device,
                                      log K = 7 address rounds over K-sized arrays, the two operand claims as one-hot evaluations
                                      (optimized/registers_read_write/{mod,sparse,rows}.rs)
-  stage 5   instruction read + RAF   the 16 address phases' T-scale scans (condensation, RAF sums, per-table suffix accumulators) and the
-                                     log T cycle rounds over combined * prod ra  (optimized/instruction_read_raf.rs; the 8 address rounds
-                                     inside a phase run over 256-entry polynomials on the caller's side and are not part of this)
+  stage 5   instruction read + RAF   the whole kernel over the 42 real lookup tables: per address phase the T-scale scans on the device (condensation, RAF
+                                     sums, per-table suffix accumulators) and the phase's 8 rounds over 256-entry prefix / suffix polynomials on the host
+                                     (jolt_host_read_raf_address_*), then the log T cycle rounds over combined * prod ra on the device, their claim
+                                     being the running claim the 128 address rounds leave  (optimized/instruction_read_raf.rs)
 
   stage 6a  booleanity, address      the pushforward masses G_i[k] = sum_j eq(r_cycle, j) [hot_i(j) = k] of all RA columns (T-scale, device), then the
                                      log K rounds over K-entry tables with the squared-weight bind on the host, where the reference keeps them
@@ -40,7 +41,6 @@ NO_ACCESS = np.uint64(0xFFFFFFFFFFFFFFFF)
 ADDRESS_BITS, PHASES, CHUNK = 128, 16, 256
 # integer Lagrange basis of the 3-node window {-1, 0, 1} at the extended nodes {-2 .. 2} (spartan_product.rs:86-105 extension_coefficients)
 PRODUCT_EXTENSION = np.array([[3, -3, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, -3, 3]], dtype=np.int64)
-N_SUFFIX_KINDS = 48
 
 
 def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5):
@@ -103,19 +103,30 @@ def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7,
     return dict(log_k=log_k, log_t=log_t, rs1=rs1, rs1_val=rs1_val, rs2=rs2, rs2_val=rs2_val, rd=rd, rd_pre=rd_pre, rd_post=rd_post)
 
 
-def suffix_lists(n_tables, rng):
-    """per table the suffix kinds it reads (LookupTableKind::suffixes()): every kind appears somewhere, 1..6 per table"""
-    kinds = list(rng.permutation(N_SUFFIX_KINDS))
-    lists = [[] for _ in range(n_tables)]
-    for i, k in enumerate(kinds):
-        lists[i % n_tables].append(int(k))
-    for l in lists:
-        if 0 not in l and rng.random() < 0.5:
-            l.insert(0, 0)
-    return lists
+N_LOOKUP_TABLES = 42
+BITMASK_TABLES = np.array([25, 26, 27, 28], dtype=np.uint8)  # VirtualSRL, VirtualSRA, VirtualROTR, VirtualROTRW
 
 
-def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_count=4, log_k=None, log_kb=None):
+def _spread_bits(v):
+    """the 32 low bits of each u64 moved to the even bit positions"""
+    v = v & np.uint64(0xFFFFFFFF)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x0000FFFF0000FFFF)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF00FF00FF)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x3333333333333333)
+    v = (v | (v << np.uint64(1))) & np.uint64(0x5555555555555555)
+    return v
+
+
+def interleave_operands(x, y):
+    """interleave_bits (crates/jolt-lookup-tables/src/interleave.rs:14-33): x on the odd bit positions, y on the even ones; -> (n, 2) u64 (lo, hi)"""
+    x, y = np.asarray(x, dtype=np.uint64), np.asarray(y, dtype=np.uint64)
+    lo = (_spread_bits(x) << np.uint64(1)) | _spread_bits(y)
+    hi = (_spread_bits(x >> np.uint64(32)) << np.uint64(1)) | _spread_bits(y >> np.uint64(32))
+    return np.stack([lo, hi], axis=1)
+
+
+def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_count=4, log_k=None, log_kb=None):
     rng = np.random.default_rng(seed + 500)
     T = 1 << n_vars
     d = {"n_vars": n_vars}
@@ -146,19 +157,27 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=40, ra_cou
     d["registers"] = consistent_register_trace(7, n_vars, rng)
     d["registers_r_cycle"] = rand_fr(n_vars, rng)
     d["registers_gamma"] = rand_fr(1, rng)[0]
-    # ---- stage 5: lookup rows
+    # ---- stage 5: lookup rows over real tables (LookupTableKind ids); `n_tables` of the 42 are present
+    present = np.sort(rng.permutation(N_LOOKUP_TABLES)[: min(n_tables, N_LOOKUP_TABLES)]).astype(np.uint8)
+    table = present[rng.integers(0, len(present), size=T)]
     idx = np.frombuffer(rng.bytes(16 * T), dtype=np.uint64).reshape(T, 2).copy()
     shapes = rng.integers(0, 8, size=T)
     idx[shapes == 0] = 0
     idx[shapes == 1, 1] = 0
     idx[shapes == 2] = np.uint64(0xFFFFFFFFFFFFFFFF)
     idx[shapes == 3, 0] &= np.uint64(0xFF)
-    table = rng.integers(0, n_tables, size=T).astype(np.uint8)
+    # the shift / rotate tables are defined on mask-shaped right operands 1..10..0 (tables/mod.rs:283-290, test_utils.rs:31-38)
+    masked = np.isin(table, BITMASK_TABLES)
+    if masked.any():
+        n = int(masked.sum())
+        x = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+        zeros = rng.integers(0, 65, size=n)
+        y = np.where(zeros >= 64, np.uint64(0), np.uint64(0xFFFFFFFFFFFFFFFF) << np.minimum(zeros, 63).astype(np.uint64))
+        idx[masked] = interleave_operands(x, y)
+    table = table.copy()
     table[rng.random(T) < 0.1] = 0xFF
-    d["lookup"] = dict(idx=idx, table=table, raf=(rng.random(T) < 0.3).astype(np.uint8), n_tables=n_tables, lists=suffix_lists(n_tables, rng))
-    d["lookup_u_point"] = rand_fr(n_vars, rng)
-    d["lookup_table_values"] = rand_fr(n_tables, rng)
-    d["lookup_raf"] = rand_fr(2, rng)
+    d["lookup"] = dict(idx=idx, table=table, raf=(rng.random(T) < 0.3).astype(np.uint8), n_tables=N_LOOKUP_TABLES, present=present)
+    d["lookup_gamma"] = rand_fr(1, rng)[0]
     d["lookup_reduction"] = rand_fr(n_vars, rng)
     d["ra_count"] = ra_count
     # ---- stage 6a: the RA selector columns of the booleanity check (instruction, bytecode, RAM chunks: 36 columns at log_k_chunk = 4; RAM cold 40 %)
@@ -464,6 +483,7 @@ class DeviceExtended:
         self.bool_cols = ctx.onehot(bo["cols"], 1 << bo["log_k"])
         lk = d["lookup"]
         self.read_raf = ctx.read_raf(lk["idx"], lk["table"], lk["raf"], lk["n_tables"])
+        self.lookup_lists = ffi.lookup_suffix_lists()  # LookupTableKind::suffixes() of the 42 tables
         bc = d["bytecode"]
         self.pc_ints = ctx.ints(bc["push_pc"])  # the address phase's PC column (unmapped rows on 0) and the cycle phase's chunk columns (unmapped rows cold)
         self.pc_chunks = ctx.onehot(bc["chunk_cols"], 1 << bc["chunk_bits"])
@@ -496,7 +516,7 @@ class DeviceExtended:
         m.destroy()
         for t in (eq, t_post, t_rs1, t_rs2):
             t.free()
-        self.claims["lookup"] = None  # needs the v tables of a proof: taken from the first proof's cycle member (same every proof)
+        self.claims["lookup"] = None  # taken from the first proof's first address message (same every proof)
         ctx.synchronize()
 
     # ---- the operators ---------------------------------------------------------------------------------------------------------
@@ -589,33 +609,42 @@ class DeviceExtended:
         return out
 
     def instruction_read_raf(self, label):
+        """OptimizedInstructionReadRafKernel round for round: 16 x (condense, scan on the device; 8 address rounds on the host), then the cycle rounds"""
         ctx, ffi, d = self.ctx, self.ffi, self.d
         lk, rr = d["lookup"], self.read_raf
         tr = ffi.HostTranscript(label)
-        u = ctx.eq_evals(d["lookup_u_point"])  # the per-cycle mass eq(r_reduction, j) every phase condenses
-        v_tables, scans = [], []
+        u = ctx.eq_evals(d["lookup_reduction"])  # the per-cycle mass eq(r_reduction, j) every phase condenses
+        present = np.zeros(N_LOOKUP_TABLES, dtype=np.uint8)
+        present[lk["present"]] = 1
+        state = ffi.HostReadRafAddress(d["lookup_gamma"], present)
+        claim = self.claims["lookup"]
+        v_tables, scans, messages, challenges = [], [], [], []
         for phase in range(PHASES):
             suffix_len = ADDRESS_BITS - 8 * (phase + 1)
             if phase:
                 rr.condense(u, v_tables[-1], suffix_len + 8)
-            raf, suf = rr.phase_scan(u, suffix_len, ADDRESS_BITS, lk["lists"])
-            # the phase's 8 address rounds run over 256-entry polynomials on the caller's side and their messages are what a real transcript absorbs;
-            # here one column of every sum stands in for them (the tests compare the full scans), and 8 challenges give the next eq table
-            tr.append(raf[:, 0])
-            tr.append(suf[:, 0])
+            raf, suf = rr.phase_scan(u, suffix_len, ADDRESS_BITS, self.lookup_lists)
+            state.init_phase(phase, raf, suf)
+            if claim is None:  # the relation's input claim (the prover holds it from the earlier stages): s_0(0) + s_0(1) summed from the tables, once
+                e = state.message()
+                claim = self.claims["lookup"] = ffi.host_fr_add(e[0], e[1])
+            claim, coeffs, chal = state.prove_phase(claim, tr)
             scans.append((raf, suf))
-            v_tables.append(ffi.host_eq_evals(np.stack([tr.challenge() for _ in range(8)])))
+            messages.append(coeffs)
+            challenges.append(chal)
+            v_tables.append(state.v_table(phase))
         u.free()
         vt = np.stack(v_tables)
-        combined, ra = rr.cycle_tables(d["lookup_table_values"], d["lookup_raf"][0], d["lookup_raf"][1], vt, ADDRESS_BITS, d["ra_count"])
+        table_values, raf_interleaved, raf_identity = state.finish()
+        state.close()
+        combined, ra = rr.cycle_tables(table_values, raf_interleaved, raf_identity, vt, ADDRESS_BITS, d["ra_count"])
         n_f = 1 + d["ra_count"]
         member = ctx.member_lc([combined] + ra, [[(None, [(self.one, i)]) for i in range(n_f)]], n_f, eq_point=d["lookup_reduction"])
-        if self.claims["lookup"] is None:
-            self.claims["lookup"] = member.input_claim()
-        out = ctx.prove_batch([member], [self.claims["lookup"]], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)
+        out = ctx.prove_batch([member], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)  # its round check holds only if the address rounds were right
         member.destroy()
         tr.close()
-        return dict(scans=scans, v_tables=vt, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+        return dict(scans=scans, address_polys=np.concatenate(messages), address_challenges=np.concatenate(challenges), v_tables=vt, table_values=table_values[lk["present"]],
+                    raf_values=np.stack([raf_interleaved, raf_identity]), cycle_claim=claim, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
 
     def address_domain(self, label):
         """the joint-domain relations whose rounds run over K-sized tables: bytecode read+RAF (6a, 6b), RAM RAF evaluation, RAM output check.  The key indexes are

@@ -433,3 +433,46 @@ EXPORT void orc_read_raf_address_rounds(const uint64_t *lookup_index, const uint
     operands_out[2] = mle_identity(challenges);
     operands_out[3] = mle_upper_all_ones(challenges);
 }
+
+/* The same rounds one at a time, for a prover that draws challenge i from a transcript that has absorbed message i: `weight` (cycles entries, in / out) holds
+ * eq(r_reduction, j) * eq(r_{<i}, k_j[<i]); round: evals_out = s_i(0), s_i(1), s_i(2); bind: the factor of challenge i. */
+EXPORT void orc_read_raf_address_round(const uint64_t *lookup_index, const uint8_t *table_index, const uint8_t *raf_flag, size_t cycles, const fr_t *weight, const fr_t *gamma,
+                                       int canonical, const fr_t *challenges /* i of them */, uint32_t i, fr_t *evals_out /* 3 */) {
+    fr_t sums[3] = {fr_zero(), fr_zero(), fr_zero()};
+#pragma omp parallel
+    {
+        fr_t local[3] = {fr_zero(), fr_zero(), fr_zero()};
+        fr_t point[LOG_K];
+        for (unsigned t = 0; t < i; ++t) point[t] = challenges[t];
+#pragma omp for schedule(static)
+        for (size_t j = 0; j < cycles; ++j) {
+            const u128 k = ((u128)lookup_index[2 * j + 1] << 64) | lookup_index[2 * j];
+            for (unsigned t = i + 1; t < LOG_K; ++t) point[t] = (k >> (LOG_K - 1 - t)) & 1 ? fr_one() : fr_zero();
+            const int bit = (int)((k >> (LOG_K - 1 - i)) & 1);
+            for (unsigned c = 0; c < 3; ++c) {
+                const fr_t cf = fr_from_u64(c);
+                const fr_t eq_c = bit ? cf : FSUB(fr_one(), cf);
+                if (fr_is_zero(&eq_c)) continue;
+                point[i] = cf;
+                local[c] = FADD(local[c], FMUL(FMUL(weight[j], eq_c), row_summand(point, table_index[j], raf_flag[j], *gamma, canonical)));
+            }
+        }
+#pragma omp critical
+        for (unsigned c = 0; c < 3; ++c) sums[c] = FADD(sums[c], local[c]);
+    }
+    for (unsigned c = 0; c < 3; ++c) evals_out[c] = sums[c];
+}
+EXPORT void orc_read_raf_address_bind(const uint64_t *lookup_index, size_t cycles, fr_t *weight, uint32_t i, const fr_t *challenge) {
+    for (size_t j = 0; j < cycles; ++j) {
+        const u128 k = ((u128)lookup_index[2 * j + 1] << 64) | lookup_index[2 * j];
+        weight[j] = FMUL(weight[j], (k >> (LOG_K - 1 - i)) & 1 ? *challenge : FSUB(fr_one(), *challenge));
+    }
+}
+/* Val_t(r_address) of every table and the operand polynomials at r_address: left, right, identity, upper_all_ones */
+EXPORT void orc_read_raf_address_values(const fr_t *challenges /* 128 */, fr_t *table_values_out /* T_COUNT */, fr_t *operands_out /* 4 */) {
+    for (unsigned t = 0; t < T_COUNT; ++t) table_values_out[t] = evaluate_mle(t, challenges);
+    operands_out[0] = mle_left_operand(challenges);
+    operands_out[1] = mle_right_operand(challenges);
+    operands_out[2] = mle_identity(challenges);
+    operands_out[3] = mle_upper_all_ones(challenges);
+}

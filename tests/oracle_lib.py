@@ -1168,3 +1168,33 @@ def read_raf_address_rounds(lookup_index, table_index, raf_flag, u, gamma, chall
     lib().orc_read_raf_address_rounds(_p(idx), _p(tab), _p(raf), C.c_size_t(idx.shape[0]), _p(uu), _p(np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4)),
                                       C.c_int(1 if canonical else 0), _p(ch), _p(evals), _p(tv), _p(ops))
     return evals.reshape(128, 3, 4), tv, ops
+
+
+class ReadRafAddressDirect:
+    """the address rounds from the definition, one at a time (orc_read_raf_address_round / _bind): for a prover whose challenges come from a transcript"""
+
+    def __init__(self, lookup_index, table_index, raf_flag, u, gamma, canonical=False):
+        self.idx, self.tab, self.raf = _rr_args(lookup_index, table_index, raf_flag)
+        self.weight = np.ascontiguousarray(u, dtype=np.uint64).reshape(-1, 4).copy()
+        self.gamma = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4).copy()
+        self.canonical = 1 if canonical else 0
+        self.challenges = fr_array(128)
+        self.i = 0
+
+    def round(self):
+        out = fr_array(3)
+        lib().orc_read_raf_address_round(_p(self.idx), _p(self.tab), _p(self.raf), C.c_size_t(self.idx.shape[0]), _p(self.weight), _p(self.gamma), C.c_int(self.canonical),
+                                         _p(self.challenges), C.c_uint32(self.i), _p(out))
+        return out
+
+    def bind(self, r):
+        rr = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        lib().orc_read_raf_address_bind(_p(self.idx), C.c_size_t(self.idx.shape[0]), _p(self.weight), C.c_uint32(self.i), _p(rr))
+        self.challenges[self.i] = rr
+        self.i += 1
+
+    def values(self):
+        assert self.i == 128
+        tv, ops = fr_array(len(TABLE_KINDS)), fr_array(4)
+        lib().orc_read_raf_address_values(_p(self.challenges), _p(tv), _p(ops))
+        return tv, ops

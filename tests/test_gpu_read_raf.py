@@ -112,3 +112,70 @@ def test_argument_checks(ctx):
         rr.phase_scan(ctx.upload(rand_fr(8, 97)), 120, ADDRESS_BITS, [[0], [1]])
     assert e.value.status == 5
     rr.free()
+
+
+@pytest.mark.parametrize("log_t,seed,canonical,all_tables", [(4, 12345, False, False), (3, 67890, True, False), (10, 31, False, True)])
+def test_address_rounds_with_device_scans_match_the_definition(ctx, log_t, seed, canonical, all_tables):
+    """The kernel end to end on its address side: device condensation + scans over the 42 REAL tables feed the host state machine (jolt_host_read_raf_address_*),
+    and every one of the 128 round polynomials equals the oracle's from-the-definition round (oracle/lookup_tables.c).  Rows, reduction point, gamma and
+    challenges are the reference kernel's own parity recipe (instruction_read_raf.rs:1477-1522, 1579-1646); the third case has every table present.  Then the
+    cycle columns built from the state machine's table values equal the oracle's built from evaluate_mle at r_address, and the running claim is their sum."""
+    from lookup_table_fixture import all_table_rows, challenge, fixture_rows
+    idx, tab, raf = all_table_rows(log_t, seed) if all_tables else fixture_rows(log_t, seed)
+    T = 1 << log_t
+    lists = ffi.lookup_suffix_lists()
+    r_reduction = O.to_mont([1000 + 37 * i for i in range(log_t)])
+    u_host = O.eq_evals(r_reduction)
+    gamma = O.to_mont([0xACE157EF])[0]
+    challenges = O.to_mont([challenge(i) for i in range(128)])
+    present = np.zeros(42, dtype=np.uint8)
+    present[[int(t) for t in set(tab.tolist()) if t != 0xFF]] = 1
+    rr = ctx.read_raf(idx, tab, raf, 42)
+    u = ctx.upload(u_host)
+    state = ffi.HostReadRafAddress(gamma, present, canonical)
+    direct = O.ReadRafAddressDirect(idx, tab, raf, u_host, gamma, canonical=canonical)
+    claim = O.read_raf_input_claim(idx, tab, raf, u_host, gamma, canonical=canonical)
+    v_tables = []
+    for phase in range(PHASES):
+        suffix_len = ADDRESS_BITS - 8 * (phase + 1)
+        if phase:
+            rr.condense(u, v_tables[-1], suffix_len + 8)
+        raf_sums, suffix_sums = rr.phase_scan(u, suffix_len, ADDRESS_BITS, lists, canonical=canonical)
+        state.init_phase(phase, raf_sums, suffix_sums)
+        if phase == 0:
+            first = state.message()  # s(1) summed from the tables: s(0) + s(1) is the first-principles input claim
+            assert np.array_equal(ffi.host_fr_add(first[0], first[1]), claim)
+        for rnd in range(8):
+            i = 8 * phase + rnd
+            got = state.message(claim)
+            assert np.array_equal(got, direct.round()), i
+            coeffs = O.univariate_from_evals(got)
+            claim = O.univariate_evaluate(coeffs, challenges[i])
+            direct.bind(challenges[i])
+            assert state.bind(challenges[i]) == (rnd == 7)
+        v_tables.append(state.v_table(phase))
+        assert np.array_equal(v_tables[-1], O.eq_evals(challenges[8 * phase: 8 * phase + 8]))
+    table_values, raf_interleaved, raf_identity = state.finish()
+    want_values, (left, right, identity, upper) = direct.values()
+    used = np.flatnonzero(present)
+    assert np.array_equal(table_values[used], want_values[used])
+    g2 = O.fr_mul(gamma.reshape(1, 4), gamma.reshape(1, 4))
+    assert np.array_equal(raf_interleaved, O.fr_add(O.fr_mul(gamma.reshape(1, 4), left.reshape(1, 4)), O.fr_mul(g2, right.reshape(1, 4)))[0])
+    want_identity = O.fr_mul(g2, identity.reshape(1, 4))
+    if canonical:
+        want_identity = O.fr_add(want_identity, O.fr_mul(O.fr_mul(g2, gamma.reshape(1, 4)), upper.reshape(1, 4)))
+    assert np.array_equal(raf_identity, want_identity[0])
+    ra_count = 8 if log_t != 3 else 4
+    vt = np.stack(v_tables)
+    combined, ra = rr.cycle_tables(table_values, raf_interleaved, raf_identity, vt, ADDRESS_BITS, ra_count)
+    want_combined, want_ra = O.read_raf_cycle_tables(idx, tab, raf, want_values, raf_interleaved, raf_identity, vt, ADDRESS_BITS, ra_count)
+    assert np.array_equal(combined.download(), want_combined)
+    orc = O.Member.expr([O.eq_evals(r_reduction), want_combined] + [want_ra[i] for i in range(ra_count)], [(O.to_mont([1])[0], list(range(2 + ra_count)))], 2 + ra_count)
+    assert np.array_equal(orc.input_claim(), claim)  # what 128 address rounds leave is what the log T cycle rounds sum
+    for i in range(ra_count):
+        assert np.array_equal(ra[i].download(), want_ra[i])
+        ra[i].free()
+    combined.free()
+    u.free()
+    state.close()
+    rr.free()

@@ -66,3 +66,17 @@ def test_all_extended_drivers_run_on_the_oracle():
                         "ram_raf_evaluation", "ram_output_check"}
     assert out["spartan_outer"]["polys"].shape[0] == 6 and out["spartan_product"]["polys"].shape[0] == 5
     assert len(out["instruction_read_raf"]["scans"]) == S.PHASES and out["instruction_read_raf"]["polys"].shape[0] == 5
+
+
+def test_read_raf_twin_paths_agree():
+    """OracleExtended.instruction_read_raf takes its address-round polynomials from the definition up to T = 2^12 and from the product's host state machine (fed
+    with the oracle's scan sums) above: at a size where both run they are the same transcript.  Each path also asserts on its way that s(0) + s(1) is the running
+    claim, starting from the first-principles input claim, and that the claim left after 128 rounds is the sum the cycle rounds start from."""
+    class HostStateMachine(OracleExtended):
+        DIRECT_ADDRESS_ROUNDS_MAX_LOG_T = 0
+    a = OracleExtended(8, seed=9).instruction_read_raf(7)
+    b = HostStateMachine(8, seed=9).instruction_read_raf(7)
+    for key in ("address_polys", "address_challenges", "v_tables", "table_values", "raf_values", "cycle_claim", "polys", "challenges", "final_claim", "claim"):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    assert a["address_polys"].shape == (128, 3, 4) and len(a["scans"]) == S.PHASES
+

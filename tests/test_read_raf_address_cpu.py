@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as O
 from jolt_amd import ffi
-from lookup_table_fixture import TABLES, all_table_rows, challenge, fixture_rows, random_index
+from lookup_table_fixture import CHANGE_DIVISOR_W_CORNER, TABLES, all_table_rows, challenge, fixture_rows, random_index
 
 R = O.R_MOD
 ADDRESS_BITS = 128
@@ -89,6 +89,28 @@ def test_prefix_suffix_decomposition_wide_phases(kind):
 def test_prefix_suffix_decomposition_small_phases():
     rng = np.random.default_rng(5)
     decomposition_run(40, 2, random_index("WindowMaskW", rng), rng)  # window_mask_w.rs:88-91: phase boundaries inside the bits the prefix reads
+
+
+def test_change_divisor_w_corner_follows_the_reference():
+    """(MIN32, -1) in the low lanes: the table entry is 1 and so is the multilinear extension, but the reference's prefix-suffix form gives
+    RightOperandW + SignExtensionRightOperand = 2^64 - 1 while bit 31 of the left operand is still in the suffix, and the product reproduces exactly that."""
+    kind = TABLES.index("VirtualChangeDivisorW")
+    k = CHANGE_DIVISOR_W_CORNER
+    assert O.table_materialize_entry(kind, k) == 1
+    bits = [(k >> (127 - i)) & 1 for i in range(128)]
+    assert fr_int(O.table_evaluate_mle(kind, mont(bits)))[0] == 1
+    checkpoints = ffi.host_lookup_prefix_default_checkpoints()
+    for phase in range(16):
+        suffix_len = ADDRESS_BITS - 8 * (phase + 1)
+        chunk = (k >> suffix_len) & 255
+        prefix_evals = fr_int(checkpoints)
+        tables = {p: fr_int(ffi.host_lookup_prefix_table(p, checkpoints, 8, suffix_len)) for p in ffi.lookup_table_prefixes(kind)}
+        for p, t in tables.items():
+            prefix_evals[p] = t[chunk]
+        suffix_evals = mont([ffi.host_suffix_mle(s, k & ((1 << suffix_len) - 1), suffix_len) for s in ffi.lookup_suffix_lists()[kind]])
+        value = fr_int(ffi.host_lookup_table_combine(kind, mont(prefix_evals), suffix_evals))[0]
+        assert value == ((1 << 64) - 1 if phase < 8 else 1), phase
+        checkpoints = mont(prefix_evals)  # Boolean challenges: the chunk's own entry is the next checkpoint
 
 
 def product_address_rounds(idx, tab, raf, u, gamma, canonical, challenges, claim, scan):

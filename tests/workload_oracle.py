@@ -296,28 +296,74 @@ class OracleExtended:
         orc.close()
         return out
 
+    # above this many cycles the from-the-definition address rounds (T x 128 x 3 table evaluations) stop being a test-sized computation
+    DIRECT_ADDRESS_ROUNDS_MAX_LOG_T = 12
+
     def instruction_read_raf(self, label):
+        """The twin of DeviceExtended.instruction_read_raf.  The T-scale scans are the oracle's (oracle/read_raf.c) at every size and are compared sum for sum.
+        The address-round polynomials are the oracle's FROM THE DEFINITION (oracle/lookup_tables.c: evaluate_mle of the row's table at the mixed point, no
+        prefix / suffix machinery) up to T = 2^12; above that they are produced by the product's host state machine fed with the ORACLE's scan sums -- the state
+        machine's only inputs, 256 entries per polynomial whatever T is -- which tests/test_read_raf_address_cpu.py pins to the definition round for round."""
+        from jolt_amd import ffi
         S, d = self.S, self.d
         lk = d["lookup"]
+        lists = ffi.lookup_suffix_lists()
         tr = O.MockTranscript(label)
-        u = O.eq_evals(d["lookup_u_point"])
-        v_tables, scans = [], []
+        u0 = O.eq_evals(d["lookup_reduction"])
+        gamma = d["lookup_gamma"]
+        claim = O.read_raf_input_claim(lk["idx"], lk["table"], lk["raf"], u0, gamma)  # first principles: materialize_entry and the operands of every row
+        input_claim = claim
+        direct = O.ReadRafAddressDirect(lk["idx"], lk["table"], lk["raf"], u0, gamma) if self.n_vars <= self.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T else None
+        present = np.zeros(S.N_LOOKUP_TABLES, dtype=np.uint8)
+        present[lk["present"]] = 1
+        state = None if direct else ffi.HostReadRafAddress(gamma, present)
+        u = u0
+        v_tables, scans, messages, challenges = [], [], [], []
         for phase in range(S.PHASES):
             suffix_len = S.ADDRESS_BITS - 8 * (phase + 1)
             if phase:
                 u = O.read_raf_condense(lk["idx"], u, v_tables[-1], suffix_len + 8)
-            raf, suf = O.read_raf_phase_scan(lk["idx"], lk["table"], lk["raf"], lk["n_tables"], u, suffix_len, S.ADDRESS_BITS, lk["lists"])
-            for v in list(raf[:, 0]) + list(suf[:, 0]):
-                tr.append_fr(v)
+            raf, suf = O.read_raf_phase_scan(lk["idx"], lk["table"], lk["raf"], lk["n_tables"], u, suffix_len, S.ADDRESS_BITS, lists)
             scans.append((raf, suf))
-            v_tables.append(O.eq_evals(np.stack([tr.challenge() for _ in range(8)])))
+            if state:
+                state.init_phase(phase, raf, suf)
+            phase_challenges = []
+            for rnd in range(8):
+                if direct:
+                    e = direct.round()
+                    assert np.array_equal(O.fr_add(e[0:1], e[1:2])[0], claim), ("s(0) + s(1) != running claim", phase, rnd)
+                else:
+                    e = state.message(claim)
+                coeffs = O.univariate_from_evals(e)
+                for c in coeffs:
+                    tr.append_fr(c)
+                r = tr.challenge()
+                claim = O.univariate_evaluate(coeffs, r)
+                if direct:
+                    direct.bind(r)
+                else:
+                    state.bind(r)
+                messages.append(coeffs)
+                phase_challenges.append(r)
+            challenges += phase_challenges
+            v_tables.append(O.eq_evals(np.stack(phase_challenges)))
         vt = np.stack(v_tables)
-        combined, ra = O.read_raf_cycle_tables(lk["idx"], lk["table"], lk["raf"], d["lookup_table_values"], d["lookup_raf"][0], d["lookup_raf"][1], vt, S.ADDRESS_BITS, d["ra_count"])
+        if direct:
+            table_values, (left, right, identity, _) = direct.values()
+            g2 = O.fr_mul(gamma.reshape(1, 4), gamma.reshape(1, 4))[0]
+            raf_interleaved = O.fr_add(O.fr_mul(gamma.reshape(1, 4), left.reshape(1, 4)), O.fr_mul(g2.reshape(1, 4), right.reshape(1, 4)))[0]
+            raf_identity = O.fr_mul(g2.reshape(1, 4), identity.reshape(1, 4))[0]
+        else:
+            table_values, raf_interleaved, raf_identity = state.finish()
+            state.close()
+        combined, ra = O.read_raf_cycle_tables(lk["idx"], lk["table"], lk["raf"], table_values, raf_interleaved, raf_identity, vt, S.ADDRESS_BITS, d["ra_count"])
         n_f = 1 + d["ra_count"]
         orc = O.Member.expr([O.eq_evals(d["lookup_reduction"]), combined] + [ra[i] for i in range(d["ra_count"])], [(self.one, list(range(1 + n_f)))], 1 + n_f)
-        claim = orc.input_claim()
+        assert np.array_equal(orc.input_claim(), claim), "the running claim after 128 address rounds is not the sum the cycle rounds start from"
         out = O.prove_batch([orc], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)
-        return dict(scans=scans, v_tables=vt, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], claim=claim)
+        return dict(scans=scans, address_polys=np.stack(messages), address_challenges=np.stack(challenges), v_tables=vt, table_values=np.asarray(table_values)[lk["present"]],
+                    raf_values=np.stack([raf_interleaved, raf_identity]), cycle_claim=claim, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"],
+                    claim=input_claim)
 
     def booleanity_address(self, label):
         S, bo = self.S, self.d["booleanity"]

@@ -25,23 +25,30 @@ def main():
             acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
         tr = ffi.HostTranscript(5)
-        t0 = time.perf_counter(); u = ctx.eq_evals(d["lookup_u_point"]); lap("eq", t0)
+        t0 = time.perf_counter(); u = ctx.eq_evals(d["lookup_reduction"]); lap("eq", t0)
+        present = np.zeros(S.N_LOOKUP_TABLES, dtype=np.uint8)
+        present[lk["present"]] = 1
+        t0 = time.perf_counter(); state = ffi.HostReadRafAddress(d["lookup_gamma"], present); lap("host_create", t0)
+        claim = e.claims["lookup"]
         v_tables = []
         for phase in range(S.PHASES):
             suffix_len = S.ADDRESS_BITS - 8 * (phase + 1)
             if phase:
                 t0 = time.perf_counter(); rr.condense(u, v_tables[-1], suffix_len + 8); lap("condense", t0)
-            t0 = time.perf_counter(); raf, suf = rr.phase_scan(u, suffix_len, S.ADDRESS_BITS, lk["lists"]); lap("scan", t0)
-            t0 = time.perf_counter(); tr.append(raf[:, 0]); tr.append(suf[:, 0]); lap("append", t0)
-            t0 = time.perf_counter(); v_tables.append(ffi.host_eq_evals(np.stack([tr.challenge() for _ in range(8)]))); lap("challenges", t0)
+            t0 = time.perf_counter(); raf, suf = rr.phase_scan(u, suffix_len, S.ADDRESS_BITS, e.lookup_lists); lap("scan", t0)
+            t0 = time.perf_counter(); state.init_phase(phase, raf, suf); lap("host_init_phase", t0)
+            if claim is None:
+                m = state.message()
+                claim = e.claims["lookup"] = ffi.host_fr_add(m[0], m[1])
+            t0 = time.perf_counter(); claim, _, _ = state.prove_phase(claim, tr); lap("host_8_rounds", t0)
+            t0 = time.perf_counter(); v_tables.append(state.v_table(phase)); lap("host_v_table", t0)
         u.free()
         vt = np.stack(v_tables)
-        t0 = time.perf_counter(); combined, ra = rr.cycle_tables(d["lookup_table_values"], d["lookup_raf"][0], d["lookup_raf"][1], vt, S.ADDRESS_BITS, d["ra_count"]); lap("cycle_tables", t0)
+        t0 = time.perf_counter(); tv, ri, rid = state.finish(); state.close(); lap("host_finish", t0)
+        t0 = time.perf_counter(); combined, ra = rr.cycle_tables(tv, ri, rid, vt, S.ADDRESS_BITS, d["ra_count"]); lap("cycle_tables", t0)
         n_f = 1 + d["ra_count"]
         t0 = time.perf_counter(); member = ctx.member_lc([combined] + ra, [[(None, [(e.one, i)]) for i in range(n_f)]], n_f, eq_point=d["lookup_reduction"]); lap("member", t0)
-        if e.claims["lookup"] is None:
-            e.claims["lookup"] = member.input_claim()
-        t0 = time.perf_counter(); ctx.prove_batch([member], [e.claims["lookup"]], [e.one], [0], log_t, n_f + 1, label=6); lap("cycle_rounds", t0)
+        t0 = time.perf_counter(); ctx.prove_batch([member], [claim], [e.one], [0], log_t, n_f + 1, label=6); lap("cycle_rounds", t0)
         member.destroy()
         print({k: round(v, 2) for k, v in acc.items()}, flush=True)
     for name, fn in (("spartan_outer", lambda: e.spartan(e.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"], e.claims["outer"], 2, 7)),
