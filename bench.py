@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-msm", action="store_true", help="sumcheck legs only (BASELINE configs[1]); default: commit + open inside the step")
     ap.add_argument("--stages", choices=["all", "2-6b"], default="all",
                     help="all (default): the step also runs the stage 1 / 2 / 5 operators that are not plain cycle-domain relations -- Spartan outer and product, the sparse "
-                         "RAM read-write matrix, the instruction read-RAF scans and cycle rounds (jolt_amd/stages.py); 2-6b: the round-2 step (comparable with BENCH_r02)")
+                         "RAM read-write matrix, instruction read-RAF checking with its 128 address rounds (jolt_amd/stages.py); 2-6b: the round-2 step (comparable with BENCH_r02)")
     ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
     ap.add_argument("--roofline-only", action="store_true", help="only run the bind-kernel roofline loop (rocprof target)")
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
@@ -386,7 +386,7 @@ def main():
         ram = the_ext.d["ram"]
         ext_note = (f"runs the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators outside the cycle-domain catalogue -- Spartan outer (uni-skip sums off 35 integer columns, Az / Bz, log T + 1 "
                     f"remainder rounds, claimed inputs), Spartan product (the same over the 6 product lanes), the sparse RAM read-write matrix (K = 2^{ram['log_k']}, "
-                    f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and the instruction read-RAF scans of all 16 address phases + log T cycle rounds, the booleanity address phase and the Hamming-weight claim reduction (pushforward masses of the 36 RA columns + log K host rounds each), and the address-domain relations -- bytecode read+RAF (five per-stage "
+                    f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and instruction read-RAF checking end to end over the 42 lookup tables (per address phase the T-scale scans on the device and the 8 rounds over 256-entry prefix / suffix polynomials on the host, 128 address rounds in all, then log T cycle rounds), the booleanity address phase and the Hamming-weight claim reduction (pushforward masses of the 36 RA columns + log K host rounds each), and the address-domain relations -- bytecode read+RAF (five per-stage "
                     f"pushforwards onto the 2^{the_ext.d['bytecode']['log_k']}-entry bytecode domain + log K rounds, then C * prod ra_i over log T rounds), RAM RAF evaluation and the RAM output check "
                     f"(pushforward / final-memory column over a sorted index of the address column + log K rounds each)"
                     + (" (per-rank replicas over each rank's block of cycles: these operators have no cross-rank form yet)" if sharded else "") + " -- ")
