@@ -364,3 +364,86 @@ impl Drop for HipReadRaf {
         let _ = unsafe { ffi::jolt_read_raf_destroy(self.ctx.raw, self.raw) };
     }
 }
+
+/// The host half of `OptimizedInstructionReadRafKernel`'s 128 address rounds (`jolt_host_read_raf_address_*`): the 256-entry prefix polynomials of a phase,
+/// the tables' `combine`, the RAF decompositions, checkpoints.  Together with [`HipReadRaf`] this is the kernel's `ProveRounds` body for rounds
+/// `0 .. address_bits`:
+///
+/// ```text
+/// prove_round(bind, round, previous_claim):                    // instruction_read_raf.rs:1352-1366
+///     if let Some(r) = bind { if address.bind(r)? { /* phase closed */ } }
+///     if round % 8 == 0 {                                       // init_phase (:747-900)
+///         let p = round / 8;
+///         if p > 0 { rows.condense(&mut u, &address.v_table(p - 1)?, 128 - 8 * p)?; }
+///         let scan = rows.phase_scan(&u, 128 - 8 * (p + 1), 128, CANONICAL_INSTRUCTION_ADDRESS, &suffix_kinds)?;
+///         address.init_phase(p, &scan)?;
+///     }
+///     UnivariatePoly::from_evals(&address.message(previous_claim)?)
+/// ```
+///
+/// after round 127's bind: `address.finish()` gives the arguments of [`HipReadRaf::cycle_tables`].  No device work happens here; table ids are
+/// `LookupTableKind::index()`.
+pub struct HipReadRafAddress {
+    raw: *mut ffi::jolt_read_raf_address,
+}
+// SAFETY: the handle owns plain host memory; calls are serialised by &mut self.
+unsafe impl Send for HipReadRafAddress {}
+
+impl HipReadRafAddress {
+    /// `LookupTableKind::suffixes()` of all 42 tables as the device scan wants them (`Suffixes as u8`), in `LookupTableKind` order.
+    pub fn suffix_kinds() -> Result<Vec<Vec<u8>>, HipError> {
+        let mut offsets = [0u32; 43];
+        check(unsafe { ffi::jolt_lookup_suffix_layout(offsets.as_mut_ptr(), ptr::null_mut()) }, ptr::null())?;
+        let mut kinds = vec![0u8; offsets[42] as usize];
+        // SAFETY: sized from the first call.
+        check(unsafe { ffi::jolt_lookup_suffix_layout(offsets.as_mut_ptr(), kinds.as_mut_ptr()) }, ptr::null())?;
+        Ok((0..42).map(|t| kinds[offsets[t] as usize..offsets[t + 1] as usize].to_vec()).collect())
+    }
+    /// `table_present[t]`: some cycle's lookup table is `t` (the kernel's non-empty buckets, `:683-697`).
+    pub fn new(gamma: Fr, table_present: &[bool; 42], canonical: bool) -> Result<Self, HipError> {
+        let present: Vec<u8> = table_present.iter().map(|&p| u8::from(p)).collect();
+        let mut raw = ptr::null_mut();
+        // SAFETY: 42 flags.
+        check(unsafe { ffi::jolt_host_read_raf_address_create((&gamma as *const Fr).cast(), present.as_ptr(), i32::from(canonical), &mut raw) }, ptr::null())?;
+        Ok(Self { raw })
+    }
+    pub fn init_phase(&mut self, phase: u32, scan: &PhaseScan) -> Result<(), HipError> {
+        // SAFETY: the scan of the 42-table layout.
+        check(unsafe { ffi::jolt_host_read_raf_address_init_phase(self.raw, phase, scan.raf.as_ptr().cast(), scan.suffix.as_ptr().cast()) }, ptr::null())
+    }
+    /// `address_message` (`:973-1050`): `[s(0), s(1), s(2)]` for `UnivariatePoly::from_evals`.
+    pub fn message(&mut self, previous_claim: Fr) -> Result<[Fr; 3], HipError> {
+        let mut evals = [Fr::default(); 3];
+        // SAFETY: three elements out.
+        check(unsafe { ffi::jolt_host_read_raf_address_message(self.raw, (&previous_claim as *const Fr).cast(), evals.as_mut_ptr().cast()) }, ptr::null())?;
+        Ok(evals)
+    }
+    /// The address branch of `bind` (`:1235-1282`); `true` when the phase closed (its eq table and the new checkpoints are in place).
+    pub fn bind(&mut self, challenge: Fr) -> Result<bool, HipError> {
+        let mut done = 0i32;
+        check(unsafe { ffi::jolt_host_read_raf_address_bind(self.raw, (&challenge as *const Fr).cast(), &mut done) }, ptr::null())?;
+        Ok(done != 0)
+    }
+    /// `eq(phase challenges, .)` of a closed phase: the `v_prev` of the next condensation and a row of `cycle_tables`' `v_tables`.
+    pub fn v_table(&self, phase: u32) -> Result<[Fr; 256], HipError> {
+        let mut out = [Fr::default(); 256];
+        check(unsafe { ffi::jolt_host_read_raf_address_v_table(self.raw, phase, out.as_mut_ptr().cast()) }, ptr::null())?;
+        Ok(out)
+    }
+    /// `init_cycle_rounds` (`:1140-1160`): `(table_values[42], raf_interleaved, raf_identity)`.
+    pub fn finish(&self) -> Result<(Vec<Fr>, Fr, Fr), HipError> {
+        let mut values = vec![Fr::default(); 42];
+        let (mut interleaved, mut identity) = (Fr::default(), Fr::default());
+        check(
+            unsafe { ffi::jolt_host_read_raf_address_finish(self.raw, values.as_mut_ptr().cast(), (&mut interleaved as *mut Fr).cast(), (&mut identity as *mut Fr).cast()) },
+            ptr::null(),
+        )?;
+        Ok((values, interleaved, identity))
+    }
+}
+impl Drop for HipReadRafAddress {
+    fn drop(&mut self) {
+        // SAFETY: created by jolt_host_read_raf_address_create.
+        let _ = unsafe { ffi::jolt_host_read_raf_address_destroy(self.raw) };
+    }
+}
