@@ -484,6 +484,8 @@ class DeviceExtended:
         lk = d["lookup"]
         self.read_raf = ctx.read_raf(lk["idx"], lk["table"], lk["raf"], lk["n_tables"])
         self.lookup_lists = ffi.lookup_suffix_lists()  # LookupTableKind::suffixes() of the 42 tables
+        # the packed output-claim facts of the kernel (claim_columns, instruction_read_raf.rs:1163-1173) as two one-hot columns: the table index, and 0 on RAF rows
+        self.lookup_claim_columns = ctx.onehot(np.stack([lk["table"], np.where(lk["raf"] != 0, 0, 0xFF).astype(np.uint8)]), 64)
         bc = d["bytecode"]
         self.pc_ints = ctx.ints(bc["push_pc"])  # the address phase's PC column (unmapped rows on 0) and the cycle phase's chunk columns (unmapped rows cold)
         self.pc_chunks = ctx.onehot(bc["chunk_cols"], 1 << bc["chunk_bits"])
@@ -641,9 +643,16 @@ class DeviceExtended:
         n_f = 1 + d["ra_count"]
         member = ctx.member_lc([combined] + ra, [[(None, [(self.one, i)]) for i in range(n_f)]], n_f, eq_point=d["lookup_reduction"])
         out = ctx.prove_batch([member], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)  # its round check holds only if the address rounds were right
+        instruction_ra = member.final_values()[1:n_f]  # output_claims (:1376-1456): the bound ra_i ...
         member.destroy()
+        # ... and the flag claims at the normalized cycle point: masses of eq(r_cycle, .) per lookup table and over the RAF rows -- one pushforward of the packed claim column
+        eq_cycle = ctx.eq_evals(out["challenges"][::-1])
+        flags = self.lookup_claim_columns.pushforward(eq_cycle)
+        flag_claims = flags.download().reshape(2, -1, 4)
+        flags.free()
+        eq_cycle.free()
         tr.close()
-        return dict(scans=scans, address_polys=np.concatenate(messages), address_challenges=np.concatenate(challenges), v_tables=vt, table_values=table_values[lk["present"]],
+        return dict(lookup_table_flags=flag_claims[0][lk["present"]], instruction_raf_flag=flag_claims[1][0], instruction_ra=instruction_ra, scans=scans, address_polys=np.concatenate(messages), address_challenges=np.concatenate(challenges), v_tables=vt, table_values=table_values[lk["present"]],
                     raf_values=np.stack([raf_interleaved, raf_identity]), cycle_claim=claim, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
 
     def address_domain(self, label):
@@ -679,3 +688,4 @@ class DeviceExtended:
         for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx, self.bool_cols, self.pc_ints, self.pc_chunks]:
             c.free()
         self.read_raf.free()
+        self.lookup_claim_columns.free()

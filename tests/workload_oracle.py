@@ -361,7 +361,11 @@ class OracleExtended:
         orc = O.Member.expr([O.eq_evals(d["lookup_reduction"]), combined] + [ra[i] for i in range(d["ra_count"])], [(self.one, list(range(1 + n_f)))], 1 + n_f)
         assert np.array_equal(orc.input_claim(), claim), "the running claim after 128 address rounds is not the sum the cycle rounds start from"
         out = O.prove_batch([orc], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)
-        return dict(scans=scans, address_polys=np.stack(messages), address_challenges=np.stack(challenges), v_tables=vt, table_values=np.asarray(table_values)[lk["present"]],
+        instruction_ra = orc.final_values()[2:1 + n_f]
+        eq_cycle = O.eq_evals(np.asarray(out["challenges"])[::-1])
+        flags = O.onehot_pushforward(lk["table"], 64, eq_cycle)
+        raf_flag = O.onehot_pushforward(np.where(lk["raf"] != 0, 0, 0xFF).astype(np.uint8), 64, eq_cycle)[0]
+        return dict(lookup_table_flags=flags[lk["present"]], instruction_raf_flag=raf_flag, instruction_ra=instruction_ra, scans=scans, address_polys=np.stack(messages), address_challenges=np.stack(challenges), v_tables=vt, table_values=np.asarray(table_values)[lk["present"]],
                     raf_values=np.stack([raf_interleaved, raf_identity]), cycle_claim=claim, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"],
                     claim=input_claim)
 
