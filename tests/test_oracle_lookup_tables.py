@@ -110,3 +110,36 @@ def test_mle_is_multilinear_in_each_variable():
             v0 = O.from_mont(O.table_evaluate_mle(kind, lo))[0]
             v1 = O.from_mont(O.table_evaluate_mle(kind, hi))[0]
             assert v == (v0 + p_int[var] * (v1 - v0)) % R, (TABLES[kind], int(var))
+
+
+def test_reference_known_answers_of_the_bit_layer():
+    """The concrete values the reference's own unit tests hold for this path (crates/jolt-lookup-tables/src/interleave.rs:66-112, lookup_bits.rs:181-246):
+    interleave / uninterleave on every pair and value they list, LookupBits masking, split, trailing zeros / leading ones -- against the oracle's bit layer, the
+    product's (suffix_mle.hip.h built for the host) and the fixture's Python integers."""
+    import ctypes as C
+    from jolt_amd import ffi
+    from lookup_table_fixture import interleave, operands
+
+    def oracle_operands(v):
+        x, y = C.c_uint64(), C.c_uint64()
+        O.lib().orc_uninterleave(C.c_uint64(v & (2**64 - 1)), C.c_uint64(v >> 64), C.byref(x), C.byref(y))
+        return x.value, y.value
+
+    M = 2**64 - 1
+    assert interleave(0b01, 0b10) == 0b0110 and interleave(1, 0) == 0b10 and interleave(0, 1) == 0b01  # roundtrip_small, single_bit_positions
+    for x, y in [(0, 0), (M, M), (M, 0), (0, M), (0xDEADBEEFCAFEBABE, 0x123456789ABCDEF0), (1, 1), (1 << 63, 1 << 63), (0xDEAD, 0xBEEF)]:
+        v = interleave(x, y)
+        assert oracle_operands(v) == (x, y) == operands(v)
+        assert O.suffix_mle(5, v, 128) == y and ffi.host_suffix_mle(5, v, 128) == y                      # Suffixes::RightOperand reads y off the index
+        assert O.suffix_mle(1, v, 128) == x & y and ffi.host_suffix_mle(1, v, 128) == x & y
+    for v in [0, 1, 2**128 - 1, 0xAAAABBBBCCCCDDDD1111222233334444]:                                     # uninterleave_interleave_roundtrip
+        assert interleave(*oracle_operands(v)) == v
+    # LookupBits::new(0xFF, 4) keeps 0x0F (new_masks_excess_bits): LowerWord of the 4-bit suffix
+    assert O.suffix_mle(10, 0xFF, 4) == 0x0F and ffi.host_suffix_mle(10, 0xFF, 4) == 0x0F
+    # split_roundtrip: 0b1101_0110 splits into 0b1101 | 0b0110 -- the chunk / suffix cut every phase makes
+    assert (0b11010110 >> 4, O.suffix_mle(10, 0b11010110, 4)) == (0b1101, 0b0110)
+    # trailing_zeros_and_leading_ones: 0b1110_1000 of length 8 has 3 of each.  As operands: y = 0b1110_1000 spread onto the even positions of a 16-bit suffix:
+    v = interleave(0b10110101, 0b11101000)
+    for lib_suffix in (O.suffix_mle, ffi.host_suffix_mle):
+        assert lib_suffix(24, v, 16) == 1 << 3              # RightShiftHelper = 2^leading_ones(y)
+        assert lib_suffix(23, v, 16) == 0b10110101 >> 3     # RightShift = x >> trailing_zeros(y)

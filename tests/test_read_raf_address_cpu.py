@@ -186,3 +186,54 @@ def test_address_rounds_every_table_present():
     idx, tab, raf = all_table_rows(7, 11)
     assert set(int(t) for t in tab if t != 0xFF) == set(range(42))
     check_against_the_definition(idx, tab, raf, 7, 0xACE157EF, False, [1000 + 37 * i for i in range(7)])
+
+
+def test_prove_phase_with_the_callers_transcript_hook():
+    """jolt_host_read_raf_address_prove_phase with a jolt_round_transcript_fn (what a Rust caller's Blake2b / Keccak transcript plugs into): the hook sees the three
+    coefficients of UnivariatePoly::from_evals(s(0), s(1), s(2)) of every round and its challenges drive the binds -- same polynomials, claims and eq tables as the
+    round-by-round message / bind calls with the same challenges."""
+    import ctypes as C
+    idx, tab, raf = fixture_rows(4, 12345)
+    lists = ffi.lookup_suffix_lists()
+    u = O.eq_evals(mont([1000 + 37 * i for i in range(4)]))
+    gamma = mont([0xACE157EF])[0]
+    present = np.zeros(42, dtype=np.uint8)
+    present[[int(t) for t in set(tab.tolist()) if t != 0xFF]] = 1
+    claim0 = fr_int(O.read_raf_input_claim(idx, tab, raf, u, gamma))[0]
+    seen = []
+    HOOK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64 * 4), C.c_size_t, C.POINTER(C.c_uint64 * 4))
+
+    def hook(user, coeffs, n, challenge_out):
+        assert n == 3
+        seen.append([[int(w) for w in coeffs[i]] for i in range(3)])
+        r = mont([challenge(len(seen) - 1)])[0]
+        for k in range(4):
+            challenge_out[0][k] = int(r[k])
+        return 0
+
+    cb = HOOK(hook)
+    a, b = ffi.HostReadRafAddress(gamma, present), ffi.HostReadRafAddress(gamma, present)
+    claim_a = mont([claim0])[0].copy()
+    claim_b, ua = claim0, u
+    for phase in range(16):
+        suffix_len = ADDRESS_BITS - 8 * (phase + 1)
+        if phase:
+            ua = O.read_raf_condense(idx, ua, a.v_table(phase - 1), suffix_len + 8)
+        sums = O.read_raf_phase_scan(idx, tab, raf, 42, ua, suffix_len, ADDRESS_BITS, lists)
+        a.init_phase(phase, *sums)
+        b.init_phase(phase, *sums)
+        coeffs, challenges = ffi.fr_array(24), ffi.fr_array(8)
+        assert ffi.lib().jolt_host_read_raf_address_prove_phase(a.h, claim_a.ctypes.data_as(C.c_void_p), cb, None, None, coeffs.ctypes.data_as(C.c_void_p),
+                                                                 challenges.ctypes.data_as(C.c_void_p)) == 0
+        for rnd in range(8):
+            e = fr_int(b.message(mont([claim_b])[0]))
+            want = fr_int(O.univariate_from_evals(mont(e)))
+            assert fr_int(np.array(seen[8 * phase + rnd], dtype=np.uint64)) == want == fr_int(coeffs[3 * rnd: 3 * rnd + 3])
+            r = challenge(8 * phase + rnd)
+            claim_b = (want[0] + want[1] * r + want[2] * r * r) % R
+            b.bind(mont([r])[0])
+        assert fr_int(claim_a)[0] == claim_b
+        assert np.array_equal(a.v_table(phase), b.v_table(phase))
+    assert all(np.array_equal(x, y) for x, y in zip(a.finish(), b.finish()))
+    a.close()
+    b.close()
