@@ -18,6 +18,9 @@
 #include <string.h>
 
 #include "fr.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define EXPORT __attribute__((visibility("default")))
 typedef unsigned __int128 u128;
@@ -367,6 +370,20 @@ static fr_t row_summand(const fr_t *point, unsigned table, int raf_flag, fr_t ga
     return value;
 }
 
+/* Threads for a sweep over `cycles` rows: a team per 8 rows at most, never more than 32.  A 256-thread team for a 16-row test case costs more in fork / join
+ * (and fights the product's own host workers for cores) than the rows cost: 23 s per small GPU test on the 256-thread box before this cap. */
+static int row_team(size_t cycles) {
+#ifdef _OPENMP
+    size_t n = cycles / 8;
+    const size_t cap = (size_t)omp_get_max_threads() < 32 ? (size_t)omp_get_max_threads() : 32;
+    if (n > cap) n = cap;
+    return n < 1 ? 1 : (int)n;
+#else
+    (void)cycles;
+    return 1;
+#endif
+}
+
 /* input_claim (instruction_read_raf.rs:1545-1575): on the INTEGER side -- materialize_entry and the operands of the index */
 EXPORT void orc_read_raf_input_claim(const uint64_t *lookup_index, const uint8_t *table_index, const uint8_t *raf_flag, size_t cycles, const fr_t *u, const fr_t *gamma,
                                      int canonical, fr_t *out) {
@@ -398,7 +415,7 @@ EXPORT void orc_read_raf_address_rounds(const uint64_t *lookup_index, const uint
     for (size_t j = 0; j < cycles; ++j) weight[j] = u[j];
     for (unsigned i = 0; i < LOG_K; ++i) {
         fr_t sums[3] = {fr_zero(), fr_zero(), fr_zero()};
-#pragma omp parallel
+#pragma omp parallel num_threads(row_team(cycles))
         {
             fr_t local[3] = {fr_zero(), fr_zero(), fr_zero()};
             fr_t point[LOG_K];
@@ -439,7 +456,7 @@ EXPORT void orc_read_raf_address_rounds(const uint64_t *lookup_index, const uint
 EXPORT void orc_read_raf_address_round(const uint64_t *lookup_index, const uint8_t *table_index, const uint8_t *raf_flag, size_t cycles, const fr_t *weight, const fr_t *gamma,
                                        int canonical, const fr_t *challenges /* i of them */, uint32_t i, fr_t *evals_out /* 3 */) {
     fr_t sums[3] = {fr_zero(), fr_zero(), fr_zero()};
-#pragma omp parallel
+#pragma omp parallel num_threads(row_team(cycles))
     {
         fr_t local[3] = {fr_zero(), fr_zero(), fr_zero()};
         fr_t point[LOG_K];
