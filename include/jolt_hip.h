@@ -509,7 +509,7 @@ int32_t jolt_grid_joint_polynomial(jolt_ctx *ctx, const jolt_onehot *const *sour
  * condensation of the per-cycle mass (:750-758), the fused RAF scan (:770-812) and the per-table suffix accumulators
  * (init_suffix_tables :901-971), and after the address rounds the combined-value / ra_i columns of the cycle rounds
  * (pending_combined_base / pending_ra_base :1203-1232; sum them with jolt_member_create_split_eq_lc: one group of 1 + ra_count factors).
- * The 256-entry prefix polynomials, checkpoints and address-round messages stay in Rust; the flag claims of output_claims are
+ * The 256-entry prefix polynomials, checkpoints and address-round messages are host code (jolt_host_read_raf_address_* below); the flag claims of output_claims are
  * jolt_onehot_pushforward over the table-index column.
  *   rows: lookup_index as (lo, hi) u64 pairs, table_index (0xFF = no lookup table; < n_tables <= 126), raf_flag (0 / 1).
  *   suffix_offsets[n_tables + 1] / suffix_kinds[]: LookupTableKind::suffixes() of every table, flattened; a kind is the discriminant of
