@@ -24,6 +24,7 @@
 #include <future>
 #include <mutex>
 #include <new>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -173,11 +174,24 @@ struct DotAcc {
 // variable after that; the caller does the same while it waits.
 class Pool {
    public:
-    static Pool& get() { static Pool p; return p; }
-    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    // Never destroyed (the workers die with the process: no join against sleeping threads at exit) and fork-aware: a child of fork() has no workers, only their
+    // std::thread husks, so it runs everything on the calling thread.
+    static Pool& get() {
+        static Pool* p = [] {
+            Pool* made = new Pool;
+            pthread_atfork(nullptr, nullptr, [] { forked().store(true, std::memory_order_relaxed); });
+            return made;
+        }();
+        return *p;
+    }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }  // shards are dealt for this many threads whoever ends up running them
     // f(tid) for tid = 0 .. size() - 1; tid 0 runs on the caller
     void run(const std::function<void(unsigned)>& f) {
         if (workers_.empty()) { f(0); return; }
+        if (forked().load(std::memory_order_relaxed)) {
+            for (unsigned t = 0; t < size(); ++t) f(t);
+            return;
+        }
         {
             std::lock_guard<std::mutex> g(m_);
             job_ = &f;
@@ -194,6 +208,7 @@ class Pool {
     }
 
    private:
+    static std::atomic<bool>& forked() { static std::atomic<bool> f{false}; return f; }
     static constexpr unsigned kSpins = 200000;  // some milliseconds: the device scan between two phases included
     Pool() {
         // JOLT_HOST_THREADS, else 8 on a host with cores to spare (>= 32 hardware threads) and 1 otherwise.  The hand-offs are only cheap while the workers SPIN
