@@ -192,6 +192,7 @@ class Pool {
             for (unsigned t = 0; t < size(); ++t) f(t);
             return;
         }
+        std::lock_guard<std::mutex> one_job(run_m_);  // the pool is shared by every handle of the process: two provers on two threads take turns
         {
             std::lock_guard<std::mutex> g(m_);
             job_ = &f;
@@ -249,7 +250,7 @@ class Pool {
     const std::function<void(unsigned)>* job_ = nullptr;
     std::atomic<uint64_t> generation_{0};
     std::atomic<unsigned> pending_{0};
-    std::mutex m_;
+    std::mutex m_, run_m_;
     std::condition_variable cv_, done_cv_;
     bool stop_ = false;
 };
