@@ -169,7 +169,6 @@ struct DotAcc {
     }
 };
 
-// ---- worker threads: spin while work keeps coming, sleep when it stops ----
 // ---- worker threads (JOLT_HOST_THREADS > 1): one hand-off per round.  Workers spin for the next hand-off for a few milliseconds and block on a condition
 // variable after that; the caller does the same while it waits.
 class Pool {
