@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as O
 from jolt_amd import ffi
-from lookup_table_fixture import CHANGE_DIVISOR_W_CORNER, TABLES, all_table_rows, challenge, fixture_rows, random_index
+from lookup_table_fixture import CHANGE_DIVISOR_W_CORNER, TABLES, all_table_rows, challenge, fixture_rows, random_index, shaped_index
 
 R = O.R_MOD
 ADDRESS_BITS = 128
@@ -78,6 +78,12 @@ def test_prefix_suffix_decomposition(kind):
     rng = np.random.default_rng(12345 + kind)
     decomposition_run(kind, 8, random_index(TABLES[kind], rng), rng)
     decomposition_run(kind, 8, random_index(TABLES[kind], rng), rng)
+    # operand shapes that take the prefixes' rarer branches: equal operands, a zero or all-ones operand, (MIN, -1), small values, one differing bit
+    for _ in range(6):
+        decomposition_run(kind, 8, shaped_index(TABLES[kind], rng), rng)
+    for edge in (0, (1 << 128) - 1, 1 << 127, (1 << 64) - 1):
+        if TABLES[kind] not in ("VirtualSRL", "VirtualSRA", "VirtualROTR", "VirtualROTRW") or edge in (0, (1 << 128) - 1):
+            decomposition_run(kind, 8, edge, rng)
 
 
 @pytest.mark.parametrize("kind", [0, 7, 15, 16, 20, 23, 24, 26, 27, 28, 29, 30, 35, 39, 40, 41])
@@ -237,3 +243,24 @@ def test_prove_phase_with_the_callers_transcript_hook():
     assert all(np.array_equal(x, y) for x, y in zip(a.finish(), b.finish()))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_address_rounds_random_configurations(case):
+    """random subsets of present tables (none at all, one, many), T = 1 .. 64, both RAF settings, rows without a table: product against the definition"""
+    from lookup_table_fixture import shaped_index
+    rng = np.random.default_rng(4000 + case)
+    log_t = int(rng.integers(0, 7))
+    T = 1 << log_t
+    n_present = [0, 1, 2, 5, 11, 23, 42, 3][case]
+    present = sorted(int(t) for t in rng.permutation(42)[:n_present])
+    idx = np.zeros((T, 2), dtype=np.uint64)
+    tab = np.full(T, 0xFF, dtype=np.uint8)
+    for j in range(T):
+        if present and rng.random() < 0.85:
+            tab[j] = present[int(rng.integers(0, len(present)))]
+        name = TABLES[tab[j]] if tab[j] != 0xFF else "And"
+        k = shaped_index(name, rng) if rng.random() < 0.5 else random_index(name, rng)
+        idx[j] = (k & (2**64 - 1), k >> 64)
+    raf = (rng.random(T) < [0.0, 1.0, 0.3, 0.5, 0.3, 0.3, 0.3, 0.3][case]).astype(np.uint8)
+    check_against_the_definition(idx, tab, raf, log_t, int(rng.integers(1, 2**63)), bool(case % 2), [int(rng.integers(0, 2**63)) for _ in range(log_t)])
