@@ -1198,3 +1198,11 @@ class ReadRafAddressDirect:
         tv, ops = fr_array(len(TABLE_KINDS)), fr_array(4)
         lib().orc_read_raf_address_values(_p(self.challenges), _p(tv), _p(ops))
         return tv, ops
+
+
+def read_raf_address_values(challenges):
+    """Val_t(r_address) of the 42 tables by evaluate_mle, and the operand polynomials (left, right, identity, upper_all_ones) at r_address"""
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(128, 4)
+    tv, ops = fr_array(len(TABLE_KINDS)), fr_array(4)
+    lib().orc_read_raf_address_values(_p(ch), _p(tv), _p(ops))
+    return tv, ops

@@ -303,7 +303,8 @@ class OracleExtended:
         """The twin of DeviceExtended.instruction_read_raf.  The T-scale scans are the oracle's (oracle/read_raf.c) at every size and are compared sum for sum.
         The address-round polynomials are the oracle's FROM THE DEFINITION (oracle/lookup_tables.c: evaluate_mle of the row's table at the mixed point, no
         prefix / suffix machinery) up to T = 2^12; above that they are produced by the product's host state machine fed with the ORACLE's scan sums -- the state
-        machine's only inputs, 256 entries per polynomial whatever T is -- which tests/test_read_raf_address_cpu.py pins to the definition round for round."""
+        machine's only inputs, 256 entries per polynomial whatever T is -- which tests/test_read_raf_address_cpu.py pins to the definition round for round; and
+        the twin then VERIFIES that sumcheck: its end values must be the oracle's evaluate_mle of every table at r_address (asserted below)."""
         from jolt_amd import ffi
         S, d = self.S, self.d
         lk = d["lookup"]
@@ -356,6 +357,14 @@ class OracleExtended:
         else:
             table_values, raf_interleaved, raf_identity = state.finish()
             state.close()
+            # The sumcheck VERIFIER's view of those 128 rounds, from independent ends: the input claim above is first principles, every round satisfied
+            # s(0) + s(1) = claim by construction, and what they must end in is fixed by the oracle's own evaluate_mle of every table (and the operand
+            # polynomials) at r_address -- equal values here and an equal cycle-phase sum below leave the state machine's polynomials no room to be wrong.
+            want_values, (left, right, identity, _) = O.read_raf_address_values(np.stack(challenges))
+            assert np.array_equal(np.asarray(table_values)[lk["present"]], want_values[lk["present"]])
+            g2 = O.fr_mul(gamma.reshape(1, 4), gamma.reshape(1, 4))
+            assert np.array_equal(raf_interleaved, O.fr_add(O.fr_mul(gamma.reshape(1, 4), left.reshape(1, 4)), O.fr_mul(g2, right.reshape(1, 4)))[0])
+            assert np.array_equal(raf_identity, O.fr_mul(g2, identity.reshape(1, 4))[0])
         combined, ra = O.read_raf_cycle_tables(lk["idx"], lk["table"], lk["raf"], table_values, raf_interleaved, raf_identity, vt, S.ADDRESS_BITS, d["ra_count"])
         n_f = 1 + d["ra_count"]
         orc = O.Member.expr([O.eq_evals(d["lookup_reduction"]), combined] + [ra[i] for i in range(d["ra_count"])], [(self.one, list(range(1 + n_f)))], 1 + n_f)
