@@ -373,7 +373,7 @@ extern "C" int32_t jolt_lookup_suffix_layout(uint32_t* offsets_out /* 43 */, uin
     return JOLT_OK;
 }
 
-namespace { void build_prefixes(jolt_read_raf_address* h); }
+namespace { void build_prefixes(jolt_read_raf_address* h); void start_prefix_build(jolt_read_raf_address* h); }
 
 extern "C" int32_t jolt_host_read_raf_address_create(const jolt_fr_t* gamma, const uint8_t* table_present, int32_t canonical, jolt_read_raf_address** out) {
     if (!gamma || !table_present || !out) return JOLT_ERR_INVALID_ARG;
@@ -448,7 +448,7 @@ extern "C" int32_t jolt_host_read_raf_address_create(const jolt_fr_t* gamma, con
         sh.polys.resize(sh.n_polys() * kChunkSize);
         sh.ext.resize(sh.polys.size());
     }
-    h->prefixes_ready = std::async(std::launch::async, [h] { build_prefixes(h); });
+    start_prefix_build(h);
     *out = h;
     return JOLT_OK;
 }
@@ -471,6 +471,14 @@ void build_prefixes(jolt_read_raf_address* h) {  // init_phase :878-897; a prefi
             for (uint32_t x = 0; x < kChunkSize; ++x) table[x] = from_fr(prefix_evaluate(p, h->checkpoints, x, kChunkLen, suffix_len));
             built[p] = table;
         }
+}
+// in the background when a thread can be had (nothing may unwind through the C ABI); init_phase builds them itself otherwise
+void start_prefix_build(jolt_read_raf_address* h) {
+    try {
+        h->prefixes_ready = std::async(std::launch::async, [h] { build_prefixes(h); });
+    } catch (...) {
+        h->prefixes_ready = std::future<void>();
+    }
 }
 void shard_init(jolt_read_raf_address* h, Shard& sh) {
     const uint32_t suffix_len = kLogK - (h->phase + 1) * kChunkLen;
@@ -617,7 +625,7 @@ void close_phase(jolt_read_raf_address* h) {
     h->phase += 1;
     h->phase_open = false;
     h->raf_sums = h->suffix_sums = nullptr;
-    if (h->phase < kPhases) h->prefixes_ready = std::async(std::launch::async, [h] { build_prefixes(h); });
+    if (h->phase < kPhases) start_prefix_build(h);
 }
 
 }  // namespace
