@@ -92,12 +92,13 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
         for (int k = 0; k < 3 && s == JOLT_OK; ++k)
             if (hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) != hipSuccess) s = JOLT_ERR_HIP;
         if (s == JOLT_OK && ctx->msm_cu_split > 0) {
-            // bit n of the mask <-> compute unit n; the split is taken inside every group of 8 consecutive bits, which gives k of 8 CUs on
-            // every XCD whether the runtime numbers the CUs XCD-major or round-robin over the XCDs
+            // bit n of the mask <-> compute unit n; the split is taken inside every group of 8 consecutive bits (bits n with n mod 8 < k), which gives k of 8
+            // CUs on every XCD whether the runtime numbers the CUs XCD-major or round-robin over the XCDs.  (Round 3 tested ((n / 8) mod 8) < k, which hands out WHOLE
+            // groups of 8: under XCD-major numbering with k <= 4 the odd XCDs got no sort CUs -- profiles/r03_cu_split_ab.txt measured that partition.)
             const int words = (ctx->num_cus + 31) / 32;
             std::vector<uint32_t> mask_sort(words, 0u), mask_bucket(words, 0u);
             for (int n = 0; n < ctx->num_cus; ++n) {
-                const bool sort_cu = ((n / 8) % 8) < ctx->msm_cu_split;
+                const bool sort_cu = (n % 8) < ctx->msm_cu_split;
                 (sort_cu ? mask_sort : mask_bucket)[n / 32] |= 1u << (n % 32);
             }
             for (int k = 0; k < 4 && s == JOLT_OK; ++k) {

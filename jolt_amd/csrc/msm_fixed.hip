@@ -867,7 +867,9 @@ extern "C" int32_t jolt_srs_precompute_windows(jolt_ctx* ctx, jolt_srs* srs, uin
         mt->pts = srs->pts;  // not owned
         mt->n = kMidN;
         const int32_t s = fx_precompute_into(ctx, mt, 20, kMidMin);
-        if (s != JOLT_OK) { delete mt; return s == JOLT_ERR_UNSUPPORTED ? JOLT_OK : s; }
+        // the mid set is an optimisation next to main tables that are already built and usable: ANY failure building it (unsupported shape, out of memory, a
+        // HIP error from the allocation) leaves the SRS as it was -- the call succeeds exactly as the next one would through the `if (srs->pre)` early exit
+        if (s != JOLT_OK) { delete mt; (void)hipGetLastError(); return JOLT_OK; }
         srs->mid_tables = mt;
     }
     return JOLT_OK;

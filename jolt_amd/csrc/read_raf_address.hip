@@ -216,14 +216,20 @@ class Pool {
         // 17.2 ms with one thread, 8.7 / 4.4 / 3.7 ms with 4 / 8 / 16; a shared 8-CPU container 29 ms with one thread, 15 ms with 4, but 600 ms with 2 while
         // both threads sat on one core.
         const unsigned hw = std::thread::hardware_concurrency();
-        unsigned n = hw >= 32 ? 8 : 1;
-        if (const char* e = std::getenv("JOLT_HOST_THREADS")) n = (unsigned)std::atoi(e);
-        if (n == 0) n = 1;
-        if (hw && n > hw) n = hw;
-        for (unsigned t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
+        long n = hw >= 32 ? 8 : 1;
+        if (const char* e = std::getenv("JOLT_HOST_THREADS")) n = std::atol(e);
+        const long cap = hw ? (long)hw : 64;  // hardware_concurrency() may report 0: still never more than a sane number of workers
+        if (n < 1) n = 1;
+        if (n > cap) n = cap;
+        // thread creation can fail (std::system_error) and this constructor runs under an extern "C" entry point: keep the workers that did start
+        try {
+            workers_.reserve((size_t)n);
+            for (long t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop((unsigned)t); });
+        } catch (...) {
+        }
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        { std::lock_guard<std::mutex> g(m_); stop_.store(true, std::memory_order_release); }
         generation_.fetch_add(1, std::memory_order_release);
         cv_.notify_all();
         for (auto& w : workers_) w.join();
@@ -234,9 +240,9 @@ class Pool {
             for (unsigned spins = 0; generation_.load(std::memory_order_acquire) == seen; ++spins) {
                 if (spins < kSpins) { __builtin_ia32_pause(); continue; }
                 std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return generation_.load(std::memory_order_acquire) != seen || stop_; });
+                cv_.wait(g, [&] { return generation_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire); });
             }
-            if (stop_) return;
+            if (stop_.load(std::memory_order_acquire)) return;
             seen = generation_.load(std::memory_order_acquire);
             (*job_)(tid);
             if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
@@ -251,7 +257,7 @@ class Pool {
     std::atomic<unsigned> pending_{0};
     std::mutex m_, run_m_;
     std::condition_variable cv_, done_cv_;
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
 };
 
 typedef F Poly[kChunkSize];  // a polynomial of the chunk; the first 256 >> (rounds bound) entries are live
@@ -381,6 +387,7 @@ extern "C" int32_t jolt_host_read_raf_address_create(const jolt_fr_t* gamma, con
     if (!fr_is_canonical(g)) return JOLT_ERR_INVALID_ARG;
     auto* h = new (std::nothrow) jolt_read_raf_address();
     if (!h) return JOLT_ERR_OOM;
+    try {  // vector growth, the pool's first use (thread creation): nothing may unwind through the C ABI
     h->gamma = from_fr(g);
     h->gamma2 = f_mul(h->gamma, h->gamma);
     h->gamma3 = f_mul(h->gamma2, h->gamma);
@@ -449,6 +456,10 @@ extern "C" int32_t jolt_host_read_raf_address_create(const jolt_fr_t* gamma, con
         sh.ext.resize(sh.polys.size());
     }
     start_prefix_build(h);
+    } catch (...) {
+        delete h;
+        return JOLT_ERR_OOM;
+    }
     *out = h;
     return JOLT_OK;
 }
@@ -588,7 +599,7 @@ void shard_message(const jolt_read_raf_address* h, Shard& sh, size_t half, bool 
 
 // One hand-off: [first step of the phase: build] [bind with r] extensions, partial sums.  Each shard touches only what it owns.
 enum : unsigned { kStepInit = 1, kStepBind = 2, kStepMessage = 4, kStepWithOne = 8 };
-void step(jolt_read_raf_address* h, unsigned what, const F* r, F out[3]) {
+void step_body(jolt_read_raf_address* h, unsigned what, const F* r, F out[3]) {
     const size_t live = kChunkSize >> h->bound;  // before the bind of this step
     const std::function<void(unsigned)> work = [&](unsigned tid) {
         if (tid >= h->shards.size()) return;
@@ -614,8 +625,18 @@ void step(jolt_read_raf_address* h, unsigned what, const F* r, F out[3]) {
         }
 }
 
+// the std::function of a hand-off may allocate, the pool's first use creates threads: an exception becomes a status here, never unwinds through the C ABI
+int32_t step(jolt_read_raf_address* h, unsigned what, const F* r, F out[3]) {
+    try {
+        step_body(h, what, r, out);
+    } catch (...) {
+        return JOLT_ERR_OOM;
+    }
+    return JOLT_OK;
+}
+
 // after the 8th bind: the phase's eq table and the new checkpoints (:1262-1275)
-void close_phase(jolt_read_raf_address* h) {
+void close_phase_body(jolt_read_raf_address* h) {
     h->v_tables.resize((size_t)(h->phase + 1) * kChunkSize);
     eq_table(h->phase_challenges, kChunkLen, h->v_tables.data() + (size_t)h->phase * kChunkSize);
     for (Shard& sh : h->shards) {
@@ -627,6 +648,14 @@ void close_phase(jolt_read_raf_address* h) {
     h->raf_sums = h->suffix_sums = nullptr;
     if (h->phase < kPhases) start_prefix_build(h);
 }
+int32_t close_phase(jolt_read_raf_address* h) {
+    try {
+        close_phase_body(h);
+    } catch (...) {
+        return JOLT_ERR_OOM;
+    }
+    return JOLT_OK;
+}
 
 }  // namespace
 
@@ -634,16 +663,20 @@ void close_phase(jolt_read_raf_address* h) {
 // suffix_sums[(offsets[t] + s) * 256 + chunk] in the layout of jolt_lookup_suffix_layout.  The sums are copied into the phase's polynomials here.
 extern "C" int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address* h, uint32_t phase, const jolt_fr_t* raf_sums, const jolt_fr_t* suffix_sums) {
     if (!h || !raf_sums || !suffix_sums || phase != h->phase || h->phase_open || phase >= kPhases) return JOLT_ERR_INVALID_ARG;
-    if (h->prefixes_ready.valid()) h->prefixes_ready.get();
-    else build_prefixes(h);
+    try {
+        if (h->prefixes_ready.valid()) h->prefixes_ready.get();
+        else build_prefixes(h);
+    } catch (...) {
+        return JOLT_ERR_OOM;
+    }
     h->raf_sums = raf_sums;
     h->suffix_sums = suffix_sums;
     h->bound = 0;
     h->phase_open = true;
     F unused[3];
-    step(h, kStepInit, nullptr, unused);
+    const int32_t st = step(h, kStepInit, nullptr, unused);
     h->raf_sums = h->suffix_sums = nullptr;
-    return JOLT_OK;
+    return st;
 }
 
 // address_message: evals_out = s(0), s(1), s(2) (UnivariatePoly::from_evals order).  previous_claim == NULL: s(1) is summed from the tables instead of
@@ -651,7 +684,7 @@ extern "C" int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address* 
 extern "C" int32_t jolt_host_read_raf_address_message(jolt_read_raf_address* h, const jolt_fr_t* previous_claim, jolt_fr_t* evals_out) {
     if (!h || !evals_out || !h->phase_open) return JOLT_ERR_INVALID_ARG;
     F e[3];
-    step(h, kStepMessage | (previous_claim ? 0u : (unsigned)kStepWithOne), nullptr, e);
+    if (const int32_t st = step(h, kStepMessage | (previous_claim ? 0u : (unsigned)kStepWithOne), nullptr, e)) return st;
     if (previous_claim) {
         F claim;
         std::memcpy(&claim, previous_claim, sizeof(F));
@@ -668,9 +701,10 @@ extern "C" int32_t jolt_host_read_raf_address_bind(jolt_read_raf_address* h, con
     if (!fr_is_canonical(r)) return JOLT_ERR_INVALID_ARG;
     const F rf = from_fr(r);
     F unused[3];
-    step(h, kStepBind, &rf, unused);
+    if (const int32_t st = step(h, kStepBind, &rf, unused)) return st;
     const bool done = h->bound == kChunkLen;
-    if (done) close_phase(h);
+    if (done)
+        if (const int32_t st = close_phase(h)) return st;
     if (phase_done) *phase_done = done ? 1 : 0;
     return JOLT_OK;
 }
@@ -687,7 +721,7 @@ extern "C" int32_t jolt_host_read_raf_address_prove_phase(jolt_read_raf_address*
     std::memcpy(&running, claim, sizeof(F));
     for (uint32_t round = 0; round < kChunkLen; ++round) {
         F e[3];
-        step(h, round ? (kStepBind | kStepMessage) : (unsigned)kStepMessage, &rf, e);
+        if (const int32_t st = step(h, round ? (kStepBind | kStepMessage) : (unsigned)kStepMessage, &rf, e)) return st;
         e[1] = f_sub(running, e[0]);
         // the quadratic through (0, e0), (1, e1), (2, e2): c2 = (e2 - 2 e1 + e0) / 2, c1 = e1 - e0 - c2
         F c[3];
@@ -712,8 +746,8 @@ extern "C" int32_t jolt_host_read_raf_address_prove_phase(jolt_read_raf_address*
         if (challenges_out) challenges_out[round] = challenge;
     }
     F unused[3];
-    step(h, kStepBind, &rf, unused);
-    close_phase(h);
+    if (const int32_t st = step(h, kStepBind, &rf, unused)) return st;
+    if (const int32_t st = close_phase(h)) return st;
     std::memcpy(claim, &running, sizeof(F));
     return JOLT_OK;
 }

@@ -674,14 +674,22 @@ static int32_t rw_ingest(jolt_rw_matrix* m, const Fr& r) {
             std::vector<uint64_t> key(n);
             std::vector<Fr> ra(n), wa(n), val(n);
             const RwArrays& c = m->st[m->cur];
+            // the destinations are locals: collect the first error and ALWAYS synchronise before leaving the scope (a copy may still be in flight)
+            hipError_t first = hipSuccess;
+            auto copy = [&](void* dst, const void* src, size_t bytes) {
+                const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+                if (first == hipSuccess) first = e;
+            };
             if (n) {
-                JOLT_HIP_TRY(ctx, hipMemcpyAsync(key.data(), c.key, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-                JOLT_HIP_TRY(ctx, hipMemcpyAsync(ra.data(), c.ra, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-                JOLT_HIP_TRY(ctx, hipMemcpyAsync(wa.data(), c.wa, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-                JOLT_HIP_TRY(ctx, hipMemcpyAsync(val.data(), c.val, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+                copy(key.data(), c.key, (size_t)n * 8);
+                copy(ra.data(), c.ra, (size_t)n * sizeof(Fr));
+                copy(wa.data(), c.wa, (size_t)n * sizeof(Fr));
+                copy(val.data(), c.val, (size_t)n * sizeof(Fr));
             }
-            JOLT_HIP_TRY(ctx, hipMemcpyAsync(&m->inc_scalar, m->inc->data(), sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-            JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            copy(&m->inc_scalar, m->inc->data(), sizeof(Fr));
+            const hipError_t sync = hipStreamSynchronize(ctx->stream);
+            JOLT_HIP_TRY(ctx, first);
+            JOLT_HIP_TRY(ctx, sync);
             for (uint32_t i = 0; i < n; ++i) {
                 const uint32_t col = (uint32_t)key[i];
                 if ((key[i] >> 32) != 0 || col >= K) { ctx->last_error = "registers matrix: a cell outside the single bound row"; return JOLT_ERR_INVALID_ARG; }
@@ -720,6 +728,7 @@ static int32_t rw_ingest(jolt_rw_matrix* m, const Fr& r) {
 extern "C" int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix* m, const jolt_fr_t* bind, jolt_fr_t* evals_out, jolt_fr_t* aux_out) {
     if (!m || !evals_out) return JOLT_ERR_INVALID_ARG;
     jolt_ctx* ctx = m->ctx;
+    if (m->registers) { ctx->last_error = "a registers handle: use jolt_registers_rw_prove_round (this entry point ignores the wa column)"; return JOLT_ERR_INVALID_ARG; }
     if (bind) {
         Fr r = fr_from_abi(bind);
         JOLT_REQUIRE(ctx, fr_is_canonical(r), "bind challenge is not a canonical Fr");
@@ -771,6 +780,7 @@ extern "C" int32_t jolt_rw_matrix_finish(jolt_rw_matrix* m, const jolt_fr_t* bin
 extern "C" int32_t jolt_rw_matrix_final_values(jolt_rw_matrix* m, jolt_fr_t* out) {
     if (!m || !out) return JOLT_ERR_INVALID_ARG;
     jolt_ctx* ctx = m->ctx;
+    if (m->registers) { ctx->last_error = "a registers handle: use jolt_registers_rw_final_values (no val_init column here)"; return JOLT_ERR_INVALID_ARG; }
     if (m->round != m->log_t + m->log_k) return JOLT_ERR_NOT_FULLY_BOUND;
     Fr vals[3];
     if (m->n) {  // AddressMajorMatrix::final_values (rw_matrix.rs:680-688): at most one entry remains
@@ -797,6 +807,7 @@ extern "C" int32_t jolt_rw_matrix_len(const jolt_rw_matrix* m, size_t* entries) 
 extern "C" int32_t jolt_rw_matrix_download(jolt_rw_matrix* m, uint64_t* rows, uint64_t* cols, jolt_fr_t* val, jolt_fr_t* ra, jolt_fr_t* prev, jolt_fr_t* next) {
     if (!m || !rows || !cols || !val || !ra || !prev || !next) return JOLT_ERR_INVALID_ARG;
     jolt_ctx* ctx = m->ctx;
+    if (m->registers) { ctx->last_error = "a registers handle: use jolt_registers_rw_download (no prev / next field columns here)"; return JOLT_ERR_INVALID_ARG; }
     const uint32_t n = m->n;
     if (!n) return JOLT_OK;
     const RwArrays& a = m->st[m->cur];

@@ -457,10 +457,10 @@ class DeviceOps:
 
 
 class DeviceExtended:
-    def __init__(self, ctx, n_vars, seed=2026, **kw):
+    def __init__(self, ctx, n_vars, seed=2026, description=None, **kw):
         from . import ffi
         self.ctx, self.ffi, self.n_vars = ctx, ffi, n_vars
-        self.d = d = build_extended(n_vars, seed, **kw)
+        self.d = d = description if description is not None else build_extended(n_vars, seed, **kw)  # description: a prebuilt build_extended(n_vars, ...)
         self.one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
         # ---- resident inputs: integer witness columns, RAM access columns, lookup rows

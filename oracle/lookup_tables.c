@@ -370,12 +370,14 @@ static fr_t row_summand(const fr_t *point, unsigned table, int raf_flag, fr_t ga
     return value;
 }
 
-/* Threads for a sweep over `cycles` rows: a team per 8 rows at most, never more than 32.  A 256-thread team for a 16-row test case costs more in fork / join
- * (and fights the product's own host workers for cores) than the rows cost: 23 s per small GPU test on the 256-thread box before this cap. */
+/* Threads for a sweep over `cycles` rows: a team per 8 rows at most, never more than 32 below 2^16 rows.  A 256-thread team for a 16-row test case costs more in
+ * fork / join (and fights the product's own host workers for cores) than the rows cost: 23 s per small GPU test on the 256-thread box before this cap.  Trace-scale
+ * sweeps (the sampled from-the-definition rounds at T = 2^20 / 2^22: ~0.3 ms of table evaluations per row) take every thread omp_set_num_threads allows. */
 static int row_team(size_t cycles) {
 #ifdef _OPENMP
     size_t n = cycles / 8;
-    const size_t cap = (size_t)omp_get_max_threads() < 32 ? (size_t)omp_get_max_threads() : 32;
+    const size_t small_cap = cycles >= ((size_t)1 << 16) ? (size_t)1 << 20 : 32;
+    const size_t cap = (size_t)omp_get_max_threads() < small_cap ? (size_t)omp_get_max_threads() : small_cap;
     if (n > cap) n = cap;
     return n < 1 ? 1 : (int)n;
 #else

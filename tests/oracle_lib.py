@@ -1181,6 +1181,16 @@ class ReadRafAddressDirect:
         self.challenges = fr_array(128)
         self.i = 0
 
+    def restart(self, i, weight, challenges=None):
+        """jump to round i: `weight` = eq(r_reduction, j) * eq(r_{<i}, k_j[<i]) per row (at a phase boundary that is the oracle's condensed u of the phase,
+        read_raf_condense), `challenges` = the i challenges drawn so far"""
+        self.weight = np.ascontiguousarray(weight, dtype=np.uint64).reshape(-1, 4).copy()
+        assert self.weight.shape[0] == self.idx.shape[0]
+        self.challenges[:] = 0
+        if i:
+            self.challenges[:i] = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)[:i]
+        self.i = i
+
     def round(self):
         out = fr_array(3)
         lib().orc_read_raf_address_round(_p(self.idx), _p(self.tab), _p(self.raf), C.c_size_t(self.idx.shape[0]), _p(self.weight), _p(self.gamma), C.c_int(self.canonical),

@@ -140,10 +140,10 @@ class OracleExtended:
     """jolt_amd.stages.DeviceExtended on the CPU oracle: the same description (build_extended), the same operator drivers, every T-scale
     quantity from oracle/r1cs.c, rw_matrix.c, read_raf.c and the dense members of oracle/sumcheck.c."""
 
-    def __init__(self, n_vars, seed=2026, **kw):
+    def __init__(self, n_vars, seed=2026, description=None, **kw):
         from jolt_amd import stages as S
         self.S, self.n_vars = S, n_vars
-        self.d = S.build_extended(n_vars, seed, **kw)
+        self.d = description if description is not None else S.build_extended(n_vars, seed, **kw)
         self.one = O.to_mont([1])[0]
         self.neg = lambda a: O.fr_neg(np.asarray(a).reshape(1, 4))[0]
 
@@ -296,15 +296,28 @@ class OracleExtended:
         orc.close()
         return out
 
-    # above this many cycles the from-the-definition address rounds (T x 128 x 3 table evaluations) stop being a test-sized computation
+    # above this many cycles the from-the-definition address rounds (T x 128 x 3 table evaluations) stop being a test-sized computation for ALL rounds ...
     DIRECT_ADDRESS_ROUNDS_MAX_LOG_T = 12
+
+    # ... and a SAMPLE of them is computed from the definition instead (round-4 review, item 1): whole phases 0, 7 and 15 up to T = 2^20 (24 of the 128 rounds: the first
+    # phase -- no checkpoints yet --, a middle one and the last, whose suffixes are empty), single rounds at the ends and in the middle above that
+    @classmethod
+    def sampled_direct_rounds(cls, n_vars):
+        if n_vars <= cls.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T:
+            return set(range(128))
+        if n_vars <= 20:
+            return {8 * p + k for p in (0, 7, 15) for k in range(8)}
+        return {0, 1, 62, 127}
 
     def instruction_read_raf(self, label):
         """The twin of DeviceExtended.instruction_read_raf.  The T-scale scans are the oracle's (oracle/read_raf.c) at every size and are compared sum for sum.
         The address-round polynomials are the oracle's FROM THE DEFINITION (oracle/lookup_tables.c: evaluate_mle of the row's table at the mixed point, no
-        prefix / suffix machinery) up to T = 2^12; above that they are produced by the product's host state machine fed with the ORACLE's scan sums -- the state
-        machine's only inputs, 256 entries per polynomial whatever T is -- which tests/test_read_raf_address_cpu.py pins to the definition round for round; and
-        the twin then VERIFIES that sumcheck: its end values must be the oracle's evaluate_mle of every table at r_address (asserted below)."""
+        prefix / suffix machinery) for every round up to T = 2^12.  Above that only the rounds of `sampled_direct_rounds` are from the definition -- they are
+        asserted equal to what the product's host state machine produces from the ORACLE's scan sums, so at those rounds the address polynomials at trace scale
+        are oracle-vs-product, not product-vs-product -- and the remaining rounds' messages are the state machine's (its only inputs are the scan sums, 256 entries
+        per polynomial whatever T is; tests/test_read_raf_address_cpu.py pins it to the definition round for round at <= 2^10).  For those the twin acts as the
+        sumcheck VERIFIER: its end values must be the oracle's evaluate_mle of every table at r_address (asserted below).  `self.direct_checked` lists the rounds
+        that were compared against the definition in the last call."""
         from jolt_amd import ffi
         S, d = self.S, self.d
         lk = d["lookup"]
@@ -314,12 +327,15 @@ class OracleExtended:
         gamma = d["lookup_gamma"]
         claim = O.read_raf_input_claim(lk["idx"], lk["table"], lk["raf"], u0, gamma)  # first principles: materialize_entry and the operands of every row
         input_claim = claim
-        direct = O.ReadRafAddressDirect(lk["idx"], lk["table"], lk["raf"], u0, gamma) if self.n_vars <= self.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T else None
+        all_direct = self.n_vars <= self.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T
+        sampled = self.sampled_direct_rounds(self.n_vars)
+        direct = O.ReadRafAddressDirect(lk["idx"], lk["table"], lk["raf"], u0, gamma)
         present = np.zeros(S.N_LOOKUP_TABLES, dtype=np.uint8)
         present[lk["present"]] = 1
-        state = None if direct else ffi.HostReadRafAddress(gamma, present)
+        state = None if all_direct else ffi.HostReadRafAddress(gamma, present)
         u = u0
         v_tables, scans, messages, challenges = [], [], [], []
+        self.direct_checked = []
         for phase in range(S.PHASES):
             suffix_len = S.ADDRESS_BITS - 8 * (phase + 1)
             if phase:
@@ -328,26 +344,38 @@ class OracleExtended:
             scans.append((raf, suf))
             if state:
                 state.init_phase(phase, raf, suf)
+            last_sampled = max([r for r in sampled if r // 8 == phase], default=-1)
+            if not all_direct and last_sampled >= 0:
+                # the definition's per-row weight eq(r_reduction, j) * eq(r_{<8 phase}, k_j[<8 phase]) IS the condensed u of this phase (both are the oracle's)
+                direct.restart(8 * phase, u, np.stack(challenges) if challenges else None)
             phase_challenges = []
             for rnd in range(8):
-                if direct:
+                g = 8 * phase + rnd
+                if all_direct:
                     e = direct.round()
                     assert np.array_equal(O.fr_add(e[0:1], e[1:2])[0], claim), ("s(0) + s(1) != running claim", phase, rnd)
+                    self.direct_checked.append(g)
                 else:
                     e = state.message(claim)
+                    if g in sampled:
+                        want = direct.round()
+                        assert np.array_equal(np.asarray(e), want), ("the state machine's address-round polynomial differs from the definition's", phase, rnd)
+                        assert np.array_equal(O.fr_add(want[0:1], want[1:2])[0], claim), ("s(0) + s(1) != running claim", phase, rnd)
+                        self.direct_checked.append(g)
                 coeffs = O.univariate_from_evals(e)
                 for c in coeffs:
                     tr.append_fr(c)
                 r = tr.challenge()
                 claim = O.univariate_evaluate(coeffs, r)
-                if direct:
+                if all_direct or g < last_sampled:
                     direct.bind(r)
-                else:
+                if state:
                     state.bind(r)
                 messages.append(coeffs)
                 phase_challenges.append(r)
             challenges += phase_challenges
             v_tables.append(O.eq_evals(np.stack(phase_challenges)))
+        direct = direct if all_direct else None
         vt = np.stack(v_tables)
         if direct:
             table_values, (left, right, identity, _) = direct.values()
