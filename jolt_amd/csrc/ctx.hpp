@@ -116,6 +116,10 @@ struct jolt_table {
     size_t len = 0;
     const Fr* view = nullptr;         // borrowed source of a member that does not own its tables
     size_t view_len = 0;
+    // != nullptr (only inside members made by jolt_member_create_lc_small, until their first bind): the evaluations are the unpromoted u64 entries of a
+    // resident witness column -- data() is null in that state; round 0 and the first bind read the integers (small_round.hip.h)
+    const void* ints = nullptr;
+    const void* ints_src = nullptr;   // what jolt_member_reset restores `ints` to
     Fr* data() const { return cur < 0 ? const_cast<Fr*>(view) : buf[cur]; }
 };
 

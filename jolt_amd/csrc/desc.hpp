@@ -24,6 +24,15 @@ struct MemberDesc {
     Fr fac_const[kMaxFactors];
     Fr lc_coeff[kMaxLc];
 };
+// What jolt_member_create_lc_small derives from the descriptor of a member some of whose tables are unpromoted u64 columns (small_round.hip.h)
+struct SmallDesc {
+    uint32_t tab_int[kMaxBatchTables];  // 1: the table is a u64 column (until the first bind)
+    uint32_t grp_int[kMaxGroups];       // 1: integer group -- one or two factors, each ONE integer column without a constant
+    uint32_t n_int_groups;
+    uint32_t pad_[3];
+    Fr grp_coeff_rr[kMaxGroups];        // the integer group's coefficient c (the product of its entries' coefficients) as c * R^2: REDC(c R^2 * I) = c I R
+    Fr lc_coeff_rr[kMaxLc];             // the same for every LC entry (used where the entry's table is an integer column inside a field-valued factor)
+};
 // current evaluation buffers of the member's tables (they ping-pong on every LowToHigh bind), passed by value
 struct TablePtrs {
     const Fr* p[kMaxBatchTables];

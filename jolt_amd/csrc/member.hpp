@@ -51,6 +51,14 @@ struct jolt_member {
     std::vector<Fr> bool_rho;
     bool uni_prescaled = false;
     std::vector<Fr> final_unscale;  // per table, empty = none
+    // jolt_member_create_lc_small: some tables are u64 witness columns until the first bind (Polynomial<T> compact scalars + bind_to_field, dense.rs:129-142)
+    jolt::SmallDesc* h_small = nullptr;  // host copy (source of the upload), owned
+    jolt::SmallDesc* d_small = nullptr;
+    std::vector<void*> promoted;         // members too small for the integer round kernel promote their columns once, here
+    bool ints_live() const {
+        for (const jolt_table* t : tables) if (t->ints) return true;
+        return false;
+    }
 };
 
 size_t jolt_internal_member_n_evals(const jolt_member* m);
