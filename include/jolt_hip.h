@@ -204,6 +204,19 @@ int32_t jolt_member_create_split_eq_product_borrowed(jolt_ctx *ctx, jolt_table *
  * shard_scale (may be NULL) as in jolt_member_create_split_eq_product_sharded.  final_values appends the bound eq scalar. */
 int32_t jolt_member_create_split_eq_lc(jolt_ctx *ctx, jolt_table *const *tables, const jolt_member_lc_desc *desc, const jolt_fr_t *w, size_t n,
                                        const jolt_fr_t *scale, const jolt_fr_t *shard_scale, jolt_member **out);
+/* The two constructors above over COMPACT-SCALAR polynomials: slot i is tables[i] (a field table) or ints[i] (a resident JOLT_INT_U64 witness column, borrowed:
+ * it must outlive the member) -- exactly one of the two per slot.  Replaces the optimized tier's Polynomial<T> members: round 0 multiplies field elements with
+ * machine integers through the deferred-reduction accumulator (FrSmallScalarAccumulator / mul_u64, crates/jolt-field/src/bn254/mont.rs:286-305,343-427) and the
+ * FIRST bind produces the field tables (Polynomial::bind_to_field, crates/jolt-poly/src/dense.rs:129-142); no promotion pass, 8 instead of 32 bytes per entry in
+ * round 0.  w == NULL: jolt_member_create_lc (flags of `desc` honoured, tables always borrowed); w != NULL: jolt_member_create_split_eq_lc.  LowToHigh only.
+ * Identical round sums and final values to the member over promoted tables (jolt_table_from_ints).  Other integer kinds: JOLT_ERR_UNSUPPORTED. */
+typedef struct jolt_ints jolt_ints;
+int32_t jolt_member_create_lc_small(jolt_ctx *ctx, jolt_table *const *tables, const jolt_ints *const *ints, const jolt_member_lc_desc *desc, const jolt_fr_t *w,
+                                    size_t n, const jolt_fr_t *scale, const jolt_fr_t *shard_scale, jolt_member **out);
+/* test hook (CPU suite): the per-pair evaluation of the integer round kernel compiled for the host -- one LowToHigh pair of a member in `desc` form; slot i is an
+ * integer column iff is_int[i] (entries int_pairs[2i], [2i+1]; otherwise fr_pairs[2i], [2i+1]); out[s], s < n_evals <= 4: the summand at 0, 1, 2, .. (skip_one: 0, 2, 3, ..) */
+int32_t jolt_host_small_round_pair(const jolt_member_lc_desc *desc, const uint8_t *is_int, const uint64_t *int_pairs, const jolt_fr_t *fr_pairs, uint32_t n_evals,
+                                   int32_t skip_one, jolt_fr_t *out);
 int32_t jolt_member_create_split_eq_uniform(jolt_ctx *ctx, jolt_table *const *tables, uint32_t V, uint32_t F, const jolt_fr_t *coeffs,
                                             const jolt_fr_t *w, size_t n, const jolt_fr_t *scale, const jolt_fr_t *shard_scale,
                                             uint32_t flags, jolt_member **out);
@@ -472,7 +485,6 @@ int32_t jolt_member_create_lazy_booleanity(jolt_ctx *ctx, const jolt_onehot *sou
  * (:230-275, :366-419: per chunk, commitment[k] = sum of the bases of the columns whose hot row is k).  The tier-2 pairing
  * product stays with the caller.  Integers are little-endian machine integers (i128 = two u64, low first, two's complement). */
 enum { JOLT_INT_U64 = 0, JOLT_INT_I64 = 1, JOLT_INT_I128 = 2 };
-typedef struct jolt_ints jolt_ints;
 int32_t jolt_ints_upload(jolt_ctx *ctx, const void *host, int32_t kind, size_t count, jolt_ints **out);
 int32_t jolt_ints_free(jolt_ctx *ctx, jolt_ints *values);
 /* out[r] = sum_j values[r*row_width + j] * srs[j] for the count / row_width rows, in row order.  row_width must be a power of

@@ -2,10 +2,13 @@
 // sumcheck members.  (MSM / HyperKZG device pieces live in msm.hip, the host-side mirror in host_mirror.hip.)
 #include <algorithm>
 #include <chrono>
+#include <type_traits>
 
 #include "host_mirror.hpp"
+#include "ints.hpp"
 #include "member.hpp"
 #include "poly_kernels.hip.h"
+#include "small_round.hip.h"
 #include "engine_kernel.hip.h"
 #include "onehot_kernels.hip.h"
 
@@ -462,12 +465,51 @@ extern "C" int32_t jolt_table_write(jolt_ctx* ctx, jolt_table* t, size_t offset,
 // ------------------------------------------------------------------------------------------------------------------
 // Bind k tables (possibly of different lengths: members of different round counts share a batch round) with one
 // challenge: ceil(k/40) launches, blockIdx.y = table.
+// Polynomial::bind_to_field (crates/jolt-poly/src/dense.rs:129-142): the first bind of tables that are still u64 witness columns (jolt_member_create_lc_small)
+// writes field elements; from then on they are ordinary tables.
+static int32_t bind_ints_to_field(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r) {
+    const Fr a_rr = mul(sub(Fr::one(), r), Fr::r2()), b_rr = mul(r, Fr::r2());
+    for (size_t base = 0; base < k; base += kMaxBatchTables) {
+        const size_t cnt = std::min<size_t>(kMaxBatchTables, k - base);
+        BindIntsBatch b;
+        size_t max_half = 0;
+        for (size_t i = 0; i < cnt; ++i) {
+            jolt_table* t = tables[base + i];
+            const size_t half = t->len / 2;
+            JOLT_TRY(jolt_internal_table_ensure_alt(t, half));  // a view (cur < 0): buffer 0
+            b.in[i] = reinterpret_cast<const uint64_t*>(t->ints);
+            b.out[i] = t->buf[0];
+            b.half[i] = half;
+            max_half = std::max(max_half, half);
+        }
+        dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>((max_half + kBlock - 1) / kBlock, 1u << 20)), (unsigned)cnt);
+        hipLaunchKernelGGL(k_bind_ints_to_field, grid, dim3(kBlock), 0, ctx->stream, b, a_rr, b_rr);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        for (size_t i = 0; i < cnt; ++i) {
+            jolt_table* t = tables[base + i];
+            t->ints = nullptr;
+            t->cur = 0;
+            t->len /= 2;
+        }
+    }
+    return JOLT_OK;
+}
+
 int32_t jolt_internal_bind(jolt_ctx* ctx, jolt_table* const* tables, size_t k, const Fr& r, int32_t order) {
     if (k == 0) return JOLT_OK;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    bool any_ints = false;
     for (size_t i = 0; i < k; ++i) {
         if (!tables[i]) return JOLT_ERR_INVALID_ARG;
         if (tables[i]->len < 2) { ctx->last_error = "cannot bind a zero-variable polynomial"; return JOLT_ERR_INVALID_ARG; }  // dense.rs:190,225 assert
+        any_ints = any_ints || tables[i]->ints != nullptr;
+    }
+    if (any_ints) {  // integer-backed tables take the bind_to_field kernel, the others the ordinary one
+        if (order != JOLT_ORDER_LOW_TO_HIGH) { ctx->last_error = "integer-backed tables bind LowToHigh only"; return JOLT_ERR_UNSUPPORTED; }
+        std::vector<jolt_table*> small, dense;
+        for (size_t i = 0; i < k; ++i) (tables[i]->ints ? small : dense).push_back(tables[i]);
+        JOLT_TRY(bind_ints_to_field(ctx, small.data(), small.size(), r));
+        return jolt_internal_bind(ctx, dense.data(), dense.size(), r, order);
     }
     const bool shifted = fr_low_limbs_zero(r);
     for (size_t base = 0; base < k; base += kMaxBatchTables) {
@@ -890,6 +932,137 @@ extern "C" int32_t jolt_member_create_split_eq_lc(jolt_ctx* ctx, jolt_table* con
     return JOLT_OK;
 }
 
+// What the integer round kernel needs to know about a descriptor (small_round.hip.h): which tables are integer columns, the R-scaled coefficients, and which
+// product groups are integer groups (every factor ONE integer column without a constant: evaluated exactly in integers, coefficient = product of its entries')
+static void build_small_desc(const MemberDesc& md, const std::vector<bool>& is_int, SmallDesc& sd) {
+    std::memset(&sd, 0, sizeof(sd));
+    const Fr r2 = Fr::r2();
+    for (size_t t = 0; t < is_int.size() && t < (size_t)kMaxBatchTables; ++t) sd.tab_int[t] = is_int[t] ? 1u : 0u;
+    for (uint32_t k = 0; k < md.n_lc; ++k) sd.lc_coeff_rr[k] = mul(md.lc_coeff[k], r2);
+    for (uint32_t g = 0; g < md.n_groups; ++g) {
+        const uint32_t f0 = md.grp_fac_off[g], f1 = md.grp_fac_off[g + 1];
+        bool ok = f1 - f0 == 1 || f1 - f0 == 2;
+        Fr coeff = Fr::one();
+        for (uint32_t f = f0; ok && f < f1; ++f) {
+            const uint32_t k0 = md.fac_lc_off[f], k1 = md.fac_lc_off[f + 1];
+            if (md.fac_has_const[f] || k1 - k0 != 1 || !is_int[md.lc_tab[k0]]) ok = false;
+            else if (!md.lc_one[k0]) coeff = mul(coeff, md.lc_coeff[k0]);
+        }
+        if (!ok) continue;
+        sd.grp_int[g] = 1;
+        sd.grp_coeff_rr[g] = mul(coeff, r2);
+        sd.n_int_groups += 1;
+    }
+}
+
+// jolt_member_create_lc / jolt_member_create_split_eq_lc (w != NULL) over tables some of which are still resident u64 witness columns: the compact-scalar
+// polynomials of the optimized tier (Polynomial<T>, crates/jolt-poly/src/dense.rs:129-142 bind_to_field; products through FrSmallScalarAccumulator,
+// crates/jolt-field/src/bn254/mont.rs:343-427).  Slot i is tables[i] (a field table, borrowed) or ints[i] (JOLT_INT_U64, borrowed: it must outlive the member).
+// Round 0 reads the integers (8 bytes per entry), the first bind writes field tables; from then on the member is an ordinary one.  Same round sums, bit for bit.
+extern "C" int32_t jolt_member_create_lc_small(jolt_ctx* ctx, jolt_table* const* tables, const jolt_ints* const* ints, const jolt_member_lc_desc* d, const jolt_fr_t* w,
+                                               size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale, jolt_member** out) {
+    if (!ctx || !tables || !ints || !d || !out) return JOLT_ERR_INVALID_ARG;
+    if (d->order != JOLT_ORDER_LOW_TO_HIGH || d->n_tables == 0 || d->n_tables > (uint32_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
+    std::vector<jolt_table> stubs(d->n_tables);
+    std::vector<jolt_table*> slots(d->n_tables);
+    std::vector<bool> is_int(d->n_tables, false);
+    bool any = false;
+    for (uint32_t i = 0; i < d->n_tables; ++i) {
+        if ((tables[i] != nullptr) == (ints[i] != nullptr)) { ctx->last_error = "every slot is either a field table or an integer column"; return JOLT_ERR_INVALID_ARG; }
+        if (tables[i]) { slots[i] = tables[i]; continue; }
+        if (ints[i]->kind != JOLT_INT_U64) { ctx->last_error = "integer-backed member tables are u64 columns (promote i64 / i128 columns with jolt_table_from_ints)"; return JOLT_ERR_UNSUPPORTED; }
+        stubs[i].ctx = ctx;
+        stubs[i].cur = -1;
+        stubs[i].len = ints[i]->count;
+        slots[i] = &stubs[i];
+        is_int[i] = any = true;
+    }
+    jolt_member_lc_desc dd = *d;
+    dd.flags |= JOLT_MEMBER_FLAG_BORROW_TABLES;
+    jolt_member* m = nullptr;
+    if (w) JOLT_TRY(jolt_member_create_split_eq_lc(ctx, slots.data(), &dd, w, n, scale, shard_scale, &m));
+    else JOLT_TRY(jolt_member_create_lc(ctx, slots.data(), &dd, &m));
+    if (!any) { *out = m; return JOLT_OK; }
+    // Rounds with few pairs run the tail kernel, which reads field tables only: such members promote their columns once, here.
+    const bool eager = m->len / 2 <= std::max<size_t>(ctx->tail_pairs, (size_t)1 << 12);
+    int32_t st = JOLT_OK;
+    for (uint32_t i = 0; st == JOLT_OK && i < d->n_tables; ++i) {
+        if (!is_int[i]) continue;
+        jolt_table* v = m->tables[i];
+        if (eager) {
+            Fr* buf = nullptr;
+            st = jolt_internal_dev_alloc(ctx, m->len * sizeof(Fr), (void**)&buf);
+            if (st != JOLT_OK) break;
+            m->promoted.push_back(buf);
+            hipLaunchKernelGGL(k_from_u64, dim3(sweep_grid(ctx, m->len)), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const uint64_t*>(ints[i]->data), buf, m->len);
+            if (hipGetLastError() != hipSuccess) st = JOLT_ERR_HIP;
+            v->view = buf;
+        } else {
+            v->ints = v->ints_src = ints[i]->data;
+        }
+    }
+    if (st == JOLT_OK && !eager) {
+        m->h_small = new (std::nothrow) SmallDesc();
+        if (!m->h_small) st = JOLT_ERR_OOM;
+        if (st == JOLT_OK) {
+            build_small_desc(m->desc, is_int, *m->h_small);
+            st = jolt_internal_dev_alloc(ctx, sizeof(SmallDesc), (void**)&m->d_small);
+        }
+        if (st == JOLT_OK && hipMemcpyAsync(m->d_small, m->h_small, sizeof(SmallDesc), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
+    }
+    if (st != JOLT_OK) { jolt_member_destroy(m); return st; }
+    *out = m;
+    return JOLT_OK;
+}
+
+// The per-pair evaluation of the integer round kernel on the HOST (small_round.hip.h: the same small_pair_eval, the same descriptor analysis), for the CPU suite:
+// one LowToHigh pair of a member in jolt_member_lc_desc form; slot i is an integer column iff is_int[i] (then int_pairs[2 i], [2 i + 1] = its lo / hi entries, else
+// fr_pairs[2 i], [2 i + 1]).  out[s], s < n_evals: the summand at the points 0, 1, 2, .. (skip_one: 0, 2, 3, ..).
+extern "C" int32_t jolt_host_small_round_pair(const jolt_member_lc_desc* d, const uint8_t* is_int, const uint64_t* int_pairs, const jolt_fr_t* fr_pairs, uint32_t n_evals,
+                                              int32_t skip_one, jolt_fr_t* out) {
+    if (!d || !is_int || !int_pairs || !fr_pairs || !out || n_evals < 1 || n_evals > 4) return JOLT_ERR_INVALID_ARG;
+    if (d->n_groups > (uint32_t)kMaxGroups || d->n_factors > (uint32_t)kMaxFactors || d->n_lc > (uint32_t)kMaxLc || d->n_tables > (uint32_t)kMaxBatchTables) return JOLT_ERR_UNSUPPORTED;
+    MemberDesc md;
+    std::memset(&md, 0, sizeof(md));
+    md.n_groups = d->n_groups; md.n_factors = d->n_factors; md.n_lc = d->n_lc;
+    for (uint32_t g = 0; g <= d->n_groups; ++g) md.grp_fac_off[g] = d->group_factor_offsets[g];
+    for (uint32_t f = 0; f <= d->n_factors; ++f) md.fac_lc_off[f] = d->factor_lc_offsets[f];
+    for (uint32_t f = 0; f < d->n_factors; ++f) {
+        md.fac_const[f] = d->factor_consts ? fr_from_abi(&d->factor_consts[f]) : Fr::zero();
+        md.fac_has_const[f] = md.fac_const[f].is_zero() ? 0u : 1u;
+    }
+    for (uint32_t k = 0; k < d->n_lc; ++k) {
+        if (d->lc_tables[k] >= d->n_tables) return JOLT_ERR_INVALID_ARG;
+        md.lc_tab[k] = d->lc_tables[k];
+        md.lc_coeff[k] = fr_from_abi(&d->lc_coeffs[k]);
+        md.lc_one[k] = md.lc_coeff[k] == Fr::one() ? 1u : 0u;
+    }
+    std::vector<bool> mask(d->n_tables);
+    for (uint32_t i = 0; i < d->n_tables; ++i) mask[i] = is_int[i] != 0;
+    SmallDesc sd;
+    build_small_desc(md, mask, sd);
+    auto ldf = [&](uint32_t ti, Fr& lo, Fr& hi) { lo = fr_from_abi(&fr_pairs[2 * ti]); hi = fr_from_abi(&fr_pairs[2 * ti + 1]); };
+    auto ldi = [&](uint32_t ti, uint64_t& lo, uint64_t& hi) { lo = int_pairs[2 * ti]; hi = int_pairs[2 * ti + 1]; };
+    auto run = [&](auto ne_tag, auto skip_tag) {
+        constexpr int NE = decltype(ne_tag)::value;
+        constexpr bool SK = decltype(skip_tag)::value;
+        Fr o[NE];
+        small_pair_eval<NE, SK>(&md, &sd, ldf, ldi, o);
+        for (int s2 = 0; s2 < NE; ++s2) fr_to_abi(&out[s2], o[s2]);
+    };
+    auto with_ne = [&](auto skip_tag) {
+        switch (n_evals) {
+            case 1: run(std::integral_constant<int, 1>{}, skip_tag); break;
+            case 2: run(std::integral_constant<int, 2>{}, skip_tag); break;
+            case 3: run(std::integral_constant<int, 3>{}, skip_tag); break;
+            default: run(std::integral_constant<int, 4>{}, skip_tag); break;
+        }
+    };
+    if (skip_one) with_ne(std::true_type{});
+    else with_ne(std::false_type{});
+    return JOLT_OK;
+}
+
 // GruenSplitEqPolynomial::new_with_scaling(w, LowToHigh, scale) (split_eq.rs:187-236): head = w[..n-1], out_point = head[..split],
 // in_point = rest; evals_cached -> one device table per prefix length.  shard_scale multiplies the E_out tables.
 static int32_t init_split_eq(jolt_ctx* ctx, jolt_member* m, const jolt_fr_t* w, size_t n, const jolt_fr_t* scale, const jolt_fr_t* shard_scale) {
@@ -1145,7 +1318,7 @@ extern "C" int32_t jolt_member_reset(jolt_member* m) {
         return JOLT_OK;
     }
     if (!m->borrowed) { m->ctx->last_error = "only members that borrow their tables can be reset"; return JOLT_ERR_UNSUPPORTED; }
-    for (jolt_table* t : m->tables) { t->cur = -1; t->len = t->view_len; }
+    for (jolt_table* t : m->tables) { t->cur = -1; t->len = t->view_len; t->ints = t->ints_src; }
     m->len = m->tables[0]->view_len;
     m->bound = 0;
     m->current_scalar = m->initial_scalar;
@@ -1228,6 +1401,20 @@ static void launch_round_group(int ne, dim3 grid, hipStream_t s, const RoundGrou
     }
 }
 
+template <bool SKIP1>
+static void launch_round_small(int ne, dim3 grid, hipStream_t s, const RoundGroupArgs& a, const SmallGroupArgs& sa, Fr* partials, const RoundDone& rd) {
+    switch (ne) {
+        case 1: hipLaunchKernelGGL((k_round_evals_small<1, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 2: hipLaunchKernelGGL((k_round_evals_small<2, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 3: hipLaunchKernelGGL((k_round_evals_small<3, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 4: hipLaunchKernelGGL((k_round_evals_small<4, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 5: hipLaunchKernelGGL((k_round_evals_small<5, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 6: hipLaunchKernelGGL((k_round_evals_small<6, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 7: hipLaunchKernelGGL((k_round_evals_small<7, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+        case 8: hipLaunchKernelGGL((k_round_evals_small<8, SKIP1>), grid, dim3(kBlock), 0, s, a, sa, partials, rd); break;
+    }
+}
+
 // Enqueue one batch round for n members.  Pending binds of LowToHigh members are FUSED into the round kernels (one pass
 // over memory per round: read the unbound table, write the bound one, accumulate the round sums); the remaining binds
 // (HighToLow members, tables a summand does not mention) are grouped by challenge into ceil(tables/40) launches.
@@ -1269,7 +1456,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     }
     struct Item {
         size_t ne, slot;
-        bool fused = false, tail = false, done = false, rows_major = false;
+        bool fused = false, tail = false, done = false, rows_major = false, small = false;
         uint32_t lds_blocks = 0;   // > 0: k_split_eq_uniform_lazy_lds with this many workgroups per product group
         Fr r;                      // challenge of the fused bind
         std::vector<const Fr*> in; // table pointers the round kernel reads
@@ -1288,7 +1475,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             // Fuse only where it pays: the separate bind kernel runs at the HBM roofline with its multiplies hidden, so moving
             // them into an ALU-bound round kernel (many multiplies per table) costs more than the saved pass; fuse the
             // bandwidth-bound members (<= 2 multiplies per table per pair) and never the latency-bound tail rounds.
-            const bool can_fuse = m->order == JOLT_ORDER_LOW_TO_HIGH && (m->len / 4 > kTailPairs || (ctx->fuse_tail && m->kind == jolt_member::kExpr)) &&
+            const bool can_fuse = !m->ints_live() && m->order == JOLT_ORDER_LOW_TO_HIGH && (m->len / 4 > kTailPairs || (ctx->fuse_tail && m->kind == jolt_member::kExpr)) &&
                                   (m->kind == jolt_member::kSplitEqProduct || (m->kind == jolt_member::kExpr && m->all_tables_used && m->muls_per_pair <= ctx->fuse_ratio * m->tables.size()));
             JOLT_TRY(member_note_bind(m, *binds[i]));  // m->len is now the bound length
             if (can_fuse) {
@@ -1321,11 +1508,13 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         jolt_member* m = members[i];
         Item& it = items[i];
         if (m->len < 2) { ctx->last_error = "prove_round on a fully bound member"; return JOLT_ERR_INVALID_ARG; }
-        if (!it.fused) for (jolt_table* t : m->tables) { it.in.push_back(t->data()); it.out.push_back(nullptr); }
+        if (!it.fused) for (jolt_table* t : m->tables) { it.in.push_back(t->ints ? reinterpret_cast<const Fr*>(t->ints) : t->data()); it.out.push_back(nullptr); }
+        it.small = m->ints_live();  // round 0 off the integer columns (small_round.hip.h): never a tail round (such members promote when they are created)
+        if (it.small && (m->kind != jolt_member::kExpr || m->order != JOLT_ORDER_LOW_TO_HIGH || !m->d_small)) { ctx->last_error = "integer-backed tables in a member that cannot read them"; return JOLT_ERR_INVALID_ARG; }
         it.ne = jolt_internal_member_n_evals(m);
         it.slot = slot;
         slot += it.ne;
-        it.tail = m->kind == jolt_member::kExpr && m->len / 2 <= kTailPairs;
+        it.tail = m->kind == jolt_member::kExpr && m->len / 2 <= kTailPairs && !it.small;
     }
     if (slot > ctx->round_cap) { ctx->last_error = "batch round returns too many sums"; return JOLT_ERR_UNSUPPORTED; }
     auto same_challenge = [&](const Item& a, const Item& b) { return a.fused == b.fused && (!a.fused || a.r == b.r); };
@@ -1374,13 +1563,14 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         tails.push_back(std::move(T));
     }
     // ---- (2b) class launches of the remaining expr members
-    struct Launch { RoundGroupArgs args; int ne, order, skip, fused, count, shifted; unsigned grid; Fr r; std::vector<size_t> who; };
+    struct Launch { RoundGroupArgs args; SmallGroupArgs sargs; int ne, order, skip, fused, count, shifted, small; unsigned grid; Fr r; std::vector<size_t> who; };
     std::vector<Launch> launches;
     for (size_t i = 0; i < n; ++i) {
         jolt_member* m = members[i];
         if (items[i].done || m->kind != jolt_member::kExpr) continue;
         Launch L;
         L.ne = (int)items[i].ne; L.order = m->order; L.skip = m->skip_one ? 1 : 0; L.fused = items[i].fused ? 1 : 0; L.count = 0; L.grid = 1;
+        L.small = items[i].small ? 1 : 0;
         L.r = items[i].fused ? items[i].r : Fr::zero();
         L.shifted = fr_low_limbs_zero(L.r) ? 1 : 0;
         uint32_t cursor = 0;
@@ -1388,7 +1578,7 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             jolt_member* mj = members[j];
             Item& it = items[j];
             if (it.done || mj->kind != jolt_member::kExpr) continue;
-            if ((int)it.ne != L.ne || mj->order != L.order || (mj->skip_one ? 1 : 0) != L.skip || !same_challenge(items[i], it)) continue;
+            if ((int)it.ne != L.ne || mj->order != L.order || (mj->skip_one ? 1 : 0) != L.skip || !same_challenge(items[i], it) || (it.small ? 1 : 0) != L.small) continue;
             if (L.count == kMaxGroupMembers || cursor + mj->tables.size() > (size_t)kMaxGroupTables) break;
             int c = L.count++;
             L.args.desc[c] = mj->d_desc;
@@ -1400,7 +1590,9 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             L.args.e_out[c] = mj->eq_weighted ? mj->e_out_cache[mj->e_out_bits]->data() : nullptr;
             L.args.e_in[c] = mj->eq_weighted ? mj->e_in_cache[mj->e_in_bits]->data() : nullptr;
             L.args.in_bits[c] = (int32_t)mj->e_in_bits;
-            L.grid = std::max<unsigned>(L.grid, (unsigned)round_grid(ctx, (mj->len / 2) * std::max<uint32_t>(1, mj->desc.n_groups)));
+            L.sargs.sd[c] = mj->d_small;
+            // the integer round kernel walks pairs (all groups of a pair inside one item), the field one (group, pair) items
+            L.grid = std::max<unsigned>(L.grid, (unsigned)round_grid(ctx, (mj->len / 2) * (L.small ? 1u : std::max<uint32_t>(1, mj->desc.n_groups))));
             L.who.push_back(j);
             it.done = true;
         }
@@ -1527,7 +1719,10 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     for (Launch& L : launches) {
         dim3 grid(L.grid, (unsigned)L.count);
         hipStream_t lst = next_stream(L.fused);
-        if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
+        if (L.small) {
+            if (L.skip) launch_round_small<true>(L.ne, grid, lst, L.args, L.sargs, ctx->d_partials, rd);
+            else launch_round_small<false>(L.ne, grid, lst, L.args, L.sargs, ctx->d_partials, rd);
+        } else if (L.order == JOLT_ORDER_LOW_TO_HIGH) {
             if (L.fused) {
                 if (L.skip) launch_round_group<0, true, true>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
                 else launch_round_group<0, false, true>(L.ne, grid, lst, L.args, L.r, L.shifted, ctx->d_partials, rd);
@@ -1760,7 +1955,7 @@ static int engine_eligible(jolt_ctx* ctx, jolt_engine* e, jolt_member* const* me
         if ((size_t)r != m->rounds - m->bound - (has_bind ? 1 : 0)) return 0;  // the member must run to its end
         if (rounds < 0) rounds = r;
         if (r != rounds) return 0;
-        for (const jolt_table* t : m->tables) if (t->len != m->len) return 0;
+        for (const jolt_table* t : m->tables) if (t->len != m->len || t->ints) return 0;
         size_t ne = jolt_internal_member_n_evals(m);
         tables += m->tables.size();
         slots += ne;
@@ -2104,6 +2299,22 @@ extern "C" int32_t jolt_round_group_final_values(jolt_ctx* ctx, jolt_member* con
     return JOLT_OK;
 }
 
+// Field views of a member's tables for the setup-time claim helper: tables that are still integer columns are promoted into temporaries (the caller frees them)
+static int32_t member_tables_as_fr(jolt_ctx* ctx, const jolt_member* m, TablePtrs& tp, std::vector<void*>& temps) {
+    for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = nullptr;
+    for (size_t i = 0; i < m->tables.size(); ++i) {
+        const jolt_table* t = m->tables[i];
+        if (!t->ints) { tp.p[i] = t->data(); continue; }
+        Fr* buf = nullptr;
+        JOLT_TRY(jolt_internal_dev_alloc(ctx, std::max<size_t>(t->len, 1) * sizeof(Fr), (void**)&buf));
+        temps.push_back(buf);
+        hipLaunchKernelGGL(k_from_u64, dim3(sweep_grid(ctx, t->len)), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const uint64_t*>(t->ints), buf, t->len);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        tp.p[i] = buf;
+    }
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     (void)jolt_internal_engine_quiesce(m ? m->ctx : nullptr);
     if (!m || !out) return JOLT_ERR_INVALID_ARG;
@@ -2112,11 +2323,16 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid, 8));
     if (m->kind == jolt_member::kExpr && !m->eq_weighted) {
         TablePtrs tp;
-        for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
-        hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)m->d_desc, tp, m->len, ctx->d_partials);
-        JOLT_HIP_TRY(ctx, hipGetLastError());
-        JOLT_TRY(reduce_into_results(ctx, grid, 1, 0));
-        return fetch_results(ctx, 1, out);
+        std::vector<void*> temps;
+        int32_t st = member_tables_as_fr(ctx, m, tp, temps);
+        if (st == JOLT_OK) {
+            hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)m->d_desc, tp, m->len, ctx->d_partials);
+            if (hipGetLastError() != hipSuccess) st = JOLT_ERR_HIP;
+        }
+        if (st == JOLT_OK) st = reduce_into_results(ctx, grid, 1, 0);
+        if (st == JOLT_OK) st = fetch_results(ctx, 1, out);
+        for (void* p : temps) jolt_internal_dev_free(ctx, p);
+        return st;
     }
     if (m->eq_weighted) {  // sum_x scale * eq(w[..remaining], x) * q(x): the inner descriptor with the dense eq table as one more factor
         size_t rem = m->rounds - m->bound;
@@ -2157,16 +2373,20 @@ extern "C" int32_t jolt_member_input_claim(jolt_member* m, jolt_fr_t* out) {
         if (st == JOLT_OK) st = jolt_internal_dev_alloc(ctx, sizeof(MemberDesc), (void**)&dd);
         if (st == JOLT_OK && hipMemcpyAsync(dd, &nd, sizeof(nd), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
         if (st == JOLT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = JOLT_ERR_HIP;
+        std::vector<void*> temps;
         if (st == JOLT_OK) {
             TablePtrs tp;
-            for (size_t i = 0; i < kMaxBatchTables; ++i) tp.p[i] = i < m->tables.size() ? m->tables[i]->data() : nullptr;
+            st = member_tables_as_fr(ctx, m, tp, temps);
             tp.p[eq_tab] = eq->data();
-            hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)dd, tp, m->len, ctx->d_partials);
-            if (hipGetLastError() != hipSuccess) st = JOLT_ERR_HIP;
+            if (st == JOLT_OK) {
+                hipLaunchKernelGGL(k_member_claim, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MemberDesc*)dd, tp, m->len, ctx->d_partials);
+                if (hipGetLastError() != hipSuccess) st = JOLT_ERR_HIP;
+            }
         }
         if (st == JOLT_OK) st = reduce_into_results(ctx, grid, 1, 0);
         if (st == JOLT_OK) st = fetch_results(ctx, 1, out);
         (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : temps) jolt_internal_dev_free(ctx, p);
         if (dd) jolt_internal_dev_free(ctx, dd);
         jolt_table_free(ctx, eq);
         return st;
@@ -2234,6 +2454,9 @@ extern "C" int32_t jolt_member_destroy(jolt_member* m) {
     for (jolt_table* t : m->e_out_cache) jolt_table_free(ctx, t);
     for (jolt_table* t : m->e_in_cache) jolt_table_free(ctx, t);
     if (m->d_desc) jolt_internal_dev_free(m->ctx, m->d_desc);
+    if (m->d_small) jolt_internal_dev_free(m->ctx, m->d_small);
+    delete m->h_small;
+    for (void* p : m->promoted) jolt_internal_dev_free(m->ctx, p);
     for (int k = 0; k < 2; ++k) if (m->d_branch[k]) jolt_internal_dev_free(m->ctx, m->d_branch[k]);
     if (m->d_base) jolt_internal_dev_free(m->ctx, m->d_base);
     if (m->d_pair) jolt_internal_dev_free(m->ctx, m->d_pair);

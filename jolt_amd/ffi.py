@@ -213,9 +213,24 @@ class Context:
         flags = (MEMBER_FLAG_SKIP_ONE if skip_one else 0) | (MEMBER_FLAG_BORROW_TABLES if borrow else 0)
         d = MemberLcDesc(len(tables), len(groups), len(consts), len(ltab), degree, order, flags,
                          goff.ctypes.data, foff.ctypes.data, consts_a.ctypes.data, ltab_a.ctypes.data, lcoef_a.ctypes.data)
-        hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        small = any(isinstance(t, Ints) for t in tables)  # compact-scalar slots: resident u64 columns read unpromoted in round 0 (jolt_member_create_lc_small)
+        hs = (C.c_void_p * len(tables))(*[None if isinstance(t, Ints) else t.h for t in tables])
         h = C.c_void_p()
-        if eq_point is not None:
+        if small:
+            assert borrow and order == ORDER_LOW_TO_HIGH, "integer-backed slots: borrowed tables, LowToHigh"
+            ih = (C.c_void_p * len(tables))(*[t.h if isinstance(t, Ints) else None for t in tables])
+            w = fr(eq_point).reshape(-1, 4) if eq_point is not None else None
+            _ck(lib().jolt_member_create_lc_small(self.h, hs, ih, C.byref(d), _p(w) if w is not None else None, C.c_size_t(0 if w is None else w.shape[0]),
+                                                  _p(fr(eq_scale)) if eq_scale is not None else None, _p(fr(shard_scale)) if shard_scale is not None else None,
+                                                  C.byref(h)), "jolt_member_create_lc_small", self)
+            if eq_point is not None:
+                m = Member(self, h, degree + 1, len(tables), True, True)
+                m.n_evals = degree
+                m.uniform = True
+                m.eq_weighted = True
+            else:
+                m = Member(self, h, degree, len(tables), False, skip_one)
+        elif eq_point is not None:
             w = fr(eq_point).reshape(-1, 4)
             _ck(lib().jolt_member_create_split_eq_lc(self.h, hs, C.byref(d), _p(w), C.c_size_t(w.shape[0]), _p(fr(eq_scale)) if eq_scale is not None else None,
                                                      _p(fr(shard_scale)) if shard_scale is not None else None, C.byref(h)), "jolt_member_create_split_eq_lc", self)
@@ -1482,3 +1497,30 @@ class HostReadRafAddress:
         if self.h:
             lib().jolt_host_read_raf_address_destroy(self.h)
             self.h = None
+
+
+def host_small_round_pair(n_tables, groups, is_int, int_pairs, fr_pairs, n_evals, skip_one):
+    """jolt_host_small_round_pair: the per-pair evaluation of the integer round kernel (small_round.hip.h) compiled for the host.  groups as in Context.member_lc;
+    int_pairs (n_tables, 2) uint64, fr_pairs (n_tables, 2, 4) Montgomery limbs -> (n_evals, 4)"""
+    goff, foff, consts, ltab, lcoef = [0], [0], [], [], []
+    zero = np.zeros(4, dtype=np.uint64)
+    for g in groups:
+        for const, entries in g:
+            consts.append(zero if const is None else fr(const))
+            for c, ti in entries:
+                lcoef.append(fr(c))
+                ltab.append(ti)
+            foff.append(len(ltab))
+        goff.append(len(consts))
+    goff, foff = np.array(goff, dtype=np.uint32), np.array(foff, dtype=np.uint32)
+    consts_a = np.ascontiguousarray(np.stack(consts)) if consts else fr_array(1)
+    ltab_a = np.array(ltab if ltab else [0], dtype=np.uint32)
+    lcoef_a = np.ascontiguousarray(np.stack(lcoef)) if lcoef else fr_array(1)
+    d = MemberLcDesc(n_tables, len(groups), len(consts), len(ltab), n_evals, ORDER_LOW_TO_HIGH, 0, goff.ctypes.data, foff.ctypes.data, consts_a.ctypes.data, ltab_a.ctypes.data,
+                     lcoef_a.ctypes.data)
+    mask = np.ascontiguousarray(is_int, dtype=np.uint8)
+    ip = np.ascontiguousarray(int_pairs, dtype=np.uint64).reshape(n_tables, 2)
+    fp = np.ascontiguousarray(fr_pairs, dtype=np.uint64).reshape(n_tables, 2, 4)
+    out = fr_array(n_evals)
+    _ck(lib().jolt_host_small_round_pair(C.byref(d), _p(mask), _p(ip), _p(fp), C.c_uint32(n_evals), C.c_int32(1 if skip_one else 0), _p(out)), "jolt_host_small_round_pair")
+    return out

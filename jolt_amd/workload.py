@@ -256,11 +256,23 @@ class DeviceWorkload:
         skip |= {ms.tables[0] for ms in self.members_spec if ms.eq_inner is not None}  # eq weight factored out: never materialised
         used = lambda ms: ms.tables[1:] if (ms.uniform is not None or ms.eq_inner is not None) else ms.tables
         skip -= {t for ms in self.members_spec if not self._lazy(ms) for t in used(ms)}
+        # Compact-scalar witness columns (the optimized tier's Polynomial<u64>: round 0 off the integers, bind_to_field on the first bind,
+        # crates/jolt-poly/src/dense.rs:129-142): u64 columns that only feed descriptor-driven members are never promoted -- the members read the resident
+        # integers (jolt_member_create_lc_small).  Not: the two committed increment columns (commit and the joint polynomial need them as field tables) and the
+        # split-eq product member's columns.  JOLT_SMALL_ROUND0=0: promote everything (the round-3 path), for an A/B.
+        import os
+        int_capable = lambda ms: ms.uniform is None and ms.fused is None and ms.split_eq is None
+        small = {t for ms in self.members_spec if int_capable(ms) for t in (ms.tables[1:] if ms.eq_inner is not None else ms.tables)
+                 if self.tables_spec[t].kind == "u64"}
+        small -= {t for ms in self.members_spec if not int_capable(ms) for t in ms.tables}
+        small -= {"s6.ram_inc", "s6.rd_inc"}
+        self._small = small if os.environ.get("JOLT_SMALL_ROUND0", "1") != "0" else set()
+        skip |= self._small
         self._skip = skip
         # ---- resident inputs
         self.ints = {}
         for name, spec in self.tables_spec.items():
-            if name in skip:
+            if name in skip and name not in self._small:
                 continue
             if spec.kind in ("u64", "i64"):
                 self.ints[name] = ctx.ints(spec.data.astype(np.uint64 if spec.kind == "u64" else np.int64))
@@ -353,7 +365,7 @@ class DeviceWorkload:
                     m = ctx.member_split_eq_uniform(tabs, V, F, coeffs, w, borrow=True)
             elif ms.eq_inner is not None:
                 dq, inner = ms.eq_inner
-                m = ctx.member_lc([self.tables[t] for t in ms.tables[1:]], self.resolver.groups(inner), dq, borrow=True,
+                m = ctx.member_lc([self._slot(t) for t in ms.tables[1:]], self.resolver.groups(inner), dq, borrow=True,
                                   eq_point=self.tables_spec[ms.tables[0]].point)
             elif ms.fused is not None:  # A = sum_i s_i * leaf_i as ONE table (jolt_rlc), then the ordinary member over fewer tables
                 parts, names, groups = ms.fused
@@ -366,9 +378,13 @@ class DeviceWorkload:
                 tabs = [self.tables[t] for t in ms.tables]
                 m = ctx.member_split_eq_product(tabs[a], tabs[b], w, borrow=True)
             else:
-                m = ctx.member_lc([self.tables[t] for t in ms.tables], self.resolver.groups(ms.groups), ms.degree, borrow=True, skip_one=True)
+                m = ctx.member_lc([self._slot(t) for t in ms.tables], self.resolver.groups(ms.groups), ms.degree, borrow=True, skip_one=True)
             self.members.append(m)
         self.prepared = True
+
+    def _slot(self, name):
+        """a member's table slot: the resident integer column for a compact-scalar witness column, the per-proof field table otherwise"""
+        return self.ints[name] if name in self._small else self.tables[name]
 
     def release(self):
         for m in self.members:

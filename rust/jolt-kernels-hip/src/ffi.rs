@@ -41,6 +41,10 @@ pub struct jolt_srs {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct jolt_ints {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct jolt_host_transcript {
     _private: [u8; 0],
 }
@@ -58,10 +62,6 @@ pub struct jolt_onehot {
 }
 #[repr(C)]
 pub struct jolt_rows {
-    _private: [u8; 0],
-}
-#[repr(C)]
-pub struct jolt_ints {
     _private: [u8; 0],
 }
 #[repr(C)]
@@ -186,6 +186,8 @@ extern "C" {
     pub fn jolt_member_create_split_eq_product(ctx: *mut jolt_ctx, a: *mut jolt_table, b: *mut jolt_table, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_member_create_split_eq_product_borrowed(ctx: *mut jolt_ctx, a: *mut jolt_table, b: *mut jolt_table, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_member_create_split_eq_lc(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, desc: *const jolt_member_lc_desc, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_member_create_lc_small(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, ints: *const *const jolt_ints, desc: *const jolt_member_lc_desc, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
+    pub fn jolt_host_small_round_pair(desc: *const jolt_member_lc_desc, is_int: *const u8, int_pairs: *const u64, fr_pairs: *const jolt_fr_t, n_evals: u32, skip_one: i32, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_member_create_split_eq_uniform(ctx: *mut jolt_ctx, tables: *const *mut jolt_table, V: u32, F: u32, coeffs: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, flags: u32, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_member_create_split_eq_product_sharded(ctx: *mut jolt_ctx, a: *mut jolt_table, b: *mut jolt_table, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_member_reset(m: *mut jolt_member) -> i32;
