@@ -14,7 +14,9 @@
 // coefficients' field images are the field weights), which is how the tests pin them; the integer ranges are the caller's contract
 // (|Az| < 2^127, |Bz| < 2^255, |Az * Bz| < 2^254; the reference's rows stay below 2^22, 2^152 and 2^174).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "ctx.hpp"
@@ -110,6 +112,129 @@ __global__ __launch_bounds__(kBlock) void k_small_uniskip(IntInputs in, const Fr
     }
     Fr acc[1] = {mul(sub(pos, neg_sum), Fr::r2())};  // plain -> Montgomery, once per thread
     block_reduce_store_at<1>(acc, partials + (node * n_slices + slice));
+}
+
+// The same sums with every column read from HBM ONCE (round 4): one workgroup takes a tile of kBlock cycles for ALL nodes.  A thread parks its cycle's column values
+// in LDS -- an indexable per-thread array, [plane][thread] with 8-byte planes (an i128 column takes two), written and read by the same thread only, so no barrier --
+// and walks the NODES nodes over them, one accumulator per node in registers (NODES is a template parameter: 9 extended nodes for Spartan outer, 5 for product
+// virtualization; other counts keep k_small_uniskip).  The per-node kernel above re-reads ~87 % of the columns for each of its nodes (~2.2 KB per cycle at 9 nodes and
+// 35 inputs against 280 B here): 4.4 ms of a T = 2^22 proof were that traffic.  partials[node * gridDim.x + block].
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+struct ColumnPlanes {
+    uint16_t first[kMaxSmallInputs];  // first plane of column v
+};
+__device__ __forceinline__ SmallInt small_from_words(uint64_t lo, uint64_t hi, int kind) {
+    SmallInt s;
+    bool negative = false;
+    if (kind == kIntKindI128) {
+        negative = (hi >> 63) != 0;
+        if (negative) {
+            lo = ~lo + 1;
+            hi = ~hi + (lo == 0 ? 1 : 0);
+        }
+    } else {
+        hi = 0;
+        negative = kind == kIntKindI64 && (lo >> 63) != 0;
+        if (negative) lo = ~lo + 1;
+    }
+    s.m[0] = (uint32_t)lo;
+    s.m[1] = (uint32_t)(lo >> 32);
+    s.m[2] = (uint32_t)hi;
+    s.m[3] = (uint32_t)(hi >> 32);
+    s.neg = negative ? 1u : 0u;
+    return s;
+}
+template <int STREAMS, int NODES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_small_uniskip_all(  // NODES accumulators in registers: two waves per SIMD, which is what the LDS planes allow anyway
+    IntInputs in, ColumnPlanes cp, const Fr* __restrict__ eq, size_t cycles, const int64_t* __restrict__ wa,
+                                                              const int64_t* __restrict__ wb, Fr* __restrict__ partials) {
+    extern __shared__ uint64_t planes[];  // [plane][kBlock]
+    const size_t stride_w = 1 + (size_t)in.n;
+    Fr acc[NODES];  // sum of +-eq * |Az * Bz| in PLAIN form (Montgomery eq x plain integer)
+#pragma unroll
+    for (int node = 0; node < NODES; ++node) acc[node] = Fr::zero();
+    for (size_t base = (size_t)blockIdx.x * kBlock; base < cycles; base += (size_t)gridDim.x * kBlock) {
+        const size_t t = base + threadIdx.x;
+        if (t >= cycles) continue;  // (no barrier below: a thread only ever touches its own LDS slots)
+        for (int v = 0; v < in.n; ++v) {
+            const uint64_t* __restrict__ col = reinterpret_cast<const uint64_t*>(in.z[v]);
+            const uint32_t pl = cp.first[v];
+            if (in.kind[v] == kIntKindI128) {
+                planes[(size_t)pl * kBlock + threadIdx.x] = col[2 * t];
+                planes[(size_t)(pl + 1) * kBlock + threadIdx.x] = col[2 * t + 1];
+            } else {
+                planes[(size_t)pl * kBlock + threadIdx.x] = col[t];
+            }
+        }
+        Fr e[STREAMS];
+#pragma unroll
+        for (int s = 0; s < STREAMS; ++s) e[s] = ld_fr(eq + STREAMS * t + s);
+        static_for<NODES>([&](auto node_c) {  // unrolled by construction: acc[node] must be a register, not an indexed stack slot
+            constexpr int node = decltype(node_c)::value;
+            const int64_t* a0 = wa + ((size_t)node * STREAMS) * stride_w;
+            const int64_t* a1 = a0 + (STREAMS - 1) * stride_w;
+            const int64_t* b0 = wb + ((size_t)node * STREAMS) * stride_w;
+            const int64_t* b1 = b0 + (STREAMS - 1) * stride_w;
+            __int128 az[2] = {(__int128)a0[0], (__int128)a1[0]};
+            U256 bp[2] = {u256_zero(), u256_zero()}, bn[2] = {u256_zero(), u256_zero()};
+            {
+                const uint32_t one[4] = {1u, 0u, 0u, 0u};
+                const int64_t c0 = b0[0], c1 = b1[0];
+                if (c0 > 0) u256_fmadd<2>(bp[0], (uint64_t)c0, one);
+                if (c0 < 0) u256_fmadd<2>(bn[0], (uint64_t)0 - (uint64_t)c0, one);
+                if (STREAMS == 2 && c1 > 0) u256_fmadd<2>(bp[1], (uint64_t)c1, one);
+                if (STREAMS == 2 && c1 < 0) u256_fmadd<2>(bn[1], (uint64_t)0 - (uint64_t)c1, one);
+            }
+            for (int v = 0; v < in.n; ++v) {
+                const int64_t wa0 = a0[1 + v], wa1 = a1[1 + v], wb0 = b0[1 + v], wb1 = b1[1 + v];
+                if ((wa0 | wa1 | wb0 | wb1) == 0) continue;  // wave-uniform
+                const int kind = in.kind[v];
+                const uint32_t pl = cp.first[v];
+                const uint64_t lo = planes[(size_t)pl * kBlock + threadIdx.x];
+                const uint64_t hi = kind == kIntKindI128 ? planes[(size_t)(pl + 1) * kBlock + threadIdx.x] : 0;
+                const SmallInt z = small_from_words(lo, hi, kind);
+                if (wa0 | wa1) {
+                    const __int128 zi = to_i128(z);
+                    az[0] += (__int128)wa0 * zi;
+                    if (STREAMS == 2) az[1] += (__int128)wa1 * zi;
+                }
+#pragma unroll
+                for (int s = 0; s < STREAMS; ++s) {
+                    const int64_t w = s ? wb1 : wb0;
+                    if (w == 0) continue;
+                    const uint64_t mag = w < 0 ? (uint64_t)0 - (uint64_t)w : (uint64_t)w;
+                    const bool negative = (w < 0) != (z.neg != 0);
+                    if (kind == kIntKindI128) {
+                        if (negative) u256_fmadd<4>(bn[s], mag, z.m); else u256_fmadd<4>(bp[s], mag, z.m);
+                    } else {
+                        if (negative) u256_fmadd<2>(bn[s], mag, z.m); else u256_fmadd<2>(bp[s], mag, z.m);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < STREAMS; ++s) {
+                const bool b_neg = !u256_geq(bp[s], bn[s]);
+                const U256 bmag = b_neg ? u256_sub(bn[s], bp[s]) : u256_sub(bp[s], bn[s]);
+                const bool a_neg = az[s] < 0;
+                const unsigned __int128 amag = a_neg ? (unsigned __int128)(-az[s]) : (unsigned __int128)az[s];
+                const U256 prod = u256_mul_u128(bmag, (uint64_t)amag, (uint64_t)(amag >> 64));
+                const Fr term = mul(e[s], fr_from_u256(prod));
+                acc[node] = a_neg != b_neg ? sub(acc[node], term) : add(acc[node], term);
+            }
+        });
+    }
+    static_for<NODES>([&](auto node_c) {
+        constexpr int node = decltype(node_c)::value;
+        Fr out[1] = {mul(acc[node], Fr::r2())};  // plain -> Montgomery, once per thread and node
+        block_reduce_store_at<1>(out, partials + ((size_t)node * gridDim.x + blockIdx.x));
+        __syncthreads();  // the reduction's LDS scratch is reused by the next node's
+    });
 }
 
 // ws[i] = w[i] * R (Montgomery form of w*R: REDC of sum ws*z lands in Montgomery form), nws[i] = -ws[i]; mask bit per weight != 0
@@ -226,9 +351,34 @@ extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* 
     JOLT_TRY(upload_bytes(ctx, a_weights, wcount * sizeof(int64_t), (void**)&wa));
     int32_t s = upload_bytes(ctx, b_weights, wcount * sizeof(int64_t), (void**)&wb);
     if (s != JOLT_OK) { jolt_internal_dev_free(ctx, wa); return s; }
-    const int grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 4));
+    int grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 4));
+    // all nodes per workgroup, columns read once (k_small_uniskip_all): the node counts of the two callers; JOLT_UNISKIP_ALL=0 keeps the per-node kernel for an A/B
+    static const bool all_enabled = !(std::getenv("JOLT_UNISKIP_ALL") && std::atoi(std::getenv("JOLT_UNISKIP_ALL")) == 0);
+    ColumnPlanes cp;
+    size_t n_planes = 0;
+    for (size_t v = 0; v < (size_t)kMaxSmallInputs; ++v) {
+        cp.first[v] = (uint16_t)n_planes;
+        if (v < n_inputs) n_planes += in.kind[v] == JOLT_INT_I128 ? 2 : 1;
+    }
+    const size_t lds_all = n_planes * kBlock * sizeof(uint64_t);
+    const bool all_nodes = all_enabled && (n_nodes == 9 || n_nodes == 5) && lds_all + 1024 <= ctx->max_lds_per_block;
+    if (all_nodes) {  // as many workgroups as stay resident: LDS-limited, at most 2 per compute unit (two waves per SIMD: the NODES accumulators live in registers)
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(2, (ctx->max_lds_per_block - 1024) / std::max<size_t>(lds_all, 1)));
+        grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * per_cu));
+    }
     s = jolt_internal_ensure_scratch(ctx, n_nodes * (size_t)grid + 8, n_nodes + 8);
-    if (s == JOLT_OK) {
+    if (s == JOLT_OK && all_nodes) {
+        const void* fn = n_streams == 2 ? (n_nodes == 9 ? (const void*)k_small_uniskip_all<2, 9> : (const void*)k_small_uniskip_all<2, 5>)
+                                        : (n_nodes == 9 ? (const void*)k_small_uniskip_all<1, 9> : (const void*)k_small_uniskip_all<1, 5>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all) != hipSuccess) { (void)hipGetLastError(); s = JOLT_ERR_HIP; }
+        if (s == JOLT_OK) {
+            if (n_streams == 2 && n_nodes == 9) hipLaunchKernelGGL((k_small_uniskip_all<2, 9>), dim3(grid), dim3(kBlock), lds_all, ctx->stream, in, cp, (const Fr*)eq->data(), cycles, (const int64_t*)wa, (const int64_t*)wb, ctx->d_partials);
+            else if (n_streams == 2) hipLaunchKernelGGL((k_small_uniskip_all<2, 5>), dim3(grid), dim3(kBlock), lds_all, ctx->stream, in, cp, (const Fr*)eq->data(), cycles, (const int64_t*)wa, (const int64_t*)wb, ctx->d_partials);
+            else if (n_nodes == 9) hipLaunchKernelGGL((k_small_uniskip_all<1, 9>), dim3(grid), dim3(kBlock), lds_all, ctx->stream, in, cp, (const Fr*)eq->data(), cycles, (const int64_t*)wa, (const int64_t*)wb, ctx->d_partials);
+            else hipLaunchKernelGGL((k_small_uniskip_all<1, 5>), dim3(grid), dim3(kBlock), lds_all, ctx->stream, in, cp, (const Fr*)eq->data(), cycles, (const int64_t*)wa, (const int64_t*)wb, ctx->d_partials);
+            s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
+        }
+    } else if (s == JOLT_OK) {
         const unsigned blocks = (unsigned)(((size_t)grid + 7) / 8 * 8 * n_nodes);
         if (n_streams == 2)
             hipLaunchKernelGGL(k_small_uniskip<2>, dim3(blocks), dim3(kBlock), 0, ctx->stream, in, (const Fr*)eq->data(), cycles, (const int64_t*)wa,
