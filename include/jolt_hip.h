@@ -683,6 +683,20 @@ int32_t jolt_key_index_pushforward(jolt_ctx *ctx, const jolt_key_index *index, j
 int32_t jolt_key_index_last_value(jolt_ctx *ctx, const jolt_key_index *index, const jolt_ints *values, const jolt_table *init, jolt_table **out);
 int32_t jolt_key_index_destroy(jolt_ctx *ctx, jolt_key_index *index);
 
+/* The hypercube-sharded form of both matrices (one process per GPU; the reference has no multi-GPU code: this is north_star's "the 2^n boolean hypercube shards
+ * across the GPUs" for rw_matrix.rs / registers_read_write/sparse.rs).  Cycles are dealt to the ranks in contiguous blocks and bind low to high, so rank g runs the
+ * first log T_local cycle rounds on a LOCAL matrix over its block (the constructors above with the low log T_local coordinates of the cycle point; its round sums,
+ * scaled by eq(w_hi, g), add over the ranks).  jolt_rw_matrix_hold_row (before the rounds) keeps the single row those rounds leave in cycle-major form;
+ * jolt_rw_matrix_bind ingests the last local challenge; jolt_rw_matrix_export_row reads the row out (cells in column order, raw checkpoints, the bound increment, the
+ * bound eq factor).  The rows of all ranks stacked in rank order are the matrix of the remaining log G cycle variables: jolt_rw_matrix_create_merged builds it on
+ * every rank (w = the log_rows HIGH coordinates, inc = the ranks' bound increments in rank order) and the ordinary prove_round / finish / final_values continue. */
+int32_t jolt_rw_matrix_hold_row(jolt_rw_matrix *m);
+int32_t jolt_rw_matrix_bind(jolt_rw_matrix *m, const jolt_fr_t *bind);
+int32_t jolt_rw_matrix_export_row(jolt_rw_matrix *m, size_t cap, uint64_t *cols, uint64_t *prev, uint64_t *next, jolt_fr_t *val, jolt_fr_t *ra, jolt_fr_t *wa /* registers */,
+                                  jolt_fr_t *inc_out, jolt_fr_t *scalar_out, size_t *n_out);
+int32_t jolt_rw_matrix_create_merged(jolt_ctx *ctx, int32_t registers, size_t log_rows, size_t log_k, size_t n, const uint64_t *rows, const uint64_t *cols,
+                                     const uint64_t *prev, const uint64_t *next, const jolt_fr_t *val, const jolt_fr_t *ra, const jolt_fr_t *wa, const jolt_fr_t *inc,
+                                     const jolt_table *val_init, const jolt_fr_t *w, const jolt_fr_t *scalar, const jolt_fr_t *gamma, jolt_rw_matrix **out);
 int32_t jolt_rw_matrix_len(const jolt_rw_matrix *m, size_t *entries);
 int32_t jolt_rw_matrix_download(jolt_rw_matrix *m, uint64_t *rows, uint64_t *cols, jolt_fr_t *val, jolt_fr_t *ra, jolt_fr_t *prev, jolt_fr_t *next);
 int32_t jolt_rw_matrix_destroy(jolt_rw_matrix *m);

@@ -459,6 +459,7 @@ struct jolt_rw_matrix {
     uint64_t* h_total = nullptr;  // pinned
     bool match_valid = false;
     bool registers = false;                 // registers read/write checking: two coefficient columns, dense K-sized address phase on the host
+    bool hold_row = false;                  // a rank's LOCAL matrix of a sharded prover: after its last cycle round the single row stays cycle-major (jolt_rw_matrix_export_row)
     std::vector<Fr> reg_ra, reg_wa, reg_val;  // the address-phase state (ReadWriteKernel::{ra, wa, val}, registers_read_write/mod.rs:162-169)
     Fr inc_scalar;
     jolt_table *inc = nullptr, *val_init = nullptr;
@@ -662,7 +663,9 @@ static int32_t rw_ingest(jolt_rw_matrix* m, const Fr& r) {
             if (nvar / 2 < current_index && m->e_in_bits > 0) m->e_in_bits -= 1;
             else if (0 < current_index && m->e_out_bits > 0) m->e_out_bits -= 1;
         }
-        if (m->round == m->log_t - 1 && m->registers) {
+        if (m->round == m->log_t - 1 && m->hold_row) {
+            // a sharded prover's local matrix: the row is exported as it is and merged with the other ranks' rows (jolt_rw_matrix_create_merged)
+        } else if (m->round == m->log_t - 1 && m->registers) {
             // SparseEntries::into_dense (registers_read_write/sparse.rs:532-561): the single remaining row scattered into K-sized arrays on the HOST
             // ("small fixed K": the address rounds cost O(K) = 128 pairs, mod.rs:30-33); eq and inc are scalars from here on
             const size_t K = (size_t)1 << m->log_k;
@@ -800,6 +803,147 @@ extern "C" int32_t jolt_rw_matrix_final_values(jolt_rw_matrix* m, jolt_fr_t* out
 extern "C" int32_t jolt_rw_matrix_len(const jolt_rw_matrix* m, size_t* entries) {
     if (!m || !entries) return JOLT_ERR_INVALID_ARG;
     *entries = m->n;
+    return JOLT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The sharded form (one process per GPU).  The cycles of a trace are dealt to the ranks in contiguous blocks and the cycle variables bind low to
+// high, so the first log T_local cycle rounds touch only a rank's own cells: rank g runs them on a LOCAL matrix over its block (the ordinary constructors with the low
+// log T_local coordinates of the point; its two round sums, scaled by eq(w_hi, g), add up over the ranks).  After them every rank holds ONE row -- at most one cell per
+// address it touched, with its raw checkpoints -- which jolt_rw_matrix_export_row reads out; the rows of all ranks, stacked in rank order, ARE the cycle-major matrix
+// of the remaining log G cycle variables (row = rank), and jolt_rw_matrix_create_merged continues from it on every rank: log G cycle rounds, then the address rounds.
+//   hold_row: call before the rounds; then the last local bind leaves the row cycle-major (no address-major / dense conversion).
+//   bind: ingest a challenge without asking for a round (the last local challenge).
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t jolt_rw_matrix_hold_row(jolt_rw_matrix* m) {
+    if (!m || m->round != 0) return JOLT_ERR_INVALID_ARG;
+    m->hold_row = true;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_rw_matrix_bind(jolt_rw_matrix* m, const jolt_fr_t* bind) {
+    if (!m || !bind) return JOLT_ERR_INVALID_ARG;
+    const Fr r = fr_from_abi(bind);
+    JOLT_REQUIRE(m->ctx, fr_is_canonical(r), "bind challenge is not a canonical Fr");
+    if (m->round >= m->log_t + m->log_k || (m->hold_row && m->round >= m->log_t)) { m->ctx->last_error = "rw matrix already bound"; return JOLT_ERR_INVALID_ARG; }
+    return rw_ingest(m, r);
+}
+// the single row a held matrix is left with after its log_t cycle rounds: *n_out cells (<= cap, else JOLT_ERR_SIZE_MISMATCH) in column order; wa: registers handles
+// only (NULL otherwise); inc_out = the bound increment column's one entry, scalar_out = the bound eq factor so far
+extern "C" int32_t jolt_rw_matrix_export_row(jolt_rw_matrix* m, size_t cap, uint64_t* cols, uint64_t* prev, uint64_t* next, jolt_fr_t* val, jolt_fr_t* ra, jolt_fr_t* wa,
+                                             jolt_fr_t* inc_out, jolt_fr_t* scalar_out, size_t* n_out) {
+    if (!m || !cols || !prev || !next || !val || !ra || !inc_out || !scalar_out || !n_out || (m->registers && !wa)) return JOLT_ERR_INVALID_ARG;
+    jolt_ctx* ctx = m->ctx;
+    if (!m->hold_row || m->round != m->log_t) { ctx->last_error = "export_row: a held matrix after its last cycle round"; return JOLT_ERR_INVALID_ARG; }
+    const uint32_t n = m->n;
+    *n_out = n;
+    if (n > cap) return JOLT_ERR_SIZE_MISMATCH;
+    const RwArrays& a = m->st[m->cur];
+    std::vector<uint64_t> key(n);
+    hipError_t first = hipSuccess;
+    auto copy = [&](void* dst, const void* src, size_t bytes) {
+        const hipError_t e = bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+        if (first == hipSuccess) first = e;
+    };
+    copy(key.data(), a.key, (size_t)n * 8);
+    copy(prev, a.prev_u, (size_t)n * 8);
+    copy(next, a.next_u, (size_t)n * 8);
+    copy(val, a.val, (size_t)n * sizeof(Fr));
+    copy(ra, a.ra, (size_t)n * sizeof(Fr));
+    if (m->registers) copy(wa, a.wa, (size_t)n * sizeof(Fr));
+    Fr inc;
+    copy(&inc, m->inc->data(), sizeof(Fr));
+    const hipError_t sync = hipStreamSynchronize(ctx->stream);
+    JOLT_HIP_TRY(ctx, first);
+    JOLT_HIP_TRY(ctx, sync);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (key[i] >> 32) { ctx->last_error = "export_row: a cell outside the single bound row"; return JOLT_ERR_INVALID_ARG; }
+        cols[i] = (uint32_t)key[i];
+    }
+    fr_to_abi(inc_out, inc);
+    fr_to_abi(scalar_out, m->current_scalar);
+    return JOLT_OK;
+}
+
+// The matrix over the remaining 2^log_rows rows (log_rows >= 1), from cells in (row, col) order: key, raw checkpoints, val, ra (and wa: registers != 0) as
+// exported; inc: the 2^log_rows entries of the bound increment column (row order); w: the log_rows remaining coordinates of the cycle point (the HIGH ones);
+// scalar: the eq factor bound so far.  RAM (registers == 0): val_init as in jolt_rw_matrix_create; registers: k = 2^log_k <= 256 registers, val_init NULL.
+extern "C" int32_t jolt_rw_matrix_create_merged(jolt_ctx* ctx, int32_t registers, size_t log_rows, size_t log_k, size_t n, const uint64_t* rows, const uint64_t* cols,
+                                                const uint64_t* prev, const uint64_t* next, const jolt_fr_t* val, const jolt_fr_t* ra, const jolt_fr_t* wa, const jolt_fr_t* inc,
+                                                const jolt_table* val_init, const jolt_fr_t* w, const jolt_fr_t* scalar, const jolt_fr_t* gamma, jolt_rw_matrix** out) {
+    if (!ctx || !inc || !w || !scalar || !gamma || !out || (n && (!rows || !cols || !prev || !next || !val || !ra))) return JOLT_ERR_INVALID_ARG;
+    if ((registers && n && !wa) || (!registers && !val_init)) return JOLT_ERR_INVALID_ARG;
+    if (log_rows < 1 || log_rows > 16 || log_k > 32 || n >= ((size_t)1 << 31)) return JOLT_ERR_UNSUPPORTED;
+    if (registers && log_k > 8) return JOLT_ERR_SIZE_MISMATCH;
+    if (!registers && val_init->len != ((size_t)1 << log_k)) return JOLT_ERR_SIZE_MISMATCH;
+    std::vector<uint64_t> key(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (rows[i] >> log_rows || cols[i] >> log_k) { ctx->last_error = "merged rw matrix: a cell outside the matrix"; return JOLT_ERR_INVALID_ARG; }
+        key[i] = (rows[i] << 32) | cols[i];
+        if (i && key[i] <= key[i - 1]) { ctx->last_error = "merged rw matrix: cells must come in (row, column) order"; return JOLT_ERR_INVALID_ARG; }
+    }
+    jolt_rw_matrix* m = new (std::nothrow) jolt_rw_matrix();
+    if (!m) return JOLT_ERR_OOM;
+    m->ctx = ctx;
+    m->registers = registers != 0;
+    m->log_t = log_rows;
+    m->log_k = log_k;
+    m->gamma = fr_from_abi(gamma);
+    m->current_scalar = fr_from_abi(scalar);
+    m->w.resize(log_rows);
+    for (size_t i = 0; i < log_rows; ++i) m->w[i] = fr_from_abi(&w[i]);
+    int32_t s = fr_is_canonical(m->gamma) && fr_is_canonical(m->current_scalar) ? JOLT_OK : JOLT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < log_rows && s == JOLT_OK; ++i) if (!fr_is_canonical(m->w[i])) s = JOLT_ERR_INVALID_ARG;
+    const size_t split = m->log_t / 2, head_len = m->log_t - 1;  // GruenSplitEqPolynomial::new over the remaining point (split_eq.rs:214-236)
+    m->out_len = std::min(split, head_len);
+    m->in_len = head_len - m->out_len;
+    m->e_out_bits = m->out_len;
+    m->e_in_bits = m->in_len;
+    if (s == JOLT_OK) s = jolt_internal_eq_levels(ctx, m->w.data(), m->out_len, Fr::one(), &m->e_out_cache);
+    if (s == JOLT_OK) s = jolt_internal_eq_levels(ctx, m->w.data() + m->out_len, m->in_len, Fr::one(), &m->e_in_cache);
+    if (s == JOLT_OK) s = jolt_table_upload(ctx, inc, (size_t)1 << log_rows, &m->inc);
+    if (s == JOLT_OK && !registers) s = jolt_table_clone(ctx, val_init, &m->val_init);
+    m->cap = (uint32_t)std::max<size_t>(n, 1);
+    const size_t scan_len = std::max<size_t>((size_t)1 << log_rows, m->cap);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_st[2][8];
+    for (int b = 0; b < 2; ++b) {
+        o_st[b][0] = take((size_t)m->cap * 8); o_st[b][1] = take((size_t)m->cap * 8); o_st[b][2] = take((size_t)m->cap * 8);
+        o_st[b][3] = take(registers ? 256 : (size_t)m->cap * 32); o_st[b][4] = take(registers ? 256 : (size_t)m->cap * 32);
+        o_st[b][5] = take((size_t)m->cap * 32); o_st[b][6] = take((size_t)m->cap * 32); o_st[b][7] = take(registers ? (size_t)m->cap * 32 : 256);
+    }
+    const size_t o_sib = take((size_t)m->cap * 4), o_match = take((size_t)m->cap * 4), o_flags = take(scan_len * 8), o_scan = take(scan_len * 8),
+                 o_bs = take(((scan_len + kBlock * kScanItems - 1) / (kBlock * kScanItems) + 1) * 8), o_total = take(256);
+    if (s == JOLT_OK) s = jolt_internal_dev_alloc(ctx, off, &m->block);
+    if (s == JOLT_OK && hipHostMalloc((void**)&m->h_total, 64, hipHostMallocDefault) != hipSuccess) s = JOLT_ERR_HIP;
+    if (s != JOLT_OK) { jolt_rw_matrix_destroy(m); return s; }
+    char* base = (char*)m->block;
+    for (int b = 0; b < 2; ++b) {
+        m->st[b].key = (uint64_t*)(base + o_st[b][0]); m->st[b].prev_u = (uint64_t*)(base + o_st[b][1]); m->st[b].next_u = (uint64_t*)(base + o_st[b][2]);
+        m->st[b].prev_f = registers ? nullptr : (Fr*)(base + o_st[b][3]); m->st[b].next_f = registers ? nullptr : (Fr*)(base + o_st[b][4]);
+        m->st[b].val = (Fr*)(base + o_st[b][5]); m->st[b].ra = (Fr*)(base + o_st[b][6]); m->st[b].wa = (Fr*)(base + o_st[b][7]);
+    }
+    m->sib_lb = (uint32_t*)(base + o_sib); m->matched = (uint32_t*)(base + o_match); m->flags = (uint64_t*)(base + o_flags); m->scan = (uint64_t*)(base + o_scan);
+    m->block_sums = (uint64_t*)(base + o_bs); m->total = (uint64_t*)(base + o_total);
+    hipError_t first = hipSuccess;
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+        const hipError_t e = bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        if (first == hipSuccess) first = e;
+    };
+    up(m->st[0].key, key.data(), n * 8);
+    up(m->st[0].prev_u, prev, n * 8);
+    up(m->st[0].next_u, next, n * 8);
+    up(m->st[0].val, val, n * sizeof(Fr));
+    up(m->st[0].ra, ra, n * sizeof(Fr));
+    if (registers) up(m->st[0].wa, wa, n * sizeof(Fr));
+    const hipError_t sync = hipStreamSynchronize(ctx->stream);  // the caller's arrays (and `key`) may be short-lived
+    if (first != hipSuccess || sync != hipSuccess) {
+        ctx->last_error = std::string("merged rw matrix: ") + hipGetErrorString(first != hipSuccess ? first : sync);
+        jolt_rw_matrix_destroy(m);
+        return JOLT_ERR_HIP;
+    }
+    m->n = (uint32_t)n;
+    *out = m;
     return JOLT_OK;
 }
 

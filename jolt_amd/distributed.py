@@ -393,6 +393,112 @@ class DeviceShard:
         pass
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# a batch over ANY device members (the stage operators of jolt_amd/stages_sharded.py): phase A on the rank's blocks, one hand-over, the redundant tail
+# ---------------------------------------------------------------------------------------------------------------------
+_P_LIMBS = np.array([(0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001 >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+
+
+def fr_add_vec(a, b):
+    """(n, 4) + (n, 4) canonical field elements (Montgomery limbs add like plain residues), vectorised: what a rank does with the other ranks' partial sums"""
+    a, b = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4), np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(a)
+    carry = np.zeros(a.shape[0], dtype=np.uint64)
+    for i in range(4):
+        s = a[:, i] + b[:, i]
+        c1 = s < a[:, i]
+        s2 = s + carry
+        c2 = s2 < s
+        out[:, i] = s2
+        carry = (c1 | c2).astype(np.uint64)
+    d = np.empty_like(out)  # out < 2 r < 2^255: one conditional subtraction
+    borrow = np.zeros(a.shape[0], dtype=np.uint64)
+    for i in range(4):
+        t = out[:, i] - _P_LIMBS[i]
+        b1 = out[:, i] < _P_LIMBS[i]
+        t2 = t - borrow
+        b2 = t < borrow
+        d[:, i] = t2
+        borrow = (b1 | b2).astype(np.uint64)
+    take = borrow == 0
+    out[take] = d[take]
+    return out
+
+
+def gather_sum(coll, values):
+    """sum over the ranks of an (n, 4) array of partial field sums: ONE all-gather + a local modular sum (RCCL has no mod-r reduction)"""
+    v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+    allv = np.ascontiguousarray(coll.all_gather_u64(v.reshape(-1)))
+    allv = allv.reshape(allv.shape[0], -1, 4)
+    acc = allv[0].copy()
+    for r in range(1, allv.shape[0]):
+        acc = fr_add_vec(acc, allv[r])
+    return acc.reshape(np.asarray(values).shape)
+
+
+class _TailShard(DeviceShard):
+    """DeviceShard whose hand-over builds throw-away tail members through each member's `_tail(tables, scalar, w_rem)` closure and keeps them (their final
+    values are the batch's); buffers and members are dropped by drop()."""
+
+    def __init__(self, ctx, members, infos, world, tail_log):
+        super().__init__(ctx, members)
+        self.infos, self.world, self.tail_log = infos, world, tail_log
+        self.tail_members, self.keep = None, []
+
+    def make_tail(self, coll, scalars):
+        ctx, world, lib = self.ctx, self.world, ffi.lib()
+        log_g = world.bit_length() - 1
+        E = 1 << self.tail_log
+        n_tab = sum(m.n_tables for m in self.members)
+        rem = log_g + self.tail_log
+        pack, gath, arena = ctx.alloc(n_tab * E), ctx.alloc(world * n_tab * E), ctx.alloc(world * n_tab * E)
+        self.keep += [pack, gath, arena]
+        hs = (C.c_void_p * len(self.members))(*[m.h for m in self.members])
+        ffi._ck(lib.jolt_round_group_pack_tables(ctx.h, hs, C.c_size_t(len(self.members)), C.c_size_t(E), pack.h), "jolt_round_group_pack_tables", ctx)
+        if isinstance(coll, NativeCollective):
+            coll.all_gather_table(pack, n_tab * E, gath)
+        else:  # torch.distributed: through the host
+            g = coll.all_gather_u64(pack.download())
+            ffi._ck(lib.jolt_table_write(ctx.h, gath.h, C.c_size_t(0), _p(np.ascontiguousarray(g.reshape(-1, 4))), C.c_size_t(world * n_tab * E)), "jolt_table_write", ctx)
+        ffi._ck(lib.jolt_tail_interleave(ctx.h, gath.h, C.c_size_t(world), C.c_size_t(n_tab), C.c_size_t(E), arena.h), "jolt_tail_interleave", ctx)
+        tails, pos = [], 0
+        for k, m in enumerate(self.members):
+            tabs = []
+            for _ in range(m.n_tables):
+                h = C.c_void_p()
+                ffi._ck(lib.jolt_table_slice(ctx.h, arena.h, C.c_size_t(pos * world * E), C.c_size_t(world * E), C.byref(h)), "jolt_table_slice", ctx)
+                tabs.append(ffi.Table(ctx, h))
+                pos += 1
+            self.keep += tabs
+            w = self.infos[k].w
+            tails.append(m._tail(tabs, scalars[k], None if w is None else np.asarray(w)[:rem]))
+        self.tail_members = tails
+        return DeviceShard(ctx, tails)
+
+    def drop(self):
+        for m in self.tail_members or []:
+            m.destroy()
+        for t in self.keep:
+            t.free()
+        self.tail_members, self.keep = None, []
+
+
+def prove_members_sharded(ctx, coll, world, members, infos, claims, coeffs, n_total, n_local, max_degree, label=0, tail_log=None, round_exchange=None, force_gather=False):
+    """One batched sumcheck over device members that hold this rank's block of their tables (every member: n_total rounds, a `_tail` closure for the hand-over).
+    -> (the transcript of prove_batch_sharded, per member its final values after ALL n_total rounds: tables..., and the eq scalar of a split-eq member)."""
+    if tail_log is None:
+        tail_log = tail_log_for(n_local, world)
+    tail_log = min(tail_log, n_local)
+    shard = _TailShard(ctx, members, infos, world, tail_log)
+    try:
+        out = prove_batch_sharded(ctx.h, infos, claims, coeffs, n_total, n_local, max_degree, world, coll, shard, label=label, tail_log=tail_log, force_gather=force_gather,
+                                  round_exchange=round_exchange)
+        finals = [m.final_values() for m in (shard.tail_members if shard.tail_members is not None else members)]
+    finally:
+        shard.drop()
+    return out, finals
+
+
 def build_sharded_spec(n_local, rank, world, seed=2026):
     """Pure description of rank `rank`'s shard of the bench workload: witness columns are seeded per rank; every derived
     leaf (eq / eq+1 / LT in the single-GPU workload) is the rank's aligned block of eq(point, .) for a GLOBAL random point

@@ -262,6 +262,18 @@ class Context:
             b.h = None
         return m
 
+    def member_split_eq_product_sharded(self, a, b, w_local, scale=None, shard_scale=None):
+        """one rank's shard of the split-eq product member (jolt_member_create_split_eq_product_sharded): a, b hold the rank's block of rows (borrowed), w_local the
+        low log2(rows) coordinates of the point, shard_scale = eq(w_hi, rank)"""
+        w = fr(w_local).reshape(-1, 4)
+        h = C.c_void_p()
+        _ck(lib().jolt_member_create_split_eq_product_sharded(self.h, a.h, b.h, _p(w), C.c_size_t(w.shape[0]), _p(fr(scale)) if scale is not None else None,
+                                                              _p(fr(shard_scale)) if shard_scale is not None else None, C.byref(h)),
+            "jolt_member_create_split_eq_product_sharded", self)
+        m = Member(self, h, 3, 2, True, False)
+        m._keepalive = [a, b]
+        return m
+
     def member_split_eq_uniform(self, tables, V, F, coeffs, w, scale=None, shard_scale=None, borrow=False):
         """eq(w,.) * sum_v coeffs[v] * prod_{i<F} tables[v*F+i]; prove_round returns q(0), q(2), .., q(F)."""
         w = fr(w).reshape(-1, 4)
@@ -1118,6 +1130,83 @@ class RwMatrix:
 
 
 Context.rw_matrix = lambda self, *a, **k: RwMatrix(self, *a, **k)
+
+
+# ---- the sharded form of both sparse matrices (jolt_rw_matrix_hold_row / _bind / _export_row / _create_merged): shared by RwMatrix and RegistersRw handles
+def rw_hold_row(m):
+    _ck(lib().jolt_rw_matrix_hold_row(m.h), "jolt_rw_matrix_hold_row", m.ctx)
+
+
+def rw_bind(m, bind):
+    _ck(lib().jolt_rw_matrix_bind(m.h, _p(fr(bind))), "jolt_rw_matrix_bind", m.ctx)
+
+
+def rw_export_row(m, registers):
+    """the single row a held local matrix is left with: dict(cols, prev, next (u64), val, ra[, wa] (n, 4), inc, scalar)"""
+    n = len(m)
+    cap = max(n, 1)
+    cols, prev, nxt = (np.zeros(cap, dtype=np.uint64) for _ in range(3))
+    val, ra, wa = fr_array(cap), fr_array(cap), fr_array(cap)
+    inc, scalar = fr_array(1), fr_array(1)
+    got = C.c_size_t()
+    _ck(lib().jolt_rw_matrix_export_row(m.h, C.c_size_t(cap), _p(cols), _p(prev), _p(nxt), _p(val), _p(ra), _p(wa) if registers else None, _p(inc), _p(scalar), C.byref(got)),
+        "jolt_rw_matrix_export_row", m.ctx)
+    n = got.value
+    out = dict(cols=cols[:n], prev=prev[:n], next=nxt[:n], val=val[:n], ra=ra[:n], inc=inc[0], scalar=scalar[0])
+    if registers:
+        out["wa"] = wa[:n]
+    return out
+
+
+class MergedRw:
+    """jolt_rw_matrix_create_merged: the matrix of the remaining log G cycle variables built from the ranks' exported rows (rank order); continues with the
+    ordinary rounds.  registers: the registers flavour (four address-round points, five final values)."""
+
+    def __init__(self, ctx, registers, log_rows, log_k, rows, cols, prev, nxt, val, ra, wa, inc, val_init, w, scalar, gamma):
+        self.ctx, self.registers = ctx, bool(registers)
+        u = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        rows, cols, prev, nxt = u(rows), u(cols), u(prev), u(nxt)
+        n = rows.shape[0]
+        val, ra = u(val).reshape(-1, 4), u(ra).reshape(-1, 4)
+        wa = u(wa).reshape(-1, 4) if registers else None
+        inc = u(inc).reshape(-1, 4)
+        assert inc.shape[0] == 1 << log_rows
+        h = C.c_void_p()
+        _ck(lib().jolt_rw_matrix_create_merged(ctx.h, C.c_int32(1 if registers else 0), C.c_size_t(log_rows), C.c_size_t(log_k), C.c_size_t(n), _p(rows), _p(cols), _p(prev), _p(nxt),
+                                               _p(val), _p(ra), _p(wa) if registers else None, _p(inc), val_init.h if val_init is not None else None,
+                                               _p(fr(w).reshape(-1, 4)), _p(fr(scalar)), _p(fr(gamma)), C.byref(h)), "jolt_rw_matrix_create_merged", ctx)
+        self.h = h
+
+    def __len__(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_rw_matrix_len(self.h, C.byref(n)), "jolt_rw_matrix_len", self.ctx)
+        return n.value
+
+    def prove_round(self, bind=None):
+        evals, aux = fr_array(4 if self.registers else 2), fr_array(3)
+        fn = lib().jolt_registers_rw_prove_round if self.registers else lib().jolt_rw_matrix_prove_round
+        _ck(fn(self.h, _p(fr(bind)) if bind is not None else None, _p(evals), _p(aux)), "jolt_rw_matrix_prove_round (merged)", self.ctx)
+        return evals, aux
+
+    def finish(self, bind):
+        _ck(lib().jolt_rw_matrix_finish(self.h, _p(fr(bind))), "jolt_rw_matrix_finish", self.ctx)
+
+    def final_values(self):
+        out = fr_array(5 if self.registers else 4)
+        fn = lib().jolt_registers_rw_final_values if self.registers else lib().jolt_rw_matrix_final_values
+        _ck(fn(self.h, _p(out)), "jolt_rw_matrix_final_values (merged)", self.ctx)
+        return out
+
+    def free(self):
+        if self.h:
+            lib().jolt_rw_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class KeyIndex:

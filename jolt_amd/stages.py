@@ -43,11 +43,14 @@ ADDRESS_BITS, PHASES, CHUNK = 128, 16, 256
 PRODUCT_EXTENSION = np.array([[3, -3, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, -3, 3]], dtype=np.int64)
 
 
-def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5):
+def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None):
     """RamAccessColumns (optimized/ram_trace.rs:22-75) of a memory-consistent synthetic trace: per cycle an optional access (address, word before,
-    word after), the word before being what the previous access to that address left (or the initial memory)."""
+    word after), the word before being what the previous access to that address left (or the initial memory).  val_init: the memory the trace starts from
+    (a later block of a longer trace: the final memory of the block before it, `val_final`); drawn when None."""
     K, T = 1 << log_k, 1 << log_t
-    val_init = rng.integers(0, 2**63, size=K, dtype=np.uint64)
+    if val_init is None:
+        val_init = rng.integers(0, 2**63, size=K, dtype=np.uint64)
+    val_init = np.ascontiguousarray(val_init, dtype=np.uint64)
     addresses = rng.integers(0, K, size=T, dtype=np.uint64)
     hit = rng.random(T) < access
     addresses[~hit] = NO_ACCESS
@@ -68,18 +71,23 @@ def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5):
         pre_s = np.where(chain_start, val_init[a_s], np.r_[post_s[:1], post_s[:-1]])
         pre[cyc[order]] = pre_s
         post[cyc[order]] = post_s
+    val_final = val_init.copy()
+    if n:
+        chain_end = np.r_[a_s[1:] != a_s[:-1], True]
+        val_final[a_s[chain_end]] = post_s[chain_end]
     inc = post.astype(np.int64) - pre.astype(np.int64)  # RamInc: words < 2^63, so the difference fits an i64
-    return dict(log_k=log_k, log_t=log_t, val_init=val_init, addresses=addresses, pre=pre, post=post, inc=inc)
+    return dict(log_k=log_k, log_t=log_t, val_init=val_init, val_final=val_final, addresses=addresses, pre=pre, post=post, inc=inc)
 
 
 REG_NONE = np.uint8(0xFF)
 
 
-def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None):
+def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None, reg_init=None):
     """RegisterCycleRow columns (optimized/registers_read_write/rows.rs:22-31) of a consistent synthetic trace: a read returns what the last
-    earlier write to that register left (registers start at 0), rd_pre likewise; rd_post is fresh.  hot: draw registers from the first
-    `hot` only (many cells per register pair)."""
+    earlier write to that register left (registers start at 0, or at reg_init for a later block of a longer trace), rd_pre likewise; rd_post is fresh.
+    hot: draw registers from the first `hot` only (many cells per register pair).  `reg_final`: the register file after the last cycle."""
     K, T = 1 << log_k, 1 << log_t
+    reg_init = np.zeros(K, dtype=np.uint64) if reg_init is None else np.ascontiguousarray(reg_init, dtype=np.uint64)
     pool = K if hot is None else min(K, hot)
     draw = lambda p: np.where(rng.random(T) < p, rng.integers(0, pool, size=T), 0xFF).astype(np.uint8)
     rs1, rs2, rd = draw(p_rs1), draw(p_rs2), draw(p_rd)
@@ -96,11 +104,16 @@ def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7,
         ok = (reg != REG_NONE) & (pos >= 0)
         posc = np.maximum(pos, 0)
         same = ok & (wreg_s[posc] == reg) if wkey_s.size else np.zeros(T, dtype=bool)
-        return np.where(same, wpost_s[posc] if wkey_s.size else 0, 0).astype(np.uint64)
+        start = np.where(reg != REG_NONE, reg_init[np.minimum(reg, K - 1)], 0)  # no earlier write in this block: what the register held when the block began
+        return np.where(same, wpost_s[posc] if wkey_s.size else 0, start).astype(np.uint64)
 
     rs1_val, rs2_val, rd_pre = value_before(rs1), value_before(rs2), value_before(rd)
+    reg_final = reg_init.copy()
+    if wkey_s.size:
+        last = np.r_[wreg_s[1:] != wreg_s[:-1], True]
+        reg_final[wreg_s[last]] = wpost_s[last]
     # RdInc as a field table needs post - pre; values are full 64-bit words, so the signed difference is kept as (magnitude, sign)
-    return dict(log_k=log_k, log_t=log_t, rs1=rs1, rs1_val=rs1_val, rs2=rs2, rs2_val=rs2_val, rd=rd, rd_pre=rd_pre, rd_post=rd_post)
+    return dict(log_k=log_k, log_t=log_t, rs1=rs1, rs1_val=rs1_val, rs2=rs2, rs2_val=rs2_val, rd=rd, rd_pre=rd_pre, rd_post=rd_post, reg_final=reg_final)
 
 
 N_LOOKUP_TABLES = 42
@@ -126,39 +139,74 @@ def interleave_operands(x, y):
     return np.stack([lo, hi], axis=1)
 
 
-def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_count=4, log_k=None, log_kb=None):
-    rng = np.random.default_rng(seed + 500)
-    T = 1 << n_vars
-    d = {"n_vars": n_vars}
-    # ---- stage 1: flags and registers of the R1CS inputs; integer uni-skip column weights (~40 % non-zero), field weights of the remainder
-    d["outer_cols"] = [rng.integers(0, 2, size=T, dtype=np.uint64) if v % 3 else rng.integers(0, 2**64, size=T, dtype=np.uint64) for v in range(n_outer)]
+def extended_params(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_count=4, log_k=None, log_kb=None):
+    """What a proof over T = 2^n_vars cycles shares between the blocks of its trace (and between the ranks of a sharded prover): the points, the batching
+    scalars, the integer / field column weights, the sizes, the K-sized public tables -- everything of the description that is not a witness column."""
+    rng = np.random.default_rng([seed + 500, 0xA11])
+    p = {"n_vars": n_vars, "n_outer": n_outer, "n_nodes": n_nodes}
+    # ---- stage 1: integer uni-skip column weights (~40 % non-zero), field weights of the remainder
     shape = (n_nodes, 2, 1 + n_outer)
-    d["outer_iwa"] = rng.integers(-2**20, 2**20, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
-    d["outer_iwb"] = rng.integers(-2**40, 2**40, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
-    d["outer_tau"] = rand_fr(n_vars + 1, rng)
-    d["outer_kernel"] = rand_fr(1, rng)[0]
-    d["outer_wa"] = rand_fr(2 * (1 + n_outer), rng).reshape(2, 1 + n_outer, 4)
-    d["outer_wb"] = rand_fr(2 * (1 + n_outer), rng).reshape(2, 1 + n_outer, 4)
+    p["outer_iwa"] = rng.integers(-2**20, 2**20, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
+    p["outer_iwb"] = rng.integers(-2**40, 2**40, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
+    p["outer_tau"] = rand_fr(n_vars + 1, rng)
+    p["outer_kernel"] = rand_fr(1, rng)[0]
+    p["outer_wa"] = rand_fr(2 * (1 + n_outer), rng).reshape(2, 1 + n_outer, 4)
+    p["outer_wb"] = rand_fr(2 * (1 + n_outer), rng).reshape(2, 1 + n_outer, 4)
+    p["product_tau"] = rand_fr(n_vars, rng)
+    p["product_kernel"] = rand_fr(1, rng)[0]
+    p["product_w"] = rand_fr(3, rng)
+    p["ram_log_k"] = min(16, max(1, n_vars)) if log_k is None else log_k
+    p["ram_tau"] = rand_fr(n_vars, rng)
+    p["ram_gamma"] = rand_fr(1, rng)[0]
+    p["registers_r_cycle"] = rand_fr(n_vars, rng)
+    p["registers_gamma"] = rand_fr(1, rng)[0]
+    p["lookup_present"] = np.sort(rng.permutation(N_LOOKUP_TABLES)[: min(n_tables, N_LOOKUP_TABLES)]).astype(np.uint8)
+    p["lookup_gamma"] = rand_fr(1, rng)[0]
+    p["lookup_reduction"] = rand_fr(n_vars, rng)
+    p["ra_count"] = ra_count
+    n_ra, log_kc = (36, 4) if n_vars >= 4 else (5, 2)
+    p["n_ra"], p["log_kc"] = n_ra, log_kc
+    p["booleanity"] = dict(log_k=log_kc, reference_cycle=rand_fr(n_vars, rng), reference_address=rand_fr(log_kc, rng), gamma=rand_fr(1, rng)[0])
+    p["hamming"] = dict(r_cycle=rand_fr(n_vars, rng), r_address=rand_fr(log_kc, rng), virtualization_points=rand_fr(n_ra * log_kc, rng).reshape(n_ra, log_kc, 4), gamma=rand_fr(1, rng)[0])
+    K_ram = 1 << p["ram_log_k"]
+    io_lo, io_len = K_ram // 4, max(1, K_ram // 16)
+    val_io = np.zeros(K_ram, dtype=np.uint64)
+    val_io[io_lo:io_lo + io_len] = rng.integers(0, 2**63, size=io_len, dtype=np.uint64)
+    p["ram_raf"] = dict(tau_low=rand_fr(n_vars, rng), lowest_address=np.uint64(0x80000000))
+    p["ram_output"] = dict(point=rand_fr(p["ram_log_k"], rng), io_lo=io_lo, io_len=io_len, val_io=val_io)
+    log_kb = log_kb if log_kb is not None else min(12, max(2, n_vars))
+    Kb = 1 << log_kb
+    p["bytecode"] = dict(log_k=log_kb, chunk_bits=4, stage_points=np.stack([rand_fr(n_vars, rng) for _ in range(5)]) if n_vars else np.zeros((5, 0, 4), dtype=np.uint64),
+                         stage_values=rand_fr(5 * Kb, rng).reshape(5, Kb, 4), gamma=rand_fr(1, rng)[0], entry_index=int(rng.integers(0, Kb)))
+    return p
+
+
+def extended_block(p, n_block, block, seed=2026, ram_init=None, reg_init=None, only_state=False):
+    """The witness columns of block `block` of the trace: T_b = 2^n_block cycles, drawn from the block's own generators, so that any rank of a sharded prover
+    builds ITS block without the others' columns.  What ties blocks together is the machine state: the RAM and the register file a block starts from are what the
+    block before it left (ram_init / reg_init: its `ram["val_final"]` / `registers["reg_final"]`; block 0 draws its memory, registers start at 0) -- a rank replays
+    the RAM / register generators of the blocks before its own (only_state=True: just those two)."""
+    T = 1 << n_block
+    gen = lambda part: np.random.default_rng([seed + 500, 0xB10C, block, part])
+    b = {}
+    b["ram"] = consistent_ram_trace(p["ram_log_k"], n_block, gen(1), val_init=ram_init)
+    b["registers"] = consistent_register_trace(7, n_block, gen(2), reg_init=reg_init)  # REGISTER_ADDRESS_BITS = 7
+    if only_state:
+        return b
+    rng = gen(3)
+    n_outer = p["n_outer"]
+    # ---- stage 1: flags and registers of the R1CS inputs
+    b["outer_cols"] = [rng.integers(0, 2, size=T, dtype=np.uint64) if v % 3 else rng.integers(0, 2**64, size=T, dtype=np.uint64) for v in range(n_outer)]
     # ---- stage 2: product lanes (SpartanProductRow, spartan_product.rs:62-84); right_instruction_input is an i128 (lo, hi two's complement)
     right_lo = rng.integers(0, 2**64, size=T, dtype=np.uint64)
     right_hi = rng.integers(-2**62, 2**62, size=T, dtype=np.int64).view(np.uint64)
-    d["product_rows"] = {
+    b["product_rows"] = {
         "left_input": rng.integers(0, 2**64, size=T, dtype=np.uint64), "lookup_output": rng.integers(0, 2**64, size=T, dtype=np.uint64),
         "jump": rng.integers(0, 2, size=T).astype(np.uint8), "right_input": np.stack([right_lo, right_hi], axis=1),
         "branch": rng.integers(0, 2, size=T).astype(np.uint8), "next_is_noop": rng.integers(0, 2, size=T).astype(np.uint8)}
-    d["product_tau"] = rand_fr(n_vars, rng)
-    d["product_kernel"] = rand_fr(1, rng)[0]
-    d["product_w"] = rand_fr(3, rng)
-    # ---- stage 2: RAM
-    d["ram"] = consistent_ram_trace(min(16, max(1, n_vars)) if log_k is None else log_k, n_vars, rng)
-    d["ram_tau"] = rand_fr(n_vars, rng)
-    d["ram_gamma"] = rand_fr(1, rng)[0]
-    # ---- stage 4: registers (REGISTER_ADDRESS_BITS = 7)
-    d["registers"] = consistent_register_trace(7, n_vars, rng)
-    d["registers_r_cycle"] = rand_fr(n_vars, rng)
-    d["registers_gamma"] = rand_fr(1, rng)[0]
-    # ---- stage 5: lookup rows over real tables (LookupTableKind ids); `n_tables` of the 42 are present
-    present = np.sort(rng.permutation(N_LOOKUP_TABLES)[: min(n_tables, N_LOOKUP_TABLES)]).astype(np.uint8)
+    # ---- stage 5: lookup rows over real tables (LookupTableKind ids)
+    rng = gen(4)
+    present = p["lookup_present"]
     table = present[rng.integers(0, len(present), size=T)]
     idx = np.frombuffer(rng.bytes(16 * T), dtype=np.uint64).reshape(T, 2).copy()
     shapes = rng.integers(0, 8, size=T)
@@ -176,31 +224,19 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_cou
         idx[masked] = interleave_operands(x, y)
     table = table.copy()
     table[rng.random(T) < 0.1] = 0xFF
-    d["lookup"] = dict(idx=idx, table=table, raf=(rng.random(T) < 0.3).astype(np.uint8), n_tables=N_LOOKUP_TABLES, present=present)
-    d["lookup_gamma"] = rand_fr(1, rng)[0]
-    d["lookup_reduction"] = rand_fr(n_vars, rng)
-    d["ra_count"] = ra_count
+    b["lookup"] = dict(idx=idx, table=table, raf=(rng.random(T) < 0.3).astype(np.uint8))
     # ---- stage 6a: the RA selector columns of the booleanity check (instruction, bytecode, RAM chunks: 36 columns at log_k_chunk = 4; RAM cold 40 %)
-    n_ra, log_kc = (36, 4) if n_vars >= 4 else (5, 2)
+    rng = gen(5)
+    n_ra, log_kc = p["n_ra"], p["log_kc"]
     cols = rng.integers(0, 1 << log_kc, size=(n_ra, T)).astype(np.uint8)
-    for p in range(max(1, n_ra // 12)):
-        cols[n_ra - 1 - p, rng.random(T) < 0.4] = 0xFF
-    d["booleanity"] = dict(cols=cols, log_k=log_kc, reference_cycle=rand_fr(n_vars, rng), reference_address=rand_fr(log_kc, rng), gamma=rand_fr(1, rng)[0])
-    # ---- stage 7: Hamming-weight claim reduction over the same RA columns: the shared cycle point of the stage-6b claims, the booleanity address point, one
-    # virtualization point per column
-    d["hamming"] = dict(r_cycle=rand_fr(n_vars, rng), r_address=rand_fr(log_kc, rng), virtualization_points=rand_fr(n_ra * log_kc, rng).reshape(n_ra, log_kc, 4), gamma=rand_fr(1, rng)[0])
-    # ---- stage 2: RAM RAF evaluation and output check over the RAM trace above (tau_low; the IO region = words [K/4, K/4 + max(1, K/16)) with public words)
-    ram = d["ram"]
-    K_ram = 1 << ram["log_k"]
-    io_lo, io_len = K_ram // 4, max(1, K_ram // 16)
-    val_io = np.zeros(K_ram, dtype=np.uint64)
-    val_io[io_lo:io_lo + io_len] = rng.integers(0, 2**63, size=io_len, dtype=np.uint64)
-    d["ram_raf"] = dict(tau_low=rand_fr(n_vars, rng), lowest_address=np.uint64(0x80000000))
-    d["ram_output"] = dict(point=rand_fr(ram["log_k"], rng), io_lo=io_lo, io_len=io_len, val_io=val_io)
-    # ---- stage 6a / 6b: bytecode read + RAF.  A program-shaped PC column: the trace runs loops of 16 .. 512 instructions (a loop body holds most of the cycles),
-    # a tail of unmapped padding cycles (push_pc 0 in the address phase, cold in the cycle phase), five stage points and per-stage value tables
-    log_kb = log_kb if log_kb is not None else min(12, max(2, n_vars))
-    Kb, pcs, j = 1 << log_kb, np.zeros(T, dtype=np.uint64), 0
+    for q in range(max(1, n_ra // 12)):
+        cols[n_ra - 1 - q, rng.random(T) < 0.4] = 0xFF
+    b["bool_cols"] = cols
+    # ---- stage 6a / 6b: a program-shaped PC column: the trace runs loops of 16 .. 512 instructions (a loop body holds most of the cycles), with a tail of unmapped
+    # padding cycles (push_pc 0 in the address phase, cold in the cycle phase)
+    rng = gen(6)
+    bc = p["bytecode"]
+    Kb, pcs, j = 1 << bc["log_k"], np.zeros(T, dtype=np.uint64), 0
     while j < T:
         body = int(rng.integers(min(16, Kb), min(512, Kb) + 1))
         start = int(rng.integers(0, Kb - body + 1))
@@ -210,13 +246,49 @@ def build_extended(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_cou
     mapped = rng.random(T) >= 0.01
     mapped[T - T // 32:] = False
     mapped[0] = True
-    chunk_bits = 4
-    n_chunks = (log_kb + chunk_bits - 1) // chunk_bits
-    chunk_cols = np.stack([np.where(mapped, (pcs >> np.uint64((n_chunks - 1 - i) * chunk_bits)) & np.uint64(15), 0xFF).astype(np.uint8) for i in range(n_chunks)])
-    d["bytecode"] = dict(log_k=log_kb, push_pc=np.where(mapped, pcs, 0).astype(np.uint64), mapped=mapped, chunk_bits=chunk_bits, chunk_cols=chunk_cols,
-                         stage_points=np.stack([rand_fr(n_vars, rng) for _ in range(5)]) if n_vars else np.zeros((5, 0, 4), dtype=np.uint64),
-                         stage_values=rand_fr(5 * Kb, rng).reshape(5, Kb, 4), gamma=rand_fr(1, rng)[0], entry_index=int(rng.integers(0, Kb)))
+    chunk_bits = bc["chunk_bits"]
+    n_chunks = (bc["log_k"] + chunk_bits - 1) // chunk_bits
+    b["bytecode"] = dict(push_pc=np.where(mapped, pcs, 0).astype(np.uint64), mapped=mapped,
+                         chunk_cols=np.stack([np.where(mapped, (pcs >> np.uint64((n_chunks - 1 - i) * chunk_bits)) & np.uint64(15), 0xFF).astype(np.uint8) for i in range(n_chunks)]))
+    return b
+
+
+def assemble_description(p, blocks):
+    """The description DeviceExtended / OracleExtended take, over the concatenation of `blocks` (one block: a plain single-process trace)."""
+    cat = lambda f: np.concatenate([f(b) for b in blocks]) if len(blocks) > 1 else f(blocks[0])
+    cat1 = lambda f: np.concatenate([f(b) for b in blocks], axis=1) if len(blocks) > 1 else f(blocks[0])
+    d = {k: p[k] for k in ("n_vars", "outer_iwa", "outer_iwb", "outer_tau", "outer_kernel", "outer_wa", "outer_wb", "product_tau", "product_kernel", "product_w", "ram_tau", "ram_gamma",
+                           "registers_r_cycle", "registers_gamma", "lookup_gamma", "lookup_reduction", "ra_count", "hamming", "ram_raf", "ram_output")}
+    d["outer_cols"] = [cat(lambda b, v=v: b["outer_cols"][v]) for v in range(p["n_outer"])]
+    d["product_rows"] = {k: cat(lambda b, k=k: b["product_rows"][k]) for k in blocks[0]["product_rows"]}
+    n_block = blocks[0]["ram"]["log_t"]
+    log_t = n_block + (len(blocks).bit_length() - 1)
+    d["ram"] = dict(log_k=p["ram_log_k"], log_t=log_t, val_init=blocks[0]["ram"]["val_init"], val_final=blocks[-1]["ram"]["val_final"],
+                    **{k: cat(lambda b, k=k: b["ram"][k]) for k in ("addresses", "pre", "post", "inc")})
+    d["registers"] = dict(log_k=7, log_t=log_t, **{k: cat(lambda b, k=k: b["registers"][k]) for k in ("rs1", "rs1_val", "rs2", "rs2_val", "rd", "rd_pre", "rd_post")})
+    d["lookup"] = dict(n_tables=N_LOOKUP_TABLES, present=p["lookup_present"], **{k: cat(lambda b, k=k: b["lookup"][k]) for k in ("idx", "table", "raf")})
+    d["booleanity"] = dict(cols=cat1(lambda b: b["bool_cols"]), **p["booleanity"])
+    d["bytecode"] = dict(push_pc=cat(lambda b: b["bytecode"]["push_pc"]), mapped=cat(lambda b: b["bytecode"]["mapped"]), chunk_cols=cat1(lambda b: b["bytecode"]["chunk_cols"]),
+                         **p["bytecode"])
     return d
+
+
+def build_blocks(p, n_block, n_blocks, seed=2026):
+    blocks, ram, reg = [], None, None
+    for g in range(n_blocks):
+        b = extended_block(p, n_block, g, seed, ram_init=ram, reg_init=reg)
+        ram, reg = b["ram"]["val_final"], b["registers"]["reg_final"]
+        blocks.append(b)
+    return blocks
+
+
+def build_extended(n_vars, seed=2026, n_blocks=1, **kw):
+    """The description of a trace of T = 2^n_vars cycles as the concatenation of n_blocks (a power of two) blocks: n_blocks = 1 is the single-process trace,
+    n_blocks = G the trace a G-rank sharded prover proves (rank g holds block g; jolt_amd/stages_sharded.py) -- the global oracle twin of that run takes this."""
+    log_b = n_blocks.bit_length() - 1
+    assert (1 << log_b) == n_blocks and log_b <= n_vars
+    p = extended_params(n_vars, seed, **kw)
+    return assemble_description(p, build_blocks(p, n_vars - log_b, n_blocks, seed))
 
 
 def committed_address_chunks(r_address, chunk_bits):
@@ -242,7 +314,7 @@ def bytecode_read_raf(ops, bc, n_vars, label):
     V = [ops.upload(bc["stage_values"][s]) for s in range(5)]
     hot = np.zeros(K, dtype=np.uint64)
     entry_trace, entry_expected = hot.copy(), hot.copy()
-    entry_trace[int(bc["push_pc"][0])] = 1
+    entry_trace[int(bc["first_pc"]) if "first_pc" in bc else int(bc["push_pc"][0])] = 1  # the PC of the trace's first cycle (a sharded prover's rank > 0 is told it)
     entry_expected[bc["entry_index"]] = 1
     tables = F + V + [ops.u64_table(np.arange(K, dtype=np.uint64)), ops.u64_table(entry_trace), ops.u64_table(entry_expected)]
     terms = [(gp[s], [s, 5 + s]) for s in range(5)] + [(gp[5], [0, 10]), (gp[6], [2, 10]), (gp[7], [11, 12])]  # stage_weights * raf_weights: g^0 g^5, g^2 g^4 (:303-311)
@@ -270,11 +342,9 @@ def bytecode_read_raf(ops, bc, n_vars, label):
     for t in eqs + [spike]:
         ops.free(t)
     n_f = 1 + len(ra)
-    member = ops.member_expr([combined] + ra, [(ops.one, list(range(n_f)))], n_f)
-    claim_c = member.input_claim()
-    cyc = ops.prove(member, claim_c, n_vars, n_f, label + 1)
-    ra_claims = ops.final_values(member)[1:]
-    ops.destroy(member)
+    # the one T-sized member of the relation: a sharded prover proves it over the ranks' blocks of cycles (cycle_product), everyone else as a plain dense member
+    cyc, claim_c, fin_c = ops.cycle_product([combined] + ra, n_vars, label + 1)
+    ra_claims = fin_c[1:]
     return dict(address=adr, claim_address=claim_a, intermediate=intermediate, val_stages=np.stack(fin[5:10]), r_address=r_address, cycle=cyc, claim_cycle=claim_c,
                 ra_claims=np.stack(ra_claims))
 
@@ -438,6 +508,16 @@ class DeviceOps:
 
     def member_gruen_product(self, a, b, w):
         return self.ctx.member_split_eq_product(a, b, w)
+
+    def cycle_product(self, tables, n_vars, label):
+        """sum_j prod_i tables[i](j) over the cycle domain: (transcript, input claim, final values)"""
+        n_f = len(tables)
+        member = self.member_expr(tables, [(self.one, list(range(n_f)))], n_f)
+        claim = member.input_claim()
+        out = self.prove(member, claim, n_vars, n_f, label)
+        fin = self.final_values(member)
+        self.destroy(member)
+        return out, claim, fin
 
     def prove(self, member, claim, n_vars, degree, label):
         out = self.ctx.prove_batch([member], [claim], [self.one], [0], n_vars, degree, label=label)

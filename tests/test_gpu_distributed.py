@@ -346,3 +346,51 @@ def test_native_rccl_with_two_ranks_on_one_device_is_refused_or_works_but_never_
     with open(os.path.join(keep, "rccl_two_ranks_one_device.txt"), "w") as f:
         f.write("\n".join(outcomes) + "\n")
     assert all(o.startswith(("refused", "all-gather ok")) for o in outcomes), outcomes
+
+
+def _extended_worker(rank, world, port, tmpdir, n_local, kw):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import pickle
+    from util import init_gloo
+    dist = init_gloo(rank, world, port, seconds=300)
+    from jolt_amd import distributed as D
+    from jolt_amd import ffi
+    from jolt_amd.stages_sharded import ShardedExtended
+    ctx = ffi.Context(0)
+    coll = D.Collective(dist, world, None)
+    ext = ShardedExtended(ctx, n_local, rank, world, coll, seed=77, **kw)
+    outs = [ext.prove(label=40), ext.prove(label=40)]  # a second proof over the resident inputs: same bytes
+    with open(os.path.join(tmpdir, f"got{rank}.pkl"), "wb") as f:
+        pickle.dump(dict(outs=outs, claims=ext.claims), f)
+    ext.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_local,kw", [(2, 6, dict(n_tables=8, log_k=5, log_kb=5)), (4, 5, dict(n_tables=6, log_k=4, log_kb=4)), (2, 10, dict(n_tables=12, log_k=8)),
+                                              (1, 6, dict(n_tables=5, log_k=4))])
+def test_sharded_stage_operators_prove_one_trace(world, n_local, kw):
+    """The stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators over ONE trace of world * 2^n_local cycles dealt to `world` ranks (jolt_amd/stages_sharded.py; all ranks on GPU 0,
+    gloo standing in for RCCL): every rank's messages -- uni-skip sums, every round polynomial of every operator (the sparse matrices' local, merged-cycle and address
+    rounds, the 128 read-RAF address rounds, the sharded cycle phases), challenges, claims, final values -- equal the single-process oracle twin of the GLOBAL trace."""
+    import pickle
+    import torch.multiprocessing as mp
+    from jolt_amd import stages as S
+    from test_gpu_extended import same
+    from workload_oracle import OracleExtended
+    port = free_port()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_extended_worker, args=(world, port, tmp, n_local, kw), nprocs=world, join=True)
+        got = [pickle.load(open(os.path.join(tmp, f"got{r}.pkl"), "rb")) for r in range(world)]
+    n_total = n_local + world.bit_length() - 1
+    want = OracleExtended(n_total, description=S.build_extended(n_total, seed=77, n_blocks=world, **kw)).prove(label=40)
+    address_domain = {"bytecode_read_raf", "ram_raf_evaluation", "ram_output_check", "hamming_weight"}
+    claim_key = {"spartan_outer": "outer", "spartan_product": "product", "ram_read_write": "ram", "registers_read_write": "registers", "instruction_read_raf": "lookup"}
+    for r in range(world):
+        for p, out in enumerate(got[r]["outs"]):
+            assert set(out) == set(want)
+            for name in out:
+                if name in claim_key:
+                    assert np.array_equal(got[r]["claims"][claim_key[name]], want[name]["claim"]), (r, name)
+                same(out[name], {k: v for k, v in want[name].items() if k != "claim" or name in address_domain}, f"rank {r} proof {p} {name}")

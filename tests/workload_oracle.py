@@ -119,6 +119,15 @@ class OracleOps:
     def member_gruen_product(self, a, b, w):
         return O.Member.gruen_product(a, b, w)
 
+    def cycle_product(self, tables, n_vars, label):
+        n_f = len(tables)
+        member = self.member_expr(tables, [(self.one, list(range(n_f)))], n_f)
+        claim = member.input_claim()
+        out = self.prove(member, claim, n_vars, n_f, label)
+        fin = self.final_values(member)
+        self.destroy(member)
+        return out, claim, fin
+
     def prove(self, member, claim, n_vars, degree, label):
         out = O.prove_batch([member], [claim], [self.one], [0], n_vars, degree, label=label)
         return dict(polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
