@@ -292,10 +292,10 @@ def main():
 
         ext = None
         if args.stages == "all":
-            # The stage 1 / 2 / 5 operators have no cross-rank form yet: every rank proves them over ITS block of cycles as an independent
-            # sub-trace (replicas: the same work per GPU as the N = 1 step, no exchange), stated in config.workload
-            from jolt_amd.stages import DeviceExtended
-            ext = DeviceExtended(ctx, args.scale, seed=2026 + 7919 * rank)
+            # the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators over ONE trace of world * 2^scale cycles dealt to the ranks in blocks (jolt_amd/stages_sharded.py): additive
+            # scans / pushforwards summed over the ranks, sharded cycle-domain batches, replicated K-sized rounds, sparse matrices with local cycle rounds + merged rows
+            from jolt_amd.stages_sharded import ShardedExtended
+            ext = ShardedExtended(ctx, args.scale, rank, world, wl.coll, tail_log=wl.tail_log, round_exchange=wl.round_exchange)
 
         def step(label=0):  # the same legs as the N = 1 step (DeviceWorkload.step): prepare, commit, extended operators, prove, open
             wl.prepare()
@@ -346,8 +346,12 @@ def main():
         if args.round_exchange == "both" and shm is not None and world > 1:  # the exchange that is NOT reported as `value`, timed first
             other = "shm" if primary == "rccl" else "rccl"
             wl.round_exchange = shm if other == "shm" else None
+            if ext is not None:
+                ext.round_exchange = wl.round_exchange
             exchange_ab = {other: round(timed(args.steps, args.warmup, 50000) / args.steps * 1e3, 3)}
         wl.round_exchange = shm if primary == "shm" else None
+        if ext is not None:
+            ext.round_exchange = wl.round_exchange
     dt = timed(args.steps, args.warmup, 0)
     if exchange_ab is not None:
         exchange_ab[primary] = round(dt / args.steps * 1e3, 3)
@@ -383,13 +387,15 @@ def main():
     ext_note = ""
     the_ext = ext if sharded else wl.ext
     if the_ext is not None:
-        ram = the_ext.d["ram"]
+        ram = the_ext.d["ram"] if hasattr(the_ext, "d") else {"log_k": the_ext.p["ram_log_k"]}
+        bc_log_k = the_ext.d["bytecode"]["log_k"] if hasattr(the_ext, "d") else the_ext.p["bytecode"]["log_k"]
         ext_note = (f"runs the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators outside the cycle-domain catalogue -- Spartan outer (uni-skip sums off 35 integer columns, Az / Bz, log T + 1 "
                     f"remainder rounds, claimed inputs), Spartan product (the same over the 6 product lanes), the sparse RAM read-write matrix (K = 2^{ram['log_k']}, "
                     f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and instruction read-RAF checking end to end over the 42 lookup tables (per address phase the T-scale scans on the device and the 8 rounds over 256-entry prefix / suffix polynomials on the host, 128 address rounds in all, then log T cycle rounds), the booleanity address phase and the Hamming-weight claim reduction (pushforward masses of the 36 RA columns + log K host rounds each), and the address-domain relations -- bytecode read+RAF (five per-stage "
-                    f"pushforwards onto the 2^{the_ext.d['bytecode']['log_k']}-entry bytecode domain + log K rounds, then C * prod ra_i over log T rounds), RAM RAF evaluation and the RAM output check "
+                    f"pushforwards onto the 2^{bc_log_k}-entry bytecode domain + log K rounds, then C * prod ra_i over log T rounds), RAM RAF evaluation and the RAM output check "
                     f"(pushforward / final-memory column over a sorted index of the address column + log K rounds each)"
-                    + (" (per-rank replicas over each rank's block of cycles: these operators have no cross-rank form yet)" if sharded else "") + " -- ")
+                    + (f" (ONE trace of {world} x 2^{args.scale} cycles dealt to the ranks in blocks: additive scans and pushforwards summed over the ranks, cycle-domain "
+                       f"sumchecks sharded like the catalogue's, K-sized rounds replicated, the sparse matrices' rows merged after the local cycle rounds)" if sharded else "") + " -- ")
     if pcs and sharded:
         what = (f"BASELINE configs[2] sharded over {world} GPU(s): sha3-shaped synthetic trace of {world} x 2^{args.scale} cycles, sumcheck + HyperKZG end-to-end -- "
                 f"every step commits the {n_onehot + 2} committed columns on the 2^{pcs_sharded.grid_vars} commitment grid (each rank its block of cycles, one all-gather of "
