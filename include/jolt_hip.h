@@ -355,6 +355,7 @@ int32_t jolt_host_pair_tables_bind(jolt_fr_t *g, jolt_fr_t *w, size_t n_polys, s
 typedef struct jolt_host_transcript jolt_host_transcript;
 int32_t jolt_host_transcript_create(uint64_t label, jolt_host_transcript **out);
 int32_t jolt_host_transcript_append_fr(jolt_host_transcript *t, const jolt_fr_t *values, size_t count); /* canonical 32-byte LE each */
+int32_t jolt_host_transcript_append_bytes(jolt_host_transcript *t, const uint8_t *bytes, size_t count); /* e.g. a compressed G1 point (32 bytes) */
 int32_t jolt_host_transcript_challenge(jolt_host_transcript *t, int32_t full_width, jolt_fr_t *out);    /* 0: 125-bit challenge shape */
 int32_t jolt_host_transcript_destroy(jolt_host_transcript *t);
 /* G1 helpers on the host: group law, equality as points, compressed serialisation
@@ -743,6 +744,17 @@ int32_t jolt_round_group_final_values(jolt_ctx *ctx, jolt_member *const *members
 int32_t jolt_host_hyperkzg_commit(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, jolt_g1_t *out);
 int32_t jolt_host_hyperkzg_open(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
                                 uint64_t transcript_label, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
+
+/* The same opening under the CALLER's Fiat-Shamir transcript -- CommitmentScheme::open(poly, point, eval, setup, hint, transcript) (crates/jolt-openings/src/
+ * schemes.rs:66-72; impl crates/jolt-hyperkzg/src/scheme.rs:314-325) with the polynomial resident in HBM.  `fn` is called three times per opening, in order:
+ *   phase 0: points = the ell - 1 level commitments (scheme.rs:148-152)        -> challenge r
+ *   phase 1: values = v[t][j], 3 * ell field elements row-major (kzg.rs:88-95) -> challenge q
+ *   phase 2: points = the three witness commitments (kzg.rs:118-124)            -> challenge d_0
+ * it absorbs them (transcript.append per element, in order) and returns the challenge; a non-zero return aborts the opening with that status. */
+typedef int32_t (*jolt_open_transcript_fn)(void *user, int32_t phase, const jolt_g1_t *points, size_t n_points, const jolt_fr_t *values, size_t n_values,
+                                           jolt_fr_t *challenge_out);
+int32_t jolt_host_hyperkzg_open_with_transcript(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
+                                                jolt_open_transcript_fn fn, void *user, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
 
 /* Term-range pieces of a commitment / opening sharded over the ranks of a node (the reference is single
  * process): an MSM of n terms against srs[base_offset .. base_offset + n) with the scalars scalars[scalar_offset ..]; the partial

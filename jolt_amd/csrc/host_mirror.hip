@@ -692,6 +692,11 @@ extern "C" int32_t jolt_host_transcript_append_fr(jolt_host_transcript* t, const
     }
     return JOLT_OK;
 }
+extern "C" int32_t jolt_host_transcript_append_bytes(jolt_host_transcript* t, const uint8_t* bytes, size_t count) {
+    if (!t || (!bytes && count)) return JOLT_ERR_INVALID_ARG;
+    t->t.append_bytes(bytes, count);
+    return JOLT_OK;
+}
 extern "C" int32_t jolt_host_transcript_challenge(jolt_host_transcript* t, int32_t full_width, jolt_fr_t* out) {
     if (!t || !out) return JOLT_ERR_INVALID_ARG;
     fr_to_abi(out, full_width ? t->t.challenge_scalar() : t->t.challenge());

@@ -375,14 +375,49 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
     return JOLT_OK;
 }
 
+// The opening's Fiat-Shamir: the library's test transcript, or the CALLER's (jolt_open_transcript_fn: the reference's Blake2b / Keccak transcript stays in Rust).
+// Three absorb-then-challenge steps: the level commitments -> r (scheme.rs:148-152), the 3 ell evaluations -> q (kzg.rs:88-95), the three witness
+// commitments -> d_0 (kzg.rs:118-124).
+namespace {
+struct OpenTranscript {
+    MockTranscript mock;
+    jolt_open_transcript_fn fn;
+    void* user;
+    int32_t after_points(int32_t phase, const G1Jac* pts, size_t n, Fr* out) {
+        if (!fn) {
+            for (size_t i = 0; i < n; ++i) append_g1(mock, pts[i]);
+            *out = mock.challenge();
+            return JOLT_OK;
+        }
+        static_assert(sizeof(G1Jac) == sizeof(jolt_g1_t), "a Jacobian point crosses the ABI as it lies in memory");
+        jolt_fr_t ch;
+        JOLT_TRY(fn(user, phase, reinterpret_cast<const jolt_g1_t*>(pts), n, nullptr, 0, &ch));
+        *out = fr_from_abi(&ch);
+        return fr_is_canonical(*out) ? JOLT_OK : JOLT_ERR_INVALID_ARG;
+    }
+    int32_t after_values(int32_t phase, const jolt_fr_t* vals, size_t n, Fr* out) {
+        if (!fn) {
+            for (size_t i = 0; i < n; ++i) mock.append_fr(fr_from_abi(&vals[i]));
+            *out = mock.challenge();
+            return JOLT_OK;
+        }
+        jolt_fr_t ch;
+        JOLT_TRY(fn(user, phase, nullptr, 0, vals, n, &ch));
+        *out = fr_from_abi(&ch);
+        return fr_is_canonical(*out) ? JOLT_OK : JOLT_ERR_INVALID_ARG;
+    }
+};
+}  // namespace
+
 // HyperKZGScheme::open (scheme.rs:122-158) + kzg_open_batch (kzg.rs:69-126)
 static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell, uint64_t transcript_label,
-                                  int rank, int world, size_t block, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+                                  int rank, int world, size_t block, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out,
+                                  jolt_open_transcript_fn transcript_fn = nullptr, void* transcript_user = nullptr) {
     if (!ctx || !srs || !evals || !point || !w || !v || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     if (ell == 0) return JOLT_ERR_EMPTY_POINT;
     if (ell > 40) return JOLT_ERR_UNSUPPORTED;
-    MockTranscript tr(transcript_label);
+    OpenTranscript tr{MockTranscript(transcript_label), transcript_fn, transcript_user};
     std::vector<jolt_table*> polys(ell, nullptr);
     auto cleanup = [&](jolt_table* extra1 = nullptr, jolt_table* extra2 = nullptr) {
         for (jolt_table* t : polys) if (t) jolt_table_free(ctx, t);
@@ -401,16 +436,17 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         ctx->msm_full_width_scalars = false;
         if (s != JOLT_OK) { cleanup(); return s; }
     }
-    for (const G1Jac& c : coms) append_g1(tr, c);  // phase 2 (scheme.rs:148-152)
-    Fr r = tr.challenge();
+    Fr r;  // phase 2 (scheme.rs:148-152)
+    s = tr.after_points(0, coms.data(), coms.size(), &r);
+    if (s != JOLT_OK) { cleanup(); return s; }
     Fr u[3] = {r, neg(r), mul(r, r)};
     jolt_fr_t u_abi[3];
     for (int t = 0; t < 3; ++t) fr_to_abi(&u_abi[t], u[t]);
     s = jolt_hyperkzg_eval3(ctx, polys.data(), ell, u_abi, v);  // kzg.rs:84-85
     if (s != JOLT_OK) { cleanup(); return s; }
-    for (int t = 0; t < 3; ++t)
-        for (size_t j = 0; j < ell; ++j) tr.append_fr(fr_from_abi(&v[(size_t)t * ell + j]));  // kzg.rs:88-92
-    Fr q = tr.challenge();
+    Fr q;  // kzg.rs:88-95: every v[t][j], row-major
+    s = tr.after_values(1, v, 3 * ell, &q);
+    if (s != JOLT_OK) { cleanup(); return s; }
     jolt_fr_t q_abi;
     fr_to_abi(&q_abi, q);
     jolt_table* b_poly = nullptr;
@@ -467,8 +503,9 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         for (int t = 0; t < 3; ++t) if (h[t]) jolt_table_free(ctx, h[t]);
         if (s != JOLT_OK) { cleanup(b_poly); return s; }
     }
-    for (int t = 0; t < 3; ++t) append_g1(tr, ws[t]);  // kzg.rs:118-124
-    Fr d0 = tr.challenge();
+    Fr d0;  // kzg.rs:118-124
+    s = tr.after_points(2, ws, 3, &d0);
+    if (s != JOLT_OK) { cleanup(b_poly); return s; }
     for (size_t i = 0; i + 1 < ell; ++i) std::memcpy(&com[i], &coms[i], sizeof(G1Jac));
     for (int t = 0; t < 3; ++t) std::memcpy(&w[t], &ws[t], sizeof(G1Jac));
     if (challenges_out) { fr_to_abi(&challenges_out[0], r); fr_to_abi(&challenges_out[1], q); fr_to_abi(&challenges_out[2], d0); }
@@ -753,6 +790,14 @@ extern "C" int32_t jolt_host_hyperkzg_open(jolt_ctx* ctx, const jolt_srs* srs, c
                                            uint64_t transcript_label, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
     return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out);
 }
+// The same opening under the CALLER's transcript (CommitmentScheme::open takes `transcript: &mut impl Transcript`, crates/jolt-openings/src/schemes.rs:66-72): `fn`
+// absorbs what the prover sends at each of the three steps and returns the challenge drawn after it.
+extern "C" int32_t jolt_host_hyperkzg_open_with_transcript(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                                           jolt_open_transcript_fn fn, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    if (!fn) return JOLT_ERR_INVALID_ARG;
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, 0, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out, fn, user);
+}
+
 
 // The same opening with its MSMs sharded over `world` ranks by term range (every rank holds the polynomial and the SRS; `gather` is a
 // jolt_gather_fn moving world x count 32-byte words -- jolt_comm_gather_round_sums / jolt_shm_gather_round_sums fit).  Every rank

@@ -352,8 +352,11 @@ extern "C" int32_t jolt_r1cs_uniskip_sums_small(jolt_ctx* ctx, const jolt_ints* 
     int32_t s = upload_bytes(ctx, b_weights, wcount * sizeof(int64_t), (void**)&wb);
     if (s != JOLT_OK) { jolt_internal_dev_free(ctx, wa); return s; }
     int grid = (int)std::max<size_t>(1, std::min<size_t>((cycles + kBlock - 1) / kBlock, (size_t)ctx->num_cus * 4));
-    // all nodes per workgroup, columns read once (k_small_uniskip_all): the node counts of the two callers; JOLT_UNISKIP_ALL=0 keeps the per-node kernel for an A/B
-    static const bool all_enabled = !(std::getenv("JOLT_UNISKIP_ALL") && std::atoi(std::getenv("JOLT_UNISKIP_ALL")) == 0);
+    // all nodes per workgroup, columns read once (k_small_uniskip_all): the node counts of the two callers.  OFF by default: measured SLOWER at T = 2^22
+    // (profiles/r04_uniskip_all_nodes_ab.txt: Spartan outer 11.2 ms against 8.7 ms with the per-node kernel) -- nine unrolled node bodies at two wavefronts per SIMD
+    // lose more on the integer pipeline than the 8x smaller column traffic saves; the per-node kernel's XCD-neighbour numbering already serves most re-reads from L2.
+    // JOLT_UNISKIP_ALL=1 selects it for an A/B.
+    static const bool all_enabled = std::getenv("JOLT_UNISKIP_ALL") && std::atoi(std::getenv("JOLT_UNISKIP_ALL")) != 0;
     ColumnPlanes cp;
     size_t n_planes = 0;
     for (size_t v = 0; v < (size_t)kMaxSmallInputs; ++v) {

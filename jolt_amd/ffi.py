@@ -570,6 +570,10 @@ class HostTranscript:
         v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
         _ck(lib().jolt_host_transcript_append_fr(self.h, _p(v), C.c_size_t(v.shape[0])), "jolt_host_transcript_append_fr")
 
+    def append_bytes(self, data):
+        buf = (C.c_uint8 * len(data))(*data)
+        _ck(lib().jolt_host_transcript_append_bytes(self.h, buf, C.c_size_t(len(data))), "jolt_host_transcript_append_bytes")
+
     def challenge(self, full_width=False):
         o = fr_array(1)
         _ck(lib().jolt_host_transcript_challenge(self.h, C.c_int32(1 if full_width else 0), _p(o)), "jolt_host_transcript_challenge")
@@ -777,6 +781,40 @@ Context.hyperkzg_rlc = _hyperkzg_rlc
 Context.hyperkzg_witness_poly = _hyperkzg_witness_poly
 Context.hyperkzg_commit = _hyperkzg_commit
 Context.hyperkzg_open = _hyperkzg_open
+
+OPEN_TRANSCRIPT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def _hyperkzg_open_with_transcript(self, srs, evals, point, absorb_points, absorb_values, challenge):
+    """jolt_host_hyperkzg_open_with_transcript: the opening under the CALLER's transcript.  absorb_points((n, 12) Jacobian limbs) / absorb_values((n, 4)) absorb what
+    the prover sends at a step, challenge() -> (4,) draws the challenge after it (three steps: level commitments -> r, evaluations -> q, witness commitments -> d_0)."""
+    p = fr(point).reshape(-1, 4)
+    ell = p.shape[0]
+    com, w, v, ch = g1_array(max(ell - 1, 1)), g1_array(3), fr_array(3 * max(ell, 1)), fr_array(3)
+    err = []
+
+    def cb(user, phase, points, n_points, values, n_values, out):
+        try:
+            if n_points:
+                absorb_points(np.ctypeslib.as_array(C.cast(points, C.POINTER(C.c_uint64)), shape=(n_points, 12)).copy())
+            if n_values:
+                absorb_values(np.ctypeslib.as_array(C.cast(values, C.POINTER(C.c_uint64)), shape=(n_values, 4)).copy())
+            c = np.ascontiguousarray(challenge(), dtype=np.uint64).reshape(4)
+            C.memmove(out, c.ctypes.data, 32)
+            return 0
+        except Exception as e:  # never unwind through the C frame
+            err.append(e)
+            return 4
+
+    fn = OPEN_TRANSCRIPT_FN(cb)
+    st = lib().jolt_host_hyperkzg_open_with_transcript(self.h, srs.h, evals.h, _p(p), C.c_size_t(ell), fn, None, _p(com), _p(w), _p(v), _p(ch))
+    if err:
+        raise err[0]
+    _ck(st, "jolt_host_hyperkzg_open_with_transcript", self)
+    return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
+
+
+Context.hyperkzg_open_with_transcript = _hyperkzg_open_with_transcript
 
 
 def host_g1_add(p, q):

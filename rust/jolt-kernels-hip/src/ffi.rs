@@ -235,6 +235,7 @@ extern "C" {
     pub fn jolt_host_pair_tables_bind(g: *mut jolt_fr_t, w: *mut jolt_fr_t, n_polys: usize, stride: usize, len: usize, challenge: *const jolt_fr_t) -> i32;
     pub fn jolt_host_transcript_create(label: u64, out: *mut *mut jolt_host_transcript) -> i32;
     pub fn jolt_host_transcript_append_fr(t: *mut jolt_host_transcript, values: *const jolt_fr_t, count: usize) -> i32;
+    pub fn jolt_host_transcript_append_bytes(t: *mut jolt_host_transcript, bytes: *const u8, count: usize) -> i32;
     pub fn jolt_host_transcript_challenge(t: *mut jolt_host_transcript, full_width: i32, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_transcript_destroy(t: *mut jolt_host_transcript) -> i32;
     pub fn jolt_host_g1_add(p: *const jolt_g1_t, q: *const jolt_g1_t, out: *mut jolt_g1_t) -> i32;
@@ -323,6 +324,10 @@ extern "C" {
     pub fn jolt_key_index_pushforward(ctx: *mut jolt_ctx, index: *const jolt_key_index, weights: *const *mut jolt_table, n_weights: usize, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_key_index_last_value(ctx: *mut jolt_ctx, index: *const jolt_key_index, values: *const jolt_ints, init: *const jolt_table, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_key_index_destroy(ctx: *mut jolt_ctx, index: *mut jolt_key_index) -> i32;
+    pub fn jolt_rw_matrix_hold_row(m: *mut jolt_rw_matrix) -> i32;
+    pub fn jolt_rw_matrix_bind(m: *mut jolt_rw_matrix, bind: *const jolt_fr_t) -> i32;
+    pub fn jolt_rw_matrix_export_row(m: *mut jolt_rw_matrix, cap: usize, cols: *mut u64, prev: *mut u64, next: *mut u64, val: *mut jolt_fr_t, ra: *mut jolt_fr_t, wa: *mut jolt_fr_t, inc_out: *mut jolt_fr_t, scalar_out: *mut jolt_fr_t, n_out: *mut usize) -> i32;
+    pub fn jolt_rw_matrix_create_merged(ctx: *mut jolt_ctx, registers: i32, log_rows: usize, log_k: usize, n: usize, rows: *const u64, cols: *const u64, prev: *const u64, next: *const u64, val: *const jolt_fr_t, ra: *const jolt_fr_t, wa: *const jolt_fr_t, inc: *const jolt_fr_t, val_init: *const jolt_table, w: *const jolt_fr_t, scalar: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_rw_matrix) -> i32;
     pub fn jolt_rw_matrix_len(m: *const jolt_rw_matrix, entries: *mut usize) -> i32;
     pub fn jolt_rw_matrix_download(m: *mut jolt_rw_matrix, rows: *mut u64, cols: *mut u64, val: *mut jolt_fr_t, ra: *mut jolt_fr_t, prev: *mut jolt_fr_t, next: *mut jolt_fr_t) -> i32;
     pub fn jolt_rw_matrix_destroy(m: *mut jolt_rw_matrix) -> i32;
@@ -344,6 +349,7 @@ extern "C" {
     pub fn jolt_round_group_final_values(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, out: *mut jolt_fr_t, capacity: usize) -> i32;
     pub fn jolt_host_hyperkzg_commit(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_hyperkzg_open_with_transcript(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, r#fn: jolt_open_transcript_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_msm_g1_table_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, base_offset: usize, scalars: *const jolt_table, scalar_offset: usize, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_commit_onehot_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, cycle_lo: usize, cycle_hi: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open_sharded(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;

@@ -208,3 +208,36 @@ def test_pool_reuses_and_trims(ctx):
     t2.free()
     ctx.trim()
     assert ctx.memory_stats()["cached_bytes"] == 0
+
+
+@pytest.mark.parametrize("ell", [1, 2, 7, 13])
+def test_open_under_the_callers_transcript(ctx, ell):
+    """jolt_host_hyperkzg_open_with_transcript (CommitmentScheme::open's `transcript: &mut impl Transcript`, crates/jolt-openings/src/schemes.rs:66-72): the caller's
+    hook absorbs the level commitments, the 3 ell evaluations and the witness commitments and returns r, q, d_0.  Driven with the library's own test transcript from
+    the outside it must give the proof of jolt_host_hyperkzg_open with the same label -- and the absorbed data must be exactly the proof's fields, in order."""
+    beta = rand_fr(1, 900 + ell)[0]
+    srs = ctx.srs_setup_from_secret(beta, 1 << ell, G1_GENERATOR)
+    poly = ctx.upload(rand_fr(1 << ell, 901 + ell))
+    point = rand_fr(ell, 902 + ell)
+    want = ctx.hyperkzg_open(srs, poly, point, label=77)
+    tr = ffi.HostTranscript(77)
+    seen = {"points": [], "values": []}
+
+    def absorb_points(pts):
+        seen["points"].append(pts)
+        for p in pts:
+            tr.append_bytes(ffi.host_g1_serialize_compressed(p))
+
+    def absorb_values(vals):
+        seen["values"].append(vals)
+        tr.append(vals)
+
+    got = ctx.hyperkzg_open_with_transcript(srs, poly, point, absorb_points, absorb_values, tr.challenge)
+    for key in ("v", "challenges"):
+        assert np.array_equal(got[key], want[key]), key
+    assert all(same_point(got["com"][i], want["com"][i]) for i in range(ell - 1)) and all(same_point(got["w"][t], want["w"][t]) for t in range(3))
+    assert len(seen["values"]) == 1 and np.array_equal(seen["values"][0], got["v"].reshape(-1, 4))
+    assert sum(p.shape[0] for p in seen["points"]) == (ell - 1) + 3
+    tr.close()
+    poly.free()
+    srs.free()
