@@ -115,6 +115,14 @@ impl HipTable {
         Ok(out)
     }
 
+    /// `Polynomial::evaluate` on the device (`jolt_table_evaluate`: one eq expansion, one dot product).
+    pub fn evaluate(&self, point: &[Fr]) -> Result<Fr, HipError> {
+        let mut out = Fr::default();
+        // SAFETY: live handles; `point` holds `point.len()` field elements, `out` one.
+        check(unsafe { ffi::jolt_table_evaluate(self.ctx.raw, self.raw, point.as_ptr().cast(), point.len(), (&mut out as *mut Fr).cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+
     /// Hand the handle to a member that takes ownership (`jolt_member_create_expr`): the table is then freed with the member.
     pub(crate) fn into_raw(self) -> *mut ffi::jolt_table {
         let raw = self.raw;

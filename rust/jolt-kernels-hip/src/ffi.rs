@@ -144,6 +144,9 @@ pub type jolt_local_round_fn = Option<
 >;
 pub type jolt_gather_fn = Option<unsafe extern "C" fn(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32>;
 pub type jolt_round_transcript_fn = Option<unsafe extern "C" fn(user: *mut c_void, compressed_coeffs: *const jolt_fr_t, n_coeffs: usize, challenge_out: *mut jolt_fr_t) -> i32>;
+pub type jolt_open_transcript_fn = Option<
+    unsafe extern "C" fn(user: *mut c_void, phase: i32, points: *const jolt_g1_t, n_points: usize, values: *const jolt_fr_t, n_values: usize, challenge_out: *mut jolt_fr_t) -> i32,
+>;
 
 #[link(name = "jolt_hip")]
 extern "C" {

@@ -12,6 +12,8 @@
 //! | `JoltGroup::msm` for `Bn254G1` (`crates/jolt-crypto/src/ec/group.rs:63-70`) | [`msm::msm_g1`] |
 //! | `optimized::{spartan_outer, spartan_product, ram_read_write, instruction_read_raf}` T-scale loops | [`ops::SpartanSums`], [`ops::HipRwMatrix`], [`ops::HipReadRaf`] |
 //! | HyperKZG prover pieces (`crates/jolt-hyperkzg/src/{kzg,scheme}.rs`) | [`msm::HipSrs`], `ffi::jolt_hyperkzg_*` |
+//! | `CommitmentScheme` + `AdditivelyHomomorphic` for HyperKZG (`crates/jolt-openings/src/schemes.rs:43-163`, `crates/jolt-hyperkzg/src/scheme.rs:275-353`) | [`pcs::HipHyperKzg`] over device-resident [`pcs::HipPoly`]s, the caller's transcript through `jolt_open_transcript_fn` |
+//! | `UniskipKernel`, `CommitWitness`, the backend constructor (`crates/jolt-kernels/src/{uniskip.rs:28-54, commitment.rs:137-160, optimized/mod.rs:136-196}`) | [`backend::HipUniskip`], [`backend::HipCommitWitness`], [`backend::mi355x`] |
 //!
 //! Host code stays Rust: Fiat-Shamir, claim wiring, round-polynomial assembly (`UnivariatePoly::from_evals`,
 //! `gruen_poly_deg_3`) and error types are the reference's; only table-sized work crosses the boundary, and per round only
@@ -23,6 +25,8 @@ pub mod context;
 pub mod member;
 pub mod msm;
 pub mod ops;
+pub mod pcs;
+pub mod backend;
 pub mod scheduler;
 pub mod status;
 
@@ -30,5 +34,7 @@ pub use context::{HipContext, HipTable};
 pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape};
 pub use msm::{msm_cache_clear, msm_cache_evict, msm_g1, HipShardedOpening, HipSrs, SharedMsmContext};
 pub use ops::{HipHotIndices, HipInts, HipKeyIndex, HipReadRaf, HipRegistersRw, HipRwMatrix, SpartanSums};
+pub use backend::{mi355x, with_relation, HipCommitWitness, HipUniskip, Mi355xParts, NodeWeights};
+pub use pcs::{HipHyperKzg, HipHyperKzgSetup, HipPoly};
 pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
 pub use status::HipError;

@@ -20,7 +20,7 @@ use crate::status::{check, HipError};
 /// `jolt_srs`: affine bases resident in HBM (+ optional fixed-base window tables).
 pub struct HipSrs {
     ctx: Arc<HipContext>,
-    raw: *mut ffi::jolt_srs,
+    pub(crate) raw: *mut ffi::jolt_srs,
     len: usize,
 }
 

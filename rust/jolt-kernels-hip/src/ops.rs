@@ -169,6 +169,7 @@ impl Drop for HipRwMatrix {
 pub struct HipHotIndices {
     ctx: Arc<HipContext>,
     pub(crate) raw: *mut ffi::jolt_onehot,
+    n_columns: usize,
 }
 // SAFETY: see HipContext.
 unsafe impl Send for HipHotIndices {}
@@ -179,7 +180,16 @@ impl HipHotIndices {
         let mut raw = ptr::null_mut();
         // SAFETY: `indices` holds n_columns * cycles bytes; the upload is synchronous.
         check(unsafe { ffi::jolt_onehot_upload(ctx.raw, indices.as_ptr(), n_columns, cycles, k, &mut raw) }, ctx.raw)?;
-        Ok(Self { ctx: Arc::clone(ctx), raw })
+        Ok(Self { ctx: Arc::clone(ctx), raw, n_columns })
+    }
+
+    /// `kzg_commit` of every column as a 0/1 polynomial on the K x T commitment grid (`jolt_grid_commit_onehot`: the sum of the T bases a
+    /// column selects, no scalars; `crates/jolt-hyperkzg/src/kzg.rs:15-27` over `TracePlacement` cycle-major, `optimized/opening.rs:340-372`).
+    pub fn grid_commit(&self, srs: &crate::msm::HipSrs) -> Result<Vec<jolt_crypto::Bn254G1>, HipError> {
+        let mut out = vec![jolt_crypto::Bn254G1::default(); self.n_columns];
+        // SAFETY: live handles of one context; `out` holds one jolt_g1_t per column.
+        check(unsafe { ffi::jolt_grid_commit_onehot(self.ctx.raw, srs.raw, self.raw, out.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok(out)
     }
 }
 impl Drop for HipHotIndices {

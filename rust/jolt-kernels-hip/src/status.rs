@@ -19,6 +19,11 @@ pub struct HipError {
 impl HipError {
     /// `Unsupported`-class statuses are recoverable: the caller falls back to another backend's slot
     /// (`crates/jolt-kernels/src/optimized/mod.rs:136-196` composes backends slot by slot).
+    /// A shape the wrapper rejects before calling into the library.
+    pub fn size_mismatch(what: &'static str) -> Self {
+        Self { status: ffi::JOLT_ERR_SIZE_MISMATCH, name: "JOLT_ERR_SIZE_MISMATCH", detail: what.to_owned() }
+    }
+
     pub fn is_recoverable(&self) -> bool {
         matches!(self.status, ffi::JOLT_ERR_NO_DEVICE | ffi::JOLT_ERR_OOM | ffi::JOLT_ERR_UNSUPPORTED)
     }

@@ -163,8 +163,54 @@ def test_rust_ffi_crate_agrees_with_the_header():
     assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0
     # every declared symbol is also what the shared library exports (the other half is test_library_exports_every_declared_symbol)
     lib_rs = open(os.path.join(root, "rust", "jolt-kernels-hip", "src", "lib.rs")).read()
-    for module in ("context", "member", "msm", "scheduler", "status", "ffi"):
+    for module in ("context", "member", "msm", "scheduler", "status", "ffi", "ops", "pcs", "backend"):
         assert f"pub mod {module};" in lib_rs and os.path.exists(os.path.join(root, "rust", "jolt-kernels-hip", "src", module + ".rs"))
+
+
+def test_hand_written_rust_calls_name_real_entry_points_with_the_right_arity():
+    """The crate cannot be compiled here, so its hand-written modules are checked mechanically against the generated declarations: every `ffi::jolt_*(`
+    call names a function ffi.rs declares, with as many arguments as the declaration has parameters; every other `ffi::` item (constants, types) exists."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rust", "jolt-kernels-hip", "src")
+    ffi_rs = open(os.path.join(root, "ffi.rs")).read()
+    decl = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (jolt_\w+)\(([^)]*)\)", ffi_rs)}
+    items = set(re.findall(r"pub (?:const|type|struct|enum) (\w+)", ffi_rs)) | set(decl)
+    assert len(decl) > 200
+
+    def split_args(text):
+        args, depth, cur = [], 0, ""
+        for ch in text:
+            if ch in "([{<":
+                depth += 1
+            elif ch in ")]}>":
+                depth -= 1
+            if ch == "," and depth == 0:
+                args.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            args.append(cur)
+        return args
+
+    checked = 0
+    for name in sorted(os.listdir(root)):
+        if not name.endswith(".rs") or name == "ffi.rs":
+            continue
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(root, name)).read())  # comments out (doc comments mention symbols freely)
+        for m in re.finditer(r"(?<!core::)(?<!std::)ffi::(\w+)", src):
+            assert m.group(1) in items, (name, m.group(1))
+        for m in re.finditer(r"ffi::(jolt_\w+)\s*\(", src):
+            fn, i, depth = m.group(1), m.end(), 1
+            start = i
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[i], 0)
+                i += 1
+            n_args = len(split_args(src[start:i - 1]))
+            n_params = len(split_args(decl[fn]))
+            assert n_args == n_params, (name, fn, n_args, n_params)
+            checked += 1
+    assert checked > 60
 
 
 def test_integration_doc_lists_the_sources_the_build_compiles():

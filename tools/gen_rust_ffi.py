@@ -23,7 +23,7 @@ def opaque_handles(path=None):
     return re.findall(r"typedef\s+struct\s+(jolt_\w+)\s+\1\s*;", open(path or HEADER).read())
 
 
-FNPTR = {"jolt_local_round_fn", "jolt_gather_fn", "jolt_round_transcript_fn"}
+FNPTR = {"jolt_local_round_fn", "jolt_gather_fn", "jolt_round_transcript_fn", "jolt_open_transcript_fn"}
 
 
 def strip_comments(src):
@@ -137,6 +137,7 @@ def render(decls):
     out.append("pub type jolt_local_round_fn = Option<\n    unsafe extern \"C\" fn(user: *mut c_void, active: *const usize, n_active: usize, binds: *const *const jolt_fr_t, evals_out: *mut jolt_fr_t, evals_count: usize) -> i32,\n>;")
     out.append("pub type jolt_gather_fn = Option<unsafe extern \"C\" fn(user: *mut c_void, local: *const jolt_fr_t, count: usize, gathered: *mut jolt_fr_t) -> i32>;")
     out.append("pub type jolt_round_transcript_fn = Option<unsafe extern \"C\" fn(user: *mut c_void, compressed_coeffs: *const jolt_fr_t, n_coeffs: usize, challenge_out: *mut jolt_fr_t) -> i32>;")
+    out.append("pub type jolt_open_transcript_fn = Option<\n    unsafe extern \"C\" fn(user: *mut c_void, phase: i32, points: *const jolt_g1_t, n_points: usize, values: *const jolt_fr_t, n_values: usize, challenge_out: *mut jolt_fr_t) -> i32,\n>;")
     out.append("")
     out.append('#[link(name = "jolt_hip")]\nextern "C" {')
     for name, ret, params in decls:
