@@ -455,6 +455,9 @@ int32_t jolt_rows_upload(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t 
 int32_t jolt_rows_free(jolt_ctx *ctx, jolt_rows *rows);
 /* integer field (width 1/2/4/8 bytes at `offset`, optionally two's complement) -> Fr table (Polynomial::bind_to_field promotion) */
 int32_t jolt_table_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table **out);
+/* the same field as a resident integer column (JOLT_INT_U64, or JOLT_INT_I64 sign-extended): the compact scalars of Polynomial<T> (crates/jolt-poly/src/dense.rs:
+ * 129-142) straight from the uploaded rows -- what jolt_member_create_lc_small and the *_small operators read; freed with jolt_ints_free */
+int32_t jolt_ints_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, jolt_ints **out);
 /* n_polys hot-index columns from ONE address field (<= 16 bytes): index_i = (field >> shifts[i]) & (2^log_k - 1)
  * (RaChunkSelector::chunk_u128, crates/jolt-witness/src/witnesses/one_hot.rs:14-52); a row whose byte at valid_offset is 0 is a
  * cold cycle (Option::None, e.g. no RAM access); valid_offset = SIZE_MAX: every row is hot.  log_k <= 8 (log_k = 8 gives a 16-bit source). */

@@ -5,6 +5,7 @@
 // The lazily bound member that consumes the source lives with the other members in capi.hip.
 #include <algorithm>
 
+#include "ints.hpp"
 #include "onehot_kernels.hip.h"
 
 using namespace jolt;
@@ -268,6 +269,42 @@ extern "C" int32_t jolt_table_from_rows(jolt_ctx* ctx, const jolt_rows* rows, si
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     *out = t;
+    return JOLT_OK;
+}
+
+// out[j] = the integer field of row j, widened to 64 bits (sign-extended when is_signed): a typed witness column as the COMPACT scalars the small-scalar members and
+// operators read (jolt_member_create_lc_small, jolt_r1cs_*_small, ...), extracted on the device from the uploaded rows -- no promotion to field elements
+static __global__ __launch_bounds__(kBlock) void k_rows_to_ints(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width, int is_signed,
+                                                                uint64_t* __restrict__ out) {
+    size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_rows) return;
+    uint64_t v = load_le(rows + j * row_bytes + offset, width);
+    const int bits = (int)width * 8;
+    if (is_signed && bits < 64 && ((v >> (bits - 1)) & 1)) v |= ~0ull << bits;
+    out[j] = v;
+}
+extern "C" int32_t jolt_ints_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, jolt_ints** out) {
+    if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_ints* v = new (std::nothrow) jolt_ints();
+    if (!v) return JOLT_ERR_OOM;
+    v->ctx = ctx;
+    v->count = rows->n_rows;
+    v->kind = is_signed ? JOLT_INT_I64 : JOLT_INT_U64;
+    hipError_t e = hipMalloc(&v->data, std::max<size_t>(v->count, 1) * 8);  // freed by jolt_ints_free (hipFree)
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rows_to_ints, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const uint8_t*)rows->data, rows->n_rows,
+                           rows->row_bytes, offset, width, is_signed ? 1 : 0, (uint64_t*)v->data);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("ints from rows: ") + hipGetErrorString(e);
+        if (v->data) (void)hipFree(v->data);
+        delete v;
+        return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
+    }
+    *out = v;
     return JOLT_OK;
 }
 

@@ -851,6 +851,14 @@ class Rows:
             self.ctx)
         return Table(self.ctx, h)
 
+    def ints(self, offset, width, signed=False):
+        """the field as a resident integer column (jolt_ints_from_rows): compact scalars, no promotion"""
+        h = C.c_void_p()
+        _ck(lib().jolt_ints_from_rows(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), C.c_int32(1 if signed else 0), C.byref(h)), "jolt_ints_from_rows", self.ctx)
+        v = Ints.__new__(Ints)
+        v.ctx, v.kind, v.count, v.h = self.ctx, "i64" if signed else "u64", self.n_rows, h
+        return v
+
     def onehot(self, offset, width, shifts, log_k, valid_offset=None):
         sh = (C.c_uint32 * len(shifts))(*shifts)
         h = C.c_void_p()

@@ -61,10 +61,13 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
         tables[name] = TableSpec(name, kind, point=rand_fr(n_vars, rng))
         return name
 
-    def onehot(name, cold=0.0, log_k=4):
-        """committed RA polynomial chunk, address-folded: K = 2^log_k = 16 (crates/jolt-prover/src/config.rs:175-186)"""
+    def onehot(name, cold=0.0, log_k=4, cold_mask=None):
+        """committed RA polynomial chunk, address-folded: K = 2^log_k = 16 (crates/jolt-prover/src/config.rs:175-186).  cold_mask: the chunks of ONE address
+        (the RAM address of a cycle) are cold together -- a cycle either accesses memory or does not"""
         idx = rng.integers(0, 1 << log_k, size=T, dtype=np.uint8)
-        if cold:
+        if cold_mask is not None:
+            idx[cold_mask] = 0xFF
+        elif cold:
             idx[rng.random(T) < cold] = 0xFF
         tables[name] = TableSpec(name, "onehot", point=rand_fr(log_k, rng), data=idx)
         return name
@@ -143,7 +146,8 @@ def build(n_vars, seed=2026, d_ram=4, n_instruction_ra=32):
                               reference="crates/jolt-kernels/src/optimized/ram_hamming_booleanity.rs:111-135"))
     # ---- stage 6b: ram_ra_virtualization  eq(r,j) * prod_{i<d} ra_i                             deg 1+d, 1+d tables
     #      ra_i(j) = eq(r_chunk_i, chunk_i(j)): one-hot selector columns, ~40 % cold cycles (specs/byte-addressable-memory.md:119)
-    t = [derived("s6.eq_rv", "eq")] + [onehot(f"s6.ram_ra{i}", cold=0.4) for i in range(d_ram)]
+    ram_cold = rng.random(T) < 0.4
+    t = [derived("s6.eq_rv", "eq")] + [onehot(f"s6.ram_ra{i}", cold_mask=ram_cold) for i in range(d_ram)]
     members.append(MemberSpec("ram_ra_virtualization", 6, 1 + d_ram, t,
                               groups=[[(None, [("one", i)]) for i in range(1 + d_ram)]],
                               uniform=(1, d_ram, ["one"]) if 2 <= d_ram <= 4 else None,
@@ -233,9 +237,13 @@ class DeviceWorkload:
     commitment grid of crates/jolt-kernels/src/commitment.rs:86-130 -- the two dense increment columns at address 0, the one-hot
     RA columns as 0/1 coefficients -- committed with HyperKZG and opened jointly at one point)."""
 
-    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, extended=False, **kw):
+    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, extended=False, witness_upload=False, **kw):
         from . import ffi
         self.ctx, self.n_vars, self.ffi, self.pcs = ctx, n_vars, ffi, pcs
+        # witness_upload: every step STARTS from the packed per-cycle rows in host memory (RowSource::rows() + WitnessBundle::from_row windows,
+        # crates/jolt-witness/src/consumer.rs:129-143, crates/jolt-kernels/src/optimized/rows.rs:22-72): one H2D copy of the rows, the typed columns and hot
+        # indices extracted on the device (jolt_rows_upload, jolt_ints_from_rows, jolt_onehot_from_rows).  Default: the witness is resident ("inputs in HBM").
+        self.witness_upload = witness_upload
         # extended: the stage 1 / 2 / 5 operators that are not plain cycle-domain relations (Spartan outer / product, the sparse RAM read-write
         # matrix, the instruction read-RAF scans + cycle rounds: jolt_amd/stages.py) inside every step, over their own resident inputs
         self.ext = None
@@ -386,6 +394,71 @@ class DeviceWorkload:
         """a member's table slot: the resident integer column for a compact-scalar witness column, the per-proof field table otherwise"""
         return self.ints[name] if name in self._small else self.tables[name]
 
+    # ---- the witness path (SURVEY.md section 8 f1): packed rows -> one upload -> columns on the device ------------------------------------
+    def pack_witness_rows(self):
+        """(rows (T, row_bytes) uint8, layout): per cycle every integer witness column as 8 bytes, then per index-encoded member ONE address field whose nibbles are
+        its RA chunks (the instruction lookup index: 16 bytes for 32 chunks; the RAM address: 2 bytes for 4) and a validity byte (0 = no access: cold cycle)"""
+        T = 1 << self.n_vars
+        names = list(self.ints)
+        fields, off = [], 0
+        for name in names:
+            fields.append(("int", name, off, 8))
+            off += 8
+        for i in sorted(self.sources):
+            ms = self.members_spec[i]
+            n, log_k = len(ms.tables) - 1, len(self.tables_spec[ms.tables[1]].point)
+            width = (n * log_k + 7) // 8
+            assert width <= 16
+            fields.append(("onehot", i, off, width, n, log_k))
+            off += width + 1
+        row_bytes = (off + 7) // 8 * 8
+        rows = np.zeros((T, row_bytes), dtype=np.uint8)
+        for f in fields:
+            if f[0] == "int":
+                spec = self.tables_spec[f[1]]
+                col = spec.data.astype(np.uint64 if spec.kind == "u64" else np.int64).view(np.uint64)
+                rows[:, f[2]:f[2] + 8] = col.reshape(-1, 1).view(np.uint8).reshape(T, 8)
+            else:
+                _, i, o, width, n, log_k = f
+                cols = [self.tables_spec[t].data for t in self.members_spec[i].tables[1:]]
+                hot = cols[0] != 0xFF
+                assert all(np.array_equal(c != 0xFF, hot) for c in cols), "the chunks of one address are cold together"
+                per = 8 // log_k  # chunks per byte
+                for b in range(width):
+                    byte = np.zeros(T, dtype=np.uint8)
+                    for q in range(per):
+                        k = b * per + q
+                        if k < n:
+                            byte |= (np.where(hot, cols[k], 0).astype(np.uint8) << np.uint8(q * log_k))
+                    rows[:, o + b] = byte
+                rows[:, o + width] = hot.astype(np.uint8)
+        return rows, fields
+
+    def upload_witness(self):
+        """one step's witness from host memory: ONE copy of the packed rows, then device-side extraction into the columns the members read"""
+        if getattr(self, "_packed", None) is None:
+            self._packed, self._fields = self.pack_witness_rows()
+        if self.prepared:
+            self.release()  # the members of the previous proof borrow the columns that are replaced here
+        rows = self.ffi.Rows(self.ctx, self._packed)
+        for f in self._fields:
+            if f[0] == "int":
+                _, name, off, width = f
+                new = rows.ints(off, width, signed=self.tables_spec[name].kind == "i64")
+                self.ints[name].free()
+                self.ints[name] = new
+            else:
+                _, i, off, width, n, log_k = f
+                new = rows.onehot(off, width, [k * log_k for k in range(n)], log_k, valid_offset=off + width)
+                self.sources[i].free()
+                self.sources[i] = new
+        rows.free()
+
+    def witness_bytes_per_cycle(self):
+        if getattr(self, "_packed", None) is None:
+            self._packed, self._fields = self.pack_witness_rows()
+        return int(self._packed.shape[1])
+
     def release(self):
         for m in self.members:
             m.destroy()
@@ -431,6 +504,8 @@ class DeviceWorkload:
 
     def step(self, label=0):
         """One proof's worth of hot-path work (bench.py's timed step)."""
+        if self.witness_upload:
+            self.upload_witness()
         self.prepare()
         out = {}
         if self.pcs:

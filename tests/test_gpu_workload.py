@@ -142,3 +142,26 @@ def test_alternate_kernel_paths_give_the_same_transcript(monkeypatch, knobs):
     for stage in want:
         for key in ("polys", "challenges", "final_claim"):
             assert np.array_equal(got[stage][key], want[stage][key]), (knobs, stage, key)
+
+
+@pytest.mark.parametrize("n_vars", [6, 15])
+def test_witness_upload_path_gives_the_same_proof(n_vars):
+    """DeviceWorkload(witness_upload=True): every step starts from the packed per-cycle rows in host memory -- one upload, the integer columns (jolt_ints_from_rows)
+    and the RA chunk indices (jolt_onehot_from_rows: the nibbles of the instruction lookup index / the RAM address, cold = invalid) extracted on the device
+    (SURVEY.md section 8 f1; RowSource::rows + WitnessBundle::from_row, crates/jolt-witness/src/consumer.rs:129-143) -- and proves what the resident witness proves"""
+    ctx = ffi.Context(0)
+    a = DeviceWorkload(ctx, n_vars, seed=12)
+    b = DeviceWorkload(ctx, n_vars, seed=12, witness_upload=True)
+    rows, fields = b.pack_witness_rows()
+    assert rows.shape == (1 << n_vars, b.witness_bytes_per_cycle()) and len(fields) == len(b.ints) + len(b.sources)
+    want = a.prove(label=7)
+    for rep in range(2):
+        got = b.step(label=7)["stages"]
+        for stage in want:
+            for key in ("polys", "challenges", "final_claim"):
+                assert np.array_equal(got[stage][key], want[stage][key]), (rep, stage, key)
+    for i in b.sources:
+        assert np.array_equal(b.sources[i].download(), a.sources[i].download())
+    a.close()
+    b.close()
+    ctx.close()
