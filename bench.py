@@ -118,7 +118,7 @@ PUBLISHED_REFERENCE = {  # what the reference itself publ
     "source": "book/src/how/optimizations/inlines.md:147,151,155", "also": "~500 kHz on a MacBook M4 Max, 16 cores (same file :149-150)"}
 
 
-def cpu_baseline(log_t, srs_dev, with_pcs):
+def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
     """The same step on the host cores through the oracle's OpenMP restatement (kind = "port": the reference is Rust + rayon and
     cannot be built in this image; its arithmetic lives in an un-vendored arkworks fork): per-proof tables, the 11 relations in the
     optimized tier's fused form (skipped s(1), linear combinations folded; the RA columns dense), and -- with_pcs -- the
@@ -131,9 +131,16 @@ def cpu_baseline(log_t, srs_dev, with_pcs):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from jolt_amd import workload as W
-    from workload_oracle import make_table, resolver
+    from workload_oracle import OracleExtended, make_table, resolver
 
     K = 16
+
+    class OracleStageOperators(OracleExtended):
+        """the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators on the host cores: the oracle twins of jolt_amd/stages.py, WITHOUT the from-the-definition address rounds the
+        parity tests add (those are checks, not prover work): the 128 read-RAF address rounds run on the library's host state machine, as in the GPU step"""
+        @classmethod
+        def sampled_direct_rounds(cls, n_vars):
+            return set() if n_vars > cls.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T else set(range(128))
 
     class Sample:
         def __init__(self, scale):
@@ -151,8 +158,9 @@ def cpu_baseline(log_t, srs_dev, with_pcs):
             self.point = W.rand_fr(scale + 4, prng)
             if with_pcs:  # the first K * T powers of the device's SRS, converted to affine once (inputs, not timed)
                 self.bases = O.baseline_prepare_bases(srs_dev.download(0, K * self.T))
+            self.ext = OracleStageOperators(scale) if with_ext else None  # the trace description (numpy) is an input, built here
 
-        legs = {"tables": 0.0, "sumchecks": 0.0, "pcs": 0.0}
+        legs = {"tables": 0.0, "sumchecks": 0.0, "pcs": 0.0, "stage_operators": 0.0}
 
         def step(self):
             t0 = time.perf_counter()
@@ -173,10 +181,14 @@ def cpu_baseline(log_t, srs_dev, with_pcs):
                 joint = O.baseline_grid_joint(self.idx, K, self.s_oh, dense, self.s_d)
                 O.hyperkzg_open(self.bases, joint, self.point, label=1)
             t3 = time.perf_counter()
+            if self.ext is not None:
+                self.ext.prove(label=1)
+            t4 = time.perf_counter()
             Sample.legs["tables"] += t1 - t0
             Sample.legs["sumchecks"] += t2 - t1
             Sample.legs["pcs"] += t3 - t2
-            return t3 - t0
+            Sample.legs["stage_operators"] += t4 - t3
+            return t4 - t0
 
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     O.baseline_use_parallel_msm(True)
@@ -213,10 +225,13 @@ def cpu_baseline(log_t, srs_dev, with_pcs):
                 f"(signed-digit XYZZ bucket MSMs, all level / witness MSMs as one pool of window x chunk tasks; affine bases prepared outside the timed region; "
                 f"Horner / RLC passes OpenMP-parallel where the reference's kzg.rs:51-105 is serial)") if with_pcs else ""
     return {"value": round(reps * (1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
-            "sample": f"the `--stages 2-6b` part of the step at T=2^{log_t} (the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators of the default step are NOT in this CPU sample: the GPU value covers more work per cycle): per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
-                      f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs, ADX) with OpenMP on {best_n} of {hw} host threads "
+            "sample": (f"the SAME step as the GPU line at T=2^{log_t}: " if with_ext else f"the `--stages 2-6b` part of the step at T=2^{log_t} (the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators are NOT in this CPU sample): ")
+                      + "per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
+                      + (" + the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators as their oracle twins (tests/workload_oracle.py OracleExtended: Spartan outer / product, both sparse matrices, "
+                         "read-RAF with its 128 address rounds on the library's host state machine, pushforwards, address-domain relations)" if with_ext else "")
+                      + f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs, ADX) with OpenMP on {best_n} of {hw} host threads "
                       f"(nproc {os.cpu_count()}; the fastest of {hw} / {max(1, hw // 2)} threads x bucket windows capped at 16 / 13 bits at T=2^{cal_scale}: {best_t:.2f} s per step there, cap {best_c}); {dt:.1f}s of CPU work: "
-                      f"table builds {Sample.legs['tables']:.1f}s, sumcheck legs {Sample.legs['sumchecks']:.1f}s, commit + open {Sample.legs['pcs']:.1f}s",
+                      f"table builds {Sample.legs['tables']:.1f}s, sumcheck legs {Sample.legs['sumchecks']:.1f}s, commit + open {Sample.legs['pcs']:.1f}s, stage operators {Sample.legs['stage_operators']:.1f}s",
             "published_reference": PUBLISHED_REFERENCE}
 
 
@@ -485,7 +500,7 @@ def main():
         if not args.no_cpu_baseline:
             try:
                 srs_dev = (pcs_sharded.srs if sharded else wl.srs) if pcs else None  # the CPU sample's grid uses a prefix of the same SRS (inputs)
-                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs))
+                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs), with_ext=(the_ext is not None))
             except Exception as e:  # the oracle is optional infrastructure: never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "cycles/s", "cores": None, "kind": "port", "sample": f"unavailable: {e}", "published_reference": PUBLISHED_REFERENCE}
         print(json.dumps(out), flush=True)
