@@ -235,6 +235,21 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
             "published_reference": PUBLISHED_REFERENCE}
 
 
+def baseline_config(world, scale, with_pcs):
+    """which entry of BASELINE.json `configs` a line stands for (the driver's ladder is N = 1, 2, 4, 8 at the default --scale 22: weak scaling, 2^22 cycles per GPU)"""
+    total = world << scale
+    if not with_pcs:
+        return f"configs[1] shape (sumcheck bind + round-poly kernels only, MSM outside the step) at T = 2^{scale}" + ("" if scale == 20 else "; configs[1] itself is --scale 20 --no-msm")
+    if world == 1:
+        return f"configs[2] (T = 2^{scale}, 1 x MI355X, sumcheck + HyperKZG MSM end-to-end)" + ("" if scale == 22 else "; configs[2] itself is --scale 22")
+    lg = total.bit_length() - 1
+    if world == 8:
+        rel = "configs[3] itself (T = 2^24)" if total == 1 << 24 else f"configs[3]'s shape at {total / (1 << 24):g} x its T = 2^24 (weak scaling keeps configs[2]'s 2^22 cycles per GPU; `--gpus 8 --scale 21` is configs[3]'s own 2^24)"
+        return f"{rel}: ONE trace of 2^{lg} cycles, hypercube + MSM sharded over 8 x MI355X, exchanges over RCCL / xGMI"
+    return (f"the weak-scaling ladder between configs[2] and configs[3]: ONE trace of {world} x 2^{scale} = 2^{lg} cycles sharded over {world} x MI355X "
+            f"(configs[2]'s load per GPU; configs[3] is the 8-GPU rung)")
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -447,7 +462,8 @@ def main():
         "vs_baseline": None,
         "dtype": "u256 (BN254 Fr / Fq, 8x u32 Montgomery limbs; integer, bit-exact)",
         "data": "synthetic",
-        "config": {"workload": what, "trace_length_per_gpu": 1 << args.scale, "parallelism": f"hypercube sharded over {world} GPU(s)"},
+        "config": {"workload": what, "trace_length_per_gpu": 1 << args.scale, "trace_length_total": total_cycles, "baseline_config": baseline_config(world, args.scale, bool(pcs)),
+                   "parallelism": f"hypercube sharded over {world} GPU(s)"},
     }
     if split is not None:
         out["config"]["ms_per_step_split"] = split
