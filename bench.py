@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--stages", choices=["all", "2-6b"], default="all",
                     help="all (default): the step also runs the stage 1 / 2 / 5 operators that are not plain cycle-domain relations -- Spartan outer and product, the sparse "
                          "RAM read-write matrix, instruction read-RAF checking with its 128 address rounds (jolt_amd/stages.py); 2-6b: the round-2 step (comparable with BENCH_r02)")
-    ap.add_argument("--witness", choices=["resident", "upload"], default="resident",
+    ap.add_argument("--witness", choices=["resident", "upload", "upload-pinned"], default="resident",
                     help="resident (default, the contract's `value`): the witness columns sit in HBM before the timed region.  upload: every step starts from the packed "
                          "per-cycle rows in HOST memory -- one H2D copy + device-side column extraction (SURVEY.md section 8 f1) -- a PCIe-inclusive diagnostic, N = 1 only")
     ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
@@ -340,7 +340,7 @@ def main():
             if pcs_sharded is not None:
                 pcs_sharded.open(label)
     else:
-        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), witness_upload=(args.witness == "upload"))
+        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), witness_upload={"resident": False, "upload": True, "upload-pinned": "pinned"}[args.witness])
         step = wl.step
 
     def barrier():
@@ -402,7 +402,7 @@ def main():
                         ("ram_read_write", lambda: e.ram_read_write(3300)), ("registers_read_write", lambda: e.registers_read_write(3350)),
                         ("instruction_read_raf", lambda: e.instruction_read_raf(3400)), ("booleanity_address", lambda: e.booleanity_address(3450)),
                         ("hamming_weight", lambda: e.hamming_weight(3470)), ("address_domain", lambda: e.address_domain(3500))]
-        legs = ([("witness_upload", wl.upload_witness)] if args.witness == "upload" else []) + [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + ext_legs + [("prove", lambda: wl.prove(label=3000))] + \
+        legs = ([("witness_upload", wl.upload_witness)] if args.witness != "resident" else []) + [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + ext_legs + [("prove", lambda: wl.prove(label=3000))] + \
                ([("open", lambda: wl.open(label=3000))] if pcs else [])
         acc = {k: 0.0 for k, _ in legs}
         reps = 2
@@ -467,9 +467,9 @@ def main():
     }
     if split is not None:
         out["config"]["ms_per_step_split"] = split
-    if not sharded and args.witness == "upload":
+    if not sharded and args.witness != "resident":
         bpc = wl.witness_bytes_per_cycle()
-        out["config"]["witness"] = {"mode": "upload: every step starts from packed rows in pageable host memory (PCIe-inclusive; NOT the contract's `value`, which has the inputs resident)",
+        out["config"]["witness"] = {"mode": f"upload: every step starts from packed rows in {'page-locked (jolt_host_pinned_alloc)' if args.witness == 'upload-pinned' else 'pageable'} host memory (PCIe-inclusive; NOT the contract's `value`, which has the inputs resident)",
                                     "bytes_per_cycle": bpc, "bytes_per_step": bpc << args.scale,
                                     "h2d_GBps": round((bpc << args.scale) / (split["witness_upload"] * 1e-3) / 1e9, 2) if split and split.get("witness_upload") else None,
                                     "note": "catalogue witness only (integer columns + RA chunk addresses); the stage operators' inputs stay resident"}

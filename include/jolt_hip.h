@@ -452,6 +452,10 @@ int32_t jolt_member_create_lazy_ra_uniform_sharded(jolt_ctx *ctx, const jolt_one
  * column per polynomial; columns are expanded on the device.  Fields are little-endian integers inside a row of row_bytes bytes. */
 typedef struct jolt_rows jolt_rows;
 int32_t jolt_rows_upload(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t row_bytes, jolt_rows **out);
+/* Page-locked host memory for the row buffer the tracer fills (the Vec<CycleRow> of crates/jolt-host/src/program.rs's trace output, packed): jolt_rows_upload
+ * from such a block runs at the link rate (no staging copy by the runtime).  Ordinary host memory in every other respect. */
+int32_t jolt_host_pinned_alloc(jolt_ctx *ctx, size_t bytes, void **out);
+int32_t jolt_host_pinned_free(jolt_ctx *ctx, void *p);
 int32_t jolt_rows_free(jolt_ctx *ctx, jolt_rows *rows);
 /* integer field (width 1/2/4/8 bytes at `offset`, optionally two's complement) -> Fr table (Polynomial::bind_to_field promotion) */
 int32_t jolt_table_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table **out);

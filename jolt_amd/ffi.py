@@ -835,6 +835,24 @@ def host_g1_serialize_compressed(p):
     return bytes(out)
 
 
+class PinnedBuffer:
+    """Page-locked host memory (jolt_host_pinned_alloc) as a numpy uint8 array of the given shape: the staging block a tracer fills and Rows uploads from"""
+
+    def __init__(self, ctx, shape):
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        _ck(lib().jolt_host_pinned_alloc(ctx.h, C.c_size_t(n), C.byref(p)), "jolt_host_pinned_alloc", ctx)
+        self.ctx, self.p = ctx, p
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).reshape(shape)
+
+    def free(self):
+        if self.p:
+            self.array = None
+            _ck(lib().jolt_host_pinned_free(self.ctx.h, self.p), "jolt_host_pinned_free", self.ctx)
+            self.p = None
+
+
 class Rows:
     """Packed typed witness rows (numpy structured or 2-D uint8 array) resident on the device; columns are expanded there."""
 

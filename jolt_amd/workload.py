@@ -243,7 +243,8 @@ class DeviceWorkload:
         # witness_upload: every step STARTS from the packed per-cycle rows in host memory (RowSource::rows() + WitnessBundle::from_row windows,
         # crates/jolt-witness/src/consumer.rs:129-143, crates/jolt-kernels/src/optimized/rows.rs:22-72): one H2D copy of the rows, the typed columns and hot
         # indices extracted on the device (jolt_rows_upload, jolt_ints_from_rows, jolt_onehot_from_rows).  Default: the witness is resident ("inputs in HBM").
-        self.witness_upload = witness_upload
+        self.witness_upload = bool(witness_upload)
+        self.witness_pinned = witness_upload == "pinned"  # the row buffer in page-locked memory (jolt_host_pinned_alloc) instead of pageable numpy memory
         # extended: the stage 1 / 2 / 5 operators that are not plain cycle-domain relations (Spartan outer / product, the sparse RAM read-write
         # matrix, the instruction read-RAF scans + cycle rounds: jolt_amd/stages.py) inside every step, over their own resident inputs
         self.ext = None
@@ -437,7 +438,13 @@ class DeviceWorkload:
     def upload_witness(self):
         """one step's witness from host memory: ONE copy of the packed rows, then device-side extraction into the columns the members read"""
         if getattr(self, "_packed", None) is None:
-            self._packed, self._fields = self.pack_witness_rows()
+            rows, self._fields = self.pack_witness_rows()
+            if self.witness_pinned:  # the tracer's row buffer in page-locked memory (jolt_host_pinned_alloc): the copy runs at the link rate
+                self._pinned = self.ffi.PinnedBuffer(self.ctx, rows.shape)
+                self._pinned.array[...] = rows
+                self._packed = self._pinned.array
+            else:
+                self._packed = rows
         if self.prepared:
             self.release()  # the members of the previous proof borrow the columns that are replaced here
         rows = self.ffi.Rows(self.ctx, self._packed)
@@ -530,6 +537,10 @@ class DeviceWorkload:
         for v in self.ints.values():
             v.free()
         self.sources, self.ints = {}, {}
+        if getattr(self, "_pinned", None) is not None:
+            self._packed = None
+            self._pinned.free()
+            self._pinned = None
         if self.own_srs and self.srs is not None:
             self.srs.free()
             self.srs = None

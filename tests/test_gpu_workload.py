@@ -144,14 +144,14 @@ def test_alternate_kernel_paths_give_the_same_transcript(monkeypatch, knobs):
             assert np.array_equal(got[stage][key], want[stage][key]), (knobs, stage, key)
 
 
-@pytest.mark.parametrize("n_vars", [6, 15])
-def test_witness_upload_path_gives_the_same_proof(n_vars):
+@pytest.mark.parametrize("n_vars,mode", [(6, True), (15, True), (12, "pinned")])
+def test_witness_upload_path_gives_the_same_proof(n_vars, mode):
     """DeviceWorkload(witness_upload=True): every step starts from the packed per-cycle rows in host memory -- one upload, the integer columns (jolt_ints_from_rows)
     and the RA chunk indices (jolt_onehot_from_rows: the nibbles of the instruction lookup index / the RAM address, cold = invalid) extracted on the device
     (SURVEY.md section 8 f1; RowSource::rows + WitnessBundle::from_row, crates/jolt-witness/src/consumer.rs:129-143) -- and proves what the resident witness proves"""
     ctx = ffi.Context(0)
     a = DeviceWorkload(ctx, n_vars, seed=12)
-    b = DeviceWorkload(ctx, n_vars, seed=12, witness_upload=True)
+    b = DeviceWorkload(ctx, n_vars, seed=12, witness_upload=mode)  # "pinned": the row buffer in jolt_host_pinned_alloc memory
     rows, fields = b.pack_witness_rows()
     assert rows.shape == (1 << n_vars, b.witness_bytes_per_cycle()) and len(fields) == len(b.ints) + len(b.sources)
     want = a.prove(label=7)
