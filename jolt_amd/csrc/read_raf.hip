@@ -44,17 +44,25 @@ struct jolt_read_raf {
     uint64_t* index = nullptr;  // [2 * cycles]: lookup_index as (lo, hi)
     uint8_t* table = nullptr;   // table index or 0xFF
     uint8_t* raf = nullptr;     // raf_flag
-    // phase scratch (grow-only)
-    uint32_t *keys = nullptr, *sorted = nullptr, *hist = nullptr, *offs = nullptr, *cursor = nullptr;
-    // a phase's rows in bin order (k_rr_gather): u, the lookup index and the flag of sorted[p] at position p, so that the scans read them contiguously
-    Fr* u_sorted = nullptr;
-    uint64_t* index_sorted = nullptr;
-    uint8_t* raf_sorted = nullptr;
+    // A phase's ORDER: its rows sorted by (table, address chunk), the bins' work items, and the lookup index / flag of sorted[p] at position p.  It depends on the
+    // witness and the phase alone -- not on any challenge -- so the order of phase p + 1 is built (into the other set) right behind phase p's scan, under the eight
+    // address rounds the host runs before it can call again (jolt_read_raf_phase_scan).
+    struct Order {
+        uint32_t *keys = nullptr, *sorted = nullptr, *hist = nullptr, *offs = nullptr, *cursor = nullptr, *seg_start = nullptr;
+        uint64_t* index_sorted = nullptr;
+        uint8_t* raf_sorted = nullptr;
+        int64_t suffix_len = -1;  // the phase this set holds the order of; -1: none
+    } order[2];
+    int cur = 0;
+    Fr* u_sorted = nullptr;  // u in the current order (k_rr_gather_u): depends on the challenges, gathered inside the scan
+    void* h_out = nullptr;   // page-locked read-back block of a scan's sums (the D2H copy then needs no staging by the runtime)
+    size_t h_out_cap = 0;
+    hipEvent_t ev_out = nullptr;
+    bool lds_attr_set = false;
     Fr *bin_raf = nullptr, *d_suffix = nullptr, *d_raf = nullptr;
     uint32_t* d_cfg = nullptr;
     std::vector<uint32_t> cfg_host;  // what d_cfg holds
     size_t suffix_cap = 0, cfg_cap = 0;
-    uint32_t* seg_start = nullptr;  // per bin: index of its first work item (a bin's rows are cut into items of kRafSegRows rows)
     Fr* part = nullptr;             // per work item: the 6 RAF sums, then one sum per suffix of the bin's table
     size_t part_cap = 0;
 };
@@ -122,15 +130,20 @@ __global__ __launch_bounds__(1024) void k_rr_segments(const uint32_t* __restrict
 // The rows of a phase in bin order: position p holds u, the lookup index and the flag of row sorted[p].  One thread per row, so the three gathers of a row
 // (the 32-byte u[j] above all) are hidden by occupancy; the scans below then read their rows contiguously.  (Scanning through sorted[] directly left every
 // lane waiting on its own chain row id -> u[j] / index[j], 16 rows deep: 0.87 ms per phase against 0.1 + 0.3 ms.)
-__global__ __launch_bounds__(kBlock) void k_rr_gather(const uint32_t* __restrict__ sorted, size_t rows, const Fr* __restrict__ u, const uint64_t* __restrict__ index,
-                                                      const uint8_t* __restrict__ raf, Fr* __restrict__ u_sorted, uint64_t* __restrict__ index_sorted, uint8_t* __restrict__ raf_sorted) {
+// Two kernels: the lookup index and the flag belong to the ORDER (witness only: k_rr_gather_rows runs with the sort, ahead of the phase), u to the scan.
+__global__ __launch_bounds__(kBlock) void k_rr_gather_rows(const uint32_t* __restrict__ sorted, size_t rows, const uint64_t* __restrict__ index, const uint8_t* __restrict__ raf,
+                                                           uint64_t* __restrict__ index_sorted, uint8_t* __restrict__ raf_sorted) {
     const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (p >= rows) return;
     const uint32_t j = sorted[p];
-    st_fr(u_sorted + p, ld_fr(u + j));
     const uint4 w = *reinterpret_cast<const uint4*>(index + 2 * (size_t)j);
     *reinterpret_cast<uint4*>(index_sorted + 2 * p) = w;
     raf_sorted[p] = raf[j];
+}
+__global__ __launch_bounds__(kBlock) void k_rr_gather_u(const uint32_t* __restrict__ sorted, size_t rows, const Fr* __restrict__ u, Fr* __restrict__ u_sorted) {
+    const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= rows) return;
+    st_fr(u_sorted + p, ld_fr(u + sorted[p]));
 }
 
 // cfg: [0 .. n_tables] suffix offsets, then the suffix kinds (one u32 each)
@@ -294,10 +307,14 @@ extern "C" int32_t jolt_read_raf_destroy(jolt_ctx* ctx, jolt_read_raf* rr) {
     if (!rr) return JOLT_OK;
     jolt_ctx* c = ctx ? ctx : rr->ctx;
     if (c) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {rr->index, rr->table, rr->raf, rr->keys, rr->sorted, rr->hist, rr->offs, rr->cursor, rr->bin_raf, rr->d_suffix, rr->d_raf, rr->d_cfg, rr->seg_start, rr->part,
-                    rr->u_sorted, rr->index_sorted, rr->raf_sorted};
+    void* ptrs[] = {rr->index, rr->table, rr->raf, rr->bin_raf, rr->d_suffix, rr->d_raf, rr->d_cfg, rr->part, rr->u_sorted};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (jolt_read_raf::Order& o : rr->order)
+        for (void* p : {(void*)o.keys, (void*)o.sorted, (void*)o.hist, (void*)o.offs, (void*)o.cursor, (void*)o.seg_start, (void*)o.index_sorted, (void*)o.raf_sorted})
+            if (p) (void)hipFree(p);
+    if (rr->h_out) (void)hipHostFree(rr->h_out);
+    if (rr->ev_out) (void)hipEventDestroy(rr->ev_out);
     delete rr;
     return JOLT_OK;
 }
@@ -317,15 +334,18 @@ extern "C" int32_t jolt_read_raf_create(jolt_ctx* ctx, const uint64_t* lookup_in
     hipError_t e = hipMalloc((void**)&rr->index, cycles * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->table, cycles);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->raf, cycles);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->keys, cycles * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->u_sorted, cycles * sizeof(Fr));
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->index_sorted, cycles * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->raf_sorted, cycles);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->sorted, cycles * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->hist, n_bins * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->offs, n_bins * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->cursor, n_bins * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&rr->seg_start, (n_bins + 1) * 4);
+    for (jolt_read_raf::Order& o : rr->order) {
+        if (e == hipSuccess) e = hipMalloc((void**)&o.keys, cycles * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.index_sorted, cycles * 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.raf_sorted, cycles);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.sorted, cycles * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.hist, n_bins * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.offs, n_bins * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.cursor, n_bins * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&o.seg_start, (n_bins + 1) * 4);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&rr->ev_out, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&rr->bin_raf, n_bins * kRafSums * sizeof(Fr));
     if (e == hipSuccess) e = hipMalloc((void**)&rr->d_raf, kRafSums * kRafChunk * sizeof(Fr));
     if (e == hipSuccess) e = hipMemcpyAsync(rr->index, lookup_index, cycles * 16, hipMemcpyHostToDevice, ctx->stream);
@@ -385,42 +405,74 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
     }
     const uint32_t B = (n_tables + 1) * kRafChunk;  // keys 1 .. B
     const size_t T = rr->cycles;
-    JOLT_HIP_TRY(ctx, hipMemsetAsync(rr->hist, 0, ((size_t)B + 1) * 4, st));
-    if (total_suffixes) JOLT_HIP_TRY(ctx, hipMemsetAsync(rr->d_suffix, 0, (size_t)total_suffixes * kRafChunk * sizeof(Fr), st));
-    hipLaunchKernelGGL(k_rr_keys, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint64_t*)rr->index, (const uint8_t*)rr->table, T, n_tables, suffix_len,
-                       rr->keys);
     const size_t lds = ((size_t)B + 1) * 4;
     if (lds > ctx->max_lds_per_block) return JOLT_ERR_UNSUPPORTED;
-    (void)hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-    (void)hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-    (void)hipGetLastError();
-    const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, T / 16384 + 1));
-    hipLaunchKernelGGL(k_msm_hist_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)rr->keys, T, B, rr->hist);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)rr->hist, rr->offs, rr->cursor, B, 0x7FFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
-    hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)rr->keys, T, B, rr->cursor, rr->sorted);
-    const uint32_t upper_suffix_bits = suffix_len > address_bits / 2 ? suffix_len - address_bits / 2 : 0;  // suffix_len.saturating_sub(address_bits / 2) (:765)
-    hipLaunchKernelGGL(k_rr_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)rr->hist, B, rr->seg_start);
-    const unsigned grid = (unsigned)std::min<size_t>((max_items + 3) / 4, (size_t)ctx->num_cus * 16);
     static const bool gathered = !(std::getenv("JOLT_RR_GATHER") && std::atoi(std::getenv("JOLT_RR_GATHER")) == 0);
+    static const bool ahead = !(std::getenv("JOLT_RR_AHEAD") && std::atoi(std::getenv("JOLT_RR_AHEAD")) == 0);
+    // the order of phase `len` into set `o`: keys, counting sort by (table, chunk), the bins' work items, lookup index and flag in that order
+    auto build_order = [&](jolt_read_raf::Order& o, uint32_t len) -> int32_t {
+        o.suffix_len = -1;
+        JOLT_HIP_TRY(ctx, hipMemsetAsync(o.hist, 0, ((size_t)B + 1) * 4, st));
+        hipLaunchKernelGGL(k_rr_keys, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint64_t*)rr->index, (const uint8_t*)rr->table, T, n_tables, len, o.keys);
+        const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, T / 16384 + 1));
+        hipLaunchKernelGGL(k_msm_hist_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)o.keys, T, B, o.hist);
+        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)o.hist, o.offs, o.cursor, B, 0x7FFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+        hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)o.keys, T, B, o.cursor, o.sorted);
+        hipLaunchKernelGGL(k_rr_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)o.hist, B, o.seg_start);
+        if (gathered)
+            hipLaunchKernelGGL(k_rr_gather_rows, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)o.sorted, T, (const uint64_t*)rr->index,
+                               (const uint8_t*)rr->raf, o.index_sorted, o.raf_sorted);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        o.suffix_len = (int64_t)len;
+        return JOLT_OK;
+    };
+    if (!rr->lds_attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_msm_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        (void)hipFuncSetAttribute((const void*)k_msm_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        (void)hipGetLastError();
+        rr->lds_attr_set = true;
+    }
+    // page-locked read-back block: the 6 x 256 RAF sums, then the suffix sums
+    const size_t out_words = (size_t)kRafSums * kRafChunk + (size_t)total_suffixes * kRafChunk;
+    if (out_words > rr->h_out_cap) {
+        if (rr->h_out) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(st)); JOLT_HIP_TRY(ctx, hipHostFree(rr->h_out)); rr->h_out = nullptr; rr->h_out_cap = 0; }
+        JOLT_HIP_TRY(ctx, hipHostMalloc(&rr->h_out, out_words * sizeof(Fr), hipHostMallocDefault));
+        rr->h_out_cap = out_words;
+    }
+    if (rr->order[rr->cur].suffix_len != (int64_t)suffix_len) {  // not prepared by the previous call (first phase of a proof, or phases out of sequence)
+        if (rr->order[1 - rr->cur].suffix_len == (int64_t)suffix_len) rr->cur = 1 - rr->cur;
+        else JOLT_TRY(build_order(rr->order[rr->cur], suffix_len));
+    }
+    jolt_read_raf::Order& o = rr->order[rr->cur];
+    if (total_suffixes) JOLT_HIP_TRY(ctx, hipMemsetAsync(rr->d_suffix, 0, (size_t)total_suffixes * kRafChunk * sizeof(Fr), st));
+    const uint32_t upper_suffix_bits = suffix_len > address_bits / 2 ? suffix_len - address_bits / 2 : 0;  // suffix_len.saturating_sub(address_bits / 2) (:765)
+    const unsigned grid = (unsigned)std::min<size_t>((max_items + 3) / 4, (size_t)ctx->num_cus * 16);
     if (gathered) {
-        hipLaunchKernelGGL(k_rr_gather, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)rr->sorted, T, (const Fr*)u->data(), (const uint64_t*)rr->index,
-                           (const uint8_t*)rr->raf, rr->u_sorted, rr->index_sorted, rr->raf_sorted);
-        hipLaunchKernelGGL(k_rr_accumulate<true>, dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)rr->index_sorted, (const uint8_t*)rr->raf_sorted, (const Fr*)rr->u_sorted,
-                           (const uint32_t*)rr->sorted, (const uint32_t*)rr->hist, (const uint32_t*)rr->offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
-                       (const uint32_t*)rr->seg_start, slots, rr->part);
+        hipLaunchKernelGGL(k_rr_gather_u, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)o.sorted, T, (const Fr*)u->data(), rr->u_sorted);
+        hipLaunchKernelGGL(k_rr_accumulate<true>, dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)o.index_sorted, (const uint8_t*)o.raf_sorted, (const Fr*)rr->u_sorted,
+                           (const uint32_t*)o.sorted, (const uint32_t*)o.hist, (const uint32_t*)o.offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
+                           (const uint32_t*)o.seg_start, slots, rr->part);
     } else {
         hipLaunchKernelGGL(k_rr_accumulate<false>, dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)rr->index, (const uint8_t*)rr->raf, (const Fr*)u->data(),
-                           (const uint32_t*)rr->sorted, (const uint32_t*)rr->hist, (const uint32_t*)rr->offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
-                       (const uint32_t*)rr->seg_start, slots, rr->part);
+                           (const uint32_t*)o.sorted, (const uint32_t*)o.hist, (const uint32_t*)o.offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
+                           (const uint32_t*)o.seg_start, slots, rr->part);
     }
-    hipLaunchKernelGGL(k_rr_fold_items, dim3((unsigned)(((size_t)B * slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const Fr*)rr->part, (const uint32_t*)rr->seg_start, n_tables,
+    hipLaunchKernelGGL(k_rr_fold_items, dim3((unsigned)(((size_t)B * slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const Fr*)rr->part, (const uint32_t*)o.seg_start, n_tables,
                        slots, (const uint32_t*)rr->d_cfg, rr->bin_raf, rr->d_suffix);
     hipLaunchKernelGGL(k_rr_fold_raf, dim3(kRafSums), dim3(kRafChunk), 0, st, (const Fr*)rr->bin_raf, n_tables + 1, rr->d_raf);
     JOLT_HIP_TRY(ctx, hipGetLastError());
-    JOLT_HIP_TRY(ctx, hipMemcpyAsync(raf_out, rr->d_raf, kRafSums * kRafChunk * sizeof(Fr), hipMemcpyDeviceToHost, st));
-    if (total_suffixes) JOLT_HIP_TRY(ctx, hipMemcpyAsync(suffix_out, rr->d_suffix, (size_t)total_suffixes * kRafChunk * sizeof(Fr), hipMemcpyDeviceToHost, st));
-    JOLT_HIP_TRY(ctx, hipStreamSynchronize(st));
-    return JOLT_OK;
+    Fr* h_raf = (Fr*)rr->h_out;
+    Fr* h_suf = h_raf + (size_t)kRafSums * kRafChunk;
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(h_raf, rr->d_raf, kRafSums * kRafChunk * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    if (total_suffixes) JOLT_HIP_TRY(ctx, hipMemcpyAsync(h_suf, rr->d_suffix, (size_t)total_suffixes * kRafChunk * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    JOLT_HIP_TRY(ctx, hipEventRecord(rr->ev_out, st));
+    // the next phase's order, queued BEHIND the read-back: it runs while the caller's host rounds do (address phases go from the top chunk down, 8 bits at a time)
+    int32_t ahead_status = JOLT_OK;
+    if (ahead && suffix_len >= kRafChunkBits) ahead_status = build_order(rr->order[1 - rr->cur], suffix_len - kRafChunkBits);
+    JOLT_HIP_TRY(ctx, hipEventSynchronize(rr->ev_out));
+    std::memcpy(raf_out, h_raf, kRafSums * kRafChunk * sizeof(Fr));
+    if (total_suffixes) std::memcpy(suffix_out, h_suf, (size_t)total_suffixes * kRafChunk * sizeof(Fr));
+    return ahead_status;
 }
 
 extern "C" int32_t jolt_read_raf_condense(jolt_ctx* ctx, jolt_read_raf* rr, jolt_table* u, const jolt_fr_t* v_table, uint32_t shift) {
