@@ -63,6 +63,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* ml = std::getenv("JOLT_MSM_LDS_SORT")) ctx->msm_lds_sort = std::atoi(ml) != 0;
     if (const char* pe = std::getenv("JOLT_POOL")) ctx->pool_enabled = std::atoi(pe) != 0;
     if (const char* la = std::getenv("JOLT_MSM_LANES")) ctx->msm_lanes = std::max(1, std::min(4, std::atoi(la)));
+    if (const char* mb = std::getenv("JOLT_MSM_BATCH")) ctx->msm_batch = std::atoi(mb) != 0;
     if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
     if (const char* sg = std::getenv("JOLT_MSM_STAGGER")) ctx->msm_stagger = std::atoi(sg) != 0;
     if (const char* gr = std::getenv("JOLT_FX_REDUCE")) ctx->msm_fx_grid_reduce = std::atoi(gr) != 0;
@@ -154,6 +155,9 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
         if (ctx->msm_ws[k]) (void)hipFree(ctx->msm_ws[k]);
         if (ctx->msm_host[k]) (void)hipHostFree(ctx->msm_host[k]);
     }
+    if (ctx->msm_batch_stream) { (void)hipStreamSynchronize(ctx->msm_batch_stream); (void)hipStreamDestroy(ctx->msm_batch_stream); }
+    if (ctx->msm_batch_ws) (void)hipFree(ctx->msm_batch_ws);
+    if (ctx->msm_batch_host) (void)hipHostFree(ctx->msm_batch_host);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_sort) if (e) (void)hipEventDestroy(e);

@@ -53,6 +53,13 @@ struct jolt_ctx {
     void* msm_ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t msm_ws_cap[4] = {0, 0, 0, 0};
     void* msm_host[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the batch of short MSMs of jolt_internal_msm_many (msm.hip): its own stream, workspace and pinned window sums, beside the four lanes
+    hipStream_t msm_batch_stream = nullptr;
+    void* msm_batch_ws = nullptr;
+    size_t msm_batch_ws_cap = 0;
+    void* msm_batch_host = nullptr;
+    size_t msm_batch_host_cap = 0;
+    bool msm_batch = true;  // JOLT_MSM_BATCH=0: every short MSM on its own (A/B)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // Sort token (JOLT_MSM_STAGGER): the partition / sort phase of a fixed-base MSM is HBM-bound and its bucket sums are bound by
     // integer multiply-adds, so concurrent lanes only gain when one lane's sort runs under ANOTHER lane's bucket sums.  Equal MSMs

@@ -14,6 +14,7 @@
 // Corner cases (P+P, P+(-P), infinity) are handled inside the group law (g1.hip.h); the result is the same POINT as
 // the reference's, in some Jacobian representation.
 #include <algorithm>
+#include <vector>
 
 #include "ctx.hpp"
 #include "msm_kernels.hip.h"
@@ -379,6 +380,134 @@ int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalar
     return jolt_internal_msm_collect(ctx, &job, out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// A BATCH of short MSMs over prefixes of the same bases in one pass of the per-window kernels (the level commitments of a HyperKZG opening below the table sets'
+// crossover: 18 MSMs of 2^18 ... 2 terms, each of which cost ~13 launches, a stream synchronisation and a host Horner on its own: 8 ms of an opening with no bucket
+// sum running, profiles/r04_open_exposed.txt).  MSM j is padded with zero scalars to the longest length N and every (MSM, window) pair becomes one WINDOW of the
+// per-window method: keys[(j W + w) N + i], W' = count * W windows of B + 1 buckets -- histogram, scan, scatter, bucket sums and window reductions are the kernels
+// of jolt_internal_msm_enqueue with W' windows, the sorted entries are base indices i as before, and the host's Horner runs per MSM over its own W window sums.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kBatchMax = 32;                       // MSMs per batch
+constexpr size_t kBatchMaxLen = (size_t)1 << 18;    // longest member: below the mid table set's crossover (msm_fixed.hip: kMidMin = 2^19)
+struct BatchScalars {
+    const Fr* ptr[kBatchMax];
+    uint32_t len[kBatchMax];
+};
+struct MsmBatchJob {
+    int count = 0, c = 0, W = 0;
+    bool queued = false;
+};
+namespace {
+__global__ __launch_bounds__(kBlock) void k_msm_digits_batch(BatchScalars b, size_t N, int c, int W, uint32_t* __restrict__ keys) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= N) return;
+    const bool live = i < b.len[j];
+    Fr s = live ? from_mont(ld_fr(b.ptr[j] + i)) : Fr::zero();
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        const int bit = w * c;
+        uint32_t raw = 0;
+        if (bit < 256) {
+            const int limb = bit >> 5, off = bit & 31;
+            const uint64_t two = (uint64_t)s.l[limb] | (limb + 1 < 8 ? (uint64_t)s.l[limb + 1] << 32 : 0ull);
+            raw = (uint32_t)(two >> off) & ((1u << c) - 1);
+        }
+        raw += carry;
+        uint32_t mag, negf;
+        if (raw > B) { mag = (1u << c) - raw; negf = 1; carry = 1; }
+        else { mag = raw; negf = 0; carry = 0; }
+        keys[((size_t)j * W + w) * N + i] = mag | (negf << 31);  // padding: zero keys (skipped by the sort)
+    }
+}
+}  // namespace
+static int32_t msm_batch_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, const int* members, int count, MsmBatchJob* job) {
+    job->count = count;
+    job->queued = false;
+    if (count == 0) return JOLT_OK;
+    size_t N = 0;
+    BatchScalars bs;
+    for (int k = 0; k < count; ++k) {
+        bs.ptr[k] = d_scalars[members[k]];
+        bs.len[k] = (uint32_t)n[members[k]];
+        N = std::max(N, n[members[k]]);
+    }
+    for (int k = count; k < kBatchMax; ++k) { bs.ptr[k] = nullptr; bs.len[k] = 0; }
+    if (N > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+    int lg = 0;
+    while (((size_t)1 << lg) < N) lg++;
+    // windows of ~64 points per bucket in the longest member: the shorter ones leave most of their buckets empty, which the reduction passes over quickly
+    const int c = std::max(3, std::min(12, lg - 6)), W = (255 + c - 1) / c, Wv = count * W;
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t G = 8, nb = (uint32_t)(((B + G - 1) / G + kBlock - 1) / kBlock);  // reduction: chains of 8 buckets
+    const size_t WB = (size_t)Wv * (B + 1);
+    const size_t avg = (N + B - 1) / B;
+    const uint32_t heavy_threshold = (uint32_t)std::max<size_t>(kLaneCap, 4 * avg);
+    const uint32_t heavy_cap = (uint32_t)((size_t)Wv * N / kHeavySeg + (size_t)Wv * N / heavy_threshold + 16);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_keys = take((size_t)Wv * N * 4), o_sorted = take((size_t)Wv * N * 4), o_hist = take(WB * 4), o_offs = take(WB * 4), o_cur = take(WB * 4),
+                 o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256), o_buckets = take(WB * sizeof(G1Jac)), o_part = take((size_t)Wv * nb * sizeof(G1Jac)),
+                 o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_wsum = take((size_t)Wv * sizeof(G1Jac));
+    if (!ctx->msm_batch_stream) JOLT_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->msm_batch_stream, hipStreamNonBlocking));
+    hipStream_t st = ctx->msm_batch_stream;
+    if (off > ctx->msm_batch_ws_cap) {
+        if (ctx->msm_batch_ws) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(st)); JOLT_HIP_TRY(ctx, hipFree(ctx->msm_batch_ws)); ctx->msm_batch_ws = nullptr; ctx->msm_batch_ws_cap = 0; }
+        JOLT_HIP_TRY(ctx, hipMalloc(&ctx->msm_batch_ws, off));
+        ctx->msm_batch_ws_cap = off;
+    }
+    if ((size_t)Wv * sizeof(G1Jac) > ctx->msm_batch_host_cap) {
+        if (ctx->msm_batch_host) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(st)); JOLT_HIP_TRY(ctx, hipHostFree(ctx->msm_batch_host)); ctx->msm_batch_host = nullptr; ctx->msm_batch_host_cap = 0; }
+        JOLT_HIP_TRY(ctx, hipHostMalloc(&ctx->msm_batch_host, (size_t)Wv * sizeof(G1Jac), hipHostMallocDefault));
+        ctx->msm_batch_host_cap = (size_t)Wv * sizeof(G1Jac);
+    }
+    char* ws = (char*)ctx->msm_batch_ws;
+    uint32_t *keys = (uint32_t*)(ws + o_keys), *sorted = (uint32_t*)(ws + o_sorted), *hist = (uint32_t*)(ws + o_hist), *offs = (uint32_t*)(ws + o_offs), *cur = (uint32_t*)(ws + o_cur),
+             *heavy = (uint32_t*)(ws + o_heavy), *hcnt = (uint32_t*)(ws + o_hcnt);
+    G1Jac *buckets = (G1Jac*)(ws + o_buckets), *part = (G1Jac*)(ws + o_part), *seg = (G1Jac*)(ws + o_seg), *wsum = (G1Jac*)(ws + o_wsum);
+    // the scalars are produced on the main stream (ev_fork is recorded there by the caller)
+    JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(hist, 0, WB * 4, st));
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(hcnt, 0, 256, st));
+    JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, WB * sizeof(G1Jac), st));
+    const unsigned gn = (unsigned)((N + kBlock - 1) / kBlock), gh = std::min<uint32_t>((heavy_cap + 3) / 4, 4096);
+    hipLaunchKernelGGL(k_msm_digits_batch, dim3(gn, count), dim3(kBlock), 0, st, bs, N, c, W, keys);
+    // counting sort through LDS, ONE workgroup per window (<= 2^18 keys, (B + 1) * 4 <= 8 KiB of counters): hundreds of windows fill the chip by themselves
+    const size_t lds_bytes = ((size_t)B + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_msm_hist_lds, dim3(1, Wv), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, N, B, hist);
+    hipLaunchKernelGGL(k_msm_scan, dim3(Wv), dim3(kBlock), 0, st, (const uint32_t*)hist, offs, cur, B, heavy_threshold, heavy, hcnt, heavy_cap);
+    hipLaunchKernelGGL(k_msm_scatter_lds, dim3(1, Wv), dim3(kSortBlock), lds_bytes, st, (const uint32_t*)keys, N, B, cur, sorted);
+    hipLaunchKernelGGL(k_msm_buckets_light<true>, dim3((unsigned)(((size_t)B + kBlock - 1) / kBlock), Wv), dim3(kBlock), 0, st, (const uint32_t*)hist, (const uint32_t*)offs,
+                       (const uint32_t*)sorted, (const G1Affine*)srs->pts, N, B, 1, heavy_threshold, buckets, (size_t)Wv);
+    hipLaunchKernelGGL(k_msm_buckets_heavy<false>, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const uint32_t*)offs,
+                       (const uint32_t*)sorted, (const G1Affine*)srs->pts, N, B, seg, LformConsts{});
+    hipLaunchKernelGGL(k_msm_heavy_combine, dim3(gh), dim3(kBlock), 0, st, (const uint32_t*)heavy, (const uint32_t*)hcnt, (const uint32_t*)hist, (const G1Jac*)seg, buckets);
+    hipLaunchKernelGGL(k_msm_window_reduce, dim3(nb, Wv), dim3(kBlock), 0, st, (const G1Jac*)buckets, B, G, part);
+    hipLaunchKernelGGL(k_msm_window_combine, dim3(Wv), dim3(64), 0, st, (const G1Jac*)part, nb, wsum);
+    JOLT_HIP_TRY(ctx, hipGetLastError());
+    JOLT_HIP_TRY(ctx, hipMemcpyAsync(ctx->msm_batch_host, wsum, (size_t)Wv * sizeof(G1Jac), hipMemcpyDeviceToHost, st));
+    job->c = c;
+    job->W = W;
+    job->queued = true;
+    return JOLT_OK;
+}
+// wait for the batch and finish on the host: per member the Horner over its W window sums
+static int32_t msm_batch_collect(jolt_ctx* ctx, const MsmBatchJob* job, const int* members, G1Jac* out) {
+    if (!job->queued) return JOLT_OK;
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->msm_batch_stream));
+    for (int k = 0; k < job->count; ++k) {
+        const G1Jac* wsum = (const G1Jac*)ctx->msm_batch_host + (size_t)k * job->W;
+        G1Jac acc = g1_identity();
+        for (int w = job->W - 1; w >= 0; --w) {
+            for (int d = 0; d < job->c; ++d) acc = g1_double(acc);
+            acc = g1_add(acc, wsum[w]);
+        }
+        out[members[k]] = acc;
+    }
+    return JOLT_OK;
+}
+
 // `count` independent MSMs over the same bases, pipelined over the four lanes (results in order).  The side lanes wait
 // for the work already queued on the main stream (the tables being committed are produced there).
 int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
@@ -389,17 +518,37 @@ int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* con
     MsmJob jobs[4];
     int32_t status = JOLT_OK;
     const size_t L = (size_t)ctx->msm_lanes;
-    for (size_t i = 0; i < count + L; ++i) {
-        int lane = (int)(i % L);
-        if (i >= L && i - L < count && status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &jobs[lane], &out[i - L]);
-        if (i < count && status == JOLT_OK) {
+    // the short prefix MSMs go as ONE batch on their own stream, queued first and collected (host Horner included) while the lanes still hold long MSMs
+    int members[kBatchMax], n_members = 0;
+    std::vector<size_t> rest;
+    for (size_t i = 0; i < count; ++i) {
+        const bool prefix = !base_offsets || base_offsets[i] == 0;
+        if (ctx->msm_batch && prefix && n[i] >= 2 && n[i] <= kBatchMaxLen && n[i] <= srs->n && n_members < kBatchMax) members[n_members++] = (int)i;
+        else rest.push_back(i);
+    }
+    if (n_members < 2) {  // nothing to share
+        rest.clear();
+        for (size_t i = 0; i < count; ++i) rest.push_back(i);
+        n_members = 0;
+    }
+    MsmBatchJob batch;
+    if (n_members) status = msm_batch_enqueue(ctx, srs, d_scalars, n, members, n_members, &batch);
+    const size_t R = rest.size();
+    for (size_t k = 0; k < R + L; ++k) {
+        int lane = (int)(k % L);
+        if (k == R && status == JOLT_OK && n_members) status = msm_batch_collect(ctx, &batch, members, out);  // every long MSM is queued: the lanes are busy
+        if (k >= L && k - L < R && status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &jobs[lane], &out[rest[k - L]]);
+        if (k < R && status == JOLT_OK) {
+            const size_t i = rest[k];
             if (base_offsets && base_offsets[i] + n[i] > srs->n) status = JOLT_ERR_SRS_TOO_SMALL;
             const jolt_srs view = jolt_srs_range_view(*srs, base_offsets && status == JOLT_OK ? base_offsets[i] : 0);  // consumed by the enqueue itself
             if (status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, &view, d_scalars[i], n[i], lane, &jobs[lane]);
         }
     }
-    if (status != JOLT_OK)
+    if (status != JOLT_OK) {
         for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->side[k]);
+        if (ctx->msm_batch_stream) (void)hipStreamSynchronize(ctx->msm_batch_stream);
+    }
     return status;
 }
 

@@ -131,7 +131,8 @@ def test_hyperkzg_pieces_match_oracle(ctx):
         want_b[: len(w)] = O.fr_add(want_b[: len(w)], O.fr_mul(w, np.repeat(qj, len(w), axis=0)))
         qj = O.fr_mul(qj, q.reshape(1, 4))
     assert np.array_equal(b, want_b)
-    for m in (1, 2, 3, 64, 65, 128, 5000):  # chunk-boundary lengths of the suffix scan
+    # chunk- and tile-boundary lengths of the suffix scan (tiles of 2048 coefficients from 65 on, a second level of tiles above 2048 * 2048 / ... : 2^17 + 5 has 65 tiles)
+    for m in (1, 2, 3, 64, 65, 128, 2047, 2048, 2049, 4096, 5000, (1 << 17) + 5):
         f = rand_fr(m, 240 + m)
         h = ctx.hyperkzg_witness_poly(ctx.upload(f), u[0])
         assert len(h) == max(m - 1, 0)
@@ -189,6 +190,43 @@ def test_hyperkzg_open_with_window_tables_is_the_oracle_proof(ctx, ell, window_b
         for t in range(3):
             assert same_point(got["w"][t], want["w"][t]), (small, t)
         tab.free()
+
+
+def test_eval3_over_many_workgroups_matches_oracle(ctx):
+    """k_horner3_strided: coefficients 256 apart per lane, lane and workgroup weights -- lengths around the 4096-coefficient workgroup tile"""
+    u = rand_fr(3, 221)
+    for m in (1, 255, 256, 257, 4095, 4096, 4097, 3 * 4096 + 17, 1 << 16):
+        f = rand_fr(m, 250 + m % 97)
+        tab = ctx.upload(f)
+        v = ctx.hyperkzg_eval3([tab], u)
+        for t in range(3):
+            assert np.array_equal(v[t, 0], O.kzg_eval_univariate(f, u[t])), (m, t)
+        tab.free()
+
+
+@pytest.mark.parametrize("ell,window_bits", [(11, 10), (12, 11), (13, 12), (16, 13)])
+def test_open_across_tile_boundaries_is_the_oracle_proof(ctx, ell, window_bits):
+    """openings whose polynomial spans 1, 2, 4 and 32 tiles of the suffix scans, on the window tables: the pair's quotient by X^2 - r^2 in one pass
+    (suffix_tiled<2>), h at r^2 through suffix_tiled<1>, the evaluations through k_horner3_strided, and the ell - 1 level commitments -- all of them short -- as
+    ONE batch of the per-window kernels (msm.hip msm_batch_enqueue): point for point the oracle's proof"""
+    n = 1 << ell
+    beta = rand_fr(1, 800 + ell)[0]
+    host_srs = O.srs_setup_from_secret(beta, n + 1)
+    srs = ctx.srs_upload(host_srs)
+    ctx.srs_precompute_windows(srs, window_bits, 1 << (ell - 2))  # the top two levels and the witness MSMs on the tables, the rest in the batch
+    evals = rand_fr(n, 810 + ell)
+    evals[n // 3:n // 3 + 40] = evals[7]  # a repeated scalar: an over-full bucket in some windows of the batch
+    point = np.stack([rand_challenge(830 + k) for k in range(ell)])
+    tab = ctx.upload(evals)
+    got = ctx.hyperkzg_open(srs, tab, point, label=12)
+    want = O.hyperkzg_open(host_srs, evals, point, label=12)
+    assert np.array_equal(got["challenges"], want["challenges"])
+    assert np.array_equal(got["v"], want["v"])
+    for i in range(ell - 1):
+        assert same_point(got["com"][i], want["com"][i]), i
+    for t in range(3):
+        assert same_point(got["w"][t], want["w"][t]), t
+    tab.free()
 
 
 @pytest.mark.parametrize("log_n", [20, 22])
