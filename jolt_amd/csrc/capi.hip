@@ -64,6 +64,7 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
     if (const char* pe = std::getenv("JOLT_POOL")) ctx->pool_enabled = std::atoi(pe) != 0;
     if (const char* la = std::getenv("JOLT_MSM_LANES")) ctx->msm_lanes = std::max(1, std::min(4, std::atoi(la)));
     if (const char* mb = std::getenv("JOLT_MSM_BATCH")) ctx->msm_batch = std::atoi(mb) != 0;
+    if (const char* po = std::getenv("JOLT_MSM_PAIR_OVERLAP")) ctx->msm_pair_overlap = std::atoi(po) != 0;
     if (const char* fx = std::getenv("JOLT_MSM_FIXED")) ctx->msm_fixed = std::atoi(fx) != 0;
     if (const char* sg = std::getenv("JOLT_MSM_STAGGER")) ctx->msm_stagger = std::atoi(sg) != 0;
     if (const char* gr = std::getenv("JOLT_FX_REDUCE")) ctx->msm_fx_grid_reduce = std::atoi(gr) != 0;
@@ -157,6 +158,8 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     }
     if (ctx->msm_batch_stream) { (void)hipStreamSynchronize(ctx->msm_batch_stream); (void)hipStreamDestroy(ctx->msm_batch_stream); }
     if (ctx->msm_batch_ws) (void)hipFree(ctx->msm_batch_ws);
+    if (ctx->msm_aux_stream) { (void)hipStreamSynchronize(ctx->msm_aux_stream); (void)hipStreamDestroy(ctx->msm_aux_stream); }
+    for (auto& pair : ctx->ev_aux) for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
     if (ctx->msm_batch_host) (void)hipHostFree(ctx->msm_batch_host);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);

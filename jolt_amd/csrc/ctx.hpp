@@ -60,6 +60,10 @@ struct jolt_ctx {
     void* msm_batch_host = nullptr;
     size_t msm_batch_host_cap = 0;
     bool msm_batch = true;  // JOLT_MSM_BATCH=0: every short MSM on its own (A/B)
+    // a pair of fixed-base MSMs over one sort (msm_fixed.hip): the first result's reduction runs here, under the second pass's bucket sums
+    hipStream_t msm_aux_stream = nullptr;
+    hipEvent_t ev_aux[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    bool msm_pair_overlap = true;  // JOLT_MSM_PAIR_OVERLAP=0: reduction between the two passes (A/B)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // Sort token (JOLT_MSM_STAGGER): the partition / sort phase of a fixed-base MSM is HBM-bound and its bucket sums are bound by
     // integer multiply-adds, so concurrent lanes only gain when one lane's sort runs under ANOTHER lane's bucket sums.  Equal MSMs

@@ -102,9 +102,12 @@ static __global__ __launch_bounds__(kBlock) void k_horner3(const Fr* __restrict_
     block_reduce_store<3>(acc, partials);
 }
 
-// The same sums with COALESCED loads (the plain, non-subtree case): thread t of a workgroup takes the coefficients base + 256 e + t, e < 16 -- adjacent lanes on
+// The same sums with coalesced loads (the plain, non-subtree case): thread t of a workgroup takes the coefficients base + 256 e + t, e < 16 -- adjacent lanes on
 // adjacent coefficients in every load -- as a polynomial in x^256, weighs it with u^t (lane_weights: u^tid) and the workgroup with (u^4096)^blockIdx.
-// (k_horner3 gives a lane 16 CONSECUTIVE coefficients: every load instruction touches 64 lines 512 bytes apart.)
+// The kernel is bound by its field multiplications (75 G/s measured at three per coefficient), not by the loads, so what pays is PLUS_MINUS: for u_1 = -u_0 (the points
+// r and -r of an opening, kzg.rs:84-85) the polynomial in x^256 takes the same value at both, and the second point costs a sign per lane instead of a multiplication per
+// coefficient: two multiplications per coefficient instead of three.
+template <bool PLUS_MINUS>
 static __global__ __launch_bounds__(kBlock) void k_horner3_strided(const Fr* __restrict__ c, size_t n, Fr3 u256, const Fr* __restrict__ lane_weights /* u^tid */,
                                                                    Fr3 u_block /* u^4096 */, Fr* __restrict__ partials) {
     __shared__ Fr block_weight[3];
@@ -120,11 +123,14 @@ static __global__ __launch_bounds__(kBlock) void k_horner3_strided(const Fr* __r
 #pragma unroll
     for (int e = kHornerChunk - 2; e >= 0; --e) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = add(mul(acc[t], u256.v[t]), ci[e]);
+        for (int t = 0; t < 3; ++t)
+            if (!(PLUS_MINUS && t == 1)) acc[t] = add(mul(acc[t], u256.v[t]), ci[e]);
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mul(mul(acc[t], ld_fr(lane_weights + t * kBlock + threadIdx.x)), block_weight[t]);
+    for (int t = 0; t < 3; ++t)
+        if (!(PLUS_MINUS && t == 1)) acc[t] = mul(mul(acc[t], ld_fr(lane_weights + t * kBlock + threadIdx.x)), block_weight[t]);
+    if (PLUS_MINUS) acc[1] = (threadIdx.x & 1) ? neg(acc[0]) : acc[0];  // (-u)^(4096 b + 256 e + t) = (-1)^t u^(...)
     block_reduce_store<3>(acc, partials);
 }
 
@@ -151,223 +157,84 @@ static int scan_chunk_log() {
     static int v = [] { const char* e = std::getenv("JOLT_SCAN_CHUNK"); int c = e ? std::atoi(e) : 64; int lg = 0; while ((1 << (lg + 1)) <= c) ++lg; return std::max(1, std::min(8, lg)); }();
     return v;
 }
-// heads[c] = Horner of chunk c with zero carry-in: sum_{k in chunk} a[k] mu^(k - chunk_start)
-static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __restrict__ a, size_t m, Fr mu, Fr* __restrict__ heads, size_t nchunks, size_t kScanChunk) {
+// LANES interleaved chains: s[k] = a[k] + mu s[k + LANES].  LANES = 1 is the suffix Horner of a witness polynomial (kzg.rs:39-44); LANES = 2 runs the even and the odd
+// coefficients as two chains, which divides by (X^2 - mu) in ONE pass -- the pair of witness polynomials at r and -r of an opening share that quotient
+// (hyperkzg_open_impl).  A chunk is kScanChunk positions of EVERY chain (kScanChunk * LANES consecutive coefficients); heads / S hold LANES values per chunk.
+// The scans are bound by their two field multiplications per coefficient (one per pass), not by the access pattern: a version through LDS tiles (coalesced loads and
+// stores, chains of 8) needed 3.1 multiplications per coefficient for its in-tile scan and measured no faster (profiles/r04_open_tiled_scan_ab.txt).
+// heads[c * LANES + l] = Horner of chunk c of chain l with zero carry-in
+template <int LANES>
+static __global__ __launch_bounds__(kBlock) void k_suffix_heads(const Fr* __restrict__ a, size_t m /* positions per chain */, Fr mu, Fr* __restrict__ heads, size_t nchunks, size_t kScanChunk) {
     size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (c >= nchunks) return;
     size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
-    Fr acc = Fr::zero();
-    for (size_t k = hi; k-- > lo;) acc = add(mul(acc, mu), ld_fr(a + k));
-    st_fr(heads + c, acc);
+    Fr acc[LANES];
+#pragma unroll
+    for (int l = 0; l < LANES; ++l) acc[l] = Fr::zero();
+    for (size_t k = hi; k-- > lo;) {
+#pragma unroll
+        for (int l = 0; l < LANES; ++l) acc[l] = add(mul(acc[l], mu), ld_fr(a + k * LANES + l));
+    }
+#pragma unroll
+    for (int l = 0; l < LANES; ++l) st_fr(heads + c * LANES + l, acc[l]);
 }
-// s[k] = a[k] + mu*s[k+1] inside chunk c, starting from the true carry-in S[c+1] (the last chunk: `carry`, the value entering the
-// array from above -- zero for a whole polynomial, the suffix evaluation of the segments above for one segment of a sharded one);
-// writes s[k] to out[k - shift] (k >= shift)
+// s inside chunk c, starting from the true carry-in S[(c + 1) * LANES + l] (the last chunk: `carry`, the value entering the array from above -- zero for a whole
+// polynomial, the suffix evaluation of the segments above for one segment of a sharded one; LANES = 1 only); writes s[k] to out[k - shift] (k >= shift, in coefficients)
+template <int LANES>
 static __global__ __launch_bounds__(kBlock) void k_suffix_apply(const Fr* __restrict__ a, size_t m, Fr mu, const Fr* __restrict__ S, size_t nchunks,
                                                                 Fr* __restrict__ out, size_t shift, size_t kScanChunk, Fr carry) {
     size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (c >= nchunks) return;
     size_t lo = c * kScanChunk, hi = lo + kScanChunk < m ? lo + kScanChunk : m;
-    Fr acc = (S != nullptr && c + 1 < nchunks) ? ld_fr(S + c + 1) : carry;
+    Fr acc[LANES];
+#pragma unroll
+    for (int l = 0; l < LANES; ++l) acc[l] = (S != nullptr && c + 1 < nchunks) ? ld_fr(S + (c + 1) * LANES + l) : carry;
     for (size_t k = hi; k-- > lo;) {
-        acc = add(mul(acc, mu), ld_fr(a + k));
-        if (k >= shift) st_fr(out + (k - shift), acc);
-    }
-}
-
-// ---- the same scan through LDS tiles: coalesced loads and stores, chains of 8 instead of 64 ---------------------------------------------------------------------
-// A workgroup owns a tile of kTile consecutive coefficients (loaded with adjacent lanes on adjacent coefficients, written back the same way); inside the tile a
-// thread owns kTileE of them.  LANES = 2 runs the recurrence s[k] = a[k] + mu s[k + 2] -- two interleaved chains, the even and the odd coefficients -- which is
-// the quotient by (X^2 - mu) in ONE pass (the witness pair at r / -r of an opening: hyperkzg_open_impl); LANES = 1 is the plain suffix Horner.
-//   chain l, position i  <->  tile index i * LANES + l;   thread t: chain t / (256 / LANES), positions [8 j, 8 j + 8) with j = t % (256 / LANES)
-// k_suffix_tile_heads: per thread the Horner value of its 8 positions with zero carry-in (kept in `thread_heads` for the apply pass), per tile and chain the value of
-// the whole chain (a tree over the threads with the weights pw[s] = mu^(8 * 2^s)).  The tile values are scanned by the same pair of kernels one level up
-// (multiplier mu^(kTile / LANES)); k_suffix_tile_apply then scans the thread heads inside the tile (Hillis-Steele, 8 steps), runs every thread's 8 positions again
-// from its true carry-in and writes the tile out.
-constexpr int kTileE = 8, kTile = kBlock * kTileE;
-struct TilePowers {
-    Fr pw[8];  // mu^(kTileE * 2^s)
-};
-// LDS slot of tile index idx: the low three bits are XORed with the thread row, so that the coalesced column accesses (adjacent lanes, adjacent idx) and the row
-// accesses (adjacent lanes, 8 * LANES apart) both spread over the banks without padding -- the tile is exactly 64 KiB and two workgroups share a CU
-template <int LANES>
-__device__ __forceinline__ uint32_t tile_slot(uint32_t idx) { return idx ^ ((idx / (kTileE * LANES)) & 7u); }
-constexpr size_t kTileLds = (size_t)kTile * sizeof(Fr);
-
-template <int LANES>
-__device__ __forceinline__ void tile_load(Fr* __restrict__ sh, const Fr* __restrict__ a, size_t m, size_t base) {
 #pragma unroll
-    for (int e = 0; e < kTileE; ++e) {
-        const uint32_t idx = (uint32_t)e * kBlock + threadIdx.x;
-        const size_t g = base + idx;
-        sh[tile_slot<LANES>(idx)] = g < m ? ld_fr(a + g) : Fr::zero();
-    }
-}
-template <int LANES>
-static __global__ __launch_bounds__(kBlock) void k_suffix_tile_heads(const Fr* __restrict__ a, size_t m, Fr mu, TilePowers tp, Fr* __restrict__ thread_heads, Fr* __restrict__ tile_heads) {
-    extern __shared__ __align__(16) unsigned char tile_raw[];
-    Fr* sh = reinterpret_cast<Fr*>(tile_raw);
-    __shared__ Fr tree[kBlock];
-    const size_t base = (size_t)blockIdx.x * kTile;
-    tile_load<LANES>(sh, a, m, base);
-    __syncthreads();
-    constexpr uint32_t per_chain = kBlock / LANES;
-    const uint32_t l = threadIdx.x / per_chain, j = threadIdx.x % per_chain;
-    Fr acc = Fr::zero();
-#pragma unroll
-    for (int e = kTileE - 1; e >= 0; --e) acc = add(mul(acc, mu), sh[tile_slot<LANES>((j * kTileE + e) * LANES + l)]);
-    st_fr(thread_heads + (size_t)blockIdx.x * kBlock + threadIdx.x, acc);
-    tree[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 0; s < 8; ++s) {
-        const uint32_t span = 1u << s;
-        if (2 * span > per_chain) break;
-        if ((j & (2 * span - 1)) == 0) tree[threadIdx.x] = add(tree[threadIdx.x], mul(tree[threadIdx.x + span], tp.pw[s]));
-        __syncthreads();
-    }
-    if (j == 0) st_fr(tile_heads + (size_t)blockIdx.x * LANES + l, tree[threadIdx.x]);
-}
-// S: the tile-level scan (S[c * LANES + l] = the value of chain l at the first position of tile c), nullptr for a single tile; carry: LANES = 1 only
-template <int LANES>
-static __global__ __launch_bounds__(kBlock) void k_suffix_tile_apply(const Fr* __restrict__ a, size_t m, Fr mu, TilePowers tp, const Fr* __restrict__ thread_heads,
-                                                                     const Fr* __restrict__ S, size_t ntiles, Fr* __restrict__ out, size_t shift, Fr carry) {
-    extern __shared__ __align__(16) unsigned char tile_raw[];
-    Fr* sh = reinterpret_cast<Fr*>(tile_raw);
-    __shared__ Fr scan[kBlock];
-    const size_t base = (size_t)blockIdx.x * kTile;
-    tile_load<LANES>(sh, a, m, base);
-    constexpr uint32_t per_chain = kBlock / LANES;
-    const uint32_t l = threadIdx.x / per_chain, j = threadIdx.x % per_chain;
-    // cin: the value entering chain l behind this tile's last position -- the next tile's scan value; behind the LAST tile the caller's carry (LANES = 1)
-    const bool last_tile = (size_t)blockIdx.x + 1 == ntiles;
-    Fr cin = last_tile ? Fr::zero() : ld_fr(S + ((size_t)blockIdx.x + 1) * LANES + l);
-    __syncthreads();
-    Fr head;
-    if (LANES == 1 && last_tile && !(carry == Fr::zero())) {  // workgroup-uniform
-        // the carry enters right behind a[m - 1]: in a partial tile as one more coefficient at tile index m - base (the padding behind it is zero), else as cin
-        const size_t tail = m - base;  // 1 .. kTile
-        if (tail < (size_t)kTile) { if (threadIdx.x == 0) sh[tile_slot<LANES>((uint32_t)tail)] = carry; }
-        else cin = carry;
-        __syncthreads();
-        head = Fr::zero();  // the stored heads do not know the carry
-#pragma unroll
-        for (int e = kTileE - 1; e >= 0; --e) head = add(mul(head, mu), sh[tile_slot<LANES>((j * kTileE + e) * LANES + l)]);
-    } else {
-        head = ld_fr(thread_heads + (size_t)blockIdx.x * kBlock + threadIdx.x);
-    }
-    // inclusive suffix scan of the thread heads along the chain (Hillis-Steele): v_j = sum_{j' >= j} head_j' mu^(8 (j' - j)); cin rides in the last thread's head
-    // with the weight mu^8, which makes v_j the value of the chain at this thread's first position
-    Fr v = j + 1 == per_chain ? add(head, mul(cin, tp.pw[0])) : head;
-    scan[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 0; s < 8; ++s) {
-        const uint32_t span = 1u << s;
-        if (span >= per_chain) break;
-        const bool has = j + span < per_chain;
-        Fr o = Fr::zero();
-        if (has) o = scan[threadIdx.x + span];
-        __syncthreads();
-        if (has) {
-            v = add(v, mul(o, tp.pw[s]));
-            scan[threadIdx.x] = v;
+        for (int l = LANES - 1; l >= 0; --l) {
+            acc[l] = add(mul(acc[l], mu), ld_fr(a + k * LANES + l));
+            const size_t g = k * LANES + l;
+            if (g >= shift) st_fr(out + (g - shift), acc[l]);
         }
-        __syncthreads();
-    }
-    // this thread's carry-in = the chain's value at the NEXT thread's first position
-    Fr acc = j + 1 < per_chain ? scan[threadIdx.x + 1] : cin;
-#pragma unroll
-    for (int e = kTileE - 1; e >= 0; --e) {
-        const uint32_t slot = tile_slot<LANES>((j * kTileE + e) * LANES + l);
-        acc = add(mul(acc, mu), sh[slot]);
-        sh[slot] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kTileE; ++e) {
-        const uint32_t idx = (uint32_t)e * kBlock + threadIdx.x;
-        const size_t g = base + idx;
-        if (g < m && g >= shift) st_fr(out + (g - shift), sh[tile_slot<LANES>(idx)]);
     }
 }
 
-int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift, const Fr& carry);
-// s[k] = a[k] + mu s[k + LANES] over a (length m, a multiple of LANES), written to out[k - shift]; carry (LANES = 1): the value entering behind a[m - 1]
+// s[k] = a[k] + mu s[k + LANES] over the m coefficients of a (m a multiple of LANES), written to out[k - shift]
 template <int LANES>
-int32_t suffix_tiled(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift, const Fr& carry) {
+int32_t suffix_scan(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift, const Fr& carry) {
     if (m % LANES) return JOLT_ERR_UNSUPPORTED;
     if (LANES != 1 && !(carry == Fr::zero())) return JOLT_ERR_UNSUPPORTED;
-    const size_t ntiles = (m + kTile - 1) / kTile;
-    if (!(carry == Fr::zero()) && ntiles > 1 && m % kTile) return JOLT_ERR_UNSUPPORTED;  // the carry enters the tile-level recurrence behind a FULL last tile
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_suffix_tile_heads<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_suffix_tile_apply<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds);
-        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return JOLT_ERR_UNSUPPORTED; }
-        attr_set = true;
-    }
-    TilePowers tp;
-    {
-        Fr p = mu;
-        for (int i = 0; i < 3; ++i) p = sqr(p);  // mu^8 = mu^kTileE
-        for (int s = 0; s < 8; ++s) { tp.pw[s] = p; p = sqr(p); }
-    }
-    Fr *thread_heads = nullptr, *tile_heads = nullptr, *S = nullptr;
-    JOLT_TRY(jolt_internal_dev_alloc(ctx, ntiles * kBlock * sizeof(Fr), (void**)&thread_heads));
-    auto release = [&]() { jolt_internal_dev_free(ctx, thread_heads); if (tile_heads) jolt_internal_dev_free(ctx, tile_heads); if (S) jolt_internal_dev_free(ctx, S); };
-    if (jolt_internal_dev_alloc(ctx, ntiles * LANES * sizeof(Fr), (void**)&tile_heads) != JOLT_OK || jolt_internal_dev_alloc(ctx, ntiles * LANES * sizeof(Fr), (void**)&S) != JOLT_OK) {
-        release();
-        return JOLT_ERR_OOM;
-    }
-    hipLaunchKernelGGL(k_suffix_tile_heads<LANES>, dim3((unsigned)ntiles), dim3(kBlock), kTileLds, ctx->stream, a, m, mu, tp, thread_heads, tile_heads);
-    int32_t s = hipGetLastError() == hipSuccess ? JOLT_OK : JOLT_ERR_HIP;
-    if (s == JOLT_OK && ntiles > 1) {
-        Fr mu_tile = mu;  // mu^(kTile / LANES)
-        for (int i = 0; (1 << i) < kTile / LANES; ++i) mu_tile = sqr(mu_tile);
-        // the tile values form LANES interleaved chains again: the same recurrence one level up (the carry enters behind the last tile)
-        s = LANES == 1 ? suffix_horner(ctx, tile_heads, ntiles, mu_tile, S, 0, carry) : suffix_tiled<LANES>(ctx, tile_heads, ntiles * LANES, mu_tile, S, 0, Fr::zero());
-    }
-    if (s == JOLT_OK) {
-        hipLaunchKernelGGL(k_suffix_tile_apply<LANES>, dim3((unsigned)ntiles), dim3(kBlock), kTileLds, ctx->stream, a, m, mu, tp, (const Fr*)thread_heads,
-                           ntiles > 1 ? (const Fr*)S : (const Fr*)nullptr, ntiles, out, shift, carry);
-        if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
-    }
-    release();  // pool blocks: reused in stream order
-    return s;
-}
-
-// s = suffix Horner of a (length m) with multiplier mu, written to out[k - shift]
-int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift, const Fr& carry) {
+    const size_t positions = m / LANES;  // per chain
     // a non-zero carry enters the chunk-level recurrence with the weight mu^chunk: the last chunk must be full (segments of a sharded
     // polynomial are powers of two long)
     if (!(carry == Fr::zero()) && (m & (m - 1)) != 0) return JOLT_ERR_UNSUPPORTED;
-    static const bool tiled = !(std::getenv("JOLT_SCAN_TILED") && std::atoi(std::getenv("JOLT_SCAN_TILED")) == 0);
-    if (tiled && m > 64) {
-        const int32_t ts = suffix_tiled<1>(ctx, a, m, mu, out, shift, carry);
-        if (ts != JOLT_ERR_UNSUPPORTED) return ts;
-    }
     const int chunk_log = scan_chunk_log();
     const size_t kScanChunk = (size_t)1 << chunk_log;
-    size_t nchunks = (m + kScanChunk - 1) / kScanChunk;
+    size_t nchunks = (positions + kScanChunk - 1) / kScanChunk;
     unsigned grid = (unsigned)((nchunks + kBlock - 1) / kBlock);
     if (nchunks <= 1) {
-        hipLaunchKernelGGL(k_suffix_apply, dim3(1), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)nullptr, (size_t)1, out, shift, kScanChunk, carry);
+        hipLaunchKernelGGL(k_suffix_apply<LANES>, dim3(1), dim3(kBlock), 0, ctx->stream, a, positions, mu, (const Fr*)nullptr, (size_t)1, out, shift, kScanChunk, carry);
         JOLT_HIP_TRY(ctx, hipGetLastError());
         return JOLT_OK;
     }
     Fr *heads = nullptr, *S = nullptr;
-    JOLT_TRY(jolt_internal_dev_alloc(ctx, nchunks * sizeof(Fr), (void**)&heads));
-    if (jolt_internal_dev_alloc(ctx, nchunks * sizeof(Fr), (void**)&S) != JOLT_OK) { jolt_internal_dev_free(ctx, heads); return JOLT_ERR_OOM; }
-    hipLaunchKernelGGL(k_suffix_heads, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, heads, nchunks, kScanChunk);
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, nchunks * LANES * sizeof(Fr), (void**)&heads));
+    if (jolt_internal_dev_alloc(ctx, nchunks * LANES * sizeof(Fr), (void**)&S) != JOLT_OK) { jolt_internal_dev_free(ctx, heads); return JOLT_ERR_OOM; }
+    hipLaunchKernelGGL(k_suffix_heads<LANES>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, positions, mu, heads, nchunks, kScanChunk);
     Fr mu_c = mu;
     for (int i = 0; i < chunk_log; ++i) mu_c = sqr(mu_c);  // mu^chunk
-    int32_t s = suffix_horner(ctx, heads, nchunks, mu_c, S, 0, carry);  // the carry enters the chunk-level recurrence at the same place
+    int32_t s = suffix_scan<LANES>(ctx, heads, nchunks * LANES, mu_c, S, 0, carry);  // the chunk values form LANES chains again; the carry enters at the same place
     if (s == JOLT_OK) {
-        hipLaunchKernelGGL(k_suffix_apply, dim3(grid), dim3(kBlock), 0, ctx->stream, a, m, mu, (const Fr*)S, nchunks, out, shift, kScanChunk, carry);
+        hipLaunchKernelGGL(k_suffix_apply<LANES>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, positions, mu, (const Fr*)S, nchunks, out, shift, kScanChunk, carry);
         if (hipGetLastError() != hipSuccess) s = JOLT_ERR_HIP;
     }
     jolt_internal_dev_free(ctx, heads);  // pool blocks: reused in stream order, no synchronisation
     jolt_internal_dev_free(ctx, S);
     return s;
+}
+// s = suffix Horner of a (length m) with multiplier mu, written to out[k - shift]
+int32_t suffix_horner(jolt_ctx* ctx, const Fr* a, size_t m, const Fr& mu, Fr* out, size_t shift, const Fr& carry = Fr::zero()) {
+    return suffix_scan<1>(ctx, a, m, mu, out, shift, carry);
 }
 
 }  // namespace
@@ -415,6 +282,7 @@ extern "C" int32_t jolt_hyperkzg_eval3(jolt_ctx* ctx, jolt_table* const* levels,
         u4096.v[t] = p;
     }
     static const bool strided = !(std::getenv("JOLT_HORNER_STRIDED") && std::atoi(std::getenv("JOLT_HORNER_STRIDED")) == 0);
+    const bool plus_minus = uu.v[1] == neg(uu.v[0]);
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, 1, 3 * ell + 8));
     Fr* chunk_weights = nullptr;
     JOLT_TRY(jolt_internal_dev_alloc(ctx, 3 * kBlock * sizeof(Fr), (void**)&chunk_weights));
@@ -426,8 +294,10 @@ extern "C" int32_t jolt_hyperkzg_eval3(jolt_ctx* ctx, jolt_table* const* levels,
         size_t per_block = (size_t)kBlock * kHornerChunk;
         int grid = (int)std::max<size_t>(1, (t->len + per_block - 1) / per_block);
         JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 3, 3 * ell + 8));
-        if (strided)
-            hipLaunchKernelGGL(k_horner3_strided, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, u256, (const Fr*)chunk_weights, u4096, ctx->d_partials);
+        if (strided && plus_minus)
+            hipLaunchKernelGGL(k_horner3_strided<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, u256, (const Fr*)chunk_weights, u4096, ctx->d_partials);
+        else if (strided)
+            hipLaunchKernelGGL(k_horner3_strided<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, u256, (const Fr*)chunk_weights, u4096, ctx->d_partials);
         else
             hipLaunchKernelGGL(k_horner3<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const Fr*)t->data(), t->len, uu, (const Fr*)chunk_weights, u4096, ctx->d_partials, TermMap{});
         JOLT_HIP_TRY(ctx, hipGetLastError());
@@ -480,7 +350,7 @@ extern "C" int32_t jolt_hyperkzg_witness_poly(jolt_ctx* ctx, const jolt_table* f
     JOLT_TRY(jolt_internal_table_new(ctx, d > 1 ? d - 1 : 0, &h));
     if (d > 1) {
         // h[k] = s[k+1] with s[k] = f[k] + u*s[k+1]  (kzg.rs:39-44)
-        int32_t s = suffix_horner(ctx, f->data(), d, uu, h->data(), 1, Fr::zero());
+        int32_t s = suffix_horner(ctx, f->data(), d, uu, h->data(), 1);
         if (s != JOLT_OK) { jolt_table_free(ctx, h); return s; }
     }
     *out = h;
@@ -658,7 +528,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         //   w[0] = Cxq + r Cq + alpha G_0,   w[1] = Cxq - r Cq + alpha G_0
         // -- the same group elements kzg.rs:108-116 commits to, from two bucket passes over one digit sort (jolt_internal_msm_fixed_enqueue, pair_shift) instead of two
         // full MSMs.  q = (h_r - alpha) / (X + r): the quotient recurrence again, whose remainder h_r[0] + q[0] (-r) is alpha.  h_(r^2) keeps its own MSM, on a second lane.
-        // q in ONE pass over B when its length is even (every opening of >= 2 variables): q[k] = B[k + 2] + r^2 q[k + 2], two interleaved chains (suffix_tiled<2>), and
+        // q in ONE pass over B when its length is even (every opening of >= 2 variables): q[k] = B[k + 2] + r^2 q[k + 2], two interleaved chains (suffix_scan<2>), and
         // alpha = B[1] + r^2 q[1] (the X^1 coefficient of B = q (X^2 - r^2) + alpha X + beta); otherwise two divisions, by (X - r) and then by (X + r)
         jolt_table *h0 = nullptr, *qp = nullptr, *h2 = nullptr;
         static const bool one_pass = !(std::getenv("JOLT_KZG_QUOTIENT2") && std::atoi(std::getenv("JOLT_KZG_QUOTIENT2")) == 0);
@@ -666,7 +536,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         if (one_pass && b_poly->len % 2 == 0) {
             s = jolt_internal_table_new(ctx, b_poly->len - 2, &qp);
             if (s == JOLT_OK) {
-                const int32_t qs = suffix_tiled<2>(ctx, b_poly->data(), b_poly->len, u[2], qp->data(), 2, Fr::zero());
+                const int32_t qs = suffix_scan<2>(ctx, b_poly->data(), b_poly->len, u[2], qp->data(), 2, Fr::zero());
                 if (qs == JOLT_OK) direct = true;
                 else if (qs == JOLT_ERR_UNSUPPORTED) { jolt_table_free(ctx, qp); qp = nullptr; }
                 else s = qs;

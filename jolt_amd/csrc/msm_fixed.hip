@@ -398,8 +398,9 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
         for (int w = 0; w < kPartPerS; ++w) {
             if (w >= W) break;  // kernel-uniform
             const uint32_t mag = keys[w] & 0x7FFFFFFFu;
-            WaveAgg ag = wave_aggregate(mag >> LO, mag != 0);
-            if (ag.do_atomic) atomicAdd(&fx_sh[mag >> LO], ag.count);
+            // plain LDS atomics: the ballot peeling of wave_aggregate cost ~60 instructions per window and scalar (660 of the ~1100 this loop spent per scalar) to save
+            // same-address serialisation that the LDS resolves in about the same time when it does occur (runs of equal scalars)
+            if (mag) atomicAdd(&fx_sh[mag >> LO], 1u);
         }
     }
     __syncthreads();
@@ -970,6 +971,11 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
                  o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
                  o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4),
                  o_grouped = take(soa ? total * 6 + 512 : (ctx->msm_fx_partition == 2 ? total * 8 : 256)), o_gcur = take(kPartBins * 4);
+    // a pair's second pass sums into its OWN bucket set and reduces through its own scratch, so that the first pass's reduction (latency bound: chains of additions on
+    // a few thousand threads) runs on the auxiliary stream under the second pass's bucket sums instead of between the two
+    const bool overlap_reduction = pair_shift != 0 && grid_reduce && ctx->msm_pair_overlap;
+    const size_t o_buckets2 = take(overlap_reduction ? n_buckets * sizeof(G1Jac) : 256), o_red2 = take(overlap_reduction ? red_points * sizeof(G1Jac) : 256),
+                 o_wsum2 = take(2 * sizeof(G1Jac));
     hipStream_t st = lane == 0 ? ctx->stream : ctx->side[lane - 1];
     // phases: sort (HBM bound) -> bucket sums (multiply-add bound) -> reduction (latency bound).  One stream by default; with JOLT_MSM_CU_SPLIT the
     // sort and the reduction run on the lane's CU-masked "sort" stream and the bucket sums on its "bucket" stream (ctx.hpp), chained by events
@@ -1121,8 +1127,8 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned bucket_grid = (unsigned)((n_buckets + kBlock - 1) / kBlock);
     const int per_result = grid_reduce ? 2 : 1;  // partial sums a result leaves in msm_host for the collect step's Horner
     if ((size_t)per_result * (pair_shift ? 2 : 1) > kMsmHostEntries) return JOLT_ERR_UNSUPPORTED;
-    // bucket sums + reduction over the sorted lists against the tables at `bases`; the result's partial sums go to msm_host[lane][slot ..]
-    auto sums_and_reduction = [&](const G1Affine* bases, int slot) -> int32_t {
+    // bucket sums over the sorted lists against the tables at `bases` into `buckets` (on the bucket stream) ...
+    auto bucket_sums = [&](const G1Affine* bases, G1Jac* buckets) -> int32_t {
         if (srs->pre_lform) {
             hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                                (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
@@ -1136,6 +1142,11 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         }
         hipLaunchKernelGGL(k_fx_heavy_combine, dim3(std::min<uint32_t>(gh, 2048)), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
                            (const G1Jac*)seg, buckets);
+        JOLT_HIP_TRY(ctx, hipGetLastError());
+        return JOLT_OK;
+    };
+    // ... and their reduction on `bst` (any stream ordered behind the sums), through the scratch at o_red / wsum; the result's partial sums go to msm_host[lane][slot ..]
+    auto reduction = [&](const G1Jac* buckets, size_t o_red, G1Jac* wsum, int slot, hipStream_t bst) -> int32_t {
         if (grid_reduce) {
             G1Jac* colpart = (G1Jac*)(ws + o_red);
             G1Jac* rowpart = colpart + (size_t)red_chunks * kRedCols;
@@ -1164,10 +1175,26 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         JOLT_HIP_TRY(ctx, hipMemcpyAsync((G1Jac*)ctx->msm_host[lane] + slot, wsum, (size_t)per_result * sizeof(G1Jac), hipMemcpyDeviceToHost, bst));
         return JOLT_OK;
     };
-    JOLT_TRY(sums_and_reduction((const G1Affine*)srs->pre, 0));
-    if (pair_shift) {
+    JOLT_TRY(bucket_sums((const G1Affine*)srs->pre, buckets));
+    if (!pair_shift) {
+        JOLT_TRY(reduction(buckets, o_red, wsum, 0, bst));
+    } else if (overlap_reduction) {
+        if (!ctx->msm_aux_stream) JOLT_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->msm_aux_stream, hipStreamNonBlocking));
+        if (!ctx->ev_aux[lane][0]) for (hipEvent_t& ev : ctx->ev_aux[lane]) JOLT_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        G1Jac* buckets2 = (G1Jac*)(ws + o_buckets2);
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[lane][0], bst));  // the first pass's buckets are complete
+        JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->msm_aux_stream, ctx->ev_aux[lane][0], 0));
+        JOLT_TRY(reduction(buckets, o_red, wsum, 0, ctx->msm_aux_stream));
+        JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[lane][1], ctx->msm_aux_stream));
+        JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets2, 0, n_buckets * sizeof(G1Jac), bst));
+        JOLT_TRY(bucket_sums((const G1Affine*)srs->pre + pair_shift, buckets2));
+        JOLT_TRY(reduction(buckets2, o_red2, (G1Jac*)(ws + o_wsum2), per_result, bst));
+        JOLT_HIP_TRY(ctx, hipStreamWaitEvent(bst, ctx->ev_aux[lane][1], 0));  // the lane's stream covers both results (jolt_internal_msm_collect waits for it alone)
+    } else {
+        JOLT_TRY(reduction(buckets, o_red, wsum, 0, bst));
         JOLT_HIP_TRY(ctx, hipMemsetAsync(buckets, 0, n_buckets * sizeof(G1Jac), bst));  // empty buckets rely on the identity the first pass overwrote nowhere; light / heavy ones are rewritten
-        JOLT_TRY(sums_and_reduction((const G1Affine*)srs->pre + pair_shift, per_result));
+        JOLT_TRY(bucket_sums((const G1Affine*)srs->pre + pair_shift, buckets));
+        JOLT_TRY(reduction(buckets, o_red, wsum, per_result, bst));
     }
     if (split) { JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][3], bst)); JOLT_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_phase[lane][3], 0)); }
     job->n = n;

@@ -131,8 +131,8 @@ def test_hyperkzg_pieces_match_oracle(ctx):
         want_b[: len(w)] = O.fr_add(want_b[: len(w)], O.fr_mul(w, np.repeat(qj, len(w), axis=0)))
         qj = O.fr_mul(qj, q.reshape(1, 4))
     assert np.array_equal(b, want_b)
-    # chunk- and tile-boundary lengths of the suffix scan (tiles of 2048 coefficients from 65 on, a second level of tiles above 2048 * 2048 / ... : 2^17 + 5 has 65 tiles)
-    for m in (1, 2, 3, 64, 65, 128, 2047, 2048, 2049, 4096, 5000, (1 << 17) + 5):
+    # chunk-boundary lengths of the suffix scan (chunks of 64 coefficients; 4097 and 2^17 + 5 need a second level of chunk values)
+    for m in (1, 2, 3, 64, 65, 128, 4096, 4097, 5000, (1 << 17) + 5):
         f = rand_fr(m, 240 + m)
         h = ctx.hyperkzg_witness_poly(ctx.upload(f), u[0])
         assert len(h) == max(m - 1, 0)
@@ -205,9 +205,9 @@ def test_eval3_over_many_workgroups_matches_oracle(ctx):
 
 
 @pytest.mark.parametrize("ell,window_bits", [(11, 10), (12, 11), (13, 12), (16, 13)])
-def test_open_across_tile_boundaries_is_the_oracle_proof(ctx, ell, window_bits):
-    """openings whose polynomial spans 1, 2, 4 and 32 tiles of the suffix scans, on the window tables: the pair's quotient by X^2 - r^2 in one pass
-    (suffix_tiled<2>), h at r^2 through suffix_tiled<1>, the evaluations through k_horner3_strided, and the ell - 1 level commitments -- all of them short -- as
+def test_open_with_one_pass_quotient_and_batched_levels_is_the_oracle_proof(ctx, ell, window_bits):
+    """openings of 2^11 ... 2^16 coefficients on the window tables: the pair's quotient by X^2 - r^2 in one pass (suffix_scan<2>, one and two levels of chunk values),
+    h at r^2 through suffix_scan<1>, the evaluations at r / -r / r^2 through k_horner3_strided<PLUS_MINUS>, and the level commitments below the tables' crossover as
     ONE batch of the per-window kernels (msm.hip msm_batch_enqueue): point for point the oracle's proof"""
     n = 1 << ell
     beta = rand_fr(1, 800 + ell)[0]

@@ -24,8 +24,11 @@ point[:, 1] = 0
 point[:, 3] &= np.uint64((1 << 61) - 1)
 ctx.hyperkzg_open(srs, evals, point, label=7)
 ctx.synchronize()
-time.sleep(0.05)  # an idle gap in the kernel trace: profiles/open_exposed.py takes the last burst
-t0 = time.perf_counter()
-ctx.hyperkzg_open(srs, evals, point, label=7)
-print("open ms", round((time.perf_counter() - t0) * 1e3, 2))
+times = []
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1):
+    time.sleep(0.05)  # an idle gap in the kernel trace: profiles/open_exposed.py takes the last burst
+    t0 = time.perf_counter()
+    ctx.hyperkzg_open(srs, evals, point, label=7)
+    times.append(round((time.perf_counter() - t0) * 1e3, 2))
+print("open ms", min(times), times)
 ctx.close()
