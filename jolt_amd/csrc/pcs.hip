@@ -13,6 +13,8 @@
 // Also here: the promotion of device-resident integer columns to field tables (Polynomial::bind_to_field's From<T>,
 // crates/jolt-poly/src/dense.rs:129-142) for inputs that are already in HBM.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "ints.hpp"
 #include "msm_kernels.hip.h"
@@ -117,6 +119,37 @@ __global__ __launch_bounds__(kBlock) void k_grid_joint(JointArgs a, const Fr* __
             acc = add(acc, a.dense_one[d] ? v : mul(v, a.dense_scalar[d]));
         }
     st_fr(out + (size_t)k * cycles + j, acc);
+}
+
+// The same with ONE thread per cycle and its K row accumulators in LDS: k_grid_joint gives every (row, cycle) pair a thread that walks all the columns and adds under
+// a predicate -- with 36 columns over 16 rows nearly every wavefront executes every addition, 16 x 36 per cycle (3.4 ms at T = 2^22, bound by those additions, where
+// the 2 GiB of output take 0.4 ms).  Here a thread reads its cycle's hot addresses once and adds each coefficient into acc[hot][thread]: 36 additions per cycle.
+// acc is [K][kJointThreads] in LDS: lane t touches column t of whatever row, the bank pattern of a linear access.
+constexpr int kJointThreads = 128;
+__global__ __launch_bounds__(kJointThreads) void k_grid_joint_rows(JointArgs a, const Fr* __restrict__ scalars, size_t cycles, uint32_t K, Fr* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char joint_raw[];
+    Fr* acc = reinterpret_cast<Fr*>(joint_raw);
+    const size_t j = (size_t)blockIdx.x * kJointThreads + threadIdx.x;
+    const bool live = j < cycles;
+    for (uint32_t k = 0; k < K; ++k) acc[k * kJointThreads + threadIdx.x] = Fr::zero();
+    if (live) {
+        for (int s = 0; s < a.n_sources; ++s) {
+            for (uint32_t p = 0; p < a.n_polys[s]; ++p) {
+                const uint32_t h = hot_load(a.idx[s], (size_t)p * cycles + j, a.wide[s]);
+                if (h < K) {  // cold cycles (the sentinel) select no row
+                    Fr* slot = acc + h * kJointThreads + threadIdx.x;
+                    *slot = add(*slot, scalars[a.first[s] + p]);
+                }
+            }
+        }
+        Fr d0 = acc[threadIdx.x];
+        for (int d = 0; d < a.n_dense; ++d) {
+            Fr v = ld_fr(a.dense[d] + j);
+            d0 = add(d0, a.dense_one[d] ? v : mul(v, a.dense_scalar[d]));
+        }
+        acc[threadIdx.x] = d0;
+        for (uint32_t k = 0; k < K; ++k) st_fr(out + (size_t)k * cycles + j, acc[k * kJointThreads + threadIdx.x]);  // a thread only ever touches its own column: no barrier
+    }
 }
 
 // The same polynomial restricted to the coefficients ONE RANK owns under a sharded term assignment (term_map.hip.h), as its compact
@@ -291,7 +324,12 @@ static int32_t grid_joint_impl(jolt_ctx* ctx, const jolt_onehot* const* sources,
     int32_t st = JOLT_OK;
     if (total) st = jolt_table_upload(ctx, onehot_scalars, total, &ds);  // synchronises: the caller's array may be short-lived
     if (st != JOLT_OK) { jolt_table_free(ctx, r); return st; }
-    if (map.kind == kTermsAll)
+    static const bool by_rows = !(std::getenv("JOLT_JOINT_ROWS") && std::atoi(std::getenv("JOLT_JOINT_ROWS")) == 0);
+    const size_t rows_lds = (size_t)K * kJointThreads * sizeof(Fr);
+    if (map.kind == kTermsAll && by_rows && rows_lds <= 64 * 1024)
+        hipLaunchKernelGGL(k_grid_joint_rows, dim3((unsigned)((T + kJointThreads - 1) / kJointThreads)), dim3(kJointThreads), rows_lds, ctx->stream, a,
+                           ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, K, r->data());
+    else if (map.kind == kTermsAll)
         hipLaunchKernelGGL(k_grid_joint, dim3((unsigned)((T + kBlock - 1) / kBlock), K), dim3(kBlock), 0, ctx->stream, a, ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, r->data());
     else
         hipLaunchKernelGGL(k_grid_joint_owned, dim3((unsigned)((len + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, a, ds ? (const Fr*)ds->data() : (const Fr*)nullptr, T, len, map,

@@ -7,7 +7,8 @@
 //   bind (:1235-1282)            HighToLow bind of every 256-entry polynomial; after 8 binds the phase's eq table and the new checkpoints
 //   init_cycle_rounds (:1140-1160)  table values, gamma-combined operand values for jolt_read_raf_cycle_tables
 // Per proof this is 128 rounds of O(256 x present tables) field work -- no T-sized data -- which is why it stays on the host (the reference keeps
-// it in rayon tasks of 8 entries); the device part of a phase is one scan launch + one condensation.  Nothing here touches the device.
+// it in rayon tasks of 8 entries); the device part of a phase is one scan launch + one condensation.  HOST ONLY: nothing here touches the device; the file keeps the
+// .hip suffix because it shares field.hip.h with the kernels (one definition of the field arithmetic for both sides; hipcc emits no device code for it).
 //
 // Cost shape (all 42 tables present): per phase ~30 prefix + 94 suffix + 12 RAF polynomials of 256 entries; a round is ~60 dot products over the live half
 // (the bilinear terms of the tables' `combine`, summed term by term instead of table by table: a table's value is never formed per entry) and ~136 binds.

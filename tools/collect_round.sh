@@ -3,7 +3,7 @@
 #   bash tools/collect_round.sh r03 [notests]
 # writes gpurun_out/<tag>/...; the files to keep are then copied into profiles/ as <tag>_* (tools/keep_round.sh).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -41,6 +41,16 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"{v/1e3:10.3f} ms  {k}")
 PY
 head -16 "$OUT/seq_kernel_sums.txt"
+# the witness path: every step from packed rows in page-locked host memory (PCIe-inclusive; never `value`)
+timeout 300 python bench.py --witness upload-pinned --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_witness_upload.json" 2>/dev/null
+python -c "import json; d=json.loads(open('$OUT/bench_witness_upload.json').read().strip().splitlines()[-1]); print('witness upload', d['ms_per_step'], d['config'].get('witness'))"
+# the step's own opening: what runs while no bucket sum does (profiles/open_exposed.py), min of 3 wall times
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p_os && timeout 500 rocprofv3 --kernel-trace -d /tmp/p_os -o o -- python "$ROOT/tools/open_step.py" 22 1 > "$OUT/open_step.txt" 2>&1; \
+  f=$(find /tmp/p_os -name "*.db" | head -1); python "$ROOT/profiles/open_exposed.py" "$f" 34 > "$OUT/open_exposed_step.txt" 2>&1 )
+echo "open of the step, 3 reps: $(timeout 300 python tools/open_step.py 22 3 2>&1 | grep 'open ms')" | tee -a "$OUT/open_exposed_step.txt"
+# the stage operators' HBM traffic per kernel (counter-free trace + FETCH_SIZE / WRITE_SIZE passes)
+bash tools/pmc_extended.sh "$OUT/pmc_ext" 22 2 > /dev/null 2>&1
+head -14 "$OUT/pmc_ext/stage_operator_traffic.txt" | cut -c1-140
 # fixed-base MSM: timings (full length + prefixes) and the kernel table of one 2^26-term MSM
 JOLT_BENCH_PREFIXES="20 21 22 23 24 25" timeout 600 python tools/bench_msm_fixed.py 26 23 > "$OUT/msm_fixed.jsonl" 2> "$OUT/msm_fixed.err"
 JOLT_MSM_LANES=1 bash tools/prof_msm_fixed.sh 26 23 34 > "$OUT/msm_fixed_kernels.txt" 2>&1
@@ -51,6 +61,7 @@ bash tools/prof_sumcheck.sh 22 "$TAG/sumcheck" > "$OUT/sumcheck.log" 2>&1
 # sharded paths with every rank on this GPU (code-path / memory checks, not measurements): bench.py --gpus 2 launching itself, the two-rank
 # 2^23-coefficient subtree opening against the oracle
 JOLT_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --scale 18 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_gpus2_share_gpu.json" 2> "$OUT/bench_gpus2.err"
+grep "^{" "$OUT/bench_gpus2_share_gpu.json" > "$OUT/bench_gpus2.tmp"; mv "$OUT/bench_gpus2.tmp" "$OUT/bench_gpus2_share_gpu.json"  # the launcher's [Gloo] chatter is not part of the line
 grep "^{" "$OUT/bench_gpus2_share_gpu.json" | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('gpus 2 (one GPU shared):', d['n_gpus'], d['ms_per_step'], d['config'].get('round_exchange_ab'), d['config']['communicator'][:80])"
 timeout 900 python tools/check_subtree_scale.py 18 > "$OUT/subtree_scale.txt" 2>&1
 tail -1 "$OUT/subtree_scale.txt"

@@ -23,6 +23,9 @@ keep bind_roofline_bench.json bind_roofline_bench.json
 keep bind_roofline_kernel_stats.txt bind_roofline_kernel_stats.txt
 keep pmc_round_kernels.txt pmc_round_kernels.txt
 keep pytest_gpu.txt pytest_gpu.txt
+keep bench_witness_upload.json bench_witness_upload.json
+keep open_exposed_step.txt open_exposed_step.txt
+keep pmc_ext/stage_operator_traffic.txt stage_operator_traffic.txt
 keep build_force.txt build_force.txt
 [ -f "$SRC/bind_traffic.json" ] && cp "$SRC/bind_traffic.json" profiles/bind_traffic.json
 ls profiles | grep "^${TAG}_"
