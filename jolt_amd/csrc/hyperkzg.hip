@@ -21,6 +21,9 @@ using namespace jolt;
 
 int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out);
 int32_t jolt_internal_msm_pair_and_one(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_a, size_t n_a, size_t shift, const Fr* d_b, size_t n_b, G1Jac* out);
+int32_t jolt_internal_msm_one_begin(jolt_ctx* ctx, const jolt_srs* srs, size_t n_a, size_t shift, const Fr* d_b, size_t n_b);
+int32_t jolt_internal_msm_pair_finish(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_a, size_t n_a, size_t shift, G1Jac* out);
+void jolt_internal_msm_one_abandon(jolt_ctx* ctx);
 int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
                                const size_t* base_offsets = nullptr);
 
@@ -532,8 +535,16 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         // alpha = B[1] + r^2 q[1] (the X^1 coefficient of B = q (X^2 - r^2) + alpha X + beta); otherwise two divisions, by (X - r) and then by (X + r)
         jolt_table *h0 = nullptr, *qp = nullptr, *h2 = nullptr;
         static const bool one_pass = !(std::getenv("JOLT_KZG_QUOTIENT2") && std::atoi(std::getenv("JOLT_KZG_QUOTIENT2")) == 0);
-        bool direct = false;
-        if (one_pass && b_poly->len % 2 == 0) {
+        static const bool early_one = !(std::getenv("JOLT_KZG_EARLY") && std::atoi(std::getenv("JOLT_KZG_EARLY")) == 0);
+        bool direct = false, begun = false;
+        // h at r^2 FIRST, and its MSM enqueued on the second lane at once: its digit sort (HBM bound) runs under the scan that produces q (bound by its multiplications)
+        s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[2], &h2);
+        if (s == JOLT_OK && early_one) {
+            const int32_t bs = jolt_internal_msm_one_begin(ctx, srs, b_poly->len - 2, 1, h2->data(), h2->len);
+            if (bs == JOLT_OK) begun = true;
+            else if (bs != JOLT_ERR_UNSUPPORTED) s = bs;
+        }
+        if (s == JOLT_OK && one_pass && b_poly->len % 2 == 0) {
             s = jolt_internal_table_new(ctx, b_poly->len - 2, &qp);
             if (s == JOLT_OK) {
                 const int32_t qs = suffix_scan<2>(ctx, b_poly->data(), b_poly->len, u[2], qp->data(), 2, Fr::zero());
@@ -546,7 +557,6 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
             s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[0], &h0);
             if (s == JOLT_OK) s = jolt_hyperkzg_witness_poly(ctx, h0, &u_abi[1], &qp);
         }
-        if (s == JOLT_OK) s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[2], &h2);
         Fr a_lo, q_lo;  // direct: B[1], q[1];  else h_r[0], q[0]
         G1Affine g0;
         if (s == JOLT_OK) {
@@ -558,7 +568,9 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         }
         if (s == JOLT_OK) {
             G1Jac three[3];
-            const int32_t ps = jolt_internal_msm_pair_and_one(ctx, srs, qp->data(), qp->len, 1, h2->data(), h2->len, three);
+            const int32_t ps = begun ? jolt_internal_msm_pair_finish(ctx, srs, qp->data(), qp->len, 1, three)
+                                     : jolt_internal_msm_pair_and_one(ctx, srs, qp->data(), qp->len, 1, h2->data(), h2->len, three);
+            begun = false;
             if (ps == JOLT_OK) {
                 const Fr alpha = direct ? add(a_lo, mul(q_lo, u[2])) : add(a_lo, mul(q_lo, u[1])), r_can = from_mont(r), a_can = from_mont(alpha);
                 const G1Jac r_cq = g1_mul_canonical(three[0], r_can.l), base = g1_add(three[1], g1_mul_canonical(g1_from_affine(g0), a_can.l));
@@ -570,6 +582,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
                 s = ps;
             }
         }
+        if (begun) jolt_internal_msm_one_abandon(ctx);  // an error between begin and finish: the lane still reads h2
         for (jolt_table* t : {h0, qp, h2}) if (t) jolt_table_free(ctx, t);
         if (s != JOLT_OK) { cleanup(b_poly); return s; }
     }

@@ -572,6 +572,55 @@ int32_t jolt_internal_msm_pair_and_one(jolt_ctx* ctx, const jolt_srs* srs, const
     return status;
 }
 
+// The same three results with the SINGLE MSM started early: jolt_internal_msm_one_begin enqueues sum_i b_i P_i on lane 1 as soon as b exists (its sort then runs under
+// whatever the main stream does next -- in an opening, the scan that produces the pair's scalars), jolt_internal_msm_pair_finish enqueues the pair on lane 0 and
+// collects both.  begin returns JOLT_ERR_UNSUPPORTED, with nothing enqueued, when the pair could not take the fixed-base method anyway or there is only one lane
+// (the caller then uses jolt_internal_msm_pair_and_one or three MSMs).
+struct MsmPendingOne {
+    MsmJob job;
+};
+int32_t jolt_internal_msm_one_begin(jolt_ctx* ctx, const jolt_srs* srs, size_t n_a, size_t shift, const Fr* d_b, size_t n_b) {
+    if (shift > srs->n || n_a > srs->n - shift) return JOLT_ERR_SRS_TOO_SMALL;
+    if (n_a == 0 || !(srs->pre && ctx->msm_fixed && n_a >= srs->pre_min_n) || ctx->msm_lanes < 2 || ctx->msm_pending_one) return JOLT_ERR_UNSUPPORTED;
+    if ((size_t)srs->pre_W * n_a >= ((size_t)1 << 32)) return JOLT_ERR_UNSUPPORTED;  // what jolt_internal_msm_fixed_enqueue would refuse for the pair
+    MsmPendingOne* p = new (std::nothrow) MsmPendingOne();
+    if (!p) return JOLT_ERR_OOM;
+    int32_t status = JOLT_OK;
+    hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); status = JOLT_ERR_HIP; }
+    if (status == JOLT_OK) status = jolt_internal_msm_enqueue(ctx, srs, d_b, n_b, 1, &p->job);
+    if (status != JOLT_OK) { (void)hipStreamSynchronize(ctx->side[0]); delete p; return status; }
+    ctx->msm_pending_one = p;
+    return JOLT_OK;
+}
+// out[0], out[1]: the pair over d_a (shift as in jolt_internal_msm_pair_and_one); out[2]: the MSM begun above
+int32_t jolt_internal_msm_pair_finish(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_a, size_t n_a, size_t shift, G1Jac* out) {
+    MsmPendingOne* p = static_cast<MsmPendingOne*>(ctx->msm_pending_one);
+    if (!p) return JOLT_ERR_INVALID_ARG;
+    ctx->msm_pending_one = nullptr;
+    MsmJob pair;
+    int32_t status = jolt_internal_msm_enqueue_pair(ctx, srs, d_a, n_a, shift, 0, &pair);  // lane 0 = the main stream: ordered behind d_a's producer
+    if (status == JOLT_OK) status = jolt_internal_msm_collect(ctx, &pair, out);
+    else if (status == JOLT_ERR_UNSUPPORTED) {  // (not expected after begin's checks) two plain MSMs, the second against the shifted bases
+        status = jolt_internal_msm(ctx, srs, d_a, n_a, &out[0]);
+        const jolt_srs view = jolt_srs_range_view(*srs, shift);
+        if (status == JOLT_OK) status = jolt_internal_msm(ctx, &view, d_a, n_a, &out[1]);
+    }
+    const int32_t one_status = jolt_internal_msm_collect(ctx, &p->job, out + 2);  // always: the lane must be drained before its workspace is used again
+    delete p;
+    if (status != JOLT_OK) (void)hipStreamSynchronize(ctx->side[0]);
+    return status != JOLT_OK ? status : one_status;
+}
+// a begun MSM whose opening failed in between: drain the lane and drop the state
+void jolt_internal_msm_one_abandon(jolt_ctx* ctx) {
+    MsmPendingOne* p = static_cast<MsmPendingOne*>(ctx->msm_pending_one);
+    if (!p) return;
+    ctx->msm_pending_one = nullptr;
+    (void)hipStreamSynchronize(ctx->side[0]);
+    delete p;
+}
+
 extern "C" int32_t jolt_msm_g1_table(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, jolt_g1_t* out) {
     if (!ctx || !srs || !scalars || !out) return JOLT_ERR_INVALID_ARG;
     if (n > scalars->len) return JOLT_ERR_SIZE_MISMATCH;
