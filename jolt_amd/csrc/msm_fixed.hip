@@ -327,7 +327,8 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments(const ui
 // pass, and an entry is carried as a 4-byte value (base index | sign) plus ONLY the digit bits the remaining passes still need: 15 bits
 // (2 bytes) after the group pass, 8 bits (1 byte) after the segment pass, which the segment sort's counting pass then reads alone:
 // ~28 GB per 2^26-term MSM.
-constexpr int kPartPerS = 12;  // entries per thread of the scalar-fed group pass = windows per scalar (W <= 12)
+constexpr int kPartPerS = 12;  // entries per thread of the scalar-fed group pass = windows per scalar (W <= 12: the main tables' 11 windows of 23 bits)
+constexpr int kPartPerWide = 13;  // ... and the instantiation for the mid table set's 13 windows of 20 bits (round 4: the mid-length level commitments sorted from the scalars too)
 template <int PER, int THREADS = kPartThreads>
 struct PartSharedN {
     uint64_t stage[THREADS * PER];
@@ -381,7 +382,7 @@ __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh
 }
 
 // digits of one scalar straight into the per-workgroup segment histogram (no key array)
-template <int LO>
+template <int LO, int PERS = kPartPerS>
 __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t nb1, uint32_t* __restrict__ hist1) {
     extern __shared__ uint32_t fx_sh[];
     for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
@@ -390,12 +391,12 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
     for (size_t base = lo; base < hi; base += kSortBlock) {  // whole wavefronts walk the loop together (ballots inside)
         const size_t i = base + threadIdx.x;
         const bool live = i < hi;
-        uint32_t keys[kPartPerS];
+        uint32_t keys[PERS];
 #pragma unroll
-        for (int w = 0; w < kPartPerS; ++w) keys[w] = 0;
+        for (int w = 0; w < PERS; ++w) keys[w] = 0;
         if (live) fx_digits_of(from_mont(ld_fr(scalars + i)), c, W, keys, 1);
 #pragma unroll
-        for (int w = 0; w < kPartPerS; ++w) {
+        for (int w = 0; w < PERS; ++w) {
             if (w >= W) break;  // kernel-uniform
             const uint32_t mag = keys[w] & 0x7FFFFFFFu;
             // plain LDS atomics: the ballot peeling of wave_aggregate cost ~60 instructions per window and scalar (660 of the ~1100 this loop spent per scalar) to save
@@ -411,27 +412,27 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
 }
 // pass 1 from the scalars: entries grouped by segment group; value = (w * stride + i) | sign << 31, low = |digit| mod 2^(LO + 7)
 constexpr int kPartThreadsS = 1024;  // 1024 x 12 entries = 96 KiB of stage, one workgroup per CU: 3.7 ms per 2^26 terms; 512 threads (three per CU) measured 4.3 ms -- the runs per bin get too short
-template <int LO>
+template <int LO, int PERS = kPartPerS>
 __global__ __launch_bounds__(kPartThreadsS) void k_fx_partition_groups_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, size_t stride, uint32_t n_groups,
                                                                              uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ out_val, uint16_t* __restrict__ out_low) {
     extern __shared__ __align__(16) unsigned char fx_part_raw[];
-    PartSharedN<kPartPerS, kPartThreadsS>& sh = *reinterpret_cast<PartSharedN<kPartPerS, kPartThreadsS>*>(fx_part_raw);
+    PartSharedN<PERS, kPartThreadsS>& sh = *reinterpret_cast<PartSharedN<PERS, kPartThreadsS>*>(fx_part_raw);
     const size_t n_tiles = (n + kPartThreadsS - 1) / kPartThreadsS;
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const size_t i = t * kPartThreadsS + threadIdx.x;
-        uint32_t keys[kPartPerS];
+        uint32_t keys[PERS];
 #pragma unroll
-        for (int w = 0; w < kPartPerS; ++w) keys[w] = 0;
+        for (int w = 0; w < PERS; ++w) keys[w] = 0;
         if (i < n) fx_digits_of(from_mont(ld_fr(scalars + i)), c, W, keys, 1);
-        uint64_t item[kPartPerS];
-        uint32_t bin[kPartPerS];
+        uint64_t item[PERS];
+        uint32_t bin[PERS];
 #pragma unroll
-        for (int u = 0; u < kPartPerS; ++u) {
+        for (int u = 0; u < PERS; ++u) {
             const uint32_t key = u < W ? keys[u] : 0u, mag = key & 0x7FFFFFFFu;
             item[u] = mag ? ((uint64_t)mag << 32) | (uint32_t)((size_t)u * stride + i) | (key & 0x80000000u) : ~0ull;
             bin[u] = mag >> (LO + kGroupBits);
         }
-        partition_tile_soa<kPartPerS, uint16_t, kPartThreadsS>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1);
+        partition_tile_soa<PERS, uint16_t, kPartThreadsS>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1);
     }
 }
 // pass 2: inside every group, by segment; low = |digit| mod 2^LO afterwards
@@ -961,8 +962,11 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const uint32_t heavy_threshold = (uint32_t)std::min<size_t>(std::max<size_t>(2 * kLaneCap, 4 * avg), kClasses - 2);
     const uint32_t heavy_cap = (uint32_t)(total / kFxHeavySeg + total / heavy_threshold + 16);
     // split entries and no key array (section 2c): 8-bit segments, the two-pass partition, W <= 12
-    const bool soa = ctx->msm_fx_soa && lo_bits == 8 && ctx->msm_fx_partition == 2 && W <= kPartPerS && ((nb1 + kGroupBins - 1) >> kGroupBits) <= (uint32_t)kPartBins &&
-                     sizeof(PartSharedN<kPartPerS, kPartThreadsS>) + 2048 <= ctx->max_lds_per_block;
+    static const bool wide_soa = !(std::getenv("JOLT_FX_SOA13") && std::atoi(std::getenv("JOLT_FX_SOA13")) == 0);
+    const bool wide = W > kPartPerS;  // 13 windows: the second instantiation of the scalar-fed passes
+    const bool soa = ctx->msm_fx_soa && lo_bits == 8 && ctx->msm_fx_partition == 2 && (W <= kPartPerS || (W <= kPartPerWide && wide_soa)) &&
+                     ((nb1 + kGroupBins - 1) >> kGroupBits) <= (uint32_t)kPartBins &&
+                     (wide ? sizeof(PartSharedN<kPartPerWide, kPartThreadsS>) : sizeof(PartSharedN<kPartPerS, kPartThreadsS>)) + 2048 <= ctx->max_lds_per_block;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_keys = take(total * 4), o_entries = take(soa ? total * 5 + 512 : total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
@@ -1018,6 +1022,9 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         hipError_t p4 = hipFuncSetAttribute((const void*)k_fx_partition_segments<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartShared));
         hipError_t q1 = hipFuncSetAttribute((const void*)k_fx_hist_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         hipError_t q2 = hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerS, kPartThreadsS>));
+        (void)hipFuncSetAttribute((const void*)k_fx_hist_scalars<8, kPartPerWide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        (void)hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8, kPartPerWide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerWide, kPartThreadsS>));
+        (void)hipGetLastError();
         hipError_t q3 = hipFuncSetAttribute((const void*)k_fx_partition_segments_soa<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPer>));
         (void)hipFuncSetAttribute((const void*)k_fx_segment_sort_staged<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ctx->max_lds_per_block > 12288 ? ctx->max_lds_per_block - 12288 : 0));
         (void)hipGetLastError();
@@ -1045,7 +1052,8 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
     if (soa) {  // digits straight into the segment histogram: no key array
         const unsigned hist_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, n / 4096));
-        hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
+        if (wide) hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerWide>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
+        else hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
     } else {
         hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, sst, d_scalars, n, c, W, keys);
         if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
@@ -1066,8 +1074,12 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     if (soa) {
         hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
         const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, (n + kPartThreadsS - 1) / kPartThreadsS));
-        hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerS, kPartThreadsS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
-                           group_cursor, g_val, g_low);
+        if (wide)
+            hipLaunchKernelGGL((k_fx_partition_groups_scalars<8, kPartPerWide>), dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerWide, kPartThreadsS>), sst, d_scalars, n, c, W,
+                               srs->pre_stride, n_groups, group_cursor, g_val, g_low);
+        else
+            hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerS, kPartThreadsS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
+                               group_cursor, g_val, g_low);
         hipLaunchKernelGGL(k_fx_partition_segments_soa<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartSharedN<kPartPer>), sst, (const uint32_t*)g_val, (const uint16_t*)g_low,
                            (const uint32_t*)offs1, nb1, (const uint32_t*)info, cur1, s_val, s_low);
     } else if (two_pass) {
