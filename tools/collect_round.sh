@@ -14,6 +14,7 @@ if [ "${2:-}" != "notests" ]; then
   timeout 1800 python -m pytest tests -q -m gpu --durations=12 > "$OUT/pytest_gpu.txt" 2>&1
   tail -3 "$OUT/pytest_gpu.txt"
 fi
+( timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ) | tee "$OUT/smoke.txt"
 # the driver's command (default flags: all stages), the round-2 step for comparison, and the sumcheck legs alone (BASELINE configs[1] shape)
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cut -c1-200 "$OUT/bench.json"
