@@ -13,6 +13,7 @@
 //! | `optimized::{spartan_outer, spartan_product, ram_read_write, instruction_read_raf}` T-scale loops | [`ops::SpartanSums`], [`ops::HipRwMatrix`], [`ops::HipReadRaf`] |
 //! | HyperKZG prover pieces (`crates/jolt-hyperkzg/src/{kzg,scheme}.rs`) | [`msm::HipSrs`], `ffi::jolt_hyperkzg_*` |
 //! | `CommitmentScheme` + `AdditivelyHomomorphic` for HyperKZG (`crates/jolt-openings/src/schemes.rs:43-163`, `crates/jolt-hyperkzg/src/scheme.rs:275-353`) | [`pcs::HipHyperKzg`] over device-resident [`pcs::HipPoly`]s, the caller's transcript through `jolt_open_transcript_fn` |
+//! | `RowSource::rows` / `WitnessBundle::from_row` witness hand-over (`crates/jolt-witness/src/consumer.rs:129-143`) | [`rows::HipPinnedRows`], [`rows::HipRows`]: one H2D copy of packed rows, columns extracted on the device |
 //! | `UniskipKernel`, `CommitWitness`, the backend constructor (`crates/jolt-kernels/src/{uniskip.rs:28-54, commitment.rs:137-160, optimized/mod.rs:136-196}`) | [`backend::HipUniskip`], [`backend::HipCommitWitness`], [`backend::mi355x`] |
 //!
 //! Host code stays Rust: Fiat-Shamir, claim wiring, round-polynomial assembly (`UnivariatePoly::from_evals`,
@@ -26,6 +27,7 @@ pub mod member;
 pub mod msm;
 pub mod ops;
 pub mod pcs;
+pub mod rows;
 pub mod backend;
 pub mod scheduler;
 pub mod status;
@@ -36,5 +38,6 @@ pub use msm::{msm_cache_clear, msm_cache_evict, msm_g1, HipShardedOpening, HipSr
 pub use ops::{HipHotIndices, HipInts, HipKeyIndex, HipReadRaf, HipRegistersRw, HipRwMatrix, SpartanSums};
 pub use backend::{mi355x, with_relation, HipCommitWitness, HipUniskip, Mi355xParts, NodeWeights};
 pub use pcs::{HipHyperKzg, HipHyperKzgSetup, HipPoly};
+pub use rows::{HipPinnedRows, HipRows};
 pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
 pub use status::HipError;

@@ -28,6 +28,10 @@ impl HipInts {
     pub fn from_i128(ctx: &Arc<HipContext>, values: &[i128]) -> Result<Self, HipError> {
         Self::upload(ctx, values.as_ptr().cast(), ffi::JOLT_INT_I128, values.len())
     }
+    /// Adopt a handle the library returned (`jolt_ints_from_rows`).
+    pub(crate) fn from_raw(ctx: &Arc<HipContext>, raw: *mut ffi::jolt_ints) -> Self {
+        Self { ctx: Arc::clone(ctx), raw }
+    }
     fn upload(ctx: &Arc<HipContext>, host: *const core::ffi::c_void, kind: i32, count: usize) -> Result<Self, HipError> {
         let mut raw = ptr::null_mut();
         // SAFETY: `host` points at `count` little-endian integers of the stated width; the upload is synchronous.
@@ -174,6 +178,10 @@ pub struct HipHotIndices {
 // SAFETY: see HipContext.
 unsafe impl Send for HipHotIndices {}
 impl HipHotIndices {
+    /// Adopt a handle the library returned (`jolt_onehot_from_rows`).
+    pub(crate) fn from_raw(ctx: &Arc<HipContext>, raw: *mut ffi::jolt_onehot, n_columns: usize) -> Self {
+        Self { ctx: Arc::clone(ctx), raw, n_columns }
+    }
     /// `indices[p * cycles + j]` in `[0, k)` or `0xFF`.
     pub fn upload(ctx: &Arc<HipContext>, indices: &[u8], n_columns: usize, cycles: usize, k: u32) -> Result<Self, HipError> {
         debug_assert_eq!(indices.len(), n_columns * cycles);

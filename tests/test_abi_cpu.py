@@ -163,7 +163,7 @@ def test_rust_ffi_crate_agrees_with_the_header():
     assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0
     # every declared symbol is also what the shared library exports (the other half is test_library_exports_every_declared_symbol)
     lib_rs = open(os.path.join(root, "rust", "jolt-kernels-hip", "src", "lib.rs")).read()
-    for module in ("context", "member", "msm", "scheduler", "status", "ffi", "ops", "pcs", "backend"):
+    for module in ("context", "member", "msm", "scheduler", "status", "ffi", "ops", "pcs", "backend", "rows"):
         assert f"pub mod {module};" in lib_rs and os.path.exists(os.path.join(root, "rust", "jolt-kernels-hip", "src", module + ".rs"))
 
 
