@@ -129,7 +129,7 @@ def test_large_trace_waits_for_side_stream_kernels():
     {"JOLT_UNIFORM_ROWS_PAIRS": "64", "JOLT_LAZY_LDS": "0"},  # one-item-per-pair forms of the uniform and lazy kernels
 ])
 def test_alternate_kernel_paths_give_the_same_transcript(monkeypatch, knobs):
-    """The measurement knobs of DESIGN.md section 6b select other kernels / grids / streams for the same sums: every one of them must
+    """The measurement knobs of docs/multi_gpu.md section 6b select other kernels / grids / streams for the same sums: every one of them must
     reproduce the default path's transcript bit for bit (T = 2^16: above every switch-over threshold, two-level tickets included)."""
     base = ffi.Context(0)
     want = DeviceWorkload(base, 16, seed=5).prove(label=9)
