@@ -382,7 +382,7 @@ __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh
 }
 
 // digits of one scalar straight into the per-workgroup segment histogram (no key array)
-template <int LO, int PERS = kPartPerS>
+template <int LO, int PERS = kPartPerS, bool PLAIN = true>
 __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t nb1, uint32_t* __restrict__ hist1) {
     extern __shared__ uint32_t fx_sh[];
     for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
@@ -401,7 +401,12 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
             const uint32_t mag = keys[w] & 0x7FFFFFFFu;
             // plain LDS atomics: the ballot peeling of wave_aggregate cost ~60 instructions per window and scalar (660 of the ~1100 this loop spent per scalar) to save
             // same-address serialisation that the LDS resolves in about the same time when it does occur (runs of equal scalars)
-            if (mag) atomicAdd(&fx_sh[mag >> LO], 1u);
+            if (PLAIN) {
+                if (mag) atomicAdd(&fx_sh[mag >> LO], 1u);
+            } else {
+                WaveAgg ag = wave_aggregate(mag >> LO, mag != 0);
+                if (ag.do_atomic) atomicAdd(&fx_sh[mag >> LO], ag.count);
+            }
         }
     }
     __syncthreads();
@@ -1023,6 +1028,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         hipError_t q1 = hipFuncSetAttribute((const void*)k_fx_hist_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         hipError_t q2 = hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerS, kPartThreadsS>));
         (void)hipFuncSetAttribute((const void*)k_fx_hist_scalars<8, kPartPerWide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        (void)hipFuncSetAttribute((const void*)k_fx_hist_scalars<8, kPartPerS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
         (void)hipFuncSetAttribute((const void*)k_fx_partition_groups_scalars<8, kPartPerWide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPerWide, kPartThreadsS>));
         (void)hipGetLastError();
         hipError_t q3 = hipFuncSetAttribute((const void*)k_fx_partition_segments_soa<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PartSharedN<kPartPer>));
@@ -1052,8 +1058,10 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
     if (soa) {  // digits straight into the segment histogram: no key array
         const unsigned hist_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, n / 4096));
+        static const bool plain_hist = !(std::getenv("JOLT_FX_HIST_PLAIN") && std::atoi(std::getenv("JOLT_FX_HIST_PLAIN")) == 0);
         if (wide) hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerWide>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
-        else hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
+        else if (plain_hist) hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
+        else hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerS, false>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
     } else {
         hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, sst, d_scalars, n, c, W, keys);
         if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
