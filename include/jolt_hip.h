@@ -284,6 +284,14 @@ int32_t jolt_srs_precompute_windows(jolt_ctx *ctx, jolt_srs *srs, uint32_t windo
  * before calling, keeping the reference's panic).  Scalars from host memory or from a device table. */
 int32_t jolt_msm_g1(jolt_ctx *ctx, const jolt_srs *srs, const jolt_fr_t *scalars, size_t n, jolt_g1_t *out);
 int32_t jolt_msm_g1_table(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *scalars, size_t n, jolt_g1_t *out);
+/* Up to three prefix MSMs in flight together on the side lanes, collected later: the dense columns of CommitWitness::commit_witness
+ * (crates/jolt-kernels/src/commitment.rs:137-160, one kzg_commit per committed polynomial) while the caller commits its one-hot columns
+ * (jolt_grid_commit_onehot) on the main stream in between.  begin: JOLT_ERR_UNSUPPORTED, with nothing enqueued, for count > 3 or a context with fewer lanes (the caller
+ * then commits one by one).  Between begin and finish no other MSM entry point of the context may be called (JOLT_ERR_INVALID_ARG); finish frees the handle
+ * whatever it returns; out[i] = sum_{k < n[i]} scalars[i][k] * srs[k]. */
+typedef struct jolt_msm_pending jolt_msm_pending;
+int32_t jolt_msm_g1_tables_begin(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *const *scalars, const size_t *n, size_t count, jolt_msm_pending **out);
+int32_t jolt_msm_g1_tables_finish(jolt_ctx *ctx, jolt_msm_pending *pending, jolt_g1_t *out);
 
 /* fold_polynomials (crates/jolt-hyperkzg/src/scheme.rs:88-114): levels_out[0] = clone of evals, then ell-1
  * LowToHigh folds with point[ell-1], ..., point[1]; ell output tables of length 2^ell, ..., 2. */

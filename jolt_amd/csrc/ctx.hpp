@@ -63,6 +63,7 @@ struct jolt_ctx {
     // a pair of fixed-base MSMs over one sort (msm_fixed.hip): the first result's reduction runs here, under the second pass's bucket sums
     hipStream_t msm_aux_stream = nullptr;
     hipEvent_t ev_aux[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    bool msm_tables_pending = false;  // between jolt_msm_g1_tables_begin and _finish: the side lanes hold MSMs in flight
     void* msm_pending_one = nullptr;  // an MSM begun by jolt_internal_msm_one_begin and not yet collected (msm.hip)
     bool msm_pair_overlap = true;  // JOLT_MSM_PAIR_OVERLAP=0: reduction between the two passes (A/B)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;

@@ -14,6 +14,7 @@
 // Corner cases (P+P, P+(-P), infinity) are handled inside the group law (g1.hip.h); the result is the same POINT as
 // the reference's, in some Jacobian representation.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "ctx.hpp"
@@ -376,6 +377,7 @@ int32_t jolt_internal_gather_owned_terms(jolt_ctx* ctx, const Fr* src, size_t n,
 
 int32_t jolt_internal_msm(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, G1Jac* out) {
     MsmJob job;
+    if (ctx->msm_tables_pending) { ctx->last_error = "an MSM while jolt_msm_g1_tables_begin's MSMs are in flight (finish them first)"; return JOLT_ERR_INVALID_ARG; }
     JOLT_TRY(jolt_internal_msm_enqueue(ctx, srs, d_scalars, n, 0, &job));
     return jolt_internal_msm_collect(ctx, &job, out);
 }
@@ -513,6 +515,7 @@ static int32_t msm_batch_collect(jolt_ctx* ctx, const MsmBatchJob* job, const in
 int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* const* d_scalars, const size_t* n, size_t count, G1Jac* out,
                                const size_t* base_offsets /* per MSM, or nullptr: every MSM multiplies the prefix */) {
     if (count == 0) return JOLT_OK;
+    if (ctx->msm_tables_pending) { ctx->last_error = "MSMs while jolt_msm_g1_tables_begin's MSMs are in flight (finish them first)"; return JOLT_ERR_INVALID_ARG; }
     JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int k = 0; k < 3; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     MsmJob jobs[4];
@@ -556,7 +559,7 @@ int32_t jolt_internal_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const Fr* con
 // JOLT_ERR_UNSUPPORTED, with nothing enqueued, when the pair cannot take the fixed-base method.
 int32_t jolt_internal_msm_pair_and_one(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_a, size_t n_a, size_t shift, const Fr* d_b, size_t n_b, G1Jac* out) {
     if (shift > srs->n || n_a > srs->n - shift) return JOLT_ERR_SRS_TOO_SMALL;
-    if (n_a == 0 || !(srs->pre && ctx->msm_fixed && n_a >= srs->pre_min_n)) return JOLT_ERR_UNSUPPORTED;
+    if (n_a == 0 || !(srs->pre && ctx->msm_fixed && n_a >= srs->pre_min_n) || ctx->msm_tables_pending) return JOLT_ERR_UNSUPPORTED;
     JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int k = 0; k < 3; ++k) JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     MsmJob pair, one;
@@ -581,7 +584,7 @@ struct MsmPendingOne {
 };
 int32_t jolt_internal_msm_one_begin(jolt_ctx* ctx, const jolt_srs* srs, size_t n_a, size_t shift, const Fr* d_b, size_t n_b) {
     if (shift > srs->n || n_a > srs->n - shift) return JOLT_ERR_SRS_TOO_SMALL;
-    if (n_a == 0 || !(srs->pre && ctx->msm_fixed && n_a >= srs->pre_min_n) || ctx->msm_lanes < 2 || ctx->msm_pending_one) return JOLT_ERR_UNSUPPORTED;
+    if (n_a == 0 || !(srs->pre && ctx->msm_fixed && n_a >= srs->pre_min_n) || ctx->msm_lanes < 2 || ctx->msm_pending_one || ctx->msm_tables_pending) return JOLT_ERR_UNSUPPORTED;
     if ((size_t)srs->pre_W * n_a >= ((size_t)1 << 32)) return JOLT_ERR_UNSUPPORTED;  // what jolt_internal_msm_fixed_enqueue would refuse for the pair
     MsmPendingOne* p = new (std::nothrow) MsmPendingOne();
     if (!p) return JOLT_ERR_OOM;
@@ -619,6 +622,57 @@ void jolt_internal_msm_one_abandon(jolt_ctx* ctx) {
     ctx->msm_pending_one = nullptr;
     (void)hipStreamSynchronize(ctx->side[0]);
     delete p;
+}
+
+// Up to three MSMs over prefixes of one SRS begun on the side lanes and collected later: the dense columns of a commitment (CommitWitness::commit_witness walks the
+// committed polynomials one by one, crates/jolt-kernels/src/commitment.rs:137-160; here they are in flight together, and the caller commits its one-hot columns on the
+// main stream in between -- their sums are bound by multiplications, these short MSMs by the latency of their sort and reduction chains).
+struct jolt_msm_pending {
+    int count = 0;
+    MsmJob jobs[3];
+};
+extern "C" int32_t jolt_msm_g1_tables_begin(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* const* scalars, const size_t* n, size_t count, jolt_msm_pending** out) {
+    if (!ctx || !srs || !scalars || !n || !out || count == 0) return JOLT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (count > 3 || (size_t)ctx->msm_lanes < count + 1 || ctx->msm_tables_pending || ctx->msm_pending_one) return JOLT_ERR_UNSUPPORTED;
+    for (size_t i = 0; i < count; ++i) {
+        if (!scalars[i]) return JOLT_ERR_INVALID_ARG;
+        if (n[i] > scalars[i]->len) return JOLT_ERR_SIZE_MISMATCH;
+        if (n[i] > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+    }
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_msm_pending* p = new (std::nothrow) jolt_msm_pending();
+    if (!p) return JOLT_ERR_OOM;
+    int32_t status = JOLT_OK;
+    hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream);
+    for (size_t i = 0; i < count && e == hipSuccess; ++i) e = hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); status = JOLT_ERR_HIP; }
+    for (size_t i = 0; i < count && status == JOLT_OK; ++i) {
+        status = jolt_internal_msm_enqueue(ctx, srs, scalars[i]->data(), n[i], (int)i + 1, &p->jobs[i]);
+        if (status == JOLT_OK) p->count = (int)i + 1;
+    }
+    if (status != JOLT_OK) {
+        for (int k = 0; k < 3; ++k) (void)hipStreamSynchronize(ctx->side[k]);
+        delete p;
+        return status;
+    }
+    ctx->msm_tables_pending = true;  // the side lanes' workspaces are taken: no other MSM of this context until the finish
+    *out = p;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_msm_g1_tables_finish(jolt_ctx* ctx, jolt_msm_pending* p, jolt_g1_t* out) {
+    if (!ctx || !p) return JOLT_ERR_INVALID_ARG;
+    int32_t status = JOLT_OK;
+    for (int i = 0; i < p->count; ++i) {
+        G1Jac r;
+        const int32_t s = jolt_internal_msm_collect(ctx, &p->jobs[i], &r);  // always: the lane is drained even after an earlier failure
+        if (s == JOLT_OK && out) std::memcpy(&out[i], &r, sizeof(r));
+        if (status == JOLT_OK) status = s;
+    }
+    ctx->msm_tables_pending = false;
+    delete p;
+    if (status == JOLT_OK && !out) status = JOLT_ERR_INVALID_ARG;
+    return status;
 }
 
 extern "C" int32_t jolt_msm_g1_table(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, jolt_g1_t* out) {

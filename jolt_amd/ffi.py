@@ -704,6 +704,27 @@ def _msm_blocks(self, srs, table, n, block, rank, world):
     return out[0]
 
 
+class PendingMsms:
+    """jolt_msm_g1_tables_begin ... _finish: up to three prefix MSMs in flight on the side lanes while the caller works on the main stream"""
+
+    def __init__(self, ctx, srs, tables, ns):
+        hs = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        nn = (C.c_size_t * len(tables))(*[int(x) for x in ns])
+        h = C.c_void_p()
+        _ck(lib().jolt_msm_g1_tables_begin(ctx.h, srs.h, hs, nn, C.c_size_t(len(tables)), C.byref(h)), "jolt_msm_g1_tables_begin", ctx)
+        self.ctx, self.h, self.count = ctx, h, len(tables)
+
+    def finish(self):
+        out = g1_array(self.count)
+        h, self.h = self.h, None
+        _ck(lib().jolt_msm_g1_tables_finish(self.ctx.h, h, _p(out)), "jolt_msm_g1_tables_finish", self.ctx)
+        return out
+
+
+def _msm_tables_begin(self, srs, tables, ns):
+    return PendingMsms(self, srs, tables, ns)
+
+
 def _msm(self, srs, scalars, n=None):
     """JoltGroup::msm(bases = srs[..n], scalars); scalars = numpy (n,4) host array or a device Table."""
     out = g1_array(1)
@@ -776,6 +797,7 @@ Context.srs_setup_from_secret_subtree = _srs_setup_from_secret_subtree
 Context.msm_subtree = _msm_subtree
 Context.hyperkzg_open_subtree = _hyperkzg_open_subtree
 Context.hyperkzg_fold = _hyperkzg_fold
+Context.msm_tables_begin = _msm_tables_begin
 Context.hyperkzg_eval3 = _hyperkzg_eval3
 Context.hyperkzg_rlc = _hyperkzg_rlc
 Context.hyperkzg_witness_poly = _hyperkzg_witness_poly

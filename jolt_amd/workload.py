@@ -11,6 +11,8 @@ device, eq / eq+1 / LT tables expanded on the device from random points).  Each 
 This module only DESCRIBES the workload (numpy + descriptors); bench.py and the tests instantiate it on the GPU
 through the C ABI, and (tests / cpu_baseline only) on the CPU oracle.
 """
+import os
+
 import numpy as np
 
 P_TOP = 0x30644E72E131A029
@@ -494,8 +496,21 @@ class DeviceWorkload:
         """Stage 0 over the commitment grid: dense increment columns = T-term MSMs of 64-bit scalars against the SRS prefix (address 0),
         one-hot columns = sums of selected bases."""
         ctx, T = self.ctx, 1 << self.n_vars
-        dense = [ctx.msm(self.srs, self.tables[name], T) for name in self.committed_dense]
-        onehot = [ctx.grid_commit_onehot(self.srs, self.sources[i]) for i in sorted(self.sources)]
+        # the dense columns' MSMs go in flight on the side lanes (short: bound by the latency of their sort and reduction chains) and are collected after the one-hot
+        # sums of bases have run on the main stream (bound by multiplications); JOLT_COMMIT_OVERLAP=0 or a context that cannot: one after the other
+        pending = None
+        if self.committed_dense and os.environ.get("JOLT_COMMIT_OVERLAP", "1") != "0":
+            try:
+                pending = ctx.msm_tables_begin(self.srs, [self.tables[name] for name in self.committed_dense], [T] * len(self.committed_dense))
+            except self.ffi.JoltError as e:
+                if e.status != 6:  # JOLT_ERR_UNSUPPORTED: this context cannot hold them in flight
+                    raise
+        dense = None if pending is not None else [ctx.msm(self.srs, self.tables[name], T) for name in self.committed_dense]
+        try:
+            onehot = [ctx.grid_commit_onehot(self.srs, self.sources[i]) for i in sorted(self.sources)]
+        finally:
+            if pending is not None:
+                dense = list(pending.finish())
         return dict(dense=np.stack(dense), onehot=np.concatenate(onehot))
 
     def joint_polynomial(self):

@@ -12,7 +12,9 @@
 use std::sync::Arc;
 
 use jolt_claims::protocols::jolt::JoltCommittedPolynomial;
+use jolt_crypto::Bn254;
 use jolt_field::Fr;
+use jolt_hyperkzg::HyperKZGCommitment;
 use jolt_kernels::commitment::{CommitWitness, CommitmentGrid, WitnessCommitment};
 use jolt_kernels::uniskip::UniskipKernel;
 use jolt_kernels::{JoltBackend, KernelError, ProofSession};
@@ -172,24 +174,59 @@ impl CommitWitness<Fr, HipHyperKzg> for HipCommitWitness {
             return self.fallback.commit_witness(session, source, ids, grid, setup);
         }
         let cycles = 1usize << grid.log_t;
+        // dense columns first onto the device (field elements, zero-extended to the grid: address 0 holds the cycles, the rest is zero) ...
+        let mut dense_tables = Vec::new();
+        let mut dense_slots = Vec::new();
+        for (slot, shape) in shapes.iter().enumerate() {
+            if let CommittedShape::Dense(col) = shape {
+                let table = source.oracle_table(*col).map_err(KernelError::from)?;
+                dense_tables.push(self.ctx.upload(&table[..cycles]).map_err(KernelError::from)?);
+                dense_slots.push(slot);
+            }
+        }
+        // ... their MSMs go in flight on the side lanes (three at a time) while the one-hot columns' sums of bases run on the main stream
+        let mut commitments: Vec<Option<HyperKZGCommitment<Bn254>>> = vec![None; ids.len()];
+        let mut onehot_done = false;
+        let mut chunks = dense_tables.chunks(3).zip(dense_slots.chunks(3)).peekable();
+        // (called with the setup's device lock held: the columns go straight to `HipHotIndices::grid_commit`, not through `HipHyperKzgSetup::grid_commit_onehot`)
+        let mut commit_onehots = |ctx: &Arc<HipContext>, srs: &crate::msm::HipSrs, out: &mut Vec<Option<HyperKZGCommitment<Bn254>>>| -> Result<(), crate::status::HipError> {
+            for (slot, shape) in shapes.iter().enumerate() {
+                if let CommittedShape::OneHot { source: col, shift } = shape {
+                    let table = source.oracle_table(*col).map_err(|_| crate::status::HipError::size_mismatch("one-hot source column unavailable"))?;
+                    let k = 1u32 << grid.log_k_chunk;
+                    let hot: Vec<u8> = table[..cycles].iter().map(|v| v.to_u64().map_or(0xFF, |a| ((a >> shift) & u64::from(k - 1)) as u8)).collect();
+                    let indices = HipHotIndices::upload(ctx, &hot, 1, cycles, k)?;
+                    let point = indices.grid_commit(srs)?.into_iter().next().ok_or_else(|| crate::status::HipError::size_mismatch("grid commit returned no point"))?;
+                    out[slot] = Some(HyperKZGCommitment { point });
+                }
+            }
+            Ok(())
+        };
+        if chunks.peek().is_none() {
+            setup.with_device(|ctx, srs| commit_onehots(ctx, srs, &mut commitments)).map_err(KernelError::from)?;
+            onehot_done = true;
+        }
+        for (tables, slots) in chunks {
+            let refs: Vec<&HipTable> = tables.iter().collect();
+            let first = !onehot_done;
+            let mut staged = vec![None; ids.len()];
+            let (coms, ()) = HipHyperKzg::commit_tables_overlapped(&refs, setup, |ctx, srs| if first { commit_onehots(ctx, srs, &mut staged) } else { Ok(()) }).map_err(KernelError::from)?;
+            if first {
+                for (dst, src) in commitments.iter_mut().zip(staged) {
+                    if src.is_some() {
+                        *dst = src;
+                    }
+                }
+                onehot_done = true;
+            }
+            for (slot, com) in slots.iter().zip(coms) {
+                commitments[*slot] = Some(com);
+            }
+        }
         ids.iter()
-            .zip(shapes)
-            .map(|(id, shape)| {
-                let commitment = match shape {
-                    CommittedShape::Dense(col) => {
-                        // the column as field elements on the device, zero-extended to the grid: address 0 holds the cycles, the rest is zero
-                        let table = source.oracle_table(col).map_err(KernelError::from)?;
-                        let poly = HipPoly::new(self.ctx.upload(&table[..cycles]).map_err(KernelError::from)?).map_err(KernelError::from)?;
-                        HipHyperKzg::commit_resident(&poly, setup).map_err(KernelError::from)?
-                    }
-                    CommittedShape::OneHot { source: col, shift } => {
-                        let table = source.oracle_table(col).map_err(KernelError::from)?;
-                        let k = 1u32 << grid.log_k_chunk;
-                        let hot: Vec<u8> = table[..cycles].iter().map(|v| v.to_u64().map_or(0xFF, |a| ((a >> shift) & u64::from(k - 1)) as u8)).collect();
-                        let indices = HipHotIndices::upload(&self.ctx, &hot, 1, cycles, k).map_err(KernelError::from)?;
-                        setup.grid_commit_onehot(&indices).map_err(KernelError::from)?.into_iter().next().ok_or(KernelError::InvariantViolation { reason: "grid commit returned no point" })?
-                    }
-                };
+            .zip(commitments)
+            .map(|(id, commitment)| {
+                let commitment = commitment.ok_or(KernelError::InvariantViolation { reason: "a committed polynomial was left without a commitment" })?;
                 Ok(WitnessCommitment { id: *id, commitment, hint: () })
             })
             .collect()

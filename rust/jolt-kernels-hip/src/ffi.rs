@@ -45,6 +45,10 @@ pub struct jolt_ints {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct jolt_msm_pending {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct jolt_host_transcript {
     _private: [u8; 0],
 }
@@ -212,6 +216,8 @@ extern "C" {
     pub fn jolt_srs_precompute_windows(ctx: *mut jolt_ctx, srs: *mut jolt_srs, window_bits: u32, min_terms: usize) -> i32;
     pub fn jolt_msm_g1(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_fr_t, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_msm_g1_table(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_msm_g1_tables_begin(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const *const jolt_table, n: *const usize, count: usize, out: *mut *mut jolt_msm_pending) -> i32;
+    pub fn jolt_msm_g1_tables_finish(ctx: *mut jolt_ctx, pending: *mut jolt_msm_pending, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_hyperkzg_fold(ctx: *mut jolt_ctx, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, levels_out: *mut *mut jolt_table) -> i32;
     pub fn jolt_hyperkzg_eval3(ctx: *mut jolt_ctx, levels: *const *mut jolt_table, ell: usize, u: *const jolt_fr_t, v_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_hyperkzg_rlc(ctx: *mut jolt_ctx, levels: *const *mut jolt_table, ell: usize, q: *const jolt_fr_t, out: *mut *mut jolt_table) -> i32;

@@ -51,7 +51,7 @@ impl HipHyperKzgSetup {
         Ok(Self { inner, device: Arc::new(DeviceSetup { ctx: Arc::clone(ctx), srs: Mutex::new(srs) }) })
     }
 
-    fn with_device<R>(&self, f: impl FnOnce(&Arc<HipContext>, &HipSrs) -> Result<R, HipError>) -> Result<R, HipError> {
+    pub(crate) fn with_device<R>(&self, f: impl FnOnce(&Arc<HipContext>, &HipSrs) -> Result<R, HipError>) -> Result<R, HipError> {
         let _device = self.device.ctx.exclusive();
         let srs = self.device.srs.lock().unwrap_or_else(std::sync::PoisonError::into_inner);
         f(&self.device.ctx, &srs)
@@ -183,7 +183,38 @@ impl HipHyperKzg {
         Ok(HyperKZGCommitment { point })
     }
 
-    /// `open` over a polynomial already in HBM: the 312 ms -> see `DESIGN.md` section 4 path of the bench.
+    /// The commitments of up to three resident dense polynomials IN FLIGHT on the side lanes while `between` runs on the main stream (the one-hot columns'
+    /// `jolt_grid_commit_onehot`): `jolt_msm_g1_tables_begin` / `_finish`.  The short MSMs of 64-bit columns are bound by the latency of their sort and reduction chains,
+    /// the one-hot sums of bases by multiplications, so the two overlap almost entirely (the commit leg).  Falls back to one `commit` after the
+    /// other -- `between` first -- when the context cannot hold them in flight (`JOLT_ERR_UNSUPPORTED`).
+    pub fn commit_tables_overlapped<R>(
+        tables: &[&HipTable],
+        setup: &HipHyperKzgSetup,
+        between: impl FnOnce(&Arc<HipContext>, &HipSrs) -> Result<R, HipError>,
+    ) -> Result<(Vec<HyperKZGCommitment<Bn254>>, R), HipError> {
+        setup.with_device(|ctx, srs| {
+            let raws: Vec<*const ffi::jolt_table> = tables.iter().map(|t| t.raw.cast_const()).collect();
+            let lens: Vec<usize> = tables.iter().map(|t| t.len()).collect();
+            let mut pending: *mut ffi::jolt_msm_pending = std::ptr::null_mut();
+            // SAFETY: `raws` / `lens` hold `tables.len()` live handles / lengths of this context; valid out-pointer.
+            let begun = unsafe { ffi::jolt_msm_g1_tables_begin(ctx.raw, srs.raw, raws.as_ptr(), lens.as_ptr(), raws.len(), &mut pending) };
+            if begun == ffi::JOLT_ERR_UNSUPPORTED || tables.is_empty() {
+                let r = between(ctx, srs)?;
+                let coms = tables.iter().map(|t| Self::commit_table(ctx, srs, t)).collect::<Result<Vec<_>, _>>()?;
+                return Ok((coms, r));
+            }
+            check(begun, ctx.raw)?;
+            let r = between(ctx, srs);
+            let mut points = vec![Bn254G1::default(); tables.len()];
+            // SAFETY: `pending` came from the begin above and is consumed exactly once, whatever `between` returned; `points` holds one jolt_g1_t per MSM.
+            let finished = unsafe { ffi::jolt_msm_g1_tables_finish(ctx.raw, pending, points.as_mut_ptr().cast()) };
+            let r = r?;
+            check(finished, ctx.raw)?;
+            Ok((points.into_iter().map(|point| HyperKZGCommitment { point }).collect(), r))
+        })
+    }
+
+    /// `open` over a polynomial already in HBM: the `open` leg of the bench (`DESIGN.md` section 4.1).
     pub fn open_resident<T: Transcript<Challenge = Fr>>(
         poly: &HipPoly,
         point: &[Fr],
