@@ -25,7 +25,7 @@ use jolt_witness::{JoltWitnessOracle, JoltWitnessPlane};
 use crate::context::{HipContext, HipTable};
 use crate::member::HipPrepare;
 use crate::ops::{HipHotIndices, HipInts, SpartanSums};
-use crate::pcs::{HipHyperKzg, HipHyperKzgSetup, HipPoly};
+use crate::pcs::{HipHyperKzg, HipHyperKzgSetup};
 use crate::scheduler::HipBuildRoundScheduler;
 
 /// What a uni-skip front parks for its remainder slot (`SpartanOuterCarry`, `optimized/spartan_outer.rs:370-392`): the integer columns
