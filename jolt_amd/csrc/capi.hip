@@ -94,8 +94,16 @@ extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** o
             s = JOLT_ERR_HIP;
         else
             *ctx->h_flag = 0;
-        for (int k = 0; k < 3 && s == JOLT_OK; ++k)
-            if (hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) != hipSuccess) s = JOLT_ERR_HIP;
+        // JOLT_SIDE_PRIORITY=1: the side streams above the main stream in priority -- short, latency-bound chains queued there (the dense commitments of
+        // jolt_msm_g1_tables_begin) then get their workgroups in ahead of a long kernel on the main stream instead of behind it
+        int prio_least = 0, prio_greatest = 0;
+        const char* sp = std::getenv("JOLT_SIDE_PRIORITY");
+        const bool side_high = sp && std::atoi(sp) != 0 && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_greatest != prio_least;
+        (void)hipGetLastError();
+        for (int k = 0; k < 3 && s == JOLT_OK; ++k) {
+            const hipError_t ce = side_high ? hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, prio_greatest) : hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking);
+            if (ce != hipSuccess) s = JOLT_ERR_HIP;
+        }
         if (s == JOLT_OK && ctx->msm_cu_split > 0) {
             // bit n of the mask <-> compute unit n; the split is taken inside every group of 8 consecutive bits (bits n with n mod 8 < k), which gives k of 8
             // CUs on every XCD whether the runtime numbers the CUs XCD-major or round-robin over the XCDs.  (Round 3 tested ((n / 8) mod 8) < k, which hands out WHOLE
