@@ -4,6 +4,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$ROOT/gpurun_out/pmc_open}
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT" ;; esac
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 JOLT_MSM_LANES=1 timeout 300 rocprofv3 --kernel-trace -d "$OUT/trace" -o e -- python "$ROOT/tools/open_one.py" 26 1 > "$OUT/trace.txt" 2>&1
