@@ -49,8 +49,8 @@ def test_extended_stages_match_oracle(n_vars, kw):
 def test_extended_stages_match_oracle_at_trace_scale():
     """T = 2^20 cycles (K = 2^16 RAM words, 42 lookup tables, 35 R1CS inputs): the sizes at which the scans run many workgroups per bin, the
     sparse matrix merges hundreds of columns per group and the uni-skip kernel streams the integer columns -- transcript for transcript.
-    Instruction read-RAF's 128 address rounds at this size: the 24 rounds of phases 0, 7 and 15 are the oracle's FROM THE DEFINITION and must equal the
-    product's; the other 104 are sumcheck-ends-verified (OracleExtended.instruction_read_raf), not lock step.  T = 2^22: tests/test_gpu_extended_t22.py."""
+    Instruction read-RAF's 128 address rounds at this size: the 17 rounds of phases 0 and 15 and round 62 are the oracle's FROM THE DEFINITION and must equal the
+    product's; the other 111 are sumcheck-ends-verified (OracleExtended.instruction_read_raf), not lock step.  T = 2^22: tests/test_gpu_extended_t22.py."""
     import oracle_lib as O
     import os
     O.baseline_set_threads(min(128, os.cpu_count() or 1))

@@ -308,15 +308,16 @@ class OracleExtended:
     # above this many cycles the from-the-definition address rounds (T x 128 x 3 table evaluations) stop being a test-sized computation for ALL rounds ...
     DIRECT_ADDRESS_ROUNDS_MAX_LOG_T = 12
 
-    # ... and a SAMPLE of them is computed from the definition instead (round-4 review, item 1): whole phases 0, 7 and 15 up to T = 2^20 (24 of the 128 rounds: the first
-    # phase -- no checkpoints yet --, a middle one and the last, whose suffixes are empty), single rounds at the ends and in the middle above that
+    # ... and a SAMPLE of them is computed from the definition instead (round-4 review, item 1): whole phases 0 and 15 plus round 62 up to T = 2^20 (17 of the 128 rounds: the first
+    # phase -- no checkpoints yet --, the last, whose suffixes are empty, and one round in the middle), single rounds at the ends and in the middle above that
+    # (the sample is sized so that the GPU suite stays within minutes: a from-the-definition round costs T x 3 table evaluations)
     @classmethod
     def sampled_direct_rounds(cls, n_vars):
         if n_vars <= cls.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T:
             return set(range(128))
         if n_vars <= 20:
-            return {8 * p + k for p in (0, 7, 15) for k in range(8)}
-        return {0, 1, 62, 127}
+            return {8 * p + k for p in (0, 15) for k in range(8)} | {62}
+        return {0, 62, 127}
 
     def instruction_read_raf(self, label):
         """The twin of DeviceExtended.instruction_read_raf.  The T-scale scans are the oracle's (oracle/read_raf.c) at every size and are compared sum for sum.
