@@ -213,3 +213,58 @@ def test_shared_memory_exchange_ignores_a_stale_segment():
     assert np.array_equal(mine, np.array([[1, 2], [7, 8]], dtype=np.uint64)) and np.array_equal(result["got"], mine)
     fresh.close()
     stale.h = None  # its file was unlinked by the fresh run's rank 0; drop the handle without touching the new segment
+
+
+def _gather_sum_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from util import init_gloo
+    dist = init_gloo(rank, world, port)
+    import oracle_lib as O
+    from jolt_amd import distributed as D
+    from util import rand_fr
+    coll = D.Collective(dist, world)
+    # every rank can rebuild every rank's share: the expected total is the oracle's sum over the ranks
+    minus_one = O.fr_neg(O.to_mont([1]))[0]
+    shares = []
+    for r in range(world):
+        v = rand_fr(37, 900 + r).copy()
+        v[0] = minus_one                      # world * (r - 1): wraps world - 1 times
+        v[1] = 0                              # zeros stay zero
+        v[2] = O.to_mont([r + 1])[0]
+        shares.append(v)
+    want = shares[0].copy()
+    for r in range(1, world):
+        want = O.fr_add(want, shares[r])
+    got = D.gather_sum(coll, shares[rank])
+    ok = np.array_equal(got, want) and got.shape == want.shape
+    # the shape of the caller's array comes back (the stage drivers pass (k, 3, 4) blocks of round sums)
+    block = np.stack([shares[rank][:12].reshape(4, 3, 4)])[0]
+    want_block = want[:12].reshape(4, 3, 4)
+    ok = ok and np.array_equal(D.gather_sum(coll, block), want_block)
+    with open(os.path.join(tmpdir, f"gs_{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_sum_is_the_modular_sum_over_the_ranks(world):
+    """distributed.gather_sum (what the cross-rank stage operators use for every additive T-scale quantity: uni-skip sums, pushforward masses, read-RAF scan sums):
+    ONE all-gather + fr_add_vec on every rank == the oracle's field sum of the ranks' shares, wrap-arounds included, for flat and blocked arrays"""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + 17 * world
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_gather_sum_worker, args=(world, port, tmp), nprocs=world, join=True)
+        for r in range(world):
+            assert open(os.path.join(tmp, f"gs_{r}.txt")).read() == "ok", r
+
+
+def test_fr_add_vec_matches_the_oracle_on_corner_operands():
+    import oracle_lib as O
+    from jolt_amd import distributed as D
+    from util import rand_fr
+    minus_one, one, zero = O.fr_neg(O.to_mont([1]))[0], O.to_mont([1])[0], np.zeros(4, dtype=np.uint64)
+    a = np.stack([minus_one, minus_one, zero, one, minus_one] + list(rand_fr(200, 77)))
+    b = np.stack([minus_one, one, zero, minus_one, zero] + list(rand_fr(200, 78)))
+    assert np.array_equal(D.fr_add_vec(a, b), O.fr_add(a, b))
