@@ -290,9 +290,12 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-1000:]  # torchrun merges the ranks' stdout: nobody but rank 0 may print a result line
-    # gloo's own connection banner goes to stdout, and the ranks' banners can interleave mid-line under torchrun
-    quiet = [l for l in r.stdout.splitlines() if l.strip() and "[Gloo]" not in l and "peer ranks" not in l]
-    assert quiet == lines, r.stdout[:1000]
+    # gloo's own connection banner ("[Gloo] Rank k is connected to N peer ranks. Expected number of connected peer ranks is : N") goes to stdout too, and the ranks'
+    # banners interleave mid-line under torchrun: every line that is not the result must be made of that banner's characters (a stray "3", half a sentence) --
+    # what this guards against is a rank printing something of its own
+    banner = set("[Gloo] Rank is connected to peer ranks. Expected number of connected peer ranks is : 0123456789")
+    for l in r.stdout.splitlines():
+        assert l.startswith("{") or set(l) <= banner, l[:200]
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["value"] == pytest.approx(world * (1 << 10) / (line["ms_per_step"] * 1e-3), rel=1e-3)
