@@ -366,3 +366,32 @@ def test_host_booleanity_address_rounds_match_the_oracle():
         dev.bind(r)
         orc.bind(r)
     assert np.array_equal(dev.intermediate(), orc.intermediate())
+
+
+def test_host_transcript_is_the_oracles_byte_for_byte():
+    """jolt_host_transcript_* (the deterministic test transcript above the ABI, re-implemented in host_mirror.hip from the text of oracle/mock_transcript.h): field
+    elements, raw bytes of every length around the absorb block size (what jolt_host_hyperkzg_open appends for compressed points), both challenge shapes, interleaved --
+    the same challenges as the oracle's transcript from the same label"""
+    import oracle_lib as O
+    from jolt_amd import ffi
+    from util import rand_fr
+    rng = np.random.default_rng(5)
+    for label in (0, 7, 2**63 + 11):
+        mine, theirs = ffi.HostTranscript(label), O.MockTranscript(label)
+        vals = rand_fr(9, 400 + label % 97)
+        for step in range(40):
+            kind = step % 4
+            if kind == 0:
+                k = int(rng.integers(1, 4))
+                mine.append(vals[:k])
+                for v in vals[:k]:
+                    theirs.append_fr(v)
+            elif kind == 1:
+                data = bytes(rng.integers(0, 256, size=int(rng.integers(1, 100)), dtype=np.uint8))
+                mine.append_bytes(data)
+                theirs.append_bytes(data)
+            elif kind == 2:
+                assert np.array_equal(mine.challenge(), theirs.challenge()), (label, step)
+            else:
+                assert np.array_equal(mine.challenge(full_width=True), theirs.challenge_scalar()), (label, step)
+        mine.close()
