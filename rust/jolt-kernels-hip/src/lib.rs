@@ -33,9 +33,9 @@ pub mod scheduler;
 pub mod status;
 
 pub use context::{HipContext, HipTable};
-pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape};
+pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape, MemberSlot};
 pub use msm::{msm_cache_clear, msm_cache_evict, msm_g1, HipShardedOpening, HipSrs, SharedMsmContext};
-pub use ops::{HipHotIndices, HipInts, HipKeyIndex, HipReadRaf, HipRegistersRw, HipRwMatrix, SpartanSums};
+pub use ops::{HipHotIndices, HipInts, HipKeyIndex, HipReadRaf, HipRegistersRw, HipRwMatrix, RwRow, SpartanSums};
 pub use backend::{mi355x, with_relation, HipCommitWitness, HipUniskip, Mi355xParts, NodeWeights};
 pub use pcs::{HipHyperKzg, HipHyperKzgSetup, HipPoly};
 pub use rows::{HipPinnedRows, HipRows};

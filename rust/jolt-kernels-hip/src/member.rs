@@ -32,6 +32,12 @@ pub enum MemberShape {
     GruenProduct,
 }
 
+/// One slot of [`HipMember::new_lc`]: a field table, or a resident `u64` witness column read as compact scalars until the first bind.
+pub enum MemberSlot<'a> {
+    Table(&'a HipTable),
+    Ints(&'a crate::ops::HipInts),
+}
+
 /// Round sums a [`crate::scheduler::HipRoundScheduler`] fetched for this member with one grouped launch; `prove_round` consumes them
 /// instead of launching on its own.
 pub(crate) type Mailbox = Rc<RefCell<Option<Vec<Fr>>>>;
@@ -85,6 +91,66 @@ impl HipMember {
         // SAFETY: live member.
         check(unsafe { ffi::jolt_member_num_rounds(raw, &mut rounds) }, ctx.raw)?;
         Ok(Self { ctx: Arc::clone(ctx), raw, shape: MemberShape::Evals { degree }, rounds, bound: 0, mailbox: Mailbox::default(), eq: None })
+    }
+
+    /// A member in the optimized tier's "sum of products of linear combinations" form over slots that are field tables OR compact-scalar witness columns
+    /// (`Polynomial<T>` before its first bind, `crates/jolt-poly/src/dense.rs:129-142`): `groups[g]` is a product of factors, a factor is
+    /// `(constant, [(coefficient, slot)])`.  Integer slots are read as they lie in round 0 and turned into field tables by the first bind
+    /// (`jolt_member_create_lc_small`; `bind_to_field`); with field slots only this is `jolt_member_create_lc`.  The slots are BORROWED: they must outlive the
+    /// member (the reference's members borrow the witness the same way).  `skip_one`: the member returns `s(0), s(2), .., s(degree)` and the host recovers `s(1)`
+    /// from the claim (`round_poly_from_skipped_evals`, `crates/jolt-kernels/src/optimized/support.rs:450-459`).
+    pub fn new_lc(
+        ctx: &Arc<HipContext>,
+        slots: &[MemberSlot<'_>],
+        groups: &[Vec<(Option<Fr>, Vec<(Fr, u32)>)>],
+        degree: usize,
+        skip_one: bool,
+    ) -> Result<Self, HipError> {
+        let mut group_factor_offsets = vec![0u32];
+        let mut factor_lc_offsets = vec![0u32];
+        let (mut consts, mut lc_tables, mut lc_coeffs) = (Vec::new(), Vec::new(), Vec::new());
+        for group in groups {
+            for (constant, lc) in group {
+                consts.push(constant.unwrap_or_default());
+                for (coefficient, slot) in lc {
+                    if *slot as usize >= slots.len() {
+                        return Err(HipError::size_mismatch("a linear combination names a slot the member does not have"));
+                    }
+                    lc_coeffs.push(*coefficient);
+                    lc_tables.push(*slot);
+                }
+                factor_lc_offsets.push(lc_tables.len() as u32);
+            }
+            group_factor_offsets.push(factor_lc_offsets.len() as u32 - 1);
+        }
+        let desc = ffi::jolt_member_lc_desc {
+            n_tables: slots.len() as u32,
+            n_groups: groups.len() as u32,
+            n_factors: consts.len() as u32,
+            n_lc: lc_tables.len() as u32,
+            degree: degree as u32,
+            order: ffi::JOLT_ORDER_LOW_TO_HIGH,
+            flags: ffi::JOLT_MEMBER_FLAG_BORROW_TABLES | if skip_one { ffi::JOLT_MEMBER_FLAG_SKIP_ONE } else { 0 },
+            group_factor_offsets: group_factor_offsets.as_ptr(),
+            factor_lc_offsets: factor_lc_offsets.as_ptr(),
+            factor_consts: consts.as_ptr().cast(),
+            lc_tables: lc_tables.as_ptr(),
+            lc_coeffs: lc_coeffs.as_ptr().cast(),
+        };
+        let tables: Vec<*mut ffi::jolt_table> = slots.iter().map(|s| match s { MemberSlot::Table(t) => t.raw, MemberSlot::Ints(_) => ptr::null_mut() }).collect();
+        let ints: Vec<*const ffi::jolt_ints> = slots.iter().map(|s| match s { MemberSlot::Ints(v) => v.raw.cast_const(), MemberSlot::Table(_) => ptr::null() }).collect();
+        let mut raw = ptr::null_mut();
+        // SAFETY: the descriptor arrays outlive the call (the library copies them); exactly one of tables[i] / ints[i] is a live handle per slot; w = NULL selects the
+        // plain (not eq-weighted) constructor, for which scale / shard_scale are unused.
+        check(
+            unsafe { ffi::jolt_member_create_lc_small(ctx.raw, tables.as_ptr(), ints.as_ptr(), &desc, ptr::null(), 0, ptr::null(), ptr::null(), &mut raw) },
+            ctx.raw,
+        )?;
+        let mut rounds = 0usize;
+        // SAFETY: live member.
+        check(unsafe { ffi::jolt_member_num_rounds(raw, &mut rounds) }, ctx.raw)?;
+        let shape = if skip_one { MemberShape::SkippedOne { degree } } else { MemberShape::Evals { degree } };
+        Ok(Self { ctx: Arc::clone(ctx), raw, shape, rounds, bound: 0, mailbox: Mailbox::default(), eq: None })
     }
 
     /// `eq(w, j) * a(j) * b(j)` served from split-eq tables (`GruenSplitEqPolynomial::new_with_scaling(w, LowToHigh, scale)`,

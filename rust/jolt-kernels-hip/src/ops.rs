@@ -162,6 +162,95 @@ impl HipRwMatrix {
         Ok(out)
     }
 }
+/// The single row a rank's LOCAL matrix is left with after its local cycle rounds (`jolt_rw_matrix_export_row`): what the ranks of a sharded prover exchange.
+#[derive(Clone, Debug, Default)]
+pub struct RwRow {
+    pub cols: Vec<u64>,
+    pub prev: Vec<u64>,
+    pub next: Vec<u64>,
+    pub val: Vec<Fr>,
+    pub ra: Vec<Fr>,
+    /// registers matrices only (empty for RAM)
+    pub wa: Vec<Fr>,
+    /// the rank's bound increment `inc(r_local)`
+    pub inc: Fr,
+    /// the rank's bound cycle-eq factor
+    pub scalar: Fr,
+}
+
+impl HipRwMatrix {
+    /// Hypercube-sharded provers (one process per GPU, cycles dealt in blocks; the reference is single-process): call BEFORE the local cycle rounds so that the row
+    /// they leave stays in cycle-major form for [`HipRwMatrix::export_row`].
+    pub fn hold_row(&mut self) -> Result<(), HipError> {
+        // SAFETY: live handle.
+        check(unsafe { ffi::jolt_rw_matrix_hold_row(self.raw) }, self.ctx.raw)
+    }
+    /// Ingest the last local challenge without asking for another round message.
+    pub fn bind(&mut self, r: Fr) -> Result<(), HipError> {
+        // SAFETY: live handle, one field element.
+        check(unsafe { ffi::jolt_rw_matrix_bind(self.raw, (&r as *const Fr).cast()) }, self.ctx.raw)
+    }
+    /// The row left after the local cycle rounds: cells in column order with their raw checkpoints, the bound increment and eq factor.
+    pub fn export_row(&mut self, registers: bool) -> Result<RwRow, HipError> {
+        let mut cap = 0usize;
+        // SAFETY: live handle, valid out-pointer.
+        check(unsafe { ffi::jolt_rw_matrix_len(self.raw, &mut cap) }, self.ctx.raw)?;
+        let mut row = RwRow { cols: vec![0; cap], prev: vec![0; cap], next: vec![0; cap], val: vec![Fr::default(); cap], ra: vec![Fr::default(); cap],
+                              wa: if registers { vec![Fr::default(); cap] } else { Vec::new() }, ..RwRow::default() };
+        let mut n = 0usize;
+        let wa_ptr = if registers { row.wa.as_mut_ptr().cast() } else { ptr::null_mut() };
+        // SAFETY: every array holds `cap` entries; wa may be null for a RAM matrix; the scalars are single field elements.
+        check(
+            unsafe {
+                ffi::jolt_rw_matrix_export_row(self.raw, cap, row.cols.as_mut_ptr(), row.prev.as_mut_ptr(), row.next.as_mut_ptr(), row.val.as_mut_ptr().cast(),
+                                               row.ra.as_mut_ptr().cast(), wa_ptr, (&mut row.inc as *mut Fr).cast(), (&mut row.scalar as *mut Fr).cast(), &mut n)
+            },
+            self.ctx.raw,
+        )?;
+        for v in [&mut row.cols, &mut row.prev, &mut row.next] {
+            v.truncate(n);
+        }
+        row.val.truncate(n);
+        row.ra.truncate(n);
+        row.wa.truncate(n);
+        Ok(row)
+    }
+    /// The matrix of the remaining `log2(rows.len())` cycle variables from the ranks' rows in rank order (`jolt_rw_matrix_create_merged`), built identically on every
+    /// rank: `w_high` = the high coordinates of the cycle point, `scalar` = the product the ranks' eq factors combine to (`eq(w_low, r_local)`), `val_init` the
+    /// initial memory (RAM) or `None` (registers start at zero).  `prove_round` / `finish` / `final_values` continue on it.
+    #[allow(clippy::too_many_arguments)]
+    pub fn merged(ctx: &Arc<HipContext>, registers: bool, log_k: usize, rows: &[RwRow], val_init: Option<&HipTable>, w_high: &[Fr], scalar: Fr, gamma: Fr) -> Result<Self, HipError> {
+        if rows.is_empty() || !rows.len().is_power_of_two() || 1usize << w_high.len() != rows.len() {
+            return Err(HipError::size_mismatch("one row per rank, a power of two of them, and one high coordinate per remaining cycle variable"));
+        }
+        let n: usize = rows.iter().map(|r| r.cols.len()).sum();
+        let (mut rr, mut cols, mut prev, mut next) = (Vec::with_capacity(n), Vec::with_capacity(n), Vec::with_capacity(n), Vec::with_capacity(n));
+        let (mut val, mut ra, mut wa, mut inc) = (Vec::with_capacity(n), Vec::with_capacity(n), Vec::with_capacity(n), Vec::with_capacity(rows.len()));
+        for (g, row) in rows.iter().enumerate() {
+            rr.extend(std::iter::repeat(g as u64).take(row.cols.len()));
+            cols.extend_from_slice(&row.cols);
+            prev.extend_from_slice(&row.prev);
+            next.extend_from_slice(&row.next);
+            val.extend_from_slice(&row.val);
+            ra.extend_from_slice(&row.ra);
+            wa.extend_from_slice(&row.wa);
+            inc.push(row.inc);
+        }
+        let mut raw = ptr::null_mut();
+        let wa_ptr: *const ffi::jolt_fr_t = if registers { wa.as_ptr().cast() } else { ptr::null() };
+        // SAFETY: all cell arrays hold `n` entries, `inc` one per row, `w_high` log2(rows) coordinates; handles live on `ctx`.
+        check(
+            unsafe {
+                ffi::jolt_rw_matrix_create_merged(ctx.raw, i32::from(registers), w_high.len(), log_k, n, rr.as_ptr(), cols.as_ptr(), prev.as_ptr(), next.as_ptr(), val.as_ptr().cast(),
+                                                  ra.as_ptr().cast(), wa_ptr, inc.as_ptr().cast(), val_init.map_or(ptr::null(), |t| t.raw.cast_const()), w_high.as_ptr().cast(),
+                                                  (&scalar as *const Fr).cast(), (&gamma as *const Fr).cast(), &mut raw)
+            },
+            ctx.raw,
+        )?;
+        Ok(Self { ctx: Arc::clone(ctx), raw })
+    }
+}
+
 impl Drop for HipRwMatrix {
     fn drop(&mut self) {
         // SAFETY: created by jolt_rw_matrix_create.
@@ -217,6 +306,18 @@ pub struct HipRegistersRw {
 unsafe impl Send for HipRegistersRw {}
 
 impl HipRegistersRw {
+    /// The sharded form (see [`HipRwMatrix::hold_row`]): the same handle type underneath, so a rank's local registers matrix is held, bound and exported through a
+    /// borrowed [`HipRwMatrix`] view; the merged matrix is `HipRwMatrix::merged(ctx, true, ..)`, driven by `jolt_registers_rw_prove_round` through
+    /// [`HipRegistersRw::from_merged`].
+    pub fn sharded<R>(&mut self, f: impl FnOnce(&mut HipRwMatrix) -> Result<R, HipError>) -> Result<R, HipError> {
+        let mut view = std::mem::ManuallyDrop::new(HipRwMatrix { ctx: Arc::clone(&self.ctx), raw: self.raw });  // not dropped: `self` owns the handle
+        f(&mut view)
+    }
+    /// Adopt a merged matrix built with `registers = true`.
+    pub fn from_merged(merged: HipRwMatrix) -> Self {
+        let merged = std::mem::ManuallyDrop::new(merged);
+        Self { ctx: Arc::clone(&merged.ctx), raw: merged.raw }
+    }
     /// `regs`: the columns rs1, rs2, rd of `RegisterCycleRow` as hot indices (k = 2^REGISTER_ADDRESS_BITS); the four value columns as u64;
     /// `inc` = RdInc.  `r_cycle` is `inputs.points.rd_write_value` (`mod.rs:110`).
     #[allow(clippy::too_many_arguments)]
