@@ -284,6 +284,8 @@ int32_t jolt_srs_precompute_windows(jolt_ctx *ctx, jolt_srs *srs, uint32_t windo
  * before calling, keeping the reference's panic).  Scalars from host memory or from a device table. */
 int32_t jolt_msm_g1(jolt_ctx *ctx, const jolt_srs *srs, const jolt_fr_t *scalars, size_t n, jolt_g1_t *out);
 int32_t jolt_msm_g1_table(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *scalars, size_t n, jolt_g1_t *out);
+/* the same for scalars the caller knows to be full-width field elements (a polynomial folded by a challenge): mid-length MSMs may then use the mid window-table set */
+int32_t jolt_msm_g1_table_full_width(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *scalars, size_t n, jolt_g1_t *out);
 /* Up to three prefix MSMs in flight together on the side lanes, collected later: the dense columns of CommitWitness::commit_witness
  * (crates/jolt-kernels/src/commitment.rs:137-160, one kzg_commit per committed polynomial) while the caller commits its one-hot columns
  * (jolt_grid_commit_onehot) on the main stream in between.  begin: JOLT_ERR_UNSUPPORTED, with nothing enqueued, for count > 3 or a context with fewer lanes (the caller
@@ -770,6 +772,12 @@ typedef int32_t (*jolt_open_transcript_fn)(void *user, int32_t phase, const jolt
                                            jolt_fr_t *challenge_out);
 int32_t jolt_host_hyperkzg_open_with_transcript(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
                                                 jolt_open_transcript_fn fn, void *user, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
+/* ... and with its first n_known level commitments supplied by the caller (HyperKZGScheme::open commits every folded polynomial by MSM, scheme.rs:141-145; for the
+ * joint polynomial of one-hot and dense columns the first folds' commitments follow by linearity from jolt_grid_commit_onehot_classes): known_levels[i] is absorbed and
+ * returned as com[i], the MSMs of those levels are skipped.  fn == NULL: the library's test transcript with transcript_label.  Single-process opening only. */
+int32_t jolt_host_hyperkzg_open_with_levels(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell, uint64_t transcript_label,
+                                            jolt_open_transcript_fn fn, void *user, const jolt_g1_t *known_levels, size_t n_known, jolt_g1_t *com, jolt_g1_t *w,
+                                            jolt_fr_t *v, jolt_fr_t *challenges_out);
 
 /* Term-range pieces of a commitment / opening sharded over the ranks of a node (the reference is single
  * process): an MSM of n terms against srs[base_offset .. base_offset + n) with the scalars scalars[scalar_offset ..]; the partial
@@ -781,6 +789,10 @@ int32_t jolt_msm_g1_table_range(jolt_ctx *ctx, const jolt_srs *srs, size_t base_
                                 size_t n, jolt_g1_t *out);
 int32_t jolt_grid_commit_onehot_range(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, size_t cycle_lo, size_t cycle_hi,
                                       jolt_g1_t *out /* n_polys */);
+/* out[c * n_polys + p] = sum over the cycles j = c (mod 2^shift) of srs[(hot_p(j) * T + j) >> shift]: the commitments of the 2^shift residue-class parts of every column
+ * on the grid of a polynomial folded `shift` times low to high (shift <= 4, T a power of two).  com(fold of the joint polynomial) is a linear combination of them:
+ * for shift = 1 and the fold variable x, sum_p s_p ((1 - x) out[0][p] + x out[1][p]) + com(the dense columns' fold). */
+int32_t jolt_grid_commit_onehot_classes(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, uint32_t shift, jolt_g1_t *out);
 int32_t jolt_host_hyperkzg_open_sharded(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
                                         uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void *user,
                                         jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);

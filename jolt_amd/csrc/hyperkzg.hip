@@ -482,7 +482,7 @@ struct OpenTranscript {
 // HyperKZGScheme::open (scheme.rs:122-158) + kzg_open_batch (kzg.rs:69-126)
 static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell, uint64_t transcript_label,
                                   int rank, int world, size_t block, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out,
-                                  jolt_open_transcript_fn transcript_fn = nullptr, void* transcript_user = nullptr) {
+                                  jolt_open_transcript_fn transcript_fn = nullptr, void* transcript_user = nullptr, const jolt_g1_t* known_levels = nullptr, size_t n_known = 0) {
     if (!ctx || !srs || !evals || !point || !w || !v || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     if (ell == 0) return JOLT_ERR_EMPTY_POINT;
@@ -498,11 +498,14 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
     if (s != JOLT_OK) { cleanup(); return s; }
     std::vector<G1Jac> coms(ell > 1 ? ell - 1 : 0);
     {  // scheme.rs:141-145: the ell-1 level commitments are independent MSMs -> pipelined over the MSM lanes
+        // the first n_known level commitments come from the caller (computed by linearity from the structure of the polynomial: jolt_grid_commit_onehot_classes)
+        if (n_known > coms.size() || (n_known && !known_levels) || (n_known && world != 1)) { cleanup(); return JOLT_ERR_INVALID_ARG; }
+        for (size_t i = 0; i < n_known; ++i) std::memcpy(&coms[i], &known_levels[i], sizeof(G1Jac));
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
-        for (size_t i = 1; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+        for (size_t i = 1 + n_known; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
         ctx->msm_full_width_scalars = true;  // folds by challenges: uniform field elements whatever the committed polynomial held
-        s = sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, coms.data());
+        s = ptrs.empty() ? JOLT_OK : sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, coms.data() + n_known);
         ctx->msm_full_width_scalars = false;
         if (s != JOLT_OK) { cleanup(); return s; }
     }
@@ -893,6 +896,15 @@ extern "C" int32_t jolt_host_hyperkzg_open_with_transcript(jolt_ctx* ctx, const 
     return hyperkzg_open_impl(ctx, srs, evals, point, ell, 0, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out, fn, user);
 }
 
+
+// The same opening with its first n_known level commitments SUPPLIED by the caller -- computed by linearity from the structure of the polynomial (the joint polynomial
+// of one-hot and dense columns: jolt_grid_commit_onehot_classes) instead of by MSM over the folded coefficients.  They are absorbed and returned like the computed ones:
+// a wrong one yields a proof the verifier rejects, nothing else.  fn == NULL: the library's test transcript with `transcript_label`.
+extern "C" int32_t jolt_host_hyperkzg_open_with_levels(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell,
+                                                       uint64_t transcript_label, jolt_open_transcript_fn fn, void* user, const jolt_g1_t* known_levels, size_t n_known,
+                                                       jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out, fn, user, known_levels, n_known);
+}
 
 // The same opening with its MSMs sharded over `world` ranks by term range (every rank holds the polynomial and the SRS; `gather` is a
 // jolt_gather_fn moving world x count 32-byte words -- jolt_comm_gather_round_sums / jolt_shm_gather_round_sums fit).  Every rank

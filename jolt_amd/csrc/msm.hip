@@ -684,6 +684,16 @@ extern "C" int32_t jolt_msm_g1_table(jolt_ctx* ctx, const jolt_srs* srs, const j
     return JOLT_OK;
 }
 
+// the same for scalars the caller KNOWS to be full-width field elements (a polynomial folded by a challenge): mid-length MSMs then take the mid table set
+// (msm_fixed.hip; 64-bit witness scalars must not: their top window would pile onto a few buckets)
+extern "C" int32_t jolt_msm_g1_table_full_width(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, jolt_g1_t* out) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    ctx->msm_full_width_scalars = true;
+    const int32_t s = jolt_msm_g1_table(ctx, srs, scalars, n, out);
+    ctx->msm_full_width_scalars = false;
+    return s;
+}
+
 // sum_i scalars[scalar_offset + i] * srs[base_offset + i], i < n: one rank's term range of a sharded MSM
 extern "C" int32_t jolt_msm_g1_table_range(jolt_ctx* ctx, const jolt_srs* srs, size_t base_offset, const jolt_table* scalars, size_t scalar_offset, size_t n,
                                            jolt_g1_t* out) {

@@ -37,29 +37,31 @@ constexpr int kGridSumBlocks = 512;  // workgroups per column: 2048 wavefront pa
 template <bool LFORM>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_grid_onehot_sum(
     const uint8_t* __restrict__ idx, uint32_t wide, size_t grid_cycles, size_t lo, size_t cycles, const G1Affine* __restrict__ bases, G1Jac* __restrict__ partial,
-    LformConsts lc) {
-    const size_t p = blockIdx.y;
+    LformConsts lc, uint32_t shift) {
+    // shift > 0 (blockIdx.z = residue class c of the cycle mod 2^shift): the sum over the cycles j = c mod 2^shift of the bases at (hot * T + j) >> shift -- the
+    // commitment of the column's class-c part on the grid of a polynomial folded `shift` times (jolt_grid_commit_onehot_classes); shift = 0 is the column itself
+    const size_t p = blockIdx.y, cls = blockIdx.z;
     const uint8_t* col = hot_col(idx, p * grid_cycles, wide);
-    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t stride = ((size_t)gridDim.x * kBlock) << shift, folded_cycles = grid_cycles >> shift;
     // XYZZ accumulator: 8M + 2S per mixed addition (g1.hip.h); LFORM: the bases are window 0 of the SRS's L-form tables and the
     // accumulator stays in limb form (fq_limb.hip.h)
     G1Xyzz acc = g1x_identity();
     G1XyzzL acc_l = g1xl_identity();
     const FqL one = fql_from_words(lc.one_l);
     // software pipeline as in sum_bucket_points<true>: the next index byte and point are in flight during the mixed addition
-    size_t j = lo + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t j = lo + cls + (((size_t)blockIdx.x * kBlock + threadIdx.x) << shift);
     uint32_t a = j < cycles ? hot_load(col, j, wide) : kColdIdx;
     G1Affine pt;
     pt.x = Fq::zero();
     pt.y = Fq::zero();
-    if (a != kColdIdx) pt = ld_aff(bases + (size_t)a * grid_cycles + j);
+    if (a != kColdIdx) pt = ld_aff(bases + (size_t)a * folded_cycles + (j >> shift));
     while (j < cycles) {
         const size_t jn = j + stride;
         const uint32_t an = jn < cycles ? hot_load(col, jn, wide) : kColdIdx;
         G1Affine pn;
         pn.x = Fq::zero();
         pn.y = Fq::zero();
-        if (an != kColdIdx) pn = ld_aff(bases + (size_t)an * grid_cycles + jn);
+        if (an != kColdIdx) pn = ld_aff(bases + (size_t)an * folded_cycles + (jn >> shift));
         if (LFORM) {
             if (!g1_aff_is_inf(pt)) acc_l = g1xl_add_mixed(acc_l, fql_from_words(pt.x), fql_from_words(pt.y), one);
         } else {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
         }
     }
     const G1Jac total = wave_sum_g1(mine, 64);
-    if ((threadIdx.x & 63) == 0) partial[(p * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = total;
+    if ((threadIdx.x & 63) == 0) partial[((cls * gridDim.y + p) * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = total;
 }
 // out[p] = sum of the column's `count` partial sums (one wavefront per column)
 __global__ __launch_bounds__(64) void k_grid_onehot_fold(const G1Jac* __restrict__ partial, uint32_t count, G1Jac* __restrict__ out) {
@@ -233,21 +235,34 @@ extern "C" int32_t jolt_grid_commit_onehot(jolt_ctx* ctx, const jolt_srs* srs, c
 
 // the partial commitments over cycles [cycle_lo, cycle_hi): one rank's share of a commitment sharded over the cycles (the ranks'
 // partial points add up to jolt_grid_commit_onehot's)
+static int32_t grid_commit_onehot_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, size_t cycle_lo, size_t cycle_hi, uint32_t shift, jolt_g1_t* out);
 extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, size_t cycle_lo, size_t cycle_hi, jolt_g1_t* out) {
+    return grid_commit_onehot_impl(ctx, srs, source, cycle_lo, cycle_hi, 0, out);
+}
+// out[c * n_polys + p] = sum over the cycles j = c mod 2^shift of srs[(hot_p(j) * T + j) >> shift]: the commitments of the 2^shift residue-class parts of every
+// column on the grid of a polynomial folded `shift` times low to high.  With them the first level commitments of an opening of the joint polynomial follow by
+// linearity instead of by MSM: com(P_1) = sum_p s_p ((1 - x) out[0][p] + x out[1][p]) + com(the dense columns' fold) for the fold variable x -- 36 sums of bases
+// at the commit leg's rate where the MSM sorts and sums 2^25 full-width scalars (jolt_host_hyperkzg_open_with_levels takes the result).
+extern "C" int32_t jolt_grid_commit_onehot_classes(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, uint32_t shift, jolt_g1_t* out) {
+    if (!source) return JOLT_ERR_INVALID_ARG;
+    if (shift > 4 || (source->cycles & (source->cycles - 1)) != 0 || source->cycles < ((size_t)1 << shift)) return JOLT_ERR_UNSUPPORTED;  // a power-of-two grid
+    return grid_commit_onehot_impl(ctx, srs, source, 0, source->cycles, shift, out);
+}
+static int32_t grid_commit_onehot_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* source, size_t cycle_lo, size_t cycle_hi, uint32_t shift, jolt_g1_t* out) {
     if (!ctx || !srs || !source || !out) return JOLT_ERR_INVALID_ARG;
-    const size_t T = source->cycles, N = source->n_polys;
+    const size_t T = source->cycles, classes = (size_t)1 << shift, N = source->n_polys;
     if (cycle_lo > cycle_hi || cycle_hi > T) return JOLT_ERR_SIZE_MISMATCH;
     if ((size_t)source->k * T > srs->n) return JOLT_ERR_SRS_TOO_SMALL;  // HyperKZGError::SrsTooSmall (kzg.rs:19-24)
     if (N > 65535) return JOLT_ERR_UNSUPPORTED;
     // lanes per column: every lane ends with an XYZZ -> Jacobian conversion and six shuffle rounds of full additions (~11 mixed additions' worth), so a lane should own
     // >= 128 cycles (32 cycles per lane at T = 2^22 made that a third of the kernel); enough workgroups over all columns to fill the chip all the same
-    const size_t span = cycle_hi - cycle_lo;
+    const size_t span = (cycle_hi - cycle_lo) >> shift;  // cycles per (column, class)
     const size_t by_work = (span + (size_t)kBlock * 128 - 1) / ((size_t)kBlock * 128), fill = ((size_t)ctx->num_cus * 8 + N - 1) / std::max<size_t>(N, 1);
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>({(span + kBlock - 1) / kBlock, std::max(by_work, fill), (size_t)kGridSumBlocks}));
     const uint32_t per_col = blocks * (kBlock / 64);
     G1Jac *partial = nullptr, *sums = nullptr;
-    JOLT_TRY(jolt_internal_dev_alloc(ctx, N * per_col * sizeof(G1Jac), (void**)&partial));
-    int32_t st = jolt_internal_dev_alloc(ctx, N * sizeof(G1Jac), (void**)&sums);
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, classes * N * per_col * sizeof(G1Jac), (void**)&partial));
+    int32_t st = jolt_internal_dev_alloc(ctx, classes * N * sizeof(G1Jac), (void**)&sums);
     if (st != JOLT_OK) { jolt_internal_dev_free(ctx, partial); return st; }
     LformConsts lc;
     {
@@ -258,14 +273,14 @@ extern "C" int32_t jolt_grid_commit_onehot_range(jolt_ctx* ctx, const jolt_srs* 
     }
     // window 0 of the fixed-base tables IS the SRS in L-form (msm_fixed.hip): the sums then run on the limb-form accumulator
     if (srs->pre && srs->pre_lform && srs->pre_stride >= (size_t)source->k * T)
-        hipLaunchKernelGGL(k_grid_onehot_sum<true>, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo, cycle_hi,
-                           (const G1Affine*)srs->pre, partial, lc);
+        hipLaunchKernelGGL(k_grid_onehot_sum<true>, dim3(blocks, (unsigned)N, (unsigned)classes), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo,
+                           cycle_hi, (const G1Affine*)srs->pre, partial, lc, shift);
     else
-        hipLaunchKernelGGL(k_grid_onehot_sum<false>, dim3(blocks, (unsigned)N), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo, cycle_hi,
-                           (const G1Affine*)srs->pts, partial, lc);
-    hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)N), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
+        hipLaunchKernelGGL(k_grid_onehot_sum<false>, dim3(blocks, (unsigned)N, (unsigned)classes), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo,
+                           cycle_hi, (const G1Affine*)srs->pts, partial, lc, shift);
+    hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)(classes * N)), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out, sums, N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, sums, classes * N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     jolt_internal_dev_free(ctx, partial);
     jolt_internal_dev_free(ctx, sums);

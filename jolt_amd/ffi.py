@@ -725,12 +725,14 @@ def _msm_tables_begin(self, srs, tables, ns):
     return PendingMsms(self, srs, tables, ns)
 
 
-def _msm(self, srs, scalars, n=None):
-    """JoltGroup::msm(bases = srs[..n], scalars); scalars = numpy (n,4) host array or a device Table."""
+def _msm(self, srs, scalars, n=None, full_width=False):
+    """JoltGroup::msm(bases = srs[..n], scalars); scalars = numpy (n,4) host array or a device Table.  full_width: the caller knows the scalars to be uniform field
+    elements (jolt_msm_g1_table_full_width)."""
     out = g1_array(1)
     if isinstance(scalars, Table):
         n = len(scalars) if n is None else n
-        _ck(lib().jolt_msm_g1_table(self.h, srs.h, scalars.h, C.c_size_t(n), _p(out)), "jolt_msm_g1_table", self)
+        fn = "jolt_msm_g1_table_full_width" if full_width else "jolt_msm_g1_table"
+        _ck(getattr(lib(), fn)(self.h, srs.h, scalars.h, C.c_size_t(n), _p(out)), fn, self)
     else:
         s = fr(scalars).reshape(-1, 4)
         n = s.shape[0] if n is None else n
@@ -773,10 +775,16 @@ def _hyperkzg_commit(self, srs, evals):
     return out[0]
 
 
-def _hyperkzg_open(self, srs, evals, point, label=0):
+def _hyperkzg_open(self, srs, evals, point, label=0, known_levels=None):
+    """known_levels: (n, 12) commitments of the first n folded polynomials, computed by the caller (jolt_host_hyperkzg_open_with_levels skips their MSMs)"""
     p = fr(point).reshape(-1, 4)
     ell = p.shape[0]
     com, w, v, ch = g1_array(max(ell - 1, 1)), g1_array(3), fr_array(3 * max(ell, 1)), fr_array(3)
+    if known_levels is not None and len(known_levels):
+        kl = np.ascontiguousarray(known_levels, dtype=np.uint64).reshape(-1, 12)
+        _ck(lib().jolt_host_hyperkzg_open_with_levels(self.h, srs.h, evals.h, _p(p), C.c_size_t(ell), C.c_uint64(label), None, None, _p(kl), C.c_size_t(kl.shape[0]),
+                                                      _p(com), _p(w), _p(v), _p(ch)), "jolt_host_hyperkzg_open_with_levels", self)
+        return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
     _ck(lib().jolt_host_hyperkzg_open(self.h, srs.h, evals.h, _p(p), C.c_size_t(ell), C.c_uint64(label), _p(com), _p(w), _p(v), _p(ch)),
         "jolt_host_hyperkzg_open", self)
     return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
@@ -1118,6 +1126,13 @@ def _grid_commit_onehot(self, srs, source):
     return out
 
 
+def _grid_commit_onehot_classes(self, srs, source, shift):
+    """(2^shift, n_polys, 12): per residue class c of the cycle mod 2^shift the sums of the bases at (hot * T + j) >> shift (jolt_grid_commit_onehot_classes)"""
+    out = g1_array(source.n_polys << shift)
+    _ck(lib().jolt_grid_commit_onehot_classes(self.h, srs.h, source.h, C.c_uint32(shift), _p(out)), "jolt_grid_commit_onehot_classes", self)
+    return out.reshape(1 << shift, source.n_polys, 12)
+
+
 def _grid_joint_polynomial(self, sources, onehot_scalars, dense, dense_scalars, log_k):
     """Joint polynomial of the stage-8 batch opening over the 2^log_k x T grid (HomomorphicBatch::prove_batch's RLC)."""
     hs = (C.c_void_p * max(len(sources), 1))(*[s.h for s in sources])
@@ -1154,6 +1169,7 @@ def _memory_stats(self):
 
 Context.table_from_ints = _table_from_ints
 Context.grid_commit_onehot = _grid_commit_onehot
+Context.grid_commit_onehot_classes = _grid_commit_onehot_classes
 Context.grid_joint_polynomial = _grid_joint_polynomial
 Context.grid_joint_polynomial_subtree = _grid_joint_polynomial_subtree
 Context.trim = _trim

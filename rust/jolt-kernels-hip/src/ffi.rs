@@ -216,6 +216,7 @@ extern "C" {
     pub fn jolt_srs_precompute_windows(ctx: *mut jolt_ctx, srs: *mut jolt_srs, window_bits: u32, min_terms: usize) -> i32;
     pub fn jolt_msm_g1(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_fr_t, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_msm_g1_table(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_msm_g1_table_full_width(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_msm_g1_tables_begin(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const *const jolt_table, n: *const usize, count: usize, out: *mut *mut jolt_msm_pending) -> i32;
     pub fn jolt_msm_g1_tables_finish(ctx: *mut jolt_ctx, pending: *mut jolt_msm_pending, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_hyperkzg_fold(ctx: *mut jolt_ctx, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, levels_out: *mut *mut jolt_table) -> i32;
@@ -362,8 +363,10 @@ extern "C" {
     pub fn jolt_host_hyperkzg_commit(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_hyperkzg_open_with_transcript(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, r#fn: jolt_open_transcript_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_hyperkzg_open_with_levels(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, r#fn: jolt_open_transcript_fn, user: *mut c_void, known_levels: *const jolt_g1_t, n_known: usize, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_msm_g1_table_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, base_offset: usize, scalars: *const jolt_table, scalar_offset: usize, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_commit_onehot_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, cycle_lo: usize, cycle_hi: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_grid_commit_onehot_classes(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, shift: u32, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open_sharded(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_owned_terms(n: usize, block: usize, rank: i32, world: i32, out: *mut usize) -> i32;
     pub fn jolt_srs_setup_from_secret_blocks(ctx: *mut jolt_ctx, beta: *const jolt_fr_t, count_global: usize, g1: *const jolt_g1_t, block: usize, rank: i32, world: i32, out: *mut *mut jolt_srs) -> i32;

@@ -102,6 +102,48 @@ def test_grid_commitments_and_joint_polynomial_match_oracle(ctx, log_t, k, cold)
         ctx.grid_joint_polynomial([ctx.onehot(idx_b, 32)], s_oh[:2], [], [], log_k)
 
 
+@pytest.mark.parametrize("log_t,shift,cold", [(4, 1, 0.0), (6, 1, 0.4), (6, 2, 0.3), (5, 3, 0.2)])
+def test_class_sums_of_onehot_columns_match_oracle(ctx, log_t, shift, cold):
+    """jolt_grid_commit_onehot_classes: class c of column p = the kzg_commit of the 0/1 polynomial on the FOLDED grid (K x T / 2^shift) that is hot at
+    (hot_p(j), j >> shift) for the cycles j = c mod 2^shift -- the oracle's commitment of that polynomial over the prefix of the same SRS"""
+    T, K = 1 << log_t, 16
+    rng = np.random.default_rng(40 + log_t + shift)
+    host_srs = O.srs_setup_from_secret(rand_fr(1, 60 + log_t)[0], K * T)
+    srs = ctx.srs_upload(host_srs)
+    idx = rng.integers(0, K, size=(3, T), dtype=np.uint8)
+    if cold:
+        idx[rng.random((3, T)) < cold] = 0xFF
+    idx[2, 1::2] = 0xFF  # a column with an empty class: the identity
+    got = ctx.grid_commit_onehot_classes(srs, ctx.onehot(idx, K), shift)
+    assert got.shape == (1 << shift, 3, 12)
+    Tf = T >> shift
+    for c in range(1 << shift):
+        for p in range(3):
+            part = idx[p, c::1 << shift]  # the cycles of class c, in order: cycle j sits at folded cycle j >> shift
+            want = O.kzg_commit(embed_onehot(part, K, Tf), host_srs[: K * Tf])
+            assert same_point(got[c, p], want), (c, p)
+
+
+def test_open_with_a_supplied_level_commitment_is_the_same_proof(ctx):
+    """jolt_host_hyperkzg_open_with_levels: the first level commitment handed in (here: the one the plain opening computes) is absorbed and returned like a computed
+    one -- same challenges, same proof; a WRONG one changes the transcript (it is the caller's responsibility: the verifier rejects such a proof)"""
+    ell = 7
+    n = 1 << ell
+    host_srs = O.srs_setup_from_secret(rand_fr(1, 91)[0], n + 1)
+    srs = ctx.srs_upload(host_srs)
+    tab, point = ctx.upload(rand_fr(n, 92)), np.stack([rand_challenge(93 + k) for k in range(ell)])
+    plain = ctx.hyperkzg_open(srs, tab, point, label=4)
+    for n_known in (1, 2, ell - 1):
+        again = ctx.hyperkzg_open(srs, tab, point, label=4, known_levels=plain["com"][:n_known])
+        assert np.array_equal(again["challenges"], plain["challenges"]) and np.array_equal(again["v"], plain["v"])
+        for i in range(ell - 1):
+            assert same_point(again["com"][i], plain["com"][i])
+        for t in range(3):
+            assert same_point(again["w"][t], plain["w"][t])
+    wrong = ctx.hyperkzg_open(srs, tab, point, label=4, known_levels=plain["com"][1:2])
+    assert not np.array_equal(wrong["challenges"], plain["challenges"])
+
+
 @pytest.mark.parametrize("n_vars", [4, 6])
 def test_workload_step_commit_and_open_bit_exact_with_oracle(ctx, n_vars):
     """The whole PCS side of DeviceWorkload.step at toy size: commitments of all 38 committed columns and the opening of the joint
