@@ -520,33 +520,47 @@ class DeviceWorkload:
     def open(self, label=0):
         """Stage 8: joint polynomial of the homomorphic batch, one HyperKZG opening at the unified point."""
         joint = self.joint_polynomial()
-        known = self.level_commitments_by_linearity() if os.environ.get("JOLT_OPEN_LEVEL1", "1") != "0" and self.grid_vars >= 2 else None
+        levels = 0 if os.environ.get("JOLT_OPEN_LEVEL1", "1") == "0" else int(os.environ.get("JOLT_OPEN_LINEAR_LEVELS", "2"))
+        levels = max(0, min(levels, self.grid_vars - 1, self.n_vars))
+        known = self.level_commitments_by_linearity(levels) if levels else None
         out = self.ctx.hyperkzg_open(self.srs, joint, self.open_point, label=label, known_levels=known)
         joint.free()
         return out
 
-    def level_commitments_by_linearity(self):
-        """The commitment of the opening's FIRST folded polynomial without an MSM over its 2^(grid_vars - 1) full-width coefficients.  The joint polynomial is
-        J = sum_p s_p [hot_p(j) = k] + [k = 0] sum_d c_d f_d[j] on the grid index k T + j, and the first fold pairs adjacent cycles with x = open_point[-1]
-        (fold i uses point[ell - i], scheme.rs:97-98): P_1 = (1 - x) J_even + x J_odd, so
-            com(P_1) = sum_p s_p ((1 - x) S_p^even + x S_p^odd) + com(the dense columns' fold)
-        with S_p^c = the sum of the bases at (hot_p(j) T + j) >> 1 over the cycles of parity c (jolt_grid_commit_onehot_classes: one-hot sums at the commit leg's
-        rate), a 2 x n_onehot-term MSM over those sums, and one T / 2-term MSM for the dense part.  Returned as the (1, 12) known_levels of hyperkzg_open."""
+    def level_commitments_by_linearity(self, levels=2):
+        """The commitments of the opening's FIRST folded polynomials without MSMs over their 2^(grid_vars - s) full-width coefficients.  The joint polynomial is
+        J = sum_p s_p [hot_p(j) = k] + [k = 0] sum_d c_d f_d[j] on the grid index k T + j, and fold b pairs cycles that differ in bit b with x_b = open_point[-1 - b]
+        (fold i uses point[ell - i], scheme.rs:97-98).  After s folds the coefficient at (k, j >> s) is the sum over the residue classes c of j mod 2^s with the
+        weight w_c = prod_b (x_b if bit b of c else 1 - x_b), so
+            com(P_s) = sum_p s_p sum_c w_c S_p^(s, c) + com(the dense columns folded s times)
+        with S_p^(s, c) = the sum of the bases at (hot_p(j) T + j) >> s over the cycles of class c (jolt_grid_commit_onehot_classes: sums of bases at the commit leg's
+        rate, the same 36 x T additions for every s), a (2^s x n_onehot)-term MSM over those sums and one (T >> s)-term MSM for the dense part.  Level 1 replaces an MSM
+        of 2^25 terms, level 2 one of 2^24; from level 3 on the MSM is the cheaper way.  Returned as the (levels, 12) known_levels of hyperkzg_open."""
         ctx, ffi, T = self.ctx, self.ffi, 1 << self.n_vars
-        x = self.open_point[-1]
-        one_minus_x = ffi.host_fr_sub(ffi.host_fr_from_u64(1), x)
-        sums = [ctx.grid_commit_onehot_classes(self.srs, self.sources[i], 1) for i in sorted(self.sources)]  # per source (2, n_polys, 12)
-        points = np.concatenate([np.concatenate([c[0] for c in sums]), np.concatenate([c[1] for c in sums])])  # even classes of all columns, then odd classes
-        scalars = np.stack([ffi.host_fr_mul(sp, one_minus_x) for sp in self.rlc_onehot] + [ffi.host_fr_mul(sp, x) for sp in self.rlc_onehot])
-        small = ctx.srs_upload(points)
-        com = ctx.msm(small, scalars)
-        small.free()
-        if self.committed_dense:
-            d = ctx.rlc([self.tables[name] for name in self.committed_dense], self.rlc_dense)  # the dense part of row 0, T coefficients
-            ctx.bind([d], x)
-            com = ffi.host_g1_add(com, ctx.msm(self.srs, d, T // 2, full_width=True))
+        one = ffi.host_fr_from_u64(1)
+        xs = [self.open_point[-1 - b] for b in range(levels)]
+        d = ctx.rlc([self.tables[name] for name in self.committed_dense], self.rlc_dense) if self.committed_dense else None  # the dense part of row 0, T coefficients
+        out = []
+        for s_ in range(1, levels + 1):
+            weights = []
+            for c in range(1 << s_):
+                w = one
+                for b in range(s_):
+                    w = ffi.host_fr_mul(w, xs[b] if (c >> b) & 1 else ffi.host_fr_sub(one, xs[b]))
+                weights.append(w)
+            sums = [ctx.grid_commit_onehot_classes(self.srs, self.sources[i], s_) for i in sorted(self.sources)]  # per source (2^s, n_polys, 12)
+            points = np.concatenate([np.concatenate([cs[c] for cs in sums]) for c in range(1 << s_)])  # class by class, the columns in source order inside
+            scalars = np.stack([ffi.host_fr_mul(sp, weights[c]) for c in range(1 << s_) for sp in self.rlc_onehot])
+            small = ctx.srs_upload(points)
+            com = ctx.msm(small, scalars)
+            small.free()
+            if d is not None:
+                ctx.bind([d], xs[s_ - 1])
+                com = ffi.host_g1_add(com, ctx.msm(self.srs, d, T >> s_, full_width=True))
+            out.append(np.asarray(com, dtype=np.uint64).reshape(12))
+        if d is not None:
             d.free()
-        return np.asarray(com, dtype=np.uint64).reshape(1, 12)
+        return np.stack(out)
 
     def step(self, label=0):
         """One proof's worth of hot-path work (bench.py's timed step)."""

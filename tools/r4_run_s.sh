@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 timeout 600 python -m pytest tests/test_gpu_pcs.py -q -m gpu -x --durations=4 > "$OUT/pytest_pcs.txt" 2>&1
 tail -4 "$OUT/pytest_pcs.txt"
-for cfg in "" "JOLT_OPEN_LEVEL1=0"; do
+for cfg in "" "JOLT_OPEN_LINEAR_LEVELS=1" "JOLT_OPEN_LINEAR_LEVELS=3" "JOLT_OPEN_LEVEL1=0"; do
   echo "step opening [$cfg] $(env $cfg timeout 300 python tools/open_step.py 22 3 2>&1 | grep 'open ms')"
 done | tee "$OUT/open_level1_ab.txt"
 timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
