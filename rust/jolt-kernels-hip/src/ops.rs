@@ -280,6 +280,15 @@ impl HipHotIndices {
         Ok(Self { ctx: Arc::clone(ctx), raw, n_columns })
     }
 
+    /// Per residue class `c` of the cycle mod `2^shift` and per column the sum of the bases at `(hot * T + j) >> shift` (`jolt_grid_commit_onehot_classes`): result
+    /// `[c * n_columns + p]`.  The commitments of the joint polynomial's first folds are linear combinations of these (`HipHyperKzg::open_resident_with_levels`).
+    pub fn grid_commit_classes(&self, srs: &crate::msm::HipSrs, shift: u32) -> Result<Vec<jolt_crypto::Bn254G1>, HipError> {
+        let mut out = vec![jolt_crypto::Bn254G1::default(); self.n_columns << shift];
+        // SAFETY: live handles of one context; `out` holds 2^shift * n_columns points.
+        check(unsafe { ffi::jolt_grid_commit_onehot_classes(self.ctx.raw, srs.raw, self.raw, shift, out.as_mut_ptr().cast()) }, self.ctx.raw)?;
+        Ok(out)
+    }
+
     /// `kzg_commit` of every column as a 0/1 polynomial on the K x T commitment grid (`jolt_grid_commit_onehot`: the sum of the T bases a
     /// column selects, no scalars; `crates/jolt-hyperkzg/src/kzg.rs:15-27` over `TracePlacement` cycle-major, `optimized/opening.rs:340-372`).
     pub fn grid_commit(&self, srs: &crate::msm::HipSrs) -> Result<Vec<jolt_crypto::Bn254G1>, HipError> {

@@ -221,7 +221,22 @@ impl HipHyperKzg {
         setup: &HipHyperKzgSetup,
         transcript: &mut T,
     ) -> Result<HyperKZGProof<Bn254>, HipError> {
-        setup.with_device(|ctx, srs| poly.resident(|t| Self::open_table(ctx, srs, t, point, transcript)))
+        setup.with_device(|ctx, srs| poly.resident(|t| Self::open_table(ctx, srs, t, point, transcript, &[])))
+    }
+
+    /// The same with the commitments of the first folded polynomials SUPPLIED (`jolt_host_hyperkzg_open_with_levels`): for the joint polynomial of one-hot and dense
+    /// columns they follow by linearity from [`crate::ops::HipHotIndices::grid_commit_classes`] -- `com(P_s) = sum_p s_p sum_c w_c S_p^(s,c) + com(dense fold)`,
+    /// `DESIGN.md` section 3.7b; `jolt_amd/workload.py::level_commitments_by_linearity` is the executable description of the combination -- instead of from MSMs over
+    /// 2^(ell - s) full-width scalars.  They are absorbed and returned like computed ones.
+    pub fn open_resident_with_levels<T: Transcript<Challenge = Fr>>(
+        poly: &HipPoly,
+        point: &[Fr],
+        setup: &HipHyperKzgSetup,
+        transcript: &mut T,
+        known_levels: &[HyperKZGCommitment<Bn254>],
+    ) -> Result<HyperKZGProof<Bn254>, HipError> {
+        let points: Vec<Bn254G1> = known_levels.iter().map(|c| c.point).collect();
+        setup.with_device(|ctx, srs| poly.resident(|t| Self::open_table(ctx, srs, t, point, transcript, &points)))
     }
 
     fn open_table<T: Transcript<Challenge = Fr>>(
@@ -230,6 +245,7 @@ impl HipHyperKzg {
         table: &HipTable,
         point: &[Fr],
         transcript: &mut T,
+        known_levels: &[Bn254G1],
     ) -> Result<HyperKZGProof<Bn254>, HipError> {
         let ell = point.len();
         let mut com = vec![Bn254G1::default(); ell.saturating_sub(1).max(1)];
@@ -240,14 +256,17 @@ impl HipHyperKzg {
         // its transcript outlive the call; the library never unwinds.
         check(
             unsafe {
-                ffi::jolt_host_hyperkzg_open_with_transcript(
+                ffi::jolt_host_hyperkzg_open_with_levels(
                     ctx.raw,
                     srs.raw,
                     table.raw,
                     point.as_ptr().cast(),
                     ell,
+                    0,
                     Some(open_hook::<T>),
                     (&mut hook as *mut Hook<'_, T>).cast(),
+                    if known_levels.is_empty() { ptr::null() } else { known_levels.as_ptr().cast() },
+                    known_levels.len(),
                     com.as_mut_ptr().cast(),
                     w.as_mut_ptr().cast(),
                     v.as_mut_ptr().cast(),
@@ -299,7 +318,7 @@ impl CommitmentScheme for HipHyperKzg {
         transcript: &mut impl Transcript<Challenge = Self::Field>,
     ) -> Result<Self::Proof, OpeningsError> {
         setup
-            .with_device(|ctx, srs| Self::open_table(ctx, srs, &Self::upload(ctx, poly)?, point, transcript))
+            .with_device(|ctx, srs| Self::open_table(ctx, srs, &Self::upload(ctx, poly)?, point, transcript, &[]))
             .map_err(|e| OpeningsError::ProveFailed(format!("HyperKZG open failed on the device: {e:?}")))
     }
 
