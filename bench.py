@@ -444,7 +444,8 @@ def main():
                 f"per-proof tables (witness promotion, eq / eq+1 / LT expansions, linear-leaf fusions, members), commits the {n_onehot + 2} committed columns "
                 f"on the 2^{wl.grid_vars} commitment grid (2 dense MSMs of T 64-bit scalars + {n_onehot} one-hot columns as sums of bases), {ext_note}proves the "
                 f"stage 2-6b cycle-domain sumchecks (11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5) and opens the joint polynomial "
-                f"(2^{wl.grid_vars} coefficients) with ONE HyperKZG opening (MSM, commit and open inside the timed region)")
+                f"(2^{wl.grid_vars} coefficients) with ONE HyperKZG opening whose first two level commitments are combined from class sums of the one-hot columns' bases instead of "
+                f"MSMs over the folded coefficients (all of it -- sums, MSMs, commit and open -- inside the timed region)")
     else:
         what = (f"sha3-shaped synthetic trace, T=2^{args.scale} per GPU: per-proof tables + {ext_note}stages 2-6b cycle-domain sumchecks "
                 f"(11 relations, {wl.n_tables} T-sized tables{onehot_note}, degree 2-5), bind + round-poly HIP kernels; MSM not in the timed region "
