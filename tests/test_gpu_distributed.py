@@ -273,8 +273,8 @@ def test_a_local_failure_in_the_sharded_opening_reaches_every_rank():
     assert outcomes == ["JoltError 9", "JoltError 9"], outcomes  # JOLT_ERR_SRS_TOO_SMALL on both
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world):
+@pytest.mark.parametrize("world,scale,steps", [(2, 10, 2), (4, 10, 2), (8, 12, 1), (8, 14, 1)])  # 8 x 2^14: configs[3]'s own shape (`--gpus 8`), as large as 8 ranks sharing one GPU finish in seconds
+def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world, scale, steps):
     """`python bench.py --gpus N` with NO launcher around it (the driver's bare command shape): the script re-executes itself under
     torch.distributed.run with N ranks and rank 0 prints one JSON line with n_gpus = N.  JOLT_BENCH_SHARE_GPU=1 puts every rank on device 0
     with gloo as the rendezvous backend (this box has one GPU; RCCL needs one device per rank): the N > 1 code path of bench.py -- sharded
@@ -285,7 +285,7 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["JOLT_BENCH_SHARE_GPU"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--scale", "10", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--scale", str(scale), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -297,7 +297,8 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world):
     for l in r.stdout.splitlines():
         assert l.startswith("{") or set(l) <= banner, l[:200]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == world and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["n_gpus"] == world and line["steps"] == steps and line["scaling"] == "weak"
+    assert line["config"]["trace_length_total"] == world << scale
     assert line["value"] == pytest.approx(world * (1 << 10) / (line["ms_per_step"] * 1e-3), rel=1e-3)
     cfg = line["config"]
     assert cfg["trace_length_per_gpu"] == 1 << 10 and "configs[2] sharded" in cfg["workload"] and "every step rebuilds" in cfg["workload"]
@@ -355,7 +356,8 @@ def _extended_worker(rank, world, port, tmpdir, n_local, kw):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
     import pickle
-    from util import init_gloo
+    from util import init_gloo, stack_dump_later
+    stack_dump_later(f"extended_w{world}_r{rank}", 240)  # a hang at N ranks leaves every rank's stack under gpurun_out/stacks/ instead of a silent timeout
     dist = init_gloo(rank, world, port, seconds=300)
     from jolt_amd import distributed as D
     from jolt_amd import ffi
@@ -363,7 +365,8 @@ def _extended_worker(rank, world, port, tmpdir, n_local, kw):
     ctx = ffi.Context(0)
     coll = D.Collective(dist, world, None)
     ext = ShardedExtended(ctx, n_local, rank, world, coll, seed=77, **kw)
-    outs = [ext.prove(label=40), ext.prove(label=40)]  # a second proof over the resident inputs: same bytes
+    outs = [ext.prove(label=40) for _ in range(1 if world >= 8 else 2)]  # a second proof over the resident inputs: same bytes (8 ranks time-slicing one GPU: one proof, the
+    # two-proof run took 134 s, profiles/r05_pytest_8rank_stage_operators.txt)
     with open(os.path.join(tmpdir, f"got{rank}.pkl"), "wb") as f:
         pickle.dump(dict(outs=outs, claims=ext.claims), f)
     ext.close()
@@ -372,7 +375,7 @@ def _extended_worker(rank, world, port, tmpdir, n_local, kw):
 
 
 @pytest.mark.parametrize("world,n_local,kw", [(2, 6, dict(n_tables=8, log_k=5, log_kb=5)), (4, 5, dict(n_tables=6, log_k=4, log_kb=4)), (2, 10, dict(n_tables=12, log_k=8)),
-                                              (1, 6, dict(n_tables=5, log_k=4))])  # (8 ranks time-slicing one GPU did not finish in the 75 s the round had left: not in the suite)
+                                              (1, 6, dict(n_tables=5, log_k=4)), (8, 4, dict(n_tables=5, log_k=4, log_kb=4))])
 def test_sharded_stage_operators_prove_one_trace(world, n_local, kw):
     """The stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators over ONE trace of world * 2^n_local cycles dealt to `world` ranks (jolt_amd/stages_sharded.py; all ranks on GPU 0,
     gloo standing in for RCCL): every rank's messages -- uni-skip sums, every round polynomial of every operator (the sparse matrices' local, merged-cycle and address

@@ -44,3 +44,15 @@ def init_gloo(rank, world, port, seconds=120):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=seconds))
     return dist
+
+
+def stack_dump_later(tag, seconds):
+    """faulthandler watchdog for the multi-process tests: if this process is still alive after `seconds`, every thread's Python stack goes to
+    gpurun_out/stacks/<tag>.txt (kept by gpurun) -- tells a hang in an exchange from plain slowness.  The process is not killed; the test's own timeouts do that."""
+    import faulthandler
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "stacks")
+    os.makedirs(d, exist_ok=True)
+    f = open(os.path.join(d, f"{tag}.txt"), "w")
+    faulthandler.dump_traceback_later(seconds, repeat=False, file=f, exit=False)
+    return f
