@@ -787,6 +787,13 @@ int32_t jolt_host_hyperkzg_open_with_levels(jolt_ctx *ctx, const jolt_srs *srs, 
  * and added in rank order, so every rank absorbs the same commitments and returns the same proof as jolt_host_hyperkzg_open. */
 int32_t jolt_msm_g1_table_range(jolt_ctx *ctx, const jolt_srs *srs, size_t base_offset, const jolt_table *scalars, size_t scalar_offset,
                                 size_t n, jolt_g1_t *out);
+/* One window of a STREAMED commitment: StreamingCommitment::{feed, feed_u64, feed_i128, feed_i128_rows_with} for a KZG-type scheme
+ * (crates/jolt-openings/src/schemes.rs:167-222; the callers: crates/jolt-kernels/src/reference/commitment.rs:86-121, optimized/commitment.rs:317-352).  The
+ * polynomial arrives in coefficient order as host slices; out = acc + sum_{i<n} values[i] * srs[base_offset + i] (acc == NULL: the identity), values being n field
+ * elements (kind JOLT_SCALAR_FR) or machine integers promoted by Ring::from_u64 / from_i64 / from_i128 (kind JOLT_INT_*).  Stateless: the caller's PartialCommitment is
+ * the pair (point, next coefficient index).  base_offset + n beyond the SRS is JOLT_ERR_SRS_TOO_SMALL. */
+enum { JOLT_SCALAR_FR = 3 };
+int32_t jolt_msm_g1_window(jolt_ctx *ctx, const jolt_srs *srs, size_t base_offset, int32_t kind, const void *host, size_t n, const jolt_g1_t *acc, jolt_g1_t *out);
 int32_t jolt_grid_commit_onehot_range(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *source, size_t cycle_lo, size_t cycle_hi,
                                       jolt_g1_t *out /* n_polys */);
 /* out[c * n_polys + p] = sum over the cycles j = c (mod 2^shift) of srs[(hot_p(j) * T + j) >> shift]: the commitments of the 2^shift residue-class parts of every column

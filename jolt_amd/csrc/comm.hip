@@ -10,6 +10,7 @@
 // container.  The caller names the library: it must be the RCCL built against the HIP runtime THIS library uses (the system one);
 // a process that imported torch also holds torch's private HIP/HSA runtime and librccl, and streams do not cross runtimes.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include "desc.hpp"
@@ -29,15 +30,50 @@ struct RcclApi {
     std::string error;
 };
 
+// how many loaded objects of this process carry `needle` in their file name
+struct LoadedCount {
+    const char* needle;
+    int n;
+};
+static int count_loaded_cb(struct dl_phdr_info* info, size_t, void* data) {
+    LoadedCount* c = (LoadedCount*)data;
+    if (info->dlpi_name && std::strstr(info->dlpi_name, c->needle)) c->n++;
+    return 0;
+}
+static int count_loaded(const char* needle) {
+    LoadedCount c{needle, 0};
+    dl_iterate_phdr(count_loaded_cb, &c);
+    return c.n;
+}
+
+// Which RCCL.  A process holds ONE HIP runtime or this communicator refuses to exist: RCCL enqueues on the context's stream, and streams do not cross runtimes.  A
+// process that imported torch BEFORE this library was loaded runs both on torch's bundled libamdhip64 (same SONAME: the loader resolves our NEEDED entry to it) and
+// already holds torch's librccl with its own librocm_smi64 -- that copy is then the one to use: loading the system librccl next to it brings a second librocm_smi64
+// whose C++ globals interpose with the first's, and the process aborts at exit with "double free or corruption" in ~std::map<amd::smi::DevInfoTypes, ..>
+// (profiles/r05_teardown_abort_backtrace.txt: the round-4 teardown abort).  So: an RCCL already in the process wins; otherwise the named / system one is loaded.
+RcclApi g_rccl;
 RcclApi* rccl_api(const char* path) {
-    static RcclApi api;
+    RcclApi& api = g_rccl;
     if (api.handle) return &api;
+    if (count_loaded("libamdhip64") > 1) {
+        api.error = "two HIP runtimes are loaded in this process (torch was imported AFTER libjolt_hip.so was loaded): import torch first, or keep torch out of the process";
+        return nullptr;
+    }
+    for (const char* c : {"librccl.so.1", "librccl.so"}) {
+        api.handle = dlopen(c, RTLD_NOW | RTLD_NOLOAD);  // matches the SONAME of an object that is already loaded, whatever path it came from
+        if (api.handle) break;
+    }
+    if (!api.handle && count_loaded("librocm_smi64") > count_loaded("librocm_smi64.so.1")) {
+        // no RCCL in the process yet, but a bundled rocm_smi under another name: the system librccl would bring librocm_smi64.so.1 beside it -- the crash above
+        api.error = "a bundled librocm_smi64 is loaded without its librccl: loading the system RCCL beside it would duplicate rocm_smi's globals";
+        return nullptr;
+    }
     const char* candidates[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* c : candidates) {
-        if (!c || !*c) continue;
-        api.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
         if (api.handle) break;
-        api.error = dlerror();
+        if (!c || !*c) continue;
+        api.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) api.error = dlerror();
     }
     if (!api.handle) return nullptr;
     api.get_unique_id = (decltype(api.get_unique_id))dlsym(api.handle, "ncclGetUniqueId");
@@ -53,6 +89,7 @@ RcclApi* rccl_api(const char* path) {
     }
     return &api;
 }
+const char* rccl_error() { return g_rccl.error.empty() ? "dlopen librccl.so.1 failed" : g_rccl.error.c_str(); }
 }  // namespace
 
 struct jolt_comm {
@@ -107,7 +144,7 @@ extern "C" int32_t jolt_comm_create(jolt_ctx* ctx, const char* rccl_path, const 
     if (!ctx || !unique_id || !out || world < 1 || rank < 0 || rank >= world) return JOLT_ERR_INVALID_ARG;
     RcclApi* api = rccl_api(rccl_path);
     if (!api) {
-        ctx->last_error = "RCCL not available (dlopen librccl.so.1 failed)";
+        ctx->last_error = std::string("RCCL not available: ") + rccl_error();
         return JOLT_ERR_UNSUPPORTED;
     }
     jolt_comm* c = new (std::nothrow) jolt_comm();

@@ -707,6 +707,38 @@ extern "C" int32_t jolt_msm_g1_table_range(jolt_ctx* ctx, const jolt_srs* srs, s
     return JOLT_OK;
 }
 
+// One window of a STREAMED commitment (StreamingCommitment::{feed, feed_u64, feed_i128}, crates/jolt-openings/src/schemes.rs:167-222): the polynomial arrives in
+// coefficient order as host slices of field elements or machine integers; the window's share is sum_i values[i] * srs[base_offset + i], added to the running
+// partial commitment.  Stateless on purpose: the caller's PartialCommitment is (point, next coefficient index), a plain value it can clone.
+extern "C" int32_t jolt_msm_g1_window(jolt_ctx* ctx, const jolt_srs* srs, size_t base_offset, int32_t kind, const void* host, size_t n, const jolt_g1_t* acc, jolt_g1_t* out) {
+    if (!ctx || !srs || !out || (!host && n)) return JOLT_ERR_INVALID_ARG;
+    if (kind != JOLT_SCALAR_FR && kind != JOLT_INT_U64 && kind != JOLT_INT_I64 && kind != JOLT_INT_I128) return JOLT_ERR_INVALID_ARG;
+    if (n > srs->n || base_offset > srs->n - n) return JOLT_ERR_SRS_TOO_SMALL;
+    G1Jac sum = g1_identity();
+    if (acc) std::memcpy(&sum, acc, sizeof(sum));
+    if (n) {
+        jolt_table* t = nullptr;
+        if (kind == JOLT_SCALAR_FR) {
+            JOLT_TRY(jolt_table_upload(ctx, (const jolt_fr_t*)host, n, &t));
+        } else {
+            jolt_ints* v = nullptr;
+            JOLT_TRY(jolt_ints_upload(ctx, host, kind, n, &v));
+            const int32_t s = jolt_table_from_ints(ctx, v, 0, n, &t);
+            jolt_ints_free(ctx, v);
+            if (s != JOLT_OK) return s;
+        }
+        jolt_g1_t part;
+        const int32_t s = jolt_msm_g1_table_range(ctx, srs, base_offset, t, 0, n, &part);
+        jolt_table_free(ctx, t);
+        if (s != JOLT_OK) return s;
+        G1Jac p;
+        std::memcpy(&p, &part, sizeof(p));
+        sum = g1_add(sum, p);
+    }
+    std::memcpy(out, &sum, sizeof(sum));
+    return JOLT_OK;
+}
+
 // rank's share of sum_{i < n} scalars[i] * SRS[i] under a sharded term assignment: `srs` is the rank's compact SRS
 // (jolt_srs_setup_from_secret_blocks / _subtree, or an upload of the same points); the shares of all ranks add up to the MSM
 static int32_t msm_share(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, const TermMap& map, jolt_g1_t* out) {

@@ -740,6 +740,20 @@ def _msm(self, srs, scalars, n=None, full_width=False):
     return out[0]
 
 
+def _msm_window(self, srs, base_offset, values, kind=None, acc=None):
+    """One window of a streamed commitment (jolt_msm_g1_window: StreamingCommitment::feed / feed_u64 / feed_i128 for a KZG-type scheme): acc + sum_i values[i] *
+    srs[base_offset + i].  values: (n, 4) uint64 field elements (kind "fr"), uint64 / int64 arrays, or i128 as an (n, 2) uint64 array (kind "i128")."""
+    v = np.ascontiguousarray(values)
+    if kind is None:
+        kind = "fr" if (v.ndim == 2 and v.shape[1] == 4) else ({np.dtype(np.uint64): "u64", np.dtype(np.int64): "i64"}[v.dtype] if v.ndim == 1 else "i128")
+    code = {"u64": 0, "i64": 1, "i128": 2, "fr": 3}[kind]
+    out = g1_array(1)
+    a = None if acc is None else np.ascontiguousarray(acc, dtype=np.uint64).reshape(-1)
+    _ck(lib().jolt_msm_g1_window(self.h, srs.h, C.c_size_t(base_offset), C.c_int32(code), v.ctypes.data_as(C.c_void_p), C.c_size_t(v.shape[0]),
+                                 None if a is None else _p(a), _p(out)), "jolt_msm_g1_window", self)
+    return out[0]
+
+
 def _hyperkzg_fold(self, evals, point):
     p = fr(point).reshape(-1, 4)
     ell = p.shape[0]
@@ -799,6 +813,7 @@ Context.srs_precompute_windows = _srs_precompute_windows
 Context.srs_upload = _srs_upload
 Context.srs_setup_from_secret = _srs_setup_from_secret
 Context.msm = _msm
+Context.msm_window = _msm_window
 Context.srs_setup_from_secret_blocks = _srs_setup_from_secret_blocks
 Context.msm_blocks = _msm_blocks
 Context.srs_setup_from_secret_subtree = _srs_setup_from_secret_subtree

@@ -262,6 +262,9 @@ pub struct Mi355xParts {
 /// which opening / derived table each leaf of its `Expr` is, `crates/jolt-kernels/src/reference/views.rs:20-138`).  A slot whose `prepare`
 /// answers `KernelError::Unsupported` (no gfx950 device, a descriptor beyond the library's compiled limits, out of HBM) is recoverable: the
 /// stage driver retries it against `optimized()`.
+///
+/// `JoltBackend::<Fr, HipHyperKzg>::optimized()` is bounded by `PCS: ModeStreamingCommitment` (`optimized/mod.rs:136-139`); `crate::streaming` is where
+/// `HipHyperKzg` meets it (`StreamingCommitment`, and `ZkStreamingCommitment` for the `zk` feature).
 pub fn mi355x(ctx: &Arc<HipContext>, parts: Mi355xParts) -> JoltBackend<Fr, HipHyperKzg> {
     let mut backend = JoltBackend::<Fr, HipHyperKzg>::optimized();
     let commit = std::mem::replace(&mut backend.commit, Box::new(NoCommit));

@@ -113,6 +113,7 @@ pub const JOLT_MEMBER_FLAG_BORROW_TABLES: u32 = 2;
 pub const JOLT_INT_U64: i32 = 0;
 pub const JOLT_INT_I64: i32 = 1;
 pub const JOLT_INT_I128: i32 = 2;
+pub const JOLT_SCALAR_FR: i32 = 3;
 pub const JOLT_MAX_MEMBER_TABLES: usize = 40;
 pub const JOLT_MAX_MEMBER_TERMS: usize = 16;
 pub const JOLT_MAX_MEMBER_FACTORS: usize = 64;
@@ -365,6 +366,7 @@ extern "C" {
     pub fn jolt_host_hyperkzg_open_with_transcript(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, r#fn: jolt_open_transcript_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_hyperkzg_open_with_levels(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, r#fn: jolt_open_transcript_fn, user: *mut c_void, known_levels: *const jolt_g1_t, n_known: usize, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_msm_g1_table_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, base_offset: usize, scalars: *const jolt_table, scalar_offset: usize, n: usize, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_msm_g1_window(ctx: *mut jolt_ctx, srs: *const jolt_srs, base_offset: usize, kind: i32, host: *const c_void, n: usize, acc: *const jolt_g1_t, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_commit_onehot_range(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, cycle_lo: usize, cycle_hi: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_commit_onehot_classes(ctx: *mut jolt_ctx, srs: *const jolt_srs, source: *const jolt_onehot, shift: u32, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_hyperkzg_open_sharded(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;

@@ -13,6 +13,7 @@
 //! | `optimized::{spartan_outer, spartan_product, ram_read_write, instruction_read_raf}` T-scale loops | [`ops::SpartanSums`], [`ops::HipRwMatrix`], [`ops::HipReadRaf`] |
 //! | HyperKZG prover pieces (`crates/jolt-hyperkzg/src/{kzg,scheme}.rs`) | [`msm::HipSrs`], `ffi::jolt_hyperkzg_*` |
 //! | `CommitmentScheme` + `AdditivelyHomomorphic` for HyperKZG (`crates/jolt-openings/src/schemes.rs:43-163`, `crates/jolt-hyperkzg/src/scheme.rs:275-353`) | [`pcs::HipHyperKzg`] over device-resident [`pcs::HipPoly`]s, the caller's transcript through `jolt_open_transcript_fn` |
+//! | `StreamingCommitment` (+ transparent-mode `ZkOpeningScheme` / `ZkStreamingCommitment` shims) for HyperKZG (`crates/jolt-openings/src/schemes.rs:167-365`): what `JoltBackend::{reference,optimized}()` bound their commit slot by (`crates/jolt-kernels/src/commitment.rs:34-45`) | [`streaming`]: staged windows through `jolt_msm_g1_window`, one-hot columns through `jolt_grid_commit_onehot` |
 //! | `RowSource::rows` / `WitnessBundle::from_row` witness hand-over (`crates/jolt-witness/src/consumer.rs:129-143`) | [`rows::HipPinnedRows`], [`rows::HipRows`]: one H2D copy of packed rows, columns extracted on the device |
 //! | `UniskipKernel`, `CommitWitness`, the backend constructor (`crates/jolt-kernels/src/{uniskip.rs:28-54, commitment.rs:137-160, optimized/mod.rs:136-196}`) | [`backend::HipUniskip`], [`backend::HipCommitWitness`], [`backend::mi355x`] |
 //!
@@ -31,6 +32,7 @@ pub mod rows;
 pub mod backend;
 pub mod scheduler;
 pub mod status;
+pub mod streaming;
 
 pub use context::{HipContext, HipTable};
 pub use member::{HipMember, HipPrepare, HipSumcheckProver, MemberShape, MemberSlot};
@@ -41,3 +43,4 @@ pub use pcs::{HipHyperKzg, HipHyperKzgSetup, HipPoly};
 pub use rows::{HipPinnedRows, HipRows};
 pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
 pub use status::HipError;
+pub use streaming::{HipOneHotChunk, HipOneHotStream, HipPartialCommitment};

@@ -280,6 +280,16 @@ impl HipHotIndices {
         Ok(Self { ctx: Arc::clone(ctx), raw, n_columns })
     }
 
+    /// The same for address spaces beyond 255 (`jolt_onehot_upload16`: two bytes per entry, `0xFFFF` = cold cycle; `log_k_chunk = 8` from
+    /// `log T >= 25`, `crates/jolt-prover/src/config.rs:175-186`).
+    pub fn upload16(ctx: &Arc<HipContext>, indices: &[u16], n_columns: usize, cycles: usize, k: u32) -> Result<Self, HipError> {
+        debug_assert_eq!(indices.len(), n_columns * cycles);
+        let mut raw = ptr::null_mut();
+        // SAFETY: `indices` holds n_columns * cycles u16 entries; the upload is synchronous.
+        check(unsafe { ffi::jolt_onehot_upload16(ctx.raw, indices.as_ptr(), n_columns, cycles, k, &mut raw) }, ctx.raw)?;
+        Ok(Self { ctx: Arc::clone(ctx), raw, n_columns })
+    }
+
     /// Per residue class `c` of the cycle mod `2^shift` and per column the sum of the bases at `(hot * T + j) >> shift` (`jolt_grid_commit_onehot_classes`): result
     /// `[c * n_columns + p]`.  The commitments of the joint polynomial's first folds are linear combinations of these (`HipHyperKzg::open_resident_with_levels`).
     pub fn grid_commit_classes(&self, srs: &crate::msm::HipSrs, shift: u32) -> Result<Vec<jolt_crypto::Bn254G1>, HipError> {

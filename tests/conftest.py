@@ -28,32 +28,3 @@ def _oracle_threads():
     except Exception:  # the oracle library is built by the fixtures that need it; nothing to configure before that
         pass
     yield
-
-
-# ---- GPU runs: leave the interpreter without its teardown --------------------------------------------------------------------------------------------------------
-# A `pytest -m gpu` process holds two HIP runtimes (the system one under libjolt_hip.so, torch's bundled one for the multi-process tests), two OpenMP runtimes
-# (liboracle's, torch's) and their atexit handlers.  Once this round glibc aborted such a process AFTER the summary line ("33 passed ... double free or corruption"
-# at interpreter exit, profiles/r04_pytest_gpu_last_tree.txt's sibling run): every test had passed, the exit status was 134.  The outcome of a test run is the
-# outcome of its tests, so a GPU run ends with os._exit(<pytest's own exit status>) once the report is written and the Python-level exit handlers have run, skipping only the loaded
-# libraries' C-level destructors; CPU runs
-# (-m "not gpu") leave normally.  bench.py and smoke() are untouched: they exit through the normal path.
-_exit_status = {"code": None}
-
-
-def pytest_sessionfinish(session, exitstatus):
-    _exit_status["code"] = int(exitstatus)
-
-
-@pytest.hookimpl(trylast=True)  # after every other plugin's unconfigure (reporters, recorders)
-def pytest_unconfigure(config):
-    expr = (config.getoption("markexpr", default="") or "").strip()
-    if _exit_status["code"] is None or "gpu" not in expr or "not gpu" in expr:
-        return
-    try:  # Python-level exit handlers still run (anything a harness registered with atexit); only the C-level destructors of the loaded libraries are skipped
-        import atexit
-        atexit._run_exitfuncs()
-    except Exception:
-        pass
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(_exit_status["code"])

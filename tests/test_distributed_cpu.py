@@ -105,7 +105,7 @@ def _worker(rank, world, port, tmpdir, tail_log):
 def test_sharded_prove_batch_matches_single_process(world, tail_log):
     """tail_log = 0: the shards run all their local rounds and hand over single entries; tail_log > 0: early hand-over of
     2^tail_log-entry tables (fewer exchanges); tail_log = n_local (world 4, 3): everything runs in the redundant tail."""
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn (standard library): the same launcher the GPU tests use
     port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(world, port, tmp, tail_log), nprocs=world, join=True)
@@ -137,7 +137,7 @@ def _msm_worker(rank, world, port, tmpdir):
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_msm_combines_to_the_single_process_point(world):
     """Term-range sharded MSM: per-rank partial sums, one all-gather of `world` Jacobian points, world-1 additions."""
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn (standard library): the same launcher the GPU tests use
     port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_msm_worker, args=(world, port, tmp), nprocs=world, join=True)
@@ -170,7 +170,7 @@ def test_shared_memory_round_exchange(world):
     """jolt_shm_* (csrc/shm_exchange.hip): the per-round exchange between the ranks of one node, host memory only -- 3000 exchanges of
     varying size between `world` processes, stragglers included, every rank sees every rank's payload of the same exchange; an
     oversized payload and a second creator are refused."""
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn (standard library): the same launcher the GPU tests use
     from jolt_amd import distributed as D
     from jolt_amd import ffi
     name = f"/jolt_test_{os.getpid()}_{world}"
@@ -252,7 +252,7 @@ def _gather_sum_worker(rank, world, port, tmpdir):
 def test_gather_sum_is_the_modular_sum_over_the_ranks(world):
     """distributed.gather_sum (what the cross-rank stage operators use for every additive T-scale quantity: uni-skip sums, pushforward masses, read-RAF scan sums):
     ONE all-gather + fr_add_vec on every rank == the oracle's field sum of the ranks' shares, wrap-arounds included, for flat and blocked arrays"""
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn (standard library): the same launcher the GPU tests use
     port = 29500 + (os.getpid() % 2000) + 17 * world
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_gather_sum_worker, args=(world, port, tmp), nprocs=world, join=True)

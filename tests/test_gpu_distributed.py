@@ -37,7 +37,7 @@ def test_sharded_device_workload_matches_global_oracle(world, n_local, tail_log)
     """tail_log 0: all local rounds sharded, single entries handed over; 3: early hand-over of 8-entry tables (packed,
     gathered, interleaved on the device); 6 = n_local: everything in the redundant tail.  World 4 and 8 (all ranks on GPU 0): two and
     three hypercube variables select the rank -- more tail rounds, the 8-rank slots of the shared-memory round exchange."""
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn: torch.multiprocessing.spawn's contract without torch in this process
     import oracle_lib as O
     from jolt_amd import distributed as D
     from jolt_amd import workload as W
@@ -148,7 +148,7 @@ def _msm_worker(rank, world, port, tmpdir):
 
 
 def test_sharded_device_msm_two_ranks():
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn: torch.multiprocessing.spawn's contract without torch in this process
     port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_msm_worker, args=(2, port, tmp), nprocs=2, join=True)
@@ -194,7 +194,7 @@ def test_sharded_commit_and_open_equal_the_single_process_proof(world, n_local, 
         (jolt_host_hyperkzg_open_subtree; window tables over the rank's own bases from n_local = 8 on);
       cyclic: polynomial arithmetic replicated, every MSM split block-cyclically over per-rank compact bases;
       range: the same with contiguous term ranges against the full SRS."""
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn: torch.multiprocessing.spawn's contract without torch in this process
     import oracle_lib as O
     port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
@@ -261,7 +261,7 @@ def test_a_local_failure_in_the_sharded_opening_reaches_every_rank():
     """One rank fails inside the opening (its SRS is too short); the status word every exchange carries makes BOTH ranks return that error instead of
     the healthy rank blocking in the collective (which the shared-memory exchange would time out of and RCCL would hang in)."""
     import subprocess
-    code = ("import sys; sys.path.insert(0, %r); import test_gpu_distributed as t, torch.multiprocessing as mp; "
+    code = ("import sys; sys.path.insert(0, %r); import test_gpu_distributed as t, util as mp; "
             "mp.spawn(t._failing_rank_worker, args=(2, %d, %r), nprocs=2, join=True)")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "outcome")
@@ -299,7 +299,7 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world, scale, steps):
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["steps"] == steps and line["scaling"] == "weak"
     assert line["config"]["trace_length_total"] == world << scale
-    assert line["value"] == pytest.approx(world * (1 << 10) / (line["ms_per_step"] * 1e-3), rel=1e-3)
+    assert line["value"] == pytest.approx(world * (1 << scale) / (line["ms_per_step"] * 1e-3), rel=1e-3)
     cfg = line["config"]
     assert cfg["trace_length_per_gpu"] == 1 << 10 and "configs[2] sharded" in cfg["workload"] and "every step rebuilds" in cfg["workload"]
     assert cfg["round_exchange"].startswith(("rccl", "torch")) and f"{world} rank(s)" in cfg["communicator"] and "pcs" in cfg
@@ -334,7 +334,7 @@ def test_native_rccl_with_two_ranks_on_one_device_is_refused_or_works_but_never_
     refuse duplicate devices (then ShardedWorkload's collective decision falls back on every rank), it must not hang, and if it ever
     accepts them the all-gather must be right.  The outcome is printed and kept under gpurun_out/ for DESIGN.md section 6."""
     import subprocess
-    code = ("import sys; sys.path.insert(0, %r); import test_gpu_distributed as t, torch.multiprocessing as mp; "
+    code = ("import sys; sys.path.insert(0, %r); import test_gpu_distributed as t, util as mp; "
             "mp.spawn(t._rccl_same_device_worker, args=(2, %d, %r), nprocs=2, join=True)")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "outcome")
@@ -381,7 +381,7 @@ def test_sharded_stage_operators_prove_one_trace(world, n_local, kw):
     gloo standing in for RCCL): every rank's messages -- uni-skip sums, every round polynomial of every operator (the sparse matrices' local, merged-cycle and address
     rounds, the 128 read-RAF address rounds, the sharded cycle phases), challenges, claims, final values -- equal the single-process oracle twin of the GLOBAL trace."""
     import pickle
-    import torch.multiprocessing as mp
+    import util as mp  # util.spawn: torch.multiprocessing.spawn's contract without torch in this process
     from jolt_amd import stages as S
     from test_gpu_extended import same
     from workload_oracle import OracleExtended

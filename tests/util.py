@@ -56,3 +56,35 @@ def stack_dump_later(tag, seconds):
     f = open(os.path.join(d, f"{tag}.txt"), "w")
     faulthandler.dump_traceback_later(seconds, repeat=False, file=f, exit=False)
     return f
+
+
+def _spawn_entry(fn, rank, args):
+    fn(rank, *args)
+
+
+def spawn(fn, args=(), nprocs=1, join=True, timeout=None):
+    """torch.multiprocessing.spawn's contract -- fn(rank, *args) in `nprocs` fresh interpreters, an exception if any of them fails -- on the standard library, so that the
+    pytest process itself never imports torch: a GPU test process that holds torch (its bundled HIP runtime, RCCL and rocm_smi) NEXT TO libjolt_hip.so's system ones
+    aborted at exit in round 4 (profiles/r05_teardown_abort_backtrace.txt).  The workers import torch first (init_gloo) and libjolt_hip.so after it: one runtime each."""
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    procs = [ctx.Process(target=_spawn_entry, args=(fn, r, tuple(args)), daemon=False) for r in range(nprocs)]
+    for p in procs:
+        p.start()
+    if not join:
+        return procs
+    failed = []
+    for r, p in enumerate(procs):
+        p.join(timeout)
+        if p.is_alive():
+            p.kill()
+            p.join()
+            failed.append((r, "timeout"))
+        elif p.exitcode != 0:
+            failed.append((r, p.exitcode))
+    if failed:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise RuntimeError(f"spawned rank(s) failed: {failed}")
+    return None

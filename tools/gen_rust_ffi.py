@@ -126,7 +126,7 @@ def render(decls):
         out.append(f"pub const {name}: i32 = {k};")
     out.append("pub const JOLT_ORDER_LOW_TO_HIGH: i32 = 0;\npub const JOLT_ORDER_HIGH_TO_LOW: i32 = 1;")
     out.append("pub const JOLT_MEMBER_FLAG_SKIP_ONE: u32 = 1;\npub const JOLT_MEMBER_FLAG_BORROW_TABLES: u32 = 2;")
-    out.append("pub const JOLT_INT_U64: i32 = 0;\npub const JOLT_INT_I64: i32 = 1;\npub const JOLT_INT_I128: i32 = 2;")
+    out.append("pub const JOLT_INT_U64: i32 = 0;\npub const JOLT_INT_I64: i32 = 1;\npub const JOLT_INT_I128: i32 = 2;\npub const JOLT_SCALAR_FR: i32 = 3;")
     out.append("pub const JOLT_MAX_MEMBER_TABLES: usize = 40;\npub const JOLT_MAX_MEMBER_TERMS: usize = 16;\npub const JOLT_MAX_MEMBER_FACTORS: usize = 64;\npub const JOLT_MAX_DEGREE: usize = 7;")
     out.append("")
     out.append("#[repr(C)]\npub struct jolt_member_desc {\n    pub n_tables: u32,\n    pub n_terms: u32,\n    pub degree: u32,\n    pub order: i32,\n"
