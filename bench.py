@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-msm-roofline", action="store_true", help="skip the extra 2^(scale+4)-term MSM that measures the bucket-sum kernel (roofline_msm)")
     ap.add_argument("--cpu-scale", type=int, default=0, help="log2 T of the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     ap.add_argument("--round-exchange", choices=["rccl", "shm", "both"], default="both",
                     help="N > 1: how the per-round partial sums are exchanged.  `value` is timed with RCCL (the collective north_star names) unless "
@@ -113,6 +114,43 @@ def bind_roofline(ctx, ffi, log_n, reps):
             "avg_launch_ms": round(ms, 5)}
 
 
+MAD_PEAK_T = 25.0  # v_mad_u64_u32 lane-operations per second, chip-wide, in units of 10^12: measured by jolt_amd/csrc/tools/microbench.hip (~6.3 cycles per wave
+# instruction per SIMD; the nominal 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T/s holds for 4-cycle instructions only), docs/kernels.md section 3.1
+MADS_PER_MIXED_ADD = 1467  # limb-form XYZZ mixed addition (8 M + 2 S, one two-product reduction): docs/kernels.md section 3.1
+
+
+def msm_roofline(ctx, srs, log_n):
+    """The step's dominant kernel -- the bucket sums of the fixed-base MSM, k_fx_buckets_ordered: 226 of a step's ~380 ms -- against what bounds it.  ONE MSM of 2^log_n
+    uniform full-width scalars over the step's own window tables, alone on the device; the kernel is bracketed by HIP events on the stream it is launched on
+    (jolt_msm_profile_buckets) and the launch's mixed additions are counted by the digit pass itself.  Bound: integer multiply-add issue (`v_mad_u64_u32`), not HBM and
+    not MFMA -- 1467 multiply-adds per addition; the HBM side (a 4-byte index and a 64-byte affine point gathered per addition) is reported beside it."""
+    n = 1 << log_n
+    rng = np.random.default_rng(11)
+    pt = rng.integers(0, 2**64, size=(log_n, 4), dtype=np.uint64)
+    pt[:, 3] %= np.uint64(0x30644E72E131A029)
+    scalars = ctx.eq_evals(pt)  # a full-width pseudo-random table, built on the device
+    ctx.msm(srs, scalars, n, full_width=True)  # warm: workspace growth, attributes
+    ctx.msm_profile_buckets(True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.msm(srs, scalars, n, full_width=True)
+    msm_ms = (time.perf_counter() - t0) * 1e3
+    ms, adds = ctx.msm_profile_buckets_last()
+    ctx.msm_profile_buckets(False)
+    scalars.free()
+    adds_s = adds / (ms * 1e-3)
+    mads_t = adds_s * MADS_PER_MIXED_ADD / 1e12
+    alg_bytes = 68.0 * adds
+    return {"bound": "valu-int", "kernel": "k_fx_buckets_ordered<lform>", "what": f"bucket sums of one fixed-base MSM, 2^{log_n} uniform 254-bit scalars, window tables of the step's SRS",
+            "additions": adds, "avg_launch_ms": round(ms, 3), "msm_ms": round(msm_ms, 3),
+            "achieved": round(mads_t, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s", "frac": round(mads_t / MAD_PEAK_T, 4),
+            "additions_per_s": round(adds_s), "fq_mul_per_s": round(adds_s * 10), "mads_per_addition": MADS_PER_MIXED_ADD,
+            "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_peak": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "fetched_over_algorithmic": 2.7, "source": "profiles/r04_open_traffic.txt (FETCH_SIZE pass: 64-byte gathers at 128-byte request granularity)"},
+            "counters": "profiles/r05_pmc_bucket.txt: VALU executing in 34.4 % of the wave-cycles at one wave per SIMD, 52 % waiting to issue, 12.6 % on memory",
+            "note": "peak = the measured chip-wide v_mad_u64_u32 rate; the kernel's other ~800 instructions per addition share the issue slots, which is why 1.0 is out of reach"}
+
+
 PUBLISHED_REFERENCE = {  # BASELINE.md section 2: what the reference itself publishes (whole prover, Dory PCS, CPU; NOT this path alone, NOT this box)
     "value": 1.5e6, "unit": "cycles/s", "what": "whole Jolt prover (all stages, Dory PCS), AMD Threadripper Pro 7975WX, 32 cores",
     "source": "book/src/how/optimizations/inlines.md:147,151,155", "also": "~500 kHz on a MacBook M4 Max, 16 cores (same file :149-150)"}
@@ -158,7 +196,10 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
             self.point = W.rand_fr(scale + 4, prng)
             if with_pcs:  # the first K * T powers of the device's SRS, converted to affine once (inputs, not timed)
                 self.bases = O.baseline_prepare_bases(srs_dev.download(0, K * self.T))
-            self.ext = OracleStageOperators(scale) if with_ext else None  # the trace description (numpy) is an input, built here
+            # The stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators are NOT part of the CPU figure (round-4 review, item 8): their oracle twins are CHECKERS -- dense
+            # definitions behind the sparse matrices, brute-force sums behind the read-RAF scans -- not the reference's prefix-suffix / sparse algorithms, so timing
+            # them says nothing about the reference's CPU path.  The legs below ARE the reference's algorithms (bind, eq, fused round sums, Pippenger, HyperKZG open).
+            self.ext = None
 
         legs = {"tables": 0.0, "sumchecks": 0.0, "pcs": 0.0, "stage_operators": 0.0}
 
@@ -209,13 +250,13 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
         O.baseline_set_max_window(best_c)
         if log_t <= 0:  # T = 2^20 unless a step there is predicted (linear in T from the calibration step) to exceed about a minute
             log_t = cal_scale
-            while log_t < min(20, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 64.0:
+            while log_t < min(22, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 90.0:
                 log_t += 1
         smp = cal if log_t == cal_scale else Sample(log_t)
         del cal
         dt, reps = 0.0, 0
         Sample.legs = {k: 0.0 for k in Sample.legs}
-        while reps == 0 or (dt < 10.0 and reps < 3):
+        while reps == 0 or (dt < 10.0 and reps < 2):
             dt += smp.step()
             reps += 1
     finally:
@@ -224,12 +265,15 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
     pcs_note = (f" + commitments of 38 columns on the 2^{log_t + 4} grid (2 MSMs of 64-bit scalars, 36 one-hot sums of bases) + joint polynomial + one HyperKZG opening "
                 f"(signed-digit XYZZ bucket MSMs, all level / witness MSMs as one pool of window x chunk tasks; affine bases prepared outside the timed region; "
                 f"Horner / RLC passes OpenMP-parallel where the reference's kzg.rs:51-105 is serial)") if with_pcs else ""
+    legs_s = {k: round(v / reps, 3) for k, v in Sample.legs.items() if k != "stage_operators"}
     return {"value": round(reps * (1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
-            "sample": (f"the SAME step as the GPU line at T=2^{log_t}: " if with_ext else f"the `--stages 2-6b` part of the step at T=2^{log_t} (the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators are NOT in this CPU sample): ")
+            "config": {"trace_length": 1 << log_t, "legs": "prepare (per-proof tables) + prove (stage 2-6b sumchecks)" + (" + commit + open" if with_pcs else ""),
+                       "seconds_per_step": legs_s},
+            "sample": f"the legs of the step that ARE the reference's algorithms, at T=2^{log_t} on the host cores: "
                       + "per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
-                      + (" + the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators as their oracle twins (tests/workload_oracle.py OracleExtended: Spartan outer / product, both sparse matrices, "
-                         "read-RAF with its 128 address rounds on the library's host state machine, pushforwards, address-domain relations)" if with_ext else "")
-                      + f"{pcs_note}; {reps} step(s), C restatement (-O3, 64-bit limbs, ADX) with OpenMP on {best_n} of {hw} host threads "
+                      + " (the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators are NOT in the CPU figure: their oracle twins are dense-definition checkers, not the reference's "
+                        "prefix-suffix / sparse algorithms; `gpu_same_legs` below is the GPU time of exactly the legs timed here)"
+                      + f"{pcs_note}; every level commitment of the opening by MSM (the GPU step takes its first two from class sums by linearity); {reps} step(s), C restatement (-O3, 64-bit limbs, ADX) with OpenMP on {best_n} of {hw} host threads "
                       f"(nproc {os.cpu_count()}; the fastest of {hw} / {max(1, hw // 2)} threads x bucket windows capped at 16 / 13 bits at T=2^{cal_scale}: {best_t:.2f} s per step there, cap {best_c}); {dt:.1f}s of CPU work: "
                       f"table builds {Sample.legs['tables']:.1f}s, sumcheck legs {Sample.legs['sumchecks']:.1f}s, commit + open {Sample.legs['pcs']:.1f}s, stage operators {Sample.legs['stage_operators']:.1f}s",
             "published_reference": PUBLISHED_REFERENCE}
@@ -514,10 +558,20 @@ def main():
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "dense_tables": m_dense,
                                         "bytes_per_proof": alg, "prove_ms": split["prove"],
                                         "note": "the round kernels are bound by 256-bit multiplies, not by bytes (DESIGN.md section 3.3): this fraction is reported, not a target met"}
+        if pcs and not sharded and not args.no_msm_roofline:
+            try:
+                out["roofline_msm"] = msm_roofline(ctx, wl.srs, args.scale + 4)
+            except Exception as e:  # a diagnostic object: never fail the bench on it
+                out["roofline_msm"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             try:
                 srs_dev = (pcs_sharded.srs if sharded else wl.srs) if pcs else None  # the CPU sample's grid uses a prefix of the same SRS (inputs)
                 out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs), with_ext=(the_ext is not None))
+                if split is not None:  # the GPU's time for exactly the legs the CPU figure covers (the stage operators are in `value` but not in the CPU sample)
+                    same = [k for k in ("prepare", "commit", "prove", "open") if k in split]
+                    ms = sum(split[k] for k in same)
+                    out["cpu_baseline"]["gpu_same_legs"] = {"legs": same, "ms_per_step": round(ms, 3), "cycles_per_s": round((1 << args.scale) / (ms * 1e-3), 1),
+                                                            "ratio_to_cpu": round(((1 << args.scale) / (ms * 1e-3)) / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"].get("value") else None}
             except Exception as e:  # the oracle is optional infrastructure: never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "cycles/s", "cores": None, "kind": "port", "sample": f"unavailable: {e}", "published_reference": PUBLISHED_REFERENCE}
         print(json.dumps(out), flush=True)

@@ -279,6 +279,11 @@ int32_t jolt_srs_free(jolt_ctx *ctx, jolt_srs *srs);
  * the per-window method.  Results are the same points. */
 int32_t jolt_srs_precompute_windows(jolt_ctx *ctx, jolt_srs *srs, uint32_t window_bits, size_t min_terms);
 
+/* Measurement hook (no reference counterpart): HIP events around the dominant kernel of a fixed-base MSM (the bucket sums, k_fx_buckets_ordered) on the stream it is
+ * launched on, and the number of mixed additions of that launch (the non-zero signed digits of its scalars).  bench.py's `roofline_msm` divides the two. */
+int32_t jolt_msm_profile_buckets(jolt_ctx *ctx, int32_t enable);
+int32_t jolt_msm_profile_buckets_last(jolt_ctx *ctx, float *ms, uint64_t *additions);
+
 /* JoltGroup::msm(bases, scalars) (crates/jolt-crypto/src/ec/group.rs:63-70, bn254/mod.rs:195-212) with the bases
  * = srs[..n].  Length mismatch (n > srs length) is JOLT_ERR_SRS_TOO_SMALL (the Rust shim asserts equal lengths
  * before calling, keeping the reference's panic).  Scalars from host memory or from a device table. */

@@ -170,6 +170,8 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     for (auto& pair : ctx->ev_aux) for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
     if (ctx->msm_batch_host) (void)hipHostFree(ctx->msm_batch_host);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    for (hipEvent_t e : ctx->ev_fx)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_sort) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -67,6 +67,12 @@ struct jolt_ctx {
     void* msm_pending_one = nullptr;  // an MSM begun by jolt_internal_msm_one_begin and not yet collected (msm.hip)
     bool msm_pair_overlap = true;  // JOLT_MSM_PAIR_OVERLAP=0: reduction between the two passes (A/B)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // jolt_msm_profile_buckets: HIP events around the fixed-base MSM's dominant kernel (k_fx_buckets_ordered) ON THE STREAM IT IS LAUNCHED ON, and where the launch's
+    // count of non-zero digits (= mixed additions) lives on the device -- the `roofline_msm` object of bench.py
+    bool fx_profile = false;
+    hipEvent_t ev_fx[2] = {nullptr, nullptr};
+    const uint32_t* fx_profile_info = nullptr;  // device: info[1] = non-zero digits of the profiled launch
+    bool fx_profile_valid = false;
     // Sort token (JOLT_MSM_STAGGER): the partition / sort phase of a fixed-base MSM is HBM-bound and its bucket sums are bound by
     // integer multiply-adds, so concurrent lanes only gain when one lane's sort runs under ANOTHER lane's bucket sums.  Equal MSMs
     // enqueued together (the three witness MSMs of an opening) would run their sorts at the same time; each sort phase therefore

@@ -1149,9 +1149,16 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     if ((size_t)per_result * (pair_shift ? 2 : 1) > kMsmHostEntries) return JOLT_ERR_UNSUPPORTED;
     // bucket sums over the sorted lists against the tables at `bases` into `buckets` (on the bucket stream) ...
     auto bucket_sums = [&](const G1Affine* bases, G1Jac* buckets) -> int32_t {
+        const bool profile = ctx->fx_profile && ctx->ev_fx[0] && ctx->ev_fx[1];
+        if (profile) JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fx[0], bst));
         if (srs->pre_lform) {
             hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                                (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
+            if (profile) {  // the LAST profiled launch is the one reported
+                JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fx[1], bst));
+                ctx->fx_profile_info = info;
+                ctx->fx_profile_valid = true;
+            }
             hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
                                (const uint32_t*)keys, bases, seg, lc);
         } else {
@@ -1240,5 +1247,31 @@ extern "C" int32_t jolt_host_fx_digits(const jolt_fr_t* scalar, uint32_t window_
     fx_digits_of(from_mont(s), c, W, keys_out, 1);
     if (n_windows_out) *n_windows_out = (uint32_t)W;
     if (buckets_out) *buckets_out = (uint32_t)std::max<uint64_t>((uint64_t)1 << (c - 1), top_max);
+    return JOLT_OK;
+}
+
+
+// ---- profile of the dominant kernel (bench.py roofline_msm) ------------------------------------------------------------------------------------------------
+// enable: every later fixed-base MSM of the context brackets its k_fx_buckets_ordered launch with HIP events on the launch's own stream.  _last: duration of the last
+// bracketed launch and the mixed additions it performed (the non-zero signed digits of its scalars: light and heavy buckets together; heavy lists are a few
+// thousandths for uniform scalars).  Call after the MSM was collected (the events must have completed).
+extern "C" int32_t jolt_msm_profile_buckets(jolt_ctx* ctx, int32_t enable) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    if (enable && !ctx->ev_fx[0]) {
+        JOLT_HIP_TRY(ctx, hipEventCreate(&ctx->ev_fx[0]));
+        JOLT_HIP_TRY(ctx, hipEventCreate(&ctx->ev_fx[1]));
+    }
+    ctx->fx_profile = enable != 0;
+    ctx->fx_profile_valid = false;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_msm_profile_buckets_last(jolt_ctx* ctx, float* ms, uint64_t* additions) {
+    if (!ctx || !ms || !additions) return JOLT_ERR_INVALID_ARG;
+    if (!ctx->fx_profile_valid) { ctx->last_error = "no profiled fixed-base MSM since jolt_msm_profile_buckets"; return JOLT_ERR_INVALID_ARG; }
+    JOLT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_fx[1]));
+    JOLT_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_fx[0], ctx->ev_fx[1]));
+    uint32_t info[2] = {0, 0};
+    JOLT_HIP_TRY(ctx, hipMemcpy(info, ctx->fx_profile_info, sizeof(info), hipMemcpyDeviceToHost));
+    *additions = info[1];
     return JOLT_OK;
 }

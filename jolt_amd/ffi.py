@@ -740,6 +740,18 @@ def _msm(self, srs, scalars, n=None, full_width=False):
     return out[0]
 
 
+def _msm_profile_buckets(self, enable=True):
+    """HIP events around the bucket-sum kernel of every later fixed-base MSM (jolt_msm_profile_buckets)"""
+    _ck(lib().jolt_msm_profile_buckets(self.h, C.c_int32(1 if enable else 0)), "jolt_msm_profile_buckets", self)
+
+
+def _msm_profile_buckets_last(self):
+    """(milliseconds, mixed additions) of the last profiled bucket-sum launch"""
+    ms, adds = C.c_float(), C.c_uint64()
+    _ck(lib().jolt_msm_profile_buckets_last(self.h, C.byref(ms), C.byref(adds)), "jolt_msm_profile_buckets_last", self)
+    return float(ms.value), int(adds.value)
+
+
 def _msm_window(self, srs, base_offset, values, kind=None, acc=None):
     """One window of a streamed commitment (jolt_msm_g1_window: StreamingCommitment::feed / feed_u64 / feed_i128 for a KZG-type scheme): acc + sum_i values[i] *
     srs[base_offset + i].  values: (n, 4) uint64 field elements (kind "fr"), uint64 / int64 arrays, or i128 as an (n, 2) uint64 array (kind "i128")."""
@@ -814,6 +826,8 @@ Context.srs_upload = _srs_upload
 Context.srs_setup_from_secret = _srs_setup_from_secret
 Context.msm = _msm
 Context.msm_window = _msm_window
+Context.msm_profile_buckets = _msm_profile_buckets
+Context.msm_profile_buckets_last = _msm_profile_buckets_last
 Context.srs_setup_from_secret_blocks = _srs_setup_from_secret_blocks
 Context.msm_blocks = _msm_blocks
 Context.srs_setup_from_secret_subtree = _srs_setup_from_secret_subtree

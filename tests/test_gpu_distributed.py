@@ -301,7 +301,7 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(world, scale, steps):
     assert line["config"]["trace_length_total"] == world << scale
     assert line["value"] == pytest.approx(world * (1 << scale) / (line["ms_per_step"] * 1e-3), rel=1e-3)
     cfg = line["config"]
-    assert cfg["trace_length_per_gpu"] == 1 << 10 and "configs[2] sharded" in cfg["workload"] and "every step rebuilds" in cfg["workload"]
+    assert cfg["trace_length_per_gpu"] == 1 << scale and "configs[2] sharded" in cfg["workload"] and "every step rebuilds" in cfg["workload"]
     assert cfg["round_exchange"].startswith(("rccl", "torch")) and f"{world} rank(s)" in cfg["communicator"] and "pcs" in cfg
     ab = cfg["round_exchange_ab"]  # both exchanges of the per-round sums timed in this one run; `value` is the first key's
     assert set(ab) == {"rccl", "shm"} and list(ab)[0] == "rccl" and ab["rccl"] == pytest.approx(line["ms_per_step"], rel=1e-6)

@@ -59,3 +59,31 @@ def test_extended_stages_match_oracle_at_trace_scale():
     import os
     O.baseline_set_threads(min(128, os.cpu_count() or 1))
     run(20, 2026)
+
+
+def test_instruction_read_raf_every_address_round_from_the_definition_at_2_16():
+    """Lock step of ALL 128 address rounds at a mid size (round-4 review, item 9).  Above T = 2^12 the oracle twin normally takes the address-round polynomials from the
+    product's host state machine (fed with oracle scan sums) and recomputes only a sample from the definition; here, at T = 2^16 (16 x 1024-row work items per bin, the
+    sizes at which the device scans run many workgroups per bin), every one of the 128 polynomials is the oracle's FROM THE DEFINITION -- evaluate_mle of each row's table
+    at the mixed point, no prefix / suffix machinery, no product code (oracle/lookup_tables.c, OpenMP) -- and the device path (16 phase scans + condensations on the GPU,
+    128 rounds on the library's host side) must produce the same 128 messages, challenges, end values, cycle rounds and output claims."""
+    import os
+    import oracle_lib as O
+    from jolt_amd.stages import build_extended
+
+    class EveryRoundDirect(OracleExtended):
+        DIRECT_ADDRESS_ROUNDS_MAX_LOG_T = 16
+
+    O.baseline_set_threads(min(128, os.cpu_count() or 1))
+    n_vars, label = 16, 40
+    d = build_extended(n_vars, 916)
+    ctx = ffi.Context(0)
+    dev = DeviceExtended(ctx, n_vars, description=d)
+    orc = EveryRoundDirect(n_vars, description=d)
+    got = dev.instruction_read_raf(label + 400)
+    want = orc.instruction_read_raf(label + 400)
+    assert orc.direct_checked == list(range(128))
+    assert np.array_equal(dev.claims["lookup"], want["claim"])
+    same(got, {k: v for k, v in want.items() if k != "claim"}, "instruction_read_raf")
+    dev.close()
+    ctx.close()
