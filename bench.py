@@ -141,13 +141,14 @@ def msm_roofline(ctx, srs, log_n):
     adds_s = adds / (ms * 1e-3)
     mads_t = adds_s * MADS_PER_MIXED_ADD / 1e12
     alg_bytes = 68.0 * adds
-    return {"bound": "valu-int", "kernel": "k_fx_buckets_ordered<lform>", "what": f"bucket sums of one fixed-base MSM, 2^{log_n} uniform 254-bit scalars, window tables of the step's SRS",
+    return {"bound": "valu-int", "kernel": "k_fx_buckets_ordered_staged", "what": f"bucket sums of one fixed-base MSM, 2^{log_n} uniform 254-bit scalars, window tables of the step's SRS",
             "additions": adds, "avg_launch_ms": round(ms, 3), "msm_ms": round(msm_ms, 3),
             "achieved": round(mads_t, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s", "frac": round(mads_t / MAD_PEAK_T, 4),
             "additions_per_s": round(adds_s), "fq_mul_per_s": round(adds_s * 10), "mads_per_addition": MADS_PER_MIXED_ADD,
             "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_peak": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "fetched_over_algorithmic": 2.7, "source": "profiles/r04_open_traffic.txt (FETCH_SIZE pass: 64-byte gathers at 128-byte request granularity)"},
-            "counters": "profiles/r05_pmc_bucket.txt: VALU executing in 34.4 % of the wave-cycles at one wave per SIMD, 52 % waiting to issue, 12.6 % on memory",
+                    "fetched_over_algorithmic": 1.98, "source": "profiles/r05_bucket_index_staging_ab.txt (FETCH_SIZE pass, corrected per the guide): 134.6 B fetched per addition -- the "
+                    "128-byte request a 64-byte point gather costs; round 4's 2.64 x included ~52 B per 4-byte index, removed by staging the lists' indices through LDS"},
+            "counters": "profiles/r05_pmc_bucket.txt (SQ pass, 3 waves per SIMD at 152 VGPRs): a wave executes a VALU instruction in 34.4 % of its resident cycles, waits to issue in 52 %, waits on memory in 12.6 %",
             "note": "peak = the measured chip-wide v_mad_u64_u32 rate; the kernel's other ~800 instructions per addition share the issue slots, which is why 1.0 is out of reach"}
 
 

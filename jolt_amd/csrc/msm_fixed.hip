@@ -769,6 +769,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
     if (cnt == 0 || cnt > heavy_threshold) return;  // empty: the memset identity stands; heavy: the segmented kernels own it
     buckets[slot] = LFORM ? sum_bucket_points_lform(sorted + offsets[slot], bases, 0u, cnt, 1u, lc) : sum_bucket_points<true>(sorted + offsets[slot], bases, 0u, cnt, 1u);
 }
+// ... with the base indices staged through LDS (msm_kernels.hip.h: sum_bucket_points_lform_staged) -- the default for L-form tables; JOLT_FX_STAGE_IDX=0 keeps the
+// kernel above for an A/B.  kFxIdxChunk indices per lane and refill: 32 = one 128-byte line; 3 workgroups of 256 lanes per CU hold 96 KB of the CU's 160 KB.
+constexpr int kFxIdxChunk = 32;
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_fx_buckets_ordered_staged(
+    const uint32_t* __restrict__ order, uint32_t n_buckets, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ sorted,
+    const G1Affine* __restrict__ bases, uint32_t heavy_threshold, G1Jac* __restrict__ buckets, LformConsts lc) {
+    __shared__ uint32_t idx_stage[kFxIdxChunk * kBlock];
+    const uint32_t gt = blockIdx.x * kBlock + threadIdx.x;
+    if (gt >= n_buckets) return;
+    const uint32_t slot = order[gt];
+    const uint32_t cnt = hist[slot];
+    if (cnt == 0 || cnt > heavy_threshold) return;
+    buckets[slot] = sum_bucket_points_lform_staged<kFxIdxChunk>(sorted + offsets[slot], bases, cnt, lc, idx_stage + threadIdx.x);
+}
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_fx_heavy_segments_staged(
+    const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ heavy_count, uint32_t heavy_cap, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ sorted, const G1Affine* __restrict__ bases, G1Jac* __restrict__ seg_sums, LformConsts lc) {
+    __shared__ uint32_t idx_stage[kFxIdxChunk * kBlock];
+    const uint32_t total = min(*heavy_count, heavy_cap);
+    for (uint32_t h = blockIdx.x * kBlock + threadIdx.x; h < total; h += gridDim.x * kBlock) {
+        const uint32_t slot = heavy_list[2 * h], sgi = heavy_list[2 * h + 1];
+        const uint32_t cnt = hist[slot], lo = sgi * kFxHeavySeg, len = min(kFxHeavySeg, cnt - lo);
+        seg_sums[h] = sum_bucket_points_lform_staged<kFxIdxChunk>(sorted + offsets[slot] + lo, bases, len, lc, idx_stage + threadIdx.x);
+    }
+}
 
 // ---- 4b. heavy buckets: one lane per kFxHeavySeg-entry segment, then one wavefront per bucket over its segment sums -------------
 template <bool LFORM>
@@ -1151,16 +1176,25 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     auto bucket_sums = [&](const G1Affine* bases, G1Jac* buckets) -> int32_t {
         const bool profile = ctx->fx_profile && ctx->ev_fx[0] && ctx->ev_fx[1];
         if (profile) JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fx[0], bst));
+        static const bool stage_idx = !(std::getenv("JOLT_FX_STAGE_IDX") && std::atoi(std::getenv("JOLT_FX_STAGE_IDX")) == 0);
         if (srs->pre_lform) {
-            hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
-                               (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
+            if (stage_idx)
+                hipLaunchKernelGGL(k_fx_buckets_ordered_staged, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+                                   (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
+            else
+                hipLaunchKernelGGL(k_fx_buckets_ordered<true>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
+                                   (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);
             if (profile) {  // the LAST profiled launch is the one reported
                 JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fx[1], bst));
                 ctx->fx_profile_info = info;
                 ctx->fx_profile_valid = true;
             }
-            hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist, (const uint32_t*)offs,
-                               (const uint32_t*)keys, bases, seg, lc);
+            if (stage_idx)
+                hipLaunchKernelGGL(k_fx_heavy_segments_staged, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
+                                   (const uint32_t*)offs, (const uint32_t*)keys, bases, seg, lc);
+            else
+                hipLaunchKernelGGL(k_fx_heavy_segments<true>, dim3(gh), dim3(kBlock), 0, bst, (const uint32_t*)heavy, (const uint32_t*)hcnt, heavy_cap, (const uint32_t*)hist,
+                                   (const uint32_t*)offs, (const uint32_t*)keys, bases, seg, lc);
         } else {
             hipLaunchKernelGGL(k_fx_buckets_ordered<false>, dim3(bucket_grid), dim3(kBlock), 0, bst, (const uint32_t*)order, (uint32_t)n_buckets, (const uint32_t*)hist,
                                (const uint32_t*)offs, (const uint32_t*)keys, bases, heavy_threshold, buckets, lc);

@@ -301,6 +301,63 @@ __device__ __forceinline__ G1Jac sum_bucket_points_lform(const uint32_t* __restr
     return out;
 }
 
+// The same sum for ONE LANE PER LIST (stride 1) with the list's base indices STAGED THROUGH LDS in chunks of CH (round 5).  A lane walks its own list: 4 bytes of a
+// line every ~4 us, and between two visits of a line ~30 MB of gathered points stream through the XCD's 4 MB L2 -- the line is gone each time, so a 4-byte index cost a
+// whole fabric request (profiles/r04_open_traffic.txt: 545 GB fetched per opening for 200 GB of points and indices; ~99 B per index).  Here a lane copies the next CH
+// indices of its list into its own LDS column in one burst (the line is fetched once and used whole, straight away) and the loop reads them from there:
+// stage[j * kBlock + threadIdx.x], a column per lane -- conflict-free, no barrier (a lane only ever reads what it wrote itself).
+template <int CH>
+__device__ __forceinline__ void stage_indices(uint32_t* __restrict__ col, const uint32_t* __restrict__ src, uint32_t first, uint32_t cnt) {
+#pragma unroll 1
+    for (int j0 = 0; j0 < CH; j0 += 8) {  // eight loads in flight: the budget of 170 registers (3 waves per SIMD) has no room for a whole chunk
+        uint32_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = first + j0 + j < cnt ? src[first + j0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) col[(j0 + j) * kBlock] = t[j];
+        if (first + j0 + 8 >= cnt) break;
+    }
+}
+template <int CH>
+__device__ __forceinline__ G1Jac sum_bucket_points_lform_staged(const uint32_t* __restrict__ src, const G1Affine* __restrict__ bases, uint32_t cnt, const LformConsts& lc,
+                                                                uint32_t* __restrict__ col /* this lane's LDS column: entry j at col[j * kBlock] */) {
+    if (cnt == 0) return g1_identity();
+    G1XyzzL acc = g1xl_identity();
+    const FqL one = fql_from_words(lc.one_l);
+    stage_indices<CH>(col, src, 0u, cnt);
+    uint32_t v = col[0], first = 0;
+    G1Affine p = ld_aff(bases + (v & 0x7FFFFFFFu));
+    for (uint32_t k = 0;;) {  // software pipeline as in sum_bucket_points_lform: the next point is in flight during the addition
+        const uint32_t kn = k + 1;
+        const bool more = kn < cnt;
+        uint32_t vn = 0;
+        G1Affine pn = p;
+        if (more) {
+            if (kn - first == (uint32_t)CH) {  // chunk used up (wave-uniform for lists of equal length, which is how the bucket order hands them out)
+                first = kn;
+                stage_indices<CH>(col, src, first, cnt);
+            }
+            vn = col[(kn - first) * kBlock];
+            pn = ld_aff(bases + (vn & 0x7FFFFFFFu));
+        }
+        if (!g1_aff_is_inf(p)) {
+            if (v >> 31) p.y = neg(p.y);
+            acc = g1xl_add_mixed(acc, fql_from_words(p.x), fql_from_words(p.y), one);
+        }
+        if (!more) break;
+        v = vn;
+        p = pn;
+        k = kn;
+    }
+    if (g1xl_is_identity(acc)) return g1_identity();
+    const FqL r256 = fql_from_words(lc.r256);
+    G1Jac out;
+    out.x = fql_to_std(fql_mul(acc.x, fql_sqr(acc.zz)), r256);
+    out.y = fql_to_std(fql_mul(acc.y, fql_sqr(acc.zzz)), r256);
+    out.z = fql_to_std(acc.zzz, r256);
+    return out;
+}
+
 // ---- 4a. light buckets: L adjacent lanes per bucket (L = 1 when there are enough buckets to fill the chip) ----------
 template <bool PIPELINED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUCKET_WAVES, JOLT_BUCKET_WAVES))) void k_msm_buckets_light(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offsets,
