@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--stages", choices=["all", "2-6b"], default="all",
                     help="all (default): the step also runs the stage 1 / 2 / 5 operators that are not plain cycle-domain relations -- Spartan outer and product, the sparse "
                          "RAM read-write matrix, instruction read-RAF checking with its 128 address rounds (jolt_amd/stages.py); 2-6b: the round-2 step (comparable with BENCH_r02)")
-    ap.add_argument("--witness", choices=["resident", "upload", "upload-pinned"], default="resident",
+    ap.add_argument("--witness", choices=["resident", "upload", "upload-pinned", "upload-overlapped"], default="resident",
                     help="resident (default, the contract's `value`): the witness columns sit in HBM before the timed region.  upload: every step starts from the packed "
                          "per-cycle rows in HOST memory -- one H2D copy + device-side column extraction (SURVEY.md section 8 f1) -- a PCIe-inclusive diagnostic, N = 1 only")
     ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-upload-rate", action="store_true", help="skip the extra timed steps that measure the PCIe-inclusive rate (value_with_upload)")
     ap.add_argument("--no-msm-roofline", action="store_true", help="skip the extra 2^(scale+4)-term MSM that measures the bucket-sum kernel (roofline_msm)")
     ap.add_argument("--cpu-scale", type=int, default=0, help="log2 T of the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     ap.add_argument("--round-exchange", choices=["rccl", "shm", "both"], default="both",
@@ -385,7 +386,7 @@ def main():
             if pcs_sharded is not None:
                 pcs_sharded.open(label)
     else:
-        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), witness_upload={"resident": False, "upload": True, "upload-pinned": "pinned"}[args.witness])
+        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), witness_upload={"resident": False, "upload": True, "upload-pinned": "pinned", "upload-overlapped": "overlapped"}[args.witness])
         step = wl.step
 
     def barrier():
@@ -430,6 +431,7 @@ def main():
         wl.round_exchange = shm if primary == "shm" else None
         if ext is not None:
             ext.round_exchange = wl.round_exchange
+    total_cycles_for_upload = 1 << args.scale
     dt = timed(args.steps, args.warmup, 0)
     if exchange_ab is not None:
         exchange_ab[primary] = round(dt / args.steps * 1e3, 3)
@@ -459,6 +461,23 @@ def main():
                 ctx.synchronize()
                 acc[k] += time.perf_counter() - t1
         split = {k: round(v / reps * 1e3, 3) for k, v in acc.items()}
+    # The PCIe-inclusive rate beside the contract's `value` (never instead of it): the same K steps with every proof starting from packed rows in page-locked HOST memory,
+    # the next proof's copy in flight under the current proof's kernels (jolt_rows_upload_begin; a tracer one trace ahead of the prover).  N = 1, resident default run only.
+    with_upload = None
+    if not sharded and args.witness == "resident" and not args.no_upload_rate:
+        try:
+            wl.witness_upload, wl.witness_pinned, wl.witness_overlapped = True, True, True
+            dt_up = timed(args.steps, max(1, min(args.warmup, 2)), 70000)
+            bpc = wl.witness_bytes_per_cycle()
+            with_upload = {"value": round(total_cycles_for_upload / (dt_up / args.steps), 1), "unit": "cycles/s", "ms_per_step": round(dt_up / args.steps * 1e3, 3),
+                           "bytes_per_cycle": bpc, "bytes_per_step": bpc << args.scale,
+                           "mode": "every step starts from packed per-cycle rows in page-locked host memory (catalogue witness: integer columns + RA chunk addresses; the stage operators' inputs stay "
+                                   "resident); one H2D copy per proof on a copy stream, begun when the PREVIOUS proof has extracted its columns, so it runs under that proof's kernels; "
+                                   "device-side column extraction inside the step"}
+        except Exception as e:  # a diagnostic: never fail the bench on it
+            with_upload = {"value": None, "error": str(e)}
+        finally:
+            wl.witness_upload = wl.witness_overlapped = False
     n_onehot = getattr(wl, "n_onehot", 0) or sum(a.shape[0] for a in getattr(wl, "committed_onehot", []))
     onehot_note = f" of which {n_onehot} are one-hot RA selector columns kept as 1-byte hot indices until their fourth bind" if n_onehot else ""
     total_cycles = (1 << args.scale) * world
@@ -515,10 +534,13 @@ def main():
         out["config"]["ms_per_step_split"] = split
     if not sharded and args.witness != "resident":
         bpc = wl.witness_bytes_per_cycle()
-        out["config"]["witness"] = {"mode": f"upload: every step starts from packed rows in {'page-locked (jolt_host_pinned_alloc)' if args.witness == 'upload-pinned' else 'pageable'} host memory (PCIe-inclusive; NOT the contract's `value`, which has the inputs resident)",
+        out["config"]["witness"] = {"mode": f"upload: every step starts from packed rows in {'page-locked (jolt_host_pinned_alloc)' if args.witness != 'upload' else 'pageable'} host memory{', the next proof copied under the current one (jolt_rows_upload_begin)' if args.witness == 'upload-overlapped' else ''} (PCIe-inclusive; NOT the contract's `value`, which has the inputs resident)",
                                     "bytes_per_cycle": bpc, "bytes_per_step": bpc << args.scale,
-                                    "h2d_GBps": round((bpc << args.scale) / (split["witness_upload"] * 1e-3) / 1e9, 2) if split and split.get("witness_upload") else None,
+                                    "h2d_GBps": round((bpc << args.scale) / (split["witness_upload"] * 1e-3) / 1e9, 2) if split and split.get("witness_upload") and args.witness != "upload-overlapped" else None,  # (overlapped: the copy is not inside the leg)
                                     "note": "catalogue witness only (integer columns + RA chunk addresses); the stage operators' inputs stay resident"}
+    if with_upload is not None:
+        out["value_with_upload"] = with_upload["value"]
+        out["config"]["witness_upload"] = with_upload
     if not sharded:
         out["config"]["device_pool_gib"] = {k.replace("_bytes", ""): round(v / 2**30, 2) for k, v in ctx.memory_stats().items()}
     if sharded:

@@ -467,6 +467,11 @@ int32_t jolt_member_create_lazy_ra_uniform_sharded(jolt_ctx *ctx, const jolt_one
  * column per polynomial; columns are expanded on the device.  Fields are little-endian integers inside a row of row_bytes bytes. */
 typedef struct jolt_rows jolt_rows;
 int32_t jolt_rows_upload(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t row_bytes, jolt_rows **out);
+/* The same copy in flight beside the context's kernels: the NEXT proof's rows moving over the link while the current proof runs (the witness is produced by the tracer
+ * ahead of the prover, crates/jolt-witness/src/consumer.rs:129-143).  `rows` must be page-locked (jolt_host_pinned_alloc) and unchanged until _wait returned; _begin
+ * returns at once, _wait orders the context's main stream behind the copy without a host synchronisation; the handle then behaves like jolt_rows_upload's. */
+int32_t jolt_rows_upload_begin(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t row_bytes, jolt_rows **out);
+int32_t jolt_rows_upload_wait(jolt_ctx *ctx, jolt_rows *rows);
 /* Page-locked host memory for the row buffer the tracer fills (the Vec<CycleRow> of crates/jolt-host/src/program.rs's trace output, packed): jolt_rows_upload
  * from such a block runs at the link rate (no staging copy by the runtime).  Ordinary host memory in every other respect. */
 int32_t jolt_host_pinned_alloc(jolt_ctx *ctx, size_t bytes, void **out);
@@ -477,6 +482,10 @@ int32_t jolt_table_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset
 /* the same field as a resident integer column (JOLT_INT_U64, or JOLT_INT_I64 sign-extended): the compact scalars of Polynomial<T> (crates/jolt-poly/src/dense.rs:
  * 129-142) straight from the uploaded rows -- what jolt_member_create_lc_small and the *_small operators read; freed with jolt_ints_free */
 int32_t jolt_ints_from_rows(jolt_ctx *ctx, const jolt_rows *rows, size_t offset, uint32_t width, int32_t is_signed, jolt_ints **out);
+/* ... and n_fields fields in ONE pass over the rows (a workgroup stages whole rows in LDS, every field is written from there): out[k] = field k.  The witness hand-over
+ * of a proof extracts every typed column of WitnessBundle::from_row (crates/jolt-kernels/src/optimized/rows.rs:22-72) -- field by field the rows were read once per field. */
+int32_t jolt_ints_from_rows_many(jolt_ctx *ctx, const jolt_rows *rows, const size_t *offsets, const uint32_t *widths, const int32_t *is_signed, size_t n_fields,
+                                 jolt_ints **out);
 /* n_polys hot-index columns from ONE address field (<= 16 bytes): index_i = (field >> shifts[i]) & (2^log_k - 1)
  * (RaChunkSelector::chunk_u128, crates/jolt-witness/src/witnesses/one_hot.rs:14-52); a row whose byte at valid_offset is 0 is a
  * cold cycle (Option::None, e.g. no RAM access); valid_offset = SIZE_MAX: every row is hot.  log_k <= 8 (log_k = 8 gives a 16-bit source). */

@@ -172,6 +172,8 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     for (hipEvent_t e : ctx->ev_fx)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->ev_copy_fork) (void)hipEventDestroy(ctx->ev_copy_fork);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_sort) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

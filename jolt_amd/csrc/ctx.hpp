@@ -69,6 +69,8 @@ struct jolt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // jolt_msm_profile_buckets: HIP events around the fixed-base MSM's dominant kernel (k_fx_buckets_ordered) ON THE STREAM IT IS LAUNCHED ON, and where the launch's
     // count of non-zero digits (= mixed additions) lives on the device -- the `roofline_msm` object of bench.py
+    hipStream_t copy_stream = nullptr;   // jolt_rows_upload_begin: H2D copies beside the main stream's kernels
+    hipEvent_t ev_copy_fork = nullptr;
     bool fx_profile = false;
     hipEvent_t ev_fx[2] = {nullptr, nullptr};
     const uint32_t* fx_profile_info = nullptr;  // device: info[1] = non-zero digits of the profiled launch

@@ -386,9 +386,10 @@ extern "C" int32_t jolt_ints_upload(jolt_ctx* ctx, const void* host, int32_t kin
 
 extern "C" int32_t jolt_ints_free(jolt_ctx* ctx, jolt_ints* v) {
     if (!v) return JOLT_OK;
-    jolt_ctx* c = ctx ? ctx : v->ctx;
-    if (c) (void)hipStreamSynchronize(c->stream);
-    if (v->data) (void)hipFree(v->data);
+    jolt_ctx* c = v->ctx ? v->ctx : ctx;
+    const bool pooled = c && v->data && c->pool_live.count(v->data);  // jolt_ints_from_rows: back to the pool, reused in stream order; uploads: the runtime's block
+    if (c && !pooled) (void)hipStreamSynchronize(c->stream);
+    if (v->data) { if (c) jolt_internal_dev_free(c, v->data); else (void)hipFree(v->data); }
     delete v;
     return JOLT_OK;
 }

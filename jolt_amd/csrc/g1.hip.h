@@ -47,6 +47,17 @@ JOLT_HD G1Jac g1_neg(const G1Jac& p) {
     return r;
 }
 
+// Y^2 = X^3 + 3 Z^6 with canonical coordinates (the identity Z = 0 passes): what a point that crosses the ABI from the caller must satisfy before it is absorbed
+JOLT_HD bool g1_is_on_curve(const G1Jac& p) {
+    Fq d;
+    if (sub_p(d, p.x) == 0 || sub_p(d, p.y) == 0 || sub_p(d, p.z) == 0) return false;  // a coordinate >= q
+    if (g1_is_identity(p)) return true;
+    const Fq z2 = sqr(p.z), z6 = mul(sqr(z2), z2);
+    const Fq three_z6 = add(dbl(z6), z6);
+    const Fq lhs = sqr(p.y), rhs = add(mul(sqr(p.x), p.x), three_z6);
+    return sub(lhs, rhs).is_zero();
+}
+
 // dbl-2009-l
 JOLT_HD G1Jac g1_double(const G1Jac& p) {
     if (g1_is_identity(p)) return p;

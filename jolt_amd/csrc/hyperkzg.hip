@@ -500,7 +500,14 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
     {  // scheme.rs:141-145: the ell-1 level commitments are independent MSMs -> pipelined over the MSM lanes
         // the first n_known level commitments come from the caller (computed by linearity from the structure of the polynomial: jolt_grid_commit_onehot_classes)
         if (n_known > coms.size() || (n_known && !known_levels) || (n_known && world != 1)) { cleanup(); return JOLT_ERR_INVALID_ARG; }
-        for (size_t i = 0; i < n_known; ++i) std::memcpy(&coms[i], &known_levels[i], sizeof(G1Jac));
+        for (size_t i = 0; i < n_known; ++i) {
+            std::memcpy(&coms[i], &known_levels[i], sizeof(G1Jac));
+            if (!g1_is_on_curve(coms[i])) {  // caller-supplied points are absorbed into the transcript and returned in the proof: at least they are points
+                ctx->last_error = "a supplied level commitment is not a point of BN254 G1 (coordinates not canonical or off the curve)";
+                cleanup();
+                return JOLT_ERR_INVALID_ARG;
+            }
+        }
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
         for (size_t i = 1 + n_known; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }

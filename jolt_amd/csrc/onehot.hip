@@ -29,7 +29,7 @@ extern "C" int32_t jolt_onehot_upload(jolt_ctx* ctx, const uint8_t* indices, siz
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ctx->last_error = std::string("onehot upload: ") + hipGetErrorString(e);
-        if (s->idx) (void)hipFree(s->idx);
+        if (s->idx) jolt_internal_dev_free(ctx, s->idx);
         delete s;
         return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
     }
@@ -56,7 +56,7 @@ extern "C" int32_t jolt_onehot_upload16(jolt_ctx* ctx, const uint16_t* indices, 
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ctx->last_error = std::string("onehot upload: ") + hipGetErrorString(e);
-        if (s->idx) (void)hipFree(s->idx);
+        if (s->idx) jolt_internal_dev_free(ctx, s->idx);
         delete s;
         return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
     }
@@ -66,9 +66,11 @@ extern "C" int32_t jolt_onehot_upload16(jolt_ctx* ctx, const uint16_t* indices, 
 
 extern "C" int32_t jolt_onehot_free(jolt_ctx* ctx, jolt_onehot* s) {
     if (!s) return JOLT_OK;
-    jolt_ctx* c = ctx ? ctx : s->ctx;
-    if (c) { (void)jolt_internal_engine_quiesce(c); (void)hipStreamSynchronize(c->stream); }
-    if (s->idx) (void)hipFree(s->idx);
+    jolt_ctx* c = s->ctx ? s->ctx : ctx;
+    if (c) (void)jolt_internal_engine_quiesce(c);
+    const bool pooled = c && s->idx && c->pool_live.count(s->idx);  // jolt_onehot_from_rows: back to the pool, reused in stream order; uploads: the runtime's block
+    if (c && !pooled) (void)hipStreamSynchronize(c->stream);
+    if (s->idx) { if (c) jolt_internal_dev_free(c, s->idx); else (void)hipFree(s->idx); }
     delete s;
     return JOLT_OK;
 }
@@ -130,6 +132,8 @@ struct jolt_rows {
     jolt_ctx* ctx = nullptr;
     uint8_t* data = nullptr;  // device, n_rows * row_bytes
     size_t n_rows = 0, row_bytes = 0;
+    hipEvent_t ready = nullptr;  // jolt_rows_upload_begin: recorded behind the copy on the context's copy stream; jolt_rows_upload_wait makes the main stream wait for it
+    bool pending = false;
 };
 
 namespace {
@@ -211,22 +215,56 @@ static __global__ __launch_bounds__(kBlock) void k_rows_sentinel_to_hot_indices(
     uint64_t v = s < 64 ? (lo >> s) | (s ? hi << (64 - s) : 0ull) : hi >> (s - 64);
     put((uint32_t)(v & ((1u << log_k) - 1)), false);
 }
+// One thread per row: the address field (<= 16 bytes) and its validity byte are read ONCE and every chunk is cut from registers.  (Round 4 ran this with one grid row per
+// chunk: 36 chunk columns re-read the 1 GB of rows 36 times, ~9 ms of the ~18 ms a step's extraction cost: profiles/r05_witness_upload_overlap.txt.)
 static __global__ __launch_bounds__(kBlock) void k_rows_to_hot_indices(const uint8_t* __restrict__ rows, size_t n_rows, size_t row_bytes, size_t offset, uint32_t width,
-                                                                       ChunkShifts sh, uint32_t log_k, size_t valid_offset, uint8_t* __restrict__ idx, uint32_t wide) {
+                                                                       ChunkShifts sh, uint32_t n_polys, uint32_t log_k, size_t valid_offset, uint8_t* __restrict__ idx, uint32_t wide) {
     size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t p = blockIdx.y;
     if (j >= n_rows) return;
     const uint8_t* row = rows + j * row_bytes;
-    auto put = [&](uint32_t v, bool cold) {
-        if (wide) reinterpret_cast<uint16_t*>(idx)[p * n_rows + j] = cold ? kOneHotCold16 : (uint16_t)v;
-        else idx[p * n_rows + j] = cold ? kOneHotCold : (uint8_t)v;
-    };
-    if (valid_offset != ~(size_t)0 && row[valid_offset] == 0) { put(0, true); return; }
-    // (field >> shift) & mask on a little-endian field of up to 16 bytes: the chunk spans at most two bytes for log_k <= 8
-    const uint32_t s = sh.shift[p], byte = s >> 3, bit = s & 7;
-    uint32_t v = byte < width ? row[offset + byte] : 0u;
-    if (byte + 1 < width) v |= (uint32_t)row[offset + byte + 1] << 8;
-    put((v >> bit) & ((1u << log_k) - 1), false);
+    const bool cold = valid_offset != ~(size_t)0 && row[valid_offset] == 0;
+    uint64_t lo = 0, hi = 0;
+    if (!cold) {
+        lo = load_le(row + offset, width < 8 ? width : 8);
+        if (width > 8) hi = load_le(row + offset + 8, width - 8);
+    }
+    const uint32_t mask = (1u << log_k) - 1;
+    for (uint32_t p = 0; p < n_polys; ++p) {
+        const uint32_t s = sh.shift[p];
+        const uint64_t v = s == 0 ? lo : (s < 64 ? (lo >> s) | (hi << (64 - s)) : hi >> (s - 64));
+        if (wide) reinterpret_cast<uint16_t*>(idx)[(size_t)p * n_rows + j] = cold ? kOneHotCold16 : (uint16_t)((uint32_t)v & mask);
+        else idx[(size_t)p * n_rows + j] = cold ? kOneHotCold : (uint8_t)((uint32_t)v & mask);
+    }
+}
+// Every integer field of the rows in ONE pass (jolt_ints_from_rows_many): a workgroup stages kRowsTile whole rows in LDS with coalesced 16-byte loads and every thread
+// then writes its row's value of field after field -- the rows are read once (1 GB at T = 2^22) instead of once per field (27 GB for the catalogue's columns).
+constexpr int kRowsTile = 256;
+constexpr int kRowsMaxFields = 48;
+struct RowFields {
+    uint32_t offset[kRowsMaxFields];
+    uint8_t width[kRowsMaxFields], is_signed[kRowsMaxFields];
+    uint64_t* out[kRowsMaxFields];
+    uint32_t n;
+};
+static __global__ __launch_bounds__(kRowsTile) void k_rows_to_ints_many(const uint8_t* __restrict__ rows, size_t n_rows, uint32_t row_bytes, RowFields f) {
+    extern __shared__ __align__(16) uint8_t rows_tile[];
+    const size_t row0 = (size_t)blockIdx.x * kRowsTile;
+    const size_t n_here = n_rows - row0 < (size_t)kRowsTile ? n_rows - row0 : (size_t)kRowsTile;
+    const size_t bytes = n_here * row_bytes;  // row_bytes is a multiple of 8 (checked by the caller), the tile starts 16-byte aligned for full tiles of 256 rows
+    const uint8_t* src = rows + row0 * row_bytes;
+    for (size_t b = (size_t)threadIdx.x * 8; b < bytes; b += (size_t)kRowsTile * 8) *reinterpret_cast<uint64_t*>(rows_tile + b) = *reinterpret_cast<const uint64_t*>(src + b);
+    __syncthreads();
+    if (threadIdx.x >= n_here) return;
+    const uint8_t* row = rows_tile + (size_t)threadIdx.x * row_bytes;
+    for (uint32_t k = 0; k < f.n; ++k) {
+        const uint32_t width = f.width[k];
+        uint64_t v = load_le(row + f.offset[k], width);
+        if (f.is_signed[k]) {
+            const int bits = (int)width * 8;
+            if (bits < 64 && (v >> (bits - 1)) & 1) v |= ~0ull << bits;  // sign-extend
+        }
+        f.out[k][row0 + threadIdx.x] = v;
+    }
 }
 }  // namespace
 
@@ -254,6 +292,48 @@ extern "C" int32_t jolt_rows_upload(jolt_ctx* ctx, const void* rows, size_t n_ro
     *out = r;
     return JOLT_OK;
 }
+// The same copy IN FLIGHT while the context works on something else -- the next proof's witness moving over the link under the current proof's kernels (round 5).
+// `rows` must be page-locked (jolt_host_pinned_alloc) and stay untouched until jolt_rows_upload_wait returned.  begin: the device block comes from the pool, whose
+// reuse is ordered on the MAIN stream, so the copy stream first waits for the main stream's position at this call, then copies, then records `ready`.  wait: the main
+// stream waits for `ready` (no host synchronisation); from then on the handle is what jolt_rows_upload returns.
+extern "C" int32_t jolt_rows_upload_begin(jolt_ctx* ctx, const void* rows, size_t n_rows, size_t row_bytes, jolt_rows** out) {
+    if (!ctx || !rows || !out || n_rows == 0 || row_bytes == 0) return JOLT_ERR_INVALID_ARG;
+    if (!ctx->copy_stream) {
+        JOLT_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        JOLT_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming));
+    }
+    jolt_rows* r = new (std::nothrow) jolt_rows();
+    if (!r) return JOLT_ERR_OOM;
+    r->ctx = ctx;
+    r->n_rows = n_rows;
+    r->row_bytes = row_bytes;
+    int32_t st = jolt_internal_dev_alloc(ctx, n_rows * row_bytes, (void**)&r->data);
+    if (st != JOLT_OK) { delete r; return st; }
+    hipError_t e = hipEventCreateWithFlags(&r->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_copy_fork, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_copy_fork, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->data, rows, n_rows * row_bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(r->ready, ctx->copy_stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        ctx->last_error = std::string("rows upload (begin): ") + hipGetErrorString(e);
+        if (r->ready) (void)hipEventDestroy(r->ready);
+        jolt_internal_dev_free(ctx, r->data);
+        delete r;
+        return JOLT_ERR_HIP;
+    }
+    r->pending = true;
+    *out = r;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_rows_upload_wait(jolt_ctx* ctx, jolt_rows* r) {
+    if (!ctx || !r) return JOLT_ERR_INVALID_ARG;
+    if (!r->pending) return JOLT_OK;
+    JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, r->ready, 0));
+    r->pending = false;
+    return JOLT_OK;
+}
 // Page-locked host memory for the buffers a caller fills once per proof and hands to jolt_rows_upload (the tracer's packed cycle rows): the H2D copy then runs
 // at the link rate without the runtime's staging copy.  Plain memory otherwise: any thread may write it, jolt_host_pinned_free releases it.
 extern "C" int32_t jolt_host_pinned_alloc(jolt_ctx* ctx, size_t bytes, void** out) {
@@ -277,8 +357,13 @@ extern "C" int32_t jolt_host_pinned_free(jolt_ctx* ctx, void* p) {
 }
 extern "C" int32_t jolt_rows_free(jolt_ctx* ctx, jolt_rows* r) {
     if (!r) return JOLT_OK;
-    jolt_ctx* c = ctx ? ctx : r->ctx;
+    if (ctx && r->ctx && ctx != r->ctx) return JOLT_ERR_INVALID_ARG;  // the block belongs to the pool of the context that uploaded it
+    jolt_ctx* c = r->ctx ? r->ctx : ctx;
     if (c) { (void)jolt_internal_engine_quiesce(c); (void)hipStreamSynchronize(c->stream); }
+    if (r->ready) {  // a copy that was begun and never waited for still writes the block: let it finish before the block goes back to the pool
+        (void)hipEventSynchronize(r->ready);
+        (void)hipEventDestroy(r->ready);
+    }
     if (r->data) { if (c) jolt_internal_dev_free(c, r->data); else (void)hipFree(r->data); }
     delete r;
     return JOLT_OK;
@@ -318,7 +403,13 @@ extern "C" int32_t jolt_ints_from_rows(jolt_ctx* ctx, const jolt_rows* rows, siz
     v->ctx = ctx;
     v->count = rows->n_rows;
     v->kind = is_signed ? JOLT_INT_I64 : JOLT_INT_U64;
-    hipError_t e = hipMalloc(&v->data, std::max<size_t>(v->count, 1) * 8);  // freed by jolt_ints_free (hipFree)
+    // from the context's pool (round 5): a proof per step extracts ~30 columns, and hipMalloc / hipFree pairs cost ~0.4 ms each and synchronise the device --
+    // 24 of the 26 ms the overlapped witness upload still paid per step (profiles/r05_witness_upload_overlap.txt); jolt_ints_free hands pool blocks back in stream order
+    {
+        const int32_t as = jolt_internal_dev_alloc(ctx, std::max<size_t>(v->count, 1) * 8, &v->data);
+        if (as != JOLT_OK) { delete v; return as; }
+    }
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rows_to_ints, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, (const uint8_t*)rows->data, rows->n_rows,
                            rows->row_bytes, offset, width, is_signed ? 1 : 0, (uint64_t*)v->data);
@@ -326,11 +417,68 @@ extern "C" int32_t jolt_ints_from_rows(jolt_ctx* ctx, const jolt_rows* rows, siz
     }
     if (e != hipSuccess) {
         ctx->last_error = std::string("ints from rows: ") + hipGetErrorString(e);
-        if (v->data) (void)hipFree(v->data);
+        if (v->data) jolt_internal_dev_free(ctx, v->data);
         delete v;
         return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
     }
     *out = v;
+    return JOLT_OK;
+}
+
+// jolt_ints_from_rows for n_fields fields at once: out[k] = field k as a resident integer column (the same values, one pass over the rows)
+extern "C" int32_t jolt_ints_from_rows_many(jolt_ctx* ctx, const jolt_rows* rows, const size_t* offsets, const uint32_t* widths, const int32_t* is_signed, size_t n_fields,
+                                            jolt_ints** out) {
+    if (!ctx || !rows || !offsets || !widths || !is_signed || !out) return JOLT_ERR_INVALID_ARG;
+    for (size_t k = 0; k < n_fields; ++k) {
+        const uint32_t w = widths[k];
+        if (!(w == 1 || w == 2 || w == 4 || w == 8) || w > rows->row_bytes || offsets[k] > rows->row_bytes - w) return JOLT_ERR_INVALID_ARG;
+        out[k] = nullptr;
+    }
+    const size_t tile_bytes = (size_t)kRowsTile * rows->row_bytes;
+    if (rows->row_bytes % 8 != 0 || tile_bytes > ctx->max_lds_per_block || rows->row_bytes > 0xFFFFFFFFull) {  // rows that do not stage: field by field
+        for (size_t k = 0; k < n_fields; ++k) {
+            const int32_t st = jolt_ints_from_rows(ctx, rows, offsets[k], widths[k], is_signed[k], &out[k]);
+            if (st != JOLT_OK) { for (size_t q = 0; q < k; ++q) { jolt_ints_free(ctx, out[q]); out[q] = nullptr; } return st; }
+        }
+        return JOLT_OK;
+    }
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    auto release = [&](size_t upto) { for (size_t q = 0; q < upto; ++q) { jolt_ints_free(ctx, out[q]); out[q] = nullptr; } };
+    for (size_t k = 0; k < n_fields; ++k) {
+        jolt_ints* v = new (std::nothrow) jolt_ints();
+        if (!v) { release(k); return JOLT_ERR_OOM; }
+        v->ctx = ctx;
+        v->count = rows->n_rows;
+        v->kind = is_signed[k] ? JOLT_INT_I64 : JOLT_INT_U64;
+        const int32_t as = jolt_internal_dev_alloc(ctx, std::max<size_t>(v->count, 1) * 8, &v->data);
+        if (as != JOLT_OK) { delete v; release(k); return as; }
+        out[k] = v;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_rows_to_ints_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    for (size_t k0 = 0; k0 < n_fields; k0 += kRowsMaxFields) {
+        RowFields f;
+        f.n = (uint32_t)std::min<size_t>(kRowsMaxFields, n_fields - k0);
+        for (uint32_t k = 0; k < (uint32_t)kRowsMaxFields; ++k) {
+            const bool live = k < f.n;
+            f.offset[k] = live ? (uint32_t)offsets[k0 + k] : 0u;
+            f.width[k] = live ? (uint8_t)widths[k0 + k] : (uint8_t)1;
+            f.is_signed[k] = live && is_signed[k0 + k] ? 1 : 0;
+            f.out[k] = live ? (uint64_t*)out[k0 + k]->data : nullptr;
+        }
+        hipLaunchKernelGGL(k_rows_to_ints_many, dim3((unsigned)((rows->n_rows + kRowsTile - 1) / kRowsTile)), dim3(kRowsTile), tile_bytes, ctx->stream, (const uint8_t*)rows->data,
+                           rows->n_rows, (uint32_t)rows->row_bytes, f);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("ints from rows (many): ") + hipGetErrorString(e);
+        release(n_fields);
+        return JOLT_ERR_HIP;
+    }
     return JOLT_OK;
 }
 
@@ -352,15 +500,19 @@ extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, s
     s->cycles = rows->n_rows;
     s->k = 1u << log_k;
     s->wide = log_k > 7 ? 1u : 0u;
-    hipError_t e = hipMalloc((void**)&s->idx, (n_polys * rows->n_rows) << s->wide);
+    hipError_t e = hipSuccess;
+    {
+        const int32_t as = jolt_internal_dev_alloc(ctx, std::max<size_t>((n_polys * rows->n_rows) << s->wide, 1), (void**)&s->idx);  // pooled, as jolt_ints_from_rows
+        if (as != JOLT_OK) { delete s; return as; }
+    }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_rows_to_hot_indices, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock), (unsigned)n_polys), dim3(kBlock), 0, ctx->stream,
-                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, valid_offset, s->idx, s->wide);
+        hipLaunchKernelGGL(k_rows_to_hot_indices, dim3((unsigned)((rows->n_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, (uint32_t)n_polys, log_k, valid_offset, s->idx, s->wide);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
         ctx->last_error = std::string("onehot from rows: ") + hipGetErrorString(e);
-        if (s->idx) (void)hipFree(s->idx);
+        if (s->idx) jolt_internal_dev_free(ctx, s->idx);
         delete s;
         return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
     }
@@ -404,7 +556,11 @@ extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows
     s->cycles = cycles;
     s->k = 1u << log_k;
     s->wide = log_k > 7 ? 1u : 0u;
-    hipError_t e = hipMalloc((void**)&s->idx, (n_polys * cycles) << s->wide);
+    hipError_t e = hipSuccess;
+    {
+        const int32_t as = jolt_internal_dev_alloc(ctx, std::max<size_t>((n_polys * cycles) << s->wide, 1), (void**)&s->idx);  // pooled, as jolt_ints_from_rows
+        if (as != JOLT_OK) { delete s; return as; }
+    }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rows_sentinel_to_hot_indices, dim3((unsigned)((cycles + kBlock - 1) / kBlock), (unsigned)n_polys), dim3(kBlock), 0, ctx->stream,
                            (const uint8_t*)rows->data, rows->n_rows, rows->row_bytes, offset, width, sh, log_k, cycles, s->idx, s->wide);
@@ -412,7 +568,7 @@ extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows
     }
     if (e != hipSuccess) {
         ctx->last_error = std::string("onehot from sentinel rows: ") + hipGetErrorString(e);
-        if (s->idx) (void)hipFree(s->idx);
+        if (s->idx) jolt_internal_dev_free(ctx, s->idx);
         delete s;
         return e == hipErrorOutOfMemory ? JOLT_ERR_OOM : JOLT_ERR_HIP;
     }

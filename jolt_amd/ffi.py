@@ -922,6 +922,22 @@ class Rows:
         _ck(lib().jolt_rows_upload(ctx.h, raw.ctypes.data_as(C.c_void_p), C.c_size_t(self.n_rows), C.c_size_t(self.row_bytes), C.byref(h)), "jolt_rows_upload", ctx)
         self.ctx, self.h = ctx, h
 
+    @classmethod
+    def begin(cls, ctx, pinned_rows):
+        """jolt_rows_upload_begin: the copy starts now on the context's copy stream and runs beside whatever the context does next; `pinned_rows` is a PinnedBuffer's
+        array (page-locked) and must stay unchanged until wait()"""
+        raw = pinned_rows
+        assert raw.flags["C_CONTIGUOUS"] and raw.ndim == 2
+        self = cls.__new__(cls)
+        self.n_rows, self.row_bytes = raw.shape[0], raw.shape[1]
+        h = C.c_void_p()
+        _ck(lib().jolt_rows_upload_begin(ctx.h, raw.ctypes.data_as(C.c_void_p), C.c_size_t(self.n_rows), C.c_size_t(self.row_bytes), C.byref(h)), "jolt_rows_upload_begin", ctx)
+        self.ctx, self.h = ctx, h
+        return self
+
+    def wait(self):
+        _ck(lib().jolt_rows_upload_wait(self.ctx.h, self.h), "jolt_rows_upload_wait", self.ctx)
+
     def table(self, offset, width, signed=False):
         h = C.c_void_p()
         _ck(lib().jolt_table_from_rows(self.ctx.h, self.h, C.c_size_t(offset), C.c_uint32(width), C.c_int32(1 if signed else 0), C.byref(h)), "jolt_table_from_rows",
@@ -935,6 +951,21 @@ class Rows:
         v = Ints.__new__(Ints)
         v.ctx, v.kind, v.count, v.h = self.ctx, "i64" if signed else "u64", self.n_rows, h
         return v
+
+    def ints_many(self, fields):
+        """[(offset, width, signed)] -> one Ints per field, all extracted in ONE pass over the rows (jolt_ints_from_rows_many)"""
+        n = len(fields)
+        offs = (C.c_size_t * n)(*[f[0] for f in fields])
+        widths = (C.c_uint32 * n)(*[f[1] for f in fields])
+        signed = (C.c_int32 * n)(*[1 if f[2] else 0 for f in fields])
+        hs = (C.c_void_p * n)()
+        _ck(lib().jolt_ints_from_rows_many(self.ctx.h, self.h, offs, widths, signed, C.c_size_t(n), hs), "jolt_ints_from_rows_many", self.ctx)
+        out = []
+        for k, f in enumerate(fields):
+            v = Ints.__new__(Ints)
+            v.ctx, v.kind, v.count, v.h = self.ctx, "i64" if f[2] else "u64", self.n_rows, C.c_void_p(hs[k])
+            out.append(v)
+        return out
 
     def onehot(self, offset, width, shifts, log_k, valid_offset=None):
         sh = (C.c_uint32 * len(shifts))(*shifts)

@@ -246,7 +246,11 @@ class DeviceWorkload:
         # crates/jolt-witness/src/consumer.rs:129-143, crates/jolt-kernels/src/optimized/rows.rs:22-72): one H2D copy of the rows, the typed columns and hot
         # indices extracted on the device (jolt_rows_upload, jolt_ints_from_rows, jolt_onehot_from_rows).  Default: the witness is resident ("inputs in HBM").
         self.witness_upload = bool(witness_upload)
-        self.witness_pinned = witness_upload == "pinned"  # the row buffer in page-locked memory (jolt_host_pinned_alloc) instead of pageable numpy memory
+        self.witness_pinned = witness_upload in ("pinned", "overlapped")  # the row buffer in page-locked memory (jolt_host_pinned_alloc) instead of pageable numpy memory
+        # "overlapped": the NEXT proof's rows are copied (jolt_rows_upload_begin, on the context's copy stream) while the current proof runs -- a prover fed by a tracer
+        # that is one trace ahead; every proof still starts from host memory, the copy is simply no longer on its critical path
+        self.witness_overlapped = witness_upload == "overlapped"
+        self._rows_in_flight = None
         # extended: the stage 1 / 2 / 5 operators that are not plain cycle-domain relations (Spartan outer / product, the sparse RAM read-write
         # matrix, the instruction read-RAF scans + cycle rounds: jolt_amd/stages.py) inside every step, over their own resident inputs
         self.ext = None
@@ -449,19 +453,28 @@ class DeviceWorkload:
                 self._packed = rows
         if self.prepared:
             self.release()  # the members of the previous proof borrow the columns that are replaced here
-        rows = self.ffi.Rows(self.ctx, self._packed)
+        if self.witness_overlapped:
+            rows = self._rows_in_flight if self._rows_in_flight is not None else self.ffi.Rows.begin(self.ctx, self._packed)  # (the first proof has nothing ahead of it)
+            self._rows_in_flight = None
+            rows.wait()
+        else:
+            rows = self.ffi.Rows(self.ctx, self._packed)
+        int_fields = [f for f in self._fields if f[0] == "int"]
+        extracted = rows.ints_many([(off, width, self.tables_spec[name].kind == "i64") for _, name, off, width in int_fields])  # every integer column in one pass over the rows
+        for (_, name, _, _), new in zip(int_fields, extracted):
+            self.ints[name].free()
+            self.ints[name] = new
         for f in self._fields:
             if f[0] == "int":
-                _, name, off, width = f
-                new = rows.ints(off, width, signed=self.tables_spec[name].kind == "i64")
-                self.ints[name].free()
-                self.ints[name] = new
+                continue
             else:
                 _, i, off, width, n, log_k = f
                 new = rows.onehot(off, width, [k * log_k for k in range(n)], log_k, valid_offset=off + width)
                 self.sources[i].free()
                 self.sources[i] = new
         rows.free()
+        if self.witness_overlapped:  # the next proof's witness starts moving now, under this proof's kernels
+            self._rows_in_flight = self.ffi.Rows.begin(self.ctx, self._packed)
 
     def witness_bytes_per_cycle(self):
         if getattr(self, "_packed", None) is None:
@@ -590,6 +603,9 @@ class DeviceWorkload:
         for v in self.ints.values():
             v.free()
         self.sources, self.ints = {}, {}
+        if getattr(self, "_rows_in_flight", None) is not None:
+            self._rows_in_flight.free()
+            self._rows_in_flight = None
         if getattr(self, "_pinned", None) is not None:
             self._packed = None
             self._pinned.free()

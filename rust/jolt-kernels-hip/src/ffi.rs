@@ -278,11 +278,14 @@ extern "C" {
     pub fn jolt_member_create_lazy_ra_uniform(ctx: *mut jolt_ctx, source: *const jolt_onehot, scale_tables: *const jolt_fr_t, V: u32, F: u32, coeffs: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_member_create_lazy_ra_uniform_sharded(ctx: *mut jolt_ctx, source: *const jolt_onehot, scale_tables: *const jolt_fr_t, V: u32, F: u32, coeffs: *const jolt_fr_t, w: *const jolt_fr_t, n: usize, scale: *const jolt_fr_t, shard_scale: *const jolt_fr_t, out: *mut *mut jolt_member) -> i32;
     pub fn jolt_rows_upload(ctx: *mut jolt_ctx, rows: *const c_void, n_rows: usize, row_bytes: usize, out: *mut *mut jolt_rows) -> i32;
+    pub fn jolt_rows_upload_begin(ctx: *mut jolt_ctx, rows: *const c_void, n_rows: usize, row_bytes: usize, out: *mut *mut jolt_rows) -> i32;
+    pub fn jolt_rows_upload_wait(ctx: *mut jolt_ctx, rows: *mut jolt_rows) -> i32;
     pub fn jolt_host_pinned_alloc(ctx: *mut jolt_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
     pub fn jolt_host_pinned_free(ctx: *mut jolt_ctx, p: *mut c_void) -> i32;
     pub fn jolt_rows_free(ctx: *mut jolt_ctx, rows: *mut jolt_rows) -> i32;
     pub fn jolt_table_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, is_signed: i32, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_ints_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, is_signed: i32, out: *mut *mut jolt_ints) -> i32;
+    pub fn jolt_ints_from_rows_many(ctx: *mut jolt_ctx, rows: *const jolt_rows, offsets: *const usize, widths: *const u32, is_signed: *const i32, n_fields: usize, out: *mut *mut jolt_ints) -> i32;
     pub fn jolt_onehot_from_rows(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, shifts: *const u32, n_polys: usize, log_k: u32, valid_offset: usize, out: *mut *mut jolt_onehot) -> i32;
     pub fn jolt_onehot_download(ctx: *mut jolt_ctx, source: *const jolt_onehot, out: *mut u8) -> i32;
     pub fn jolt_table_from_rows_window(ctx: *mut jolt_ctx, rows: *const jolt_rows, offset: usize, width: u32, is_signed: i32, lookahead: i32, cycles: usize, padding_value: i64, none_value: i64, out: *mut *mut jolt_table) -> i32;

@@ -145,22 +145,32 @@ unsafe extern "C" fn open_hook<T: Transcript<Challenge = Fr>>(
     n_values: usize,
     challenge_out: *mut ffi::jolt_fr_t,
 ) -> i32 {
-    // SAFETY: `user` is the `Hook` `open` passes for the duration of the call; the arrays hold the stated counts of 96- / 32-byte
-    // elements with the layouts of `Bn254G1` / `Fr` (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24, crates/jolt-field/src/bn254/mod.rs:33-43).
-    let hook = unsafe { &mut *user.cast::<Hook<'_, T>>() };
-    if n_points != 0 {
-        for p in unsafe { std::slice::from_raw_parts(points.cast::<Bn254G1>(), n_points) } {
-            hook.transcript.append(p);
+    // The transcript is the caller's code: a panic inside `append` / `challenge` must not unwind through the C frames of libjolt_hip.so (undefined behaviour).
+    // It is caught here and reported as a status, which aborts the opening with that status (`jolt_open_transcript_fn`: "a non-zero return aborts").
+    let outcome = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+        // SAFETY: `user` is the `Hook` `open` passes for the duration of the call; the arrays hold the stated counts of 96- / 32-byte
+        // elements with the layouts of `Bn254G1` / `Fr` (crates/jolt-crypto/src/ec/bn254/mod.rs:17-24, crates/jolt-field/src/bn254/mod.rs:33-43).
+        let hook = unsafe { &mut *user.cast::<Hook<'_, T>>() };
+        if n_points != 0 {
+            // SAFETY: as above: `n_points` points at `points`.
+            for p in unsafe { std::slice::from_raw_parts(points.cast::<Bn254G1>(), n_points) } {
+                hook.transcript.append(p);
+            }
         }
-    }
-    if n_values != 0 {
-        for v in unsafe { std::slice::from_raw_parts(values.cast::<Fr>(), n_values) } {
-            hook.transcript.append(v);
+        if n_values != 0 {
+            // SAFETY: as above: `n_values` field elements at `values`.
+            for v in unsafe { std::slice::from_raw_parts(values.cast::<Fr>(), n_values) } {
+                hook.transcript.append(v);
+            }
         }
+        let challenge: Fr = hook.transcript.challenge();
+        // SAFETY: `challenge_out` is one writable jolt_fr_t.
+        unsafe { challenge_out.cast::<Fr>().write(challenge) };
+    }));
+    match outcome {
+        Ok(()) => ffi::JOLT_OK,
+        Err(_) => ffi::JOLT_ERR_INVALID_ARG,
     }
-    let challenge: Fr = hook.transcript.challenge();
-    unsafe { challenge_out.cast::<Fr>().write(challenge) };
-    ffi::JOLT_OK
 }
 
 impl HipHyperKzg {

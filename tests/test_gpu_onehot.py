@@ -234,7 +234,22 @@ def test_packed_witness_rows_expand_to_tables_and_hot_indices(ctx):
     assert np.array_equal(R.table(dt.fields["ram_inc"][1], 8, signed=True).download(), O.fr_from_i64(rows["ram_inc"]))
     assert np.array_equal(R.table(dt.fields["pc"][1], 4).download(), O.fr_from_u64(rows["pc"].astype(np.uint64)))
     assert np.array_equal(R.table(dt.fields["ram_valid"][1], 1).download(), O.fr_from_u64(rows["ram_valid"].astype(np.uint64)))
+    # every integer field in ONE pass over the rows (jolt_ints_from_rows_many: whole rows staged in LDS) -- the same columns as field by field, on a ragged row count too
+    fields = [(dt.fields["rd_inc"][1], 8, True), (dt.fields["ram_inc"][1], 8, True), (dt.fields["pc"][1], 4, False), (dt.fields["ram_valid"][1], 1, False),
+              (dt.fields["lookup_hi"][1], 8, False), (dt.fields["ram_addr"][1], 2, False)]
+    for n_rows in (T, 777):
+        Rn = R if n_rows == T else ffi.Rows(ctx, rows[:n_rows])
+        many = Rn.ints_many(fields)
+        for (off, width, signed), col in zip(fields, many):
+            one = Rn.ints(off, width, signed=signed)
+            assert col.count == n_rows and np.array_equal(ctx.table_from_ints(col).download(), ctx.table_from_ints(one).download()), (n_rows, off, width)
+            assert np.array_equal(ctx.table_from_ints(col).download(), Rn.table(off, width, signed=signed).download())
+            one.free()
+            col.free()
+    with pytest.raises(ffi.JoltError):
+        R.ints_many([(dt.itemsize - 4, 8, False)])  # field beyond the row
     # instruction RA: 32 chunks of 4 bits of the 128-bit lookup index, most significant chunk first
+    chunks, bits = 32, 4    # instruction RA: 32 chunks of 4 bits of the 128-bit lookup index, most significant chunk first
     chunks, bits = 32, 4
     shifts = [(chunks - 1 - i) * bits for i in range(chunks)]
     src = R.onehot(dt.fields["lookup_lo"][1], 16, shifts, bits)

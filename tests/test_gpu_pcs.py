@@ -142,6 +142,15 @@ def test_open_with_a_supplied_level_commitment_is_the_same_proof(ctx):
             assert same_point(again["w"][t], plain["w"][t])
     wrong = ctx.hyperkzg_open(srs, tab, point, label=4, known_levels=plain["com"][1:2])
     assert not np.array_equal(wrong["challenges"], plain["challenges"])
+    # ... but it must at least BE a point: coordinates off the curve or not canonical are refused before anything is absorbed
+    off_curve = np.array(plain["com"][:1], dtype=np.uint64).copy()
+    off_curve[0, 0] ^= np.uint64(1)
+    not_canonical = np.array(plain["com"][:1], dtype=np.uint64).copy()
+    not_canonical[0, :4] = np.uint64(2**64 - 1)
+    for bad in (off_curve, not_canonical):
+        with pytest.raises(ffi.JoltError) as e:
+            ctx.hyperkzg_open(srs, tab, point, label=4, known_levels=bad)
+        assert e.value.status == 1
 
 
 @pytest.mark.parametrize("n_vars", [4, 6])

@@ -144,7 +144,7 @@ def test_alternate_kernel_paths_give_the_same_transcript(monkeypatch, knobs):
             assert np.array_equal(got[stage][key], want[stage][key]), (knobs, stage, key)
 
 
-@pytest.mark.parametrize("n_vars,mode", [(6, True), (15, True), (12, "pinned")])
+@pytest.mark.parametrize("n_vars,mode", [(6, True), (15, True), (12, "pinned"), (13, "overlapped")])  # "overlapped": the next proof's rows copied under this proof's kernels
 def test_witness_upload_path_gives_the_same_proof(n_vars, mode):
     """DeviceWorkload(witness_upload=True): every step starts from the packed per-cycle rows in host memory -- one upload, the integer columns (jolt_ints_from_rows)
     and the RA chunk indices (jolt_onehot_from_rows: the nibbles of the instruction lookup index / the RAM address, cold = invalid) extracted on the device
@@ -155,7 +155,7 @@ def test_witness_upload_path_gives_the_same_proof(n_vars, mode):
     rows, fields = b.pack_witness_rows()
     assert rows.shape == (1 << n_vars, b.witness_bytes_per_cycle()) and len(fields) == len(b.ints) + len(b.sources)
     want = a.prove(label=7)
-    for rep in range(2):
+    for rep in range(3 if mode == "overlapped" else 2):  # (overlapped: the first proof waits for its own copy, the later ones for a copy begun a proof earlier)
         got = b.step(label=7)["stages"]
         for stage in want:
             for key in ("polys", "challenges", "final_claim"):
