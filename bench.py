@@ -158,7 +158,7 @@ PUBLISHED_REFERENCE = {  # what the reference itself publ
     "source": "book/src/how/optimizations/inlines.md:147,151,155", "also": "~500 kHz on a MacBook M4 Max, 16 cores (same file :149-150)"}
 
 
-def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
+def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False, gpu_scale=0):
     """The same step on the host cores through the oracle's OpenMP restatement (kind = "port": the reference is Rust + rayon and
     cannot be built in this image; its arithmetic lives in an un-vendored arkworks fork): per-proof tables, the 11 relations in the
     optimized tier's fused form (skipped s(1), linear combinations folded; the RA columns dense), and -- with_pcs -- the
@@ -183,7 +183,8 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
             return set() if n_vars > cls.DIRECT_ADDRESS_ROUNDS_MAX_LOG_T else set(range(128))
 
     class Sample:
-        def __init__(self, scale):
+        def __init__(self, scale, pcs=True):
+            self.pcs = pcs and with_pcs
             self.scale, self.T = scale, 1 << scale
             self.spec, self.members_spec, gammas = W.build(scale, 2026)
             self.res, self.one, _ = resolver(gammas)
@@ -196,7 +197,7 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
             self.idx = np.stack([self.spec[t].data for ms in self.members_spec if ms.uniform is not None for t in ms.tables[1:]])
             self.s_oh, self.s_d = W.rand_fr(self.idx.shape[0], prng), W.rand_fr(2, prng)
             self.point = W.rand_fr(scale + 4, prng)
-            if with_pcs:  # the first K * T powers of the device's SRS, converted to affine once (inputs, not timed)
+            if self.pcs:  # the first K * T powers of the device's SRS, converted to affine once (inputs, not timed)
                 self.bases = O.baseline_prepare_bases(srs_dev.download(0, K * self.T))
             # The stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators are NOT part of the CPU figure (round-4 review, item 8): their oracle twins are CHECKERS -- dense
             # definitions behind the sparse matrices, brute-force sums behind the read-RAF scans -- not the reference's prefix-suffix / sparse algorithms, so timing
@@ -217,7 +218,7 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
                 else:
                     O.baseline_member_sumcheck(tabs, self.res.groups(ms.groups), ms.degree, self.chal)
             t2 = time.perf_counter()
-            if with_pcs:
+            if self.pcs:
                 dense = [tables["s6.ram_inc"], tables["s6.rd_inc"]]
                 O.baseline_msm_many(self.bases, dense)
                 O.baseline_grid_onehot_sums(self.bases, self.idx)
@@ -252,7 +253,7 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
         O.baseline_set_max_window(best_c)
         if log_t <= 0:  # T = 2^20 unless a step there is predicted (linear in T from the calibration step) to exceed about a minute
             log_t = cal_scale
-            while log_t < min(22, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 90.0:
+            while log_t < min(22, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 40.0:  # the contract's bounded sample: ~10-30 s of CPU work per step
                 log_t += 1
         smp = cal if log_t == cal_scale else Sample(log_t)
         del cal
@@ -261,6 +262,19 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
         while reps == 0 or (dt < 10.0 and reps < 2):
             dt += smp.step()
             reps += 1
+        # the sumcheck legs alone (per-proof tables + the 11 relations) at the GPU line's own T when that fits ~20 s: reported beside the sample, not inside `value`
+        legs_at_gpu_t = None
+        per_cycle = (Sample.legs["tables"] + Sample.legs["sumchecks"]) / reps / (1 << log_t)
+        if gpu_scale and gpu_scale > log_t and per_cycle * (1 << gpu_scale) <= 25.0:
+            del smp
+            big = Sample(gpu_scale, pcs=False)
+            keep = dict(Sample.legs)
+            Sample.legs = {k: 0.0 for k in Sample.legs}
+            big.step()
+            legs_at_gpu_t = {"trace_length": 1 << gpu_scale, "tables_s": round(Sample.legs["tables"], 3), "sumchecks_s": round(Sample.legs["sumchecks"], 3),
+                             "cycles_per_s": round((1 << gpu_scale) / (Sample.legs["tables"] + Sample.legs["sumchecks"]), 1)}
+            Sample.legs = keep
+            del big
     finally:
         O.baseline_use_parallel_msm(False)
         O.baseline_set_max_window(16)
@@ -270,7 +284,7 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False):
     legs_s = {k: round(v / reps, 3) for k, v in Sample.legs.items() if k != "stage_operators"}
     return {"value": round(reps * (1 << log_t) / dt, 1), "unit": "cycles/s", "cores": best_n, "kind": "port",
             "config": {"trace_length": 1 << log_t, "legs": "prepare (per-proof tables) + prove (stage 2-6b sumchecks)" + (" + commit + open" if with_pcs else ""),
-                       "seconds_per_step": legs_s},
+                       "seconds_per_step": legs_s, "sumcheck_legs_at_the_gpu_lines_T": legs_at_gpu_t},
             "sample": f"the legs of the step that ARE the reference's algorithms, at T=2^{log_t} on the host cores: "
                       + "per-proof tables + the 11 relations in the optimized tier's fused form (skipped s(1), dense RA columns), all rounds"
                       + " (the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators are NOT in the CPU figure: their oracle twins are dense-definition checkers, not the reference's "
@@ -589,7 +603,7 @@ def main():
         if not args.no_cpu_baseline:
             try:
                 srs_dev = (pcs_sharded.srs if sharded else wl.srs) if pcs else None  # the CPU sample's grid uses a prefix of the same SRS (inputs)
-                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs), with_ext=(the_ext is not None))
+                out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs), with_ext=(the_ext is not None), gpu_scale=args.scale)
                 if split is not None:  # the GPU's time for exactly the legs the CPU figure covers (the stage operators are in `value` but not in the CPU sample)
                     same = [k for k in ("prepare", "commit", "prove", "open") if k in split]
                     ms = sum(split[k] for k in same)
