@@ -3,7 +3,7 @@
 #   bash tools/collect_round.sh r03 [notests]
 # writes gpurun_out/<tag>/...; the files to keep are then copied into profiles/ as <tag>_* (tools/keep_round.sh).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -18,7 +18,7 @@ fi
 # the driver's command (default flags: all stages), the round-2 step for comparison, and the sumcheck legs alone (BASELINE configs[1] shape)
 timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cut -c1-200 "$OUT/bench.json"
-timeout 300 python bench.py --stages 2-6b --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_stages_2-6b.json" 2>/dev/null
+timeout 300 python bench.py --stages 2-6b --no-cpu-baseline --no-msm-roofline --no-upload-rate --steps 10 --warmup 3 > "$OUT/bench_stages_2-6b.json" 2>/dev/null
 timeout 300 python bench.py --no-msm --stages 2-6b --scale 22 --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_nomsm_22.json" 2>/dev/null
 timeout 300 python bench.py --no-msm --stages 2-6b --scale 20 --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_nomsm_20.json" 2>/dev/null
 for f in bench bench_stages_2-6b bench_nomsm_22 bench_nomsm_20; do python -c "import json,sys; d=json.loads(open('$OUT/$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d['config'].get('ms_per_step_split'))"; done
@@ -43,8 +43,11 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
 PY
 head -16 "$OUT/seq_kernel_sums.txt"
 # the witness path: every step from packed rows in page-locked host memory (PCIe-inclusive; never `value`)
-timeout 300 python bench.py --witness upload-pinned --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/bench_witness_upload.json" 2>/dev/null
+timeout 300 python bench.py --witness upload-pinned --no-cpu-baseline --no-msm-roofline --steps 10 --warmup 3 > "$OUT/bench_witness_upload.json" 2>/dev/null
 python -c "import json; d=json.loads(open('$OUT/bench_witness_upload.json').read().strip().splitlines()[-1]); print('witness upload', d['ms_per_step'], d['config'].get('witness'))"
+# ... and with the next proof's rows copied under the current proof (round 5)
+timeout 300 python bench.py --witness upload-overlapped --no-cpu-baseline --no-msm-roofline --steps 10 --warmup 3 > "$OUT/bench_witness_upload_overlapped.json" 2>/dev/null
+python -c "import json; d=json.loads(open('$OUT/bench_witness_upload_overlapped.json').read().strip().splitlines()[-1]); print('witness upload overlapped', d['ms_per_step'], d['config'].get('witness'))"
 # the step's own opening: what runs while no bucket sum does (profiles/open_exposed.py), min of 3 wall times
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p_os && timeout 500 rocprofv3 --kernel-trace -d /tmp/p_os -o o -- python "$ROOT/tools/open_step.py" 22 1 > "$OUT/open_step.txt" 2>&1; \
   f=$(find /tmp/p_os -name "*.db" | head -1); python "$ROOT/profiles/open_exposed.py" "$f" 34 > "$OUT/open_exposed_step.txt" 2>&1 )

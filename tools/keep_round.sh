@@ -24,6 +24,7 @@ keep bind_roofline_kernel_stats.txt bind_roofline_kernel_stats.txt
 keep pmc_round_kernels.txt pmc_round_kernels.txt
 keep pytest_gpu.txt pytest_gpu.txt
 keep bench_witness_upload.json bench_witness_upload.json
+keep bench_witness_upload_overlapped.json bench_witness_upload_overlapped.json
 keep open_exposed_step.txt open_exposed_step.txt
 keep pmc_ext/stage_operator_traffic.txt stage_operator_traffic.txt
 keep build_force.txt build_force.txt
