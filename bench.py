@@ -253,7 +253,7 @@ def cpu_baseline(log_t, srs_dev, with_pcs, with_ext=False, gpu_scale=0):
         O.baseline_set_max_window(best_c)
         if log_t <= 0:  # T = 2^20 unless a step there is predicted (linear in T from the calibration step) to exceed about a minute
             log_t = cal_scale
-            while log_t < min(22, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 40.0:  # the contract's bounded sample: ~10-30 s of CPU work per step
+            while log_t < min(22, max_grid) and best_t * (1 << (log_t + 1 - cal_scale)) <= 48.0:  # the contract's bounded sample: ~10-30 s of CPU work per step
                 log_t += 1
         smp = cal if log_t == cal_scale else Sample(log_t)
         del cal
@@ -401,6 +401,8 @@ def main():
                 pcs_sharded.open(label)
     else:
         wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), witness_upload={"resident": False, "upload": True, "upload-pinned": "pinned", "upload-overlapped": "overlapped"}[args.witness])
+        if os.environ.get("JOLT_FLIP_UPLOAD") == "1":  # diagnostic: a RESIDENT-built workload switched to the overlapped upload before the timed loop (what the value_with_upload leg does)
+            wl.witness_upload, wl.witness_pinned, wl.witness_overlapped = True, True, True
         step = wl.step
 
     def barrier():
@@ -452,6 +454,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     # where the step time goes: two more steps (outside the timed region) with a synchronisation after each leg
     split = None
+    if os.environ.get("JOLT_FLIP_UPLOAD") == "after" and not sharded:  # diagnostic: the legs of a step AFTER a resident timed loop, with the overlapped upload switched on
+        wl.witness_upload, wl.witness_pinned, wl.witness_overlapped = True, True, True
+        args.witness = "upload-overlapped"
+        for i in range(3):
+            step(label=90000 + i)
     if not sharded and not args.no_split:
         ext_legs = []
         if wl.ext is not None:
@@ -478,12 +485,17 @@ def main():
     # The PCIe-inclusive rate beside the contract's `value` (never instead of it): the same K steps with every proof starting from packed rows in page-locked HOST memory,
     # the next proof's copy in flight under the current proof's kernels (jolt_rows_upload_begin; a tracer one trace ahead of the prover).  N = 1, resident default run only.
     with_upload = None
-    if not sharded and args.witness == "resident" and not args.no_upload_rate:
+    if pcs and not sharded and args.witness == "resident" and not args.no_upload_rate:
         try:
             wl.witness_upload, wl.witness_pinned, wl.witness_overlapped = True, True, True
-            dt_up = timed(args.steps, max(1, min(args.warmup, 2)), 70000)
+            dt_up = timed(args.steps, max(3, args.warmup), 70000)  # (the first proof has no copy ahead of it, the second meets a cold pool)
             bpc = wl.witness_bytes_per_cycle()
+            # the resident step once more, right behind it: by now the part has run ~30 steps back to back and clocks lower than in the first timed loop, so the upload's
+            # cost is the difference to THIS figure, not to `ms_per_step`
+            wl.witness_upload = wl.witness_overlapped = False
+            dt_res = timed(args.steps, 1, 80000)
             with_upload = {"value": round(total_cycles_for_upload / (dt_up / args.steps), 1), "unit": "cycles/s", "ms_per_step": round(dt_up / args.steps * 1e3, 3),
+                           "resident_ms_per_step_right_after": round(dt_res / args.steps * 1e3, 3),
                            "bytes_per_cycle": bpc, "bytes_per_step": bpc << args.scale,
                            "mode": "every step starts from packed per-cycle rows in page-locked host memory (catalogue witness: integer columns + RA chunk addresses; the stage operators' inputs stay "
                                    "resident); one H2D copy per proof on a copy stream, begun when the PREVIOUS proof has extracted its columns, so it runs under that proof's kernels; "

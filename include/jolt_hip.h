@@ -469,7 +469,7 @@ typedef struct jolt_rows jolt_rows;
 int32_t jolt_rows_upload(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t row_bytes, jolt_rows **out);
 /* The same copy in flight beside the context's kernels: the NEXT proof's rows moving over the link while the current proof runs (the witness is produced by the tracer
  * ahead of the prover, crates/jolt-witness/src/consumer.rs:129-143).  `rows` must be page-locked (jolt_host_pinned_alloc) and unchanged until _wait returned; _begin
- * returns at once, _wait orders the context's main stream behind the copy without a host synchronisation; the handle then behaves like jolt_rows_upload's. */
+ * returns at once, _wait blocks the host until the copy has landed (begun a proof earlier, it has); the handle then behaves like jolt_rows_upload's. */
 int32_t jolt_rows_upload_begin(jolt_ctx *ctx, const void *rows, size_t n_rows, size_t row_bytes, jolt_rows **out);
 int32_t jolt_rows_upload_wait(jolt_ctx *ctx, jolt_rows *rows);
 /* Page-locked host memory for the row buffer the tracer fills (the Vec<CycleRow> of crates/jolt-host/src/program.rs's trace output, packed): jolt_rows_upload

@@ -132,8 +132,7 @@ struct jolt_rows {
     jolt_ctx* ctx = nullptr;
     uint8_t* data = nullptr;  // device, n_rows * row_bytes
     size_t n_rows = 0, row_bytes = 0;
-    hipEvent_t ready = nullptr;  // jolt_rows_upload_begin: recorded behind the copy on the context's copy stream; jolt_rows_upload_wait makes the main stream wait for it
-    bool pending = false;
+    bool pending = false;  // jolt_rows_upload_begin's copy has not been waited for yet (jolt_rows_upload_wait synchronises the host with the copy stream)
 };
 
 namespace {
@@ -294,8 +293,8 @@ extern "C" int32_t jolt_rows_upload(jolt_ctx* ctx, const void* rows, size_t n_ro
 }
 // The same copy IN FLIGHT while the context works on something else -- the next proof's witness moving over the link under the current proof's kernels (round 5).
 // `rows` must be page-locked (jolt_host_pinned_alloc) and stay untouched until jolt_rows_upload_wait returned.  begin: the device block comes from the pool, whose
-// reuse is ordered on the MAIN stream, so the copy stream first waits for the main stream's position at this call, then copies, then records `ready`.  wait: the main
-// stream waits for `ready` (no host synchronisation); from then on the handle is what jolt_rows_upload returns.
+// reuse is ordered on the MAIN stream, so the copy stream first waits for the main stream's position at this call, then copies.  wait: the host synchronises with the
+// copy stream (the copy was begun a proof ago: nothing to wait for in practice); from then on the handle is what jolt_rows_upload returns.
 extern "C" int32_t jolt_rows_upload_begin(jolt_ctx* ctx, const void* rows, size_t n_rows, size_t row_bytes, jolt_rows** out) {
     if (!ctx || !rows || !out || n_rows == 0 || row_bytes == 0) return JOLT_ERR_INVALID_ARG;
     if (!ctx->copy_stream) {
@@ -309,16 +308,17 @@ extern "C" int32_t jolt_rows_upload_begin(jolt_ctx* ctx, const void* rows, size_
     r->row_bytes = row_bytes;
     int32_t st = jolt_internal_dev_alloc(ctx, n_rows * row_bytes, (void**)&r->data);
     if (st != JOLT_OK) { delete r; return st; }
-    hipError_t e = hipEventCreateWithFlags(&r->ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev_copy_fork, ctx->stream);
+    // NOTHING is enqueued behind the copy on the copy stream (no event record): the runtime multiplexes its streams onto four hardware queues, and a marker that waits
+    // for the copy's completion blocks every later packet of whichever stream shares that queue -- with the main stream on it, the next proof's first kernels waited
+    // out the whole copy (prepare 2.7 -> 20.3 ms, profiles/r05_witness_upload_overlap.txt).  _wait synchronises the HOST with the copy stream instead; by then the
+    // copy has long landed.
+    hipError_t e = hipEventRecord(ctx->ev_copy_fork, ctx->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_copy_fork, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(r->data, rows, n_rows * row_bytes, hipMemcpyHostToDevice, ctx->copy_stream);
-    if (e == hipSuccess) e = hipEventRecord(r->ready, ctx->copy_stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(ctx->copy_stream);
         ctx->last_error = std::string("rows upload (begin): ") + hipGetErrorString(e);
-        if (r->ready) (void)hipEventDestroy(r->ready);
         jolt_internal_dev_free(ctx, r->data);
         delete r;
         return JOLT_ERR_HIP;
@@ -330,7 +330,7 @@ extern "C" int32_t jolt_rows_upload_begin(jolt_ctx* ctx, const void* rows, size_
 extern "C" int32_t jolt_rows_upload_wait(jolt_ctx* ctx, jolt_rows* r) {
     if (!ctx || !r) return JOLT_ERR_INVALID_ARG;
     if (!r->pending) return JOLT_OK;
-    JOLT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, r->ready, 0));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));  // host-side: the copy was begun a proof ago
     r->pending = false;
     return JOLT_OK;
 }
@@ -360,10 +360,7 @@ extern "C" int32_t jolt_rows_free(jolt_ctx* ctx, jolt_rows* r) {
     if (ctx && r->ctx && ctx != r->ctx) return JOLT_ERR_INVALID_ARG;  // the block belongs to the pool of the context that uploaded it
     jolt_ctx* c = r->ctx ? r->ctx : ctx;
     if (c) { (void)jolt_internal_engine_quiesce(c); (void)hipStreamSynchronize(c->stream); }
-    if (r->ready) {  // a copy that was begun and never waited for still writes the block: let it finish before the block goes back to the pool
-        (void)hipEventSynchronize(r->ready);
-        (void)hipEventDestroy(r->ready);
-    }
+    if (r->pending && c && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);  // a copy that was begun and never waited for still writes the block
     if (r->data) { if (c) jolt_internal_dev_free(c, r->data); else (void)hipFree(r->data); }
     delete r;
     return JOLT_OK;

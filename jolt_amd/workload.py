@@ -451,14 +451,25 @@ class DeviceWorkload:
                 self._packed = self._pinned.array
             else:
                 self._packed = rows
+        import os, time
+        trace = os.environ.get("JOLT_TRACE_UPLOAD") == "1"
+        marks = []
+
+        def mark(what):
+            if trace:
+                self.ctx.synchronize()
+                marks.append((what, time.perf_counter()))
+        mark("start")
         if self.prepared:
             self.release()  # the members of the previous proof borrow the columns that are replaced here
+        mark("release")
         if self.witness_overlapped:
             rows = self._rows_in_flight if self._rows_in_flight is not None else self.ffi.Rows.begin(self.ctx, self._packed)  # (the first proof has nothing ahead of it)
             self._rows_in_flight = None
             rows.wait()
         else:
             rows = self.ffi.Rows(self.ctx, self._packed)
+        mark("rows ready")
         int_fields = [f for f in self._fields if f[0] == "int"]
         extracted = rows.ints_many([(off, width, self.tables_spec[name].kind == "i64") for _, name, off, width in int_fields])  # every integer column in one pass over the rows
         for (_, name, _, _), new in zip(int_fields, extracted):
@@ -472,9 +483,15 @@ class DeviceWorkload:
                 new = rows.onehot(off, width, [k * log_k for k in range(n)], log_k, valid_offset=off + width)
                 self.sources[i].free()
                 self.sources[i] = new
+        mark("extracted")
         rows.free()
+        mark("rows freed")
         if self.witness_overlapped:  # the next proof's witness starts moving now, under this proof's kernels
             self._rows_in_flight = self.ffi.Rows.begin(self.ctx, self._packed)
+        mark("next begun")
+        if trace:
+            import sys
+            print("[upload trace] " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.2f}" for a, b in zip(marks, marks[1:])), file=sys.stderr)
 
     def witness_bytes_per_cycle(self):
         if getattr(self, "_packed", None) is None:

@@ -8,7 +8,7 @@ import re
 import sqlite3
 import sys
 
-BUCKET = ("k_fx_buckets_ordered", "k_fx_heavy_segments", "k_msm_buckets_light", "k_msm_buckets_heavy")
+BUCKET = ("k_fx_buckets_ordered", "k_fx_buckets_ordered_staged", "k_fx_heavy_segments", "k_fx_heavy_segments_staged", "k_msm_buckets_light", "k_msm_buckets_heavy")
 
 
 def short(name):
