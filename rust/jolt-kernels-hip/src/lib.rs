@@ -40,7 +40,7 @@ pub use msm::{msm_cache_clear, msm_cache_evict, msm_g1, HipShardedOpening, HipSr
 pub use ops::{HipHotIndices, HipInts, HipKeyIndex, HipReadRaf, HipRegistersRw, HipRwMatrix, RwRow, SpartanSums};
 pub use backend::{mi355x, with_relation, HipCommitWitness, HipUniskip, Mi355xParts, NodeWeights};
 pub use pcs::{HipHyperKzg, HipHyperKzgSetup, HipPoly};
-pub use rows::{HipPinnedRows, HipRows};
+pub use rows::{HipPinnedRows, HipRows, HipRowsInFlight};
 pub use scheduler::{HipBuildRoundScheduler, HipRoundScheduler};
 pub use status::HipError;
 pub use streaming::{HipOneHotChunk, HipOneHotStream, HipPartialCommitment};

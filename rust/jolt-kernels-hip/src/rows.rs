@@ -88,8 +88,40 @@ impl HipRows {
         check(unsafe { ffi::jolt_rows_upload(ctx.raw, bytes.as_ptr().cast(), n_rows, row_bytes, &mut raw) }, ctx.raw)?;
         Ok(Self { ctx: Arc::clone(ctx), raw, n_rows, row_bytes })
     }
+    /// The copy IN FLIGHT beside whatever the context does next (`jolt_rows_upload_begin`): the NEXT proof's rows cross the link under the current proof's kernels.
+    /// The buffer is borrowed until the returned [`HipRowsInFlight`] is waited for (or dropped): the tracer cannot refill it before that, which is what the
+    /// lifetime says.
+    pub fn begin<'a>(ctx: &Arc<HipContext>, rows: &'a HipPinnedRows) -> Result<HipRowsInFlight<'a>, HipError> {
+        let bytes = rows.as_slice();
+        let row_bytes = rows.row_bytes();
+        if row_bytes == 0 || bytes.is_empty() || bytes.len() % row_bytes != 0 {
+            return Err(HipError::size_mismatch("row buffer is not a whole number of rows"));
+        }
+        let n_rows = bytes.len() / row_bytes;
+        let mut raw = ptr::null_mut();
+        // SAFETY: `bytes` is page-locked (HipPinnedRows), holds n_rows * row_bytes bytes and stays borrowed -- hence unchanged and alive -- until the wait.
+        check(unsafe { ffi::jolt_rows_upload_begin(ctx.raw, bytes.as_ptr().cast(), n_rows, row_bytes, &mut raw) }, ctx.raw)?;
+        Ok(HipRowsInFlight { rows: Some(Self { ctx: Arc::clone(ctx), raw, n_rows, row_bytes }), _source: std::marker::PhantomData })
+    }
     pub fn n_rows(&self) -> usize {
         self.n_rows
+    }
+    /// Every integer field of `fields` (`(offset, width, signed)`) as a compact integer column, all of them in ONE pass over the rows
+    /// (`jolt_ints_from_rows_many`: whole rows staged in LDS) -- what a proof's witness hand-over calls instead of [`HipRows::ints`] per field.
+    pub fn ints_many(&self, fields: &[(usize, u32, bool)]) -> Result<Vec<HipInts>, HipError> {
+        for &(offset, width, _) in fields {
+            self.field_ok(offset, width)?;
+        }
+        let offsets: Vec<usize> = fields.iter().map(|f| f.0).collect();
+        let widths: Vec<u32> = fields.iter().map(|f| f.1).collect();
+        let signed: Vec<i32> = fields.iter().map(|f| i32::from(f.2)).collect();
+        let mut raws: Vec<*mut ffi::jolt_ints> = vec![ptr::null_mut(); fields.len()];
+        // SAFETY: live handles of one context; the four arrays hold `fields.len()` entries each; on failure the library has released what it had created.
+        check(
+            unsafe { ffi::jolt_ints_from_rows_many(self.ctx.raw, self.raw, offsets.as_ptr(), widths.as_ptr(), signed.as_ptr(), fields.len(), raws.as_mut_ptr()) },
+            self.ctx.raw,
+        )?;
+        Ok(raws.into_iter().map(|raw| HipInts::from_raw(&self.ctx, raw)).collect())
     }
     fn field_ok(&self, offset: usize, width: u32) -> Result<(), HipError> {
         if matches!(width, 1 | 2 | 4 | 8) && (width as usize) <= self.row_bytes && offset <= self.row_bytes - width as usize {
@@ -137,3 +169,20 @@ impl Drop for HipRows {
         let _ = unsafe { ffi::jolt_rows_free(self.ctx.raw, self.raw) };
     }
 }
+
+/// Rows whose host-to-device copy was begun and not yet waited for; borrows the page-locked source for as long as the copy may read it.
+pub struct HipRowsInFlight<'a> {
+    rows: Option<HipRows>,
+    _source: std::marker::PhantomData<&'a HipPinnedRows>,
+}
+
+impl HipRowsInFlight<'_> {
+    /// Blocks the host until the copy has landed (begun a proof earlier, it has) and hands the rows over (`jolt_rows_upload_wait`).
+    pub fn wait(mut self) -> Result<HipRows, HipError> {
+        let rows = self.rows.take().ok_or_else(|| HipError::size_mismatch("rows already taken"))?;
+        // SAFETY: live handles of one context.
+        check(unsafe { ffi::jolt_rows_upload_wait(rows.ctx.raw, rows.raw) }, rows.ctx.raw)?;
+        Ok(rows)
+    }
+}
+// Dropping a `HipRowsInFlight` that was never waited for drops its `HipRows`: `jolt_rows_free` lets the copy finish before the block goes back to the pool.
