@@ -109,13 +109,12 @@ class Collective:
 
 
 def _system_rccl_path():
-    """The RCCL that lives next to the HIP runtime libjolt_hip.so itself uses.
+    """The librccl the native communicator opens when the process holds none yet (comm.hip: rccl_api): the system one next to the HIP runtime libjolt_hip.so uses.
 
-    libjolt_hip.so is linked against the system libamdhip64 (under $ROCM_PATH), torch ships its own copy of the HIP and HSA runtimes
-    with a different SONAME, so a process that imports torch holds TWO runtimes.  The context's stream and buffers belong to the
-    system runtime; handing them to torch's bundled librccl (linked against torch's runtime) would cross runtimes.  The native
-    communicator therefore opens the system librccl by ABSOLUTE path (a bare "librccl.so.1" would be de-duplicated by SONAME to
-    the copy torch mapped).  JOLT_RCCL_PATH overrides."""
+    Round 5: an RCCL that is ALREADY in the process wins -- in a process that imported torch first (bench.py --gpus N) both libjolt_hip.so and torch resolve
+    libamdhip64.so.7 to torch's bundled copy (same SONAME), torch's librccl is loaded with it, and loading the system librccl beside it would bring a second rocm_smi
+    whose globals interpose with the first's (the round-4 teardown abort, profiles/r05_teardown_abort_backtrace.txt).  A process with TWO HIP runtimes (torch imported
+    after libjolt_hip.so was loaded) gets no native communicator at all.  JOLT_RCCL_PATH overrides the path of the fallback."""
     env = os.environ.get("JOLT_RCCL_PATH")
     if env:
         return env
@@ -140,7 +139,7 @@ class NativeCollective:
     """RCCL communicator owned by libjolt_hip.so (jolt_comm_*): rank 0 draws the ncclUniqueId, torch.distributed
     broadcasts it, every rank joins.  The round loop then calls RCCL without going through Python.
 
-    Which RCCL: the system one next to the HIP runtime the context lives in (`_system_rccl_path`), never torch's bundled copy.
+    Which RCCL: the one the process already holds (torch's bundled copy in a process that imported torch), else the system one (`_system_rccl_path`); comm.hip decides.
     ShardedWorkload falls back to the torch.distributed collective (collectively, on every rank) when the native communicator
     cannot be created."""
 
@@ -565,7 +564,7 @@ class ShardedWorkload:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if not same:
                     err = "probe all-gather mismatch"
-            self.communicator_note = "native RCCL communicator (jolt_comm_*, system librccl, %d rank(s))" % world
+            self.communicator_note = "native RCCL communicator (jolt_comm_*: the librccl the process already holds -- torch's when torch is imported -- else the system one; %d rank(s))" % world
             if int(ok.item()) == 1:
                 coll = native
             else:
