@@ -377,6 +377,8 @@ int32_t jolt_host_transcript_destroy(jolt_host_transcript *t);
  * (crates/jolt-crypto/src/ec/bn254/mod.rs:139-171) */
 int32_t jolt_host_g1_add(const jolt_g1_t *p, const jolt_g1_t *q, jolt_g1_t *out);
 int32_t jolt_host_g1_eq(const jolt_g1_t *p, const jolt_g1_t *q, int32_t *equal);
+/* canonical coordinates on y^2 = x^3 + 3 (Jacobian: Y^2 = X^3 + 3 Z^6) or the identity: the check applied to points supplied by the caller (known level commitments) */
+int32_t jolt_host_g1_is_on_curve(const jolt_g1_t *p, int32_t *on_curve);
 int32_t jolt_host_g1_serialize_compressed(const jolt_g1_t *p, uint8_t out[32]);
 
 /* jolt_sumcheck::prove_batch (crates/jolt-sumcheck/src/prover.rs:193-362) over device members with the

@@ -789,6 +789,15 @@ extern "C" int32_t jolt_host_g1_add(const jolt_g1_t* p, const jolt_g1_t* q, jolt
     std::memcpy(out, &r, sizeof(r));
     return JOLT_OK;
 }
+// is `p` a point of BN254 G1 in the ABI's representation: canonical Montgomery coordinates with Y^2 = X^3 + 3 Z^6, or the identity (Z = 0)?  What every point a caller
+// hands in must satisfy before it is absorbed (jolt_host_hyperkzg_open_with_levels); G1 has cofactor 1, so on the curve is in the group.
+extern "C" int32_t jolt_host_g1_is_on_curve(const jolt_g1_t* p, int32_t* on_curve) {
+    if (!p || !on_curve) return JOLT_ERR_INVALID_ARG;
+    G1Jac a;
+    std::memcpy(&a, p, sizeof(a));
+    *on_curve = g1_is_on_curve(a) ? 1 : 0;
+    return JOLT_OK;
+}
 extern "C" int32_t jolt_host_g1_eq(const jolt_g1_t* p, const jolt_g1_t* q, int32_t* equal) {
     if (!p || !q || !equal) return JOLT_ERR_INVALID_ARG;
     G1Jac a, b;

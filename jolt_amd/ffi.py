@@ -882,6 +882,12 @@ def host_g1_add(p, q):
     return o[0]
 
 
+def host_g1_is_on_curve(p):
+    e = C.c_int32()
+    _ck(lib().jolt_host_g1_is_on_curve(_p(np.ascontiguousarray(p, dtype=np.uint64)), C.byref(e)), "jolt_host_g1_is_on_curve")
+    return bool(e.value)
+
+
 def host_g1_eq(p, q):
     e = C.c_int32()
     _ck(lib().jolt_host_g1_eq(_p(np.ascontiguousarray(p, dtype=np.uint64)), _p(np.ascontiguousarray(q, dtype=np.uint64)), C.byref(e)), "jolt_host_g1_eq")

@@ -253,6 +253,7 @@ extern "C" {
     pub fn jolt_host_transcript_destroy(t: *mut jolt_host_transcript) -> i32;
     pub fn jolt_host_g1_add(p: *const jolt_g1_t, q: *const jolt_g1_t, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_g1_eq(p: *const jolt_g1_t, q: *const jolt_g1_t, equal: *mut i32) -> i32;
+    pub fn jolt_host_g1_is_on_curve(p: *const jolt_g1_t, on_curve: *mut i32) -> i32;
     pub fn jolt_host_g1_serialize_compressed(p: *const jolt_g1_t, out: *mut u8) -> i32;
     pub fn jolt_host_prove_batch(ctx: *mut jolt_ctx, members: *const *mut jolt_member, n_members: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, offsets: *const usize, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, use_round_group: i32, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_batch_begin(ctx: *mut jolt_ctx, n_members: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, rounds: *const usize, offsets: *const usize, kinds: *const i32, degrees: *const u32, split_eq_points: *const *const jolt_fr_t, split_eq_scales: *const jolt_fr_t, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, out: *mut *mut jolt_batch) -> i32;

@@ -273,6 +273,37 @@ def test_trait_bound_audit_catches_the_round_4_gap(tmp_path):
     assert any("thiserror" in f for f in found), found
 
 
+def test_host_on_curve_check_accepts_group_elements_and_refuses_everything_else():
+    """g1_is_on_curve (g1.hip.h) through jolt_host_g1_is_on_curve: what jolt_host_hyperkzg_open_with_levels applies to the level commitments a caller supplies.  Oracle
+    points in their many projective representations (scalar multiples, sums, doublings, P + (-P) = the identity) pass; a flipped bit in any coordinate, a coordinate
+    that is not reduced mod q and the affine 'infinity' (0, 0, 1) do not."""
+    import oracle_lib as O
+    from jolt_amd import ffi
+    g = O.g1_generator()
+    pts = [g, O.g1_identity(), O.g1_double(g), O.g1_neg(g)]
+    rng = np.random.default_rng(5)
+    for k in range(12):
+        s = O.to_mont([int(rng.integers(1, 2**62)) * (1 + k)])[0]
+        p = O.g1_scalar_mul(g, s)
+        pts += [p, O.g1_add(p, pts[k % len(pts)]), O.g1_double(p)]
+    pts.append(O.g1_add(pts[5], O.g1_neg(pts[5])))
+    for p in pts:
+        assert ffi.host_g1_is_on_curve(np.asarray(p, dtype=np.uint64)), p
+    for p in pts[4:16]:
+        q = np.asarray(p, dtype=np.uint64).copy()
+        if O.g1_is_identity(q):
+            continue
+        for limb in (0, 5, 9):  # one bit in X, Y, Z
+            bad = q.copy()
+            bad[limb] ^= np.uint64(1 << 7)
+            assert not ffi.host_g1_is_on_curve(bad), (limb, p)
+        unreduced = q.copy()
+        unreduced[0:4] = np.uint64(2**64 - 1)  # X >= q
+        assert not ffi.host_g1_is_on_curve(unreduced)
+    one_q = np.asarray(g, dtype=np.uint64)[0:4]
+    assert not ffi.host_g1_is_on_curve(np.concatenate([np.zeros(8, dtype=np.uint64), one_q]))  # (0, 0, 1): 0 != 3
+
+
 def test_integration_doc_lists_the_sources_the_build_compiles():
     """INTEGRATION.md section 4 names exactly jolt_amd/build.py:SOURCES (round-1 review: the list had gone stale)"""
     import re
