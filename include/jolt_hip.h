@@ -335,6 +335,9 @@ int32_t jolt_host_g1_sum_limb_form(const uint64_t *points, const uint8_t *negate
 /* The signed-digit recoding of the fixed-base MSM for one scalar (negation above r / 2, c-bit signed windows, unsigned top window), built for
  * the host: keys_out[w] = |digit_w| | sign << 31 for w < ceil(253 / c); *buckets_out = the bucket count of a table set with this c. */
 int32_t jolt_host_fx_digits(const jolt_fr_t *scalar, uint32_t window_bits, uint32_t *keys_out, uint32_t *n_windows_out, uint32_t *buckets_out);
+/* ... and the size of the REGION the capacity sort gives segment `segment` (256 buckets) of an n-term MSM over uniform scalars: expected digits + 8 standard deviations + 64
+ * (msm_fixed.hip section 2d; the sort falls back to exact offsets on the device when a region overflows).  Host code, for the CPU suite. */
+int32_t jolt_host_fx_segment_capacity(uint64_t n, uint32_t window_bits, uint32_t segment, uint32_t *capacity);
 /* UnivariatePoly::from_evals / evaluate (crates/jolt-poly/src/univariate.rs:198-202) */
 int32_t jolt_host_univariate_from_evals(const jolt_fr_t *evals, size_t n, jolt_fr_t *coeffs_out);
 int32_t jolt_host_univariate_evaluate(const jolt_fr_t *coeffs, size_t n, const jolt_fr_t *x, jolt_fr_t *out);

@@ -129,9 +129,10 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist(const uint32_t* __restri
 }
 // exclusive scan of the nb1 segment counts (one workgroup); info[0] = largest segment, info[1] = non-zero digits in total
 __global__ __launch_bounds__(kSortBlock) void k_fx_scan(const uint32_t* __restrict__ hist1, uint32_t nb1, uint32_t* __restrict__ offs1, uint32_t* __restrict__ cursor1,
-                                                       uint32_t* __restrict__ info) {
+                                                       uint32_t* __restrict__ info, const uint32_t* __restrict__ run_if = nullptr) {
     __shared__ uint32_t sm[kSortBlock];
     __shared__ uint32_t smax[kSortBlock];
+    if (run_if && *run_if == 0) return;
     const uint32_t per = (nb1 + kSortBlock - 1) / kSortBlock;
     const uint32_t lo = min(threadIdx.x * per, nb1), hi = min(lo + per, nb1);
     uint32_t local = 0, mx = 0;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_scan(const uint32_t* __restri
         cursor1[k] = run;
         run += hist1[k];
     }
-    if (threadIdx.x == kSortBlock - 1) { info[0] = smax[threadIdx.x]; info[1] = sm[threadIdx.x]; }
+    if (threadIdx.x == kSortBlock - 1) { info[0] = smax[threadIdx.x]; info[1] = sm[threadIdx.x]; info[3] = 0; }  // info[3]: the entries a capacity sort counted (0: info[1] is the count)
 }
 // entries[pos] = (low bits of |digit|) << 32 | (w * stride + i) | sign << 31, grouped by segment
 template <int LO>
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_groups(const uint
     }
 }
 // group_cursor[g] = offset of the group's first segment
-__global__ __launch_bounds__(kPartBins) void k_fx_group_cursors(const uint32_t* __restrict__ offs1, uint32_t n_groups, uint32_t* __restrict__ group_cursor) {
+__global__ __launch_bounds__(kPartBins) void k_fx_group_cursors(const uint32_t* __restrict__ offs1, uint32_t n_groups, uint32_t* __restrict__ group_cursor,
+                                                               const uint32_t* __restrict__ run_if = nullptr) {
+    if (run_if && *run_if == 0) return;
     if (threadIdx.x < n_groups) group_cursor[threadIdx.x] = offs1[threadIdx.x << kGroupBits];
 }
 // pass 2: inside every group, by segment (cursor1[segment] starts at the segment's offset)
@@ -334,9 +337,13 @@ struct PartSharedN {
     uint64_t stage[THREADS * PER];
     uint32_t cnt[kPartBins], lstart[kPartBins], gbase[kPartBins], wsum[4];
 };
+// lim_a / lim_b (capacity regions, section 2d): bin b may be written up to position lim_a[b] (+ lim_b[b]); a tile that would cross it drops the bin's entries and raises
+// *overflow -- the exact passes then redo the sort.  lim_a == nullptr: exact offsets, nothing to check.
+constexpr uint32_t kFxDropped = 0xFFFFFFFFu;
 template <int PER, typename LOW, int THREADS = kPartThreads>
 __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh, const uint64_t (&item)[PER], const uint32_t (&bin)[PER], uint32_t nbins, uint32_t* __restrict__ cursors,
-                                                   uint32_t* __restrict__ out_val, LOW* __restrict__ out_low, int bin_shift, uint32_t bin_mask, uint32_t low_mask) {
+                                                   uint32_t* __restrict__ out_val, LOW* __restrict__ out_low, int bin_shift, uint32_t bin_mask, uint32_t low_mask,
+                                                   const uint32_t* __restrict__ lim_a = nullptr, const uint32_t* __restrict__ lim_b = nullptr, uint32_t* __restrict__ overflow = nullptr) {
     const uint32_t tid = threadIdx.x;
     if (tid < kPartBins) sh.cnt[tid] = 0;
     __syncthreads();
@@ -359,7 +366,15 @@ __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh
         uint32_t before = 0;
         for (uint32_t k = 0; k < (tid >> 6); ++k) before += sh.wsum[k];
         sh.lstart[tid] = before + incl - v;
-        sh.gbase[tid] = v ? atomicAdd(&cursors[tid], v) : 0u;
+        uint32_t g = v ? atomicAdd(&cursors[tid], v) : 0u;
+        if (lim_a && v) {
+            const uint32_t limit = lim_a[tid] + (lim_b ? lim_b[tid] : 0u);
+            if (g > limit || v > limit - g) {  // the region is full: nothing of this bin is written, the exact passes take over
+                g = kFxDropped;
+                atomicOr(overflow, 1u);
+            }
+        }
+        sh.gbase[tid] = g;
     }
     __syncthreads();
     const uint32_t valid = sh.lstart[kPartBins - 1] + sh.cnt[kPartBins - 1];
@@ -373,9 +388,12 @@ __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh
         if (j < valid) {
             const uint64_t it = sh.stage[j];
             const uint32_t hi = (uint32_t)(it >> 32), b = (hi >> bin_shift) & bin_mask;
-            const uint32_t pos = sh.gbase[b] + (j - sh.lstart[b]);
-            out_val[pos] = (uint32_t)it;
-            out_low[pos] = (LOW)(hi & low_mask);
+            const uint32_t gb = sh.gbase[b];
+            if (gb != kFxDropped) {
+                const uint32_t pos = gb + (j - sh.lstart[b]);
+                out_val[pos] = (uint32_t)it;
+                out_low[pos] = (LOW)(hi & low_mask);
+            }
         }
     }
     __syncthreads();
@@ -383,8 +401,10 @@ __device__ __forceinline__ void partition_tile_soa(PartSharedN<PER, THREADS>& sh
 
 // digits of one scalar straight into the per-workgroup segment histogram (no key array)
 template <int LO, int PERS = kPartPerS, bool PLAIN = true>
-__global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t nb1, uint32_t* __restrict__ hist1) {
+__global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, uint32_t nb1, uint32_t* __restrict__ hist1,
+                                                               const uint32_t* __restrict__ run_if = nullptr) {
     extern __shared__ uint32_t fx_sh[];
+    if (run_if && *run_if == 0) return;  // the fallback of the capacity-region sort (section 2d): only when a region overflowed
     for (uint32_t b = threadIdx.x; b < nb1; b += kSortBlock) fx_sh[b] = 0;
     __syncthreads();
     const size_t per = (((n + gridDim.x - 1) / gridDim.x) + kSortBlock - 1) / kSortBlock * kSortBlock, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
@@ -419,9 +439,12 @@ __global__ __launch_bounds__(kSortBlock) void k_fx_hist_scalars(const Fr* __rest
 constexpr int kPartThreadsS = 1024;  // 1024 x 12 entries = 96 KiB of stage, one workgroup per CU: 3.7 ms per 2^26 terms; 512 threads (three per CU) measured 4.3 ms -- the runs per bin get too short
 template <int LO, int PERS = kPartPerS>
 __global__ __launch_bounds__(kPartThreadsS) void k_fx_partition_groups_scalars(const Fr* __restrict__ scalars, size_t n, int c, int W, size_t stride, uint32_t n_groups,
-                                                                             uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ out_val, uint16_t* __restrict__ out_low) {
+                                                                             uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ out_val, uint16_t* __restrict__ out_low,
+                                                                             const uint32_t* __restrict__ group_limit = nullptr, uint32_t* __restrict__ overflow = nullptr,
+                                                                             const uint32_t* __restrict__ run_if = nullptr) {
     extern __shared__ __align__(16) unsigned char fx_part_raw[];
     PartSharedN<PERS, kPartThreadsS>& sh = *reinterpret_cast<PartSharedN<PERS, kPartThreadsS>*>(fx_part_raw);
+    if (run_if && *run_if == 0) return;
     const size_t n_tiles = (n + kPartThreadsS - 1) / kPartThreadsS;
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const size_t i = t * kPartThreadsS + threadIdx.x;
@@ -437,23 +460,32 @@ __global__ __launch_bounds__(kPartThreadsS) void k_fx_partition_groups_scalars(c
             item[u] = mag ? ((uint64_t)mag << 32) | (uint32_t)((size_t)u * stride + i) | (key & 0x80000000u) : ~0ull;
             bin[u] = mag >> (LO + kGroupBits);
         }
-        partition_tile_soa<PERS, uint16_t, kPartThreadsS>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1);
+        partition_tile_soa<PERS, uint16_t, kPartThreadsS>(sh, item, bin, n_groups, group_cursor, out_val, out_low, LO + kGroupBits, 0xFFFFFFFFu, (1u << (LO + kGroupBits)) - 1,
+                                                          group_limit, nullptr, overflow);
     }
 }
 // pass 2: inside every group, by segment; low = |digit| mod 2^LO afterwards
 template <int LO>
 __global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments_soa(const uint32_t* __restrict__ g_val, const uint16_t* __restrict__ g_low, const uint32_t* __restrict__ offs1, uint32_t nb1,
                                                                            const uint32_t* __restrict__ info, uint32_t* __restrict__ cursor1, uint32_t* __restrict__ out_val,
-                                                                           uint8_t* __restrict__ out_low) {
+                                                                           uint8_t* __restrict__ out_low, const uint32_t* __restrict__ group_end = nullptr,
+                                                                           const uint32_t* __restrict__ group_limit = nullptr, const uint32_t* __restrict__ seg_cap = nullptr,
+                                                                           uint32_t* __restrict__ overflow = nullptr, const uint32_t* __restrict__ run_if = nullptr) {
     extern __shared__ __align__(16) unsigned char fx_part_raw[];
     PartSharedN<kPartPer>& sh = *reinterpret_cast<PartSharedN<kPartPer>*>(fx_part_raw);
     __shared__ uint32_t tiles_before[kPartBins + 1];
+    if (run_if && *run_if == 0) return;
     const uint32_t n_groups = (nb1 + kGroupBins - 1) >> kGroupBits;
     const uint32_t total = info[1];
+    // group_end (capacity regions): group g's entries are [offs1[first segment], group_end[g]) -- where pass 1's cursor stopped --, not up to the next group's start
+    auto group_hi = [&](uint32_t g) -> uint32_t {
+        if (group_end) return min(group_end[g], group_limit[g]);  // (a cursor that ran past its region: overflow, already flagged -- nothing beyond the region is read)
+        return ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+    };
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t g = 0; g < n_groups; ++g) {
-            const uint32_t lo = offs1[g << kGroupBits], hi = ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+            const uint32_t lo = offs1[g << kGroupBits], hi = max(group_hi(g), lo);
             tiles_before[g] = run;
             run += (hi - lo + kPartTile - 1) / kPartTile;
         }
@@ -468,7 +500,7 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments_soa(cons
             if (tiles_before[mid] <= t) g_lo = mid; else g_hi = mid;
         }
         const uint32_t g = g_lo;
-        const uint32_t lo = offs1[g << kGroupBits], hi = ((g + 1) << kGroupBits) < nb1 ? offs1[(g + 1) << kGroupBits] : total;
+        const uint32_t lo = offs1[g << kGroupBits], hi = max(group_hi(g), lo);
         const uint32_t first = lo + (t - tiles_before[g]) * kPartTile;
         const uint32_t nbins = min((uint32_t)kGroupBins, nb1 - (g << kGroupBits));
         uint64_t item[kPartPer];
@@ -480,8 +512,64 @@ __global__ __launch_bounds__(kPartThreads) void k_fx_partition_segments_soa(cons
             item[u] = k < hi ? ((uint64_t)low << 32) | g_val[k] : ~0ull;
             bin[u] = (low >> LO) & (kGroupBins - 1);
         }
-        partition_tile_soa<kPartPer, uint8_t>(sh, item, bin, nbins, cursor1 + (g << kGroupBits), out_val, out_low, LO, kGroupBins - 1, (1u << LO) - 1);
+        partition_tile_soa<kPartPer, uint8_t>(sh, item, bin, nbins, cursor1 + (g << kGroupBits), out_val, out_low, LO, kGroupBins - 1, (1u << LO) - 1,
+                                              seg_cap ? offs1 + (g << kGroupBits) : nullptr, seg_cap ? seg_cap + (g << kGroupBits) : nullptr, overflow);
     }
+}
+
+// ---- 2d. the same sort WITHOUT the histogram pass, for scalars the caller knows to be uniform field elements (round 5; JOLT_FX_CAPACITY=0 switches it off) ----------
+// The histogram pass exists to give every segment its exact place; for uniform scalars the digit counts are predictable -- a bucket below 2^(c-1) collects the signed
+// digits of W - 1 windows (2 (W - 1) n / 2^c on average) and, up to top_max, the unsigned top window (n / top_max) -- so every segment gets a REGION of its expected size
+// plus 8 standard deviations and 64 entries, the two partition passes run straight from the cursors of those regions, the counts fall out of the cursors afterwards, and
+// 1.65 ms of digit recomputation per 2^26-term MSM is not spent.  Nothing depends on the scalars BEING uniform: a pass that would cross a region's end drops the bin,
+// raises a flag in device memory, and the exact passes (histogram, scan, both partitions) -- enqueued behind every capacity sort, returning at once while the flag is
+// clear -- redo the sort.  No host round trip either way.
+struct FxCapModel {
+    double n, p_signed, p_top;   // terms; per-bucket probability of a signed lower-window digit / of the top window's digit
+    uint32_t half, top_max;      // 2^(c-1); the top window's digits are < top_max
+};
+JOLT_HD uint32_t fx_segment_capacity(const FxCapModel& m, uint32_t seg, uint32_t seg_buckets) {
+    const uint64_t lo = (uint64_t)seg * seg_buckets, hi = lo + seg_buckets;  // buckets [lo, hi)
+    const uint64_t below_half = lo < m.half ? (hi < m.half ? hi : m.half) - lo : 0, below_top = lo < m.top_max ? (hi < m.top_max ? hi : m.top_max) - lo : 0;
+    const bool has_half = lo <= m.half && m.half < hi;  // |digit| = 2^(c-1) itself: one of the two signs only
+    const double mean = m.n * ((double)below_half * m.p_signed + (has_half ? 0.5 * m.p_signed : 0.0) + (double)below_top * m.p_top);
+    double root = 0.0;
+    if (mean > 0.0) {  // integer square root by Newton steps: the host and the device must agree to the last entry
+        root = mean > 1.0 ? mean : 1.0;
+        for (int k = 0; k < 40; ++k) root = 0.5 * (root + mean / root);
+    }
+    const uint64_t cap = (uint64_t)(mean + 8.0 * root) + 64;
+    return (uint32_t)((cap + 3) & ~(uint64_t)3);
+}
+// hist1[seg] = the region size of segment seg (k_fx_scan then turns them into offs1 / cursor1 / info[1] like counts); info[2] = the overflow flag, cleared
+__global__ __launch_bounds__(kBlock) void k_fx_capacity_regions(FxCapModel m, uint32_t nb1, uint32_t seg_buckets, uint32_t* __restrict__ hist1, uint32_t* __restrict__ info) {
+    const uint32_t seg = blockIdx.x * kBlock + threadIdx.x;
+    if (seg == 0) info[2] = 0;
+    if (seg < nb1) hist1[seg] = fx_segment_capacity(m, seg, seg_buckets);
+}
+// group_cursor[g] = start of the group's first region, group_limit[g] = end of its last
+__global__ __launch_bounds__(kPartBins) void k_fx_group_regions(const uint32_t* __restrict__ offs1, const uint32_t* __restrict__ cap, uint32_t nb1, uint32_t n_groups,
+                                                               uint32_t* __restrict__ group_cursor, uint32_t* __restrict__ group_limit) {
+    const uint32_t g = threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t last = min(((g + 1) << kGroupBits), nb1) - 1;
+    group_cursor[g] = offs1[g << kGroupBits];
+    group_limit[g] = offs1[last] + cap[last];
+}
+// after the two passes: hist1[seg] = entries the segment received (its region size until now); a cursor beyond its region is an overflow the passes already flagged
+__global__ __launch_bounds__(kBlock) void k_fx_counts_from_cursors(const uint32_t* __restrict__ offs1, const uint32_t* __restrict__ cursor1, uint32_t nb1, uint32_t* __restrict__ hist1,
+                                                                  uint32_t* __restrict__ info) {
+    const uint32_t seg = blockIdx.x * kBlock + threadIdx.x;
+    if (seg >= nb1) return;
+    const uint32_t cap = hist1[seg], got = cursor1[seg] - offs1[seg];
+    if (got > cap) atomicOr(&info[2], 1u);
+    hist1[seg] = got > cap ? 0u : got;
+    if (got && got <= cap) atomicAdd(&info[3], got);  // the sort's true size (info[1] holds the regions' total): what jolt_msm_profile_buckets_last reports
+}
+__global__ __launch_bounds__(kBlock) void k_fx_clear_if(uint32_t* __restrict__ words, uint32_t count, const uint32_t* __restrict__ run_if) {
+    if (*run_if == 0) return;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) words[i] = 0;
 }
 
 // ---- 3. one workgroup per segment: counting sort by the low bits in LDS; emits the bucket table of the shared bucket kernels ----
@@ -965,6 +1053,31 @@ constexpr size_t kMsmHostEntries = 128;
 // pair_shift > 0: TWO MSMs over the same scalars, sum_i s_i P_i and sum_i s_i P_(i + pair_shift): the digits, and with them the whole sort, are the scalars' alone,
 // so the second MSM is one more pass of bucket sums and reduction over the same sorted lists with the table pointer moved by pair_shift points (the witness
 // commitments at r and -r of a HyperKZG opening are such a pair: hyperkzg.hip).  n + pair_shift must not exceed the tables' point count.
+// the digit model of n uniform scalars under c-bit signed windows with an unsigned top window (section 2d); false when the top window does not fit the model
+static bool fx_capacity_model(size_t n, int c, int W, FxCapModel* m) {
+    const int top_shift = c * (W - 1) + 1;  // the top window's range: ((r - 1) / 2) >> (c (W - 1)), as jolt_host_fx_digits computes it
+    if (254 - top_shift > 31 || top_shift < 1) return false;
+    auto limb32 = [](int j) -> uint64_t { return j < 8 ? (uint64_t)(uint32_t)FrParams::P[j] : 0ull; };
+    const uint64_t top_max = ((limb32(top_shift >> 5) | (limb32((top_shift >> 5) + 1) << 32)) >> (top_shift & 31)) + 1;
+    if (top_max == 0 || top_max > 0xFFFFFFFFull) return false;
+    m->n = (double)n;
+    m->p_signed = 2.0 / (double)((uint64_t)1 << c) * (double)(W - 1);
+    m->p_top = 1.0 / (double)top_max;
+    m->half = 1u << (c - 1);
+    m->top_max = (uint32_t)top_max;
+    return true;
+}
+// the region a segment of 256 buckets gets in the capacity sort of an n-term MSM with window_bits-bit windows: pinned in the CPU suite against the digit histogram of
+// uniform scalars (no region may be smaller than what the digits of real scalars put there, and the regions together stay within a few per cent of the entries)
+extern "C" int32_t jolt_host_fx_segment_capacity(uint64_t n, uint32_t window_bits, uint32_t segment, uint32_t* capacity) {
+    if (!capacity || window_bits < 2 || window_bits > 26) return JOLT_ERR_INVALID_ARG;
+    const int c = (int)window_bits, W = (253 + c - 1) / c;
+    FxCapModel m;
+    if (!fx_capacity_model((size_t)n, c, W, &m)) return JOLT_ERR_UNSUPPORTED;
+    *capacity = fx_segment_capacity(m, segment, 1u << fx_lo_bits(c));
+    return JOLT_OK;
+}
+
 int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, const Fr* d_scalars, size_t n, int lane, MsmJob* job, size_t pair_shift) {
     const int c = srs->pre_c, W = srs->pre_W;
     const int lo_bits = fx_lo_bits(c);
@@ -997,14 +1110,38 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const bool soa = ctx->msm_fx_soa && lo_bits == 8 && ctx->msm_fx_partition == 2 && (W <= kPartPerS || (W <= kPartPerWide && wide_soa)) &&
                      ((nb1 + kGroupBins - 1) >> kGroupBits) <= (uint32_t)kPartBins &&
                      (wide ? sizeof(PartSharedN<kPartPerWide, kPartThreadsS>) : sizeof(PartSharedN<kPartPerS, kPartThreadsS>)) + 2048 <= ctx->max_lds_per_block;
+    // capacity regions instead of a histogram pass (section 2d): scalars the caller marked as uniform field elements, the split-entry path, long enough to matter
+    static const bool capacity_on = !(std::getenv("JOLT_FX_CAPACITY") && std::atoi(std::getenv("JOLT_FX_CAPACITY")) == 0);
+    FxCapModel cap_model;
+    size_t cap_total = 0;
+    bool capacity = capacity_on && soa && ctx->msm_full_width_scalars && n >= ((size_t)1 << 16);
+    if (capacity) {
+        capacity = fx_capacity_model(n, c, W, &cap_model);
+        const uint64_t top_max = cap_model.top_max;
+        if (capacity) {
+            // the region sizes take a handful of distinct values (whole segments below 2^(c-1), below top_max, beyond both, and the boundary segments): evaluated once each;
+            // 8 entries per segment on top, should the device's arithmetic round a size differently (the device's own sizes are what the offsets come from)
+            uint64_t key_prev = ~0ull;
+            uint32_t cap_prev = 0;
+            for (uint32_t sgm = 0; sgm < nb1; ++sgm) {
+                const uint64_t lo = (uint64_t)sgm * kSegBuckets, hi = lo + kSegBuckets;
+                const uint64_t below_half = lo < cap_model.half ? std::min<uint64_t>(hi, cap_model.half) - lo : 0, below_top = lo < top_max ? std::min<uint64_t>(hi, top_max) - lo : 0;
+                const uint64_t key = below_half | (below_top << 20) | ((uint64_t)(lo <= cap_model.half && cap_model.half < hi) << 40);
+                if (key != key_prev) { cap_prev = fx_segment_capacity(cap_model, sgm, kSegBuckets); key_prev = key; }
+                cap_total += cap_prev + 8;
+            }
+            capacity = cap_total < ((size_t)1 << 32) - 4096;
+        }
+    }
+    const size_t span = capacity ? std::max(cap_total, total) : total;  // positions the sort's buffers are addressed with
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_keys = take(total * 4), o_entries = take(soa ? total * 5 + 512 : total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
+    const size_t o_keys = take(span * 4), o_entries = take(soa ? span * 5 + 512 : total * 8), o_hist = take((size_t)nb1 * 4), o_offs = take((size_t)nb1 * 4), o_cur = take((size_t)nb1 * 4),
                  o_info = take(256), o_buckets = take(n_buckets * sizeof(G1Jac)), o_part = take((size_t)nb * sizeof(G1Jac)), o_wsum = take(2 * sizeof(G1Jac)),
                  o_red = take(std::max<size_t>(red_points, 1) * sizeof(G1Jac)),
                  o_bhist = take(n_buckets * 4), o_boffs = take(n_buckets * 4), o_heavy = take((size_t)heavy_cap * 8), o_hcnt = take(256),
                  o_seg = take((size_t)heavy_cap * sizeof(G1Jac)), o_cls = take(kClasses * 4 * 2), o_order = take(n_buckets * 4),
-                 o_grouped = take(soa ? total * 6 + 512 : (ctx->msm_fx_partition == 2 ? total * 8 : 256)), o_gcur = take(kPartBins * 4);
+                 o_grouped = take(soa ? span * 6 + 512 : (ctx->msm_fx_partition == 2 ? total * 8 : 256)), o_gcur = take(kPartBins * 4), o_glim = take(kPartBins * 4);
     // a pair's second pass sums into its OWN bucket set and reduces through its own scratch, so that the first pass's reduction (latency bound: chains of additions on
     // a few thousand threads) runs on the auxiliary stream under the second pass's bucket sums instead of between the two
     const bool overlap_reduction = pair_shift != 0 && grid_reduce && ctx->msm_pair_overlap;
@@ -1036,6 +1173,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     uint32_t *class_hist = (uint32_t*)(ws + o_cls), *class_cursor = class_hist + kClasses, *order = (uint32_t*)(ws + o_order);
     uint64_t* grouped = (uint64_t*)(ws + o_grouped);
     uint32_t* group_cursor = (uint32_t*)(ws + o_gcur);
+    uint32_t* group_limit = (uint32_t*)(ws + o_glim);
     const uint32_t n_groups = (nb1 + kGroupBins - 1) >> kGroupBits;
     const size_t lds_bytes = (size_t)nb1 * sizeof(uint32_t);
     if (lds_bytes > ctx->max_lds_per_block) return JOLT_ERR_UNSUPPORTED;
@@ -1078,16 +1216,23 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
         JOLT_HIP_TRY(ctx, hipEventRecord(ctx->ev_phase[lane][0], st));
         JOLT_HIP_TRY(ctx, hipStreamWaitEvent(sst, ctx->ev_phase[lane][0], 0));
     }
-    JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, sst));
     const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock);
     const unsigned slices = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, total / 16384));
-    if (soa) {  // digits straight into the segment histogram: no key array
-        const unsigned hist_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, n / 4096));
-        static const bool plain_hist = !(std::getenv("JOLT_FX_HIST_PLAIN") && std::atoi(std::getenv("JOLT_FX_HIST_PLAIN")) == 0);
-        if (wide) hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerWide>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
-        else if (plain_hist) hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
-        else hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerS, false>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1);
+    const unsigned hist_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, n / 4096));
+    static const bool plain_hist = !(std::getenv("JOLT_FX_HIST_PLAIN") && std::atoi(std::getenv("JOLT_FX_HIST_PLAIN")) == 0);
+    // the exact histogram from the scalars (run_if != nullptr: the fallback behind a capacity sort, a no-op while that sort's overflow flag is clear)
+    auto hist_from_scalars = [&](const uint32_t* run_if) {
+        if (wide) hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerWide>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1, run_if);
+        else if (plain_hist) hipLaunchKernelGGL(k_fx_hist_scalars<8>, dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1, run_if);
+        else hipLaunchKernelGGL((k_fx_hist_scalars<8, kPartPerS, false>), dim3(hist_grid), dim3(kSortBlock), lds_bytes, sst, d_scalars, n, c, W, nb1, hist1, run_if);
+    };
+    if (capacity) {  // region sizes take the histogram's place; k_fx_scan below turns them into offsets and cursors like counts
+        hipLaunchKernelGGL(k_fx_capacity_regions, dim3((nb1 + kBlock - 1) / kBlock), dim3(kBlock), 0, sst, cap_model, nb1, kSegBuckets, hist1, info);
+    } else if (soa) {  // digits straight into the segment histogram: no key array
+        JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, sst));
+        hist_from_scalars(nullptr);
     } else {
+        JOLT_HIP_TRY(ctx, hipMemsetAsync(hist1, 0, (size_t)nb1 * 4, sst));
         hipLaunchKernelGGL(k_fx_digits, dim3(gn), dim3(kBlock), 0, sst, d_scalars, n, c, W, keys);
         if (lo_bits == 8) hipLaunchKernelGGL(k_fx_hist<8>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
         else hipLaunchKernelGGL(k_fx_hist<11>, dim3(slices), dim3(kSortBlock), lds_bytes, sst, (const uint32_t*)keys, total, nb1, hist1);
@@ -1101,20 +1246,40 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     const unsigned part_grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, (total + kPartTile - 1) / kPartTile));
     // split-entry arrays of the SoA path inside the two entry buffers
     uint32_t* g_val = (uint32_t*)grouped;
-    uint16_t* g_low = (uint16_t*)((char*)grouped + ((total * 4 + 255) & ~(size_t)255));
+    uint16_t* g_low = (uint16_t*)((char*)grouped + ((span * 4 + 255) & ~(size_t)255));
     uint32_t* s_val = (uint32_t*)entries;
-    uint8_t* s_low = (uint8_t*)((char*)entries + ((total * 4 + 255) & ~(size_t)255));
+    uint8_t* s_low = (uint8_t*)((char*)entries + ((span * 4 + 255) & ~(size_t)255));
     if (soa) {
-        hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
         const unsigned grid_s = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus, (n + kPartThreadsS - 1) / kPartThreadsS));
-        if (wide)
-            hipLaunchKernelGGL((k_fx_partition_groups_scalars<8, kPartPerWide>), dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerWide, kPartThreadsS>), sst, d_scalars, n, c, W,
-                               srs->pre_stride, n_groups, group_cursor, g_val, g_low);
-        else
-            hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerS, kPartThreadsS>), sst, d_scalars, n, c, W, srs->pre_stride, n_groups,
-                               group_cursor, g_val, g_low);
-        hipLaunchKernelGGL(k_fx_partition_segments_soa<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartSharedN<kPartPer>), sst, (const uint32_t*)g_val, (const uint16_t*)g_low,
-                           (const uint32_t*)offs1, nb1, (const uint32_t*)info, cur1, s_val, s_low);
+        // the two partition passes: over capacity regions (limits checked, overflow flagged) or over exact offsets (run_if: only when that flag is up)
+        auto partition_passes = [&](bool regions, const uint32_t* run_if) {
+            const uint32_t* glim = regions ? group_limit : nullptr;
+            uint32_t* flag = regions ? info + 2 : nullptr;
+            if (wide)
+                hipLaunchKernelGGL((k_fx_partition_groups_scalars<8, kPartPerWide>), dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerWide, kPartThreadsS>), sst, d_scalars, n, c, W,
+                                   srs->pre_stride, n_groups, group_cursor, g_val, g_low, glim, flag, run_if);
+            else
+                hipLaunchKernelGGL(k_fx_partition_groups_scalars<8>, dim3(grid_s), dim3(kPartThreadsS), sizeof(PartSharedN<kPartPerS, kPartThreadsS>), sst, d_scalars, n, c, W, srs->pre_stride,
+                                   n_groups, group_cursor, g_val, g_low, glim, flag, run_if);
+            hipLaunchKernelGGL(k_fx_partition_segments_soa<8>, dim3(part_grid), dim3(kPartThreads), sizeof(PartSharedN<kPartPer>), sst, (const uint32_t*)g_val, (const uint16_t*)g_low,
+                               (const uint32_t*)offs1, nb1, (const uint32_t*)info, cur1, s_val, s_low, regions ? (const uint32_t*)group_cursor : nullptr, glim,
+                               regions ? (const uint32_t*)hist1 : nullptr, flag, run_if);
+        };
+        if (capacity) {
+            hipLaunchKernelGGL(k_fx_group_regions, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, (const uint32_t*)hist1, nb1, n_groups, group_cursor, group_limit);
+            partition_passes(true, nullptr);
+            hipLaunchKernelGGL(k_fx_counts_from_cursors, dim3((nb1 + kBlock - 1) / kBlock), dim3(kBlock), 0, sst, (const uint32_t*)offs1, (const uint32_t*)cur1, nb1, hist1, info);
+            // the exact sort, enqueued behind it: every kernel returns at its first instruction unless a region overflowed
+            const uint32_t* flag = info + 2;
+            hipLaunchKernelGGL(k_fx_clear_if, dim3((nb1 + kBlock - 1) / kBlock), dim3(kBlock), 0, sst, hist1, nb1, flag);
+            hist_from_scalars(flag);
+            hipLaunchKernelGGL(k_fx_scan, dim3(1), dim3(kSortBlock), 0, sst, (const uint32_t*)hist1, nb1, offs1, cur1, info, flag);
+            hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor, flag);
+            partition_passes(false, flag);
+        } else {
+            hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
+            partition_passes(false, nullptr);
+        }
     } else if (two_pass) {
         hipLaunchKernelGGL(k_fx_group_cursors, dim3(1), dim3(kPartBins), 0, sst, (const uint32_t*)offs1, n_groups, group_cursor);
         if (lo_bits == 8) {
@@ -1304,8 +1469,8 @@ extern "C" int32_t jolt_msm_profile_buckets_last(jolt_ctx* ctx, float* ms, uint6
     if (!ctx->fx_profile_valid) { ctx->last_error = "no profiled fixed-base MSM since jolt_msm_profile_buckets"; return JOLT_ERR_INVALID_ARG; }
     JOLT_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_fx[1]));
     JOLT_HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_fx[0], ctx->ev_fx[1]));
-    uint32_t info[2] = {0, 0};
+    uint32_t info[4] = {0, 0, 0, 0};
     JOLT_HIP_TRY(ctx, hipMemcpy(info, ctx->fx_profile_info, sizeof(info), hipMemcpyDeviceToHost));
-    *additions = info[1];
+    *additions = info[3] ? info[3] : info[1];  // a capacity sort counts its entries in info[3]; the exact scan leaves the total in info[1]
     return JOLT_OK;
 }

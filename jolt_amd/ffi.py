@@ -1641,6 +1641,13 @@ def host_fx_digits(scalar, window_bits):
     return [(-1 if int(k) >> 31 else 1) * (int(k) & 0x7FFFFFFF) for k in keys[: nw.value]], nb.value
 
 
+def host_fx_segment_capacity(n, window_bits, segment):
+    """the region (in entries) the capacity sort of an n-term fixed-base MSM gives segment `segment` of 256 buckets (jolt_host_fx_segment_capacity)"""
+    cap = C.c_uint32()
+    _ck(lib().jolt_host_fx_segment_capacity(C.c_uint64(n), C.c_uint32(window_bits), C.c_uint32(segment), C.byref(cap)), "jolt_host_fx_segment_capacity")
+    return int(cap.value)
+
+
 def host_suffix_mle(kind, bits, length):
     out = C.c_uint64()
     _ck(lib().jolt_host_suffix_mle(C.c_uint32(kind), C.c_uint64(bits & (2**64 - 1)), C.c_uint64((bits >> 64) & (2**64 - 1)), C.c_uint32(length), C.byref(out)), "jolt_host_suffix_mle")

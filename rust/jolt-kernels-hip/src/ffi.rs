@@ -237,6 +237,7 @@ extern "C" {
     pub fn jolt_host_fq_limb_op(op: i32, a: *const jolt_fr_t, b: *const jolt_fr_t, c: *const jolt_fr_t, d: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_g1_sum_limb_form(points: *const u64, negate: *const u8, count: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_fx_digits(scalar: *const jolt_fr_t, window_bits: u32, keys_out: *mut u32, n_windows_out: *mut u32, buckets_out: *mut u32) -> i32;
+    pub fn jolt_host_fx_segment_capacity(n: u64, window_bits: u32, segment: u32, capacity: *mut u32) -> i32;
     pub fn jolt_host_univariate_from_evals(evals: *const jolt_fr_t, n: usize, coeffs_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_univariate_evaluate(coeffs: *const jolt_fr_t, n: usize, x: *const jolt_fr_t, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_gruen_poly_from_q(current_scalar: *const jolt_fr_t, point_i: *const jolt_fr_t, q_evals: *const jolt_fr_t, dq: usize, s0_plus_s1: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t) -> i32;

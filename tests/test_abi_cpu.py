@@ -273,6 +273,55 @@ def test_trait_bound_audit_catches_the_round_4_gap(tmp_path):
     assert any("thiserror" in f for f in found), found
 
 
+@pytest.mark.parametrize("c,log_n", [(23, 16), (20, 16), (16, 14)])
+def test_capacity_regions_hold_the_digits_of_uniform_scalars(c, log_n):
+    """The capacity sort of the fixed-base MSM (msm_fixed.hip section 2d) gives every segment of 256 buckets a region sized from the digit MODEL of uniform scalars instead
+    of counting the digits first.  Here the digits of 2^log_n uniform scalars are recoded by an independent Python restatement of the recoding (checked against the
+    library's jolt_host_fx_digits on a sample), counted per segment, and every count must fit its region; regions where no digit can land keep the minimum; and at the
+    benchmarked size (n = 2^26, c = 23) the regions together exceed the expected number of entries by less than 6 %."""
+    from jolt_amd import ffi
+    import oracle_lib as O
+    r = O.R_MOD
+    rng = random.Random(1000 * c + log_n)
+    n, W, B = 1 << log_n, (253 + c - 1) // c, 1 << (c - 1)
+    counts = {}
+    for i in range(n):
+        s = rng.randrange(r)
+        t = s if s <= (r - 1) // 2 else r - s
+        carry, digits = 0, []
+        for w in range(W - 1):
+            raw = ((t >> (w * c)) & ((1 << c) - 1)) + carry
+            if raw > B:
+                digits.append((1 << c) - raw)
+                carry = 1
+            else:
+                digits.append(raw)
+                carry = 0
+        digits.append((t >> ((W - 1) * c)) + carry)
+        if i < 40:  # the restatement above IS the library's recoding (magnitudes)
+            got, _ = ffi.host_fx_digits(O.to_mont([s])[0], c)
+            assert [abs(d) for d in got] == digits, (s, c)
+        for d in digits:
+            if d:
+                counts[d >> 8] = counts.get(d >> 8, 0) + 1
+    top_max = (((r - 1) // 2) >> ((W - 1) * c)) + 1
+    n_segments = (max(B, top_max) >> 8) + 1
+    caps = {seg: ffi.host_fx_segment_capacity(n, c, seg) for seg in set(counts) | {0, (B >> 8), (B >> 8) + 1, (top_max >> 8), n_segments - 1}}
+    for seg, cnt in counts.items():
+        assert seg < n_segments and cnt <= caps[seg], (seg, cnt, caps[seg])
+    assert all(v % 4 == 0 and v >= 64 for v in caps.values())
+    beyond = (max(B, top_max) >> 8) + 5
+    assert ffi.host_fx_segment_capacity(n, c, beyond) == 64  # no digit reaches it: the floor only
+    if c == 23:  # the benchmarked MSM: 2^26 terms -- 738 M entries expected, the regions' total within 6 % of it
+        N = 1 << 26
+        total = sum(ffi.host_fx_segment_capacity(N, 23, seg) for seg in (0, 1)) // 2  # a typical low segment
+        low, high = total, ffi.host_fx_segment_capacity(N, 23, (B >> 8) + 2)
+        n_low, n_high = B >> 8, (top_max >> 8) - (B >> 8)
+        regions = n_low * low + n_high * high
+        expected = N * 10 * (1 - 2.0 ** -23) + N  # ten signed windows (a zero digit is not stored) + the top window
+        assert expected < regions < 1.06 * expected, (regions, expected)
+
+
 def test_host_on_curve_check_accepts_group_elements_and_refuses_everything_else():
     """g1_is_on_curve (g1.hip.h) through jolt_host_g1_is_on_curve: what jolt_host_hyperkzg_open_with_levels applies to the level commitments a caller supplies.  Oracle
     points in their many projective representations (scalar multiples, sums, doublings, P + (-P) = the identity) pass; a flipped bit in any coordinate, a coordinate

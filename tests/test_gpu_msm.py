@@ -324,6 +324,41 @@ def test_fixed_base_msm_at_2_20_is_the_kzg_commitment(ctx, window_bits):
     srs.free()
 
 
+@pytest.mark.parametrize("window_bits", [0, 13, 23])
+def test_capacity_sort_is_the_kzg_commitment_and_falls_back_on_the_device(ctx, window_bits):
+    """The sort without a histogram pass (msm_fixed.hip section 2d: capacity regions from the digit model of uniform scalars, taken when the caller marks the scalars
+    full-width).  Uniform scalars: commit(p) == p(beta) G at 2^20 terms and on a ragged prefix, like the exact sort.  Scalars that are NOT what the caller claimed --
+    all equal, 64-bit, a few thousand distinct values, zero -- overflow their regions; the exact passes enqueued behind the capacity sort must then produce the result
+    (no host round trip: the flag lives in device memory), again equal to p(beta) G and to the point the exact sort (full_width = False) gives."""
+    n = 1 << 20
+    beta = rand_fr(1, 640)[0]
+    g = O.g1_generator()
+    srs = ctx.srs_setup_from_secret(beta, n, g)
+    ctx.srs_precompute_windows(srs, window_bits, 1 << 12)
+    full = rand_fr(n, 641)
+    want = O.g1_scalar_mul(g, O.kzg_eval_univariate(full, beta))
+    tab = ctx.upload(full)
+    assert same_point(ctx.msm(srs, tab, full_width=True), want)
+    assert same_point(ctx.msm(srs, tab, full_width=True), ctx.msm(srs, tab))  # twice: the workspace of the first run (flag, cursors) does not leak into the second
+    m = (1 << 19) + 77
+    assert same_point(ctx.msm(srs, tab, m, full_width=True), O.g1_scalar_mul(g, O.kzg_eval_univariate(full[:m], beta)))
+    rng = np.random.default_rng(642)
+    skewed = {"all equal": np.repeat(rand_fr(1, 643), n, axis=0),
+              "64-bit": O.fr_from_u64(rng.integers(0, 2**64, size=n, dtype=np.uint64)),
+              "4096 distinct values": rand_fr(4096, 644)[rng.integers(0, 4096, size=n)],
+              "zero": np.zeros((n, 4), dtype=np.uint64)}
+    for name, scalars in skewed.items():
+        t = ctx.upload(np.ascontiguousarray(scalars))
+        got = ctx.msm(srs, t, full_width=True)
+        assert same_point(got, ctx.msm(srs, t)), name
+        if name != "4096 distinct values":
+            assert same_point(got, O.g1_scalar_mul(g, O.kzg_eval_univariate(np.ascontiguousarray(scalars), beta))), name
+        t.free()
+    assert same_point(ctx.msm(srs, tab, full_width=True), want)  # and a uniform one again after the fallbacks
+    tab.free()
+    srs.free()
+
+
 @pytest.mark.parametrize("world,block,n_global", [(2, 64, 1024), (4, 32, 1024), (8, 16, 2048), (2, 2048, 16384)])
 def test_block_cyclic_shares_add_up_to_the_msm(ctx, world, block, n_global):
     """The block-cyclic term assignment of the sharded PCS legs: rank g's compact SRS holds the powers beta^i with

@@ -35,7 +35,7 @@ def main():
         b, adds = ctx.msm_profile_buckets_last()
         ms_b.append(b)
         assert ffi.host_g1_eq(p, first)  # the same group element (the Jacobian coordinates depend on the order the sort's atomics left the lists in)
-    print(json.dumps({"stage_idx": os.environ.get("JOLT_FX_STAGE_IDX", "1"), "log_n": log_n, "additions": adds, "bucket_ms": [round(x, 3) for x in ms_b],
+    print(json.dumps({"stage_idx": os.environ.get("JOLT_FX_STAGE_IDX", "1"), "capacity": os.environ.get("JOLT_FX_CAPACITY", "1"), "log_n": log_n, "additions": adds, "bucket_ms": [round(x, 3) for x in ms_b],
                       "msm_ms": [round(x, 3) for x in ms_all], "adds_per_s_G": round(adds / (min(ms_b) * 1e-3) / 1e9, 3),
                       "point": [int(x) for x in np.asarray(first).reshape(-1)[:4]]}), flush=True)
 
