@@ -10,15 +10,18 @@ bash tools/seq_step.sh "$TAG/seq" > "$OUT/seq.log" 2>&1
 python - "$OUT/seq/seq_all.txt" > "$OUT/seq_kernel_sums.txt" <<'PY'
 import sys, collections
 rows = [l.split() for l in open(sys.argv[1]) if l.strip()]
-half = rows[len(rows) // 2:]  # the timed step (the warm-up step is the first half)
+# the run is one warm-up step + one timed step, identical in their kernels: everything but the set-up kernels, halved (a positional "second half" broke when the
+# capacity sort added its no-op fallback launches)
 acc = collections.OrderedDict()
-for r in half:
+for r in rows:
     try:
         dur = float(r[-2])
     except ValueError:
         continue
-    acc[r[2]] = acc.get(r[2], 0.0) + dur
-print("# kernel time of ONE bench step, JOLT_MSM_LANES=1 (no overlap between MSMs): ms per kernel name, MSM / PCS kernels only (tools/seq_step.sh)")
+    if r[2] in ("k_fx_to_lform", "k_fx_next_window", "k_srs_powers"):
+        continue
+    acc[r[2]] = acc.get(r[2], 0.0) + dur / 2
+print("# kernel time of ONE bench step, JOLT_MSM_LANES=1 (no overlap between MSMs): ms per kernel name, MSM / PCS kernels only (tools/seq_step.sh; the run's two steps halved)")
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"{v/1e3:10.3f} ms  {k}")
 PY
