@@ -78,6 +78,8 @@ const char *jolt_last_error(const jolt_ctx *ctx);
  * by live handles, cached by the pool, and the high-water mark of both (any pointer may be NULL). */
 int32_t jolt_ctx_trim(jolt_ctx *ctx);
 int32_t jolt_ctx_memory_stats(const jolt_ctx *ctx, size_t *live_bytes, size_t *cached_bytes, size_t *peak_bytes);
+/* ... and what the context holds outside the pool: the grow-only workspaces of its MSM lanes and of the batch of short MSMs (bytes). */
+int32_t jolt_ctx_workspace_stats(const jolt_ctx *ctx, size_t *msm_lane_bytes, size_t *msm_batch_bytes);
 /* Device-event timing of everything enqueued between begin and end on the context's stream (milliseconds). */
 int32_t jolt_timer_begin(jolt_ctx *ctx);
 int32_t jolt_timer_end(jolt_ctx *ctx, float *elapsed_ms);

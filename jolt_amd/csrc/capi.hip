@@ -275,6 +275,16 @@ extern "C" int32_t jolt_ctx_memory_stats(const jolt_ctx* ctx, size_t* live_bytes
     return JOLT_OK;
 }
 
+/* Device memory the context holds OUTSIDE the pool: the grow-only workspaces of the four MSM lanes and of the batch of short MSMs (what the pool's statistics do not see). */
+extern "C" int32_t jolt_ctx_workspace_stats(const jolt_ctx* ctx, size_t* msm_lane_bytes, size_t* msm_batch_bytes) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    size_t lanes = 0;
+    for (size_t cap : ctx->msm_ws_cap) lanes += cap;
+    if (msm_lane_bytes) *msm_lane_bytes = lanes;
+    if (msm_batch_bytes) *msm_batch_bytes = ctx->msm_batch_ws_cap;
+    return JOLT_OK;
+}
+
 int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t results) {
     if (partials > ctx->partials_cap || results > ctx->results_cap)
         for (int k = 0; k < 3; ++k) if (ctx->side[k]) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side[k]));

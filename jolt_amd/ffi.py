@@ -1230,7 +1230,11 @@ def _trim(self):
 def _memory_stats(self):
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     _ck(lib().jolt_ctx_memory_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "jolt_ctx_memory_stats", self)
-    return {"live_bytes": a.value, "cached_bytes": b.value, "peak_bytes": c.value}
+    out = {"live_bytes": a.value, "cached_bytes": b.value, "peak_bytes": c.value}
+    la, ba = C.c_size_t(), C.c_size_t()
+    _ck(lib().jolt_ctx_workspace_stats(self.h, C.byref(la), C.byref(ba)), "jolt_ctx_workspace_stats", self)
+    out["msm_lanes_bytes"], out["msm_batch_bytes"] = la.value, ba.value  # outside the pool: grow-only MSM workspaces
+    return out
 
 
 Context.table_from_ints = _table_from_ints

@@ -163,6 +163,7 @@ extern "C" {
     pub fn jolt_last_error(ctx: *const jolt_ctx) -> *const c_char;
     pub fn jolt_ctx_trim(ctx: *mut jolt_ctx) -> i32;
     pub fn jolt_ctx_memory_stats(ctx: *const jolt_ctx, live_bytes: *mut usize, cached_bytes: *mut usize, peak_bytes: *mut usize) -> i32;
+    pub fn jolt_ctx_workspace_stats(ctx: *const jolt_ctx, msm_lane_bytes: *mut usize, msm_batch_bytes: *mut usize) -> i32;
     pub fn jolt_timer_begin(ctx: *mut jolt_ctx) -> i32;
     pub fn jolt_timer_end(ctx: *mut jolt_ctx, elapsed_ms: *mut f32) -> i32;
     pub fn jolt_table_upload(ctx: *mut jolt_ctx, host: *const jolt_fr_t, len: usize, out: *mut *mut jolt_table) -> i32;

@@ -241,6 +241,8 @@ def test_bench_step_at_configs2_scale():
         assert np.array_equal(again["stages"][st]["polys"], out["stages"][st]["polys"])
     stats = c.memory_stats()
     assert stats["peak_bytes"] < 200 * 2**30  # fits one MI355X with room to spare
+    # ... the MSM workspaces outside the pool included (jolt_ctx_workspace_stats: four lanes + the batch of short MSMs), and they are not nothing at this size
+    assert stats["msm_lanes_bytes"] > 2**30 and stats["peak_bytes"] + stats["msm_lanes_bytes"] + stats["msm_batch_bytes"] < 240 * 2**30
     wl.close()
     c.close()
 
