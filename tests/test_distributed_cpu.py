@@ -101,7 +101,7 @@ def _worker(rank, world, port, tmpdir, tail_log):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tail_log", [(2, 0), (2, 2), (4, 0), (4, 1), (4, 3)])
+@pytest.mark.parametrize("world,tail_log", [(2, 0), (2, 2), (4, 0), (4, 1), (4, 3), (8, 0), (8, 2)])  # 8 ranks: three hypercube variables select the rank, two stay local
 def test_sharded_prove_batch_matches_single_process(world, tail_log):
     """tail_log = 0: the shards run all their local rounds and hand over single entries; tail_log > 0: early hand-over of
     2^tail_log-entry tables (fewer exchanges); tail_log = n_local (world 4, 3): everything runs in the redundant tail."""
@@ -134,7 +134,7 @@ def _msm_worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_msm_combines_to_the_single_process_point(world):
     """Term-range sharded MSM: per-rank partial sums, one all-gather of `world` Jacobian points, world-1 additions."""
     import util as mp  # util.spawn (standard library): the same launcher the GPU tests use
@@ -248,7 +248,7 @@ def _gather_sum_worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_gather_sum_is_the_modular_sum_over_the_ranks(world):
     """distributed.gather_sum (what the cross-rank stage operators use for every additive T-scale quantity: uni-skip sums, pushforward masses, read-RAF scan sums):
     ONE all-gather + fr_add_vec on every rank == the oracle's field sum of the ranks' shares, wrap-arounds included, for flat and blocked arrays"""
