@@ -115,8 +115,9 @@ def bind_roofline(ctx, ffi, log_n, reps):
             "avg_launch_ms": round(ms, 5)}
 
 
-MAD_PEAK_T = 25.0  # v_mad_u64_u32 lane-operations per second, chip-wide, in units of 10^12: measured by jolt_amd/csrc/tools/microbench.hip (~6.3 cycles per wave
-# instruction per SIMD; the nominal 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T/s holds for 4-cycle instructions only), docs/kernels.md section 3.1
+MAD_NOMINAL_T = 39.3  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: the lane rate if v_mad_u64_u32 issued like a 4-cycle instruction (it does not: ~6.3 cycles per wave
+# instruction per SIMD measured, docs/kernels.md section 3.1).  The bound roofline_msm divides by is MEASURED in the run (jolt_ctx_measure_mad_peak, ~50 ms of a register-only
+# multiply-add loop on the same device and stream, right before the profiled MSM); the nominal figure is reported beside it.
 MADS_PER_MIXED_ADD = 1467  # limb-form XYZZ mixed addition (8 M + 2 S, one two-product reduction): docs/kernels.md section 3.1
 
 
@@ -131,6 +132,8 @@ def msm_roofline(ctx, srs, log_n):
     pt[:, 3] %= np.uint64(0x30644E72E131A029)
     scalars = ctx.eq_evals(pt)  # a full-width pseudo-random table, built on the device
     ctx.msm(srs, scalars, n, full_width=True)  # warm: workspace growth, attributes
+    peak_rate, peak_ms, peak_launches = ctx.measure_mad_peak(50.0)
+    peak_t = peak_rate / 1e12
     ctx.msm_profile_buckets(True)
     ctx.synchronize()
     t0 = time.perf_counter()
@@ -144,13 +147,16 @@ def msm_roofline(ctx, srs, log_n):
     alg_bytes = 68.0 * adds
     return {"bound": "valu-int", "kernel": "k_fx_buckets_ordered_staged", "what": f"bucket sums of one fixed-base MSM, 2^{log_n} uniform 254-bit scalars, window tables of the step's SRS",
             "additions": adds, "avg_launch_ms": round(ms, 3), "msm_ms": round(msm_ms, 3),
-            "achieved": round(mads_t, 2), "peak": MAD_PEAK_T, "unit": "T v_mad_u64_u32/s", "frac": round(mads_t / MAD_PEAK_T, 4),
+            "achieved": round(mads_t, 2), "peak": round(peak_t, 2), "unit": "T v_mad_u64_u32/s", "frac": round(mads_t / peak_t, 4),
+            "peak_measured": round(peak_t, 3), "peak_source": f"jolt_ctx_measure_mad_peak in this process, this device: best of {peak_launches} launches ({peak_ms:.1f} ms of kernel time, HIP events "
+            "on the context's stream) of a register-only loop of independent v_mad_u64_u32 (8 accumulators per lane, 8 workgroups per CU)",
+            "peak_nominal": MAD_NOMINAL_T, "frac_of_nominal": round(mads_t / MAD_NOMINAL_T, 4),
             "additions_per_s": round(adds_s), "fq_mul_per_s": round(adds_s * 10), "mads_per_addition": MADS_PER_MIXED_ADD,
             "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_peak": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "fetched_over_algorithmic": 1.98, "source": "profiles/r05_bucket_index_staging_ab.txt (FETCH_SIZE pass, corrected per the guide): 134.6 B fetched per addition -- the "
                     "128-byte request a 64-byte point gather costs; round 4's 2.64 x included ~52 B per 4-byte index, removed by staging the lists' indices through LDS"},
             "counters": "profiles/r05_pmc_bucket.txt (SQ pass, 3 waves per SIMD at 152 VGPRs): a wave executes a VALU instruction in 34.4 % of its resident cycles, waits to issue in 52 %, waits on memory in 12.6 %",
-            "note": "peak = the measured chip-wide v_mad_u64_u32 rate; the kernel's other ~800 instructions per addition share the issue slots, which is why 1.0 is out of reach"}
+            "note": "peak = the chip-wide v_mad_u64_u32 rate measured in this run; the kernel's other ~800 instructions per addition share the issue slots, which is why 1.0 is out of reach"}
 
 
 PUBLISHED_REFERENCE = {  # what the reference itself publishes (whole prover, Dory PCS, CPU; NOT this path alone, NOT this box)

@@ -285,6 +285,11 @@ int32_t jolt_srs_precompute_windows(jolt_ctx *ctx, jolt_srs *srs, uint32_t windo
  * launched on, and the number of mixed additions of that launch (the non-zero signed digits of its scalars).  bench.py's `roofline_msm` divides the two. */
 int32_t jolt_msm_profile_buckets(jolt_ctx *ctx, int32_t enable);
 int32_t jolt_msm_profile_buckets_last(jolt_ctx *ctx, float *ms, uint64_t *additions);
+/* Measurement hook (no reference counterpart; SURVEY.md section 8d: "the run must print the peak it divides by"): the chip-wide issue rate of v_mad_u64_u32 -- the
+ * instruction the bucket sums are bound by -- measured now, on this context's device: a register-only loop of independent 64-bit multiply-adds launched until
+ * >= target_ms of kernel time have been timed with HIP events on the context's stream; *mads_per_s = the best launch's lane-operations per second.
+ * timed_ms / launches (optional): what was timed. */
+int32_t jolt_ctx_measure_mad_peak(jolt_ctx *ctx, float target_ms, double *mads_per_s, float *timed_ms, uint32_t *launches);
 
 /* JoltGroup::msm(bases, scalars) (crates/jolt-crypto/src/ec/group.rs:63-70, bn254/mod.rs:195-212) with the bases
  * = srs[..n].  Length mismatch (n > srs length) is JOLT_ERR_SRS_TOO_SMALL (the Rust shim asserts equal lengths

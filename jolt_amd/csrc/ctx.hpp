@@ -94,6 +94,7 @@ struct jolt_ctx {
     bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
     bool msm_lds_attr_set = false;
     bool msm_fx_attr_set = false;
+    bool rows_many_attr_set = false;  // k_rows_to_ints_many's dynamic-LDS limit raised on this device (onehot.hip)
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)
     bool msm_full_width_scalars = false;  // set by a caller around MSMs whose scalars are uniform field elements (the level commitments of an opening): lets mid-length ones use the mid table set

@@ -1474,3 +1474,68 @@ extern "C" int32_t jolt_msm_profile_buckets_last(jolt_ctx* ctx, float* ms, uint6
     *additions = info[3] ? info[3] : info[1];  // a capacity sort counts its entries in info[3]; the exact scan leaves the total in info[1]
     return JOLT_OK;
 }
+
+
+// ---- the bound roofline_msm divides by, measured in the process that divides by it ---------------------------------------------------------------------------
+// Chip-wide v_mad_u64_u32 issue rate: 8 independent 64-bit accumulators per lane, `iters` x 8 multiply-adds per thread, no memory traffic (one store per thread at the
+// end), 8 workgroups of 256 per CU -- the loop of jolt_amd/csrc/tools/microbench.hip's k_mad.  Launches are repeated until >= target_ms of kernel time have been timed
+// with HIP events on the context's stream; the best launch's rate is reported (the bound is what the part can do, not its average under a cold clock).
+namespace {
+__global__ __launch_bounds__(256) void k_mad_peak(uint64_t* out, uint32_t a0, uint32_t b0, int iters) {
+    uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;
+    uint64_t acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = k;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = (uint64_t)a * (uint32_t)(b + k) + acc[k];
+        a += (uint32_t)acc[0];
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s ^= acc[k];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+}  // namespace
+extern "C" int32_t jolt_ctx_measure_mad_peak(jolt_ctx* ctx, float target_ms, double* mads_per_s, float* timed_ms, uint32_t* launches) {
+    if (!ctx || !mads_per_s || !(target_ms > 0.f) || target_ms > 5000.f) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    const int blocks = (int)ctx->num_cus * 8, iters = 4096;
+    uint64_t* out = nullptr;
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, (size_t)blocks * 256 * sizeof(uint64_t), (void**)&out));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 0.0;
+    float total = 0.f;
+    uint32_t count = 0;
+    const double mads = (double)blocks * 256.0 * (double)iters * 8.0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_mad_peak, dim3(blocks), dim3(256), 0, ctx->stream, out, 12345u, 67891u, iters);  // warm: code object load, clocks
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    while (e == hipSuccess && total < target_ms && count < 10000) {
+        e = hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(k_mad_peak, dim3(blocks), dim3(256), 0, ctx->stream, out, 12345u + count, 67891u, iters);
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess || !(ms > 0.f)) break;
+        total += ms;
+        ++count;
+        best = std::max(best, mads / ((double)ms * 1e-3));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    jolt_internal_dev_free(ctx, out);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        ctx->last_error = std::string("mad peak measurement: ") + hipGetErrorString(e);
+        return JOLT_ERR_HIP;
+    }
+    *mads_per_s = best;
+    if (timed_ms) *timed_ms = total;
+    if (launches) *launches = count;
+    return JOLT_OK;
+}

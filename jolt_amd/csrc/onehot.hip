@@ -134,6 +134,13 @@ struct jolt_rows {
     size_t n_rows = 0, row_bytes = 0;
     bool pending = false;  // jolt_rows_upload_begin's copy has not been waited for yet (jolt_rows_upload_wait synchronises the host with the copy stream)
 };
+// Every consumer of a row block: the extraction kernels run on the context's main stream, which has no dependency on the copy stream (by design: see
+// jolt_rows_upload_begin), so a handle whose copy has not been waited for must be refused -- extracting from it would prove over a partly copied witness.
+static int32_t rows_ready(jolt_ctx* ctx, const jolt_rows* rows) {
+    if (rows->ctx != ctx) { ctx->last_error = "rows belong to another context"; return JOLT_ERR_INVALID_ARG; }
+    if (rows->pending) { ctx->last_error = "rows used before jolt_rows_upload_wait: the copy begun by jolt_rows_upload_begin may not have landed"; return JOLT_ERR_INVALID_ARG; }
+    return JOLT_OK;
+}
 
 namespace {
 __device__ __forceinline__ uint64_t load_le(const uint8_t* p, uint32_t width) {
@@ -368,6 +375,7 @@ extern "C" int32_t jolt_rows_free(jolt_ctx* ctx, jolt_rows* r) {
 
 extern "C" int32_t jolt_table_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, jolt_table** out) {
     if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(rows_ready(ctx, rows));
     if (!(width == 1 || width == 2 || width == 4 || width == 8) || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     jolt_table* t = nullptr;
@@ -393,6 +401,7 @@ static __global__ __launch_bounds__(kBlock) void k_rows_to_ints(const uint8_t* _
 }
 extern "C" int32_t jolt_ints_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, jolt_ints** out) {
     if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(rows_ready(ctx, rows));
     if (!(width == 1 || width == 2 || width == 4 || width == 8) || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     jolt_ints* v = new (std::nothrow) jolt_ints();
@@ -426,6 +435,7 @@ extern "C" int32_t jolt_ints_from_rows(jolt_ctx* ctx, const jolt_rows* rows, siz
 extern "C" int32_t jolt_ints_from_rows_many(jolt_ctx* ctx, const jolt_rows* rows, const size_t* offsets, const uint32_t* widths, const int32_t* is_signed, size_t n_fields,
                                             jolt_ints** out) {
     if (!ctx || !rows || !offsets || !widths || !is_signed || !out) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(rows_ready(ctx, rows));
     for (size_t k = 0; k < n_fields; ++k) {
         const uint32_t w = widths[k];
         if (!(w == 1 || w == 2 || w == 4 || w == 8) || w > rows->row_bytes || offsets[k] > rows->row_bytes - w) return JOLT_ERR_INVALID_ARG;
@@ -451,11 +461,17 @@ extern "C" int32_t jolt_ints_from_rows_many(jolt_ctx* ctx, const jolt_rows* rows
         if (as != JOLT_OK) { delete v; release(k); return as; }
         out[k] = v;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_rows_to_ints_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block);
-        (void)hipGetLastError();
-        attr_set = true;
+    if (!ctx->rows_many_attr_set) {  // once per context (= per device): the attribute is per device
+        if (hipFuncSetAttribute((const void*)k_rows_to_ints_many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->max_lds_per_block) != hipSuccess) {
+            (void)hipGetLastError();  // refused: the tile does not stage on this device -> field by field
+            release(n_fields);
+            for (size_t k = 0; k < n_fields; ++k) {
+                const int32_t st = jolt_ints_from_rows(ctx, rows, offsets[k], widths[k], is_signed[k], &out[k]);
+                if (st != JOLT_OK) { release(k); return st; }
+            }
+            return JOLT_OK;
+        }
+        ctx->rows_many_attr_set = true;
     }
     for (size_t k0 = 0; k0 < n_fields; k0 += kRowsMaxFields) {
         RowFields f;
@@ -482,6 +498,7 @@ extern "C" int32_t jolt_ints_from_rows_many(jolt_ctx* ctx, const jolt_rows* rows
 extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
                                          uint32_t log_k, size_t valid_offset, jolt_onehot** out) {
     if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(rows_ready(ctx, rows));
     if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;  // log_k = 8: 16-bit indices
     if (valid_offset != ~(size_t)0 && valid_offset >= rows->row_bytes) return JOLT_ERR_INVALID_ARG;
     ChunkShifts sh;
@@ -520,6 +537,7 @@ extern "C" int32_t jolt_onehot_from_rows(jolt_ctx* ctx, const jolt_rows* rows, s
 extern "C" int32_t jolt_table_from_rows_window(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, int32_t is_signed, int32_t lookahead, size_t cycles,
                                                int64_t padding_value, int64_t none_value, jolt_table** out) {
     if (!ctx || !rows || !out) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(rows_ready(ctx, rows));
     if (!(width == 1 || width == 2 || width == 4 || width == 8) || width > rows->row_bytes || offset > rows->row_bytes - width || (lookahead != 0 && lookahead != 1)) return JOLT_ERR_INVALID_ARG;
     if (rows->n_rows > cycles) return JOLT_ERR_SIZE_MISMATCH;  // rows.rs:44-53: the physical trace must fit the cycle domain
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
@@ -538,6 +556,7 @@ extern "C" int32_t jolt_table_from_rows_window(jolt_ctx* ctx, const jolt_rows* r
 extern "C" int32_t jolt_onehot_from_rows_sentinel(jolt_ctx* ctx, const jolt_rows* rows, size_t offset, uint32_t width, const uint32_t* shifts, size_t n_polys,
                                                   uint32_t log_k, size_t cycles, jolt_onehot** out) {
     if (!ctx || !rows || !shifts || !out || n_polys == 0 || n_polys > (size_t)kMaxBatchTables) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(rows_ready(ctx, rows));
     if (log_k == 0 || log_k > 8 || width == 0 || width > 16 || width > rows->row_bytes || offset > rows->row_bytes - width) return JOLT_ERR_INVALID_ARG;
     if (rows->n_rows > cycles || cycles == 0) return JOLT_ERR_SIZE_MISMATCH;
     ChunkShifts sh;

@@ -752,6 +752,13 @@ def _msm_profile_buckets_last(self):
     return float(ms.value), int(adds.value)
 
 
+def _measure_mad_peak(self, target_ms=50.0):
+    """jolt_ctx_measure_mad_peak: (v_mad_u64_u32 lane-operations per second chip-wide, kernel milliseconds timed, launches)"""
+    rate, ms, n = C.c_double(), C.c_float(), C.c_uint32()
+    _ck(lib().jolt_ctx_measure_mad_peak(self.h, C.c_float(target_ms), C.byref(rate), C.byref(ms), C.byref(n)), "jolt_ctx_measure_mad_peak", self)
+    return float(rate.value), float(ms.value), int(n.value)
+
+
 def _msm_window(self, srs, base_offset, values, kind=None, acc=None):
     """One window of a streamed commitment (jolt_msm_g1_window: StreamingCommitment::feed / feed_u64 / feed_i128 for a KZG-type scheme): acc + sum_i values[i] *
     srs[base_offset + i].  values: (n, 4) uint64 field elements (kind "fr"), uint64 / int64 arrays, or i128 as an (n, 2) uint64 array (kind "i128")."""
@@ -828,6 +835,7 @@ Context.msm = _msm
 Context.msm_window = _msm_window
 Context.msm_profile_buckets = _msm_profile_buckets
 Context.msm_profile_buckets_last = _msm_profile_buckets_last
+Context.measure_mad_peak = _measure_mad_peak
 Context.srs_setup_from_secret_blocks = _srs_setup_from_secret_blocks
 Context.msm_blocks = _msm_blocks
 Context.srs_setup_from_secret_subtree = _srs_setup_from_secret_subtree

@@ -218,6 +218,7 @@ extern "C" {
     pub fn jolt_srs_precompute_windows(ctx: *mut jolt_ctx, srs: *mut jolt_srs, window_bits: u32, min_terms: usize) -> i32;
     pub fn jolt_msm_profile_buckets(ctx: *mut jolt_ctx, enable: i32) -> i32;
     pub fn jolt_msm_profile_buckets_last(ctx: *mut jolt_ctx, ms: *mut f32, additions: *mut u64) -> i32;
+    pub fn jolt_ctx_measure_mad_peak(ctx: *mut jolt_ctx, target_ms: f32, mads_per_s: *mut f64, timed_ms: *mut f32, launches: *mut u32) -> i32;
     pub fn jolt_msm_g1(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_fr_t, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_msm_g1_table(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_msm_g1_table_full_width(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, out: *mut jolt_g1_t) -> i32;

@@ -165,3 +165,30 @@ def test_witness_upload_path_gives_the_same_proof(n_vars, mode):
     a.close()
     b.close()
     ctx.close()
+
+
+def test_rows_handle_is_refused_before_its_copy_has_been_waited_for():
+    """jolt_rows_upload_begin's handle is pending until jolt_rows_upload_wait: the extraction kernels run on the main stream, which does not depend on the copy
+    stream, so every *_from_rows entry point must refuse it (JOLT_ERR_INVALID_ARG) rather than extract from a partly copied block -- and serve it after the wait"""
+    ctx = ffi.Context(0)
+    T, row_bytes = 1 << 10, 24
+    buf = ffi.PinnedBuffer(ctx, (T, row_bytes))
+    rng = np.random.default_rng(3)
+    buf.array[...] = rng.integers(0, 256, size=(T, row_bytes), dtype=np.uint8)
+    rows = ffi.Rows.begin(ctx, buf.array)
+    calls = [lambda: rows.table(0, 8), lambda: rows.ints(8, 8), lambda: rows.ints_many([(0, 8, False), (8, 8, True)]), lambda: rows.onehot(16, 2, [0, 4, 8, 12], 4, valid_offset=18),
+             lambda: rows.window_table(0, 8, False, 1, T), lambda: rows.onehot_sentinel(16, 2, [0, 4], 4, T)]
+    for call in calls:
+        with pytest.raises(ffi.JoltError) as e:
+            call()
+        assert e.value.status == 1 and "jolt_rows_upload_wait" in str(e.value), str(e.value)  # JOLT_ERR_INVALID_ARG
+    rows.wait()
+    col = rows.ints(8, 8)
+    assert np.array_equal(col.download(), buf.array[:, 8:16].copy().view(np.uint64).reshape(T))
+    many = rows.ints_many([(0, 8, False), (8, 8, True)])
+    assert np.array_equal(many[1].download().view(np.uint64), col.download())
+    for v in many + [col]:
+        v.free()
+    rows.free()
+    buf.free()
+    ctx.close()

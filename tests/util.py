@@ -62,7 +62,7 @@ def _spawn_entry(fn, rank, args):
     fn(rank, *args)
 
 
-def spawn(fn, args=(), nprocs=1, join=True, timeout=None):
+def spawn(fn, args=(), nprocs=1, join=True, timeout=None):  # timeout None: 1800 s
     """torch.multiprocessing.spawn's contract -- fn(rank, *args) in `nprocs` fresh interpreters, an exception if any of them fails -- on the standard library, so that the
     pytest process itself never imports torch: a GPU test process that holds torch (its bundled HIP runtime, RCCL and rocm_smi) NEXT TO libjolt_hip.so's system ones
     aborted at exit in round 4 (profiles/r05_teardown_abort_backtrace.txt).  The workers import torch first (init_gloo) and libjolt_hip.so after it: one runtime each."""
@@ -73,18 +73,27 @@ def spawn(fn, args=(), nprocs=1, join=True, timeout=None):
         p.start()
     if not join:
         return procs
+    # poll all ranks together: the first rank that exits non-zero (or the deadline) ends the others at once -- a sibling blocked in a collective would otherwise
+    # sit out the gloo / shared-memory timeout (120 - 300 s) before the test failed
+    import time
+    deadline = time.monotonic() + (timeout if timeout is not None else 1800.0)
     failed = []
-    for r, p in enumerate(procs):
-        p.join(timeout)
-        if p.is_alive():
-            p.kill()
-            p.join()
-            failed.append((r, "timeout"))
-        elif p.exitcode != 0:
-            failed.append((r, p.exitcode))
+    while True:
+        alive = [p for p in procs if p.is_alive()]
+        failed = [(r, p.exitcode) for r, p in enumerate(procs) if not p.is_alive() and p.exitcode != 0]
+        if failed or not alive:
+            break
+        if time.monotonic() > deadline:
+            failed = [(r, "timeout") for r, p in enumerate(procs) if p.is_alive()]
+            break
+        time.sleep(0.05)
     if failed:
         for p in procs:
             if p.is_alive():
                 p.kill()
+        for p in procs:
+            p.join()
         raise RuntimeError(f"spawned rank(s) failed: {failed}")
+    for p in procs:
+        p.join()
     return None

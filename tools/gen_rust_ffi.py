@@ -16,7 +16,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 HEADER = os.path.join(ROOT, "include", "jolt_hip.h")
 FFI_RS = os.path.join(ROOT, "rust", "jolt-kernels-hip", "src", "ffi.rs")
 
-SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "size_t": "usize", "float": "f32",
+SCALARS = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "size_t": "usize", "float": "f32", "double": "f64",
            "void": "c_void", "char": "c_char"}
 def opaque_handles(path=None):
     """every `typedef struct X X;` of the header, in declaration order: the handle types ffi.rs must define (a hand-kept list went stale in round 3)"""
