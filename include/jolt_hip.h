@@ -621,6 +621,8 @@ int32_t jolt_host_read_raf_address_destroy(jolt_read_raf_address *h);
 int32_t jolt_host_read_raf_address_init_phase(jolt_read_raf_address *h, uint32_t phase, const jolt_fr_t *raf_sums, const jolt_fr_t *suffix_sums);
 int32_t jolt_host_read_raf_address_message(jolt_read_raf_address *h, const jolt_fr_t *previous_claim, jolt_fr_t *evals_out /* 3 */);
 int32_t jolt_host_read_raf_address_bind(jolt_read_raf_address *h, const jolt_fr_t *challenge, int32_t *phase_done);
+/* bind + the next round's message in one hand-off (ProveRounds::prove_round with Some(bind), prover.rs:45-51), for the 1st .. 7th bind of a phase */
+int32_t jolt_host_read_raf_address_bind_message(jolt_read_raf_address *h, const jolt_fr_t *challenge, const jolt_fr_t *previous_claim, jolt_fr_t *evals_out /* 3 */);
 int32_t jolt_host_read_raf_address_prove_phase(jolt_read_raf_address *h, jolt_fr_t *claim, jolt_round_transcript_fn fn, void *user, jolt_host_transcript *test_transcript,
                                                jolt_fr_t *coeffs_out /* 8 x 3; may be NULL */, jolt_fr_t *challenges_out /* 8; may be NULL */);
 int32_t jolt_host_read_raf_address_v_table(const jolt_read_raf_address *h, uint32_t phase, jolt_fr_t *out /* 256 */);
@@ -869,6 +871,86 @@ int32_t jolt_grid_joint_polynomial_subtree(jolt_ctx *ctx, const jolt_onehot *con
 int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell,
                                         uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void *user,
                                         jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Stage operators as ProveRounds objects -- one per backend slot (crates/jolt-kernels/src/backend.rs:126-171).
+ *
+ * A slot is a PrepareKernel<F, R> whose prepare(..) returns Box<dyn SumcheckKernel<F, Relation = R>> (backend.rs:98-111, kernel.rs:72-126):
+ * ProveRounds (crates/jolt-sumcheck/src/prover.rs:52-72) + output_claims.  jolt_stage_<operator>_create IS that prepare: every T-scale pass that
+ * depends on no round challenge runs there, over inputs that are resident in HBM (borrowed: they must outlive the operator).  The object then
+ * follows the fused contract (prover.rs:45-51): prove_round(bind = the PREVIOUS round's challenge or NULL in the first active round, round,
+ * previous_claim) returns the round message as UnivariatePoly coefficients c_0 .. c_{n-1} (n <= degree + 1; s(0) + s(1) = previous_claim),
+ * finish_rounds(bind) applies the last challenge, output_claims are SumcheckKernel::output_claims in the order each constructor documents.
+ * Errors as everywhere in this header; a message that fails its own round check is JOLT_ERR_ROUND_CHECK.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct jolt_stage_op jolt_stage_op;
+int32_t jolt_stage_op_num_rounds(const jolt_stage_op *op, size_t *rounds);                  /* ProveRounds::num_rounds */
+int32_t jolt_stage_op_degree(const jolt_stage_op *op, size_t *degree);                      /* the largest degree of a round message */
+int32_t jolt_stage_op_input_claim(jolt_stage_op *op, jolt_fr_t *claim);                     /* test / bench convenience: a prover holds it from the earlier stages */
+int32_t jolt_stage_op_prove_round(jolt_stage_op *op, const jolt_fr_t *bind, size_t round, const jolt_fr_t *previous_claim, jolt_fr_t *coeffs_out, size_t cap,
+                                  size_t *n_coeffs);                                        /* ProveRounds::prove_round (prover.rs:57-66) */
+int32_t jolt_stage_op_finish_rounds(jolt_stage_op *op, const jolt_fr_t *bind);              /* ProveRounds::finish_rounds (prover.rs:68-71) */
+int32_t jolt_stage_op_output_claims(jolt_stage_op *op, jolt_fr_t *out, size_t cap, size_t *n); /* SumcheckKernel::output_claims (kernel.rs:86-92) */
+/* Intermediate values an operator keeps on the host for parity tests, by name: "masses" (pushforwards: n_polys x K), "scan_raf" / "scan_suffix" (the 16 read-RAF
+ * phase scans), "v_tables", "table_values", "raf_values", "cycle_claim".  out == NULL asks for the count. */
+int32_t jolt_stage_op_kept(const jolt_stage_op *op, const char *key, jolt_fr_t *out, size_t cap, size_t *n);
+/* Rounds [first, first + n) of `parent` as an operator of its own (the parent stays alive and owns the state): a caller can put the phases of one kernel under
+ * different transcripts or drivers; a window's last challenge is handed to the parent with the next window's first round. */
+int32_t jolt_stage_op_window(jolt_stage_op *parent, size_t first, size_t n, jolt_stage_op **out);
+int32_t jolt_stage_op_destroy(jolt_stage_op *op);
+
+/* UniskipKernel (crates/jolt-kernels/src/uniskip.rs:28-54) of Spartan outer (n_streams = 2) / product (n_streams = 1): the extended-node sums t1 of the uni-skip
+ * first round off the integer columns (jolt_r1cs_uniskip_sums_small) against eq(tau, .) expanded here.  tau: n_tau coordinates (cycle variables, then the stream). */
+int32_t jolt_stage_spartan_uniskip_sums(jolt_ctx *ctx, const jolt_ints *const *cols, size_t n_cols, uint32_t n_streams, const jolt_fr_t *tau, size_t n_tau,
+                                        const int64_t *a_weights, const int64_t *b_weights, size_t n_nodes, jolt_fr_t *sums_out);
+/* spartan_outer / spartan_product remainder (optimized/spartan_outer.rs:236-300,780-850; spartan_product.rs:321-437): Az / Bz at the uni-skip challenge
+ * (field weights [stream][1 + n_cols]), the split-eq product member over them, n_tau rounds of degree 3.  output_claims: the n_cols claimed inputs at the cycle point. */
+int32_t jolt_stage_spartan_remainder_create(jolt_ctx *ctx, const jolt_ints *const *cols, size_t n_cols, uint32_t n_streams, const jolt_fr_t *a_weights,
+                                            const jolt_fr_t *b_weights, const jolt_fr_t *tau, size_t n_tau, const jolt_fr_t *scale, jolt_stage_op **out);
+/* ram_read_write (optimized/ram_read_write.rs:58-330): RamAccessColumns (u64 jolt_ints of T entries), RamInc (i64, T), the initial memory (u64, K); log T cycle rounds
+ * (cubic, gruen_poly_deg_3) then log K address rounds (quadratic).  output_claims: {ra, val, inc, bound cycle-eq factor}. */
+int32_t jolt_stage_ram_read_write_create(jolt_ctx *ctx, const jolt_ints *addresses, const jolt_ints *pre_values, const jolt_ints *post_values, const jolt_ints *inc,
+                                         const jolt_ints *val_init, const jolt_fr_t *tau_low, const jolt_fr_t *gamma, jolt_stage_op **out);
+/* registers_read_write (optimized/registers_read_write/mod.rs:79-402): `regs` = the hot-index columns rs1, rs2, rd (K = 128), the value columns, RdInc (i128).
+ * output_claims: {registers_val, rd_wa, gamma rs1_ra + gamma^2 rs2_ra, rd_inc, bound cycle-eq factor, rs1_ra, rs2_ra}. */
+int32_t jolt_stage_registers_read_write_create(jolt_ctx *ctx, const jolt_onehot *regs, const jolt_ints *rs1_val, const jolt_ints *rs2_val, const jolt_ints *rd_pre,
+                                               const jolt_ints *rd_post, const jolt_ints *inc, const jolt_fr_t *r_cycle, const jolt_fr_t *gamma, jolt_stage_op **out);
+/* booleanity_address (optimized/booleanity.rs:152-427): the pushforward masses of all RA columns against eq(reference_cycle, .) (T-scale, here), then log K rounds
+ * of degree 3 over K-entry tables.  Input claim zero.  output_claims: {the phase's intermediate claim}. */
+int32_t jolt_stage_booleanity_address_create(jolt_ctx *ctx, const jolt_onehot *cols, const jolt_fr_t *reference_cycle, size_t n_cycle, const jolt_fr_t *reference_address,
+                                             const jolt_fr_t *gamma, jolt_stage_op **out);
+/* hamming_weight_claim_reduction (optimized/hamming_weight_claim_reduction.rs:83-300): virtualization_points = n_polys x log K.  output_claims: the bound G_i. */
+int32_t jolt_stage_hamming_weight_create(jolt_ctx *ctx, const jolt_onehot *cols, const jolt_fr_t *r_cycle, size_t n_cycle, const jolt_fr_t *r_address,
+                                         const jolt_fr_t *virtualization_points, const jolt_fr_t *gamma, jolt_stage_op **out);
+/* instruction_read_raf (optimized/instruction_read_raf.rs:736-1456), ONE kernel of 128 + log T rounds: 16 address phases (condensation + scans on the device at each
+ * phase's first round, 8 quadratic rounds over 256-entry polynomials on the host) and the cycle rounds over combined * prod ra_i (degree ra_count + 2).
+ * claim_columns: the packed flag facts as four K = 16 hot-index columns (tables 0..15, 16..31, 32..41; RAF rows on 0).
+ * output_claims: {lookup_table_flags of the present tables, instruction_raf_flag, the ra_count bound ra_i}. */
+int32_t jolt_stage_instruction_read_raf_create(jolt_ctx *ctx, jolt_read_raf *rows, const jolt_onehot *claim_columns, const jolt_fr_t *r_reduction, size_t n_vars,
+                                               const jolt_fr_t *gamma, const uint8_t *table_present /* 42 */, uint32_t ra_count, jolt_stage_op **out);
+/* bytecode_read_raf_address (optimized/bytecode_read_raf.rs:152-437): the five stage pushforwards onto the bytecode domain in one walk over the PC index, log K
+ * rounds of degree 2 over 13 K-sized tables.  output_claims: {the 13 bound tables (F_0..4, V_0..4, Int, entry_trace, entry_expected), the intermediate claim}.
+ * bytecode_read_raf_cycle (:440-690) is prepared from the finished address operator (its parked eq tables are consumed): log T rounds of C * prod ra_i;
+ * output_claims: the bound ra_i. */
+int32_t jolt_stage_bytecode_read_raf_address_create(jolt_ctx *ctx, const jolt_key_index *pc_index, const jolt_fr_t *stage_points /* 5 x n_vars */, size_t n_vars,
+                                                    const jolt_fr_t *stage_values /* 5 x K */, const jolt_fr_t *gamma, uint64_t first_pc, uint64_t entry_index,
+                                                    jolt_stage_op **out);
+int32_t jolt_stage_bytecode_read_raf_cycle_create(jolt_ctx *ctx, jolt_stage_op *address, const jolt_onehot *pc_chunks, uint32_t chunk_bits, jolt_stage_op **out);
+/* ram_raf_evaluation (optimized/ram_raf_evaluation.rs:17-62): log K rounds of ra_folded * unmap.  output_claims: {ra_folded, unmap} bound. */
+int32_t jolt_stage_ram_raf_evaluation_create(jolt_ctx *ctx, const jolt_key_index *ram_index, const jolt_fr_t *tau_low, size_t n_vars, uint64_t lowest_address,
+                                             jolt_stage_op **out);
+/* ram_output_check (optimized/ram_output_check.rs:50-215): val_final from the access columns (T-scale, here), log K rounds of degree 3.
+ * output_claims: {val_final at the bound address point}. */
+int32_t jolt_stage_ram_output_check_create(jolt_ctx *ctx, const jolt_key_index *ram_index, const jolt_ints *post_values, const uint64_t *val_init /* K */,
+                                           const uint64_t *val_io /* K */, uint64_t io_lo, uint64_t io_len, const jolt_fr_t *r_address, jolt_stage_op **out);
+/* Drivers for the tests and the bench (a Rust host calls the contract above from its own prove_batch): prove_batch (prover.rs:193-362) over operators with the
+ * library's test transcript; and one operator driven alone -- per round the message, every coefficient absorbed, Transcript::challenge -- with
+ * coeffs_out = rounds x stride (tails zeroed), n_coeffs_out[r] = the coefficients of round r, claim in = input claim / out = the final claim. */
+int32_t jolt_host_prove_batch_ops(jolt_ctx *ctx, jolt_stage_op *const *ops, size_t n_ops, const jolt_fr_t *input_claims, const jolt_fr_t *coefficients,
+                                  const size_t *offsets, size_t max_num_vars, size_t max_degree, uint64_t transcript_label, int32_t challenge_mode,
+                                  jolt_fr_t *out_polys, jolt_fr_t *out_challenges, jolt_fr_t *out_member_claims, jolt_fr_t *out_final_claim);
+int32_t jolt_host_stage_op_prove_alone(jolt_stage_op *op, jolt_host_transcript *transcript, jolt_fr_t *claim, jolt_fr_t *coeffs_out, size_t stride,
+                                       uint32_t *n_coeffs_out, jolt_fr_t *challenges_out);
 
 #ifdef __cplusplus
 }

@@ -14,10 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libjolt_hip.so")
-# host_mirror.hip, shm_exchange.hip and read_raf_address.hip hold HOST code only (the C++ mirror of the reference's drivers above the ABI, the shared-memory round
+# host_mirror.hip, shm_exchange.hip, read_raf_address.hip and stage_ops.hip hold HOST code only (the C++ mirror of the reference's drivers above the ABI, the shared-memory round
 # exchange, the 128 read-RAF address rounds); they keep the .hip suffix and go through hipcc like the rest because they share field.hip.h (JOLT_HD functions: one
 # definition of the field arithmetic for both sides) -- hipcc emits no device code for them
-SOURCES = ["capi.hip", "host_mirror.hip", "batch.hip", "views.hip", "msm.hip", "msm_fixed.hip", "hyperkzg.hip", "comm.hip", "onehot.hip", "dory.hip", "pcs.hip", "rw_matrix.hip", "r1cs.hip", "small_r1cs.hip", "read_raf.hip", "key_index.hip", "shm_exchange.hip", "read_raf_address.hip"]
+SOURCES = ["capi.hip", "host_mirror.hip", "batch.hip", "views.hip", "msm.hip", "msm_fixed.hip", "hyperkzg.hip", "comm.hip", "onehot.hip", "dory.hip", "pcs.hip", "rw_matrix.hip", "r1cs.hip", "small_r1cs.hip", "read_raf.hip", "key_index.hip", "shm_exchange.hip", "read_raf_address.hip", "stage_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("JOLT_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DJOLT_BUCKET_WAVES=2 for A/B builds
 

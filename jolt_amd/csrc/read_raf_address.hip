@@ -710,6 +710,21 @@ extern "C" int32_t jolt_host_read_raf_address_bind(jolt_read_raf_address* h, con
     return JOLT_OK;
 }
 
+// bind + the next message in ONE hand-off (the fused ProveRounds contract, prover.rs:45-51): for the binds that do not close the phase (the 1st .. 7th of a phase);
+// the 8th goes through jolt_host_read_raf_address_bind, after which the next phase's scan sums are due (init_phase) before a message exists.
+extern "C" int32_t jolt_host_read_raf_address_bind_message(jolt_read_raf_address* h, const jolt_fr_t* challenge, const jolt_fr_t* previous_claim, jolt_fr_t* evals_out) {
+    if (!h || !challenge || !previous_claim || !evals_out || !h->phase_open || h->bound + 1 >= kChunkLen) return JOLT_ERR_INVALID_ARG;
+    const Fr r = fr_from_abi(challenge);
+    if (!fr_is_canonical(r)) return JOLT_ERR_INVALID_ARG;
+    const F rf = from_fr(r);
+    F e[3], claim;
+    if (const int32_t st = step(h, kStepBind | kStepMessage, &rf, e)) return st;
+    std::memcpy(&claim, previous_claim, sizeof(F));
+    e[1] = f_sub(claim, e[0]);
+    std::memcpy(evals_out, e, sizeof(e));
+    return JOLT_OK;
+}
+
 // The 8 rounds of the open phase in one call: message -> UnivariatePoly::from_evals coefficients [c0, c1, c2] -> transcript -> bind.  The transcript is the
 // caller's hook (jolt_round_transcript_fn: absorbs the coefficients, returns the challenge) or, with fn == NULL, the library's test transcript `test_transcript`
 // (append the three coefficients, Transcript::challenge).  claim: in = the running claim before the phase, out = after it.  A round's bind shares its

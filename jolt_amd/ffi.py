@@ -1800,3 +1800,198 @@ def host_small_round_pair(n_tables, groups, is_int, int_pairs, fr_pairs, n_evals
     out = fr_array(n_evals)
     _ck(lib().jolt_host_small_round_pair(C.byref(d), _p(mask), _p(ip), _p(fp), C.c_uint32(n_evals), C.c_int32(1 if skip_one else 0), _p(out)), "jolt_host_small_round_pair")
     return out
+
+
+# ---- stage operators as ProveRounds objects (stage_ops.hip): one per backend slot ---------------------------------------------------------------------------
+class StageOp:
+    """jolt_stage_op: prove_round / finish_rounds / output_claims of one stage operator.  `keep`: Python objects the operator borrows (they must outlive it)."""
+
+    def __init__(self, ctx, handle, keep=()):
+        self.ctx, self.h, self._keep = ctx, handle, list(keep)
+
+    @property
+    def rounds(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_stage_op_num_rounds(self.h, C.byref(n)), "jolt_stage_op_num_rounds", self.ctx)
+        return n.value
+
+    @property
+    def degree(self):
+        n = C.c_size_t()
+        _ck(lib().jolt_stage_op_degree(self.h, C.byref(n)), "jolt_stage_op_degree", self.ctx)
+        return n.value
+
+    def input_claim(self):
+        o = fr_array(1)
+        _ck(lib().jolt_stage_op_input_claim(self.h, _p(o)), "jolt_stage_op_input_claim", self.ctx)
+        return o[0]
+
+    def prove_round(self, bind, rnd, previous_claim):
+        """ProveRounds::prove_round: the round message as coefficients (n, 4)"""
+        cap = self.degree + 1
+        out, n = fr_array(cap), C.c_size_t()
+        _ck(lib().jolt_stage_op_prove_round(self.h, _p(fr(bind)) if bind is not None else None, C.c_size_t(rnd), _p(fr(previous_claim)), _p(out), C.c_size_t(cap), C.byref(n)),
+            "jolt_stage_op_prove_round", self.ctx)
+        return out[: n.value].copy()
+
+    def finish_rounds(self, bind):
+        _ck(lib().jolt_stage_op_finish_rounds(self.h, _p(fr(bind))), "jolt_stage_op_finish_rounds", self.ctx)
+
+    def output_claims(self):
+        n = C.c_size_t()
+        out = fr_array(256)
+        _ck(lib().jolt_stage_op_output_claims(self.h, _p(out), C.c_size_t(256), C.byref(n)), "jolt_stage_op_output_claims", self.ctx)
+        return out[: n.value].copy()
+
+    def kept(self, key):
+        n = C.c_size_t()
+        _ck(lib().jolt_stage_op_kept(self.h, key.encode(), None, C.c_size_t(0), C.byref(n)), "jolt_stage_op_kept", self.ctx)
+        out = fr_array(max(n.value, 1))
+        _ck(lib().jolt_stage_op_kept(self.h, key.encode(), _p(out), C.c_size_t(n.value), C.byref(n)), "jolt_stage_op_kept", self.ctx)
+        return out[: n.value]
+
+    def window(self, first, n):
+        h = C.c_void_p()
+        _ck(lib().jolt_stage_op_window(self.h, C.c_size_t(first), C.c_size_t(n), C.byref(h)), "jolt_stage_op_window", self.ctx)
+        return StageOp(self.ctx, h, keep=[self])
+
+    def prove_alone(self, transcript, claim):
+        """jolt_host_stage_op_prove_alone: -> dict(polys = per round the message's coefficients, challenges, final_claim)"""
+        rounds, stride = self.rounds, self.degree + 1
+        c = fr(claim).reshape(4).copy()
+        coeffs, counts, chal = fr_array(max(rounds * stride, 1)), np.zeros(max(rounds, 1), dtype=np.uint32), fr_array(max(rounds, 1))
+        _ck(lib().jolt_host_stage_op_prove_alone(self.h, transcript.h, _p(c), _p(coeffs), C.c_size_t(stride), counts.ctypes.data_as(C.c_void_p), _p(chal)),
+            "jolt_host_stage_op_prove_alone", self.ctx)
+        coeffs = coeffs.reshape(-1, stride, 4)
+        return dict(polys=[coeffs[r, : counts[r]].copy() for r in range(rounds)], challenges=chal[:rounds].copy() if rounds else np.zeros((0, 4), dtype=np.uint64), final_claim=c)
+
+    def destroy(self):
+        if self.h:
+            lib().jolt_stage_op_destroy(self.h)
+            self.h = None
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _prove_batch_ops(self, ops, input_claims, coefficients, offsets, max_num_vars, max_degree, label=0, challenge_mode=0):
+    """prove_batch (prover.rs:193-362) over stage operators (jolt_host_prove_batch_ops): the same outputs as Context.prove_batch"""
+    n = len(ops)
+    hs = (C.c_void_p * n)(*[o.h for o in ops])
+    ic = np.ascontiguousarray(np.stack(input_claims), dtype=np.uint64).reshape(-1, 4)
+    co = np.ascontiguousarray(np.stack(coefficients), dtype=np.uint64).reshape(-1, 4)
+    offs = (C.c_size_t * n)(*offsets)
+    polys, chal = fr_array(max(max_num_vars * (max_degree + 1), 1)), fr_array(max(max_num_vars, 1))
+    mclaims, final = fr_array(n), fr_array(1)
+    _ck(lib().jolt_host_prove_batch_ops(self.h, hs, C.c_size_t(n), _p(ic), _p(co), offs, C.c_size_t(max_num_vars), C.c_size_t(max_degree), C.c_uint64(label),
+                                        C.c_int32(challenge_mode), _p(polys), _p(chal), _p(mclaims), _p(final)), "jolt_host_prove_batch_ops", self)
+    return dict(polys=polys[: max_num_vars * (max_degree + 1)].reshape(max_num_vars, max_degree + 1, 4), challenges=chal[:max_num_vars], member_claims=mclaims, final_claim=final[0])
+
+
+def _stage_spartan_uniskip_sums(self, cols, tau, a_weights, b_weights, streams):
+    wa = np.ascontiguousarray(a_weights, dtype=np.int64).reshape(-1, streams, 1 + len(cols))
+    wb = np.ascontiguousarray(b_weights, dtype=np.int64).reshape(-1, streams, 1 + len(cols))
+    t = fr(tau).reshape(-1, 4)
+    out = fr_array(wa.shape[0])
+    _ck(lib().jolt_stage_spartan_uniskip_sums(self.h, _handles(cols), C.c_size_t(len(cols)), C.c_uint32(streams), _p(t), C.c_size_t(t.shape[0]), wa.ctypes.data_as(C.c_void_p),
+                                              wb.ctypes.data_as(C.c_void_p), C.c_size_t(wa.shape[0]), _p(out)), "jolt_stage_spartan_uniskip_sums", self)
+    return out
+
+
+def _stage_spartan_remainder(self, cols, fa, fb, tau, scale, streams):
+    wa, wb = fr(fa).reshape(streams, 1 + len(cols), 4), fr(fb).reshape(streams, 1 + len(cols), 4)
+    t = fr(tau).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_spartan_remainder_create(self.h, _handles(cols), C.c_size_t(len(cols)), C.c_uint32(streams), _p(wa), _p(wb), _p(t), C.c_size_t(t.shape[0]),
+                                                  _p(fr(scale)) if scale is not None else None, C.byref(h)), "jolt_stage_spartan_remainder_create", self)
+    return StageOp(self, h, keep=cols)
+
+
+def _stage_ram_read_write(self, addresses, pre, post, inc, val_init, tau_low, gamma):
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_ram_read_write_create(self.h, addresses.h, pre.h, post.h, inc.h, val_init.h, _p(fr(tau_low).reshape(-1, 4)), _p(fr(gamma)), C.byref(h)),
+        "jolt_stage_ram_read_write_create", self)
+    return StageOp(self, h, keep=[addresses, pre, post, inc, val_init])
+
+
+def _stage_registers_read_write(self, regs, rs1_val, rs2_val, rd_pre, rd_post, inc, r_cycle, gamma):
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_registers_read_write_create(self.h, regs.h, rs1_val.h, rs2_val.h, rd_pre.h, rd_post.h, inc.h, _p(fr(r_cycle).reshape(-1, 4)), _p(fr(gamma)), C.byref(h)),
+        "jolt_stage_registers_read_write_create", self)
+    return StageOp(self, h, keep=[regs, rs1_val, rs2_val, rd_pre, rd_post, inc])
+
+
+def _stage_booleanity_address(self, cols, reference_cycle, reference_address, gamma):
+    rc = fr(reference_cycle).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_booleanity_address_create(self.h, cols.h, _p(rc), C.c_size_t(rc.shape[0]), _p(fr(reference_address).reshape(-1, 4)), _p(fr(gamma)), C.byref(h)),
+        "jolt_stage_booleanity_address_create", self)
+    return StageOp(self, h, keep=[cols])
+
+
+def _stage_hamming_weight(self, cols, r_cycle, r_address, virtualization_points, gamma):
+    rc = fr(r_cycle).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_hamming_weight_create(self.h, cols.h, _p(rc), C.c_size_t(rc.shape[0]), _p(fr(r_address).reshape(-1, 4)),
+                                               _p(np.ascontiguousarray(virtualization_points, dtype=np.uint64).reshape(-1, 4)), _p(fr(gamma)), C.byref(h)),
+        "jolt_stage_hamming_weight_create", self)
+    return StageOp(self, h, keep=[cols])
+
+
+def _stage_instruction_read_raf(self, rows, claim_columns, r_reduction, gamma, table_present, ra_count):
+    rr = fr(r_reduction).reshape(-1, 4)
+    present = np.zeros(NUM_LOOKUP_TABLES, dtype=np.uint8)
+    present[: len(table_present)] = np.asarray(table_present, dtype=np.uint8)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_instruction_read_raf_create(self.h, rows.h, claim_columns.h, _p(rr), C.c_size_t(rr.shape[0]), _p(fr(gamma)), _p(present), C.c_uint32(ra_count), C.byref(h)),
+        "jolt_stage_instruction_read_raf_create", self)
+    return StageOp(self, h, keep=[rows, claim_columns])
+
+
+def _stage_bytecode_read_raf_address(self, pc_index, stage_points, stage_values, gamma, first_pc, entry_index):
+    sp = np.ascontiguousarray(stage_points, dtype=np.uint64).reshape(5, -1, 4)
+    sv = np.ascontiguousarray(stage_values, dtype=np.uint64).reshape(5, -1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_bytecode_read_raf_address_create(self.h, pc_index.h, _p(sp), C.c_size_t(sp.shape[1]), _p(sv), _p(fr(gamma)), C.c_uint64(int(first_pc)),
+                                                          C.c_uint64(int(entry_index)), C.byref(h)), "jolt_stage_bytecode_read_raf_address_create", self)
+    return StageOp(self, h, keep=[pc_index])
+
+
+def _stage_bytecode_read_raf_cycle(self, address_op, pc_chunks, chunk_bits):
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_bytecode_read_raf_cycle_create(self.h, address_op.h, pc_chunks.h, C.c_uint32(chunk_bits), C.byref(h)), "jolt_stage_bytecode_read_raf_cycle_create", self)
+    return StageOp(self, h, keep=[pc_chunks])
+
+
+def _stage_ram_raf_evaluation(self, ram_index, tau_low, lowest_address):
+    t = fr(tau_low).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_ram_raf_evaluation_create(self.h, ram_index.h, _p(t), C.c_size_t(t.shape[0]), C.c_uint64(int(lowest_address)), C.byref(h)),
+        "jolt_stage_ram_raf_evaluation_create", self)
+    return StageOp(self, h, keep=[ram_index])
+
+
+def _stage_ram_output_check(self, ram_index, post_values, val_init, val_io, io_lo, io_len, r_address):
+    vi, vo = np.ascontiguousarray(val_init, dtype=np.uint64), np.ascontiguousarray(val_io, dtype=np.uint64)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_ram_output_check_create(self.h, ram_index.h, post_values.h, _p(vi), _p(vo), C.c_uint64(int(io_lo)), C.c_uint64(int(io_len)), _p(fr(r_address).reshape(-1, 4)),
+                                                 C.byref(h)), "jolt_stage_ram_output_check_create", self)
+    return StageOp(self, h, keep=[ram_index, post_values])
+
+
+Context.prove_batch_ops = _prove_batch_ops
+Context.stage_spartan_uniskip_sums = _stage_spartan_uniskip_sums
+Context.stage_spartan_remainder = _stage_spartan_remainder
+Context.stage_ram_read_write = _stage_ram_read_write
+Context.stage_registers_read_write = _stage_registers_read_write
+Context.stage_booleanity_address = _stage_booleanity_address
+Context.stage_hamming_weight = _stage_hamming_weight
+Context.stage_instruction_read_raf = _stage_instruction_read_raf
+Context.stage_bytecode_read_raf_address = _stage_bytecode_read_raf_address
+Context.stage_bytecode_read_raf_cycle = _stage_bytecode_read_raf_cycle
+Context.stage_ram_raf_evaluation = _stage_ram_raf_evaluation
+Context.stage_ram_output_check = _stage_ram_output_check

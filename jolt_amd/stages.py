@@ -605,153 +605,131 @@ class DeviceExtended:
         self.claims["lookup"] = None  # taken from the first proof's first address message (same every proof)
         ctx.synchronize()
 
-    # ---- the operators ---------------------------------------------------------------------------------------------------------
+    # ---- the operators: each one a jolt_stage_op (csrc/stage_ops.hip) -- created (= the slot's PrepareKernel::prepare), driven through the ProveRounds contract by a
+    # ---- driver of the library (prove_batch over operators, or alone against a test transcript), asked for its output claims, destroyed.  Nothing else happens here.
+    def _alone(self, op, claim, label):
+        tr = self.ffi.HostTranscript(label)
+        out = op.prove_alone(tr, claim)
+        tr.close()
+        return out
+
+    def _batch(self, op, claim, rounds, degree, label):
+        out = self.ctx.prove_batch_ops([op], [claim], [self.one], [0], rounds, degree, label=label)
+        return dict(polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+
     def spartan(self, cols, iwa, iwb, fa, fb, tau, kernel, claim, streams, label):
         ctx, ffi = self.ctx, self.ffi
-        eq = ctx.eq_evals(tau)
-        sums = ctx.r1cs_uniskip_sums_small(cols, eq, iwa, iwb, streams=streams)
-        eq.free()
+        sums = ctx.stage_spartan_uniskip_sums(cols, tau, iwa, iwb, streams)
         tr = ffi.HostTranscript(label)
         tr.append(sums)
         r0 = tr.challenge()  # the uni-skip challenge (the Lagrange weights of the remainder are a function of it; fixed weights here)
         tr.close()
-        az, bz = ctx.r1cs_materialize_small(cols, fa, fb, streams=streams)
-        member = ctx.member_split_eq_product(az, bz, tau, scale=kernel)
-        rounds = len(tau)
-        out = ctx.prove_batch([member], [claim], [self.one], [0], rounds, 3, label=label + 1)
-        member.destroy()
-        point = out["challenges"][rounds - self.n_vars:][::-1]  # the cycle coordinates, most significant first
-        values = ctx.ints_evaluate(cols, point)
+        op = ctx.stage_spartan_remainder(cols, fa, fb, tau, kernel, streams)
+        out = self._batch(op, claim, len(tau), 3, label + 1)
+        values = op.output_claims()
+        op.destroy()
         return dict(sums=sums, r0=r0, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], values=values)
 
     def ram_read_write(self, label):
-        global _sub
-        ctx, ffi, d = self.ctx, self.ffi, self.d
-        ram = d["ram"]
-        inc, val_init = ctx.table_from_ints(self.ram_inc), ctx.table_from_ints(self.ram_val_init)
-        m = ctx.rw_matrix(self.ram_cols[0], self.ram_cols[1], self.ram_cols[2], inc, val_init, d["ram_tau"], d["ram_gamma"])
-        inc.free()
-        val_init.free()
-        tr = ffi.HostTranscript(label)
-        _sub = ffi.host_fr_sub
-        out = rw_rounds(lambda rnd, bind: m.prove_round(bind), m.finish, m.final_values, ram["log_t"], ram["log_k"], self.claims["ram"], tr, ffi.host_gruen_poly_deg_3,
-                        ffi.host_univariate_from_evals, ffi.host_univariate_evaluate)
-        tr.close()
-        m.free()
+        d = self.d
+        op = self.ctx.stage_ram_read_write(self.ram_cols[0], self.ram_cols[1], self.ram_cols[2], self.ram_inc, self.ram_val_init, d["ram_tau"], d["ram_gamma"])
+        out = self._alone(op, self.claims["ram"], label)
+        out["final_values"] = op.output_claims()
+        op.destroy()
         return out
 
     def registers_read_write(self, label):
-        global _sub
-        ctx, ffi, d = self.ctx, self.ffi, self.d
-        reg = d["registers"]
-        log_t, log_k = reg["log_t"], reg["log_k"]
-        inc = ctx.table_from_ints(self.reg_inc)
-        m = ctx.registers_rw(self.reg_idx, *self.reg_cols, inc, d["registers_r_cycle"], d["registers_gamma"])
-        inc.free()
-        tr = ffi.HostTranscript(label)
-        _sub = ffi.host_fr_sub
-        out = rw_rounds(lambda rnd, bind: m.prove_round(bind), m.finish, m.final_values, log_t, log_k, self.claims["registers"], tr, ffi.host_gruen_poly_deg_3,
-                        ffi.host_univariate_from_evals, ffi.host_univariate_evaluate, four_point_address=True)
-        tr.close()
-        m.free()
-        # RegistersReadWriteOutputClaims::{rs1_ra, rs2_ra}: the index columns evaluated at the bound point (r_address, r_cycle) = the reversed halves of the challenges
-        r_cycle = out["challenges"][:log_t][::-1]
-        eq_adr = ctx.upload(ffi.host_eq_evals(out["challenges"][log_t:][::-1]))
-        claims = []
-        for p in (0, 1):
-            col = self.reg_idx.materialize(p, eq_adr)
-            claims.append(ctx.evaluate(col, r_cycle))
-            col.free()
-        eq_adr.free()
-        out["operand_claims"] = np.stack(claims)
+        d = self.d
+        op = self.ctx.stage_registers_read_write(self.reg_idx, *self.reg_cols, self.reg_inc, d["registers_r_cycle"], d["registers_gamma"])
+        out = self._alone(op, self.claims["registers"], label)
+        claims = op.output_claims()
+        op.destroy()
+        out["final_values"], out["operand_claims"] = claims[:5], claims[5:7]  # RegistersReadWriteOutputClaims::{rs1_ra, rs2_ra} last
         return out
 
     def booleanity_address(self, label):
-        ctx, ffi, bo = self.ctx, self.ffi, self.d["booleanity"]
-        eq = ctx.eq_evals(bo["reference_cycle"])
-        g = self.bool_cols.pushforward(eq)  # cycle_pushforward (booleanity.rs:152-237): the only T-scale work of the phase
-        eq.free()
-        masses = g.download().reshape(bo["cols"].shape[0], 1 << bo["log_k"], 4)
-        g.free()
-        tr = ffi.HostTranscript(label)
-        out = booleanity_address_rounds(ffi.HostBooleanityAddress(masses, bo["gamma"], bo["reference_address"]), bo["log_k"], tr, ffi.host_univariate_from_evals,
-                                        ffi.host_univariate_evaluate)
-        tr.close()
-        out["masses"] = masses
+        bo = self.d["booleanity"]
+        op = self.ctx.stage_booleanity_address(self.bool_cols, bo["reference_cycle"], bo["reference_address"], bo["gamma"])
+        out = self._alone(op, np.zeros(4, dtype=np.uint64), label)
+        out["intermediate"] = op.output_claims()[0]
+        out["masses"] = op.kept("masses").reshape(bo["cols"].shape[0], 1 << bo["log_k"], 4)
+        op.destroy()
         return out
 
     def hamming_weight(self, label):
-        ctx, ffi, bo, hw = self.ctx, self.ffi, self.d["booleanity"], self.d["hamming"]
-        eq = ctx.eq_evals(hw["r_cycle"])
-        g = self.bool_cols.pushforward(eq)  # FamilySelectors::pushforwards (hamming_weight_claim_reduction.rs:83-117): all RA columns against ONE eq table
-        eq.free()
-        masses = g.download().reshape(bo["cols"].shape[0], 1 << bo["log_k"], 4)
-        g.free()
-        tr = ffi.HostTranscript(label)
-        out = hamming_weight_rounds(ffi.HostHammingWeight(masses, hw["gamma"], hw["r_address"], hw["virtualization_points"]), bo["log_k"], tr, ffi.host_univariate_from_evals,
-                                    ffi.host_univariate_evaluate, ffi.host_fr_sub)
-        tr.close()
-        out["masses"] = masses
+        bo, hw = self.d["booleanity"], self.d["hamming"]
+        op = self.ctx.stage_hamming_weight(self.bool_cols, hw["r_cycle"], hw["r_address"], hw["virtualization_points"], hw["gamma"])
+        claim = op.input_claim()
+        out = self._alone(op, claim, label)
+        out["claim"] = claim
+        out["g_claims"] = op.output_claims()
+        out["masses"] = op.kept("masses").reshape(bo["cols"].shape[0], 1 << bo["log_k"], 4)
+        op.destroy()
         return out
 
     def instruction_read_raf(self, label):
-        """OptimizedInstructionReadRafKernel round for round: 16 x (condense, scan on the device; 8 address rounds on the host), then the cycle rounds"""
-        ctx, ffi, d = self.ctx, self.ffi, self.d
-        lk, rr = d["lookup"], self.read_raf
-        tr = ffi.HostTranscript(label)
-        u = ctx.eq_evals(d["lookup_reduction"])  # the per-cycle mass eq(r_reduction, j) every phase condenses
+        """OptimizedInstructionReadRafKernel as ONE operator of 128 + log T rounds; the address rounds run against the test transcript `label`, the cycle rounds as a
+        one-member batch under `label + 1` (two windows of the operator), as the oracle twin does"""
+        ctx, d = self.ctx, self.d
+        lk = d["lookup"]
         present = np.zeros(N_LOOKUP_TABLES, dtype=np.uint8)
         present[lk["present"]] = 1
-        state = ffi.HostReadRafAddress(d["lookup_gamma"], present)
-        claim = self.claims["lookup"]
-        v_tables, scans, messages, challenges = [], [], [], []
-        for phase in range(PHASES):
-            suffix_len = ADDRESS_BITS - 8 * (phase + 1)
-            if phase:
-                rr.condense(u, v_tables[-1], suffix_len + 8)
-            raf, suf = rr.phase_scan(u, suffix_len, ADDRESS_BITS, self.lookup_lists)
-            state.init_phase(phase, raf, suf)
-            if claim is None:  # the relation's input claim (the prover holds it from the earlier stages): s_0(0) + s_0(1) summed from the tables, once
-                e = state.message()
-                claim = self.claims["lookup"] = ffi.host_fr_add(e[0], e[1])
-            claim, coeffs, chal = state.prove_phase(claim, tr)
-            scans.append((raf, suf))
-            messages.append(coeffs)
-            challenges.append(chal)
-            v_tables.append(state.v_table(phase))
-        u.free()
-        vt = np.stack(v_tables)
-        table_values, raf_interleaved, raf_identity = state.finish()
-        state.close()
-        combined, ra = rr.cycle_tables(table_values, raf_interleaved, raf_identity, vt, ADDRESS_BITS, d["ra_count"])
+        op = ctx.stage_instruction_read_raf(self.read_raf, self.lookup_claim_columns, d["lookup_reduction"], d["lookup_gamma"], present, d["ra_count"])
+        if self.claims["lookup"] is None:  # the relation's input claim (the prover holds it from the earlier stages): summed from the first phase's tables, once
+            self.claims["lookup"] = op.input_claim()
+        address, cycle = op.window(0, ADDRESS_BITS), op.window(ADDRESS_BITS, self.n_vars)
+        adr = self._alone(address, self.claims["lookup"], label)
         n_f = 1 + d["ra_count"]
-        member = ctx.member_lc([combined] + ra, [[(None, [(self.one, i)]) for i in range(n_f)]], n_f, eq_point=d["lookup_reduction"])
-        out = ctx.prove_batch([member], [claim], [self.one], [0], self.n_vars, n_f + 1, label=label + 1)  # its round check holds only if the address rounds were right
-        instruction_ra = member.final_values()[1:n_f]  # output_claims (:1376-1456): the bound ra_i ...
-        member.destroy()
-        # ... and the flag claims at the normalized cycle point: masses of eq(r_cycle, .) per lookup table and over the RAF rows -- one pushforward of the packed claim column
-        eq_cycle = ctx.eq_evals(out["challenges"][::-1])
-        flags = self.lookup_claim_columns.pushforward(eq_cycle)
-        flag_claims = flags.download().reshape(4, 16, 4)
-        flags.free()
-        eq_cycle.free()
-        tr.close()
-        return dict(lookup_table_flags=flag_claims[:3].reshape(48, 4)[lk["present"]], instruction_raf_flag=flag_claims[3][0], instruction_ra=instruction_ra, scans=scans, address_polys=np.concatenate(messages), address_challenges=np.concatenate(challenges), v_tables=vt, table_values=table_values[lk["present"]],
-                    raf_values=np.stack([raf_interleaved, raf_identity]), cycle_claim=claim, polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+        out = self._batch(cycle, adr["final_claim"], self.n_vars, n_f + 1, label + 1)  # its round check holds only if the address rounds were right
+        claims = op.output_claims()
+        n_present = int(present.sum())
+        raf_scans = op.kept("scan_raf").reshape(PHASES, 6, CHUNK, 4)
+        suf_scans = op.kept("scan_suffix").reshape(PHASES, -1, CHUNK, 4)
+        res = dict(lookup_table_flags=claims[:n_present], instruction_raf_flag=claims[n_present], instruction_ra=claims[n_present + 1:],
+                   scans=[(raf_scans[ph], suf_scans[ph]) for ph in range(PHASES)], address_polys=np.stack(adr["polys"]), address_challenges=adr["challenges"],
+                   v_tables=op.kept("v_tables").reshape(PHASES, CHUNK, 4), table_values=op.kept("table_values")[lk["present"]], raf_values=op.kept("raf_values"),
+                   cycle_claim=op.kept("cycle_claim")[0], polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"])
+        address.destroy()
+        cycle.destroy()
+        op.destroy()
+        return res
 
     def address_domain(self, label):
         """the joint-domain relations whose rounds run over K-sized tables: bytecode read+RAF (6a, 6b), RAM RAF evaluation, RAM output check.  The key indexes are
         per-proof work (the reference builds its PC rows / RamAccessColumns once per proof and shares them through the session)"""
-        ctx, d = self.ctx, self.d
-        ram, bc = d["ram"], d["bytecode"]
-        indexes = {"pc": ctx.key_index(self.pc_ints, 1 << bc["log_k"]), "ram": ctx.key_index(self.ram_cols[0], 1 << ram["log_k"]), "ram_post": self.ram_cols[2]}
-        ops = DeviceOps(ctx, self.ffi, indexes, self.pc_chunks)
-        out = {"bytecode_read_raf": bytecode_read_raf(ops, bc, self.n_vars, label),
-               "ram_raf_evaluation": ram_raf_evaluation(ops, ram, d["ram_raf"], label + 10),
-               "ram_output_check": ram_output_check(ops, ram, d["ram_output"], label + 20)}
-        indexes["pc"].free()
-        indexes["ram"].free()
-        return out
+        ctx, d, n_vars = self.ctx, self.d, self.n_vars
+        ram, bc, raf, io = d["ram"], d["bytecode"], d["ram_raf"], d["ram_output"]
+        pc_index, ram_index = ctx.key_index(self.pc_ints, 1 << bc["log_k"]), ctx.key_index(self.ram_cols[0], 1 << ram["log_k"])
+        # ---- 6a / 6b: bytecode read + RAF
+        first_pc = int(bc["first_pc"]) if "first_pc" in bc else int(bc["push_pc"][0])
+        a_op = ctx.stage_bytecode_read_raf_address(pc_index, bc["stage_points"], bc["stage_values"], bc["gamma"], first_pc, bc["entry_index"])
+        claim_a = a_op.input_claim()
+        adr = self._batch(a_op, claim_a, bc["log_k"], 2, label)
+        fin = a_op.output_claims()  # the 13 bound tables, then the intermediate claim
+        c_op = ctx.stage_bytecode_read_raf_cycle(a_op, self.pc_chunks, bc["chunk_bits"])
+        claim_c = c_op.input_claim()
+        cyc = self._batch(c_op, claim_c, n_vars, c_op.degree, label + 1)
+        bytecode = dict(address=adr, claim_address=claim_a, intermediate=fin[13], val_stages=fin[5:10], r_address=adr["challenges"][::-1], cycle=cyc, claim_cycle=claim_c,
+                        ra_claims=c_op.output_claims())
+        c_op.destroy()
+        a_op.destroy()
+        # ---- stage 2: RAM RAF evaluation
+        op = ctx.stage_ram_raf_evaluation(ram_index, raf["tau_low"], raf["lowest_address"])
+        claim = op.input_claim()
+        raf_out = self._batch(op, claim, ram["log_k"], 2, label + 10)
+        raf_out["claim"] = claim
+        raf_out["ra_claim"] = op.output_claims()[0]
+        op.destroy()
+        # ---- stage 2: RAM output check
+        op = ctx.stage_ram_output_check(ram_index, self.ram_cols[2], ram["val_init"], io["val_io"], io["io_lo"], io["io_len"], io["point"])
+        claim = op.input_claim()
+        oc = self._batch(op, claim, ram["log_k"], 3, label + 20)
+        oc["claim"] = claim
+        oc["val_final_claim"] = op.output_claims()[0]
+        op.destroy()
+        pc_index.free()
+        ram_index.free()
+        return {"bytecode_read_raf": bytecode, "ram_raf_evaluation": raf_out, "ram_output_check": oc}
 
     def prove(self, label=0):
         d = self.d

@@ -92,6 +92,10 @@ pub struct jolt_comm {
 pub struct jolt_shm {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct jolt_stage_op {
+    _private: [u8; 0],
+}
 
 /// Status codes (`enum` of the header); see `crate::status` for the mapping onto the reference's error types.
 pub const JOLT_OK: i32 = 0;
@@ -323,6 +327,7 @@ extern "C" {
     pub fn jolt_host_read_raf_address_init_phase(h: *mut jolt_read_raf_address, phase: u32, raf_sums: *const jolt_fr_t, suffix_sums: *const jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_message(h: *mut jolt_read_raf_address, previous_claim: *const jolt_fr_t, evals_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_bind(h: *mut jolt_read_raf_address, challenge: *const jolt_fr_t, phase_done: *mut i32) -> i32;
+    pub fn jolt_host_read_raf_address_bind_message(h: *mut jolt_read_raf_address, challenge: *const jolt_fr_t, previous_claim: *const jolt_fr_t, evals_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_prove_phase(h: *mut jolt_read_raf_address, claim: *mut jolt_fr_t, r#fn: jolt_round_transcript_fn, user: *mut c_void, test_transcript: *mut jolt_host_transcript, coeffs_out: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_v_table(h: *const jolt_read_raf_address, phase: u32, out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_read_raf_address_finish(h: *const jolt_read_raf_address, table_values: *mut jolt_fr_t, raf_interleaved: *mut jolt_fr_t, raf_identity: *mut jolt_fr_t) -> i32;
@@ -389,4 +394,26 @@ extern "C" {
     pub fn jolt_msm_g1_table_subtree(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, rank: i32, world: i32, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_joint_polynomial_subtree(ctx: *mut jolt_ctx, sources: *const *const jolt_onehot, n_sources: usize, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, log_k: u32, rank: i32, world: i32, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_host_hyperkzg_open_subtree(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_stage_op_num_rounds(op: *const jolt_stage_op, rounds: *mut usize) -> i32;
+    pub fn jolt_stage_op_degree(op: *const jolt_stage_op, degree: *mut usize) -> i32;
+    pub fn jolt_stage_op_input_claim(op: *mut jolt_stage_op, claim: *mut jolt_fr_t) -> i32;
+    pub fn jolt_stage_op_prove_round(op: *mut jolt_stage_op, bind: *const jolt_fr_t, round: usize, previous_claim: *const jolt_fr_t, coeffs_out: *mut jolt_fr_t, cap: usize, n_coeffs: *mut usize) -> i32;
+    pub fn jolt_stage_op_finish_rounds(op: *mut jolt_stage_op, bind: *const jolt_fr_t) -> i32;
+    pub fn jolt_stage_op_output_claims(op: *mut jolt_stage_op, out: *mut jolt_fr_t, cap: usize, n: *mut usize) -> i32;
+    pub fn jolt_stage_op_kept(op: *const jolt_stage_op, key: *const c_char, out: *mut jolt_fr_t, cap: usize, n: *mut usize) -> i32;
+    pub fn jolt_stage_op_window(parent: *mut jolt_stage_op, first: usize, n: usize, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_op_destroy(op: *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_spartan_uniskip_sums(ctx: *mut jolt_ctx, cols: *const *const jolt_ints, n_cols: usize, n_streams: u32, tau: *const jolt_fr_t, n_tau: usize, a_weights: *const i64, b_weights: *const i64, n_nodes: usize, sums_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_stage_spartan_remainder_create(ctx: *mut jolt_ctx, cols: *const *const jolt_ints, n_cols: usize, n_streams: u32, a_weights: *const jolt_fr_t, b_weights: *const jolt_fr_t, tau: *const jolt_fr_t, n_tau: usize, scale: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_ram_read_write_create(ctx: *mut jolt_ctx, addresses: *const jolt_ints, pre_values: *const jolt_ints, post_values: *const jolt_ints, inc: *const jolt_ints, val_init: *const jolt_ints, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_registers_read_write_create(ctx: *mut jolt_ctx, regs: *const jolt_onehot, rs1_val: *const jolt_ints, rs2_val: *const jolt_ints, rd_pre: *const jolt_ints, rd_post: *const jolt_ints, inc: *const jolt_ints, r_cycle: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_booleanity_address_create(ctx: *mut jolt_ctx, cols: *const jolt_onehot, reference_cycle: *const jolt_fr_t, n_cycle: usize, reference_address: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_hamming_weight_create(ctx: *mut jolt_ctx, cols: *const jolt_onehot, r_cycle: *const jolt_fr_t, n_cycle: usize, r_address: *const jolt_fr_t, virtualization_points: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_instruction_read_raf_create(ctx: *mut jolt_ctx, rows: *mut jolt_read_raf, claim_columns: *const jolt_onehot, r_reduction: *const jolt_fr_t, n_vars: usize, gamma: *const jolt_fr_t, table_present: *const u8, ra_count: u32, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_bytecode_read_raf_address_create(ctx: *mut jolt_ctx, pc_index: *const jolt_key_index, stage_points: *const jolt_fr_t, n_vars: usize, stage_values: *const jolt_fr_t, gamma: *const jolt_fr_t, first_pc: u64, entry_index: u64, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_bytecode_read_raf_cycle_create(ctx: *mut jolt_ctx, address: *mut jolt_stage_op, pc_chunks: *const jolt_onehot, chunk_bits: u32, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_ram_raf_evaluation_create(ctx: *mut jolt_ctx, ram_index: *const jolt_key_index, tau_low: *const jolt_fr_t, n_vars: usize, lowest_address: u64, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_ram_output_check_create(ctx: *mut jolt_ctx, ram_index: *const jolt_key_index, post_values: *const jolt_ints, val_init: *const u64, val_io: *const u64, io_lo: u64, io_len: u64, r_address: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_host_prove_batch_ops(ctx: *mut jolt_ctx, ops: *const *mut jolt_stage_op, n_ops: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, offsets: *const usize, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_stage_op_prove_alone(op: *mut jolt_stage_op, transcript: *mut jolt_host_transcript, claim: *mut jolt_fr_t, coeffs_out: *mut jolt_fr_t, stride: usize, n_coeffs_out: *mut u32, challenges_out: *mut jolt_fr_t) -> i32;
 }

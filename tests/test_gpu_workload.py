@@ -184,9 +184,10 @@ def test_rows_handle_is_refused_before_its_copy_has_been_waited_for():
         assert e.value.status == 1 and "jolt_rows_upload_wait" in str(e.value), str(e.value)  # JOLT_ERR_INVALID_ARG
     rows.wait()
     col = rows.ints(8, 8)
-    assert np.array_equal(col.download(), buf.array[:, 8:16].copy().view(np.uint64).reshape(T))
-    many = rows.ints_many([(0, 8, False), (8, 8, True)])
-    assert np.array_equal(many[1].download().view(np.uint64), col.download())
+    want = ctx.from_u64(buf.array[:, 8:16].copy().view(np.uint64).reshape(T))
+    assert np.array_equal(ctx.table_from_ints(col).download(), want.download())
+    many = rows.ints_many([(0, 8, False), (8, 8, False)])
+    assert np.array_equal(ctx.table_from_ints(many[1]).download(), want.download())
     for v in many + [col]:
         v.free()
     rows.free()
