@@ -872,6 +872,26 @@ int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx *ctx, const jolt_srs *srs, cons
                                         uint64_t transcript_label, int32_t rank, int32_t world, jolt_gather_fn gather, void *user,
                                         jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v, jolt_fr_t *challenges_out);
 
+/* The commitment grid's OPENING HINT -- CommitmentScheme::commit returns (Commitment, OpeningHint) (crates/jolt-openings/src/schemes.rs:60-72): what the committer can
+ * precompute for the opening from the polynomials and the setup alone.  For the grid's one-hot columns: per fold depth s = 1 .. levels (<= 4) the residue-class sums
+ * S_p^(s, c) = sum over the cycles j = c mod 2^s of srs[(hot_p(j) * T + j) >> s] (what jolt_grid_commit_onehot_classes returns to the host), kept on the device.
+ * None of it depends on a challenge.  background != 0: enqueued on the context's lowest-priority stream at one wavefront per SIMD and returned at once -- the sums run
+ * under the latency-bound legs between the commitment and the opening; 0: on the main stream.  jolt_host_hyperkzg_open_grid turns them into the opening's first level
+ * commitments by linearity (same points as scheme.rs:141-145 commits by MSM).  The sources must outlive the hint's sums (jolt_grid_hint_wait, or the opening). */
+typedef struct jolt_grid_hint jolt_grid_hint;
+int32_t jolt_grid_hint_begin(jolt_ctx *ctx, const jolt_srs *srs, const jolt_onehot *const *sources, size_t n_sources, uint32_t levels, int32_t background,
+                             jolt_grid_hint **out);
+int32_t jolt_grid_hint_wait(jolt_ctx *ctx, jolt_grid_hint *hint);
+int32_t jolt_grid_hint_download(jolt_ctx *ctx, jolt_grid_hint *hint, uint32_t level, jolt_g1_t *out /* 2^level x n_cols, [class][column] */); /* test hook */
+int32_t jolt_grid_hint_free(jolt_ctx *ctx, jolt_grid_hint *hint);
+/* HyperKZGScheme::open (crates/jolt-hyperkzg/src/scheme.rs:122-158) of the grid's joint polynomial `evals` (jolt_grid_joint_polynomial over the same sources, scalars and
+ * dense columns) with the first `levels` level commitments by linearity: one-hot part from the hint, dense part as (T >> s)-term MSMs of the dense columns' folds inside
+ * the same MSM pipeline as the remaining levels.  fn == NULL: the library's test transcript under transcript_label.  Proof identical to jolt_host_hyperkzg_open(evals). */
+int32_t jolt_host_hyperkzg_open_grid(jolt_ctx *ctx, const jolt_srs *srs, const jolt_table *evals, const jolt_fr_t *point, size_t ell, uint64_t transcript_label,
+                                     jolt_open_transcript_fn fn, void *user, const jolt_grid_hint *hint, uint32_t levels, const jolt_fr_t *onehot_scalars,
+                                     jolt_table *const *dense, size_t n_dense, const jolt_fr_t *dense_scalars, jolt_g1_t *com, jolt_g1_t *w, jolt_fr_t *v,
+                                     jolt_fr_t *challenges_out);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Stage operators as ProveRounds objects -- one per backend slot (crates/jolt-kernels/src/backend.rs:126-171).
  *

@@ -2,6 +2,7 @@
 // sumcheck members.  (MSM / HyperKZG device pieces live in msm.hip, the host-side mirror in host_mirror.hip.)
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <type_traits>
 
 #include "host_mirror.hpp"
@@ -35,6 +36,16 @@ extern "C" const char* jolt_status_string(int32_t s) {
     return "unknown status";
 }
 extern "C" int32_t jolt_abi_version(void) { return JOLT_HIP_ABI_VERSION; }
+
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and packets of streams that share a queue execute in order: with
+// the main stream, three MSM lanes, the batch stream, the copy stream and the background hint stream, a long background kernel could sit in front of the main stream's
+// latency-bound launches.  Eight queues measured -7 ms per proof at T = 2^22 (profiles/r06_hint_ab.txt).  The runtime reads the variable once, when it initialises --
+// before any HIP call of a process that loads this library first; a caller's own setting wins.
+namespace {
+struct HwQueueDefault {
+    HwQueueDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queue_default;
+}  // namespace
 
 extern "C" int32_t jolt_ctx_create(int32_t device_id, void* stream, jolt_ctx** out) {
     if (!out) return JOLT_ERR_INVALID_ARG;
@@ -165,6 +176,7 @@ extern "C" int32_t jolt_ctx_destroy(jolt_ctx* ctx) {
         if (ctx->msm_host[k]) (void)hipHostFree(ctx->msm_host[k]);
     }
     if (ctx->msm_batch_stream) { (void)hipStreamSynchronize(ctx->msm_batch_stream); (void)hipStreamDestroy(ctx->msm_batch_stream); }
+    if (ctx->hint_stream) { (void)hipStreamSynchronize(ctx->hint_stream); (void)hipStreamDestroy(ctx->hint_stream); }
     if (ctx->msm_batch_ws) (void)hipFree(ctx->msm_batch_ws);
     if (ctx->msm_aux_stream) { (void)hipStreamSynchronize(ctx->msm_aux_stream); (void)hipStreamDestroy(ctx->msm_aux_stream); }
     for (auto& pair : ctx->ev_aux) for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
@@ -185,6 +197,7 @@ extern "C" int32_t jolt_ctx_synchronize(jolt_ctx* ctx) {
     if (!ctx) return JOLT_ERR_INVALID_ARG;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));
     for (int k = 0; k < 3; ++k) if (ctx->side[k]) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side[k]));
+    if (ctx->hint_stream) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->hint_stream));
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return JOLT_OK;
 }

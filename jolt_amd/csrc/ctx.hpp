@@ -55,6 +55,7 @@ struct jolt_ctx {
     void* msm_host[4] = {nullptr, nullptr, nullptr, nullptr};
     // the batch of short MSMs of jolt_internal_msm_many (msm.hip): its own stream, workspace and pinned window sums, beside the four lanes
     hipStream_t msm_batch_stream = nullptr;
+    hipStream_t hint_stream = nullptr;  // lowest priority: the opening hint's class sums (pcs.hip jolt_grid_hint_begin), created at first use
     void* msm_batch_ws = nullptr;
     size_t msm_batch_ws_cap = 0;
     void* msm_batch_host = nullptr;
@@ -94,6 +95,7 @@ struct jolt_ctx {
     bool fuse_tail = false;       // JOLT_FUSE_TAIL=1: pending binds of expr members are applied inside the tail kernel too
     bool msm_lds_attr_set = false;
     bool msm_fx_attr_set = false;
+    bool grid_hint_attr_set = false;  // k_grid_onehot_sum's dynamic-LDS limit raised on this device (pcs.hip: background class sums reserve LDS to stay at one wave per SIMD)
     bool rows_many_attr_set = false;  // k_rows_to_ints_many's dynamic-LDS limit raised on this device (onehot.hip)
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)

@@ -12,6 +12,7 @@
 
 #include "ctx.hpp"
 #include "g1.hip.h"
+#include "grid_hint.hpp"
 #include "host_mirror.hpp"
 #include "poly_kernels.hip.h"
 #include "srs.hpp"
@@ -479,10 +480,25 @@ struct OpenTranscript {
 };
 }  // namespace
 
+// The first level commitments of an opening of the commitment grid's joint polynomial by LINEARITY (docs/kernels.md section 3.7b): the one-hot part from the hint's
+// class sums (grid_hint.hpp; the combination runs on the hint's stream beside the level MSMs), the dense part as MSMs over the dense columns' folds (T >> s terms, in
+// the same pipeline as the other levels' MSMs) -- no host round trip, nothing allocated outside the pool.
+namespace {
+struct GridLinear {
+    const jolt_grid_hint* hint;
+    const jolt_fr_t* onehot_scalars;  // n_cols
+    jolt_table* const* dense;
+    size_t n_dense;
+    const jolt_fr_t* dense_scalars;
+    uint32_t levels;
+};
+}  // namespace
+
 // HyperKZGScheme::open (scheme.rs:122-158) + kzg_open_batch (kzg.rs:69-126)
 static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell, uint64_t transcript_label,
                                   int rank, int world, size_t block, jolt_gather_fn gather, void* user, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out,
-                                  jolt_open_transcript_fn transcript_fn = nullptr, void* transcript_user = nullptr, const jolt_g1_t* known_levels = nullptr, size_t n_known = 0) {
+                                  jolt_open_transcript_fn transcript_fn = nullptr, void* transcript_user = nullptr, const jolt_g1_t* known_levels = nullptr, size_t n_known = 0,
+                                  const GridLinear* lin = nullptr) {
     if (!ctx || !srs || !evals || !point || !w || !v || (ell > 1 && !com)) return JOLT_ERR_INVALID_ARG;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     if (ell == 0) return JOLT_ERR_EMPTY_POINT;
@@ -508,12 +524,67 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
                 return JOLT_ERR_INVALID_ARG;
             }
         }
+        // levels by linearity: the one-hot part's combination goes on the hint's stream now, the dense folds' MSMs join the other levels' below
+        size_t n_lin = 0;
+        G1Jac* d_small = nullptr;
+        void* d_temp = nullptr;
+        std::vector<jolt_table*> dense_levels;
+        jolt_table* dense_rlc = nullptr;
+        auto lin_cleanup = [&]() {
+            if (d_small) jolt_internal_dev_free(ctx, d_small);
+            if (d_temp) jolt_internal_dev_free(ctx, d_temp);
+            for (jolt_table* t : dense_levels) if (t) jolt_table_free(ctx, t);
+            if (dense_rlc) jolt_table_free(ctx, dense_rlc);
+            d_small = nullptr;
+            d_temp = nullptr;
+            dense_levels.clear();
+            dense_rlc = nullptr;
+        };
+        if (lin && lin->hint && world == 1 && n_known == 0) {
+            const jolt_grid_hint* h = lin->hint;
+            size_t log_t = 0;
+            while (((size_t)1 << log_t) < h->cycles) ++log_t;
+            n_lin = std::min<size_t>({(size_t)lin->levels, (size_t)h->levels, coms.size(), log_t ? log_t - 1 : 0});  // (the dense folds exist down to 2 coefficients)
+            if ((size_t)h->k * h->cycles != evals->len || (lin->n_dense && (!lin->dense || !lin->dense_scalars)) || !lin->onehot_scalars) { cleanup(); return JOLT_ERR_INVALID_ARG; }
+            if (n_lin) {
+                std::vector<Fr> sc(h->n_cols), xs(n_lin);
+                for (size_t p = 0; p < h->n_cols; ++p) sc[p] = fr_from_abi(&lin->onehot_scalars[p]);
+                for (size_t b = 0; b < n_lin; ++b) xs[b] = fr_from_abi(&point[ell - 1 - b]);  // fold i uses point[ell - i] (scheme.rs:97-98)
+                s = jolt_internal_grid_hint_combine(ctx, h, (uint32_t)n_lin, sc.data(), xs.data(), &d_small, &d_temp);
+                if (s == JOLT_OK && lin->n_dense) {
+                    for (size_t dd = 0; dd < lin->n_dense && s == JOLT_OK; ++dd)
+                        if (!lin->dense[dd] || lin->dense[dd]->len != h->cycles) s = JOLT_ERR_SIZE_MISMATCH;
+                    if (s == JOLT_OK) s = jolt_rlc(ctx, lin->dense, lin->n_dense, lin->dense_scalars, &dense_rlc);  // the dense part of row 0: T coefficients
+                    if (s == JOLT_OK) {
+                        dense_levels.assign(log_t, nullptr);
+                        s = jolt_hyperkzg_fold(ctx, dense_rlc, point + (ell - log_t), log_t, dense_levels.data());  // its folds by the same low variables
+                    }
+                }
+                if (s != JOLT_OK) { lin_cleanup(); cleanup(); return s; }
+            }
+        }
+        const size_t first_msm = std::max(n_known, n_lin);
         std::vector<const Fr*> ptrs;
         std::vector<size_t> lens;
-        for (size_t i = 1 + n_known; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+        for (size_t i = 1 + first_msm; i < ell; ++i) { ptrs.push_back(polys[i]->data()); lens.push_back(polys[i]->len); }
+        const size_t n_level_msms = ptrs.size();
+        if (n_lin && dense_rlc)
+            for (size_t s_ = 1; s_ <= n_lin; ++s_) { ptrs.push_back(dense_levels[s_]->data()); lens.push_back(dense_levels[s_]->len); }
+        std::vector<G1Jac> msm_out(ptrs.size());
         ctx->msm_full_width_scalars = true;  // folds by challenges: uniform field elements whatever the committed polynomial held
-        s = ptrs.empty() ? JOLT_OK : sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, coms.data() + n_known);
+        s = ptrs.empty() ? JOLT_OK : sharded_msm_many(ctx, srs, ptrs, lens, rank, world, block, gather, user, msm_out.data());
         ctx->msm_full_width_scalars = false;
+        if (s == JOLT_OK && n_lin) {
+            std::vector<G1Jac> small(n_lin);
+            hipError_t e = hipMemcpyAsync(small.data(), d_small, n_lin * sizeof(G1Jac), hipMemcpyDeviceToHost, lin->hint->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(lin->hint->stream);
+            if (e != hipSuccess) { (void)hipGetLastError(); ctx->last_error = std::string("hyperkzg open (levels by linearity): ") + hipGetErrorString(e); s = JOLT_ERR_HIP; }
+            for (size_t i = 0; i < n_lin && s == JOLT_OK; ++i) coms[i] = dense_rlc ? g1_add(small[i], msm_out[n_level_msms + i]) : small[i];
+        } else if (n_lin) {
+            (void)hipStreamSynchronize(lin->hint->stream);  // the combination still reads d_temp
+        }
+        for (size_t i = 0; i < n_level_msms && s == JOLT_OK; ++i) coms[first_msm + i] = msm_out[i];
+        lin_cleanup();
         if (s != JOLT_OK) { cleanup(); return s; }
     }
     Fr r;  // phase 2 (scheme.rs:148-152)
@@ -915,6 +986,18 @@ extern "C" int32_t jolt_host_hyperkzg_open_with_levels(jolt_ctx* ctx, const jolt
                                                        uint64_t transcript_label, jolt_open_transcript_fn fn, void* user, const jolt_g1_t* known_levels, size_t n_known,
                                                        jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v, jolt_fr_t* challenges_out) {
     return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out, fn, user, known_levels, n_known);
+}
+
+// The opening of the commitment grid's joint polynomial (jolt_grid_joint_polynomial: `evals`, 2^ell = K * T coefficients) with its first `levels` level commitments
+// by linearity from the commit-time hint (jolt_grid_hint_begin over the same one-hot sources, onehot_scalars in their column order) and the dense columns
+// (`dense` of T entries each with dense_scalars: the same arguments jolt_grid_joint_polynomial took).  The same proof as jolt_host_hyperkzg_open of `evals`.
+extern "C" int32_t jolt_host_hyperkzg_open_grid(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* evals, const jolt_fr_t* point, size_t ell, uint64_t transcript_label,
+                                                jolt_open_transcript_fn fn, void* user, const jolt_grid_hint* hint, uint32_t levels, const jolt_fr_t* onehot_scalars,
+                                                jolt_table* const* dense, size_t n_dense, const jolt_fr_t* dense_scalars, jolt_g1_t* com, jolt_g1_t* w, jolt_fr_t* v,
+                                                jolt_fr_t* challenges_out) {
+    if (!hint || !onehot_scalars || hint->ctx != ctx) return JOLT_ERR_INVALID_ARG;
+    const GridLinear lin{hint, onehot_scalars, dense, n_dense, dense_scalars, levels};
+    return hyperkzg_open_impl(ctx, srs, evals, point, ell, transcript_label, 0, 1, 0, nullptr, nullptr, com, w, v, challenges_out, fn, user, nullptr, 0, &lin);
 }
 
 // The same opening with its MSMs sharded over `world` ranks by term range (every rank holds the polynomial and the SRS; `gather` is a

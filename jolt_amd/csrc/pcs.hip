@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "grid_hint.hpp"
 #include "ints.hpp"
 #include "msm_kernels.hip.h"
 #include "onehot.hpp"
@@ -83,13 +84,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JOLT_BUC
     const G1Jac total = wave_sum_g1(mine, 64);
     if ((threadIdx.x & 63) == 0) partial[((cls * gridDim.y + p) * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)] = total;
 }
-// out[p] = sum of the column's `count` partial sums (one wavefront per column)
-__global__ __launch_bounds__(64) void k_grid_onehot_fold(const G1Jac* __restrict__ partial, uint32_t count, G1Jac* __restrict__ out) {
+// out[..] = sum of the column's `count` partial sums (one wavefront per (class, column)); blockIdx.x = cls * n_cols + p lands at out[cls * out_cols + first + p]
+// (out_cols = n_cols, first = 0: out[blockIdx.x]; otherwise the columns of one source inside a row of all the sources' columns: jolt_grid_hint)
+__global__ __launch_bounds__(64) void k_grid_onehot_fold(const G1Jac* __restrict__ partial, uint32_t count, G1Jac* __restrict__ out, uint32_t n_cols, uint32_t out_cols,
+                                                         uint32_t first) {
     const size_t p = blockIdx.x;
     G1Jac acc = g1_identity();
     for (uint32_t k = threadIdx.x; k < count; k += 64) acc = g1_add(acc, partial[p * count + k]);
     acc = wave_sum_g1(acc, 64);
-    if (threadIdx.x == 0) out[p] = acc;
+    if (threadIdx.x == 0) out[(p / n_cols) * out_cols + first + (p % n_cols)] = acc;
+}
+// out[level] = sum_i scalars[i] * points[i] over the few hundred (class, column) terms of one level of a grid hint: one lane per term (MSB-first double-and-add over the
+// canonical scalar), wavefront sums, one workgroup per level (blockIdx.x); the terms of level l are [offsets[l], offsets[l + 1])
+__global__ __launch_bounds__(1024) void k_grid_hint_combine(const G1Jac* __restrict__ points, const Fr* __restrict__ scalars, const uint32_t* __restrict__ offsets,
+                                                            G1Jac* __restrict__ out) {
+    __shared__ G1Jac wave_total[16];
+    const uint32_t lo = offsets[blockIdx.x], hi = offsets[blockIdx.x + 1];
+    G1Jac acc = g1_identity();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const Fr k = from_mont(scalars[i]);
+        acc = g1_add(acc, g1_mul_canonical(points[i], k.l));
+    }
+    acc = wave_sum_g1(acc, 64);
+    if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        G1Jac total = wave_total[0];
+        for (uint32_t w = 1; w < (blockDim.x >> 6); ++w) total = g1_add(total, wave_total[w]);
+        out[blockIdx.x] = total;
+    }
 }
 
 constexpr int kJointMaxSources = 4;
@@ -278,13 +301,189 @@ static int32_t grid_commit_onehot_impl(jolt_ctx* ctx, const jolt_srs* srs, const
     else
         hipLaunchKernelGGL(k_grid_onehot_sum<false>, dim3(blocks, (unsigned)N, (unsigned)classes), dim3(kBlock), 0, ctx->stream, (const uint8_t*)source->idx, source->wide, T, cycle_lo,
                            cycle_hi, (const G1Affine*)srs->pts, partial, lc, shift);
-    hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)(classes * N)), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums);
+    hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)(classes * N)), dim3(64), 0, ctx->stream, (const G1Jac*)partial, per_col, sums, (uint32_t)N, (uint32_t)N, 0u);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, sums, classes * N * sizeof(G1Jac), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     jolt_internal_dev_free(ctx, partial);
     jolt_internal_dev_free(ctx, sums);
     if (e != hipSuccess) { ctx->last_error = std::string("grid one-hot commit: ") + hipGetErrorString(e); return JOLT_ERR_HIP; }
+    return JOLT_OK;
+}
+
+// ---- the opening hint of the grid's one-hot columns (grid_hint.hpp) ------------------------------------------------------------------------------------------
+static int32_t hint_stream_of(jolt_ctx* ctx, hipStream_t* out) {
+    if (!ctx->hint_stream) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);  // numerically lowest = highest priority
+        if (hipStreamCreateWithPriority(&ctx->hint_stream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
+            JOLT_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->hint_stream, hipStreamNonBlocking));
+        }
+    }
+    *out = ctx->hint_stream;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_grid_hint_free(jolt_ctx* ctx, jolt_grid_hint* h) {
+    if (!h) return JOLT_OK;
+    if (!ctx || h->ctx != ctx) return JOLT_ERR_INVALID_ARG;
+    // the buffers go back to the pool, whose blocks later main-stream work may reuse at once: the main stream first joins the stream that wrote them
+    if (h->ready) {
+        if (h->stream != ctx->stream) (void)hipStreamWaitEvent(ctx->stream, h->ready, 0);
+        (void)hipEventDestroy(h->ready);
+    }
+    if (h->sums) jolt_internal_dev_free(ctx, h->sums);
+    if (h->partial) jolt_internal_dev_free(ctx, h->partial);
+    delete h;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_grid_hint_begin(jolt_ctx* ctx, const jolt_srs* srs, const jolt_onehot* const* sources, size_t n_sources, uint32_t levels, int32_t background,
+                                        jolt_grid_hint** out) {
+    if (!ctx || !srs || !sources || !n_sources || !out || levels == 0 || levels > 4) return JOLT_ERR_INVALID_ARG;
+    *out = nullptr;
+    const size_t T = sources[0] ? sources[0]->cycles : 0;
+    size_t n_cols = 0, max_cols = 0;
+    for (size_t q = 0; q < n_sources; ++q) {
+        if (!sources[q] || sources[q]->cycles != T || sources[q]->k != sources[0]->k || sources[q]->n_polys > 65535) return JOLT_ERR_INVALID_ARG;
+        n_cols += sources[q]->n_polys;
+        max_cols = std::max(max_cols, sources[q]->n_polys);
+    }
+    if (T == 0 || (T & (T - 1)) != 0 || T < ((size_t)1 << levels)) return JOLT_ERR_UNSUPPORTED;  // a power-of-two grid at least 2^levels wide
+    if ((size_t)sources[0]->k * T > srs->n) return JOLT_ERR_SRS_TOO_SMALL;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    jolt_grid_hint* h = new (std::nothrow) jolt_grid_hint();
+    if (!h) return JOLT_ERR_OOM;
+    h->ctx = ctx;
+    h->levels = levels;
+    h->k = sources[0]->k;
+    h->n_cols = n_cols;
+    h->cycles = T;
+    for (uint32_t s_ = 1; s_ <= levels; ++s_) h->level_offset[s_] = h->level_offset[s_ - 1] + ((size_t)n_cols << s_);
+    // one wavefront per SIMD in the background: a 256-lane workgroup that reserves most of a CU's LDS keeps the other wave slots (and 2 / 3 of the registers) free
+    // for whatever the main stream launches meanwhile -- latency-bound round kernels find a slot at once instead of waiting for one of these long workgroups to retire
+    const size_t lds = background ? std::min<size_t>(ctx->max_lds_per_block, (size_t)96 * 1024) : 0;
+    int32_t st = JOLT_OK;
+    if (background) st = hint_stream_of(ctx, &h->stream);
+    else h->stream = ctx->stream;
+    const size_t span_min = T >> levels;
+    const size_t blocks_max = std::max<size_t>(1, std::min<size_t>((T / 2 + kBlock - 1) / kBlock, (size_t)kGridSumBlocks));
+    (void)span_min;
+    if (st == JOLT_OK) st = jolt_internal_dev_alloc(ctx, h->level_offset[levels] * sizeof(G1Jac), (void**)&h->sums);
+    if (st == JOLT_OK) st = jolt_internal_dev_alloc(ctx, ((size_t)max_cols << levels) * blocks_max * (kBlock / 64) * sizeof(G1Jac), (void**)&h->partial);
+    hipError_t e = hipSuccess;
+    if (st == JOLT_OK) {
+        e = hipEventCreateWithFlags(&h->ready, hipEventDisableTiming);
+        if (e == hipSuccess && h->stream != ctx->stream) {  // the sources were produced on the main stream; pool blocks may still be read by work queued there
+            e = hipEventRecord(ctx->ev_fork, ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ctx->ev_fork, 0);
+        }
+        if (e == hipSuccess && lds && !ctx->grid_hint_attr_set) {
+            e = hipFuncSetAttribute((const void*)k_grid_onehot_sum<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_grid_onehot_sum<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) ctx->grid_hint_attr_set = true;
+        }
+    }
+    LformConsts lc;
+    {
+        Fq thirty_two = Fq::zero();
+        thirty_two.l[0] = 32;
+        lc.one_l = to_mont(thirty_two);
+        lc.r256 = Fq::one();
+    }
+    for (uint32_t s_ = 1; s_ <= levels && st == JOLT_OK && e == hipSuccess; ++s_) {
+        const size_t classes = (size_t)1 << s_, span = T >> s_;
+        uint32_t first = 0;
+        for (size_t q = 0; q < n_sources; ++q) {
+            const jolt_onehot* src = sources[q];
+            const size_t N = src->n_polys;
+            const size_t by_work = (span + (size_t)kBlock * 128 - 1) / ((size_t)kBlock * 128), fill = ((size_t)ctx->num_cus * 8 + N - 1) / std::max<size_t>(N, 1);
+            const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>({(span + kBlock - 1) / kBlock, std::max(by_work, fill), blocks_max}));
+            const uint32_t per_col = blocks * (kBlock / 64);
+            if (srs->pre && srs->pre_lform && srs->pre_stride >= (size_t)src->k * T)
+                hipLaunchKernelGGL(k_grid_onehot_sum<true>, dim3(blocks, (unsigned)N, (unsigned)classes), dim3(kBlock), lds, h->stream, (const uint8_t*)src->idx, src->wide, T, (size_t)0, T,
+                                   (const G1Affine*)srs->pre, h->partial, lc, s_);
+            else
+                hipLaunchKernelGGL(k_grid_onehot_sum<false>, dim3(blocks, (unsigned)N, (unsigned)classes), dim3(kBlock), lds, h->stream, (const uint8_t*)src->idx, src->wide, T, (size_t)0, T,
+                                   (const G1Affine*)srs->pts, h->partial, lc, s_);
+            hipLaunchKernelGGL(k_grid_onehot_fold, dim3((unsigned)(classes * N)), dim3(64), 0, h->stream, (const G1Jac*)h->partial, per_col, h->sums + h->level_offset[s_ - 1],
+                               (uint32_t)N, (uint32_t)n_cols, first);
+            first += (uint32_t)N;
+            e = hipGetLastError();
+            if (e != hipSuccess) break;
+        }
+    }
+    if (st == JOLT_OK && e == hipSuccess) e = hipEventRecord(h->ready, h->stream);
+    if (st == JOLT_OK && e != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->last_error = std::string("grid hint: ") + hipGetErrorString(e);
+        st = JOLT_ERR_HIP;
+    }
+    if (st != JOLT_OK) {
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        jolt_grid_hint_free(ctx, h);
+        return st;
+    }
+    *out = h;
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_grid_hint_wait(jolt_ctx* ctx, jolt_grid_hint* h) {  // host-side: the sums have landed (tests, timing)
+    if (!ctx || !h || h->ctx != ctx) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipEventSynchronize(h->ready));
+    return JOLT_OK;
+}
+// test hook: the class sums of level `level` (1-based) as host points, [class][column] (= jolt_grid_commit_onehot_classes of each source, concatenated per class)
+extern "C" int32_t jolt_grid_hint_download(jolt_ctx* ctx, jolt_grid_hint* h, uint32_t level, jolt_g1_t* out) {
+    if (!ctx || !h || h->ctx != ctx || !out || level == 0 || level > h->levels) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipEventSynchronize(h->ready));
+    JOLT_HIP_TRY(ctx, hipMemcpy(out, h->sums + h->level_offset[level - 1], (h->n_cols << level) * sizeof(G1Jac), hipMemcpyDeviceToHost));
+    return JOLT_OK;
+}
+int32_t jolt_internal_grid_hint_combine(jolt_ctx* ctx, const jolt_grid_hint* h, uint32_t levels, const Fr* onehot_scalars, const Fr* xs, G1Jac** d_out, void** d_temp) {
+    if (!ctx || !h || h->ctx != ctx || !onehot_scalars || !xs || !d_out || !d_temp || levels == 0 || levels > h->levels) return JOLT_ERR_INVALID_ARG;
+    *d_out = nullptr;
+    *d_temp = nullptr;
+    const size_t total = h->level_offset[levels];
+    std::vector<Fr> scalars(total);
+    std::vector<uint32_t> offsets(levels + 1);
+    for (uint32_t s_ = 1; s_ <= levels; ++s_) {
+        offsets[s_ - 1] = (uint32_t)h->level_offset[s_ - 1];
+        for (size_t c = 0; c < ((size_t)1 << s_); ++c) {
+            Fr w = Fr::one();
+            for (uint32_t b = 0; b < s_; ++b) w = mul(w, ((c >> b) & 1) ? xs[b] : sub(Fr::one(), xs[b]));
+            for (size_t p = 0; p < h->n_cols; ++p) scalars[h->level_offset[s_ - 1] + c * h->n_cols + p] = mul(onehot_scalars[p], w);
+        }
+    }
+    offsets[levels] = (uint32_t)total;
+    const size_t bytes_scalars = total * sizeof(Fr), bytes_offsets = ((size_t)levels + 1) * sizeof(uint32_t);
+    unsigned char* temp = nullptr;
+    G1Jac* dout = nullptr;
+    JOLT_TRY(jolt_internal_dev_alloc(ctx, bytes_scalars + bytes_offsets, (void**)&temp));
+    int32_t st = jolt_internal_dev_alloc(ctx, (size_t)levels * sizeof(G1Jac), (void**)&dout);
+    if (st != JOLT_OK) { jolt_internal_dev_free(ctx, temp); return st; }
+    hipError_t e = hipSuccess;
+    if (h->stream != ctx->stream) {  // fresh pool blocks may still be read by work queued on the main stream
+        e = hipEventRecord(ctx->ev_fork, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ctx->ev_fork, 0);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(temp, scalars.data(), bytes_scalars, hipMemcpyHostToDevice, h->stream);  // pageable sources: staged before the call returns
+    if (e == hipSuccess) e = hipMemcpyAsync(temp + bytes_scalars, offsets.data(), bytes_offsets, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->ready, 0);
+    if (e == hipSuccess) {
+        const size_t widest = h->n_cols << levels;
+        const unsigned threads = (unsigned)std::min<size_t>(1024, (widest + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_grid_hint_combine, dim3(levels), dim3(threads), 0, h->stream, (const G1Jac*)h->sums, (const Fr*)temp, (const uint32_t*)(temp + bytes_scalars), dout);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->stream);
+        jolt_internal_dev_free(ctx, temp);
+        jolt_internal_dev_free(ctx, dout);
+        ctx->last_error = std::string("grid hint combine: ") + hipGetErrorString(e);
+        return JOLT_ERR_HIP;
+    }
+    *d_out = dout;
+    *d_temp = temp;
     return JOLT_OK;
 }
 

@@ -46,6 +46,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -m jolt_amd.build` (there is no CPU fallback)")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (capi.hip sets the same default when the library is loaded; here for processes whose HIP runtime starts before it)
         _lib = C.CDLL(LIB_PATH)
         _lib.jolt_status_string.restype = C.c_char_p
         _lib.jolt_last_error.restype = C.c_char_p
@@ -823,6 +824,50 @@ def _hyperkzg_open(self, srs, evals, point, label=0, known_levels=None):
     return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
 
 
+class GridHint:
+    """The commitment grid's opening hint (jolt_grid_hint_begin): the class sums of the one-hot columns for the first `levels` level commitments of an opening, in
+    flight on the context's background stream (or its main stream) from the moment this returns"""
+
+    def __init__(self, ctx, srs, sources, levels, background=True):
+        hs = (C.c_void_p * len(sources))(*[s_.h for s_ in sources])
+        h = C.c_void_p()
+        _ck(lib().jolt_grid_hint_begin(ctx.h, srs.h, hs, C.c_size_t(len(sources)), C.c_uint32(levels), C.c_int32(1 if background else 0), C.byref(h)), "jolt_grid_hint_begin", ctx)
+        self.ctx, self.h, self.levels, self.n_cols, self._keep = ctx, h, levels, sum(s_.n_polys for s_ in sources), list(sources)
+
+    def wait(self):
+        _ck(lib().jolt_grid_hint_wait(self.ctx.h, self.h), "jolt_grid_hint_wait", self.ctx)
+
+    def download(self, level):
+        out = g1_array(self.n_cols << level)
+        _ck(lib().jolt_grid_hint_download(self.ctx.h, self.h, C.c_uint32(level), _p(out)), "jolt_grid_hint_download", self.ctx)
+        return out.reshape(1 << level, self.n_cols, 12)
+
+    def free(self):
+        if self.h:
+            lib().jolt_grid_hint_free(self.ctx.h, self.h)
+            self.h = None
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _hyperkzg_open_grid(self, srs, evals, point, hint, levels, onehot_scalars, dense, dense_scalars, label=0):
+    """jolt_host_hyperkzg_open_grid: the opening of the grid's joint polynomial with its first `levels` level commitments by linearity from the commit-time hint"""
+    p = fr(point).reshape(-1, 4)
+    ell = p.shape[0]
+    com, w, v, ch = g1_array(max(ell - 1, 1)), g1_array(3), fr_array(3 * max(ell, 1)), fr_array(3)
+    osc = np.ascontiguousarray(onehot_scalars, dtype=np.uint64).reshape(-1, 4)
+    dsc = np.ascontiguousarray(dense_scalars, dtype=np.uint64).reshape(-1, 4) if len(dense) else None
+    hs = (C.c_void_p * max(len(dense), 1))(*[t.h for t in dense])
+    _ck(lib().jolt_host_hyperkzg_open_grid(self.h, srs.h, evals.h, _p(p), C.c_size_t(ell), C.c_uint64(label), None, None, hint.h, C.c_uint32(levels), _p(osc), hs,
+                                           C.c_size_t(len(dense)), _p(dsc) if dsc is not None else None, _p(com), _p(w), _p(v), _p(ch)), "jolt_host_hyperkzg_open_grid", self)
+    return dict(com=com[: ell - 1], w=w, v=v.reshape(3, ell, 4), challenges=ch)
+
+
 def _srs_precompute_windows(self, srs, window_bits=0, min_terms=0):
     """Fixed-base tables 2^(c*w) * srs[i] (one bucket set for all windows of an MSM): ceil(255/c) copies of the bases in HBM."""
     _ck(lib().jolt_srs_precompute_windows(self.h, srs.h, C.c_uint32(window_bits), C.c_size_t(min_terms)), "jolt_srs_precompute_windows", self)
@@ -848,6 +893,8 @@ Context.hyperkzg_rlc = _hyperkzg_rlc
 Context.hyperkzg_witness_poly = _hyperkzg_witness_poly
 Context.hyperkzg_commit = _hyperkzg_commit
 Context.hyperkzg_open = _hyperkzg_open
+Context.hyperkzg_open_grid = _hyperkzg_open_grid
+Context.grid_hint = lambda self, srs, sources, levels, background=True: GridHint(self, srs, sources, levels, background)
 
 OPEN_TRANSCRIPT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p)
 

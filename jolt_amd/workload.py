@@ -325,7 +325,7 @@ class DeviceWorkload:
             self.open_point = rand_fr(self.grid_vars, prng)
         elif pcs is not None:
             raise ValueError(pcs)
-        self.tables, self.members, self.prepared = {}, [], False
+        self.tables, self.members, self.prepared, self.hint = {}, [], False, None
         self.prepare()
         ctx.synchronize()
         # input claims: in the real prover these are the previous stage's output claims; here computed once, untimed
@@ -460,6 +460,9 @@ class DeviceWorkload:
                 self.ctx.synchronize()
                 marks.append((what, time.perf_counter()))
         mark("start")
+        if self.hint is not None:  # a hint nobody opened with: it reads the columns that are replaced below
+            self.hint.free()
+            self.hint = None
         if self.prepared:
             self.release()  # the members of the previous proof borrow the columns that are replaced here
         mark("release")
@@ -541,56 +544,41 @@ class DeviceWorkload:
         finally:
             if pending is not None:
                 dense = list(pending.finish())
+        # the opening hint (CommitmentScheme::commit returns (Commitment, OpeningHint), schemes.rs:60-72): the class sums behind the opening's first level commitments are a
+        # function of the witness and the SRS alone -- enqueued now in the background, they run under the latency-bound stage operators and sumcheck legs
+        levels = self.linear_levels()
+        if levels and os.environ.get("JOLT_HINT_AT_COMMIT", "1") != "0":
+            if self.hint is not None:
+                self.hint.free()
+            self.hint = ctx.grid_hint(self.srs, [self.sources[i] for i in sorted(self.sources)], levels, background=os.environ.get("JOLT_HINT_BACKGROUND", "1") != "0")
         return dict(dense=np.stack(dense), onehot=np.concatenate(onehot))
 
     def joint_polynomial(self):
         return self.ctx.grid_joint_polynomial([self.sources[i] for i in sorted(self.sources)], self.rlc_onehot,
                                               [self.tables[name] for name in self.committed_dense], self.rlc_dense, self.log_k)
 
-    def open(self, label=0):
-        """Stage 8: joint polynomial of the homomorphic batch, one HyperKZG opening at the unified point."""
-        joint = self.joint_polynomial()
+    def linear_levels(self):
+        """how many of the opening's first level commitments come by linearity from the commit-time hint (JOLT_OPEN_LINEAR_LEVELS, default 2; 0: every level by MSM)"""
         levels = 0 if os.environ.get("JOLT_OPEN_LEVEL1", "1") == "0" else int(os.environ.get("JOLT_OPEN_LINEAR_LEVELS", "2"))
-        levels = max(0, min(levels, self.grid_vars - 1, self.n_vars))
-        known = self.level_commitments_by_linearity(levels) if levels else None
-        out = self.ctx.hyperkzg_open(self.srs, joint, self.open_point, label=label, known_levels=known)
+        return max(0, min(levels, 4, self.grid_vars - 1, self.n_vars - 1))
+
+    def open(self, label=0):
+        """Stage 8: joint polynomial of the homomorphic batch, one HyperKZG opening at the unified point; the first level commitments by linearity from the opening hint
+        the commit leg left in flight (jolt_host_hyperkzg_open_grid) -- begun here if this proof has none"""
+        joint = self.joint_polynomial()
+        levels = self.linear_levels()
+        if levels and self.hint is None:
+            self.hint = self.ctx.grid_hint(self.srs, [self.sources[i] for i in sorted(self.sources)], levels, background=False)
+        if levels:
+            out = self.ctx.hyperkzg_open_grid(self.srs, joint, self.open_point, self.hint, levels, self.rlc_onehot, [self.tables[name] for name in self.committed_dense],
+                                              self.rlc_dense, label=label)
+        else:
+            out = self.ctx.hyperkzg_open(self.srs, joint, self.open_point, label=label)
+        if self.hint is not None:
+            self.hint.free()
+            self.hint = None
         joint.free()
         return out
-
-    def level_commitments_by_linearity(self, levels=2):
-        """The commitments of the opening's FIRST folded polynomials without MSMs over their 2^(grid_vars - s) full-width coefficients.  The joint polynomial is
-        J = sum_p s_p [hot_p(j) = k] + [k = 0] sum_d c_d f_d[j] on the grid index k T + j, and fold b pairs cycles that differ in bit b with x_b = open_point[-1 - b]
-        (fold i uses point[ell - i], scheme.rs:97-98).  After s folds the coefficient at (k, j >> s) is the sum over the residue classes c of j mod 2^s with the
-        weight w_c = prod_b (x_b if bit b of c else 1 - x_b), so
-            com(P_s) = sum_p s_p sum_c w_c S_p^(s, c) + com(the dense columns folded s times)
-        with S_p^(s, c) = the sum of the bases at (hot_p(j) T + j) >> s over the cycles of class c (jolt_grid_commit_onehot_classes: sums of bases at the commit leg's
-        rate, the same 36 x T additions for every s), a (2^s x n_onehot)-term MSM over those sums and one (T >> s)-term MSM for the dense part.  Level 1 replaces an MSM
-        of 2^25 terms, level 2 one of 2^24; from level 3 on the MSM is the cheaper way.  Returned as the (levels, 12) known_levels of hyperkzg_open."""
-        ctx, ffi, T = self.ctx, self.ffi, 1 << self.n_vars
-        one = ffi.host_fr_from_u64(1)
-        xs = [self.open_point[-1 - b] for b in range(levels)]
-        d = ctx.rlc([self.tables[name] for name in self.committed_dense], self.rlc_dense) if self.committed_dense else None  # the dense part of row 0, T coefficients
-        out = []
-        for s_ in range(1, levels + 1):
-            weights = []
-            for c in range(1 << s_):
-                w = one
-                for b in range(s_):
-                    w = ffi.host_fr_mul(w, xs[b] if (c >> b) & 1 else ffi.host_fr_sub(one, xs[b]))
-                weights.append(w)
-            sums = [ctx.grid_commit_onehot_classes(self.srs, self.sources[i], s_) for i in sorted(self.sources)]  # per source (2^s, n_polys, 12)
-            points = np.concatenate([np.concatenate([cs[c] for cs in sums]) for c in range(1 << s_)])  # class by class, the columns in source order inside
-            scalars = np.stack([ffi.host_fr_mul(sp, weights[c]) for c in range(1 << s_) for sp in self.rlc_onehot])
-            small = ctx.srs_upload(points)
-            com = ctx.msm(small, scalars)
-            small.free()
-            if d is not None:
-                ctx.bind([d], xs[s_ - 1])
-                com = ffi.host_g1_add(com, ctx.msm(self.srs, d, T >> s_, full_width=True))
-            out.append(np.asarray(com, dtype=np.uint64).reshape(12))
-        if d is not None:
-            d.free()
-        return np.stack(out)
 
     def step(self, label=0):
         """One proof's worth of hot-path work (bench.py's timed step)."""
@@ -611,6 +599,9 @@ class DeviceWorkload:
         return sum(len(t) for t in self.tables.values()) * 32
 
     def close(self):
+        if getattr(self, "hint", None) is not None:  # (before the sources it reads)
+            self.hint.free()
+            self.hint = None
         self.release()
         if self.ext is not None:
             self.ext.close()

@@ -93,6 +93,10 @@ pub struct jolt_shm {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct jolt_grid_hint {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct jolt_stage_op {
     _private: [u8; 0],
 }
@@ -394,6 +398,11 @@ extern "C" {
     pub fn jolt_msm_g1_table_subtree(ctx: *mut jolt_ctx, srs: *const jolt_srs, scalars: *const jolt_table, n: usize, rank: i32, world: i32, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_grid_joint_polynomial_subtree(ctx: *mut jolt_ctx, sources: *const *const jolt_onehot, n_sources: usize, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, log_k: u32, rank: i32, world: i32, out: *mut *mut jolt_table) -> i32;
     pub fn jolt_host_hyperkzg_open_subtree(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, rank: i32, world: i32, gather: jolt_gather_fn, user: *mut c_void, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_grid_hint_begin(ctx: *mut jolt_ctx, srs: *const jolt_srs, sources: *const *const jolt_onehot, n_sources: usize, levels: u32, background: i32, out: *mut *mut jolt_grid_hint) -> i32;
+    pub fn jolt_grid_hint_wait(ctx: *mut jolt_ctx, hint: *mut jolt_grid_hint) -> i32;
+    pub fn jolt_grid_hint_download(ctx: *mut jolt_ctx, hint: *mut jolt_grid_hint, level: u32, out: *mut jolt_g1_t) -> i32;
+    pub fn jolt_grid_hint_free(ctx: *mut jolt_ctx, hint: *mut jolt_grid_hint) -> i32;
+    pub fn jolt_host_hyperkzg_open_grid(ctx: *mut jolt_ctx, srs: *const jolt_srs, evals: *const jolt_table, point: *const jolt_fr_t, ell: usize, transcript_label: u64, r#fn: jolt_open_transcript_fn, user: *mut c_void, hint: *const jolt_grid_hint, levels: u32, onehot_scalars: *const jolt_fr_t, dense: *const *mut jolt_table, n_dense: usize, dense_scalars: *const jolt_fr_t, com: *mut jolt_g1_t, w: *mut jolt_g1_t, v: *mut jolt_fr_t, challenges_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_stage_op_num_rounds(op: *const jolt_stage_op, rounds: *mut usize) -> i32;
     pub fn jolt_stage_op_degree(op: *const jolt_stage_op, degree: *mut usize) -> i32;
     pub fn jolt_stage_op_input_claim(op: *mut jolt_stage_op, claim: *mut jolt_fr_t) -> i32;

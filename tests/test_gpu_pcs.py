@@ -124,6 +124,48 @@ def test_class_sums_of_onehot_columns_match_oracle(ctx, log_t, shift, cold):
             assert same_point(got[c, p], want), (c, p)
 
 
+@pytest.mark.parametrize("log_t,levels,background,fixed_base", [(5, 2, False, False), (6, 3, True, False), (7, 4, True, False), (10, 2, True, True), (12, 4, False, True)])
+def test_grid_hint_and_the_opening_by_linearity_are_the_plain_opening(ctx, log_t, levels, background, fixed_base):
+    """jolt_grid_hint_begin: the hint's class sums are jolt_grid_commit_onehot_classes of each source (oracle-checked above), whether they ran in the background (lowest
+    priority stream, LDS-limited to one wavefront per SIMD) or on the main stream; and jolt_host_hyperkzg_open_grid -- the first levels by linearity from the hint,
+    the dense folds' MSMs in the level pipeline -- returns the proof of jolt_host_hyperkzg_open of the same joint polynomial: same transcript, equal points"""
+    T, K, log_k = 1 << log_t, 16, 4
+    rng = np.random.default_rng(70 + log_t + levels)
+    srs = ctx.srs_setup_from_secret(rand_fr(1, 80 + log_t)[0], K * T, G1_GENERATOR)
+    if fixed_base:
+        ctx.srs_precompute_windows(srs, 10, 1)
+    idx_a = rng.integers(0, K, size=(3, T), dtype=np.uint8)
+    idx_a[:, rng.random(T) < 0.4] = 0xFF
+    idx_b = rng.integers(0, K, size=(5, T), dtype=np.uint8)
+    idx_b[4, 1::2] = 0xFF
+    sources = [ctx.onehot(idx_a, K), ctx.onehot(idx_b, K)]
+    dense = [ctx.from_u64(rng.integers(0, 2**64, size=T, dtype=np.uint64)), ctx.from_i64(rng.integers(-2**62, 2**62, size=T, dtype=np.int64))]
+    s_oh, s_d, point = rand_fr(8, 90 + log_t), rand_fr(2, 91 + log_t), rand_fr(log_k + log_t, 92 + log_t)
+    hint = ctx.grid_hint(srs, sources, levels, background=background)
+    for s_ in range(1, levels + 1):
+        want = np.concatenate([ctx.grid_commit_onehot_classes(srs, src, s_) for src in sources], axis=1)
+        got = hint.download(s_)
+        assert got.shape == want.shape == (1 << s_, 8, 12)
+        assert all(same_point(got[c, p], want[c, p]) for c in range(1 << s_) for p in range(8)), s_
+    joint = ctx.grid_joint_polynomial(sources, s_oh, dense, s_d, log_k)
+    plain = ctx.hyperkzg_open(srs, joint, point, label=9)
+    for lv in range(1, levels + 1):
+        got = ctx.hyperkzg_open_grid(srs, joint, point, hint, lv, s_oh, dense, s_d, label=9)
+        assert np.array_equal(got["challenges"], plain["challenges"]) and np.array_equal(got["v"], plain["v"]), lv
+        assert all(same_point(got["com"][i], plain["com"][i]) for i in range(log_k + log_t - 1)), lv
+        assert all(same_point(got["w"][t], plain["w"][t]) for t in range(3)), lv
+    only_onehot = ctx.grid_joint_polynomial(sources, s_oh, [], [], log_k)  # no dense columns: the levels are the hint's combination alone
+    plain = ctx.hyperkzg_open(srs, only_onehot, point, label=10)
+    got = ctx.hyperkzg_open_grid(srs, only_onehot, point, hint, levels, s_oh, [], [], label=10)
+    assert np.array_equal(got["challenges"], plain["challenges"]) and all(same_point(got["com"][i], plain["com"][i]) for i in range(log_k + log_t - 1))
+    hint.free()
+    for t in dense + [joint, only_onehot]:
+        t.free()
+    for src in sources:
+        src.free()
+    srs.free()
+
+
 def test_open_with_a_supplied_level_commitment_is_the_same_proof(ctx):
     """jolt_host_hyperkzg_open_with_levels: the first level commitment handed in (here: the one the plain opening computes) is absorbed and returned like a computed
     one -- same challenges, same proof; a WRONG one changes the transcript (it is the caller's responsibility: the verifier rejects such a proof)"""

@@ -1,11 +1,11 @@
-"""The identity behind the opening's first level commitments (jolt_amd/workload.py::level_commitments_by_linearity), on the oracle alone:
+"""The identity behind the opening's first level commitments (jolt_host_hyperkzg_open_grid over a jolt_grid_hint), on the oracle alone:
 for the joint polynomial J = sum_p s_p [hot_p(j) = k] + [k = 0] sum_d c_d f_d[j] on the grid index k T + j, the commitment of its s-th LowToHigh fold is
 
     com(P_s) = sum_p s_p sum_c w_c S_p^(s,c) + com(the dense part folded s times),      w_c = prod_b (x_b if bit b of c else 1 - x_b),  x_b = point[ell - 1 - b]
 
 with S_p^(s,c) the sum of the SRS bases at (hot_p(j) T + j) >> s over the cycles j = c mod 2^s.  Everything here is the oracle's: the folds are
 hyperkzg_fold_polynomials, the commitments kzg_commit, the group operations g1_*; no device, no product code -- this pins the weights, the bit order of the classes and
-the base index of the class sums that the device path (jolt_grid_commit_onehot_classes + jolt_host_hyperkzg_open_with_levels) relies on."""
+the base index of the class sums that the device path (jolt_grid_hint_begin / jolt_grid_commit_onehot_classes + jolt_host_hyperkzg_open_grid) relies on."""
 import numpy as np
 import pytest
 
