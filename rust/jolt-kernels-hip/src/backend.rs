@@ -19,12 +19,16 @@ use jolt_kernels::commitment::{CommitWitness, CommitmentGrid, WitnessCommitment}
 use jolt_kernels::uniskip::UniskipKernel;
 use jolt_kernels::{JoltBackend, KernelError, ProofSession};
 use jolt_poly::UnivariatePoly;
-use jolt_verifier::stages::relations::{OuterRemainder, ProductRemainder};
+use jolt_verifier::stages::stage1::outer_remainder::OuterRemainder;
+use jolt_verifier::stages::stage2::product_remainder::ProductRemainder;
 use jolt_witness::{JoltWitnessOracle, JoltWitnessPlane};
 
 use crate::context::{HipContext, HipTable};
+use crate::leaves;
 use crate::member::HipPrepare;
+use crate::opening::{HipGridHint, HipJointOpening, HipOpeningHint, ResidentCommitted, ResidentGridBlock};
 use crate::ops::{HipHotIndices, HipInts, SpartanSums};
+use crate::stage;
 use crate::pcs::{HipHyperKzg, HipHyperKzgSetup};
 use crate::scheduler::HipBuildRoundScheduler;
 
@@ -85,7 +89,7 @@ impl<R> HipUniskip<R> {
                 let table = witness.oracle_table(*id).map_err(KernelError::from)?;
                 let ints: Vec<i128> = table
                     .iter()
-                    .map(|v| v.to_i128().ok_or(KernelError::InvariantViolation { reason: "an R1CS input outside the i128 range" }))
+                    .map(|v| crate::status::fr_to_i128(v).ok_or(KernelError::InvariantViolation { reason: "an R1CS input outside the i128 range" }))
                     .collect::<Result<_, _>>()?;
                 HipInts::from_i128(&self.ctx, &ints).map_err(KernelError::from)
             })
@@ -170,64 +174,90 @@ impl CommitWitness<Fr, HipHyperKzg> for HipCommitWitness {
         let Some(shapes) = shapes else {
             return self.fallback.commit_witness(session, source, ids, grid, setup);
         };
-        if grid.order != jolt_kernels::commitment::TracePolynomialOrder::CycleMajor {
+        if grid.order != jolt_claims::protocols::jolt::TracePolynomialOrder::CycleMajor {
             return self.fallback.commit_witness(session, source, ids, grid, setup);
         }
         let cycles = 1usize << grid.log_t;
-        // dense columns first onto the device (field elements, zero-extended to the grid: address 0 holds the cycles, the rest is zero) ...
-        let mut dense_tables = Vec::new();
+        let k = 1u32 << grid.log_k_chunk;
+        // dense columns onto the device (field elements; address 0 of the grid holds the cycles, the rest is zero) ...
+        let mut dense_tables: Vec<Arc<HipTable>> = Vec::new();
         let mut dense_slots = Vec::new();
+        // ... and ALL one-hot columns as ONE resident block of hot indices (n_columns x T bytes): one sum-of-bases launch commits them, the opening hint's class sums
+        // run over the same block, and stage 8 builds the joint polynomial from it (crate::opening)
+        let mut onehot_slots = Vec::new();
+        let mut hot: Vec<u8> = Vec::new();
         for (slot, shape) in shapes.iter().enumerate() {
-            if let CommittedShape::Dense(col) = shape {
-                let table = source.oracle_table(*col).map_err(KernelError::from)?;
-                dense_tables.push(self.ctx.upload(&table[..cycles]).map_err(KernelError::from)?);
-                dense_slots.push(slot);
-            }
-        }
-        // ... their MSMs go in flight on the side lanes (three at a time) while the one-hot columns' sums of bases run on the main stream
-        let mut commitments: Vec<Option<HyperKZGCommitment<Bn254>>> = vec![None; ids.len()];
-        let mut onehot_done = false;
-        let mut chunks = dense_tables.chunks(3).zip(dense_slots.chunks(3)).peekable();
-        // (called with the setup's device lock held: the columns go straight to `HipHotIndices::grid_commit`, not through `HipHyperKzgSetup::grid_commit_onehot`)
-        let mut commit_onehots = |ctx: &Arc<HipContext>, srs: &crate::msm::HipSrs, out: &mut Vec<Option<HyperKZGCommitment<Bn254>>>| -> Result<(), crate::status::HipError> {
-            for (slot, shape) in shapes.iter().enumerate() {
-                if let CommittedShape::OneHot { source: col, shift } = shape {
-                    let table = source.oracle_table(*col).map_err(|_| crate::status::HipError::size_mismatch("one-hot source column unavailable"))?;
-                    let k = 1u32 << grid.log_k_chunk;
-                    let hot: Vec<u8> = table[..cycles].iter().map(|v| v.to_u64().map_or(0xFF, |a| ((a >> shift) & u64::from(k - 1)) as u8)).collect();
-                    let indices = HipHotIndices::upload(ctx, &hot, 1, cycles, k)?;
-                    let point = indices.grid_commit(srs)?.into_iter().next().ok_or_else(|| crate::status::HipError::size_mismatch("grid commit returned no point"))?;
-                    out[slot] = Some(HyperKZGCommitment { point });
+            match shape {
+                CommittedShape::Dense(col) => {
+                    let table = source.oracle_table(*col).map_err(KernelError::from)?;
+                    dense_tables.push(Arc::new(self.ctx.upload(&table[..cycles]).map_err(KernelError::from)?));
+                    dense_slots.push(slot);
+                }
+                CommittedShape::OneHot { source: col, shift } => {
+                    let table = source.oracle_table(*col).map_err(KernelError::from)?;
+                    hot.extend(table[..cycles].iter().map(|v| crate::status::fr_to_u64(v).map_or(0xFF, |a| ((a >> shift) & u64::from(k - 1)) as u8)));
+                    onehot_slots.push(slot);
                 }
             }
+        }
+        let mut commitments: Vec<Option<HyperKZGCommitment<Bn254>>> = vec![None; ids.len()];
+        let mut hints: Vec<HipOpeningHint> = vec![HipOpeningHint::None; ids.len()];
+        // the one-hot block: commit, then the class sums of the opening's first two level commitments in the BACKGROUND (jolt_grid_hint_begin: lowest-priority stream,
+        // one wavefront per SIMD) -- they depend on the witness and the SRS alone and run under the latency-bound stages between here and stage 8
+        let mut block: Option<Arc<ResidentGridBlock>> = None;
+        let mut commit_block = |ctx: &Arc<HipContext>, srs: &crate::msm::HipSrs, out: &mut Vec<Option<HyperKZGCommitment<Bn254>>>| -> Result<(), crate::status::HipError> {
+            if onehot_slots.is_empty() {
+                return Ok(());
+            }
+            let indices = HipHotIndices::upload(ctx, &hot, onehot_slots.len(), cycles, k)?;
+            for (slot, point) in onehot_slots.iter().zip(indices.grid_commit(srs)?) {
+                out[*slot] = Some(HyperKZGCommitment { point });
+            }
+            let class_sums = HipGridHint::begin(ctx, srs, &indices, 2, true).ok(); // (a refusal costs the opening two MSMs, nothing else)
+            block = Some(Arc::new(ResidentGridBlock::new(ctx, indices, onehot_slots.len(), grid.log_t, grid.log_k_chunk, class_sums)));
             Ok(())
         };
-        if chunks.peek().is_none() {
-            setup.with_device(|ctx, srs| commit_onehots(ctx, srs, &mut commitments)).map_err(KernelError::from)?;
-            onehot_done = true;
+        // the dense columns' MSMs go in flight on the side lanes (three at a time) while the one-hot block's sums of bases run on the main stream
+        let refs_all: Vec<&HipTable> = dense_tables.iter().map(|t| t.as_ref()).collect();
+        let mut first = true;
+        if refs_all.is_empty() {
+            setup.with_device(|ctx, srs| commit_block(ctx, srs, &mut commitments)).map_err(KernelError::from)?;
         }
-        for (tables, slots) in chunks {
-            let refs: Vec<&HipTable> = tables.iter().collect();
-            let first = !onehot_done;
+        for (tables, slots) in refs_all.chunks(3).zip(dense_slots.chunks(3)) {
             let mut staged = vec![None; ids.len()];
-            let (coms, ()) = HipHyperKzg::commit_tables_overlapped(&refs, setup, |ctx, srs| if first { commit_onehots(ctx, srs, &mut staged) } else { Ok(()) }).map_err(KernelError::from)?;
-            if first {
+            let run_block = first;
+            let (coms, ()) = HipHyperKzg::commit_tables_overlapped(tables, setup, |ctx, srs| if run_block { commit_block(ctx, srs, &mut staged) } else { Ok(()) }).map_err(KernelError::from)?;
+            if run_block {
                 for (dst, src) in commitments.iter_mut().zip(staged) {
                     if src.is_some() {
                         *dst = src;
                     }
                 }
-                onehot_done = true;
+                first = false;
             }
             for (slot, com) in slots.iter().zip(coms) {
                 commitments[*slot] = Some(com);
             }
         }
+        if let Some(block) = &block {
+            for (column, slot) in onehot_slots.iter().enumerate() {
+                hints[*slot] = HipOpeningHint::OneHot { block: Arc::clone(block), column };
+            }
+        }
+        for (table, slot) in dense_tables.iter().zip(&dense_slots) {
+            hints[*slot] = HipOpeningHint::Dense { table: Arc::clone(table), log_k: grid.log_k_chunk };
+        }
+        // stage 8's joint-opening slot finds the resident columns here (HipJointOpening)
+        let resident = session.state_or_insert_with(ResidentCommitted::default);
+        for (id, hint) in ids.iter().zip(&hints) {
+            let _ = resident.0.insert(*id, hint.clone());
+        }
         ids.iter()
             .zip(commitments)
-            .map(|(id, commitment)| {
+            .zip(hints)
+            .map(|((id, commitment), hint)| {
                 let commitment = commitment.ok_or(KernelError::InvariantViolation { reason: "a committed polynomial was left without a commitment" })?;
-                Ok(WitnessCommitment { id: *id, commitment, hint: () })
+                Ok(WitnessCommitment { id: *id, commitment, hint })
             })
             .collect()
     }
@@ -254,24 +284,65 @@ pub struct Mi355xParts {
     pub assemble_outer: fn(&[Fr], &[Fr], &[Fr]) -> Result<UnivariatePoly<Fr>, KernelError<Fr>>,
     pub assemble_product: fn(&[Fr], &[Fr], &[Fr]) -> Result<UnivariatePoly<Fr>, KernelError<Fr>>,
     pub classify_committed: fn(JoltCommittedPolynomial) -> Option<CommittedShape>,
+    /// the remainder members' field weights at the uni-skip challenge, their scale and their output openings (crate-private helpers of `jolt-kernels` today)
+    pub outer_remainder_weights: stage::RemainderWeights<OuterRemainder<Fr>>,
+    pub outer_remainder_openings: fn(&OuterRemainder<Fr>) -> Vec<jolt_claims::protocols::jolt::JoltOpeningId>,
+    pub product_remainder_weights: stage::RemainderWeights<ProductRemainder<Fr>>,
+    pub product_remainder_openings: fn(&ProductRemainder<Fr>) -> Vec<jolt_claims::protocols::jolt::JoltOpeningId>,
+    /// `read_raf_stage_values` of the bytecode address phase (O(K) host work from the program image; crate-private in `jolt-kernels`)
+    pub bytecode_stage_values: stage::StageValues,
 }
 
 /// `JoltBackend::optimized()` with the slots this crate serves overwritten by their device kernels -- the composition pattern of
-/// `optimized/mod.rs:136-196`: the commit slot, the round-traversal factory and the two uni-skip fronts here; the cycle-domain relation
-/// slots of stages 2 - 6b through [`with_relation`], one line per relation with that relation's leaf resolver (`member::ResolveLeaves`:
-/// which opening / derived table each leaf of its `Expr` is, `crates/jolt-kernels/src/reference/views.rs:20-138`).  A slot whose `prepare`
+/// `optimized/mod.rs:136-196`.  27 of the registry's 37 slots (`crates/jolt-kernels/src/backend.rs:126-171`): the commit slot, the round-traversal factory, the two
+/// uni-skip fronts and the joint opening; the eleven stage operators as `jolt_stage_op` kernels (`crate::stage`); the eleven cycle-domain relations of stages 2 - 6b
+/// through [`with_relation`] with each relation's leaf resolver (`crate::leaves`: which opening / derived table each leaf of its `Expr` is,
+/// `crates/jolt-kernels/src/reference/views.rs:20-138`).  A slot whose `prepare`
 /// answers `KernelError::Unsupported` (no gfx950 device, a descriptor beyond the library's compiled limits, out of HBM) is recoverable: the
 /// stage driver retries it against `optimized()`.
 ///
 /// `JoltBackend::<Fr, HipHyperKzg>::optimized()` is bounded by `PCS: ModeStreamingCommitment` (`optimized/mod.rs:136-139`); `crate::streaming` is where
 /// `HipHyperKzg` meets it (`StreamingCommitment`, and `ZkStreamingCommitment` for the `zk` feature).
 pub fn mi355x(ctx: &Arc<HipContext>, parts: Mi355xParts) -> JoltBackend<Fr, HipHyperKzg> {
+    #[allow(non_upper_case_globals)]
+    const LowToHigh: jolt_poly::BindingOrder = jolt_poly::BindingOrder::LowToHigh;
     let mut backend = JoltBackend::<Fr, HipHyperKzg>::optimized();
+    // ---- bespoke slots: commit (stage 0), the round-traversal factory, the two uni-skip fronts, the joint opening (stage 8)
     let commit = std::mem::replace(&mut backend.commit, Box::new(NoCommit));
     backend.commit = Box::new(HipCommitWitness::new(ctx, commit, parts.classify_committed));
     backend.round_scheduler = Box::new(HipBuildRoundScheduler { ctx: Arc::clone(ctx) });
     backend.spartan_outer_uniskip = Box::new(HipUniskip::<OuterRemainder<Fr>>::new(ctx, parts.outer_weights, parts.outer_inputs, 2, parts.assemble_outer));
     backend.spartan_product_uniskip = Box::new(HipUniskip::<ProductRemainder<Fr>>::new(ctx, parts.product_weights, parts.product_inputs, 1, parts.assemble_product));
+    let joint = std::mem::replace(&mut backend.joint_opening, Box::new(NoJointOpening));
+    backend.joint_opening = Box::new(HipJointOpening { ctx: Arc::clone(ctx), fallback: joint });
+    // ---- the stage operators: one jolt_stage_op each (crate::stage)
+    backend.spartan_outer_remainder =
+        Box::new(stage::HipSpartanRemainder::<OuterRemainder<Fr>> { ctx: Arc::clone(ctx), weights: parts.outer_remainder_weights, openings: parts.outer_remainder_openings });
+    backend.spartan_product_remainder =
+        Box::new(stage::HipSpartanRemainder::<ProductRemainder<Fr>> { ctx: Arc::clone(ctx), weights: parts.product_remainder_weights, openings: parts.product_remainder_openings });
+    backend.ram_read_write = Box::new(stage::HipRamReadWrite::new(ctx));
+    backend.ram_raf_evaluation = Box::new(stage::HipRamRafEvaluation::new(ctx));
+    backend.ram_output_check = Box::new(stage::HipRamOutputCheck::new(ctx));
+    backend.registers_read_write = Box::new(stage::HipRegistersReadWrite::new(ctx));
+    backend.instruction_read_raf = Box::new(stage::HipInstructionReadRaf::new(ctx));
+    backend.booleanity_address = Box::new(stage::HipBooleanityAddress::new(ctx));
+    backend.bytecode_read_raf_address = Box::new(stage::HipBytecodeReadRafAddressWith { slot: stage::HipBytecodeReadRafAddress::new(ctx), stage_values: parts.bytecode_stage_values });
+    backend.bytecode_read_raf_cycle = Box::new(stage::HipBytecodeReadRafCycle::new(ctx));
+    backend.hamming_weight_claim_reduction = Box::new(stage::HipHammingWeightClaimReduction::new(ctx));
+    // ---- the eleven cycle-domain relations of stages 2 - 6b: the generic device member over each relation's leaf resolver (crate::leaves)
+    backend.instruction_claim_reduction = with_relation(ctx, LowToHigh, leaves::InstructionClaimReductionLeaves);
+    backend.spartan_shift = with_relation(ctx, LowToHigh, leaves::SpartanShiftLeaves);
+    backend.instruction_input = with_relation(ctx, LowToHigh, leaves::InstructionInputLeaves);
+    backend.registers_claim_reduction = with_relation(ctx, LowToHigh, leaves::RegistersClaimReductionLeaves);
+    backend.ram_val_check = with_relation(ctx, LowToHigh, leaves::RamValCheckLeaves);
+    backend.registers_val_evaluation = with_relation(ctx, LowToHigh, leaves::RegistersValEvaluationLeaves);
+    backend.ram_ra_claim_reduction = with_relation(ctx, LowToHigh, leaves::RamRaClaimReductionLeaves);
+    backend.inc_claim_reduction = with_relation(ctx, LowToHigh, leaves::IncClaimReductionLeaves);
+    backend.ram_hamming_booleanity = with_relation(ctx, LowToHigh, leaves::RamHammingBooleanityLeaves);
+    backend.ram_ra_virtualization = with_relation(ctx, LowToHigh, leaves::RamRaVirtualizationLeaves);
+    backend.instruction_ra_virtualization = with_relation(ctx, LowToHigh, leaves::InstructionRaVirtualizationLeaves);
+    // left on `optimized()`: booleanity_cycle (its joint (address || cycle) member is harness-scale in the reference tier), the advice and
+    // precommitted-program reductions and the advice opening evaluation (no T-scale work: DESIGN.md section 7)
     backend
 }
 
@@ -282,6 +353,20 @@ pub fn with_relation<R, T>(ctx: &Arc<HipContext>, order: jolt_poly::BindingOrder
     Box::new(HipPrepare::new(Arc::clone(ctx), order, leaves))
 }
 
+/// Stand-in that only ever lives for the duration of a `mem::replace`.
+struct NoJointOpening;
+impl jolt_kernels::opening::JointOpeningPolynomials<Fr> for NoJointOpening {
+    fn prepare(
+        &self,
+        _: &mut ProofSession,
+        _: &dyn JoltWitnessPlane<Fr>,
+        _: &[JoltCommittedPolynomial],
+        _: &std::collections::BTreeMap<JoltCommittedPolynomial, Vec<Fr>>,
+        _: CommitmentGrid,
+    ) -> Result<Vec<Box<dyn jolt_poly::MultilinearPoly<Fr>>>, KernelError<Fr>> {
+        Err(KernelError::Unsupported { reason: "placeholder joint-opening slot" })
+    }
+}
 /// Stand-in that only ever lives for the duration of a `mem::replace`.
 struct NoCommit;
 impl CommitWitness<Fr, HipHyperKzg> for NoCommit {

@@ -2,7 +2,7 @@
 use std::ptr;
 use std::sync::Arc;
 
-use jolt_field::Fr;
+use jolt_field::{Fr, Ring};
 
 use crate::ffi;
 use crate::status::{check, HipError};
@@ -76,6 +76,36 @@ impl HipContext {
         // SAFETY: as above.
         check(unsafe { ffi::jolt_lt_evals(self.raw, r.as_ptr().cast(), r.len(), &mut raw) }, self.raw)?;
         Ok(HipTable { ctx: Arc::clone(self), raw })
+    }
+}
+
+impl HipContext {
+    /// `EqPlusOnePolynomial::evals(r, None).1` (`crates/jolt-poly/src/eq_plus_one.rs:71-130`): the eq+1 table (its eq companion is dropped).
+    pub fn eq_plus_one_evals(self: &Arc<Self>, r: &[Fr]) -> Result<HipTable, HipError> {
+        let (mut eq, mut eq1) = (ptr::null_mut(), ptr::null_mut());
+        // SAFETY: layouts as above; both out-pointers valid.
+        check(unsafe { ffi::jolt_eq_plus_one_evals(self.raw, r.as_ptr().cast(), r.len(), ptr::null(), &mut eq, &mut eq1) }, self.raw)?;
+        drop(HipTable { ctx: Arc::clone(self), raw: eq });
+        Ok(HipTable { ctx: Arc::clone(self), raw: eq1 })
+    }
+
+    /// `sum_i scalars[i] * tables[i]` (`jolt_rlc`; `RlcSource::to_dense`, `crates/jolt-poly/src/multilinear.rs:358-464`).
+    pub fn rlc(self: &Arc<Self>, tables: &[&HipTable], scalars: &[Fr]) -> Result<HipTable, HipError> {
+        if tables.len() != scalars.len() || tables.is_empty() {
+            return Err(HipError::size_mismatch("one scalar per table, at least one table"));
+        }
+        let handles: Vec<*mut ffi::jolt_table> = tables.iter().map(|t| t.raw).collect();
+        let mut raw = ptr::null_mut();
+        // SAFETY: live handles of equal length; one scalar per table.
+        check(unsafe { ffi::jolt_rlc(self.raw, handles.as_ptr(), handles.len(), scalars.as_ptr().cast(), &mut raw) }, self.raw)?;
+        Ok(HipTable { ctx: Arc::clone(self), raw })
+    }
+
+    /// `LtPolynomial::evaluations(r)[j] + constant` (`reference/ram_val_check.rs:23-26`): the LT table and a table of ones combined on the device.
+    pub fn lt_evals_plus(self: &Arc<Self>, r: &[Fr], constant: Fr) -> Result<HipTable, HipError> {
+        let lt = self.lt_evals(r)?;
+        let ones = self.upload_u64(&vec![1u64; 1usize << r.len()])?;
+        self.rlc(&[&lt, &ones], &[Fr::from_u64(1), constant])
     }
 }
 

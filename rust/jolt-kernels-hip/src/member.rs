@@ -308,7 +308,9 @@ where
     SumcheckOutputClaims<Fr, R>: OutputClaims<Fr>,
     ConcreteSumcheckChallenges<Fr, R>: SumcheckChallenges<Fr, JoltChallengeId>,
 {
-    fn opening(&self, ctx: &Arc<HipContext>, witness: &dyn JoltWitnessPlane<Fr>, id: &JoltOpeningId) -> Result<HipTable, KernelError<Fr>>;
+    /// The table of an opening leaf: the witness column itself (`dense_view`), or its fold against a point of the relation (`address_fold`: the relation and its consumed
+    /// points are in `inputs`).
+    fn opening(&self, ctx: &Arc<HipContext>, witness: &dyn JoltWitnessPlane<Fr>, inputs: &ProverInputs<'_, Fr, R>, id: &JoltOpeningId) -> Result<HipTable, KernelError<Fr>>;
     fn derived(&self, ctx: &Arc<HipContext>, inputs: &ProverInputs<'_, Fr, R>, id: &JoltDerivedId) -> Result<HipTable, KernelError<Fr>>;
 }
 
@@ -351,7 +353,7 @@ where
                         let k = match opening_index.get(id) {
                             Some(&k) => k,
                             None => {
-                                tables.push(self.tables.opening(&self.ctx, witness, id)?);
+                                tables.push(self.tables.opening(&self.ctx, witness, &inputs, id)?);
                                 let _ = opening_index.insert(*id, tables.len() - 1);
                                 tables.len() - 1
                             }

@@ -386,7 +386,7 @@ impl Drop for HipRegistersRw {
 /// final-memory column of the RAM output check.
 pub struct HipKeyIndex {
     ctx: Arc<HipContext>,
-    raw: *mut ffi::jolt_key_index,
+    pub(crate) raw: *mut ffi::jolt_key_index,
 }
 // SAFETY: see HipContext.
 unsafe impl Send for HipKeyIndex {}
@@ -428,7 +428,7 @@ impl Drop for HipKeyIndex {
 /// The packed rows of instruction read+RAF checking on the device (`InstructionCycleRow`, `optimized/instruction_read_raf.rs:86-125`).
 pub struct HipReadRaf {
     ctx: Arc<HipContext>,
-    raw: *mut ffi::jolt_read_raf,
+    pub(crate) raw: *mut ffi::jolt_read_raf,
     n_tables: u32,
 }
 // SAFETY: see HipContext.

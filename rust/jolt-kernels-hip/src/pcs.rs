@@ -297,7 +297,8 @@ impl CommitmentScheme for HipHyperKzg {
     type Proof = HyperKZGProof<Bn254>;
     type ProverSetup = HipHyperKzgSetup;
     type VerifierSetup = HyperKZGVerifierSetup<Bn254>;
-    type OpeningHint = ();
+    /// the committed column as it lies in HBM + the class sums begun at commit time (`crate::opening`)
+    type OpeningHint = crate::opening::HipOpeningHint;
     /// The reference's parameters and the GPU to put the bases on.
     type SetupParams = (<HyperKZGScheme<Bn254> as CommitmentScheme>::SetupParams, i32);
 
@@ -315,7 +316,7 @@ impl CommitmentScheme for HipHyperKzg {
     fn commit<P: MultilinearPoly<Self::Field> + ?Sized>(poly: &P, setup: &Self::ProverSetup) -> Result<(Self::Output, Self::OpeningHint), OpeningsError> {
         setup
             .with_device(|ctx, srs| Self::commit_table(ctx, srs, &Self::upload(ctx, poly)?))
-            .map(|c| (c, ()))
+            .map(|c| (c, Self::OpeningHint::default()))
             .map_err(|e| OpeningsError::CommitFailed(format!("HyperKZG commit failed on the device: {e:?}")))
     }
 
@@ -324,9 +325,17 @@ impl CommitmentScheme for HipHyperKzg {
         point: &[Self::Field],
         _eval: Self::Field,
         setup: &Self::ProverSetup,
-        _hint: Option<Self::OpeningHint>,
+        hint: Option<Self::OpeningHint>,
         transcript: &mut impl Transcript<Challenge = Self::Field>,
     ) -> Result<Self::Proof, OpeningsError> {
+        // a homomorphic batch whose members are all resident (`combine_hints`): the joint polynomial is built and opened on the device, the host-side RLC is never densified
+        if let Some(crate::opening::HipOpeningHint::Joint(joint)) = &hint {
+            if joint.block.as_ref().map_or(joint.log_k, |b| b.log_k + b.log_t) == point.len() || joint.block.is_none() {
+                return setup
+                    .with_device(|ctx, srs| Self::open_joint(ctx, srs, joint, point, transcript))
+                    .map_err(|e| OpeningsError::ProveFailed(format!("HyperKZG batch open failed on the device: {e:?}")));
+            }
+        }
         setup
             .with_device(|ctx, srs| Self::open_table(ctx, srs, &Self::upload(ctx, poly)?, point, transcript, &[]))
             .map_err(|e| OpeningsError::ProveFailed(format!("HyperKZG open failed on the device: {e:?}")))
@@ -344,7 +353,77 @@ impl CommitmentScheme for HipHyperKzg {
     }
 }
 
+impl HipHyperKzg {
+    /// `jolt_host_hyperkzg_open_grid`: the batch's joint polynomial (`jolt_grid_joint_polynomial` over the resident columns) opened with its first level commitments by
+    /// linearity from the class sums the commit slot began (`jolt_grid_hint_begin`); the same proof `open_table` returns for the densified joint polynomial.
+    fn open_joint<T: Transcript<Challenge = Fr>>(
+        ctx: &Arc<HipContext>,
+        srs: &HipSrs,
+        joint: &crate::opening::JointHint,
+        point: &[Fr],
+        transcript: &mut T,
+    ) -> Result<HyperKZGProof<Bn254>, HipError> {
+        let table = joint.joint_polynomial(ctx)?;
+        // the class sums begun at commit time, or begun now (main stream) when the batch comes without them
+        let class_sums = match &joint.block {
+            Some(block) => {
+                let parked = block.hint.lock().unwrap_or_else(std::sync::PoisonError::into_inner).take();
+                match parked {
+                    Some(h) => Some(h),
+                    None => Some(crate::opening::HipGridHint::begin(ctx, srs, &block.indices, 2, false)?),
+                }
+            }
+            None => None,
+        };
+        let Some(class_sums) = class_sums else {
+            return Self::open_table(ctx, srs, &table, point, transcript, &[]);
+        };
+        let ell = point.len();
+        let mut com = vec![Bn254G1::default(); ell.saturating_sub(1).max(1)];
+        let mut w = [Bn254G1::default(); 3];
+        let mut v = vec![Fr::default(); 3 * ell.max(1)];
+        let mut hook = Hook { transcript };
+        let dense: Vec<*mut ffi::jolt_table> = joint.dense.iter().map(|(t, _)| t.raw).collect();
+        let dense_scalars: Vec<Fr> = joint.dense.iter().map(|(_, s)| *s).collect();
+        // SAFETY: live handles; output arrays sized as the header states; one scalar per hint column / dense table; the hook and its transcript outlive the call.
+        check(
+            unsafe {
+                ffi::jolt_host_hyperkzg_open_grid(
+                    ctx.raw,
+                    srs.raw,
+                    table.raw,
+                    point.as_ptr().cast(),
+                    ell,
+                    0,
+                    Some(open_hook::<T>),
+                    (&mut hook as *mut Hook<'_, T>).cast(),
+                    class_sums.raw,
+                    class_sums.levels,
+                    joint.onehot_scalars.as_ptr().cast(),
+                    if dense.is_empty() { ptr::null() } else { dense.as_ptr() },
+                    dense.len(),
+                    if dense.is_empty() { ptr::null() } else { dense_scalars.as_ptr().cast() },
+                    com.as_mut_ptr().cast(),
+                    w.as_mut_ptr().cast(),
+                    v.as_mut_ptr().cast(),
+                    ptr::null_mut(),
+                )
+            },
+            ctx.raw,
+        )?;
+        com.truncate(ell.saturating_sub(1));
+        let rows: Vec<Vec<Fr>> = v.chunks(ell.max(1)).map(<[Fr]>::to_vec).collect();
+        let v: [Vec<Fr>; 3] = rows.try_into().map_err(|_| HipError::size_mismatch("three evaluation rows"))?;
+        Ok(HyperKZGProof { com, w, v })
+    }
+}
+
 impl AdditivelyHomomorphic for HipHyperKzg {
+    /// `schemes.rs:157-162`: the members' resident columns with the batch's RLC scalars -- what `open` builds the joint polynomial from on the device.
+    fn combine_hints(hints: Vec<Self::OpeningHint>, scalars: &[Self::Field]) -> Self::OpeningHint {
+        crate::opening::combine_hints(hints, scalars)
+    }
+
     /// `C = sum_i s_i C_i` (`scheme.rs:346-352`): a few dozen points -- the host's `JoltGroup::msm`, as in the reference.
     fn combine(commitments: &[Self::Output], scalars: &[Self::Field]) -> Self::Output {
         assert_eq!(commitments.len(), scalars.len());

@@ -1,7 +1,7 @@
 //! Status codes of the C ABI mapped onto the reference's error types (`include/jolt_hip.h:44-59`).
 use core::ffi::CStr;
 
-use jolt_field::Fr;
+use jolt_field::{CanonicalEncoding, Fr};
 use jolt_kernels::{KernelError, SumcheckKernelError};
 use jolt_sumcheck::SumcheckError;
 
@@ -73,4 +73,13 @@ pub(crate) fn to_kernel_seam_error(e: HipError, remaining: usize) -> SumcheckKer
 pub(crate) fn to_sumcheck_error(e: HipError) -> SumcheckError<Fr> {
     tracing::error!(status = e.status, detail = %e.detail, "libjolt_hip call failed");
     SumcheckError::MissingEvaluationSource { kind: "device" }
+}
+
+/// A field element that is a machine integer, decoded (`CanonicalEncoding::to_u64_checked`, `crates/jolt-field/src/algebra.rs:300-313`).
+pub(crate) fn fr_to_u64(v: &Fr) -> Option<u64> {
+    v.to_u64_checked()
+}
+/// The same for the signed 128-bit range: a value above 2^127 is the negative of a small one (`F::from_i128`'s image).
+pub(crate) fn fr_to_i128(v: &Fr) -> Option<i128> {
+    v.to_u128_checked().and_then(|u| i128::try_from(u).ok()).or_else(|| (-*v).to_u128_checked().and_then(|u| i128::try_from(u).ok()).map(|m| -m))
 }

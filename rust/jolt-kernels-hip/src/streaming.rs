@@ -264,7 +264,7 @@ impl StreamingCommitment for HipHyperKzg {
                 sum
             }
         };
-        (HyperKZGCommitment { point }, ())
+        (HyperKZGCommitment { point }, Self::OpeningHint::default())
     }
 }
 
@@ -324,14 +324,17 @@ fn no_hiding_mode() -> OpeningsError {
 }
 
 /// With the `zk` feature `ModeStreamingCommitment` is `ZkStreamingCommitment` (`crates/jolt-kernels/src/commitment.rs:42-45`): the bound is met so the
-/// crate compiles in either mode; the hiding finishes have no transparent meaning and the stage-0 driver cannot be handed an `Err` from
-/// here, so they produce the TRANSPARENT commitment and the opening -- `open_zk` above -- is where a ZK proof over this scheme stops.
+/// crate compiles in either mode.  The hiding finishes have no transparent meaning: the trait gives them no `Result`, so they REFUSE by panicking -- a
+/// non-hiding commitment must never be produced (and absorbed, and sent) under a ZK proof; `open_zk` above refuses the same way one step later for callers that
+/// committed elsewhere.  (HyperKZG in this crate is the transparent scheme; a hiding variant is out of the hot path's scope)
 impl ZkStreamingCommitment for HipHyperKzg {
-    fn finish_zk_with_hint(partial: Self::PartialCommitment, setup: &Self::ProverSetup) -> (Self::Output, Self::OpeningHint) {
-        <Self as StreamingCommitment>::finish_with_hint(partial, setup)
+    fn finish_zk_with_hint(_partial: Self::PartialCommitment, _setup: &Self::ProverSetup) -> (Self::Output, Self::OpeningHint) {
+        tracing::error!("HipHyperKzg has no hiding commitment: a ZK proof over this scheme is refused at its first commitment");
+        panic!("HipHyperKzg::finish_zk_with_hint: the device HyperKZG is transparent; refusing to return a non-hiding commitment under the zk feature")
     }
 
-    fn finish_zk_one_hot_column_major_chunks(setup: &Self::ProverSetup, one_hot_k: usize, chunks: &[Self::OneHotChunkCommitment]) -> (Self::Output, Self::OpeningHint) {
-        <Self as StreamingCommitment>::finish_one_hot_column_major_chunks(setup, one_hot_k, chunks)
+    fn finish_zk_one_hot_column_major_chunks(_setup: &Self::ProverSetup, _one_hot_k: usize, _chunks: &[Self::OneHotChunkCommitment]) -> (Self::Output, Self::OpeningHint) {
+        tracing::error!("HipHyperKzg has no hiding commitment: a ZK proof over this scheme is refused at its first commitment");
+        panic!("HipHyperKzg::finish_zk_one_hot_column_major_chunks: the device HyperKZG is transparent; refusing to return a non-hiding commitment under the zk feature")
     }
 }

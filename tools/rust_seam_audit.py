@@ -6,6 +6,10 @@ checks a type-checker would make at the SEAM are made here, mechanically:
   2. trait impls: for every `impl Trait for Type` of a REFERENCE trait, the required items (methods and associated types without a default) are all there,
      nothing is defined that the trait does not declare, every method has the trait's number of parameters, the trait's reference supertraits are implemented
      for the same type, and associated types the trait bounds by derivable std traits (Clone, Debug, ...) derive them when they are in-tree types;
+  4. backend slots: every `backend.<slot> = ..` of `mi355x()` is a field of the reference's `JoltBackend` (crates/jolt-kernels/src/backend.rs:126-171) and the assigned
+     type implements that slot's trait FOR THAT SLOT'S RELATION (`PrepareKernel<Fr, R>` / `UniskipKernel<Fr, R>` / `ResolveLeaves<R>` behind `with_relation`); >= 25 slots;
+  5. imports: every `use jolt_x::a::b::Item` resolves to a pub item (or pub re-export) of module a::b of the reference crate (round 6: two modules had imported relation
+     types from `jolt_verifier::stages::relations`, which does not export them);
   3. generic uses: for every `Name::<A, B>::func(` over a reference type (and the uses INTEGRATION.md advertises, ADVERTISED below), the `where` clauses of the
      reference's `impl<..> Name<..>` / `fn func<..>` are parsed, the concrete arguments substituted, and every bound on an in-tree type is checked against the
      in-tree impls -- through the reference's blanket impls (`impl<P: StreamingCommitment> ModeStreamingCommitment for P`), under every cfg(feature) variant the
@@ -607,6 +611,135 @@ class Audit:
         for adv in ADVERTISED:
             self.check_generic_use(adv["why"], adv["crate"], None, adv["item"], adv["args"], adv.get("projections"), adv.get("file"))
 
+    # ---- 4. the backend's slots: every `backend.<slot> = ..` of mi355x() against the registry (crates/jolt-kernels/src/backend.rs:126-171) ---------------------------------
+    def registry(self):
+        """slot name -> (trait, relation or None), from the reference's `pub struct JoltBackend` (live) or the fixture"""
+        if not self.live:
+            return self.surface.get("slots", {})
+        src = strip(open(os.path.join(crate_dir("jolt_kernels"), "backend.rs")).read())
+        m = re.search(r"pub struct JoltBackend<[^>]*>\s*(?:where[^{]*)?\{", src)
+        body = src[m.end():match_close(src, m.end() - 1) - 1]
+        slots = {}
+        for f in split_top(body):
+            fm = re.match(r"\s*pub\s+(\w+)\s*:\s*Box<\s*dyn\s+(\w+)<(.*)>\s*>\s*$", re.sub(r"\s+", " ", f), re.S)
+            if not fm:
+                continue
+            args = split_top(fm.group(3))
+            relation = None
+            if fm.group(2) in ("PrepareKernel", "UniskipKernel") and len(args) >= 2:
+                relation = re.sub(r"<.*", "", args[1].strip())
+            slots[fm.group(1)] = [fm.group(2), relation]
+        self.surface["slots"] = slots
+        # the slots `optimized()` overwrites (optimized/mod.rs:136-196): what a backend "as complete as the optimized tier" serves
+        opt = strip(open(os.path.join(crate_dir("jolt_kernels"), "optimized", "mod.rs")).read())
+        self.surface["optimized_slots"] = sorted(set(re.findall(r"backend\.(\w+)\s*=", opt)))
+        return slots
+
+    def check_backend_slots(self):
+        slots = self.registry()
+        src = self.crate.files.get("backend.rs", "")
+        m = re.search(r"pub fn mi355x\b[^{]*\{", src)
+        if not m or not slots:
+            self.findings.append("backend.rs: pub fn mi355x not found (or no registry to check it against)")
+            return
+        body = src[m.end():match_close(src, m.end() - 1) - 1]
+        impls = {}
+        for i in self.crate.impls:
+            impls.setdefault(i["type"], []).append(i)
+        served = {}
+        for am in re.finditer(r"backend\.(\w+)\s*=\s*([^;]+);", body):
+            slot, expr = am.group(1), re.sub(r"\s+", " ", am.group(2))
+            if slot not in slots:
+                self.findings.append(f"mi355x(): `backend.{slot}` is not a slot of JoltBackend")
+                continue
+            trait, relation = slots[slot]
+            wm = re.search(r"with_relation\(\s*\w+\s*,\s*\w+\s*,\s*(?:\w+::)*(\w+)\s*\)", expr)
+            if wm:  # the generic device member over a leaf resolver: the resolver must be `ResolveLeaves<that slot's relation>`
+                leaves = wm.group(1)
+                rels = [re.sub(r"<.*", "", a.strip()) for i in impls.get(leaves, []) if i["trait"] == "ResolveLeaves" for a in split_top(i["trait_args"] or "")[:1]]
+                if trait != "PrepareKernel":
+                    self.findings.append(f"mi355x(): slot `{slot}` is a {trait}, not a PrepareKernel: with_relation does not fit")
+                elif relation not in rels:
+                    self.findings.append(f"mi355x(): slot `{slot}` proves {relation}, but {leaves} resolves the leaves of {rels or 'nothing'}")
+                served[slot] = f"HipPrepare<{relation}, {leaves}>"
+                continue
+            tm = re.search(r"Box::new\(\s*((?:\w+::)*\w+)", expr)
+            if tm:  # the type is the last CamelCase segment of the path (`stage::HipX::new(ctx)`, `HipUniskip::<R>::new(..)`, `stage::HipY { .. }`)
+                camel = [seg for seg in tm.group(1).split("::") if seg[:1].isupper()]
+                tm = re.match(r"(\w+)", camel[-1]) if camel else None
+            if not tm:
+                self.findings.append(f"mi355x(): cannot read the type assigned to `backend.{slot}`: {expr[:80]}")
+                continue
+            ty = tm.group(1)
+            fits = []
+            for i in impls.get(ty, []):
+                if i["trait"] != trait:
+                    continue
+                args = [re.sub(r"<.*", "", a.strip()) for a in split_top(i["trait_args"] or "")]
+                if relation is None or relation in args or any(a in ("R", "$relation") for a in args):
+                    fits.append(i)
+            if not fits:
+                self.findings.append(f"mi355x(): slot `{slot}` needs `impl {trait}<Fr{', ' + relation if relation else ''}..> for {ty}`; none in the crate")
+            served[slot] = ty
+        self.slots_served = served
+        # placeholders that only live inside a mem::replace do not count
+        real = {k: v for k, v in served.items()}
+        if len(real) < 25:
+            self.findings.append(f"mi355x() overwrites {len(real)} of {len(slots)} slots; the round-5 review asks for >= 25")
+
+    # ---- 5. imports: every `use <reference crate>::path::Item` names a pub item of that crate at that path ---------------------------------------------------------------
+    def check_imports(self):
+        if not self.live:
+            return
+        cache = {}
+
+        def module_sources(crate, mods):
+            """sources of module `mods` of `crate`: [(path, text)] of <mods>.rs / <mods>/mod.rs (the crate root: lib.rs); None when the module does not exist"""
+            key = (crate, tuple(mods))
+            if key not in cache:
+                base = crate_dir(crate)
+                cands = [os.path.join(base, "lib.rs")] if not mods else [os.path.join(base, *mods) + ".rs", os.path.join(base, *mods, "mod.rs")]
+                found = [(c, strip(open(c).read())) for c in cands if os.path.isfile(c)]
+                if not found and mods:  # an inline `pub mod name { .. }` of the parent
+                    parent = module_sources(crate, mods[:-1])
+                    if parent:
+                        for path, text in parent:
+                            im = re.search(r"\bmod\s+%s\s*\{" % re.escape(mods[-1]), text)
+                            if im:
+                                found.append((path, text[im.end():match_close(text, im.end() - 1) - 1]))
+                cache[key] = found or None
+            return cache[key]
+
+        def declares(text, name):
+            if re.search(r"\bpub(?:\([^)]*\))?\s+(?:unsafe\s+)?(?:struct|enum|trait|fn|type|const|static|mod|union)\s+%s\b" % re.escape(name), text):
+                return True
+            if re.search(r"macro_rules!\s+%s\b" % re.escape(name), text):
+                return True
+            for um in re.finditer(r"\bpub(?:\([^)]*\))?\s+use\s+([^;]+);", text):
+                flat = flatten_use(re.sub(r"\s+", " ", um.group(1)))
+                if name in flat or "*" in flat:
+                    return True
+            return False
+
+        for fname, uses in self.crate.uses.items():
+            for local, full in uses.items():
+                parts = full.split("::")
+                crate = parts[0]
+                if crate not in self.crate.deps or not crate.startswith("jolt_") or len(parts) < 2 or parts[-1] == "*":
+                    continue
+                mods, item = parts[1:-1], parts[-1]
+                if "__private" in mods:
+                    continue  # doc-hidden re-exports a derive macro uses
+                srcs = module_sources(crate, mods)
+                if srcs is None:
+                    self.findings.append(f"{fname}: `use {full}`: {crate} has no module `{'::'.join(mods)}`")
+                    continue
+                if not any(declares(text, item) for _, text in srcs):
+                    # a name that is itself a module file
+                    if module_sources(crate, mods + [item]):
+                        continue
+                    self.findings.append(f"{fname}: `use {full}`: `{item}` is not a pub item of {crate}::{'::'.join(mods) or '(crate root)'}")
+
     def run(self):
         self.check_crate_roots()
         # trait lookups for blanket impls need the traits of the bounds too: prime the surface with every reference trait the crate names
@@ -614,6 +747,8 @@ class Audit:
         for extra in ("ModeStreamingCommitment",):
             self.trait("jolt_kernels", extra)
         self.check_generic_uses()
+        self.check_backend_slots()
+        self.check_imports()
         return self.findings
 
 
@@ -652,7 +787,11 @@ def main():
     findings = a.run()
     for f in findings:
         print("FINDING", f)
-    print(f"{len(findings)} finding(s); {len(a.crate.impls)} trait impls, reference surface {'live' if live else 'from the fixture'}")
+    served = getattr(a, "slots_served", {})
+    print(f"{len(findings)} finding(s); {len(a.crate.impls)} trait impls, mi355x() serves {len(served)} of {len(a.surface.get('slots', {}))} JoltBackend slots, reference surface {'live' if live else 'from the fixture'}")
+    if "--slots" in sys.argv:
+        for slot, (trait, relation) in sorted(a.surface.get("slots", {}).items()):
+            print(f"  {slot:36s} {trait:26s} {relation or '':34s} {served.get(slot, '-- optimized() --')}")
     sys.exit(1 if findings else 0)
 
 
