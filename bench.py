@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--witness", choices=["resident", "upload", "upload-pinned", "upload-overlapped"], default="resident",
                     help="resident (default, the contract's `value`): the witness columns sit in HBM before the timed region.  upload: every step starts from the packed "
                          "per-cycle rows in HOST memory -- one H2D copy + device-side column extraction (SURVEY.md section 8 f1) -- a PCIe-inclusive diagnostic, N = 1 only")
+    ap.add_argument("--ram-addresses", choices=["uniform", "hotset"], default="uniform",
+                    help="address stream of the synthetic RAM / register accesses of the stage operators: uniform over the K words, or hotset (90 %% of the accesses on ~2^10 "
+                         "words / 8 registers: BASELINE configs[4]'s btreemap shape, specs/byte-addressable-memory.md:119,127-130)")
     ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
     ap.add_argument("--roofline-only", action="store_true", help="only run the bind-kernel roofline loop (rocprof target)")
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
@@ -406,7 +409,7 @@ def main():
             if pcs_sharded is not None:
                 pcs_sharded.open(label)
     else:
-        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), witness_upload={"resident": False, "upload": True, "upload-pinned": "pinned", "upload-overlapped": "overlapped"}[args.witness])
+        wl = DeviceWorkload(ctx, args.scale, pcs=pcs, extended=(args.stages == "all"), ram_addresses=args.ram_addresses, witness_upload={"resident": False, "upload": True, "upload-pinned": "pinned", "upload-overlapped": "overlapped"}[args.witness])
         if os.environ.get("JOLT_FLIP_UPLOAD") == "1":  # diagnostic: a RESIDENT-built workload switched to the overlapped upload before the timed loop (what the value_with_upload leg does)
             wl.witness_upload, wl.witness_pinned, wl.witness_overlapped = True, True, True
         step = wl.step
@@ -476,16 +479,19 @@ def main():
                         ("ram_read_write", lambda: e.ram_read_write(3300)), ("registers_read_write", lambda: e.registers_read_write(3350)),
                         ("instruction_read_raf", lambda: e.instruction_read_raf(3400)), ("booleanity_address", lambda: e.booleanity_address(3450)),
                         ("hamming_weight", lambda: e.hamming_weight(3470)), ("address_domain", lambda: e.address_domain(3500))]
-        legs = ([("witness_upload", wl.upload_witness)] if args.witness != "resident" else []) + [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + ext_legs + [("prove", lambda: wl.prove(label=3000))] + \
-               ([("open", lambda: wl.open(label=3000))] if pcs else [])
+        # "opening_hint_background": what is left of the class sums the commit leg began on the background stream once the commit itself has landed -- in the step
+        # they run UNDER the stage operators and the sumcheck legs (and slow those down a little: the legs of this split, timed one by one, add up to more than the step)
+        hint_leg = [("opening_hint_background", lambda: wl.hint.wait() if getattr(wl, "hint", None) is not None else None)] if pcs else []
+        legs = ([("witness_upload", wl.upload_witness)] if args.witness != "resident" else []) + [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + hint_leg + ext_legs + \
+               [("prove", lambda: wl.prove(label=3000))] + ([("open", lambda: wl.open(label=3000))] if pcs else [])
         acc = {k: 0.0 for k, _ in legs}
         reps = 2
         for _ in range(reps):
             for k, fn in legs:
-                ctx.synchronize()
+                ctx.synchronize_foreground() if k == "opening_hint_background" else ctx.synchronize()
                 t1 = time.perf_counter()
                 fn()
-                ctx.synchronize()
+                ctx.synchronize_foreground() if k == "commit" else ctx.synchronize()
                 acc[k] += time.perf_counter() - t1
         split = {k: round(v / reps * 1e3, 3) for k, v in acc.items()}
     # The PCIe-inclusive rate beside the contract's `value` (never instead of it): the same K steps with every proof starting from packed rows in page-locked HOST memory,
@@ -560,7 +566,7 @@ def main():
         "dtype": "u256 (BN254 Fr / Fq, 8x u32 Montgomery limbs; integer, bit-exact)",
         "data": "synthetic",
         "config": {"workload": what, "trace_length_per_gpu": 1 << args.scale, "trace_length_total": total_cycles, "baseline_config": baseline_config(world, args.scale, bool(pcs)),
-                   "parallelism": f"hypercube sharded over {world} GPU(s)"},
+                   "parallelism": f"hypercube sharded over {world} GPU(s)", "ram_addresses": args.ram_addresses},
     }
     if split is not None:
         out["config"]["ms_per_step_split"] = split
@@ -622,8 +628,17 @@ def main():
             try:
                 srs_dev = (pcs_sharded.srs if sharded else wl.srs) if pcs else None  # the CPU sample's grid uses a prefix of the same SRS (inputs)
                 out["cpu_baseline"] = cpu_baseline(args.cpu_scale, srs_dev, bool(pcs), with_ext=(the_ext is not None), gpu_scale=args.scale)
+                at_t = os.path.join(ROOT, "profiles", "r06_cpu_baseline_T22.json")
+                if args.cpu_scale == 0 and args.scale == 22 and os.path.exists(at_t):  # the same CPU legs at the GPU line's own T: ~2.5 minutes of CPU work, collected once per round
+                    try:
+                        rec = json.load(open(at_t))
+                        out["cpu_baseline"]["config"]["at_gpu_T"] = {"trace_length": rec["config"]["trace_length"], "value": rec["value"], "cores": rec["cores"],
+                                                                      "seconds_per_step": rec["config"]["seconds_per_step"],
+                                                                      "source": "profiles/r06_cpu_baseline_T22.json (`bench.py --cpu-scale 22` on a GPU box's host; NOT collected in this run)"}
+                    except Exception:
+                        pass
                 if split is not None:  # the GPU's time for exactly the legs the CPU figure covers (the stage operators are in `value` but not in the CPU sample)
-                    same = [k for k in ("prepare", "commit", "prove", "open") if k in split]
+                    same = [k for k in ("prepare", "commit", "opening_hint_background", "prove", "open") if k in split]
                     ms = sum(split[k] for k in same)
                     out["cpu_baseline"]["gpu_same_legs"] = {"legs": same, "ms_per_step": round(ms, 3), "cycles_per_s": round((1 << args.scale) / (ms * 1e-3), 1),
                                                             "ratio_to_cpu": round(((1 << args.scale) / (ms * 1e-3)) / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"].get("value") else None}

@@ -71,6 +71,8 @@ int32_t jolt_abi_version(void);
 int32_t jolt_ctx_create(int32_t device_id, void *stream, jolt_ctx **out);
 int32_t jolt_ctx_destroy(jolt_ctx *ctx);
 int32_t jolt_ctx_synchronize(jolt_ctx *ctx);
+/* ... without the background stream (jolt_grid_hint_begin's class sums may outlive the leg that began them): what a caller timing a leg waits for */
+int32_t jolt_ctx_synchronize_foreground(jolt_ctx *ctx);
 const char *jolt_last_error(const jolt_ctx *ctx);
 /* Device memory of tables, members and temporaries comes from a per-context pool (a proof builds and drops dozens of T-sized
  * derived tables -- the Vec<Fr> allocations of EqPolynomial::evals & co. in the reference; hipMalloc / hipFree cost 0.1-1 ms each

@@ -201,6 +201,14 @@ extern "C" int32_t jolt_ctx_synchronize(jolt_ctx* ctx) {
     JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return JOLT_OK;
 }
+// The same without the background (hint) stream: what a caller that times a leg waits for -- the opening hint's class sums are meant to outlive the leg that began them.
+extern "C" int32_t jolt_ctx_synchronize_foreground(jolt_ctx* ctx) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    JOLT_TRY(jolt_internal_engine_quiesce(ctx));
+    for (int k = 0; k < 3; ++k) if (ctx->side[k]) JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side[k]));
+    JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JOLT_OK;
+}
 extern "C" const char* jolt_last_error(const jolt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 extern "C" int32_t jolt_timer_begin(jolt_ctx* ctx) {

@@ -99,6 +99,9 @@ struct jolt_ctx {
     bool rows_many_attr_set = false;  // k_rows_to_ints_many's dynamic-LDS limit raised on this device (onehot.hip)
     int msm_lanes = 4;            // MSM lanes used by jolt_internal_msm_many (JOLT_MSM_LANES=1: every MSM on the main stream, for standalone kernel durations)
     int msm_fx_partition = 2;     // JOLT_FX_PARTITION=1: one-pass segment scatter (A/B of the two coalesced passes in msm_fixed.hip)
+    bool msm_uniform_scalars = false;     // set around MSMs whose scalars are UNIFORM field elements (quotients of a random linear combination, the witness polynomials of an opening): the digit sort
+                                          // may then size its regions from the digit model (capacity sort, msm_fixed.hip 2d).  Level commitments do not set it: the folds of a sparse or
+                                          // few-valued polynomial overflow the regions and would pay the capacity passes AND the exact sort
     bool msm_full_width_scalars = false;  // set by a caller around MSMs whose scalars are uniform field elements (the level commitments of an opening): lets mid-length ones use the mid table set
     bool msm_fx_soa = true;          // fixed-base MSM: no key array, split entries in the partition / segment sort (JOLT_FX_SOA=0: 8-byte entries, for an A/B)
     bool msm_fx_grid_reduce = true;  // fixed-base MSM: bucket reduction by rows and columns (JOLT_FX_REDUCE=0: running sums, for an A/B)

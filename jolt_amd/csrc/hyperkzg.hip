@@ -621,9 +621,9 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         // h at r^2 FIRST, and its MSM enqueued on the second lane at once: its digit sort (HBM bound) runs under the scan that produces q (bound by its multiplications)
         s = jolt_hyperkzg_witness_poly(ctx, b_poly, &u_abi[2], &h2);
         if (s == JOLT_OK && early_one) {
-            ctx->msm_full_width_scalars = true;  // quotients of the random linear combination: uniform field elements (lets the sort use capacity regions, msm_fixed.hip 2d)
+            ctx->msm_full_width_scalars = ctx->msm_uniform_scalars = true;  // quotients of the random linear combination: uniform field elements (lets the sort use capacity regions, msm_fixed.hip 2d)
             const int32_t bs = jolt_internal_msm_one_begin(ctx, srs, b_poly->len - 2, 1, h2->data(), h2->len);
-            ctx->msm_full_width_scalars = false;
+            ctx->msm_full_width_scalars = ctx->msm_uniform_scalars = false;
             if (bs == JOLT_OK) begun = true;
             else if (bs != JOLT_ERR_UNSUPPORTED) s = bs;
         }
@@ -651,10 +651,10 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
         }
         if (s == JOLT_OK) {
             G1Jac three[3];
-            ctx->msm_full_width_scalars = true;
+            ctx->msm_full_width_scalars = ctx->msm_uniform_scalars = true;
             const int32_t ps = begun ? jolt_internal_msm_pair_finish(ctx, srs, qp->data(), qp->len, 1, three)
                                      : jolt_internal_msm_pair_and_one(ctx, srs, qp->data(), qp->len, 1, h2->data(), h2->len, three);
-            ctx->msm_full_width_scalars = false;
+            ctx->msm_full_width_scalars = ctx->msm_uniform_scalars = false;
             begun = false;
             if (ps == JOLT_OK) {
                 const Fr alpha = direct ? add(a_lo, mul(q_lo, u[2])) : add(a_lo, mul(q_lo, u[1])), r_can = from_mont(r), a_can = from_mont(alpha);

@@ -688,9 +688,9 @@ extern "C" int32_t jolt_msm_g1_table(jolt_ctx* ctx, const jolt_srs* srs, const j
 // (msm_fixed.hip; 64-bit witness scalars must not: their top window would pile onto a few buckets)
 extern "C" int32_t jolt_msm_g1_table_full_width(jolt_ctx* ctx, const jolt_srs* srs, const jolt_table* scalars, size_t n, jolt_g1_t* out) {
     if (!ctx) return JOLT_ERR_INVALID_ARG;
-    ctx->msm_full_width_scalars = true;
+    ctx->msm_full_width_scalars = ctx->msm_uniform_scalars = true;  // the caller vouches for uniform field elements: mid tables AND the capacity sort
     const int32_t s = jolt_msm_g1_table(ctx, srs, scalars, n, out);
-    ctx->msm_full_width_scalars = false;
+    ctx->msm_full_width_scalars = ctx->msm_uniform_scalars = false;
     return s;
 }
 

@@ -1114,7 +1114,7 @@ int32_t jolt_internal_msm_fixed_enqueue(jolt_ctx* ctx, const jolt_srs* srs, cons
     static const bool capacity_on = !(std::getenv("JOLT_FX_CAPACITY") && std::atoi(std::getenv("JOLT_FX_CAPACITY")) == 0);
     FxCapModel cap_model;
     size_t cap_total = 0;
-    bool capacity = capacity_on && soa && ctx->msm_full_width_scalars && n >= ((size_t)1 << 16);
+    bool capacity = capacity_on && soa && ctx->msm_uniform_scalars && n >= ((size_t)1 << 16);
     if (capacity) {
         capacity = fx_capacity_model(n, c, W, &cap_model);
         const uint64_t top_max = cap_model.top_max;

@@ -90,6 +90,10 @@ class Context:
             lib().jolt_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
+    def synchronize_foreground(self):
+        """every stream but the background one (the opening hint's class sums)"""
+        _ck(lib().jolt_ctx_synchronize_foreground(self.h), "jolt_ctx_synchronize_foreground", self)
+
     def synchronize(self):
         _ck(lib().jolt_ctx_synchronize(self.h), "jolt_ctx_synchronize", self)
 

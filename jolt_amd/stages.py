@@ -43,15 +43,33 @@ ADDRESS_BITS, PHASES, CHUNK = 128, 16, 256
 PRODUCT_EXTENSION = np.array([[3, -3, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, -3, 3]], dtype=np.int64)
 
 
-def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None):
+HOTSET_SHARE = 0.9  # share of the accesses that fall on the hot set (addresses="hotset")
+
+
+def hotset_addresses(K, T, rng, hot=None):
+    """A skewed (btreemap-like) address stream: HOTSET_SHARE of the accesses on `hot` addresses scattered over [0, K) (default min(2^10, max(1, K / 64)): the tree's
+    upper levels and the allocator's free lists are touched by every operation, specs/byte-addressable-memory.md:119,127-130; crates/jolt-prover/src/profile.rs:80-84),
+    the rest uniform over K.  Deterministic in `rng`."""
+    hot = max(1, min(K, hot if hot is not None else min(1 << 10, max(1, K // 64))))
+    hot_set = rng.permutation(K)[:hot].astype(np.uint64)
+    a = rng.integers(0, K, size=T, dtype=np.uint64)
+    on_hot = rng.random(T) < HOTSET_SHARE
+    a[on_hot] = hot_set[rng.integers(0, hot, size=int(on_hot.sum()))]
+    return a
+
+
+def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None, addresses="uniform"):
     """RamAccessColumns (optimized/ram_trace.rs:22-75) of a memory-consistent synthetic trace: per cycle an optional access (address, word before,
     word after), the word before being what the previous access to that address left (or the initial memory).  val_init: the memory the trace starts from
-    (a later block of a longer trace: the final memory of the block before it, `val_final`); drawn when None."""
+    (a later block of a longer trace: the final memory of the block before it, `val_final`); drawn when None.  addresses: "uniform" over the K words, or "hotset"
+    (hotset_addresses: 90 % of the accesses on ~2^10 words -- chains of thousands of accesses per hot word, most words never touched)."""
     K, T = 1 << log_k, 1 << log_t
     if val_init is None:
         val_init = rng.integers(0, 2**63, size=K, dtype=np.uint64)
     val_init = np.ascontiguousarray(val_init, dtype=np.uint64)
-    addresses = rng.integers(0, K, size=T, dtype=np.uint64)
+    if addresses not in ("uniform", "hotset"):
+        raise ValueError(addresses)
+    addresses = rng.integers(0, K, size=T, dtype=np.uint64) if addresses == "uniform" else hotset_addresses(K, T, rng)
     hit = rng.random(T) < access
     addresses[~hit] = NO_ACCESS
     cyc = np.nonzero(hit)[0]
@@ -82,14 +100,17 @@ def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None
 REG_NONE = np.uint8(0xFF)
 
 
-def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None, reg_init=None):
+def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None, reg_init=None, addresses="uniform"):
     """RegisterCycleRow columns (optimized/registers_read_write/rows.rs:22-31) of a consistent synthetic trace: a read returns what the last
     earlier write to that register left (registers start at 0, or at reg_init for a later block of a longer trace), rd_pre likewise; rd_post is fresh.
     hot: draw registers from the first `hot` only (many cells per register pair).  `reg_final`: the register file after the last cycle."""
     K, T = 1 << log_k, 1 << log_t
     reg_init = np.zeros(K, dtype=np.uint64) if reg_init is None else np.ascontiguousarray(reg_init, dtype=np.uint64)
     pool = K if hot is None else min(K, hot)
-    draw = lambda p: np.where(rng.random(T) < p, rng.integers(0, pool, size=T), 0xFF).astype(np.uint8)
+    if addresses == "hotset":  # 90 % of the operands on 8 of the K registers (a compiled loop lives in a handful of registers), the rest uniform
+        draw = lambda p: np.where(rng.random(T) < p, hotset_addresses(K, T, rng, hot=min(8, K)), 0xFF).astype(np.uint8)
+    else:
+        draw = lambda p: np.where(rng.random(T) < p, rng.integers(0, pool, size=T), 0xFF).astype(np.uint8)
     rs1, rs2, rd = draw(p_rs1), draw(p_rs2), draw(p_rd)
     rd_post = np.where(rd != REG_NONE, rng.integers(0, 2**64, size=T, dtype=np.uint64), 0).astype(np.uint64)
     cyc = np.arange(T, dtype=np.int64)
@@ -139,11 +160,11 @@ def interleave_operands(x, y):
     return np.stack([lo, hi], axis=1)
 
 
-def extended_params(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_count=4, log_k=None, log_kb=None):
+def extended_params(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_count=4, log_k=None, log_kb=None, ram_addresses="uniform"):
     """What a proof over T = 2^n_vars cycles shares between the blocks of its trace (and between the ranks of a sharded prover): the points, the batching
     scalars, the integer / field column weights, the sizes, the K-sized public tables -- everything of the description that is not a witness column."""
     rng = np.random.default_rng([seed + 500, 0xA11])
-    p = {"n_vars": n_vars, "n_outer": n_outer, "n_nodes": n_nodes}
+    p = {"n_vars": n_vars, "n_outer": n_outer, "n_nodes": n_nodes, "ram_addresses": ram_addresses}  # ram_addresses: "uniform" | "hotset" (RAM words AND registers)
     # ---- stage 1: integer uni-skip column weights (~40 % non-zero), field weights of the remainder
     shape = (n_nodes, 2, 1 + n_outer)
     p["outer_iwa"] = rng.integers(-2**20, 2**20, size=shape).astype(np.int64) * (rng.random(shape) < 0.4)
@@ -189,8 +210,8 @@ def extended_block(p, n_block, block, seed=2026, ram_init=None, reg_init=None, o
     T = 1 << n_block
     gen = lambda part: np.random.default_rng([seed + 500, 0xB10C, block, part])
     b = {}
-    b["ram"] = consistent_ram_trace(p["ram_log_k"], n_block, gen(1), val_init=ram_init)
-    b["registers"] = consistent_register_trace(7, n_block, gen(2), reg_init=reg_init)  # REGISTER_ADDRESS_BITS = 7
+    b["ram"] = consistent_ram_trace(p["ram_log_k"], n_block, gen(1), val_init=ram_init, addresses=p.get("ram_addresses", "uniform"))
+    b["registers"] = consistent_register_trace(7, n_block, gen(2), reg_init=reg_init, addresses=p.get("ram_addresses", "uniform"))  # REGISTER_ADDRESS_BITS = 7
     if only_state:
         return b
     rng = gen(3)

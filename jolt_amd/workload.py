@@ -239,7 +239,7 @@ class DeviceWorkload:
     commitment grid of crates/jolt-kernels/src/commitment.rs:86-130 -- the two dense increment columns at address 0, the one-hot
     RA columns as 0/1 coefficients -- committed with HyperKZG and opened jointly at one point)."""
 
-    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, extended=False, witness_upload=False, **kw):
+    def __init__(self, ctx, n_vars, seed=2026, pcs=None, srs=None, fixed_base=True, extended=False, witness_upload=False, ram_addresses="uniform", **kw):
         from . import ffi
         self.ctx, self.n_vars, self.ffi, self.pcs = ctx, n_vars, ffi, pcs
         # witness_upload: every step STARTS from the packed per-cycle rows in host memory (RowSource::rows() + WitnessBundle::from_row windows,
@@ -256,7 +256,7 @@ class DeviceWorkload:
         self.ext = None
         if extended:
             from .stages import DeviceExtended
-            self.ext = DeviceExtended(ctx, n_vars, seed)
+            self.ext = DeviceExtended(ctx, n_vars, seed, ram_addresses=ram_addresses)  # "hotset": a btreemap-like skewed RAM / register address stream
         self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)

@@ -91,3 +91,24 @@ def test_address_domain_relations_at_benchmark_scale(pair):
     assert set(got) == set(want) == {"bytecode_read_raf", "ram_raf_evaluation", "ram_output_check"}
     for name in got:
         same(got[name], want[name], name)
+
+
+def test_memory_checking_operators_on_a_hot_set_trace_at_benchmark_scale():
+    """BASELINE configs[4]'s shape at T = 2^22 (`bench.py --ram-addresses hotset`): the RAM and register address streams skewed onto a hot set (90 % of the accesses on 2^10
+    of the 2^16 words / 8 of the 128 registers, jolt_amd.stages.hotset_addresses) where every other test draws them uniformly.  The operators whose data structures
+    depend on the address distribution -- both sparse read-write matrices, the RAM key index behind RAF evaluation and the output check -- against the oracle twin."""
+    import oracle_lib as O
+    O.baseline_set_threads(min(128, os.cpu_count() or 1))
+    d = build_extended(N_VARS, SEED + 1, ram_addresses="hotset")
+    hit = d["ram"]["addresses"][d["ram"]["addresses"] != np.uint64(0xFFFFFFFFFFFFFFFF)]
+    assert np.unique(hit, return_counts=True)[1].max() > 1000  # (uniform: ~38 accesses per word)
+    ctx = ffi.Context(0)
+    dev = DeviceExtended(ctx, N_VARS, description=d)
+    orc = OracleExtended(N_VARS, description=d)
+    check(dev, dev.ram_read_write(LABEL + 300), orc.ram_read_write(LABEL + 300), "ram_read_write (hot set)", "ram")
+    check(dev, dev.registers_read_write(LABEL + 350), orc.registers_read_write(LABEL + 350), "registers_read_write (hot set)", "registers")
+    got, want = dev.address_domain(LABEL + 500), orc.address_domain(LABEL + 500)
+    for name in ("ram_raf_evaluation", "ram_output_check"):
+        same(got[name], want[name], name + " (hot set)")
+    dev.close()
+    ctx.close()

@@ -52,6 +52,34 @@ def test_pushforward_matches_fold_cycles(ctx, log_t, k, n_w, skew, cold):
     pd.free()
 
 
+@pytest.mark.parametrize("log_t,k", [(14, 1 << 12), (18, 1 << 16), (20, 1 << 16)])
+def test_pushforward_and_last_value_on_a_hot_set_key_stream(ctx, log_t, k):
+    """Keys drawn like a btreemap's RAM addresses (90 % on <= 2^10 of the k keys, jolt_amd.stages.hotset_addresses): bins of thousands of rows next to empty bins -- the
+    sorted index, its work items and both walks against the oracle's fold_cycles / last_value"""
+    from jolt_amd.stages import hotset_addresses
+    rng = np.random.default_rng(9000 + log_t)
+    T = 1 << log_t
+    keys = hotset_addresses(k, T, rng)
+    keys[rng.random(T) < 0.4] = NONE  # the RAM column's cold cycles
+    weights = [rand_fr(T, rng) for _ in range(2)]
+    kd = ctx.ints(keys)
+    ix = ctx.key_index(kd, k)
+    tabs = [ctx.upload(w) for w in weights]
+    out = ix.pushforward(tabs)
+    for s in range(2):
+        assert np.array_equal(out[s].download(), O.fold_cycles(keys, k, weights[s])), s
+    post = rng.integers(0, 2**64, size=T, dtype=np.uint64)
+    init = rand_fr(k, rng)
+    pd, it = ctx.ints(post), ctx.upload(init)
+    last = ix.last_value(pd, it)
+    assert np.array_equal(last.download(), O.last_value(keys, post, k, init))
+    for t in tabs + out + [it, last]:
+        t.free()
+    ix.free()
+    kd.free()
+    pd.free()
+
+
 def test_argument_checks(ctx):
     keys = ctx.ints(np.arange(8, dtype=np.uint64))
     with pytest.raises(ffi.JoltError):

@@ -107,6 +107,14 @@ def test_registers_at_trace_scale(ctx):
     lockstep(ctx, S.consistent_register_trace(7, 16, rng), 4343, compare_cells=False)
 
 
+@pytest.mark.parametrize("log_t", [10, 16])
+def test_registers_on_a_hot_set_of_registers(ctx, log_t):
+    """90 % of the operands on 8 of the 128 registers (a compiled loop lives in a handful of registers; jolt_amd.stages.hotset_addresses): write chains tens of thousands
+    of cycles long per hot register, up to three cells of one cycle in the same few columns"""
+    rng = np.random.default_rng(6100 + log_t)
+    lockstep(ctx, S.consistent_register_trace(7, log_t, rng, addresses="hotset"), 6200 + log_t, compare_cells=(log_t <= 10))
+
+
 def test_registers_argument_checks(ctx):
     rng = np.random.default_rng(5)
     tr = S.consistent_register_trace(3, 4, rng)

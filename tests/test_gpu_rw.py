@@ -87,6 +87,18 @@ def test_sparse_matrix_at_trace_scale(ctx):
     lockstep(ctx, make_trace(14, 16, 42, access=0.45, write=0.6), 4242, compare_entries=False)
 
 
+@pytest.mark.parametrize("log_k,log_t", [(10, 12), (14, 16), (16, 17)])
+def test_sparse_matrix_on_a_hot_set_address_stream(ctx, log_k, log_t):
+    """A btreemap-like trace (BASELINE configs[4]; jolt_amd.stages.hotset_addresses): 90 % of the accesses on <= 2^10 words -- access chains thousands of cycles long per
+    hot word, column groups of thousands of cells in the late cycle rounds, most of the K words never touched -- where the uniform traces above spread two or three
+    accesses over every word.  The merge-rank scatter of the bind, the match scans and the address rounds against the oracle, round for round."""
+    from jolt_amd import stages as S
+    tr = S.consistent_ram_trace(log_k, log_t, np.random.default_rng(5000 + log_t), access=0.6, write=0.5, addresses="hotset")
+    hit = tr["addresses"][tr["addresses"] != S.NO_ACCESS]
+    assert np.unique(hit, return_counts=True)[1].max() > (len(hit) >> 11)  # the stream IS skewed: some word takes hundreds of times its uniform share
+    lockstep(ctx, tr, 7100 + log_t, compare_entries=(log_t <= 12))
+
+
 def test_rw_matrix_argument_checks(ctx):
     tr = make_trace(3, 4, 5)
     inc, vi = ctx.upload(O.to_mont([int(v) % O.R_MOD for v in tr["inc"]])), ctx.upload(O.fr_from_u64(tr["val_init"]))
