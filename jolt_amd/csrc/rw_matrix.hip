@@ -488,6 +488,15 @@ static int32_t rw_read_total(jolt_rw_matrix* m, uint32_t* out) {
     return JOLT_OK;
 }
 static unsigned rw_grid(uint32_t n) { return std::max<unsigned>(1, (n + kBlock - 1) / kBlock); }
+// workgroups per CU of the round kernels' grid-stride loops (JOLT_RW_GRID_MULT; 4 = one resident set at 4 waves per SIMD)
+static uint32_t rw_round_mult() {
+    static const uint32_t m = [] {
+        const char* e = std::getenv("JOLT_RW_GRID_MULT");
+        const int v = e ? std::atoi(e) : 0;
+        return (uint32_t)(v > 0 && v <= 64 ? v : 4);
+    }();
+    return m;
+}
 
 extern "C" int32_t jolt_rw_matrix_destroy(jolt_rw_matrix* m) {
     if (!m) return JOLT_OK;
@@ -739,7 +748,7 @@ extern "C" int32_t jolt_rw_matrix_prove_round(jolt_rw_matrix* m, const jolt_fr_t
         JOLT_TRY(rw_ingest(m, r));
     }
     if (m->round >= m->log_t + m->log_k) { ctx->last_error = "prove_round on a fully bound rw matrix"; return JOLT_ERR_INVALID_ARG; }
-    const int grid = (int)std::max<uint32_t>(1, std::min<uint32_t>((m->n + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * 4));
+    const int grid = (int)std::max<uint32_t>(1, std::min<uint32_t>((m->n + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * rw_round_mult()));
     JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 2 + 8, 8));
     RwArrays& a = m->st[m->cur];
     Fr zero = Fr::zero();
@@ -1078,7 +1087,7 @@ extern "C" int32_t jolt_registers_rw_prove_round(jolt_rw_matrix* m, const jolt_f
     for (int k = 0; k < 4; ++k) fr_to_abi(&evals_out[k], zero);
     if (aux_out) for (int k = 0; k < 3; ++k) fr_to_abi(&aux_out[k], zero);
     if (m->round < m->log_t) {
-        const int grid = (int)std::max<uint32_t>(1, std::min<uint32_t>((m->n + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * 4));
+        const int grid = (int)std::max<uint32_t>(1, std::min<uint32_t>((m->n + kBlock - 1) / kBlock, (uint32_t)ctx->num_cus * rw_round_mult()));
         JOLT_TRY(jolt_internal_ensure_scratch(ctx, (size_t)grid * 2 + 8, 8));
         RwArrays& a = m->st[m->cur];
         if (m->n && !m->match_valid) {

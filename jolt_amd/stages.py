@@ -46,19 +46,26 @@ PRODUCT_EXTENSION = np.array([[3, -3, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, -
 HOTSET_SHARE = 0.9  # share of the accesses that fall on the hot set (addresses="hotset")
 
 
-def hotset_addresses(K, T, rng, hot=None):
-    """A skewed (btreemap-like) address stream: HOTSET_SHARE of the accesses on `hot` addresses scattered over [0, K) (default min(2^10, max(1, K / 64)): the tree's
-    upper levels and the allocator's free lists are touched by every operation, specs/byte-addressable-memory.md:119,127-130; crates/jolt-prover/src/profile.rs:80-84),
-    the rest uniform over K.  Deterministic in `rng`."""
+def draw_hot_set(K, rng, hot=None):
+    """the hot words of a skewed address stream: `hot` addresses scattered over [0, K) (default min(2^10, max(1, K / 64)))"""
     hot = max(1, min(K, hot if hot is not None else min(1 << 10, max(1, K // 64))))
-    hot_set = rng.permutation(K)[:hot].astype(np.uint64)
+    return rng.permutation(K)[:hot].astype(np.uint64)
+
+
+def hotset_addresses(K, T, rng, hot=None, hot_set=None):
+    """A skewed (btreemap-like) address stream: HOTSET_SHARE of the accesses on a hot set of addresses scattered over [0, K) (the tree's upper levels and the allocator's
+    free lists are touched by every operation, specs/byte-addressable-memory.md:119,127-130; crates/jolt-prover/src/profile.rs:80-84), the rest uniform over K.
+    hot_set: the hot addresses themselves (a trace dealt in blocks shares ONE hot set: extended_params draws it), else draw_hot_set(K, rng, hot).  Deterministic in `rng`."""
+    if hot_set is None:
+        hot_set = draw_hot_set(K, rng, hot)
+    hot_set = np.asarray(hot_set, dtype=np.uint64)
     a = rng.integers(0, K, size=T, dtype=np.uint64)
     on_hot = rng.random(T) < HOTSET_SHARE
-    a[on_hot] = hot_set[rng.integers(0, hot, size=int(on_hot.sum()))]
+    a[on_hot] = hot_set[rng.integers(0, len(hot_set), size=int(on_hot.sum()))]
     return a
 
 
-def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None, addresses="uniform"):
+def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None, addresses="uniform", hot_set=None):
     """RamAccessColumns (optimized/ram_trace.rs:22-75) of a memory-consistent synthetic trace: per cycle an optional access (address, word before,
     word after), the word before being what the previous access to that address left (or the initial memory).  val_init: the memory the trace starts from
     (a later block of a longer trace: the final memory of the block before it, `val_final`); drawn when None.  addresses: "uniform" over the K words, or "hotset"
@@ -69,7 +76,7 @@ def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None
     val_init = np.ascontiguousarray(val_init, dtype=np.uint64)
     if addresses not in ("uniform", "hotset"):
         raise ValueError(addresses)
-    addresses = rng.integers(0, K, size=T, dtype=np.uint64) if addresses == "uniform" else hotset_addresses(K, T, rng)
+    addresses = rng.integers(0, K, size=T, dtype=np.uint64) if addresses == "uniform" else hotset_addresses(K, T, rng, hot_set=hot_set)
     hit = rng.random(T) < access
     addresses[~hit] = NO_ACCESS
     cyc = np.nonzero(hit)[0]
@@ -100,7 +107,7 @@ def consistent_ram_trace(log_k, log_t, rng, access=0.6, write=0.5, val_init=None
 REG_NONE = np.uint8(0xFF)
 
 
-def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None, reg_init=None, addresses="uniform"):
+def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7, hot=None, reg_init=None, addresses="uniform", hot_set=None):
     """RegisterCycleRow columns (optimized/registers_read_write/rows.rs:22-31) of a consistent synthetic trace: a read returns what the last
     earlier write to that register left (registers start at 0, or at reg_init for a later block of a longer trace), rd_pre likewise; rd_post is fresh.
     hot: draw registers from the first `hot` only (many cells per register pair).  `reg_final`: the register file after the last cycle."""
@@ -108,7 +115,8 @@ def consistent_register_trace(log_k, log_t, rng, p_rs1=0.8, p_rs2=0.6, p_rd=0.7,
     reg_init = np.zeros(K, dtype=np.uint64) if reg_init is None else np.ascontiguousarray(reg_init, dtype=np.uint64)
     pool = K if hot is None else min(K, hot)
     if addresses == "hotset":  # 90 % of the operands on 8 of the K registers (a compiled loop lives in a handful of registers), the rest uniform
-        draw = lambda p: np.where(rng.random(T) < p, hotset_addresses(K, T, rng, hot=min(8, K)), 0xFF).astype(np.uint8)
+        regs_hot = hot_set if hot_set is not None else draw_hot_set(K, rng, min(8, K))
+        draw = lambda p: np.where(rng.random(T) < p, hotset_addresses(K, T, rng, hot_set=regs_hot), 0xFF).astype(np.uint8)
     else:
         draw = lambda p: np.where(rng.random(T) < p, rng.integers(0, pool, size=T), 0xFF).astype(np.uint8)
     rs1, rs2, rd = draw(p_rs1), draw(p_rs2), draw(p_rd)
@@ -193,6 +201,9 @@ def extended_params(n_vars, seed=2026, n_outer=35, n_nodes=9, n_tables=42, ra_co
     io_lo, io_len = K_ram // 4, max(1, K_ram // 16)
     val_io = np.zeros(K_ram, dtype=np.uint64)
     val_io[io_lo:io_lo + io_len] = rng.integers(0, 2**63, size=io_len, dtype=np.uint64)
+    if ram_addresses == "hotset":  # ONE hot set per trace, whatever the number of blocks it is dealt in (its own generator: the other draws stay what they were)
+        hs = np.random.default_rng([seed + 500, 0x407])
+        p["ram_hot_set"], p["reg_hot_set"] = draw_hot_set(K_ram, hs), draw_hot_set(1 << 7, hs, 8)
     p["ram_raf"] = dict(tau_low=rand_fr(n_vars, rng), lowest_address=np.uint64(0x80000000))
     p["ram_output"] = dict(point=rand_fr(p["ram_log_k"], rng), io_lo=io_lo, io_len=io_len, val_io=val_io)
     log_kb = log_kb if log_kb is not None else min(12, max(2, n_vars))
@@ -210,8 +221,8 @@ def extended_block(p, n_block, block, seed=2026, ram_init=None, reg_init=None, o
     T = 1 << n_block
     gen = lambda part: np.random.default_rng([seed + 500, 0xB10C, block, part])
     b = {}
-    b["ram"] = consistent_ram_trace(p["ram_log_k"], n_block, gen(1), val_init=ram_init, addresses=p.get("ram_addresses", "uniform"))
-    b["registers"] = consistent_register_trace(7, n_block, gen(2), reg_init=reg_init, addresses=p.get("ram_addresses", "uniform"))  # REGISTER_ADDRESS_BITS = 7
+    b["ram"] = consistent_ram_trace(p["ram_log_k"], n_block, gen(1), val_init=ram_init, addresses=p.get("ram_addresses", "uniform"), hot_set=p.get("ram_hot_set"))
+    b["registers"] = consistent_register_trace(7, n_block, gen(2), reg_init=reg_init, addresses=p.get("ram_addresses", "uniform"), hot_set=p.get("reg_hot_set"))  # REGISTER_ADDRESS_BITS = 7
     if only_state:
         return b
     rng = gen(3)

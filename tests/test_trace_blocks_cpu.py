@@ -66,3 +66,24 @@ def test_a_rank_rebuilds_its_own_block_from_the_carried_state(n_blocks):
         assert np.array_equal(cheap["ram"]["val_final"], blk["ram"]["val_final"]) and np.array_equal(cheap["registers"]["reg_final"], blk["registers"]["reg_final"])
         ram_state, reg_state = blk["ram"]["val_final"], blk["registers"]["reg_final"]
     assert np.array_equal(ram_state, whole["ram"]["val_final"])
+
+
+@pytest.mark.parametrize("n_vars,n_blocks", [(9, 1), (10, 4)])
+def test_a_hot_set_trace_is_one_consistent_execution_and_is_skewed(n_vars, n_blocks):
+    """ram_addresses="hotset" (BASELINE configs[4]'s btreemap shape, jolt_amd.stages.hotset_addresses): 90 % of the RAM accesses on a hot set of words and of the register
+    operands on 8 registers -- still ONE consistent execution (every read returns the last write), whole or dealt in blocks, and measurably skewed"""
+    kw = dict(KW)
+    kw["log_k"] = 8
+    d = S.build_extended(n_vars, seed=77, n_blocks=n_blocks, ram_addresses="hotset", **kw)
+    replay_ram(d["ram"])
+    replay_registers(d["registers"])
+    hit = d["ram"]["addresses"][d["ram"]["addresses"] != S.NO_ACCESS]
+    counts = np.sort(np.unique(hit, return_counts=True)[1])[::-1]
+    hot = max(1, (1 << 8) // 64)
+    assert counts[:hot].sum() > 0.8 * len(hit)  # the hot set takes ~ 90 % + its uniform share
+    rd = d["registers"]["rd"][d["registers"]["rd"] != S.REG_NONE]
+    assert np.sort(np.unique(rd, return_counts=True)[1])[::-1][:8].sum() > 0.8 * len(rd)
+    uniform = S.build_extended(n_vars, seed=77, n_blocks=n_blocks, **kw)
+    assert not np.array_equal(uniform["ram"]["addresses"], d["ram"]["addresses"])
+    with pytest.raises(ValueError):
+        S.consistent_ram_trace(4, 4, np.random.default_rng(0), addresses="zipf")
