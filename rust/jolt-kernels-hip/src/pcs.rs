@@ -236,7 +236,7 @@ impl HipHyperKzg {
 
     /// The same with the commitments of the first folded polynomials SUPPLIED (`jolt_host_hyperkzg_open_with_levels`): for the joint polynomial of one-hot and dense
     /// columns they follow by linearity from [`crate::ops::HipHotIndices::grid_commit_classes`] -- `com(P_s) = sum_p s_p sum_c w_c S_p^(s,c) + com(dense fold)`,
-    /// `DESIGN.md` section 3.7b; `jolt_amd/workload.py::level_commitments_by_linearity` is the executable description of the combination -- instead of from MSMs over
+    /// `docs/kernels.md` section 3.7b; `HipHyperKzg::open_joint` (section 3.7c) is the path that computes them on the device -- instead of from MSMs over
     /// 2^(ell - s) full-width scalars.  They are absorbed and returned like computed ones.
     pub fn open_resident_with_levels<T: Transcript<Challenge = Fr>>(
         poly: &HipPoly,

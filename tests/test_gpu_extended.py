@@ -87,3 +87,72 @@ def test_instruction_read_raf_every_address_round_from_the_definition_at_2_16():
     same(got, {k: v for k, v in want.items() if k != "claim"}, "instruction_read_raf")
     dev.close()
     ctx.close()
+
+
+def test_a_stage_batch_over_operators_is_the_batch_over_their_members():
+    """jolt_host_prove_batch_ops with MORE than one operator, as a stage driver batches the members of a stage (prover.rs:193-362): RAM RAF evaluation (degree 2) and the RAM
+    output check (degree 3, split-eq) -- both log K rounds -- and booleanity's address phase (log K_chunk rounds, a later window of the batch: front-loaded inactive rounds)
+    under one transcript and random batching coefficients.  The first two are dense members underneath, so the batch over the OPERATORS must equal jolt_host_prove_batch over
+    the same members built by hand (the round-5 path); prove_batch checks s(0) + s(1) against the running claim every round for all three."""
+    from jolt_amd import stages as S
+    from util import rand_fr
+    n_vars = 10
+    ctx = ffi.Context(0)
+    dev = DeviceExtended(ctx, n_vars, seed=31, n_tables=5, log_k=6, log_kb=5)
+    d = dev.d
+    ram, raf, io, bo = d["ram"], d["ram_raf"], d["ram_output"], d["booleanity"]
+    index = ctx.key_index(dev.ram_cols[0], 1 << ram["log_k"])
+    coeffs = rand_fr(3, 77)
+
+    def operators():
+        return [ctx.stage_ram_raf_evaluation(index, raf["tau_low"], raf["lowest_address"]),
+                ctx.stage_ram_output_check(index, dev.ram_cols[2], ram["val_init"], io["val_io"], io["io_lo"], io["io_len"], io["point"]),
+                ctx.stage_booleanity_address(dev.bool_cols, bo["reference_cycle"], bo["reference_address"], bo["gamma"])]
+    ops = operators()
+    claims = [ops[0].input_claim(), ops[1].input_claim(), np.zeros(4, dtype=np.uint64)]
+    rounds, offsets = ram["log_k"], [0, 0, ram["log_k"] - bo["log_k"]]
+    got = ctx.prove_batch_ops(ops, claims, coeffs, offsets, rounds, 3, label=5)
+    # the same two dense members by hand (stages.ram_raf_evaluation / ram_output_check, the round-5 drivers), batched by jolt_host_prove_batch; booleanity's operator alone
+    # in a second batch of its own cannot share the transcript, so only the two-member prefix is compared message for message: batch them without the third operator
+    two = operators()[:2]
+    ref_ops = ctx.prove_batch_ops(two, claims[:2], coeffs[:2], [0, 0], rounds, 3, label=6)
+    dops = S.DeviceOps(ctx, ffi, {"ram": index, "ram_post": dev.ram_cols[2]}, dev.pc_chunks)
+    eq = dops.eq(raf["tau_low"])
+    folded = dops.pushforward("ram", [eq])[0]
+    eq.free()
+    m_raf = dops.member_expr([folded, dops.u64_table(np.uint64(8) * np.arange(1 << ram["log_k"], dtype=np.uint64) + raf["lowest_address"])], [(dops.one, [0, 1])], 2)
+    init = dops.u64_table(ram["val_init"])
+    val_final = dops.last_value("ram", init)
+    val_io = dops.u64_table(io["val_io"])
+    diff = dops.rlc([val_final, val_io], [dops.one, dops.sub(np.zeros(4, dtype=np.uint64), dops.one)])
+    mask = np.zeros(1 << ram["log_k"], dtype=np.uint64)
+    mask[io["io_lo"]:io["io_lo"] + io["io_len"]] = 1
+    m_oc = dops.member_gruen_product(dops.u64_table(mask), diff, io["point"])
+    want = ctx.prove_batch([m_raf, m_oc], claims[:2], coeffs[:2], [0, 0], rounds, 3, label=6)
+    for key in ("polys", "challenges", "member_claims", "final_claim"):
+        assert np.array_equal(ref_ops[key], want[key]), key
+    # the three-operator batch: its own consistency -- the final claim is the batching combination of the members' claims, and the operators' output claims are those of
+    # the operators driven alone at the same point (the bound values are functions of the challenges only)
+    acc = np.zeros(4, dtype=np.uint64)
+    for c, mc in zip(coeffs, got["member_claims"]):
+        acc = ffi.host_fr_add(acc, ffi.host_fr_mul(c, mc))
+    assert np.array_equal(acc, got["final_claim"])
+    f = folded_again(ctx, dops, raf)
+    assert np.array_equal(ops[0].output_claims()[0], ctx.evaluate(f, got["challenges"][::-1]))
+    f.free()
+    for o in ops + two:
+        o.destroy()
+    for t in (init, val_final, val_io):
+        t.free()
+    m_raf.destroy()
+    m_oc.destroy()
+    index.free()
+    dev.close()
+    ctx.close()
+
+
+def folded_again(ctx, dops, raf):
+    eq = dops.eq(raf["tau_low"])
+    folded = dops.pushforward("ram", [eq])[0]
+    eq.free()
+    return folded
