@@ -965,7 +965,10 @@ int32_t jolt_stage_ram_raf_evaluation_create(jolt_ctx *ctx, const jolt_key_index
  * output_claims: {val_final at the bound address point}. */
 int32_t jolt_stage_ram_output_check_create(jolt_ctx *ctx, const jolt_key_index *ram_index, const jolt_ints *post_values, const uint64_t *val_init /* K */,
                                            const uint64_t *val_io /* K */, uint64_t io_lo, uint64_t io_len, const jolt_fr_t *r_address, jolt_stage_op **out);
-/* Drivers for the tests and the bench (a Rust host calls the contract above from its own prove_batch): prove_batch (prover.rs:193-362) over operators with the
+/* Test hook (CPU suite; no device, no context): the reference tier's dense member (NaiveSumcheckProver, crates/jolt-kernels/src/reference/naive.rs:53-377, LowToHigh) over HOST
+ * tables as a stage operator, so that the contract and the two drivers below run without a GPU against the oracle's prove_batch.  Tables are copied. */
+int32_t jolt_stage_host_expr_create(const jolt_fr_t *const *tables, size_t len, const jolt_member_desc *desc, jolt_stage_op **out);
+/* Drivers for the tests and the bench (a Rust host calls the contract above from its own prove_batch; `ctx` may be NULL for host-only operators): prove_batch (prover.rs:193-362) over operators with the
  * library's test transcript; and one operator driven alone -- per round the message, every coefficient absorbed, Transcript::challenge -- with
  * coeffs_out = rounds x stride (tails zeroed), n_coeffs_out[r] = the coefficients of round r, claim in = input claim / out = the final claim. */
 int32_t jolt_host_prove_batch_ops(jolt_ctx *ctx, jolt_stage_op *const *ops, size_t n_ops, const jolt_fr_t *input_claims, const jolt_fr_t *coefficients,

@@ -730,6 +730,7 @@ extern "C" int32_t jolt_host_prove_batch(jolt_ctx* ctx, jolt_member* const* memb
     std::vector<BatchMember> described;
     for (size_t i = 0; i < n_members; ++i) {
         if (!members[i]) return JOLT_ERR_INVALID_ARG;
+        if (offsets[i] > max_num_vars || members[i]->rounds > max_num_vars - offsets[i]) return JOLT_ERR_INVALID_ARG;  // WindowOutOfRange (before the prelude scales claims by 2^(max - rounds))
         owned.emplace_back(new DeviceMember(members[i]));
         ms.push_back(owned.back().get());
         described.push_back(BatchMember{fr_from_abi(&input_claims[i]), fr_from_abi(&coefficients[i]), members[i]->rounds, offsets[i]});

@@ -681,6 +681,68 @@ struct WindowOp final : jolt_stage_op {
     int32_t output_claims(std::vector<Fr>* out) override { return parent->output_claims(out); }
 };
 
+// A dense member over HOST tables (NaiveSumcheckProver, crates/jolt-kernels/src/reference/naive.rs:53-377, LowToHigh): sum_k coeffs[k] prod_{f in term k} table[f].
+// No device, no context: it exists so that the drivers above the contract (prove_batch over operators, the alone driver, round windows) and the contract's own error
+// behaviour are exercised by the CPU suite against the oracle's prove_batch; the product's operators are the device-backed ones above.
+struct HostExprOp final : jolt_stage_op {
+    std::vector<std::vector<Fr>> tables;
+    std::vector<uint32_t> offs, facs;
+    std::vector<Fr> coeffs;
+    size_t len = 0;
+
+    Fr summand(const std::vector<Fr>& at) const {
+        Fr acc = Fr::zero();
+        for (size_t k = 0; k + 1 < offs.size(); ++k) {
+            Fr term = coeffs[k];
+            for (uint32_t f = offs[k]; f < offs[k + 1]; ++f) term = mul(term, at[facs[f]]);
+            acc = add(acc, term);
+        }
+        return acc;
+    }
+    int32_t apply(const Fr& r) {
+        if (len < 2) return JOLT_ERR_INVALID_ARG;
+        binds.push_back(r);
+        for (std::vector<Fr>& t : tables) {
+            for (size_t y = 0; y < len / 2; ++y) t[y] = add(t[2 * y], mul(r, sub(t[2 * y + 1], t[2 * y])));  // dense.rs:222-263
+            t.resize(len / 2);
+        }
+        len /= 2;
+        return JOLT_OK;
+    }
+    int32_t prove_round(const Fr* bind, size_t, const Fr& claim, UnivariatePoly* out) override {
+        if (bind) JOLT_TRY(apply(*bind));
+        if (len < 2) return JOLT_ERR_INVALID_ARG;
+        std::vector<Fr> evals(degree + 1, Fr::zero()), at(tables.size());
+        for (size_t y = 0; y < len / 2; ++y) {
+            for (size_t t = 0; t <= degree; ++t) {
+                const Fr x = fr_from_u64(t);
+                for (size_t i = 0; i < tables.size(); ++i) at[i] = add(tables[i][2 * y], mul(x, sub(tables[i][2 * y + 1], tables[i][2 * y])));
+                evals[t] = add(evals[t], summand(at));
+            }
+        }
+        if (add(evals[0], evals[1]) != claim) return JOLT_ERR_ROUND_CHECK;  // naive.rs:298-306
+        *out = UnivariatePoly::from_evals(evals.data(), evals.size());
+        return JOLT_OK;
+    }
+    int32_t finish_rounds(const Fr& bind) override { return apply(bind); }
+    int32_t input_claim(Fr* out) override {
+        std::vector<Fr> at(tables.size());
+        Fr acc = Fr::zero();
+        for (size_t j = 0; j < len; ++j) {
+            for (size_t i = 0; i < tables.size(); ++i) at[i] = tables[i][j];
+            acc = add(acc, summand(at));
+        }
+        *out = acc;
+        return JOLT_OK;
+    }
+    int32_t output_claims(std::vector<Fr>* out) override {
+        if (len != 1) return JOLT_ERR_NOT_FULLY_BOUND;
+        out->clear();
+        for (const std::vector<Fr>& t : tables) out->push_back(t[0]);
+        return JOLT_OK;
+    }
+};
+
 template <class Op>
 Op* new_op(jolt_ctx* ctx, const char* name) {
     Op* op = new (std::nothrow) Op();
@@ -1111,6 +1173,37 @@ extern "C" int32_t jolt_stage_ram_output_check_create(jolt_ctx* ctx, const jolt_
     return JOLT_OK;
 }
 
+// Test hook (CPU suite): the reference tier's dense member over host tables as a stage operator -- see HostExprOp.  `tables`: n_tables arrays of `len` (a power of two)
+// canonical field elements, copied; the descriptor as for jolt_member_create_expr (LowToHigh only).
+extern "C" int32_t jolt_stage_host_expr_create(const jolt_fr_t* const* tables, size_t len, const jolt_member_desc* desc, jolt_stage_op** out) {
+    if (!tables || !desc || !out || len == 0 || (len & (len - 1)) != 0 || desc->n_tables == 0 || desc->n_tables > JOLT_MAX_MEMBER_TABLES || desc->n_terms == 0 ||
+        desc->n_terms > JOLT_MAX_MEMBER_TERMS || desc->degree == 0 || desc->degree > JOLT_MAX_DEGREE || desc->order != JOLT_ORDER_LOW_TO_HIGH || !desc->term_offsets ||
+        !desc->factors || !desc->coeffs)
+        return JOLT_ERR_INVALID_ARG;
+    HostExprOp* op = new_op<HostExprOp>(nullptr, "host_expr");
+    if (!op) return JOLT_ERR_OOM;
+    std::unique_ptr<HostExprOp> hold(op);
+    op->len = len;
+    op->rounds = log2_exact(len);
+    op->degree = desc->degree;
+    op->offs.assign(desc->term_offsets, desc->term_offsets + desc->n_terms + 1);
+    if (op->offs.back() > JOLT_MAX_MEMBER_FACTORS) return JOLT_ERR_INVALID_ARG;
+    op->facs.assign(desc->factors, desc->factors + op->offs.back());
+    for (uint32_t f : op->facs)
+        if (f >= desc->n_tables) return JOLT_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < desc->n_terms; ++k) {
+        if (op->offs[k + 1] < op->offs[k] || op->offs[k + 1] - op->offs[k] > desc->degree) return JOLT_ERR_INVALID_ARG;
+        op->coeffs.push_back(fr_from_abi(&desc->coeffs[k]));
+        if (!fr_is_canonical(op->coeffs.back())) return JOLT_ERR_INVALID_ARG;
+    }
+    for (uint32_t i = 0; i < desc->n_tables; ++i) {
+        if (!tables[i] || !all_canonical(tables[i], len)) return JOLT_ERR_INVALID_ARG;
+        op->tables.push_back(from_abi(tables[i], len));
+    }
+    *out = hold.release();
+    return JOLT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------------------------
@@ -1118,11 +1211,13 @@ extern "C" int32_t jolt_stage_ram_output_check_create(jolt_ctx* ctx, const jolt_
 extern "C" int32_t jolt_host_prove_batch_ops(jolt_ctx* ctx, jolt_stage_op* const* ops, size_t n_ops, const jolt_fr_t* input_claims, const jolt_fr_t* coefficients,
                                              const size_t* offsets, size_t max_num_vars, size_t max_degree, uint64_t transcript_label, int32_t challenge_mode,
                                              jolt_fr_t* out_polys, jolt_fr_t* out_challenges, jolt_fr_t* out_member_claims, jolt_fr_t* out_final_claim) {
-    if (!ctx || (!ops && n_ops) || !input_claims || !coefficients || !offsets || !out_polys || !out_challenges || !out_member_claims || !out_final_claim) return JOLT_ERR_INVALID_ARG;
+    (void)ctx;  // (may be NULL: host-only operators carry none; device-backed ones carry their own)
+    if ((!ops && n_ops) || !input_claims || !coefficients || !offsets || !out_polys || !out_challenges || !out_member_claims || !out_final_claim) return JOLT_ERR_INVALID_ARG;
     std::vector<ProveRounds*> ms;
     std::vector<BatchMember> described;
     for (size_t i = 0; i < n_ops; ++i) {
         if (!ops[i]) return JOLT_ERR_INVALID_ARG;
+        if (offsets[i] > max_num_vars || ops[i]->rounds > max_num_vars - offsets[i]) return JOLT_ERR_INVALID_ARG;  // WindowOutOfRange (before the prelude scales claims by 2^(max - rounds))
         ms.push_back(ops[i]);
         described.push_back(BatchMember{fr_from_abi(&input_claims[i]), fr_from_abi(&coefficients[i]), ops[i]->rounds, offsets[i]});
     }

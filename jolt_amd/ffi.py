@@ -1929,6 +1929,28 @@ class StageOp:
             pass
 
 
+def stage_host_expr(tables, terms, degree):
+    """jolt_stage_host_expr_create: the dense member over HOST tables as a stage operator (no device, no context): terms = [(coeff_limbs, [table indices]), ...]"""
+    tabs = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+    offs, facs = [0], []
+    for _, f in terms:
+        facs.extend(f)
+        offs.append(len(facs))
+    offs = np.array(offs, dtype=np.uint32)
+    facs_a = np.array(facs if facs else [0], dtype=np.uint32)
+    coeffs = np.ascontiguousarray(np.stack([fr(c) for c, _ in terms])).reshape(-1, 4)
+    d = MemberDesc(len(tabs), len(terms), degree, ORDER_LOW_TO_HIGH, offs.ctypes.data, facs_a.ctypes.data, coeffs.ctypes.data)
+    ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_host_expr_create(ptrs, C.c_size_t(tabs[0].shape[0]), C.byref(d), C.byref(h)), "jolt_stage_host_expr_create")
+    return StageOp(None, h)
+
+
+def prove_batch_ops(ops, input_claims, coefficients, offsets, max_num_vars, max_degree, label=0, challenge_mode=0):
+    """jolt_host_prove_batch_ops without a context (host-only operators)"""
+    return _prove_batch_ops(None, ops, input_claims, coefficients, offsets, max_num_vars, max_degree, label, challenge_mode)
+
+
 def _prove_batch_ops(self, ops, input_claims, coefficients, offsets, max_num_vars, max_degree, label=0, challenge_mode=0):
     """prove_batch (prover.rs:193-362) over stage operators (jolt_host_prove_batch_ops): the same outputs as Context.prove_batch"""
     n = len(ops)
@@ -1938,7 +1960,7 @@ def _prove_batch_ops(self, ops, input_claims, coefficients, offsets, max_num_var
     offs = (C.c_size_t * n)(*offsets)
     polys, chal = fr_array(max(max_num_vars * (max_degree + 1), 1)), fr_array(max(max_num_vars, 1))
     mclaims, final = fr_array(n), fr_array(1)
-    _ck(lib().jolt_host_prove_batch_ops(self.h, hs, C.c_size_t(n), _p(ic), _p(co), offs, C.c_size_t(max_num_vars), C.c_size_t(max_degree), C.c_uint64(label),
+    _ck(lib().jolt_host_prove_batch_ops(self.h if self is not None else None, hs, C.c_size_t(n), _p(ic), _p(co), offs, C.c_size_t(max_num_vars), C.c_size_t(max_degree), C.c_uint64(label),
                                         C.c_int32(challenge_mode), _p(polys), _p(chal), _p(mclaims), _p(final)), "jolt_host_prove_batch_ops", self)
     return dict(polys=polys[: max_num_vars * (max_degree + 1)].reshape(max_num_vars, max_degree + 1, 4), challenges=chal[:max_num_vars], member_claims=mclaims, final_claim=final[0])
 

@@ -424,6 +424,7 @@ extern "C" {
     pub fn jolt_stage_bytecode_read_raf_cycle_create(ctx: *mut jolt_ctx, address: *mut jolt_stage_op, pc_chunks: *const jolt_onehot, chunk_bits: u32, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_ram_raf_evaluation_create(ctx: *mut jolt_ctx, ram_index: *const jolt_key_index, tau_low: *const jolt_fr_t, n_vars: usize, lowest_address: u64, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_ram_output_check_create(ctx: *mut jolt_ctx, ram_index: *const jolt_key_index, post_values: *const jolt_ints, val_init: *const u64, val_io: *const u64, io_lo: u64, io_len: u64, r_address: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_host_expr_create(tables: *const *const jolt_fr_t, len: usize, desc: *const jolt_member_desc, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_host_prove_batch_ops(ctx: *mut jolt_ctx, ops: *const *mut jolt_stage_op, n_ops: usize, input_claims: *const jolt_fr_t, coefficients: *const jolt_fr_t, offsets: *const usize, max_num_vars: usize, max_degree: usize, transcript_label: u64, challenge_mode: i32, out_polys: *mut jolt_fr_t, out_challenges: *mut jolt_fr_t, out_member_claims: *mut jolt_fr_t, out_final_claim: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_stage_op_prove_alone(op: *mut jolt_stage_op, transcript: *mut jolt_host_transcript, claim: *mut jolt_fr_t, coeffs_out: *mut jolt_fr_t, stride: usize, n_coeffs_out: *mut u32, challenges_out: *mut jolt_fr_t) -> i32;
 }
