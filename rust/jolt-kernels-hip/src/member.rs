@@ -9,7 +9,7 @@ use std::sync::Arc;
 use jolt_claims::protocols::jolt::{JoltChallengeId, JoltDerivedId, JoltOpeningId};
 use jolt_claims::{InputClaims, OutputClaims, Source, SumcheckChallenges, SymbolicSumcheck};
 use jolt_field::Fr;
-use jolt_kernels::{KernelError, MaybeAllocative, PrepareKernel, ProofSession, ProverInputs, SumcheckKernel, SumcheckKernelError};
+use jolt_kernels::{KernelError, PrepareKernel, ProofSession, ProverInputs, SumcheckKernel, SumcheckKernelError};
 use jolt_poly::{BindingOrder, GruenSplitEqPolynomial, UnivariatePoly};
 use jolt_sumcheck::{ProveRounds, SumcheckError};
 use jolt_verifier::stages::relations::{ConcreteSumcheck, ConcreteSumcheckChallenges, SumcheckInputClaims, SumcheckOutputClaims};
@@ -250,7 +250,14 @@ pub struct HipSumcheckProver<R> {
     n_tables: usize,
 }
 
-impl<R> MaybeAllocative for HipSumcheckProver<R> {}
+#[cfg(feature = "allocative")]
+impl<R> allocative::Allocative for HipSumcheckProver<R> {
+    fn visit<'a, 'b: 'a>(&self, visitor: &'a mut allocative::Visitor<'b>) {
+        let mut visitor = visitor.enter_self_sized::<Self>();
+        visitor.visit_simple(allocative::Key::new("heap"), 0usize); // the tables live in HBM
+        visitor.exit();
+    }
+}
 
 impl<R> ProveRounds<Fr> for HipSumcheckProver<R>
 where

@@ -20,7 +20,7 @@ use jolt_claims::protocols::jolt::{JoltCommittedPolynomial, TracePolynomialOrder
 use jolt_field::{Fr, Ring};
 use jolt_kernels::commitment::CommitmentGrid;
 use jolt_kernels::opening::JointOpeningPolynomials;
-use jolt_kernels::{KernelError, MaybeAllocative, ProofSession};
+use jolt_kernels::{KernelError, ProofSession};
 use jolt_poly::MultilinearPoly;
 use jolt_witness::JoltWitnessPlane;
 
@@ -276,7 +276,7 @@ impl MultilinearPoly<Fr> for HipGridColumn {
 /// What the commit slot parks for stage 8: the resident column behind every committed polynomial it served.
 #[derive(Default)]
 pub struct ResidentCommitted(pub BTreeMap<JoltCommittedPolynomial, HipOpeningHint>);
-impl MaybeAllocative for ResidentCommitted {}
+crate::status::zero_host_heap!(ResidentCommitted);
 
 /// `backend.joint_opening`: the committed polynomials in final-opening batch order, embedded over the grid -- from the columns the commit slot left resident
 /// ([`ResidentCommitted`]); anything else (advice, precommitted program tables, address-major order) goes to the fallback slot, as `HipCommitWitness` does.

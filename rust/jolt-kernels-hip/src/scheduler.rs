@@ -10,7 +10,7 @@ use std::rc::Rc;
 use std::sync::{Arc, Mutex};
 
 use jolt_field::Fr;
-use jolt_kernels::{BuildRoundScheduler, MaybeAllocative, ProofSession};
+use jolt_kernels::{BuildRoundScheduler, ProofSession};
 use jolt_sumcheck::{MemberFinish, MemberRound, RoundScheduler, SumcheckError};
 
 use crate::context::HipContext;
@@ -31,7 +31,7 @@ unsafe impl Send for Entry {}
 pub struct HipBatchCarry {
     entries: Arc<Mutex<Vec<Entry>>>,
 }
-impl MaybeAllocative for HipBatchCarry {}
+crate::status::zero_host_heap!(HipBatchCarry);
 
 pub(crate) fn register_member(session: &mut ProofSession, member: &HipMember) {
     let n_evals = match member.shape {

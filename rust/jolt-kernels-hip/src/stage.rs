@@ -27,7 +27,7 @@ use jolt_claims::protocols::jolt::relations::registers::read_write_checking::Reg
 use jolt_claims::protocols::jolt::{JoltChallengeId, JoltOpeningId, JoltPolynomialId, JoltRelationId, JoltVirtualPolynomial};
 use jolt_claims::{InputClaims, OutputClaims, SumcheckChallenges};
 use jolt_field::Fr;
-use jolt_kernels::{KernelError, MaybeAllocative, PrepareKernel, ProofSession, ProverInputs, SumcheckKernel, SumcheckKernelError};
+use jolt_kernels::{KernelError, PrepareKernel, ProofSession, ProverInputs, SumcheckKernel, SumcheckKernelError};
 use jolt_poly::UnivariatePoly;
 use jolt_sumcheck::{ProveRounds, SumcheckError};
 use jolt_verifier::stages::relations::{ConcreteSumcheck, ConcreteSumcheckChallenges, SumcheckInputClaims, SumcheckOutputClaims};
@@ -146,12 +146,18 @@ where
     _keep: Vec<Arc<dyn core::any::Any + Send + Sync>>,
 }
 
-impl<R: ConcreteSumcheck<Fr>> MaybeAllocative for HipStageKernel<R>
+#[cfg(feature = "allocative")]
+impl<R: ConcreteSumcheck<Fr>> allocative::Allocative for HipStageKernel<R>
 where
     SumcheckInputClaims<Fr, R>: InputClaims<Fr>,
     SumcheckOutputClaims<Fr, R>: OutputClaims<Fr>,
     ConcreteSumcheckChallenges<Fr, R>: SumcheckChallenges<Fr, JoltChallengeId>,
 {
+    fn visit<'a, 'b: 'a>(&self, visitor: &'a mut allocative::Visitor<'b>) {
+        let mut visitor = visitor.enter_self_sized::<Self>();
+        visitor.visit_simple(allocative::Key::new("heap"), 0usize); // the operator's state lives in HBM and inside libjolt_hip.so
+        visitor.exit();
+    }
 }
 
 impl<R: ConcreteSumcheck<Fr>> ProveRounds<Fr> for HipStageKernel<R>
@@ -306,7 +312,7 @@ pub struct ResidentTrace {
     pc: Option<Arc<ResidentPc>>,
     ra_columns: Option<Arc<HipHotIndices>>,
 }
-impl MaybeAllocative for ResidentTrace {}
+crate::status::zero_host_heap!(ResidentTrace);
 
 const NO_ACCESS: u64 = u64::MAX;
 
@@ -873,7 +879,7 @@ impl PrepareKernel<Fr, InstructionReadRaf<Fr>> for HipInstructionReadRaf {
 /// What the bytecode address phase parks for the cycle phase (`SumcheckKernel::park_residue`): the finished operator, whose eq tables and bound values the cycle
 /// operator is prepared from (`jolt_stage_bytecode_read_raf_cycle_create`).
 pub struct HipBytecodeAddressResidue(pub HipStageOp);
-impl MaybeAllocative for HipBytecodeAddressResidue {}
+crate::status::zero_host_heap!(HipBytecodeAddressResidue);
 
 slot!(
     /// `backend.bytecode_read_raf_address` (replaces `optimized/bytecode_read_raf.rs:241-330`).  `stage_values`: the K-sized per-stage value tables of the program

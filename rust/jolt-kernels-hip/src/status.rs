@@ -83,3 +83,20 @@ pub(crate) fn fr_to_u64(v: &Fr) -> Option<u64> {
 pub(crate) fn fr_to_i128(v: &Fr) -> Option<i128> {
     v.to_u128_checked().and_then(|u| i128::try_from(u).ok()).or_else(|| (-*v).to_u128_checked().and_then(|u| i128::try_from(u).ok()).map(|m| -m))
 }
+
+/// `MaybeAllocative` for this crate's session entries and kernels.  Without the `allocative` feature the reference blanket-implements it for every type
+/// (`impl<T: ?Sized> MaybeAllocative for T`, `crates/jolt-kernels/src/backend.rs:195-198`): a manual impl would CONFLICT (E0119), so nothing is written.  With the feature it
+/// is `allocative::Allocative`: the state lives in HBM, the host heap behind it is a few handles -- reported as zero bytes (`optimized::impl_allocative!`'s shape).
+macro_rules! zero_host_heap {
+    ($type:ty) => {
+        #[cfg(feature = "allocative")]
+        impl allocative::Allocative for $type {
+            fn visit<'a, 'b: 'a>(&self, visitor: &'a mut allocative::Visitor<'b>) {
+                let mut visitor = visitor.enter_self_sized::<Self>();
+                visitor.visit_simple(allocative::Key::new("heap"), 0usize);
+                visitor.exit();
+            }
+        }
+    };
+}
+pub(crate) use zero_host_heap;
