@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--ram-addresses", choices=["uniform", "hotset"], default="uniform",
                     help="address stream of the synthetic RAM / register accesses of the stage operators: uniform over the K words, or hotset (90 %% of the accesses on ~2^10 "
                          "words / 8 registers: BASELINE configs[4]'s btreemap shape, specs/byte-addressable-memory.md:119,127-130)")
+    ap.add_argument("--transcript", choices=["blake2b", "keccak", "test"], default="blake2b",
+                    help="the Fiat-Shamir transcript every sumcheck / opening of the step draws its challenges from: blake2b = the reference's LegacyBlake2bTranscript "
+                         "(what its benchmark profile proves with, crates/jolt-prover/src/profile.rs:69), keccak = its KeccakTranscript, test = the deterministic stand-in of rounds 1-5")
     ap.add_argument("--no-split", action="store_true", help="skip the extra (untimed) steps that attribute the step time to its legs")
     ap.add_argument("--roofline-only", action="store_true", help="only run the bind-kernel roofline loop (rocprof target)")
     ap.add_argument("--roofline-scale", type=int, default=24, help="log2 of the table length for the bind roofline (512 MiB at 24: beyond L2+MALL)")
@@ -321,6 +324,7 @@ def baseline_config(world, scale, with_pcs):
 
 def main():
     args = parse()
+    TR = {"blake2b": 1 << 62, "keccak": 2 << 62, "test": 0}[args.transcript]  # the engine lives in the two top bits of every transcript label (include/jolt_hip.h)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -425,14 +429,14 @@ def main():
     def timed(steps, warmup, base):
         """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over the ranks."""
         for i in range(warmup):
-            step(label=base + 1000 + i)
+            step(label=TR | (base + 1000 + i))
         barrier()
         if sharded:
             for k in _D.TIMINGS:
                 _D.TIMINGS[k] = 0.0
         t0 = time.perf_counter()
         for i in range(steps):
-            step(label=base + 2000 + i)
+            step(label=TR | (base + 2000 + i))
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -467,23 +471,23 @@ def main():
         wl.witness_upload, wl.witness_pinned, wl.witness_overlapped = True, True, True
         args.witness = "upload-overlapped"
         for i in range(3):
-            step(label=90000 + i)
+            step(label=TR | (90000 + i))
     if not sharded and not args.no_split:
         ext_legs = []
         if wl.ext is not None:
             e, dd = wl.ext, wl.ext.d
             ext_legs = [("spartan_outer", lambda: e.spartan(e.outer_ints, dd["outer_iwa"], dd["outer_iwb"], dd["outer_wa"], dd["outer_wb"], dd["outer_tau"], dd["outer_kernel"],
-                                                           e.claims["outer"], 2, 3100)),
+                                                           e.claims["outer"], 2, TR | 3100)),
                         ("spartan_product", lambda: e.spartan(e.product_ints, e.product_ia, e.product_ib, e.product_fa, e.product_fb, dd["product_tau"], dd["product_kernel"],
-                                                             e.claims["product"], 1, 3200)),
-                        ("ram_read_write", lambda: e.ram_read_write(3300)), ("registers_read_write", lambda: e.registers_read_write(3350)),
-                        ("instruction_read_raf", lambda: e.instruction_read_raf(3400)), ("booleanity_address", lambda: e.booleanity_address(3450)),
-                        ("hamming_weight", lambda: e.hamming_weight(3470)), ("address_domain", lambda: e.address_domain(3500))]
+                                                             e.claims["product"], 1, TR | 3200)),
+                        ("ram_read_write", lambda: e.ram_read_write(TR | 3300)), ("registers_read_write", lambda: e.registers_read_write(TR | 3350)),
+                        ("instruction_read_raf", lambda: e.instruction_read_raf(TR | 3400)), ("booleanity_address", lambda: e.booleanity_address(TR | 3450)),
+                        ("hamming_weight", lambda: e.hamming_weight(TR | 3470)), ("address_domain", lambda: e.address_domain(TR | 3500))]
         # "opening_hint_background": what is left of the class sums the commit leg began on the background stream once the commit itself has landed -- in the step
         # they run UNDER the stage operators and the sumcheck legs (and slow those down a little: the legs of this split, timed one by one, add up to more than the step)
         hint_leg = [("opening_hint_background", lambda: wl.hint.wait() if getattr(wl, "hint", None) is not None else None)] if pcs else []
         legs = ([("witness_upload", wl.upload_witness)] if args.witness != "resident" else []) + [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + hint_leg + ext_legs + \
-               [("prove", lambda: wl.prove(label=3000))] + ([("open", lambda: wl.open(label=3000))] if pcs else [])
+               [("prove", lambda: wl.prove(label=TR | 3000))] + ([("open", lambda: wl.open(label=TR | 3000))] if pcs else [])
         acc = {k: 0.0 for k, _ in legs}
         reps = 2
         for _ in range(reps):
@@ -566,7 +570,11 @@ def main():
         "dtype": "u256 (BN254 Fr / Fq, 8x u32 Montgomery limbs; integer, bit-exact)",
         "data": "synthetic",
         "config": {"workload": what, "trace_length_per_gpu": 1 << args.scale, "trace_length_total": total_cycles, "baseline_config": baseline_config(world, args.scale, bool(pcs)),
-                   "parallelism": f"hypercube sharded over {world} GPU(s)", "ram_addresses": args.ram_addresses},
+                   "parallelism": f"hypercube sharded over {world} GPU(s)", "ram_addresses": args.ram_addresses,
+                   "transcript": {"blake2b": "jolt_transcript::LegacyBlake2bTranscript (DigestTranscript<Blake2b-256>: the transcript of the reference's benchmark profile, crates/jolt-prover/src/profile.rs:69), "
+                                             "round polynomials / commitments / evaluations absorbed in the reference's encodings",
+                                  "keccak": "jolt_transcript::KeccakTranscript (spongefish Keccak duplex sponge; pinned by the reference's known-answer vector)",
+                                  "test": "the deterministic test transcript of rounds 1-5"}[args.transcript]},
     }
     if split is not None:
         out["config"]["ms_per_step_split"] = split

@@ -377,14 +377,35 @@ int32_t jolt_host_hamming_weights(const jolt_fr_t *gamma, const jolt_fr_t *r_add
 int32_t jolt_host_pair_tables_round(const jolt_fr_t *g, const jolt_fr_t *w, size_t n_polys, size_t stride, size_t len, jolt_fr_t *evals_out /* 3 */);
 int32_t jolt_host_pair_tables_bind(jolt_fr_t *g, jolt_fr_t *w, size_t n_polys, size_t stride, size_t len, const jolt_fr_t *challenge);
 /* The Fiat-Shamir surface of members the caller drives round by round outside prove_batch (RamReadWriteKernel's rounds, the read-RAF
- * phases): Transcript::{append, challenge, challenge_scalar} (crates/jolt-transcript/src/legacy.rs:55-100) over the deterministic TEST
- * transcript of jolt_host_prove_batch.  A Rust caller keeps its own Blake2b / Keccak transcript and never calls these. */
+ * phases): Transcript::{new, append_bytes, append, challenge, challenge_scalar, state} (crates/jolt-transcript/src/legacy.rs:32-100) and the
+ * reference's encodings of what the path absorbs -- a field element as 32 BIG-endian bytes (legacy.rs:116-123), Label / LabelWithCount / U64Word
+ * (legacy.rs:146-209), a compressed labelled round polynomial (crates/jolt-sumcheck/src/round_proof.rs:129-143: LabelWithCount(label, n - 1), the
+ * constant, the coefficients of degree >= 2).  Three engines; every `transcript_label` argument of this header selects one with its two top bits:
+ *   JOLT_TRANSCRIPT_TEST (0)            the deterministic test transcript of rounds 1-5;
+ *   JOLT_TRANSCRIPT_BLAKE2B_LEGACY (1)  jolt_transcript::LegacyBlake2bTranscript = DigestTranscript<Blake2b<U32>> (crates/jolt-transcript/src/digest.rs:84-189),
+ *                                       the transcript of the reference's benchmark profile (crates/jolt-prover/src/profile.rs:69,726);
+ *   JOLT_TRANSCRIPT_KECCAK_SPONGE (2)   jolt_transcript::KeccakTranscript = SpongeTranscript<spongefish Keccak> (legacy.rs:211-305), pinned by the reference's
+ *                                       known-answer vector (crates/jolt-transcript/tests/keccak_tests.rs:13-29).
+ *   JOLT_TRANSCRIPT_BLAKE2B_SPONGE (3)  jolt_transcript::Blake2bTranscript = SpongeTranscript<spongefish Blake2b512> (lib.rs:63-66); the reference's vector
+ *                                       (tests/blake2b_tests.rs:13-37) pins it through the first challenge only -- unpinned beyond, used by no parity claim.
+ * For engines 1 - 3 an integer label L names the session "jolt-amd/<L mod 2^62>" (ASCII); _create_labelled takes the reference's byte labels (b"Jolt").
+ * A Rust caller keeps its own transcript object and never calls these (jolt_round_transcript_fn / jolt_open_transcript_fn are its hooks). */
+enum { JOLT_TRANSCRIPT_TEST = 0, JOLT_TRANSCRIPT_BLAKE2B_LEGACY = 1, JOLT_TRANSCRIPT_KECCAK_SPONGE = 2, JOLT_TRANSCRIPT_BLAKE2B_SPONGE = 3 };
+#define JOLT_TRANSCRIPT_LABEL(kind, label) (((uint64_t)(kind) << 62) | ((uint64_t)(label) & (((uint64_t)1 << 62) - 1)))
 typedef struct jolt_host_transcript jolt_host_transcript;
 int32_t jolt_host_transcript_create(uint64_t label, jolt_host_transcript **out);
-int32_t jolt_host_transcript_append_fr(jolt_host_transcript *t, const jolt_fr_t *values, size_t count); /* canonical 32-byte LE each */
+int32_t jolt_host_transcript_create_labelled(int32_t kind, const uint8_t *label, size_t label_len, jolt_host_transcript **out); /* label_len <= 32 (MAX_LABEL_LEN) */
+int32_t jolt_host_transcript_append_fr(jolt_host_transcript *t, const jolt_fr_t *values, size_t count); /* 32 big-endian bytes each, one append per value */
 int32_t jolt_host_transcript_append_bytes(jolt_host_transcript *t, const uint8_t *bytes, size_t count); /* e.g. a compressed G1 point (32 bytes) */
+int32_t jolt_host_transcript_append_label(jolt_host_transcript *t, const char *label, int32_t with_count, uint64_t count); /* Label (<= 32 bytes) / LabelWithCount (<= 24) */
+int32_t jolt_host_transcript_append_u64_word(jolt_host_transcript *t, uint64_t value);
+int32_t jolt_host_transcript_append_round_poly(jolt_host_transcript *t, const char *label, const jolt_fr_t *coefficients, size_t count); /* all `count` coefficients in; the linear one is skipped */
 int32_t jolt_host_transcript_challenge(jolt_host_transcript *t, int32_t full_width, jolt_fr_t *out);    /* 0: 125-bit challenge shape */
+int32_t jolt_host_transcript_state(const jolt_host_transcript *t, uint8_t *out32);
 int32_t jolt_host_transcript_destroy(jolt_host_transcript *t);
+/* the two hash primitives behind engines 1 and 2, for known-answer tests: BLAKE2b (RFC 7693, unkeyed, 1..64 digest bytes), Keccak-f[1600] on a 200-byte state */
+int32_t jolt_host_blake2b(const uint8_t *in, size_t n, size_t outlen, uint8_t *out);
+int32_t jolt_host_keccak_f1600(uint8_t *state200);
 /* G1 helpers on the host: group law, equality as points, compressed serialisation
  * (crates/jolt-crypto/src/ec/bn254/mod.rs:139-171) */
 int32_t jolt_host_g1_add(const jolt_g1_t *p, const jolt_g1_t *q, jolt_g1_t *out);

@@ -17,7 +17,7 @@ struct jolt_batch {
     jolt_ctx* ctx = nullptr;
     size_t n = 0, max_num_vars = 0, max_degree = 0, round = 0;
     bool full_width = false;
-    MockTranscript transcript{0};
+    LabelledTranscript transcript{0};
     // caller-owned Fiat-Shamir (jolt_host_batch_set_transcript): absorbs the round's compressed polynomial, returns the challenge
     jolt_round_transcript_fn round_transcript = nullptr;
     void* round_transcript_user = nullptr;
@@ -47,7 +47,7 @@ extern "C" int32_t jolt_host_batch_begin(jolt_ctx* ctx, size_t n_members, const 
     b->max_num_vars = max_num_vars;
     b->max_degree = max_degree;
     b->full_width = challenge_mode != 0;
-    b->transcript = MockTranscript(transcript_label);
+    b->transcript = LabelledTranscript(transcript_label);
     b->running_claim = Fr::zero();
     for (size_t i = 0; i < n_members; ++i) {
         if (offsets[i] + rounds[i] > max_num_vars || degrees[i] < 1 || degrees[i] > max_degree) { delete b; return JOLT_ERR_INVALID_ARG; }
@@ -215,8 +215,7 @@ extern "C" int32_t jolt_host_batch_run(jolt_batch* b, jolt_member* const* member
             challenge = fr_from_abi(&ch);
             JOLT_REQUIRE(b->ctx, fr_is_canonical(challenge), "transcript callback returned a non-canonical challenge");
         } else {
-            b->transcript.append_fr(poly.coefficients[0]);
-            for (size_t k = 2; k < poly.coefficients.size(); ++k) b->transcript.append_fr(poly.coefficients[k]);
+            b->transcript.append_round_poly(kSumcheckRoundLabel, poly.coefficients.data(), poly.coefficients.size());
             challenge = b->full_width ? b->transcript.challenge_scalar() : b->transcript.challenge();
         }
         b->running_claim = poly.evaluate(challenge);

@@ -1,6 +1,10 @@
 // jolt_amd/csrc/host_mirror.hip -- implementation of host_mirror.hpp and of the jolt_host_* exports (sumcheck side).
 #include "host_mirror.hpp"
 
+#include <algorithm>
+#include <array>
+#include <string>
+
 #include "member.hpp"
 
 using namespace jolt;
@@ -130,11 +134,54 @@ int32_t gruen_poly_from_q(const Fr& current_scalar, const Fr& point_i, const Fr*
 }
 
 // ---- transcript ----------------------------------------------------------------------------------------------
-void Transcript::append_fr(const Fr& v) {
-    uint8_t b[32];
-    fr_to_bytes_le(v, b);
-    append_bytes(b, 32);
+Fr Transcript::challenge() {
+    uint8_t b[16];
+    draw16(b);
+    return fr_from_challenge_bytes(b, 16);
 }
+Fr Transcript::challenge_scalar() {
+    uint8_t b[16];
+    draw16(b);
+    return fr_from_scalar_challenge_bytes(b, 16);
+}
+void Transcript::append_fr(const Fr& v) {  // legacy.rs:116-123: to_bytes_le, reversed
+    uint8_t le[32], be[32];
+    fr_to_bytes_le(v, le);
+    std::reverse_copy(le, le + 32, be);
+    append_bytes(be, 32);
+}
+namespace {
+struct Word32 {
+    uint8_t b[32] = {};
+    void text(const char* label, size_t cap) { std::memcpy(b, label, std::min(std::strlen(label), cap)); }
+    void tail_u64(uint64_t v) {
+        for (int i = 0; i < 8; ++i) b[31 - i] = (uint8_t)(v >> (8 * i));
+    }
+};
+}  // namespace
+void Transcript::append_label(const char* label) {
+    Word32 w;
+    w.text(label, 32);
+    append_bytes(w.b, 32);
+}
+void Transcript::append_label_with_count(const char* label, uint64_t count) {
+    Word32 w;
+    w.text(label, 24);
+    w.tail_u64(count);
+    append_bytes(w.b, 32);
+}
+void Transcript::append_u64_word(uint64_t v) {
+    Word32 w;
+    w.tail_u64(v);
+    append_bytes(w.b, 32);
+}
+void Transcript::append_round_poly(const char* label, const Fr* coefficients, size_t n) {
+    if (n == 0) return;  // round_proof.rs:135-137
+    append_label_with_count(label, (uint64_t)(n - 1));
+    append_fr(coefficients[0]);
+    for (size_t k = 2; k < n; ++k) append_fr(coefficients[k]);
+}
+
 static inline uint64_t mix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -168,15 +215,296 @@ void MockTranscript::draw16(uint8_t out[16]) {
     absorb_word(lo ^ hi);
     for (int i = 0; i < 8; ++i) { out[i] = (uint8_t)(lo >> (8 * i)); out[8 + i] = (uint8_t)(hi >> (8 * i)); }
 }
-Fr MockTranscript::challenge() {
-    uint8_t b[16];
-    draw16(b);
-    return fr_from_challenge_bytes(b, 16);
+void MockTranscript::state(uint8_t out[32]) const { std::memcpy(out, s, 32); }
+
+// ---- BLAKE2b (RFC 7693): eight-word chain value, 128-byte blocks, twelve rounds of the G mixing over the message schedule ----
+namespace {
+class Blake2b {
+   public:
+    explicit Blake2b(size_t digest_bytes) : out_(digest_bytes) {
+        h_ = iv();
+        h_[0] ^= 0x01010000ull | (uint64_t)digest_bytes;
+    }
+    void update(const uint8_t* p, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            if (fill_ == block_.size()) flush(false);  // only once more input is known to follow
+            block_[fill_++] = p[i];
+        }
+    }
+    void finish(uint8_t* out) {
+        std::fill(block_.begin() + fill_, block_.end(), (uint8_t)0);
+        flush(true);
+        for (size_t i = 0; i < out_; ++i) out[i] = (uint8_t)(h_[i >> 3] >> (8 * (i & 7)));
+    }
+
+   private:
+    static std::array<uint64_t, 8> iv() {
+        return {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    }
+    void flush(bool last) {
+        counter_ += fill_;  // messages here are far below 2^64 bytes: the high counter word stays zero
+        std::array<uint64_t, 16> m{}, v{};
+        for (size_t w = 0; w < 16; ++w)
+            for (size_t k = 0; k < 8; ++k) m[w] |= (uint64_t)block_[8 * w + k] << (8 * k);
+        const std::array<uint64_t, 8> c = iv();
+        for (size_t i = 0; i < 8; ++i) { v[i] = h_[i]; v[8 + i] = c[i]; }
+        v[12] ^= counter_;
+        if (last) v[14] = ~v[14];
+        auto rr = [](uint64_t x, unsigned k) { return (x >> k) | (x << (64 - k)); };
+        auto g = [&](int a, int b, int cc, int d, uint64_t x, uint64_t y) {
+            v[a] += v[b] + x; v[d] = rr(v[d] ^ v[a], 32); v[cc] += v[d]; v[b] = rr(v[b] ^ v[cc], 24);
+            v[a] += v[b] + y; v[d] = rr(v[d] ^ v[a], 16); v[cc] += v[d]; v[b] = rr(v[b] ^ v[cc], 63);
+        };
+        static const uint8_t schedule[10][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+        for (int round = 0; round < 12; ++round) {
+            const uint8_t* sg = schedule[round % 10];
+            for (int col = 0; col < 4; ++col) g(col, 4 + col, 8 + col, 12 + col, m[sg[2 * col]], m[sg[2 * col + 1]]);
+            for (int diag = 0; diag < 4; ++diag)
+                g(diag, 4 + (diag + 1) % 4, 8 + (diag + 2) % 4, 12 + (diag + 3) % 4, m[sg[8 + 2 * diag]], m[sg[9 + 2 * diag]]);
+        }
+        for (size_t i = 0; i < 8; ++i) h_[i] ^= v[i] ^ v[8 + i];
+        fill_ = 0;
+    }
+    std::array<uint64_t, 8> h_{};
+    std::array<uint8_t, 128> block_{};
+    size_t fill_ = 0, out_;
+    uint64_t counter_ = 0;
+};
+}  // namespace
+void blake2b_digest(const uint8_t* in, size_t n, size_t outlen, uint8_t* out) {
+    Blake2b h(outlen);
+    h.update(in, n);
+    h.finish(out);
 }
-Fr MockTranscript::challenge_scalar() {
-    uint8_t b[16];
-    draw16(b);
-    return fr_from_scalar_challenge_bytes(b, 16);
+
+LegacyBlake2bTranscript::LegacyBlake2bTranscript(const uint8_t* label, size_t n) {  // digest.rs:153-174
+    uint8_t padded[32] = {};
+    std::memcpy(padded, label, std::min<size_t>(n, 32));
+    blake2b_digest(padded, 32, 32, chain);
+}
+void LegacyBlake2bTranscript::step(const uint8_t* payload, size_t n) {  // hasher() + update_state (digest.rs:100-104,129-131)
+    uint8_t round_word[32] = {};
+    for (int i = 0; i < 4; ++i) round_word[31 - i] = (uint8_t)(n_rounds >> (8 * i));
+    Blake2b h(32);
+    h.update(chain, 32);
+    h.update(round_word, 32);
+    h.update(payload, n);
+    h.finish(chain);
+    ++n_rounds;
+}
+void LegacyBlake2bTranscript::append_bytes(const uint8_t* b, size_t n) { step(b, n); }
+void LegacyBlake2bTranscript::draw16(uint8_t out[16]) {  // challenge_bytes of 16 <= 32 bytes: one digest, its first half (digest.rs:106-127)
+    step(nullptr, 0);
+    std::memcpy(out, chain, 16);
+}
+void LegacyBlake2bTranscript::state(uint8_t out[32]) const { std::memcpy(out, chain, 32); }
+
+// ---- Keccak-f[1600] (FIPS 202): theta, rho + pi along the 24-step lane walk, chi, iota ----
+void keccak_f1600(uint8_t bytes[200]) {
+    static const uint64_t iota[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+                                      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+                                      0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+                                      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+                                      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int walk_lane[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    static const int walk_rot[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    uint64_t a[25];
+    for (int i = 0; i < 25; ++i) {
+        a[i] = 0;
+        for (int k = 7; k >= 0; --k) a[i] = (a[i] << 8) | bytes[8 * i + k];
+    }
+    auto rl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    for (int round = 0; round < 24; ++round) {
+        uint64_t parity[5];
+        for (int x = 0; x < 5; ++x) parity[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; ++x) {
+            const uint64_t d = parity[(x + 4) % 5] ^ rl(parity[(x + 1) % 5], 1);
+            for (int y = 0; y < 25; y += 5) a[y + x] ^= d;
+        }
+        uint64_t carry = a[1];
+        for (int i = 0; i < 24; ++i) {
+            const uint64_t next = a[walk_lane[i]];
+            a[walk_lane[i]] = rl(carry, walk_rot[i]);
+            carry = next;
+        }
+        for (int y = 0; y < 25; y += 5) {
+            uint64_t row[5];
+            for (int x = 0; x < 5; ++x) row[x] = a[y + x];
+            for (int x = 0; x < 5; ++x) a[y + x] = row[x] ^ (~row[(x + 1) % 5] & row[(x + 2) % 5]);
+        }
+        a[0] ^= iota[round];
+    }
+    for (int i = 0; i < 25; ++i)
+        for (int k = 0; k < 8; ++k) bytes[8 * i + k] = (uint8_t)(a[i] >> (8 * k));
+}
+// the duplex (spongefish DuplexSponge, overwrite mode): input REPLACES rate bytes; a full rate is permuted before more input; the first squeeze after an absorb permutes
+void KeccakSpongeTranscript::absorb(const uint8_t* b, size_t n) {
+    squeeze_pos = 136;
+    size_t done = 0;
+    while (done < n) {
+        if (absorb_pos == 136) {
+            keccak_f1600(lanes);
+            absorb_pos = 0;
+            continue;
+        }
+        const size_t take = std::min<size_t>(n - done, 136 - absorb_pos);
+        std::memcpy(lanes + absorb_pos, b + done, take);
+        absorb_pos += (unsigned)take;
+        done += take;
+    }
+}
+void KeccakSpongeTranscript::squeeze(uint8_t* out, size_t n) {
+    size_t done = 0;
+    while (done < n) {
+        if (squeeze_pos == 136) {
+            squeeze_pos = 0;
+            absorb_pos = 0;
+            keccak_f1600(lanes);
+        }
+        const size_t take = std::min<size_t>(n - done, 136 - squeeze_pos);
+        std::memcpy(out + done, lanes + squeeze_pos, take);
+        squeeze_pos += (unsigned)take;
+        done += take;
+    }
+}
+KeccakSpongeTranscript::KeccakSpongeTranscript(const uint8_t* label, size_t n) {  // SpongeTranscript::new (legacy.rs:254-268)
+    std::memset(lanes, 0, sizeof lanes);
+    uint8_t protocol_id[64] = {};  // PROTOCOL_ID (setup.rs:38-54)
+    static const char id[] = "a16z/jolt-transcript/v1";
+    std::memcpy(protocol_id, id, sizeof id - 1);
+    absorb(protocol_id, 64);
+    std::vector<uint8_t> session(8 + n);  // BytesMsg(label): u64 LE length, then the bytes (codec.rs:36-43)
+    for (int i = 0; i < 8; ++i) session[i] = (uint8_t)((uint64_t)n >> (8 * i));
+    std::memcpy(session.data() + 8, label, n);
+    absorb(session.data(), session.size());
+    absorb(nullptr, 0);  // EmptyInstance (setup.rs:59-66)
+}
+void KeccakSpongeTranscript::append_bytes(const uint8_t* b, size_t n) {  // legacy.rs:270-288: marker, u64 LE length, body -- one absorb
+    std::vector<uint8_t> framed(9 + n);
+    framed[0] = 0x9B;
+    for (int i = 0; i < 8; ++i) framed[1 + i] = (uint8_t)((uint64_t)n >> (8 * i));
+    if (n) std::memcpy(framed.data() + 9, b, n);
+    absorb(framed.data(), framed.size());
+}
+void KeccakSpongeTranscript::draw16(uint8_t out[16]) { squeeze(out, 16); }
+void KeccakSpongeTranscript::state(uint8_t out[32]) const {  // peek_state (legacy.rs:243-248)
+    KeccakSpongeTranscript copy = *this;
+    copy.squeeze(out, 32);
+}
+
+// ---- spongefish DigestBridge<Blake2b512>: one running hash while absorbing (opened by a zero mask block and the chaining value), a ratchet H(H(.)) at the first squeeze,
+// ---- output blocks H(..01 mask || chaining value || block index) with the unused tail of a block kept for the next squeeze
+struct Blake2bSpongeTranscript::Bridge {
+    enum class Mode { Start, Absorb, Squeeze } mode = Mode::Start;
+    Blake2b running{64};
+    std::array<uint8_t, 64> chaining{}, block{};
+    size_t block_left = 0;
+    uint64_t blocks_out = 0;
+    static void mask(Blake2b& h, uint8_t tag) {
+        std::array<uint8_t, 128> m{};
+        m.back() = tag;
+        h.update(m.data(), m.size());
+    }
+    static void be64(Blake2b& h, uint64_t v) {
+        uint8_t b[8];
+        for (int i = 0; i < 8; ++i) b[7 - i] = (uint8_t)(v >> (8 * i));
+        h.update(b, 8);
+    }
+    void close_squeeze() {
+        if (mode != Mode::Squeeze) return;
+        Blake2b h(64);
+        mask(h, 0x02);
+        h.update(chaining.data(), 64);
+        be64(h, 64 * blocks_out - block_left);
+        h.finish(chaining.data());
+        running = Blake2b(64);
+        mode = Mode::Start;
+        block_left = 0;
+    }
+    void absorb(const uint8_t* p, size_t n) {
+        close_squeeze();
+        if (mode == Mode::Start) {
+            mode = Mode::Absorb;
+            mask(running, 0x00);
+            running.update(chaining.data(), 64);
+        }
+        running.update(p, n);
+    }
+    void squeeze(uint8_t* out, size_t n) {
+        if (mode == Mode::Absorb) {
+            std::array<uint8_t, 64> once;
+            running.finish(once.data());
+            blake2b_digest(once.data(), 64, 64, chaining.data());
+            running = Blake2b(64);
+            mode = Mode::Start;
+        }
+        if (mode == Mode::Start) {
+            mode = Mode::Squeeze;
+            blocks_out = 0;
+            block_left = 0;
+            mask(running, 0x01);
+            running.update(chaining.data(), 64);
+        }
+        for (size_t done = 0; done < n;) {
+            if (block_left == 0) {
+                Blake2b h = running;
+                be64(h, blocks_out++);
+                h.finish(block.data());
+                block_left = 64;
+            }
+            const size_t take = std::min(n - done, block_left);
+            std::memcpy(out + done, block.data() + (64 - block_left), take);
+            block_left -= take;
+            done += take;
+        }
+    }
+};
+Blake2bSpongeTranscript::Blake2bSpongeTranscript(const uint8_t* label, size_t n) : bridge(std::make_shared<Bridge>()) {
+    uint8_t protocol_id[64] = {};
+    static const char id[] = "a16z/jolt-transcript/v1";
+    std::memcpy(protocol_id, id, sizeof id - 1);
+    bridge->absorb(protocol_id, 64);
+    std::vector<uint8_t> session(8 + n);
+    for (int i = 0; i < 8; ++i) session[i] = (uint8_t)((uint64_t)n >> (8 * i));
+    std::memcpy(session.data() + 8, label, n);
+    bridge->absorb(session.data(), session.size());
+    bridge->absorb(nullptr, 0);
+}
+void Blake2bSpongeTranscript::append_bytes(const uint8_t* b, size_t n) {
+    std::vector<uint8_t> framed(9 + n);
+    framed[0] = 0x9B;
+    for (int i = 0; i < 8; ++i) framed[1 + i] = (uint8_t)((uint64_t)n >> (8 * i));
+    if (n) std::memcpy(framed.data() + 9, b, n);
+    bridge->absorb(framed.data(), framed.size());
+}
+void Blake2bSpongeTranscript::draw16(uint8_t out[16]) { bridge->squeeze(out, 16); }
+void Blake2bSpongeTranscript::state(uint8_t out[32]) const {
+    Bridge copy = *bridge;
+    copy.squeeze(out, 32);
+}
+
+LabelledTranscript::LabelledTranscript(int kind, const uint8_t* label, size_t n) {
+    if (n > 32) return;
+    if (kind == 1) inner.reset(new LegacyBlake2bTranscript(label, n));
+    else if (kind == 2) inner.reset(new KeccakSpongeTranscript(label, n));
+    else if (kind == 3) inner.reset(new Blake2bSpongeTranscript(label, n));
+}
+LabelledTranscript::LabelledTranscript(uint64_t label) {
+    const int kind = (int)(label >> 62);
+    if (kind == 0) {
+        inner.reset(new MockTranscript(label));
+        return;
+    }
+    const std::string text = "jolt-amd/" + std::to_string(label & ((1ull << 62) - 1));
+    if (kind == 1) inner.reset(new LegacyBlake2bTranscript(reinterpret_cast<const uint8_t*>(text.data()), text.size()));
+    else if (kind == 2) inner.reset(new KeccakSpongeTranscript(reinterpret_cast<const uint8_t*>(text.data()), text.size()));
+    else inner.reset(new Blake2bSpongeTranscript(reinterpret_cast<const uint8_t*>(text.data()), text.size()));
 }
 
 // ---- DeviceMember --------------------------------------------------------------------------------------------
@@ -374,8 +702,7 @@ int32_t prove_batch(const BatchPrelude& prelude, std::vector<ProveRounds*>& memb
         Fr round_sum = add(batched_poly.evaluate(Fr::zero()), batched_poly.evaluate(Fr::one()));
         if (round_sum != running_claim) return fail(JOLT_ERR_ROUND_CHECK, round);  // prover.rs:316-324
         // ClearSumcheckRecorder::absorb_round (recorder.rs:118-130): compressed poly (linear term omitted), then challenge
-        transcript.append_fr(batched_poly.coefficients[0]);
-        for (size_t k = 2; k < batched_poly.coefficients.size(); ++k) transcript.append_fr(batched_poly.coefficients[k]);
+        transcript.append_round_poly(kSumcheckRoundLabel, batched_poly.coefficients.data(), batched_poly.coefficients.size());
         Fr challenge = full_width_challenges ? transcript.challenge_scalar() : transcript.challenge();
         running_claim = batched_poly.evaluate(challenge);
         challenges.push_back(challenge);
@@ -675,13 +1002,55 @@ extern "C" int32_t jolt_host_pair_tables_bind(jolt_fr_t* g, jolt_fr_t* w, size_t
 // ---- the caller-side Fiat-Shamir of members that are driven round by round outside prove_batch (sparse read-write matrix, read-RAF
 // phases): the deterministic test transcript behind four entry points; a Rust caller uses its own Transcript instead.
 struct jolt_host_transcript {
-    MockTranscript t;
+    LabelledTranscript t;
     explicit jolt_host_transcript(uint64_t label) : t(label) {}
+    jolt_host_transcript(int kind, const uint8_t* label, size_t n) : t(kind, label, n) {}
 };
 extern "C" int32_t jolt_host_transcript_create(uint64_t label, jolt_host_transcript** out) {
     if (!out) return JOLT_ERR_INVALID_ARG;
     *out = new (std::nothrow) jolt_host_transcript(label);
     return *out ? JOLT_OK : JOLT_ERR_OOM;
+}
+extern "C" int32_t jolt_host_transcript_create_labelled(int32_t kind, const uint8_t* label, size_t label_len, jolt_host_transcript** out) {
+    if (!out || (!label && label_len) || label_len > 32 || kind < JOLT_TRANSCRIPT_BLAKE2B_LEGACY || kind > JOLT_TRANSCRIPT_BLAKE2B_SPONGE) return JOLT_ERR_INVALID_ARG;
+    *out = new (std::nothrow) jolt_host_transcript((int)kind, label, label_len);
+    return *out ? JOLT_OK : JOLT_ERR_OOM;
+}
+extern "C" int32_t jolt_host_transcript_append_label(jolt_host_transcript* t, const char* label, int32_t with_count, uint64_t count) {
+    if (!t || !label || std::strlen(label) > (with_count ? 24u : 32u)) return JOLT_ERR_INVALID_ARG;
+    if (with_count) t->t.append_label_with_count(label, count);
+    else t->t.append_label(label);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_transcript_append_u64_word(jolt_host_transcript* t, uint64_t value) {
+    if (!t) return JOLT_ERR_INVALID_ARG;
+    t->t.append_u64_word(value);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_transcript_append_round_poly(jolt_host_transcript* t, const char* label, const jolt_fr_t* coefficients, size_t count) {
+    if (!t || !label || std::strlen(label) > 24 || (!coefficients && count)) return JOLT_ERR_INVALID_ARG;
+    std::vector<Fr> c(count);
+    for (size_t i = 0; i < count; ++i) {
+        c[i] = fr_from_abi(&coefficients[i]);
+        if (!fr_is_canonical(c[i])) return JOLT_ERR_INVALID_ARG;
+    }
+    t->t.append_round_poly(label, c.data(), count);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_transcript_state(const jolt_host_transcript* t, uint8_t* out32) {
+    if (!t || !out32) return JOLT_ERR_INVALID_ARG;
+    t->t.state(out32);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_blake2b(const uint8_t* in, size_t n, size_t outlen, uint8_t* out) {
+    if ((!in && n) || !out || outlen < 1 || outlen > 64) return JOLT_ERR_INVALID_ARG;
+    blake2b_digest(in, n, outlen, out);
+    return JOLT_OK;
+}
+extern "C" int32_t jolt_host_keccak_f1600(uint8_t* state200) {
+    if (!state200) return JOLT_ERR_INVALID_ARG;
+    keccak_f1600(state200);
+    return JOLT_OK;
 }
 extern "C" int32_t jolt_host_transcript_append_fr(jolt_host_transcript* t, const jolt_fr_t* values, size_t count) {
     if (!t || (!values && count)) return JOLT_ERR_INVALID_ARG;
@@ -736,7 +1105,7 @@ extern "C" int32_t jolt_host_prove_batch(jolt_ctx* ctx, jolt_member* const* memb
         described.push_back(BatchMember{fr_from_abi(&input_claims[i]), fr_from_abi(&coefficients[i]), members[i]->rounds, offsets[i]});
     }
     BatchPrelude prelude = BatchPrelude::make(std::move(described), max_num_vars, max_degree);
-    MockTranscript tr(transcript_label);
+    LabelledTranscript tr(transcript_label);
     SequentialRounds seq;
     DeviceGroupedRounds grouped(ctx);
     RoundScheduler& sched = use_round_group ? static_cast<RoundScheduler&>(grouped) : static_cast<RoundScheduler&>(seq);

@@ -37,28 +37,90 @@ struct SumcheckError {
     size_t round = 0;
 };
 
-// Fiat-Shamir surface the path needs (append bytes / squeeze a challenge); the real Blake2b/Keccak transcript of
-// crates/jolt-transcript plugs in here.
+// Fiat-Shamir surface the path needs (crates/jolt-transcript/src/legacy.rs:32-100): absorb bytes, squeeze a challenge, and the reference's encodings of what the path
+// absorbs -- a field element as 32 BIG-endian bytes (legacy.rs:116-123), the 32-byte label words (legacy.rs:146-209), a compressed labelled round polynomial
+// (crates/jolt-sumcheck/src/round_proof.rs:129-143).
 struct Transcript {
     virtual ~Transcript() = default;
     virtual void append_bytes(const uint8_t* b, size_t n) = 0;
-    virtual Fr challenge() = 0;         // Transcript::challenge: 16 bytes -> from_challenge_bytes (125-bit shape)
-    virtual Fr challenge_scalar() = 0;  // Transcript::challenge_scalar: 16 bytes -> from_scalar_challenge_bytes
-    void append_fr(const Fr& v);        // canonical 32-byte LE (mod.rs:116-123)
+    virtual void draw16(uint8_t out[16]) = 0;  // the 16 squeezed bytes behind either challenge shape
+    virtual void state(uint8_t out[32]) const = 0;  // Transcript::state
+    Fr challenge();         // Transcript::challenge: 16 bytes -> from_challenge_bytes (125-bit shape)
+    Fr challenge_scalar();  // Transcript::challenge_scalar: 16 bytes -> from_scalar_challenge_bytes
+    void append_fr(const Fr& v);
+    void append_label(const char* label);                             // Label
+    void append_label_with_count(const char* label, uint64_t count);  // LabelWithCount
+    void append_u64_word(uint64_t v);                                 // U64Word
+    void append_round_poly(const char* label, const Fr* coefficients, size_t n);  // CompressedLabeledRoundPoly::append_to_transcript
 };
+constexpr const char* kSumcheckRoundLabel = "sumcheck_poly";  // crates/jolt-sumcheck/src/lib.rs:105
+constexpr const char* kUniskipRoundLabel = "uniskip_poly";    // :107
 
 // Deterministic test transcript; re-implemented from the SPEC comment in oracle/mock_transcript.h.
 struct MockTranscript final : Transcript {
     uint64_t s[4];
     explicit MockTranscript(uint64_t label);
     void append_bytes(const uint8_t* b, size_t n) override;
-    Fr challenge() override;
-    Fr challenge_scalar() override;
+    void draw16(uint8_t out[16]) override;
+    void state(uint8_t out[32]) const override;
 
    private:
     void absorb_word(uint64_t w);
-    void draw16(uint8_t out[16]);
 };
+
+// jolt_transcript::LegacyBlake2bTranscript = DigestTranscript<Blake2b<U32>> (crates/jolt-transcript/src/digest.rs:84-189, lib.rs:70-75): the transcript of the
+// reference's benchmark profile (crates/jolt-prover/src/profile.rs:69).  Chained digests: state' = H(state || 28 zero bytes || n_rounds u32 BE || payload).
+struct LegacyBlake2bTranscript final : Transcript {
+    uint8_t chain[32];
+    uint32_t n_rounds = 0;
+    LegacyBlake2bTranscript(const uint8_t* label, size_t n);  // n <= 32 (MAX_LABEL_LEN, legacy.rs:17)
+    void append_bytes(const uint8_t* b, size_t n) override;
+    void draw16(uint8_t out[16]) override;
+    void state(uint8_t out[32]) const override;
+
+   private:
+    void step(const uint8_t* payload, size_t n);
+};
+
+// jolt_transcript::KeccakTranscript = SpongeTranscript<spongefish::instantiations::Keccak> (legacy.rs:211-305): spongefish's duplex sponge over Keccak-f[1600]
+// (overwrite mode, rate 136, zero initial state; spongefish rev d2d190b1 is a Cargo dependency, restated from its published construction) behind the facade's framing.
+struct KeccakSpongeTranscript final : Transcript {
+    uint8_t lanes[200];
+    unsigned absorb_pos = 0, squeeze_pos = 136;
+    KeccakSpongeTranscript(const uint8_t* label, size_t n);
+    void append_bytes(const uint8_t* b, size_t n) override;
+    void draw16(uint8_t out[16]) override;
+    void state(uint8_t out[32]) const override;
+
+   private:
+    void absorb(const uint8_t* b, size_t n);
+    void squeeze(uint8_t* out, size_t n);
+};
+
+// jolt_transcript::Blake2bTranscript = SpongeTranscript<spongefish::instantiations::Blake2b512> (lib.rs:63-66): the facade's framing over spongefish's hash-to-duplex
+// bridge.  The reference's known-answer vector (tests/blake2b_tests.rs:13-37) pins it through the FIRST challenge; how a squeeze is closed before the next absorb is
+// restated from the crate's published source without a vector -- unpinned there, used by no parity claim and not by the bench.
+struct Blake2bSpongeTranscript final : Transcript {
+    struct Bridge;
+    std::shared_ptr<Bridge> bridge;  // shared_ptr only for the incomplete type; copied deeply by state()
+    Blake2bSpongeTranscript(const uint8_t* label, size_t n);
+    void append_bytes(const uint8_t* b, size_t n) override;
+    void draw16(uint8_t out[16]) override;
+    void state(uint8_t out[32]) const override;
+};
+
+// What a 64-bit transcript label of the C ABI selects: the two top bits name the engine (0 the test transcript, 1 LegacyBlake2b, 2 Keccak sponge, 3 Blake2b512 sponge; for 1 - 3 the session
+// label is the ASCII string "jolt-amd/<label mod 2^62>"), or an engine with a byte label as the reference writes it (`Transcript::new(b"Jolt")`).
+struct LabelledTranscript final : Transcript {
+    std::unique_ptr<Transcript> inner;
+    explicit LabelledTranscript(uint64_t label);
+    LabelledTranscript(int kind, const uint8_t* label, size_t n);  // inner stays null for an unknown kind / a label over 32 bytes
+    void append_bytes(const uint8_t* b, size_t n) override { inner->append_bytes(b, n); }
+    void draw16(uint8_t out[16]) override { inner->draw16(out); }
+    void state(uint8_t out[32]) const override { inner->state(out); }
+};
+void blake2b_digest(const uint8_t* in, size_t n, size_t outlen, uint8_t* out);  // RFC 7693, unkeyed
+void keccak_f1600(uint8_t lanes[200]);                                             // FIPS 202
 
 // prover.rs:52-72
 struct ProveRounds {

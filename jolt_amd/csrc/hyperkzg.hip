@@ -451,7 +451,7 @@ static int32_t sharded_msm_many(jolt_ctx* ctx, const jolt_srs* srs, const std::v
 // commitments -> d_0 (kzg.rs:118-124).
 namespace {
 struct OpenTranscript {
-    MockTranscript mock;
+    LabelledTranscript mock;
     jolt_open_transcript_fn fn;
     void* user;
     int32_t after_points(int32_t phase, const G1Jac* pts, size_t n, Fr* out) {
@@ -503,7 +503,7 @@ static int32_t hyperkzg_open_impl(jolt_ctx* ctx, const jolt_srs* srs, const jolt
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !gather)) return JOLT_ERR_INVALID_ARG;
     if (ell == 0) return JOLT_ERR_EMPTY_POINT;
     if (ell > 40) return JOLT_ERR_UNSUPPORTED;
-    OpenTranscript tr{MockTranscript(transcript_label), transcript_fn, transcript_user};
+    OpenTranscript tr{LabelledTranscript(transcript_label), transcript_fn, transcript_user};
     std::vector<jolt_table*> polys(ell, nullptr);
     auto cleanup = [&](jolt_table* extra1 = nullptr, jolt_table* extra2 = nullptr) {
         for (jolt_table* t : polys) if (t) jolt_table_free(ctx, t);
@@ -763,7 +763,7 @@ extern "C" int32_t jolt_host_hyperkzg_open_subtree(jolt_ctx* ctx, const jolt_srs
     const size_t lam = ell - gamma;
     if (evals->len != ((size_t)1 << lam)) return JOLT_ERR_SIZE_MISMATCH;
     if (srs->n < evals->len) return JOLT_ERR_SRS_TOO_SMALL;
-    MockTranscript tr(transcript_label);
+    LabelledTranscript tr(transcript_label);
     std::vector<Fr> x(ell);
     for (size_t i = 0; i < ell; ++i) {
         x[i] = fr_from_abi(&point[i]);

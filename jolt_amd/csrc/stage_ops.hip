@@ -1222,7 +1222,7 @@ extern "C" int32_t jolt_host_prove_batch_ops(jolt_ctx* ctx, jolt_stage_op* const
         described.push_back(BatchMember{fr_from_abi(&input_claims[i]), fr_from_abi(&coefficients[i]), ops[i]->rounds, offsets[i]});
     }
     BatchPrelude prelude = BatchPrelude::make(std::move(described), max_num_vars, max_degree);
-    MockTranscript tr(transcript_label);
+    LabelledTranscript tr(transcript_label);
     SequentialRounds seq;
     ProvedBatch proved;
     SumcheckError err;

@@ -564,20 +564,44 @@ class HostHammingWeight:
         return self.g[:, 0].copy()
 
 
-class HostTranscript:
-    """The deterministic test transcript of jolt_host_prove_batch for members driven round by round from here (jolt_host_transcript_*)."""
+TRANSCRIPT_TEST, TRANSCRIPT_BLAKE2B, TRANSCRIPT_KECCAK, TRANSCRIPT_BLAKE2B_SPONGE = 0, 1 << 62, 2 << 62, 3 << 62  # OR into any `label` / `transcript_label`: the engine behind it (include/jolt_hip.h)
 
-    def __init__(self, label):
+
+class HostTranscript:
+    """jolt_host_transcript_*: the library's transcripts for members driven round by round from here.  `label`: an integer whose two top bits select the engine
+    (TRANSCRIPT_TEST: the deterministic test transcript; TRANSCRIPT_BLAKE2B: the reference's LegacyBlake2bTranscript, the one its benchmark profile proves with;
+    TRANSCRIPT_KECCAK: its KeccakTranscript), or a byte label with `kind` 1 / 2 -- the reference's `Transcript::new(b"...")`."""
+
+    def __init__(self, label, kind=None):
         self.h = C.c_void_p()
-        _ck(lib().jolt_host_transcript_create(C.c_uint64(label), C.byref(self.h)), "jolt_host_transcript_create")
+        if isinstance(label, (bytes, bytearray)):
+            buf = (C.c_uint8 * max(1, len(label))).from_buffer_copy(bytes(label) if len(label) else b"\0")
+            _ck(lib().jolt_host_transcript_create_labelled(C.c_int32(kind), buf, C.c_size_t(len(label)), C.byref(self.h)), "jolt_host_transcript_create_labelled")
+        else:
+            _ck(lib().jolt_host_transcript_create(C.c_uint64(label), C.byref(self.h)), "jolt_host_transcript_create")
 
     def append(self, values):
         v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
         _ck(lib().jolt_host_transcript_append_fr(self.h, _p(v), C.c_size_t(v.shape[0])), "jolt_host_transcript_append_fr")
 
     def append_bytes(self, data):
-        buf = (C.c_uint8 * len(data))(*data)
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) if len(data) else b"\0")
         _ck(lib().jolt_host_transcript_append_bytes(self.h, buf, C.c_size_t(len(data))), "jolt_host_transcript_append_bytes")
+
+    def append_label(self, label, count=None):
+        _ck(lib().jolt_host_transcript_append_label(self.h, C.c_char_p(label), C.c_int32(0 if count is None else 1), C.c_uint64(count or 0)), "jolt_host_transcript_append_label")
+
+    def append_u64_word(self, value):
+        _ck(lib().jolt_host_transcript_append_u64_word(self.h, C.c_uint64(value)), "jolt_host_transcript_append_u64_word")
+
+    def append_round_poly(self, coefficients, label=b"sumcheck_poly"):
+        v = np.ascontiguousarray(coefficients, dtype=np.uint64).reshape(-1, 4)
+        _ck(lib().jolt_host_transcript_append_round_poly(self.h, C.c_char_p(label), _p(v), C.c_size_t(v.shape[0])), "jolt_host_transcript_append_round_poly")
+
+    def state(self):
+        out = (C.c_uint8 * 32)()
+        _ck(lib().jolt_host_transcript_state(self.h, out), "jolt_host_transcript_state")
+        return bytes(out)
 
     def challenge(self, full_width=False):
         o = fr_array(1)
@@ -588,6 +612,19 @@ class HostTranscript:
         if self.h:
             lib().jolt_host_transcript_destroy(self.h)
             self.h = None
+
+
+def host_blake2b(data, outlen=32):
+    out = (C.c_uint8 * outlen)()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) if len(data) else b"\0")
+    _ck(lib().jolt_host_blake2b(buf, C.c_size_t(len(data)), C.c_size_t(outlen), out), "jolt_host_blake2b")
+    return bytes(out)
+
+
+def host_keccak_f1600(state):
+    buf = (C.c_uint8 * 200).from_buffer_copy(bytes(state))
+    _ck(lib().jolt_host_keccak_f1600(buf), "jolt_host_keccak_f1600")
+    return bytes(buf)
 
     def __del__(self):
         try:

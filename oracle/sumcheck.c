@@ -433,8 +433,7 @@ EXPORT int orc_prove_batch(orc_member **members, size_t n_members, const fr_t *i
          * trailing zeros trimmed down to degree 1 (prover.rs:168-177), then squeeze the challenge */
         size_t ncoef = stride;
         while (ncoef > 2 && fr_is_zero(&batched[ncoef - 1])) ncoef--;
-        mt_append_fr(&tr, &batched[0]);
-        for (size_t k = 2; k < ncoef; ++k) mt_append_fr(&tr, &batched[k]);
+        mt_append_round_poly(&tr, "sumcheck_poly", batched, ncoef); /* CompressedLabeledRoundPoly::sumcheck (round_proof.rs:115-143) */
         fr_t challenge = challenge_mode ? mt_challenge_scalar(&tr) : mt_challenge(&tr);
         out_challenges[round] = challenge;
         orc_univariate_evaluate(batched, stride, &challenge, &running_claim);
@@ -458,7 +457,26 @@ done:
 }
 
 /* Mock-transcript access for tests that drive the product side with the same challenge stream */
+EXPORT size_t orc_mt_sizeof(void) { return sizeof(mock_transcript); }
 EXPORT void orc_mt_init(mock_transcript *t, uint64_t label) { mt_init(t, label); }
+EXPORT int orc_mt_init_bytes(mock_transcript *t, uint64_t kind, const uint8_t *label, size_t n) { return mt_init_bytes(t, kind, label, n); }
+EXPORT void orc_mt_append_label(mock_transcript *t, const char *label) { mt_append_label(t, label); }
+EXPORT void orc_mt_append_label_with_count(mock_transcript *t, const char *label, uint64_t count) { mt_append_label_with_count(t, label, count); }
+EXPORT void orc_mt_append_u64_word(mock_transcript *t, uint64_t v) { mt_append_u64_word(t, v); }
+EXPORT void orc_mt_append_round_poly(mock_transcript *t, const char *label, const fr_t *coeffs, size_t n) { mt_append_round_poly(t, label, coeffs, n); }
+EXPORT void orc_mt_state(const mock_transcript *t, uint8_t out[32]) { /* Transcript::state (digest.rs:191-193; legacy.rs:302-304: 32 bytes squeezed from a clone) */
+    if (t->kind == MT_KIND_BLAKE2B_LEGACY) memcpy(out, t->state, 32);
+    else if (t->kind == MT_KIND_KECCAK_SPONGE) { orc_keccak_duplex c = t->sponge; orc_duplex_squeeze(&c, out, 32); }
+    else if (t->kind == MT_KIND_BLAKE2B_SPONGE) { mock_transcript c = *t; mt_bridge_squeeze(&c, out, 32); }
+    else memcpy(out, t->s, 32);
+}
+EXPORT void orc_blake2b_digest(const uint8_t *in, size_t n, size_t outlen, uint8_t *out) {
+    orc_blake2b h;
+    orc_blake2b_init(&h, outlen);
+    orc_blake2b_update(&h, in, n);
+    orc_blake2b_final(&h, out);
+}
+EXPORT void orc_keccak_f1600_permute(uint8_t st[200]) { orc_keccak_f1600(st); }
 EXPORT void orc_mt_append_bytes(mock_transcript *t, const uint8_t *b, size_t n) { mt_append_bytes(t, b, n); }
 EXPORT void orc_mt_append_fr(mock_transcript *t, const fr_t *a) { mt_append_fr(t, a); }
 EXPORT void orc_mt_challenge(mock_transcript *t, fr_t *out) { *out = mt_challenge(t); }

@@ -259,10 +259,17 @@ extern "C" {
     pub fn jolt_host_pair_tables_round(g: *const jolt_fr_t, w: *const jolt_fr_t, n_polys: usize, stride: usize, len: usize, evals_out: *mut jolt_fr_t) -> i32;
     pub fn jolt_host_pair_tables_bind(g: *mut jolt_fr_t, w: *mut jolt_fr_t, n_polys: usize, stride: usize, len: usize, challenge: *const jolt_fr_t) -> i32;
     pub fn jolt_host_transcript_create(label: u64, out: *mut *mut jolt_host_transcript) -> i32;
+    pub fn jolt_host_transcript_create_labelled(kind: i32, label: *const u8, label_len: usize, out: *mut *mut jolt_host_transcript) -> i32;
     pub fn jolt_host_transcript_append_fr(t: *mut jolt_host_transcript, values: *const jolt_fr_t, count: usize) -> i32;
     pub fn jolt_host_transcript_append_bytes(t: *mut jolt_host_transcript, bytes: *const u8, count: usize) -> i32;
+    pub fn jolt_host_transcript_append_label(t: *mut jolt_host_transcript, label: *const c_char, with_count: i32, count: u64) -> i32;
+    pub fn jolt_host_transcript_append_u64_word(t: *mut jolt_host_transcript, value: u64) -> i32;
+    pub fn jolt_host_transcript_append_round_poly(t: *mut jolt_host_transcript, label: *const c_char, coefficients: *const jolt_fr_t, count: usize) -> i32;
     pub fn jolt_host_transcript_challenge(t: *mut jolt_host_transcript, full_width: i32, out: *mut jolt_fr_t) -> i32;
+    pub fn jolt_host_transcript_state(t: *const jolt_host_transcript, out32: *mut u8) -> i32;
     pub fn jolt_host_transcript_destroy(t: *mut jolt_host_transcript) -> i32;
+    pub fn jolt_host_blake2b(r#in: *const u8, n: usize, outlen: usize, out: *mut u8) -> i32;
+    pub fn jolt_host_keccak_f1600(state200: *mut u8) -> i32;
     pub fn jolt_host_g1_add(p: *const jolt_g1_t, q: *const jolt_g1_t, out: *mut jolt_g1_t) -> i32;
     pub fn jolt_host_g1_eq(p: *const jolt_g1_t, q: *const jolt_g1_t, equal: *mut i32) -> i32;
     pub fn jolt_host_g1_is_on_curve(p: *const jolt_g1_t, on_curve: *mut i32) -> i32;

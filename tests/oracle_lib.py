@@ -415,10 +415,23 @@ def triple_product_round_evals(a, b, c):
     return o
 
 
+TRANSCRIPT_MOCK, TRANSCRIPT_BLAKE2B, TRANSCRIPT_KECCAK, TRANSCRIPT_BLAKE2B_SPONGE = 0, 1 << 62, 2 << 62, 3 << 62  # the two top bits of a transcript label select the engine (oracle/mock_transcript.h)
+
+
 class MockTranscript:
-    def __init__(self, label=0):
-        self.s = (C.c_uint64 * 4)()
-        lib().orc_mt_init(self.s, C.c_uint64(label))
+    """The oracle's transcript (oracle/mock_transcript.h): the engine is selected by the label's two top bits -- 0 the deterministic stand-in, TRANSCRIPT_BLAKE2B the
+    reference's LegacyBlake2bTranscript, TRANSCRIPT_KECCAK its KeccakTranscript -- or explicitly with a byte label (`kind` 1 / 2, the reference's `Transcript::new(b"...")`)."""
+
+    def __init__(self, label=0, kind=None):
+        L = lib()
+        L.orc_mt_sizeof.restype = C.c_size_t
+        self.s = (C.c_uint8 * L.orc_mt_sizeof())()
+        if isinstance(label, (bytes, bytearray)):
+            buf = (C.c_uint8 * max(1, len(label))).from_buffer_copy(bytes(label) if len(label) else b"\0")
+            if L.orc_mt_init_bytes(self.s, C.c_uint64(kind), buf, C.c_size_t(len(label))) != 0:
+                raise ValueError("transcript label longer than 32 bytes or unknown kind")
+        else:
+            L.orc_mt_init(self.s, C.c_uint64(label))
 
     def append_bytes(self, b):
         buf = (C.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if len(b) else b"\0")
@@ -427,6 +440,24 @@ class MockTranscript:
     def append_fr(self, a):
         a = np.ascontiguousarray(a, dtype=np.uint64)
         lib().orc_mt_append_fr(self.s, _p(a))
+
+    def append_label(self, label):
+        lib().orc_mt_append_label(self.s, C.c_char_p(label))
+
+    def append_label_with_count(self, label, count):
+        lib().orc_mt_append_label_with_count(self.s, C.c_char_p(label), C.c_uint64(count))
+
+    def append_u64_word(self, v):
+        lib().orc_mt_append_u64_word(self.s, C.c_uint64(v))
+
+    def append_round_poly(self, coeffs, label=b"sumcheck_poly"):
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        lib().orc_mt_append_round_poly(self.s, C.c_char_p(label), _p(c), C.c_size_t(c.shape[0]))
+
+    def state(self):
+        out = (C.c_uint8 * 32)()
+        lib().orc_mt_state(self.s, out)
+        return bytes(out)
 
     def challenge(self):
         o = fr_array(1)
@@ -437,6 +468,13 @@ class MockTranscript:
         o = fr_array(1)
         lib().orc_mt_challenge_scalar(self.s, _p(o))
         return o[0]
+
+
+def blake2b_digest(data, outlen=32):
+    out = (C.c_uint8 * outlen)()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) if len(data) else b"\0")
+    lib().orc_blake2b_digest(buf, C.c_size_t(len(data)), C.c_size_t(outlen), out)
+    return bytes(out)
 
 
 # ---------------------------------------------------------------- G1 / MSM / HyperKZG
