@@ -476,12 +476,14 @@ def main():
         ext_legs = []
         if wl.ext is not None:
             e, dd = wl.ext, wl.ext.d
+            boo = {}  # the booleanity address phase's output: the cycle phase starts from its bound point
             ext_legs = [("spartan_outer", lambda: e.spartan(e.outer_ints, dd["outer_iwa"], dd["outer_iwb"], dd["outer_wa"], dd["outer_wb"], dd["outer_tau"], dd["outer_kernel"],
                                                            e.claims["outer"], 2, TR | 3100)),
                         ("spartan_product", lambda: e.spartan(e.product_ints, e.product_ia, e.product_ib, e.product_fa, e.product_fb, dd["product_tau"], dd["product_kernel"],
                                                              e.claims["product"], 1, TR | 3200)),
                         ("ram_read_write", lambda: e.ram_read_write(TR | 3300)), ("registers_read_write", lambda: e.registers_read_write(TR | 3350)),
-                        ("instruction_read_raf", lambda: e.instruction_read_raf(TR | 3400)), ("booleanity_address", lambda: e.booleanity_address(TR | 3450)),
+                        ("instruction_read_raf", lambda: e.instruction_read_raf(TR | 3400)), ("booleanity_address", lambda: boo.update(e.booleanity_address(TR | 3450))),
+                        ("booleanity_cycle", lambda: e.booleanity_cycle(TR | 3460, boo["challenges"][::-1])),
                         ("hamming_weight", lambda: e.hamming_weight(TR | 3470)), ("address_domain", lambda: e.address_domain(TR | 3500))]
         # "opening_hint_background": what is left of the class sums the commit leg began on the background stream once the commit itself has landed -- in the step
         # they run UNDER the stage operators and the sumcheck legs (and slow those down a little: the legs of this split, timed one by one, add up to more than the step)

@@ -12,6 +12,7 @@
 //   jolt_stage_ram_read_write_create               ram_read_write                               optimized/ram_read_write.rs:58-330
 //   jolt_stage_registers_read_write_create         registers_read_write                         optimized/registers_read_write/mod.rs:79-402
 //   jolt_stage_booleanity_address_create           booleanity_address                           optimized/booleanity.rs:152-427
+//   jolt_stage_booleanity_cycle_create             booleanity_cycle                             optimized/booleanity.rs:436-690
 //   jolt_stage_hamming_weight_create               hamming_weight_claim_reduction               optimized/hamming_weight_claim_reduction.rs:83-300
 //   jolt_stage_instruction_read_raf_create         instruction_read_raf (address + cycle)       optimized/instruction_read_raf.rs:736-1456
 //   jolt_stage_bytecode_read_raf_address_create    bytecode_read_raf_address                    optimized/bytecode_read_raf.rs:152-437
@@ -345,6 +346,41 @@ struct BooleanityAddressOp final : jolt_stage_op {
         Fr acc = Fr::zero();
         for (size_t i = 0; i < n_polys; ++i) acc = add(acc, mul(fr_from_abi(&weights[i]), sub(fr_from_abi(&squared[i * K]), fr_from_abi(&linear[i * K]))));
         out->assign(1, mul(fr_from_abi(&eq[0]), acc));
+        return JOLT_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Booleanity, cycle phase (stage 6b): eq(reference_cycle, j) * eq(r_address, reference_address) * sum_i (H_i(j)^2 - gamma^i H_i(j)) over the lazily bound RA columns,
+// H_i(j) = gamma^i eq(r_address)[hot_i(j)] (optimized/booleanity.rs:436-633).  The member is jolt_member_create_lazy_booleanity; the round message is
+// gruen_poly_deg_3 of its two sums (member_round); the output claims are the bound columns unscaled by gamma^-i (booleanity.rs:652-657).
+// ------------------------------------------------------------------------------------------------------------------
+struct BooleanityCycleOp final : jolt_stage_op {
+    size_t n_polys = 0;
+    std::vector<Fr> rho_inv;
+    MemberH member;
+
+    int32_t prove_round(const Fr* bind, size_t, const Fr& claim, UnivariatePoly* out) override {
+        if (bind) binds.push_back(*bind);
+        return member_round(ctx, member.m, bind, claim, out);
+    }
+    int32_t finish_rounds(const Fr& bind) override {
+        binds.push_back(bind);
+        return member_finish(member.m, bind);
+    }
+    int32_t input_claim(Fr* out) override {  // = the address phase's intermediate claim (BooleanityAddressPhaseOutputClaims::intermediate)
+        jolt_fr_t c;
+        JOLT_TRY(jolt_member_input_claim(member.m, &c));
+        *out = fr_from_abi(&c);
+        return JOLT_OK;
+    }
+    int32_t output_claims(std::vector<Fr>* out) override {
+        if (binds.size() != rounds) return JOLT_ERR_NOT_FULLY_BOUND;
+        std::vector<Fr> fin;
+        JOLT_TRY(member_finals(member.m, n_polys + 1, &fin));  // the bound H_i, then the split-eq scalar (the fully bound EqAddressCycle, validate_derived_tables :666-680)
+        out->resize(n_polys);
+        for (size_t i = 0; i < n_polys; ++i) (*out)[i] = mul(fin[i], rho_inv[i]);
+        kept["eq_scalar"] = {fin[n_polys]};
         return JOLT_OK;
     }
 };
@@ -936,6 +972,49 @@ extern "C" int32_t jolt_stage_booleanity_address_create(jolt_ctx* ctx, const jol
         cur = mul(cur, g2);
     }
     JOLT_TRY(host_eq(from_abi(reference_address, log_k), &op->eq));
+    *out = hold.release();
+    return JOLT_OK;
+}
+
+extern "C" int32_t jolt_stage_booleanity_cycle_create(jolt_ctx* ctx, const jolt_onehot* cols, const jolt_fr_t* r_address, const jolt_fr_t* reference_address,
+                                                      const jolt_fr_t* reference_cycle, size_t n_cycle, const jolt_fr_t* gamma, jolt_stage_op** out) {
+    if (!ctx || !cols || !r_address || !reference_address || (!reference_cycle && n_cycle) || !gamma || !out || ((size_t)1 << n_cycle) != cols->cycles) return JOLT_ERR_INVALID_ARG;
+    const size_t log_k = log2_exact(cols->k);
+    if (((size_t)1 << log_k) != cols->k || !all_canonical(r_address, log_k) || !all_canonical(reference_address, log_k) || !all_canonical(reference_cycle, n_cycle) ||
+        !all_canonical(gamma, 1))
+        return JOLT_ERR_INVALID_ARG;
+    const Fr g = fr_from_abi(gamma);
+    if (g.is_zero()) return JOLT_ERR_INVALID_ARG;  // "booleanity batching gamma must be invertible" (booleanity.rs:497-501)
+    BooleanityCycleOp* op = new_op<BooleanityCycleOp>(ctx, "booleanity_cycle");
+    if (!op) return JOLT_ERR_OOM;
+    std::unique_ptr<BooleanityCycleOp> hold(op);
+    op->n_polys = cols->n_polys;
+    op->rounds = n_cycle;
+    op->degree = 3;
+    // the fixed address factor of the EqAddressCycle public rides in the split-eq scaling (booleanity.rs:489-495); the K-sized tables gamma^i * eq(r_address, .)
+    const std::vector<Fr> ra = from_abi(r_address, log_k), ref = from_abi(reference_address, log_k);
+    Fr scalar = Fr::one();
+    for (size_t b = 0; b < log_k; ++b) {  // eq_mle: prod_b (a_b c_b + (1 - a_b)(1 - c_b))
+        const Fr ac = mul(ra[b], ref[b]);
+        scalar = mul(scalar, add(sub(sub(Fr::one(), ra[b]), ref[b]), add(ac, ac)));
+    }
+    std::vector<jolt_fr_t> eq_address;
+    JOLT_TRY(host_eq(ra, &eq_address));
+    const size_t K = cols->k;
+    std::vector<jolt_fr_t> tables(op->n_polys * K), rho(op->n_polys);
+    op->rho_inv.resize(op->n_polys);
+    const Fr g_inv = inv(g);
+    Fr cur = Fr::one(), cur_inv = Fr::one();
+    for (size_t i = 0; i < op->n_polys; ++i) {
+        fr_to_abi(&rho[i], cur);
+        op->rho_inv[i] = cur_inv;
+        for (size_t k = 0; k < K; ++k) fr_to_abi(&tables[i * K + k], mul(cur, fr_from_abi(&eq_address[k])));
+        cur = mul(cur, g);
+        cur_inv = mul(cur_inv, g_inv);
+    }
+    jolt_fr_t sc;
+    fr_to_abi(&sc, scalar);
+    JOLT_TRY(jolt_member_create_lazy_booleanity(ctx, cols, tables.data(), rho.data(), reference_cycle, n_cycle, &sc, &op->member.m));
     *out = hold.release();
     return JOLT_OK;
 }

@@ -2043,6 +2043,14 @@ def _stage_booleanity_address(self, cols, reference_cycle, reference_address, ga
     return StageOp(self, h, keep=[cols])
 
 
+def _stage_booleanity_cycle(self, cols, r_address, reference_address, reference_cycle, gamma):
+    rc = fr(reference_cycle).reshape(-1, 4)
+    h = C.c_void_p()
+    _ck(lib().jolt_stage_booleanity_cycle_create(self.h, cols.h, _p(fr(r_address).reshape(-1, 4)), _p(fr(reference_address).reshape(-1, 4)), _p(rc), C.c_size_t(rc.shape[0]),
+                                                 _p(fr(gamma)), C.byref(h)), "jolt_stage_booleanity_cycle_create", self)
+    return StageOp(self, h, keep=[cols])
+
+
 def _stage_hamming_weight(self, cols, r_cycle, r_address, virtualization_points, gamma):
     rc = fr(r_cycle).reshape(-1, 4)
     h = C.c_void_p()
@@ -2099,6 +2107,7 @@ Context.stage_spartan_remainder = _stage_spartan_remainder
 Context.stage_ram_read_write = _stage_ram_read_write
 Context.stage_registers_read_write = _stage_registers_read_write
 Context.stage_booleanity_address = _stage_booleanity_address
+Context.stage_booleanity_cycle = _stage_booleanity_cycle
 Context.stage_hamming_weight = _stage_hamming_weight
 Context.stage_instruction_read_raf = _stage_instruction_read_raf
 Context.stage_bytecode_read_raf_address = _stage_bytecode_read_raf_address

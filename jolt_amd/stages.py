@@ -688,6 +688,18 @@ class DeviceExtended:
         op.destroy()
         return out
 
+    def booleanity_cycle(self, label, r_address):
+        """stage 6b after 6a: `r_address` = the address phase's bound point (its challenges, last first); the input claim is that phase's intermediate claim"""
+        bo = self.d["booleanity"]
+        op = self.ctx.stage_booleanity_cycle(self.bool_cols, r_address, bo["reference_address"], bo["reference_cycle"], bo["gamma"])
+        claim = op.input_claim()
+        out = self._batch(op, claim, self.n_vars, 3, label)
+        out["claim"] = claim
+        out["ra_claims"] = op.output_claims()
+        out["eq_scalar"] = op.kept("eq_scalar")[0]
+        op.destroy()
+        return out
+
     def hamming_weight(self, label):
         bo, hw = self.d["booleanity"], self.d["hamming"]
         op = self.ctx.stage_hamming_weight(self.bool_cols, hw["r_cycle"], hw["r_address"], hw["virtualization_points"], hw["gamma"])
@@ -765,6 +777,7 @@ class DeviceExtended:
 
     def prove(self, label=0):
         d = self.d
+        booleanity_address = self.booleanity_address(label + 450)
         return {
             **self.address_domain(label + 500),
             "spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
@@ -774,7 +787,8 @@ class DeviceExtended:
             "ram_read_write": self.ram_read_write(label + 300),
             "registers_read_write": self.registers_read_write(label + 350),
             "instruction_read_raf": self.instruction_read_raf(label + 400),
-            "booleanity_address": self.booleanity_address(label + 450),
+            "booleanity_address": booleanity_address,
+            "booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1]),
             "hamming_weight": self.hamming_weight(label + 470),
         }
 

@@ -326,6 +326,7 @@ pub fn mi355x(ctx: &Arc<HipContext>, parts: Mi355xParts) -> JoltBackend<Fr, HipH
     backend.registers_read_write = Box::new(stage::HipRegistersReadWrite::new(ctx));
     backend.instruction_read_raf = Box::new(stage::HipInstructionReadRaf::new(ctx));
     backend.booleanity_address = Box::new(stage::HipBooleanityAddress::new(ctx));
+    backend.booleanity_cycle = Box::new(stage::HipBooleanityCycle::new(ctx));
     backend.bytecode_read_raf_address = Box::new(stage::HipBytecodeReadRafAddressWith { slot: stage::HipBytecodeReadRafAddress::new(ctx), stage_values: parts.bytecode_stage_values });
     backend.bytecode_read_raf_cycle = Box::new(stage::HipBytecodeReadRafCycle::new(ctx));
     backend.hamming_weight_claim_reduction = Box::new(stage::HipHammingWeightClaimReduction::new(ctx));

@@ -425,6 +425,7 @@ extern "C" {
     pub fn jolt_stage_ram_read_write_create(ctx: *mut jolt_ctx, addresses: *const jolt_ints, pre_values: *const jolt_ints, post_values: *const jolt_ints, inc: *const jolt_ints, val_init: *const jolt_ints, tau_low: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_registers_read_write_create(ctx: *mut jolt_ctx, regs: *const jolt_onehot, rs1_val: *const jolt_ints, rs2_val: *const jolt_ints, rd_pre: *const jolt_ints, rd_post: *const jolt_ints, inc: *const jolt_ints, r_cycle: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_booleanity_address_create(ctx: *mut jolt_ctx, cols: *const jolt_onehot, reference_cycle: *const jolt_fr_t, n_cycle: usize, reference_address: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
+    pub fn jolt_stage_booleanity_cycle_create(ctx: *mut jolt_ctx, cols: *const jolt_onehot, r_address: *const jolt_fr_t, reference_address: *const jolt_fr_t, reference_cycle: *const jolt_fr_t, n_cycle: usize, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_hamming_weight_create(ctx: *mut jolt_ctx, cols: *const jolt_onehot, r_cycle: *const jolt_fr_t, n_cycle: usize, r_address: *const jolt_fr_t, virtualization_points: *const jolt_fr_t, gamma: *const jolt_fr_t, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_instruction_read_raf_create(ctx: *mut jolt_ctx, rows: *mut jolt_read_raf, claim_columns: *const jolt_onehot, r_reduction: *const jolt_fr_t, n_vars: usize, gamma: *const jolt_fr_t, table_present: *const u8, ra_count: u32, out: *mut *mut jolt_stage_op) -> i32;
     pub fn jolt_stage_bytecode_read_raf_address_create(ctx: *mut jolt_ctx, pc_index: *const jolt_key_index, stage_points: *const jolt_fr_t, n_vars: usize, stage_values: *const jolt_fr_t, gamma: *const jolt_fr_t, first_pc: u64, entry_index: u64, out: *mut *mut jolt_stage_op) -> i32;

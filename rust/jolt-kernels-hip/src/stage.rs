@@ -40,6 +40,7 @@ use jolt_verifier::stages::stage4::registers_read_write_checking::RegistersReadW
 use jolt_verifier::stages::stage5::InstructionReadRaf;
 use jolt_verifier::stages::stage6a::booleanity::BooleanityAddressPhase;
 use jolt_verifier::stages::stage6a::bytecode_read_raf::BytecodeReadRafAddressPhase;
+use jolt_verifier::stages::stage6b::booleanity::Booleanity;
 use jolt_verifier::stages::stage6b::bytecode_read_raf::BytecodeReadRafCycle;
 use jolt_verifier::stages::stage7::hamming_weight_claim_reduction::HammingWeightClaimReduction;
 use jolt_witness::witnesses::{
@@ -766,6 +767,58 @@ impl PrepareKernel<Fr, BooleanityAddressPhase<Fr>> for HipBooleanityAddress {
         Ok(kernel(op, vec![columns], Box::new(|v, _| {
             short(v, 1)?;
             Ok(BooleanityAddressPhaseOutputClaims { intermediate: v[0] })
+        })))
+    }
+}
+
+slot!(
+    /// `backend.booleanity_cycle` (replaces `optimized/booleanity.rs:436-690`): the stage-6b cycle phase over the same resident RA columns, lazily bound.
+    HipBooleanityCycle
+);
+impl PrepareKernel<Fr, Booleanity<Fr>> for HipBooleanityCycle {
+    #[tracing::instrument(skip_all, name = "HipBooleanityCycle::prepare")]
+    fn prepare(
+        &self,
+        session: &mut ProofSession,
+        witness: &dyn JoltWitnessPlane<Fr>,
+        inputs: ProverInputs<'_, Fr, Booleanity<Fr>>,
+    ) -> Result<Box<dyn SumcheckKernel<Fr, Relation = Booleanity<Fr>>>, KernelError<Fr>> {
+        let relation = inputs.relation;
+        let dimensions = relation.dimensions();
+        let layout = dimensions.layout;
+        let (r_address, reference_address, reference_cycle) = (relation.r_address(), relation.reference_address(), relation.reference_cycle());
+        if r_address.len() != dimensions.log_k_chunk || reference_address.len() != dimensions.log_k_chunk || reference_cycle.len() != dimensions.log_t {
+            return Err(KernelError::InvariantViolation { reason: "booleanity cycle-phase point lengths disagree with the dimensions" });
+        }
+        // the operator serves exactly the base RA layout's members (optimized/booleanity.rs:459-481 fails closed on the lattice variant the same way)
+        let openings: Vec<JoltOpeningId> = layout.openings(JoltRelationId::Booleanity).collect();
+        if openings.len() != layout.total() {
+            return Err(KernelError::Unsupported { reason: "the device booleanity cycle operator serves the base RA layout only" });
+        }
+        let columns = ResidentTrace::ra_columns(session, &self.ctx, witness, dimensions.log_t, dimensions.log_k_chunk, (layout.instruction(), layout.bytecode(), layout.ram()))?;
+        let gamma = inputs.challenges.gamma;
+        let mut raw = ptr::null_mut();
+        // SAFETY: live columns over T cycles; r_address / reference_address hold log K elements, reference_cycle log T, gamma one.
+        check(
+            unsafe {
+                ffi::jolt_stage_booleanity_cycle_create(
+                    self.ctx.raw,
+                    columns.raw,
+                    r_address.as_ptr().cast(),
+                    reference_address.as_ptr().cast(),
+                    reference_cycle.as_ptr().cast(),
+                    reference_cycle.len(),
+                    (&gamma as *const Fr).cast(),
+                    &mut raw,
+                )
+            },
+            self.ctx.raw,
+        )?;
+        let op = HipStageOp::adopt(&self.ctx, raw)?;
+        // output values: the bound columns, unscaled by gamma^-i inside the operator, in the layout's canonical order (booleanity.rs:652-662)
+        Ok(kernel(op, vec![columns], Box::new(move |v, _| {
+            short(v, openings.len())?;
+            SumcheckOutputClaims::<Fr, Booleanity<Fr>>::from_opening_values(|id: &JoltOpeningId| openings.iter().position(|o| o == id).map(|k| v[k])).map_err(SumcheckKernelError::from)
         })))
     }
 }

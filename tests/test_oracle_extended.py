@@ -62,10 +62,13 @@ def test_consistent_trace_is_consistent():
 
 def test_all_extended_drivers_run_on_the_oracle():
     out = OracleExtended(5, seed=12, n_tables=6).prove(label=3)
-    assert set(out) == {"spartan_outer", "spartan_product", "ram_read_write", "registers_read_write", "instruction_read_raf", "booleanity_address", "hamming_weight", "bytecode_read_raf",
+    assert set(out) == {"spartan_outer", "spartan_product", "ram_read_write", "registers_read_write", "instruction_read_raf", "booleanity_address", "booleanity_cycle", "hamming_weight", "bytecode_read_raf",
                         "ram_raf_evaluation", "ram_output_check"}
     assert out["spartan_outer"]["polys"].shape[0] == 6 and out["spartan_product"]["polys"].shape[0] == 5
     assert len(out["instruction_read_raf"]["scans"]) == S.PHASES and out["instruction_read_raf"]["polys"].shape[0] == 5
+    # stage 6b starts where stage 6a ended: the cycle phase's input claim (summed from the definition over the dense columns at the address phase's bound point) is the
+    # address phase's intermediate output claim -- which also pins the order in which the address challenges form r_address
+    assert np.array_equal(out["booleanity_cycle"]["claim"], out["booleanity_address"]["intermediate"])
 
 
 def test_read_raf_twin_paths_agree():

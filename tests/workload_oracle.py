@@ -436,6 +436,41 @@ class OracleExtended:
         out["claim"] = np.zeros(4, dtype=np.uint64)
         return out
 
+    def booleanity_cycle(self, label, r_address):
+        """the cycle phase FROM THE DEFINITION (crates/jolt-kernels/src/reference/booleanity.rs, the naive tier): a flat Expr member over the dense eq table
+        eq(reference_cycle, .) * eq(r_address, reference_address) and the dense columns H_i(j) = gamma^i eq(r_address, hot_i(j)) (0 on a cold cycle), summand
+        sum_i (H_i^2 - gamma^i H_i); one-member prove_batch; the output claims are the bound columns divided by gamma^i"""
+        bo = self.d["booleanity"]
+        cols, K = bo["cols"], 1 << bo["log_k"]
+        N, T = cols.shape
+        one = O.to_mont([1])[0]
+        mul = lambda a, b: O.fr_mul(np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+        eq_address = O.eq_evals(np.asarray(r_address).reshape(-1, 4)) if bo["log_k"] else O.to_mont([1])
+        scalar = one
+        for a, c in zip(np.asarray(r_address).reshape(-1, 4), np.asarray(bo["reference_address"]).reshape(-1, 4)):  # eq_mle(r_address, reference_address)
+            ac = mul(a, c)
+            term = O.fr_add(O.fr_sub(O.fr_sub(one.reshape(1, 4), a.reshape(1, 4)), c.reshape(1, 4)), O.fr_add(ac.reshape(1, 4), ac.reshape(1, 4)))[0]
+            scalar = mul(scalar, term)
+        rho, dense = [one], []
+        for i in range(N):
+            table = np.concatenate([O.fr_mul(eq_address, np.repeat(rho[i].reshape(1, 4), K, axis=0)), np.zeros((1, 4), dtype=np.uint64)])  # slot K: a cold cycle
+            idx = np.where(cols[i] == 0xFF, K, cols[i]).astype(np.int64)
+            dense.append(np.ascontiguousarray(table[idx]))
+            rho.append(mul(rho[i], bo["gamma"]))
+        eq = O.eq_evals(bo["reference_cycle"], scalar) if self.n_vars else scalar.reshape(1, 4)
+        neg = lambda x: O.fr_neg(np.asarray(x).reshape(1, 4))[0]
+        terms = []
+        for i in range(N):
+            terms.append((one, [0, 1 + i, 1 + i]))
+            terms.append((neg(rho[i]), [0, 1 + i]))
+        member = O.Member.expr([eq] + dense, terms, 3)
+        claim = member.input_claim()
+        out = O.prove_batch([member], [claim], [one], [0], self.n_vars, 3, label=label)
+        fv = member.final_values()
+        inv = lambda x: O.fr_inv(np.asarray(x).reshape(1, 4))[0]
+        return dict(polys=out["polys"], challenges=out["challenges"], final_claim=out["final_claim"], claim=claim,
+                    ra_claims=np.stack([mul(fv[1 + i], inv(rho[i])) for i in range(N)]), eq_scalar=fv[0])
+
     def hamming_weight(self, label):
         S, bo, hw = self.S, self.d["booleanity"], self.d["hamming"]
         K = 1 << bo["log_k"]
@@ -465,6 +500,8 @@ class OracleExtended:
                 "ram_output_check": S.ram_output_check(ops, ram, d["ram_output"], label + 20)}
 
     def prove(self, label=0):
-        return {**self.address_domain(label + 500), "spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
+        booleanity_address = self.booleanity_address(label + 450)
+        return {"booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1]),
+                **self.address_domain(label + 500), "spartan_outer": self.spartan_outer(label + 100), "spartan_product": self.spartan_product(label + 200), "ram_read_write": self.ram_read_write(label + 300),
                 "registers_read_write": self.registers_read_write(label + 350), "instruction_read_raf": self.instruction_read_raf(label + 400),
-                "booleanity_address": self.booleanity_address(label + 450), "hamming_weight": self.hamming_weight(label + 470)}
+                "booleanity_address": booleanity_address, "hamming_weight": self.hamming_weight(label + 470)}
