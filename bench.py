@@ -489,7 +489,9 @@ def main():
         # they run UNDER the stage operators and the sumcheck legs (and slow those down a little: the legs of this split, timed one by one, add up to more than the step)
         hint_leg = [("opening_hint_background", lambda: wl.hint.wait() if getattr(wl, "hint", None) is not None else None)] if pcs else []
         legs = ([("witness_upload", wl.upload_witness)] if args.witness != "resident" else []) + [("prepare", wl.prepare)] + ([("commit", wl.commit)] if pcs else []) + hint_leg + ext_legs + \
-               [("prove", lambda: wl.prove(label=TR | 3000))] + ([("open", lambda: wl.open(label=TR | 3000))] if pcs else [])
+               [("prove", lambda: wl.prove(label=TR | 3000))] + \
+               ([("stages_1_to_7_as_in_the_step", lambda: wl.prove_stages(label=TR | 3000))] if getattr(wl, "_stage_worker", None) is not None else []) + \
+               ([("open", lambda: wl.open(label=TR | 3000))] if pcs else [])
         acc = {k: 0.0 for k, _ in legs}
         reps = 2
         for _ in range(reps):
@@ -580,6 +582,10 @@ def main():
     }
     if split is not None:
         out["config"]["ms_per_step_split"] = split
+        if "stages_1_to_7_as_in_the_step" in split:
+            out["config"]["ms_per_step_split_note"] = ("every operator leg and `prove` are timed ALONE, one after the other; in the step the operators of protocol stage k run on their own "
+                                                       "context and host thread beside stage k's batched sumcheck (never across a stage boundary): `stages_1_to_7_as_in_the_step` is that "
+                                                       "whole block timed as the step runs it, and replaces the sum of the operator legs + `prove` when the legs are added up")
     if not sharded and args.witness != "resident":
         bpc = wl.witness_bytes_per_cycle()
         out["config"]["witness"] = {"mode": f"upload: every step starts from packed rows in {'page-locked (jolt_host_pinned_alloc)' if args.witness != 'upload' else 'pageable'} host memory{', the next proof copied under the current one (jolt_rows_upload_begin)' if args.witness == 'upload-overlapped' else ''} (PCIe-inclusive; NOT the contract's `value`, which has the inputs resident)",
@@ -591,6 +597,8 @@ def main():
         out["config"]["witness_upload"] = with_upload
     if not sharded:
         out["config"]["device_pool_gib"] = {k.replace("_bytes", ""): round(v / 2**30, 2) for k, v in ctx.memory_stats().items()}
+        if not sharded and getattr(wl, "ext_ctx", None) is not None:  # the stage operators' own context
+            out["config"]["device_pool_gib"]["stage_operator_context"] = {k.replace("_bytes", ""): round(v / 2**30, 2) for k, v in wl.ext_ctx.memory_stats().items() if "msm" not in k}
     if sharded:
         rounds = "shared-memory exchange of the round sums between the ranks of the node" if wl.round_exchange is not None else "RCCL all-gather of the round sums"
         out["config"]["collective"] = f"{rounds}; {type(wl.coll).__name__}: RCCL all-gather of the 2^tail_log-entry tables"

@@ -73,6 +73,9 @@ int32_t jolt_ctx_destroy(jolt_ctx *ctx);
 int32_t jolt_ctx_synchronize(jolt_ctx *ctx);
 /* ... without the background stream (jolt_grid_hint_begin's class sums may outlive the leg that began them): what a caller timing a leg waits for */
 int32_t jolt_ctx_synchronize_foreground(jolt_ctx *ctx);
+/* Select the context's device on the CALLING host thread (the runtime's current device is per thread).  Contexts are single-threaded objects; two contexts on one device may be
+ * driven from two threads at once -- the stage operators of one protocol stage beside that stage's batched sumcheck, as the reference batches them (crates/jolt-prover/src/stages). */
+int32_t jolt_ctx_bind_thread(jolt_ctx *ctx);
 const char *jolt_last_error(const jolt_ctx *ctx);
 /* Device memory of tables, members and temporaries comes from a per-context pool (a proof builds and drops dozens of T-sized
  * derived tables -- the Vec<Fr> allocations of EqPolynomial::evals & co. in the reference; hipMalloc / hipFree cost 0.1-1 ms each

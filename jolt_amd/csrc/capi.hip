@@ -202,6 +202,14 @@ extern "C" int32_t jolt_ctx_synchronize(jolt_ctx* ctx) {
     return JOLT_OK;
 }
 // The same without the background (hint) stream: what a caller that times a leg waits for -- the opening hint's class sums are meant to outlive the leg that began them.
+// A host thread other than the one that created the context must select the context's device before it calls into the library (the HIP runtime's current device is
+// per thread and starts at device 0): the stage operators of one protocol stage run on their own context and thread beside the stage's batched sumcheck (workload.py).
+extern "C" int32_t jolt_ctx_bind_thread(jolt_ctx* ctx) {
+    if (!ctx) return JOLT_ERR_INVALID_ARG;
+    JOLT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return JOLT_OK;
+}
+
 extern "C" int32_t jolt_ctx_synchronize_foreground(jolt_ctx* ctx) {
     if (!ctx) return JOLT_ERR_INVALID_ARG;
     JOLT_TRY(jolt_internal_engine_quiesce(ctx));

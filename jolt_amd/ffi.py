@@ -80,6 +80,7 @@ def _ck(status, where, ctx=None):
 class Context:
     def __init__(self, device_id=0, stream=None):
         self.h = C.c_void_p()
+        self.device_id = device_id
         st = lib().jolt_ctx_create(C.c_int32(device_id), C.c_void_p(stream) if stream else None, C.byref(self.h))
         if st != 0:
             self.h = C.c_void_p()
@@ -89,6 +90,10 @@ class Context:
         if self.h:
             lib().jolt_ctx_destroy(self.h)
             self.h = C.c_void_p()
+
+    def bind_thread(self):
+        """select this context's device on the calling thread (a worker thread starts on device 0)"""
+        _ck(lib().jolt_ctx_bind_thread(self.h), "jolt_ctx_bind_thread", self)
 
     def synchronize_foreground(self):
         """every stream but the background one (the opening hint's class sums)"""

@@ -738,13 +738,11 @@ class DeviceExtended:
         op.destroy()
         return res
 
-    def address_domain(self, label):
-        """the joint-domain relations whose rounds run over K-sized tables: bytecode read+RAF (6a, 6b), RAM RAF evaluation, RAM output check.  The key indexes are
-        per-proof work (the reference builds its PC rows / RamAccessColumns once per proof and shares them through the session)"""
+    def bytecode_read_raf(self, label):
+        """stage 6a / 6b: bytecode read + RAF over a sorted index of the PC column (per-proof work: the reference builds its PC rows once per proof)"""
         ctx, d, n_vars = self.ctx, self.d, self.n_vars
-        ram, bc, raf, io = d["ram"], d["bytecode"], d["ram_raf"], d["ram_output"]
-        pc_index, ram_index = ctx.key_index(self.pc_ints, 1 << bc["log_k"]), ctx.key_index(self.ram_cols[0], 1 << ram["log_k"])
-        # ---- 6a / 6b: bytecode read + RAF
+        bc = d["bytecode"]
+        pc_index = ctx.key_index(self.pc_ints, 1 << bc["log_k"])
         first_pc = int(bc["first_pc"]) if "first_pc" in bc else int(bc["push_pc"][0])
         a_op = ctx.stage_bytecode_read_raf_address(pc_index, bc["stage_points"], bc["stage_values"], bc["gamma"], first_pc, bc["entry_index"])
         claim_a = a_op.input_claim()
@@ -757,40 +755,64 @@ class DeviceExtended:
                         ra_claims=c_op.output_claims())
         c_op.destroy()
         a_op.destroy()
-        # ---- stage 2: RAM RAF evaluation
+        pc_index.free()
+        return bytecode
+
+    def ram_address_domain(self, label):
+        """stage 2: RAM RAF evaluation and the RAM output check over a sorted index of the address column (RamAccessColumns, once per proof)"""
+        ctx, d = self.ctx, self.d
+        ram, raf, io = d["ram"], d["ram_raf"], d["ram_output"]
+        ram_index = ctx.key_index(self.ram_cols[0], 1 << ram["log_k"])
         op = ctx.stage_ram_raf_evaluation(ram_index, raf["tau_low"], raf["lowest_address"])
         claim = op.input_claim()
         raf_out = self._batch(op, claim, ram["log_k"], 2, label + 10)
         raf_out["claim"] = claim
         raf_out["ra_claim"] = op.output_claims()[0]
         op.destroy()
-        # ---- stage 2: RAM output check
         op = ctx.stage_ram_output_check(ram_index, self.ram_cols[2], ram["val_init"], io["val_io"], io["io_lo"], io["io_len"], io["point"])
         claim = op.input_claim()
         oc = self._batch(op, claim, ram["log_k"], 3, label + 20)
         oc["claim"] = claim
         oc["val_final_claim"] = op.output_claims()[0]
         op.destroy()
-        pc_index.free()
         ram_index.free()
-        return {"bytecode_read_raf": bytecode, "ram_raf_evaluation": raf_out, "ram_output_check": oc}
+        return {"ram_raf_evaluation": raf_out, "ram_output_check": oc}
+
+    def address_domain(self, label):
+        """the joint-domain relations whose rounds run over K-sized tables: bytecode read+RAF (6a, 6b), RAM RAF evaluation, RAM output check"""
+        return {"bytecode_read_raf": self.bytecode_read_raf(label), **self.ram_address_domain(label)}
+
+    # The operators by PROTOCOL STAGE (crates/jolt-prover/src/stages: the members of one stage are proved as one batch and share no challenge across members; a stage's
+    # inputs are the previous stage's outputs).  `prove` runs the stages in order; DeviceWorkload.step runs each stage's operators here BESIDE that stage's batched sumcheck
+    # of the cycle-domain catalogue (own context, own host thread), never across a stage boundary.
+    STAGES = (1, 2, 4, 5, 6, 7)
+
+    def prove_stage(self, stage, label=0):
+        d = self.d
+        if stage == 1:
+            return {"spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
+                                                  self.claims["outer"], 2, label + 100)}
+        if stage == 2:
+            return {"spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"], d["product_kernel"],
+                                                    self.claims["product"], 1, label + 200),
+                    "ram_read_write": self.ram_read_write(label + 300), **self.ram_address_domain(label + 500)}
+        if stage == 4:
+            return {"registers_read_write": self.registers_read_write(label + 350)}
+        if stage == 5:
+            return {"instruction_read_raf": self.instruction_read_raf(label + 400)}
+        if stage == 6:
+            booleanity_address = self.booleanity_address(label + 450)
+            return {"bytecode_read_raf": self.bytecode_read_raf(label + 500), "booleanity_address": booleanity_address,
+                    "booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1])}
+        if stage == 7:
+            return {"hamming_weight": self.hamming_weight(label + 470)}
+        return {}
 
     def prove(self, label=0):
-        d = self.d
-        booleanity_address = self.booleanity_address(label + 450)
-        return {
-            **self.address_domain(label + 500),
-            "spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
-                                          self.claims["outer"], 2, label + 100),
-            "spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"], d["product_kernel"],
-                                            self.claims["product"], 1, label + 200),
-            "ram_read_write": self.ram_read_write(label + 300),
-            "registers_read_write": self.registers_read_write(label + 350),
-            "instruction_read_raf": self.instruction_read_raf(label + 400),
-            "booleanity_address": booleanity_address,
-            "booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1]),
-            "hamming_weight": self.hamming_weight(label + 470),
-        }
+        out = {}
+        for stage in self.STAGES:
+            out.update(self.prove_stage(stage, label))
+        return out
 
     def close(self):
         for c in self.outer_ints + self.product_ints + self.ram_cols + self.reg_cols + [self.ram_inc, self.ram_val_init, self.reg_inc, self.reg_idx, self.bool_cols, self.pc_ints, self.pc_chunks]:

@@ -253,10 +253,19 @@ class DeviceWorkload:
         self._rows_in_flight = None
         # extended: the stage 1 / 2 / 5 operators that are not plain cycle-domain relations (Spartan outer / product, the sparse RAM read-write
         # matrix, the instruction read-RAF scans + cycle rounds: jolt_amd/stages.py) inside every step, over their own resident inputs
-        self.ext = None
+        self.ext, self.ext_ctx, self._stage_worker = None, None, None
         if extended:
+            import os
             from .stages import DeviceExtended
-            self.ext = DeviceExtended(ctx, n_vars, seed, ram_addresses=ram_addresses)  # "hotset": a btreemap-like skewed RAM / register address stream
+            # The stage operators live on THEIR OWN context (own stream, scratch and pool) and are driven from a worker thread, so that the operators of protocol stage k run
+            # beside stage k's batched sumcheck of the catalogue -- the reference proves a stage's members as one batch; nothing crosses a stage boundary (prove_stages).
+            # JOLT_STAGE_CONCURRENCY=0: one context, the operators and the catalogue one after the other (the structure of rounds 3 - 5, for an A/B).
+            if os.environ.get("JOLT_STAGE_CONCURRENCY", "1") != "0":
+                from concurrent.futures import ThreadPoolExecutor
+                self.ext_ctx = ffi.Context(ctx.device_id)
+                self._stage_worker = ThreadPoolExecutor(max_workers=1)
+                self._stage_worker.submit(self.ext_ctx.bind_thread).result()
+            self.ext = DeviceExtended(self.ext_ctx or ctx, n_vars, seed, ram_addresses=ram_addresses)  # "hotset": a btreemap-like skewed RAM / register address stream
         self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
@@ -511,19 +520,39 @@ class DeviceWorkload:
         self.prepared = False
 
     # ---- the proof ---------------------------------------------------------------------------------------------------
+    def prove_stage(self, stage, label=0):
+        idxs = self.stages[stage]
+        ms = [self.members[i] for i in idxs]
+        deg = max(m.degree for m in ms)
+        return self.ctx.prove_batch(ms, [self.claims[i] for i in idxs], [self.batch_coeffs[i] for i in idxs], [0] * len(ms), self.n_vars, deg, label=label + stage,
+                                    use_round_group=True)
+
     def prove(self, label=0):
         """Every stage's batched sumcheck, then rewind the members (they borrow their tables). Returns per-stage outputs."""
         if not self.prepared:
             self.prepare()
-        outs = {}
-        for stage, idxs in sorted(self.stages.items()):
-            ms = [self.members[i] for i in idxs]
-            deg = max(m.degree for m in ms)
-            outs[stage] = self.ctx.prove_batch(ms, [self.claims[i] for i in idxs], [self.batch_coeffs[i] for i in idxs], [0] * len(ms),
-                                               self.n_vars, deg, label=label + stage, use_round_group=True)
+        outs = {stage: self.prove_stage(stage, label) for stage in sorted(self.stages)}
         for m in self.members:
             m.reset()
         return outs
+
+    def prove_stages(self, label=0):
+        """Stages 1 .. 7 in protocol order: per stage the stage operators (their own context, the worker thread) BESIDE the stage's batched sumcheck of the catalogue (this
+        thread); both finish before the next stage starts.  -> (the operators' outputs, the catalogue's per-stage outputs), the same values as `ext.prove` and `prove`."""
+        if not self.prepared:
+            self.prepare()
+        ext_out, outs = {}, {}
+        for stage in sorted(set(self.stages) | set(self.ext.STAGES)):
+            pending = self._stage_worker.submit(self.ext.prove_stage, stage, label) if stage in self.ext.STAGES else None
+            try:
+                if stage in self.stages:
+                    outs[stage] = self.prove_stage(stage, label)
+            finally:
+                if pending is not None:
+                    ext_out.update(pending.result())
+        for m in self.members:
+            m.reset()
+        return ext_out, outs
 
     def commit(self):
         """Stage 0 over the commitment grid: dense increment columns = T-term MSMs of 64-bit scalars against the SRS prefix (address 0),
@@ -588,9 +617,12 @@ class DeviceWorkload:
         out = {}
         if self.pcs:
             out["commit"] = self.commit()
-        if self.ext is not None:
-            out["extended"] = self.ext.prove(label)
-        out["stages"] = self.prove(label)
+        if self.ext is not None and self._stage_worker is not None:
+            out["extended"], out["stages"] = self.prove_stages(label)
+        else:
+            if self.ext is not None:
+                out["extended"] = self.ext.prove(label)
+            out["stages"] = self.prove(label)
         if self.pcs:
             out["open"] = self.open(label)
         return out
@@ -606,6 +638,12 @@ class DeviceWorkload:
         if self.ext is not None:
             self.ext.close()
             self.ext = None
+        if self._stage_worker is not None:
+            self._stage_worker.shutdown(wait=True)
+            self._stage_worker = None
+        if self.ext_ctx is not None:
+            self.ext_ctx.close()
+            self.ext_ctx = None
         for s in self.sources.values():
             s.free()
         for v in self.ints.values():

@@ -169,6 +169,7 @@ extern "C" {
     pub fn jolt_ctx_destroy(ctx: *mut jolt_ctx) -> i32;
     pub fn jolt_ctx_synchronize(ctx: *mut jolt_ctx) -> i32;
     pub fn jolt_ctx_synchronize_foreground(ctx: *mut jolt_ctx) -> i32;
+    pub fn jolt_ctx_bind_thread(ctx: *mut jolt_ctx) -> i32;
     pub fn jolt_last_error(ctx: *const jolt_ctx) -> *const c_char;
     pub fn jolt_ctx_trim(ctx: *mut jolt_ctx) -> i32;
     pub fn jolt_ctx_memory_stats(ctx: *const jolt_ctx, live_bytes: *mut usize, cached_bytes: *mut usize, peak_bytes: *mut usize) -> i32;
