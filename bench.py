@@ -483,7 +483,7 @@ def main():
                                                              e.claims["product"], 1, TR | 3200)),
                         ("ram_read_write", lambda: e.ram_read_write(TR | 3300)), ("registers_read_write", lambda: e.registers_read_write(TR | 3350)),
                         ("instruction_read_raf", lambda: e.instruction_read_raf(TR | 3400)), ("booleanity_address", lambda: boo.update(e.booleanity_address(TR | 3450))),
-                        ("booleanity_cycle", lambda: e.booleanity_cycle(TR | 3460, boo["challenges"][::-1])),
+                        ("booleanity_cycle", lambda: e.booleanity_cycle(TR | 3460, boo["challenges"][::-1], boo["intermediate"])),
                         ("hamming_weight", lambda: e.hamming_weight(TR | 3470)), ("address_domain", lambda: e.address_domain(TR | 3500))]
         # "opening_hint_background": what is left of the class sums the commit leg began on the background stream once the commit itself has landed -- in the step
         # they run UNDER the stage operators and the sumcheck legs (and slow those down a little: the legs of this split, timed one by one, add up to more than the step)

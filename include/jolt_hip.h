@@ -967,7 +967,7 @@ int32_t jolt_stage_booleanity_address_create(jolt_ctx *ctx, const jolt_onehot *c
                                              const jolt_fr_t *gamma, jolt_stage_op **out);
 /* booleanity_cycle (optimized/booleanity.rs:436-690, stage 6b): eq(reference_cycle, j) eq(r_address, reference_address) sum_i (H_i(j)^2 - gamma^i H_i(j)) over the lazily bound
  * RA columns, H_i(j) = gamma^i eq(r_address, hot_i(j)); r_address = the address phase's bound point (log K coordinates, most significant first).  log T rounds of degree 3
- * (gruen_poly_deg_3 of the member's two sums); input_claim = the address phase's intermediate claim; output claims: the n_polys bound columns unscaled, ra_i(r_address, r_cycle). */
+ * (gruen_poly_deg_3 of the member's two sums); the input claim is the address phase's intermediate claim (the caller's; no input_claim helper); output claims: the n_polys bound columns unscaled, ra_i(r_address, r_cycle). */
 int32_t jolt_stage_booleanity_cycle_create(jolt_ctx *ctx, const jolt_onehot *cols, const jolt_fr_t *r_address, const jolt_fr_t *reference_address, const jolt_fr_t *reference_cycle,
                                            size_t n_cycle, const jolt_fr_t *gamma, jolt_stage_op **out);
 /* hamming_weight_claim_reduction (optimized/hamming_weight_claim_reduction.rs:83-300): virtualization_points = n_polys x log K.  output_claims: the bound G_i. */

@@ -357,6 +357,7 @@ struct BooleanityAddressOp final : jolt_stage_op {
 // ------------------------------------------------------------------------------------------------------------------
 struct BooleanityCycleOp final : jolt_stage_op {
     size_t n_polys = 0;
+    bool dense = false;  // fewer than four cycle variables: the same summand over materialised columns (the lazy form is index-encoded for four binds)
     std::vector<Fr> rho_inv;
     MemberH member;
 
@@ -368,19 +369,14 @@ struct BooleanityCycleOp final : jolt_stage_op {
         binds.push_back(bind);
         return member_finish(member.m, bind);
     }
-    int32_t input_claim(Fr* out) override {  // = the address phase's intermediate claim (BooleanityAddressPhaseOutputClaims::intermediate)
-        jolt_fr_t c;
-        JOLT_TRY(jolt_member_input_claim(member.m, &c));
-        *out = fr_from_abi(&c);
-        return JOLT_OK;
-    }
+    // (the input claim is the address phase's intermediate claim, BooleanityAddressPhaseOutputClaims::intermediate: the caller holds it; a wrong one fails the first round check)
     int32_t output_claims(std::vector<Fr>* out) override {
         if (binds.size() != rounds) return JOLT_ERR_NOT_FULLY_BOUND;
         std::vector<Fr> fin;
-        JOLT_TRY(member_finals(member.m, n_polys + 1, &fin));  // the bound H_i, then the split-eq scalar (the fully bound EqAddressCycle, validate_derived_tables :666-680)
+        JOLT_TRY(member_finals(member.m, n_polys + 1, &fin));  // the bound H_i and the eq scalar (the fully bound EqAddressCycle, validate_derived_tables :666-680): last (lazy) or first (dense)
         out->resize(n_polys);
-        for (size_t i = 0; i < n_polys; ++i) (*out)[i] = mul(fin[i], rho_inv[i]);
-        kept["eq_scalar"] = {fin[n_polys]};
+        for (size_t i = 0; i < n_polys; ++i) (*out)[i] = mul(fin[dense ? 1 + i : i], rho_inv[i]);
+        kept["eq_scalar"] = {fin[dense ? 0 : n_polys]};
         return JOLT_OK;
     }
 };
@@ -1014,7 +1010,27 @@ extern "C" int32_t jolt_stage_booleanity_cycle_create(jolt_ctx* ctx, const jolt_
     }
     jolt_fr_t sc;
     fr_to_abi(&sc, scalar);
-    JOLT_TRY(jolt_member_create_lazy_booleanity(ctx, cols, tables.data(), rho.data(), reference_cycle, n_cycle, &sc, &op->member.m));
+    if (n_cycle < 4) {
+        op->dense = true;
+        std::vector<TableH> tabs;
+        jolt_table* eqt = nullptr;
+        JOLT_TRY(jolt_eq_evals(ctx, reference_cycle, n_cycle, &sc, &eqt));
+        tabs.emplace_back(ctx, eqt);
+        std::vector<std::pair<Fr, std::vector<uint32_t>>> terms;
+        for (size_t i = 0; i < op->n_polys; ++i) {
+            TableH scale;
+            JOLT_TRY(fr_table(ctx, &tables[i * K], K, &scale));
+            jolt_table* col = nullptr;
+            JOLT_TRY(jolt_onehot_materialize(ctx, cols, i, scale.t, &col));
+            tabs.emplace_back(ctx, col);
+            const uint32_t t = (uint32_t)(1 + i);
+            terms.push_back({Fr::one(), {0u, t, t}});
+            terms.push_back({neg(fr_from_abi(&rho[i])), {0u, t}});
+        }
+        JOLT_TRY(expr_member(ctx, tabs, terms, 3, &op->member));
+    } else {
+        JOLT_TRY(jolt_member_create_lazy_booleanity(ctx, cols, tables.data(), rho.data(), reference_cycle, n_cycle, &sc, &op->member.m));
+    }
     *out = hold.release();
     return JOLT_OK;
 }

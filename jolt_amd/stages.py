@@ -688,11 +688,11 @@ class DeviceExtended:
         op.destroy()
         return out
 
-    def booleanity_cycle(self, label, r_address):
-        """stage 6b after 6a: `r_address` = the address phase's bound point (its challenges, last first); the input claim is that phase's intermediate claim"""
+    def booleanity_cycle(self, label, r_address, claim):
+        """stage 6b after 6a: `r_address` = the address phase's bound point (its challenges, last first), `claim` = that phase's intermediate output claim (a wrong one
+        fails the batch's first round check)"""
         bo = self.d["booleanity"]
         op = self.ctx.stage_booleanity_cycle(self.bool_cols, r_address, bo["reference_address"], bo["reference_cycle"], bo["gamma"])
-        claim = op.input_claim()
         out = self._batch(op, claim, self.n_vars, 3, label)
         out["claim"] = claim
         out["ra_claims"] = op.output_claims()
@@ -803,7 +803,7 @@ class DeviceExtended:
         if stage == 6:
             booleanity_address = self.booleanity_address(label + 450)
             return {"bytecode_read_raf": self.bytecode_read_raf(label + 500), "booleanity_address": booleanity_address,
-                    "booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1])}
+                    "booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1], booleanity_address["intermediate"])}
         if stage == 7:
             return {"hamming_weight": self.hamming_weight(label + 470)}
         return {}

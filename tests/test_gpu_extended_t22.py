@@ -84,7 +84,7 @@ def test_pushforward_operators_at_benchmark_scale(pair):
     same(dev.hamming_weight(LABEL + 470), orc.hamming_weight(LABEL + 470), "hamming_weight")
     # stage 6b: the booleanity cycle phase over the same 36 lazily bound columns, 22 rounds, from the address phase's bound point
     r_address = got["challenges"][::-1]
-    cyc, cyc_want = dev.booleanity_cycle(LABEL + 460, r_address), orc.booleanity_cycle(LABEL + 460, r_address)
+    cyc, cyc_want = dev.booleanity_cycle(LABEL + 460, r_address, got["intermediate"]), orc.booleanity_cycle(LABEL + 460, r_address)
     same(cyc, cyc_want, "booleanity_cycle")
     assert np.array_equal(cyc["claim"], got["intermediate"])
 
