@@ -571,7 +571,9 @@ class DeviceOps:
 class DeviceExtended:
     def __init__(self, ctx, n_vars, seed=2026, description=None, **kw):
         from . import ffi
-        self.ctx, self.ffi, self.n_vars = ctx, ffi, n_vars
+        import threading
+        self._home_ctx, self._tls = ctx, threading.local()  # `self.ctx`: the calling thread's context (bind_context), the home context otherwise
+        self.ffi, self.n_vars = ffi, n_vars
         self.d = d = description if description is not None else build_extended(n_vars, seed, **kw)  # description: a prebuilt build_extended(n_vars, ...)
         self.one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
@@ -636,6 +638,14 @@ class DeviceExtended:
             t.free()
         self.claims["lookup"] = None  # taken from the first proof's first address message (same every proof)
         ctx.synchronize()
+
+    @property
+    def ctx(self):
+        return getattr(self._tls, "ctx", None) or self._home_ctx
+
+    def bind_context(self, ctx):
+        """operators the CALLING thread creates from now on live on `ctx` (its stream, scratch and pool); the resident inputs stay where they are and are only read"""
+        self._tls.ctx = ctx
 
     # ---- the operators: each one a jolt_stage_op (csrc/stage_ops.hip) -- created (= the slot's PrepareKernel::prepare), driven through the ProveRounds contract by a
     # ---- driver of the library (prove_batch over operators, or alone against a test transcript), asked for its output claims, destroyed.  Nothing else happens here.
@@ -787,26 +797,36 @@ class DeviceExtended:
     # of the cycle-domain catalogue (own context, own host thread), never across a stage boundary.
     STAGES = (1, 2, 4, 5, 6, 7)
 
-    def prove_stage(self, stage, label=0):
+    def stage_chains(self, stage, label=0):
+        """the operators of one protocol stage as independent CHAINS: [(slot, fn)] -- fn() -> {name: output}; chains of a stage share no challenge and may run at the same
+        time on different contexts (slot 0: the home context, which owns the read-RAF rows' mutable order buffers; slot 1: a second one).  Inside a chain the order matters
+        (the booleanity cycle phase starts from the address phase's bound point and claim)."""
         d = self.d
         if stage == 1:
-            return {"spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
-                                                  self.claims["outer"], 2, label + 100)}
+            return [(0, lambda: {"spartan_outer": self.spartan(self.outer_ints, d["outer_iwa"], d["outer_iwb"], d["outer_wa"], d["outer_wb"], d["outer_tau"], d["outer_kernel"],
+                                                               self.claims["outer"], 2, label + 100)})]
         if stage == 2:
-            return {"spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"], d["product_kernel"],
-                                                    self.claims["product"], 1, label + 200),
-                    "ram_read_write": self.ram_read_write(label + 300), **self.ram_address_domain(label + 500)}
+            return [(0, lambda: {"ram_read_write": self.ram_read_write(label + 300)}),
+                    (1, lambda: {"spartan_product": self.spartan(self.product_ints, self.product_ia, self.product_ib, self.product_fa, self.product_fb, d["product_tau"],
+                                                                 d["product_kernel"], self.claims["product"], 1, label + 200), **self.ram_address_domain(label + 500)})]
         if stage == 4:
-            return {"registers_read_write": self.registers_read_write(label + 350)}
+            return [(0, lambda: {"registers_read_write": self.registers_read_write(label + 350)})]
         if stage == 5:
-            return {"instruction_read_raf": self.instruction_read_raf(label + 400)}
+            return [(0, lambda: {"instruction_read_raf": self.instruction_read_raf(label + 400)})]
         if stage == 6:
-            booleanity_address = self.booleanity_address(label + 450)
-            return {"bytecode_read_raf": self.bytecode_read_raf(label + 500), "booleanity_address": booleanity_address,
-                    "booleanity_cycle": self.booleanity_cycle(label + 460, booleanity_address["challenges"][::-1], booleanity_address["intermediate"])}
+            def booleanity():
+                address = self.booleanity_address(label + 450)
+                return {"booleanity_address": address, "booleanity_cycle": self.booleanity_cycle(label + 460, address["challenges"][::-1], address["intermediate"])}
+            return [(0, lambda: {"bytecode_read_raf": self.bytecode_read_raf(label + 500)}), (1, booleanity)]
         if stage == 7:
-            return {"hamming_weight": self.hamming_weight(label + 470)}
-        return {}
+            return [(0, lambda: {"hamming_weight": self.hamming_weight(label + 470)})]
+        return []
+
+    def prove_stage(self, stage, label=0):
+        out = {}
+        for _, chain in self.stage_chains(stage, label):
+            out.update(chain())
+        return out
 
     def prove(self, label=0):
         out = {}

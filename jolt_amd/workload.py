@@ -253,19 +253,24 @@ class DeviceWorkload:
         self._rows_in_flight = None
         # extended: the stage 1 / 2 / 5 operators that are not plain cycle-domain relations (Spartan outer / product, the sparse RAM read-write
         # matrix, the instruction read-RAF scans + cycle rounds: jolt_amd/stages.py) inside every step, over their own resident inputs
-        self.ext, self.ext_ctx, self._stage_worker = None, None, None
+        self.ext, self.ext_ctx, self._stage_worker, self._stage_slots = None, None, None, []
         if extended:
             import os
             from .stages import DeviceExtended
             # The stage operators live on THEIR OWN context (own stream, scratch and pool) and are driven from a worker thread, so that the operators of protocol stage k run
             # beside stage k's batched sumcheck of the catalogue -- the reference proves a stage's members as one batch; nothing crosses a stage boundary (prove_stages).
             # JOLT_STAGE_CONCURRENCY=0: one context, the operators and the catalogue one after the other (the structure of rounds 3 - 5, for an A/B).
+            # JOLT_STAGE_CONTEXTS (default 2): independent operator chains of one stage (RAM read-write beside the product remainder and the RAM address-domain relations;
+            # bytecode read+RAF beside the booleanity phases) each get a context and a thread.
             if os.environ.get("JOLT_STAGE_CONCURRENCY", "1") != "0":
                 from concurrent.futures import ThreadPoolExecutor
                 self.ext_ctx = ffi.Context(ctx.device_id)
-                self._stage_worker = ThreadPoolExecutor(max_workers=1)
-                self._stage_worker.submit(self.ext_ctx.bind_thread).result()
+                n_slots = max(1, min(2, int(os.environ.get("JOLT_STAGE_CONTEXTS", "2"))))
+                self._stage_slots = [(ThreadPoolExecutor(max_workers=1), self.ext_ctx if k == 0 else ffi.Context(ctx.device_id)) for k in range(n_slots)]
+                self._stage_worker = self._stage_slots[0][0]
             self.ext = DeviceExtended(self.ext_ctx or ctx, n_vars, seed, ram_addresses=ram_addresses)  # "hotset": a btreemap-like skewed RAM / register address stream
+            for pool, slot_ctx in self._stage_slots:
+                pool.submit(lambda c=slot_ctx: (c.bind_thread(), self.ext.bind_context(c))).result()
         self.tables_spec, self.members_spec, gammas = build(n_vars, seed, **kw)
         one = ffi.host_fr_from_u64(1)
         zero = np.zeros(4, dtype=np.uint64)
@@ -542,14 +547,23 @@ class DeviceWorkload:
         if not self.prepared:
             self.prepare()
         ext_out, outs = {}, {}
+        n_slots = len(self._stage_slots)
         for stage in sorted(set(self.stages) | set(self.ext.STAGES)):
-            pending = self._stage_worker.submit(self.ext.prove_stage, stage, label) if stage in self.ext.STAGES else None
+            pending = [self._stage_slots[slot % n_slots][0].submit(chain) for slot, chain in self.ext.stage_chains(stage, label)]  # (one slot: its chains queue up in order)
             try:
                 if stage in self.stages:
                     outs[stage] = self.prove_stage(stage, label)
             finally:
-                if pending is not None:
-                    ext_out.update(pending.result())
+                results = []
+                for f in pending:  # every chain is waited for, also when one of them (or the catalogue's batch) raised
+                    try:
+                        results.append(f.result())
+                    except Exception as e:  # noqa: BLE001 -- re-raised below
+                        results.append(e)
+            for r in results:
+                if isinstance(r, Exception):
+                    raise r
+                ext_out.update(r)
         for m in self.members:
             m.reset()
         return ext_out, outs
@@ -638,9 +652,11 @@ class DeviceWorkload:
         if self.ext is not None:
             self.ext.close()
             self.ext = None
-        if self._stage_worker is not None:
-            self._stage_worker.shutdown(wait=True)
-            self._stage_worker = None
+        for pool, slot_ctx in self._stage_slots:
+            pool.shutdown(wait=True)
+            if slot_ctx is not self.ext_ctx:
+                slot_ctx.close()
+        self._stage_slots, self._stage_worker = [], None
         if self.ext_ctx is not None:
             self.ext_ctx.close()
             self.ext_ctx = None
