@@ -4,10 +4,11 @@
 # header comment copy the judged summaries into profiles/r06_*.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r06
+TAG=${1:-r06}
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-bash tools/collect_round.sh r06 2>&1 | tail -60
+bash tools/collect_round.sh $TAG 2>&1 | tail -60
 # rocprofv3's OWN --kernel-trace --stats tables (csv) of the bind roofline command and of one 2^26-term MSM (what roofline_msm runs)
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p_st1 /tmp/p_st2
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_st1 -o bind -- python "$ROOT/bench.py" --roofline-only > "$OUT/bind_roofline_bench_stats_run.json" 2> "$OUT/bind_stats.err"
