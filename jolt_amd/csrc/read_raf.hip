@@ -105,8 +105,18 @@ __device__ __forceinline__ Fr small_value(const SmallAcc& acc) { return mul(smal
 // Work items.  Lookup indices are skewed (small operands, zero, all-ones: a third of a real trace's rows can share one chunk value), so a
 // bin is cut into items of kRafSegRows rows, one wavefront each; partial sums are folded per bin afterwards.  (One wavefront per BIN took as
 // long as the fullest bin: 9 ms per phase on a trace with 12 % zero indices where uniform indices take 1.3 ms.)
-constexpr uint32_t kRafSegRows = 1024;
-__global__ __launch_bounds__(1024) void k_rr_segments(const uint32_t* __restrict__ hist, uint32_t n_bins, uint32_t* __restrict__ seg_start) {
+constexpr uint32_t kRafSegRowsDefault = 1024;
+// rows per work item (a power of two, 64 .. 4096): JOLT_RAF_SEG_ROWS, for the A/B of shorter per-lane chains against more partial sums to fold
+static uint32_t raf_seg_rows() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("JOLT_RAF_SEG_ROWS");
+        uint32_t r = e ? (uint32_t)std::atoi(e) : kRafSegRowsDefault;
+        if (r < 64 || r > 4096 || (r & (r - 1))) r = kRafSegRowsDefault;
+        return r;
+    }();
+    return v;
+}
+__global__ __launch_bounds__(1024) void k_rr_segments(const uint32_t* __restrict__ hist, uint32_t n_bins, uint32_t kRafSegRows, uint32_t* __restrict__ seg_start) {
     __shared__ uint32_t sm[1024];
     const uint32_t per = (n_bins + 1023) / 1024, lo = min(threadIdx.x * per, n_bins), hi = min(lo + per, n_bins);
     uint32_t local = 0;
@@ -151,7 +161,7 @@ template <bool GATHERED>
 __global__ __launch_bounds__(kBlock) void k_rr_accumulate(const uint64_t* __restrict__ index /* in bin order */, const uint8_t* __restrict__ raf /* in bin order */,
                                                           const Fr* __restrict__ u /* in bin order */, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                           uint32_t n_tables, uint32_t suffix_len, uint32_t upper_suffix_bits, int canonical,
-                                                          const uint32_t* __restrict__ cfg, const uint32_t* __restrict__ seg_start, uint32_t slots, Fr* __restrict__ part) {
+                                                          const uint32_t* __restrict__ cfg, const uint32_t* __restrict__ seg_start, uint32_t slots, uint32_t kRafSegRows, Fr* __restrict__ part) {
     const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64);
     const uint32_t n_bins = (n_tables + 1) * kRafChunk, n_items = seg_start[n_bins];
     for (uint32_t item = wave; item < n_items; item += n_waves) {
@@ -391,6 +401,7 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
     uint32_t max_suffixes = 0;
     for (uint32_t t = 0; t < n_tables; ++t) max_suffixes = std::max(max_suffixes, suffix_offsets[t + 1] - suffix_offsets[t]);
     const uint32_t slots = kRafSums + max_suffixes;
+    const uint32_t kRafSegRows = raf_seg_rows();
     const size_t max_items = rr->cycles / kRafSegRows + (size_t)(n_tables + 1) * kRafChunk + 1;
     if (max_items * slots > rr->part_cap) {
         if (rr->part) { JOLT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); JOLT_HIP_TRY(ctx, hipFree(rr->part)); rr->part = nullptr; }
@@ -418,7 +429,7 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
         hipLaunchKernelGGL(k_msm_hist_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)o.keys, T, B, o.hist);
         hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(kBlock), 0, st, (const uint32_t*)o.hist, o.offs, o.cursor, B, 0x7FFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
         hipLaunchKernelGGL(k_msm_scatter_lds, dim3(slices, 1), dim3(kSortBlock), lds, st, (const uint32_t*)o.keys, T, B, o.cursor, o.sorted);
-        hipLaunchKernelGGL(k_rr_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)o.hist, B, o.seg_start);
+        hipLaunchKernelGGL(k_rr_segments, dim3(1), dim3(1024), 0, st, (const uint32_t*)o.hist, B, raf_seg_rows(), o.seg_start);
         if (gathered)
             hipLaunchKernelGGL(k_rr_gather_rows, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)o.sorted, T, (const uint64_t*)rr->index,
                                (const uint8_t*)rr->raf, o.index_sorted, o.raf_sorted);
@@ -451,11 +462,11 @@ extern "C" int32_t jolt_read_raf_phase_scan(jolt_ctx* ctx, jolt_read_raf* rr, co
         hipLaunchKernelGGL(k_rr_gather_u, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const uint32_t*)o.sorted, T, (const Fr*)u->data(), rr->u_sorted);
         hipLaunchKernelGGL(k_rr_accumulate<true>, dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)o.index_sorted, (const uint8_t*)o.raf_sorted, (const Fr*)rr->u_sorted,
                            (const uint32_t*)o.sorted, (const uint32_t*)o.hist, (const uint32_t*)o.offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
-                           (const uint32_t*)o.seg_start, slots, rr->part);
+                           (const uint32_t*)o.seg_start, slots, kRafSegRows, rr->part);
     } else {
         hipLaunchKernelGGL(k_rr_accumulate<false>, dim3(grid), dim3(kBlock), 0, st, (const uint64_t*)rr->index, (const uint8_t*)rr->raf, (const Fr*)u->data(),
                            (const uint32_t*)o.sorted, (const uint32_t*)o.hist, (const uint32_t*)o.offs, n_tables, suffix_len, upper_suffix_bits, (int)canonical, (const uint32_t*)rr->d_cfg,
-                           (const uint32_t*)o.seg_start, slots, rr->part);
+                           (const uint32_t*)o.seg_start, slots, kRafSegRows, rr->part);
     }
     hipLaunchKernelGGL(k_rr_fold_items, dim3((unsigned)(((size_t)B * slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (const Fr*)rr->part, (const uint32_t*)o.seg_start, n_tables,
                        slots, (const uint32_t*)rr->d_cfg, rr->bin_raf, rr->d_suffix);
