@@ -193,3 +193,39 @@ def test_rows_handle_is_refused_before_its_copy_has_been_waited_for():
     rows.free()
     buf.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("n_vars,contexts", [(9, "2"), (16, "2"), (12, "1")])
+def test_concurrent_stages_prove_what_the_serial_order_proves(n_vars, contexts, monkeypatch):
+    """DeviceWorkload.step runs, per protocol stage, the stage operators on their own contexts and host threads beside the stage's batched sumcheck (prove_stages): every
+    operator's transcript and claims and every catalogue stage must be what the operators one after the other on ONE context (DeviceExtended.prove) and the catalogue
+    alone (DeviceWorkload.prove) produce -- three times over, so that a race between the contexts would have three chances to show"""
+    from jolt_amd.stages import DeviceExtended
+    from test_gpu_extended import same
+    monkeypatch.setenv("JOLT_STAGE_CONTEXTS", contexts)
+    ctx = ffi.Context(0)
+    serial_ext = DeviceExtended(ctx, n_vars, seed=31)
+    want_ext = serial_ext.prove(label=ffi.TRANSCRIPT_BLAKE2B | 60)
+    serial_ext.close()
+    plain = DeviceWorkload(ctx, n_vars, seed=31)
+    want = plain.prove(label=ffi.TRANSCRIPT_BLAKE2B | 60)
+    plain.close()
+    wl = DeviceWorkload(ctx, n_vars, seed=31, extended=True)
+    assert wl._stage_worker is not None and len(wl._stage_slots) == int(contexts)
+    for rep in range(3):
+        out = wl.step(label=ffi.TRANSCRIPT_BLAKE2B | 60)
+        assert set(out["extended"]) == set(want_ext)
+        for name in want_ext:
+            same(out["extended"][name], want_ext[name], f"rep {rep} {name}")
+        for stage in want:
+            for key in ("polys", "challenges", "final_claim"):
+                assert np.array_equal(out["stages"][stage][key], want[stage][key]), (rep, stage, key)
+    wl.close()
+    monkeypatch.setenv("JOLT_STAGE_CONCURRENCY", "0")
+    serial = DeviceWorkload(ctx, n_vars, seed=31, extended=True)
+    assert serial._stage_worker is None and serial.ext_ctx is None
+    out = serial.step(label=ffi.TRANSCRIPT_BLAKE2B | 60)
+    for name in want_ext:
+        same(out["extended"][name], want_ext[name], f"serial {name}")
+    serial.close()
+    ctx.close()
