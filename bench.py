@@ -534,7 +534,7 @@ def main():
         bc_log_k = the_ext.d["bytecode"]["log_k"] if hasattr(the_ext, "d") else the_ext.p["bytecode"]["log_k"]
         ext_note = (f"runs the stage 1 / 2 / 4 / 5 / 6a / 6b / 7 operators outside the cycle-domain catalogue -- Spartan outer (uni-skip sums off 35 integer columns, Az / Bz, log T + 1 "
                     f"remainder rounds, claimed inputs), Spartan product (the same over the 6 product lanes), the sparse RAM read-write matrix (K = 2^{ram['log_k']}, "
-                    f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and instruction read-RAF checking end to end over the 42 lookup tables (per address phase the T-scale scans on the device and the 8 rounds over 256-entry prefix / suffix polynomials on the host, 128 address rounds in all, then log T cycle rounds), the booleanity address phase and the Hamming-weight claim reduction (pushforward masses of the 36 RA columns + log K host rounds each), and the address-domain relations -- bytecode read+RAF (five per-stage "
+                    f"log T + log K rounds), registers read-write checking (<= 3 cells per cycle over 128 registers, log T + 7 rounds, operand claims) and instruction read-RAF checking end to end over the 42 lookup tables (per address phase the T-scale scans on the device and the 8 rounds over 256-entry prefix / suffix polynomials on the host, 128 address rounds in all, then log T cycle rounds), the booleanity address phase and the Hamming-weight claim reduction (pushforward masses of the 36 RA columns + log K host rounds each), the booleanity cycle phase (the 36 columns lazily bound, log T rounds; N = 1 only), and the address-domain relations -- bytecode read+RAF (five per-stage "
                     f"pushforwards onto the 2^{bc_log_k}-entry bytecode domain + log K rounds, then C * prod ra_i over log T rounds), RAM RAF evaluation and the RAM output check "
                     f"(pushforward / final-memory column over a sorted index of the address column + log K rounds each)"
                     + (f" (ONE trace of {world} x 2^{args.scale} cycles dealt to the ranks in blocks: additive scans and pushforwards summed over the ranks, cycle-domain "
