@@ -116,3 +116,56 @@ def test_contract_errors():
     with pytest.raises(ffi.JoltError):
         ffi.stage_host_expr(tabs, [(terms[0][0], [0, 5])], 2)  # a factor that names no table
     op.destroy()
+
+
+@pytest.mark.parametrize("kind", [ffi.TRANSCRIPT_BLAKE2B, ffi.TRANSCRIPT_KECCAK, ffi.TRANSCRIPT_BLAKE2B_SPONGE])
+def test_a_batch_under_the_reference_transcripts_is_the_oracle_batch(kind):
+    """prove_batch over operators with the engine in the label's two top bits (LegacyBlake2bTranscript, KeccakTranscript, the Blake2b512 sponge): the library's C++ transcripts
+    and the oracle's C ones draw the same challenges from the same messages -- and not the test transcript's"""
+    a, b = members(21, 6, [[0, 1], [2, 3]]), members(22, 4, [[0, 1, 2]])
+    ops, orcs = [a[0], b[0]], [a[1], b[1]]
+    claims = [o.input_claim() for o in ops]
+    coeffs = rand_fr(2, 77)
+    want = O.prove_batch(orcs, claims, coeffs, [0, 2], 6, 3, label=kind | 5)
+    got = ffi.prove_batch_ops(ops, claims, coeffs, [0, 2], 6, 3, label=kind | 5)
+    for key in ("polys", "challenges", "member_claims", "final_claim"):
+        assert np.array_equal(got[key], want[key]), key
+    for o in ops:
+        o.destroy()
+    ops = [members(21, 6, [[0, 1], [2, 3]])[0], members(22, 4, [[0, 1, 2]])[0]]
+    other = ffi.prove_batch_ops(ops, claims, coeffs, [0, 2], 6, 3, label=5)
+    assert not np.array_equal(other["challenges"], got["challenges"])
+    for o in ops:
+        o.destroy()
+
+
+def test_a_host_proof_replays_under_a_hashlib_verifier():
+    """the bytes the reference's verifier reads (crates/jolt-sumcheck/src/recorder.rs:118-130, round_proof.rs:129-143, crates/jolt-transcript/src/digest.rs:84-189): from the
+    compressed round polynomials and the claimed sum alone, a verifier written here over hashlib.blake2b recovers each linear coefficient, absorbs
+    LabelWithCount("sumcheck_poly", d) + d big-endian coefficients, squeezes the 125-bit challenge, and arrives at the prover's challenges and final claim -- no GPU"""
+    import hashlib
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    to_int = lambda x: int.from_bytes(O.fr_to_bytes_le(x), "little")
+    op, _, degree, _, _ = members(31, 7, [[0, 1, 2], [3]])
+    claim0 = op.input_claim()
+    coeff = rand_fr(1, 5)[0]
+    label = ffi.TRANSCRIPT_BLAKE2B | 4242
+    out = ffi.prove_batch_ops([op], [claim0], [coeff], [0], 7, degree, label=label)
+    op.destroy()
+    claim = to_int(coeff) * to_int(claim0) % R
+    state, n_rounds = hashlib.blake2b(b"jolt-amd/4242".ljust(32, b"\0"), digest_size=32).digest(), 0
+    inv_r = pow(2**256, -1, R)
+    for r in range(7):
+        coeffs = [to_int(c) for c in out["polys"][r]]
+        while len(coeffs) > 2 and coeffs[-1] == 0:
+            coeffs.pop()
+        stored = [coeffs[0]] + coeffs[2:]
+        assert (claim - 2 * stored[0] - sum(stored[1:])) % R == coeffs[1], r
+        for payload in [b"sumcheck_poly".ljust(24, b"\0") + len(stored).to_bytes(8, "big")] + [c.to_bytes(32, "big") for c in stored]:
+            state, n_rounds = hashlib.blake2b(state + bytes(28) + n_rounds.to_bytes(4, "big") + payload, digest_size=32).digest(), n_rounds + 1
+        state, n_rounds = hashlib.blake2b(state + bytes(28) + n_rounds.to_bytes(4, "big"), digest_size=32).digest(), n_rounds + 1
+        v = int.from_bytes(state[:16], "little")
+        challenge = (((v & (2**64 - 1)) << 128) | (((v >> 64) & (2**61 - 1)) << 192)) * inv_r % R
+        assert challenge == to_int(out["challenges"][r]), r
+        claim = sum(c * pow(challenge, k, R) for k, c in enumerate(coeffs)) % R
+    assert claim == to_int(out["final_claim"])
