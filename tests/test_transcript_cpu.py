@@ -180,3 +180,42 @@ def test_transcript_entry_points_refuse_bad_arguments():
         t.append_label(b"y" * 25, 1)
     with pytest.raises(Exception):
         t.append(np.full((1, 4), 2**64 - 1, dtype=np.uint64))  # not canonical
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3])
+@pytest.mark.parametrize("side", ["oracle", "product"])
+def test_the_references_transcript_property_tests(kind, side):
+    """crates/jolt-transcript/tests/common/mod.rs:24-175 (`transcript_tests!`, instantiated there for every engine) re-run on both implementations: determinism, domain
+    separation by label, unique successive challenges, appends change the state, order and data sensitivity, an EMPTY append changes the state (and does so
+    reproducibly), large data, a 32-byte label is accepted and a 33-byte one refused, challenge vectors are distinct"""
+    if side == "oracle":
+        new = lambda label: O.MockTranscript(label, kind=kind)
+        app = lambda t, b: t.append_bytes(b)
+    else:
+        new = lambda label: ffi.HostTranscript(label, kind=kind)
+        app = lambda t, b: t.append_bytes(b)
+    ch = lambda t: fr_int(t.challenge())
+
+    def after(label, *chunks):
+        t = new(label)
+        for c in chunks:
+            app(t, c)
+        return ch(t)
+
+    assert after(b"test", b"hello") == after(b"test", b"hello")  # test_determinism
+    assert after(b"label_a") != after(b"label_b")  # test_domain_separation
+    t = new(b"test")
+    seen = [ch(t) for _ in range(100)]
+    assert len(set(seen)) == 100  # test_challenge_uniqueness
+    assert after(b"test") != after(b"test", b"data")  # test_append_changes_state
+    assert after(b"test", b"a", b"b") != after(b"test", b"b", b"a")  # test_order_matters
+    assert after(b"test", b"data1") != after(b"test", b"data2")  # test_data_sensitivity
+    assert after(b"test", b"") != after(b"test")  # test_empty_bytes: the framing absorbs a length / a round word even for no payload
+    assert after(b"test", b"") == after(b"test", b"")
+    assert after(b"test", bytes(range(256)) * 40) == after(b"test", bytes(range(256)) * 40)  # test_large_data
+    assert after(b"ab", b"c") != after(b"a", b"bc")
+    assert after(b"x" * 32) == after(b"x" * 32)  # test_max_valid_label
+    with pytest.raises(Exception):
+        new(b"x" * 33)  # test_label_too_long (the reference panics; here an error status)
+    t = new(b"test")
+    assert len({ch(t) for _ in range(5)}) == 5  # test_challenge_vector
