@@ -336,6 +336,10 @@ int32_t jolt_internal_ensure_scratch(jolt_ctx* ctx, size_t partials, size_t resu
     return JOLT_OK;
 }
 
+static bool bool_lds_on() {
+    static const bool on = !(std::getenv("JOLT_BOOL_LDS") && std::atoi(std::getenv("JOLT_BOOL_LDS")) == 0);
+    return on;
+}
 // LDS bytes of one product group's branch tables (k_split_eq_uniform_lazy_lds): F polynomials x width x (K + 1) entries
 constexpr size_t kLazyLdsMax = 48 * 1024;
 static inline size_t lazy_lds_bytes(const jolt_member* m) {
@@ -1515,7 +1519,8 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
     struct Item {
         size_t ne, slot;
         bool fused = false, tail = false, done = false, rows_major = false, small = false;
-        uint32_t lds_blocks = 0;   // > 0: k_split_eq_uniform_lazy_lds with this many workgroups per product group
+        uint32_t lds_blocks = 0;   // > 0: k_split_eq_uniform_lazy_lds with this many workgroups per product group (booleanity: per column group)
+        uint32_t bool_cols = 0;    // > 0: k_split_eq_booleanity_lds with this many columns per group
         Fr r;                      // challenge of the fused bind
         std::vector<const Fr*> in; // table pointers the round kernel reads
         std::vector<Fr*> out;      // fused: where the bound tables go
@@ -1678,6 +1683,18 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
             items[i].lds_blocks = (uint32_t)std::max<size_t>(1, (size_t)round_grid(ctx, (members[i]->len / 2) * members[i]->uni_V) / members[i]->uni_V);
             items[i].grid = (int)(items[i].lds_blocks * members[i]->uni_V);
         }
+        // the booleanity member's index-encoded rounds: column groups with their branch tables in LDS (k_split_eq_booleanity_lds; JOLT_BOOL_LDS=0: global gathers)
+        if (members[i]->kind == jolt_member::kSplitEqBooleanity && members[i]->lazy_width >= 1 && members[i]->lazy_width <= 8 && members[i]->onehot && !members[i]->onehot->wide &&
+            ctx->lazy_lds && bool_lds_on()) {
+            const size_t per_col = (size_t)members[i]->lazy_width * ((size_t)members[i]->onehot->k + 1) * sizeof(Fr), n_cols = members[i]->tables.size();
+            const size_t cpg = std::min(n_cols, kLazyLdsMax / per_col);
+            if (cpg >= 1) {
+                const size_t groups = (n_cols + cpg - 1) / cpg;
+                items[i].bool_cols = (uint32_t)((n_cols + groups - 1) / groups);  // even groups
+                items[i].lds_blocks = (uint32_t)std::max<size_t>(1, (size_t)round_grid(ctx, (members[i]->len / 2) * groups) / groups);
+                items[i].grid = (int)(items[i].lds_blocks * groups);
+            }
+        }
         items[i].part_off = (uint32_t)part_total;
         part_total += (size_t)items[i].grid * items[i].ne;
     }
@@ -1813,7 +1830,10 @@ static int32_t group_enqueue(jolt_ctx* ctx, jolt_member* const* members, size_t 
         const Fr* e_out = m->e_out_cache[m->e_out_bits]->data();
         const Fr* e_in = m->e_in_cache[m->e_in_bits]->data();
         hipStream_t bst = next_stream();
-        if (m->lazy_width)
+        if (m->lazy_width && it.bool_cols)
+            hipLaunchKernelGGL(k_split_eq_booleanity_lds, dim3(it.grid), dim3(kBlock), (size_t)it.bool_cols * m->lazy_width * ((size_t)m->onehot->k + 1) * sizeof(Fr), bst, ba,
+                               it.bool_cols, it.lds_blocks, e_out, e_in, (int)m->e_in_bits, m->len / 2, ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
+        else if (m->lazy_width)
             hipLaunchKernelGGL(k_split_eq_booleanity<true>, dim3(it.grid), dim3(kBlock), 0, bst, ba, e_out, e_in, (int)m->e_in_bits, m->len / 2,
                                ctx->d_partials + it.part_off, (uint32_t)i, (uint32_t)it.slot, rd);
         else

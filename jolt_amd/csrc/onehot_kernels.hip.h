@@ -311,6 +311,56 @@ static __global__ __launch_bounds__(kBlock) void k_split_eq_booleanity(Booleanit
     finish_member(partials, 2, ticket, slot, rd);
 }
 
+// The index-encoded rounds of the same member with the branch tables in LDS (round 6, second session): n columns x width x K entries spill the 32 KiB L1 from the
+// second lazy round on (36 columns of K = 16: 18 / 36 / 72 / 144 KiB), and every 32-byte lookup then costs an L2 line.  The columns are dealt to `col_groups` groups of
+// workgroups, `cols_per_group` columns each (their tables, one zero entry per row for the cold index: <= 48 KiB); the summand is a SUM over columns, so the groups' partial
+// sums simply add.  blockIdx.x = group * blocks_per_group + block within the group; the 2 * width index bytes of a pair are one aligned load.
+static __global__ __launch_bounds__(kBlock) void k_split_eq_booleanity_lds(BooleanityArgs a, uint32_t cols_per_group, uint32_t blocks_per_group, const Fr* __restrict__ e_out,
+                                                                           const Fr* __restrict__ e_in, int in_bits, size_t rows, Fr* __restrict__ partials, uint32_t ticket,
+                                                                           uint32_t slot, RoundDone rd) {
+    extern __shared__ uint4 bool_lds_raw[];
+    Fr* tab = reinterpret_cast<Fr*>(bool_lds_raw);
+    const uint32_t g = blockIdx.x / blocks_per_group, bx = blockIdx.x - g * blocks_per_group;
+    const uint32_t c0 = g * cols_per_group, nc = min(cols_per_group, (uint32_t)a.n - c0);
+    const uint32_t KP = a.K + 1, per_col_lds = a.width * KP, per_col = a.width * a.K;
+    for (uint32_t e = threadIdx.x; e < nc * per_col_lds; e += kBlock) {
+        const uint32_t k = e / per_col_lds, r = e - k * per_col_lds, off = r / KP, entry = r - off * KP;
+        tab[e] = entry < a.K ? ld_fr(a.branch + (size_t)(c0 + k) * per_col + (size_t)off * a.K + entry) : Fr::zero();
+    }
+    __syncthreads();
+    Fr acc[2] = {Fr::zero(), Fr::zero()};
+    const size_t mask = ((size_t)1 << in_bits) - 1;
+    const uint32_t width = a.width;
+    for (size_t row = (size_t)bx * kBlock + threadIdx.x; row < rows; row += (size_t)blocks_per_group * kBlock) {
+        Fr constant = Fr::zero(), leading = Fr::zero();
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint8_t* col = a.idx + (size_t)(c0 + k) * a.cycles0 + 2 * row * width;  // lo: bytes [0, width), hi: [width, 2 width)
+            uint64_t b_lo, b_hi;
+            if (width == 8) { uint4 q = *reinterpret_cast<const uint4*>(col); b_lo = (uint64_t)q.x | ((uint64_t)q.y << 32); b_hi = (uint64_t)q.z | ((uint64_t)q.w << 32); }
+            else if (width == 4) { uint2 q = *reinterpret_cast<const uint2*>(col); b_lo = q.x; b_hi = q.y; }
+            else if (width == 2) { uint32_t q = *reinterpret_cast<const uint32_t*>(col); b_lo = q & 0xFFFFu; b_hi = q >> 16; }
+            else { uint32_t q = *reinterpret_cast<const uint16_t*>(col); b_lo = q & 0xFFu; b_hi = q >> 8; }
+            const Fr* tk = tab + k * per_col_lds;
+            Fr h0 = Fr::zero(), h1 = Fr::zero();
+            for (uint32_t off = 0; off < width; ++off) {
+                uint32_t i0 = (uint32_t)(b_lo >> (8 * off)) & 0xFFu, i1 = (uint32_t)(b_hi >> (8 * off)) & 0xFFu;
+                i0 = i0 == kOneHotCold ? a.K : i0;
+                i1 = i1 == kOneHotCold ? a.K : i1;
+                h0 = add(h0, tk[off * KP + i0]);
+                h1 = add(h1, tk[off * KP + i1]);
+            }
+            const Fr delta = sub(h1, h0);
+            constant = add(constant, mul(h0, sub(h0, a.rho[c0 + k])));
+            leading = add(leading, sqr(delta));
+        }
+        const Fr w = mul(ld_fr(e_out + (row >> in_bits)), ld_fr(e_in + (row & mask)));
+        acc[0] = add(acc[0], mul(w, constant));
+        acc[1] = add(acc[1], mul(w, leading));
+    }
+    block_reduce_store<2>(acc, partials);
+    finish_member(partials, 2, ticket, slot, rd);
+}
+
 // row-major form (uniform_rows_body): one item per pair, the V products inside; used while a round has enough pairs to fill the chip
 template <int F>
 static __global__ __launch_bounds__(kBlock) void k_split_eq_uniform_lazy_rows(LazyArgs a, const Fr* __restrict__ e_out, const Fr* __restrict__ e_in, int in_bits,
