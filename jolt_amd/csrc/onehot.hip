@@ -113,8 +113,11 @@ extern "C" int32_t jolt_onehot_pushforward(jolt_ctx* ctx, const jolt_onehot* s, 
     else
         hipLaunchKernelGGL(k_onehot_pushforward, dim3(nblocks, (unsigned)s->n_polys), dim3(kBlock), s->k * sizeof(Fr), ctx->stream, (const uint8_t*)s->idx, s->wide,
                            (const Fr*)weights->data(), s->cycles, s->k, ctx->d_partials);
-    hipLaunchKernelGGL(k_onehot_pushforward_reduce, dim3((s->k + kBlock - 1) / kBlock, (unsigned)s->n_polys), dim3(kBlock), 0, ctx->stream,
-                       (const Fr*)ctx->d_partials, nblocks, s->k, t->data());
+    if (s->k <= (uint32_t)kBlock && nblocks >= 8)
+        hipLaunchKernelGGL(k_onehot_pushforward_reduce_split, dim3((unsigned)s->n_polys), dim3(kBlock), 0, ctx->stream, (const Fr*)ctx->d_partials, nblocks, s->k, t->data());
+    else
+        hipLaunchKernelGGL(k_onehot_pushforward_reduce, dim3((s->k + kBlock - 1) / kBlock, (unsigned)s->n_polys), dim3(kBlock), 0, ctx->stream,
+                           (const Fr*)ctx->d_partials, nblocks, s->k, t->data());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { jolt_table_free(ctx, t); ctx->last_error = hipGetErrorString(e); return JOLT_ERR_HIP; }
     *out = t;

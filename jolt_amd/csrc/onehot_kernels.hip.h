@@ -164,6 +164,24 @@ static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward_reduce(con
     st_fr(out + p * K + k, s);
 }
 
+// The same sums for K <= kBlock with the partial tables of a polynomial dealt to kBlock / K lanes per bucket (round 6, second session): the kernel above walks its
+// nblocks partials as ONE dependent chain per (polynomial, bucket) -- 1024 loads and additions at T = 2^22, 0.37 ms for 576 busy threads; here a workgroup per polynomial
+// keeps kBlock / K chains of nblocks K / kBlock links per bucket and folds them through LDS.  blockIdx.x = polynomial.
+static __global__ __launch_bounds__(kBlock) void k_onehot_pushforward_reduce_split(const Fr* __restrict__ partials, int nblocks, uint32_t K, Fr* __restrict__ out) {
+    __shared__ Fr part[kBlock];
+    const size_t p = blockIdx.x;
+    const uint32_t G = kBlock / K, k = threadIdx.x % K, g = threadIdx.x / K;  // G >= 1 chains per bucket; threads beyond G * K idle
+    Fr s = Fr::zero();
+    if (g < G)
+        for (int b = (int)g; b < nblocks; b += (int)G) s = add(s, ld_fr(partials + ((size_t)p * nblocks + b) * K + k));
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0) {
+        for (uint32_t h = 1; h < G; ++h) s = add(s, part[h * K + k]);
+        st_fr(out + p * K + k, s);
+    }
+}
+
 // Round sums of eq(w, j) * sum_v c_v * prod_{i<F} ra_{vF+i}(j) while the selector columns are still index-encoded: the same
 // sums as k_split_eq_uniform<F> over dense tables, with every (lo, hi) pair gathered (lazy_ra.rs:116-149 lo_hi_all).
 struct LazyArgs {
