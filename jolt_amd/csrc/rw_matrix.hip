@@ -603,13 +603,26 @@ extern "C" int32_t jolt_rw_matrix_create(jolt_ctx* ctx, const uint64_t* addresse
     return rw_create_impl(ctx, addresses, pre_values, post_values, false, 0, cycles, inc, val_init, tau_low, gamma, out);
 }
 // accesses and out-of-range addresses of a resident column: counters[0], counters[1]
+// (grid-stride, one atomic pair per WORKGROUP: one per wavefront of a cycles / 256 grid was 65 536 atomics on the same two words at T = 2^22 -- 0.75 ms for a 32 MiB read)
 __global__ __launch_bounds__(kBlock) void k_rw_count_accesses(const uint64_t* __restrict__ addresses, uint32_t cycles, uint64_t K, uint32_t* __restrict__ counters) {
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t a = j < cycles ? addresses[j] : kNoAccess;
-    const uint64_t hit = __ballot(a != kNoAccess), bad = __ballot(a != kNoAccess && a >= K);
-    if ((threadIdx.x & 63) == 0) {
-        if (hit) atomicAdd(&counters[0], (uint32_t)__popcll(hit));
-        if (bad) atomicAdd(&counters[1], (uint32_t)__popcll(bad));
+    __shared__ uint32_t s_hit[kBlock / 64], s_bad[kBlock / 64];
+    uint32_t hit = 0, bad = 0;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < cycles; j += gridDim.x * kBlock) {
+        const uint64_t a = addresses[j];
+        hit += a != kNoAccess ? 1u : 0u;
+        bad += (a != kNoAccess && a >= K) ? 1u : 0u;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        hit += __shfl_xor(hit, off, 64);
+        bad += __shfl_xor(bad, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_hit[threadIdx.x >> 6] = hit; s_bad[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t h = 0, b = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { h += s_hit[w]; b += s_bad[w]; }
+        if (h) atomicAdd(&counters[0], h);
+        if (b) atomicAdd(&counters[1], b);
     }
 }
 // The same member over access columns that are ALREADY in HBM (three u64 jolt_ints of `cycles` entries: the witness is uploaded once per
@@ -626,7 +639,7 @@ extern "C" int32_t jolt_rw_matrix_create_resident(jolt_ctx* ctx, const jolt_ints
     uint32_t h_counters[2] = {0, 0};
     hipError_t e = hipMemsetAsync(d_counters, 0, 8, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_rw_count_accesses, dim3(rw_grid((uint32_t)cycles)), dim3(kBlock), 0, ctx->stream, (const uint64_t*)addresses->data, (uint32_t)cycles,
+        hipLaunchKernelGGL(k_rw_count_accesses, dim3(std::min<uint32_t>(rw_grid((uint32_t)cycles), (uint32_t)ctx->num_cus * 8)), dim3(kBlock), 0, ctx->stream, (const uint64_t*)addresses->data, (uint32_t)cycles,
                            (uint64_t)val_init->len, d_counters);
         e = hipGetLastError();
     }
